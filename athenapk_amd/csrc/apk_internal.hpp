@@ -1,0 +1,135 @@
+// apk_internal.hpp -- internal types shared by the kernels and the C-ABI layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/apk_amd.h"
+
+namespace apk {
+
+// What a kernel sees of a MeshBlockPack: a device array of per-block descriptors plus the
+// (uniform) block geometry.  Interior index bounds follow Parthenon's IndexDomain::interior
+// (SURVEY.md App. A.5): [ng, ng+nx-1] in active dimensions, {0} in collapsed ones.
+struct PackView {
+  const apk_block_desc *blocks;  // device
+  int nblocks, nvar, nhydro;
+  int ng, ndim;
+  int nx1, nx2, nx3;
+  int ni, nj, nk;  // extents including ghosts
+  int is, ie, js, je, ks, ke;
+  int64_t sj, sk, sn;  // element strides of j, k and variable index
+};
+
+inline PackView make_view(const apk_pack_desc &d, const apk_block_desc *dev_blocks) {
+  PackView v{};
+  v.blocks = dev_blocks;
+  v.nblocks = d.nblocks;
+  v.nhydro = d.nhydro;
+  v.nvar = d.nhydro + d.nscalars;
+  v.ng = d.ng;
+  v.nx1 = d.nx[0];
+  v.nx2 = d.nx[1];
+  v.nx3 = d.nx[2];
+  v.ndim = (d.nx[2] > 1) ? 3 : ((d.nx[1] > 1) ? 2 : 1);
+  v.ni = d.nx[0] + 2 * d.ng;
+  v.nj = (d.nx[1] > 1) ? d.nx[1] + 2 * d.ng : 1;
+  v.nk = (d.nx[2] > 1) ? d.nx[2] + 2 * d.ng : 1;
+  v.is = d.ng;
+  v.ie = d.ng + d.nx[0] - 1;
+  v.js = (d.nx[1] > 1) ? d.ng : 0;
+  v.je = (d.nx[1] > 1) ? d.ng + d.nx[1] - 1 : 0;
+  v.ks = (d.nx[2] > 1) ? d.ng : 0;
+  v.ke = (d.nx[2] > 1) ? d.ng + d.nx[2] - 1 : 0;
+  v.sj = v.ni;
+  v.sk = (int64_t)v.ni * v.nj;
+  v.sn = v.sk * v.nk;
+  return v;
+}
+
+}  // namespace apk
+
+struct apk_pack {
+  apk::PackView view;
+  apk_pack_desc desc;  // desc.blocks points into h_blocks
+  std::vector<apk_block_desc> h_blocks;
+  apk_block_desc *d_blocks = nullptr;
+  bool have_flux[3] = {false, false, false};
+};
+
+struct apk_ctx {
+  int device = -1;
+  unsigned *d_flags = nullptr;       // latched APK_FLAG_* bits
+  unsigned long long *d_u64 = nullptr;  // [8] scratch words (min-reduction, counters)
+  double *d_partial = nullptr;       // reduction partials
+  size_t partial_cap = 0;            // in doubles
+  unsigned char *d_mark = nullptr;   // FOFC cell marks
+  size_t mark_cap = 0;
+  void *h_pinned = nullptr;          // 256 B pinned host staging
+  char err[512] = {0};
+};
+
+struct apk_copy_plan {
+  apk_copy_region *d_regions = nullptr;
+  int n = 0;
+  int64_t max_cells = 0;
+};
+
+namespace apk {
+
+inline int set_err(apk_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
+  if (ctx) {
+    if (e != hipSuccess)
+      std::snprintf(ctx->err, sizeof(ctx->err), "%s: %s", what, hipGetErrorString(e));
+    else
+      std::snprintf(ctx->err, sizeof(ctx->err), "%s", what);
+  }
+  return code;
+}
+
+#define APK_HIP_TRY(ctx, expr)                                              \
+  do {                                                                      \
+    hipError_t e__ = (expr);                                                \
+    if (e__ != hipSuccess) return apk::set_err((ctx), APK_ERR_DEVICE, #expr, e__); \
+  } while (0)
+
+// ---- kernel launchers implemented in the .hip translation units ---------------------
+// flux arrays path (one TU per (fluid, riemann) family to keep compile times parallel)
+int launch_fluxes_euler_hlle(const PackView &pv, int recon, double gamma, double c_h,
+                             hipStream_t s);
+int launch_fluxes_euler_hllc(const PackView &pv, int recon, double gamma, double c_h,
+                             hipStream_t s);
+int launch_fluxes_mhd_hlle(const PackView &pv, int recon, double gamma, double c_h,
+                           hipStream_t s);
+int launch_fluxes_mhd_hlld(const PackView &pv, int recon, double gamma, double c_h,
+                           hipStream_t s);
+// (dc,none) and (dc,llf = CalculateFluxesTight) for both fluids
+int launch_fluxes_misc(const PackView &pv, int fluid, int riemann, double gamma, double c_h,
+                       hipStream_t s);
+
+int launch_update_flux_div(const PackView &u0, const PackView &u1, double gam0, double gam1,
+                           double beta_dt, hipStream_t s);
+int launch_dedner(const PackView &pv, int extended, double coeff, double beta_dt,
+                  hipStream_t s);
+int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsigned *d_flags,
+                        hipStream_t s);
+int launch_min_dt(const PackView &pv, int fluid, double gamma, unsigned long long *d_min_bits,
+                  hipStream_t s);
+int launch_history(const PackView &pv, int fluid, double *d_partial, int *nblocks_out,
+                   double *d_out8, hipStream_t s);
+int launch_fofc_mark(const PackView &u0, const PackView &u1, int fluid, double gam0,
+                     double gam1, double beta_dt, int attempt, unsigned char *d_mark,
+                     unsigned long long *d_count, hipStream_t s);
+int launch_fofc_fix(const PackView &u0, int fluid, double gamma, double c_h,
+                    const unsigned char *d_mark, hipStream_t s);
+int launch_copy_regions(const apk_copy_region *d_regions, int n, int64_t max_cells,
+                        hipStream_t s);
+// fused stage path (kernels_fused.hip)
+int launch_stage_fused(const PackView &u0, const PackView &u1, const apk_stage_args &a,
+                       double dedner_coeff, hipStream_t s);
+
+}  // namespace apk

@@ -1,0 +1,367 @@
+// capi.hip -- the extern "C" boundary (include/apk_amd.h).  Validates arguments on the host
+// (the reference aborts with PARTHENON_FAIL on unknown options, src/hydro/hydro.cpp:299,338,
+// 366; here they become error codes), then enqueues kernels on the caller's stream.
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <new>
+
+#include "apk_internal.hpp"
+
+using namespace apk;
+
+namespace {
+
+hipStream_t as_stream(apk_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+bool valid_eos(const apk_eos *e) { return e && e->gamma > 1.0; }
+
+// registry of compiled-in flux functions: src/hydro/hydro.cpp:386-416
+bool in_registry(const apk_flux_cfg &c) {
+  const bool recon_ok = c.recon >= APK_RC_DC && c.recon <= APK_RC_LIMO3;
+  if (!recon_ok) return false;
+  if (c.riemann == APK_RS_NONE || c.riemann == APK_RS_LLF) return c.recon == APK_RC_DC;
+  if (c.fluid == APK_FLUID_EULER) return c.riemann == APK_RS_HLLE || c.riemann == APK_RS_HLLC;
+  if (c.fluid == APK_FLUID_GLMMHD) return c.riemann == APK_RS_HLLE || c.riemann == APK_RS_HLLD;
+  return false;
+}
+
+int need_nghost(int recon) {  // src/hydro/hydro.cpp:316-339
+  switch (recon) {
+  case APK_RC_DC: return 1;
+  case APK_RC_PPM:
+  case APK_RC_WENOZ: return 3;
+  default: return 2;
+  }
+}
+
+int check_cfg(apk_ctx *ctx, const apk_pack *md, const apk_flux_cfg &cfg) {
+  if (!in_registry(cfg)) return set_err(ctx, APK_ERR_UNSUPPORTED, "flux function not in registry");
+  const int nh = (cfg.fluid == APK_FLUID_EULER) ? 5 : 9;
+  if (md->view.nhydro != nh) return set_err(ctx, APK_ERR_INVALID, "pack nhydro does not match fluid");
+  if (md->view.ng < need_nghost(cfg.recon))
+    return set_err(ctx, APK_ERR_NGHOST, "need more ghost zones for chosen reconstruction");
+  return APK_OK;
+}
+
+bool same_shape(const apk_pack *a, const apk_pack *b) {
+  const PackView &x = a->view, &y = b->view;
+  return x.nblocks == y.nblocks && x.nvar == y.nvar && x.ni == y.ni && x.nj == y.nj &&
+         x.nk == y.nk && x.ng == y.ng;
+}
+
+int ensure_partial(apk_ctx *ctx, size_t n) {
+  if (ctx->partial_cap >= n) return APK_OK;
+  if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+  ctx->d_partial = nullptr;
+  ctx->partial_cap = 0;
+  APK_HIP_TRY(ctx, hipMalloc(&ctx->d_partial, n * sizeof(double)));
+  ctx->partial_cap = n;
+  return APK_OK;
+}
+
+int ensure_mark(apk_ctx *ctx, size_t n) {
+  if (ctx->mark_cap >= n) return APK_OK;
+  if (ctx->d_mark) (void)hipFree(ctx->d_mark);
+  ctx->d_mark = nullptr;
+  ctx->mark_cap = 0;
+  APK_HIP_TRY(ctx, hipMalloc(&ctx->d_mark, n));
+  ctx->mark_cap = n;
+  return APK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int apk_version(void) { return APK_AMD_VERSION; }
+
+int apk_fp_strict(void) {
+#ifdef APK_FP_STRICT
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+int apk_create(apk_ctx **out) {
+  if (!out) return APK_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return APK_ERR_NO_DEVICE;
+  apk_ctx *ctx = new (std::nothrow) apk_ctx();
+  if (!ctx) return APK_ERR_INVALID;
+  if (hipGetDevice(&ctx->device) != hipSuccess) {
+    delete ctx;
+    return APK_ERR_NO_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess ||
+      std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    // kernels are compiled for gfx950 only; anything else cannot run them
+    delete ctx;
+    return APK_ERR_NO_DEVICE;
+  }
+  if (hipMalloc(&ctx->d_flags, sizeof(unsigned)) != hipSuccess ||
+      hipMalloc(&ctx->d_u64, 16 * sizeof(unsigned long long)) != hipSuccess ||
+      hipHostMalloc(&ctx->h_pinned, 256, hipHostMallocDefault) != hipSuccess) {
+    apk_destroy(ctx);
+    return APK_ERR_DEVICE;
+  }
+  (void)hipMemset(ctx->d_flags, 0, sizeof(unsigned));
+  (void)hipMemset(ctx->d_u64, 0, 16 * sizeof(unsigned long long));
+  *out = ctx;
+  return APK_OK;
+}
+
+void apk_destroy(apk_ctx *ctx) {
+  if (!ctx) return;
+  if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+  if (ctx->d_u64) (void)hipFree(ctx->d_u64);
+  if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+  if (ctx->d_mark) (void)hipFree(ctx->d_mark);
+  if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  delete ctx;
+}
+
+const char *apk_last_error(const apk_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+int apk_pack_create(apk_ctx *ctx, const apk_pack_desc *desc, apk_pack **out) {
+  if (!ctx || !desc || !out) return APK_ERR_INVALID;
+  *out = nullptr;
+  if (desc->nblocks <= 0 || !desc->blocks) return set_err(ctx, APK_ERR_INVALID, "empty pack");
+  if (desc->nhydro != 5 && desc->nhydro != 9) return set_err(ctx, APK_ERR_INVALID, "nhydro must be 5 or 9");
+  if (desc->nscalars < 0 || desc->ng < 1 || desc->nx[0] < 1 || desc->nx[1] < 1 || desc->nx[2] < 1)
+    return set_err(ctx, APK_ERR_INVALID, "bad pack geometry");
+  if (desc->nx[1] == 1 && desc->nx[2] > 1) return set_err(ctx, APK_ERR_INVALID, "nx2 == 1 requires nx3 == 1");
+  apk_pack *p = new (std::nothrow) apk_pack();
+  if (!p) return APK_ERR_INVALID;
+  p->h_blocks.assign(desc->blocks, desc->blocks + desc->nblocks);
+  p->desc = *desc;
+  p->desc.blocks = p->h_blocks.data();
+  for (int d = 0; d < 3; ++d) {
+    p->have_flux[d] = true;
+    for (const auto &b : p->h_blocks) p->have_flux[d] = p->have_flux[d] && (b.flux[d] != nullptr);
+  }
+  for (const auto &b : p->h_blocks) {
+    if (!b.cons) {
+      delete p;
+      return set_err(ctx, APK_ERR_INVALID, "block without cons pointer");
+    }
+  }
+  const size_t bytes = sizeof(apk_block_desc) * desc->nblocks;
+  hipError_t e = hipMalloc(&p->d_blocks, bytes);
+  if (e == hipSuccess) e = hipMemcpy(p->d_blocks, p->h_blocks.data(), bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (p->d_blocks) (void)hipFree(p->d_blocks);
+    delete p;
+    return set_err(ctx, APK_ERR_DEVICE, "apk_pack_create", e);
+  }
+  p->view = make_view(p->desc, p->d_blocks);
+  *out = p;
+  return APK_OK;
+}
+
+void apk_pack_destroy(apk_pack *pack) {
+  if (!pack) return;
+  if (pack->d_blocks) (void)hipFree(pack->d_blocks);
+  delete pack;
+}
+
+int apk_calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos,
+                         double c_h, apk_stream_t stream) {
+  if (!ctx || !md || !valid_eos(eos)) return set_err(ctx, APK_ERR_INVALID, "apk_calculate_fluxes: bad argument");
+  int rc = check_cfg(ctx, md, cfg);
+  if (rc != APK_OK) return rc;
+  for (int d = 0; d < md->view.ndim; ++d)
+    if (!md->have_flux[d]) return set_err(ctx, APK_ERR_INVALID, "pack has no flux arrays");
+  for (const auto &b : md->h_blocks)
+    if (!b.prim) return set_err(ctx, APK_ERR_INVALID, "block without prim pointer");
+  hipStream_t s = as_stream(stream);
+  const PackView &pv = md->view;
+  if (cfg.riemann == APK_RS_NONE || cfg.riemann == APK_RS_LLF)
+    rc = launch_fluxes_misc(pv, cfg.fluid, cfg.riemann, eos->gamma, c_h, s);
+  else if (cfg.fluid == APK_FLUID_EULER)
+    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_euler_hlle(pv, cfg.recon, eos->gamma, c_h, s)
+                                      : launch_fluxes_euler_hllc(pv, cfg.recon, eos->gamma, c_h, s);
+  else
+    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_mhd_hlle(pv, cfg.recon, eos->gamma, c_h, s)
+                                      : launch_fluxes_mhd_hlld(pv, cfg.recon, eos->gamma, c_h, s);
+  if (rc != APK_OK) return set_err(ctx, rc, "flux kernel launch failed", hipGetLastError());
+  return APK_OK;
+}
+
+int apk_update_with_flux_divergence(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
+                                    double gam0, double gam1, double beta_dt,
+                                    apk_stream_t stream) {
+  if (!ctx || !u0 || !u1 || !same_shape(u0, u1))
+    return set_err(ctx, APK_ERR_INVALID, "apk_update_with_flux_divergence: bad argument");
+  for (int d = 0; d < u0->view.ndim; ++d)
+    if (!u0->have_flux[d]) return set_err(ctx, APK_ERR_INVALID, "u0 pack has no flux arrays");
+  int rc = launch_update_flux_div(u0->view, u1->view, gam0, gam1, beta_dt, as_stream(stream));
+  if (rc != APK_OK) return set_err(ctx, rc, "update kernel launch failed", hipGetLastError());
+  return APK_OK;
+}
+
+int apk_dedner_source(apk_ctx *ctx, const apk_pack *md, int extended, double alpha, double c_h,
+                      double mindx, double beta_dt, apk_stream_t stream) {
+  if (!ctx || !md || md->view.nhydro != 9 || !(mindx > 0.0))
+    return set_err(ctx, APK_ERR_INVALID, "apk_dedner_source: bad argument");
+  // Mignone & Tzeferacos 2010 (27): dedner_source.cpp:32
+  const double coeff = std::exp(-alpha * c_h * beta_dt / mindx);
+  int rc = launch_dedner(md->view, extended, coeff, beta_dt, as_stream(stream));
+  if (rc != APK_OK) return set_err(ctx, rc, "dedner kernel launch failed", hipGetLastError());
+  return APK_OK;
+}
+
+int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
+                    const apk_stage_args *a, apk_stream_t stream) {
+  if (!ctx || !u0 || !u1 || !a || !same_shape(u0, u1) || !valid_eos(&a->eos))
+    return set_err(ctx, APK_ERR_INVALID, "apk_stage_fused: bad argument");
+  int rc = check_cfg(ctx, u0, a->cfg);
+  if (rc != APK_OK) return rc;
+  if (a->cfg.riemann == APK_RS_NONE || a->cfg.riemann == APK_RS_LLF)
+    return set_err(ctx, APK_ERR_UNSUPPORTED, "fused stage: none/llf solvers use the flux-array path");
+  if (a->dedner != 0 && (a->cfg.fluid != APK_FLUID_GLMMHD || !(a->mindx > 0.0)))
+    return set_err(ctx, APK_ERR_INVALID, "fused stage: Dedner source needs glmmhd and mindx > 0");
+  double coeff = 1.0;
+  if (a->dedner != 0) coeff = std::exp(-a->glmmhd_alpha * a->c_h * a->beta_dt / a->mindx);
+  rc = launch_stage_fused(u0->view, u1->view, *a, coeff, as_stream(stream));
+  if (rc != APK_OK) return set_err(ctx, rc, "fused stage kernel launch failed", hipGetLastError());
+  return APK_OK;
+}
+
+int apk_cons_to_prim(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,
+                     apk_stream_t stream) {
+  if (!ctx || !md || !valid_eos(eos) || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||
+      md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9))
+    return set_err(ctx, APK_ERR_INVALID, "apk_cons_to_prim: bad argument");
+  int rc = launch_cons_to_prim(md->view, fluid, *eos, ctx->d_flags, as_stream(stream));
+  if (rc != APK_OK) return set_err(ctx, rc, "cons_to_prim kernel launch failed", hipGetLastError());
+  return APK_OK;
+}
+
+int apk_estimate_timestep(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,
+                          double cfl, double *dt_out, apk_stream_t stream) {
+  if (!ctx || !md || !valid_eos(eos) || !dt_out ||
+      md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9))
+    return set_err(ctx, APK_ERR_INVALID, "apk_estimate_timestep: bad argument");
+  hipStream_t s = as_stream(stream);
+  const double huge = std::numeric_limits<double>::max();
+  unsigned long long bits;
+  std::memcpy(&bits, &huge, sizeof(bits));
+  auto *h = static_cast<unsigned long long *>(ctx->h_pinned);
+  h[0] = bits;
+  APK_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_u64, h, sizeof(bits), hipMemcpyHostToDevice, s));
+  int rc = launch_min_dt(md->view, fluid, eos->gamma, ctx->d_u64, s);
+  if (rc != APK_OK) return set_err(ctx, rc, "min_dt kernel launch failed", hipGetLastError());
+  APK_HIP_TRY(ctx, hipMemcpyAsync(h + 1, ctx->d_u64, sizeof(bits), hipMemcpyDeviceToHost, s));
+  APK_HIP_TRY(ctx, hipStreamSynchronize(s));
+  double m;
+  std::memcpy(&m, h + 1, sizeof(m));
+  *dt_out = cfl * m;  // hydro.cpp:909
+  return APK_OK;
+}
+
+int apk_first_order_flux_correct(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1, int fluid,
+                                 const apk_eos *eos, double c_h, double gam0, double gam1,
+                                 double beta_dt, long long *num_corrected, apk_stream_t stream) {
+  if (!ctx || !u0 || !u1 || !same_shape(u0, u1) || !valid_eos(eos) ||
+      u0->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9))
+    return set_err(ctx, APK_ERR_INVALID, "apk_first_order_flux_correct: bad argument");
+  for (int d = 0; d < u0->view.ndim; ++d)
+    if (!u0->have_flux[d]) return set_err(ctx, APK_ERR_INVALID, "u0 pack has no flux arrays");
+  hipStream_t s = as_stream(stream);
+  int rc = ensure_mark(ctx, (size_t)u0->view.nblocks * (size_t)u0->view.sn);
+  if (rc != APK_OK) return rc;
+  auto *h = static_cast<unsigned long long *>(ctx->h_pinned);
+  long long total = 0;
+  unsigned long long corrected = 0;
+  int attempts = 0;
+  do {  // hydro.cpp:1265-1339: <= 4 attempts, one host sync per attempt
+    APK_HIP_TRY(ctx, hipMemsetAsync(ctx->d_u64 + 2, 0, sizeof(unsigned long long), s));
+    rc = launch_fofc_mark(u0->view, u1->view, fluid, gam0, gam1, beta_dt, attempts, ctx->d_mark,
+                          ctx->d_u64 + 2, s);
+    if (rc != APK_OK) return set_err(ctx, rc, "fofc mark kernel launch failed", hipGetLastError());
+    APK_HIP_TRY(ctx, hipMemcpyAsync(h + 2, ctx->d_u64 + 2, sizeof(unsigned long long),
+                                    hipMemcpyDeviceToHost, s));
+    APK_HIP_TRY(ctx, hipStreamSynchronize(s));
+    corrected = h[2];
+    if (corrected > 0) {
+      rc = launch_fofc_fix(u0->view, fluid, eos->gamma, c_h, ctx->d_mark, s);
+      if (rc != APK_OK) return set_err(ctx, rc, "fofc fix kernel launch failed", hipGetLastError());
+    }
+    total += (long long)corrected;
+    attempts += 1;
+  } while (corrected > 0 && attempts < 4);
+  if (num_corrected) *num_corrected = total;
+  return APK_OK;
+}
+
+int apk_history(apk_ctx *ctx, const apk_pack *md, int fluid, double *out8, apk_stream_t stream) {
+  if (!ctx || !md || !out8 || md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9))
+    return set_err(ctx, APK_ERR_INVALID, "apk_history: bad argument");
+  hipStream_t s = as_stream(stream);
+  int nwg = 0;
+  launch_history(md->view, fluid, nullptr, &nwg, nullptr, s);
+  int rc = ensure_partial(ctx, (size_t)nwg * 8 + 8);
+  if (rc != APK_OK) return rc;
+  double *d_out = ctx->d_partial + (size_t)nwg * 8;
+  rc = launch_history(md->view, fluid, ctx->d_partial, &nwg, d_out, s);
+  if (rc != APK_OK) return set_err(ctx, rc, "history kernel launch failed", hipGetLastError());
+  auto *h = static_cast<double *>(ctx->h_pinned) + 8;
+  APK_HIP_TRY(ctx, hipMemcpyAsync(h, d_out, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+  APK_HIP_TRY(ctx, hipStreamSynchronize(s));
+  std::memcpy(out8, h, 8 * sizeof(double));
+  return APK_OK;
+}
+
+int apk_poll_device_flags(apk_ctx *ctx, unsigned *flags, apk_stream_t stream) {
+  if (!ctx || !flags) return APK_ERR_INVALID;
+  hipStream_t s = as_stream(stream);
+  auto *h = reinterpret_cast<unsigned *>(static_cast<char *>(ctx->h_pinned) + 192);
+  APK_HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_flags, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  APK_HIP_TRY(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(unsigned), s));
+  APK_HIP_TRY(ctx, hipStreamSynchronize(s));
+  *flags = *h;
+  return APK_OK;
+}
+
+int apk_copy_plan_create(apk_ctx *ctx, const apk_copy_region *regions, int n,
+                         apk_copy_plan **out) {
+  if (!ctx || !out || n < 0 || (n > 0 && !regions)) return APK_ERR_INVALID;
+  apk_copy_plan *p = new (std::nothrow) apk_copy_plan();
+  if (!p) return APK_ERR_INVALID;
+  p->n = n;
+  for (int r = 0; r < n; ++r) {
+    const int64_t c = (int64_t)regions[r].ext[0] * regions[r].ext[1] * regions[r].ext[2];
+    if (c > p->max_cells) p->max_cells = c;
+  }
+  if (n > 0) {
+    hipError_t e = hipMalloc(&p->d_regions, sizeof(apk_copy_region) * n);
+    if (e == hipSuccess)
+      e = hipMemcpy(p->d_regions, regions, sizeof(apk_copy_region) * n, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      if (p->d_regions) (void)hipFree(p->d_regions);
+      delete p;
+      return set_err(ctx, APK_ERR_DEVICE, "apk_copy_plan_create", e);
+    }
+  }
+  *out = p;
+  return APK_OK;
+}
+
+void apk_copy_plan_destroy(apk_copy_plan *plan) {
+  if (!plan) return;
+  if (plan->d_regions) (void)hipFree(plan->d_regions);
+  delete plan;
+}
+
+int apk_copy_plan_run(apk_ctx *ctx, const apk_copy_plan *plan, apk_stream_t stream) {
+  if (!ctx || !plan) return APK_ERR_INVALID;
+  int rc = launch_copy_regions(plan->d_regions, plan->n, plan->max_cells, as_stream(stream));
+  if (rc != APK_OK) return set_err(ctx, rc, "copy kernel launch failed", hipGetLastError());
+  return APK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+// flux_kernel.hpp -- "flux arrays" path: one kernel per sweep direction that reconstructs
+// the L/R face states, solves the Riemann problem and stores flux(dir, v, k, j, i) over the
+// SAME index ranges the reference writes (src/hydro/hydro.cpp:1025-1208).  This is the
+// path behind apk_calculate_fluxes(): it materialises the face fluxes in HBM, which the
+// first-order flux correction and AMR flux correction consume.  The bandwidth-lean fused
+// path is in kernels_fused.hip.
+//
+// Mapping: one lane per face, 64 consecutive lanes along x1 so every stencil load is a
+// coalesced 512-B row segment; the 4..6 stencil rows a lane touches along the sweep
+// direction are shared with its neighbours through L1/L2.
+#pragma once
+
+#include "apk_internal.hpp"
+#include "hydro_math.hpp"
+
+namespace apk {
+
+struct FluxExtent {
+  int i0, i1, j0, j1, k0, k1;
+};
+
+// the reference's loop limits (hydro.cpp:1031-1039, 1106-1110, 1158)
+inline FluxExtent flux_extent(const PackView &pv, int dir) {
+  FluxExtent e;
+  const bool d2 = pv.nx2 > 1, d3 = pv.nx3 > 1;
+  if (dir == 1) {
+    e.i0 = pv.is;
+    e.i1 = pv.ie + 1;
+    e.j0 = d2 ? pv.js - 1 : pv.js;
+    e.j1 = d2 ? pv.je + 1 : pv.je;
+    e.k0 = (d2 && d3) ? pv.ks - 1 : pv.ks;
+    e.k1 = (d2 && d3) ? pv.ke + 1 : pv.ke;
+  } else if (dir == 2) {
+    e.i0 = pv.is - 1;
+    e.i1 = pv.ie + 1;
+    e.j0 = pv.js;
+    e.j1 = pv.je + 1;
+    e.k0 = d3 ? pv.ks - 1 : pv.ks;
+    e.k1 = d3 ? pv.ke + 1 : pv.ke;
+  } else {
+    e.i0 = pv.is - 1;
+    e.i1 = pv.ie + 1;
+    e.j0 = pv.js - 1;
+    e.j1 = pv.je + 1;
+    e.k0 = pv.ks;
+    e.k1 = pv.ke + 1;
+  }
+  return e;
+}
+
+// CalculateFluxesTight limits (hydro.cpp:1006-1009)
+inline FluxExtent tight_extent(const PackView &pv, int dir) {
+  FluxExtent e;
+  e.i0 = pv.is;
+  e.i1 = pv.ie + 1;
+  e.j0 = pv.js;
+  e.j1 = (pv.ndim >= 2) ? pv.je + 1 : pv.je;
+  e.k0 = pv.ks;
+  e.k1 = (pv.ndim >= 3) ? pv.ke + 1 : pv.ke;
+  (void)dir;
+  return e;
+}
+
+// L state of the face = ql of the lower cell, R state = qr of the upper cell.
+template <int RECON>
+APK_DEV void face_states(const double *c, int64_t st, double dx, int var, double &wl,
+                         double &wr) {
+  double dummy;
+  if constexpr (RECON == APK_RC_DC) {
+    wl = c[-st];
+    wr = c[0];
+  } else if constexpr (RECON == APK_RC_PPM || RECON == APK_RC_WENOZ) {
+    const double qm3 = c[-3 * st], qm2 = c[-2 * st], qm1 = c[-st], q0 = c[0], qp1 = c[st],
+                 qp2 = c[2 * st];
+    reconstruct<RECON>(qm3, qm2, qm1, q0, qp1, dx, var, wl, dummy);
+    reconstruct<RECON>(qm2, qm1, q0, qp1, qp2, dx, var, dummy, wr);
+  } else {
+    const double qm2 = c[-2 * st], qm1 = c[-st], q0 = c[0], qp1 = c[st];
+    reconstruct<RECON>(0.0, qm2, qm1, q0, 0.0, dx, var, wl, dummy);
+    reconstruct<RECON>(0.0, qm1, q0, qp1, 0.0, dx, var, dummy, wr);
+  }
+}
+
+template <int FLUID, int RECON, int RS, int DIR>
+__global__ void __launch_bounds__(256)
+flux_kernel(PackView pv, FluxExtent e, double gamma, double c_h) {
+  constexpr int NV = nvars<FLUID>();
+  const int i = e.i0 + blockIdx.x * 64 + threadIdx.x;
+  const int j = e.j0 + blockIdx.y * 4 + threadIdx.y;
+  const int nkext = e.k1 - e.k0 + 1;
+  const int b = blockIdx.z / nkext;
+  const int k = e.k0 + blockIdx.z % nkext;
+  if (i > e.i1 || j > e.j1) return;
+  const apk_block_desc blk = pv.blocks[b];
+  const int64_t st = (DIR == 1) ? 1 : ((DIR == 2) ? pv.sj : pv.sk);
+  const int64_t cell = k * pv.sk + j * pv.sj + i;
+  const double *p = blk.prim + cell;
+  const double dx = blk.dx[DIR - 1];
+
+  double wln[NV], wrn[NV];  // natural order
+#pragma unroll
+  for (int n = 0; n < NV; ++n) face_states<RECON>(p + n * pv.sn, st, dx, n, wln[n], wrn[n]);
+
+  double wl[NV], wr[NV], f[NV];  // direction-permuted order
+#pragma unroll
+  for (int s = 0; s < NV; ++s) {
+    wl[s] = wln[perm<DIR>(s)];
+    wr[s] = wrn[perm<DIR>(s)];
+  }
+  riemann<FLUID, RS>(wl, wr, gamma, c_h, f);
+
+  double *fo = blk.flux[DIR - 1] + cell;
+#pragma unroll
+  for (int s = 0; s < NV; ++s) fo[perm<DIR>(s) * pv.sn] = f[s];
+
+  // passive scalars: upwind on the mass flux (hydro.cpp:1088-1097)
+  for (int n = NV; n < pv.nvar; ++n) {
+    double sl, sr;
+    face_states<RECON>(p + n * pv.sn, st, dx, n, sl, sr);
+    fo[n * pv.sn] = (f[IDN] >= 0.0) ? f[IDN] * sl : f[IDN] * sr;
+  }
+}
+
+template <int FLUID, int RECON, int RS, int DIR>
+inline void launch_flux_dir(const PackView &pv, const FluxExtent &e, double gamma, double c_h,
+                            hipStream_t s) {
+  const int nie = e.i1 - e.i0 + 1, nje = e.j1 - e.j0 + 1, nke = e.k1 - e.k0 + 1;
+  dim3 block(64, 4, 1);
+  dim3 grid((nie + 63) / 64, (nje + 3) / 4, nke * pv.nblocks);
+  hipLaunchKernelGGL((flux_kernel<FLUID, RECON, RS, DIR>), grid, block, 0, s, pv, e, gamma, c_h);
+}
+
+template <int FLUID, int RECON, int RS>
+inline int launch_flux_all_dirs(const PackView &pv, double gamma, double c_h, hipStream_t s,
+                                bool tight = false) {
+  launch_flux_dir<FLUID, RECON, RS, 1>(pv, tight ? tight_extent(pv, 1) : flux_extent(pv, 1),
+                                       gamma, c_h, s);
+  if (pv.ndim >= 2)
+    launch_flux_dir<FLUID, RECON, RS, 2>(pv, tight ? tight_extent(pv, 2) : flux_extent(pv, 2),
+                                         gamma, c_h, s);
+  if (pv.ndim >= 3)
+    launch_flux_dir<FLUID, RECON, RS, 3>(pv, tight ? tight_extent(pv, 3) : flux_extent(pv, 3),
+                                         gamma, c_h, s);
+  return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
+}
+
+// recon dispatch for one (fluid, riemann) family: the registry of hydro.cpp:386-416
+template <int FLUID, int RS>
+inline int launch_flux_family(const PackView &pv, int recon, double gamma, double c_h,
+                              hipStream_t s) {
+  switch (recon) {
+  case APK_RC_DC: return launch_flux_all_dirs<FLUID, APK_RC_DC, RS>(pv, gamma, c_h, s);
+  case APK_RC_PLM: return launch_flux_all_dirs<FLUID, APK_RC_PLM, RS>(pv, gamma, c_h, s);
+  case APK_RC_PPM: return launch_flux_all_dirs<FLUID, APK_RC_PPM, RS>(pv, gamma, c_h, s);
+  case APK_RC_WENOZ: return launch_flux_all_dirs<FLUID, APK_RC_WENOZ, RS>(pv, gamma, c_h, s);
+  case APK_RC_WENO3: return launch_flux_all_dirs<FLUID, APK_RC_WENO3, RS>(pv, gamma, c_h, s);
+  case APK_RC_LIMO3: return launch_flux_all_dirs<FLUID, APK_RC_LIMO3, RS>(pv, gamma, c_h, s);
+  default: return APK_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace apk

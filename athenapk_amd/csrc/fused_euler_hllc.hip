@@ -1,0 +1,9 @@
+// fused_euler_hllc.hip -- fused stage sweeps for the (APK_FLUID_EULER, APK_RS_HLLC) family.
+#include "fused_kernel.hpp"
+
+namespace apk {
+int launch_fused_euler_hllc(const PackView &u0, const PackView &u1, int recon,
+                         const StageParams &sp, hipStream_t s) {
+  return launch_fused_family<APK_FLUID_EULER, APK_RS_HLLC>(u0, u1, recon, sp, s);
+}
+}  // namespace apk

@@ -1,0 +1,948 @@
+// sim.cpp -- implementation of the standalone host driver (include/apk_host.h).
+#include "sim.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+using namespace apk;
+
+namespace {
+
+constexpr double kHuge = std::numeric_limits<double>::max();
+
+int fail(apk_sim *s, int code, const std::string &msg) {
+  if (s) s->err = msg;
+  return code;
+}
+
+#define SIM_TRY(s, expr)                                                        \
+  do {                                                                          \
+    int rc__ = (expr);                                                          \
+    if (rc__ != APK_OK) {                                                       \
+      if ((s)->err.empty() && (s)->ctx) (s)->err = apk_last_error((s)->ctx);    \
+      if ((s)->err.empty()) (s)->err = #expr;                                   \
+      return rc__;                                                              \
+    }                                                                           \
+  } while (0)
+
+#define SIM_HIP(s, expr)                                                        \
+  do {                                                                          \
+    hipError_t e__ = (expr);                                                    \
+    if (e__ != hipSuccess) return fail((s), APK_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+hipStream_t hs(const apk_sim *s) { return reinterpret_cast<hipStream_t>(s->stream); }
+
+int parse_bc(const std::string &v) {
+  if (v == "periodic") return BC_PERIODIC;
+  if (v == "outflow") return BC_OUTFLOW;
+  if (v == "reflecting") return BC_REFLECT;
+  throw std::runtime_error("unknown boundary condition: " + v);
+}
+
+// ---- Hydro::Initialize (src/hydro/hydro.cpp:264-826), options of this path only ---------
+void hydro_initialize(apk_sim *s) {
+  ParameterInput &pin = s->pin;
+  HydroPackage &pkg = s->pkg;
+  pkg.cfl = pin.GetOrAddReal("parthenon/time", "cfl", 0.3);
+  const std::string fluid = pin.GetOrAddString("hydro", "fluid", "euler");
+  if (fluid == "euler") {
+    pkg.fluid = APK_FLUID_EULER;
+    pkg.nhydro = 5;
+  } else if (fluid == "glmmhd") {
+    pkg.fluid = APK_FLUID_GLMMHD;
+    pkg.nhydro = 9;
+    const std::string src = pin.GetOrAddString("hydro", "glmmhd_source", "dedner_plain");
+    if (src == "dedner_plain") pkg.glmmhd_source_extended = false;
+    else if (src == "dedner_extended") pkg.glmmhd_source_extended = true;
+    else throw std::runtime_error("AthenaPK hydro: Unknown glmmhd_source");
+    pkg.glmmhd_alpha = pin.GetOrAddReal("hydro", "glmmhd_alpha", 0.1);
+    pkg.calc_c_h = true;
+  } else {
+    throw std::runtime_error("AthenaPK hydro: Unknown fluid method.");
+  }
+  pkg.max_dt = pin.GetOrAddReal("hydro", "max_dt", -1.0);
+
+  const std::string recon = pin.GetString("hydro", "reconstruction");
+  int need_ng = 3;
+  if (recon == "dc") pkg.recon = APK_RC_DC, need_ng = 1;
+  else if (recon == "plm") pkg.recon = APK_RC_PLM, need_ng = 2;
+  else if (recon == "ppm") pkg.recon = APK_RC_PPM, need_ng = 3;
+  else if (recon == "limo3") pkg.recon = APK_RC_LIMO3, need_ng = 2;
+  else if (recon == "weno3") pkg.recon = APK_RC_WENO3, need_ng = 2;
+  else if (recon == "wenoz") pkg.recon = APK_RC_WENOZ, need_ng = 3;
+  else throw std::runtime_error("AthenaPK hydro: Unknown reconstruction method.");
+
+  pkg.calc_dt_hyp = true;
+  const std::string riemann = pin.GetString("hydro", "riemann");
+  if (riemann == "llf") {
+    pkg.riemann = APK_RS_LLF;
+    if (pkg.recon != APK_RC_DC) throw std::runtime_error("LLF Riemann solver only implemented with DC reconstruction.");
+  } else if (riemann == "hlle") {
+    pkg.riemann = APK_RS_HLLE;
+  } else if (riemann == "hllc") {
+    pkg.riemann = APK_RS_HLLC;
+  } else if (riemann == "hlld") {
+    pkg.riemann = APK_RS_HLLD;
+  } else if (riemann == "none") {
+    pkg.riemann = APK_RS_NONE;
+    pkg.calc_dt_hyp = false;
+    if (pkg.recon != APK_RC_DC) throw std::runtime_error("'none' Riemann solver only supported with DC reconstruction.");
+  } else {
+    throw std::runtime_error("AthenaPK hydro: Unknown riemann solver.");
+  }
+  if (pin.DoesParameterExist("hydro", "calc_dt_hyp")) pkg.calc_dt_hyp = pin.GetBoolean("hydro", "calc_dt_hyp");
+  // registry check (flux_functions.at(...) throws in the reference, hydro.cpp:420)
+  const bool hydro_ok = pkg.fluid == APK_FLUID_EULER && (pkg.riemann == APK_RS_HLLE || pkg.riemann == APK_RS_HLLC);
+  const bool mhd_ok = pkg.fluid == APK_FLUID_GLMMHD && (pkg.riemann == APK_RS_HLLE || pkg.riemann == APK_RS_HLLD);
+  if (!(hydro_ok || mhd_ok || pkg.riemann == APK_RS_LLF || pkg.riemann == APK_RS_NONE))
+    throw std::runtime_error("AthenaPK hydro: no flux function for this fluid/riemann combination");
+
+  const int nghost = pin.GetInteger("parthenon/mesh", "nghost");
+  if (nghost < need_ng) throw std::runtime_error("AthenaPK hydro: Need more ghost zones for chosen reconstruction.");
+
+  const std::string integ = pin.GetString("parthenon/time", "integrator");
+  pkg.flux_other_stage = {pkg.fluid, pkg.recon, pkg.riemann};
+  pkg.flux_first_stage = pkg.flux_other_stage;
+  // Parthenon low-storage integrator coefficients
+  if (integ == "rk1") {
+    pkg.integrator = APK_INT_RK1;
+    s->nstages = 1;
+    s->beta[0] = 1.0, s->gam0[0] = 0.0, s->gam1[0] = 1.0;
+  } else if (integ == "rk2") {
+    pkg.integrator = APK_INT_RK2;
+    s->nstages = 2;
+    s->beta[0] = 1.0, s->gam0[0] = 0.0, s->gam1[0] = 1.0;
+    s->beta[1] = 0.5, s->gam0[1] = 0.5, s->gam1[1] = 0.5;
+  } else if (integ == "rk3") {
+    pkg.integrator = APK_INT_RK3;
+    s->nstages = 3;
+    s->beta[0] = 1.0, s->gam0[0] = 0.0, s->gam1[0] = 1.0;
+    s->beta[1] = 0.25, s->gam0[1] = 0.25, s->gam1[1] = 0.75;
+    s->beta[2] = 2.0 / 3.0, s->gam0[2] = 2.0 / 3.0, s->gam1[2] = 1.0 / 3.0;
+  } else if (integ == "vl2") {
+    pkg.integrator = APK_INT_VL2;
+    s->nstages = 2;
+    s->beta[0] = 0.5, s->gam0[0] = 0.0, s->gam1[0] = 1.0;
+    s->beta[1] = 1.0, s->gam0[1] = 0.0, s->gam1[1] = 1.0;
+    // override first stage (predictor) to first order (hydro.cpp:457-463)
+    pkg.flux_first_stage = {pkg.fluid, APK_RC_DC, pkg.riemann};
+  } else {
+    throw std::runtime_error("unknown integrator: " + integ);
+  }
+  pkg.first_order_flux_correct = pin.GetOrAddBoolean("hydro", "first_order_flux_correct", false);
+
+  const std::string eos = pin.GetString("hydro", "eos");
+  if (eos != "adiabatic") throw std::runtime_error("AthenaPK hydro: Unknown EOS");
+  pkg.eos.gamma = pin.GetReal("hydro", "gamma");
+  pkg.eos.dfloor = pin.GetOrAddReal("hydro", "dfloor", -1.0);
+  pkg.eos.pfloor = pin.GetOrAddReal("hydro", "pfloor", -1.0);
+  const double Tfloor = pin.GetOrAddReal("hydro", "Tfloor", -1.0);
+  if (Tfloor > 0.0) throw std::runtime_error("Temperature floor requires units and gas composition (not part of this path).");
+  pkg.eos.efloor = Tfloor;
+  pkg.eos.vceil = pin.GetOrAddReal("hydro", "vceil", std::numeric_limits<double>::infinity());
+  const double Tceil = pin.GetOrAddReal("hydro", "Tceil", std::numeric_limits<double>::infinity());
+  if (Tceil < std::numeric_limits<double>::infinity())
+    throw std::runtime_error("Temperature ceiling requires units and gas composition (not part of this path).");
+  pkg.eos.eceil = Tceil;
+  pkg.nscalars = pin.GetOrAddInteger("hydro", "nscalars", 0);
+  if (pkg.nscalars < 0) throw std::runtime_error("hydro/nscalars must be >= 0");
+}
+
+void mesh_initialize(apk_sim *s) {
+  ParameterInput &pin = s->pin;
+  Mesh &m = s->mesh;
+  const char *nxk[3] = {"nx1", "nx2", "nx3"};
+  const char *mink[3] = {"x1min", "x2min", "x3min"}, *maxk[3] = {"x1max", "x2max", "x3max"};
+  const char *ibc[3] = {"ix1_bc", "ix2_bc", "ix3_bc"}, *obc[3] = {"ox1_bc", "ox2_bc", "ox3_bc"};
+  for (int d = 0; d < 3; ++d) {
+    m.nx[d] = pin.GetOrAddInteger("parthenon/mesh", nxk[d], 1);
+    m.mb[d] = pin.GetOrAddInteger("parthenon/meshblock", nxk[d], m.nx[d]);
+    s->xmin[d] = pin.GetOrAddReal("parthenon/mesh", mink[d], -0.5);
+    s->xmax[d] = pin.GetOrAddReal("parthenon/mesh", maxk[d], 0.5);
+    s->dx[d] = (s->xmax[d] - s->xmin[d]) / (double)m.nx[d];
+    m.bc_in[d] = parse_bc(pin.GetOrAddString("parthenon/mesh", ibc[d], "periodic"));
+    m.bc_out[d] = parse_bc(pin.GetOrAddString("parthenon/mesh", obc[d], "periodic"));
+  }
+  if (pin.GetOrAddString("parthenon/mesh", "refinement", "none") != "none")
+    throw std::runtime_error("mesh refinement is outside this path (uniform meshes only)");
+  m.ng = pin.GetInteger("parthenon/mesh", "nghost");
+  m.nvar = s->pkg.nhydro + s->pkg.nscalars;
+  m.rank = s->rank;
+  m.nranks = s->nranks;
+  m.Build();
+  s->nper = m.sn * m.nvar;
+  s->tlim = pin.GetOrAddReal("parthenon/time", "tlim", 1.0);
+  s->nlim = pin.GetOrAddInteger("parthenon/time", "nlim", -1);
+}
+
+// ---- problem generators ---------------------------------------------------------------------
+// cell centre: Xc = xmin + (global_index + 1/2) dx.  x0[d] carries the
+// global index of the block's first interior cell, so centres do not depend on the decomposition.
+double xc(const apk_sim *s, const double x0[3], int d, int idx) {
+  const int ng = s->mesh.Active(d) ? s->mesh.ng : 0;
+  return s->xmin[d] + ((x0[d] + (double)(idx - ng)) + 0.5) * s->dx[d];
+}
+void block_origin(const apk_sim *s, int lb, double x0[3]) {
+  int bc[3];
+  s->mesh.Loc(s->mesh.local_gids[lb], bc);
+  for (int d = 0; d < 3; ++d) x0[d] = (double)(bc[d] * s->mesh.mb[d]);
+}
+
+// hydro eigensystem, src/pgen/linear_wave.cpp:421-500 (eigenvalues + right eigenvectors)
+void lw_eigensystem(double gm1, double v1, double v2, double v3, double h, double ev[5], double rem[5][5]) {
+  const double vsq = v1 * v1 + v2 * v2 + v3 * v3;
+  const double asq = gm1 * std::max((h - 0.5 * vsq), 1.0e-20);
+  const double a = std::sqrt(asq);
+  ev[0] = v1 - a;
+  ev[1] = ev[2] = ev[3] = v1;
+  ev[4] = v1 + a;
+  const double col[5][5] = {{1.0, v1 - a, v2, v3, h - v1 * a},
+                            {0.0, 0.0, 1.0, 0.0, v2},
+                            {0.0, 0.0, 0.0, 1.0, v3},
+                            {1.0, v1, v2, v3, 0.5 * vsq},
+                            {1.0, v1 + a, v2, v3, h + v1 * a}};
+  for (int c = 0; c < 5; ++c)
+    for (int r = 0; r < 5; ++r) rem[r][c] = col[c][r];
+}
+
+// src/pgen/linear_wave.cpp:72-176 (InitUserMeshData)
+void lw_setup(apk_sim *s) {
+  ParameterInput &pin = s->pin;
+  LinearWaveState &lw = s->lw;
+  lw.wave_flag = pin.GetInteger("problem/linear_wave", "wave_flag");
+  if (lw.wave_flag < 0 || lw.wave_flag > 4) throw std::runtime_error("problem/linear_wave/wave_flag must be 0..4");
+  lw.amp = pin.GetReal("problem/linear_wave", "amp");
+  lw.vflow = pin.GetOrAddReal("problem/linear_wave", "vflow", 0.0);
+  double ang_2 = pin.GetOrAddReal("problem/linear_wave", "ang_2", -999.9);
+  double ang_3 = pin.GetOrAddReal("problem/linear_wave", "ang_3", -999.9);
+  const bool ang_2_vert = pin.GetOrAddBoolean("problem/linear_wave", "ang_2_vert", false);
+  const bool ang_3_vert = pin.GetOrAddBoolean("problem/linear_wave", "ang_3_vert", false);
+  lw.compute_error = pin.GetOrAddBoolean("problem/linear_wave", "compute_error", false);
+  lw.gam = s->pkg.eos.gamma;
+  lw.gm1 = lw.gam - 1.0;
+  const double x1size = s->xmax[0] - s->xmin[0], x2size = s->xmax[1] - s->xmin[1],
+               x3size = s->xmax[2] - s->xmin[2];
+  if (ang_3 == -999.9) ang_3 = std::atan(x1size / x2size);
+  lw.sin_a3 = std::sin(ang_3);
+  lw.cos_a3 = std::cos(ang_3);
+  if (ang_3_vert) {
+    lw.sin_a3 = 1.0;
+    lw.cos_a3 = 0.0;
+    ang_3 = 0.5 * M_PI;
+  }
+  if (ang_2 == -999.9) ang_2 = std::atan(0.5 * (x1size * lw.cos_a3 + x2size * lw.sin_a3) / x3size);
+  lw.sin_a2 = std::sin(ang_2);
+  lw.cos_a2 = std::cos(ang_2);
+  if (ang_2_vert) {
+    lw.sin_a2 = 1.0;
+    lw.cos_a2 = 0.0;
+    ang_2 = 0.5 * M_PI;
+  }
+  const double x1 = x1size * lw.cos_a2 * lw.cos_a3;
+  const double x2 = x2size * lw.cos_a2 * lw.sin_a3;
+  const double x3 = x3size * lw.sin_a2;
+  const int f2 = (s->mesh.nx[1] > 1) ? 1 : 0, f3 = (s->mesh.nx[2] > 1) ? 1 : 0;
+  lw.lambda = x1;
+  if (f2 && ang_3 != 0.0) lw.lambda = std::min(lw.lambda, x2);
+  if (f3 && ang_2 != 0.0) lw.lambda = std::min(lw.lambda, x3);
+  if (ang_3_vert) lw.lambda = x2;
+  if (ang_2_vert) lw.lambda = x3;
+  lw.k_par = 2.0 * (M_PI) / lw.lambda;
+  lw.d0 = 1.0;
+  lw.u0 = lw.vflow;
+  lw.p0 = 1.0 / lw.gam;
+  const double v0 = 0.0, w0 = 0.0;
+  const double h0 = ((lw.p0 / lw.gm1 + 0.5 * lw.d0 * (lw.u0 * lw.u0 + v0 * v0 + w0 * w0)) + lw.p0) / lw.d0;
+  lw_eigensystem(lw.gm1, lw.u0, v0, w0, h0, lw.ev, lw.rem);
+  if (pin.GetOrAddBoolean("problem/linear_wave", "test", false)) {
+    // reinterpret tlim as the number of wave periods (linear_wave.cpp:169-175)
+    s->tlim = lw.lambda / std::abs(lw.ev[lw.wave_flag]) * s->tlim;
+  }
+}
+
+// analytic conserved state at a cell centre (linear_wave.cpp:355-373 == :206-226)
+void lw_state(const LinearWaveState &lw, double x1, double x2, double x3, double u[5]) {
+  const double x = lw.cos_a2 * (x1 * lw.cos_a3 + x2 * lw.sin_a3) + x3 * lw.sin_a2;
+  const double sn = std::sin(lw.k_par * x);
+  const int wf = lw.wave_flag;
+  u[0] = lw.d0 + lw.amp * sn * lw.rem[0][wf];
+  const double mx = lw.d0 * lw.vflow + lw.amp * sn * lw.rem[1][wf];
+  const double my = lw.amp * sn * lw.rem[2][wf];
+  const double mz = lw.amp * sn * lw.rem[3][wf];
+  u[1] = mx * lw.cos_a2 * lw.cos_a3 - my * lw.sin_a3 - mz * lw.sin_a2 * lw.cos_a3;
+  u[2] = mx * lw.cos_a2 * lw.sin_a3 + my * lw.cos_a3 - mz * lw.sin_a2 * lw.sin_a3;
+  u[3] = mx * lw.sin_a2 + mz * lw.cos_a2;
+  u[4] = lw.p0 / lw.gm1 + 0.5 * lw.d0 * lw.u0 * lw.u0 + lw.amp * sn * lw.rem[4][wf];
+}
+
+// fills the interior of one block's host image [nvar][Nk][Nj][Ni]
+void pgen_block(apk_sim *s, int lb, std::vector<double> &u) {
+  const Mesh &m = s->mesh;
+  const HydroPackage &pkg = s->pkg;
+  std::fill(u.begin(), u.end(), 0.0);
+  double x0[3];
+  block_origin(s, lb, x0);
+  auto at = [&](int n, int k, int j, int i) -> double & { return u[n * m.sn + k * m.sk + j * m.sj + i]; };
+  const bool mhd = pkg.fluid == APK_FLUID_GLMMHD;
+  const double gm1 = pkg.eos.gamma - 1.0;
+  ParameterInput &pin = s->pin;
+  double sod[7] = {0};
+  if (s->problem_id == "sod") {  // src/pgen/sod.cpp:24-30
+    sod[0] = pin.GetOrAddReal("problem/sod", "rho_l", 1.0);
+    sod[1] = pin.GetOrAddReal("problem/sod", "pres_l", 1.0);
+    sod[2] = pin.GetOrAddReal("problem/sod", "u_l", 0.0);
+    sod[3] = pin.GetOrAddReal("problem/sod", "rho_r", 0.125);
+    sod[4] = pin.GetOrAddReal("problem/sod", "pres_r", 0.1);
+    sod[5] = pin.GetOrAddReal("problem/sod", "u_r", 0.0);
+    sod[6] = pin.GetOrAddReal("problem/sod", "x_discont", 0.5);
+  }
+  for (int k = m.ks; k <= m.ke; ++k)
+    for (int j = m.js; j <= m.je; ++j)
+      for (int i = m.is; i <= m.ie; ++i) {
+        const double x1 = xc(s, x0, 0, i), x2 = xc(s, x0, 1, j), x3 = xc(s, x0, 2, k);
+        if (s->problem_id == "linear_wave") {
+          double w[5];
+          lw_state(s->lw, x1, x2, x3, w);
+          for (int n = 0; n < 5; ++n) at(n, k, j, i) = w[n];
+        } else if (s->problem_id == "sod") {  // src/pgen/sod.cpp:37-50
+          const bool left = x1 < sod[6];
+          const double rho = left ? sod[0] : sod[3], pr = left ? sod[1] : sod[4], ux = left ? sod[2] : sod[5];
+          at(0, k, j, i) = rho;
+          at(1, k, j, i) = rho * ux;
+          at(4, k, j, i) = 0.5 * rho * ux * ux + pr / (pkg.eos.gamma - 1.0);
+        } else if (s->problem_id == "orszag_tang") {  // src/pgen/orszag_tang.cpp:33-61
+          if (!mhd) throw std::runtime_error("orszag_tang requires hydro/fluid = glmmhd");
+          const double B0 = 1.0 / std::sqrt(4.0 * M_PI), d0 = 25.0 / (36.0 * M_PI), v0 = 1.0,
+                       p0 = 5.0 / (12.0 * M_PI);
+          at(0, k, j, i) = d0;
+          at(1, k, j, i) = d0 * v0 * std::sin(2.0 * M_PI * x2);
+          at(2, k, j, i) = -d0 * v0 * std::sin(2.0 * M_PI * x1);
+          at(3, k, j, i) = 0.0;
+          at(5, k, j, i) = B0 * std::sin(2.0 * M_PI * x2);
+          at(6, k, j, i) = B0 * std::sin(4.0 * M_PI * x1);
+          at(7, k, j, i) = 0.0;
+          const double b1 = at(5, k, j, i), b2 = at(6, k, j, i), b3 = at(7, k, j, i);
+          const double m1 = at(1, k, j, i), m2 = at(2, k, j, i), m3 = at(3, k, j, i);
+          at(4, k, j, i) = p0 / gm1 + 0.5 * (b1 * b1 + b2 * b2 + b3 * b3 + (m1 * m1 + m2 * m2 + m3 * m3) / at(0, k, j, i));
+        } else if (s->problem_id == "synthetic") {
+          // analytic, seedless smooth state (SURVEY.md 8(d) synthetic kernel benchmark)
+          const double tp = 2.0 * M_PI;
+          const double fx = (x1 - s->xmin[0]) / (s->xmax[0] - s->xmin[0]);
+          const double fy = (x2 - s->xmin[1]) / (s->xmax[1] - s->xmin[1]);
+          const double fz = (x3 - s->xmin[2]) / (s->xmax[2] - s->xmin[2]);
+          const double rho = 1.0 + 0.2 * std::sin(tp * (fx + fy + fz));
+          const double p = 1.0 + 0.1 * std::cos(tp * (fx - fy + 2.0 * fz));
+          const double v1 = 0.17 * std::sin(tp * (fy + fz));
+          const double v2 = 0.17 * std::cos(tp * (fx - fz));
+          const double v3 = 0.17 * std::sin(tp * (2.0 * fx + fy));
+          double b1 = 0, b2 = 0, b3 = 0, psi = 0;
+          if (mhd) {
+            b1 = 0.28 * std::cos(tp * (fy - fz));
+            b2 = 0.28 * std::sin(tp * (fx + 2.0 * fz));
+            b3 = 0.28 * std::cos(tp * (fx + fy));
+            psi = 0.01 * std::sin(tp * (fx + fy - fz));
+          }
+          at(0, k, j, i) = rho;
+          at(1, k, j, i) = rho * v1;
+          at(2, k, j, i) = rho * v2;
+          at(3, k, j, i) = rho * v3;
+          double e = p / gm1 + 0.5 * rho * (v1 * v1 + v2 * v2 + v3 * v3);
+          if (mhd) {
+            e += 0.5 * (b1 * b1 + b2 * b2 + b3 * b3);
+            at(5, k, j, i) = b1;
+            at(6, k, j, i) = b2;
+            at(7, k, j, i) = b3;
+            at(8, k, j, i) = psi;
+          }
+          at(4, k, j, i) = e;
+          for (int n = pkg.nhydro; n < m.nvar; ++n)
+            at(n, k, j, i) = rho * (0.5 + 0.25 * std::sin(tp * (fx + (n - pkg.nhydro + 1) * fy)));
+        } else {
+          throw std::runtime_error("unknown job/problem_id: " + s->problem_id);
+        }
+      }
+}
+
+// ---- device resources -----------------------------------------------------------------------
+int dev_alloc(apk_sim *s, const char *tag, size_t bytes, double **out) {
+  *out = nullptr;
+  if (bytes == 0) return APK_OK;
+  if (s->have_alloc) {
+    *out = static_cast<double *>(s->alloc.alloc(s->alloc.user, tag, bytes));
+    if (!*out) return fail(s, APK_ERR_DEVICE, std::string("allocator returned NULL for ") + tag);
+    return APK_OK;
+  }
+  SIM_HIP(s, hipMalloc(out, bytes));
+  return APK_OK;
+}
+void dev_free(apk_sim *s, double *p) {
+  if (!p) return;
+  if (s->have_alloc) {
+    if (s->alloc.release) s->alloc.release(s->alloc.user, p);
+  } else {
+    (void)hipFree(p);
+  }
+}
+
+int build_packs(apk_sim *s) {
+  if (s->mu0) apk_pack_destroy(s->mu0);
+  if (s->mu1) apk_pack_destroy(s->mu1);
+  s->mu0 = s->mu1 = nullptr;
+  const int nlb = (int)s->mesh.local_gids.size();
+  std::vector<apk_block_desc> b0(nlb), b1(nlb);
+  for (int lb = 0; lb < nlb; ++lb) {
+    b0[lb].cons = s->d_cons + lb * s->nper;
+    b0[lb].prim = s->d_prim + lb * s->nper;
+    b1[lb].cons = s->d_u1 + lb * s->nper;
+    b1[lb].prim = nullptr;
+    for (int d = 0; d < 3; ++d) {
+      b0[lb].flux[d] = s->d_flux[d] ? s->d_flux[d] + lb * s->nper : nullptr;
+      b1[lb].flux[d] = nullptr;
+      b0[lb].dx[d] = b1[lb].dx[d] = s->dx[d];
+    }
+  }
+  apk_pack_desc d{};
+  d.nblocks = nlb;
+  d.nhydro = s->pkg.nhydro;
+  d.nscalars = s->pkg.nscalars;
+  for (int q = 0; q < 3; ++q) d.nx[q] = s->mesh.mb[q];
+  d.ng = s->mesh.ng;
+  d.blocks = b0.data();
+  SIM_TRY(s, apk_pack_create(s->ctx, &d, &s->mu0));
+  d.blocks = b1.data();
+  SIM_TRY(s, apk_pack_create(s->ctx, &d, &s->mu1));
+  return APK_OK;
+}
+
+int ensure_flux_arrays(apk_sim *s) {
+  bool changed = false;
+  const size_t bytes = (size_t)s->nper * s->mesh.local_gids.size() * sizeof(double);
+  const char *tags[3] = {"flux1", "flux2", "flux3"};
+  for (int d = 0; d < s->mesh.ndim; ++d) {
+    if (!s->d_flux[d]) {
+      SIM_TRY(s, dev_alloc(s, tags[d], bytes, &s->d_flux[d]));
+      SIM_HIP(s, hipMemsetAsync(s->d_flux[d], 0, bytes, hs(s)));
+      changed = true;
+    }
+  }
+  if (changed || !s->mu0) return build_packs(s);
+  return APK_OK;
+}
+
+bool stage_can_fuse(const apk_sim *s) {
+  return s->fused && !s->pkg.first_order_flux_correct && s->pkg.nscalars == 0 &&
+         s->pkg.riemann != APK_RS_NONE && s->pkg.riemann != APK_RS_LLF;
+}
+
+double *region_base(apk_sim *s, int kind, int block) {
+  if (kind == RK_BLOCK) return s->d_cons + (int64_t)block * s->nper;
+  if (kind == RK_SEND) return s->send_buf[block];
+  return s->recv_buf[block];
+}
+
+int build_copy_plans(apk_sim *s) {
+  for (int ph = 0; ph < PH_COUNT; ++ph) {
+    std::vector<apk_copy_region> regs;
+    for (const BoxRegion &r : s->mesh.plan[ph]) {
+      apk_copy_region c{};
+      c.src = region_base(s, r.src_kind, r.src_block) + r.src_off;
+      c.dst = region_base(s, r.dst_kind, r.dst_block) + r.dst_off;
+      for (int q = 0; q < 3; ++q) c.ext[q] = r.ext[q];
+      c.nvar = r.nvar;
+      for (int q = 0; q < 4; ++q) {
+        c.src_stride[q] = r.src_stride[q];
+        c.dst_stride[q] = r.dst_stride[q];
+      }
+      c.flip_var = r.flip_var;
+      regs.push_back(c);
+    }
+    SIM_TRY(s, apk_copy_plan_create(s->ctx, regs.data(), (int)regs.size(), &s->plans[ph]));
+  }
+  return APK_OK;
+}
+
+// EvolutionDriver::SetGlobalTimeStep
+void set_global_dt(apk_sim *s, double dt_est) {
+  double dt = s->dt;
+  if (dt < 0.1 * kHuge) dt *= 2.0;
+  if (dt_est < dt) dt = dt_est;
+  if (s->time < s->tlim && (s->tlim - s->time) < dt) dt = s->tlim - s->time;
+  s->dt = dt;
+}
+
+// Hydro::EstimateTimestep<fluid> over this rank's pack + global min (hydro.cpp:913-977)
+int estimate_timestep(apk_sim *s, double *dt_out) {
+  double dt = kHuge;
+  if (s->pkg.calc_dt_hyp) {
+    SIM_TRY(s, apk_estimate_timestep(s->ctx, s->mu0, s->pkg.fluid, &s->pkg.eos, s->pkg.cfl, &dt, s->stream));
+    if (s->pkg.fluid == APK_FLUID_GLMMHD && dt < s->pkg.dt_hyp) s->pkg.dt_hyp = dt;  // hydro.cpp:903-908
+  }
+  if (s->pkg.max_dt > 0.0 && s->pkg.max_dt < dt) dt = s->pkg.max_dt;
+  unsigned flags = 0;
+  SIM_TRY(s, apk_poll_device_flags(s->ctx, &flags, s->stream));
+  if (flags & APK_FLAG_NEG_DENSITY)
+    return fail(s, APK_ERR_INVALID, "Got negative density. Consider enabling first-order flux correction or setting a reasonble density floor.");
+  if (flags & APK_FLAG_NEG_PRESSURE)
+    return fail(s, APK_ERR_INVALID, "Got negative pressure. Consider enabling first-order flux correction or setting a reasonble pressure or temperature floor.");
+  if (s->have_comm && s->nranks > 1) {
+    if (s->comm.allreduce_min(s->comm.user, &dt, 1) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_min failed");
+  }
+  *dt_out = dt;
+  return APK_OK;
+}
+
+int exchange_ghosts(apk_sim *s) {
+  const bool remote = !s->mesh.peers.empty();
+  if (remote) {
+    SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plans[PH_PACK], s->stream));
+  }
+  SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plans[PH_LOCAL], s->stream));
+  if (remote) {
+    if (!s->have_comm || !s->comm.exchange) return fail(s, APK_ERR_INVALID, "remote neighbours but no comm ops");
+    if (s->comm.exchange(s->comm.user) != 0) return fail(s, APK_ERR_DEVICE, "halo exchange failed");
+    SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plans[PH_UNPACK], s->stream));
+  }
+  for (int ph = PH_BC1; ph <= PH_BC3; ++ph) SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plans[ph], s->stream));
+  return APK_OK;
+}
+
+int fill_derived(apk_sim *s) {
+  return apk_cons_to_prim(s->ctx, s->mu0, s->pkg.fluid, &s->pkg.eos, s->stream);
+}
+
+// Hydro::PreStepMeshUserWorkInLoop (hydro.cpp:102-143)
+int pre_step(apk_sim *s) {
+  if (!s->pkg.calc_c_h) return APK_OK;
+  double mindx = s->dx[0];  // CalculateGlobalMinDx on a uniform mesh (hydro.cpp:65-95)
+  if (s->mesh.Active(1)) mindx = std::fmin(mindx, s->dx[1]);
+  if (s->mesh.Active(2)) mindx = std::fmin(mindx, s->dx[2]);
+  double mins[3] = {mindx, s->pkg.dt_hyp, kHuge};
+  if (s->have_comm && s->nranks > 1) {
+    if (s->comm.allreduce_min(s->comm.user, mins, 3) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_min failed");
+  }
+  s->pkg.mindx = mins[0];
+  s->pkg.dt_hyp = mins[1];
+  s->pkg.c_h = s->pkg.cfl * s->pkg.mindx / s->pkg.dt_hyp;
+  return APK_OK;
+}
+
+// one stage of HydroDriver::MakeTaskCollection (hydro_driver.cpp:474-577)
+int do_stage(apk_sim *s, int stage) {
+  HydroPackage &pkg = s->pkg;
+  const double g0 = s->gam0[stage - 1], g1 = s->gam1[stage - 1];
+  const double beta_dt = s->beta[stage - 1] * s->dt;
+  const size_t field_bytes = (size_t)s->nper * s->mesh.local_gids.size() * sizeof(double);
+  if (stage == 1) {  // init u1 (hydro_driver.cpp:474-495)
+    SIM_HIP(s, hipMemcpyAsync(s->d_u1, s->d_cons, field_bytes, hipMemcpyDeviceToDevice, hs(s)));
+  }
+  const apk_flux_cfg cfg = (stage == 1) ? pkg.flux_first_stage : pkg.flux_other_stage;
+  if (stage_can_fuse(s)) {
+    apk_stage_args a{};
+    a.cfg = cfg;
+    a.eos = pkg.eos;
+    a.c_h = pkg.c_h;
+    a.gam0 = g0;
+    a.gam1 = g1;
+    a.beta_dt = beta_dt;
+    a.dedner = (pkg.fluid == APK_FLUID_GLMMHD) ? (pkg.glmmhd_source_extended ? 2 : 1) : 0;
+    a.glmmhd_alpha = pkg.glmmhd_alpha;
+    a.mindx = pkg.mindx;
+    SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0, s->mu1, &a, s->stream));
+  } else {
+    SIM_TRY(s, ensure_flux_arrays(s));
+    SIM_TRY(s, apk_calculate_fluxes(s->ctx, s->mu0, cfg, &pkg.eos, pkg.c_h, s->stream));
+    if (pkg.first_order_flux_correct) {
+      long long nfix = 0;
+      SIM_TRY(s, apk_first_order_flux_correct(s->ctx, s->mu0, s->mu1, pkg.fluid, &pkg.eos, pkg.c_h, g0, g1,
+                                              beta_dt, &nfix, s->stream));
+      s->fofc_total += nfix;
+    }
+    SIM_TRY(s, apk_update_with_flux_divergence(s->ctx, s->mu0, s->mu1, g0, g1, beta_dt, s->stream));
+    if (pkg.fluid == APK_FLUID_GLMMHD) {
+      SIM_TRY(s, apk_dedner_source(s->ctx, s->mu0, pkg.glmmhd_source_extended ? 1 : 0, pkg.glmmhd_alpha,
+                                   pkg.c_h, pkg.mindx, beta_dt, s->stream));
+    }
+  }
+  SIM_TRY(s, exchange_ghosts(s));
+  SIM_TRY(s, fill_derived(s));
+  if (stage == s->nstages && pkg.calc_c_h) {  // hydro_driver.cpp:589-603
+    pkg.mindx = kHuge;
+    pkg.dt_hyp = kHuge;
+  }
+  return APK_OK;
+}
+
+int create_common(const char *deck, const char *const *overrides, int noverrides, int rank, int nranks,
+                  apk_sim **out, char *errbuf, size_t errlen) {
+  if (!out || !deck) return APK_ERR_INVALID;
+  *out = nullptr;
+  apk_sim *s = new (std::nothrow) apk_sim();
+  if (!s) return APK_ERR_INVALID;
+  s->rank = rank;
+  s->nranks = nranks;
+  try {
+    s->pin.LoadFromString(deck);
+    for (int i = 0; i < noverrides; ++i) s->pin.ApplyOverride(overrides[i]);
+    s->problem_id = s->pin.GetString("job", "problem_id");
+    hydro_initialize(s);
+    mesh_initialize(s);
+    if (s->problem_id == "linear_wave") lw_setup(s);
+    else if (s->problem_id != "sod" && s->problem_id != "orszag_tang" && s->problem_id != "synthetic")
+      throw std::runtime_error("unknown job/problem_id: " + s->problem_id);
+  } catch (const std::exception &e) {
+    if (errbuf && errlen) std::snprintf(errbuf, errlen, "%s", e.what());
+    delete s;
+    return APK_ERR_INVALID;
+  }
+  *out = s;
+  return APK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int apk_sim_create_host_only(const char *deck, const char *const *overrides, int noverrides, int rank,
+                             int nranks, apk_sim **out, char *errbuf, size_t errlen) {
+  int rc = create_common(deck, overrides, noverrides, rank, nranks, out, errbuf, errlen);
+  if (rc == APK_OK) (*out)->host_only = true;
+  return rc;
+}
+
+int apk_sim_create(const char *deck, const char *const *overrides, int noverrides, int rank, int nranks,
+                   const apk_allocator *allocator, const apk_comm_ops *comm, apk_stream_t stream,
+                   apk_sim **out, char *errbuf, size_t errlen) {
+  int rc = create_common(deck, overrides, noverrides, rank, nranks, out, errbuf, errlen);
+  if (rc != APK_OK) return rc;
+  apk_sim *s = *out;
+  auto bail = [&](int code) {
+    if (errbuf && errlen) std::snprintf(errbuf, errlen, "%s", s->err.c_str());
+    apk_sim_destroy(s);
+    *out = nullptr;
+    return code;
+  };
+  s->stream = stream;
+  if (allocator && allocator->alloc) {
+    s->alloc = *allocator;
+    s->have_alloc = true;
+  }
+  if (comm) {
+    s->comm = *comm;
+    s->have_comm = true;
+  }
+  if (nranks > 1 && !(comm && comm->exchange && comm->allreduce_min && comm->allreduce_sum)) {
+    s->err = "nranks > 1 requires comm ops";
+    return bail(APK_ERR_INVALID);
+  }
+  rc = apk_create(&s->ctx);
+  if (rc != APK_OK) {
+    s->err = "apk_create failed: no usable gfx950 device (there is no CPU fallback)";
+    return bail(rc);
+  }
+  const size_t nlb = s->mesh.local_gids.size();
+  const size_t bytes = (size_t)s->nper * nlb * sizeof(double);
+  if ((rc = dev_alloc(s, "cons", bytes, &s->d_cons)) != APK_OK) return bail(rc);
+  if ((rc = dev_alloc(s, "prim", bytes, &s->d_prim)) != APK_OK) return bail(rc);
+  if ((rc = dev_alloc(s, "u1", bytes, &s->d_u1)) != APK_OK) return bail(rc);
+  if (hipMemset(s->d_cons, 0, bytes) != hipSuccess || hipMemset(s->d_prim, 0, bytes) != hipSuccess ||
+      hipMemset(s->d_u1, 0, bytes) != hipSuccess) {
+    s->err = "hipMemset failed";
+    return bail(APK_ERR_DEVICE);
+  }
+  for (size_t p = 0; p < s->mesh.peers.size(); ++p) {
+    double *sb = nullptr, *rb = nullptr;
+    const std::string st = "send:" + std::to_string(s->mesh.peers[p].rank);
+    const std::string rt = "recv:" + std::to_string(s->mesh.peers[p].rank);
+    if ((rc = dev_alloc(s, st.c_str(), s->mesh.peers[p].send_count * sizeof(double), &sb)) != APK_OK) return bail(rc);
+    if ((rc = dev_alloc(s, rt.c_str(), s->mesh.peers[p].recv_count * sizeof(double), &rb)) != APK_OK) return bail(rc);
+    s->send_buf.push_back(sb);
+    s->recv_buf.push_back(rb);
+  }
+  if (!stage_can_fuse(s)) {
+    if ((rc = ensure_flux_arrays(s)) != APK_OK) return bail(rc);
+  } else if ((rc = build_packs(s)) != APK_OK) {
+    return bail(rc);
+  }
+  if ((rc = build_copy_plans(s)) != APK_OK) return bail(rc);
+  return APK_OK;
+}
+
+void apk_sim_destroy(apk_sim *s) {
+  if (!s) return;
+  if (!s->host_only) {
+    (void)hipDeviceSynchronize();
+    for (auto &p : s->plans) apk_copy_plan_destroy(p);
+    apk_pack_destroy(s->mu0);
+    apk_pack_destroy(s->mu1);
+    dev_free(s, s->d_cons);
+    dev_free(s, s->d_prim);
+    dev_free(s, s->d_u1);
+    for (auto *f : s->d_flux) dev_free(s, f);
+    for (auto *b : s->send_buf) dev_free(s, b);
+    for (auto *b : s->recv_buf) dev_free(s, b);
+    apk_destroy(s->ctx);
+  }
+  delete s;
+}
+
+const char *apk_sim_last_error(const apk_sim *s) { return s ? s->err.c_str() : "null sim"; }
+
+int apk_sim_set_fused(apk_sim *s, int fused) {
+  if (!s) return APK_ERR_INVALID;
+  s->fused = fused != 0;
+  if (!s->host_only && !stage_can_fuse(s)) return ensure_flux_arrays(s);
+  return APK_OK;
+}
+
+int apk_sim_initialize(apk_sim *s) {
+  if (!s || s->host_only) return APK_ERR_INVALID;
+  s->err.clear();
+  const int nlb = (int)s->mesh.local_gids.size();
+  std::vector<double> host((size_t)s->nper);
+  try {
+    for (int lb = 0; lb < nlb; ++lb) {
+      pgen_block(s, lb, host);
+      SIM_HIP(s, hipMemcpy(s->d_cons + (int64_t)lb * s->nper, host.data(), sizeof(double) * s->nper, hipMemcpyHostToDevice));
+    }
+  } catch (const std::exception &e) {
+    return fail(s, APK_ERR_INVALID, e.what());
+  }
+  s->time = 0.0;
+  s->ncycle = 0;
+  s->dt = kHuge;
+  s->fofc_total = 0;
+  s->pkg.mindx = kHuge;
+  s->pkg.dt_hyp = kHuge;
+  SIM_TRY(s, exchange_ghosts(s));
+  SIM_TRY(s, fill_derived(s));
+  double est = kHuge;
+  SIM_TRY(s, estimate_timestep(s, &est));
+  set_global_dt(s, est);
+  return APK_OK;
+}
+
+int apk_sim_step(apk_sim *s) {
+  if (!s || s->host_only) return APK_ERR_INVALID;
+  s->err.clear();
+  if (s->time < s->tlim && (s->tlim - s->time) < s->dt) s->dt = s->tlim - s->time;
+  SIM_TRY(s, pre_step(s));
+  for (int stage = 1; stage <= s->nstages; ++stage) SIM_TRY(s, do_stage(s, stage));
+  s->time += s->dt;
+  s->ncycle += 1;
+  double est = kHuge;
+  SIM_TRY(s, estimate_timestep(s, &est));
+  set_global_dt(s, est);
+  return APK_OK;
+}
+
+int apk_sim_run(apk_sim *s, int nlim, int *ncycles) {
+  if (!s) return APK_ERR_INVALID;
+  int n = 0;
+  while (s->time < s->tlim && (nlim < 0 || n < nlim)) {
+    int rc = apk_sim_step(s);
+    if (rc != APK_OK) return rc;
+    ++n;
+  }
+  if (ncycles) *ncycles = n;
+  return APK_OK;
+}
+
+double apk_sim_time(const apk_sim *s) { return s->time; }
+double apk_sim_dt(const apk_sim *s) { return s->dt; }
+double apk_sim_tlim(const apk_sim *s) { return s->tlim; }
+double apk_sim_c_h(const apk_sim *s) { return s->pkg.c_h; }
+int apk_sim_ncycle(const apk_sim *s) { return s->ncycle; }
+long long apk_sim_fofc_count(const apk_sim *s) { return s->fofc_total; }
+
+int apk_sim_get_info(const apk_sim *s, apk_sim_info *o) {
+  if (!s || !o) return APK_ERR_INVALID;
+  std::memset(o, 0, sizeof(*o));
+  o->fluid = s->pkg.fluid;
+  o->recon = s->pkg.recon;
+  o->riemann = s->pkg.riemann;
+  o->integrator = s->pkg.integrator;
+  for (int d = 0; d < 3; ++d) {
+    o->nx[d] = s->mesh.nx[d];
+    o->mb[d] = s->mesh.mb[d];
+    o->xmin[d] = s->xmin[d];
+    o->xmax[d] = s->xmax[d];
+    o->dx[d] = s->dx[d];
+  }
+  o->ng = s->mesh.ng;
+  o->nhydro = s->pkg.nhydro;
+  o->nscalars = s->pkg.nscalars;
+  o->ndim = s->mesh.ndim;
+  o->nblocks_total = s->mesh.nblocks_total;
+  o->nblocks_local = (int)s->mesh.local_gids.size();
+  o->first_gid = s->mesh.local_gids.empty() ? -1 : s->mesh.local_gids[0];
+  o->rank = s->rank;
+  o->nranks = s->nranks;
+  o->npeers = (int)s->mesh.peers.size();
+  o->fofc = s->pkg.first_order_flux_correct;
+  o->dedner_extended = s->pkg.glmmhd_source_extended;
+  o->fused = stage_can_fuse(s);
+  o->cfl = s->pkg.cfl;
+  o->gamma = s->pkg.eos.gamma;
+  o->glmmhd_alpha = s->pkg.glmmhd_alpha;
+  o->cells_per_block = s->mesh.sn;
+  o->zones_local = (int64_t)s->mesh.mb[0] * s->mesh.mb[1] * s->mesh.mb[2] * (int64_t)s->mesh.local_gids.size();
+  o->zones_total = (int64_t)s->mesh.nx[0] * s->mesh.nx[1] * s->mesh.nx[2];
+  return APK_OK;
+}
+
+int apk_sim_block_location(const apk_sim *s, int lb, int *gid, int loc[3]) {
+  if (!s || lb < 0 || lb >= (int)s->mesh.local_gids.size()) return APK_ERR_INVALID;
+  if (gid) *gid = s->mesh.local_gids[lb];
+  if (loc) s->mesh.Loc(s->mesh.local_gids[lb], loc);
+  return APK_OK;
+}
+
+void *apk_sim_block_ptr(const apk_sim *s, int lb, int field) {
+  if (!s || s->host_only || lb < 0 || lb >= (int)s->mesh.local_gids.size()) return nullptr;
+  double *base = field == 0 ? s->d_cons : (field == 1 ? s->d_prim : (field == 2 ? s->d_u1 : nullptr));
+  return base ? base + (int64_t)lb * s->nper : nullptr;
+}
+
+int apk_sim_read_block(apk_sim *s, int lb, int field, double *host_out) {
+  void *p = apk_sim_block_ptr(s, lb, field);
+  if (!p || !host_out) return APK_ERR_INVALID;
+  SIM_HIP(s, hipStreamSynchronize(hs(s)));
+  SIM_HIP(s, hipMemcpy(host_out, p, sizeof(double) * s->nper, hipMemcpyDeviceToHost));
+  return APK_OK;
+}
+
+int apk_sim_write_block(apk_sim *s, int lb, int field, const double *host_in) {
+  void *p = apk_sim_block_ptr(s, lb, field);
+  if (!p || !host_in) return APK_ERR_INVALID;
+  SIM_HIP(s, hipStreamSynchronize(hs(s)));
+  SIM_HIP(s, hipMemcpy(p, host_in, sizeof(double) * s->nper, hipMemcpyHostToDevice));
+  return APK_OK;
+}
+
+int apk_sim_gather(apk_sim *s, int field, double *out) {
+  if (!s || s->host_only || !out) return APK_ERR_INVALID;
+  const Mesh &m = s->mesh;
+  std::vector<double> host((size_t)s->nper);
+  const int64_t NX = m.nx[0], NY = m.nx[1], NZ = m.nx[2];
+  for (int lb = 0; lb < (int)m.local_gids.size(); ++lb) {
+    int rc = apk_sim_read_block(s, lb, field, host.data());
+    if (rc != APK_OK) return rc;
+    int bc[3];
+    m.Loc(m.local_gids[lb], bc);
+    for (int n = 0; n < m.nvar; ++n)
+      for (int k = m.ks; k <= m.ke; ++k)
+        for (int j = m.js; j <= m.je; ++j)
+          for (int i = m.is; i <= m.ie; ++i) {
+            const int64_t gi = (int64_t)bc[0] * m.mb[0] + (i - m.is), gj = (int64_t)bc[1] * m.mb[1] + (j - m.js),
+                          gk = (int64_t)bc[2] * m.mb[2] + (k - m.ks);
+            out[((n * NZ + gk) * NY + gj) * NX + gi] = host[n * m.sn + k * m.sk + j * m.sj + i];
+          }
+  }
+  return APK_OK;
+}
+
+int apk_sim_history(apk_sim *s, double *out8) {
+  if (!s || s->host_only || !out8) return APK_ERR_INVALID;
+  SIM_TRY(s, apk_history(s->ctx, s->mu0, s->pkg.fluid, out8, s->stream));
+  if (s->have_comm && s->nranks > 1) {
+    if (s->comm.allreduce_sum(s->comm.user, out8, 8) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_sum failed");
+  }
+  return APK_OK;
+}
+
+// src/pgen/linear_wave.cpp:183-335
+int apk_sim_linear_wave_errors(apk_sim *s, double *rms, double *l1, double *mx) {
+  if (!s || s->host_only || s->problem_id != "linear_wave" || !rms || !l1 || !mx) return APK_ERR_INVALID;
+  const Mesh &m = s->mesh;
+  std::vector<double> host((size_t)s->nper);
+  const double cellvol = s->dx[0] * s->dx[1] * s->dx[2];
+  double acc[10] = {0};
+  for (int lb = 0; lb < (int)m.local_gids.size(); ++lb) {
+    int rc = apk_sim_read_block(s, lb, 0, host.data());
+    if (rc != APK_OK) return rc;
+    double x0[3];
+    block_origin(s, lb, x0);
+    for (int k = m.ks; k <= m.ke; ++k)
+      for (int j = m.js; j <= m.je; ++j)
+        for (int i = m.is; i <= m.ie; ++i) {
+          double u[5];
+          lw_state(s->lw, xc(s, x0, 0, i), xc(s, x0, 1, j), xc(s, x0, 2, k), u);
+          for (int n = 0; n < 5; ++n) {
+            const double e = std::abs(u[n] - host[n * m.sn + k * m.sk + j * m.sj + i]);
+            acc[n] += e * cellvol;
+            if (e > acc[5 + n]) acc[5 + n] = e;
+          }
+        }
+  }
+  if (s->have_comm && s->nranks > 1) {
+    if (s->comm.allreduce_sum(s->comm.user, acc, 5) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_sum failed");
+    // MAX of non-negative values through the MIN callback
+    double neg[5];
+    for (int n = 0; n < 5; ++n) neg[n] = -acc[5 + n];
+    if (s->comm.allreduce_min(s->comm.user, neg, 5) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_min failed");
+    for (int n = 0; n < 5; ++n) acc[5 + n] = -neg[n];
+  }
+  const double vol = (s->xmax[0] - s->xmin[0]) * (s->xmax[1] - s->xmin[1]) * (s->xmax[2] - s->xmin[2]);
+  double r = 0.0;
+  for (int n = 0; n < 5; ++n) {
+    l1[n] = acc[n] / vol;
+    mx[n] = acc[5 + n];
+    r += l1[n] * l1[n];
+  }
+  *rms = std::sqrt(r);
+  return APK_OK;
+}
+
+int apk_sim_exchange_ghosts(apk_sim *s) {
+  if (!s || s->host_only) return APK_ERR_INVALID;
+  return exchange_ghosts(s);
+}
+int apk_sim_fill_derived(apk_sim *s) {
+  if (!s || s->host_only) return APK_ERR_INVALID;
+  return fill_derived(s);
+}
+int apk_sim_estimate_timestep(apk_sim *s, double *dt) {
+  if (!s || s->host_only || !dt) return APK_ERR_INVALID;
+  return estimate_timestep(s, dt);
+}
+
+int apk_sim_peer(const apk_sim *s, int p, apk_peer_info *o) {
+  if (!s || !o || p < 0 || p >= (int)s->mesh.peers.size()) return APK_ERR_INVALID;
+  o->rank = s->mesh.peers[p].rank;
+  o->send_count = s->mesh.peers[p].send_count;
+  o->recv_count = s->mesh.peers[p].recv_count;
+  o->send_buf = (p < (int)s->send_buf.size()) ? s->send_buf[p] : nullptr;
+  o->recv_buf = (p < (int)s->recv_buf.size()) ? s->recv_buf[p] : nullptr;
+  return APK_OK;
+}
+
+int apk_sim_plan_size(const apk_sim *s, int phase) {
+  if (!s || phase < 0 || phase >= PH_COUNT) return APK_ERR_INVALID;
+  return (int)s->mesh.plan[phase].size();
+}
+
+int apk_sim_plan_region(const apk_sim *s, int phase, int r, apk_region_info *o) {
+  if (!s || !o || phase < 0 || phase >= PH_COUNT || r < 0 || r >= (int)s->mesh.plan[phase].size()) return APK_ERR_INVALID;
+  const BoxRegion &b = s->mesh.plan[phase][r];
+  o->src_kind = b.src_kind;
+  o->src_block = b.src_block;
+  o->dst_kind = b.dst_kind;
+  o->dst_block = b.dst_block;
+  o->src_off = b.src_off;
+  o->dst_off = b.dst_off;
+  o->nvar = b.nvar;
+  o->flip_var = b.flip_var;
+  for (int q = 0; q < 3; ++q) o->ext[q] = b.ext[q];
+  for (int q = 0; q < 4; ++q) {
+    o->src_stride[q] = b.src_stride[q];
+    o->dst_stride[q] = b.dst_stride[q];
+  }
+  return APK_OK;
+}
+
+}  // extern "C"

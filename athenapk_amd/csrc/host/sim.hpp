@@ -1,0 +1,80 @@
+// sim.hpp -- standalone host driver above the hot-path boundary: the "Hydro" package
+// options (src/hydro/hydro.cpp:264-826), the per-cycle c_h update (hydro.cpp:102-143), the
+// per-stage task order (src/hydro/hydro_driver.cpp:347-673) and Parthenon's dt control
+// (SURVEY.md App. A.2-A.4).  All compute goes through the C-ABI of include/apk_amd.h.
+#pragma once
+
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../../include/apk_amd.h"
+#include "../../../include/apk_host.h"
+#include "mesh.hpp"
+#include "params.hpp"
+
+namespace apk {
+
+// "Hydro" StateDescriptor params (names as in hydro.cpp)
+struct HydroPackage {
+  int fluid = APK_FLUID_EULER;
+  int recon = APK_RC_UNDEFINED;
+  int riemann = APK_RS_UNDEFINED;
+  int integrator = APK_INT_UNDEFINED;
+  int nhydro = 5, nscalars = 0;
+  double cfl = 0.3;
+  apk_eos eos{};
+  bool glmmhd_source_extended = false;  // hydro/glmmhd_source
+  double glmmhd_alpha = 0.1;
+  bool calc_c_h = false, calc_dt_hyp = true;
+  bool first_order_flux_correct = false;
+  double max_dt = -1.0;
+  // mutable params
+  double c_h = 0.0;
+  double mindx = std::numeric_limits<double>::max();
+  double dt_hyp = std::numeric_limits<double>::max();
+  // flux function keys (FluxFunKey_t) of the first and the other stages (hydro.cpp:449-467)
+  apk_flux_cfg flux_first_stage{}, flux_other_stage{};
+};
+
+struct LinearWaveState {  // globals of src/pgen/linear_wave.cpp
+  int wave_flag = 0;
+  double amp = 0.0, vflow = 0.0;
+  double sin_a2 = 0, cos_a2 = 1, sin_a3 = 0, cos_a3 = 1, k_par = 0, lambda = 1;
+  double d0 = 1, p0 = 0, u0 = 0, gam = 0, gm1 = 0, ev[5] = {0}, rem[5][5] = {{0}};
+  bool compute_error = false;
+};
+
+}  // namespace apk
+
+struct apk_sim {
+  apk::ParameterInput pin;
+  apk::Mesh mesh;
+  apk::HydroPackage pkg;
+  std::string problem_id;
+  apk::LinearWaveState lw;
+  bool host_only = false;
+  bool fused = true;
+  int rank = 0, nranks = 1;
+  double xmin[3] = {0, 0, 0}, xmax[3] = {1, 1, 1}, dx[3] = {1, 1, 1};
+  // SimTime
+  double time = 0.0, dt = std::numeric_limits<double>::max(), tlim = 1.0;
+  int nlim = -1, ncycle = 0;
+  long long fofc_total = 0;
+  // integrator (Parthenon LowStorageIntegrator)
+  int nstages = 0;
+  double beta[4] = {0}, gam0[4] = {0}, gam1[4] = {0};
+  // device state
+  apk_ctx *ctx = nullptr;
+  apk_stream_t stream = nullptr;
+  apk_allocator alloc{};
+  bool have_alloc = false;
+  apk_comm_ops comm{};
+  bool have_comm = false;
+  int64_t nper = 0;  // doubles per field per block
+  double *d_cons = nullptr, *d_prim = nullptr, *d_u1 = nullptr, *d_flux[3] = {nullptr, nullptr, nullptr};
+  std::vector<double *> send_buf, recv_buf;
+  apk_pack *mu0 = nullptr, *mu1 = nullptr;  // MeshData "base" and "u1"
+  apk_copy_plan *plans[apk::PH_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::string err;
+};

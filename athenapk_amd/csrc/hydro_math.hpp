@@ -1,0 +1,827 @@
+// hydro_math.hpp -- pointwise device arithmetic of the hot path (gfx950, fp64).
+//
+// Reconstruction, Riemann solvers and EOS as wave64-friendly inline device functions.
+// Everything is templated on the option enums so that component permutations and
+// variable counts are compile-time constants: no dynamically indexed register arrays
+// (which would be demoted to scratch memory), no run-time solver dispatch inside kernels.
+//
+// Floating-point contract: operation order and grouping follow the reference expressions
+// (cited per function) so that the -ffp-contract=off build of this library reproduces
+// the CPU oracle bit for bit; the default build lets the compiler contract a*b+c into
+// v_fma_f64 (same expressions, <= few ulp apart, see DESIGN.md "Floating point").
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/apk_amd.h"
+
+namespace apk {
+
+#define APK_DEV __device__ __forceinline__
+
+constexpr double kTiny = 1.0e-20;       // Parthenon TINY_NUMBER
+constexpr double kHlldSmall = 1.0e-8;   // glmmhd_hlld.hpp:36
+constexpr int NHYDRO = 5;
+constexpr int NGLMMHD = 9;
+// natural variable indices (src/main.hpp:19-33)
+enum { IDN = 0, IM1 = 1, IM2 = 2, IM3 = 3, IEN = 4, IB1 = 5, IB2 = 6, IB3 = 7, IPS = 8 };
+enum { IV1 = 1, IV2 = 2, IV3 = 3, IPR = 4 };
+
+APK_DEV double sqr(double x) { return x * x; }
+APK_DEV double min2(double a, double b) { return (b < a) ? b : a; }  // std::min
+APK_DEV double max2(double a, double b) { return (a < b) ? b : a; }  // std::max
+// Parthenon SIGN(x) = (x < 0) ? -1 : 1 ; carried as a bool "is negative"
+APK_DEV bool neg(double x) { return x < 0.0; }
+APK_DEV double with_sign(bool negative, double mag) { return negative ? -mag : mag; }
+
+template <int FLUID>
+constexpr int nvars() {
+  return FLUID == APK_FLUID_EULER ? NHYDRO : NGLMMHD;
+}
+
+// number of ghost layers a reconstruction needs (src/hydro/hydro.cpp:316-339)
+constexpr int recon_nghost(int recon) {
+  return recon == APK_RC_DC ? 1 : ((recon == APK_RC_PPM || recon == APK_RC_WENOZ) ? 3 : 2);
+}
+// stencil half width
+constexpr int recon_halfwidth(int recon) {
+  return recon == APK_RC_DC ? 0 : ((recon == APK_RC_PPM || recon == APK_RC_WENOZ) ? 2 : 1);
+}
+
+// ======================================================================================
+// Reconstruction.  Each function reconstructs cell i and returns
+//   ql = L state at face i+1/2  (the reference's ql_ip1)
+//   qr = R state at face i-1/2  (the reference's qr_i)
+// ======================================================================================
+
+// src/recon/plm_simple.hpp:21-37
+APK_DEV void plm(double qm1, double q0, double qp1, double &ql, double &qr) {
+  const double dl = q0 - qm1;
+  const double dr = qp1 - q0;
+  const double prod = dl * dr;
+  double slope = 0.0;
+  if (prod > 0.0) slope = prod / (dl + dr);
+  ql = q0 + slope;
+  qr = q0 - slope;
+}
+
+// one interface of PPM step 2a (src/recon/ppm_simple.hpp:66-98); the reference states it
+// twice, for (q_im1,q_i) and (q_i,q_ip1).
+APK_DEV double ppm_limit_interface(double qlo, double qhi, double face, double d2lo,
+                                   double d2hi) {
+  constexpr double C2 = 1.25;
+  const double below = face - qlo;
+  const double above = qhi - face;
+  const double d2f = 3.0 * (qlo + qhi - 2.0 * face);
+  const bool s = neg(d2f);
+  double lim = 0.0;
+  if (s == neg(d2lo) && s == neg(d2hi)) {
+    lim = with_sign(s, min2(C2 * fabs(d2lo), min2(C2 * fabs(d2hi), fabs(d2f))));
+  }
+  const double alt = 0.5 * (qlo + qhi) - lim / 6.0;
+  return (below * above < 0.0) ? alt : face;
+}
+
+// src/recon/ppm_simple.hpp:39-162
+APK_DEV void ppm(double qm2, double qm1, double q0, double qp1, double qp2, double &ql,
+                 double &qr) {
+  constexpr double C2 = 1.25;
+  const double da = q0 - qm1;
+  const double db = qp1 - q0;
+  const double dd_m = 0.5 * da + 0.5 * (qm1 - qm2);
+  const double dd_c = 0.5 * db + 0.5 * da;
+  const double dd_p = 0.5 * (qp2 - qp1) + 0.5 * db;
+  double face_m = 0.5 * (qm1 + q0) + (dd_m - dd_c) / 6.0;
+  double face_p = 0.5 * (q0 + qp1) + (dd_c - dd_p) / 6.0;
+
+  const double d2_m = qm2 + q0 - 2.0 * qm1;
+  const double d2_c = qm1 + qp1 - 2.0 * q0;
+  const double d2_p = q0 + qp2 - 2.0 * qp1;
+  face_m = ppm_limit_interface(qm1, q0, face_m, d2_m, d2_c);
+  face_p = ppm_limit_interface(q0, qp1, face_p, d2_c, d2_p);
+
+  const double d2_face = 6.0 * (face_m + face_p - 2.0 * q0);
+  const double dminus = q0 - face_m;
+  const double dplus = face_p - q0;
+  const double ext_a = dminus * dplus;
+  const double ext_b = (qp1 - q0) * (q0 - qm1);
+
+  const bool s = neg(d2_m);
+  double d2lim = 0.0;
+  if (s == neg(d2_c) && s == neg(d2_p) && s == neg(d2_face)) {
+    d2lim = with_sign(neg(d2_face), min2(min2(C2 * fabs(d2_m), C2 * fabs(d2_c)),
+                                         min2(C2 * fabs(d2_p), fabs(d2_face))));
+  }
+  const double scale_lo = max2(fabs(qm1), fabs(qm2));
+  const double scale_hi = max2(max2(fabs(q0), fabs(qp1)), fabs(qp2));
+  double ratio = 0.0;
+  if (fabs(d2_face) > (1.0e-12) * max2(scale_lo, scale_hi)) ratio = d2lim / d2_face;
+
+  const double ext_m = q0 - ratio * dminus;
+  const double ext_p = q0 + ratio * dplus;
+  const double over_m = q0 - 2.0 * dplus;
+  const double over_p = q0 + 2.0 * dminus;
+
+  double r = face_m, l = face_p;
+  if (ext_a <= 0.0 || ext_b <= 0.0) {
+    if (ratio <= (1.0 - (1.0e-12))) {
+      r = ext_m;
+      l = ext_p;
+    }
+  } else {
+    if (fabs(dminus) >= 2.0 * fabs(dplus)) r = over_m;
+    if (fabs(dplus) >= 2.0 * fabs(dminus)) l = over_p;
+  }
+  ql = l;
+  qr = r;
+}
+
+// src/recon/wenoz_simple.hpp:28-81
+APK_DEV void wenoz(double qm2, double qm1, double q0, double qp1, double qp2, double &ql,
+                   double &qr) {
+  constexpr double c0 = 13. / 12., c1 = 0.25;
+  const double b0 = c0 * sqr(qm2 + q0 - 2.0 * qm1) + c1 * sqr(qm2 + 3.0 * q0 - 4.0 * qm1);
+  const double b1 = c0 * sqr(qm1 + qp1 - 2.0 * q0) + c1 * sqr(qm1 - qp1);
+  const double b2 = c0 * sqr(qp2 + q0 - 2.0 * qp1) + c1 * sqr(qp2 + 3.0 * q0 - 4.0 * qp1);
+  constexpr double eps = 1.0e-42;
+  const double tau5 = fabs(b0 - b2);
+  const double i0 = tau5 / (b0 + eps);
+  const double i1 = tau5 / (b1 + eps);
+  const double i2 = tau5 / (b2 + eps);
+
+  double f0 = (2.0 * qm2 - 7.0 * qm1 + 11.0 * q0);
+  double f1 = (-1.0 * qm1 + 5.0 * q0 + 2.0 * qp1);
+  double f2 = (2.0 * q0 + 5.0 * qp1 - qp2);
+  double a0 = 0.1 * (1.0 + sqr(i0));
+  double a1 = 0.6 * (1.0 + sqr(i1));
+  double a2 = 0.3 * (1.0 + sqr(i2));
+  double asum = 6.0 * (a0 + a1 + a2);
+  ql = (f0 * a0 + f1 * a1 + f2 * a2) / asum;
+
+  f0 = (2.0 * qp2 - 7.0 * qp1 + 11.0 * q0);
+  f1 = (-1.0 * qp1 + 5.0 * q0 + 2.0 * qm1);
+  f2 = (2.0 * q0 + 5.0 * qm1 - qm2);
+  a0 = 0.1 * (1.0 + sqr(i2));
+  a1 = 0.6 * (1.0 + sqr(i1));
+  a2 = 0.3 * (1.0 + sqr(i0));
+  asum = 6.0 * (a0 + a1 + a2);
+  qr = (f0 * a0 + f1 * a1 + f2 * a2) / asum;
+}
+
+// src/recon/weno3_simple.hpp:26-63
+APK_DEV void weno3(double qm1, double q0, double qp1, double dx2, double &ql, double &qr) {
+  const double bp = sqr(qp1 - q0);
+  const double bm = sqr(q0 - qm1);
+  const double tau = sqr(qp1 - 2.0 * q0 + qm1);
+  const double ip = tau / (bp + dx2);
+  const double im = tau / (bm + dx2);
+  double f0 = q0 + qp1;
+  double f1 = -qm1 + 3.0 * q0;
+  double a0 = (1.0 + ip) * 2.0 / 3.0;
+  double a1 = (1.0 + im) / 3.0;
+  double asum = 2.0 * (a0 + a1);
+  ql = (a0 * f0 + a1 * f1) / asum;
+  f0 = q0 + qm1;
+  f1 = -qp1 + 3.0 * q0;
+  a0 = (1.0 + im) * 2.0 / 3.0;
+  a1 = (1.0 + ip) / 3.0;
+  asum = 2.0 * (a0 + a1);
+  qr = (a0 * f0 + a1 * f1) / asum;
+}
+
+// src/hydro/diffusion/diffusion.hpp:37-47
+APK_DEV double minmod(double a, double b) {
+  if (a * b > 0) return (a > 0) ? min2(a, b) : max2(a, b);
+  return 0.0;
+}
+
+// src/recon/limo3_simple.hpp:27-58
+APK_DEV double limo3_limiter(double dvp, double dvm, double dx) {
+  constexpr double r = 0.1;
+  constexpr double eps = 10.0 * 2.220446049250313e-16;
+  const double theta = dvm / (dvp + kTiny);
+  const double q = (2.0 + theta) / 3.0;
+  const double phi =
+      max2(0.0, min2(q, max2(-0.5 * theta, min2(2.0 * theta, min2(q, 1.6)))));
+  double eta = r * dx;
+  eta = (dvm * dvm + dvp * dvp) / (eta * eta);
+  if (eta <= 1.0 - eps) return q;
+  if (eta >= 1.0 + eps) return phi;
+  return 0.5 * ((1.0 - (eta - 1.0) / eps) * q + (1.0 + (eta - 1.0) / eps) * phi);
+}
+
+// src/recon/limo3_simple.hpp:65-78
+APK_DEV void limo3(double qm1, double q0, double qp1, double dx, bool ensure_positivity,
+                   double &ql, double &qr) {
+  const double dqp = qp1 - q0;
+  const double dqm = q0 - qm1;
+  double l = q0 + 0.5 * dqp * limo3_limiter(dqp, dqm, dx);
+  double r = q0 - 0.5 * dqm * limo3_limiter(dqm, dqp, dx);
+  if (ensure_positivity && (l <= 0.0 || r <= 0.0)) {
+    const double dmm = minmod(dqp, dqm);
+    l = q0 + 0.5 * dmm;
+    r = q0 - 0.5 * dmm;
+  }
+  ql = l;
+  qr = r;
+}
+
+// Generic entry (the Reconstruct<recon,DIR> wrappers).  `var` is the variable index:
+// LimO3 falls back to minmod for density and pressure only (limo3_simple.hpp:98).
+template <int RECON>
+APK_DEV void reconstruct(double qm2, double qm1, double q0, double qp1, double qp2, double dx,
+                         int var, double &ql, double &qr) {
+  if constexpr (RECON == APK_RC_DC) {
+    ql = q0;
+    qr = q0;
+  } else if constexpr (RECON == APK_RC_PLM) {
+    plm(qm1, q0, qp1, ql, qr);
+  } else if constexpr (RECON == APK_RC_PPM) {
+    ppm(qm2, qm1, q0, qp1, qp2, ql, qr);
+  } else if constexpr (RECON == APK_RC_WENOZ) {
+    wenoz(qm2, qm1, q0, qp1, qp2, ql, qr);
+  } else if constexpr (RECON == APK_RC_WENO3) {
+    double dx2 = dx;
+    dx2 = dx2 * dx2;
+    weno3(qm1, q0, qp1, dx2, ql, qr);
+  } else {
+    limo3(qm1, q0, qp1, dx, (var == IDN || var == IPR), ql, qr);
+  }
+}
+
+// ======================================================================================
+// EOS helpers
+// ======================================================================================
+// src/eos/adiabatic_hydro.hpp:43-45
+APK_DEV double sound_speed(double gamma, double d, double p) { return sqrt(gamma * p / d); }
+// src/eos/adiabatic_glmmhd.hpp:47-54
+APK_DEV double fast_speed(double gamma, double d, double p, double bx, double by, double bz) {
+  const double asq = gamma * p;
+  const double ct2 = by * by + bz * bz;
+  const double qsq = bx * bx + ct2 + asq;
+  const double tmp = bx * bx + ct2 - asq;
+  return sqrt(0.5 * (qsq + sqrt(tmp * tmp + 4.0 * asq * ct2)) / d);
+}
+
+// ======================================================================================
+// Riemann solvers.  States are direction-permuted: w[IV1] is the normal velocity,
+// w[IB1] the normal field.  f[] is returned in the same permuted order.
+// ======================================================================================
+struct Cons1D {  // glmmhd_hlld.hpp:32-34
+  double d, mx, my, mz, e, by, bz;
+};
+
+// src/hydro/rsolvers/hydro_hlle.hpp:40-138
+APK_DEV void hydro_hlle(const double (&wl)[NHYDRO], const double (&wr)[NHYDRO], double gamma,
+                        double (&f)[NHYDRO]) {
+  const double gm1 = gamma - 1.0;
+  const double igm1 = 1.0 / gm1;
+  const double sdl = sqrt(wl[IDN]);
+  const double sdr = sqrt(wr[IDN]);
+  const double isum = 1.0 / (sdl + sdr);
+  const double roe_v1 = (sdl * wl[IV1] + sdr * wr[IV1]) * isum;
+  const double roe_v2 = (sdl * wl[IV2] + sdr * wr[IV2]) * isum;
+  const double roe_v3 = (sdl * wl[IV3] + sdr * wr[IV3]) * isum;
+  const double el = wl[IPR] * igm1 + 0.5 * wl[IDN] * (sqr(wl[IV1]) + sqr(wl[IV2]) + sqr(wl[IV3]));
+  const double er = wr[IPR] * igm1 + 0.5 * wr[IDN] * (sqr(wr[IV1]) + sqr(wr[IV2]) + sqr(wr[IV3]));
+  const double hroe = ((el + wl[IPR]) / sdl + (er + wr[IPR]) / sdr) * isum;
+  const double cl = sound_speed(gamma, wl[IDN], wl[IPR]);
+  const double cr = sound_speed(gamma, wr[IDN], wr[IPR]);
+  const double q = hroe - 0.5 * (sqr(roe_v1) + sqr(roe_v2) + sqr(roe_v3));
+  const double a = (q < 0.0) ? 0.0 : sqrt(gm1 * q);
+  const double al = min2((roe_v1 - a), (wl[IV1] - cl));
+  const double ar = max2((roe_v1 + a), (wr[IV1] + cr));
+  const double bp = ar > 0.0 ? ar : kTiny;
+  const double bm = al < 0.0 ? al : kTiny;  // hydro HLLE: +TINY (:97-98)
+  const double vxl = wl[IV1] - bm;
+  const double vxr = wr[IV1] - bp;
+  double fl[NHYDRO], fr[NHYDRO];
+  fl[IDN] = wl[IDN] * vxl;
+  fr[IDN] = wr[IDN] * vxr;
+  fl[IV1] = wl[IDN] * wl[IV1] * vxl;
+  fr[IV1] = wr[IDN] * wr[IV1] * vxr;
+  fl[IV2] = wl[IDN] * wl[IV2] * vxl;
+  fr[IV2] = wr[IDN] * wr[IV2] * vxr;
+  fl[IV3] = wl[IDN] * wl[IV3] * vxl;
+  fr[IV3] = wr[IDN] * wr[IV3] * vxr;
+  fl[IV1] += wl[IPR];
+  fr[IV1] += wr[IPR];
+  fl[IEN] = el * vxl + wl[IPR] * wl[IV1];
+  fr[IEN] = er * vxr + wr[IPR] * wr[IV1];
+  double tmp = 0.0;
+  if (bp != bm) tmp = 0.5 * (bp + bm) / (bp - bm);
+#pragma unroll
+  for (int n = 0; n < NHYDRO; ++n) f[n] = 0.5 * (fl[n] + fr[n]) + (fl[n] - fr[n]) * tmp;
+}
+
+// src/hydro/rsolvers/hydro_hllc.hpp:32-157
+APK_DEV void hydro_hllc(const double (&wl)[NHYDRO], const double (&wr)[NHYDRO], double gamma,
+                        double (&f)[NHYDRO]) {
+  const double gm1 = gamma - 1.0;
+  const double igm1 = 1.0 / gm1;
+  const double cl = sound_speed(gamma, wl[IDN], wl[IPR]);
+  const double cr = sound_speed(gamma, wr[IDN], wr[IPR]);
+  const double el = wl[IPR] * igm1 + 0.5 * wl[IDN] * (sqr(wl[IV1]) + sqr(wl[IV2]) + sqr(wl[IV3]));
+  const double er = wr[IPR] * igm1 + 0.5 * wr[IDN] * (sqr(wr[IV1]) + sqr(wr[IV2]) + sqr(wr[IV3]));
+  const double rhoa = .5 * (wl[IDN] + wr[IDN]);
+  const double ca = .5 * (cl + cr);
+  const double pmid = .5 * (wl[IPR] + wr[IPR] + (wl[IV1] - wr[IV1]) * rhoa * ca);
+  const double ql = (pmid <= wl[IPR])
+                        ? 1.0
+                        : sqrt(1.0 + (gamma + 1) / (2 * gamma) * (pmid / wl[IPR] - 1.0));
+  const double qr = (pmid <= wr[IPR])
+                        ? 1.0
+                        : sqrt(1.0 + (gamma + 1) / (2 * gamma) * (pmid / wr[IPR] - 1.0));
+  const double al = wl[IV1] - cl * ql;
+  const double ar = wr[IV1] + cr * qr;
+  const double bp = ar > 0.0 ? ar : (kTiny);
+  const double bm = al < 0.0 ? al : -(kTiny);
+  double vxl = wl[IV1] - al;
+  double vxr = wr[IV1] - ar;
+  const double tl = wl[IPR] + vxl * wl[IDN] * wl[IV1];
+  const double tr = wr[IPR] + vxr * wr[IDN] * wr[IV1];
+  const double ml = wl[IDN] * vxl;
+  const double mr = -(wr[IDN] * vxr);
+  const double am = (tl - tr) / (ml + mr);
+  double cp = (ml * tr + mr * tl) / (ml + mr);
+  cp = cp > 0.0 ? cp : 0.0;
+  vxl = wl[IV1] - bm;
+  vxr = wr[IV1] - bp;
+  double fl[NHYDRO], fr[NHYDRO];
+  fl[IDN] = wl[IDN] * vxl;
+  fr[IDN] = wr[IDN] * vxr;
+  fl[IV1] = wl[IDN] * wl[IV1] * vxl + wl[IPR];
+  fr[IV1] = wr[IDN] * wr[IV1] * vxr + wr[IPR];
+  fl[IV2] = wl[IDN] * wl[IV2] * vxl;
+  fr[IV2] = wr[IDN] * wr[IV2] * vxr;
+  fl[IV3] = wl[IDN] * wl[IV3] * vxl;
+  fr[IV3] = wr[IDN] * wr[IV3] * vxr;
+  fl[IEN] = el * vxl + wl[IPR] * wl[IV1];
+  fr[IEN] = er * vxr + wr[IPR] * wr[IV1];
+  double sl, sr, sm;
+  if (am >= 0.0) {
+    sl = am / (am - bm);
+    sr = 0.0;
+    sm = -bm / (am - bm);
+  } else {
+    sl = 0.0;
+    sr = -am / (bp - am);
+    sm = bp / (bp - am);
+  }
+  f[IDN] = sl * fl[IDN] + sr * fr[IDN];
+  f[IV1] = sl * fl[IV1] + sr * fr[IV1] + sm * cp;
+  f[IV2] = sl * fl[IV2] + sr * fr[IV2];
+  f[IV3] = sl * fl[IV3] + sr * fr[IV3];
+  f[IEN] = sl * fl[IEN] + sr * fr[IEN] + sm * cp * am;
+}
+
+// src/hydro/rsolvers/hydro_dc_llf.hpp:43-142 (wl/wr are the first-order states)
+APK_DEV void hydro_llf(const double (&wl)[NHYDRO], const double (&wr)[NHYDRO], double gamma,
+                       double (&f)[NHYDRO]) {
+  const double igm1 = 1.0 / (gamma - 1.0);
+  double qa = wl[IDN] * wl[IV1];
+  double qb = wr[IDN] * wr[IV1];
+  const double fs_d = qa + qb;
+  double fs_mx = qa * wl[IV1] + qb * wr[IV1];
+  const double fs_my = qa * wl[IV2] + qb * wr[IV2];
+  const double fs_mz = qa * wl[IV3] + qb * wr[IV3];
+  const double el = wl[IPR] * igm1 + 0.5 * wl[IDN] * (sqr(wl[IV1]) + sqr(wl[IV2]) + sqr(wl[IV3]));
+  const double er = wr[IPR] * igm1 + 0.5 * wr[IDN] * (sqr(wr[IV1]) + sqr(wr[IV2]) + sqr(wr[IV3]));
+  fs_mx += (wl[IPR] + wr[IPR]);
+  const double fs_e = (el + wl[IPR]) * wl[IV1] + (er + wr[IPR]) * wr[IV1];
+  qa = sound_speed(gamma, wl[IDN], wl[IPR]);
+  qb = sound_speed(gamma, wr[IDN], wr[IPR]);
+  const double a = fmax((fabs(wl[IV1]) + qa), (fabs(wr[IV1]) + qb));
+  const double du_d = a * (wr[IDN] - wl[IDN]);
+  const double du_mx = a * (wr[IDN] * wr[IV1] - wl[IDN] * wl[IV1]);
+  const double du_my = a * (wr[IDN] * wr[IV2] - wl[IDN] * wl[IV2]);
+  const double du_mz = a * (wr[IDN] * wr[IV3] - wl[IDN] * wl[IV3]);
+  const double du_e = a * (er - el);
+  f[IDN] = 0.5 * (fs_d - du_d);
+  f[IV1] = 0.5 * (fs_mx - du_mx);
+  f[IV2] = 0.5 * (fs_my - du_my);
+  f[IV3] = 0.5 * (fs_mz - du_mz);
+  f[IEN] = 0.5 * (fs_e - du_e);
+}
+
+// GLM 2x2 interface state shared by the MHD solvers (glmmhd_hlld.hpp:88-92)
+APK_DEV void glm_interface(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD],
+                           double c_h, double &bxi, double &psii) {
+  bxi = 0.5 * (wl[IB1] + wr[IB1]) - 0.5 / c_h * (wr[IPS] - wl[IPS]);
+  psii = 0.5 * (wl[IPS] + wr[IPS]) - 0.5 * c_h * (wr[IB1] - wl[IB1]);
+}
+
+// src/hydro/rsolvers/glmmhd_hlle.hpp:27-192
+APK_DEV void glmmhd_hlle(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD],
+                         double gamma, double c_h, double (&f)[NGLMMHD]) {
+  const double gm1 = gamma - 1.0;
+  double bxi, psii;
+  glm_interface(wl, wr, c_h, bxi, psii);
+  f[IB1] = psii;
+  f[IPS] = sqr(c_h) * bxi;
+
+  const double sdl = sqrt(wl[IDN]);
+  const double sdr = sqrt(wr[IDN]);
+  const double isum = 1.0 / (sdl + sdr);
+  const double roe_d = sdl * sdr;
+  const double roe_v1 = (sdl * wl[IV1] + sdr * wr[IV1]) * isum;
+  const double roe_v2 = (sdl * wl[IV2] + sdr * wr[IV2]) * isum;
+  const double roe_v3 = (sdl * wl[IV3] + sdr * wr[IV3]) * isum;
+  const double roe_b2 = (sdr * wl[IB2] + sdl * wr[IB2]) * isum;
+  const double roe_b3 = (sdr * wl[IB3] + sdl * wr[IB3]) * isum;
+  const double x = 0.5 * (sqr(wl[IB2] - wr[IB2]) + sqr(wl[IB3] - wr[IB3])) / (sqr(sdl + sdr));
+  const double y = 0.5 * (wl[IDN] + wr[IDN]) / roe_d;
+  const double pbl = 0.5 * (bxi * bxi + sqr(wl[IB2]) + sqr(wl[IB3]));
+  const double pbr = 0.5 * (bxi * bxi + sqr(wr[IB2]) + sqr(wr[IB3]));
+  const double el =
+      wl[IPR] / gm1 + 0.5 * wl[IDN] * (sqr(wl[IV1]) + sqr(wl[IV2]) + sqr(wl[IV3])) + pbl;
+  const double er =
+      wr[IPR] / gm1 + 0.5 * wr[IDN] * (sqr(wr[IV1]) + sqr(wr[IV2]) + sqr(wr[IV3])) + pbr;
+  const double hroe = ((el + wl[IPR] + pbl) / sdl + (er + wr[IPR] + pbr) / sdr) * isum;
+  const double cl = fast_speed(gamma, wl[IDN], wl[IPR], wl[IB1], wl[IB2], wl[IB3]);
+  const double cr = fast_speed(gamma, wr[IDN], wr[IPR], wr[IB1], wr[IB2], wr[IB3]);
+  const double btsq = sqr(roe_b2) + sqr(roe_b3);
+  const double vaxsq = bxi * bxi / roe_d;
+  const double bt_starsq = (gm1 - (gm1 - 1.0) * y) * btsq;
+  const double hp = hroe - (vaxsq + btsq / roe_d);
+  const double vsq = sqr(roe_v1) + sqr(roe_v2) + sqr(roe_v3);
+  const double twid_asq = max2((gm1 * (hp - 0.5 * vsq) - (gm1 - 1.0) * x), 0.0);
+  const double ct2 = bt_starsq / roe_d;
+  const double tsum = vaxsq + ct2 + twid_asq;
+  const double tdif = vaxsq + ct2 - twid_asq;
+  const double cf2_cs2 = sqrt(tdif * tdif + 4.0 * twid_asq * ct2);
+  const double cfsq = 0.5 * (tsum + cf2_cs2);
+  const double a = sqrt(cfsq);
+  const double al = min2((roe_v1 - a), (wl[IV1] - cl));
+  const double ar = max2((roe_v1 + a), (wr[IV1] + cr));
+  const double bp = ar > 0.0 ? ar : 0.0;  // MHD HLLE: 0.0 (:134-135)
+  const double bm = al < 0.0 ? al : 0.0;
+  const double vxl = wl[IV1] - bm;
+  const double vxr = wr[IV1] - bp;
+  double fl[NGLMMHD], fr[NGLMMHD];
+  fl[IDN] = wl[IDN] * vxl;
+  fr[IDN] = wr[IDN] * vxr;
+  fl[IV1] = wl[IDN] * wl[IV1] * vxl + pbl - sqr(bxi);
+  fr[IV1] = wr[IDN] * wr[IV1] * vxr + pbr - sqr(bxi);
+  fl[IV2] = wl[IDN] * wl[IV2] * vxl - bxi * wl[IB2];
+  fr[IV2] = wr[IDN] * wr[IV2] * vxr - bxi * wr[IB2];
+  fl[IV3] = wl[IDN] * wl[IV3] * vxl - bxi * wl[IB3];
+  fr[IV3] = wr[IDN] * wr[IV3] * vxr - bxi * wr[IB3];
+  fl[IV1] += wl[IPR];
+  fr[IV1] += wr[IPR];
+  fl[IEN] = el * vxl + wl[IV1] * (wl[IPR] + pbl - bxi * bxi);
+  fr[IEN] = er * vxr + wr[IV1] * (wr[IPR] + pbr - bxi * bxi);
+  fl[IEN] -= bxi * (wl[IB2] * wl[IV2] + wl[IB3] * wl[IV3]);
+  fr[IEN] -= bxi * (wr[IB2] * wr[IV2] + wr[IB3] * wr[IV3]);
+  fl[IB2] = wl[IB2] * vxl - bxi * wl[IV2];
+  fr[IB2] = wr[IB2] * vxr - bxi * wr[IV2];
+  fl[IB3] = wl[IB3] * vxl - bxi * wl[IV3];
+  fr[IB3] = wr[IB3] * vxr - bxi * wr[IV3];
+  double tmp = 0.0;
+  if (bp != bm) tmp = 0.5 * (bp + bm) / (bp - bm);
+#define APK_HLLE_MIX(n) f[n] = 0.5 * (fl[n] + fr[n]) + (fl[n] - fr[n]) * tmp
+  APK_HLLE_MIX(IDN);
+  APK_HLLE_MIX(IV1);
+  APK_HLLE_MIX(IV2);
+  APK_HLLE_MIX(IV3);
+  APK_HLLE_MIX(IEN);
+  APK_HLLE_MIX(IB2);
+  APK_HLLE_MIX(IB3);
+#undef APK_HLLE_MIX
+}
+
+// ---- HLLD (src/hydro/rsolvers/glmmhd_hlld.hpp:39-396) -----------------------------------
+// conserved 1-D state and magnetic pressure of one side (:95-118)
+APK_DEV void hlld_side_state(const double (&w)[NGLMMHD], double igm1, double bxsq, Cons1D &u,
+                             double &pb) {
+  pb = 0.5 * (bxsq + (sqr(w[IB2]) + sqr(w[IB3])));
+  const double ke = 0.5 * w[IDN] * (sqr(w[IV1]) + (sqr(w[IV2]) + sqr(w[IV3])));
+  u.d = w[IDN];
+  u.mx = w[IV1] * u.d;
+  u.my = w[IV2] * u.d;
+  u.mz = w[IV3] * u.d;
+  u.e = w[IPR] * igm1 + ke + pb;
+  u.by = w[IB2];
+  u.bz = w[IB3];
+}
+// physical flux of one side (:141-155)
+APK_DEV void hlld_side_flux(const double (&w)[NGLMMHD], const Cons1D &u, double pt, double bxi,
+                            double bxsq, Cons1D &fx) {
+  fx.d = u.mx;
+  fx.mx = u.mx * w[IV1] + pt - bxsq;
+  fx.my = u.my * w[IV1] - bxi * u.by;
+  fx.mz = u.mz * w[IV1] - bxi * u.bz;
+  fx.e = w[IV1] * (u.e + pt - bxsq) - bxi * (w[IV2] * u.by + w[IV3] * u.bz);
+  fx.by = u.by * w[IV1] - bxi * w[IV2];
+  fx.bz = u.bz * w[IV1] - bxi * w[IV3];
+}
+// star state of one side, eqns (39),(43)-(48) of M&K (:187-250); ust.d is set by the caller
+APK_DEV void hlld_star_side(const double (&w)[NGLMMHD], const Cons1D &u, double sd, double sdm,
+                            double sdm_inv, double sm, double pt, double ptst, double bxi,
+                            double bxsq, double ust_d_inv, Cons1D &ust, double &vbst) {
+  ust.mx = ust.d * sm;
+  const double denom = u.d * sd * sdm - bxsq;
+  if (fabs(denom) < (kHlldSmall)*ptst) {
+    ust.my = ust.d * w[IV2];
+    ust.mz = ust.d * w[IV3];
+    ust.by = u.by;
+    ust.bz = u.bz;
+  } else {
+    double tmp = bxi * (sd - sdm) / denom;
+    ust.my = ust.d * (w[IV2] - u.by * tmp);
+    ust.mz = ust.d * (w[IV3] - u.bz * tmp);
+    tmp = (u.d * sqr(sd) - bxsq) / denom;
+    ust.by = u.by * tmp;
+    ust.bz = u.bz * tmp;
+  }
+  vbst = (ust.mx * bxi + (ust.my * ust.by + ust.mz * ust.bz)) * ust_d_inv;
+  ust.e = (sd * u.e - pt * w[IV1] + ptst * sm +
+           bxi * (w[IV1] * bxi + (w[IV2] * u.by + w[IV3] * u.bz) - vbst)) *
+          sdm_inv;
+}
+// a <- s * (a - b)  (:297-327)
+APK_DEV void hlld_jump(Cons1D &a, const Cons1D &b, double s) {
+  a.d = s * (a.d - b.d);
+  a.mx = s * (a.mx - b.mx);
+  a.my = s * (a.my - b.my);
+  a.mz = s * (a.mz - b.mz);
+  a.e = s * (a.e - b.e);
+  a.by = s * (a.by - b.by);
+  a.bz = s * (a.bz - b.bz);
+}
+
+APK_DEV void glmmhd_hlld(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD],
+                         double gamma, double c_h, double (&f)[NGLMMHD]) {
+  const double gm1 = gamma - 1.0;
+  const double igm1 = 1.0 / gm1;
+  double bxi, psii;
+  glm_interface(wl, wr, c_h, bxi, psii);
+  f[IB1] = psii;
+  f[IPS] = sqr(c_h) * bxi;
+  const double bxsq = bxi * bxi;
+
+  Cons1D ul, ur, fl, fr;
+  double pbl, pbr;
+  hlld_side_state(wl, igm1, bxsq, ul, pbl);
+  hlld_side_state(wr, igm1, bxsq, ur, pbr);
+
+  // fast speeds from the RECONSTRUCTED normal field, not bxi (:122-125)
+  const double cfl = fast_speed(gamma, wl[IDN], wl[IPR], wl[IB1], wl[IB2], wl[IB3]);
+  const double cfr = fast_speed(gamma, wr[IDN], wr[IPR], wr[IB1], wr[IB2], wr[IB3]);
+  const double s0 = min2(wl[IV1] - cfl, wr[IV1] - cfr);
+  const double s4 = max2(wl[IV1] + cfl, wr[IV1] + cfr);
+
+  const double ptl = wl[IPR] + pbl;
+  const double ptr = wr[IPR] + pbr;
+  hlld_side_flux(wl, ul, ptl, bxi, bxsq, fl);
+  hlld_side_flux(wr, ur, ptr, bxi, bxsq, fr);
+
+  const double sdl = s0 - wl[IV1];
+  const double sdr = s4 - wr[IV1];
+  const double s2 = (sdr * ur.mx - sdl * ul.mx + (ptl - ptr)) / (sdr * ur.d - sdl * ul.d);
+  const double sdml = s0 - s2;
+  const double sdmr = s4 - s2;
+  const double sdml_inv = 1.0 / sdml;
+  const double sdmr_inv = 1.0 / sdmr;
+  Cons1D ulst, urst, uldst, urdst;
+  ulst.d = ul.d * sdl * sdml_inv;
+  urst.d = ur.d * sdr * sdmr_inv;
+  const double ulst_d_inv = 1.0 / ulst.d;
+  const double urst_d_inv = 1.0 / urst.d;
+  const double sqrtdl = sqrt(ulst.d);
+  const double sqrtdr = sqrt(urst.d);
+  const double s1 = s2 - fabs(bxi) / sqrtdl;
+  const double s3 = s2 + fabs(bxi) / sqrtdr;
+
+  const double ptstl = ptl + ul.d * sdl * (s2 - wl[IV1]);
+  const double ptstr = ptr + ur.d * sdr * (s2 - wr[IV1]);
+  const double ptst = 0.5 * (ptstr + ptstl);
+
+  double vbstl, vbstr;
+  hlld_star_side(wl, ul, sdl, sdml, sdml_inv, s2, ptl, ptst, bxi, bxsq, ulst_d_inv, ulst, vbstl);
+  hlld_star_side(wr, ur, sdr, sdmr, sdmr_inv, s2, ptr, ptst, bxi, bxsq, urst_d_inv, urst, vbstr);
+
+  if (0.5 * bxsq < (kHlldSmall)*ptst) {
+    uldst = ulst;
+    urdst = urst;
+  } else {
+    const double invsumd = 1.0 / (sqrtdl + sqrtdr);
+    const double bxsig = (bxi > 0.0 ? 1.0 : -1.0);
+    uldst.d = ulst.d;
+    urdst.d = urst.d;
+    uldst.mx = ulst.mx;
+    urdst.mx = urst.mx;
+    double tmp = invsumd * (sqrtdl * (ulst.my * ulst_d_inv) + sqrtdr * (urst.my * urst_d_inv) +
+                            bxsig * (urst.by - ulst.by));
+    uldst.my = uldst.d * tmp;
+    urdst.my = urdst.d * tmp;
+    tmp = invsumd * (sqrtdl * (ulst.mz * ulst_d_inv) + sqrtdr * (urst.mz * urst_d_inv) +
+                     bxsig * (urst.bz - ulst.bz));
+    uldst.mz = uldst.d * tmp;
+    urdst.mz = urdst.d * tmp;
+    tmp = invsumd * (sqrtdl * urst.by + sqrtdr * ulst.by +
+                     bxsig * sqrtdl * sqrtdr * ((urst.my * urst_d_inv) - (ulst.my * ulst_d_inv)));
+    uldst.by = urdst.by = tmp;
+    tmp = invsumd * (sqrtdl * urst.bz + sqrtdr * ulst.bz +
+                     bxsig * sqrtdl * sqrtdr * ((urst.mz * urst_d_inv) - (ulst.mz * ulst_d_inv)));
+    uldst.bz = urdst.bz = tmp;
+    tmp = s2 * bxi + (uldst.my * uldst.by + uldst.mz * uldst.bz) / uldst.d;
+    uldst.e = ulst.e - sqrtdl * bxsig * (vbstl - tmp);
+    urdst.e = urst.e + sqrtdr * bxsig * (vbstr - tmp);
+  }
+
+  // jumps across the waves in the reference's order (double-star before star)
+  hlld_jump(uldst, ulst, s1);
+  hlld_jump(ulst, ul, s0);
+  hlld_jump(urdst, urst, s3);
+  hlld_jump(urst, ur, s4);
+
+  Cons1D r;
+  if (s0 >= 0.0) {
+    r = fl;
+  } else if (s4 <= 0.0) {
+    r = fr;
+  } else if (s1 >= 0.0) {
+    r.d = fl.d + ulst.d;
+    r.mx = fl.mx + ulst.mx;
+    r.my = fl.my + ulst.my;
+    r.mz = fl.mz + ulst.mz;
+    r.e = fl.e + ulst.e;
+    r.by = fl.by + ulst.by;
+    r.bz = fl.bz + ulst.bz;
+  } else if (s2 >= 0.0) {
+    r.d = fl.d + ulst.d + uldst.d;
+    r.mx = fl.mx + ulst.mx + uldst.mx;
+    r.my = fl.my + ulst.my + uldst.my;
+    r.mz = fl.mz + ulst.mz + uldst.mz;
+    r.e = fl.e + ulst.e + uldst.e;
+    r.by = fl.by + ulst.by + uldst.by;
+    r.bz = fl.bz + ulst.bz + uldst.bz;
+  } else if (s3 > 0.0) {
+    r.d = fr.d + urst.d + urdst.d;
+    r.mx = fr.mx + urst.mx + urdst.mx;
+    r.my = fr.my + urst.my + urdst.my;
+    r.mz = fr.mz + urst.mz + urdst.mz;
+    r.e = fr.e + urst.e + urdst.e;
+    r.by = fr.by + urst.by + urdst.by;
+    r.bz = fr.bz + urst.bz + urdst.bz;
+  } else {
+    r.d = fr.d + urst.d;
+    r.mx = fr.mx + urst.mx;
+    r.my = fr.my + urst.my;
+    r.mz = fr.mz + urst.mz;
+    r.e = fr.e + urst.e;
+    r.by = fr.by + urst.by;
+    r.bz = fr.bz + urst.bz;
+  }
+  f[IDN] = r.d;
+  f[IV1] = r.mx;
+  f[IV2] = r.my;
+  f[IV3] = r.mz;
+  f[IEN] = r.e;
+  f[IB2] = r.by;
+  f[IB3] = r.bz;
+}
+
+// src/hydro/rsolvers/glmmhd_dc_llf.hpp:46-179
+APK_DEV void glmmhd_llf(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD], double gamma,
+                        double c_h, double (&f)[NGLMMHD]) {
+  const double igm1 = 1.0 / (gamma - 1.0);
+  double bxi, psii;
+  glm_interface(wl, wr, c_h, bxi, psii);
+  double qa = wl[IDN] * wl[IV1];
+  double qb = wr[IDN] * wr[IV1];
+  const double qc = 0.5 * (sqr(wl[IB2]) + sqr(wl[IB3]) - sqr(bxi));
+  const double qd = 0.5 * (sqr(wr[IB2]) + sqr(wr[IB3]) - sqr(bxi));
+  const double fs_d = qa + qb;
+  double fs_mx = qa * wl[IV1] + qb * wr[IV1] + qc + qd;
+  const double fs_my = qa * wl[IV2] + qb * wr[IV2] - bxi * (wl[IB2] + wr[IB2]);
+  const double fs_mz = qa * wl[IV3] + qb * wr[IV3] - bxi * (wl[IB3] + wr[IB3]);
+  const double fs_by = wl[IB2] * wl[IV1] + wr[IB2] * wr[IV1] - bxi * (wl[IV2] + wr[IV2]);
+  const double fs_bz = wl[IB3] * wl[IV1] + wr[IB3] * wr[IV1] - bxi * (wl[IV3] + wr[IV3]);
+  const double el = wl[IPR] * igm1 +
+                    0.5 * wl[IDN] * (sqr(wl[IV1]) + sqr(wl[IV2]) + sqr(wl[IV3])) + qc + sqr(bxi);
+  const double er = wr[IPR] * igm1 +
+                    0.5 * wr[IDN] * (sqr(wr[IV1]) + sqr(wr[IV2]) + sqr(wr[IV3])) + qd + sqr(bxi);
+  fs_mx += (wl[IPR] + wr[IPR]);
+  double fs_e = (el + wl[IPR] + qc) * wl[IV1] + (er + wr[IPR] + qd) * wr[IV1];
+  fs_e -= bxi * (wl[IB2] * wl[IV2] + wl[IB3] * wl[IV3]);
+  fs_e -= bxi * (wr[IB2] * wr[IV2] + wr[IB3] * wr[IV3]);
+  qa = fast_speed(gamma, wl[IDN], wl[IPR], wl[IB1], wl[IB2], wl[IB3]);
+  qb = fast_speed(gamma, wr[IDN], wr[IPR], wr[IB1], wr[IB2], wr[IB3]);
+  const double a = fmax((fabs(wl[IV1]) + qa), (fabs(wr[IV1]) + qb));
+  const double du_d = a * (wr[IDN] - wl[IDN]);
+  const double du_mx = a * (wr[IDN] * wr[IV1] - wl[IDN] * wl[IV1]);
+  const double du_my = a * (wr[IDN] * wr[IV2] - wl[IDN] * wl[IV2]);
+  const double du_mz = a * (wr[IDN] * wr[IV3] - wl[IDN] * wl[IV3]);
+  const double du_e = a * (er - el);
+  const double du_by = a * (wr[IB2] - wl[IB2]);
+  const double du_bz = a * (wr[IB3] - wl[IB3]);
+  f[IDN] = 0.5 * (fs_d - du_d);
+  f[IV1] = 0.5 * (fs_mx - du_mx);
+  f[IV2] = 0.5 * (fs_my - du_my);
+  f[IV3] = 0.5 * (fs_mz - du_mz);
+  f[IEN] = 0.5 * (fs_e - du_e);
+  f[IB1] = psii;
+  f[IB2] = 0.5 * (fs_by - du_by);
+  f[IB3] = 0.5 * (fs_bz - du_bz);
+  f[IPS] = sqr(c_h) * bxi;
+}
+
+// compile-time dispatch: Riemann<fluid, rsolver>::Solve for one face
+template <int FLUID, int RS>
+APK_DEV void riemann(const double (&wl)[nvars<FLUID>()], const double (&wr)[nvars<FLUID>()],
+                     double gamma, double c_h, double (&f)[nvars<FLUID>()]) {
+  if constexpr (RS == APK_RS_NONE) {  // rsolvers.hpp:35-63
+#pragma unroll
+    for (int n = 0; n < nvars<FLUID>(); ++n) f[n] = 0.0;
+  } else if constexpr (FLUID == APK_FLUID_EULER) {
+    if constexpr (RS == APK_RS_HLLE) hydro_hlle(wl, wr, gamma, f);
+    else if constexpr (RS == APK_RS_HLLC) hydro_hllc(wl, wr, gamma, f);
+    else hydro_llf(wl, wr, gamma, f);
+  } else {
+    if constexpr (RS == APK_RS_HLLE) glmmhd_hlle(wl, wr, gamma, c_h, f);
+    else if constexpr (RS == APK_RS_HLLD) glmmhd_hlld(wl, wr, gamma, c_h, f);
+    else glmmhd_llf(wl, wr, gamma, c_h, f);
+  }
+}
+
+// Direction permutation (e.g. glmmhd_hlld.hpp:45-49): natural index of the permuted slot.
+// DIR = 1,2,3 ; slot in {IDN,IV1,IV2,IV3,IPR/IEN,IB1,IB2,IB3,IPS}
+template <int DIR>
+constexpr int perm(int slot) {
+  constexpr int vx = DIR, vy = IV1 + ((DIR - IV1) + 1) % 3, vz = IV1 + ((DIR - IV1) + 2) % 3;
+  return slot == IV1   ? vx
+         : slot == IV2 ? vy
+         : slot == IV3 ? vz
+         : slot == IB1 ? vx - 1 + NHYDRO
+         : slot == IB2 ? vy - 1 + NHYDRO
+         : slot == IB3 ? vz - 1 + NHYDRO
+                       : slot;
+}
+
+// ======================================================================================
+// cons -> prim for one cell (src/eos/adiabatic_hydro.hpp:52-142, adiabatic_glmmhd.hpp:62-167)
+// u/w hold the NH hydro/MHD variables; returns APK_FLAG_* bits.  u may be modified.
+// ======================================================================================
+template <int FLUID>
+APK_DEV unsigned cons_to_prim_cell(const apk_eos &eos, double (&u)[nvars<FLUID>()],
+                                   double (&w)[nvars<FLUID>()], double &di_out) {
+  constexpr bool mhd = (FLUID == APK_FLUID_GLMMHD);
+  unsigned flags = 0;
+  const double gm1 = eos.gamma - 1.0;
+  if (!(u[IDN] > 0.0 || eos.dfloor > 0.0)) flags |= APK_FLAG_NEG_DENSITY;
+  u[IDN] = (u[IDN] > eos.dfloor) ? u[IDN] : eos.dfloor;
+  w[IDN] = u[IDN];
+  const double di = 1.0 / u[IDN];
+  di_out = di;
+  w[IV1] = u[IM1] * di;
+  w[IV2] = u[IM2] * di;
+  w[IV3] = u[IM3] * di;
+  double e_B = 0.0;
+  double e_k = 0.5 * di * (sqr(u[IM1]) + sqr(u[IM2]) + sqr(u[IM3]));
+  if constexpr (mhd) {
+    w[IB1] = u[IB1];
+    w[IB2] = u[IB2];
+    w[IB3] = u[IB3];
+    w[IPS] = u[IPS];
+    e_B = 0.5 * (sqr(u[IB1]) + sqr(u[IB2]) + sqr(u[IB3]));
+    w[IPR] = gm1 * (u[IEN] - e_k - e_B);
+  } else {
+    w[IPR] = gm1 * (u[IEN] - e_k);
+  }
+  const double v2 = sqr(w[IV1]) + sqr(w[IV2]) + sqr(w[IV3]);
+  if (v2 > sqr(eos.vceil)) {
+    const double v = sqrt(v2);
+    w[IV1] *= eos.vceil / v;
+    w[IV2] *= eos.vceil / v;
+    w[IV3] *= eos.vceil / v;
+    u[IM1] *= eos.vceil / v;
+    u[IM2] *= eos.vceil / v;
+    u[IM3] *= eos.vceil / v;
+    const double e_k_new = 0.5 * u[IDN] * sqr(eos.vceil);
+    u[IEN] -= e_k - e_k_new;
+    e_k = e_k_new;
+  }
+  if (!(w[IPR] > 0.0 || eos.pfloor > 0.0 || eos.efloor > 0.0)) flags |= APK_FLAG_NEG_PRESSURE;
+  if ((eos.pfloor > 0.0) && (w[IPR] < eos.pfloor)) {
+    if constexpr (mhd) u[IEN] = (eos.pfloor / gm1) + e_k + e_B;
+    else u[IEN] = (eos.pfloor / gm1) + e_k;
+    w[IPR] = eos.pfloor;
+  }
+  const double eff_floor = gm1 * u[IDN] * eos.efloor;
+  if (w[IPR] < eff_floor) {
+    if constexpr (mhd) u[IEN] = (u[IDN] * eos.efloor) + e_k + e_B;
+    else u[IEN] = (u[IDN] * eos.efloor) + e_k;
+    w[IPR] = eff_floor;
+  }
+  const double eff_ceil = gm1 * u[IDN] * eos.eceil;
+  if (w[IPR] > eff_ceil) {
+    if constexpr (mhd) u[IEN] = (u[IDN] * eos.eceil) + e_k + e_B;
+    else u[IEN] = (u[IDN] * eos.eceil) + e_k;
+    w[IPR] = eff_ceil;
+  }
+  return flags;
+}
+
+}  // namespace apk

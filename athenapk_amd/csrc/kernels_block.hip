@@ -1,0 +1,428 @@
+// kernels_block.hip -- the streaming kernels either side of the flux sweeps:
+// flux-divergence/RK update, Dedner source, cons->prim, dt and history reductions,
+// first-order flux correction, strided box copies (ghost zones).
+// All are HBM-bound: one lane per cell along x1 (coalesced 512 B per wave per variable),
+// variables looped inside the lane so each cell's nvar doubles stream once.
+#include "apk_internal.hpp"
+#include "hydro_math.hpp"
+
+namespace apk {
+
+namespace {
+
+struct CellIdx {
+  int b, k, j, i;
+  bool ok;
+};
+
+// interior cell of this lane; grid = (ceil(nx1/64), ceil(nx2/4), nx3*nblocks), block (64,4)
+APK_DEV CellIdx interior_cell(const PackView &pv) {
+  CellIdx c;
+  c.i = pv.is + blockIdx.x * 64 + threadIdx.x;
+  c.j = pv.js + blockIdx.y * 4 + threadIdx.y;
+  c.b = blockIdx.z / pv.nx3;
+  c.k = pv.ks + blockIdx.z % pv.nx3;
+  c.ok = (c.i <= pv.ie) && (c.j <= pv.je);
+  return c;
+}
+
+inline dim3 interior_grid(const PackView &pv) {
+  return dim3((pv.nx1 + 63) / 64, (pv.nx2 + 3) / 4, pv.nx3 * pv.nblocks);
+}
+
+// Parthenon Update::FluxDivHelper (un-vendored):
+// du = A1 F1(i+1) - A1 F1(i) [+ A2 ..][+ A3 ..];  return -du / V
+APK_DEV double flux_div(const PackView &pv, const apk_block_desc &blk, int64_t idx,
+                        const double (&area)[3], double vol) {
+  const double *f1 = blk.flux[0] + idx;
+  double du = (area[0] * f1[1] - area[0] * f1[0]);
+  if (pv.ndim >= 2) {
+    const double *f2 = blk.flux[1] + idx;
+    du += (area[1] * f2[pv.sj] - area[1] * f2[0]);
+  }
+  if (pv.ndim == 3) {
+    const double *f3 = blk.flux[2] + idx;
+    du += (area[2] * f3[pv.sk] - area[2] * f3[0]);
+  }
+  return -du / vol;
+}
+
+APK_DEV void block_areas(const apk_block_desc &blk, double (&area)[3], double &vol) {
+  area[0] = blk.dx[1] * blk.dx[2];
+  area[1] = blk.dx[0] * blk.dx[2];
+  area[2] = blk.dx[0] * blk.dx[1];
+  vol = blk.dx[0] * blk.dx[1] * blk.dx[2];
+}
+
+// ---- UpdateWithFluxDivergence (call site src/hydro/hydro_driver.cpp:534-537) ----------
+__global__ void __launch_bounds__(256)
+update_flux_div_kernel(PackView u0, PackView u1, double gam0, double gam1, double beta_dt) {
+  const CellIdx c = interior_cell(u0);
+  if (!c.ok) return;
+  const apk_block_desc b0 = u0.blocks[c.b];
+  const double *c1 = u1.blocks[c.b].cons;
+  double area[3], vol;
+  block_areas(b0, area, vol);
+  const int64_t cell = c.k * u0.sk + c.j * u0.sj + c.i;
+  for (int n = 0; n < u0.nvar; ++n) {
+    const int64_t idx = n * u0.sn + cell;
+    b0.cons[idx] =
+        gam0 * b0.cons[idx] + gam1 * c1[idx] + beta_dt * flux_div(u0, b0, idx, area, vol);
+  }
+}
+
+// ---- DednerSource (src/hydro/glmmhd/dedner_source.cpp:17-75) ----------------------------
+template <bool EXTENDED>
+__global__ void __launch_bounds__(256)
+dedner_kernel(PackView pv, double coeff, double beta_dt) {
+  const CellIdx c = interior_cell(pv);
+  if (!c.ok) return;
+  const apk_block_desc blk = pv.blocks[c.b];
+  const int64_t cell = c.k * pv.sk + c.j * pv.sj + c.i;
+  double *u = blk.cons + cell;
+  if constexpr (EXTENDED) {
+    const double *w = blk.prim + cell;
+    const int64_t so = (pv.ndim >= 2) ? pv.sj : 0;
+    const int64_t ko = (pv.ndim >= 3) ? pv.sk : 0;  // k_offset = 0 in 2-D (:34-40)
+    const double *b1 = w + IB1 * pv.sn, *b2 = w + IB2 * pv.sn, *b3 = w + IB3 * pv.sn;
+    const double *ps = w + IPS * pv.sn;
+    const double divB = 0.5 * ((b1[1] - b1[-1]) / blk.dx[0] + (b2[so] - b2[-so]) / blk.dx[1] +
+                               (b3[ko] - b3[-ko]) / blk.dx[2]);
+    u[IM1 * pv.sn] -= beta_dt * divB * b1[0];
+    u[IM2 * pv.sn] -= beta_dt * divB * b2[0];
+    u[IM3 * pv.sn] -= beta_dt * divB * b3[0];
+    u[IEN * pv.sn] -= 0.5 * beta_dt *
+                      (b1[0] * (ps[1] - ps[-1]) / blk.dx[0] +
+                       b2[0] * (ps[so] - ps[-so]) / blk.dx[1] +
+                       b3[0] * (ps[ko] - ps[-ko]) / blk.dx[2]);
+  }
+  u[IPS * pv.sn] *= coeff;
+}
+
+// ---- ConservedToPrimitive over the ENTIRE block (src/eos/adiabatic_hydro.cpp:33-55) -----
+template <int FLUID>
+__global__ void __launch_bounds__(256)
+cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags) {
+  constexpr int NV = nvars<FLUID>();
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int j = blockIdx.y * 4 + threadIdx.y;
+  const int b = blockIdx.z / pv.nk;
+  const int k = blockIdx.z % pv.nk;
+  if (i >= pv.ni || j >= pv.nj) return;
+  const apk_block_desc blk = pv.blocks[b];
+  const int64_t cell = k * pv.sk + j * pv.sj + i;
+  double u[NV], w[NV];
+#pragma unroll
+  for (int n = 0; n < NV; ++n) u[n] = blk.cons[n * pv.sn + cell];
+  const double d_in = u[IDN], m1 = u[IM1], m2 = u[IM2], m3 = u[IM3], e_in = u[IEN];
+  double di;
+  const unsigned fl = cons_to_prim_cell<FLUID>(eos, u, w, di);
+  if (fl) atomicOr(flags, fl);
+  // floors / ceilings write the conserved state back (adiabatic_hydro.hpp:81,92-136);
+  // only touched entries are stored so the common no-floor case stays read-only on cons.
+  if (u[IDN] != d_in) blk.cons[IDN * pv.sn + cell] = u[IDN];
+  if (u[IM1] != m1) blk.cons[IM1 * pv.sn + cell] = u[IM1];
+  if (u[IM2] != m2) blk.cons[IM2 * pv.sn + cell] = u[IM2];
+  if (u[IM3] != m3) blk.cons[IM3 * pv.sn + cell] = u[IM3];
+  if (u[IEN] != e_in) blk.cons[IEN * pv.sn + cell] = u[IEN];
+#pragma unroll
+  for (int n = 0; n < NV; ++n) blk.prim[n * pv.sn + cell] = w[n];
+  for (int n = NV; n < pv.nvar; ++n)  // passive scalars (:139-141)
+    blk.prim[n * pv.sn + cell] = blk.cons[n * pv.sn + cell] * di;
+}
+
+// ---- wave/workgroup reductions -------------------------------------------------------------
+APK_DEV double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
+  return v;
+}
+APK_DEV double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// ---- EstimateHyperbolicTimestep (src/hydro/hydro.cpp:828-896) ----------------------------
+// positive doubles order like their bit patterns, so the global min is one 64-bit atomicMin
+template <int FLUID>
+__global__ void __launch_bounds__(256)
+min_dt_kernel(PackView pv, double gamma, unsigned long long *min_bits) {
+  const CellIdx c = interior_cell(pv);
+  double min_dt = 1.7976931348623157e308;
+  if (c.ok) {
+    const apk_block_desc blk = pv.blocks[c.b];
+    const double *w = blk.prim + c.k * pv.sk + c.j * pv.sj + c.i;
+    const double d = w[IDN * pv.sn], v1 = w[IV1 * pv.sn], v2 = w[IV2 * pv.sn],
+                 v3 = w[IV3 * pv.sn], p = w[IPR * pv.sn];
+    double lx, ly = 0.0, lz = 0.0;
+    if constexpr (FLUID == APK_FLUID_EULER) {
+      lx = sound_speed(gamma, d, p);
+      ly = lx;
+      lz = lx;
+    } else {
+      const double b1 = w[IB1 * pv.sn], b2 = w[IB2 * pv.sn], b3 = w[IB3 * pv.sn];
+      lx = fast_speed(gamma, d, p, b1, b2, b3);
+      if (pv.ndim > 1) ly = fast_speed(gamma, d, p, b2, b3, b1);
+      if (pv.ndim > 2) lz = fast_speed(gamma, d, p, b3, b1, b2);
+    }
+    min_dt = fmin(min_dt, blk.dx[0] / (fabs(v1) + lx));
+    if (pv.ndim > 1) min_dt = fmin(min_dt, blk.dx[1] / (fabs(v2) + ly));
+    if (pv.ndim > 2) min_dt = fmin(min_dt, blk.dx[2] / (fabs(v3) + lz));
+  }
+  min_dt = wave_min(min_dt);
+  __shared__ double part[4];
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  if ((tid & 63) == 0) part[tid >> 6] = min_dt;
+  __syncthreads();
+  if (tid == 0) {
+    const double m = fmin(fmin(part[0], part[1]), fmin(part[2], part[3]));
+    atomicMin(min_bits, (unsigned long long)__double_as_longlong(m));
+  }
+}
+
+// ---- HydroHst (src/hydro/hydro.cpp:145-208): per-workgroup partials, fixed-order final ----
+template <int FLUID>
+__global__ void __launch_bounds__(256) history_kernel(PackView pv, double *partial) {
+  const CellIdx c = interior_cell(pv);
+  double h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c.ok) {
+    const apk_block_desc blk = pv.blocks[c.b];
+    const double vol = blk.dx[0] * blk.dx[1] * blk.dx[2];
+    const double *u = blk.cons + c.k * pv.sk + c.j * pv.sj + c.i;
+    const double d = u[IDN * pv.sn], m1 = u[IM1 * pv.sn], m2 = u[IM2 * pv.sn],
+                 m3 = u[IM3 * pv.sn];
+    h[0] = d * vol;
+    h[1] = m1 * vol;
+    h[2] = m2 * vol;
+    h[3] = m3 * vol;
+    h[4] = 0.5 / d * (sqr(m1) + sqr(m2) + sqr(m3)) * vol;
+    h[5] = u[IEN * pv.sn] * vol;
+    if constexpr (FLUID == APK_FLUID_GLMMHD) {
+      const double *b1 = u + IB1 * pv.sn, *b2 = u + IB2 * pv.sn, *b3 = u + IB3 * pv.sn;
+      h[6] = 0.5 * (sqr(b1[0]) + sqr(b2[0]) + sqr(b3[0])) * vol;
+      const int64_t so = (pv.ndim >= 2) ? pv.sj : 0;
+      double divb = (b1[1] - b1[-1]) / blk.dx[0] + (b2[so] - b2[-so]) / blk.dx[1];
+      if (pv.ndim == 3) divb += (b3[pv.sk] - b3[-pv.sk]) / blk.dx[2];
+      const double abs_b = sqrt(sqr(b1[0]) + sqr(b2[0]) + sqr(b3[0]));
+      h[7] = (abs_b != 0)
+                 ? 0.5 * (sqrt(sqr(blk.dx[0]) + sqr(blk.dx[1]) + sqr(blk.dx[2]))) * fabs(divb) /
+                       abs_b * vol
+                 : 0;
+    }
+  }
+  __shared__ double part[4][8];
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const double s = wave_sum(h[q]);
+    if ((tid & 63) == 0) part[tid >> 6][q] = s;
+  }
+  __syncthreads();
+  if (tid < 8) {
+    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    partial[(int64_t)wg * 8 + tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+  }
+}
+
+__global__ void __launch_bounds__(256) history_final_kernel(const double *partial, int nwg,
+                                                            double *out8) {
+  // 8 quantities x 32 lanes each; fixed summation order => run-to-run deterministic
+  const int q = threadIdx.x / 32, lane = threadIdx.x % 32;
+  double s = 0.0;
+  for (int w = lane; w < nwg; w += 32) s += partial[(int64_t)w * 8 + q];
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) s += __shfl_down(s, off, 32);
+  if (lane == 0) out8[q] = s;
+}
+
+// ---- FirstOrderFluxCorrect (src/hydro/hydro.cpp:1223-1342), two-phase schedule -------------
+template <int FLUID>
+__global__ void __launch_bounds__(256)
+fofc_mark_kernel(PackView u0, PackView u1, double gam0, double gam1, double beta_dt,
+                 int attempt, unsigned char *mark, unsigned long long *count) {
+  constexpr int NV = nvars<FLUID>();
+  const CellIdx c = interior_cell(u0);
+  bool bad = false;
+  if (c.ok) {
+    const apk_block_desc b0 = u0.blocks[c.b];
+    const double *c1 = u1.blocks[c.b].cons;
+    double area[3], vol;
+    block_areas(b0, area, vol);
+    const int64_t cell = c.k * u0.sk + c.j * u0.sj + c.i;
+    double nc[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int64_t idx = n * u0.sn + cell;
+      nc[n] = gam0 * b0.cons[idx] + gam1 * c1[idx] + beta_dt * flux_div(u0, b0, idx, area, vol);
+    }
+    double new_p = nc[IEN] - 0.5 * (sqr(nc[IM1]) + sqr(nc[IM2]) + sqr(nc[IM3])) / nc[IDN];
+    if constexpr (FLUID == APK_FLUID_GLMMHD)
+      new_p -= 0.5 * (sqr(nc[IB1]) + sqr(nc[IB2]) + sqr(nc[IB3]));
+    bad = !(nc[IDN] > 0.0 && new_p > 0.0);
+    if (bad && attempt > 2 && nc[IDN] > 0.0 && new_p < 0.0) bad = false;  // rely on the floor
+    mark[(int64_t)c.b * u0.sn + cell] = bad ? 1 : 0;
+  }
+  const unsigned long long m = __ballot(bad);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+}
+
+// DC + LLF flux of one face straight from prim (hydro_dc_llf.hpp:43-142,
+// glmmhd_dc_llf.hpp:46-179), including passive scalars
+template <int FLUID, int DIR>
+APK_DEV void llf_face(const PackView &pv, const apk_block_desc &blk, int64_t cell, double gamma,
+                      double c_h) {
+  constexpr int NV = nvars<FLUID>();
+  const int64_t st = (DIR == 1) ? 1 : ((DIR == 2) ? pv.sj : pv.sk);
+  const double *p = blk.prim + cell;
+  double wl[NV], wr[NV], f[NV];
+#pragma unroll
+  for (int s = 0; s < NV; ++s) {
+    wl[s] = p[perm<DIR>(s) * pv.sn - st];
+    wr[s] = p[perm<DIR>(s) * pv.sn];
+  }
+  riemann<FLUID, APK_RS_LLF>(wl, wr, gamma, c_h, f);
+  double *fo = blk.flux[DIR - 1] + cell;
+#pragma unroll
+  for (int s = 0; s < NV; ++s) fo[perm<DIR>(s) * pv.sn] = f[s];
+  for (int n = NV; n < pv.nvar; ++n)
+    fo[n * pv.sn] = (f[IDN] >= 0.0) ? f[IDN] * p[n * pv.sn - st] : f[IDN] * p[n * pv.sn];
+}
+
+template <int FLUID>
+__global__ void __launch_bounds__(256)
+fofc_fix_kernel(PackView pv, double gamma, double c_h, const unsigned char *mark) {
+  const CellIdx c = interior_cell(pv);
+  if (!c.ok) return;
+  const int64_t cell = c.k * pv.sk + c.j * pv.sj + c.i;
+  if (!mark[(int64_t)c.b * pv.sn + cell]) return;
+  const apk_block_desc blk = pv.blocks[c.b];
+  llf_face<FLUID, 1>(pv, blk, cell, gamma, c_h);
+  llf_face<FLUID, 1>(pv, blk, cell + 1, gamma, c_h);
+  if (pv.ndim >= 2) {
+    llf_face<FLUID, 2>(pv, blk, cell, gamma, c_h);
+    llf_face<FLUID, 2>(pv, blk, cell + pv.sj, gamma, c_h);
+  }
+  if (pv.ndim >= 3) {
+    llf_face<FLUID, 3>(pv, blk, cell, gamma, c_h);
+    llf_face<FLUID, 3>(pv, blk, cell + pv.sk, gamma, c_h);
+  }
+}
+
+// ---- strided box copies (ghost exchange / message packing / physical boundaries) -----------
+__global__ void __launch_bounds__(256)
+copy_regions_kernel(const apk_copy_region *regions) {
+  const apk_copy_region r = regions[blockIdx.y];
+  const int64_t plane = (int64_t)r.ext[0] * r.ext[1];
+  const int64_t cells = plane * r.ext[2];
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < cells;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(t / plane);
+    const int64_t rem = t - (int64_t)k * plane;
+    const int j = (int)(rem / r.ext[0]);
+    const int i = (int)(rem - (int64_t)j * r.ext[0]);
+    const int64_t so = i * r.src_stride[0] + j * r.src_stride[1] + k * r.src_stride[2];
+    const int64_t dof = i * r.dst_stride[0] + j * r.dst_stride[1] + k * r.dst_stride[2];
+    for (int v = 0; v < r.nvar; ++v) {
+      const double x = r.src[so + v * r.src_stride[3]];
+      r.dst[dof + v * r.dst_stride[3]] = (v == r.flip_var) ? -x : x;
+    }
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+int launch_update_flux_div(const PackView &u0, const PackView &u1, double gam0, double gam1,
+                           double beta_dt, hipStream_t s) {
+  hipLaunchKernelGGL(update_flux_div_kernel, interior_grid(u0), dim3(64, 4, 1), 0, s, u0, u1,
+                     gam0, gam1, beta_dt);
+  return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
+}
+
+int launch_dedner(const PackView &pv, int extended, double coeff, double beta_dt,
+                  hipStream_t s) {
+  if (extended)
+    hipLaunchKernelGGL(dedner_kernel<true>, interior_grid(pv), dim3(64, 4, 1), 0, s, pv, coeff,
+                       beta_dt);
+  else
+    hipLaunchKernelGGL(dedner_kernel<false>, interior_grid(pv), dim3(64, 4, 1), 0, s, pv, coeff,
+                       beta_dt);
+  return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
+}
+
+int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsigned *d_flags,
+                        hipStream_t s) {
+  dim3 grid((pv.ni + 63) / 64, (pv.nj + 3) / 4, pv.nk * pv.nblocks);
+  if (fluid == APK_FLUID_EULER)
+    hipLaunchKernelGGL(cons_to_prim_kernel<APK_FLUID_EULER>, grid, dim3(64, 4, 1), 0, s, pv, eos,
+                       d_flags);
+  else
+    hipLaunchKernelGGL(cons_to_prim_kernel<APK_FLUID_GLMMHD>, grid, dim3(64, 4, 1), 0, s, pv, eos,
+                       d_flags);
+  return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
+}
+
+int launch_min_dt(const PackView &pv, int fluid, double gamma, unsigned long long *d_min_bits,
+                  hipStream_t s) {
+  if (fluid == APK_FLUID_EULER)
+    hipLaunchKernelGGL(min_dt_kernel<APK_FLUID_EULER>, interior_grid(pv), dim3(64, 4, 1), 0, s, pv,
+                       gamma, d_min_bits);
+  else
+    hipLaunchKernelGGL(min_dt_kernel<APK_FLUID_GLMMHD>, interior_grid(pv), dim3(64, 4, 1), 0, s,
+                       pv, gamma, d_min_bits);
+  return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
+}
+
+int launch_history(const PackView &pv, int fluid, double *d_partial, int *nwg_out, double *d_out8,
+                   hipStream_t s) {
+  const dim3 grid = interior_grid(pv);
+  const int nwg = grid.x * grid.y * grid.z;
+  if (nwg_out) *nwg_out = nwg;
+  if (!d_partial) return APK_OK;  // size query
+  if (fluid == APK_FLUID_EULER)
+    hipLaunchKernelGGL(history_kernel<APK_FLUID_EULER>, grid, dim3(64, 4, 1), 0, s, pv, d_partial);
+  else
+    hipLaunchKernelGGL(history_kernel<APK_FLUID_GLMMHD>, grid, dim3(64, 4, 1), 0, s, pv,
+                       d_partial);
+  hipLaunchKernelGGL(history_final_kernel, dim3(1), dim3(256), 0, s, d_partial, nwg, d_out8);
+  return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
+}
+
+int launch_fofc_mark(const PackView &u0, const PackView &u1, int fluid, double gam0, double gam1,
+                     double beta_dt, int attempt, unsigned char *d_mark,
+                     unsigned long long *d_count, hipStream_t s) {
+  if (fluid == APK_FLUID_EULER)
+    hipLaunchKernelGGL(fofc_mark_kernel<APK_FLUID_EULER>, interior_grid(u0), dim3(64, 4, 1), 0, s,
+                       u0, u1, gam0, gam1, beta_dt, attempt, d_mark, d_count);
+  else
+    hipLaunchKernelGGL(fofc_mark_kernel<APK_FLUID_GLMMHD>, interior_grid(u0), dim3(64, 4, 1), 0, s,
+                       u0, u1, gam0, gam1, beta_dt, attempt, d_mark, d_count);
+  return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
+}
+
+int launch_fofc_fix(const PackView &u0, int fluid, double gamma, double c_h,
+                    const unsigned char *d_mark, hipStream_t s) {
+  if (fluid == APK_FLUID_EULER)
+    hipLaunchKernelGGL(fofc_fix_kernel<APK_FLUID_EULER>, interior_grid(u0), dim3(64, 4, 1), 0, s,
+                       u0, gamma, c_h, d_mark);
+  else
+    hipLaunchKernelGGL(fofc_fix_kernel<APK_FLUID_GLMMHD>, interior_grid(u0), dim3(64, 4, 1), 0, s,
+                       u0, gamma, c_h, d_mark);
+  return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
+}
+
+int launch_copy_regions(const apk_copy_region *d_regions, int n, int64_t max_cells, hipStream_t s) {
+  if (n <= 0) return APK_OK;
+  int gx = (int)((max_cells + 255) / 256);
+  if (gx < 1) gx = 1;
+  if (gx > 64) gx = 64;
+  // gridDim.y is limited to 65535
+  for (int off = 0; off < n; off += 65535) {
+    const int m = (n - off > 65535) ? 65535 : (n - off);
+    hipLaunchKernelGGL(copy_regions_kernel, dim3(gx, m, 1), dim3(256), 0, s, d_regions + off);
+  }
+  return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
+}
+
+}  // namespace apk

@@ -1,0 +1,275 @@
+"""Python handle on the native host driver (include/apk_host.h) plus the two pieces of
+plumbing torch provides: device memory for the fields / message buffers and
+torch.distributed (backend "nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests) for the
+per-stage halo exchange and the tiny min/sum all-reduces (src/hydro/hydro.cpp:122-128).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+
+class HaloExchanger:
+    """One grouped send/recv per peer rank per stage (ncclGroupStart .. ncclSend/ncclRecv ..
+    ncclGroupEnd under the hood).  Works on whatever device the buffers live on, so the same
+    code runs over RCCL on GPUs and over gloo on CPU in the tests."""
+
+    def __init__(self, peers, group=None):
+        # peers: list of (rank, send_tensor, recv_tensor)
+        self.peers = list(peers)
+        self.group = group
+
+    def exchange(self):
+        import torch.distributed as dist
+        if not self.peers:
+            return
+        ops = []
+        for rank, send_t, recv_t in self.peers:
+            ops.append(dist.P2POp(dist.irecv, recv_t, rank, group=self.group))
+            ops.append(dist.P2POp(dist.isend, send_t, rank, group=self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+def _allreduce(vals_ptr, n, op, device, group=None):
+    import torch.distributed as dist
+    a = np.ctypeslib.as_array(vals_ptr, shape=(n,))
+    t = torch.from_numpy(a.copy()).to(device)
+    dist.all_reduce(t, op=op, group=group)
+    a[:] = t.cpu().numpy()
+
+
+class Simulation:
+    """apk_sim: deck + overrides -> mesh partition, packs, ghost plans, stage loop (C++)."""
+
+    def __init__(self, deck, overrides=(), rank=0, nranks=1, strict=False, use_torch_alloc=True,
+                 group=None):
+        self.lib = L.load(strict)
+        self.rank, self.nranks = rank, nranks
+        self._tensors = {}   # ptr -> tensor (keeps allocations alive)
+        self._by_tag = {}
+        self._group = group
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self._dev = dev
+
+        def _alloc(user, tag, nbytes):
+            t = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=dev)
+            self._tensors[t.data_ptr()] = t
+            self._by_tag[tag.decode()] = t
+            return t.data_ptr()
+
+        def _release(user, ptr):
+            self._tensors.pop(ptr, None)
+
+        self._alloc_cb = L.ALLOC_FN(_alloc)
+        self._release_cb = L.RELEASE_FN(_release)
+        allocator = L.Allocator(None, self._alloc_cb, self._release_cb)
+
+        self._halo = None
+
+        def _exchange(user):
+            try:
+                self._halo.exchange()
+                return 0
+            except Exception as e:  # surfaced as APK_ERR_DEVICE by the driver
+                self._cb_error = e
+                return 1
+
+        def _amin(user, vals, n):
+            try:
+                import torch.distributed as dist
+                _allreduce(vals, n, dist.ReduceOp.MIN, dev, group)
+                return 0
+            except Exception as e:
+                self._cb_error = e
+                return 1
+
+        def _asum(user, vals, n):
+            try:
+                import torch.distributed as dist
+                _allreduce(vals, n, dist.ReduceOp.SUM, dev, group)
+                return 0
+            except Exception as e:
+                self._cb_error = e
+                return 1
+
+        self._cb_error = None
+        self._ex_cb, self._amin_cb, self._asum_cb = L.EXCHANGE_FN(_exchange), L.ALLREDUCE_FN(_amin), L.ALLREDUCE_FN(_asum)
+        comm = L.CommOps(None, self._ex_cb, self._amin_cb, self._asum_cb)
+
+        ov = (C.c_char_p * max(1, len(overrides)))(*[o.encode() for o in overrides])
+        err = C.create_string_buffer(1024)
+        h = C.c_void_p()
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = self.lib.apk_sim_create(deck.encode(), ov, len(overrides), rank, nranks,
+                                     C.byref(allocator) if use_torch_alloc else None,
+                                     C.byref(comm) if nranks > 1 else None, stream, C.byref(h), err, len(err))
+        if rc != L.APK_OK:
+            raise L.ApkError(rc, err.value.decode())
+        self.h = h
+        self.info = L.SimInfo()
+        self._check(self.lib.apk_sim_get_info(self.h, C.byref(self.info)))
+        # wire the per-peer message buffers into the exchanger
+        peers = []
+        for p in range(self.info.npeers):
+            pi = L.PeerInfo()
+            self._check(self.lib.apk_sim_peer(self.h, p, C.byref(pi)))
+            st = self._by_tag["send:%d" % pi.rank][:pi.send_count]
+            rt = self._by_tag["recv:%d" % pi.rank][:pi.recv_count]
+            peers.append((pi.rank, st, rt))
+        self._halo = HaloExchanger(peers, group)
+
+    def _check(self, rc):
+        if rc != L.APK_OK:
+            msg = self.lib.apk_sim_last_error(self.h).decode() if self.h else ""
+            if self._cb_error is not None:
+                msg += " [callback: %r]" % (self._cb_error,)
+            raise L.ApkError(rc, msg)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.apk_sim_destroy(self.h)
+            self.h = None
+            self._tensors.clear()
+            self._by_tag.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- driver -----------------------------------------------------------------------
+    def set_fused(self, fused):
+        self._check(self.lib.apk_sim_set_fused(self.h, int(fused)))
+        self._check(self.lib.apk_sim_get_info(self.h, C.byref(self.info)))
+
+    def initialize(self):
+        self._check(self.lib.apk_sim_initialize(self.h))
+        return self
+
+    def step(self):
+        self._check(self.lib.apk_sim_step(self.h))
+
+    def run(self, nlim=-1):
+        n = C.c_int(0)
+        self._check(self.lib.apk_sim_run(self.h, nlim, C.byref(n)))
+        return n.value
+
+    time = property(lambda s: s.lib.apk_sim_time(s.h))
+    dt = property(lambda s: s.lib.apk_sim_dt(s.h))
+    tlim = property(lambda s: s.lib.apk_sim_tlim(s.h))
+    c_h = property(lambda s: s.lib.apk_sim_c_h(s.h))
+    ncycle = property(lambda s: s.lib.apk_sim_ncycle(s.h))
+    fofc_count = property(lambda s: s.lib.apk_sim_fofc_count(s.h))
+
+    @property
+    def block_shape(self):
+        i = self.info
+        nk = i.mb[2] + 2 * i.ng if i.mb[2] > 1 else 1
+        nj = i.mb[1] + 2 * i.ng if i.mb[1] > 1 else 1
+        return (i.nhydro + i.nscalars, nk, nj, i.mb[0] + 2 * i.ng)
+
+    def read_block(self, lb, field="cons"):
+        out = np.empty(self.block_shape)
+        self._check(self.lib.apk_sim_read_block(self.h, lb, {"cons": 0, "prim": 1, "u1": 2}[field],
+                                                out.ctypes.data_as(L.c_dp)))
+        return out
+
+    def write_block(self, lb, arr, field="cons"):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        assert a.shape == self.block_shape
+        self._check(self.lib.apk_sim_write_block(self.h, lb, {"cons": 0, "prim": 1, "u1": 2}[field],
+                                                 a.ctypes.data_as(L.c_dp)))
+
+    def gather(self, field="cons"):
+        i = self.info
+        out = np.zeros((i.nhydro + i.nscalars, i.nx[2], i.nx[1], i.nx[0]))
+        self._check(self.lib.apk_sim_gather(self.h, {"cons": 0, "prim": 1, "u1": 2}[field],
+                                            out.ctypes.data_as(L.c_dp)))
+        return out
+
+    def block_gid(self, lb):
+        gid = C.c_int(0)
+        loc = (C.c_int * 3)()
+        self._check(self.lib.apk_sim_block_location(self.h, lb, C.byref(gid), C.byref(loc)))
+        return gid.value, tuple(loc)
+
+    def history(self):
+        out = (C.c_double * 8)()
+        self._check(self.lib.apk_sim_history(self.h, out))
+        return np.array(out[:])
+
+    def linear_wave_errors(self):
+        rms = C.c_double(0.0)
+        l1, mx = (C.c_double * 5)(), (C.c_double * 5)()
+        self._check(self.lib.apk_sim_linear_wave_errors(self.h, C.byref(rms), l1, mx))
+        return rms.value, np.array(l1[:]), np.array(mx[:])
+
+    def exchange_ghosts(self):
+        self._check(self.lib.apk_sim_exchange_ghosts(self.h))
+
+    def fill_derived(self):
+        self._check(self.lib.apk_sim_fill_derived(self.h))
+
+    def estimate_timestep(self):
+        dt = C.c_double(0.0)
+        self._check(self.lib.apk_sim_estimate_timestep(self.h, C.byref(dt)))
+        return dt.value
+
+
+class HostPlan:
+    """Host-only view of a rank's mesh partition and ghost-exchange plan (no GPU needed)."""
+
+    PHASES = {"local": 0, "pack": 1, "unpack": 2, "bc1": 3, "bc2": 4, "bc3": 5}
+
+    def __init__(self, deck, overrides=(), rank=0, nranks=1, strict=False):
+        self.lib = L.load(strict)
+        ov = (C.c_char_p * max(1, len(overrides)))(*[o.encode() for o in overrides])
+        err = C.create_string_buffer(1024)
+        h = C.c_void_p()
+        rc = self.lib.apk_sim_create_host_only(deck.encode(), ov, len(overrides), rank, nranks,
+                                               C.byref(h), err, len(err))
+        if rc != L.APK_OK:
+            raise L.ApkError(rc, err.value.decode())
+        self.h = h
+        self.info = L.SimInfo()
+        self.lib.apk_sim_get_info(self.h, C.byref(self.info))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.apk_sim_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def block_gid(self, lb):
+        gid = C.c_int(0)
+        loc = (C.c_int * 3)()
+        self.lib.apk_sim_block_location(self.h, lb, C.byref(gid), C.byref(loc))
+        return gid.value, tuple(loc)
+
+    def peers(self):
+        out = []
+        for p in range(self.info.npeers):
+            pi = L.PeerInfo()
+            self.lib.apk_sim_peer(self.h, p, C.byref(pi))
+            out.append((pi.rank, pi.send_count, pi.recv_count))
+        return out
+
+    def regions(self, phase):
+        ph = self.PHASES[phase]
+        n = self.lib.apk_sim_plan_size(self.h, ph)
+        out = []
+        for r in range(n):
+            ri = L.RegionInfo()
+            self.lib.apk_sim_plan_region(self.h, ph, r, C.byref(ri))
+            out.append(ri)
+        return out
+
+    @property
+    def tlim(self):
+        return self.lib.apk_sim_tlim(self.h)

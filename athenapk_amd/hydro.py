@@ -1,0 +1,194 @@
+"""Host-side mirror of the reference's task functions for the flux-divergence path.
+
+Names follow the reference (Hydro::CalculateFluxes, Update::UpdateWithFluxDivergence,
+GLMMHD::DednerSource, ConservedToPrimitive, EstimateTimestep, FirstOrderFluxCorrect) so the
+parity tests read like the reference's call sites (src/hydro/hydro_driver.cpp:499-577).
+torch is plumbing only: it owns device memory (the role Parthenon plays for AthenaPK) and
+the HIP stream; every operation is one call through the C-ABI of libapk_amd.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+
+def _check(rc, ctx_lib=None, ctx=None):
+    if rc != L.APK_OK:
+        msg = ""
+        if ctx_lib is not None and ctx:
+            msg = ctx_lib.apk_last_error(ctx).decode()
+        raise L.ApkError(rc, msg)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Context:
+    """apk_ctx: workspace on the current HIP device.  No device -> ApkError (no fallback)."""
+
+    def __init__(self, strict=False):
+        self.lib = L.load(strict)
+        self.strict = bool(strict)
+        h = C.c_void_p()
+        rc = self.lib.apk_create(C.byref(h))
+        if rc != L.APK_OK:
+            raise L.ApkError(rc, "apk_create: no usable gfx950 device; the HIP path has no CPU fallback")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.apk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def poll_flags(self):
+        f = C.c_uint(0)
+        _check(self.lib.apk_poll_device_flags(self.h, C.byref(f), _stream()), self.lib, self.h)
+        return f.value
+
+
+class MeshData:
+    """A MeshBlockPack: per-block cons / prim / flux tensors [nvar][Nk][Nj][Ni] on the GPU.
+
+    Built from host arrays (numpy) or existing CUDA tensors; owns the tensors it creates.
+    """
+
+    def __init__(self, ctx, nx, ng, nhydro, nscalars=0, dx=(1.0, 1.0, 1.0), nblocks=1,
+                 cons=None, prim=None, with_flux=True):
+        self.ctx = ctx
+        self.nx, self.ng, self.nhydro, self.nscalars = tuple(nx), ng, nhydro, nscalars
+        self.nvar = nhydro + nscalars
+        ni = nx[0] + 2 * ng
+        nj = nx[1] + 2 * ng if nx[1] > 1 else 1
+        nk = nx[2] + 2 * ng if nx[2] > 1 else 1
+        self.shape = (self.nvar, nk, nj, ni)
+        self.ndim = 3 if nx[2] > 1 else (2 if nx[1] > 1 else 1)
+        self.nblocks = nblocks
+        self.dx = tuple(dx)
+        dev = torch.device("cuda")
+
+        def field(src):
+            if src is None:
+                return torch.zeros((nblocks,) + self.shape, dtype=torch.float64, device=dev)
+            if isinstance(src, torch.Tensor):
+                t = src.to(device=dev, dtype=torch.float64).contiguous()
+            else:
+                t = torch.from_numpy(np.ascontiguousarray(src, dtype=np.float64)).to(dev)
+            return t.reshape((nblocks,) + self.shape).contiguous()
+
+        self.cons = field(cons)
+        self.prim = field(prim)
+        self.flux = [field(None) if (with_flux and d < self.ndim) else None for d in range(3)]
+        blocks = (L.BlockDesc * nblocks)()
+        per = int(np.prod(self.shape)) * 8
+        for b in range(nblocks):
+            blocks[b].cons = self.cons.data_ptr() + b * per
+            blocks[b].prim = self.prim.data_ptr() + b * per
+            for d in range(3):
+                blocks[b].flux[d] = (self.flux[d].data_ptr() + b * per) if self.flux[d] is not None else None
+            blocks[b].dx[:] = list(dx)
+        desc = L.PackDesc()
+        desc.nblocks, desc.nhydro, desc.nscalars, desc.ng = nblocks, nhydro, nscalars, ng
+        desc.nx[:] = list(nx)
+        desc.blocks = blocks
+        h = C.c_void_p()
+        _check(ctx.lib.apk_pack_create(ctx.h, C.byref(desc), C.byref(h)), ctx.lib, ctx.h)
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.ctx.lib.apk_pack_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def cons_host(self):
+        torch.cuda.synchronize()
+        return self.cons.cpu().numpy()
+
+    def prim_host(self):
+        torch.cuda.synchronize()
+        return self.prim.cpu().numpy()
+
+    def flux_host(self, d):
+        torch.cuda.synchronize()
+        return self.flux[d].cpu().numpy()
+
+
+def _cfg(fluid, recon, riemann):
+    return L.FluxCfg(L.FLUID[fluid], L.RECON[recon], L.RIEMANN[riemann])
+
+
+# ---- the task functions ---------------------------------------------------------------------
+def CalculateFluxes(md, fluid, recon, riemann, eos, c_h=0.0):
+    """Hydro::CalculateFluxes<fluid,recon,rsolver>(md)  -- src/hydro/hydro.cpp:1025"""
+    ctx = md.ctx
+    _check(ctx.lib.apk_calculate_fluxes(ctx.h, md.h, _cfg(fluid, recon, riemann), C.byref(eos),
+                                        float(c_h), _stream()), ctx.lib, ctx.h)
+
+
+def UpdateWithFluxDivergence(u0, u1, gam0, gam1, beta_dt):
+    """parthenon::Update::UpdateWithFluxDivergence -- call site hydro_driver.cpp:534"""
+    ctx = u0.ctx
+    _check(ctx.lib.apk_update_with_flux_divergence(ctx.h, u0.h, u1.h, gam0, gam1, beta_dt,
+                                                   _stream()), ctx.lib, ctx.h)
+
+
+def DednerSource(md, extended, alpha, c_h, mindx, beta_dt):
+    """GLMMHD::DednerSource<extended>(md, beta_dt) -- src/hydro/glmmhd/dedner_source.cpp:17"""
+    ctx = md.ctx
+    _check(ctx.lib.apk_dedner_source(ctx.h, md.h, int(extended), alpha, c_h, mindx, beta_dt,
+                                     _stream()), ctx.lib, ctx.h)
+
+
+def StageFused(u0, u1, fluid, recon, riemann, eos, c_h, gam0, gam1, beta_dt, dedner=0,
+               glmmhd_alpha=0.1, mindx=1.0):
+    """Fused CalculateFluxes -> UpdateWithFluxDivergence -> DednerSource for one RK stage."""
+    ctx = u0.ctx
+    a = L.StageArgs()
+    a.cfg = _cfg(fluid, recon, riemann)
+    a.eos = eos
+    a.c_h, a.gam0, a.gam1, a.beta_dt = c_h, gam0, gam1, beta_dt
+    a.dedner, a.glmmhd_alpha, a.mindx = dedner, glmmhd_alpha, mindx
+    _check(ctx.lib.apk_stage_fused(ctx.h, u0.h, u1.h, C.byref(a), _stream()), ctx.lib, ctx.h)
+
+
+def ConservedToPrimitive(md, fluid, eos):
+    """EquationOfState::ConservedToPrimitive(md) -- src/eos/adiabatic_hydro.cpp:33"""
+    ctx = md.ctx
+    _check(ctx.lib.apk_cons_to_prim(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), _stream()), ctx.lib, ctx.h)
+
+
+def EstimateTimestep(md, fluid, eos, cfl):
+    """Hydro::EstimateHyperbolicTimestep<fluid>(md) -- src/hydro/hydro.cpp:828"""
+    ctx = md.ctx
+    dt = C.c_double(0.0)
+    _check(ctx.lib.apk_estimate_timestep(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), cfl, C.byref(dt),
+                                         _stream()), ctx.lib, ctx.h)
+    return dt.value
+
+
+def FirstOrderFluxCorrect(u0, u1, fluid, eos, c_h, gam0, gam1, beta_dt):
+    """Hydro::FirstOrderFluxCorrect<fluid>(u0,u1,gam0,gam1,beta_dt) -- hydro.cpp:1223"""
+    ctx = u0.ctx
+    n = C.c_longlong(0)
+    _check(ctx.lib.apk_first_order_flux_correct(ctx.h, u0.h, u1.h, L.FLUID[fluid], C.byref(eos), c_h,
+                                                gam0, gam1, beta_dt, C.byref(n), _stream()), ctx.lib, ctx.h)
+    return n.value
+
+
+def HydroHst(md, fluid):
+    """HydroHst<...> reductions -- src/hydro/hydro.cpp:145-208"""
+    ctx = md.ctx
+    out = (C.c_double * 8)()
+    _check(ctx.lib.apk_history(ctx.h, md.h, L.FLUID[fluid], out, _stream()), ctx.lib, ctx.h)
+    return np.array(out[:])

@@ -1,0 +1,203 @@
+/*
+ * apk_amd.h -- C-ABI of the MI355X-native AthenaPK hot path (libapk_amd.so).
+ *
+ * Drop-in boundary: these entry points are what a Parthenon/AthenaPK build binds in place
+ * of the Kokkos task functions of the flux-divergence update.  Every entry point cites
+ * the reference interface (file:line under the AthenaPK tree) it replaces; the adapter a
+ * maintainer adds on the reference side is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C types only; device memory is BORROWED for the duration of a call
+ *    (Parthenon owns all field storage; src/hydro/hydro.cpp:777-786).
+ *  - every call is asynchronous on the caller's HIP stream (`apk_stream_t` = hipStream_t
+ *    cast to void*; NULL = default stream) unless it returns a host scalar.
+ *  - return value: APK_OK (0) or a negative APK_ERR_* code.  Never throws, never aborts.
+ *    Device-side "PARTHENON_REQUIRE" conditions (negative density / pressure in
+ *    ConsToPrim, src/eos/adiabatic_hydro.hpp:77-79,111-113) are latched in a flag word
+ *    read back with apk_poll_device_flags().
+ *  - block field layout: [nvar][Nk][Nj][Ni] doubles, i fastest, Ni = nx1 + 2*ng (no
+ *    ghosts in a collapsed dimension); flux(d, v, k, j, i) is the flux through the LOWER
+ *    d-face of cell (k,j,i)  (SURVEY.md 8, App. A.5).
+ *  - variable order: cons (rho, m1, m2, m3, E [,B1,B2,B3,psi], scalars...),
+ *    prim (rho, v1, v2, v3, p [,B1,B2,B3,psi], scalars...)   src/main.hpp:19-33
+ */
+#ifndef APK_AMD_H_
+#define APK_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APK_AMD_VERSION 1
+
+/* ---- option enums: numeric values = position in the reference's enum classes,
+ *      src/main.hpp:35-38 ---- */
+enum apk_riemann { APK_RS_UNDEFINED = 0, APK_RS_NONE = 1, APK_RS_HLLE = 2, APK_RS_LLF = 3,
+                   APK_RS_HLLC = 4, APK_RS_HLLD = 5 };
+enum apk_recon { APK_RC_UNDEFINED = 0, APK_RC_DC = 1, APK_RC_PLM = 2, APK_RC_PPM = 3,
+                 APK_RC_WENOZ = 4, APK_RC_WENO3 = 5, APK_RC_LIMO3 = 6 };
+enum apk_integrator { APK_INT_UNDEFINED = 0, APK_INT_RK1 = 1, APK_INT_RK2 = 2,
+                      APK_INT_VL2 = 3, APK_INT_RK3 = 4 };
+enum apk_fluid { APK_FLUID_UNDEFINED = 0, APK_FLUID_EULER = 1, APK_FLUID_GLMMHD = 2 };
+
+enum apk_status {
+  APK_OK = 0,
+  APK_ERR_INVALID = -1,      /* bad argument / inconsistent pack */
+  APK_ERR_UNSUPPORTED = -2,  /* (fluid,recon,riemann) not in the registry, hydro.cpp:386-416 */
+  APK_ERR_NGHOST = -3,       /* too few ghost zones for the reconstruction, hydro.cpp:444-447 */
+  APK_ERR_DEVICE = -4,       /* HIP runtime error (see apk_last_error) */
+  APK_ERR_NO_DEVICE = -5     /* no HIP device / extension not usable: fail loudly */
+};
+
+/* device flag bits latched by kernels (apk_poll_device_flags) */
+#define APK_FLAG_NEG_DENSITY 1u
+#define APK_FLAG_NEG_PRESSURE 2u
+
+typedef void *apk_stream_t; /* hipStream_t */
+
+/* AdiabaticHydroEOS / AdiabaticGLMMHDEOS parameters: src/eos/eos.hpp:33-61,
+ * defaults src/hydro/hydro.cpp:507-537 (floors <= 0 disabled, ceilings +inf disabled) */
+typedef struct apk_eos {
+  double gamma;
+  double pfloor, dfloor, efloor;
+  double vceil, eceil;
+} apk_eos;
+
+/* what CalculateFluxes is templated on: src/hydro/hydro.hpp:43-46,53 (FluxFunKey_t) */
+typedef struct apk_flux_cfg {
+  int fluid;   /* apk_fluid */
+  int recon;   /* apk_recon */
+  int riemann; /* apk_riemann */
+} apk_flux_cfg;
+
+/* one meshblock of a MeshBlockPack: what `pack(b)(v,k,j,i)`, `pack(b).flux(d,v,k,j,i)`
+ * and `pack.GetCoords(b).Dxc<d>()` resolve to (src/hydro/hydro.cpp:1041-1073).
+ * All pointers are DEVICE pointers; flux[d] may be NULL if the caller only uses the fused
+ * stage path (or for inactive dimensions). */
+typedef struct apk_block_desc {
+  double *cons;
+  double *prim;
+  double *flux[3];
+  double dx[3];
+} apk_block_desc;
+
+/* MeshData / MeshBlockPack: src/hydro/hydro.cpp:1026-1063 */
+typedef struct apk_pack_desc {
+  int nblocks;  /* cons_in.GetDim(5) */
+  int nhydro;   /* pkg->Param<int>("nhydro"): 5 or 9 */
+  int nscalars; /* pkg->Param<int>("nscalars") */
+  int nx[3];    /* block_size.nx(X1DIR..X3DIR); 1 = collapsed dimension */
+  int ng;       /* parthenon/mesh/nghost */
+  const apk_block_desc *blocks; /* HOST array [nblocks] */
+} apk_pack_desc;
+
+typedef struct apk_ctx apk_ctx;   /* workspace: flag words, reduction scratch */
+typedef struct apk_pack apk_pack; /* device-resident copy of an apk_pack_desc */
+
+/* ---- lifetime ---------------------------------------------------------------------- */
+/* Creates the workspace on the CURRENT HIP device.  Fails with APK_ERR_NO_DEVICE when no
+ * gfx950-capable device is visible: there is no CPU fallback. */
+int apk_create(apk_ctx **out);
+void apk_destroy(apk_ctx *ctx);
+const char *apk_last_error(const apk_ctx *ctx);
+int apk_version(void);
+/* 1 if this library was built with -ffp-contract=off (bit-parity build), else 0 */
+int apk_fp_strict(void);
+
+/* Uploads the descriptors (tiny H2D copy, synchronous).  Rebuild after remeshing, like
+ * Parthenon rebuilds its packs. */
+int apk_pack_create(apk_ctx *ctx, const apk_pack_desc *desc, apk_pack **out);
+void apk_pack_destroy(apk_pack *pack);
+
+/* ---- the hot path ------------------------------------------------------------------- */
+
+/* Replaces Hydro::CalculateFluxes<fluid,recon,rsolver>(std::shared_ptr<MeshData<Real>>&)
+ * src/hydro/hydro.cpp:1025-1208 (type FluxFun_t, hydro.hpp:43-46; registry
+ * hydro.cpp:386-416; (dc,llf) maps to CalculateFluxesTight hydro.cpp:980-1022).
+ * Reads prim, writes flux[d] over the reference's loop extents. */
+int apk_calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg,
+                         const apk_eos *eos, double c_h, apk_stream_t stream);
+
+/* Replaces parthenon::Update::UpdateWithFluxDivergence<MeshData<Real>>(u0,u1,gam0,gam1,
+ * beta_dt); call site src/hydro/hydro_driver.cpp:534-537.
+ * u0.cons <- gam0*u0.cons + gam1*u1.cons + beta_dt * (-div F(u0.flux)) on interior cells. */
+int apk_update_with_flux_divergence(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
+                                    double gam0, double gam1, double beta_dt,
+                                    apk_stream_t stream);
+
+/* Replaces GLMMHD::DednerSource<extended>(MeshData<Real>*, Real beta_dt)
+ * src/hydro/glmmhd/dedner_source.cpp:17-75 (called through Hydro::AddUnsplitSources,
+ * src/hydro/hydro.cpp:227-246).  c_h, mindx, alpha are the package params of
+ * dedner_source.cpp:27-29. */
+int apk_dedner_source(apk_ctx *ctx, const apk_pack *md, int extended, double alpha,
+                      double c_h, double mindx, double beta_dt, apk_stream_t stream);
+
+/* Fused fast path for one RK stage of one pack = CalculateFluxes -> UpdateWithFlux-
+ * Divergence -> DednerSource (hydro_driver.cpp:510-544) without materialising the flux
+ * arrays in HBM.  Not usable when first-order flux correction or AMR flux correction needs
+ * the face fluxes.  u1 may alias u0 only if gam1 == 0. */
+typedef struct apk_stage_args {
+  apk_flux_cfg cfg;
+  apk_eos eos;
+  double c_h;
+  double gam0, gam1, beta_dt; /* integrator->gam0/gam1/beta[stage-1]*dt */
+  int dedner;                 /* 0 = off (euler), 1 = plain, 2 = extended */
+  double glmmhd_alpha, mindx;
+} apk_stage_args;
+int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
+                    const apk_stage_args *args, apk_stream_t stream);
+
+/* Replaces EquationOfState::ConservedToPrimitive(MeshData<Real>*) over the ENTIRE block
+ * src/eos/adiabatic_hydro.cpp:33-55, adiabatic_glmmhd.cpp:33-56 (pkg->FillDerivedMesh,
+ * src/hydro/hydro.cpp:705-713). */
+int apk_cons_to_prim(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,
+                     apk_stream_t stream);
+
+/* Replaces Hydro::EstimateHyperbolicTimestep<fluid>(MeshData<Real>*)
+ * src/hydro/hydro.cpp:828-910.  Synchronises `stream`; *dt_out = cfl * min(...). */
+int apk_estimate_timestep(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,
+                          double cfl, double *dt_out, apk_stream_t stream);
+
+/* Replaces Hydro::FirstOrderFluxCorrect<fluid>(u0,u1,gam0,gam1,beta_dt)
+ * src/hydro/hydro.cpp:1223-1342.  Iterates <= 4 attempts, one host sync per attempt like
+ * the reference's parallel_reduce.  *num_corrected (optional) = cells corrected. */
+int apk_first_order_flux_correct(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
+                                 int fluid, const apk_eos *eos, double c_h, double gam0,
+                                 double gam1, double beta_dt, long long *num_corrected,
+                                 apk_stream_t stream);
+
+/* Replaces the HydroHst<...> reductions src/hydro/hydro.cpp:145-208:
+ * out[8] = mass, 1-mom, 2-mom, 3-mom, KE, tot-E, ME, relDivB.  Synchronises `stream`. */
+int apk_history(apk_ctx *ctx, const apk_pack *md, int fluid, double *out8,
+                apk_stream_t stream);
+
+/* Reads-and-clears the device flag word (APK_FLAG_*).  Synchronises `stream`. */
+int apk_poll_device_flags(apk_ctx *ctx, unsigned *flags, apk_stream_t stream);
+
+/* ---- ghost zones (the step either side of the path; Parthenon bvals, call sites
+ *      src/hydro/hydro_driver.cpp:506,567-568) ------------------------------------------ */
+/* One strided box copy: dst(v, k, j, i) = sign_v * src(v, k', j', i').  With a zero source
+ * stride it broadcasts (outflow); with a negative stride it mirrors (reflecting,
+ * src/bvals/boundary_conditions_apk.hpp:38-85).  Used for same-rank neighbour copies,
+ * packing into / unpacking from contiguous message buffers, and physical boundaries. */
+typedef struct apk_copy_region {
+  const double *src;
+  double *dst;
+  int ext[3];             /* box extent (ni, nj, nk) */
+  int nvar;
+  int64_t src_stride[4];  /* element strides for (i, j, k, v) */
+  int64_t dst_stride[4];
+  int flip_var;           /* variable index whose sign is flipped, or -1 */
+} apk_copy_region;
+typedef struct apk_copy_plan apk_copy_plan;
+int apk_copy_plan_create(apk_ctx *ctx, const apk_copy_region *regions, int n,
+                         apk_copy_plan **out);
+void apk_copy_plan_destroy(apk_copy_plan *plan);
+int apk_copy_plan_run(apk_ctx *ctx, const apk_copy_plan *plan, apk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APK_AMD_H_ */

@@ -1,0 +1,135 @@
+/*
+ * apk_host.h -- C-ABI of the host-side mini-driver that sits ABOVE the hot-path boundary
+ * (include/apk_amd.h) in the standalone build.  It mirrors the reference's control flow
+ * for this path only: input deck -> Hydro::Initialize options (src/hydro/hydro.cpp:264-826)
+ * -> per-cycle PreStepMeshUserWorkInLoop (hydro.cpp:102-143) -> per-stage task order of
+ * HydroDriver::MakeTaskCollection (src/hydro/hydro_driver.cpp:347-673) -> dt control.
+ * In a real AthenaPK build Parthenon plays this role and only apk_amd.h is bound
+ * (INTEGRATION.md).  Everything here is C++ compiled into libapk_amd.so; Python (tests,
+ * bench.py) talks to it through ctypes and supplies device memory / torch.distributed.
+ */
+#ifndef APK_HOST_H_
+#define APK_HOST_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "apk_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct apk_sim apk_sim;
+
+/* Device-memory provider.  NULL => hipMalloc/hipFree.  bench.py / tests pass callbacks
+ * that hand out torch CUDA tensors, so that message buffers can be given to
+ * torch.distributed (RCCL) without copies.  `tag` names the buffer ("cons", "send:3", ...). */
+typedef struct apk_allocator {
+  void *user;
+  void *(*alloc)(void *user, const char *tag, size_t bytes);
+  void (*release)(void *user, void *ptr);
+} apk_allocator;
+
+/* Inter-rank operations (one process per GPU).  NULL => single rank.
+ *  exchange: all per-peer send buffers are packed and the pack kernels are complete on the
+ *            sim's stream when this is called; on return the per-peer receive buffers must
+ *            be ready to be read by work enqueued on that stream.
+ *  allreduce_min: in-place MIN over ranks of n doubles (dt; mindx/dt_hyp: hydro.cpp:122-128).
+ *  allreduce_sum: in-place SUM over ranks (history output). */
+typedef struct apk_comm_ops {
+  void *user;
+  int (*exchange)(void *user);
+  int (*allreduce_min)(void *user, double *vals, int n);
+  int (*allreduce_sum)(void *user, double *vals, int n);
+} apk_comm_ops;
+
+/* ---- creation from an Athena-style input deck ("<block>" / "key = value") -------------
+ * `deck` is the deck TEXT; `overrides` are "block/key=value" strings exactly like the
+ * reference's command line (README.md:113-119).  rank/nranks select this process' share
+ * of the meshblocks (Morton-ordered contiguous ranges, like Parthenon).
+ * On failure returns a negative apk_status and, if errbuf != NULL, a message. */
+int apk_sim_create(const char *deck, const char *const *overrides, int noverrides, int rank,
+                   int nranks, const apk_allocator *allocator, const apk_comm_ops *comm,
+                   apk_stream_t stream, apk_sim **out, char *errbuf, size_t errlen);
+void apk_sim_destroy(apk_sim *sim);
+const char *apk_sim_last_error(const apk_sim *sim);
+
+/* host-only mode: builds mesh / partition / ghost plans without touching a GPU (used by the
+ * CPU tests of the host logic and the world_size-2 gloo tests). */
+int apk_sim_create_host_only(const char *deck, const char *const *overrides, int noverrides,
+                             int rank, int nranks, apk_sim **out, char *errbuf, size_t errlen);
+
+/* ---- problem setup ------------------------------------------------------------------- */
+/* Runs the problem generator selected by <job> problem_id (linear_wave, sod, orszag_tang,
+ * synthetic), then ghost exchange -> FillDerived -> first EstimateTimestep (App. A.4). */
+int apk_sim_initialize(apk_sim *sim);
+
+/* ---- time integration ---------------------------------------------------------------- */
+int apk_sim_step(apk_sim *sim);                      /* one cycle */
+int apk_sim_run(apk_sim *sim, int nlim, int *ncycles); /* until tlim or nlim cycles (<0: none) */
+double apk_sim_time(const apk_sim *sim);
+double apk_sim_dt(const apk_sim *sim);
+double apk_sim_tlim(const apk_sim *sim);
+double apk_sim_c_h(const apk_sim *sim);
+int apk_sim_ncycle(const apk_sim *sim);
+long long apk_sim_fofc_count(const apk_sim *sim);
+/* 0 = flux-array path (CalculateFluxes + Update + Dedner), 1 = fused stage path */
+int apk_sim_set_fused(apk_sim *sim, int fused);
+
+/* ---- introspection ------------------------------------------------------------------- */
+typedef struct apk_sim_info {
+  int fluid, recon, riemann, integrator;
+  int nx[3], mb[3], ng, nhydro, nscalars, ndim;
+  int nblocks_total, nblocks_local, first_gid;
+  int rank, nranks, npeers;
+  int fofc, dedner_extended, fused;
+  double cfl, gamma, glmmhd_alpha;
+  double xmin[3], xmax[3], dx[3];
+  int64_t cells_per_block; /* incl. ghosts */
+  int64_t zones_local;     /* interior cells on this rank */
+  int64_t zones_total;
+} apk_sim_info;
+int apk_sim_get_info(const apk_sim *sim, apk_sim_info *info);
+/* global block id and logical (bx,by,bz) of local block lb */
+int apk_sim_block_location(const apk_sim *sim, int lb, int *gid, int loc[3]);
+/* device pointers of local block lb: field 0 = cons, 1 = prim, 2 = u1.cons */
+void *apk_sim_block_ptr(const apk_sim *sim, int lb, int field);
+/* copy the interior of every local block of `field` into a global-shaped host array
+ * [nvar][nx3][nx2][nx1] (only this rank's cells are written) */
+int apk_sim_gather(apk_sim *sim, int field, double *host_out);
+/* copy one full block (incl. ghosts) host<->device */
+int apk_sim_read_block(apk_sim *sim, int lb, int field, double *host_out);
+int apk_sim_write_block(apk_sim *sim, int lb, int field, const double *host_in);
+/* history sums over the whole mesh (allreduce'd): mass,1-mom,2-mom,3-mom,KE,tot-E,ME,relDivB */
+int apk_sim_history(apk_sim *sim, double *out8);
+/* linear-wave L1 errors vs the initial condition (src/pgen/linear_wave.cpp:183-335) */
+int apk_sim_linear_wave_errors(apk_sim *sim, double *rms, double *l1_5, double *max_5);
+/* individual driver steps, exposed for tests */
+int apk_sim_exchange_ghosts(apk_sim *sim);
+int apk_sim_fill_derived(apk_sim *sim);
+int apk_sim_estimate_timestep(apk_sim *sim, double *dt);
+
+/* ---- ghost-exchange plan introspection (host logic; valid in host-only mode) ----------- */
+typedef struct apk_peer_info {
+  int rank;
+  int64_t send_count, recv_count; /* doubles */
+  void *send_buf, *recv_buf;      /* device pointers (NULL in host-only mode) */
+} apk_peer_info;
+int apk_sim_peer(const apk_sim *sim, int p, apk_peer_info *info);
+/* number of box copies in each phase: 0 local, 1 pack, 2 unpack, 3..5 physical BC x1..x3 */
+int apk_sim_plan_size(const apk_sim *sim, int phase);
+/* region r of a phase, with src/dst expressed as (kind, block, element offset):
+ * kind 0 = local block cons, 1 = send buffer of peer `block`, 2 = recv buffer of peer `block` */
+typedef struct apk_region_info {
+  int src_kind, src_block, dst_kind, dst_block;
+  int64_t src_off, dst_off;
+  int ext[3], nvar, flip_var;
+  int64_t src_stride[4], dst_stride[4];
+} apk_region_info;
+int apk_sim_plan_region(const apk_sim *sim, int phase, int r, apk_region_info *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APK_HOST_H_ */

@@ -1,0 +1,265 @@
+"""ctypes binding of the CPU ORACLE (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY.  May be imported from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never from the athenapk_amd package (the product).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# enums (mirror src/main.hpp:35-38 of the reference via apk_oracle.h)
+FLUID = {"euler": 1, "glmmhd": 2}
+RECON = {"dc": 1, "plm": 2, "ppm": 3, "wenoz": 4, "weno3": 5, "limo3": 6}
+RIEMANN = {"none": 1, "hlle": 2, "llf": 3, "hllc": 4, "hlld": 5}
+INTEGRATOR = {"rk1": 1, "rk2": 2, "vl2": 3, "rk3": 4}
+BC = {"periodic": 0, "outflow": 1, "reflecting": 2}
+
+c_dp = C.POINTER(C.c_double)
+
+
+class Eos(C.Structure):
+    _fields_ = [("gamma", C.c_double), ("pfloor", C.c_double), ("dfloor", C.c_double),
+                ("efloor", C.c_double), ("vceil", C.c_double), ("eceil", C.c_double)]
+
+
+def make_eos(gamma, pfloor=-1.0, dfloor=-1.0, efloor=-1.0, vceil=float("inf"),
+             eceil=float("inf")):
+    return Eos(gamma, pfloor, dfloor, efloor, vceil, eceil)
+
+
+class Geom(C.Structure):
+    _fields_ = [("nx", C.c_int * 3), ("ng", C.c_int), ("nvar", C.c_int), ("nhydro", C.c_int),
+                ("dx", C.c_double * 3)]
+
+    @property
+    def shape(self):
+        ng = self.ng
+        ni = self.nx[0] + 2 * ng
+        nj = self.nx[1] + 2 * ng if self.nx[1] > 1 else 1
+        nk = self.nx[2] + 2 * ng if self.nx[2] > 1 else 1
+        return (self.nvar, nk, nj, ni)
+
+
+def make_geom(nx, ng, nhydro, nscalars=0, dx=(1.0, 1.0, 1.0)):
+    g = Geom()
+    g.nx[:] = list(nx)
+    g.ng = ng
+    g.nhydro = nhydro
+    g.nvar = nhydro + nscalars
+    g.dx[:] = list(dx)
+    return g
+
+
+class SimParams(C.Structure):
+    _fields_ = [("fluid", C.c_int), ("recon", C.c_int), ("riemann", C.c_int),
+                ("integrator", C.c_int), ("nx", C.c_int * 3), ("mb", C.c_int * 3),
+                ("ng", C.c_int), ("nscalars", C.c_int), ("bc_inner", C.c_int * 3),
+                ("bc_outer", C.c_int * 3), ("xmin", C.c_double * 3), ("xmax", C.c_double * 3),
+                ("cfl", C.c_double), ("glmmhd_alpha", C.c_double),
+                ("dedner_extended", C.c_int), ("first_order_flux_correct", C.c_int),
+                ("eos", Eos), ("nthreads", C.c_int)]
+
+
+def build(fast=False, force=False):
+    """Compile the oracle with gcc (strict build by default)."""
+    target = "liboracle_fast.so" if fast else "liboracle.so"
+    path = os.path.join(_HERE, target)
+    srcs = [os.path.join(_HERE, f) for f in
+            ("recon.c", "riemann.c", "block.c", "sim.c", "apk_oracle.h", "Makefile")]
+    stale = (not os.path.exists(path)) or any(
+        os.path.getmtime(s) > os.path.getmtime(path) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", target], check=True,
+                       stdout=subprocess.DEVNULL)
+    return path
+
+
+def _declare(lib):
+    d, i, l, p = C.c_double, C.c_int, C.c_long, c_dp
+    G, E = C.POINTER(Geom), C.POINTER(Eos)
+    sig = {
+        "orc_recon_many": (None, [i, l, p, d, i, p, p]),
+        "orc_riemann_many": (None, [i, i, i, l, p, p, d, d, p]),
+        "orc_sound_speed": (d, [d, d, d]),
+        "orc_fast_speed": (d, [d, d, d, d, d, d]),
+        "orc_cons_to_prim_cell": (i, [i, E, i, i, p, p]),
+        "orc_calculate_fluxes": (None, [G, i, i, i, E, d, p, p, p, p]),
+        "orc_calculate_fluxes_tight": (None, [G, i, E, d, p, p, p, p]),
+        "orc_update_flux_div": (None, [G, p, p, p, p, p, d, d, d]),
+        "orc_dedner_source": (None, [G, i, d, d, d, d, p, p]),
+        "orc_cons_to_prim": (l, [G, i, E, p, p]),
+        "orc_estimate_dt_hyp": (d, [G, i, E, p]),
+        "orc_first_order_flux_correct": (l, [G, i, E, d, p, p, p, p, p, p, d, d, d]),
+        "orc_history": (None, [G, i, p, p]),
+        "orc_sim_create": (C.c_void_p, [C.POINTER(SimParams)]),
+        "orc_sim_destroy": (None, [C.c_void_p]),
+        "orc_sim_nblocks": (i, [C.c_void_p]),
+        "orc_sim_block_geom": (None, [C.c_void_p, G]),
+        "orc_sim_cons": (p, [C.c_void_p, i]),
+        "orc_sim_prim": (p, [C.c_void_p, i]),
+        "orc_sim_block_origin": (None, [C.c_void_p, i, p]),
+        "orc_pgen_linear_wave": (d, [C.c_void_p, i, d, d]),
+        "orc_pgen_sod": (None, [C.c_void_p, d, d, d, d, d, d, d]),
+        "orc_pgen_orszag_tang": (None, [C.c_void_p]),
+        "orc_pgen_synthetic": (None, [C.c_void_p]),
+        "orc_sim_initialize": (None, [C.c_void_p]),
+        "orc_sim_step": (d, [C.c_void_p, d]),
+        "orc_sim_run": (i, [C.c_void_p, d, i]),
+        "orc_sim_time": (d, [C.c_void_p]),
+        "orc_sim_dt": (d, [C.c_void_p]),
+        "orc_sim_c_h": (d, [C.c_void_p]),
+        "orc_sim_fofc_count": (l, [C.c_void_p]),
+        "orc_sim_history": (None, [C.c_void_p, p]),
+        "orc_linear_wave_errors": (d, [C.c_void_p, i, d, d, p, p]),
+        "orc_sim_gather_cons": (None, [C.c_void_p, p]),
+        "orc_sim_exchange_ghosts": (None, [C.c_void_p]),
+        "orc_sim_fill_derived": (None, [C.c_void_p]),
+        "orc_integrator_coeffs": (i, [i, p, p, p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+
+
+_LIBS = {}
+
+
+def load(fast=False):
+    key = bool(fast)
+    if key not in _LIBS:
+        lib = C.CDLL(build(fast=fast))
+        _declare(lib)
+        _LIBS[key] = lib
+    return _LIBS[key]
+
+
+def dp(a):
+    """double* of a C-contiguous float64 numpy array."""
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_dp)
+
+
+# ---------------------------------------------------------------------------------------
+# convenience wrappers
+def recon_many(recon, q, dx=1.0, n=0, lib=None):
+    lib = lib or load()
+    q = np.ascontiguousarray(q, dtype=np.float64).reshape(-1, 5)
+    m = q.shape[0]
+    ql, qr = np.empty(m), np.empty(m)
+    lib.orc_recon_many(RECON[recon], m, dp(q), dx, n, dp(ql), dp(qr))
+    return ql, qr
+
+
+def riemann_many(fluid, riemann, ivx, wl, wr, gamma, c_h=0.0, lib=None):
+    lib = lib or load()
+    nv = 5 if fluid == "euler" else 9
+    wl = np.ascontiguousarray(wl, dtype=np.float64).reshape(-1, nv)
+    wr = np.ascontiguousarray(wr, dtype=np.float64).reshape(-1, nv)
+    out = np.empty_like(wl)
+    lib.orc_riemann_many(FLUID[fluid], RIEMANN[riemann], ivx, wl.shape[0], dp(wl), dp(wr),
+                         gamma, c_h, dp(out))
+    return out
+
+
+def integrator_coeffs(name, lib=None):
+    lib = lib or load()
+    b, g0, g1 = np.zeros(4), np.zeros(4), np.zeros(4)
+    n = lib.orc_integrator_coeffs(INTEGRATOR[name], dp(b), dp(g0), dp(g1))
+    return n, b[:n], g0[:n], g1[:n]
+
+
+class Sim:
+    """Thin OO wrapper over the orc_sim_* mini-driver."""
+
+    def __init__(self, fluid="euler", recon="plm", riemann="hlle", integrator="vl2",
+                 nx=(64, 32, 32), mb=None, ng=2, nscalars=0, bc=("periodic",) * 3,
+                 bc_outer=None, xmin=(0.0, 0.0, 0.0), xmax=(1.0, 1.0, 1.0), cfl=0.3,
+                 gamma=5.0 / 3.0, glmmhd_alpha=0.1, dedner_extended=False, fofc=False,
+                 eos=None, nthreads=0, fast=False):
+        self.lib = load(fast=fast)
+        p = SimParams()
+        p.fluid, p.recon, p.riemann = FLUID[fluid], RECON[recon], RIEMANN[riemann]
+        p.integrator = INTEGRATOR[integrator]
+        p.nx[:] = list(nx)
+        p.mb[:] = list(mb or nx)
+        p.ng, p.nscalars = ng, nscalars
+        p.bc_inner[:] = [BC[b] for b in bc]
+        p.bc_outer[:] = [BC[b] for b in (bc_outer or bc)]
+        p.xmin[:] = list(xmin)
+        p.xmax[:] = list(xmax)
+        p.cfl, p.glmmhd_alpha = cfl, glmmhd_alpha
+        p.dedner_extended, p.first_order_flux_correct = int(dedner_extended), int(fofc)
+        p.eos = eos or make_eos(gamma)
+        p.nthreads = nthreads
+        self.params = p
+        self.h = self.lib.orc_sim_create(C.byref(p))
+        if not self.h:
+            raise ValueError("mesh not divisible by meshblock size")
+        self.geom = Geom()
+        self.lib.orc_sim_block_geom(self.h, C.byref(self.geom))
+        self.fluid = fluid
+        self.nx = tuple(nx)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_sim_destroy(self.h)
+            self.h = None
+
+    @property
+    def nblocks(self):
+        return self.lib.orc_sim_nblocks(self.h)
+
+    def cons(self, b):
+        return np.ctypeslib.as_array(self.lib.orc_sim_cons(self.h, b), shape=self.geom.shape)
+
+    def prim(self, b):
+        return np.ctypeslib.as_array(self.lib.orc_sim_prim(self.h, b), shape=self.geom.shape)
+
+    def pgen(self, name, **kw):
+        if name == "linear_wave":
+            self._lw = (kw.get("wave_flag", 0), kw.get("amp", 1e-6), kw.get("vflow", 0.0))
+            self.period = self.lib.orc_pgen_linear_wave(self.h, *self._lw)
+        elif name == "sod":
+            self.lib.orc_pgen_sod(self.h, kw.get("rho_l", 1.0), kw.get("pres_l", 1.0),
+                                  kw.get("u_l", 0.0), kw.get("rho_r", 0.125),
+                                  kw.get("pres_r", 0.1), kw.get("u_r", 0.0),
+                                  kw.get("x_discont", 0.5))
+        elif name == "orszag_tang":
+            self.lib.orc_pgen_orszag_tang(self.h)
+        elif name == "synthetic":
+            self.lib.orc_pgen_synthetic(self.h)
+        else:
+            raise ValueError(name)
+        self.lib.orc_sim_initialize(self.h)
+        return self
+
+    def step(self, tlim=1e300):
+        return self.lib.orc_sim_step(self.h, tlim)
+
+    def run(self, tlim, nlim=-1):
+        return self.lib.orc_sim_run(self.h, tlim, nlim)
+
+    time = property(lambda self: self.lib.orc_sim_time(self.h))
+    dt = property(lambda self: self.lib.orc_sim_dt(self.h))
+    c_h = property(lambda self: self.lib.orc_sim_c_h(self.h))
+    fofc_count = property(lambda self: self.lib.orc_sim_fofc_count(self.h))
+
+    def history(self):
+        out = np.zeros(8)
+        self.lib.orc_sim_history(self.h, dp(out))
+        return out
+
+    def linear_wave_errors(self):
+        l1, mx = np.zeros(5), np.zeros(5)
+        rms = self.lib.orc_linear_wave_errors(self.h, *self._lw, dp(l1), dp(mx))
+        return rms, l1, mx
+
+    def gather_cons(self):
+        out = np.zeros((self.geom.nvar, self.nx[2], self.nx[1], self.nx[0]))
+        self.lib.orc_sim_gather_cons(self.h, dp(out))
+        return out

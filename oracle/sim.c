@@ -1,0 +1,620 @@
+/*
+ * sim.c -- ORACLE (test infrastructure only; see apk_oracle.h).
+ * Mini-driver reproducing the per-stage ordering of HydroDriver::MakeTaskCollection
+ * (src/hydro/hydro_driver.cpp:347-673) on a uniform mesh of equal meshblocks, plus the
+ * Parthenon-side semantics it depends on (un-vendored => unpinned):
+ * low-storage integrator coefficients, dt control, ghost fill order, cell centres.
+ */
+#include "apk_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define DBL_HUGE 1.7976931348623157e308
+
+struct orc_sim {
+  orc_sim_params p;
+  orc_geom g;
+  int nb[3], nblocks;
+  long nper; /* doubles per field per block */
+  double **cons, **prim, **u1, **flux[3];
+  double time, dt, c_h, mindx, dt_hyp;
+  int ncycle;
+  long fofc_total;
+  /* linear wave state (src/pgen/linear_wave.cpp globals) */
+  double lw_sin_a2, lw_cos_a2, lw_sin_a3, lw_cos_a3, lw_kpar, lw_lambda;
+  double lw_d0, lw_p0, lw_u0, lw_gam, lw_gm1, lw_ev[5], lw_rem[5][5];
+};
+
+/* SURVEY.md App. A.2 */
+int orc_integrator_coeffs(int integrator, double *beta, double *gam0, double *gam1) {
+  switch (integrator) {
+  case ORC_INT_RK1:
+    beta[0] = 1.0; gam0[0] = 0.0; gam1[0] = 1.0;
+    return 1;
+  case ORC_INT_RK2:
+    beta[0] = 1.0; gam0[0] = 0.0; gam1[0] = 1.0;
+    beta[1] = 0.5; gam0[1] = 0.5; gam1[1] = 0.5;
+    return 2;
+  case ORC_INT_VL2:
+    beta[0] = 0.5; gam0[0] = 0.0; gam1[0] = 1.0;
+    beta[1] = 1.0; gam0[1] = 0.0; gam1[1] = 1.0;
+    return 2;
+  case ORC_INT_RK3:
+    beta[0] = 1.0;       gam0[0] = 0.0;       gam1[0] = 1.0;
+    beta[1] = 0.25;      gam0[1] = 0.25;      gam1[1] = 0.75;
+    beta[2] = 2.0 / 3.0; gam0[2] = 2.0 / 3.0; gam1[2] = 1.0 / 3.0;
+    return 3;
+  default:
+    return 0;
+  }
+}
+
+orc_sim *orc_sim_create(const orc_sim_params *p) {
+  orc_sim *s = (orc_sim *)calloc(1, sizeof(orc_sim));
+  s->p = *p;
+  for (int d = 0; d < 3; ++d) {
+    if (p->nx[d] % p->mb[d] != 0) {
+      free(s);
+      return NULL;
+    }
+    s->nb[d] = p->nx[d] / p->mb[d];
+    s->g.nx[d] = p->mb[d];
+    s->g.dx[d] = (p->xmax[d] - p->xmin[d]) / (double)p->nx[d];
+  }
+  s->g.ng = p->ng;
+  s->g.nhydro = (p->fluid == ORC_FLUID_EULER) ? ORC_NHYDRO : ORC_NGLMMHD;
+  s->g.nvar = s->g.nhydro + p->nscalars;
+  s->nblocks = s->nb[0] * s->nb[1] * s->nb[2];
+  s->nper = orc_ncell(&s->g) * s->g.nvar;
+  s->cons = (double **)calloc(s->nblocks, sizeof(double *));
+  s->prim = (double **)calloc(s->nblocks, sizeof(double *));
+  s->u1 = (double **)calloc(s->nblocks, sizeof(double *));
+  for (int d = 0; d < 3; ++d) s->flux[d] = (double **)calloc(s->nblocks, sizeof(double *));
+  for (int b = 0; b < s->nblocks; ++b) {
+    s->cons[b] = (double *)calloc(s->nper, sizeof(double));
+    s->prim[b] = (double *)calloc(s->nper, sizeof(double));
+    s->u1[b] = (double *)calloc(s->nper, sizeof(double));
+    for (int d = 0; d < 3; ++d) s->flux[d][b] = (double *)calloc(s->nper, sizeof(double));
+  }
+  s->mindx = DBL_HUGE;
+  s->dt_hyp = DBL_HUGE;
+  s->dt = DBL_HUGE;
+#ifdef _OPENMP
+  if (p->nthreads > 0) omp_set_num_threads(p->nthreads);
+#endif
+  return s;
+}
+
+void orc_sim_destroy(orc_sim *s) {
+  if (!s) return;
+  for (int b = 0; b < s->nblocks; ++b) {
+    free(s->cons[b]);
+    free(s->prim[b]);
+    free(s->u1[b]);
+    for (int d = 0; d < 3; ++d) free(s->flux[d][b]);
+  }
+  free(s->cons);
+  free(s->prim);
+  free(s->u1);
+  for (int d = 0; d < 3; ++d) free(s->flux[d]);
+  free(s);
+}
+
+int orc_sim_nblocks(const orc_sim *s) { return s->nblocks; }
+void orc_sim_block_geom(const orc_sim *s, orc_geom *g) { *g = s->g; }
+double *orc_sim_cons(orc_sim *s, int b) { return s->cons[b]; }
+double *orc_sim_prim(orc_sim *s, int b) { return s->prim[b]; }
+double orc_sim_time(const orc_sim *s) { return s->time; }
+double orc_sim_dt(const orc_sim *s) { return s->dt; }
+double orc_sim_c_h(const orc_sim *s) { return s->c_h; }
+long orc_sim_fofc_count(const orc_sim *s) { return s->fofc_total; }
+
+static void block_coords(const orc_sim *s, int b, int bc[3]) {
+  bc[0] = b % s->nb[0];
+  bc[1] = (b / s->nb[0]) % s->nb[1];
+  bc[2] = b / (s->nb[0] * s->nb[1]);
+}
+
+/* x0[d] carries the GLOBAL index of the block's first interior cell (as a double) so that
+ * cell centres depend on the global cell index only, not on the block decomposition. */
+void orc_sim_block_origin(const orc_sim *s, int b, double x0[3]) {
+  int bc[3];
+  block_coords(s, b, bc);
+  for (int d = 0; d < 3; ++d) x0[d] = (double)(bc[d] * s->p.mb[d]);
+}
+
+/* cell centre: Xc = xmin + (global_index + 1/2) dx */
+static inline double xc(const orc_sim *s, const double x0[3], int d, int idx) {
+  const int ng = (s->g.nx[d] > 1) ? s->g.ng : 0;
+  return s->p.xmin[d] + ((x0[d] + (double)(idx - ng)) + 0.5) * s->g.dx[d];
+}
+
+typedef struct {
+  int is, ie, js, je, ks, ke, ni, nj, nk;
+  long sj, sk, sn;
+} sb_t;
+
+static sb_t sim_bounds(const orc_geom *g) {
+  sb_t b;
+  b.ni = orc_ni(g);
+  b.nj = orc_nj(g);
+  b.nk = orc_nk(g);
+  b.is = g->ng;
+  b.ie = g->ng + g->nx[0] - 1;
+  b.js = (g->nx[1] > 1) ? g->ng : 0;
+  b.je = (g->nx[1] > 1) ? g->ng + g->nx[1] - 1 : 0;
+  b.ks = (g->nx[2] > 1) ? g->ng : 0;
+  b.ke = (g->nx[2] > 1) ? g->ng + g->nx[2] - 1 : 0;
+  b.sj = b.ni;
+  b.sk = (long)b.ni * b.nj;
+  b.sn = b.sk * b.nk;
+  return b;
+}
+
+#define SAT(arr, n, k, j, i) (arr)[(n)*bb.sn + (k)*bb.sk + (j)*bb.sj + (i)]
+
+/* ---------------------------------------------------------------------------------------
+ * Ghost fill (Parthenon bvals, un-vendored):
+ * (1) every ghost cell whose global index lies inside the mesh (after periodic wrap) is
+ *     copied from the owning block's interior;
+ * (2) physical (non-periodic) boundaries are then applied in the order inner_x1, outer_x1,
+ *     inner_x2, outer_x2, inner_x3, outer_x3, each over the ENTIRE transverse extent. */
+void orc_sim_exchange_ghosts(orc_sim *s) {
+  const sb_t bb = sim_bounds(&s->g);
+  const int ng = s->g.ng;
+  const int nvar = s->g.nvar;
+  const int act[3] = {1, s->g.nx[1] > 1, s->g.nx[2] > 1};
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < s->nblocks; ++b) {
+    int bc[3];
+    block_coords(s, b, bc);
+    double *u = s->cons[b];
+    for (int k = 0; k < bb.nk; ++k)
+      for (int j = 0; j < bb.nj; ++j)
+        for (int i = 0; i < bb.ni; ++i) {
+          const int loc[3] = {i, j, k};
+          int interior = 1, ok = 1;
+          int src_b[3], src_l[3];
+          for (int d = 0; d < 3; ++d) {
+            if (!act[d]) {
+              src_b[d] = 0;
+              src_l[d] = 0;
+              continue;
+            }
+            const int li = loc[d] - ng; /* block-local interior index */
+            if (li < 0 || li >= s->p.mb[d]) interior = 0;
+            int gi = bc[d] * s->p.mb[d] + li;
+            if (gi < 0 || gi >= s->p.nx[d]) {
+              const int periodic = (gi < 0) ? (s->p.bc_inner[d] == ORC_BC_PERIODIC)
+                                            : (s->p.bc_outer[d] == ORC_BC_PERIODIC);
+              if (!periodic) {
+                ok = 0;
+                break;
+              }
+              gi = ((gi % s->p.nx[d]) + s->p.nx[d]) % s->p.nx[d];
+            }
+            src_b[d] = gi / s->p.mb[d];
+            src_l[d] = gi % s->p.mb[d] + ng;
+          }
+          if (interior || !ok) continue;
+          const int sb = src_b[0] + s->nb[0] * (src_b[1] + s->nb[1] * src_b[2]);
+          const double *v = s->cons[sb];
+          for (int n = 0; n < nvar; ++n)
+            SAT(u, n, k, j, i) = SAT(v, n, src_l[2], src_l[1], src_l[0]);
+        }
+  }
+  /* physical boundaries: outflow = copy last active cell (docs/input.md:416-419) */
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < s->nblocks; ++b) {
+    int bc[3];
+    block_coords(s, b, bc);
+    double *u = s->cons[b];
+    const int lo[3] = {bb.is, bb.js, bb.ks};
+    const int hi[3] = {bb.ie, bb.je, bb.ke};
+    const int ext[3] = {bb.ni, bb.nj, bb.nk};
+    for (int d = 0; d < 3; ++d) {
+      if (!act[d]) continue;
+      for (int side = 0; side < 2; ++side) {
+        const int at_edge = side ? (bc[d] == s->nb[d] - 1) : (bc[d] == 0);
+        const int kind = side ? s->p.bc_outer[d] : s->p.bc_inner[d];
+        if (!at_edge || kind == ORC_BC_PERIODIC) continue;
+        const int g0 = side ? hi[d] + 1 : 0;
+        const int g1 = side ? ext[d] - 1 : lo[d] - 1;
+        for (int n = 0; n < nvar; ++n)
+          for (int k = 0; k < bb.nk; ++k)
+            for (int j = 0; j < bb.nj; ++j)
+              for (int i = 0; i < bb.ni; ++i) {
+                const int loc[3] = {i, j, k};
+                if (loc[d] < g0 || loc[d] > g1) continue;
+                int src[3] = {i, j, k};
+                double sign = 1.0;
+                if (kind == ORC_BC_OUTFLOW) {
+                  src[d] = side ? hi[d] : lo[d];
+                } else { /* reflecting: src/bvals/boundary_conditions_apk.hpp:38-85 */
+                  src[d] = side ? (2 * hi[d] + 1 - loc[d]) : (2 * lo[d] - 1 - loc[d]);
+                  if (n == ORC_IM1 + d) sign = -1.0;
+                }
+                SAT(u, n, k, j, i) = sign * SAT(u, n, src[2], src[1], src[0]);
+              }
+      }
+    }
+  }
+}
+
+void orc_sim_fill_derived(orc_sim *s) {
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < s->nblocks; ++b)
+    orc_cons_to_prim(&s->g, s->p.fluid, &s->p.eos, s->cons[b], s->prim[b]);
+}
+
+/* Hydro::EstimateTimestep over all blocks (hydro.cpp:913-977, hyperbolic part only) */
+static double estimate_timestep(orc_sim *s) {
+  double m = DBL_HUGE;
+#pragma omp parallel for schedule(static) reduction(min : m)
+  for (int b = 0; b < s->nblocks; ++b) {
+    const double v = orc_estimate_dt_hyp(&s->g, s->p.fluid, &s->p.eos, s->prim[b]);
+    if (v < m) m = v;
+  }
+  const double dt = s->p.cfl * m;
+  if (s->p.fluid == ORC_FLUID_GLMMHD) {
+    if (dt < s->dt_hyp) s->dt_hyp = dt; /* hydro.cpp:903-908 */
+  }
+  return dt;
+}
+
+/* EvolutionDriver::SetGlobalTimeStep */
+static void set_global_dt(orc_sim *s, double dt_est, double tlim) {
+  double dt = s->dt;
+  if (dt < 0.1 * DBL_HUGE) dt *= 2.0;
+  if (dt_est < dt) dt = dt_est;
+  if (s->time < tlim && (tlim - s->time) < dt) dt = tlim - s->time;
+  s->dt = dt;
+}
+
+void orc_sim_initialize(orc_sim *s) {
+  orc_sim_exchange_ghosts(s);
+  orc_sim_fill_derived(s);
+  const double est = estimate_timestep(s);
+  s->time = 0.0;
+  s->ncycle = 0;
+  s->dt = DBL_HUGE;
+  set_global_dt(s, est, DBL_HUGE);
+}
+
+/* Hydro::PreStepMeshUserWorkInLoop (hydro.cpp:102-143) */
+static void pre_step(orc_sim *s) {
+  if (s->p.fluid != ORC_FLUID_GLMMHD) return;
+  double mindx = s->g.dx[0];
+  if (s->g.nx[1] > 1) mindx = fmin(mindx, s->g.dx[1]);
+  if (s->g.nx[2] > 1) mindx = fmin(mindx, s->g.dx[2]);
+  s->mindx = mindx;
+  s->c_h = s->p.cfl * s->mindx / s->dt_hyp;
+}
+
+double orc_sim_step(orc_sim *s, double tlim) {
+  double beta[4], gam0[4], gam1[4];
+  const int nstages = orc_integrator_coeffs(s->p.integrator, beta, gam0, gam1);
+  if (s->time < tlim && (tlim - s->time) < s->dt) s->dt = tlim - s->time;
+  pre_step(s);
+  const double dt = s->dt;
+  for (int stage = 1; stage <= nstages; ++stage) {
+    const double g0 = gam0[stage - 1], g1 = gam1[stage - 1];
+    const double beta_dt = beta[stage - 1] * dt;
+    /* vl2 predictor uses donor cell with the same Riemann solver (hydro.cpp:457-463) */
+    const int recon =
+        (stage == 1 && s->p.integrator == ORC_INT_VL2) ? ORC_RC_DC : s->p.recon;
+    long fofc = 0;
+#pragma omp parallel for schedule(static) reduction(+ : fofc)
+    for (int b = 0; b < s->nblocks; ++b) {
+      if (stage == 1) memcpy(s->u1[b], s->cons[b], sizeof(double) * s->nper);
+      if (s->p.riemann == ORC_RS_LLF) {
+        orc_calculate_fluxes_tight(&s->g, s->p.fluid, &s->p.eos, s->c_h, s->prim[b],
+                                   s->flux[0][b], s->flux[1][b], s->flux[2][b]);
+      } else {
+        orc_calculate_fluxes(&s->g, s->p.fluid, recon, s->p.riemann, &s->p.eos, s->c_h,
+                             s->prim[b], s->flux[0][b], s->flux[1][b], s->flux[2][b]);
+      }
+      if (s->p.first_order_flux_correct) {
+        fofc += orc_first_order_flux_correct(&s->g, s->p.fluid, &s->p.eos, s->c_h, s->cons[b],
+                                             s->prim[b], s->u1[b], s->flux[0][b],
+                                             s->flux[1][b], s->flux[2][b], g0, g1, beta_dt);
+      }
+      orc_update_flux_div(&s->g, s->cons[b], s->u1[b], s->flux[0][b], s->flux[1][b],
+                          s->flux[2][b], g0, g1, beta_dt);
+      if (s->p.fluid == ORC_FLUID_GLMMHD) {
+        orc_dedner_source(&s->g, s->p.dedner_extended, s->p.glmmhd_alpha, s->c_h, s->mindx,
+                          beta_dt, s->cons[b], s->prim[b]);
+      }
+    }
+    s->fofc_total += fofc;
+    orc_sim_exchange_ghosts(s);
+    orc_sim_fill_derived(s);
+    if (stage == nstages) {
+      /* reset reduction params (hydro_driver.cpp:589-603) then EstimateTimestep */
+      if (s->p.fluid == ORC_FLUID_GLMMHD) {
+        s->mindx = DBL_HUGE;
+        s->dt_hyp = DBL_HUGE;
+      }
+    }
+  }
+  s->time += dt;
+  s->ncycle += 1;
+  const double est = estimate_timestep(s);
+  set_global_dt(s, est, tlim);
+  return dt;
+}
+
+int orc_sim_run(orc_sim *s, double tlim, int nlim) {
+  int n = 0;
+  while (s->time < tlim && (nlim < 0 || n < nlim)) {
+    orc_sim_step(s, tlim);
+    ++n;
+  }
+  return n;
+}
+
+void orc_sim_history(orc_sim *s, double *out8) {
+  for (int q = 0; q < 8; ++q) out8[q] = 0.0;
+  for (int b = 0; b < s->nblocks; ++b) {
+    double o[8];
+    orc_history(&s->g, s->p.fluid, s->cons[b], o);
+    for (int q = 0; q < 8; ++q) out8[q] += o[q];
+  }
+}
+
+void orc_sim_gather_cons(orc_sim *s, double *out) {
+  const sb_t bb = sim_bounds(&s->g);
+  const long NX = s->p.nx[0], NY = s->p.nx[1], NZ = s->p.nx[2];
+  for (int b = 0; b < s->nblocks; ++b) {
+    int bc[3];
+    block_coords(s, b, bc);
+    for (int n = 0; n < s->g.nvar; ++n)
+      for (int k = bb.ks; k <= bb.ke; ++k)
+        for (int j = bb.js; j <= bb.je; ++j)
+          for (int i = bb.is; i <= bb.ie; ++i) {
+            const long gi = bc[0] * s->p.mb[0] + (i - bb.is);
+            const long gj = bc[1] * s->p.mb[1] + (j - bb.js);
+            const long gk = bc[2] * s->p.mb[2] + (k - bb.ks);
+            out[((n * NZ + gk) * NY + gj) * NX + gi] = SAT(s->cons[b], n, k, j, i);
+          }
+  }
+}
+
+/* ------------------------- problem generators ------------------------------------------ */
+
+/* hydro eigensystem, src/pgen/linear_wave.cpp:421-500 (only ev and rem are needed) */
+static void lw_eigensystem(double gm1, double v1, double v2, double v3, double h,
+                           double ev[5], double rem[5][5]) {
+  const double vsq = v1 * v1 + v2 * v2 + v3 * v3;
+  const double asq = gm1 * fmax((h - 0.5 * vsq), ORC_TINY_NUMBER);
+  const double a = sqrt(asq);
+  ev[0] = v1 - a;
+  ev[1] = v1;
+  ev[2] = v1;
+  ev[3] = v1;
+  ev[4] = v1 + a;
+  const double col[5][5] = {{1.0, v1 - a, v2, v3, h - v1 * a},
+                            {0.0, 0.0, 1.0, 0.0, v2},
+                            {0.0, 0.0, 0.0, 1.0, v3},
+                            {1.0, v1, v2, v3, 0.5 * vsq},
+                            {1.0, v1 + a, v2, v3, h + v1 * a}};
+  for (int c = 0; c < 5; ++c)
+    for (int r = 0; r < 5; ++r) rem[r][c] = col[c][r];
+}
+
+/* src/pgen/linear_wave.cpp:72-176 (InitUserMeshData) */
+static void lw_setup(orc_sim *s, double vflow) {
+  const double x1size = s->p.xmax[0] - s->p.xmin[0];
+  const double x2size = s->p.xmax[1] - s->p.xmin[1];
+  const double x3size = s->p.xmax[2] - s->p.xmin[2];
+  s->lw_gam = s->p.eos.gamma;
+  s->lw_gm1 = s->lw_gam - 1.0;
+  double ang_3 = atan(x1size / x2size);
+  s->lw_sin_a3 = sin(ang_3);
+  s->lw_cos_a3 = cos(ang_3);
+  double ang_2 = atan(0.5 * (x1size * s->lw_cos_a3 + x2size * s->lw_sin_a3) / x3size);
+  s->lw_sin_a2 = sin(ang_2);
+  s->lw_cos_a2 = cos(ang_2);
+  const double x1 = x1size * s->lw_cos_a2 * s->lw_cos_a3;
+  const double x2 = x2size * s->lw_cos_a2 * s->lw_sin_a3;
+  const double x3 = x3size * s->lw_sin_a2;
+  const int f2 = (s->p.nx[1] > 1) ? 1 : 0;
+  const int f3 = (s->p.nx[2] > 1) ? 1 : 0;
+  double lambda = x1;
+  if (f2 && ang_3 != 0.0) lambda = fmin(lambda, x2);
+  if (f3 && ang_2 != 0.0) lambda = fmin(lambda, x3);
+  s->lw_lambda = lambda;
+  s->lw_kpar = 2.0 * (M_PI) / lambda;
+  s->lw_d0 = 1.0;
+  s->lw_u0 = vflow;
+  s->lw_p0 = 1.0 / s->lw_gam;
+  const double v0 = 0.0, w0 = 0.0;
+  const double h0 = ((s->lw_p0 / s->lw_gm1 +
+                      0.5 * s->lw_d0 * (s->lw_u0 * s->lw_u0 + v0 * v0 + w0 * w0)) +
+                     s->lw_p0) /
+                    s->lw_d0;
+  lw_eigensystem(s->lw_gm1, s->lw_u0, v0, w0, h0, s->lw_ev, s->lw_rem);
+}
+
+/* analytic conserved state at a cell centre (linear_wave.cpp:355-373 == :206-226) */
+static void lw_state(const orc_sim *s, int wave_flag, double amp, double vflow, double x1,
+                     double x2, double x3, double u[5]) {
+  const double x = s->lw_cos_a2 * (x1 * s->lw_cos_a3 + x2 * s->lw_sin_a3) + x3 * s->lw_sin_a2;
+  const double sn = sin(s->lw_kpar * x);
+  u[ORC_IDN] = s->lw_d0 + amp * sn * s->lw_rem[0][wave_flag];
+  const double mx = s->lw_d0 * vflow + amp * sn * s->lw_rem[1][wave_flag];
+  const double my = amp * sn * s->lw_rem[2][wave_flag];
+  const double mz = amp * sn * s->lw_rem[3][wave_flag];
+  u[ORC_IM1] = mx * s->lw_cos_a2 * s->lw_cos_a3 - my * s->lw_sin_a3 -
+               mz * s->lw_sin_a2 * s->lw_cos_a3;
+  u[ORC_IM2] = mx * s->lw_cos_a2 * s->lw_sin_a3 + my * s->lw_cos_a3 -
+               mz * s->lw_sin_a2 * s->lw_sin_a3;
+  u[ORC_IM3] = mx * s->lw_sin_a2 + mz * s->lw_cos_a2;
+  u[ORC_IEN] = s->lw_p0 / s->lw_gm1 + 0.5 * s->lw_d0 * s->lw_u0 * s->lw_u0 +
+               amp * sn * s->lw_rem[4][wave_flag];
+}
+
+double orc_pgen_linear_wave(orc_sim *s, int wave_flag, double amp, double vflow) {
+  lw_setup(s, vflow);
+  const sb_t bb = sim_bounds(&s->g);
+  for (int b = 0; b < s->nblocks; ++b) {
+    double x0[3];
+    orc_sim_block_origin(s, b, x0);
+    for (int k = bb.ks; k <= bb.ke; ++k)
+      for (int j = bb.js; j <= bb.je; ++j)
+        for (int i = bb.is; i <= bb.ie; ++i) {
+          double u[5];
+          lw_state(s, wave_flag, amp, vflow, xc(s, x0, 0, i), xc(s, x0, 1, j),
+                   xc(s, x0, 2, k), u);
+          for (int n = 0; n < 5; ++n) SAT(s->cons[b], n, k, j, i) = u[n];
+        }
+  }
+  /* "test = true": tlim is reinterpreted as number of periods (linear_wave.cpp:169-175) */
+  return s->lw_lambda / fabs(s->lw_ev[wave_flag]);
+}
+
+/* src/pgen/linear_wave.cpp:183-335 */
+double orc_linear_wave_errors(orc_sim *s, int wave_flag, double amp, double vflow, double *l1,
+                              double *maxerr) {
+  const sb_t bb = sim_bounds(&s->g);
+  const double cellvol = s->g.dx[0] * s->g.dx[1] * s->g.dx[2];
+  for (int n = 0; n < 5; ++n) l1[n] = maxerr[n] = 0.0;
+  for (int b = 0; b < s->nblocks; ++b) {
+    double x0[3];
+    orc_sim_block_origin(s, b, x0);
+    for (int k = bb.ks; k <= bb.ke; ++k)
+      for (int j = bb.js; j <= bb.je; ++j)
+        for (int i = bb.is; i <= bb.ie; ++i) {
+          double u[5];
+          lw_state(s, wave_flag, amp, vflow, xc(s, x0, 0, i), xc(s, x0, 1, j),
+                   xc(s, x0, 2, k), u);
+          for (int n = 0; n < 5; ++n) {
+            const double e = fabs(u[n] - SAT(s->cons[b], n, k, j, i));
+            l1[n] += e * cellvol;
+            if (e > maxerr[n]) maxerr[n] = e;
+          }
+        }
+  }
+  const double vol = (s->p.xmax[0] - s->p.xmin[0]) * (s->p.xmax[1] - s->p.xmin[1]) *
+                     (s->p.xmax[2] - s->p.xmin[2]);
+  double rms = 0.0;
+  for (int n = 0; n < 5; ++n) {
+    l1[n] = l1[n] / vol;
+    rms += l1[n] * l1[n];
+  }
+  return sqrt(rms);
+}
+
+/* src/pgen/sod.cpp:17-51 */
+void orc_pgen_sod(orc_sim *s, double rho_l, double pres_l, double u_l, double rho_r,
+                  double pres_r, double u_r, double x_discont) {
+  const sb_t bb = sim_bounds(&s->g);
+  const double gamma = s->p.eos.gamma;
+  for (int b = 0; b < s->nblocks; ++b) {
+    double x0[3];
+    orc_sim_block_origin(s, b, x0);
+    for (int k = bb.ks; k <= bb.ke; ++k)
+      for (int j = bb.js; j <= bb.je; ++j)
+        for (int i = bb.is; i <= bb.ie; ++i) {
+          double *u = s->cons[b];
+          if (xc(s, x0, 0, i) < x_discont) {
+            SAT(u, ORC_IDN, k, j, i) = rho_l;
+            SAT(u, ORC_IM1, k, j, i) = rho_l * u_l;
+            SAT(u, ORC_IEN, k, j, i) = 0.5 * rho_l * u_l * u_l + pres_l / (gamma - 1.0);
+          } else {
+            SAT(u, ORC_IDN, k, j, i) = rho_r;
+            SAT(u, ORC_IM1, k, j, i) = rho_r * u_r;
+            SAT(u, ORC_IEN, k, j, i) = 0.5 * rho_r * u_r * u_r + pres_r / (gamma - 1.0);
+          }
+        }
+  }
+}
+
+/* src/pgen/orszag_tang.cpp:25-63 */
+void orc_pgen_orszag_tang(orc_sim *s) {
+  const sb_t bb = sim_bounds(&s->g);
+  const double gm1 = s->p.eos.gamma - 1.0;
+  const double B0 = 1.0 / sqrt(4.0 * M_PI);
+  const double d0 = 25.0 / (36.0 * M_PI);
+  const double v0 = 1.0;
+  const double p0 = 5.0 / (12.0 * M_PI);
+  for (int b = 0; b < s->nblocks; ++b) {
+    double x0[3];
+    orc_sim_block_origin(s, b, x0);
+    double *u = s->cons[b];
+    for (int k = bb.ks; k <= bb.ke; ++k)
+      for (int j = bb.js; j <= bb.je; ++j)
+        for (int i = bb.is; i <= bb.ie; ++i) {
+          const double x1 = xc(s, x0, 0, i), x2 = xc(s, x0, 1, j);
+          SAT(u, ORC_IDN, k, j, i) = d0;
+          SAT(u, ORC_IM1, k, j, i) = d0 * v0 * sin(2.0 * M_PI * x2);
+          SAT(u, ORC_IM2, k, j, i) = -d0 * v0 * sin(2.0 * M_PI * x1);
+          SAT(u, ORC_IM3, k, j, i) = 0.0;
+          SAT(u, ORC_IB1, k, j, i) = B0 * sin(2.0 * M_PI * x2);
+          SAT(u, ORC_IB2, k, j, i) = B0 * sin(4.0 * M_PI * x1);
+          SAT(u, ORC_IB3, k, j, i) = 0.0;
+          const double b1 = SAT(u, ORC_IB1, k, j, i), b2 = SAT(u, ORC_IB2, k, j, i),
+                       b3 = SAT(u, ORC_IB3, k, j, i);
+          const double m1 = SAT(u, ORC_IM1, k, j, i), m2 = SAT(u, ORC_IM2, k, j, i),
+                       m3 = SAT(u, ORC_IM3, k, j, i);
+          SAT(u, ORC_IEN, k, j, i) =
+              p0 / gm1 + 0.5 * (b1 * b1 + b2 * b2 + b3 * b3 +
+                                (m1 * m1 + m2 * m2 + m3 * m3) / SAT(u, ORC_IDN, k, j, i));
+        }
+  }
+}
+
+/* Analytic, seedless smooth state for the synthetic kernel benchmark:
+ * rho = 1+0.2 sin, p = 1+0.1 cos, |v| <= 0.3, |B| <= 0.5, psi = 0.01 sin; periodic in the
+ * mesh.  Arguments are fractions of the domain so that the field is exactly periodic. */
+void orc_pgen_synthetic(orc_sim *s) {
+  const sb_t bb = sim_bounds(&s->g);
+  const double gm1 = s->p.eos.gamma - 1.0;
+  const int mhd = (s->p.fluid == ORC_FLUID_GLMMHD);
+  const double tp = 2.0 * M_PI;
+  for (int b = 0; b < s->nblocks; ++b) {
+    double x0[3];
+    orc_sim_block_origin(s, b, x0);
+    double *u = s->cons[b];
+    for (int k = bb.ks; k <= bb.ke; ++k)
+      for (int j = bb.js; j <= bb.je; ++j)
+        for (int i = bb.is; i <= bb.ie; ++i) {
+          const double fx = (xc(s, x0, 0, i) - s->p.xmin[0]) / (s->p.xmax[0] - s->p.xmin[0]);
+          const double fy = (xc(s, x0, 1, j) - s->p.xmin[1]) / (s->p.xmax[1] - s->p.xmin[1]);
+          const double fz = (xc(s, x0, 2, k) - s->p.xmin[2]) / (s->p.xmax[2] - s->p.xmin[2]);
+          const double rho = 1.0 + 0.2 * sin(tp * (fx + fy + fz));
+          const double p = 1.0 + 0.1 * cos(tp * (fx - fy + 2.0 * fz));
+          const double v1 = 0.17 * sin(tp * (fy + fz));
+          const double v2 = 0.17 * cos(tp * (fx - fz));
+          const double v3 = 0.17 * sin(tp * (2.0 * fx + fy));
+          double b1 = 0.0, b2 = 0.0, b3 = 0.0, psi = 0.0;
+          if (mhd) {
+            b1 = 0.28 * cos(tp * (fy - fz));
+            b2 = 0.28 * sin(tp * (fx + 2.0 * fz));
+            b3 = 0.28 * cos(tp * (fx + fy));
+            psi = 0.01 * sin(tp * (fx + fy - fz));
+          }
+          SAT(u, ORC_IDN, k, j, i) = rho;
+          SAT(u, ORC_IM1, k, j, i) = rho * v1;
+          SAT(u, ORC_IM2, k, j, i) = rho * v2;
+          SAT(u, ORC_IM3, k, j, i) = rho * v3;
+          double e = p / gm1 + 0.5 * rho * (v1 * v1 + v2 * v2 + v3 * v3);
+          if (mhd) {
+            e += 0.5 * (b1 * b1 + b2 * b2 + b3 * b3);
+            SAT(u, ORC_IB1, k, j, i) = b1;
+            SAT(u, ORC_IB2, k, j, i) = b2;
+            SAT(u, ORC_IB3, k, j, i) = b3;
+            SAT(u, ORC_IPS, k, j, i) = psi;
+          }
+          SAT(u, ORC_IEN, k, j, i) = e;
+          for (int n = s->g.nhydro; n < s->g.nvar; ++n)
+            SAT(u, n, k, j, i) = rho * (0.5 + 0.25 * sin(tp * (fx + (n - s->g.nhydro + 1) * fy)));
+        }
+  }
+}
