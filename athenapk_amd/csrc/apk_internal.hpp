@@ -70,6 +70,18 @@ struct apk_ctx {
   unsigned char *d_mark = nullptr;   // FOFC cell marks
   size_t mark_cap = 0;
   void *h_pinned = nullptr;          // 256 B pinned host staging
+  double *d_du = nullptr;            // fused path: flux-difference accumulator
+  size_t du_cap = 0;                 // in doubles
+  // optional kernel timing (apk_kernel_timing_*)
+  bool timing_on = false;
+  struct TimedSpan {
+    int slot;
+    hipEvent_t start, stop;
+  };
+  std::vector<TimedSpan> spans;       // recorded, not yet read
+  std::vector<hipEvent_t> free_events;
+  double timing_ms[APK_T_COUNT] = {0};
+  long long timing_n[APK_T_COUNT] = {0};
   char err[512] = {0};
 };
 
@@ -128,8 +140,36 @@ int launch_fofc_fix(const PackView &u0, int fluid, double gamma, double c_h,
                     const unsigned char *d_mark, hipStream_t s);
 int launch_copy_regions(const apk_copy_region *d_regions, int n, int64_t max_cells,
                         hipStream_t s);
-// fused stage path (kernels_fused.hip)
-int launch_stage_fused(const PackView &u0, const PackView &u1, const apk_stage_args &a,
-                       double dedner_coeff, hipStream_t s);
+// fused stage path (fused_dispatch.hip)
+int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
+                       const apk_stage_args &a, double dedner_coeff, hipStream_t s);
+
+// RAII span: records start/stop events around the launches issued in its scope
+struct ScopedTiming {
+  apk_ctx *ctx;
+  hipStream_t s;
+  int idx = -1;
+  ScopedTiming(apk_ctx *c, int slot, hipStream_t st) : ctx(c), s(st) {
+    if (!ctx || !ctx->timing_on) return;
+    auto grab = [&]() {
+      hipEvent_t e = nullptr;
+      if (!ctx->free_events.empty()) {
+        e = ctx->free_events.back();
+        ctx->free_events.pop_back();
+      } else if (hipEventCreate(&e) != hipSuccess) {
+        e = nullptr;
+      }
+      return e;
+    };
+    apk_ctx::TimedSpan sp{slot, grab(), grab()};
+    if (!sp.start || !sp.stop) return;
+    (void)hipEventRecord(sp.start, s);
+    ctx->spans.push_back(sp);
+    idx = (int)ctx->spans.size() - 1;
+  }
+  ~ScopedTiming() {
+    if (idx >= 0) (void)hipEventRecord(ctx->spans[idx].stop, s);
+  }
+};
 
 }  // namespace apk

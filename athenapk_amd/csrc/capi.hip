@@ -120,7 +120,13 @@ void apk_destroy(apk_ctx *ctx) {
   if (ctx->d_u64) (void)hipFree(ctx->d_u64);
   if (ctx->d_partial) (void)hipFree(ctx->d_partial);
   if (ctx->d_mark) (void)hipFree(ctx->d_mark);
+  if (ctx->d_du) (void)hipFree(ctx->d_du);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  for (auto &sp : ctx->spans) {
+    (void)hipEventDestroy(sp.start);
+    (void)hipEventDestroy(sp.stop);
+  }
+  for (auto e : ctx->free_events) (void)hipEventDestroy(e);
   delete ctx;
 }
 
@@ -179,6 +185,7 @@ int apk_calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, con
     if (!b.prim) return set_err(ctx, APK_ERR_INVALID, "block without prim pointer");
   hipStream_t s = as_stream(stream);
   const PackView &pv = md->view;
+  ScopedTiming timing(ctx, APK_T_FLUXES, s);
   if (cfg.riemann == APK_RS_NONE || cfg.riemann == APK_RS_LLF)
     rc = launch_fluxes_misc(pv, cfg.fluid, cfg.riemann, eos->gamma, c_h, s);
   else if (cfg.fluid == APK_FLUID_EULER)
@@ -198,6 +205,7 @@ int apk_update_with_flux_divergence(apk_ctx *ctx, const apk_pack *u0, const apk_
     return set_err(ctx, APK_ERR_INVALID, "apk_update_with_flux_divergence: bad argument");
   for (int d = 0; d < u0->view.ndim; ++d)
     if (!u0->have_flux[d]) return set_err(ctx, APK_ERR_INVALID, "u0 pack has no flux arrays");
+  ScopedTiming timing(ctx, APK_T_UPDATE, as_stream(stream));
   int rc = launch_update_flux_div(u0->view, u1->view, gam0, gam1, beta_dt, as_stream(stream));
   if (rc != APK_OK) return set_err(ctx, rc, "update kernel launch failed", hipGetLastError());
   return APK_OK;
@@ -209,6 +217,7 @@ int apk_dedner_source(apk_ctx *ctx, const apk_pack *md, int extended, double alp
     return set_err(ctx, APK_ERR_INVALID, "apk_dedner_source: bad argument");
   // Mignone & Tzeferacos 2010 (27): dedner_source.cpp:32
   const double coeff = std::exp(-alpha * c_h * beta_dt / mindx);
+  ScopedTiming timing(ctx, APK_T_DEDNER, as_stream(stream));
   int rc = launch_dedner(md->view, extended, coeff, beta_dt, as_stream(stream));
   if (rc != APK_OK) return set_err(ctx, rc, "dedner kernel launch failed", hipGetLastError());
   return APK_OK;
@@ -226,7 +235,7 @@ int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
     return set_err(ctx, APK_ERR_INVALID, "fused stage: Dedner source needs glmmhd and mindx > 0");
   double coeff = 1.0;
   if (a->dedner != 0) coeff = std::exp(-a->glmmhd_alpha * a->c_h * a->beta_dt / a->mindx);
-  rc = launch_stage_fused(u0->view, u1->view, *a, coeff, as_stream(stream));
+  rc = launch_stage_fused(ctx, u0->view, u1->view, *a, coeff, as_stream(stream));
   if (rc != APK_OK) return set_err(ctx, rc, "fused stage kernel launch failed", hipGetLastError());
   return APK_OK;
 }
@@ -236,6 +245,7 @@ int apk_cons_to_prim(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos 
   if (!ctx || !md || !valid_eos(eos) || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||
       md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9))
     return set_err(ctx, APK_ERR_INVALID, "apk_cons_to_prim: bad argument");
+  ScopedTiming timing(ctx, APK_T_C2P, as_stream(stream));
   int rc = launch_cons_to_prim(md->view, fluid, *eos, ctx->d_flags, as_stream(stream));
   if (rc != APK_OK) return set_err(ctx, rc, "cons_to_prim kernel launch failed", hipGetLastError());
   return APK_OK;
@@ -253,7 +263,11 @@ int apk_estimate_timestep(apk_ctx *ctx, const apk_pack *md, int fluid, const apk
   auto *h = static_cast<unsigned long long *>(ctx->h_pinned);
   h[0] = bits;
   APK_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_u64, h, sizeof(bits), hipMemcpyHostToDevice, s));
-  int rc = launch_min_dt(md->view, fluid, eos->gamma, ctx->d_u64, s);
+  int rc;
+  {
+    ScopedTiming timing(ctx, APK_T_MIN_DT, s);
+    rc = launch_min_dt(md->view, fluid, eos->gamma, ctx->d_u64, s);
+  }
   if (rc != APK_OK) return set_err(ctx, rc, "min_dt kernel launch failed", hipGetLastError());
   APK_HIP_TRY(ctx, hipMemcpyAsync(h + 1, ctx->d_u64, sizeof(bits), hipMemcpyDeviceToHost, s));
   APK_HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -359,8 +373,37 @@ void apk_copy_plan_destroy(apk_copy_plan *plan) {
 
 int apk_copy_plan_run(apk_ctx *ctx, const apk_copy_plan *plan, apk_stream_t stream) {
   if (!ctx || !plan) return APK_ERR_INVALID;
+  if (plan->n <= 0) return APK_OK;
+  ScopedTiming timing(ctx, APK_T_COPY, as_stream(stream));
   int rc = launch_copy_regions(plan->d_regions, plan->n, plan->max_cells, as_stream(stream));
   if (rc != APK_OK) return set_err(ctx, rc, "copy kernel launch failed", hipGetLastError());
+  return APK_OK;
+}
+
+int apk_kernel_timing_enable(apk_ctx *ctx, int on) {
+  if (!ctx) return APK_ERR_INVALID;
+  ctx->timing_on = on != 0;
+  return APK_OK;
+}
+
+int apk_kernel_timing_read(apk_ctx *ctx, int slot, double *total_ms, long long *launches) {
+  if (!ctx || slot < 0 || slot >= APK_T_COUNT) return APK_ERR_INVALID;
+  // fold every completed span into the per-slot totals, then hand the events back
+  for (auto &sp : ctx->spans) {
+    float ms = 0.0f;
+    hipError_t e = hipEventSynchronize(sp.stop);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, sp.start, sp.stop);
+    if (e != hipSuccess) return set_err(ctx, APK_ERR_DEVICE, "apk_kernel_timing_read", e);
+    ctx->timing_ms[sp.slot] += (double)ms;
+    ctx->timing_n[sp.slot] += 1;
+    ctx->free_events.push_back(sp.start);
+    ctx->free_events.push_back(sp.stop);
+  }
+  ctx->spans.clear();
+  if (total_ms) *total_ms = ctx->timing_ms[slot];
+  if (launches) *launches = ctx->timing_n[slot];
+  ctx->timing_ms[slot] = 0.0;
+  ctx->timing_n[slot] = 0;
   return APK_OK;
 }
 

@@ -1,17 +1,11 @@
-// fused_dispatch.hip -- entry of the fused stage path: owns the du scratch array and picks
-// the (fluid, riemann) family.
+// fused_dispatch.hip -- entry of the fused stage path: sizes the du workspace of the handle
+// and picks the (fluid, riemann) family.
 #include "fused_kernel.hpp"
 
 namespace apk {
 
-namespace {
-double *g_du = nullptr;      // per-process scratch, grown on demand (never shrinks)
-size_t g_du_cap = 0;         // in doubles
-int g_du_device = -1;
-}  // namespace
-
-int launch_stage_fused(const PackView &u0, const PackView &u1, const apk_stage_args &a,
-                       double dedner_coeff, hipStream_t s) {
+int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
+                       const apk_stage_args &a, double dedner_coeff, hipStream_t s) {
   if (u0.nvar != u0.nhydro) return APK_ERR_UNSUPPORTED;  // passive scalars: flux-array path
   StageParams sp;
   sp.gamma = a.eos.gamma;
@@ -22,22 +16,20 @@ int launch_stage_fused(const PackView &u0, const PackView &u1, const apk_stage_a
   sp.dedner = a.dedner;
   sp.dedner_coeff = dedner_coeff;
   sp.du = nullptr;
+  sp.ctx = ctx;
   if (u0.ndim > 1) {
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) return APK_ERR_DEVICE;
     const size_t need = (size_t)u0.nblocks * (size_t)u0.nvar * (size_t)u0.sn;
-    if (need > g_du_cap || dev != g_du_device) {
-      if (g_du) {
-        (void)hipDeviceSynchronize();
-        (void)hipFree(g_du);
+    if (need > ctx->du_cap) {  // workspace owned by the handle, grown on demand
+      if (ctx->d_du) {
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(ctx->d_du);
       }
-      g_du = nullptr;
-      g_du_cap = 0;
-      if (hipMalloc(&g_du, need * sizeof(double)) != hipSuccess) return APK_ERR_DEVICE;
-      g_du_cap = need;
-      g_du_device = dev;
+      ctx->d_du = nullptr;
+      ctx->du_cap = 0;
+      if (hipMalloc(&ctx->d_du, need * sizeof(double)) != hipSuccess) return APK_ERR_DEVICE;
+      ctx->du_cap = need;
     }
-    sp.du = g_du;
+    sp.du = ctx->d_du;
   }
   if (a.cfg.fluid == APK_FLUID_EULER) {
     if (a.cfg.riemann == APK_RS_HLLE) return launch_fused_euler_hlle(u0, u1, a.cfg.recon, sp, s);

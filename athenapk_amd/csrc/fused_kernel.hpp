@@ -28,6 +28,7 @@ struct StageParams {
   double dedner_coeff;
   int dedner;  // 0 off, 1 plain, 2 extended
   double *du;  // scratch: [nblocks][nvar][Nk][Nj][Ni]
+  apk_ctx *ctx;  // host side only (kernel timing); never dereferenced on the device
 };
 
 // ---- DPP wave shifts (gfx9: wave_shr:1 = 0x138, wave_shl:1 = 0x130) ------------------------
@@ -265,15 +266,24 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
   const int wpp = (int)((run + 61) / 62);
   const dim3 g1((wpp + 3) / 4, u0.nx3 * u0.nblocks, 1);
   if (u0.ndim == 1) {
+    ScopedTiming t(sp.ctx, APK_T_FUSED_X1, s);
     hipLaunchKernelGGL((fused_x1_kernel<FLUID, RECON, RS, true>), g1, dim3(256), 0, s, u0, u1, sp, wpp);
   } else {
-    hipLaunchKernelGGL((fused_x1_kernel<FLUID, RECON, RS, false>), g1, dim3(256), 0, s, u0, u1, sp, wpp);
+    {
+      ScopedTiming t(sp.ctx, APK_T_FUSED_X1, s);
+      hipLaunchKernelGGL((fused_x1_kernel<FLUID, RECON, RS, false>), g1, dim3(256), 0, s, u0, u1, sp, wpp);
+    }
     const dim3 g2((u0.nx1 + 63) / 64, (u0.nx3 + 3) / 4, u0.nblocks);
     if (u0.ndim == 2) {
+      ScopedTiming t(sp.ctx, APK_T_FUSED_X2, s);
       hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 2, true>), g2, dim3(256), 0, s, u0, u1, sp);
     } else {
-      hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 2, false>), g2, dim3(256), 0, s, u0, u1, sp);
+      {
+        ScopedTiming t(sp.ctx, APK_T_FUSED_X2, s);
+        hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 2, false>), g2, dim3(256), 0, s, u0, u1, sp);
+      }
       const dim3 g3((u0.nx1 + 63) / 64, (u0.nx2 + 3) / 4, u0.nblocks);
+      ScopedTiming t(sp.ctx, APK_T_FUSED_X3, s);
       hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 3, true>), g3, dim3(256), 0, s, u0, u1, sp);
     }
   }

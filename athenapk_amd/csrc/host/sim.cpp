@@ -911,6 +911,15 @@ int apk_sim_estimate_timestep(apk_sim *s, double *dt) {
   return estimate_timestep(s, dt);
 }
 
+int apk_sim_kernel_timing_enable(apk_sim *s, int on) {
+  if (!s || s->host_only) return APK_ERR_INVALID;
+  return apk_kernel_timing_enable(s->ctx, on);
+}
+int apk_sim_kernel_timing_read(apk_sim *s, int slot, double *total_ms, long long *launches) {
+  if (!s || s->host_only) return APK_ERR_INVALID;
+  return apk_kernel_timing_read(s->ctx, slot, total_ms, launches);
+}
+
 int apk_sim_peer(const apk_sim *s, int p, apk_peer_info *o) {
   if (!s || !o || p < 0 || p >= (int)s->mesh.peers.size()) return APK_ERR_INVALID;
   o->rank = s->mesh.peers[p].rank;

@@ -208,6 +208,18 @@ class Simulation:
         self._check(self.lib.apk_sim_linear_wave_errors(self.h, C.byref(rms), l1, mx))
         return rms.value, np.array(l1[:]), np.array(mx[:])
 
+    def kernel_timing(self, on):
+        self._check(self.lib.apk_sim_kernel_timing_enable(self.h, int(on)))
+
+    def read_kernel_timing(self):
+        """{slot name: (total_ms, launches)} accumulated since the last read (HIP events)."""
+        out = {}
+        for slot, name in enumerate(L.TIMING_SLOTS):
+            ms, n = C.c_double(0.0), C.c_longlong(0)
+            self._check(self.lib.apk_sim_kernel_timing_read(self.h, slot, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
     def exchange_ghosts(self):
         self._check(self.lib.apk_sim_exchange_ghosts(self.h))
 

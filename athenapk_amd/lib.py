@@ -17,6 +17,9 @@ RECON = {"dc": 1, "plm": 2, "ppm": 3, "wenoz": 4, "weno3": 5, "limo3": 6}
 RIEMANN = {"none": 1, "hlle": 2, "llf": 3, "hllc": 4, "hlld": 5}
 INTEGRATOR = {"rk1": 1, "rk2": 2, "vl2": 3, "rk3": 4}
 
+TIMING_SLOTS = ("fused_x1", "fused_x2", "fused_x3", "fluxes", "update", "dedner", "cons_to_prim",
+                "min_dt", "copy_regions")
+
 APK_OK = 0
 APK_ERR_INVALID, APK_ERR_UNSUPPORTED, APK_ERR_NGHOST, APK_ERR_DEVICE, APK_ERR_NO_DEVICE = -1, -2, -3, -4, -5
 FLAG_NEG_DENSITY, FLAG_NEG_PRESSURE = 1, 2
@@ -126,6 +129,8 @@ def _signatures():
         "apk_copy_plan_create": (i, [vp, C.POINTER(CopyRegion), i, pp]),
         "apk_copy_plan_destroy": (None, [vp]),
         "apk_copy_plan_run": (i, [vp, vp, vp]),
+        "apk_kernel_timing_enable": (i, [vp, i]),
+        "apk_kernel_timing_read": (i, [vp, i, c_dp, C.POINTER(ll)]),
         # apk_host.h
         "apk_sim_create": (i, [C.c_char_p, strs, i, i, i, C.POINTER(Allocator), C.POINTER(CommOps),
                                vp, pp, C.c_char_p, C.c_size_t]),
@@ -153,6 +158,8 @@ def _signatures():
         "apk_sim_exchange_ghosts": (i, [vp]),
         "apk_sim_fill_derived": (i, [vp]),
         "apk_sim_estimate_timestep": (i, [vp, c_dp]),
+        "apk_sim_kernel_timing_enable": (i, [vp, i]),
+        "apk_sim_kernel_timing_read": (i, [vp, i, c_dp, C.POINTER(ll)]),
         "apk_sim_peer": (i, [vp, i, C.POINTER(PeerInfo)]),
         "apk_sim_plan_size": (i, [vp, i]),
         "apk_sim_plan_region": (i, [vp, i, i, C.POINTER(RegionInfo)]),

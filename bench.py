@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""bench.py -- cell-updates/s (zone-cycles/s) of the 3-D GLM-MHD PPM+HLLD update on a uniform
+grid (BASELINE.json metric), one process per GPU.
+
+A "step" is one full cycle of the native driver on synthetic smooth MHD data resident in HBM:
+c_h update -> for each VL2 stage [fused reconstruct->Riemann->flux-difference sweeps + RK update
++ Dedner source -> ghost-zone exchange -> ConsToPrim] -> hyperbolic dt estimate (+ min
+all-reduce).  Weak scaling: every GPU owns a 256^3 brick = 8 meshblocks of 128^3; ghost zones
+between bricks travel as one RCCL send/recv per peer per stage (torch.distributed "nccl").
+
+  python bench.py                          # N=1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  roofline     : algorithmic bytes of one fused stage / live HIP-event time of its kernels
+  cpu_baseline : the CPU oracle (-O3 -march=native, OpenMP) on a bounded sample of the same
+                 workload on this box's host cores -- a reported baseline, not the target.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+# algorithmic bytes (fp64, compulsory traffic) -- SURVEY.md 8(d)
+B_STAGE = {"glmmhd": (216.0, 288.0), "euler": (120.0, 160.0)}   # per cell-stage: gam0 == 0 / != 0
+B_C2P = {"glmmhd": 144.0, "euler": 80.0}                        # ConsToPrim per cell-stage
+GAM0 = {"rk1": (0.0,), "rk2": (0.0, 0.5), "vl2": (0.0, 0.0), "rk3": (0.0, 0.25, 2.0 / 3.0)}
+
+WORKLOADS = {
+    # name: (deck, fluid, integrator, per-GPU brick, meshblock, description)
+    "mhd_ppm_hlld_vl2_256": ("synthetic_mhd", "glmmhd", "vl2", 256, 128,
+                             "GLM-MHD PPM+HLLD+Dedner VL2, synthetic smooth state, 256^3 per GPU in 128^3 meshblocks"),
+}
+RANK_GRID = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
+
+
+def cpu_baseline(fluid, integrator, target_s=12.0):
+    """Times the oracle (kind 'port': no reference binary can be built here) on host cores."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    mb = 16 if cores > 64 else 32
+    n = 128
+    sim = O.Sim(fluid=fluid, recon="ppm", riemann="hlld", integrator=integrator, nx=(n, n, n), mb=(mb, mb, mb),
+                ng=3, xmax=(1.0, 1.0, 1.0), cfl=0.3, nthreads=cores, fast=True)
+    sim.pgen("synthetic")
+    t0 = time.perf_counter()
+    sim.step()
+    t1 = time.perf_counter() - t0
+    cycles = int(min(50, max(1, math.ceil(target_s / max(t1, 1e-3)))))
+    t0 = time.perf_counter()
+    for _ in range(cycles):
+        sim.step()
+    dt = time.perf_counter() - t0
+    return {"value": n ** 3 * cycles / dt, "unit": "cell-updates/s", "cores": cores, "kind": "port",
+            "sample": "%d cycles of the same scheme on a %d^3 mesh in %d^3 meshblocks, oracle built -O3 "
+                      "-march=native -fopenmp, %.1f s" % (cycles, n, mb, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="mhd_ppm_hlld_vl2_256", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="use the flux-array path (for A/B)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from athenapk_amd import decks, driver
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    deck, fluid, integrator, brick, mb, desc = WORKLOADS[args.workload]
+    if world not in RANK_GRID:
+        raise SystemExit("supported GPU counts: %s" % sorted(RANK_GRID))
+    grid = RANK_GRID[world]
+    ov = ["parthenon/mesh/nx%d=%d" % (d + 1, brick * grid[d]) for d in range(3)]
+    ov += ["parthenon/meshblock/nx%d=%d" % (d + 1, mb) for d in range(3)]
+    sim = driver.Simulation(decks.load(deck), ov, rank=rank, nranks=world, strict=False)
+    if args.unfused:
+        sim.set_fused(False)
+    sim.initialize()
+    info = sim.info
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sim.step()
+    sim.kernel_timing(True)
+    sim.read_kernel_timing()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timing = sim.read_kernel_timing()
+    sim.kernel_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        zones_total = int(info.zones_total)
+        zones_local = int(info.zones_local)
+        value = zones_total * args.steps / elapsed
+        nstages = len(GAM0[integrator])
+        per_kernel = {k: (ms / n if n else 0.0) for k, (ms, n) in timing.items()}
+        # one "launch" of the fused stage = its three sweep kernels back to back
+        if args.unfused:
+            stage_ms = per_kernel["fluxes"] + per_kernel["update"] + per_kernel["dedner"]
+            stage_name = "flux-array stage: CalculateFluxes + UpdateWithFluxDivergence + DednerSource"
+        else:
+            stage_ms = per_kernel["fused_x1"] + per_kernel["fused_x2"] + per_kernel["fused_x3"]
+            stage_name = "fused stage: x1 DPP sweep + x2 march + x3 march (+RK update +Dedner)"
+        b_stage = sum(B_STAGE[fluid][0 if g0 == 0.0 else 1] for g0 in GAM0[integrator]) / nstages
+        achieved = b_stage * zones_local / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
+        b_cycle = sum(B_STAGE[fluid][0 if g0 == 0.0 else 1] for g0 in GAM0[integrator]) + nstages * B_C2P[fluid]
+        dominant = max(("fused_x1", "fused_x2", "fused_x3", "fluxes", "cons_to_prim", "copy_regions", "update"),
+                       key=lambda k: timing[k][0])
+        out = {
+            "metric": "cell-updates/s (zone-cycles/s) for 3D MHD PPM+HLLD, uniform grid",
+            "value": value,
+            "unit": "cell-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "description": desc,
+                       "mesh": [int(info.nx[0]), int(info.nx[1]), int(info.nx[2])],
+                       "meshblock": [mb, mb, mb], "blocks_per_gpu": int(info.nblocks_local),
+                       "integrator": integrator, "nstages": nstages, "nghost": int(info.ng),
+                       "path": "flux-array" if args.unfused else "fused",
+                       "parallelism": "domain decomposition, %dx%dx%d GPU grid" % grid},
+            "cell_stage_updates_per_s": value * nstages,
+            "roofline": {
+                "bound": "hbm",
+                "kernel": stage_name,
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_cell_stage": b_stage,
+                "cells_per_launch": zones_local,
+                "stage_ms": stage_ms,
+                "per_kernel_avg_ms": per_kernel,
+                "dominant_kernel": dominant,
+                "whole_cycle": {"algorithmic_bytes_per_zone_cycle": b_cycle,
+                                "achieved": value / world * b_cycle / 1e9,
+                                "frac": value / world * b_cycle / 1e9 / HBM_PEAK_GBS},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(fluid, integrator)
+            except Exception as e:  # the baseline is informational; never lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "cell-updates/s", "cores": os.cpu_count(),
+                                       "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    sim.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

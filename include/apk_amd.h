@@ -197,6 +197,27 @@ int apk_copy_plan_create(apk_ctx *ctx, const apk_copy_region *regions, int n,
 void apk_copy_plan_destroy(apk_copy_plan *plan);
 int apk_copy_plan_run(apk_ctx *ctx, const apk_copy_plan *plan, apk_stream_t stream);
 
+/* ---- in-library kernel timing (HIP events on the caller's stream) ------------------------
+ * bench.py needs the average duration of individual kernels measured live on the stream
+ * they are launched on.  When enabled, every kernel launch of the listed groups is
+ * bracketed by hipEventRecord; apk_kernel_timing_read() synchronises, accumulates and
+ * resets.  Off by default (zero overhead). */
+enum apk_timing_slot {
+  APK_T_FUSED_X1 = 0, /* fused x1 sweep            */
+  APK_T_FUSED_X2 = 1, /* fused x2 march            */
+  APK_T_FUSED_X3 = 2, /* fused x3 march            */
+  APK_T_FLUXES = 3,   /* flux-array sweeps (all directions of one call) */
+  APK_T_UPDATE = 4,   /* UpdateWithFluxDivergence  */
+  APK_T_DEDNER = 5,   /* DednerSource              */
+  APK_T_C2P = 6,      /* ConservedToPrimitive      */
+  APK_T_MIN_DT = 7,   /* EstimateHyperbolicTimestep */
+  APK_T_COPY = 8,     /* strided box copies (ghost zones) */
+  APK_T_COUNT = 9
+};
+int apk_kernel_timing_enable(apk_ctx *ctx, int on);
+/* total_ms / launches may be NULL */
+int apk_kernel_timing_read(apk_ctx *ctx, int slot, double *total_ms, long long *launches);
+
 #ifdef __cplusplus
 }
 #endif

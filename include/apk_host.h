@@ -110,6 +110,10 @@ int apk_sim_exchange_ghosts(apk_sim *sim);
 int apk_sim_fill_derived(apk_sim *sim);
 int apk_sim_estimate_timestep(apk_sim *sim, double *dt);
 
+/* kernel timing of the sim's hot-path handle (apk_kernel_timing_* of apk_amd.h) */
+int apk_sim_kernel_timing_enable(apk_sim *sim, int on);
+int apk_sim_kernel_timing_read(apk_sim *sim, int slot, double *total_ms, long long *launches);
+
 /* ---- ghost-exchange plan introspection (host logic; valid in host-only mode) ----------- */
 typedef struct apk_peer_info {
   int rank;

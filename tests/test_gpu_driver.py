@@ -1,0 +1,201 @@
+"""GPU driver-level parity: the native host driver (deck -> stages -> dt) on the device vs
+the oracle's mini-driver on the CPU, on the BASELINE configurations scaled to sizes the
+oracle finishes in seconds, plus size-independent properties at BASELINE's full sizes."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _sim(deck, overrides, strict=True, fused=True):
+    from athenapk_amd import decks, driver
+    s = driver.Simulation(decks.load(deck), overrides, strict=strict)
+    s.set_fused(fused)
+    return s
+
+
+def _assert_same(got, want, strict, tol=1e-12):
+    if strict:
+        assert np.array_equal(got, want), "max abs diff %.3e" % np.max(np.abs(got - want))
+    else:
+        assert np.max(np.abs(got - want)) <= tol * (np.max(np.abs(want)) + 1e-300)
+
+
+# ---- config 1: linear_wave3d, 64x32x32 single meshblock, PLM + HLLE, RK2 -----------------------------
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+def test_config1_linear_wave_matches_oracle(oracle, strict):
+    s = _sim("linear_wave3d", [], strict=strict).initialize()
+    o = oracle.Sim(fluid="euler", recon="plm", riemann="hlle", integrator="rk2", nx=(64, 32, 32), ng=2,
+                   xmax=(3.0, 1.5, 1.5), cfl=0.3, nthreads=os.cpu_count())
+    o.pgen("linear_wave", wave_flag=0, amp=1e-6)
+    assert s.tlim == o.period  # "test = true": one wave period
+    assert s.dt == o.dt
+    n_gpu = s.run()
+    n_cpu = o.run(o.period)
+    assert n_gpu == n_cpu
+    _assert_same(s.gather("cons"), o.gather_cons(), strict)
+    rms, l1, _ = s.linear_wave_errors()
+    rms_o, l1_o, _ = o.linear_wave_errors()
+    # north_star: linear-wave L1 error within 1e-12 of the reference arithmetic
+    assert abs(rms - rms_o) <= 1e-12 and np.all(np.abs(l1 - l1_o) <= 1e-12)
+    if strict:
+        assert rms == rms_o
+
+
+def test_meshblock_decomposition_and_fused_path_do_not_change_a_bit(oracle):
+    base = ["parthenon/time/integrator=vl2", "parthenon/time/tlim=0.1"]
+    a = _sim("linear_wave3d", base, fused=True).initialize()
+    b = _sim("linear_wave3d", base + ["parthenon/meshblock/nx1=32", "parthenon/meshblock/nx2=16",
+                                      "parthenon/meshblock/nx3=16"], fused=True).initialize()
+    c = _sim("linear_wave3d", base, fused=False).initialize()
+    assert b.info.nblocks_local == 8 and a.info.fused == 1 and c.info.fused == 0
+    for sim in (a, b, c):
+        sim.run()
+    ua = a.gather()
+    assert np.array_equal(ua, b.gather())
+    assert np.array_equal(ua, c.gather())
+
+
+@pytest.mark.parametrize("integrator,recon,riemann,ng", [("rk3", "ppm", "hlle", 3), ("rk3", "wenoz", "hllc", 3),
+                                                         ("rk1", "dc", "llf", 2), ("vl2", "weno3", "hlle", 2),
+                                                         ("rk3", "limo3", "hlle", 2)])
+def test_linear_wave_method_matrix_matches_oracle(oracle, integrator, recon, riemann, ng):
+    """The method combinations of the reference's convergence suite (convergence.py:33-45)."""
+    ov = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=16", "parthenon/mesh/nx3=16",
+          "parthenon/meshblock/nx1=16", "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=8",
+          "parthenon/mesh/nghost=%d" % ng, "parthenon/time/integrator=%s" % integrator,
+          "hydro/reconstruction=%s" % recon, "hydro/riemann=%s" % riemann, "parthenon/time/tlim=0.25"]
+    s = _sim("linear_wave3d", ov).initialize()
+    o = oracle.Sim(fluid="euler", recon=recon, riemann=riemann, integrator=integrator, nx=(32, 16, 16), ng=ng,
+                   xmax=(3.0, 1.5, 1.5), cfl=0.3)
+    o.pgen("linear_wave", wave_flag=0, amp=1e-6)
+    assert s.run() == o.run(0.25 * o.period)
+    assert np.array_equal(s.gather(), o.gather_cons())
+
+
+# ---- config 2: Sod 3-D, PLM + HLLC, RK2, outflow in x1 -----------------------------------------------
+def test_config2_sod_matches_oracle(oracle):
+    ov = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=8", "parthenon/mesh/nx3=8",
+          "parthenon/meshblock/nx1=32", "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=4",
+          "parthenon/time/tlim=0.1"]
+    s = _sim("sod", ov).initialize()
+    o = oracle.Sim(fluid="euler", recon="plm", riemann="hllc", integrator="rk2", nx=(64, 8, 8), ng=2,
+                   bc=("outflow", "periodic", "periodic"), xmin=(0.0, -0.5, -0.5), xmax=(1.0, 0.5, 0.5),
+                   gamma=1.4, cfl=0.3).pgen("sod")
+    assert s.run() == o.run(0.1)
+    assert np.array_equal(s.gather(), o.gather_cons())
+
+
+def test_config2_full_size_sod_stays_one_dimensional():
+    """256^3, 8 meshblocks of 128^3 (BASELINE config 2).  Size-independent property: a
+    planar problem keeps zero transverse momentum and no transverse structure, bitwise."""
+    s = _sim("sod", [], strict=False).initialize()
+    assert s.info.nblocks_local == 8 and s.info.zones_total == 256 ** 3
+    m0 = s.history()[0]
+    s.run(nlim=3)
+    u = s.gather()
+    assert np.all(u[2] == 0.0) and np.all(u[3] == 0.0)
+    assert np.array_equal(u[:, :1, :1, :].repeat(256, 1).repeat(256, 2), u)
+    # mass changes only through the outflow faces, which carry no flux yet
+    assert s.history()[0] == pytest.approx(m0, rel=1e-13)
+    assert u[0].min() >= 0.125 - 1e-12 and u[0].max() <= 1.0 + 1e-12
+
+
+# ---- config 3: Orszag-Tang, PPM + HLLD + Dedner, VL2 --------------------------------------------------
+@pytest.mark.parametrize("fofc", [False, True], ids=["plain", "fofc"])
+def test_config3_orszag_tang_conserved_totals(oracle, fofc):
+    ov = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "parthenon/meshblock/nx1=32",
+          "parthenon/meshblock/nx2=32", "parthenon/time/tlim=0.1",
+          "hydro/first_order_flux_correct=%s" % ("true" if fofc else "false")]
+    s = _sim("orszag_tang", ov).initialize()
+    o = oracle.Sim(fluid="glmmhd", recon="ppm", riemann="hlld", integrator="vl2", nx=(64, 64, 1), ng=3,
+                   xmin=(-0.5, -0.5, -0.5), xmax=(0.5, 0.5, 0.5), cfl=0.4, fofc=fofc).pgen("orszag_tang")
+    assert s.run() == o.run(0.1)
+    assert s.c_h == o.c_h
+    assert np.array_equal(s.gather(), o.gather_cons())
+    assert s.fofc_count == o.fofc_count
+    h, ho = s.history(), o.history()
+    # north_star: Orszag-Tang conserved totals (mass, momenta, total energy; hydro.cpp:172-183)
+    np.testing.assert_allclose(h[[0, 4, 5, 6]], ho[[0, 4, 5, 6]], rtol=1e-12)
+    assert abs(h[1] - ho[1]) < 1e-13 and abs(h[2] - ho[2]) < 1e-13
+
+
+def test_config3_fma_build_totals_within_tolerance(oracle):
+    ov = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "parthenon/meshblock/nx1=64",
+          "parthenon/meshblock/nx2=64", "parthenon/time/tlim=0.1"]
+    s = _sim("orszag_tang", ov, strict=False).initialize()
+    o = oracle.Sim(fluid="glmmhd", recon="ppm", riemann="hlld", integrator="vl2", nx=(64, 64, 1), ng=3,
+                   xmin=(-0.5, -0.5, -0.5), xmax=(0.5, 0.5, 0.5), cfl=0.4).pgen("orszag_tang")
+    s.run()
+    o.run(0.1)
+    h, ho = s.history(), o.history()
+    np.testing.assert_allclose(h[[0, 4, 5, 6]], ho[[0, 4, 5, 6]], rtol=1e-12)
+    u, uo = s.gather(), o.gather_cons()
+    assert np.max(np.abs(u - uo)) <= 1e-10 * np.max(np.abs(uo))  # FMA deviation after 30+ cycles
+
+
+def test_config3_full_size_orszag_tang_symmetry_and_conservation():
+    """512^2 (BASELINE config 3).  Properties: mass / energy conserved to round-off and the
+    solution keeps the vortex' point symmetry u(x,y) -> u(-x,-y) with (m,B) odd/even."""
+    s = _sim("orszag_tang", [], strict=False).initialize()
+    assert s.info.zones_total == 512 * 512
+    h0 = s.history()
+    s.run(nlim=20)
+    h1 = s.history()
+    assert h1[0] == pytest.approx(h0[0], rel=1e-13)
+    assert h1[5] == pytest.approx(h0[5], rel=1e-12)
+    assert abs(h1[1]) < 1e-12 and abs(h1[2]) < 1e-12
+    u = s.gather()[:, 0]
+    rot = u[:, ::-1, ::-1]
+    assert np.max(np.abs(u[0] - rot[0])) < 1e-11   # density: even
+    assert np.max(np.abs(u[1] + rot[1])) < 1e-11   # momentum: odd
+
+
+# ---- the reference's own regression bounds, on the device -------------------------------------------
+def test_reference_bound_hydro_linear_wave_on_gpu():
+    """convergence.py:163-164 at the reference's resolution (128x64x64, VL2+PLM+HLLE)."""
+    with open(os.path.join(GOLD, "oracle_pins.json")) as f:
+        pin = json.load(f)["hydro_vl2_plm_hlle_128x64x64"]
+    ov = ["parthenon/mesh/nx1=128", "parthenon/mesh/nx2=64", "parthenon/mesh/nx3=64",
+          "parthenon/meshblock/nx1=128", "parthenon/meshblock/nx2=64", "parthenon/meshblock/nx3=64",
+          "parthenon/time/integrator=vl2"]
+    s = _sim("linear_wave3d", ov, strict=False).initialize()
+    assert s.run() == pin["cycles"]
+    rms, _, _ = s.linear_wave_errors()
+    assert float("%e" % rms) <= pin["reference_bound"]
+    assert abs(rms - pin["rms_l1"]) <= 1e-12
+
+
+def test_reference_bound_mhd_linear_wave_on_gpu():
+    """mhd_convergence.py:167-169 (256x128x128, RK3+WENOZ+HLLE through the GLM-MHD solver)."""
+    with open(os.path.join(GOLD, "oracle_pins.json")) as f:
+        pin = json.load(f)["glmmhd_rk3_wenoz_hlle_256x128x128"]
+    ov = ["parthenon/mesh/nx1=256", "parthenon/mesh/nx2=128", "parthenon/mesh/nx3=128",
+          "parthenon/meshblock/nx1=128", "parthenon/meshblock/nx2=128", "parthenon/meshblock/nx3=128",
+          "parthenon/mesh/nghost=3", "parthenon/time/integrator=rk3", "hydro/reconstruction=wenoz",
+          "hydro/fluid=glmmhd"]
+    s = _sim("linear_wave3d", ov, strict=False).initialize()
+    assert s.run() == pin["cycles"]
+    rms, _, _ = s.linear_wave_errors()
+    assert rms <= pin["reference_bound"]
+    assert abs(rms - pin["rms_l1"]) <= 1e-12
+
+
+# ---- north-star benchmark workload at full size: properties ------------------------------------------
+def test_synthetic_mhd_256_cubed_conserves_and_matches_flux_array_path():
+    a = _sim("synthetic_mhd", [], strict=False, fused=True).initialize()
+    assert a.info.zones_total == 256 ** 3 and a.info.nblocks_local == 8
+    h0 = a.history()
+    a.run(nlim=2)
+    h1 = a.history()
+    for q in (0, 1, 2, 3, 5):  # mass, momenta, total energy on a periodic box
+        assert abs(h1[q] - h0[q]) <= 1e-12 * max(abs(h0[q]), h0[0])
+    b = _sim("synthetic_mhd", [], strict=False, fused=False).initialize()
+    b.run(nlim=2)
+    ua, ub = a.gather(), b.gather()
+    assert np.array_equal(ua, ub)

@@ -1,0 +1,312 @@
+"""GPU parity tests: every call goes through the C-ABI of libapk_amd[_strict].so and is
+compared with the CPU oracle on the same seeded inputs.
+
+  strict build (-ffp-contract=off): BIT-EXACT agreement with the oracle is required.
+  default build (FMA contraction):  |diff| <= 1e-12 * scale  (north_star tolerance).
+"""
+import numpy as np
+import pytest
+
+import helpers as H
+from helpers import FUSABLE, NGHOST, NHYDRO, REGISTRY
+
+pytestmark = pytest.mark.gpu
+
+GAMMA = 5.0 / 3.0
+C_H = 1.9
+FAST_TOL = 1e-12
+
+
+def _ctx(request, strict):
+    return request.getfixturevalue("gpu_ctx_strict" if strict else "gpu_ctx_fast")
+
+
+def _cmp(got, want, strict, what):
+    if strict:
+        if not np.array_equal(got, want):
+            bad = np.argwhere(got != want)
+            raise AssertionError("%s: %d entries differ bitwise, first at %s: %r vs %r" % (
+                what, len(bad), bad[0], got[tuple(bad[0])], want[tuple(bad[0])]))
+    else:
+        scale = np.max(np.abs(want)) + 1e-300
+        err = np.max(np.abs(got - want)) / scale
+        assert err <= FAST_TOL, "%s: max scaled error %.3e" % (what, err)
+
+
+def _case(fluid, recon, nx, kind="smooth", nscalars=0, nblocks=2, seed=11, dx=(0.1, 0.07, 0.13)):
+    ng = NGHOST[recon] if recon != "dc" else 2
+    prim = H.random_prim(fluid, nx, ng, nscalars=nscalars, seed=seed, kind=kind, nblocks=nblocks)
+    g = H.geom(fluid, nx, ng, nscalars, dx)
+    return ng, prim, g
+
+
+# ---- Hydro::CalculateFluxes: every entry of the registry, 3-D ------------------------------------
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("fluid,recon,riemann", REGISTRY)
+def test_calculate_fluxes_registry_3d(request, fluid, recon, riemann, strict):
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    nx = (16, 8, 8)
+    ng, prim, g = _case(fluid, recon, nx, kind="smooth")
+    md = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=prim.shape[0], prim=prim)
+    hydro.CalculateFluxes(md, fluid, recon, riemann, hydro.L.make_eos(GAMMA), C_H)
+    want = H.orc_fluxes(fluid, recon, riemann, g, prim, GAMMA, C_H)
+    for d in range(3):
+        _cmp(md.flux_host(d), want[d], strict, "flux%d %s/%s/%s" % (d + 1, fluid, recon, riemann))
+
+
+@pytest.mark.parametrize("kind", ["rough", "shock"])
+@pytest.mark.parametrize("fluid,recon,riemann", [("euler", "ppm", "hllc"), ("euler", "wenoz", "hlle"),
+                                                 ("glmmhd", "ppm", "hlld"), ("glmmhd", "limo3", "hlld"),
+                                                 ("glmmhd", "plm", "hlle")])
+def test_calculate_fluxes_discontinuous_data_bitexact(request, fluid, recon, riemann, kind):
+    """Limiter / solver branches (PPM extremum logic, HLLD degenerate states, supersonic
+    upwinding) on rough and shocked data."""
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    nx = (24, 6, 5)
+    ng, prim, g = _case(fluid, recon, nx, kind=kind, seed=23)
+    md = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=prim.shape[0], prim=prim)
+    hydro.CalculateFluxes(md, fluid, recon, riemann, hydro.L.make_eos(GAMMA), C_H)
+    want = H.orc_fluxes(fluid, recon, riemann, g, prim, GAMMA, C_H)
+    for d in range(3):
+        _cmp(md.flux_host(d), want[d], True, "flux%d" % (d + 1))
+
+
+@pytest.mark.parametrize("nx", [(20, 12, 1), (33, 1, 1)], ids=["2d", "1d"])
+@pytest.mark.parametrize("fluid,recon,riemann", [("euler", "plm", "hlle"), ("glmmhd", "ppm", "hlld"),
+                                                 ("glmmhd", "dc", "llf")])
+def test_calculate_fluxes_collapsed_dimensions(request, nx, fluid, recon, riemann):
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    ng, prim, g = _case(fluid, recon, nx, kind="rough", seed=5)
+    md = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=prim.shape[0], prim=prim)
+    hydro.CalculateFluxes(md, fluid, recon, riemann, hydro.L.make_eos(GAMMA), C_H)
+    want = H.orc_fluxes(fluid, recon, riemann, g, prim, GAMMA, C_H)
+    ndim = 2 if nx[1] > 1 else 1
+    for d in range(ndim):
+        _cmp(md.flux_host(d), want[d], True, "flux%d" % (d + 1))
+
+
+@pytest.mark.parametrize("fluid,recon,riemann", [("euler", "plm", "hllc"), ("glmmhd", "wenoz", "hlld"),
+                                                 ("euler", "dc", "llf")])
+def test_passive_scalar_fluxes(request, fluid, recon, riemann):
+    """hydro.cpp:1088-1097: F_n = F_rho * (F_rho >= 0 ? wl_n : wr_n)."""
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    nx = (12, 6, 4)
+    ng, prim, g = _case(fluid, recon, nx, kind="smooth", nscalars=3, seed=9)
+    md = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], nscalars=3, dx=tuple(g.dx), nblocks=prim.shape[0], prim=prim)
+    hydro.CalculateFluxes(md, fluid, recon, riemann, hydro.L.make_eos(GAMMA), C_H)
+    want = H.orc_fluxes(fluid, recon, riemann, g, prim, GAMMA, C_H)
+    for d in range(3):
+        _cmp(md.flux_host(d), want[d], True, "flux%d" % (d + 1))
+
+
+# ---- UpdateWithFluxDivergence / DednerSource / ConsToPrim / dt / history ------------------------------
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("nx", [(16, 8, 8), (16, 10, 1), (24, 1, 1)], ids=["3d", "2d", "1d"])
+def test_update_with_flux_divergence(request, strict, nx):
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    fluid, ng = "glmmhd", 3
+    g = H.geom(fluid, nx, ng, 1, (0.1, 0.07, 0.13))
+    rng = np.random.default_rng(3)
+    shp = (2,) + H.block_shape(nx, ng, 10)
+    u0, u1 = rng.uniform(-1, 1, shp), rng.uniform(-1, 1, shp)
+    fl = [rng.uniform(-1, 1, shp) for _ in range(3)]
+    m0 = hydro.MeshData(ctx, nx, ng, 9, nscalars=1, dx=tuple(g.dx), nblocks=2, cons=u0)
+    for d in range(m0.ndim):
+        m0.flux[d].copy_(hydro.torch.from_numpy(fl[d]))
+    m1 = hydro.MeshData(ctx, nx, ng, 9, nscalars=1, dx=tuple(g.dx), nblocks=2, cons=u1, with_flux=False)
+    hydro.UpdateWithFluxDivergence(m0, m1, 0.25, 0.75, 0.0123)
+    want = H.orc_update(g, u0, u1, fl, 0.25, 0.75, 0.0123)
+    _cmp(m0.cons_host(), want, strict, "update")
+
+
+@pytest.mark.parametrize("extended", [False, True], ids=["plain", "extended"])
+@pytest.mark.parametrize("nx", [(16, 8, 8), (16, 10, 1)], ids=["3d", "2d"])
+def test_dedner_source(request, extended, nx):
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    ng = 2
+    g = H.geom("glmmhd", nx, ng, 0, (0.1, 0.07, 0.13))
+    prim = H.random_prim("glmmhd", nx, ng, seed=4, kind="rough", nblocks=2)
+    cons = H.prim_to_cons("glmmhd", prim, GAMMA)
+    md = hydro.MeshData(ctx, nx, ng, 9, dx=tuple(g.dx), nblocks=2, cons=cons, prim=prim, with_flux=False)
+    hydro.DednerSource(md, extended, 0.1, C_H, 0.07, 0.011)
+    want = H.orc_dedner(g, cons, prim, extended, 0.1, C_H, 0.07, 0.011)
+    _cmp(md.cons_host(), want, True, "dedner")
+
+
+@pytest.mark.parametrize("fluid", ["euler", "glmmhd"])
+@pytest.mark.parametrize("floors", ["off", "on"])
+def test_cons_to_prim(request, oracle, fluid, floors):
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    nx, ng = (12, 6, 5), 2
+    g = H.geom(fluid, nx, ng, 2)
+    w = H.random_prim(fluid, nx, ng, nscalars=2, seed=8, kind="rough", nblocks=2)
+    u = H.prim_to_cons(fluid, w, 1.4)
+    kw = {}
+    if floors == "on":
+        u[0, 4, 2, 3, 4] = 1e-7      # negative pressure -> pressure floor rewrites E
+        u[1, 0, 1, 1, 1] = 1e-9      # tiny density -> density floor
+        u[0, 1, 3, 2, 5] = 50.0      # huge momentum -> velocity ceiling
+        kw = dict(pfloor=1e-3, dfloor=1e-2, vceil=10.0)
+    md = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], nscalars=2, nblocks=2, cons=u, with_flux=False)
+    ctx.poll_flags()
+    hydro.ConservedToPrimitive(md, fluid, hydro.L.make_eos(1.4, **kw))
+    u_want, w_want, bad = H.orc_c2p(fluid, g, u, oracle.make_eos(1.4, **kw))
+    assert bad == 0
+    _cmp(md.prim_host(), w_want, True, "prim")
+    _cmp(md.cons_host(), u_want, True, "cons after floors")
+    assert ctx.poll_flags() == 0
+
+
+def test_cons_to_prim_latches_negative_state_flags(request):
+    """adiabatic_hydro.hpp:77-79,111-113: PARTHENON_REQUIRE -> latched device flag."""
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    nx, ng = (8, 4, 4), 2
+    w = H.random_prim("euler", nx, ng, seed=8, kind="rough")
+    u = H.prim_to_cons("euler", w, 1.4)
+    u[0, 0, 2, 2, 2] = -1.0
+    md = hydro.MeshData(ctx, nx, ng, 5, cons=u, with_flux=False)
+    ctx.poll_flags()
+    hydro.ConservedToPrimitive(md, "euler", hydro.L.make_eos(1.4))
+    assert ctx.poll_flags() & hydro.L.FLAG_NEG_DENSITY
+    u[0, 0, 2, 2, 2] = 1.0
+    u[0, 4, 2, 2, 2] = -5.0
+    md = hydro.MeshData(ctx, nx, ng, 5, cons=u, with_flux=False)
+    hydro.ConservedToPrimitive(md, "euler", hydro.L.make_eos(1.4))
+    assert ctx.poll_flags() == hydro.L.FLAG_NEG_PRESSURE
+
+
+@pytest.mark.parametrize("fluid", ["euler", "glmmhd"])
+@pytest.mark.parametrize("nx", [(16, 8, 8), (16, 10, 1), (40, 1, 1)], ids=["3d", "2d", "1d"])
+def test_estimate_timestep(request, fluid, nx):
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    ng = 2
+    g = H.geom(fluid, nx, ng, 0, (0.1, 0.07, 0.13))
+    prim = H.random_prim(fluid, nx, ng, seed=6, kind="rough", nblocks=3)
+    md = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, prim=prim, with_flux=False)
+    dt = hydro.EstimateTimestep(md, fluid, hydro.L.make_eos(GAMMA), 0.3)
+    assert dt == 0.3 * H.orc_min_dt(fluid, g, prim, GAMMA)
+
+
+@pytest.mark.parametrize("fluid", ["euler", "glmmhd"])
+def test_history(request, fluid):
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    nx, ng = (16, 8, 8), 2
+    g = H.geom(fluid, nx, ng, 0, (0.1, 0.07, 0.13))
+    prim = H.random_prim(fluid, nx, ng, seed=12, kind="smooth", nblocks=2)
+    cons = H.prim_to_cons(fluid, prim, GAMMA)
+    md = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=2, cons=cons, with_flux=False)
+    got = hydro.HydroHst(md, fluid)
+    want = H.orc_history(fluid, g, cons)
+    # a sum: order of additions differs (as it does between Kokkos back ends)
+    np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-15)
+
+
+# ---- FirstOrderFluxCorrect ------------------------------------------------------------------------
+@pytest.mark.parametrize("fluid", ["euler", "glmmhd"])
+def test_first_order_flux_correct(request, fluid):
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    nx, ng = (16, 8, 6), 2
+    g = H.geom(fluid, nx, ng, 0, (0.1, 0.1, 0.1))
+    prim = H.random_prim(fluid, nx, ng, seed=31, kind="shock", nblocks=2)
+    prim[:, 4] *= 1e-3  # very cold: a large explicit step drives the trial pressure negative
+    cons = H.prim_to_cons(fluid, prim, GAMMA)
+    fl = H.orc_fluxes(fluid, "plm", "hlle", g, prim, GAMMA, C_H)
+    beta_dt = 0.06
+    want_fl, want_n = H.orc_fofc(fluid, g, cons, prim, cons, fl, GAMMA, C_H, 0.0, 1.0, beta_dt)
+    assert want_n > 0, "test data must trigger corrections"
+    m0 = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=2, cons=cons, prim=prim)
+    for d in range(3):
+        m0.flux[d].copy_(hydro.torch.from_numpy(fl[d]))
+    m1 = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=2, cons=cons, with_flux=False)
+    n = hydro.FirstOrderFluxCorrect(m0, m1, fluid, hydro.L.make_eos(GAMMA), C_H, 0.0, 1.0, beta_dt)
+    assert n == want_n
+    for d in range(3):
+        _cmp(m0.flux_host(d), want_fl[d], True, "corrected flux%d" % (d + 1))
+
+
+# ---- fused stage = CalculateFluxes + UpdateWithFluxDivergence + DednerSource -------------------------
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("fluid,recon,riemann", FUSABLE)
+def test_fused_stage_registry_3d(request, fluid, recon, riemann, strict):
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    nx = (70, 9, 7)  # > 64 wide: exercises the x1 wave-overlap scheme and idle lanes
+    ng, prim, g = _case(fluid, recon, nx, kind="smooth", seed=17)
+    cons = H.prim_to_cons(fluid, prim, GAMMA)
+    rng = np.random.default_rng(2)
+    u1 = cons * (1.0 + 1e-3 * rng.standard_normal(cons.shape))
+    ded = 1 if fluid == "glmmhd" else 0
+    m0 = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=prim.shape[0], cons=cons, prim=prim,
+                        with_flux=False)
+    m1 = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=prim.shape[0], cons=u1, with_flux=False)
+    hydro.StageFused(m0, m1, fluid, recon, riemann, hydro.L.make_eos(GAMMA), C_H, 0.25, 0.75, 0.004, dedner=ded,
+                     glmmhd_alpha=0.1, mindx=0.07)
+    want = H.orc_stage(fluid, recon, riemann, g, cons, u1, prim, GAMMA, C_H, 0.25, 0.75, 0.004, dedner=ded,
+                       alpha=0.1, mindx=0.07)
+    _cmp(m0.cons_host(), want, strict, "fused stage %s/%s/%s" % (fluid, recon, riemann))
+
+
+@pytest.mark.parametrize("nx", [(130, 12, 1), (200, 1, 1)], ids=["2d", "1d"])
+@pytest.mark.parametrize("dedner", [1, 2], ids=["plain", "extended"])
+def test_fused_stage_collapsed_dimensions_and_dedner(request, nx, dedner):
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    fluid, recon, riemann = "glmmhd", "ppm", "hlld"
+    ng, prim, g = _case(fluid, recon, nx, kind="rough", seed=19)
+    cons = H.prim_to_cons(fluid, prim, GAMMA)
+    m0 = hydro.MeshData(ctx, nx, ng, 9, dx=tuple(g.dx), nblocks=prim.shape[0], cons=cons, prim=prim, with_flux=False)
+    m1 = hydro.MeshData(ctx, nx, ng, 9, dx=tuple(g.dx), nblocks=prim.shape[0], cons=cons, with_flux=False)
+    hydro.StageFused(m0, m1, fluid, recon, riemann, hydro.L.make_eos(GAMMA), C_H, 0.0, 1.0, 0.002, dedner=dedner,
+                     glmmhd_alpha=0.1, mindx=0.07)
+    want = H.orc_stage(fluid, recon, riemann, g, cons, cons, prim, GAMMA, C_H, 0.0, 1.0, 0.002, dedner=dedner,
+                       alpha=0.1, mindx=0.07)
+    _cmp(m0.cons_host(), want, True, "fused stage")
+
+
+def test_fused_stage_3d_extended_dedner_and_first_stage_gam0_zero(request):
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    fluid, recon, riemann = "glmmhd", "wenoz", "hlld"
+    nx = (64, 8, 8)
+    ng, prim, g = _case(fluid, recon, nx, kind="shock", seed=29)
+    cons = H.prim_to_cons(fluid, prim, GAMMA)
+    m0 = hydro.MeshData(ctx, nx, ng, 9, dx=tuple(g.dx), nblocks=prim.shape[0], cons=cons, prim=prim, with_flux=False)
+    m1 = hydro.MeshData(ctx, nx, ng, 9, dx=tuple(g.dx), nblocks=prim.shape[0], cons=cons, with_flux=False)
+    hydro.StageFused(m0, m1, fluid, recon, riemann, hydro.L.make_eos(GAMMA), C_H, 0.0, 1.0, 0.003, dedner=2,
+                     glmmhd_alpha=0.1, mindx=0.07)
+    want = H.orc_stage(fluid, recon, riemann, g, cons, cons, prim, GAMMA, C_H, 0.0, 1.0, 0.003, dedner=2,
+                       alpha=0.1, mindx=0.07)
+    _cmp(m0.cons_host(), want, True, "fused stage")
+
+
+# ---- error conventions of the boundary ----------------------------------------------------------------
+def test_boundary_error_codes(request):
+    from athenapk_amd import hydro
+    from athenapk_amd import lib as L
+    ctx = _ctx(request, True)
+    nx = (8, 4, 4)
+    prim = H.random_prim("euler", nx, 2, seed=1)
+    md = hydro.MeshData(ctx, nx, 2, 5, prim=prim)
+    with pytest.raises(L.ApkError) as e:  # ppm needs 3 ghost zones (hydro.cpp:444-447)
+        hydro.CalculateFluxes(md, "euler", "ppm", "hlle", L.make_eos(1.4))
+    assert e.value.code == L.APK_ERR_NGHOST
+    with pytest.raises(L.ApkError) as e:  # hlld is not a hydro solver (registry hydro.cpp:386-416)
+        hydro.CalculateFluxes(md, "euler", "plm", "hlld", L.make_eos(1.4))
+    assert e.value.code == L.APK_ERR_UNSUPPORTED
+    with pytest.raises(L.ApkError) as e:  # llf only with dc (hydro.cpp:347-349)
+        hydro.CalculateFluxes(md, "euler", "plm", "llf", L.make_eos(1.4))
+    assert e.value.code == L.APK_ERR_UNSUPPORTED
+    with pytest.raises(L.ApkError) as e:  # fluid does not match the pack
+        hydro.CalculateFluxes(md, "glmmhd", "plm", "hlle", L.make_eos(1.4))
+    assert e.value.code == L.APK_ERR_INVALID

@@ -1,0 +1,220 @@
+"""CPU tests of the host side (no GPU, no compute calls): the C-ABI library loads and exports
+every symbol the headers declare, deck parsing mirrors Hydro::Initialize's option handling,
+and the Morton partition + ghost-exchange plans are correct (executed here with numpy and
+compared with the oracle's whole-mesh ghost fill)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(apk_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.mark.parametrize("strict", [False, True], ids=["fma", "strict"])
+def test_library_loads_and_exports_every_declared_symbol(strict):
+    from athenapk_amd import lib as L
+    lib = L.load(strict)
+    declared = _declared_functions("apk_amd.h") + _declared_functions("apk_host.h")
+    assert len(declared) > 40
+    for name in declared:
+        assert hasattr(lib, name), "%s declared in include/ but not exported" % name
+    assert set(declared) == set(L.SYMBOLS)  # the ctypes table binds exactly the declared API
+    assert lib.apk_version() == 1
+    assert lib.apk_fp_strict() == int(strict)
+
+
+def test_no_device_fails_loudly_without_fallback():
+    """On a box without a gfx950 GPU the context cannot be created: the product has no CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from athenapk_amd import lib as L
+    lib = L.load()
+    h = C.c_void_p()
+    assert lib.apk_create(C.byref(h)) == L.APK_ERR_NO_DEVICE
+    assert not h.value
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "athenapk_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("the oracle", "").replace("CPU oracle", ""), (
+                    "%s mentions the oracle" % os.path.join(dirpath, f))
+
+
+# ---- deck handling (Hydro::Initialize) -------------------------------------------------------------------
+def _plan(deck, overrides=(), rank=0, nranks=1):
+    from athenapk_amd import decks, driver
+    return driver.HostPlan(decks.load(deck), list(overrides), rank=rank, nranks=nranks)
+
+
+def test_deck_defaults_and_overrides():
+    from athenapk_amd import lib as L
+    p = _plan("linear_wave3d")
+    i = p.info
+    assert (i.fluid, i.recon, i.riemann, i.integrator) == (L.FLUID["euler"], L.RECON["plm"], L.RIEMANN["hlle"],
+                                                           L.INTEGRATOR["rk2"])
+    assert list(i.nx) == [64, 32, 32] and i.ng == 2 and i.nhydro == 5 and i.cfl == 0.3
+    assert i.nblocks_total == 1 and i.ndim == 3
+    # "test = true" reinterprets tlim as wave periods (linear_wave.cpp:169-175): lambda = 1, a = 1
+    assert p.tlim == pytest.approx(1.0, rel=1e-14)
+    p = _plan("linear_wave3d", ["hydro/fluid=glmmhd", "hydro/reconstruction=wenoz", "parthenon/mesh/nghost=3",
+                                "parthenon/time/integrator=rk3", "hydro/riemann=hlld"])
+    assert p.info.nhydro == 9 and p.info.recon == L.RECON["wenoz"] and p.info.riemann == L.RIEMANN["hlld"]
+    assert p.info.glmmhd_alpha == 0.1 and p.info.dedner_extended == 0  # defaults hydro.cpp:285-295
+
+
+@pytest.mark.parametrize("overrides,msg", [
+    (["hydro/reconstruction=ppm"], "Need more ghost zones"),                 # hydro.cpp:444-447
+    (["hydro/reconstruction=foo"], "Unknown reconstruction"),                # hydro.cpp:338
+    (["hydro/riemann=roe"], "Unknown riemann"),                              # hydro.cpp:366
+    (["hydro/riemann=llf"], "LLF Riemann solver only implemented with DC"),  # hydro.cpp:347-349
+    (["hydro/fluid=mhd"], "Unknown fluid"),                                  # hydro.cpp:299
+    (["hydro/riemann=hlld"], "no flux function"),                            # registry hydro.cpp:386-420
+    (["parthenon/meshblock/nx1=48"], "multiple of the meshblock"),
+    (["parthenon/mesh/refinement=adaptive"], "uniform meshes only"),
+    (["job/problem_id=cluster"], "unknown job/problem_id"),
+])
+def test_deck_errors_are_reported_not_fatal(overrides, msg):
+    from athenapk_amd import lib as L
+    with pytest.raises(L.ApkError) as e:
+        _plan("linear_wave3d", overrides)
+    assert e.value.code == L.APK_ERR_INVALID and msg in str(e.value)
+
+
+def test_morton_partition_gives_bricks():
+    """4x4x4 meshblocks over 8 ranks: each rank owns a 2x2x2 brick."""
+    ov = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "parthenon/mesh/nx3=64",
+          "parthenon/meshblock/nx1=16", "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=16"]
+    seen = set()
+    for r in range(8):
+        p = _plan("synthetic_mhd", ov, rank=r, nranks=8)
+        assert p.info.nblocks_local == 8
+        locs = np.array([p.block_gid(lb)[1] for lb in range(8)])
+        assert np.all(locs.max(axis=0) - locs.min(axis=0) == 1)  # a 2x2x2 brick
+        seen |= {p.block_gid(lb)[0] for lb in range(8)}
+        # a periodic 2x2x2 rank grid: every other rank is a neighbour (faces, edges, corners)
+        assert sorted(q[0] for q in p.peers()) == [q for q in range(8) if q != r]
+    assert seen == set(range(64))
+
+
+# ---- ghost-exchange plans, executed on the host -------------------------------------------------------
+def _run_plans(deck, overrides, nranks, fill, nvar):
+    """Emulates all ranks in one process: returns {gid: block array} after the exchange."""
+    plans = [_plan(deck, overrides, rank=r, nranks=nranks) for r in range(nranks)]
+    i0 = plans[0].info
+    shape = (nvar, i0.mb[2] + 2 * i0.ng if i0.mb[2] > 1 else 1, i0.mb[1] + 2 * i0.ng if i0.mb[1] > 1 else 1,
+             i0.mb[0] + 2 * i0.ng)
+    blocks, sendb, recvb = [], [], []
+    for r, p in enumerate(plans):
+        blk = []
+        for lb in range(p.info.nblocks_local):
+            gid, loc = p.block_gid(lb)
+            blk.append(fill(gid, loc, shape))
+        blocks.append(blk)
+        sendb.append({q: np.zeros(sc) for q, sc, rc in p.peers()})
+        recvb.append({q: np.zeros(rc) for q, sc, rc in p.peers()})
+
+    def base(r, kind, idx):
+        p = plans[r]
+        if kind == 0:
+            return blocks[r][idx].reshape(-1)
+        peer = p.peers()[idx][0]
+        return (sendb if kind == 1 else recvb)[r][peer]
+
+    def run(r, phase):
+        for reg in plans[r].regions(phase):
+            src, dst = base(r, reg.src_kind, reg.src_block), base(r, reg.dst_kind, reg.dst_block)
+            ii, jj, kk, vv = np.meshgrid(np.arange(reg.ext[0]), np.arange(reg.ext[1]), np.arange(reg.ext[2]),
+                                         np.arange(reg.nvar), indexing="ij")
+            so = reg.src_off + ii * reg.src_stride[0] + jj * reg.src_stride[1] + kk * reg.src_stride[2] + vv * reg.src_stride[3]
+            do = reg.dst_off + ii * reg.dst_stride[0] + jj * reg.dst_stride[1] + kk * reg.dst_stride[2] + vv * reg.dst_stride[3]
+            val = src[so]
+            if reg.flip_var >= 0:
+                val = np.where(vv == reg.flip_var, -val, val)
+            dst[do] = val
+
+    for r in range(nranks):
+        run(r, "pack")
+        run(r, "local")
+    for r, p in enumerate(plans):  # the "wire": my send buffer to q is q's recv buffer from me
+        for q, sc, rc in p.peers():
+            assert sendb[r][q].size == recvb[q][r].size
+            recvb[q][r][:] = sendb[r][q]
+    for r in range(nranks):
+        run(r, "unpack")
+        for ph in ("bc1", "bc2", "bc3"):
+            run(r, ph)
+    out = {}
+    for r, p in enumerate(plans):
+        for lb in range(p.info.nblocks_local):
+            out[p.block_gid(lb)[0]] = blocks[r][lb]
+    return out, plans[0].info
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 3, 8])
+@pytest.mark.parametrize("case", ["periodic3d", "sod_outflow", "ot2d"])
+def test_ghost_plans_reproduce_the_oracle_ghost_fill(oracle, case, nranks):
+    if case == "periodic3d":
+        deck, ov = "synthetic_mhd", ["parthenon/mesh/nx1=24", "parthenon/mesh/nx2=16", "parthenon/mesh/nx3=16",
+                                     "parthenon/meshblock/nx1=12", "parthenon/meshblock/nx2=8",
+                                     "parthenon/meshblock/nx3=8"]
+        okw = dict(fluid="glmmhd", recon="ppm", riemann="hlld", integrator="vl2", nx=(24, 16, 16), mb=(12, 8, 8), ng=3)
+        pg = "synthetic"
+    elif case == "sod_outflow":
+        deck, ov = "sod", ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=8", "parthenon/mesh/nx3=8",
+                           "parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=4", "parthenon/meshblock/nx3=8"]
+        okw = dict(fluid="euler", recon="plm", riemann="hllc", integrator="rk2", nx=(32, 8, 8), mb=(8, 4, 8), ng=2,
+                   bc=("outflow", "periodic", "periodic"), xmin=(0.0, -0.5, -0.5), xmax=(1.0, 0.5, 0.5), gamma=1.4)
+        pg = "sod"
+    else:
+        deck, ov = "orszag_tang", ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/meshblock/nx1=8",
+                                   "parthenon/meshblock/nx2=16"]
+        okw = dict(fluid="glmmhd", recon="ppm", riemann="hlld", integrator="vl2", nx=(32, 32, 1), mb=(8, 16, 1), ng=3,
+                   xmin=(-0.5, -0.5, -0.5), xmax=(0.5, 0.5, 0.5))
+        pg = "orszag_tang"
+    o = oracle.Sim(**okw)
+    o.pgen(pg)
+    nvar = o.geom.nvar
+    rng = np.random.default_rng(0)
+    # distinct interior data per block, garbage in the ghosts
+    for b in range(o.nblocks):
+        o.cons(b)[...] = rng.uniform(1.0, 2.0, o.cons(b).shape)
+    start = {b: o.cons(b).copy() for b in range(o.nblocks)}
+    o.lib.orc_sim_exchange_ghosts(o.h)
+
+    def fill(gid, loc, shape):
+        assert shape == start[gid].shape
+        return start[gid].copy()
+
+    got, info = _run_plans(deck, ov, nranks, fill, nvar)
+    assert len(got) == o.nblocks
+    for gid, arr in got.items():
+        assert np.array_equal(arr, o.cons(gid)), "block %d differs" % gid
+
+
+def test_reflecting_boundary_plan(oracle):
+    ov = ["parthenon/mesh/nx1=16", "parthenon/mesh/nx2=8", "parthenon/mesh/nx3=8", "parthenon/meshblock/nx1=8",
+          "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=8", "parthenon/mesh/ix1_bc=reflecting",
+          "parthenon/mesh/ox1_bc=reflecting"]
+    o = oracle.Sim(fluid="euler", recon="plm", riemann="hllc", integrator="rk2", nx=(16, 8, 8), mb=(8, 8, 8), ng=2,
+                   bc=("reflecting", "periodic", "periodic"), xmin=(0.0, -0.5, -0.5), xmax=(1.0, 0.5, 0.5), gamma=1.4)
+    o.pgen("sod")
+    rng = np.random.default_rng(1)
+    for b in range(o.nblocks):
+        o.cons(b)[...] = rng.uniform(1.0, 2.0, o.cons(b).shape)
+    start = {b: o.cons(b).copy() for b in range(o.nblocks)}
+    o.lib.orc_sim_exchange_ghosts(o.h)
+    got, _ = _run_plans("sod", ov, 2, lambda gid, loc, shape: start[gid].copy(), 5)
+    for gid, arr in got.items():
+        assert np.array_equal(arr, o.cons(gid))
