@@ -265,25 +265,27 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
   const int64_t run = (int64_t)u0.nx2 * u0.ni;
   const int wpp = (int)((run + 61) / 62);
   const dim3 g1((wpp + 3) / 4, u0.nx3 * u0.nblocks, 1);
+  // timing slots: donor-cell stages (VL2 predictor) are accounted separately
+  constexpr int TS = (RECON == APK_RC_DC) ? (int)APK_T_FUSED_DC_X1 : (int)APK_T_FUSED_X1;
   if (u0.ndim == 1) {
-    ScopedTiming t(sp.ctx, APK_T_FUSED_X1, s);
+    ScopedTiming t(sp.ctx, TS + 0, s);
     hipLaunchKernelGGL((fused_x1_kernel<FLUID, RECON, RS, true>), g1, dim3(256), 0, s, u0, u1, sp, wpp);
   } else {
     {
-      ScopedTiming t(sp.ctx, APK_T_FUSED_X1, s);
+      ScopedTiming t(sp.ctx, TS + 0, s);
       hipLaunchKernelGGL((fused_x1_kernel<FLUID, RECON, RS, false>), g1, dim3(256), 0, s, u0, u1, sp, wpp);
     }
     const dim3 g2((u0.nx1 + 63) / 64, (u0.nx3 + 3) / 4, u0.nblocks);
     if (u0.ndim == 2) {
-      ScopedTiming t(sp.ctx, APK_T_FUSED_X2, s);
+      ScopedTiming t(sp.ctx, TS + 1, s);
       hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 2, true>), g2, dim3(256), 0, s, u0, u1, sp);
     } else {
       {
-        ScopedTiming t(sp.ctx, APK_T_FUSED_X2, s);
+        ScopedTiming t(sp.ctx, TS + 1, s);
         hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 2, false>), g2, dim3(256), 0, s, u0, u1, sp);
       }
       const dim3 g3((u0.nx1 + 63) / 64, (u0.nx2 + 3) / 4, u0.nblocks);
-      ScopedTiming t(sp.ctx, APK_T_FUSED_X3, s);
+      ScopedTiming t(sp.ctx, TS + 2, s);
       hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 3, true>), g3, dim3(256), 0, s, u0, u1, sp);
     }
   }

@@ -147,11 +147,21 @@ APK_DEV double wave_sum(double v) {
 // positive doubles order like their bit patterns, so the global min is one 64-bit atomicMin
 template <int FLUID>
 __global__ void __launch_bounds__(256)
-min_dt_kernel(PackView pv, double gamma, unsigned long long *min_bits) {
-  const CellIdx c = interior_cell(pv);
+min_dt_kernel(PackView pv, double gamma, unsigned long long *min_bits, int kchunks) {
+  // grid = (ceil(nx1/64), ceil(nx2/4), nblocks*kchunks): every workgroup walks a slab of k
+  // planes of its (i,j) tile, so the pack costs ~2k atomics instead of one per plane tile
+  CellIdx c;
+  c.i = pv.is + blockIdx.x * 64 + threadIdx.x;
+  c.j = pv.js + blockIdx.y * 4 + threadIdx.y;
+  c.b = blockIdx.z / kchunks;
+  const int chunk = blockIdx.z % kchunks;
+  const int klen = (pv.nx3 + kchunks - 1) / kchunks;
+  const int k0 = pv.ks + chunk * klen;
+  const int k1 = (k0 + klen - 1 < pv.ke) ? k0 + klen - 1 : pv.ke;
+  c.ok = (c.i <= pv.ie) && (c.j <= pv.je);
   double min_dt = 1.7976931348623157e308;
-  if (c.ok) {
-    const apk_block_desc blk = pv.blocks[c.b];
+  const apk_block_desc blk = pv.blocks[c.b];
+  for (c.k = k0; c.ok && c.k <= k1; ++c.k) {
     const double *w = blk.prim + c.k * pv.sk + c.j * pv.sj + c.i;
     const double d = w[IDN * pv.sn], v1 = w[IV1 * pv.sn], v2 = w[IV2 * pv.sn],
                  v3 = w[IV3 * pv.sn], p = w[IPR * pv.sn];
@@ -365,12 +375,14 @@ int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsig
 
 int launch_min_dt(const PackView &pv, int fluid, double gamma, unsigned long long *d_min_bits,
                   hipStream_t s) {
+  const int kchunks = pv.nx3 >= 8 ? 8 : pv.nx3;
+  const dim3 grid((pv.nx1 + 63) / 64, (pv.nx2 + 3) / 4, pv.nblocks * kchunks);
   if (fluid == APK_FLUID_EULER)
-    hipLaunchKernelGGL(min_dt_kernel<APK_FLUID_EULER>, interior_grid(pv), dim3(64, 4, 1), 0, s, pv,
-                       gamma, d_min_bits);
+    hipLaunchKernelGGL(min_dt_kernel<APK_FLUID_EULER>, grid, dim3(64, 4, 1), 0, s, pv, gamma,
+                       d_min_bits, kchunks);
   else
-    hipLaunchKernelGGL(min_dt_kernel<APK_FLUID_GLMMHD>, interior_grid(pv), dim3(64, 4, 1), 0, s,
-                       pv, gamma, d_min_bits);
+    hipLaunchKernelGGL(min_dt_kernel<APK_FLUID_GLMMHD>, grid, dim3(64, 4, 1), 0, s, pv, gamma,
+                       d_min_bits, kchunks);
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }
 

@@ -18,7 +18,7 @@ RIEMANN = {"none": 1, "hlle": 2, "llf": 3, "hllc": 4, "hlld": 5}
 INTEGRATOR = {"rk1": 1, "rk2": 2, "vl2": 3, "rk3": 4}
 
 TIMING_SLOTS = ("fused_x1", "fused_x2", "fused_x3", "fluxes", "update", "dedner", "cons_to_prim",
-                "min_dt", "copy_regions")
+                "min_dt", "copy_regions", "fused_dc_x1", "fused_dc_x2", "fused_dc_x3")
 
 APK_OK = 0
 APK_ERR_INVALID, APK_ERR_UNSUPPORTED, APK_ERR_NGHOST, APK_ERR_DEVICE, APK_ERR_NO_DEVICE = -1, -2, -3, -4, -5

@@ -212,7 +212,10 @@ enum apk_timing_slot {
   APK_T_C2P = 6,      /* ConservedToPrimitive      */
   APK_T_MIN_DT = 7,   /* EstimateHyperbolicTimestep */
   APK_T_COPY = 8,     /* strided box copies (ghost zones) */
-  APK_T_COUNT = 9
+  APK_T_FUSED_DC_X1 = 9,  /* the three fused sweeps when the stage reconstructs with donor */
+  APK_T_FUSED_DC_X2 = 10, /* cell (VL2 predictor, hydro.cpp:457-463); slots 0-2 then hold   */
+  APK_T_FUSED_DC_X3 = 11, /* only the high-order stages                                    */
+  APK_T_COUNT = 12
 };
 int apk_kernel_timing_enable(apk_ctx *ctx, int on);
 /* total_ms / launches may be NULL */

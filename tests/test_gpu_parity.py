@@ -23,8 +23,10 @@ def _ctx(request, strict):
 
 def _cmp(got, want, strict, what):
     if strict:
-        if not np.array_equal(got, want):
-            bad = np.argwhere(got != want)
+        # NaNs (e.g. sqrt of a negative reconstructed pressure on rough data) must appear in the
+        # same places on both sides; everything else must agree bit for bit
+        if not np.array_equal(got, want, equal_nan=True):
+            bad = np.argwhere((got != want) & ~(np.isnan(got) & np.isnan(want)))
             raise AssertionError("%s: %d entries differ bitwise, first at %s: %r vs %r" % (
                 what, len(bad), bad[0], got[tuple(bad[0])], want[tuple(bad[0])]))
     else:
@@ -222,7 +224,7 @@ def test_first_order_flux_correct(request, fluid):
     prim[:, 4] *= 1e-3  # very cold: a large explicit step drives the trial pressure negative
     cons = H.prim_to_cons(fluid, prim, GAMMA)
     fl = H.orc_fluxes(fluid, "plm", "hlle", g, prim, GAMMA, C_H)
-    beta_dt = 0.06
+    beta_dt = 0.3 if fluid == "euler" else 0.06  # large enough to drive trial states negative
     want_fl, want_n = H.orc_fofc(fluid, g, cons, prim, cons, fl, GAMMA, C_H, 0.0, 1.0, beta_dt)
     assert want_n > 0, "test data must trigger corrections"
     m0 = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=2, cons=cons, prim=prim)
