@@ -236,6 +236,7 @@ int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
   double coeff = 1.0;
   if (a->dedner != 0) coeff = std::exp(-a->glmmhd_alpha * a->c_h * a->beta_dt / a->mindx);
   rc = launch_stage_fused(ctx, u0->view, u1->view, *a, coeff, as_stream(stream));
+  if (rc == APK_ERR_UNSUPPORTED) return set_err(ctx, rc, "fused stage: option combination not supported (scalars, 1-D/extended-Dedner fill_derived)");
   if (rc != APK_OK) return set_err(ctx, rc, "fused stage kernel launch failed", hipGetLastError());
   return APK_OK;
 }
@@ -248,6 +249,29 @@ int apk_cons_to_prim(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos 
   ScopedTiming timing(ctx, APK_T_C2P, as_stream(stream));
   int rc = launch_cons_to_prim(md->view, fluid, *eos, ctx->d_flags, as_stream(stream));
   if (rc != APK_OK) return set_err(ctx, rc, "cons_to_prim kernel launch failed", hipGetLastError());
+  return APK_OK;
+}
+
+int apk_cons_to_prim_ghosts(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,
+                            apk_stream_t stream) {
+  if (!ctx || !md || !valid_eos(eos) || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||
+      md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9))
+    return set_err(ctx, APK_ERR_INVALID, "apk_cons_to_prim_ghosts: bad argument");
+  ScopedTiming timing(ctx, APK_T_C2P, as_stream(stream));
+  int rc = launch_cons_to_prim(md->view, fluid, *eos, ctx->d_flags, as_stream(stream), true);
+  if (rc != APK_OK) return set_err(ctx, rc, "cons_to_prim kernel launch failed", hipGetLastError());
+  return APK_OK;
+}
+
+int apk_stage_dt_read(apk_ctx *ctx, double cfl, double *dt_out, apk_stream_t stream) {
+  if (!ctx || !dt_out) return APK_ERR_INVALID;
+  hipStream_t s = as_stream(stream);
+  auto *h = static_cast<unsigned long long *>(ctx->h_pinned);
+  APK_HIP_TRY(ctx, hipMemcpyAsync(h + 4, ctx->d_u64 + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  APK_HIP_TRY(ctx, hipStreamSynchronize(s));
+  double m;
+  std::memcpy(&m, h + 4, sizeof(m));
+  *dt_out = cfl * m;  // hydro.cpp:909
   return APK_OK;
 }
 

@@ -17,6 +17,23 @@ int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
   sp.dedner_coeff = dedner_coeff;
   sp.du = nullptr;
   sp.ctx = ctx;
+  sp.eos = a.eos;
+  sp.flags = ctx->d_flags;
+  sp.dt_bits = ctx->d_u64 + 4;  // word 4: min of the finishing sweep (apk_stage_dt_read)
+  int extra = EXTRA_NONE;
+  if (a.fill_derived) {
+    // in-place prim replacement is only safe when the finishing sweep is a march (x2/x3) and
+    // the extended Dedner source does not read neighbouring primitives
+    if (u0.ndim == 1 || a.dedner == 2) return APK_ERR_UNSUPPORTED;
+    extra = a.estimate_dt ? EXTRA_C2P_DT : EXTRA_C2P;
+  } else if (a.estimate_dt) {
+    return APK_ERR_INVALID;
+  }
+  if (extra == EXTRA_C2P_DT) {
+    static const double huge = 1.7976931348623157e308;  // +max: neutral element of the min
+    if (hipMemcpyAsync(sp.dt_bits, &huge, sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess)
+      return APK_ERR_DEVICE;
+  }
   if (u0.ndim > 1) {
     const size_t need = (size_t)u0.nblocks * (size_t)u0.nvar * (size_t)u0.sn;
     if (need > ctx->du_cap) {  // workspace owned by the handle, grown on demand
@@ -32,11 +49,11 @@ int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
     sp.du = ctx->d_du;
   }
   if (a.cfg.fluid == APK_FLUID_EULER) {
-    if (a.cfg.riemann == APK_RS_HLLE) return launch_fused_euler_hlle(u0, u1, a.cfg.recon, sp, s);
-    if (a.cfg.riemann == APK_RS_HLLC) return launch_fused_euler_hllc(u0, u1, a.cfg.recon, sp, s);
+    if (a.cfg.riemann == APK_RS_HLLE) return launch_fused_euler_hlle(u0, u1, a.cfg.recon, sp, extra, s);
+    if (a.cfg.riemann == APK_RS_HLLC) return launch_fused_euler_hllc(u0, u1, a.cfg.recon, sp, extra, s);
   } else if (a.cfg.fluid == APK_FLUID_GLMMHD) {
-    if (a.cfg.riemann == APK_RS_HLLE) return launch_fused_mhd_hlle(u0, u1, a.cfg.recon, sp, s);
-    if (a.cfg.riemann == APK_RS_HLLD) return launch_fused_mhd_hlld(u0, u1, a.cfg.recon, sp, s);
+    if (a.cfg.riemann == APK_RS_HLLE) return launch_fused_mhd_hlle(u0, u1, a.cfg.recon, sp, extra, s);
+    if (a.cfg.riemann == APK_RS_HLLD) return launch_fused_mhd_hlld(u0, u1, a.cfg.recon, sp, extra, s);
   }
   return APK_ERR_UNSUPPORTED;
 }

@@ -7,10 +7,11 @@
 //    reconstructs ITS cell once, the L state travels one lane to the right and the face flux
 //    one lane to the left with DPP wave shifts (no LDS, no barrier).  62 of 64 lanes retire a
 //    cell; lanes that land on ghost columns idle.
-//  * x2 / x3 sweeps: one lane per x1 column (coalesced 512 B rows), marching along the sweep
-//    direction with the 3/5-point stencil, the previous face's L state and the previous face
-//    flux held in VGPRs -- the reference's "march j / march k with swapped scratch pencils"
-//    (src/hydro/hydro.cpp:1112-1199) without scratch memory and without team barriers.
+//  * x2 / x3 sweeps: one lane per x1 column (coalesced 512 B rows), one wave per workgroup
+//    marching along the sweep direction; the 3/5-point stencil sits in a private LDS ring, the
+//    newest row, the previous face's L state and the previous face flux in VGPRs -- the
+//    reference's "march j / march k with swapped scratch pencils"
+//    (src/hydro/hydro.cpp:1112-1199) without global scratch and without team barriers.
 //  The flux difference is accumulated in the reference's order, du = x1 term (+ x2 term)
 //  (+ x3 term), through one scratch array, and the sweep of the last active direction applies
 //  u0 <- gam0 u0 + gam1 u1 + beta_dt (-du/V) and the Dedner source, so results are
@@ -28,8 +29,15 @@ struct StageParams {
   double dedner_coeff;
   int dedner;  // 0 off, 1 plain, 2 extended
   double *du;  // scratch: [nblocks][nvar][Nk][Nj][Ni]
+  // optional work of the finishing sweep (apk_stage_args.fill_derived / estimate_dt)
+  apk_eos eos;                   // floors / ceilings for the in-place ConsToPrim
+  unsigned *flags;               // latched APK_FLAG_* word
+  unsigned long long *dt_bits;   // min over cells of dx_d/(|v_d|+c_d), as ordered bits
   apk_ctx *ctx;  // host side only (kernel timing); never dereferenced on the device
 };
+
+// what the finishing sweep does besides the RK update + Dedner source
+enum { EXTRA_NONE = 0, EXTRA_C2P = 1, EXTRA_C2P_DT = 2 };
 
 // ---- DPP wave shifts (gfx9: wave_shr:1 = 0x138, wave_shl:1 = 0x130) ------------------------
 APK_DEV double wave_shr1(double x) {  // lane l receives lane l-1 (lane 0 keeps its own)
@@ -48,10 +56,10 @@ APK_DEV double wave_shl1(double x) {  // lane l receives lane l+1 (lane 63 keeps
 // ---- end-of-stage update of one cell (FINAL sweep) -------------------------------------------
 // UpdateWithFluxDivergence (hydro_driver.cpp:534-537) then DednerSource
 // (dedner_source.cpp:42-74), in that order, exactly as the task list runs them.
-template <int FLUID>
+template <int FLUID, int EXTRA = EXTRA_NONE>
 APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0, const double *c1,
                          int64_t cell, const double (&du)[nvars<FLUID>()], double vol,
-                         const StageParams &sp) {
+                         const StageParams &sp, double &lane_min_dt) {
   constexpr int NV = nvars<FLUID>();
   double un[NV];
 #pragma unroll
@@ -77,6 +85,32 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0, const dou
                   b3[0] * (ps[ko] - ps[-ko]) / b0.dx[2]);
     }
     if (sp.dedner != 0) un[IPS] *= sp.dedner_coeff;
+  }
+  if constexpr (EXTRA != EXTRA_NONE) {
+    // FillDerived for this cell (adiabatic_hydro.hpp:52-142): in a march along x2/x3 no other lane
+    // reads this column of prim during the sweep and this lane's stencil copy sits in its LDS
+    // ring, so prim can be replaced in place.  Floors/ceilings act on `un` before it is stored.
+    double w[NV], di;
+    const unsigned fl = cons_to_prim_cell<FLUID>(sp.eos, un, w, di);
+    if (fl) atomicOr(sp.flags, fl);
+#pragma unroll
+    for (int n = 0; n < NV; ++n) b0.prim[n * pv.sn + cell] = w[n];
+    if constexpr (EXTRA == EXTRA_C2P_DT) {
+      // EstimateHyperbolicTimestep (hydro.cpp:845-895) on the fresh primitives
+      double lx, ly = 0.0, lz = 0.0;
+      if constexpr (FLUID == APK_FLUID_EULER) {
+        lx = sound_speed(sp.eos.gamma, w[IDN], w[IPR]);
+        ly = lx;
+        lz = lx;
+      } else {
+        lx = fast_speed(sp.eos.gamma, w[IDN], w[IPR], w[IB1], w[IB2], w[IB3]);
+        if (pv.ndim > 1) ly = fast_speed(sp.eos.gamma, w[IDN], w[IPR], w[IB2], w[IB3], w[IB1]);
+        if (pv.ndim > 2) lz = fast_speed(sp.eos.gamma, w[IDN], w[IPR], w[IB3], w[IB1], w[IB2]);
+      }
+      lane_min_dt = fmin(lane_min_dt, b0.dx[0] / (fabs(w[IV1]) + lx));
+      if (pv.ndim > 1) lane_min_dt = fmin(lane_min_dt, b0.dx[1] / (fabs(w[IV2]) + ly));
+      if (pv.ndim > 2) lane_min_dt = fmin(lane_min_dt, b0.dx[2] / (fabs(w[IV3]) + lz));
+    }
   }
 #pragma unroll
   for (int n = 0; n < NV; ++n) b0.cons[n * pv.sn + cell] = un[n];
@@ -145,7 +179,8 @@ fused_x1_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_plane) {
   if (!do_cell) return;
   if constexpr (FINAL) {
     const double vol = b0.dx[0] * b0.dx[1] * b0.dx[2];
-    finish_cell<FLUID>(u0, b0, u1.blocks[b].cons, cell, du, vol, sp);
+    double unused_dt = 0.0;
+    finish_cell<FLUID>(u0, b0, u1.blocks[b].cons, cell, du, vol, sp, unused_dt);
   } else {
     double *d = sp.du + (int64_t)b * u0.sn * u0.nvar + cell;
 #pragma unroll
@@ -154,20 +189,33 @@ fused_x1_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_plane) {
 }
 
 // ==============================================================================================
-// x2 / x3 sweeps: register-resident march
+// x2 / x3 sweeps: one wave per workgroup marching along the sweep direction
 // ==============================================================================================
-template <int FLUID, int RECON, int RS, int DIR, bool FINAL>
-__global__ void __launch_bounds__(256)
+// Stencil rows c-H .. c+H-1 of the wave's 64 columns live in a private LDS ring
+// (ring[slot][var][lane], conflict-free ds_read_b64, no barrier: a lane only ever touches its own
+// column); the newest row c+H is loaded from HBM one iteration ahead and sits in registers while
+// the Riemann problem of the previous face is solved.  Keeping the ring out of the VGPR file
+// (it would be 2H*NV doubles = 72 VGPRs for PPM/GLM-MHD) is what lets two waves share a SIMD.
+constexpr int kMarchMinWaves = 2;
+
+template <int FLUID, int RECON>
+constexpr int march_lds_bytes() {
+  return 2 * recon_halfwidth(RECON) * nvars<FLUID>() * 64 * (int)sizeof(double);
+}
+
+template <int FLUID, int RECON, int RS, int DIR, bool FINAL, int EXTRA = EXTRA_NONE>
+__global__ void __launch_bounds__(64, kMarchMinWaves)
 fused_march_kernel(PackView u0, PackView u1, StageParams sp) {
   static_assert(DIR == 2 || DIR == 3, "march is for x2/x3");
+  static_assert(FINAL || EXTRA == EXTRA_NONE, "extras belong to the finishing sweep");
+  double lane_min_dt = 1.7976931348623157e308;
   constexpr int NV = nvars<FLUID>();
   constexpr int H = recon_halfwidth(RECON);
-  constexpr int W = 2 * H + 1;
-  // lanes along x1 (interior only), the transverse index on blockIdx.y
-  const int i = u0.is + blockIdx.x * 64 + (threadIdx.x & 63);
-  const int trans = blockIdx.y * 4 + (threadIdx.x >> 6);  // k for DIR==2, j for DIR==3
-  const int ntrans = (DIR == 2) ? u0.nx3 : u0.nx2;
-  if (trans >= ntrans) return;  // wave-uniform
+  constexpr int NS = 2 * H;  // ring slots
+  extern __shared__ __attribute__((aligned(16))) double ring[];
+  const int lane = threadIdx.x;
+  const int i = u0.is + blockIdx.x * 64 + lane;
+  const int trans = blockIdx.y;  // k for DIR==2, j for DIR==3
   const bool active = (i <= u0.ie);
   const int ii = active ? i : u0.ie;  // idle lanes shadow a valid column, never store
   const int b = blockIdx.z;
@@ -183,14 +231,18 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp) {
   const double area = (DIR == 2) ? b0.dx[0] * b0.dx[2] : b0.dx[0] * b0.dx[1];
   const double vol = b0.dx[0] * b0.dx[1] * b0.dx[2];
   double *dscratch = sp.du + (int64_t)b * u0.sn * u0.nvar;
+  const double *prim = b0.prim + base;
 
-  // stencil registers P[n][0..W-1] = prim(n, c-H .. c+H) for the current cell c
-  double P[NV][W];
+  // row r of the stencil lives in slot (r - (s-1-H)) mod NS
   int c = s - 1;
+  const int r0 = c - H;
 #pragma unroll
-  for (int n = 0; n < NV; ++n)
+  for (int m = 0; m < NS; ++m)
 #pragma unroll
-    for (int m = 0; m < W; ++m) P[n][m] = b0.prim[n * u0.sn + base + (int64_t)(c - H + m) * st];
+    for (int n = 0; n < NV; ++n) ring[(m * NV + n) * 64 + lane] = prim[n * u0.sn + (int64_t)(r0 + m) * st];
+  double Pn[NV];  // row c+H
+#pragma unroll
+  for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + (int64_t)(c + H) * st];
 
   double wl_prev[NV];  // permuted L state at face c (from cell c-1)
   double f_prev[NV];   // permuted flux at face c-1
@@ -200,24 +252,37 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp) {
     f_prev[q] = 0.0;
   }
 
+  int slot0 = 0;  // slot holding row c-H
   for (; c <= e + 1; ++c) {
-    // prefetch the row entering the stencil next iteration
-    double Pn[NV];
-    const bool more = (c < e + 1);
-    if (more) {
-#pragma unroll
-      for (int n = 0; n < NV; ++n) Pn[n] = b0.prim[n * u0.sn + base + (int64_t)(c + 1 + H) * st];
-    }
-    // reconstruct cell c
+    // reconstruct cell c from ring rows c-H..c+H-1 and the register row c+H
     double qln[NV], qrn[NV];
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
-      if constexpr (H == 0)
-        reconstruct<RECON>(0.0, 0.0, P[n][0], 0.0, 0.0, dx, n, qln[n], qrn[n]);
-      else if constexpr (H == 1)
-        reconstruct<RECON>(0.0, P[n][0], P[n][1], P[n][2], 0.0, dx, n, qln[n], qrn[n]);
-      else
-        reconstruct<RECON>(P[n][0], P[n][1], P[n][2], P[n][3], P[n][4], dx, n, qln[n], qrn[n]);
+      if constexpr (H == 0) {
+        reconstruct<RECON>(0.0, 0.0, Pn[n], 0.0, 0.0, dx, n, qln[n], qrn[n]);
+      } else if constexpr (H == 1) {
+        const double a0 = ring[(slot0 * NV + n) * 64 + lane];
+        const double a1 = ring[(((slot0 + 1) & 1) * NV + n) * 64 + lane];
+        reconstruct<RECON>(0.0, a0, a1, Pn[n], 0.0, dx, n, qln[n], qrn[n]);
+      } else {
+        const double a0 = ring[(slot0 * NV + n) * 64 + lane];
+        const double a1 = ring[(((slot0 + 1) & 3) * NV + n) * 64 + lane];
+        const double a2 = ring[(((slot0 + 2) & 3) * NV + n) * 64 + lane];
+        const double a3 = ring[(((slot0 + 3) & 3) * NV + n) * 64 + lane];
+        reconstruct<RECON>(a0, a1, a2, a3, Pn[n], dx, n, qln[n], qrn[n]);
+      }
+    }
+    // row c+H replaces row c-H in the ring; fetch row c+1+H for the next iteration now so the
+    // loads fly while the Riemann problem below is solved
+    const bool more = (c < e + 1);
+    if (more) {
+      if constexpr (NS > 0) {
+#pragma unroll
+        for (int n = 0; n < NV; ++n) ring[(slot0 * NV + n) * 64 + lane] = Pn[n];
+        slot0 = (slot0 + 1) & (NS - 1);
+      }
+#pragma unroll
+      for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + (int64_t)(c + 1 + H) * st];
     }
     if (c >= s) {
       double wr[NV], f[NV];
@@ -235,7 +300,7 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp) {
         }
         if (active) {
           if constexpr (FINAL) {
-            finish_cell<FLUID>(u0, b0, c1, cell, du, vol, sp);
+            finish_cell<FLUID, EXTRA>(u0, b0, c1, cell, du, vol, sp, lane_min_dt);
           } else {
 #pragma unroll
             for (int n = 0; n < NV; ++n) dscratch[n * u0.sn + cell] = du[n];
@@ -247,21 +312,173 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp) {
     }
 #pragma unroll
     for (int q = 0; q < NV; ++q) wl_prev[q] = qln[perm<DIR>(q)];
+  }
+  if constexpr (EXTRA == EXTRA_C2P_DT) {
+    // one atomic per wave for the whole march (positive doubles order like their bit patterns)
+    double m = lane_min_dt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_down(m, off, 64));
+    if (lane == 0) atomicMin(sp.dt_bits, (unsigned long long)__double_as_longlong(m));
+  }
+}
+
+// ==============================================================================================
+// 3-D: x1 and x2 sweeps in ONE march (saves a full round trip of the du array and a re-read of
+// prim).  Lanes are the flattened (k, i) cells of one j-row of a block, Ni per k (ghost columns
+// included so a row edge never needs a neighbour wave), 62 useful lanes per wave as in the x1
+// sweep; the wave marches along j.  Row c of the march is the x1 pencil: its fluxes are exchanged
+// with DPP wave shifts, its flux difference waits one iteration in registers until the x2 flux
+// at face c+1 is known, then du = (x1 term + x2 term) is stored in the reference's order.
+// ==============================================================================================
+template <int FLUID, int RECON, int RS>
+__global__ void __launch_bounds__(64, kMarchMinWaves)
+fused_march12_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_block) {
+  constexpr int NV = nvars<FLUID>();
+  constexpr int H = recon_halfwidth(RECON);
+  constexpr int NS = 2 * H;
+  extern __shared__ __attribute__((aligned(16))) double ring[];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.z;
+  const apk_block_desc b0 = u0.blocks[b];
+
+  const int64_t run = (int64_t)u0.nx3 * u0.ni;
+  const int64_t t = (int64_t)blockIdx.x * 62 + lane - 1;
+  const bool in_run = (t >= 0) && (t < run);
+  const int64_t tc = in_run ? t : (t < 0 ? 0 : run - 1);  // out-of-run lanes shadow a valid column
+  const int krow = (int)(tc / u0.ni);
+  const int i = (int)(tc - (int64_t)krow * u0.ni);
+  const bool x1_recon = in_run && (i >= u0.is - 1) && (i <= u0.ie + 1);
+  // the cell column this lane retires (needs the lane on its left and on its right)
+  const bool active = in_run && (lane >= 1) && (lane <= 62) && (i >= u0.is) && (i <= u0.ie);
+
+  const int64_t st = u0.sj;
+  const int s = u0.js, e = u0.je;
+  const int64_t base = (int64_t)(u0.ks + krow) * u0.sk + i;
+  const double dx1 = b0.dx[0], dx2 = b0.dx[1];
+  const double area1 = b0.dx[1] * b0.dx[2];
+  const double area2 = b0.dx[0] * b0.dx[2];
+  double *dscratch = sp.du + (int64_t)b * u0.sn * u0.nvar;
+  const double *prim = b0.prim + base;
+
+  int c = s - 1;
+  const int r0 = c - H;
+#pragma unroll
+  for (int m = 0; m < NS; ++m)
+#pragma unroll
+    for (int n = 0; n < NV; ++n) ring[(m * NV + n) * 64 + lane] = prim[n * u0.sn + (int64_t)(r0 + m) * st];
+  double Pn[NV];
+#pragma unroll
+  for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + (int64_t)(c + H) * st];
+
+  double wl_prev[NV], f_prev[NV], du1_prev[NV];  // x2 L state / x2 flux / x1 flux difference of row c-1
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    wl_prev[q] = 0.0;
+    f_prev[q] = 0.0;
+    du1_prev[q] = 0.0;
+  }
+
+  int slot0 = 0;
+  for (; c <= e + 1; ++c) {
+    // ---- x2: reconstruct cell c along j ---------------------------------------------------------
+    double qln[NV], qrn[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      if constexpr (H == 0) {
+        reconstruct<RECON>(0.0, 0.0, Pn[n], 0.0, 0.0, dx2, n, qln[n], qrn[n]);
+      } else if constexpr (H == 1) {
+        const double a0 = ring[(slot0 * NV + n) * 64 + lane];
+        const double a1 = ring[(((slot0 + 1) & 1) * NV + n) * 64 + lane];
+        reconstruct<RECON>(0.0, a0, a1, Pn[n], 0.0, dx2, n, qln[n], qrn[n]);
+      } else {
+        const double a0 = ring[(slot0 * NV + n) * 64 + lane];
+        const double a1 = ring[(((slot0 + 1) & 3) * NV + n) * 64 + lane];
+        const double a2 = ring[(((slot0 + 2) & 3) * NV + n) * 64 + lane];
+        const double a3 = ring[(((slot0 + 3) & 3) * NV + n) * 64 + lane];
+        reconstruct<RECON>(a0, a1, a2, a3, Pn[n], dx2, n, qln[n], qrn[n]);
+      }
+    }
+    const bool more = (c < e + 1);
     if (more) {
+      if constexpr (NS > 0) {
+#pragma unroll
+        for (int n = 0; n < NV; ++n) ring[(slot0 * NV + n) * 64 + lane] = Pn[n];
+        slot0 = (slot0 + 1) & (NS - 1);
+      }
+#pragma unroll
+      for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + (int64_t)(c + 1 + H) * st];
+    }
+    if (c >= s) {
+      double wr[NV], f[NV];
+#pragma unroll
+      for (int q = 0; q < NV; ++q) wr[q] = qrn[perm<2>(q)];
+      riemann<FLUID, RS>(wl_prev, wr, sp.gamma, sp.c_h, f);
+      if (c >= s + 1 && active) {
+        // cell c-1: du = (x1 term) + (x2 term), the reference's accumulation order
+        const int64_t cell = base + (int64_t)(c - 1) * st;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const int n = perm<2>(q);
+          dscratch[n * u0.sn + cell] = du1_prev[n] + (area2 * f[q] - area2 * f_prev[q]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NV; ++q) f_prev[q] = f[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NV; ++q) wl_prev[q] = qln[perm<2>(q)];
+
+    // ---- x1: row c is an interior row -> its x1 flux difference (all lanes take part in the DPP) --
+    if (c >= s && c <= e) {  // wave-uniform
+      double ql1[NV], qr1[NV];
 #pragma unroll
       for (int n = 0; n < NV; ++n) {
+        double qm2 = 1.0, qm1 = 1.0, q0 = 1.0, qp1 = 1.0, qp2 = 1.0;
+        if (x1_recon) {
+          const double *cc = prim + n * u0.sn + (int64_t)c * st;
+          q0 = cc[0];
+          if constexpr (H >= 1) {
+            qm1 = cc[-1];
+            qp1 = cc[1];
+          }
+          if constexpr (H >= 2) {
+            qm2 = cc[-2];
+            qp2 = cc[2];
+          }
+        }
+        reconstruct<RECON>(qm2, qm1, q0, qp1, qp2, dx1, n, ql1[n], qr1[n]);
+      }
+      double wl[NV], wr[NV], f[NV];
 #pragma unroll
-        for (int m = 0; m + 1 < W; ++m) P[n][m] = P[n][m + 1];
-        P[n][W - 1] = Pn[n];
+      for (int q = 0; q < NV; ++q) {
+        wl[q] = wave_shr1(ql1[perm<1>(q)]);
+        wr[q] = qr1[perm<1>(q)];
+      }
+      riemann<FLUID, RS>(wl, wr, sp.gamma, sp.c_h, f);
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const double fup = wave_shl1(f[q]);
+        du1_prev[perm<1>(q)] = (area1 * fup - area1 * f[q]);
       }
     }
   }
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------
+template <int FLUID, int RECON, int RS, int DIR>
+inline void launch_final_march(const PackView &u0, const PackView &u1, const StageParams &sp, int extra,
+                               dim3 grid, int lds, hipStream_t s) {
+  if (extra == EXTRA_C2P_DT)
+    hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, DIR, true, EXTRA_C2P_DT>), grid, dim3(64), lds, s, u0, u1, sp);
+  else if (extra == EXTRA_C2P)
+    hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, DIR, true, EXTRA_C2P>), grid, dim3(64), lds, s, u0, u1, sp);
+  else
+    hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, DIR, true, EXTRA_NONE>), grid, dim3(64), lds, s, u0, u1, sp);
+}
+
 template <int FLUID, int RECON, int RS>
 inline int launch_fused_stage(const PackView &u0, const PackView &u1, const StageParams &sp,
-                              hipStream_t s) {
+                              int extra, hipStream_t s) {
   const int64_t run = (int64_t)u0.nx2 * u0.ni;
   const int wpp = (int)((run + 61) / 62);
   const dim3 g1((wpp + 3) / 4, u0.nx3 * u0.nblocks, 1);
@@ -270,45 +487,63 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
   if (u0.ndim == 1) {
     ScopedTiming t(sp.ctx, TS + 0, s);
     hipLaunchKernelGGL((fused_x1_kernel<FLUID, RECON, RS, true>), g1, dim3(256), 0, s, u0, u1, sp, wpp);
+  } else if (u0.ndim == 3) {
+    constexpr int lds = march_lds_bytes<FLUID, RECON>();
+    if constexpr (RECON == APK_RC_DC) {
+      // donor cell: the sweeps are HBM-bound, so x1 and x2 share ONE march over (k,i)-flattened
+      // lanes (one du round trip and one prim read less).  With a high-order reconstruction
+      // the sweeps are ALU-bound and the 62/64 x 128/134 lane efficiency of the flattened march
+      // (and its 2216-wave grid on a 2048-wave machine) costs more than the traffic it saves
+      // (measured: PPM+HLLD 3.3 ms fused vs 1.39 + 1.02 ms separate on 8 x 128^3).
+      const int64_t run12 = (int64_t)u0.nx3 * u0.ni;
+      const int wpb = (int)((run12 + 61) / 62);
+      ScopedTiming t(sp.ctx, TS + 0, s);
+      hipLaunchKernelGGL((fused_march12_kernel<FLUID, RECON, RS>), dim3(wpb, 1, u0.nblocks), dim3(64), lds, s,
+                         u0, u1, sp, wpb);
+    } else {
+      {
+        ScopedTiming t(sp.ctx, TS + 0, s);
+        hipLaunchKernelGGL((fused_x1_kernel<FLUID, RECON, RS, false>), g1, dim3(256), 0, s, u0, u1, sp, wpp);
+      }
+      const dim3 g2((u0.nx1 + 63) / 64, u0.nx3, u0.nblocks);
+      ScopedTiming t(sp.ctx, TS + 1, s);
+      hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 2, false>), g2, dim3(64), lds, s, u0, u1, sp);
+    }
+    const dim3 g3((u0.nx1 + 63) / 64, u0.nx2, u0.nblocks);
+    ScopedTiming t(sp.ctx, TS + 2, s);
+    launch_final_march<FLUID, RECON, RS, 3>(u0, u1, sp, extra, g3, lds, s);
   } else {
     {
       ScopedTiming t(sp.ctx, TS + 0, s);
       hipLaunchKernelGGL((fused_x1_kernel<FLUID, RECON, RS, false>), g1, dim3(256), 0, s, u0, u1, sp, wpp);
     }
-    const dim3 g2((u0.nx1 + 63) / 64, (u0.nx3 + 3) / 4, u0.nblocks);
-    if (u0.ndim == 2) {
-      ScopedTiming t(sp.ctx, TS + 1, s);
-      hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 2, true>), g2, dim3(256), 0, s, u0, u1, sp);
-    } else {
-      {
-        ScopedTiming t(sp.ctx, TS + 1, s);
-        hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 2, false>), g2, dim3(256), 0, s, u0, u1, sp);
-      }
-      const dim3 g3((u0.nx1 + 63) / 64, (u0.nx2 + 3) / 4, u0.nblocks);
-      ScopedTiming t(sp.ctx, TS + 2, s);
-      hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 3, true>), g3, dim3(256), 0, s, u0, u1, sp);
-    }
+    // 2-D: the (j,i)-flattened x1 sweep keeps far more waves in flight than a march over a
+    // single k-plane would; the x2 march finishes the stage
+    constexpr int lds = march_lds_bytes<FLUID, RECON>();
+    const dim3 g2((u0.nx1 + 63) / 64, u0.nx3, u0.nblocks);
+    ScopedTiming t(sp.ctx, TS + 1, s);
+    launch_final_march<FLUID, RECON, RS, 2>(u0, u1, sp, extra, g2, lds, s);
   }
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }
 
 template <int FLUID, int RS>
 inline int launch_fused_family(const PackView &u0, const PackView &u1, int recon,
-                               const StageParams &sp, hipStream_t s) {
+                               const StageParams &sp, int extra, hipStream_t s) {
   switch (recon) {
-  case APK_RC_DC: return launch_fused_stage<FLUID, APK_RC_DC, RS>(u0, u1, sp, s);
-  case APK_RC_PLM: return launch_fused_stage<FLUID, APK_RC_PLM, RS>(u0, u1, sp, s);
-  case APK_RC_PPM: return launch_fused_stage<FLUID, APK_RC_PPM, RS>(u0, u1, sp, s);
-  case APK_RC_WENOZ: return launch_fused_stage<FLUID, APK_RC_WENOZ, RS>(u0, u1, sp, s);
-  case APK_RC_WENO3: return launch_fused_stage<FLUID, APK_RC_WENO3, RS>(u0, u1, sp, s);
-  case APK_RC_LIMO3: return launch_fused_stage<FLUID, APK_RC_LIMO3, RS>(u0, u1, sp, s);
+  case APK_RC_DC: return launch_fused_stage<FLUID, APK_RC_DC, RS>(u0, u1, sp, extra, s);
+  case APK_RC_PLM: return launch_fused_stage<FLUID, APK_RC_PLM, RS>(u0, u1, sp, extra, s);
+  case APK_RC_PPM: return launch_fused_stage<FLUID, APK_RC_PPM, RS>(u0, u1, sp, extra, s);
+  case APK_RC_WENOZ: return launch_fused_stage<FLUID, APK_RC_WENOZ, RS>(u0, u1, sp, extra, s);
+  case APK_RC_WENO3: return launch_fused_stage<FLUID, APK_RC_WENO3, RS>(u0, u1, sp, extra, s);
+  case APK_RC_LIMO3: return launch_fused_stage<FLUID, APK_RC_LIMO3, RS>(u0, u1, sp, extra, s);
   default: return APK_ERR_UNSUPPORTED;
   }
 }
 
-int launch_fused_euler_hlle(const PackView &u0, const PackView &u1, int recon, const StageParams &sp, hipStream_t s);
-int launch_fused_euler_hllc(const PackView &u0, const PackView &u1, int recon, const StageParams &sp, hipStream_t s);
-int launch_fused_mhd_hlle(const PackView &u0, const PackView &u1, int recon, const StageParams &sp, hipStream_t s);
-int launch_fused_mhd_hlld(const PackView &u0, const PackView &u1, int recon, const StageParams &sp, hipStream_t s);
+int launch_fused_euler_hlle(const PackView &u0, const PackView &u1, int recon, const StageParams &sp, int extra, hipStream_t s);
+int launch_fused_euler_hllc(const PackView &u0, const PackView &u1, int recon, const StageParams &sp, int extra, hipStream_t s);
+int launch_fused_mhd_hlle(const PackView &u0, const PackView &u1, int recon, const StageParams &sp, int extra, hipStream_t s);
+int launch_fused_mhd_hlld(const PackView &u0, const PackView &u1, int recon, const StageParams &sp, int extra, hipStream_t s);
 
 }  // namespace apk

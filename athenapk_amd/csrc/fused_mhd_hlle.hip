@@ -3,7 +3,7 @@
 
 namespace apk {
 int launch_fused_mhd_hlle(const PackView &u0, const PackView &u1, int recon,
-                         const StageParams &sp, hipStream_t s) {
-  return launch_fused_family<APK_FLUID_GLMMHD, APK_RS_HLLE>(u0, u1, recon, sp, s);
+                         const StageParams &sp, int extra, hipStream_t s) {
+  return launch_fused_family<APK_FLUID_GLMMHD, APK_RS_HLLE>(u0, u1, recon, sp, extra, s);
 }
 }  // namespace apk

@@ -390,32 +390,34 @@ void dev_free(apk_sim *s, double *p) {
 }
 
 int build_packs(apk_sim *s) {
-  if (s->mu0) apk_pack_destroy(s->mu0);
-  if (s->mu1) apk_pack_destroy(s->mu1);
-  s->mu0 = s->mu1 = nullptr;
   const int nlb = (int)s->mesh.local_gids.size();
-  std::vector<apk_block_desc> b0(nlb), b1(nlb);
-  for (int lb = 0; lb < nlb; ++lb) {
-    b0[lb].cons = s->d_cons + lb * s->nper;
-    b0[lb].prim = s->d_prim + lb * s->nper;
-    b1[lb].cons = s->d_u1 + lb * s->nper;
-    b1[lb].prim = nullptr;
-    for (int d = 0; d < 3; ++d) {
-      b0[lb].flux[d] = s->d_flux[d] ? s->d_flux[d] + lb * s->nper : nullptr;
-      b1[lb].flux[d] = nullptr;
-      b0[lb].dx[d] = b1[lb].dx[d] = s->dx[d];
+  for (int p = 0; p < 2; ++p) {
+    if (s->mu0_of[p]) apk_pack_destroy(s->mu0_of[p]);
+    if (s->mu1_of[p]) apk_pack_destroy(s->mu1_of[p]);
+    s->mu0_of[p] = s->mu1_of[p] = nullptr;
+    std::vector<apk_block_desc> b0(nlb), b1(nlb);
+    for (int lb = 0; lb < nlb; ++lb) {
+      b0[lb].cons = s->d_cons2[p] + lb * s->nper;
+      b0[lb].prim = s->d_prim + lb * s->nper;
+      b1[lb].cons = s->d_cons2[p] + lb * s->nper;
+      b1[lb].prim = nullptr;
+      for (int d = 0; d < 3; ++d) {
+        b0[lb].flux[d] = s->d_flux[d] ? s->d_flux[d] + lb * s->nper : nullptr;
+        b1[lb].flux[d] = nullptr;
+        b0[lb].dx[d] = b1[lb].dx[d] = s->dx[d];
+      }
     }
+    apk_pack_desc d{};
+    d.nblocks = nlb;
+    d.nhydro = s->pkg.nhydro;
+    d.nscalars = s->pkg.nscalars;
+    for (int q = 0; q < 3; ++q) d.nx[q] = s->mesh.mb[q];
+    d.ng = s->mesh.ng;
+    d.blocks = b0.data();
+    SIM_TRY(s, apk_pack_create(s->ctx, &d, &s->mu0_of[p]));
+    d.blocks = b1.data();
+    SIM_TRY(s, apk_pack_create(s->ctx, &d, &s->mu1_of[p]));
   }
-  apk_pack_desc d{};
-  d.nblocks = nlb;
-  d.nhydro = s->pkg.nhydro;
-  d.nscalars = s->pkg.nscalars;
-  for (int q = 0; q < 3; ++q) d.nx[q] = s->mesh.mb[q];
-  d.ng = s->mesh.ng;
-  d.blocks = b0.data();
-  SIM_TRY(s, apk_pack_create(s->ctx, &d, &s->mu0));
-  d.blocks = b1.data();
-  SIM_TRY(s, apk_pack_create(s->ctx, &d, &s->mu1));
   return APK_OK;
 }
 
@@ -430,7 +432,7 @@ int ensure_flux_arrays(apk_sim *s) {
       changed = true;
     }
   }
-  if (changed || !s->mu0) return build_packs(s);
+  if (changed || !s->mu0_of[0]) return build_packs(s);
   return APK_OK;
 }
 
@@ -439,19 +441,20 @@ bool stage_can_fuse(const apk_sim *s) {
          s->pkg.riemann != APK_RS_NONE && s->pkg.riemann != APK_RS_LLF;
 }
 
-double *region_base(apk_sim *s, int kind, int block) {
-  if (kind == RK_BLOCK) return s->d_cons + (int64_t)block * s->nper;
+double *region_base(apk_sim *s, int parity, int kind, int block) {
+  if (kind == RK_BLOCK) return s->d_cons2[parity] + (int64_t)block * s->nper;
   if (kind == RK_SEND) return s->send_buf[block];
   return s->recv_buf[block];
 }
 
 int build_copy_plans(apk_sim *s) {
+  for (int par = 0; par < 2; ++par)
   for (int ph = 0; ph < PH_COUNT; ++ph) {
     std::vector<apk_copy_region> regs;
     for (const BoxRegion &r : s->mesh.plan[ph]) {
       apk_copy_region c{};
-      c.src = region_base(s, r.src_kind, r.src_block) + r.src_off;
-      c.dst = region_base(s, r.dst_kind, r.dst_block) + r.dst_off;
+      c.src = region_base(s, par, r.src_kind, r.src_block) + r.src_off;
+      c.dst = region_base(s, par, r.dst_kind, r.dst_block) + r.dst_off;
       for (int q = 0; q < 3; ++q) c.ext[q] = r.ext[q];
       c.nvar = r.nvar;
       for (int q = 0; q < 4; ++q) {
@@ -461,7 +464,7 @@ int build_copy_plans(apk_sim *s) {
       c.flip_var = r.flip_var;
       regs.push_back(c);
     }
-    SIM_TRY(s, apk_copy_plan_create(s->ctx, regs.data(), (int)regs.size(), &s->plans[ph]));
+    SIM_TRY(s, apk_copy_plan_create(s->ctx, regs.data(), (int)regs.size(), &s->plans_of[par][ph]));
   }
   return APK_OK;
 }
@@ -479,7 +482,12 @@ void set_global_dt(apk_sim *s, double dt_est) {
 int estimate_timestep(apk_sim *s, double *dt_out) {
   double dt = kHuge;
   if (s->pkg.calc_dt_hyp) {
-    SIM_TRY(s, apk_estimate_timestep(s->ctx, s->mu0, s->pkg.fluid, &s->pkg.eos, s->pkg.cfl, &dt, s->stream));
+    if (s->stage_dt_pending) {  // already reduced by the finishing sweep of the last stage
+      SIM_TRY(s, apk_stage_dt_read(s->ctx, s->pkg.cfl, &dt, s->stream));
+      s->stage_dt_pending = false;
+    } else {
+      SIM_TRY(s, apk_estimate_timestep(s->ctx, s->mu0(), s->pkg.fluid, &s->pkg.eos, s->pkg.cfl, &dt, s->stream));
+    }
     if (s->pkg.fluid == APK_FLUID_GLMMHD && dt < s->pkg.dt_hyp) s->pkg.dt_hyp = dt;  // hydro.cpp:903-908
   }
   if (s->pkg.max_dt > 0.0 && s->pkg.max_dt < dt) dt = s->pkg.max_dt;
@@ -499,20 +507,20 @@ int estimate_timestep(apk_sim *s, double *dt_out) {
 int exchange_ghosts(apk_sim *s) {
   const bool remote = !s->mesh.peers.empty();
   if (remote) {
-    SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plans[PH_PACK], s->stream));
+    SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(PH_PACK), s->stream));
   }
-  SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plans[PH_LOCAL], s->stream));
+  SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(PH_LOCAL), s->stream));
   if (remote) {
     if (!s->have_comm || !s->comm.exchange) return fail(s, APK_ERR_INVALID, "remote neighbours but no comm ops");
     if (s->comm.exchange(s->comm.user) != 0) return fail(s, APK_ERR_DEVICE, "halo exchange failed");
-    SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plans[PH_UNPACK], s->stream));
+    SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(PH_UNPACK), s->stream));
   }
-  for (int ph = PH_BC1; ph <= PH_BC3; ++ph) SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plans[ph], s->stream));
+  for (int ph = PH_BC1; ph <= PH_BC3; ++ph) SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(ph), s->stream));
   return APK_OK;
 }
 
 int fill_derived(apk_sim *s) {
-  return apk_cons_to_prim(s->ctx, s->mu0, s->pkg.fluid, &s->pkg.eos, s->stream);
+  return apk_cons_to_prim(s->ctx, s->mu0(), s->pkg.fluid, &s->pkg.eos, s->stream);
 }
 
 // Hydro::PreStepMeshUserWorkInLoop (hydro.cpp:102-143)
@@ -537,10 +545,19 @@ int do_stage(apk_sim *s, int stage) {
   const double g0 = s->gam0[stage - 1], g1 = s->gam1[stage - 1];
   const double beta_dt = s->beta[stage - 1] * s->dt;
   const size_t field_bytes = (size_t)s->nper * s->mesh.local_gids.size() * sizeof(double);
-  if (stage == 1) {  // init u1 (hydro_driver.cpp:474-495)
-    SIM_HIP(s, hipMemcpyAsync(s->d_u1, s->d_cons, field_bytes, hipMemcpyDeviceToDevice, hs(s)));
+  if (stage == 1) {
+    // "init u1" (hydro_driver.cpp:474-495) without the copy: the buffer holding u0 becomes the
+    // register u1 and the stage writes the new u0 into the other buffer.  Valid because
+    // gam0[0] == 0 for rk1/rk2/vl2/rk3, i.e. stage 1 never reads the old contents of its output.
+    if (g0 != 0.0) {
+      SIM_HIP(s, hipMemcpyAsync(s->d_cons2[1 - s->cur], s->d_cons2[s->cur], field_bytes, hipMemcpyDeviceToDevice, hs(s)));
+    }
+    s->u1buf = s->cur;
+    s->cur = 1 - s->cur;
   }
   const apk_flux_cfg cfg = (stage == 1) ? pkg.flux_first_stage : pkg.flux_other_stage;
+  bool fused_fill = false;
+  s->stage_dt_pending = false;
   if (stage_can_fuse(s)) {
     apk_stage_args a{};
     a.cfg = cfg;
@@ -552,24 +569,34 @@ int do_stage(apk_sim *s, int stage) {
     a.dedner = (pkg.fluid == APK_FLUID_GLMMHD) ? (pkg.glmmhd_source_extended ? 2 : 1) : 0;
     a.glmmhd_alpha = pkg.glmmhd_alpha;
     a.mindx = pkg.mindx;
-    SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0, s->mu1, &a, s->stream));
+    // let the finishing sweep do FillDerived (and, in the last stage, the dt estimate) on the
+    // cells it updates; only the ghost zones are converted after the exchange
+    fused_fill = (s->mesh.ndim >= 2) && a.dedner != 2;
+    a.fill_derived = fused_fill ? 1 : 0;
+    a.estimate_dt = (fused_fill && stage == s->nstages && pkg.calc_dt_hyp) ? 1 : 0;
+    SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
+    s->stage_dt_pending = a.estimate_dt != 0;
   } else {
     SIM_TRY(s, ensure_flux_arrays(s));
-    SIM_TRY(s, apk_calculate_fluxes(s->ctx, s->mu0, cfg, &pkg.eos, pkg.c_h, s->stream));
+    SIM_TRY(s, apk_calculate_fluxes(s->ctx, s->mu0(), cfg, &pkg.eos, pkg.c_h, s->stream));
     if (pkg.first_order_flux_correct) {
       long long nfix = 0;
-      SIM_TRY(s, apk_first_order_flux_correct(s->ctx, s->mu0, s->mu1, pkg.fluid, &pkg.eos, pkg.c_h, g0, g1,
+      SIM_TRY(s, apk_first_order_flux_correct(s->ctx, s->mu0(), s->mu1(), pkg.fluid, &pkg.eos, pkg.c_h, g0, g1,
                                               beta_dt, &nfix, s->stream));
       s->fofc_total += nfix;
     }
-    SIM_TRY(s, apk_update_with_flux_divergence(s->ctx, s->mu0, s->mu1, g0, g1, beta_dt, s->stream));
+    SIM_TRY(s, apk_update_with_flux_divergence(s->ctx, s->mu0(), s->mu1(), g0, g1, beta_dt, s->stream));
     if (pkg.fluid == APK_FLUID_GLMMHD) {
-      SIM_TRY(s, apk_dedner_source(s->ctx, s->mu0, pkg.glmmhd_source_extended ? 1 : 0, pkg.glmmhd_alpha,
+      SIM_TRY(s, apk_dedner_source(s->ctx, s->mu0(), pkg.glmmhd_source_extended ? 1 : 0, pkg.glmmhd_alpha,
                                    pkg.c_h, pkg.mindx, beta_dt, s->stream));
     }
   }
   SIM_TRY(s, exchange_ghosts(s));
-  SIM_TRY(s, fill_derived(s));
+  if (fused_fill) {
+    SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
+  } else {
+    SIM_TRY(s, fill_derived(s));
+  }
   if (stage == s->nstages && pkg.calc_c_h) {  // hydro_driver.cpp:589-603
     pkg.mindx = kHuge;
     pkg.dt_hyp = kHuge;
@@ -646,11 +673,11 @@ int apk_sim_create(const char *deck, const char *const *overrides, int noverride
   }
   const size_t nlb = s->mesh.local_gids.size();
   const size_t bytes = (size_t)s->nper * nlb * sizeof(double);
-  if ((rc = dev_alloc(s, "cons", bytes, &s->d_cons)) != APK_OK) return bail(rc);
+  if ((rc = dev_alloc(s, "cons", bytes, &s->d_cons2[0])) != APK_OK) return bail(rc);
   if ((rc = dev_alloc(s, "prim", bytes, &s->d_prim)) != APK_OK) return bail(rc);
-  if ((rc = dev_alloc(s, "u1", bytes, &s->d_u1)) != APK_OK) return bail(rc);
-  if (hipMemset(s->d_cons, 0, bytes) != hipSuccess || hipMemset(s->d_prim, 0, bytes) != hipSuccess ||
-      hipMemset(s->d_u1, 0, bytes) != hipSuccess) {
+  if ((rc = dev_alloc(s, "u1", bytes, &s->d_cons2[1])) != APK_OK) return bail(rc);
+  if (hipMemset(s->d_cons2[0], 0, bytes) != hipSuccess || hipMemset(s->d_prim, 0, bytes) != hipSuccess ||
+      hipMemset(s->d_cons2[1], 0, bytes) != hipSuccess) {
     s->err = "hipMemset failed";
     return bail(APK_ERR_DEVICE);
   }
@@ -676,12 +703,15 @@ void apk_sim_destroy(apk_sim *s) {
   if (!s) return;
   if (!s->host_only) {
     (void)hipDeviceSynchronize();
-    for (auto &p : s->plans) apk_copy_plan_destroy(p);
-    apk_pack_destroy(s->mu0);
-    apk_pack_destroy(s->mu1);
-    dev_free(s, s->d_cons);
+    for (auto &pp : s->plans_of)
+      for (auto &p : pp) apk_copy_plan_destroy(p);
+    for (int p = 0; p < 2; ++p) {
+      apk_pack_destroy(s->mu0_of[p]);
+      apk_pack_destroy(s->mu1_of[p]);
+    }
+    dev_free(s, s->d_cons2[0]);
     dev_free(s, s->d_prim);
-    dev_free(s, s->d_u1);
+    dev_free(s, s->d_cons2[1]);
     for (auto *f : s->d_flux) dev_free(s, f);
     for (auto *b : s->send_buf) dev_free(s, b);
     for (auto *b : s->recv_buf) dev_free(s, b);
@@ -707,7 +737,7 @@ int apk_sim_initialize(apk_sim *s) {
   try {
     for (int lb = 0; lb < nlb; ++lb) {
       pgen_block(s, lb, host);
-      SIM_HIP(s, hipMemcpy(s->d_cons + (int64_t)lb * s->nper, host.data(), sizeof(double) * s->nper, hipMemcpyHostToDevice));
+      SIM_HIP(s, hipMemcpy(s->d_cons() + (int64_t)lb * s->nper, host.data(), sizeof(double) * s->nper, hipMemcpyHostToDevice));
     }
   } catch (const std::exception &e) {
     return fail(s, APK_ERR_INVALID, e.what());
@@ -804,7 +834,7 @@ int apk_sim_block_location(const apk_sim *s, int lb, int *gid, int loc[3]) {
 
 void *apk_sim_block_ptr(const apk_sim *s, int lb, int field) {
   if (!s || s->host_only || lb < 0 || lb >= (int)s->mesh.local_gids.size()) return nullptr;
-  double *base = field == 0 ? s->d_cons : (field == 1 ? s->d_prim : (field == 2 ? s->d_u1 : nullptr));
+  double *base = field == 0 ? s->d_cons() : (field == 1 ? s->d_prim : (field == 2 ? s->d_cons2[s->u1buf] : nullptr));
   return base ? base + (int64_t)lb * s->nper : nullptr;
 }
 
@@ -848,7 +878,7 @@ int apk_sim_gather(apk_sim *s, int field, double *out) {
 
 int apk_sim_history(apk_sim *s, double *out8) {
   if (!s || s->host_only || !out8) return APK_ERR_INVALID;
-  SIM_TRY(s, apk_history(s->ctx, s->mu0, s->pkg.fluid, out8, s->stream));
+  SIM_TRY(s, apk_history(s->ctx, s->mu0(), s->pkg.fluid, out8, s->stream));
   if (s->have_comm && s->nranks > 1) {
     if (s->comm.allreduce_sum(s->comm.user, out8, 8) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_sum failed");
   }

@@ -61,6 +61,7 @@ struct apk_sim {
   double time = 0.0, dt = std::numeric_limits<double>::max(), tlim = 1.0;
   int nlim = -1, ncycle = 0;
   long long fofc_total = 0;
+  bool stage_dt_pending = false;  // the last fused stage already reduced the hyperbolic dt
   // integrator (Parthenon LowStorageIntegrator)
   int nstages = 0;
   double beta[4] = {0}, gam0[4] = {0}, gam1[4] = {0};
@@ -72,9 +73,22 @@ struct apk_sim {
   apk_comm_ops comm{};
   bool have_comm = false;
   int64_t nper = 0;  // doubles per field per block
-  double *d_cons = nullptr, *d_prim = nullptr, *d_u1 = nullptr, *d_flux[3] = {nullptr, nullptr, nullptr};
+  // Two conserved-variable buffers: the stage-1 "u1 <- u0" DeepCopy of the reference
+  // (hydro_driver.cpp:474-495) is a buffer-role swap here -- stage 1 has gam0 = 0 for every
+  // integrator, so it reads the old state as u1 and writes the new state into the other buffer.
+  double *d_cons2[2] = {nullptr, nullptr};
+  int cur = 0;    // buffer holding the current state u0 ("base")
+  int u1buf = 1;  // buffer holding the register u1 of the step in flight
+  double *d_prim = nullptr, *d_flux[3] = {nullptr, nullptr, nullptr};
   std::vector<double *> send_buf, recv_buf;
-  apk_pack *mu0 = nullptr, *mu1 = nullptr;  // MeshData "base" and "u1"
-  apk_copy_plan *plans[apk::PH_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // per buffer: the pack presenting it as MeshData "base" (with prim/flux), the pack presenting it
+  // as "u1" (cons only), and the ghost-exchange plans that target it
+  apk_pack *mu0_of[2] = {nullptr, nullptr}, *mu1_of[2] = {nullptr, nullptr};
+  apk_copy_plan *plans_of[2][apk::PH_COUNT] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
+                                               {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
+  apk_pack *mu0() const { return mu0_of[cur]; }
+  apk_pack *mu1() const { return mu1_of[u1buf]; }
+  apk_copy_plan *plan(int ph) const { return plans_of[cur][ph]; }
+  double *d_cons() const { return d_cons2[cur]; }
   std::string err;
 };

@@ -27,6 +27,15 @@ constexpr int NGLMMHD = 9;
 enum { IDN = 0, IM1 = 1, IM2 = 2, IM3 = 3, IEN = 4, IB1 = 5, IB2 = 6, IB3 = 7, IPS = 8 };
 enum { IV1 = 1, IV2 = 2, IV3 = 3, IPR = 4 };
 
+// x / 6.0 appears four times per PPM call (ppm_simple.hpp:55-56,78,95).  The parity build keeps
+// the IEEE division; the default build multiplies by the reciprocal (<= 1 ulp apart), which
+// removes ~40 fp64 instructions per call (a correctly rounded fp64 divide is ~11 instructions).
+#ifdef APK_FP_STRICT
+#define APK_DIV6(x) ((x) / 6.0)
+#else
+#define APK_DIV6(x) ((x) * (1.0 / 6.0))
+#endif
+
 APK_DEV double sqr(double x) { return x * x; }
 APK_DEV double min2(double a, double b) { return (b < a) ? b : a; }  // std::min
 APK_DEV double max2(double a, double b) { return (a < b) ? b : a; }  // std::max
@@ -72,14 +81,17 @@ APK_DEV double ppm_limit_interface(double qlo, double qhi, double face, double d
   constexpr double C2 = 1.25;
   const double below = face - qlo;
   const double above = qhi - face;
-  const double d2f = 3.0 * (qlo + qhi - 2.0 * face);
-  const bool s = neg(d2f);
-  double lim = 0.0;
-  if (s == neg(d2lo) && s == neg(d2hi)) {
-    lim = with_sign(s, min2(C2 * fabs(d2lo), min2(C2 * fabs(d2hi), fabs(d2f))));
+  // The limited value only replaces `face` at a local extremum (CD eq 84); evaluating it lazily
+  // changes no result and lets a wave without extrema skip the limiter and its division.
+  if (below * above < 0.0) {
+    const double d2f = 3.0 * (qlo + qhi - 2.0 * face);
+    const bool s = neg(d2f);
+    const bool agree = (s == neg(d2lo)) && (s == neg(d2hi));
+    const double mag = min2(C2 * fabs(d2lo), min2(C2 * fabs(d2hi), fabs(d2f)));
+    const double lim = agree ? with_sign(s, mag) : 0.0;
+    return 0.5 * (qlo + qhi) - APK_DIV6(lim);
   }
-  const double alt = 0.5 * (qlo + qhi) - lim / 6.0;
-  return (below * above < 0.0) ? alt : face;
+  return face;
 }
 
 // src/recon/ppm_simple.hpp:39-162
@@ -91,8 +103,8 @@ APK_DEV void ppm(double qm2, double qm1, double q0, double qp1, double qp2, doub
   const double dd_m = 0.5 * da + 0.5 * (qm1 - qm2);
   const double dd_c = 0.5 * db + 0.5 * da;
   const double dd_p = 0.5 * (qp2 - qp1) + 0.5 * db;
-  double face_m = 0.5 * (qm1 + q0) + (dd_m - dd_c) / 6.0;
-  double face_p = 0.5 * (q0 + qp1) + (dd_c - dd_p) / 6.0;
+  double face_m = 0.5 * (qm1 + q0) + APK_DIV6(dd_m - dd_c);
+  double face_p = 0.5 * (q0 + qp1) + APK_DIV6(dd_c - dd_p);
 
   const double d2_m = qm2 + q0 - 2.0 * qm1;
   const double d2_c = qm1 + qp1 - 2.0 * q0;
@@ -100,37 +112,31 @@ APK_DEV void ppm(double qm2, double qm1, double q0, double qp1, double qp2, doub
   face_m = ppm_limit_interface(qm1, q0, face_m, d2_m, d2_c);
   face_p = ppm_limit_interface(q0, qp1, face_p, d2_c, d2_p);
 
-  const double d2_face = 6.0 * (face_m + face_p - 2.0 * q0);
   const double dminus = q0 - face_m;
   const double dplus = face_p - q0;
   const double ext_a = dminus * dplus;
   const double ext_b = (qp1 - q0) * (q0 - qm1);
 
-  const bool s = neg(d2_m);
-  double d2lim = 0.0;
-  if (s == neg(d2_c) && s == neg(d2_p) && s == neg(d2_face)) {
-    d2lim = with_sign(neg(d2_face), min2(min2(C2 * fabs(d2_m), C2 * fabs(d2_c)),
-                                         min2(C2 * fabs(d2_p), fabs(d2_face))));
-  }
-  const double scale_lo = max2(fabs(qm1), fabs(qm2));
-  const double scale_hi = max2(max2(fabs(q0), fabs(qp1)), fabs(qp2));
-  double ratio = 0.0;
-  if (fabs(d2_face) > (1.0e-12) * max2(scale_lo, scale_hi)) ratio = d2lim / d2_face;
-
-  const double ext_m = q0 - ratio * dminus;
-  const double ext_p = q0 + ratio * dplus;
-  const double over_m = q0 - 2.0 * dplus;
-  const double over_p = q0 + 2.0 * dminus;
-
   double r = face_m, l = face_p;
   if (ext_a <= 0.0 || ext_b <= 0.0) {
+    // local extremum: CS limiter on the parabola (steps 4 of ppm_simple.hpp:104-150).  The
+    // limited second-derivative ratio is only consumed here, so it is only computed here.
+    const double d2_face = 6.0 * (face_m + face_p - 2.0 * q0);
+    const bool s = neg(d2_m);
+    const bool agree = (s == neg(d2_c)) && (s == neg(d2_p)) && (s == neg(d2_face));
+    const double mag = min2(min2(C2 * fabs(d2_m), C2 * fabs(d2_c)), min2(C2 * fabs(d2_p), fabs(d2_face)));
+    const double d2lim = agree ? with_sign(neg(d2_face), mag) : 0.0;
+    const double scale_lo = max2(fabs(qm1), fabs(qm2));
+    const double scale_hi = max2(max2(fabs(q0), fabs(qp1)), fabs(qp2));
+    double ratio = 0.0;
+    if (fabs(d2_face) > (1.0e-12) * max2(scale_lo, scale_hi)) ratio = d2lim / d2_face;
     if (ratio <= (1.0 - (1.0e-12))) {
-      r = ext_m;
-      l = ext_p;
+      r = q0 - ratio * dminus;
+      l = q0 + ratio * dplus;
     }
   } else {
-    if (fabs(dminus) >= 2.0 * fabs(dplus)) r = over_m;
-    if (fabs(dplus) >= 2.0 * fabs(dminus)) l = over_p;
+    if (fabs(dminus) >= 2.0 * fabs(dplus)) r = q0 - 2.0 * dplus;
+    if (fabs(dplus) >= 2.0 * fabs(dminus)) l = q0 + 2.0 * dminus;
   }
   ql = l;
   qr = r;

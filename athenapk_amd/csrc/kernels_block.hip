@@ -66,8 +66,9 @@ update_flux_div_kernel(PackView u0, PackView u1, double gam0, double gam1, doubl
   const int64_t cell = c.k * u0.sk + c.j * u0.sj + c.i;
   for (int n = 0; n < u0.nvar; ++n) {
     const int64_t idx = n * u0.sn + cell;
-    b0.cons[idx] =
-        gam0 * b0.cons[idx] + gam1 * c1[idx] + beta_dt * flux_div(u0, b0, idx, area, vol);
+    // gam0 == 0 (first stage of every integrator): the old contents of u0 are not an input
+    const double old = (gam0 != 0.0) ? b0.cons[idx] : 0.0;
+    b0.cons[idx] = gam0 * old + gam1 * c1[idx] + beta_dt * flux_div(u0, b0, idx, area, vol);
   }
 }
 
@@ -102,13 +103,15 @@ dedner_kernel(PackView pv, double coeff, double beta_dt) {
 // ---- ConservedToPrimitive over the ENTIRE block (src/eos/adiabatic_hydro.cpp:33-55) -----
 template <int FLUID>
 __global__ void __launch_bounds__(256)
-cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags) {
+cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags, int ghosts_only) {
   constexpr int NV = nvars<FLUID>();
   const int i = blockIdx.x * 64 + threadIdx.x;
   const int j = blockIdx.y * 4 + threadIdx.y;
   const int b = blockIdx.z / pv.nk;
   const int k = blockIdx.z % pv.nk;
   if (i >= pv.ni || j >= pv.nj) return;
+  // ghost zones only: interior cells were converted by the finishing sweep of the fused stage
+  if (ghosts_only && i >= pv.is && i <= pv.ie && j >= pv.js && j <= pv.je && k >= pv.ks && k <= pv.ke) return;
   const apk_block_desc blk = pv.blocks[b];
   const int64_t cell = k * pv.sk + j * pv.sj + i;
   double u[NV], w[NV];
@@ -264,7 +267,8 @@ fofc_mark_kernel(PackView u0, PackView u1, double gam0, double gam1, double beta
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
       const int64_t idx = n * u0.sn + cell;
-      nc[n] = gam0 * b0.cons[idx] + gam1 * c1[idx] + beta_dt * flux_div(u0, b0, idx, area, vol);
+      const double old = (gam0 != 0.0) ? b0.cons[idx] : 0.0;
+      nc[n] = gam0 * old + gam1 * c1[idx] + beta_dt * flux_div(u0, b0, idx, area, vol);
     }
     double new_p = nc[IEN] - 0.5 * (sqr(nc[IM1]) + sqr(nc[IM2]) + sqr(nc[IM3])) / nc[IDN];
     if constexpr (FLUID == APK_FLUID_GLMMHD)
@@ -362,14 +366,14 @@ int launch_dedner(const PackView &pv, int extended, double coeff, double beta_dt
 }
 
 int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsigned *d_flags,
-                        hipStream_t s) {
+                        hipStream_t s, bool ghosts_only) {
   dim3 grid((pv.ni + 63) / 64, (pv.nj + 3) / 4, pv.nk * pv.nblocks);
   if (fluid == APK_FLUID_EULER)
     hipLaunchKernelGGL(cons_to_prim_kernel<APK_FLUID_EULER>, grid, dim3(64, 4, 1), 0, s, pv, eos,
-                       d_flags);
+                       d_flags, (int)ghosts_only);
   else
     hipLaunchKernelGGL(cons_to_prim_kernel<APK_FLUID_GLMMHD>, grid, dim3(64, 4, 1), 0, s, pv, eos,
-                       d_flags);
+                       d_flags, (int)ghosts_only);
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }
 

@@ -151,14 +151,16 @@ def DednerSource(md, extended, alpha, c_h, mindx, beta_dt):
 
 
 def StageFused(u0, u1, fluid, recon, riemann, eos, c_h, gam0, gam1, beta_dt, dedner=0,
-               glmmhd_alpha=0.1, mindx=1.0):
-    """Fused CalculateFluxes -> UpdateWithFluxDivergence -> DednerSource for one RK stage."""
+               glmmhd_alpha=0.1, mindx=1.0, fill_derived=False, estimate_dt=False):
+    """Fused CalculateFluxes -> UpdateWithFluxDivergence -> DednerSource for one RK stage;
+    optionally also FillDerived / the dt estimate on the updated cells."""
     ctx = u0.ctx
     a = L.StageArgs()
     a.cfg = _cfg(fluid, recon, riemann)
     a.eos = eos
     a.c_h, a.gam0, a.gam1, a.beta_dt = c_h, gam0, gam1, beta_dt
     a.dedner, a.glmmhd_alpha, a.mindx = dedner, glmmhd_alpha, mindx
+    a.fill_derived, a.estimate_dt = int(fill_derived), int(estimate_dt)
     _check(ctx.lib.apk_stage_fused(ctx.h, u0.h, u1.h, C.byref(a), _stream()), ctx.lib, ctx.h)
 
 
@@ -166,6 +168,19 @@ def ConservedToPrimitive(md, fluid, eos):
     """EquationOfState::ConservedToPrimitive(md) -- src/eos/adiabatic_hydro.cpp:33"""
     ctx = md.ctx
     _check(ctx.lib.apk_cons_to_prim(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), _stream()), ctx.lib, ctx.h)
+
+
+def ConservedToPrimitiveGhosts(md, fluid, eos):
+    """ConsToPrim on the ghost zones only (companion of StageFused(fill_derived=True))."""
+    ctx = md.ctx
+    _check(ctx.lib.apk_cons_to_prim_ghosts(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), _stream()), ctx.lib, ctx.h)
+
+
+def StageDt(ctx, cfl):
+    """cfl * min dx/(|v|+c) reduced by the last StageFused(estimate_dt=True)."""
+    dt = C.c_double(0.0)
+    _check(ctx.lib.apk_stage_dt_read(ctx.h, cfl, C.byref(dt), _stream()), ctx.lib, ctx.h)
+    return dt.value
 
 
 def EstimateTimestep(md, fluid, eos, cfl):

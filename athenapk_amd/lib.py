@@ -54,7 +54,8 @@ class PackDesc(C.Structure):
 class StageArgs(C.Structure):
     _fields_ = [("cfg", FluxCfg), ("eos", Eos), ("c_h", C.c_double), ("gam0", C.c_double),
                 ("gam1", C.c_double), ("beta_dt", C.c_double), ("dedner", C.c_int),
-                ("glmmhd_alpha", C.c_double), ("mindx", C.c_double)]
+                ("glmmhd_alpha", C.c_double), ("mindx", C.c_double), ("fill_derived", C.c_int),
+                ("estimate_dt", C.c_int)]
 
 
 class CopyRegion(C.Structure):
@@ -122,6 +123,8 @@ def _signatures():
         "apk_dedner_source": (i, [vp, vp, i, d, d, d, d, vp]),
         "apk_stage_fused": (i, [vp, vp, vp, C.POINTER(StageArgs), vp]),
         "apk_cons_to_prim": (i, [vp, vp, i, E, vp]),
+        "apk_cons_to_prim_ghosts": (i, [vp, vp, i, E, vp]),
+        "apk_stage_dt_read": (i, [vp, d, c_dp, vp]),
         "apk_estimate_timestep": (i, [vp, vp, i, E, d, c_dp, vp]),
         "apk_first_order_flux_correct": (i, [vp, vp, vp, i, E, d, d, d, d, C.POINTER(ll), vp]),
         "apk_history": (i, [vp, vp, i, c_dp, vp]),

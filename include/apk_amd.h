@@ -145,6 +145,17 @@ typedef struct apk_stage_args {
   double gam0, gam1, beta_dt; /* integrator->gam0/gam1/beta[stage-1]*dt */
   int dedner;                 /* 0 = off (euler), 1 = plain, 2 = extended */
   double glmmhd_alpha, mindx;
+  /* Optional: let the finishing sweep also do the work of the NEXT two tasks on the cells it
+   * updates, saving two passes over the interior:
+   *  fill_derived = 1: apply ConsToPrim (floors included) and store prim in place
+   *                    (Update::FillDerived, hydro_driver.cpp:571-577).  The caller then only
+   *                    needs apk_cons_to_prim_ghosts() after the ghost exchange.  Not in 1-D,
+   *                    not with dedner == 2 (APK_ERR_UNSUPPORTED).
+   *  estimate_dt  = 1: (needs fill_derived) also min-reduce dx_d/(|v_d|+c_d) over those cells
+   *                    (EstimateHyperbolicTimestep, hydro.cpp:828-896); read it with
+   *                    apk_stage_dt_read(). */
+  int fill_derived;
+  int estimate_dt;
 } apk_stage_args;
 int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
                     const apk_stage_args *args, apk_stream_t stream);
@@ -154,6 +165,15 @@ int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
  * src/hydro/hydro.cpp:705-713). */
 int apk_cons_to_prim(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,
                      apk_stream_t stream);
+
+/* ConsToPrim restricted to the ghost zones of every block (interior cells untouched): the
+ * companion of apk_stage_fused(fill_derived = 1). */
+int apk_cons_to_prim_ghosts(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,
+                            apk_stream_t stream);
+
+/* Result of the last apk_stage_fused(estimate_dt = 1) on this context: *dt_out = cfl * min.
+ * Synchronises `stream`. */
+int apk_stage_dt_read(apk_ctx *ctx, double cfl, double *dt_out, apk_stream_t stream);
 
 /* Replaces Hydro::EstimateHyperbolicTimestep<fluid>(MeshData<Real>*)
  * src/hydro/hydro.cpp:828-910.  Synchronises `stream`; *dt_out = cfl * min(...). */

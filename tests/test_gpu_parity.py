@@ -312,3 +312,58 @@ def test_boundary_error_codes(request):
     with pytest.raises(L.ApkError) as e:  # fluid does not match the pack
         hydro.CalculateFluxes(md, "glmmhd", "plm", "hlle", L.make_eos(1.4))
     assert e.value.code == L.APK_ERR_INVALID
+
+
+# ---- fused stage with FillDerived + dt estimate folded into the finishing sweep -----------------------
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("fluid,recon,riemann,nx", [("glmmhd", "ppm", "hlld", (70, 9, 7)),
+                                                    ("euler", "plm", "hllc", (66, 10, 6)),
+                                                    ("glmmhd", "dc", "hlld", (64, 8, 8)),
+                                                    ("glmmhd", "ppm", "hlld", (130, 12, 1))])
+def test_fused_stage_fill_derived_and_dt(request, oracle, fluid, recon, riemann, nx, strict):
+    """finishing sweep = update + Dedner + ConsToPrim (in place) + hyperbolic dt, vs the oracle's
+    separate tasks (hydro_driver.cpp:534-577,605-613)."""
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    ng, prim, g = _case(fluid, recon, nx, kind="smooth", seed=41)
+    cons = H.prim_to_cons(fluid, prim, GAMMA)
+    ded = 1 if fluid == "glmmhd" else 0
+    eos_kw = dict(pfloor=1e-6, dfloor=1e-6)
+    m0 = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=prim.shape[0], cons=cons, prim=prim,
+                        with_flux=False)
+    m1 = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=prim.shape[0], cons=cons, with_flux=False)
+    ctx.poll_flags()
+    hydro.StageFused(m0, m1, fluid, recon, riemann, hydro.L.make_eos(GAMMA, **eos_kw), C_H, 0.0, 1.0, 0.004,
+                     dedner=ded, glmmhd_alpha=0.1, mindx=0.07, fill_derived=True, estimate_dt=True)
+    dt = hydro.StageDt(ctx, 0.3)
+    want_cons = H.orc_stage(fluid, recon, riemann, g, cons, cons, prim, GAMMA, C_H, 0.0, 1.0, 0.004, dedner=ded,
+                            alpha=0.1, mindx=0.07)
+    want_cons, want_prim, bad = H.orc_c2p(fluid, g, want_cons, oracle.make_eos(GAMMA, **eos_kw))
+    assert bad == 0 and ctx.poll_flags() == 0
+    want_dt = 0.3 * H.orc_min_dt(fluid, g, want_prim, GAMMA)
+    _cmp(H.interior(m0.cons_host(), nx, ng), H.interior(want_cons, nx, ng), strict, "cons")
+    _cmp(H.interior(m0.prim_host(), nx, ng), H.interior(want_prim, nx, ng), strict, "prim (interior, in place)")
+    if strict:
+        assert dt == want_dt
+    else:
+        assert dt == pytest.approx(want_dt, rel=1e-12)
+    # ghost zones of prim are untouched by the stage and converted by the companion call
+    ghosts_before = m0.prim_host().copy()
+    hydro.ConservedToPrimitiveGhosts(m0, fluid, hydro.L.make_eos(GAMMA, **eos_kw))
+    full_cons, full_prim, _ = H.orc_c2p(fluid, g, m0.cons_host(), oracle.make_eos(GAMMA, **eos_kw))
+    _cmp(m0.prim_host(), full_prim, strict, "prim after ghost conversion")
+    assert np.array_equal(H.interior(ghosts_before, nx, ng), H.interior(m0.prim_host(), nx, ng))
+
+
+def test_fused_fill_derived_rejected_where_unsafe(request):
+    from athenapk_amd import hydro
+    from athenapk_amd import lib as L
+    ctx = _ctx(request, True)
+    nx = (64, 1, 1)
+    ng, prim, g = _case("glmmhd", "ppm", nx, seed=3)
+    cons = H.prim_to_cons("glmmhd", prim, GAMMA)
+    m0 = hydro.MeshData(ctx, nx, ng, 9, nblocks=prim.shape[0], cons=cons, prim=prim, with_flux=False)
+    with pytest.raises(L.ApkError) as e:  # 1-D: the finishing sweep is the x1 sweep, lanes share prim
+        hydro.StageFused(m0, m0, "glmmhd", "ppm", "hlld", L.make_eos(GAMMA), C_H, 0.0, 1.0, 1e-3, dedner=1,
+                         mindx=0.1, fill_derived=True)
+    assert e.value.code == L.APK_ERR_UNSUPPORTED
