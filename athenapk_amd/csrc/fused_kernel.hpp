@@ -57,16 +57,17 @@ APK_DEV double wave_shl1(double x) {  // lane l receives lane l+1 (lane 63 keeps
 // UpdateWithFluxDivergence (hydro_driver.cpp:534-537) then DednerSource
 // (dedner_source.cpp:42-74), in that order, exactly as the task list runs them.
 template <int FLUID, int EXTRA = EXTRA_NONE>
-APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0, const double *c1,
-                         int64_t cell, const double (&du)[nvars<FLUID>()], double vol,
-                         const StageParams &sp, double &lane_min_dt) {
+APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
+                         const double (&u1v)[nvars<FLUID>()], int64_t cell,
+                         const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp,
+                         double &lane_min_dt) {
   constexpr int NV = nvars<FLUID>();
   double un[NV];
 #pragma unroll
   for (int n = 0; n < NV; ++n) {
     const int64_t idx = n * pv.sn + cell;
     const double old = (sp.gam0 != 0.0) ? b0.cons[idx] : 0.0;
-    un[n] = sp.gam0 * old + sp.gam1 * c1[idx] + sp.beta_dt * (-du[n] / vol);
+    un[n] = sp.gam0 * old + sp.gam1 * u1v[n] + sp.beta_dt * (-du[n] / vol);
   }
   if constexpr (FLUID == APK_FLUID_GLMMHD) {
     if (sp.dedner == 2) {
@@ -120,7 +121,7 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0, const dou
 // x1 sweep
 // ==============================================================================================
 template <int FLUID, int RECON, int RS, bool FINAL>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 fused_x1_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_plane) {
   constexpr int NV = nvars<FLUID>();
   constexpr int H = recon_halfwidth(RECON);
@@ -180,7 +181,11 @@ fused_x1_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_plane) {
   if constexpr (FINAL) {
     const double vol = b0.dx[0] * b0.dx[1] * b0.dx[2];
     double unused_dt = 0.0;
-    finish_cell<FLUID>(u0, b0, u1.blocks[b].cons, cell, du, vol, sp, unused_dt);
+    double u1v[NV];
+    const double *c1 = u1.blocks[b].cons;
+#pragma unroll
+    for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + cell];
+    finish_cell<FLUID>(u0, b0, u1v, cell, du, vol, sp, unused_dt);
   } else {
     double *d = sp.du + (int64_t)b * u0.sn * u0.nvar + cell;
 #pragma unroll
@@ -254,6 +259,18 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp) {
 
   int slot0 = 0;  // slot holding row c-H
   for (; c <= e + 1; ++c) {
+    // the streaming operands of the cell that completes in this iteration (c-1) are requested
+    // first, so they are in flight during the reconstruction and the Riemann solve
+    const int64_t done = base + (int64_t)(c - 1) * st;
+    double duv[NV], u1v[NV];
+    if (c >= s + 1) {
+#pragma unroll
+      for (int n = 0; n < NV; ++n) duv[n] = dscratch[n * u0.sn + done];
+      if constexpr (FINAL) {
+#pragma unroll
+        for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
+      }
+    }
     // reconstruct cell c from ring rows c-H..c+H-1 and the register row c+H
     double qln[NV], qrn[NV];
 #pragma unroll
@@ -291,16 +308,16 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp) {
       riemann<FLUID, RS>(wl_prev, wr, sp.gamma, sp.c_h, f);
       if (c >= s + 1) {
         // cell c-1 is complete: (A F(c) - A F(c-1)) joins du
-        const int64_t cell = base + (int64_t)(c - 1) * st;
+        const int64_t cell = done;
         double du[NV];
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
           const int n = perm<DIR>(q);
-          du[n] = dscratch[n * u0.sn + cell] + (area * f[q] - area * f_prev[q]);
+          du[n] = duv[n] + (area * f[q] - area * f_prev[q]);
         }
         if (active) {
           if constexpr (FINAL) {
-            finish_cell<FLUID, EXTRA>(u0, b0, c1, cell, du, vol, sp, lane_min_dt);
+            finish_cell<FLUID, EXTRA>(u0, b0, u1v, cell, du, vol, sp, lane_min_dt);
           } else {
 #pragma unroll
             for (int n = 0; n < NV; ++n) dscratch[n * u0.sn + cell] = du[n];

@@ -36,21 +36,25 @@ B_C2P = {"glmmhd": 144.0, "euler": 80.0}                        # ConsToPrim per
 GAM0 = {"rk1": (0.0,), "rk2": (0.0, 0.5), "vl2": (0.0, 0.0), "rk3": (0.0, 0.25, 2.0 / 3.0)}
 
 WORKLOADS = {
-    # name: (deck, fluid, integrator, per-GPU brick, meshblock, description)
-    "mhd_ppm_hlld_vl2_256": ("synthetic_mhd", "glmmhd", "vl2", 256, 128,
+    # name: (deck, fluid, integrator, recon, riemann, per-GPU brick, meshblock, description)
+    # default = the configuration the BASELINE metric is quoted on (3-D MHD PPM+HLLD, uniform grid)
+    "mhd_ppm_hlld_vl2_256": ("synthetic_mhd", "glmmhd", "vl2", "ppm", "hlld", 256, 128,
                              "GLM-MHD PPM+HLLD+Dedner VL2, synthetic smooth state, 256^3 per GPU in 128^3 meshblocks"),
+    # BASELINE configs[1]: Sod shock tube 256^3, hydro PLM+HLLC RK2
+    "hydro_plm_hllc_rk2_256": ("sod", "euler", "rk2", "plm", "hllc", 256, 128,
+                               "hydro PLM+HLLC RK2, 3-D Sod shock tube (outflow x1), 256^3 per GPU in 128^3 meshblocks"),
 }
 RANK_GRID = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
 
 
-def cpu_baseline(fluid, integrator, target_s=12.0):
+def cpu_baseline(fluid, integrator, recon, riemann, target_s=12.0):
     """Times the oracle (kind 'port': no reference binary can be built here) on host cores."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
     mb = 16 if cores > 64 else 32
     n = 128
-    sim = O.Sim(fluid=fluid, recon="ppm", riemann="hlld", integrator=integrator, nx=(n, n, n), mb=(mb, mb, mb),
-                ng=3, xmax=(1.0, 1.0, 1.0), cfl=0.3, nthreads=cores, fast=True)
+    sim = O.Sim(fluid=fluid, recon=recon, riemann=riemann, integrator=integrator, nx=(n, n, n), mb=(mb, mb, mb),
+                ng=3 if recon in ("ppm", "wenoz") else 2, xmax=(1.0, 1.0, 1.0), cfl=0.3, nthreads=cores, fast=True)
     sim.pgen("synthetic")
     t0 = time.perf_counter()
     sim.step()
@@ -92,7 +96,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
-    deck, fluid, integrator, brick, mb, desc = WORKLOADS[args.workload]
+    deck, fluid, integrator, recon, riemann, brick, mb, desc = WORKLOADS[args.workload]
     if world not in RANK_GRID:
         raise SystemExit("supported GPU counts: %s" % sorted(RANK_GRID))
     grid = RANK_GRID[world]
@@ -141,7 +145,9 @@ def main():
         else:
             # the high-order (PPM+HLLD) stage; the VL2 donor-cell predictor is timed in its own slots
             stage_ms = per_kernel["fused_x1"] + per_kernel["fused_x2"] + per_kernel["fused_x3"]
-            stage_name = "fused PPM+HLLD stage: x1 DPP sweep + x2 march + x3 march (+RK update +Dedner)"
+            stage_name = ("fused %s+%s stage: x1 DPP sweep + x2 march + x3 march (+RK update%s, +ConsToPrim of "
+                          "the interior, +dt in the last stage)" % (recon.upper(), riemann.upper(),
+                                                                    " +Dedner" if fluid == "glmmhd" else ""))
         # high-order stages only (for vl2: the corrector, gam0 = 0)
         ho = [g0 for n, g0 in enumerate(GAM0[integrator]) if not (integrator == "vl2" and n == 0)]
         b_stage = sum(B_STAGE[fluid][0 if g0 == 0.0 else 1] for g0 in ho) / len(ho)
@@ -151,7 +157,8 @@ def main():
                         "cons_to_prim", "copy_regions", "update", "min_dt"),
                        key=lambda k: timing[k][0])
         out = {
-            "metric": "cell-updates/s (zone-cycles/s) for 3D MHD PPM+HLLD, uniform grid",
+            "metric": "cell-updates/s (zone-cycles/s) for 3D %s, uniform grid" % (
+                "MHD PPM+HLLD" if fluid == "glmmhd" else "hydro %s+%s" % (recon.upper(), riemann.upper())),
             "value": value,
             "unit": "cell-updates/s",
             "n_gpus": world,
@@ -193,7 +200,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(fluid, integrator)
+                out["cpu_baseline"] = cpu_baseline(fluid, integrator, recon, riemann)
             except Exception as e:  # the baseline is informational; never lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "cell-updates/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": "failed: %r" % (e,)}
