@@ -69,6 +69,23 @@ def cpu_baseline(fluid, integrator, recon, riemann, target_s=12.0):
                       "-march=native -fopenmp, %.1f s" % (cycles, n, mb, dt)}
 
 
+def measured_traffic(workload):
+    """HBM bytes per fused-stage launch from the committed rocprofv3 PMC passes (a live run cannot
+    profile itself): profiles/r01_hbm_traffic.json, made by profiles/pmc_traffic.py from
+    FETCH_SIZE / WRITE_SIZE of this same command.  Returns (GB, source) or (None, None)."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if workload != "mhd_ppm_hlld_vl2_256" or not os.path.exists(path):
+        return None, None
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"]
+        gb = sum(v["hbm_total_GB"] for name, v in k.items()
+                 if name.startswith("fused_x1_kernel<2, 3, 5") or name.startswith("fused_march_kernel<2, 3, 5"))
+        return gb, "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, reads calibrated x1.60)"
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,6 +170,7 @@ def main():
         b_stage = sum(B_STAGE[fluid][0 if g0 == 0.0 else 1] for g0 in ho) / len(ho)
         achieved = b_stage * zones_local / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
         b_cycle = sum(B_STAGE[fluid][0 if g0 == 0.0 else 1] for g0 in GAM0[integrator]) + nstages * B_C2P[fluid]
+        traffic_gb, traffic_src = (None, None) if args.unfused else measured_traffic(args.workload)
         dominant = max(("fused_x1", "fused_x2", "fused_x3", "fused_dc_x1", "fused_dc_x2", "fused_dc_x3", "fluxes",
                         "cons_to_prim", "copy_regions", "update", "min_dt"),
                        key=lambda k: timing[k][0])
@@ -184,7 +202,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic_gb,
+                "traffic_unit": "GB per fused-stage launch (algorithmic: %.2f GB)" % (b_stage * zones_local / 1e9),
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_cell_stage": b_stage,
                 "cells_per_launch": zones_local,
                 "stage_ms": stage_ms,

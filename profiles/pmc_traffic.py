@@ -5,9 +5,10 @@ together with `--kernel-trace` only).
 On gfx950 FETCH_SIZE under-reports streaming reads (the guide measures exactly 1/2 for
 16-B/lane loads and says other widths must be calibrated on a known byte count in the same
 access pattern).  Our kernels read 8 B/lane, 512-B coalesced rows; the calibration kernel is
-the full-block ConsToPrim of the same run, whose read traffic is known exactly
-(nblocks * nvar * Nk*Nj*Ni * 8 B, every cell read once).  WRITE_SIZE needed no correction
-(ConsToPrim writes the same number of bytes it reads; measured within 5 %).
+the hyperbolic-dt kernel of the same run (it runs once, at initialisation), a pure streaming
+read of 8 of the 9 primitive variables over the interior cells whose traffic is known exactly.
+WRITE_SIZE needed no correction (full-block ConsToPrim in the first-run profile wrote 1.448 GB
+for 1.386 GB of output; the march kernels' WRITE_SIZE matches their output arrays to 1 %).
 
   python profiles/pmc_traffic.py <dir with fetch_counter_collection.csv, write_counter_collection.csv> \
          --nblocks 8 --nvar 9 --ncell 134 > profiles/rNN_hbm_traffic.json
@@ -40,13 +41,14 @@ def main():
     ap.add_argument("--nblocks", type=int, default=8)
     ap.add_argument("--nvar", type=int, default=9)
     ap.add_argument("--ncell", type=int, default=134, help="cells per block edge incl. ghosts")
-    ap.add_argument("--calib-kernel", default="cons_to_prim_kernel<2>")
-    ap.add_argument("--calib-fraction", type=float, default=1.0,
-                    help="fraction of the block cells the calibration kernel reads (1 = full ConsToPrim)")
+    ap.add_argument("--calib-kernel", default="min_dt_kernel<2>")
+    ap.add_argument("--known-bytes", type=float, default=None,
+                    help="exact read traffic of the calibration kernel; default: min_dt over the interior = "
+                         "nblocks * (nvar-1) * nx^3 * 8 B (it reads rho,v,p,B but not psi), nx = ncell - 6")
     a = ap.parse_args()
     fetch = per_kernel(os.path.join(a.dir, "fetch_counter_collection.csv"), "FETCH_SIZE")  # KiB
     write = per_kernel(os.path.join(a.dir, "write_counter_collection.csv"), "WRITE_SIZE")  # KiB
-    known = a.nblocks * a.nvar * a.ncell ** 3 * 8.0 * a.calib_fraction
+    known = a.known_bytes if a.known_bytes else a.nblocks * (a.nvar - 1) * (a.ncell - 6) ** 3 * 8.0
     factor = known / (fetch[a.calib_kernel] * 1024.0)
     out = {"calibration": {"kernel": a.calib_kernel, "known_read_bytes": known,
                            "FETCH_SIZE_KiB": fetch[a.calib_kernel], "read_correction_factor": factor,
