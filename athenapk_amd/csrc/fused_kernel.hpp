@@ -288,6 +288,11 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp) {
         const double a3 = ring[(((slot0 + 3) & 3) * NV + n) * 64 + lane];
         reconstruct<RECON>(a0, a1, a2, a3, Pn[n], dx, n, qln[n], qrn[n]);
       }
+      // The 9 reconstructions are independent; left alone the scheduler interleaves them all and
+      // the weighted schemes (WENO-Z: 5 divisions and ~40 live values per call) spill.  An empty
+      // volatile asm pins each result before the next variable starts: less ILP, no scratch.
+      if constexpr (RECON == APK_RC_WENOZ || RECON == APK_RC_WENO3 || RECON == APK_RC_LIMO3)
+        asm volatile("" : "+v"(qln[n]), "+v"(qrn[n]));
     }
     // row c+H replaces row c-H in the ring; fetch row c+1+H for the next iteration now so the
     // loads fly while the Riemann problem below is solved

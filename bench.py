@@ -40,6 +40,9 @@ WORKLOADS = {
     # default = the configuration the BASELINE metric is quoted on (3-D MHD PPM+HLLD, uniform grid)
     "mhd_ppm_hlld_vl2_256": ("synthetic_mhd", "glmmhd", "vl2", "ppm", "hlld", 256, 128,
                              "GLM-MHD PPM+HLLD+Dedner VL2, synthetic smooth state, 256^3 per GPU in 128^3 meshblocks"),
+    # BASELINE configs[3] scheme (driven-turbulence config without the forcing term): WENOZ+HLLD RK3
+    "mhd_wenoz_hlld_rk3_256": ("synthetic_mhd", "glmmhd", "rk3", "wenoz", "hlld", 256, 128,
+                               "GLM-MHD WENOZ+HLLD+Dedner RK3, synthetic smooth state, 256^3 per GPU in 128^3 meshblocks"),
     # BASELINE configs[1]: Sod shock tube 256^3, hydro PLM+HLLC RK2
     "hydro_plm_hllc_rk2_256": ("sod", "euler", "rk2", "plm", "hllc", 256, 128,
                                "hydro PLM+HLLC RK2, 3-D Sod shock tube (outflow x1), 256^3 per GPU in 128^3 meshblocks"),
@@ -119,6 +122,7 @@ def main():
     grid = RANK_GRID[world]
     ov = ["parthenon/mesh/nx%d=%d" % (d + 1, brick * grid[d]) for d in range(3)]
     ov += ["parthenon/meshblock/nx%d=%d" % (d + 1, mb) for d in range(3)]
+    ov += ["parthenon/time/integrator=%s" % integrator, "hydro/reconstruction=%s" % recon, "hydro/riemann=%s" % riemann]
     sim = driver.Simulation(decks.load(deck), ov, rank=rank, nranks=world, strict=False)
     if args.unfused:
         sim.set_fused(False)
