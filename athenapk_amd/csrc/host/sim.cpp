@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <sstream>
 
 using namespace apk;
 
@@ -368,6 +369,119 @@ void pgen_block(apk_sim *s, int lb, std::vector<double> &u) {
       }
 }
 
+
+// ---- few-modes turbulence driver -----------------------------------------------------------
+// turbulence::ProblemInitPackageData (src/pgen/turbulence.cpp:103-200) + the checks of
+// FewModesFT::SetPhases (src/utils/few_modes_ft.cpp:113-140)
+void turbulence_setup(apk_sim *s) {
+  ParameterInput &pin = s->pin;
+  const int num_modes = pin.GetInteger("problem/turbulence", "num_modes");
+  const uint32_t rseed = static_cast<uint32_t>(pin.GetOrAddInteger("problem/turbulence", "rseed", -1));
+  const double k_peak = pin.GetOrAddReal("problem/turbulence", "kpeak", 0.0);
+  s->accel_rms = pin.GetReal("problem/turbulence", "accel_rms");
+  const double t_corr = pin.GetReal("problem/turbulence", "corr_time");
+  const double sol_weight = pin.GetReal("problem/turbulence", "sol_weight");
+  if (num_modes <= 0) throw std::runtime_error("problem/turbulence/num_modes must be positive");
+  std::vector<double> k_vec(3 * (size_t)num_modes);
+  for (int d = 0; d < 3; ++d)
+    for (int m = 1; m <= num_modes; ++m)
+      k_vec[(size_t)d * num_modes + (m - 1)] = pin.GetInteger("modes", "k_" + std::to_string(m) + "_" + std::to_string(d));
+  if (pin.GetOrAddInteger("parthenon/mesh", "pack_size", -1) != -1)
+    throw std::runtime_error("Few modes FT currently needs parthenon/mesh/pack_size=-1 to work because of global reductions.");
+  const Mesh &m = s->mesh;
+  const double L[3] = {s->xmax[0] - s->xmin[0], s->xmax[1] - s->xmin[1], s->xmax[2] - s->xmin[2]};
+  if (!(m.nx[0] == m.nx[1] && m.nx[1] == m.nx[2] && L[0] == L[1] && L[1] == L[2]))
+    throw std::runtime_error("FMFT has only been tested with cubic meshes and constant dx/dy/dz. "
+                             "Remove this warning at your own risk.");
+  if (pin.DoesParameterExist("problem/turbulence", "accel_hat_0_0_r"))
+    throw std::runtime_error("restarting the turbulence driver state is not supported");
+  if (s->pkg.fluid == APK_FLUID_GLMMHD) {
+    const int b_config = pin.GetInteger("problem/turbulence", "b_config");
+    if (b_config == 3) throw std::runtime_error("Random B fields not implemented yet.");
+    if (b_config < 0 || b_config > 2)
+      throw std::runtime_error("problem/turbulence/b_config = " + std::to_string(b_config) + " is not supported (0, 1, 2 are)");
+  }
+  const int gnx[3] = {m.nx[0], m.nx[1], m.nx[2]};
+  s->fmft = std::make_unique<FewModesFT>(num_modes, std::move(k_vec), k_peak, sol_weight, t_corr, rseed, gnx);
+}
+
+// turbulence::ProblemGenerator (src/pgen/turbulence.cpp:217-370): a MeshData-wide generator --
+// the magnetic field is normalised with a global reduction -- so it fills all local blocks at once
+int pgen_turbulence(apk_sim *s, std::vector<std::vector<double>> &blocks) {
+  const Mesh &m = s->mesh;
+  ParameterInput &pin = s->pin;
+  const bool mhd = s->pkg.fluid == APK_FLUID_GLMMHD;
+  const double gm1 = pin.GetReal("hydro", "gamma") - 1.0;
+  const double p0 = pin.GetReal("problem/turbulence", "p0");
+  const double rho0 = pin.GetReal("problem/turbulence", "rho0");
+  const double Lx = s->xmax[0] - s->xmin[0], Ly = s->xmax[1] - s->xmin[1], Lz = s->xmax[2] - s->xmin[2];
+  const double x3min = s->xmin[2];
+  const double kz = 2.0 * M_PI / Lz;
+  const double vol = s->dx[0] * s->dx[1] * s->dx[2];
+  const int nlb = (int)m.local_gids.size();
+  blocks.assign(nlb, std::vector<double>((size_t)s->nper, 0.0));
+  double b_norm = 0.0;
+  if (mhd) {
+    const double b0 = pin.GetReal("problem/turbulence", "b0");
+    const int b_config = pin.GetInteger("problem/turbulence", "b_config");
+    double mag_en_sum = 0.0;
+    for (int lb = 0; lb < nlb; ++lb) {
+      double x0[3];
+      block_origin(s, lb, x0);
+      std::vector<double> &u = blocks[lb];
+      for (int k = m.ks; k <= m.ke; ++k)
+        for (int j = m.js; j <= m.je; ++j)
+          for (int i = m.is; i <= m.ie; ++i) {
+            double b1 = 0.0;
+            if (b_config == 0) b1 = b0;                                                   // uniform
+            if (b_config == 1) b1 = (xc(s, x0, 2, k) < x3min + Lz / 2.0) ? b0 : -b0;      // no net flux
+            if (b_config == 2) b1 = b0 / std::sqrt(0.5) * std::sin(kz * xc(s, x0, 2, k));  // sin(z)
+            u[5 * m.sn + k * m.sk + j * m.sj + i] = b1;
+            mag_en_sum += 0.5 * (b1 * b1 + 0.0 + 0.0) * vol;
+          }
+    }
+    if (s->have_comm && s->nranks > 1) {
+      if (s->comm.allreduce_sum(s->comm.user, &mag_en_sum, 1) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_sum failed");
+    }
+    b_norm = std::sqrt(mag_en_sum / (Lx * Ly * Lz) / (0.5 * b0 * b0));
+  }
+  double v0[3] = {0., 0., 0.};
+  if (pin.DoesParameterExist("problem/turbulence", "v0")) {
+    std::string txt = pin.GetString("problem/turbulence", "v0");
+    for (char &c : txt)
+      if (c == ',') c = ' ';
+    std::istringstream iss(txt);
+    int n = 0;
+    double v;
+    while (iss >> v) {
+      if (n < 3) v0[n] = v;
+      ++n;
+    }
+    if (n != 3) throw std::runtime_error("Initial velocity vector should have three components.");
+  }
+  for (int lb = 0; lb < nlb; ++lb) {
+    std::vector<double> &u = blocks[lb];
+    for (int k = m.ks; k <= m.ke; ++k)
+      for (int j = m.js; j <= m.je; ++j)
+        for (int i = m.is; i <= m.ie; ++i) {
+          const int64_t c = k * m.sk + j * m.sj + i;
+          u[0 * m.sn + c] = rho0;
+          u[1 * m.sn + c] = rho0 * v0[0];
+          u[2 * m.sn + c] = rho0 * v0[1];
+          u[3 * m.sn + c] = rho0 * v0[2];
+          u[4 * m.sn + c] = p0 / gm1 + 0.5 * rho0 * (v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2]);
+          if (mhd) {
+            u[5 * m.sn + c] /= b_norm;
+            u[6 * m.sn + c] /= b_norm;
+            u[7 * m.sn + c] /= b_norm;
+            const double b1 = u[5 * m.sn + c], b2 = u[6 * m.sn + c], b3 = u[7 * m.sn + c];
+            u[4 * m.sn + c] += 0.5 * (b1 * b1 + b2 * b2 + b3 * b3);
+          }
+        }
+  }
+  return APK_OK;
+}
+
 // ---- device resources -----------------------------------------------------------------------
 int dev_alloc(apk_sim *s, const char *tag, size_t bytes, double **out) {
   *out = nullptr;
@@ -539,6 +653,65 @@ int pre_step(apk_sim *s) {
   return APK_OK;
 }
 
+// acc field, per-block phase tables (FewModesFT::SetPhases, few_modes_ft.cpp:142-195) and the
+// device descriptor of the driver
+int turbulence_device_setup(apk_sim *s) {
+  const Mesh &m = s->mesh;
+  const int nlb = (int)m.local_gids.size();
+  const int M = s->fmft->num_modes();
+  const size_t acc_per = 3 * (size_t)m.sn;
+  const size_t ph_per = (size_t)(m.mb[0] + m.mb[1] + m.mb[2]) * M * 2;
+  SIM_TRY(s, dev_alloc(s, "acc", acc_per * nlb * sizeof(double), &s->d_acc));
+  SIM_TRY(s, dev_alloc(s, "turbulence_phases", ph_per * nlb * sizeof(double), &s->d_phases));
+  SIM_HIP(s, hipMemset(s->d_acc, 0, acc_per * nlb * sizeof(double)));
+  std::vector<double> ph(ph_per * nlb);
+  std::vector<apk_fmft_block> desc(nlb);
+  for (int lb = 0; lb < nlb; ++lb) {
+    int bc[3];
+    m.Loc(m.local_gids[lb], bc);
+    double *h = ph.data() + ph_per * lb;
+    double *d = s->d_phases + ph_per * lb;
+    size_t off = 0;
+    const double *dptr[3];
+    for (int ax = 0; ax < 3; ++ax) {
+      s->fmft->Phases(ax, m.mb[ax], bc[ax] * m.mb[ax], m.nx[ax], h + off);
+      dptr[ax] = d + off;
+      off += (size_t)m.mb[ax] * M * 2;
+    }
+    desc[lb].acc = s->d_acc + acc_per * lb;
+    desc[lb].phases_i = dptr[0];
+    desc[lb].phases_j = dptr[1];
+    desc[lb].phases_k = dptr[2];
+  }
+  SIM_HIP(s, hipMemcpy(s->d_phases, ph.data(), ph.size() * sizeof(double), hipMemcpyHostToDevice));
+  SIM_TRY(s, apk_fmft_create(s->ctx, desc.data(), nlb, M, &s->fm_dev));
+  return APK_OK;
+}
+
+// turbulence::Driving = Generate + Perturb (src/pgen/turbulence.cpp:373-482), the first-order
+// operator-split source run after the last stage (src/hydro/hydro_driver.cpp:559-560)
+int turbulence_driving(apk_sim *s, double dt) {
+  s->fmft->Evolve(dt);
+  const auto &vh = s->fmft->var_hat();
+  std::vector<double> flat(vh.size() * 2);
+  for (size_t q = 0; q < vh.size(); ++q) {
+    flat[2 * q] = vh[q].real();
+    flat[2 * q + 1] = vh[q].imag();
+  }
+  SIM_TRY(s, apk_fmft_inverse(s->ctx, s->mu0(), s->fm_dev, flat.data(), s->stream));
+  double sums[4];
+  SIM_TRY(s, apk_turb_mean_momentum(s->ctx, s->mu0(), s->fm_dev, sums, s->stream));  // synchronises: flat is free
+  const bool mpi = s->have_comm && s->nranks > 1;
+  if (mpi && s->comm.allreduce_sum(s->comm.user, sums, 4) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_sum failed");
+  double ampl = 0.0;
+  SIM_TRY(s, apk_turb_remove_mean(s->ctx, s->mu0(), s->fm_dev, sums, &ampl, s->stream));
+  if (mpi && s->comm.allreduce_sum(s->comm.user, &ampl, 1) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_sum failed");
+  const double box = (s->xmax[0] - s->xmin[0]) * (s->xmax[1] - s->xmin[1]) * (s->xmax[2] - s->xmin[2]);
+  const double norm = s->accel_rms / std::sqrt(ampl / box);
+  SIM_TRY(s, apk_turb_apply(s->ctx, s->mu0(), s->fm_dev, norm, dt, s->stream));
+  return APK_OK;
+}
+
 // one stage of HydroDriver::MakeTaskCollection (hydro_driver.cpp:474-577)
 int do_stage(apk_sim *s, int stage) {
   HydroPackage &pkg = s->pkg;
@@ -571,7 +744,8 @@ int do_stage(apk_sim *s, int stage) {
     a.mindx = pkg.mindx;
     // let the finishing sweep do FillDerived (and, in the last stage, the dt estimate) on the
     // cells it updates; only the ghost zones are converted after the exchange
-    fused_fill = (s->mesh.ndim >= 2) && a.dedner != 2;
+    // (not when the turbulence driver kicks the state after this stage)
+    fused_fill = (s->mesh.ndim >= 2) && a.dedner != 2 && !(s->fmft && stage == s->nstages);
     a.fill_derived = fused_fill ? 1 : 0;
     a.estimate_dt = (fused_fill && stage == s->nstages && pkg.calc_dt_hyp) ? 1 : 0;
     SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
@@ -591,6 +765,7 @@ int do_stage(apk_sim *s, int stage) {
                                    pkg.c_h, pkg.mindx, beta_dt, s->stream));
     }
   }
+  if (s->fmft && stage == s->nstages) SIM_TRY(s, turbulence_driving(s, s->dt));
   SIM_TRY(s, exchange_ghosts(s));
   if (fused_fill) {
     SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
@@ -619,6 +794,7 @@ int create_common(const char *deck, const char *const *overrides, int noverrides
     hydro_initialize(s);
     mesh_initialize(s);
     if (s->problem_id == "linear_wave") lw_setup(s);
+    else if (s->problem_id == "turbulence") turbulence_setup(s);
     else if (s->problem_id != "sod" && s->problem_id != "orszag_tang" && s->problem_id != "synthetic")
       throw std::runtime_error("unknown job/problem_id: " + s->problem_id);
   } catch (const std::exception &e) {
@@ -696,6 +872,7 @@ int apk_sim_create(const char *deck, const char *const *overrides, int noverride
     return bail(rc);
   }
   if ((rc = build_copy_plans(s)) != APK_OK) return bail(rc);
+  if (s->fmft && (rc = turbulence_device_setup(s)) != APK_OK) return bail(rc);
   return APK_OK;
 }
 
@@ -709,6 +886,9 @@ void apk_sim_destroy(apk_sim *s) {
       apk_pack_destroy(s->mu0_of[p]);
       apk_pack_destroy(s->mu1_of[p]);
     }
+    apk_fmft_destroy(s->fm_dev);
+    dev_free(s, s->d_acc);
+    dev_free(s, s->d_phases);
     dev_free(s, s->d_cons2[0]);
     dev_free(s, s->d_prim);
     dev_free(s, s->d_cons2[1]);
@@ -735,9 +915,18 @@ int apk_sim_initialize(apk_sim *s) {
   const int nlb = (int)s->mesh.local_gids.size();
   std::vector<double> host((size_t)s->nper);
   try {
-    for (int lb = 0; lb < nlb; ++lb) {
-      pgen_block(s, lb, host);
-      SIM_HIP(s, hipMemcpy(s->d_cons() + (int64_t)lb * s->nper, host.data(), sizeof(double) * s->nper, hipMemcpyHostToDevice));
+    if (s->problem_id == "turbulence") {
+      std::vector<std::vector<double>> blocks;
+      SIM_TRY(s, pgen_turbulence(s, blocks));
+      for (int lb = 0; lb < nlb; ++lb)
+        SIM_HIP(s, hipMemcpy(s->d_cons() + (int64_t)lb * s->nper, blocks[lb].data(), sizeof(double) * s->nper,
+                             hipMemcpyHostToDevice));
+    } else {
+      for (int lb = 0; lb < nlb; ++lb) {
+        pgen_block(s, lb, host);
+        SIM_HIP(s, hipMemcpy(s->d_cons() + (int64_t)lb * s->nper, host.data(), sizeof(double) * s->nper,
+                             hipMemcpyHostToDevice));
+      }
     }
   } catch (const std::exception &e) {
     return fail(s, APK_ERR_INVALID, e.what());
@@ -882,6 +1071,48 @@ int apk_sim_history(apk_sim *s, double *out8) {
   if (s->have_comm && s->nranks > 1) {
     if (s->comm.allreduce_sum(s->comm.user, out8, 8) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_sum failed");
   }
+  return APK_OK;
+}
+
+// TurbulenceHst<Ms|Ma|pb> (src/pgen/turbulence.cpp:47-101), summed over ranks like Parthenon's
+// UserHistoryOperation::sum
+int apk_sim_turbulence_history(apk_sim *s, double *out3) {
+  if (!s || s->host_only || !out3) return APK_ERR_INVALID;
+  SIM_TRY(s, apk_turbulence_history(s->ctx, s->mu0(), s->pkg.fluid, s->pkg.eos.gamma, out3, s->stream));
+  if (s->have_comm && s->nranks > 1) {
+    if (s->comm.allreduce_sum(s->comm.user, out3, 3) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_sum failed");
+  }
+  return APK_OK;
+}
+
+int apk_sim_fmft_num_modes(const apk_sim *s) { return (s && s->fmft) ? s->fmft->num_modes() : 0; }
+
+int apk_sim_fmft_var_hat(const apk_sim *s, double *out) {
+  if (!s || !s->fmft || !out) return APK_ERR_INVALID;
+  const auto &vh = s->fmft->var_hat();
+  for (size_t q = 0; q < vh.size(); ++q) {
+    out[2 * q] = vh[q].real();
+    out[2 * q + 1] = vh[q].imag();
+  }
+  return APK_OK;
+}
+
+int apk_sim_fmft_evolve(apk_sim *s, double dt) {
+  if (!s || !s->fmft) return APK_ERR_INVALID;
+  s->fmft->Evolve(dt);
+  return APK_OK;
+}
+
+int apk_sim_fmft_phases(const apk_sim *s, int axis, int n, int g0, double *out) {
+  if (!s || !s->fmft || !out || axis < 0 || axis > 2 || n <= 0) return APK_ERR_INVALID;
+  s->fmft->Phases(axis, n, g0, s->mesh.nx[axis], out);
+  return APK_OK;
+}
+
+int apk_sim_read_acc(apk_sim *s, int lb, double *host_out) {
+  if (!s || s->host_only || !s->d_acc || !host_out || lb < 0 || lb >= (int)s->mesh.local_gids.size()) return APK_ERR_INVALID;
+  SIM_HIP(s, hipStreamSynchronize(hs(s)));
+  SIM_HIP(s, hipMemcpy(host_out, s->d_acc + 3 * (int64_t)s->mesh.sn * lb, sizeof(double) * 3 * s->mesh.sn, hipMemcpyDeviceToHost));
   return APK_OK;
 }
 

@@ -5,6 +5,7 @@
 #pragma once
 
 #include <limits>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -12,6 +13,7 @@
 #include "../../../include/apk_host.h"
 #include "mesh.hpp"
 #include "params.hpp"
+#include "turbulence.hpp"
 
 namespace apk {
 
@@ -90,5 +92,11 @@ struct apk_sim {
   apk_pack *mu1() const { return mu1_of[u1buf]; }
   apk_copy_plan *plan(int ph) const { return plans_of[cur][ph]; }
   double *d_cons() const { return d_cons2[cur]; }
+  // few-modes turbulence driver (problem_id = turbulence; src/pgen/turbulence.cpp:103-200)
+  std::unique_ptr<apk::FewModesFT> fmft;
+  double accel_rms = 0.0;
+  double *d_acc = nullptr;     // [nblocks][3][Nk][Nj][Ni]
+  double *d_phases = nullptr;  // per block: phases_i | phases_j | phases_k
+  apk_fmft *fm_dev = nullptr;
   std::string err;
 };

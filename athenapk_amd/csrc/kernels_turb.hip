@@ -1,0 +1,291 @@
+// kernels_turb.hip -- device side of the few-modes turbulence driver (BASELINE config 4):
+// explicit inverse transform of <= ~100 modes per cell and the Perturb kernels.
+// The inverse transform is ALU-bound (3 x num_modes complex MACs per cell): one lane per cell,
+// x1 along the lanes so phases_i is a coalesced read, phases_j / phases_k and var_hat are
+// wave-uniform (scalar loads).
+#include <cstring>
+#include <new>
+
+#include "apk_internal.hpp"
+#include "hydro_math.hpp"
+
+struct apk_fmft {
+  int nblocks = 0, num_modes = 0;
+  apk_fmft_block *d_blocks = nullptr;
+  double *d_var_hat = nullptr;  // [3][M][2]
+};
+
+namespace apk {
+namespace {
+
+APK_DEV bool interior_of(const PackView &pv, int &b, int &k, int &j, int &i) {
+  i = pv.is + blockIdx.x * 64 + threadIdx.x;
+  j = pv.js + blockIdx.y * 4 + threadIdx.y;
+  b = blockIdx.z / pv.nx3;
+  k = pv.ks + blockIdx.z % pv.nx3;
+  return (i <= pv.ie) && (j <= pv.je);
+}
+inline dim3 igrid(const PackView &pv) { return dim3((pv.nx1 + 63) / 64, (pv.nx2 + 3) / 4, pv.nx3 * pv.nblocks); }
+
+// few_modes_ft.cpp:330-347
+__global__ void __launch_bounds__(256)
+fmft_inverse_kernel(PackView pv, const apk_fmft_block *blocks, const double *var_hat, int M) {
+  int b, k, j, i;
+  if (!interior_of(pv, b, k, j, i)) return;
+  const apk_fmft_block blk = blocks[b];
+  const double *pi = blk.phases_i + (int64_t)(i - pv.is) * M * 2;
+  const double *pj = blk.phases_j + (int64_t)(j - pv.js) * M * 2;
+  const double *pk = blk.phases_k + (int64_t)(k - pv.ks) * M * 2;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int m = 0; m < M; ++m) {
+    const double ir = pi[2 * m], ii = pi[2 * m + 1];
+    const double jr = pj[2 * m], ji = pj[2 * m + 1];
+    const double kr = pk[2 * m], ki = pk[2 * m + 1];
+    // phase = phase_i * phase_j * phase_k (complex products, left to right)
+    const double pr = ir * jr - ii * ji, pim = ir * ji + ii * jr;
+    const double qr = pr * kr - pim * ki, qi = pr * ki + pim * kr;
+    s0 += 2. * (var_hat[(0 * M + m) * 2] * qr - var_hat[(0 * M + m) * 2 + 1] * qi);
+    s1 += 2. * (var_hat[(1 * M + m) * 2] * qr - var_hat[(1 * M + m) * 2 + 1] * qi);
+    s2 += 2. * (var_hat[(2 * M + m) * 2] * qr - var_hat[(2 * M + m) * 2 + 1] * qi);
+  }
+  const int64_t cell = k * pv.sk + j * pv.sj + i;
+  blk.acc[0 * pv.sn + cell] = s0;
+  blk.acc[1 * pv.sn + cell] = s1;
+  blk.acc[2 * pv.sn + cell] = s2;
+}
+
+APK_DEV double wsum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// generic "NQ sums per workgroup" epilogue: partial[wg][NQ]
+template <int NQ>
+APK_DEV void store_partials(const double (&h)[NQ], double *partial) {
+  __shared__ double part[4][NQ];
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const double s = wsum(h[q]);
+    if ((tid & 63) == 0) part[tid >> 6][q] = s;
+  }
+  __syncthreads();
+  if (tid < NQ) {
+    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    partial[(int64_t)wg * NQ + tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+  }
+}
+
+template <int NQ>
+__global__ void __launch_bounds__(256) final_sum_kernel(const double *partial, int nwg, double *out) {
+  // NQ <= 8 quantities x 32 lanes each, fixed order => deterministic
+  const int q = threadIdx.x / 32, lane = threadIdx.x % 32;
+  if (q >= NQ) return;
+  double s = 0.0;
+  for (int w = lane; w < nwg; w += 32) s += partial[(int64_t)w * NQ + q];
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) s += __shfl_down(s, off, 32);
+  if (lane == 0) out[q] = s;
+}
+
+// turbulence.cpp:395-413
+__global__ void __launch_bounds__(256)
+turb_mean_momentum_kernel(PackView pv, const apk_fmft_block *blocks, double *partial) {
+  int b, k, j, i;
+  double h[4] = {0, 0, 0, 0};
+  if (interior_of(pv, b, k, j, i)) {
+    const apk_block_desc blk = pv.blocks[b];
+    const double vol = blk.dx[0] * blk.dx[1] * blk.dx[2];
+    const int64_t cell = k * pv.sk + j * pv.sj + i;
+    const double den = blk.cons[IDN * pv.sn + cell];
+    const double *acc = blocks[b].acc + cell;
+    h[0] = den * vol;
+    h[1] = den * acc[0 * pv.sn] * vol;
+    h[2] = den * acc[1 * pv.sn] * vol;
+    h[3] = den * acc[2 * pv.sn] * vol;
+  }
+  store_partials<4>(h, partial);
+}
+
+// turbulence.cpp:421-430
+__global__ void __launch_bounds__(256)
+turb_remove_mean_kernel(PackView pv, const apk_fmft_block *blocks, double m1, double m2, double m3,
+                        double *partial) {
+  int b, k, j, i;
+  double h[1] = {0};
+  if (interior_of(pv, b, k, j, i)) {
+    const apk_block_desc blk = pv.blocks[b];
+    const double vol = blk.dx[0] * blk.dx[1] * blk.dx[2];
+    const int64_t cell = k * pv.sk + j * pv.sj + i;
+    double *acc = blocks[b].acc + cell;
+    const double a0 = acc[0 * pv.sn] - m1, a1 = acc[1 * pv.sn] - m2, a2 = acc[2 * pv.sn] - m3;
+    acc[0 * pv.sn] = a0;
+    acc[1 * pv.sn] = a1;
+    acc[2 * pv.sn] = a2;
+    h[0] = sqr(a0) * vol + sqr(a1) * vol + sqr(a2) * vol;
+  }
+  store_partials<1>(h, partial);
+}
+
+// turbulence.cpp:446-469
+__global__ void __launch_bounds__(256)
+turb_apply_kernel(PackView pv, const apk_fmft_block *blocks, double norm, double dt) {
+  int b, k, j, i;
+  if (!interior_of(pv, b, k, j, i)) return;
+  const apk_block_desc blk = pv.blocks[b];
+  const int64_t cell = k * pv.sk + j * pv.sj + i;
+  double *acc = blocks[b].acc + cell;
+  double *u = blk.cons + cell;
+  const double a0 = acc[0 * pv.sn] * norm, a1 = acc[1 * pv.sn] * norm, a2 = acc[2 * pv.sn] * norm;
+  acc[0 * pv.sn] = a0;
+  acc[1 * pv.sn] = a1;
+  acc[2 * pv.sn] = a2;
+  const double den = u[IDN * pv.sn];
+  const double qa = dt * den;
+  const double m1 = u[IM1 * pv.sn], m2 = u[IM2 * pv.sn], m3 = u[IM3 * pv.sn];
+  u[IEN * pv.sn] += (m1 * dt * a0 + m2 * dt * a1 + m3 * dt * a2 +
+                     (sqr(a0) + sqr(a1) + sqr(a2)) * qa * qa / (2 * den));
+  u[IM1 * pv.sn] = m1 + qa * a0;
+  u[IM2 * pv.sn] = m2 + qa * a1;
+  u[IM3 * pv.sn] = m3 + qa * a2;
+}
+
+// turbulence.cpp:47-101
+template <int FLUID>
+__global__ void __launch_bounds__(256) turb_history_kernel(PackView pv, double gamma, double *partial) {
+  int b, k, j, i;
+  double h[3] = {0, 0, 0};
+  if (interior_of(pv, b, k, j, i)) {
+    const apk_block_desc blk = pv.blocks[b];
+    const double vol = blk.dx[0] * blk.dx[1] * blk.dx[2];
+    const double *w = blk.prim + k * pv.sk + j * pv.sj + i;
+    const double d = w[IDN * pv.sn], p = w[IPR * pv.sn];
+    const double vel2 = (w[IV1 * pv.sn] * w[IV1 * pv.sn] + w[IV2 * pv.sn] * w[IV2 * pv.sn] +
+                         w[IV3 * pv.sn] * w[IV3 * pv.sn]);
+    const double c_s = sqrt(gamma * p / d);
+    const double e_kin = 0.5 * d * vel2;
+    h[0] = sqrt(vel2) / c_s * vol;
+    if constexpr (FLUID == APK_FLUID_GLMMHD) {
+      const double B2 = (w[IB1 * pv.sn] * w[IB1 * pv.sn] + w[IB2 * pv.sn] * w[IB2 * pv.sn] +
+                         w[IB3 * pv.sn] * w[IB3 * pv.sn]);
+      const double e_mag = 0.5 * B2;
+      h[1] = sqrt(e_kin / e_mag) * vol;
+      h[2] = p / e_mag * vol;
+    }
+  }
+  store_partials<3>(h, partial);
+}
+
+int ensure_partial_cap(apk_ctx *ctx, size_t n) {
+  if (ctx->partial_cap >= n) return APK_OK;
+  if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+  ctx->d_partial = nullptr;
+  ctx->partial_cap = 0;
+  if (hipMalloc(&ctx->d_partial, n * sizeof(double)) != hipSuccess) return APK_ERR_DEVICE;
+  ctx->partial_cap = n;
+  return APK_OK;
+}
+
+// run a partial-sum kernel result through the final reduction and bring NQ doubles to the host
+template <int NQ>
+int finish_sums(apk_ctx *ctx, int nwg, double *out, hipStream_t s) {
+  double *d_out = ctx->d_partial + (size_t)nwg * NQ;
+  hipLaunchKernelGGL(final_sum_kernel<NQ>, dim3(1), dim3(256), 0, s, ctx->d_partial, nwg, d_out);
+  auto *h = static_cast<double *>(ctx->h_pinned) + 16;
+  if (hipMemcpyAsync(h, d_out, NQ * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return APK_ERR_DEVICE;
+  if (hipStreamSynchronize(s) != hipSuccess) return APK_ERR_DEVICE;
+  std::memcpy(out, h, NQ * sizeof(double));
+  return APK_OK;
+}
+
+}  // namespace
+}  // namespace apk
+
+using namespace apk;
+
+extern "C" {
+
+int apk_fmft_create(apk_ctx *ctx, const apk_fmft_block *blocks, int nblocks, int num_modes, apk_fmft **out) {
+  if (!ctx || !blocks || !out || nblocks <= 0 || num_modes <= 0) return APK_ERR_INVALID;
+  *out = nullptr;
+  apk_fmft *f = new (std::nothrow) apk_fmft();
+  if (!f) return APK_ERR_INVALID;
+  f->nblocks = nblocks;
+  f->num_modes = num_modes;
+  hipError_t e = hipMalloc(&f->d_blocks, sizeof(apk_fmft_block) * nblocks);
+  if (e == hipSuccess) e = hipMemcpy(f->d_blocks, blocks, sizeof(apk_fmft_block) * nblocks, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&f->d_var_hat, sizeof(double) * 3 * num_modes * 2);
+  if (e != hipSuccess) {
+    apk_fmft_destroy(f);
+    return set_err(ctx, APK_ERR_DEVICE, "apk_fmft_create", e);
+  }
+  *out = f;
+  return APK_OK;
+}
+
+void apk_fmft_destroy(apk_fmft *f) {
+  if (!f) return;
+  if (f->d_blocks) (void)hipFree(f->d_blocks);
+  if (f->d_var_hat) (void)hipFree(f->d_var_hat);
+  delete f;
+}
+
+int apk_fmft_inverse(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, const double *var_hat_host,
+                     apk_stream_t stream) {
+  if (!ctx || !md || !f || !var_hat_host || f->nblocks != md->view.nblocks)
+    return set_err(ctx, APK_ERR_INVALID, "apk_fmft_inverse: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  APK_HIP_TRY(ctx, hipMemcpyAsync(f->d_var_hat, var_hat_host, sizeof(double) * 3 * f->num_modes * 2,
+                                  hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(fmft_inverse_kernel, igrid(md->view), dim3(64, 4, 1), 0, s, md->view, f->d_blocks,
+                     f->d_var_hat, f->num_modes);
+  return hipGetLastError() == hipSuccess ? APK_OK : set_err(ctx, APK_ERR_DEVICE, "fmft_inverse launch", hipGetLastError());
+}
+
+int apk_turb_mean_momentum(apk_ctx *ctx, const apk_pack *md, const apk_fmft *f, double *sums4,
+                           apk_stream_t stream) {
+  if (!ctx || !md || !f || !sums4 || f->nblocks != md->view.nblocks) return set_err(ctx, APK_ERR_INVALID, "apk_turb_mean_momentum: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 g = igrid(md->view);
+  const int nwg = g.x * g.y * g.z;
+  if (ensure_partial_cap(ctx, (size_t)nwg * 4 + 8) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "partial buffer");
+  hipLaunchKernelGGL(turb_mean_momentum_kernel, g, dim3(64, 4, 1), 0, s, md->view, f->d_blocks, ctx->d_partial);
+  return finish_sums<4>(ctx, nwg, sums4, s);
+}
+
+int apk_turb_remove_mean(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, const double *sums4, double *ampl_sum,
+                         apk_stream_t stream) {
+  if (!ctx || !md || !f || !sums4 || !ampl_sum || f->nblocks != md->view.nblocks)
+    return set_err(ctx, APK_ERR_INVALID, "apk_turb_remove_mean: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 g = igrid(md->view);
+  const int nwg = g.x * g.y * g.z;
+  if (ensure_partial_cap(ctx, (size_t)nwg * 4 + 8) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "partial buffer");
+  hipLaunchKernelGGL(turb_remove_mean_kernel, g, dim3(64, 4, 1), 0, s, md->view, f->d_blocks, sums4[1] / sums4[0],
+                     sums4[2] / sums4[0], sums4[3] / sums4[0], ctx->d_partial);
+  return finish_sums<1>(ctx, nwg, ampl_sum, s);
+}
+
+int apk_turb_apply(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, double norm, double dt, apk_stream_t stream) {
+  if (!ctx || !md || !f || f->nblocks != md->view.nblocks) return set_err(ctx, APK_ERR_INVALID, "apk_turb_apply: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(turb_apply_kernel, igrid(md->view), dim3(64, 4, 1), 0, s, md->view, f->d_blocks, norm, dt);
+  return hipGetLastError() == hipSuccess ? APK_OK : set_err(ctx, APK_ERR_DEVICE, "turb_apply launch", hipGetLastError());
+}
+
+int apk_turbulence_history(apk_ctx *ctx, const apk_pack *md, int fluid, double gamma, double *out3,
+                           apk_stream_t stream) {
+  if (!ctx || !md || !out3) return set_err(ctx, APK_ERR_INVALID, "apk_turbulence_history: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 g = igrid(md->view);
+  const int nwg = g.x * g.y * g.z;
+  if (ensure_partial_cap(ctx, (size_t)nwg * 4 + 8) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "partial buffer");
+  if (fluid == APK_FLUID_EULER)
+    hipLaunchKernelGGL(turb_history_kernel<APK_FLUID_EULER>, g, dim3(64, 4, 1), 0, s, md->view, gamma, ctx->d_partial);
+  else
+    hipLaunchKernelGGL(turb_history_kernel<APK_FLUID_GLMMHD>, g, dim3(64, 4, 1), 0, s, md->view, gamma, ctx->d_partial);
+  return finish_sums<3>(ctx, nwg, out3, s);
+}
+
+}  // extern "C"

@@ -41,7 +41,34 @@ def _allreduce(vals_ptr, n, op, device, group=None):
     a[:] = t.cpu().numpy()
 
 
-class Simulation:
+class _FmftHost:
+    """Host spectral state of the few-modes turbulence driver (FewModesFT,
+    /root/reference src/utils/few_modes_ft.cpp); works on host-only sims too."""
+
+    def fmft_num_modes(self):
+        return self.lib.apk_sim_fmft_num_modes(self.h)
+
+    def fmft_var_hat(self):
+        out = np.zeros((3, self.fmft_num_modes(), 2))
+        rc = self.lib.apk_sim_fmft_var_hat(self.h, out.ctypes.data_as(L.c_dp))
+        if rc != L.APK_OK:
+            raise L.ApkError(rc, "no turbulence driver in this sim")
+        return out
+
+    def fmft_evolve(self, dt):
+        rc = self.lib.apk_sim_fmft_evolve(self.h, float(dt))
+        if rc != L.APK_OK:
+            raise L.ApkError(rc, "no turbulence driver in this sim")
+
+    def fmft_phases(self, axis, n, g0):
+        out = np.zeros((n, self.fmft_num_modes(), 2))
+        rc = self.lib.apk_sim_fmft_phases(self.h, axis, n, g0, out.ctypes.data_as(L.c_dp))
+        if rc != L.APK_OK:
+            raise L.ApkError(rc, "no turbulence driver in this sim")
+        return out
+
+
+class Simulation(_FmftHost):
     """apk_sim: deck + overrides -> mesh partition, packs, ghost plans, stage loop (C++)."""
 
     def __init__(self, deck, overrides=(), rank=0, nranks=1, strict=False, use_torch_alloc=True,
@@ -202,6 +229,17 @@ class Simulation:
         self._check(self.lib.apk_sim_history(self.h, out))
         return np.array(out[:])
 
+    def turbulence_history(self):
+        """volume sums of sonic Mach number, Alfvenic Mach number, plasma beta (TurbulenceHst)"""
+        out = (C.c_double * 3)()
+        self._check(self.lib.apk_sim_turbulence_history(self.h, out))
+        return np.array(out[:])
+
+    def read_acc(self, lb):
+        out = np.empty((3,) + self.block_shape[1:])
+        self._check(self.lib.apk_sim_read_acc(self.h, lb, out.ctypes.data_as(L.c_dp)))
+        return out
+
     def linear_wave_errors(self):
         rms = C.c_double(0.0)
         l1, mx = (C.c_double * 5)(), (C.c_double * 5)()
@@ -232,7 +270,7 @@ class Simulation:
         return dt.value
 
 
-class HostPlan:
+class HostPlan(_FmftHost):
     """Host-only view of a rank's mesh partition and ghost-exchange plan (no GPU needed)."""
 
     PHASES = {"local": 0, "pack": 1, "unpack": 2, "bc1": 3, "bc2": 4, "bc3": 5}

@@ -207,3 +207,74 @@ def HydroHst(md, fluid):
     out = (C.c_double * 8)()
     _check(ctx.lib.apk_history(ctx.h, md.h, L.FLUID[fluid], out, _stream()), ctx.lib, ctx.h)
     return np.array(out[:])
+
+
+# ---- few-modes turbulence driver -------------------------------------------------------------
+class FewModesFT:
+    """Device side of FewModesFT / turbulence::Perturb for one MeshData: the acceleration field
+    "acc" and the per-block phase tables (src/utils/few_modes_ft.cpp:142-195,
+    src/pgen/turbulence.cpp:119-127).  `phases[b]` is (phases_i, phases_j, phases_k), each
+    [n][num_modes][2]."""
+
+    def __init__(self, md, phases):
+        self.md = md
+        ctx = md.ctx
+        dev = torch.device("cuda")
+        self.num_modes = int(np.asarray(phases[0][0]).shape[1])
+        self.acc = torch.zeros((md.nblocks, 3) + md.shape[1:], dtype=torch.float64, device=dev)
+        self._ph = [[torch.from_numpy(np.ascontiguousarray(p, dtype=np.float64)).to(dev) for p in blk]
+                    for blk in phases]
+        blocks = (L.FmftBlock * md.nblocks)()
+        per = 3 * int(np.prod(md.shape[1:])) * 8
+        for b in range(md.nblocks):
+            blocks[b].acc = self.acc.data_ptr() + b * per
+            blocks[b].phases_i, blocks[b].phases_j, blocks[b].phases_k = [t.data_ptr() for t in self._ph[b]]
+        h = C.c_void_p()
+        _check(ctx.lib.apk_fmft_create(ctx.h, blocks, md.nblocks, self.num_modes, C.byref(h)), ctx.lib, ctx.h)
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.md.ctx.lib.apk_fmft_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def Inverse(self, var_hat):
+        """FewModesFT::Generate's inverse transform -- src/utils/few_modes_ft.cpp:322-347"""
+        ctx = self.md.ctx
+        vh = np.ascontiguousarray(var_hat, dtype=np.float64)
+        assert vh.shape == (3, self.num_modes, 2)
+        _check(ctx.lib.apk_fmft_inverse(ctx.h, self.md.h, self.h, vh.ctypes.data_as(L.c_dp), _stream()), ctx.lib, ctx.h)
+        torch.cuda.current_stream().synchronize()  # vh must outlive the copy
+
+    def Perturb(self, dt, accel_rms, box_volume, allreduce_sum=None):
+        """turbulence::Perturb -- src/pgen/turbulence.cpp:384-470.  `allreduce_sum(np.ndarray)`
+        stands where the reference calls MPI_Allreduce."""
+        ctx = self.md.ctx
+        sums = np.zeros(4)
+        _check(ctx.lib.apk_turb_mean_momentum(ctx.h, self.md.h, self.h, sums.ctypes.data_as(L.c_dp), _stream()),
+               ctx.lib, ctx.h)
+        if allreduce_sum is not None:
+            allreduce_sum(sums)
+        ampl = np.zeros(1)
+        _check(ctx.lib.apk_turb_remove_mean(ctx.h, self.md.h, self.h, sums.ctypes.data_as(L.c_dp),
+                                            ampl.ctypes.data_as(L.c_dp), _stream()), ctx.lib, ctx.h)
+        if allreduce_sum is not None:
+            allreduce_sum(ampl)
+        norm = accel_rms / np.sqrt(ampl[0] / box_volume)
+        _check(ctx.lib.apk_turb_apply(ctx.h, self.md.h, self.h, float(norm), float(dt), _stream()), ctx.lib, ctx.h)
+        return norm
+
+    def acc_host(self):
+        torch.cuda.synchronize()
+        return self.acc.cpu().numpy()
+
+
+def TurbulenceHst(md, fluid, gamma):
+    """TurbulenceHst<Ms|Ma|pb> -- src/pgen/turbulence.cpp:47-101"""
+    ctx = md.ctx
+    out = (C.c_double * 3)()
+    _check(ctx.lib.apk_turbulence_history(ctx.h, md.h, L.FLUID[fluid], float(gamma), out, _stream()), ctx.lib, ctx.h)
+    return np.array(out[:])

@@ -58,6 +58,11 @@ class StageArgs(C.Structure):
                 ("estimate_dt", C.c_int)]
 
 
+class FmftBlock(C.Structure):
+    _fields_ = [("acc", C.c_void_p), ("phases_i", C.c_void_p), ("phases_j", C.c_void_p),
+                ("phases_k", C.c_void_p)]
+
+
 class CopyRegion(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("ext", C.c_int * 3),
                 ("nvar", C.c_int), ("src_stride", C.c_int64 * 4),
@@ -128,6 +133,13 @@ def _signatures():
         "apk_estimate_timestep": (i, [vp, vp, i, E, d, c_dp, vp]),
         "apk_first_order_flux_correct": (i, [vp, vp, vp, i, E, d, d, d, d, C.POINTER(ll), vp]),
         "apk_history": (i, [vp, vp, i, c_dp, vp]),
+        "apk_fmft_create": (i, [vp, C.POINTER(FmftBlock), i, i, pp]),
+        "apk_fmft_destroy": (None, [vp]),
+        "apk_fmft_inverse": (i, [vp, vp, vp, c_dp, vp]),
+        "apk_turb_mean_momentum": (i, [vp, vp, vp, c_dp, vp]),
+        "apk_turb_remove_mean": (i, [vp, vp, vp, c_dp, c_dp, vp]),
+        "apk_turb_apply": (i, [vp, vp, vp, d, d, vp]),
+        "apk_turbulence_history": (i, [vp, vp, i, d, c_dp, vp]),
         "apk_poll_device_flags": (i, [vp, C.POINTER(C.c_uint), vp]),
         "apk_copy_plan_create": (i, [vp, C.POINTER(CopyRegion), i, pp]),
         "apk_copy_plan_destroy": (None, [vp]),
@@ -158,6 +170,12 @@ def _signatures():
         "apk_sim_write_block": (i, [vp, i, i, c_dp]),
         "apk_sim_history": (i, [vp, c_dp]),
         "apk_sim_linear_wave_errors": (i, [vp, c_dp, c_dp, c_dp]),
+        "apk_sim_turbulence_history": (i, [vp, c_dp]),
+        "apk_sim_fmft_num_modes": (i, [vp]),
+        "apk_sim_fmft_var_hat": (i, [vp, c_dp]),
+        "apk_sim_fmft_evolve": (i, [vp, d]),
+        "apk_sim_fmft_phases": (i, [vp, i, i, i, c_dp]),
+        "apk_sim_read_acc": (i, [vp, i, c_dp]),
         "apk_sim_exchange_ghosts": (i, [vp]),
         "apk_sim_fill_derived": (i, [vp]),
         "apk_sim_estimate_timestep": (i, [vp, c_dp]),

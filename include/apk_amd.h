@@ -217,6 +217,42 @@ int apk_copy_plan_create(apk_ctx *ctx, const apk_copy_region *regions, int n,
 void apk_copy_plan_destroy(apk_copy_plan *plan);
 int apk_copy_plan_run(apk_ctx *ctx, const apk_copy_plan *plan, apk_stream_t stream);
 
+/* ---- few-modes turbulence driver (BASELINE config 4 forcing; "next" row of SURVEY 8(f)) -------
+ * The device side of turbulence::Driving (src/pgen/turbulence.cpp:373-482), which AthenaPK
+ * enrols as Hydro::ProblemSourceFirstOrder (src/main.cpp:115, run after the last stage,
+ * src/hydro/hydro_driver.cpp:559-560), and of FewModesFT::Generate's inverse transform
+ * (src/utils/few_modes_ft.cpp:322-347).  The spectral state (3 x num_modes complex numbers),
+ * its host RNG and the Ornstein-Uhlenbeck update stay on the host, as in the reference. */
+typedef struct apk_fmft_block {
+  double *acc;            /* [3][Nk][Nj][Ni] acceleration field ("acc", turbulence.cpp:119-127) */
+  const double *phases_i; /* [nx1][num_modes][2]  (few_modes_ft.cpp:143-160) */
+  const double *phases_j; /* [nx2][num_modes][2] */
+  const double *phases_k; /* [nx3][num_modes][2] */
+} apk_fmft_block;
+typedef struct apk_fmft apk_fmft;
+int apk_fmft_create(apk_ctx *ctx, const apk_fmft_block *blocks /* host array */, int nblocks,
+                    int num_modes, apk_fmft **out);
+void apk_fmft_destroy(apk_fmft *f);
+/* acc(b, n, k, j, i) = sum_m 2 (Re var_hat(n,m) Re phase - Im var_hat(n,m) Im phase) on the
+ * interior; var_hat_host is [3][num_modes][2], copied to the device on `stream`: keep it valid
+ * until the stream has been synchronised (apk_turb_mean_momentum, the next step, does) */
+int apk_fmft_inverse(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, const double *var_hat_host,
+                     apk_stream_t stream);
+/* turbulence::Perturb in three device steps around the reference's two MPI_Allreduce's
+ * (turbulence.cpp:395-436): sums4 = (mass, rho*acc_1..3) * cell volume  [synchronises];
+ * subtract sums4[n+1]/sums4[0] from acc_n and return sum acc^2 * volume    [synchronises];
+ * scale acc by norm and kick momentum / energy with dt (turbulence.cpp:446-469). */
+int apk_turb_mean_momentum(apk_ctx *ctx, const apk_pack *md, const apk_fmft *f, double *sums4,
+                           apk_stream_t stream);
+int apk_turb_remove_mean(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, const double *sums4,
+                         double *ampl_sum, apk_stream_t stream);
+int apk_turb_apply(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, double norm, double dt,
+                   apk_stream_t stream);
+/* TurbulenceHst<Ms|Ma|pb> (turbulence.cpp:47-101): out3 = volume sums of sonic Mach number,
+ * Alfvenic Mach number, plasma beta.  Synchronises. */
+int apk_turbulence_history(apk_ctx *ctx, const apk_pack *md, int fluid, double gamma, double *out3,
+                           apk_stream_t stream);
+
 /* ---- in-library kernel timing (HIP events on the caller's stream) ------------------------
  * bench.py needs the average duration of individual kernels measured live on the stream
  * they are launched on.  When enabled, every kernel launch of the listed groups is

@@ -104,6 +104,18 @@ int apk_sim_write_block(apk_sim *sim, int lb, int field, const double *host_in);
 /* history sums over the whole mesh (allreduce'd): mass,1-mom,2-mom,3-mom,KE,tot-E,ME,relDivB */
 int apk_sim_history(apk_sim *sim, double *out8);
 /* linear-wave L1 errors vs the initial condition (src/pgen/linear_wave.cpp:183-335) */
+/* few-modes turbulence driver (job/problem_id = turbulence).  History: volume sums of Ms, Ma,
+ * plasma beta (src/pgen/turbulence.cpp:47-101; divide by the box volume for the means).  The
+ * fmft_* calls expose the host spectral state (FewModesFT, src/utils/few_modes_ft.cpp) and also
+ * work on a host-only sim: var_hat is [3][num_modes][2]; evolve advances the OU process by dt
+ * (consuming RNG draws exactly as a driven step does); phases fills [n][num_modes][2] for cells
+ * g0..g0+n-1 of `axis`.  read_acc copies block lb's acceleration field [3][Nk][Nj][Ni]. */
+int apk_sim_turbulence_history(apk_sim *sim, double *out3);
+int apk_sim_fmft_num_modes(const apk_sim *sim);
+int apk_sim_fmft_var_hat(const apk_sim *sim, double *out);
+int apk_sim_fmft_evolve(apk_sim *sim, double dt);
+int apk_sim_fmft_phases(const apk_sim *sim, int axis, int n, int g0, double *out);
+int apk_sim_read_acc(apk_sim *sim, int lb, double *host_out);
 int apk_sim_linear_wave_errors(apk_sim *sim, double *rms, double *l1_5, double *max_5);
 /* individual driver steps, exposed for tests */
 int apk_sim_exchange_ghosts(apk_sim *sim);

@@ -182,6 +182,42 @@ void orc_sim_gather_cons(orc_sim *s, double *out);
 void orc_sim_exchange_ghosts(orc_sim *s);
 void orc_sim_fill_derived(orc_sim *s);
 
+/* ---- few-modes turbulence driver (turbulence.c; BASELINE config 4 forcing) ---------------- */
+#include <stdint.h>
+typedef struct {
+  uint32_t mt[624];
+  int idx;
+} orc_mt19937; /* std::mt19937 */
+void orc_mt_seed(orc_mt19937 *g, uint32_t seed);
+uint32_t orc_mt_next(orc_mt19937 *g);
+double orc_uniform_m1_p1(orc_mt19937 *g); /* std::uniform_real_distribution<>(-1,1) (libstdc++) */
+
+typedef struct {
+  int num_modes;
+  double k_peak, sol_weight, t_corr;
+  double *k_vec;       /* [3][M] */
+  double *var_hat;     /* [3][M][2] (re, im) */
+  double *var_hat_new; /* [3][M][2] */
+  orc_mt19937 rng;
+} orc_fmft;
+orc_fmft *orc_fmft_create(int num_modes, const double *k_vec, double k_peak, double sol_weight,
+                          double t_corr, uint32_t rseed);
+void orc_fmft_destroy(orc_fmft *f);
+void orc_fmft_evolve(orc_fmft *f, double dt);
+void orc_fmft_phases(const orc_fmft *f, int axis, int n, int g0, int gn, double *out);
+void orc_fmft_inverse(const orc_fmft *f, const orc_geom *g, const double *ph_i, const double *ph_j,
+                      const double *ph_k, double *acc);
+void orc_turb_perturb(int nblocks, const orc_geom *g, double **cons, double **acc, double dt,
+                      double accel_rms, double box_volume);
+void orc_turb_history(const orc_geom *g, int fluid, double gamma, const double *prim, double *out3);
+/* src/pgen/turbulence.cpp:217-370 (b_config 0, 1, 2) + enrols the driver on the sim */
+void orc_pgen_turbulence(orc_sim *s, double rho0, double p0, double b0, int b_config, int num_modes,
+                         const double *k_vec, double k_peak, double sol_weight, double t_corr,
+                         double accel_rms, uint32_t rseed);
+void orc_sim_turb_history(orc_sim *s, double *out3);
+const double *orc_sim_var_hat(const orc_sim *s);
+double *orc_sim_acc(orc_sim *s, int b);
+
 /* integrator coefficient table; returns nstages */
 int orc_integrator_coeffs(int integrator, double *beta, double *gam0, double *gam1);
 

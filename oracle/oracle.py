@@ -69,7 +69,7 @@ def build(fast=False, force=False):
     target = "liboracle_fast.so" if fast else "liboracle.so"
     path = os.path.join(_HERE, target)
     srcs = [os.path.join(_HERE, f) for f in
-            ("recon.c", "riemann.c", "block.c", "sim.c", "apk_oracle.h", "Makefile")]
+            ("recon.c", "riemann.c", "block.c", "sim.c", "turbulence.c", "apk_oracle.h", "Makefile")]
     stale = (not os.path.exists(path)) or any(
         os.path.getmtime(s) > os.path.getmtime(path) for s in srcs)
     if force or stale:
@@ -119,6 +119,20 @@ def _declare(lib):
         "orc_sim_exchange_ghosts": (None, [C.c_void_p]),
         "orc_sim_fill_derived": (None, [C.c_void_p]),
         "orc_integrator_coeffs": (i, [i, p, p, p]),
+        "orc_pgen_turbulence": (None, [C.c_void_p, d, d, d, i, i, p, d, d, d, d, C.c_uint32]),
+        "orc_sim_turb_history": (None, [C.c_void_p, p]),
+        "orc_sim_var_hat": (p, [C.c_void_p]),
+        "orc_sim_acc": (p, [C.c_void_p, i]),
+        "orc_mt_seed": (None, [C.c_void_p, C.c_uint32]),
+        "orc_mt_next": (C.c_uint32, [C.c_void_p]),
+        "orc_uniform_m1_p1": (d, [C.c_void_p]),
+        "orc_fmft_create": (C.c_void_p, [i, p, d, d, d, C.c_uint32]),
+        "orc_fmft_destroy": (None, [C.c_void_p]),
+        "orc_fmft_evolve": (None, [C.c_void_p, d]),
+        "orc_fmft_phases": (None, [C.c_void_p, i, i, i, i, p]),
+        "orc_fmft_inverse": (None, [C.c_void_p, G, p, p, p, p]),
+        "orc_turb_history": (None, [G, i, d, p, p]),
+        "orc_turb_perturb": (None, [i, G, C.POINTER(p), C.POINTER(p), d, d, d]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -233,6 +247,13 @@ class Sim:
             self.lib.orc_pgen_orszag_tang(self.h)
         elif name == "synthetic":
             self.lib.orc_pgen_synthetic(self.h)
+        elif name == "turbulence":
+            kv = np.ascontiguousarray(kw["k_vec"], dtype=np.float64)  # [3][M]
+            self._turb_modes = kv.shape[1]
+            self.lib.orc_pgen_turbulence(self.h, kw.get("rho0", 1.0), kw.get("p0", 1.0), kw.get("b0", 0.01),
+                                         kw.get("b_config", 0), kv.shape[1], dp(kv), kw.get("kpeak", 2.0),
+                                         kw.get("sol_weight", 1.0), kw.get("corr_time", 1.0),
+                                         kw.get("accel_rms", 0.5), kw.get("rseed", 20190729))
         else:
             raise ValueError(name)
         self.lib.orc_sim_initialize(self.h)
@@ -254,6 +275,18 @@ class Sim:
         self.lib.orc_sim_history(self.h, dp(out))
         return out
 
+    def turb_history(self):
+        """volume sums of sonic Mach, Alfvenic Mach, plasma beta (TurbulenceHst)"""
+        out = np.zeros(3)
+        self.lib.orc_sim_turb_history(self.h, dp(out))
+        return out
+
+    def var_hat(self):
+        return np.ctypeslib.as_array(self.lib.orc_sim_var_hat(self.h), shape=(3, self._turb_modes, 2)).copy()
+
+    def acc(self, b):
+        return np.ctypeslib.as_array(self.lib.orc_sim_acc(self.h, b), shape=(3,) + self.geom.shape[1:])
+
     def linear_wave_errors(self):
         l1, mx = np.zeros(5), np.zeros(5)
         rms = self.lib.orc_linear_wave_errors(self.h, *self._lw, dp(l1), dp(mx))
@@ -263,3 +296,47 @@ class Sim:
         out = np.zeros((self.geom.nvar, self.nx[2], self.nx[1], self.nx[0]))
         self.lib.orc_sim_gather_cons(self.h, dp(out))
         return out
+
+
+class MT19937(C.Structure):
+    """std::mt19937 restated (turbulence.c)"""
+    _fields_ = [("mt", C.c_uint32 * 624), ("idx", C.c_int)]
+
+
+class _FmftStruct(C.Structure):
+    _fields_ = [("num_modes", C.c_int), ("k_peak", C.c_double), ("sol_weight", C.c_double), ("t_corr", C.c_double),
+                ("k_vec", C.POINTER(C.c_double)), ("var_hat", C.POINTER(C.c_double)),
+                ("var_hat_new", C.POINTER(C.c_double)), ("rng", MT19937)]
+
+
+class Fmft:
+    """FewModesFT spectral state (orc_fmft)"""
+
+    def __init__(self, lib, k_vec, k_peak=2.0, sol_weight=1.0, t_corr=1.0, rseed=20190729):
+        self.lib = lib
+        kv = np.ascontiguousarray(k_vec, dtype=np.float64)
+        self.M = kv.shape[1]
+        self.h = lib.orc_fmft_create(self.M, dp(kv), k_peak, sol_weight, t_corr, rseed)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_fmft_destroy(self.h)
+            self.h = None
+
+    def evolve(self, dt):
+        self.lib.orc_fmft_evolve(self.h, dt)
+
+    def var_hat(self):
+        st = C.cast(self.h, C.POINTER(_FmftStruct)).contents
+        return np.ctypeslib.as_array(st.var_hat, shape=(3, self.M, 2)).copy()
+
+    def phases(self, axis, n, g0, gn):
+        out = np.zeros((n, self.M, 2))
+        self.lib.orc_fmft_phases(self.h, axis, n, g0, gn, dp(out))
+        return out
+
+    def inverse(self, geom, ph_i, ph_j, ph_k):
+        acc = np.zeros((3,) + geom.shape[1:])
+        self.lib.orc_fmft_inverse(self.h, C.byref(geom), dp(np.ascontiguousarray(ph_i)),
+                                  dp(np.ascontiguousarray(ph_j)), dp(np.ascontiguousarray(ph_k)), dp(acc))
+        return acc

@@ -26,6 +26,10 @@ struct orc_sim {
   double time, dt, c_h, mindx, dt_hyp;
   int ncycle;
   long fofc_total;
+  /* turbulence driver (NULL unless orc_pgen_turbulence was called) */
+  orc_fmft *fmft;
+  double accel_rms;
+  double **acc, **ph_i, **ph_j, **ph_k;
   /* linear wave state (src/pgen/linear_wave.cpp globals) */
   double lw_sin_a2, lw_cos_a2, lw_sin_a3, lw_cos_a3, lw_kpar, lw_lambda;
   double lw_d0, lw_p0, lw_u0, lw_gam, lw_gm1, lw_ev[5], lw_rem[5][5];
@@ -93,6 +97,19 @@ orc_sim *orc_sim_create(const orc_sim_params *p) {
 
 void orc_sim_destroy(orc_sim *s) {
   if (!s) return;
+  if (s->fmft) {
+    for (int b = 0; b < s->nblocks; ++b) {
+      free(s->acc[b]);
+      free(s->ph_i[b]);
+      free(s->ph_j[b]);
+      free(s->ph_k[b]);
+    }
+    free(s->acc);
+    free(s->ph_i);
+    free(s->ph_j);
+    free(s->ph_k);
+    orc_fmft_destroy(s->fmft);
+  }
   for (int b = 0; b < s->nblocks; ++b) {
     free(s->cons[b]);
     free(s->prim[b]);
@@ -333,6 +350,16 @@ double orc_sim_step(orc_sim *s, double tlim) {
       }
     }
     s->fofc_total += fofc;
+    if (stage == nstages && s->fmft) {
+      /* AddSplitSourcesFirstOrder -> turbulence::Driving(md, tm, tm.dt) (hydro_driver.cpp:559-560,
+       * src/pgen/turbulence.cpp:476-482): Generate then Perturb */
+      orc_fmft_evolve(s->fmft, dt);
+      for (int b = 0; b < s->nblocks; ++b)
+        orc_fmft_inverse(s->fmft, &s->g, s->ph_i[b], s->ph_j[b], s->ph_k[b], s->acc[b]);
+      const double box = (s->p.xmax[0] - s->p.xmin[0]) * (s->p.xmax[1] - s->p.xmin[1]) *
+                         (s->p.xmax[2] - s->p.xmin[2]);
+      orc_turb_perturb(s->nblocks, &s->g, s->cons, s->acc, dt, s->accel_rms, box);
+    }
     orc_sim_exchange_ghosts(s);
     orc_sim_fill_derived(s);
     if (stage == nstages) {
@@ -618,3 +645,88 @@ void orc_pgen_synthetic(orc_sim *s) {
         }
   }
 }
+
+
+/* src/pgen/turbulence.cpp:217-370 (uniform / no-net-flux / sin(z) field, b_config 0/1/2) */
+void orc_pgen_turbulence(orc_sim *s, double rho0, double p0, double b0, int b_config, int num_modes,
+                         const double *k_vec, double k_peak, double sol_weight, double t_corr,
+                         double accel_rms, uint32_t rseed) {
+  const sb_t bb = sim_bounds(&s->g);
+  const int mhd = (s->p.fluid == ORC_FLUID_GLMMHD);
+  const double gm1 = s->p.eos.gamma - 1.0;
+  const double x3min = s->p.xmin[2];
+  const double Lx = s->p.xmax[0] - s->p.xmin[0], Ly = s->p.xmax[1] - s->p.xmin[1],
+               Lz = s->p.xmax[2] - s->p.xmin[2];
+  const double kz = 2.0 * M_PI / Lz;
+  const double vol = s->g.dx[0] * s->g.dx[1] * s->g.dx[2];
+  double b_norm = 0.0;
+  if (mhd) {
+    double mag_en_sum = 0.0;
+    for (int b = 0; b < s->nblocks; ++b) {
+      double x0[3];
+      orc_sim_block_origin(s, b, x0);
+      double *u = s->cons[b];
+      for (int k = bb.ks; k <= bb.ke; ++k)
+        for (int j = bb.js; j <= bb.je; ++j)
+          for (int i = bb.is; i <= bb.ie; ++i) {
+            double b1 = 0.0;
+            if (b_config == 0) b1 = b0;
+            if (b_config == 1) b1 = (xc(s, x0, 2, k) < x3min + Lz / 2.0) ? b0 : -b0;
+            if (b_config == 2) b1 = b0 / sqrt(0.5) * sin(kz * xc(s, x0, 2, k));
+            /* the vector-potential terms vanish for these configurations (a == 0) */
+            SAT(u, ORC_IB1, k, j, i) = b1;
+            SAT(u, ORC_IB2, k, j, i) = 0.0;
+            SAT(u, ORC_IB3, k, j, i) = 0.0;
+            mag_en_sum += 0.5 * (b1 * b1 + 0.0 + 0.0) * vol;
+          }
+    }
+    b_norm = sqrt(mag_en_sum / (Lx * Ly * Lz) / (0.5 * b0 * b0));
+  }
+  for (int b = 0; b < s->nblocks; ++b) {
+    double *u = s->cons[b];
+    for (int k = bb.ks; k <= bb.ke; ++k)
+      for (int j = bb.js; j <= bb.je; ++j)
+        for (int i = bb.is; i <= bb.ie; ++i) {
+          SAT(u, ORC_IDN, k, j, i) = rho0;
+          SAT(u, ORC_IM1, k, j, i) = rho0 * 0.0;
+          SAT(u, ORC_IM2, k, j, i) = rho0 * 0.0;
+          SAT(u, ORC_IM3, k, j, i) = rho0 * 0.0;
+          SAT(u, ORC_IEN, k, j, i) = p0 / gm1 + 0.5 * rho0 * (0.0 + 0.0 + 0.0);
+          if (mhd) {
+            SAT(u, ORC_IB1, k, j, i) /= b_norm;
+            SAT(u, ORC_IB2, k, j, i) /= b_norm;
+            SAT(u, ORC_IB3, k, j, i) /= b_norm;
+            const double b1 = SAT(u, ORC_IB1, k, j, i), b2 = SAT(u, ORC_IB2, k, j, i),
+                         b3 = SAT(u, ORC_IB3, k, j, i);
+            SAT(u, ORC_IEN, k, j, i) += 0.5 * (b1 * b1 + b2 * b2 + b3 * b3);
+          }
+        }
+  }
+  /* enrol the driver: FewModesFT + per-block phase tables (SetPhases) + acc field */
+  s->fmft = orc_fmft_create(num_modes, k_vec, k_peak, sol_weight, t_corr, rseed);
+  s->accel_rms = accel_rms;
+  s->acc = (double **)calloc(s->nblocks, sizeof(double *));
+  s->ph_i = (double **)calloc(s->nblocks, sizeof(double *));
+  s->ph_j = (double **)calloc(s->nblocks, sizeof(double *));
+  s->ph_k = (double **)calloc(s->nblocks, sizeof(double *));
+  for (int b = 0; b < s->nblocks; ++b) {
+    int bc[3];
+    block_coords(s, b, bc);
+    s->acc[b] = (double *)calloc((size_t)3 * bb.sn, sizeof(double));
+    s->ph_i[b] = (double *)malloc(sizeof(double) * s->g.nx[0] * num_modes * 2);
+    s->ph_j[b] = (double *)malloc(sizeof(double) * s->g.nx[1] * num_modes * 2);
+    s->ph_k[b] = (double *)malloc(sizeof(double) * s->g.nx[2] * num_modes * 2);
+    orc_fmft_phases(s->fmft, 0, s->g.nx[0], bc[0] * s->p.mb[0], s->p.nx[0], s->ph_i[b]);
+    orc_fmft_phases(s->fmft, 1, s->g.nx[1], bc[1] * s->p.mb[1], s->p.nx[1], s->ph_j[b]);
+    orc_fmft_phases(s->fmft, 2, s->g.nx[2], bc[2] * s->p.mb[2], s->p.nx[2], s->ph_k[b]);
+  }
+}
+
+void orc_sim_turb_history(orc_sim *s, double *out3) {
+  out3[0] = out3[1] = out3[2] = 0.0;
+  for (int b = 0; b < s->nblocks; ++b)
+    orc_turb_history(&s->g, s->p.fluid, s->p.eos.gamma, s->prim[b], out3);
+}
+
+const double *orc_sim_var_hat(const orc_sim *s) { return s->fmft ? s->fmft->var_hat : NULL; }
+double *orc_sim_acc(orc_sim *s, int b) { return s->fmft ? s->acc[b] : NULL; }

@@ -171,6 +171,27 @@ def orc_history(fluid, g, cons):
     return tot
 
 
+def orc_turb_perturb(g, cons, acc, dt, accel_rms, box_volume):
+    """in-place on copies; returns (cons, acc)"""
+    lib = O.load()
+    nb = cons.shape[0]
+    u = [np.ascontiguousarray(cons[b]).copy() for b in range(nb)]
+    a = [np.ascontiguousarray(acc[b]).copy() for b in range(nb)]
+    P = C.POINTER(C.c_double)
+    up = (P * nb)(*[O.dp(x) for x in u])
+    ap = (P * nb)(*[O.dp(x) for x in a])
+    lib.orc_turb_perturb(nb, C.byref(g), up, ap, dt, accel_rms, box_volume)
+    return np.stack(u), np.stack(a)
+
+
+def orc_turb_history(fluid, g, prim, gamma):
+    lib = O.load()
+    out = np.zeros(3)
+    for b in range(prim.shape[0]):
+        lib.orc_turb_history(C.byref(g), O.FLUID[fluid], gamma, O.dp(np.ascontiguousarray(prim[b])), O.dp(out))
+    return out
+
+
 def orc_fofc(fluid, g, u0c, u0p, u1c, fl, gamma, c_h, gam0, gam1, beta_dt):
     lib = O.load()
     eos = O.make_eos(gamma)

@@ -210,3 +210,60 @@ def test_synthetic_mhd_256_cubed_conserves_and_matches_flux_array_path():
     assert np.array_equal(ub, c.gather())
     # ... and the FMA build stays within the stated tolerance of it
     assert np.max(np.abs(ua - ub)) <= 1e-12 * np.max(np.abs(ub))
+
+
+# ---- config 4 forcing: few-modes turbulence driver ---------------------------------------------------
+def _turb_k_vec():
+    from athenapk_amd import decks
+    kv, block = {}, None
+    for line in decks.load("turbulence").splitlines():
+        line = line.split("#")[0].strip()
+        if line.startswith("<"):
+            block = line.strip("<>")
+        elif "=" in line and block == "modes":
+            k, v = [x.strip() for x in line.split("=")]
+            kv[k] = int(v)
+    n = len(kv) // 3
+    return np.array([[kv["k_%d_%d" % (m + 1, d)] for m in range(n)] for d in range(3)], dtype=np.float64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("b_config", [0, 2])
+def test_turbulence_driver_matches_oracle(oracle, strict, b_config):
+    """32^3 in 8 meshblocks, 12 driven cycles.  The spectral state is bit-identical (same host RNG);
+    the fields agree to round-off (the Perturb sums are reduced in a different order)."""
+    ov = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=32", "parthenon/meshblock/nx1=16",
+          "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=16", "problem/turbulence/b_config=%d" % b_config]
+    s = _sim("turbulence", ov, strict=strict).initialize()
+    o = oracle.Sim(fluid="glmmhd", recon="plm", riemann="hlle", integrator="vl2", nx=(32, 32, 32), mb=(16, 16, 16),
+                   ng=2, cfl=0.3, gamma=1.0001, nthreads=os.cpu_count())
+    o.pgen("turbulence", k_vec=_turb_k_vec(), b_config=b_config)
+    np.testing.assert_allclose(s.gather("cons"), o.gather_cons(), rtol=1e-14, atol=0)
+    for _ in range(12):
+        s.step()
+        o.step()
+    assert np.array_equal(s.fmft_var_hat(), o.var_hat())
+    assert abs(s.time - o.time) <= 1e-13 * o.time
+    np.testing.assert_allclose(s.gather("cons"), o.gather_cons(), rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(s.turbulence_history(), o.turb_history(), rtol=1e-10)
+    np.testing.assert_allclose(s.history(), o.history(), rtol=1e-11, atol=1e-14)
+
+
+@pytest.mark.gpu
+def test_turbulence_reference_regression_windows():
+    """The reference's turbulence regression test (tst/regression/test_suites/turbulence/
+    turbulence.py:44-52): 64^3 PLM + HLLE VL2 GLM-MHD driven to t = 5 must end with a sonic Mach
+    number in (0.45, 0.50) and an Alfvenic Mach number in (12.8, 13.6).  Also compared with the
+    oracle's run of the same deck (tests/golden/turbulence_pin.json)."""
+    import json
+    pin = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "turbulence_pin.json")))
+    s = _sim("turbulence", [], strict=False).initialize()
+    n = s.run()
+    ms, ma, pb = s.turbulence_history()  # unit box: volume sums are the means
+    assert 0.45 < ms < 0.50
+    assert 12.8 < ma < 13.6
+    assert n == pin["cycles"]
+    assert abs(ms - pin["Ms"]) < 1e-6 * pin["Ms"] and abs(ma - pin["Ma"]) < 1e-6 * pin["Ma"]
+    h = s.history()
+    assert abs(h[0] - 1.0) < 1e-12 and np.abs(h[1:4]).max() < 1e-12

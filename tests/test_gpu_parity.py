@@ -367,3 +367,66 @@ def test_fused_fill_derived_rejected_where_unsafe(request):
         hydro.StageFused(m0, m0, "glmmhd", "ppm", "hlld", L.make_eos(GAMMA), C_H, 0.0, 1.0, 1e-3, dedner=1,
                          mindx=0.1, fill_derived=True)
     assert e.value.code == L.APK_ERR_UNSUPPORTED
+
+
+# ---- few-modes turbulence driver kernels ------------------------------------------------------------
+def _turb_case(oracle, nblocks_axis=2, n=16, ng=2):
+    """an n^3 box split in nblocks_axis^3 blocks; returns geometry, spectral state, phases per block"""
+    rng = np.random.default_rng(5)
+    kv = np.array([[1, 0, 0, 1, 2, 0, -1, 2], [0, 1, 0, 1, -1, 2, 1, 2], [0, 0, 1, -1, 0, 1, 2, 2]], dtype=np.float64)
+    f = oracle.Fmft(oracle.load(), kv, k_peak=2.0, sol_weight=0.7, t_corr=0.5, rseed=7)
+    f.evolve(0.1)
+    f.evolve(0.1)
+    mb = n // nblocks_axis
+    g = H.geom("glmmhd", (mb, mb, mb), ng, 0, (1.0 / n,) * 3)
+    phases = []
+    for bk in range(nblocks_axis):
+        for bj in range(nblocks_axis):
+            for bi in range(nblocks_axis):
+                phases.append((f.phases(0, mb, bi * mb, n), f.phases(1, mb, bj * mb, n), f.phases(2, mb, bk * mb, n)))
+    return f, g, mb, phases
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+def test_fmft_inverse(request, oracle, strict):
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    f, g, mb, phases = _turb_case(oracle)
+    nb = len(phases)
+    md = hydro.MeshData(ctx, (mb, mb, mb), 2, 9, dx=tuple(g.dx), nblocks=nb, with_flux=False)
+    drv = hydro.FewModesFT(md, phases)
+    drv.Inverse(f.var_hat())
+    got = drv.acc_host()
+    want = np.stack([f.inverse(g, *phases[b]) for b in range(nb)])
+    _cmp(got, want, strict, "acc")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+def test_turbulence_perturb_and_history(request, oracle, strict):
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    f, g, mb, phases = _turb_case(oracle)
+    nb = len(phases)
+    nx = (mb, mb, mb)
+    prim = H.random_prim("glmmhd", nx, 2, seed=21, kind="smooth", nblocks=nb)
+    cons = H.prim_to_cons("glmmhd", prim, GAMMA)
+    md = hydro.MeshData(ctx, nx, 2, 9, dx=tuple(g.dx), nblocks=nb, cons=cons, prim=prim, with_flux=False)
+    drv = hydro.FewModesFT(md, phases)
+    drv.Inverse(f.var_hat())
+    acc0 = drv.acc_host()
+    drv.Perturb(0.01, 0.5, 1.0)
+    want_u, want_a = H.orc_turb_perturb(g, cons, acc0, 0.01, 0.5, 1.0)
+    # the two global sums are accumulated in a different order than the oracle's serial loop
+    np.testing.assert_allclose(drv.acc_host(), want_a, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(md.cons_host(), want_u, rtol=1e-12, atol=1e-14)
+    # ghost zones untouched
+    assert np.array_equal(md.cons_host()[:, :, 0], cons[:, :, 0])
+    # RMS of the normalised field is accel_rms, mass-weighted mean is zero
+    a = drv.acc_host()[:, :, 2:-2, 2:-2, 2:-2]
+    assert abs(np.sqrt((a ** 2).sum(axis=1).mean()) - 0.5) < 1e-12
+    for fluid in ("glmmhd", "euler"):
+        got = hydro.TurbulenceHst(md, fluid, GAMMA)
+        want = H.orc_turb_history(fluid, g, prim, GAMMA)
+        np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-15)

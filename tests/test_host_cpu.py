@@ -218,3 +218,49 @@ def test_reflecting_boundary_plan(oracle):
     got, _ = _run_plans("sod", ov, 2, lambda gid, loc, shape: start[gid].copy(), 5)
     for gid, arr in got.items():
         assert np.array_equal(arr, o.cons(gid))
+
+
+# ---- few-modes turbulence driver: host spectral state (FewModesFT) ---------------------------------------
+def _deck_k_vec(p):
+    from athenapk_amd import decks
+    kv, block = {}, None
+    for line in decks.load("turbulence").splitlines():
+        line = line.split("#")[0].strip()
+        if line.startswith("<"):
+            block = line.strip("<>")
+        elif "=" in line and block == "modes":
+            k, v = [x.strip() for x in line.split("=")]
+            kv[k] = int(v)
+    n = len(kv) // 3
+    return np.array([[kv["k_%d_%d" % (m + 1, d)] for m in range(n)] for d in range(3)], dtype=np.float64)
+
+
+def test_turbulence_host_state_matches_oracle_bitwise(oracle):
+    """std::mt19937 + std::uniform_real_distribution in the product vs the oracle's restatement
+    of both: identical spectral coefficients over 50 OU steps, identical phase tables."""
+    p = _plan("turbulence")
+    assert p.fmft_num_modes() == 30
+    kv = _deck_k_vec(p)
+    f = oracle.Fmft(oracle.load(), kv, k_peak=2.0, sol_weight=1.0, t_corr=1.0, rseed=20190729)
+    assert np.all(p.fmft_var_hat() == 0.0)
+    for n in range(50):
+        dt = 0.002 + 1e-4 * n
+        p.fmft_evolve(dt)
+        f.evolve(dt)
+        assert np.array_equal(p.fmft_var_hat(), f.var_hat())
+    for ax, (n, g0) in enumerate(((64, 0), (32, 32), (32, 0))):
+        assert np.array_equal(p.fmft_phases(ax, n, g0), f.phases(ax, n, g0, 64))
+
+
+@pytest.mark.parametrize("overrides,msg", [
+    (["modes/k_3_0=40"], "k_vec x1 mode too large"),                              # few_modes_ft.cpp:49-53
+    (["problem/turbulence/sol_weight=1.5"], "sol_weight for projection"),       # few_modes_ft.cpp:83-86
+    (["parthenon/mesh/pack_size=4"], "pack_size=-1"),                            # few_modes_ft.cpp:113-116
+    (["parthenon/mesh/x1max=2.0"], "cubic meshes"),                              # few_modes_ft.cpp:132-135
+    (["problem/turbulence/b_config=3"], "Random B fields not implemented yet"),  # turbulence.cpp:264
+])
+def test_turbulence_deck_errors(overrides, msg):
+    from athenapk_amd import lib as L
+    with pytest.raises(L.ApkError) as e:
+        _plan("turbulence", overrides)
+    assert e.value.code == L.APK_ERR_INVALID and msg in str(e.value)

@@ -285,3 +285,132 @@ def test_orszag_tang_totals_conserved(oracle):
     assert abs(h1[1]) < 1e-13 and abs(h1[2]) < 1e-13  # momenta stay zero
     assert h1[5] == pytest.approx(h0[5], rel=1e-12)   # total energy (dedner_plain is conservative)
     assert s.c_h > 0
+
+
+# ---- few-modes turbulence driver ------------------------------------------------------------------------
+def _deck_modes():
+    import os
+    kv = {}
+    block = None
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for line in open(os.path.join(root, "inputs", "turbulence.in")):
+        line = line.split("#")[0].strip()
+        if line.startswith("<"):
+            block = line.strip("<>")
+        elif "=" in line and block == "modes":
+            k, v = [x.strip() for x in line.split("=")]
+            kv[k] = int(v)
+    n = len(kv) // 3
+    return np.array([[kv["k_%d_%d" % (m + 1, d)] for m in range(n)] for d in range(3)], dtype=np.float64)
+
+
+def test_mt19937_known_answer(oracle):
+    """ISO C++ [rand.predef]: the 10000th consecutive invocation of a default-constructed
+    std::mt19937 (seed 5489) produces 4123659995."""
+    from oracle import oracle as O
+    g = O.MT19937()
+    lib = oracle.load()
+    oracle.load().orc_mt_seed(C.byref(g), 5489)
+    v = 0
+    for _ in range(10000):
+        v = lib.orc_mt_next(C.byref(g))
+    assert v == 4123659995
+
+
+def test_uniform_real_matches_libstdcxx(oracle, tmp_path):
+    """The reference draws with std::uniform_real_distribution<>(-1,1)(std::mt19937)
+    (few_modes_ft.cpp:205-219); compare the restatement with the C++ standard library here."""
+    import subprocess
+    from oracle import oracle as O
+    src = tmp_path / "draw.cpp"
+    src.write_text('#include <cstdio>\n#include <random>\nint main(){std::mt19937 r;r.seed(20190729u);'
+                   'std::uniform_real_distribution<> d(-1.0,1.0);for(int i=0;i<2000;++i)std::printf("%a\\n",d(r));}\n')
+    exe = tmp_path / "draw"
+    subprocess.check_call(["g++", "-O1", "-o", str(exe), str(src)])
+    want = [float.fromhex(x) for x in subprocess.check_output([str(exe)]).decode().split()]
+    g = O.MT19937()
+    lib = oracle.load()
+    oracle.load().orc_mt_seed(C.byref(g), 20190729)
+    got = [lib.orc_uniform_m1_p1(C.byref(g)) for _ in range(2000)]
+    assert got == want
+
+
+def test_fmft_spectrum_properties(oracle):
+    from oracle import oracle as O
+    kv = _deck_modes()
+    f = O.Fmft(oracle.load(), kv, k_peak=2.0, sol_weight=1.0, t_corr=1.0)
+    assert np.all(f.var_hat() == 0.0)
+    f.evolve(0.01)
+    vh = f.var_hat()
+    a = vh[..., 0] + 1j * vh[..., 1]
+    # purely solenoidal forcing: k . a_hat(k) = 0 for every mode
+    kmag = np.sqrt((kv ** 2).sum(0))
+    assert np.abs((kv / kmag * a).sum(0)).max() < 1e-14 * np.abs(a).max()
+    # OU: after one step from zero the state is sqrt(1 - exp(-2 dt / t_corr)) times the new draw,
+    # a second step keeps exp(-dt / t_corr) of it
+    g = O.Fmft(oracle.load(), kv, k_peak=2.0, sol_weight=1.0, t_corr=1.0)
+    g.evolve(1e9)   # c_drift = 0: pure new realisation
+    assert np.isfinite(g.var_hat()).all() and np.abs(g.var_hat()).max() > 0
+    # the parabolic spectrum vanishes for |k| >= sqrt(2) k_peak
+    h = O.Fmft(oracle.load(), np.array([[4.0, 1.0], [0.0, 1.0], [0.0, 1.0]]), k_peak=2.0, sol_weight=-1.0)
+    h.evolve(1.0)
+    assert np.all(h.var_hat()[:, 0] == 0.0) and np.abs(h.var_hat()[:, 1]).max() > 0
+
+
+def test_fmft_inverse_is_a_real_field_of_the_listed_modes(oracle):
+    """acc(x) = sum_m 2 Re(a_hat_m e^{i k_m x}) with the k_x = 0 modes halved: check against a
+    direct numpy evaluation, and that phases of split blocks tile the full-domain table."""
+    from oracle import oracle as O
+    kv = _deck_modes()
+    n = 8
+    f = O.Fmft(oracle.load(), kv)
+    f.evolve(0.05)
+    ph = [f.phases(ax, n, 0, n) for ax in range(3)]
+    for ax in range(3):
+        assert np.array_equal(f.phases(ax, n // 2, n // 2, n), ph[ax][n // 2:])
+    g = O.make_geom((n, n, n), 2, 9, dx=(1.0 / n,) * 3)
+    acc = f.inverse(g, *ph)[:, 2:-2, 2:-2, 2:-2]
+    vh = f.var_hat()
+    a = vh[..., 0] + 1j * vh[..., 1]
+    idx = np.arange(n)
+    K, J, I = np.meshgrid(idx, idx, idx, indexing="ij")
+    want = np.zeros((3, n, n, n))
+    for m in range(kv.shape[1]):
+        e = np.exp(2j * np.pi * (kv[0, m] * I + kv[1, m] * J + kv[2, m] * K) / n)
+        w = 0.5 if kv[0, m] == 0 else 1.0
+        for c in range(3):
+            want[c] += 2.0 * w * (a[c, m] * e).real
+    assert np.abs(acc - want).max() < 1e-12 * np.abs(want).max()
+
+
+def test_turbulence_driver_small_run(oracle):
+    """16^3 driven MHD box: the forcing has zero net momentum input and the requested RMS, the
+    decomposition (1 vs 8 blocks) only changes summation order."""
+    from oracle import oracle as O
+    kv = _deck_modes()
+    res = []
+    for mb in ((16, 16, 16), (8, 8, 8)):
+        s = O.Sim(fluid="glmmhd", recon="plm", riemann="hlle", integrator="vl2", nx=(16, 16, 16), mb=mb, ng=2,
+                  cfl=0.3, gamma=1.0001)
+        s.pgen("turbulence", k_vec=kv)
+        for _ in range(5):
+            s.step()
+        accs = np.stack([s.acc(b)[:, 2:-2, 2:-2, 2:-2] for b in range(s.nblocks)])
+        rms = np.sqrt((accs ** 2).sum(axis=1).mean())
+        assert abs(rms - 0.5) < 1e-12
+        h = s.history()
+        assert np.abs(h[1:4]).max() < 1e-15      # total momentum stays zero
+        res.append((s.gather_cons(), s.var_hat(), s.time))
+    assert np.array_equal(res[0][1], res[1][1])
+    # E ~ p0 / (gamma - 1) = 1e4: compare relative to each variable's scale
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-12, atol=1e-13)
+
+
+def test_turbulence_pin_is_inside_the_reference_windows():
+    """tests/golden/turbulence_pin.json is the oracle run of the reference's turbulence regression
+    case (tst/regression/test_suites/turbulence/turbulence.py:44-52)."""
+    import json
+    import os
+    pin = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "turbulence_pin.json")))
+    assert 0.45 < pin["Ms"] < 0.50
+    assert 12.8 < pin["Ma"] < 13.6
