@@ -43,9 +43,9 @@ class FewModesFT {
   std::uniform_real_distribution<> &dist() { return dist_; }
 
   // phase table of one axis for n interior cells starting at global index g0 on a gn-cell axis:
-  // out[idx][m] = exp(i * 2 pi k_axis(m) / gn * ((idx + g0) mod gn)), the k_x = 0 modes halved
-  // along x1 (the complex-to-real transform counts them twice)
-  void Phases(int axis, int n, int g0, int gn, double *out /*[n][M][2]*/) const {
+  // out(re|im, m, idx) = exp(i * 2 pi k_axis(m) / gn * ((idx + g0) mod gn)), the k_x = 0 modes
+  // halved along x1 (the complex-to-real transform counts them twice)
+  void Phases(int axis, int n, int g0, int gn, double *out /*[2][M][n]*/) const {
     for (int idx = 0; idx < n; ++idx) {
       const double g = static_cast<double>((idx + g0) % gn);
       for (int m = 0; m < M_; ++m) {
@@ -56,8 +56,8 @@ class FewModesFT {
           re = 0.5 * re;
           im = 0.5 * im;
         }
-        out[((size_t)idx * M_ + m) * 2 + 0] = re;
-        out[((size_t)idx * M_ + m) * 2 + 1] = im;
+        out[((size_t)0 * M_ + m) * n + idx] = re;
+        out[((size_t)1 * M_ + m) * n + idx] = im;
       }
     }
   }

@@ -33,14 +33,17 @@ fmft_inverse_kernel(PackView pv, const apk_fmft_block *blocks, const double *var
   int b, k, j, i;
   if (!interior_of(pv, b, k, j, i)) return;
   const apk_fmft_block blk = blocks[b];
-  const double *pi = blk.phases_i + (int64_t)(i - pv.is) * M * 2;
-  const double *pj = blk.phases_j + (int64_t)(j - pv.js) * M * 2;
-  const double *pk = blk.phases_k + (int64_t)(k - pv.ks) * M * 2;
+  // phases(c, m, idx), idx fastest (the reference's variable shape {2, num_modes, nx}):
+  // phases_i is a coalesced row per (c, m); phases_j / phases_k are wave-uniform
+  const double *pi = blk.phases_i + (i - pv.is);
+  const double *pj = blk.phases_j + (j - pv.js);
+  const double *pk = blk.phases_k + (k - pv.ks);
+  const int64_t n1 = pv.nx1, n2 = pv.nx2, n3 = pv.nx3;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   for (int m = 0; m < M; ++m) {
-    const double ir = pi[2 * m], ii = pi[2 * m + 1];
-    const double jr = pj[2 * m], ji = pj[2 * m + 1];
-    const double kr = pk[2 * m], ki = pk[2 * m + 1];
+    const double ir = pi[m * n1], ii = pi[(M + m) * n1];
+    const double jr = pj[m * n2], ji = pj[(M + m) * n2];
+    const double kr = pk[m * n3], ki = pk[(M + m) * n3];
     // phase = phase_i * phase_j * phase_k (complex products, left to right)
     const double pr = ir * jr - ii * ji, pim = ir * ji + ii * jr;
     const double qr = pr * kr - pim * ki, qi = pr * ki + pim * kr;

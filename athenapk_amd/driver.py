@@ -25,17 +25,28 @@ class HaloExchanger:
         import torch.distributed as dist
         if not self.peers:
             return
-        ops = []
+        # gloo has no device send/recv: development runs that put several ranks on one GPU
+        # (tests, `APK_DIST_BACKEND=gloo bench.py`) bounce the messages through host memory
+        staged = self.peers[0][1].is_cuda and dist.get_backend(self.group) == "gloo"
+        ops, back = [], []
         for rank, send_t, recv_t in self.peers:
+            if staged:
+                host_recv = torch.empty(recv_t.shape, dtype=recv_t.dtype)
+                back.append((recv_t, host_recv))
+                send_t, recv_t = send_t.cpu(), host_recv
             ops.append(dist.P2POp(dist.irecv, recv_t, rank, group=self.group))
             ops.append(dist.P2POp(dist.isend, send_t, rank, group=self.group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        for dev_t, host_t in back:
+            dev_t.copy_(host_t)
 
 
 def _allreduce(vals_ptr, n, op, device, group=None):
     import torch.distributed as dist
     a = np.ctypeslib.as_array(vals_ptr, shape=(n,))
+    if dist.get_backend(group) == "gloo":
+        device = "cpu"
     t = torch.from_numpy(a.copy()).to(device)
     dist.all_reduce(t, op=op, group=group)
     a[:] = t.cpu().numpy()
@@ -61,7 +72,7 @@ class _FmftHost:
             raise L.ApkError(rc, "no turbulence driver in this sim")
 
     def fmft_phases(self, axis, n, g0):
-        out = np.zeros((n, self.fmft_num_modes(), 2))
+        out = np.zeros((2, self.fmft_num_modes(), n))
         rc = self.lib.apk_sim_fmft_phases(self.h, axis, n, g0, out.ctypes.data_as(L.c_dp))
         if rc != L.APK_OK:
             raise L.ApkError(rc, "no turbulence driver in this sim")

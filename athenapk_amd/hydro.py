@@ -214,13 +214,14 @@ class FewModesFT:
     """Device side of FewModesFT / turbulence::Perturb for one MeshData: the acceleration field
     "acc" and the per-block phase tables (src/utils/few_modes_ft.cpp:142-195,
     src/pgen/turbulence.cpp:119-127).  `phases[b]` is (phases_i, phases_j, phases_k), each
-    [n][num_modes][2]."""
+    [2][num_modes][n] (re|im, mode, cell)."""
 
     def __init__(self, md, phases):
         self.md = md
         ctx = md.ctx
         dev = torch.device("cuda")
         self.num_modes = int(np.asarray(phases[0][0]).shape[1])
+        assert np.asarray(phases[0][0]).shape[0] == 2
         self.acc = torch.zeros((md.nblocks, 3) + md.shape[1:], dtype=torch.float64, device=dev)
         self._ph = [[torch.from_numpy(np.ascontiguousarray(p, dtype=np.float64)).to(dev) for p in blk]
                     for blk in phases]

@@ -110,11 +110,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # development aid (one-GPU boxes): APK_SHARE_GPU=1 puts every rank on cuda:0 and
+    # APK_DIST_BACKEND=gloo stages the halo messages through the host; the driver's runs use
+    # neither (one rank per GPU, RCCL)
+    backend = os.environ.get("APK_DIST_BACKEND", "nccl")
+    if os.environ.get("APK_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     deck, fluid, integrator, recon, riemann, brick, mb, desc = WORKLOADS[args.workload]
     if world not in RANK_GRID:
@@ -149,7 +158,7 @@ def main():
     timing = sim.read_kernel_timing()
     sim.kernel_timing(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -197,7 +206,8 @@ def main():
                        "meshblock": [mb, mb, mb], "blocks_per_gpu": int(info.nblocks_local),
                        "integrator": integrator, "nstages": nstages, "nghost": int(info.ng),
                        "path": "flux-array" if args.unfused else "fused",
-                       "parallelism": "domain decomposition, %dx%dx%d GPU grid" % grid},
+                       "parallelism": "domain decomposition, %dx%dx%d GPU grid" % grid,
+                       "comm_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None},
             "cell_stage_updates_per_s": value * nstages,
             "roofline": {
                 "bound": "hbm",

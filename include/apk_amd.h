@@ -225,9 +225,10 @@ int apk_copy_plan_run(apk_ctx *ctx, const apk_copy_plan *plan, apk_stream_t stre
  * its host RNG and the Ornstein-Uhlenbeck update stay on the host, as in the reference. */
 typedef struct apk_fmft_block {
   double *acc;            /* [3][Nk][Nj][Ni] acceleration field ("acc", turbulence.cpp:119-127) */
-  const double *phases_i; /* [nx1][num_modes][2]  (few_modes_ft.cpp:143-160) */
-  const double *phases_j; /* [nx2][num_modes][2] */
-  const double *phases_k; /* [nx3][num_modes][2] */
+  const double *phases_i; /* [2][num_modes][nx1]: (re|im, mode, cell), the shape of the reference's
+                             "<prefix>_phases_i" variable (few_modes_ft.cpp:60-62, 143-160) */
+  const double *phases_j; /* [2][num_modes][nx2] */
+  const double *phases_k; /* [2][num_modes][nx3] */
 } apk_fmft_block;
 typedef struct apk_fmft apk_fmft;
 int apk_fmft_create(apk_ctx *ctx, const apk_fmft_block *blocks /* host array */, int nblocks,

@@ -108,7 +108,7 @@ int apk_sim_history(apk_sim *sim, double *out8);
  * plasma beta (src/pgen/turbulence.cpp:47-101; divide by the box volume for the means).  The
  * fmft_* calls expose the host spectral state (FewModesFT, src/utils/few_modes_ft.cpp) and also
  * work on a host-only sim: var_hat is [3][num_modes][2]; evolve advances the OU process by dt
- * (consuming RNG draws exactly as a driven step does); phases fills [n][num_modes][2] for cells
+ * (consuming RNG draws exactly as a driven step does); phases fills [2][num_modes][n] for cells
  * g0..g0+n-1 of `axis`.  read_acc copies block lb's acceleration field [3][Nk][Nj][Ni]. */
 int apk_sim_turbulence_history(apk_sim *sim, double *out3);
 int apk_sim_fmft_num_modes(const apk_sim *sim);

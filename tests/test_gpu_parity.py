@@ -395,7 +395,7 @@ def test_fmft_inverse(request, oracle, strict):
     f, g, mb, phases = _turb_case(oracle)
     nb = len(phases)
     md = hydro.MeshData(ctx, (mb, mb, mb), 2, 9, dx=tuple(g.dx), nblocks=nb, with_flux=False)
-    drv = hydro.FewModesFT(md, phases)
+    drv = hydro.FewModesFT(md, [[p.transpose(2, 1, 0) for p in blk] for blk in phases])
     drv.Inverse(f.var_hat())
     got = drv.acc_host()
     want = np.stack([f.inverse(g, *phases[b]) for b in range(nb)])
@@ -413,7 +413,7 @@ def test_turbulence_perturb_and_history(request, oracle, strict):
     prim = H.random_prim("glmmhd", nx, 2, seed=21, kind="smooth", nblocks=nb)
     cons = H.prim_to_cons("glmmhd", prim, GAMMA)
     md = hydro.MeshData(ctx, nx, 2, 9, dx=tuple(g.dx), nblocks=nb, cons=cons, prim=prim, with_flux=False)
-    drv = hydro.FewModesFT(md, phases)
+    drv = hydro.FewModesFT(md, [[p.transpose(2, 1, 0) for p in blk] for blk in phases])
     drv.Inverse(f.var_hat())
     acc0 = drv.acc_host()
     drv.Perturb(0.01, 0.5, 1.0)
