@@ -10,6 +10,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 namespace apk {
 
@@ -42,6 +43,16 @@ class ParameterInput {
     const std::string path = Trim(arg.substr(0, eq));
     if (path.find('/') == std::string::npos) throw std::runtime_error("override must be block/key=value: " + arg);
     values_[path] = Trim(arg.substr(eq + 1));
+  }
+  // names of the blocks that start with `prefix` (e.g. "parthenon/output"), in deck order of
+  // their names
+  std::vector<std::string> BlocksWithPrefix(const std::string &prefix) const {
+    std::vector<std::string> out;
+    for (const auto &kv : values_) {
+      const std::string block = kv.first.substr(0, kv.first.rfind('/'));
+      if (block.compare(0, prefix.size(), prefix) == 0 && (out.empty() || out.back() != block)) out.push_back(block);
+    }
+    return out;
   }
   bool DoesParameterExist(const std::string &block, const std::string &key) const {
     return values_.count(block + "/" + key) > 0;

@@ -1116,6 +1116,131 @@ int apk_sim_read_acc(apk_sim *s, int lb, double *host_out) {
   return APK_OK;
 }
 
+int apk_sim_history_labels(const apk_sim *s, char *buf, size_t len) {
+  if (!s || !buf || !len) return APK_ERR_INVALID;
+  std::string l = "mass 1-mom 2-mom 3-mom KE tot-E";
+  const bool mhd = s->pkg.fluid == APK_FLUID_GLMMHD;
+  if (mhd) l += " ME relDivB";
+  if (s->fmft) l += mhd ? " Ms Ma plasma_beta" : " Ms";
+  std::snprintf(buf, len, "%s", l.c_str());
+  return APK_OK;
+}
+
+int apk_sim_write_history(apk_sim *s, const char *path) {
+  if (!s || s->host_only || !path) return APK_ERR_INVALID;
+  const bool mhd = s->pkg.fluid == APK_FLUID_GLMMHD;
+  double h[8], t3[3] = {0, 0, 0};
+  int rc = apk_sim_history(s, h);
+  if (rc != APK_OK) return rc;
+  if (s->fmft && (rc = apk_sim_turbulence_history(s, t3)) != APK_OK) return rc;
+  if (s->rank != 0) return APK_OK;
+  std::vector<double> row(h, h + (mhd ? 8 : 6));
+  if (s->fmft) row.insert(row.end(), t3, t3 + (mhd ? 3 : 1));
+  FILE *f = std::fopen(path, "r");
+  const bool fresh = (f == nullptr);
+  if (f) std::fclose(f);
+  f = std::fopen(path, "a");
+  if (!f) return fail(s, APK_ERR_INVALID, std::string("history file could not be opened: ") + path);
+  if (fresh) {
+    char labels[256];
+    apk_sim_history_labels(s, labels, sizeof(labels));
+    int col = 1;
+    std::fprintf(f, "#  History data\n");
+    std::fprintf(f, "# [%d]=time     ", col++);
+    std::fprintf(f, "[%d]=dt       ", col++);
+    std::fprintf(f, "[%d]=cycle    ", col++);
+    std::fprintf(f, "[%d]=nbtotal  ", col++);
+    std::istringstream iss(labels);
+    std::string lab;
+    while (iss >> lab) std::fprintf(f, "[%d]=%-8s", col++, lab.c_str());
+    std::fprintf(f, "\n");
+  }
+  const std::string fmt = " " + s->pin.GetOrAddString("parthenon/output_defaults", "data_format", "%12.5e");
+  std::fprintf(f, fmt.c_str(), s->time);
+  std::fprintf(f, fmt.c_str(), s->dt);
+  std::fprintf(f, " %d %d", s->ncycle, s->mesh.nblocks_total);
+  for (double v : row) std::fprintf(f, fmt.c_str(), v);
+  std::fprintf(f, "\n");
+  std::fclose(f);
+  return APK_OK;
+}
+
+int apk_sim_write_linear_wave_errors(apk_sim *s, const char *path) {
+  if (!s || !path) return APK_ERR_INVALID;
+  double rms = 0.0, l1[5], mx[5];
+  int rc = apk_sim_linear_wave_errors(s, &rms, l1, mx);
+  if (rc != APK_OK) return rc;
+  if (s->rank != 0) return APK_OK;
+  double max_max_over_l1 = 0.0;
+  for (int n = 0; n < 5; ++n) max_max_over_l1 = std::fmax(max_max_over_l1, mx[n] / l1[n]);
+  FILE *f = std::fopen(path, "r");
+  const bool fresh = (f == nullptr);
+  if (f) std::fclose(f);
+  f = std::fopen(path, "a");
+  if (!f) return fail(s, APK_ERR_INVALID, "Error output file could not be opened");
+  if (fresh) {
+    std::fprintf(f, "# Nx1  Nx2  Nx3  Ncycle  ");
+    std::fprintf(f, "RMS-L1-Error  d_L1  M1_L1  M2_L1  M3_L1  E_L1 ");
+    std::fprintf(f, "  Largest-Max/L1  d_max  M1_max  M2_max  M3_max  E_max ");
+    std::fprintf(f, "\n");
+  }
+  // column 3 repeats Nx2: that is what linear_wave.cpp:323-324 prints
+  std::fprintf(f, "%d  %d", s->mesh.nx[0], s->mesh.nx[1]);
+  std::fprintf(f, "  %d  %d", s->mesh.nx[1], s->ncycle);
+  std::fprintf(f, "  %e  %e", rms, l1[0]);
+  std::fprintf(f, "  %e  %e  %e", l1[1], l1[2], l1[3]);
+  std::fprintf(f, "  %e", l1[4]);
+  std::fprintf(f, "  %e  %e  ", max_max_over_l1, mx[0]);
+  std::fprintf(f, "%e  %e  %e", mx[1], mx[2], mx[3]);
+  std::fprintf(f, "  %e", mx[4]);
+  std::fprintf(f, "\n");
+  std::fclose(f);
+  return APK_OK;
+}
+
+int apk_sim_execute(apk_sim *s, const char *outdir, int *ncycles) {
+  if (!s || s->host_only || !outdir) return APK_ERR_INVALID;
+  struct HstOut {
+    std::string path;
+    double dt, next;
+  };
+  std::vector<HstOut> outs;
+  try {
+    const std::string base = s->pin.GetOrAddString("parthenon/job", "problem_id", "parthenon");
+    for (const std::string &blk : s->pin.BlocksWithPrefix("parthenon/output")) {
+      if (blk == "parthenon/output_defaults" || !s->pin.DoesParameterExist(blk, "file_type")) continue;
+      if (s->pin.GetString(blk, "file_type") != "hst") continue;  // hdf5 / rst outputs are out of scope
+      const std::string num = blk.substr(std::string("parthenon/output").size());
+      outs.push_back({std::string(outdir) + "/" + base + ".out" + num + ".hst", s->pin.GetReal(blk, "dt"), 0.0});
+      if (s->pin.DoesParameterExist(blk, "data_format"))
+        s->pin.ApplyOverride("parthenon/output_defaults/data_format=" + s->pin.GetString(blk, "data_format"));
+    }
+  } catch (const std::exception &e) {
+    return fail(s, APK_ERR_INVALID, e.what());
+  }
+  SIM_TRY(s, apk_sim_initialize(s));
+  for (auto &o : outs) {
+    if (s->rank == 0) std::remove(o.path.c_str());
+    SIM_TRY(s, apk_sim_write_history(s, o.path.c_str()));
+    o.next = o.dt;
+  }
+  int n = 0;
+  while (s->time < s->tlim && (s->nlim < 0 || n < s->nlim)) {
+    SIM_TRY(s, apk_sim_step(s));
+    ++n;
+    const bool last = !(s->time < s->tlim && (s->nlim < 0 || n < s->nlim));
+    for (auto &o : outs)
+      if (s->time >= o.next || last) {
+        SIM_TRY(s, apk_sim_write_history(s, o.path.c_str()));
+        while (o.next <= s->time) o.next += o.dt;
+      }
+  }
+  if (s->problem_id == "linear_wave" && s->lw.compute_error)
+    SIM_TRY(s, apk_sim_write_linear_wave_errors(s, (std::string(outdir) + "/linearwave-errors.dat").c_str()));
+  if (ncycles) *ncycles = n;
+  return APK_OK;
+}
+
 // src/pgen/linear_wave.cpp:183-335
 int apk_sim_linear_wave_errors(apk_sim *s, double *rms, double *l1, double *mx) {
   if (!s || s->host_only || s->problem_id != "linear_wave" || !rms || !l1 || !mx) return APK_ERR_INVALID;

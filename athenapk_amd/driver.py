@@ -240,6 +240,25 @@ class Simulation(_FmftHost):
         self._check(self.lib.apk_sim_history(self.h, out))
         return np.array(out[:])
 
+    def history_labels(self):
+        buf = C.create_string_buffer(256)
+        self._check(self.lib.apk_sim_history_labels(self.h, buf, len(buf)))
+        return buf.value.decode().split()
+
+    def write_history(self, path):
+        """append one row in Parthenon's .hst layout (header when the file is new)"""
+        self._check(self.lib.apk_sim_write_history(self.h, str(path).encode()))
+
+    def write_linear_wave_errors(self, path):
+        """append one row of linearwave-errors.dat (src/pgen/linear_wave.cpp:296-334)"""
+        self._check(self.lib.apk_sim_write_linear_wave_errors(self.h, str(path).encode()))
+
+    def execute(self, outdir):
+        """initialize + main loop + the deck's hst outputs + the linear-wave error file"""
+        n = C.c_int(0)
+        self._check(self.lib.apk_sim_execute(self.h, str(outdir).encode(), C.byref(n)))
+        return n.value
+
     def turbulence_history(self):
         """volume sums of sonic Mach number, Alfvenic Mach number, plasma beta (TurbulenceHst)"""
         out = (C.c_double * 3)()

@@ -170,6 +170,10 @@ def _signatures():
         "apk_sim_write_block": (i, [vp, i, i, c_dp]),
         "apk_sim_history": (i, [vp, c_dp]),
         "apk_sim_linear_wave_errors": (i, [vp, c_dp, c_dp, c_dp]),
+        "apk_sim_history_labels": (i, [vp, C.c_char_p, C.c_size_t]),
+        "apk_sim_write_history": (i, [vp, C.c_char_p]),
+        "apk_sim_write_linear_wave_errors": (i, [vp, C.c_char_p]),
+        "apk_sim_execute": (i, [vp, C.c_char_p, C.POINTER(C.c_int)]),
         "apk_sim_turbulence_history": (i, [vp, c_dp]),
         "apk_sim_fmft_num_modes": (i, [vp]),
         "apk_sim_fmft_var_hat": (i, [vp, c_dp]),

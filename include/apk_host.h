@@ -116,6 +116,24 @@ int apk_sim_fmft_var_hat(const apk_sim *sim, double *out);
 int apk_sim_fmft_evolve(apk_sim *sim, double dt);
 int apk_sim_fmft_phases(const apk_sim *sim, int axis, int n, int g0, double *out);
 int apk_sim_read_acc(apk_sim *sim, int lb, double *host_out);
+/* ---- text outputs in the reference's formats ---------------------------------------------
+ * History: one row per call, "time dt cycle nbtotal" followed by the package's history list
+ * (src/hydro/hydro.cpp:422-441: mass 1-mom 2-mom 3-mom KE tot-E [ME relDivB]; turbulence adds
+ * Ms [Ma plasma_beta], src/pgen/turbulence.cpp:104-116), under the two '#' header lines
+ * Parthenon's history writer emits ("[n]=label" columns), so numpy.genfromtxt-based analysis
+ * written for the reference reads it unchanged (e.g. tst/regression/test_suites/turbulence/
+ * turbulence.py:42-52 takes Ms, Ma from the third- and second-to-last columns).  The header is
+ * written when the file does not exist yet.  All ranks must call; rank 0 writes.
+ * Error file: src/pgen/linear_wave.cpp:296-334 ("linearwave-errors.dat": header when new,
+ * otherwise append; the Nx2-twice quirk of the reference's row is kept). */
+int apk_sim_history_labels(const apk_sim *sim, char *buf, size_t len); /* space separated */
+int apk_sim_write_history(apk_sim *sim, const char *path);
+int apk_sim_write_linear_wave_errors(apk_sim *sim, const char *path);
+/* main loop of a deck run (what `athenaPK -i deck` does for the scope here): initialize, step to
+ * tlim / nlim, write every <parthenon/output*> block with file_type = hst to
+ * <outdir>/<parthenon/job problem_id, default "parthenon">.out<N>.hst at its `dt` cadence (t = 0
+ * and the final time included), and, for linear_wave with compute_error, the error file. */
+int apk_sim_execute(apk_sim *sim, const char *outdir, int *ncycles);
 int apk_sim_linear_wave_errors(apk_sim *sim, double *rms, double *l1_5, double *max_5);
 /* individual driver steps, exposed for tests */
 int apk_sim_exchange_ghosts(apk_sim *sim);

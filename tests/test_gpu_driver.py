@@ -267,3 +267,56 @@ def test_turbulence_reference_regression_windows():
     assert abs(ms - pin["Ms"]) < 1e-6 * pin["Ms"] and abs(ma - pin["Ma"]) < 1e-6 * pin["Ma"]
     h = s.history()
     assert abs(h[0] - 1.0) < 1e-12 and np.abs(h[1:4]).max() < 1e-12
+
+
+# ---- text outputs in the reference's formats -------------------------------------------------------------
+@pytest.mark.gpu
+def test_cli_history_file_is_readable_by_the_reference_analysis(tmp_path):
+    """`python -m athenapk_amd -i turbulence ...` writes parthenon.out1.hst; read it the way the
+    reference's turbulence.py:42-52 does (np.genfromtxt, Ms / Ma = third / second to last column)."""
+    from athenapk_amd import __main__ as cli
+    ov = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=32", "parthenon/meshblock/nx1=32",
+          "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=16", "parthenon/time/tlim=0.25",
+          "parthenon/output1/data_format=%.14e"]
+    assert cli.main(["-i", "turbulence", "-d", str(tmp_path)] + ov) == 0
+    path = os.path.join(str(tmp_path), "parthenon.out1.hst")
+    head = open(path).readlines()[:2]
+    assert head[0].startswith("#  History data")
+    names = head[1].lstrip("#").split()
+    assert names[:4] == ["[1]=time", "[2]=dt", "[3]=cycle", "[4]=nbtotal"]
+    assert [n.split("=")[1] for n in names[4:]] == ["mass", "1-mom", "2-mom", "3-mom", "KE", "tot-E", "ME", "relDivB",
+                                                     "Ms", "Ma", "plasma_beta"]
+    data = np.genfromtxt(path)
+    assert data.shape[1] == 15
+    assert data[0, 0] == 0.0 and data[-1, 0] == 0.25 and len(data) == 4   # t = 0, 0.1, 0.2, tlim
+    assert np.all(data[:, 3] == 4)
+    assert np.all(np.abs(data[:, 4] - 1.0) < 1e-13)                       # mass
+    assert data[0, -3] == 0.0 and data[-1, -3] > 0.05                      # Ms grows from rest
+    assert np.all(np.diff(data[:, 8]) > 0)                                 # KE is being injected
+    named = np.genfromtxt(path, names=True, skip_header=1)                 # diffusion_linwave3d.py:118 style
+    assert named["1time"][-1] == 0.25 and named["13Ms"][-1] == data[-1, -3]
+
+
+@pytest.mark.gpu
+def test_cli_linear_wave_error_file(tmp_path, oracle):
+    """convergence.py:158-163 reads linearwave-errors.dat with np.genfromtxt and checks column 4
+    (RMS-L1-Error); two runs append two rows."""
+    from athenapk_amd import __main__ as cli
+    for nx in (16, 32):
+        ov = ["parthenon/mesh/nx1=%d" % (2 * nx), "parthenon/mesh/nx2=%d" % nx, "parthenon/mesh/nx3=%d" % nx,
+              "parthenon/meshblock/nx1=%d" % nx, "parthenon/meshblock/nx2=%d" % nx, "parthenon/meshblock/nx3=%d" % nx]
+        assert cli.main(["-i", "linear_wave3d", "-d", str(tmp_path), "--strict"] + ov) == 0
+    path = os.path.join(str(tmp_path), "linearwave-errors.dat")
+    assert open(path).readline().startswith("# Nx1  Nx2  Nx3  Ncycle  RMS-L1-Error  d_L1  M1_L1")
+    data = np.genfromtxt(path)
+    assert data.shape == (2, 16)
+    assert list(data[:, 0]) == [32, 64] and list(data[:, 1]) == [16, 32] and list(data[:, 2]) == [16, 32]
+    o = oracle.Sim(fluid="euler", recon="plm", riemann="hlle", integrator="rk2", nx=(64, 32, 32), ng=2,
+                   xmax=(3.0, 1.5, 1.5), cfl=0.3, gamma=GAMMA_DECK, nthreads=os.cpu_count())
+    o.pgen("linear_wave", wave_flag=0, amp=1e-6)
+    n = o.run(o.period)
+    rms, l1, mx = o.linear_wave_errors()
+    assert data[1, 3] == n
+    want = [float("%e" % v) for v in [rms] + list(l1) + [np.max(mx / l1)] + list(mx)]
+    assert list(data[1, 4:]) == want
+    assert data[1, 4] < data[0, 4] / 3.0   # second order
