@@ -1,0 +1,358 @@
+// kernels_amr.hip -- mesh-refinement operators (prolongation, restriction of cells and of face
+// fluxes) as batched index-box plans, and block tagging.  All of it is HBM-bound streaming work:
+// one thread per coarse cell and variable, i fastest, so reads of the coarse buffer and the
+// paired (fi, fi+1) writes of the fine array coalesce; one launch covers every box of the plan
+// (blockIdx.y = box), which is what matters for AMR meshes made of many 16^3 blocks.
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "apk_internal.hpp"
+#include "hydro_math.hpp"
+
+struct apk_refine_plan {
+  apk_refine_geom geom{};
+  int nvar = 0, nops = 0;
+  int64_t max_items = 0;
+  apk_refine_op *d_ops = nullptr;
+};
+
+namespace apk {
+namespace {
+
+struct RefineDims {
+  int DIM;
+  int fn[3], cn[3];  // cell-centred array extents
+  int fs[3], cs[3];  // first interior index
+};
+
+__host__ __device__ inline RefineDims refine_dims(const apk_refine_geom &g) {
+  RefineDims r;
+  r.DIM = (g.nx[2] > 1) ? 3 : ((g.nx[1] > 1) ? 2 : 1);
+  for (int d = 0; d < 3; ++d) {
+    const bool act = (d == 0) || g.nx[d] > 1;
+    r.fn[d] = act ? g.nx[d] + 2 * g.ng : 1;
+    r.cn[d] = act ? g.nx[d] / 2 + 2 * g.cng : 1;
+    r.fs[d] = (d < r.DIM) ? g.ng : 0;
+    r.cs[d] = (d < r.DIM) ? g.cng : 0;
+  }
+  return r;
+}
+
+APK_DEV double sign_of(double a) { return (a < 0.) ? -1. : 1.; }
+// UniformCartesian cell centre of an index space whose first interior index is s
+APK_DEV double xc_of(double xmin, double dx, int s, int idx) { return (xmin - s * dx) + (idx + 0.5) * dx; }
+
+struct Spacing {
+  double dxm, dxp, dxfm, dxfp;
+};
+// Parthenon refinement_ops::util::GetGridSpacings<DIM, CC>
+APK_DEV Spacing spacings(double xmin, double dx, int cs, int fs, int ci, int fi) {
+  const double cdx = 2.0 * dx;
+  const double xm = xc_of(xmin, cdx, cs, ci - 1);
+  const double xc = xc_of(xmin, cdx, cs, ci);
+  const double xp = xc_of(xmin, cdx, cs, ci + 1);
+  const double fxm = xc_of(xmin, dx, fs, fi);
+  const double fxp = xc_of(xmin, dx, fs, fi + 1);
+  return {xc - xm, xp - xc, xc - fxm, fxp - xc};
+}
+// Parthenon refinement_ops::util::GradMinMod
+APK_DEV double grad_minmod(double fc, double fm, double fp, double dxm, double dxp) {
+  const double gxm = (fc - fm) / dxm;
+  const double gxp = (fp - fc) / dxp;
+  return 0.5 * (sign_of(gxm) + sign_of(gxp)) * fmin(fabs(gxm), fabs(gxp));
+}
+
+// custom_ops.hpp:60-183 (el == CC)
+template <int DIM>
+APK_DEV void prolongate_cell(const apk_refine_geom &g, const RefineDims &r, const apk_refine_op &op, int v, int k,
+                             int j, int i) {
+  const int64_t csj = r.cn[0], csk = (int64_t)r.cn[0] * r.cn[1], csn = csk * r.cn[2];
+  const int64_t fsj = r.fn[0], fsk = (int64_t)r.fn[0] * r.fn[1], fsn = fsk * r.fn[2];
+  const double *c = op.src + v * csn + k * csk + j * csj + i;
+  const int fi = (i - r.cs[0]) * 2 + r.fs[0];
+  const int fj = (DIM > 1) ? (j - r.cs[1]) * 2 + r.fs[1] : r.fs[1];
+  const int fk = (DIM > 2) ? (k - r.cs[2]) * 2 + r.fs[2] : r.fs[2];
+  double *f = op.dst + v * fsn + fk * fsk + fj * fsj + fi;
+  const double fc = c[0];
+  const Spacing s1 = spacings(op.xmin[0], g.dx[0], r.cs[0], r.fs[0], i, fi);
+  double gx1c = grad_minmod(fc, c[-1], c[1], s1.dxm, s1.dxp);
+  Spacing s2{0, 0, 0, 0}, s3{0, 0, 0, 0};
+  double gx2c = 0, gx3c = 0;
+  if constexpr (DIM > 1) {
+    s2 = spacings(op.xmin[1], g.dx[1], r.cs[1], r.fs[1], j, fj);
+    gx2c = grad_minmod(fc, c[-csj], c[csj], s2.dxm, s2.dxp);
+  }
+  if constexpr (DIM > 2) {
+    s3 = spacings(op.xmin[2], g.dx[2], r.cs[2], r.fs[2], k, fk);
+    gx3c = grad_minmod(fc, c[-csk], c[csk], s3.dxm, s3.dxp);
+  }
+  double dqmax = fabs(gx1c) * fmax(s1.dxfm, s1.dxfp);
+  if constexpr (DIM > 1) dqmax += fabs(gx2c) * fmax(s2.dxfm, s2.dxfp);
+  if constexpr (DIM > 2) dqmax += fabs(gx3c) * fmax(s3.dxfm, s3.dxfp);
+  constexpr int jlim = (DIM > 1) ? 1 : 0, klim = (DIM > 2) ? 1 : 0;
+  double qmin = fc, qmax = fc;
+#pragma unroll
+  for (int koff = -klim; koff <= klim; koff++)
+#pragma unroll
+    for (int joff = -jlim; joff <= jlim; joff++)
+#pragma unroll
+      for (int ioff = -1; ioff <= 1; ioff++) {
+        const double q = c[koff * csk + joff * csj + ioff];
+        qmin = fmin(qmin, q);
+        qmax = fmax(qmax, q);
+      }
+  double alpha = 1.0;
+  if (dqmax * alpha > (qmax - fc)) alpha = (qmax - fc) / dqmax;
+  if (dqmax * alpha > (fc - qmin)) alpha = (fc - qmin) / dqmax;
+  gx1c *= alpha;
+  gx2c *= alpha;
+  gx3c *= alpha;
+  const double dx1fm = s1.dxfm, dx1fp = s1.dxfp, dx2fm = s2.dxfm, dx2fp = s2.dxfp, dx3fm = s3.dxfm, dx3fp = s3.dxfp;
+  f[0] = fc - (gx1c * dx1fm + gx2c * dx2fm + gx3c * dx3fm);
+  f[1] = fc + (gx1c * dx1fp - gx2c * dx2fm - gx3c * dx3fm);
+  if constexpr (DIM > 1) {
+    f[fsj] = fc - (gx1c * dx1fm - gx2c * dx2fp + gx3c * dx3fm);
+    f[fsj + 1] = fc + (gx1c * dx1fp + gx2c * dx2fp - gx3c * dx3fm);
+  }
+  if constexpr (DIM > 2) {
+    f[fsk] = fc - (gx1c * dx1fm + gx2c * dx2fm - gx3c * dx3fp);
+    f[fsk + 1] = fc + (gx1c * dx1fp - gx2c * dx2fm + gx3c * dx3fp);
+    f[fsk + fsj] = fc - (gx1c * dx1fm - gx2c * dx2fp - gx3c * dx3fp);
+    f[fsk + fsj + 1] = fc + (gx1c * dx1fp + gx2c * dx2fp + gx3c * dx3fp);
+  }
+}
+
+// RestrictAverage for cells (el = 0) and faces (el = 1..3): uniform weights, pairwise sums
+APK_DEV void restrict_cell(const apk_refine_geom &g, const RefineDims &r, const apk_refine_op &op, int el, int v,
+                           int k, int j, int i) {
+  int fn[3] = {r.fn[0], r.fn[1], r.fn[2]}, cn[3] = {r.cn[0], r.cn[1], r.cn[2]};
+  if (el >= 1) {
+    fn[el - 1] += 1;
+    cn[el - 1] += 1;
+  }
+  const int64_t csj = cn[0], csk = (int64_t)cn[0] * cn[1], csn = csk * cn[2];
+  const int64_t fsj = fn[0], fsk = (int64_t)fn[0] * fn[1], fsn = fsk * fn[2];
+  const int fi = (i - r.cs[0]) * 2 + r.fs[0];
+  const int fj = (r.DIM > 1) ? (j - r.cs[1]) * 2 + r.fs[1] : 0;
+  const int fk = (r.DIM > 2) ? (k - r.cs[2]) * 2 + r.fs[2] : 0;
+  const int oi1 = (el != 1) ? 1 : 0;
+  const int oj1 = (r.DIM > 1 && el != 2) ? 1 : 0;
+  const int ok1 = (r.DIM > 2 && el != 3) ? 1 : 0;
+  double w = 1.0;
+  if (el != 1) w *= g.dx[0];
+  if (el != 2) w *= g.dx[1];
+  if (el != 3) w *= g.dx[2];
+  const double *f = op.src + v * fsn + fk * fsk + fj * fsj + fi;
+  double vol[2][2][2], t[2][2][2];
+#pragma unroll
+  for (int ok = 0; ok < 2; ++ok)
+#pragma unroll
+    for (int oj = 0; oj < 2; ++oj)
+#pragma unroll
+      for (int oi = 0; oi < 2; ++oi) {
+        const bool in = !(ok > ok1 || oj > oj1 || oi > oi1);
+        vol[ok][oj][oi] = in ? w : 0.0;
+        t[ok][oj][oi] = in ? w * f[ok * fsk + oj * fsj + oi] : 0.0;
+      }
+  const double tvol = ((vol[0][0][0] + vol[0][1][0]) + (vol[0][0][1] + vol[0][1][1])) +
+                      ((vol[1][0][0] + vol[1][1][0]) + (vol[1][0][1] + vol[1][1][1]));
+  op.dst[v * csn + k * csk + j * csj + i] = (((t[0][0][0] + t[0][1][0]) + (t[0][0][1] + t[0][1][1])) +
+                                             ((t[1][0][0] + t[1][1][0]) + (t[1][0][1] + t[1][1][1]))) /
+                                            tvol;
+}
+
+__global__ void __launch_bounds__(256) refine_ops_kernel(apk_refine_geom g, int nvar, const apk_refine_op *ops) {
+  const apk_refine_op op = ops[blockIdx.y];
+  const RefineDims r = refine_dims(g);
+  const int e0 = op.hi[0] - op.lo[0] + 1, e1 = op.hi[1] - op.lo[1] + 1, e2 = op.hi[2] - op.lo[2] + 1;
+  const int64_t cells = (int64_t)e0 * e1 * e2, items = cells * nvar;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < items; t += (int64_t)gridDim.x * blockDim.x) {
+    const int v = (int)(t / cells);
+    int64_t c = t - (int64_t)v * cells;
+    const int i = op.lo[0] + (int)(c % e0);
+    c /= e0;
+    const int j = op.lo[1] + (int)(c % e1);
+    const int k = op.lo[2] + (int)(c / e1);
+    if (op.kind == APK_RO_PROLONGATE) {
+      if (r.DIM == 3) prolongate_cell<3>(g, r, op, v, k, j, i);
+      else if (r.DIM == 2) prolongate_cell<2>(g, r, op, v, k, j, i);
+      else prolongate_cell<1>(g, r, op, v, k, j, i);
+    } else {
+      restrict_cell(g, r, op, op.kind - APK_RO_RESTRICT_CELL, v, k, j, i);
+    }
+  }
+}
+
+// ---- tagging ---------------------------------------------------------------------------------
+// one workgroup row per (block, k-plane chunk); the criteria are non-negative, so their bit
+// patterns order like unsigned integers and one atomicMax per workgroup suffices
+template <int CRIT>
+__global__ void __launch_bounds__(256) tag_kernel(PackView pv, unsigned long long *block_max) {
+  const int b = blockIdx.z;
+  const apk_block_desc blk = pv.blocks[b];
+  const int ndim = (pv.nx3 > 1) ? 3 : ((pv.nx2 > 1) ? 2 : 1);
+  // extents per criterion (gradient.cpp:33-36,45-46,79-81; other.cpp:31-32)
+  int il = pv.is, iu = pv.ie, jl = pv.js, ju = pv.je, kl = pv.ks, ku = pv.ke;
+  if (CRIT == APK_TAG_PRESSURE_GRADIENT) {
+    il -= 1, iu += 1, jl -= 1, ju += 1;
+    if (ndim == 3) kl -= 1, ku += 1;
+  } else if (CRIT == APK_TAG_VELOCITY_GRADIENT) {
+    il -= 1, iu += 1, jl -= 1, ju += 1;
+  } else {
+    iu += 1;
+  }
+  double m = 0.0;
+  const int i = il + blockIdx.x * 64 + threadIdx.x;
+  const int j = jl + blockIdx.y * 4 + threadIdx.y;
+  if (i <= iu && j <= ju) {
+    for (int k = kl; k <= ku; ++k) {
+      const int64_t c = k * pv.sk + j * pv.sj + i;
+      if (CRIT == APK_TAG_PRESSURE_GRADIENT) {
+        const double *p = blk.prim + IPR * pv.sn + c;
+        const double a = 0.5 * (p[1] - p[-1]), bb = 0.5 * (p[pv.sj] - p[-pv.sj]);
+        double eps;
+        if (ndim == 3) {
+          const double cc = 0.5 * (p[pv.sk] - p[-pv.sk]);
+          eps = sqrt(sqr(a) + sqr(bb) + sqr(cc)) / p[0];
+        } else {
+          eps = sqrt(sqr(a) + sqr(bb)) / p[0];
+        }
+        m = fmax(m, eps);
+      } else if (CRIT == APK_TAG_VELOCITY_GRADIENT) {
+        const double *v1 = blk.prim + IV1 * pv.sn + c, *v2 = blk.prim + IV2 * pv.sn + c;
+        const double vgy = fabs(v2[1] - v2[-1]) * 0.5;
+        const double vgx = fabs(v1[pv.sj] - v1[-pv.sj]) * 0.5;
+        const double vg = sqrt(vgx * vgx + vgy * vgy);
+        if (vg > m) m = vg;
+      } else {
+        m = fmax(m, blk.prim[IDN * pv.sn + c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+  __shared__ double part[4];
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  if ((tid & 63) == 0) part[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    const double mm = fmax(fmax(part[0], part[1]), fmax(part[2], part[3]));
+    atomicMax(block_max + b, (unsigned long long)__double_as_longlong(mm));
+  }
+}
+
+}  // namespace
+}  // namespace apk
+
+using namespace apk;
+
+extern "C" {
+
+int apk_refine_plan_create(apk_ctx *ctx, const apk_refine_geom *geom, int nvar, const apk_refine_op *ops, int nops,
+                           apk_refine_plan **out) {
+  if (!ctx || !geom || !ops || !out || nvar <= 0 || nops <= 0) return set_err(ctx, APK_ERR_INVALID, "apk_refine_plan_create: bad argument");
+  *out = nullptr;
+  if (geom->ng < 1 || geom->cng < 1) return set_err(ctx, APK_ERR_NGHOST, "apk_refine_plan_create: ng, cng must be >= 1");
+  for (int d = 0; d < 3; ++d)
+    if (geom->nx[d] < 1 || (geom->nx[d] > 1 && (geom->nx[d] & 1)))
+      return set_err(ctx, APK_ERR_INVALID, "apk_refine_plan_create: active dimensions need an even number of cells");
+  const RefineDims r = refine_dims(*geom);
+  int64_t max_items = 0;
+  for (int n = 0; n < nops; ++n) {
+    const apk_refine_op &op = ops[n];
+    if (op.kind < APK_RO_PROLONGATE || op.kind > APK_RO_RESTRICT_FACE3 || !op.src || !op.dst)
+      return set_err(ctx, APK_ERR_INVALID, "apk_refine_plan_create: bad op");
+    const int el = (op.kind >= APK_RO_RESTRICT_FACE1) ? op.kind - APK_RO_RESTRICT_CELL : 0;
+    if (el > r.DIM) return set_err(ctx, APK_ERR_INVALID, "apk_refine_plan_create: face direction is collapsed");
+    int64_t cells = 1;
+    for (int d = 0; d < 3; ++d) {
+      // prolongation reads one coarse cell either side in active dimensions
+      const int halo = (op.kind == APK_RO_PROLONGATE && d < r.DIM) ? 1 : 0;
+      const int top = r.cn[d] + ((el == d + 1) ? 1 : 0) - 1;
+      if (op.lo[d] > op.hi[d] || op.lo[d] - halo < 0 || op.hi[d] + halo > top)
+        return set_err(ctx, APK_ERR_INVALID, "apk_refine_plan_create: index box outside of the coarse buffer");
+      cells *= op.hi[d] - op.lo[d] + 1;
+    }
+    max_items = cells * nvar > max_items ? cells * nvar : max_items;
+  }
+  apk_refine_plan *p = new (std::nothrow) apk_refine_plan();
+  if (!p) return APK_ERR_INVALID;
+  p->geom = *geom;
+  p->nvar = nvar;
+  p->nops = nops;
+  p->max_items = max_items;
+  hipError_t e = hipMalloc(&p->d_ops, sizeof(apk_refine_op) * nops);
+  if (e == hipSuccess) e = hipMemcpy(p->d_ops, ops, sizeof(apk_refine_op) * nops, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    apk_refine_plan_destroy(p);
+    return set_err(ctx, APK_ERR_DEVICE, "apk_refine_plan_create", e);
+  }
+  *out = p;
+  return APK_OK;
+}
+
+void apk_refine_plan_destroy(apk_refine_plan *p) {
+  if (!p) return;
+  if (p->d_ops) (void)hipFree(p->d_ops);
+  delete p;
+}
+
+int apk_refine_plan_run(apk_ctx *ctx, const apk_refine_plan *p, apk_stream_t stream) {
+  if (!ctx || !p) return set_err(ctx, APK_ERR_INVALID, "apk_refine_plan_run: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int64_t gx = (p->max_items + 255) / 256;
+  if (gx > 4096) gx = 4096;  // grid-stride beyond that
+  hipLaunchKernelGGL(refine_ops_kernel, dim3((unsigned)gx, (unsigned)p->nops), dim3(256), 0, s, p->geom, p->nvar, p->d_ops);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? APK_OK : set_err(ctx, APK_ERR_DEVICE, "refine_ops launch", e);
+}
+
+int apk_tag_blocks(apk_ctx *ctx, const apk_pack *md, int criterion, double p0, double p1, int *tags, double *crit,
+                   apk_stream_t stream) {
+  if (!ctx || !md || !tags || criterion < APK_TAG_PRESSURE_GRADIENT || criterion > APK_TAG_MAX_DENSITY)
+    return set_err(ctx, APK_ERR_INVALID, "apk_tag_blocks: bad argument");
+  const PackView &pv = md->view;
+  if (pv.ng < 1) return set_err(ctx, APK_ERR_NGHOST, "apk_tag_blocks needs one ghost cell");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int nb = pv.nblocks;
+  const int ndim = (pv.nx3 > 1) ? 3 : ((pv.nx2 > 1) ? 2 : 1);
+  if (criterion == APK_TAG_PRESSURE_GRADIENT && ndim == 1) {  // gradient.cpp:56-58: AmrTag::same
+    for (int b = 0; b < nb; ++b) {
+      tags[b] = 0;
+      if (crit) crit[b] = 0.0;
+    }
+    return APK_OK;
+  }
+  if (criterion == APK_TAG_VELOCITY_GRADIENT && ndim == 1)
+    return set_err(ctx, APK_ERR_UNSUPPORTED, "xyvelocity_gradient needs at least two dimensions");
+  if (ctx->partial_cap < (size_t)nb) {
+    if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+    ctx->d_partial = nullptr;
+    ctx->partial_cap = 0;
+    APK_HIP_TRY(ctx, hipMalloc(&ctx->d_partial, sizeof(double) * (nb + 64)));
+    ctx->partial_cap = nb + 64;
+  }
+  auto *d_max = reinterpret_cast<unsigned long long *>(ctx->d_partial);
+  APK_HIP_TRY(ctx, hipMemsetAsync(d_max, 0, sizeof(unsigned long long) * nb, s));
+  const dim3 grid((pv.nx1 + 2 + 63) / 64, (pv.nx2 + 2 + 3) / 4, nb), block(64, 4, 1);
+  if (criterion == APK_TAG_PRESSURE_GRADIENT)
+    hipLaunchKernelGGL(tag_kernel<APK_TAG_PRESSURE_GRADIENT>, grid, block, 0, s, pv, d_max);
+  else if (criterion == APK_TAG_VELOCITY_GRADIENT)
+    hipLaunchKernelGGL(tag_kernel<APK_TAG_VELOCITY_GRADIENT>, grid, block, 0, s, pv, d_max);
+  else
+    hipLaunchKernelGGL(tag_kernel<APK_TAG_MAX_DENSITY>, grid, block, 0, s, pv, d_max);
+  std::vector<double> h(nb);
+  APK_HIP_TRY(ctx, hipMemcpyAsync(h.data(), d_max, sizeof(double) * nb, hipMemcpyDeviceToHost, s));
+  APK_HIP_TRY(ctx, hipStreamSynchronize(s));
+  const double refine_above = p0;
+  const double deref_below = (criterion == APK_TAG_PRESSURE_GRADIENT) ? 0.25 * p0
+                             : (criterion == APK_TAG_VELOCITY_GRADIENT) ? 0.5 * p0 : p1;
+  for (int b = 0; b < nb; ++b) {
+    tags[b] = (h[b] > refine_above) ? 1 : ((h[b] < deref_below) ? -1 : 0);
+    if (crit) crit[b] = h[b];
+  }
+  return APK_OK;
+}
+
+}  // extern "C"

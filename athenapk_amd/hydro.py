@@ -279,3 +279,53 @@ def TurbulenceHst(md, fluid, gamma):
     out = (C.c_double * 3)()
     _check(ctx.lib.apk_turbulence_history(ctx.h, md.h, L.FLUID[fluid], float(gamma), out, _stream()), ctx.lib, ctx.h)
     return np.array(out[:])
+
+
+# ---- mesh-refinement operators and tagging -----------------------------------------------------
+class RefinePlan:
+    """A batch of prolongation / restriction index boxes over meshblocks of one shape, run in one
+    launch.  ops: list of (kind, src_tensor, dst_tensor, lo, hi, xmin) with kind in
+    lib.REFINE_OPS; tensors are CUDA float64 (fine arrays [nvar][Nk][Nj][Ni], coarse buffers
+    [nvar][cNk][cNj][cNi], face arrays one longer along their direction).
+    ProlongateCellMinModMultiD -- src/hydro/prolongation/custom_ops.hpp:49-186; RestrictAverage
+    (Parthenon), registered at src/hydro/hydro.cpp:780-781."""
+
+    def __init__(self, ctx, nx, ng, cng, dx, nvar, ops):
+        self.ctx = ctx
+        g = L.RefineGeom()
+        g.nx[:] = list(nx)
+        g.ng, g.cng = ng, cng
+        g.dx[:] = list(dx)
+        arr = (L.RefineOp * len(ops))()
+        self._keep = []
+        for n, (kind, src, dst, lo, hi, xmin) in enumerate(ops):
+            arr[n].kind = L.REFINE_OPS[kind]
+            arr[n].src, arr[n].dst = src.data_ptr(), dst.data_ptr()
+            arr[n].lo[:], arr[n].hi[:], arr[n].xmin[:] = list(lo), list(hi), list(xmin)
+            self._keep += [src, dst]
+        h = C.c_void_p()
+        _check(ctx.lib.apk_refine_plan_create(ctx.h, C.byref(g), nvar, arr, len(ops), C.byref(h)), ctx.lib, ctx.h)
+        self.h = h
+
+    def run(self):
+        _check(self.ctx.lib.apk_refine_plan_run(self.ctx.h, self.h, _stream()), self.ctx.lib, self.ctx.h)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.ctx.lib.apk_refine_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def TagBlocks(md, criterion, p0, p1=0.0):
+    """refinement::gradient::PressureGradient / VelocityGradient (src/refinement/gradient.cpp:18-99),
+    refinement::other::MaxDensity (src/refinement/other.cpp:18-44) for every block of the pack.
+    Returns (tags, criterion values); tags: +1 refine, 0 same, -1 derefine."""
+    ctx = md.ctx
+    tags = (C.c_int * md.nblocks)()
+    crit = (C.c_double * md.nblocks)()
+    _check(ctx.lib.apk_tag_blocks(ctx.h, md.h, L.TAG_CRITERIA[criterion], float(p0), float(p1), tags, crit, _stream()),
+           ctx.lib, ctx.h)
+    return np.array(tags[:]), np.array(crit[:])

@@ -63,6 +63,19 @@ class FmftBlock(C.Structure):
                 ("phases_k", C.c_void_p)]
 
 
+class RefineGeom(C.Structure):
+    _fields_ = [("nx", C.c_int * 3), ("ng", C.c_int), ("cng", C.c_int), ("dx", C.c_double * 3)]
+
+
+class RefineOp(C.Structure):
+    _fields_ = [("kind", C.c_int), ("src", C.c_void_p), ("dst", C.c_void_p), ("lo", C.c_int * 3),
+                ("hi", C.c_int * 3), ("xmin", C.c_double * 3)]
+
+
+REFINE_OPS = {"prolongate": 0, "restrict_cell": 1, "restrict_face1": 2, "restrict_face2": 3, "restrict_face3": 4}
+TAG_CRITERIA = {"pressure_gradient": 0, "xyvelocity_gradient": 1, "maxdensity": 2}
+
+
 class CopyRegion(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("ext", C.c_int * 3),
                 ("nvar", C.c_int), ("src_stride", C.c_int64 * 4),
@@ -140,6 +153,10 @@ def _signatures():
         "apk_turb_remove_mean": (i, [vp, vp, vp, c_dp, c_dp, vp]),
         "apk_turb_apply": (i, [vp, vp, vp, d, d, vp]),
         "apk_turbulence_history": (i, [vp, vp, i, d, c_dp, vp]),
+        "apk_refine_plan_create": (i, [vp, C.POINTER(RefineGeom), i, C.POINTER(RefineOp), i, pp]),
+        "apk_refine_plan_destroy": (None, [vp]),
+        "apk_refine_plan_run": (i, [vp, vp, vp]),
+        "apk_tag_blocks": (i, [vp, vp, i, d, d, C.POINTER(C.c_int), c_dp, vp]),
         "apk_poll_device_flags": (i, [vp, C.POINTER(C.c_uint), vp]),
         "apk_copy_plan_create": (i, [vp, C.POINTER(CopyRegion), i, pp]),
         "apk_copy_plan_destroy": (None, [vp]),

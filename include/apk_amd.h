@@ -254,6 +254,52 @@ int apk_turb_apply(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, double norm, d
 int apk_turbulence_history(apk_ctx *ctx, const apk_pack *md, int fluid, double gamma, double *out3,
                            apk_stream_t stream);
 
+/* ---- mesh-refinement operators and block tagging (SURVEY 8(f) rank 3 building blocks) -------
+ * The operators AthenaPK registers for `cons` (src/hydro/hydro.cpp:780-781):
+ * Hydro::refinement_ops::ProlongateCellMinModMultiD (src/hydro/prolongation/custom_ops.hpp:49-186)
+ * and Parthenon's RestrictAverage for cells and, for the coarse-fine flux correction
+ * (src/hydro/hydro_driver.cpp:527-531), for face fluxes.  A plan is a list of index boxes over
+ * many meshblocks of one shape, executed in ONE launch (AMR meshes have many 16^3 blocks: a launch
+ * per block and per buffer would be latency bound).  Fine arrays are [nvar][Nk][Nj][Ni] with `ng`
+ * ghosts, coarse buffers [nvar][cNk][cNj][cNi] with nx/2 interior cells and `cng` ghosts per active
+ * dimension; face arrays have one more entry along their own direction.  Index boxes are inclusive
+ * and given in COARSE indices; prolongation reads one coarse cell beyond the box. */
+typedef struct apk_refine_geom {
+  int nx[3];    /* fine interior cells of a meshblock (1 in a collapsed dimension) */
+  int ng;       /* fine ghost cells */
+  int cng;      /* coarse-buffer ghost cells */
+  double dx[3]; /* fine cell widths */
+} apk_refine_geom;
+enum {
+  APK_RO_PROLONGATE = 0,    /* src = coarse buffer, dst = fine array */
+  APK_RO_RESTRICT_CELL = 1, /* src = fine array,   dst = coarse buffer */
+  APK_RO_RESTRICT_FACE1 = 2,
+  APK_RO_RESTRICT_FACE2 = 3,
+  APK_RO_RESTRICT_FACE3 = 4
+};
+typedef struct apk_refine_op {
+  int kind;
+  const double *src; /* device */
+  double *dst;       /* device */
+  int lo[3], hi[3];
+  double xmin[3]; /* lower interior corner of the block (enters the slope spacings as in the
+                     reference, which differences cell-centre coordinates) */
+} apk_refine_op;
+typedef struct apk_refine_plan apk_refine_plan;
+int apk_refine_plan_create(apk_ctx *ctx, const apk_refine_geom *geom, int nvar,
+                           const apk_refine_op *ops /* host */, int nops, apk_refine_plan **out);
+void apk_refine_plan_destroy(apk_refine_plan *p);
+int apk_refine_plan_run(apk_ctx *ctx, const apk_refine_plan *p, apk_stream_t stream);
+
+/* Block tagging, one launch for the whole pack: refinement::gradient::PressureGradient
+ * (src/refinement/gradient.cpp:18-61: refine above p0, derefine below 0.25 p0),
+ * VelocityGradient (:64-96: p0, 0.5 p0), refinement::other::MaxDensity (src/refinement/other.cpp:
+ * 18-44: refine above p0, derefine below p1).  tags[b] = +1 refine / 0 same / -1 derefine,
+ * crit[b] (may be NULL) = the reduced criterion.  Synchronises. */
+enum { APK_TAG_PRESSURE_GRADIENT = 0, APK_TAG_VELOCITY_GRADIENT = 1, APK_TAG_MAX_DENSITY = 2 };
+int apk_tag_blocks(apk_ctx *ctx, const apk_pack *md, int criterion, double p0, double p1, int *tags,
+                   double *crit, apk_stream_t stream);
+
 /* ---- in-library kernel timing (HIP events on the caller's stream) ------------------------
  * bench.py needs the average duration of individual kernels measured live on the stream
  * they are launched on.  When enabled, every kernel launch of the listed groups is

@@ -224,4 +224,24 @@ int orc_integrator_coeffs(int integrator, double *beta, double *gam0, double *ga
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- mesh-refinement operators and tagging (amr.c; SURVEY 8(f) rank 3 building blocks) ------ */
+typedef struct {
+  int nx[3];      /* fine interior cells of the meshblock (1 in a collapsed dimension) */
+  int ng;         /* fine ghost cells */
+  int cng;        /* ghost cells of the coarse buffer */
+  double xmin[3]; /* lower interior corner of the block */
+  double dx[3];   /* fine cell widths */
+} orc_refine_geom;
+int orc_refine_ndim(const orc_refine_geom *r);
+void orc_refine_dims(const orc_refine_geom *r, int fine[3], int coarse[3]);
+void orc_prolongate_minmod(const orc_refine_geom *r, int nvar, const double *coarse, double *fine,
+                           const int lo[3], const int hi[3]);
+void orc_restrict_average(const orc_refine_geom *r, int nvar, int el, const double *fine, double *coarse,
+                          const int lo[3], const int hi[3]);
+int orc_tag_pressure_gradient(const orc_geom *g, const double *prim, double threshold, double *crit);
+int orc_tag_velocity_gradient(const orc_geom *g, const double *prim, double threshold, double *crit);
+int orc_tag_max_density(const orc_geom *g, const double *prim, double refine_above, double deref_below,
+                        double *crit);
+
 #endif /* APK_ORACLE_H_ */

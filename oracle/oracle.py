@@ -123,6 +123,12 @@ def _declare(lib):
         "orc_sim_turb_history": (None, [C.c_void_p, p]),
         "orc_sim_var_hat": (p, [C.c_void_p]),
         "orc_sim_acc": (p, [C.c_void_p, i]),
+        "orc_refine_dims": (None, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "orc_prolongate_minmod": (None, [C.c_void_p, i, p, p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "orc_restrict_average": (None, [C.c_void_p, i, i, p, p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "orc_tag_pressure_gradient": (i, [G, p, d, C.POINTER(d)]),
+        "orc_tag_velocity_gradient": (i, [G, p, d, C.POINTER(d)]),
+        "orc_tag_max_density": (i, [G, p, d, d, C.POINTER(d)]),
         "orc_mt_seed": (None, [C.c_void_p, C.c_uint32]),
         "orc_mt_next": (C.c_uint32, [C.c_void_p]),
         "orc_uniform_m1_p1": (d, [C.c_void_p]),
@@ -296,6 +302,49 @@ class Sim:
         out = np.zeros((self.geom.nvar, self.nx[2], self.nx[1], self.nx[0]))
         self.lib.orc_sim_gather_cons(self.h, dp(out))
         return out
+
+
+class RefineGeom(C.Structure):
+    _fields_ = [("nx", C.c_int * 3), ("ng", C.c_int), ("cng", C.c_int), ("xmin", C.c_double * 3),
+                ("dx", C.c_double * 3)]
+
+    def dims(self):
+        """(fine shape, coarse shape) as (nk, nj, ni)"""
+        f, c = (C.c_int * 3)(), (C.c_int * 3)()
+        load().orc_refine_dims(C.byref(self), f, c)
+        return (f[2], f[1], f[0]), (c[2], c[1], c[0])
+
+
+def make_refine_geom(nx, ng, cng, xmin=(0.0, 0.0, 0.0), dx=(1.0, 1.0, 1.0)):
+    r = RefineGeom()
+    r.nx[:] = list(nx)
+    r.ng, r.cng = ng, cng
+    r.xmin[:] = list(xmin)
+    r.dx[:] = list(dx)
+    return r
+
+
+def prolongate(r, coarse, fine, lo, hi):
+    """in place on `fine`; coarse [nvar][cNk][cNj][cNi]"""
+    I3 = C.c_int * 3
+    load().orc_prolongate_minmod(C.byref(r), coarse.shape[0], dp(coarse), dp(fine), I3(*lo), I3(*hi))
+
+
+def restrict(r, el, fine, coarse, lo, hi):
+    I3 = C.c_int * 3
+    load().orc_restrict_average(C.byref(r), fine.shape[0], el, dp(fine), dp(coarse), I3(*lo), I3(*hi))
+
+
+def tag(kind, g, prim, p0, p1=0.0):
+    lib = load()
+    crit = C.c_double(0.0)
+    if kind == "pressure_gradient":
+        t = lib.orc_tag_pressure_gradient(C.byref(g), dp(prim), p0, C.byref(crit))
+    elif kind == "xyvelocity_gradient":
+        t = lib.orc_tag_velocity_gradient(C.byref(g), dp(prim), p0, C.byref(crit))
+    else:
+        t = lib.orc_tag_max_density(C.byref(g), dp(prim), p0, p1, C.byref(crit))
+    return t, crit.value
 
 
 class MT19937(C.Structure):

@@ -1,0 +1,219 @@
+"""Mesh-refinement operators and tagging (SURVEY 8(f) rank 3 building blocks).
+CPU: properties of the oracle restatement (the reference holds no vectors for these operators:
+parity is unpinned and the properties below are what the upstream operators guarantee).
+GPU: the HIP plan kernels against the oracle, bit for bit in the strict build."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+
+def _fields(r, nvar, seed, kind="smooth"):
+    from oracle import oracle as O
+    fs, cs = r.dims()
+    rng = np.random.default_rng(seed)
+    k, j, i = np.meshgrid(np.arange(cs[0]), np.arange(cs[1]), np.arange(cs[2]), indexing="ij")
+    coarse = np.empty((nvar,) + cs)
+    for v in range(nvar):
+        if kind == "smooth":
+            coarse[v] = 1.5 + np.sin(0.7 * i + 0.3 * v) * np.cos(0.5 * j) + 0.3 * np.sin(0.9 * k + v)
+        else:
+            coarse[v] = rng.uniform(-1.0, 1.0, cs)
+    fine = rng.uniform(-1.0, 1.0, (nvar,) + fs)
+    return coarse, fine
+
+
+def _interior_box(r):
+    lo = [r.cng if (d == 0 or r.nx[d] > 1) else 0 for d in range(3)]
+    hi = [r.cng + r.nx[d] // 2 - 1 if (d == 0 or r.nx[d] > 1) else 0 for d in range(3)]
+    return lo, hi
+
+
+GEOMS = [((16, 16, 16), 2, 2), ((16, 8, 1), 2, 2), ((12, 1, 1), 3, 3), ((8, 8, 8), 3, 3)]
+
+
+@pytest.mark.parametrize("nx,ng,cng", GEOMS)
+def test_prolongation_is_conservative_and_bounded(oracle, nx, ng, cng):
+    r = oracle.make_refine_geom(nx, ng, cng, xmin=(0.25, -0.5, 1.0), dx=(0.01, 0.02, 0.04))
+    for kind in ("smooth", "rough"):
+        coarse, fine = _fields(r, 3, 1, kind)
+        lo, hi = _interior_box(r)
+        oracle.prolongate(r, coarse, fine, lo, hi)
+        ndim = oracle.load().orc_refine_ndim(C.byref(r))
+        sl_f = tuple(slice(r.ng, r.ng + nx[d]) if (d == 0 or nx[d] > 1) else slice(0, 1) for d in (2, 1, 0))
+        fi = fine[(slice(None),) + sl_f]
+        # mean of the 2^d children = parent (offsets are symmetric on a uniform grid)
+        shp = (3,) + tuple(x for d in (2, 1, 0) for x in ((nx[d] // 2, 2) if (d == 0 or nx[d] > 1) else (1, 1)))
+        child_mean = fi.reshape(shp).mean(axis=(2, 4, 6))
+        sl_c = tuple(slice(lo[d], hi[d] + 1) for d in (2, 1, 0))
+        parent = coarse[(slice(None),) + sl_c]
+        assert np.abs(child_mean - parent).max() < 1e-13
+        # no new extrema: children stay within the min/max of the 3^d coarse neighbourhood
+        from scipy.ndimage import maximum_filter, minimum_filter
+        size = (1,) + tuple(3 if (d == 0 or nx[d] > 1) else 1 for d in (2, 1, 0))
+        cmax = maximum_filter(coarse, size=size, mode="nearest")[(slice(None),) + sl_c]
+        cmin = minimum_filter(coarse, size=size, mode="nearest")[(slice(None),) + sl_c]
+        rep = [2 if (d == 0 or nx[d] > 1) else 1 for d in (2, 1, 0)]
+        up = lambda a: a.repeat(rep[0], 1).repeat(rep[1], 2).repeat(rep[2], 3)  # noqa: E731
+        assert np.all(fi <= up(cmax) + 1e-14) and np.all(fi >= up(cmin) - 1e-14)
+        assert ndim == sum(1 for d in range(3) if d == 0 or nx[d] > 1)
+
+
+def test_prolongation_reproduces_linear_data_and_restriction_inverts_it(oracle):
+    r = oracle.make_refine_geom((16, 16, 16), 2, 2, xmin=(0.0, 0.0, 0.0), dx=(0.5, 0.5, 0.5))
+    fs, cs = r.dims()
+    k, j, i = np.meshgrid(np.arange(cs[0]), np.arange(cs[1]), np.arange(cs[2]), indexing="ij")
+    xc = lambda idx: (idx - r.cng + 0.5) * 1.0  # noqa: E731  coarse centres (cdx = 1)
+    coarse = (2.0 + 0.25 * xc(i) - 0.5 * xc(j) + 0.125 * xc(k))[None]
+    fine = np.zeros((1,) + fs)
+    lo, hi = _interior_box(r)
+    oracle.prolongate(r, coarse, fine, lo, hi)
+    fk, fj, fi = np.meshgrid(np.arange(fs[0]), np.arange(fs[1]), np.arange(fs[2]), indexing="ij")
+    xf = lambda idx: (idx - r.ng + 0.5) * 0.5  # noqa: E731
+    want = 2.0 + 0.25 * xf(fi) - 0.5 * xf(fj) + 0.125 * xf(fk)
+    s = slice(r.ng, r.ng + 16)
+    assert np.abs(fine[0, s, s, s] - want[s, s, s]).max() < 1e-13
+    back = np.zeros_like(coarse)
+    oracle.restrict(r, 0, fine, back, lo, hi)
+    c = slice(r.cng, r.cng + 8)
+    assert np.abs(back[0, c, c, c] - coarse[0, c, c, c]).max() < 1e-13
+
+
+def test_flux_restriction_is_the_area_average(oracle):
+    r = oracle.make_refine_geom((8, 8, 8), 2, 2, dx=(0.1, 0.2, 0.4))
+    fs, cs = r.dims()
+    rng = np.random.default_rng(3)
+    for el in (1, 2, 3):
+        ax = 3 - el  # numpy axis of the face direction in (k, j, i)
+        fshape = tuple(n + (1 if a == ax else 0) for a, n in enumerate(fs))
+        cshape = tuple(n + (1 if a == ax else 0) for a, n in enumerate(cs))
+        fine = rng.uniform(-1, 1, (2,) + fshape)
+        coarse = np.zeros((2,) + cshape)
+        lo, hi = _interior_box(r)
+        hi[el - 1] += 1  # the upper face of the last coarse cell
+        oracle.restrict(r, el, fine, coarse, lo, hi)
+        for (k, j, i) in ((2, 3, 4), (5, 5, 2), (2, 2, 2)):
+            fk, fj, fi = [(x - r.cng) * 2 + r.ng for x in (k, j, i)]
+            sl = [slice(fk, fk + 2), slice(fj, fj + 2), slice(fi, fi + 2)]
+            sl[ax] = slice(sl[ax].start, sl[ax].start + 1)
+            assert abs(coarse[1, k, j, i] - fine[(1,) + tuple(sl)].mean()) < 1e-15
+
+
+def test_tagging_criteria(oracle):
+    nx, ng = (16, 16, 16), 2
+    g = H.geom("euler", nx, ng)
+    prim = H.random_prim("euler", nx, ng, seed=4, kind="smooth")[0]
+    t, eps = oracle.tag("pressure_gradient", g, prim, 1e9)
+    assert t == -1 and eps > 0
+    assert oracle.tag("pressure_gradient", g, prim, eps * 0.99)[0] == 1
+    assert oracle.tag("pressure_gradient", g, prim, eps * 2.0)[0] == 0      # between thr/4 and thr
+    t, vg = oracle.tag("xyvelocity_gradient", g, prim, 1e9)
+    assert t == -1 and oracle.tag("xyvelocity_gradient", g, prim, vg * 1.5)[0] == 0
+    t, rho = oracle.tag("maxdensity", g, prim, 1e9, 1e-9)
+    assert t == 0 and rho == prim[0, ng:-ng, ng:-ng, ng:ng + nx[0] + 1].max()   # i runs to ib.e + 1
+    # a constant-pressure block never refines on the pressure criterion
+    flat = prim.copy()
+    flat[4] = 1.0
+    assert oracle.tag("pressure_gradient", g, flat, 1e-3) == (-1, 0.0)
+    # 1-D: AmrTag::same
+    g1 = H.geom("euler", (16, 1, 1), ng)
+    p1 = H.random_prim("euler", (16, 1, 1), ng, seed=4)[0]
+    assert oracle.tag("pressure_gradient", g1, p1, 1e-3)[0] == 0
+
+
+# ---- GPU parity -------------------------------------------------------------------------------------------
+def _ctx(request, strict):
+    return request.getfixturevalue("gpu_ctx_strict" if strict else "gpu_ctx_fast")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("nx,ng,cng", GEOMS)
+def test_refine_plan_matches_oracle(request, oracle, nx, ng, cng, strict):
+    """Several blocks x (prolongate interior, prolongate a ghost slab, restrict cells, restrict
+    the three face fluxes) in one plan / one launch."""
+    import torch
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    dx = (0.01, 0.02, 0.04)
+    nvar, nblocks = 3, 3
+    dev = torch.device("cuda")
+    ops, checks = [], []
+    for b in range(nblocks):
+        xmin = (0.25 + b * 0.16, -0.5, 1.0 + 0.3 * b)
+        r = oracle.make_refine_geom(nx, ng, cng, xmin=xmin, dx=dx)
+        ndim = sum(1 for d in range(3) if d == 0 or nx[d] > 1)
+        fs, cs = r.dims()
+        coarse, fine = _fields(r, nvar, 10 + b, "rough" if b == 1 else "smooth")
+        lo, hi = _interior_box(r)
+        # ghost slab on the lower x1 side: coarse cells cng-1 (needs cng >= 2 for the stencil)
+        glo, ghi = list(lo), list(hi)
+        glo[0] = ghi[0] = r.cng - 1
+        want_f = fine.copy()
+        oracle.prolongate(r, coarse, want_f, lo, hi)
+        oracle.prolongate(r, coarse, want_f, glo, ghi)
+        cd, fd = torch.from_numpy(coarse).to(dev), torch.from_numpy(fine).to(dev)
+        ops += [("prolongate", cd, fd, lo, hi, xmin), ("prolongate", cd, fd, glo, ghi, xmin)]
+        checks.append((fd, want_f, "prolongate b%d" % b))
+        # restriction of cells into a second coarse buffer
+        src = np.random.default_rng(20 + b).uniform(-2, 2, (nvar,) + fs)
+        want_c = np.full((nvar,) + cs, 7.0)
+        oracle.restrict(r, 0, src, want_c, lo, hi)
+        sd, cd2 = torch.from_numpy(src).to(dev), torch.full((nvar,) + cs, 7.0, dtype=torch.float64, device=dev)
+        ops.append(("restrict_cell", sd, cd2, lo, hi, xmin))
+        checks.append((cd2, want_c, "restrict b%d" % b))
+        for el in range(1, ndim + 1):
+            ax = 3 - el
+            fshape = tuple(n + (1 if a == ax else 0) for a, n in enumerate(fs))
+            cshape = tuple(n + (1 if a == ax else 0) for a, n in enumerate(cs))
+            fl = np.random.default_rng(30 + b + el).uniform(-2, 2, (nvar,) + fshape)
+            want = np.zeros((nvar,) + cshape)
+            flo, fhi = list(lo), list(hi)
+            fhi[el - 1] += 1
+            oracle.restrict(r, el, fl, want, flo, fhi)
+            fld, cfd = torch.from_numpy(fl).to(dev), torch.zeros((nvar,) + cshape, dtype=torch.float64, device=dev)
+            ops.append(("restrict_face%d" % el, fld, cfd, flo, fhi, xmin))
+            checks.append((cfd, want, "flux%d b%d" % (el, b)))
+    plan = hydro.RefinePlan(ctx, nx, ng, cng, dx, nvar, ops)
+    plan.run()
+    torch.cuda.synchronize()
+    for t, want, what in checks:
+        got = t.cpu().numpy()
+        if strict:
+            assert np.array_equal(got, want), what
+        else:
+            assert np.abs(got - want).max() <= 1e-13 * max(1.0, np.abs(want).max()), what
+
+
+@pytest.mark.gpu
+def test_refine_plan_rejects_boxes_outside_the_buffer(request):
+    import torch
+    from athenapk_amd import hydro, lib as L
+    ctx = _ctx(request, True)
+    t = torch.zeros(3 * 12 * 12 * 12, dtype=torch.float64, device="cuda")
+    with pytest.raises(L.ApkError) as e:
+        hydro.RefinePlan(ctx, (8, 8, 8), 2, 2, (1, 1, 1), 1, [("prolongate", t, t, (0, 2, 2), (5, 5, 5), (0, 0, 0))])
+    assert e.value.code == L.APK_ERR_INVALID
+    with pytest.raises(L.ApkError):
+        hydro.RefinePlan(ctx, (8, 7, 1), 2, 2, (1, 1, 1), 1, [("restrict_cell", t, t, (2, 2, 0), (5, 5, 0), (0, 0, 0))])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx", [(16, 16, 16), (32, 16, 1)])
+def test_tag_blocks_matches_oracle(request, oracle, nx):
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    ng, nb = 2, 5
+    g = H.geom("glmmhd", nx, ng, 0, (0.1, 0.1, 0.1))
+    prim = H.random_prim("glmmhd", nx, ng, seed=8, kind="smooth", nblocks=nb)
+    prim[2, 4] = 1.0          # a block with flat pressure
+    prim[3, 0] *= 5.0         # a dense block
+    md = hydro.MeshData(ctx, nx, ng, 9, dx=tuple(g.dx), nblocks=nb, prim=prim, with_flux=False)
+    for crit, p0, p1 in (("pressure_gradient", 0.02, 0.0), ("xyvelocity_gradient", 0.03, 0.0), ("maxdensity", 4.0, 1.2)):
+        tags, vals = hydro.TagBlocks(md, crit, p0, p1)
+        want = [oracle.tag(crit, g, prim[b], p0, p1) for b in range(nb)]
+        assert list(tags) == [w[0] for w in want], crit
+        assert list(vals) == [w[1] for w in want], crit       # a max: order independent, bit exact
+        assert len(set(tags)) > 1

@@ -319,4 +319,4 @@ def test_cli_linear_wave_error_file(tmp_path, oracle):
     assert data[1, 3] == n
     want = [float("%e" % v) for v in [rms] + list(l1) + [np.max(mx / l1)] + list(mx)]
     assert list(data[1, 4:]) == want
-    assert data[1, 4] < data[0, 4] / 3.0   # second order
+    assert data[1, 4] < data[0, 4] / 2.5   # approaching second order (PLM, 16 -> 32 cells per wavelength)
