@@ -486,6 +486,149 @@ fused_march12_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_blo
   }
 }
 
+// ==============================================================================================
+// 3-D donor cell (the VL2 predictor): the WHOLE stage in one march, no du array at all.
+// A donor-cell face flux depends on the two adjacent cells only, so one lane can own a cell
+// column and produce all six of its face fluxes: lanes are the flattened (j, i) cells of the
+// interior rows of a block (62 useful lanes per wave, DPP wave shifts for the x1 faces as in the
+// x1 sweep), the wave marches along k carrying the lower x3 flux and the (x1 + x2) flux
+// difference of the previous plane in registers, and both x2 faces of a cell are solved by its
+// own lane from the rows j-1, j, j+1 (4 Riemann problems per cell instead of 3; the second x2
+// solve is bit-identical to the neighbour lane's, so the scheme stays conservative to the last
+// bit).  Traffic: prim in (the j+-1 rows hit L2), u1 in, u0 out = the algorithmic 216 B/cell
+// against 504 B/cell of the two-march schedule.  prim is only read, so no lane can observe a
+// half-updated state; FillDerived of the stage is left to ConservedToPrimitive.
+// ==============================================================================================
+template <int FLUID, int RS>
+__global__ void __launch_bounds__(64, kMarchMinWaves)
+fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg) {
+  constexpr int NV = nvars<FLUID>();
+  const int lane = threadIdx.x;
+  const int b = blockIdx.z;
+  const apk_block_desc b0 = u0.blocks[b];
+  const double *c1 = u1.blocks[b].cons;
+
+  const int64_t run = (int64_t)u0.nx2 * u0.ni;
+  const int64_t t = (int64_t)blockIdx.x * 62 + lane - 1;
+  const bool in_run = (t >= 0) && (t < run);
+  const int64_t tc = in_run ? t : (t < 0 ? 0 : run - 1);  // out-of-run lanes shadow a valid column
+  const int row = (int)(tc / u0.ni);
+  const int i = (int)(tc - (int64_t)row * u0.ni);
+  const bool active = in_run && (lane >= 1) && (lane <= 62) && (i >= u0.is) && (i <= u0.ie);
+
+  const int64_t col = (int64_t)(u0.js + row) * u0.sj + i;
+  const double *prim = b0.prim + col;
+  const double area1 = b0.dx[1] * b0.dx[2], area2 = b0.dx[0] * b0.dx[2], area3 = b0.dx[0] * b0.dx[1];
+  const double vol = b0.dx[0] * b0.dx[1] * b0.dx[2];
+  // the march is cut into gridDim.y segments of kseg planes: 2216 full-length waves on a machine
+  // with 2048 wave slots (256 VGPRs -> 2 per SIMD) would run in two rounds; many short waves
+  // keep every slot busy, for one redundant x3 solve per segment
+  const int s = u0.ks + blockIdx.y * kseg;
+  const int e = (s + kseg - 1 < u0.ke) ? s + kseg - 1 : u0.ke;
+
+  // State carried from plane to plane: the previous plane's primitives stay in VGPRs; the lower
+  // x3 flux and the (x1 + x2) flux difference wait in a private LDS stash (stash[slot][var][lane],
+  // conflict-free, no barrier: a lane only touches its own column), which keeps the kernel under
+  // 128 VGPRs = 4 waves per SIMD while an HLLD solve is in flight.
+  extern __shared__ __attribute__((aligned(16))) double stash[];
+  double *st_f3 = stash + lane;            // [q * 64]: permuted x3 flux at face c-1
+  double *st_du = stash + NV * 64 + lane;  // [n * 64]: (x1 term + x2 term) of plane c-1, natural order
+  double wprev[NV];                        // natural-order state of plane c-1
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    wprev[n] = prim[n * u0.sn + (int64_t)(s - 1) * u0.sk];
+    st_f3[n * 64] = 0.0;
+    st_du[n * 64] = 0.0;
+  }
+  double lane_unused = 0.0;
+  // The four Riemann problems of a cell are independent; left alone the scheduler interleaves them
+  // (HLLD keeps ~40 temporaries live per solve) and the kernel spills.  APK_CHAIN makes the
+  // inputs of the next solve depend on the outputs of the previous one, so they run back to back.
+#define APK_CHAIN(out, in)                                         \
+  _Pragma("unroll") for (int q_ = 0; q_ < NV; ++q_) asm volatile("" : "+v"(out[q_]), "+v"(in[q_]))
+  for (int c = s; c <= e + 1; ++c) {
+    const int64_t off = (int64_t)c * u0.sk;
+    double wc[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) wc[n] = prim[n * u0.sn + off];
+    // ---- x3 face c (between planes c-1 and c)
+    {
+      double wl3[NV], wr3[NV], f3[NV];
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        wl3[q] = wprev[perm<3>(q)];
+        wr3[q] = wc[perm<3>(q)];
+      }
+      riemann<FLUID, RS>(wl3, wr3, sp.gamma, sp.c_h, f3);
+      APK_CHAIN(f3, wc);
+      if (c >= s + 1) {
+        const int64_t done = col + (int64_t)(c - 1) * u0.sk;
+        double du[NV], u1v[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const int n = perm<3>(q);
+          du[n] = st_du[n * 64] + (area3 * f3[q] - area3 * st_f3[q * 64]);
+        }
+#pragma unroll
+        for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
+        if (active) finish_cell<FLUID, EXTRA_NONE>(u0, b0, u1v, done, du, vol, sp, lane_unused);
+      }
+#pragma unroll
+      for (int q = 0; q < NV; ++q) st_f3[q * 64] = f3[q];
+    }
+#pragma unroll
+    for (int n = 0; n < NV; ++n) wprev[n] = wc[n];
+    if (c <= e) {  // wave-uniform
+      // ---- x1 faces of plane c: L state from the lane on the left, upper flux from the right
+      {
+        double wl[NV], wr[NV], f[NV], d1[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          wr[q] = wc[perm<1>(q)];
+          wl[q] = wave_shr1(wr[q]);
+        }
+        riemann<FLUID, RS>(wl, wr, sp.gamma, sp.c_h, f);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const double fup = wave_shl1(f[q]);
+          d1[q] = (area1 * fup - area1 * f[q]);
+        }
+        APK_CHAIN(d1, wc);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) st_du[perm<1>(q) * 64] = d1[q];
+      }
+      // ---- x2 faces j and j+1 of this cell
+      double flo[NV];
+      {
+        double wm[NV], w2[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          wm[q] = prim[perm<2>(q) * u0.sn + off - u0.sj];
+          w2[q] = wc[perm<2>(q)];
+        }
+        riemann<FLUID, RS>(wm, w2, sp.gamma, sp.c_h, flo);
+        APK_CHAIN(flo, wc);
+      }
+      {
+        double wp[NV], w2[NV], fhi[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          wp[q] = prim[perm<2>(q) * u0.sn + off + u0.sj];
+          w2[q] = wc[perm<2>(q)];
+        }
+        riemann<FLUID, RS>(w2, wp, sp.gamma, sp.c_h, fhi);
+        APK_CHAIN(fhi, wc);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const int n = perm<2>(q);
+          st_du[n * 64] = st_du[n * 64] + (area2 * fhi[q] - area2 * flo[q]);
+        }
+      }
+    }
+  }
+#undef APK_CHAIN
+}
+
 // ---- launch helpers ---------------------------------------------------------------------------
 template <int FLUID, int RECON, int RS, int DIR>
 inline void launch_final_march(const PackView &u0, const PackView &u1, const StageParams &sp, int extra,
@@ -512,7 +655,17 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
   } else if (u0.ndim == 3) {
     constexpr int lds = march_lds_bytes<FLUID, RECON>();
     if constexpr (RECON == APK_RC_DC) {
-      // donor cell: the sweeps are HBM-bound, so x1 and x2 share ONE march over (k,i)-flattened
+      if (extra == EXTRA_NONE) {
+        // whole donor-cell stage in one march (see fused_dc3_kernel)
+        const int wpb = (int)((run + 61) / 62);
+        const int kseg = (u0.nx3 >= 32) ? 16 : u0.nx3;
+        const int nseg = (u0.nx3 + kseg - 1) / kseg;
+        ScopedTiming t(sp.ctx, TS + 0, s);
+        hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS>), dim3(wpb, nseg, u0.nblocks), dim3(64),
+                           2 * nvars<FLUID>() * 64 * (int)sizeof(double), s, u0, u1, sp, kseg);
+        return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
+      }
+      // (with FillDerived fused into the stage) donor cell: the sweeps are HBM-bound, so x1 and x2 share ONE march over (k,i)-flattened
       // lanes (one du round trip and one prim read less).  With a high-order reconstruction
       // the sweeps are ALU-bound and the 62/64 x 128/134 lane efficiency of the flattened march
       // (and its 2216-wave grid on a 2048-wave machine) costs more than the traffic it saves

@@ -745,7 +745,10 @@ int do_stage(apk_sim *s, int stage) {
     // let the finishing sweep do FillDerived (and, in the last stage, the dt estimate) on the
     // cells it updates; only the ghost zones are converted after the exchange
     // (not when the turbulence driver kicks the state after this stage)
-    fused_fill = (s->mesh.ndim >= 2) && a.dedner != 2 && !(s->fmft && stage == s->nstages);
+    // nor in a 3-D donor-cell stage (the VL2 predictor): its single-march kernel leaves prim
+    // untouched and the full ConservedToPrimitive pass is cheaper than the du round trip it avoids
+    fused_fill = (s->mesh.ndim >= 2) && a.dedner != 2 && !(s->fmft && stage == s->nstages) &&
+                 !(cfg.recon == APK_RC_DC && s->mesh.ndim == 3);
     a.fill_derived = fused_fill ? 1 : 0;
     a.estimate_dt = (fused_fill && stage == s->nstages && pkg.calc_dt_hyp) ? 1 : 0;
     SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));

@@ -102,18 +102,9 @@ dedner_kernel(PackView pv, double coeff, double beta_dt) {
 
 // ---- ConservedToPrimitive over the ENTIRE block (src/eos/adiabatic_hydro.cpp:33-55) -----
 template <int FLUID>
-__global__ void __launch_bounds__(256)
-cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags, int ghosts_only) {
+APK_DEV void cons_to_prim_at(const PackView &pv, const apk_block_desc &blk, const apk_eos &eos, unsigned *flags,
+                             int64_t cell) {
   constexpr int NV = nvars<FLUID>();
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  const int j = blockIdx.y * 4 + threadIdx.y;
-  const int b = blockIdx.z / pv.nk;
-  const int k = blockIdx.z % pv.nk;
-  if (i >= pv.ni || j >= pv.nj) return;
-  // ghost zones only: interior cells were converted by the finishing sweep of the fused stage
-  if (ghosts_only && i >= pv.is && i <= pv.ie && j >= pv.js && j <= pv.je && k >= pv.ks && k <= pv.ke) return;
-  const apk_block_desc blk = pv.blocks[b];
-  const int64_t cell = k * pv.sk + j * pv.sj + i;
   double u[NV], w[NV];
 #pragma unroll
   for (int n = 0; n < NV; ++n) u[n] = blk.cons[n * pv.sn + cell];
@@ -132,6 +123,57 @@ cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags, int ghosts_only) 
   for (int n = 0; n < NV; ++n) blk.prim[n * pv.sn + cell] = w[n];
   for (int n = NV; n < pv.nvar; ++n)  // passive scalars (:139-141)
     blk.prim[n * pv.sn + cell] = blk.cons[n * pv.sn + cell] * di;
+}
+
+template <int FLUID>
+__global__ void __launch_bounds__(256)
+cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int j = blockIdx.y * 4 + threadIdx.y;
+  const int b = blockIdx.z / pv.nk;
+  const int k = blockIdx.z % pv.nk;
+  if (i >= pv.ni || j >= pv.nj) return;
+  cons_to_prim_at<FLUID>(pv, pv.blocks[b], eos, flags, k * pv.sk + j * pv.sj + i);
+}
+
+// Ghost zones only (the interior was converted by the finishing sweep of the fused stage).  The
+// ghost shell of a block is enumerated as three groups of slabs so that no thread is launched
+// for an interior cell: x3 slabs (whole planes), x2 slabs of the interior planes (whole rows),
+// x1 slabs of the interior rows (2 ng cells per row).
+template <int FLUID>
+__global__ void __launch_bounds__(256)
+cons_to_prim_ghosts_kernel(PackView pv, apk_eos eos, unsigned *flags, int64_t na, int64_t nb_, int64_t nc) {
+  const int b = blockIdx.y;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int gk = pv.nk - pv.nx3, gj = pv.nj - pv.nx2, gi = pv.ni - pv.nx1;  // ghost layers (both sides)
+  int i, j, k;
+  if (t < na) {  // x3 slabs: (kk, j, i), i fastest
+    const int64_t plane = (int64_t)pv.nj * pv.ni;
+    const int kk = (int)(t / plane);
+    const int64_t r = t - kk * plane;
+    j = (int)(r / pv.ni);
+    i = (int)(r - (int64_t)j * pv.ni);
+    k = (kk < gk / 2) ? kk : pv.ke + 1 + (kk - gk / 2);
+  } else if (t < na + nb_) {  // x2 slabs of interior planes: (k, jj, i)
+    const int64_t q = t - na;
+    const int64_t per = (int64_t)gj * pv.ni;
+    k = pv.ks + (int)(q / per);
+    const int64_t r = q - (int64_t)(k - pv.ks) * per;
+    const int jj = (int)(r / pv.ni);
+    i = (int)(r - (int64_t)jj * pv.ni);
+    j = (jj < gj / 2) ? jj : pv.je + 1 + (jj - gj / 2);
+  } else if (t < na + nb_ + nc) {  // x1 slabs of interior rows: (k, j, ii)
+    const int64_t q = t - na - nb_;
+    const int64_t per = (int64_t)pv.nx2 * gi;
+    k = pv.ks + (int)(q / per);
+    const int64_t r = q - (int64_t)(k - pv.ks) * per;
+    j = pv.js + (int)(r / gi);
+    const int ii = (int)(r - (int64_t)(j - pv.js) * gi);
+    i = (ii < gi / 2) ? ii : pv.ie + 1 + (ii - gi / 2);
+  } else {
+    return;
+  }
+  cons_to_prim_at<FLUID>(pv, pv.blocks[b], eos, flags, k * pv.sk + j * pv.sj + i);
 }
 
 // ---- wave/workgroup reductions -------------------------------------------------------------
@@ -367,13 +409,22 @@ int launch_dedner(const PackView &pv, int extended, double coeff, double beta_dt
 
 int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsigned *d_flags,
                         hipStream_t s, bool ghosts_only) {
+  if (ghosts_only) {
+    const int64_t na = (int64_t)(pv.nk - pv.nx3) * pv.nj * pv.ni;
+    const int64_t nb = (int64_t)pv.nx3 * (pv.nj - pv.nx2) * pv.ni;
+    const int64_t nc = (int64_t)pv.nx3 * pv.nx2 * (pv.ni - pv.nx1);
+    const dim3 grid((unsigned)((na + nb + nc + 255) / 256), pv.nblocks, 1);
+    if (fluid == APK_FLUID_EULER)
+      hipLaunchKernelGGL(cons_to_prim_ghosts_kernel<APK_FLUID_EULER>, grid, dim3(256), 0, s, pv, eos, d_flags, na, nb, nc);
+    else
+      hipLaunchKernelGGL(cons_to_prim_ghosts_kernel<APK_FLUID_GLMMHD>, grid, dim3(256), 0, s, pv, eos, d_flags, na, nb, nc);
+    return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
+  }
   dim3 grid((pv.ni + 63) / 64, (pv.nj + 3) / 4, pv.nk * pv.nblocks);
   if (fluid == APK_FLUID_EULER)
-    hipLaunchKernelGGL(cons_to_prim_kernel<APK_FLUID_EULER>, grid, dim3(64, 4, 1), 0, s, pv, eos,
-                       d_flags, (int)ghosts_only);
+    hipLaunchKernelGGL(cons_to_prim_kernel<APK_FLUID_EULER>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags);
   else
-    hipLaunchKernelGGL(cons_to_prim_kernel<APK_FLUID_GLMMHD>, grid, dim3(64, 4, 1), 0, s, pv, eos,
-                       d_flags, (int)ghosts_only);
+    hipLaunchKernelGGL(cons_to_prim_kernel<APK_FLUID_GLMMHD>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags);
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }
 

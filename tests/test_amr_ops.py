@@ -211,9 +211,13 @@ def test_tag_blocks_matches_oracle(request, oracle, nx):
     prim[2, 4] = 1.0          # a block with flat pressure
     prim[3, 0] *= 5.0         # a dense block
     md = hydro.MeshData(ctx, nx, ng, 9, dx=tuple(g.dx), nblocks=nb, prim=prim, with_flux=False)
-    for crit, p0, p1 in (("pressure_gradient", 0.02, 0.0), ("xyvelocity_gradient", 0.03, 0.0), ("maxdensity", 4.0, 1.2)):
+    for crit in ("pressure_gradient", "xyvelocity_gradient", "maxdensity"):
+        # thresholds between the blocks' criterion values, so that the pack holds several tags
+        vals_o = sorted(oracle.tag(crit, g, prim[b], 1e300, 0.0)[1] for b in range(nb))
+        p0 = 0.5 * (vals_o[-1] + vals_o[-2])
+        p1 = 0.5 * (vals_o[0] + vals_o[1])
         tags, vals = hydro.TagBlocks(md, crit, p0, p1)
         want = [oracle.tag(crit, g, prim[b], p0, p1) for b in range(nb)]
         assert list(tags) == [w[0] for w in want], crit
         assert list(vals) == [w[1] for w in want], crit       # a max: order independent, bit exact
-        assert len(set(tags)) > 1
+        assert len(set(tags)) > 1, crit
