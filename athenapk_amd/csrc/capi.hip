@@ -233,6 +233,14 @@ int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
     return set_err(ctx, APK_ERR_UNSUPPORTED, "fused stage: none/llf solvers use the flux-array path");
   if (a->dedner != 0 && (a->cfg.fluid != APK_FLUID_GLMMHD || !(a->mindx > 0.0)))
     return set_err(ctx, APK_ERR_INVALID, "fused stage: Dedner source needs glmmhd and mindx > 0");
+  if (a->fill_derived < 0 || a->fill_derived > 2) return set_err(ctx, APK_ERR_INVALID, "fused stage: fill_derived must be 0, 1 or 2");
+  if (a->fill_derived == 2) {
+    for (const apk_block_desc &b : u1->h_blocks)
+      if (!b.prim) return set_err(ctx, APK_ERR_INVALID, "fused stage: fill_derived = 2 needs prim arrays in u1");
+    for (size_t b = 0; b < u0->h_blocks.size(); ++b)
+      if (u0->h_blocks[b].prim == u1->h_blocks[b].prim)
+        return set_err(ctx, APK_ERR_INVALID, "fused stage: fill_derived = 2 needs u1.prim distinct from u0.prim");
+  }
   double coeff = 1.0;
   if (a->dedner != 0) coeff = std::exp(-a->glmmhd_alpha * a->c_h * a->beta_dt / a->mindx);
   rc = launch_stage_fused(ctx, u0->view, u1->view, *a, coeff, as_stream(stream));

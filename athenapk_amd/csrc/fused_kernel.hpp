@@ -33,6 +33,7 @@ struct StageParams {
   apk_eos eos;                   // floors / ceilings for the in-place ConsToPrim
   unsigned *flags;               // latched APK_FLAG_* word
   unsigned long long *dt_bits;   // min over cells of dx_d/(|v_d|+c_d), as ordered bits
+  int prim_to_u1;                // fill_derived = 2: the new primitives go to u1's prim arrays
   apk_ctx *ctx;  // host side only (kernel timing); never dereferenced on the device
 };
 
@@ -60,7 +61,7 @@ template <int FLUID, int EXTRA = EXTRA_NONE>
 APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
                          const double (&u1v)[nvars<FLUID>()], int64_t cell,
                          const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp,
-                         double &lane_min_dt) {
+                         double &lane_min_dt, double *prim_dst = nullptr) {
   constexpr int NV = nvars<FLUID>();
   double un[NV];
 #pragma unroll
@@ -90,12 +91,14 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
   if constexpr (EXTRA != EXTRA_NONE) {
     // FillDerived for this cell (adiabatic_hydro.hpp:52-142): in a march along x2/x3 no other lane
     // reads this column of prim during the sweep and this lane's stencil copy sits in its LDS
-    // ring, so prim can be replaced in place.  Floors/ceilings act on `un` before it is stored.
+    // ring, so prim can be replaced in place (prim_dst = this block's prim); kernels whose lanes
+    // read neighbouring columns from memory get prim_dst = u1's prim arrays instead.
+    // Floors/ceilings act on `un` before it is stored.
     double w[NV], di;
     const unsigned fl = cons_to_prim_cell<FLUID>(sp.eos, un, w, di);
     if (fl) atomicOr(sp.flags, fl);
 #pragma unroll
-    for (int n = 0; n < NV; ++n) b0.prim[n * pv.sn + cell] = w[n];
+    for (int n = 0; n < NV; ++n) prim_dst[n * pv.sn + cell] = w[n];
     if constexpr (EXTRA == EXTRA_C2P_DT) {
       // EstimateHyperbolicTimestep (hydro.cpp:845-895) on the fresh primitives
       double lx, ly = 0.0, lz = 0.0;
@@ -237,6 +240,7 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp) {
   const double vol = b0.dx[0] * b0.dx[1] * b0.dx[2];
   double *dscratch = sp.du + (int64_t)b * u0.sn * u0.nvar;
   const double *prim = b0.prim + base;
+  double *prim_dst = (EXTRA != EXTRA_NONE && sp.prim_to_u1) ? u1.blocks[b].prim : b0.prim;
 
   // row r of the stencil lives in slot (r - (s-1-H)) mod NS
   int c = s - 1;
@@ -322,7 +326,7 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp) {
         }
         if (active) {
           if constexpr (FINAL) {
-            finish_cell<FLUID, EXTRA>(u0, b0, u1v, cell, du, vol, sp, lane_min_dt);
+            finish_cell<FLUID, EXTRA>(u0, b0, u1v, cell, du, vol, sp, lane_min_dt, prim_dst);
           } else {
 #pragma unroll
             for (int n = 0; n < NV; ++n) dscratch[n * u0.sn + cell] = du[n];
@@ -499,14 +503,16 @@ fused_march12_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_blo
 // against 504 B/cell of the two-march schedule.  prim is only read, so no lane can observe a
 // half-updated state; FillDerived of the stage is left to ConservedToPrimitive.
 // ==============================================================================================
-template <int FLUID, int RS>
+template <int FLUID, int RS, int EXTRA = EXTRA_NONE>
 __global__ void __launch_bounds__(64, kMarchMinWaves)
 fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg) {
   constexpr int NV = nvars<FLUID>();
+  double lane_min_dt = 1.7976931348623157e308;
   const int lane = threadIdx.x;
   const int b = blockIdx.z;
   const apk_block_desc b0 = u0.blocks[b];
   const double *c1 = u1.blocks[b].cons;
+  double *prim_dst = u1.blocks[b].prim;  // EXTRA != NONE only (never in place here)
 
   const int64_t run = (int64_t)u0.nx2 * u0.ni;
   const int64_t t = (int64_t)blockIdx.x * 62 + lane - 1;
@@ -540,7 +546,6 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg) {
     st_f3[n * 64] = 0.0;
     st_du[n * 64] = 0.0;
   }
-  double lane_unused = 0.0;
   // The four Riemann problems of a cell are independent; left alone the scheduler interleaves them
   // (HLLD keeps ~40 temporaries live per solve) and the kernel spills.  APK_CHAIN makes the
   // inputs of the next solve depend on the outputs of the previous one, so they run back to back.
@@ -571,7 +576,7 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg) {
         }
 #pragma unroll
         for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
-        if (active) finish_cell<FLUID, EXTRA_NONE>(u0, b0, u1v, done, du, vol, sp, lane_unused);
+        if (active) finish_cell<FLUID, EXTRA>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst);
       }
 #pragma unroll
       for (int q = 0; q < NV; ++q) st_f3[q * 64] = f3[q];
@@ -627,6 +632,12 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg) {
     }
   }
 #undef APK_CHAIN
+  if constexpr (EXTRA == EXTRA_C2P_DT) {
+    double m = lane_min_dt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_down(m, off, 64));
+    if (lane == 0) atomicMin(sp.dt_bits, (unsigned long long)__double_as_longlong(m));
+  }
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------
@@ -655,14 +666,20 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
   } else if (u0.ndim == 3) {
     constexpr int lds = march_lds_bytes<FLUID, RECON>();
     if constexpr (RECON == APK_RC_DC) {
-      if (extra == EXTRA_NONE) {
-        // whole donor-cell stage in one march (see fused_dc3_kernel)
+      if (extra == EXTRA_NONE || sp.prim_to_u1) {
+        // whole donor-cell stage in one march (see fused_dc3_kernel); its FillDerived is out of place
         const int wpb = (int)((run + 61) / 62);
         const int kseg = (u0.nx3 >= 32) ? 16 : u0.nx3;
         const int nseg = (u0.nx3 + kseg - 1) / kseg;
+        const dim3 g(wpb, nseg, u0.nblocks);
+        constexpr int lds3 = 2 * nvars<FLUID>() * 64 * (int)sizeof(double);
         ScopedTiming t(sp.ctx, TS + 0, s);
-        hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS>), dim3(wpb, nseg, u0.nblocks), dim3(64),
-                           2 * nvars<FLUID>() * 64 * (int)sizeof(double), s, u0, u1, sp, kseg);
+        if (extra == EXTRA_C2P_DT)
+          hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_C2P_DT>), g, dim3(64), lds3, s, u0, u1, sp, kseg);
+        else if (extra == EXTRA_C2P)
+          hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_C2P>), g, dim3(64), lds3, s, u0, u1, sp, kseg);
+        else
+          hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_NONE>), g, dim3(64), lds3, s, u0, u1, sp, kseg);
         return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
       }
       // (with FillDerived fused into the stage) donor cell: the sweeps are HBM-bound, so x1 and x2 share ONE march over (k,i)-flattened

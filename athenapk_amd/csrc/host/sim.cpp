@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <sstream>
@@ -505,34 +506,46 @@ void dev_free(apk_sim *s, double *p) {
 
 int build_packs(apk_sim *s) {
   const int nlb = (int)s->mesh.local_gids.size();
-  for (int p = 0; p < 2; ++p) {
-    if (s->mu0_of[p]) apk_pack_destroy(s->mu0_of[p]);
-    if (s->mu1_of[p]) apk_pack_destroy(s->mu1_of[p]);
-    s->mu0_of[p] = s->mu1_of[p] = nullptr;
-    std::vector<apk_block_desc> b0(nlb), b1(nlb);
-    for (int lb = 0; lb < nlb; ++lb) {
-      b0[lb].cons = s->d_cons2[p] + lb * s->nper;
-      b0[lb].prim = s->d_prim + lb * s->nper;
-      b1[lb].cons = s->d_cons2[p] + lb * s->nper;
-      b1[lb].prim = nullptr;
-      for (int d = 0; d < 3; ++d) {
-        b0[lb].flux[d] = s->d_flux[d] ? s->d_flux[d] + lb * s->nper : nullptr;
-        b1[lb].flux[d] = nullptr;
-        b0[lb].dx[d] = b1[lb].dx[d] = s->dx[d];
+  for (int p = 0; p < 2; ++p)
+    for (int w = 0; w < 2; ++w) {
+      if (s->mu0_of[p][w]) apk_pack_destroy(s->mu0_of[p][w]);
+      if (s->mu1_of[p][w]) apk_pack_destroy(s->mu1_of[p][w]);
+      s->mu0_of[p][w] = s->mu1_of[p][w] = nullptr;
+      if (!s->d_prim2[w]) continue;
+      double *spare = s->d_prim2[1 - w];  // may be null: then u1 carries no prim
+      std::vector<apk_block_desc> b0(nlb), b1(nlb);
+      for (int lb = 0; lb < nlb; ++lb) {
+        b0[lb].cons = s->d_cons2[p] + lb * s->nper;
+        b0[lb].prim = s->d_prim2[w] + lb * s->nper;
+        b1[lb].cons = s->d_cons2[p] + lb * s->nper;
+        b1[lb].prim = spare ? spare + lb * s->nper : nullptr;
+        for (int d = 0; d < 3; ++d) {
+          b0[lb].flux[d] = s->d_flux[d] ? s->d_flux[d] + lb * s->nper : nullptr;
+          b1[lb].flux[d] = nullptr;
+          b0[lb].dx[d] = b1[lb].dx[d] = s->dx[d];
+        }
       }
+      apk_pack_desc d{};
+      d.nblocks = nlb;
+      d.nhydro = s->pkg.nhydro;
+      d.nscalars = s->pkg.nscalars;
+      for (int q = 0; q < 3; ++q) d.nx[q] = s->mesh.mb[q];
+      d.ng = s->mesh.ng;
+      d.blocks = b0.data();
+      SIM_TRY(s, apk_pack_create(s->ctx, &d, &s->mu0_of[p][w]));
+      d.blocks = b1.data();
+      SIM_TRY(s, apk_pack_create(s->ctx, &d, &s->mu1_of[p][w]));
     }
-    apk_pack_desc d{};
-    d.nblocks = nlb;
-    d.nhydro = s->pkg.nhydro;
-    d.nscalars = s->pkg.nscalars;
-    for (int q = 0; q < 3; ++q) d.nx[q] = s->mesh.mb[q];
-    d.ng = s->mesh.ng;
-    d.blocks = b0.data();
-    SIM_TRY(s, apk_pack_create(s->ctx, &d, &s->mu0_of[p]));
-    d.blocks = b1.data();
-    SIM_TRY(s, apk_pack_create(s->ctx, &d, &s->mu1_of[p]));
-  }
   return APK_OK;
+}
+
+// second primitive buffer, on first use
+int ensure_spare_prim(apk_sim *s) {
+  if (s->d_prim2[1 - s->pcur]) return APK_OK;
+  const size_t bytes = (size_t)s->nper * s->mesh.local_gids.size() * sizeof(double);
+  SIM_TRY(s, dev_alloc(s, "prim2", bytes, &s->d_prim2[1 - s->pcur]));
+  SIM_HIP(s, hipMemsetAsync(s->d_prim2[1 - s->pcur], 0, bytes, hs(s)));
+  return build_packs(s);
 }
 
 int ensure_flux_arrays(apk_sim *s) {
@@ -546,7 +559,7 @@ int ensure_flux_arrays(apk_sim *s) {
       changed = true;
     }
   }
-  if (changed || !s->mu0_of[0]) return build_packs(s);
+  if (changed || !s->mu0()) return build_packs(s);
   return APK_OK;
 }
 
@@ -747,12 +760,24 @@ int do_stage(apk_sim *s, int stage) {
     // (not when the turbulence driver kicks the state after this stage)
     // nor in a 3-D donor-cell stage (the VL2 predictor): its single-march kernel leaves prim
     // untouched and the full ConservedToPrimitive pass is cheaper than the du round trip it avoids
-    fused_fill = (s->mesh.ndim >= 2) && a.dedner != 2 && !(s->fmft && stage == s->nstages) &&
-                 !(cfg.recon == APK_RC_DC && s->mesh.ndim == 3);
-    a.fill_derived = fused_fill ? 1 : 0;
+    fused_fill = (s->mesh.ndim >= 2) && a.dedner != 2 && !(s->fmft && stage == s->nstages);
+    // A 3-D donor-cell stage (the VL2 predictor) runs as ONE march whose lanes read their
+    // neighbours' primitives from memory, so it cannot replace prim in place: it writes the new
+    // primitives into the spare buffer ("u1.prim") and the two prim buffers swap roles.
+    static const int dc_mode = std::getenv("APK_DC_MODE") ? std::atoi(std::getenv("APK_DC_MODE")) : 2;  // A/B switch
+    const bool dc3 = cfg.recon == APK_RC_DC && s->mesh.ndim == 3 && dc_mode != 0;
+    bool swap_prim = false;
+    if (dc3 && fused_fill && dc_mode == 2) {
+      SIM_TRY(s, ensure_spare_prim(s));
+      swap_prim = true;
+    } else if (dc3) {
+      fused_fill = false;  // dc_mode 1: single march, separate full ConservedToPrimitive
+    }
+    a.fill_derived = fused_fill ? (swap_prim ? 2 : 1) : 0;
     a.estimate_dt = (fused_fill && stage == s->nstages && pkg.calc_dt_hyp) ? 1 : 0;
     SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
     s->stage_dt_pending = a.estimate_dt != 0;
+    if (swap_prim) s->pcur = 1 - s->pcur;
   } else {
     SIM_TRY(s, ensure_flux_arrays(s));
     SIM_TRY(s, apk_calculate_fluxes(s->ctx, s->mu0(), cfg, &pkg.eos, pkg.c_h, s->stream));
@@ -853,9 +878,9 @@ int apk_sim_create(const char *deck, const char *const *overrides, int noverride
   const size_t nlb = s->mesh.local_gids.size();
   const size_t bytes = (size_t)s->nper * nlb * sizeof(double);
   if ((rc = dev_alloc(s, "cons", bytes, &s->d_cons2[0])) != APK_OK) return bail(rc);
-  if ((rc = dev_alloc(s, "prim", bytes, &s->d_prim)) != APK_OK) return bail(rc);
+  if ((rc = dev_alloc(s, "prim", bytes, &s->d_prim2[0])) != APK_OK) return bail(rc);
   if ((rc = dev_alloc(s, "u1", bytes, &s->d_cons2[1])) != APK_OK) return bail(rc);
-  if (hipMemset(s->d_cons2[0], 0, bytes) != hipSuccess || hipMemset(s->d_prim, 0, bytes) != hipSuccess ||
+  if (hipMemset(s->d_cons2[0], 0, bytes) != hipSuccess || hipMemset(s->d_prim2[0], 0, bytes) != hipSuccess ||
       hipMemset(s->d_cons2[1], 0, bytes) != hipSuccess) {
     s->err = "hipMemset failed";
     return bail(APK_ERR_DEVICE);
@@ -885,15 +910,17 @@ void apk_sim_destroy(apk_sim *s) {
     (void)hipDeviceSynchronize();
     for (auto &pp : s->plans_of)
       for (auto &p : pp) apk_copy_plan_destroy(p);
-    for (int p = 0; p < 2; ++p) {
-      apk_pack_destroy(s->mu0_of[p]);
-      apk_pack_destroy(s->mu1_of[p]);
-    }
+    for (int p = 0; p < 2; ++p)
+      for (int w = 0; w < 2; ++w) {
+        apk_pack_destroy(s->mu0_of[p][w]);
+        apk_pack_destroy(s->mu1_of[p][w]);
+      }
     apk_fmft_destroy(s->fm_dev);
     dev_free(s, s->d_acc);
     dev_free(s, s->d_phases);
     dev_free(s, s->d_cons2[0]);
-    dev_free(s, s->d_prim);
+    dev_free(s, s->d_prim2[0]);
+    dev_free(s, s->d_prim2[1]);
     dev_free(s, s->d_cons2[1]);
     for (auto *f : s->d_flux) dev_free(s, f);
     for (auto *b : s->send_buf) dev_free(s, b);
@@ -1026,7 +1053,7 @@ int apk_sim_block_location(const apk_sim *s, int lb, int *gid, int loc[3]) {
 
 void *apk_sim_block_ptr(const apk_sim *s, int lb, int field) {
   if (!s || s->host_only || lb < 0 || lb >= (int)s->mesh.local_gids.size()) return nullptr;
-  double *base = field == 0 ? s->d_cons() : (field == 1 ? s->d_prim : (field == 2 ? s->d_cons2[s->u1buf] : nullptr));
+  double *base = field == 0 ? s->d_cons() : (field == 1 ? s->d_prim() : (field == 2 ? s->d_cons2[s->u1buf] : nullptr));
   return base ? base + (int64_t)lb * s->nper : nullptr;
 }
 

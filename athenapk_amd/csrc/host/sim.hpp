@@ -81,15 +81,22 @@ struct apk_sim {
   double *d_cons2[2] = {nullptr, nullptr};
   int cur = 0;    // buffer holding the current state u0 ("base")
   int u1buf = 1;  // buffer holding the register u1 of the step in flight
-  double *d_prim = nullptr, *d_flux[3] = {nullptr, nullptr, nullptr};
+  // Two primitive-variable buffers as well (the second one is allocated on first use): a stage
+  // whose finishing kernel cannot replace prim in place (3-D donor cell, see fused_dc3_kernel)
+  // writes the new primitives into the other buffer and the roles swap.
+  double *d_prim2[2] = {nullptr, nullptr};
+  int pcur = 0;  // buffer holding the primitives of the current state
+  double *d_flux[3] = {nullptr, nullptr, nullptr};
   std::vector<double *> send_buf, recv_buf;
   // per buffer: the pack presenting it as MeshData "base" (with prim/flux), the pack presenting it
-  // as "u1" (cons only), and the ghost-exchange plans that target it
-  apk_pack *mu0_of[2] = {nullptr, nullptr}, *mu1_of[2] = {nullptr, nullptr};
+  // as "u1" (cons, plus the spare prim buffer when there is one), and the ghost-exchange plans that target it
+  // [cons buffer][prim buffer]; mu1 packs carry the OTHER prim buffer's arrays as "u1.prim"
+  apk_pack *mu0_of[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *mu1_of[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   apk_copy_plan *plans_of[2][apk::PH_COUNT] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
                                                {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
-  apk_pack *mu0() const { return mu0_of[cur]; }
-  apk_pack *mu1() const { return mu1_of[u1buf]; }
+  apk_pack *mu0() const { return mu0_of[cur][pcur]; }
+  apk_pack *mu1() const { return mu1_of[u1buf][pcur]; }
+  double *d_prim() const { return d_prim2[pcur]; }
   apk_copy_plan *plan(int ph) const { return plans_of[cur][ph]; }
   double *d_cons() const { return d_cons2[cur]; }
   // few-modes turbulence driver (problem_id = turbulence; src/pgen/turbulence.cpp:103-200)

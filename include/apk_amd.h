@@ -151,6 +151,11 @@ typedef struct apk_stage_args {
    *                    (Update::FillDerived, hydro_driver.cpp:571-577).  The caller then only
    *                    needs apk_cons_to_prim_ghosts() after the ghost exchange.  Not in 1-D,
    *                    not with dedner == 2 (APK_ERR_UNSUPPORTED).
+   *  fill_derived = 2: the same, but the new primitives are written into u1's prim arrays
+   *                    ("u1.prim", which AthenaPK also carries: hydro_driver.cpp:484-493) and
+   *                    u0's are left untouched; the caller swaps the roles of the two prim
+   *                    arrays afterwards.  This is what lets a 3-D donor-cell stage (the VL2
+   *                    predictor) run as a single march with no flux-difference array at all.
    *  estimate_dt  = 1: (needs fill_derived) also min-reduce dx_d/(|v_d|+c_d) over those cells
    *                    (EstimateHyperbolicTimestep, hydro.cpp:828-896); read it with
    *                    apk_stage_dt_read(). */

@@ -355,6 +355,52 @@ def test_fused_stage_fill_derived_and_dt(request, oracle, fluid, recon, riemann,
     assert np.array_equal(H.interior(ghosts_before, nx, ng), H.interior(m0.prim_host(), nx, ng))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("fluid,recon,riemann,nx,gam0", [("glmmhd", "dc", "hlld", (64, 8, 34), 0.0),
+                                                         ("glmmhd", "dc", "hlle", (70, 9, 7), 0.5),
+                                                         ("euler", "dc", "hllc", (66, 10, 6), 0.0),
+                                                         ("euler", "dc", "hlle", (64, 8, 8), 0.0),
+                                                         ("glmmhd", "ppm", "hlld", (70, 9, 7), 0.0),
+                                                         ("euler", "plm", "hllc", (66, 10, 1), 0.5)])
+def test_fused_stage_fill_derived_out_of_place(request, oracle, fluid, recon, riemann, nx, gam0, strict):
+    """fill_derived = 2: the new primitives land in u1's prim arrays, u0.prim stays as it was.
+    For 3-D donor cell this is the single-march kernel (fused_dc3_kernel), incl. its k segments
+    (nx3 = 34 -> 16 + 16 + 2 planes)."""
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    ng, prim, g = _case(fluid, recon, nx, kind="smooth", seed=43)
+    cons = H.prim_to_cons(fluid, prim, GAMMA)
+    u1c = cons * 1.01 if gam0 != 0.0 else cons
+    ded = 1 if fluid == "glmmhd" else 0
+    eos_kw = dict(pfloor=1e-6, dfloor=1e-6)
+    sentinel = np.full_like(prim, -7.0)
+    m0 = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=prim.shape[0], cons=cons, prim=prim,
+                        with_flux=False)
+    m1 = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=prim.shape[0], cons=u1c, prim=sentinel,
+                        with_flux=False)
+    ctx.poll_flags()
+    hydro.StageFused(m0, m1, fluid, recon, riemann, hydro.L.make_eos(GAMMA, **eos_kw), C_H, gam0, 1.0 - gam0, 0.004,
+                     dedner=ded, glmmhd_alpha=0.1, mindx=0.07, fill_derived=2, estimate_dt=True)
+    dt = hydro.StageDt(ctx, 0.3)
+    want_cons = H.orc_stage(fluid, recon, riemann, g, cons, u1c, prim, GAMMA, C_H, gam0, 1.0 - gam0, 0.004,
+                            dedner=ded, alpha=0.1, mindx=0.07)
+    want_cons, want_prim, bad = H.orc_c2p(fluid, g, want_cons, oracle.make_eos(GAMMA, **eos_kw))
+    assert bad == 0 and ctx.poll_flags() == 0
+    _cmp(H.interior(m0.cons_host(), nx, ng), H.interior(want_cons, nx, ng), strict, "cons")
+    _cmp(H.interior(m1.prim_host(), nx, ng), H.interior(want_prim, nx, ng), strict, "u1.prim (interior)")
+    assert np.array_equal(m0.prim_host(), prim), "u0.prim must not be touched"
+    got1 = m1.prim_host()
+    mask = np.ones(got1.shape, dtype=bool)
+    H.interior(mask, nx, ng)[...] = False
+    assert np.all(got1[mask] == -7.0), "ghost zones of u1.prim must not be touched"
+    want_dt = 0.3 * H.orc_min_dt(fluid, g, want_prim, GAMMA)
+    if strict:
+        assert dt == want_dt
+    else:
+        assert dt == pytest.approx(want_dt, rel=1e-12)
+
+
 def test_fused_fill_derived_rejected_where_unsafe(request):
     from athenapk_amd import hydro
     from athenapk_amd import lib as L
@@ -367,6 +413,10 @@ def test_fused_fill_derived_rejected_where_unsafe(request):
         hydro.StageFused(m0, m0, "glmmhd", "ppm", "hlld", L.make_eos(GAMMA), C_H, 0.0, 1.0, 1e-3, dedner=1,
                          mindx=0.1, fill_derived=True)
     assert e.value.code == L.APK_ERR_UNSUPPORTED
+    with pytest.raises(L.ApkError) as e:  # out of place needs a second prim array
+        hydro.StageFused(m0, m0, "glmmhd", "ppm", "hlld", L.make_eos(GAMMA), C_H, 0.0, 1.0, 1e-3, dedner=1,
+                         mindx=0.1, fill_derived=2)
+    assert e.value.code == L.APK_ERR_INVALID
 
 
 # ---- few-modes turbulence driver kernels ------------------------------------------------------------
