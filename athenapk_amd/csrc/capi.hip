@@ -233,6 +233,9 @@ int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
     return set_err(ctx, APK_ERR_UNSUPPORTED, "fused stage: none/llf solvers use the flux-array path");
   if (a->dedner != 0 && (a->cfg.fluid != APK_FLUID_GLMMHD || !(a->mindx > 0.0)))
     return set_err(ctx, APK_ERR_INVALID, "fused stage: Dedner source needs glmmhd and mindx > 0");
+  if (a->phase < 0 || a->phase > 2 || (a->phase == 1) != (a->x1_window != nullptr) ||
+      (a->phase == 1 && (a->x1_window_rl < 3 || a->x1_window_rl > u0->view.ni)))
+    return set_err(ctx, APK_ERR_INVALID, "fused stage: phase / x1_window mismatch");
   if (a->fill_derived < 0 || a->fill_derived > 2) return set_err(ctx, APK_ERR_INVALID, "fused stage: fill_derived must be 0, 1 or 2");
   if (a->fill_derived == 2) {
     for (const apk_block_desc &b : u1->h_blocks)
@@ -244,7 +247,7 @@ int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
   double coeff = 1.0;
   if (a->dedner != 0) coeff = std::exp(-a->glmmhd_alpha * a->c_h * a->beta_dt / a->mindx);
   rc = launch_stage_fused(ctx, u0->view, u1->view, *a, coeff, as_stream(stream));
-  if (rc == APK_ERR_UNSUPPORTED) return set_err(ctx, rc, "fused stage: option combination not supported (scalars, 1-D/extended-Dedner fill_derived)");
+  if (rc == APK_ERR_UNSUPPORTED) return set_err(ctx, rc, "fused stage: option combination not supported (scalars, 1-D/extended-Dedner fill_derived, split 1-D or 3-D donor-cell stage)");
   if (rc != APK_OK) return set_err(ctx, rc, "fused stage kernel launch failed", hipGetLastError());
   return APK_OK;
 }

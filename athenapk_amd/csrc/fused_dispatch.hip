@@ -22,6 +22,9 @@ int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
   sp.dt_bits = ctx->d_u64 + 4;  // word 4: min of the finishing sweep (apk_stage_dt_read)
   int extra = EXTRA_NONE;
   sp.prim_to_u1 = (a.fill_derived == 2) ? 1 : 0;
+  sp.phase = a.phase;
+  sp.x1_window = (a.phase == 1) ? a.x1_window : nullptr;
+  sp.x1_window_rl = a.x1_window_rl;
   if (a.fill_derived) {
     // in-place prim replacement is only safe when the finishing sweep is a march (x2/x3) and
     // the extended Dedner source does not read neighbouring primitives

@@ -34,6 +34,11 @@ struct StageParams {
   unsigned *flags;               // latched APK_FLAG_* word
   unsigned long long *dt_bits;   // min over cells of dx_d/(|v_d|+c_d), as ordered bits
   int prim_to_u1;                // fill_derived = 2: the new primitives go to u1's prim arrays
+  // optional per-block column window of the x1 sweep (apk_stage_args.x1_window): {i0, rl, lo, hi}:
+  // rows are flattened with length rl starting at column i0 and only cells lo..hi retire
+  const int *x1_window;
+  int x1_window_rl;  // largest rl in x1_window (sizes the grid)
+  int phase;         // apk_stage_args.phase
   apk_ctx *ctx;  // host side only (kernel timing); never dereferenced on the device
 };
 
@@ -135,10 +140,20 @@ fused_x1_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_plane) {
   const int k = u0.ks + blockIdx.y % u0.nx3;
   const apk_block_desc b0 = u0.blocks[b];
 
-  const int64_t run = (int64_t)u0.nx2 * u0.ni;  // contiguous cells of this plane's interior rows
+  // The interior rows of this plane are flattened into one run of cells, `rl` per row starting at
+  // column i0 (the whole row by default; a thin window next to a face when the sweep is split
+  // around a halo exchange that is still in flight).  Ghost / window-edge columns separate the rows.
+  int i0 = 0, rl = u0.ni, lo = u0.is, hi = u0.ie;
+  if (sp.x1_window) {
+    const int *w = sp.x1_window + 4 * b;
+    i0 = w[0], rl = w[1], lo = w[2], hi = w[3];
+    if (rl <= 0) return;  // nothing to do in this block
+  }
+  const int64_t run = (int64_t)u0.nx2 * rl;
   const int64_t t = (int64_t)wave * 62 + lane - 1;
-  const int row = (int)((t >= 0 ? t : 0) / u0.ni);
-  const int i = (int)(t - (int64_t)row * u0.ni);
+  if ((int64_t)wave * 62 - 1 >= run) return;  // whole wave beyond this block's run
+  const int row = (int)((t >= 0 ? t : 0) / rl);
+  const int i = i0 + (int)(t - (int64_t)row * rl);
   const bool in_run = (t >= 0) && (t < run);
   const bool do_recon = in_run && (i >= u0.is - 1) && (i <= u0.ie + 1);
   const int64_t cell = k * u0.sk + (int64_t)(u0.js + row) * u0.sj + i;
@@ -179,7 +194,7 @@ fused_x1_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_plane) {
     const double fup = wave_shl1(f[s]);
     du[perm<1>(s)] = (a1 * fup - a1 * f[s]);
   }
-  const bool do_cell = in_run && (lane >= 1) && (lane <= 62) && (i >= u0.is) && (i <= u0.ie);
+  const bool do_cell = in_run && (lane >= 1) && (lane <= 62) && (i >= lo) && (i <= hi);
   if (!do_cell) return;
   if constexpr (FINAL) {
     const double vol = b0.dx[0] * b0.dx[1] * b0.dx[2];
@@ -656,8 +671,15 @@ template <int FLUID, int RECON, int RS>
 inline int launch_fused_stage(const PackView &u0, const PackView &u1, const StageParams &sp,
                               int extra, hipStream_t s) {
   const int64_t run = (int64_t)u0.nx2 * u0.ni;
-  const int wpp = (int)((run + 61) / 62);
+  // a windowed x1 sweep (phase 1) flattens at most x1_window_rl columns per row
+  const int64_t run1 = sp.x1_window ? (int64_t)u0.nx2 * sp.x1_window_rl : run;
+  const int wpp = (int)((run1 + 61) / 62);
   const dim3 g1((wpp + 3) / 4, u0.nx3 * u0.nblocks, 1);
+  if (sp.phase != 0) {
+    // split stage: only where the x1 sweep is its own, non-finishing kernel
+    if (u0.ndim == 1 || (RECON == APK_RC_DC && u0.ndim == 3)) return APK_ERR_UNSUPPORTED;
+  }
+  const bool do_x1 = sp.phase != 2, do_rest = sp.phase != 1;
   // timing slots: donor-cell stages (VL2 predictor) are accounted separately
   constexpr int TS = (RECON == APK_RC_DC) ? (int)APK_T_FUSED_DC_X1 : (int)APK_T_FUSED_X1;
   if (u0.ndim == 1) {
@@ -693,28 +715,34 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
       hipLaunchKernelGGL((fused_march12_kernel<FLUID, RECON, RS>), dim3(wpb, 1, u0.nblocks), dim3(64), lds, s,
                          u0, u1, sp, wpb);
     } else {
-      {
+      if (do_x1) {
         ScopedTiming t(sp.ctx, TS + 0, s);
         hipLaunchKernelGGL((fused_x1_kernel<FLUID, RECON, RS, false>), g1, dim3(256), 0, s, u0, u1, sp, wpp);
       }
-      const dim3 g2((u0.nx1 + 63) / 64, u0.nx3, u0.nblocks);
-      ScopedTiming t(sp.ctx, TS + 1, s);
-      hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 2, false>), g2, dim3(64), lds, s, u0, u1, sp);
+      if (do_rest) {
+        const dim3 g2((u0.nx1 + 63) / 64, u0.nx3, u0.nblocks);
+        ScopedTiming t(sp.ctx, TS + 1, s);
+        hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 2, false>), g2, dim3(64), lds, s, u0, u1, sp);
+      }
     }
-    const dim3 g3((u0.nx1 + 63) / 64, u0.nx2, u0.nblocks);
-    ScopedTiming t(sp.ctx, TS + 2, s);
-    launch_final_march<FLUID, RECON, RS, 3>(u0, u1, sp, extra, g3, lds, s);
+    if (do_rest) {
+      const dim3 g3((u0.nx1 + 63) / 64, u0.nx2, u0.nblocks);
+      ScopedTiming t(sp.ctx, TS + 2, s);
+      launch_final_march<FLUID, RECON, RS, 3>(u0, u1, sp, extra, g3, lds, s);
+    }
   } else {
-    {
+    if (do_x1) {
       ScopedTiming t(sp.ctx, TS + 0, s);
       hipLaunchKernelGGL((fused_x1_kernel<FLUID, RECON, RS, false>), g1, dim3(256), 0, s, u0, u1, sp, wpp);
     }
     // 2-D: the (j,i)-flattened x1 sweep keeps far more waves in flight than a march over a
     // single k-plane would; the x2 march finishes the stage
-    constexpr int lds = march_lds_bytes<FLUID, RECON>();
-    const dim3 g2((u0.nx1 + 63) / 64, u0.nx3, u0.nblocks);
-    ScopedTiming t(sp.ctx, TS + 1, s);
-    launch_final_march<FLUID, RECON, RS, 2>(u0, u1, sp, extra, g2, lds, s);
+    if (do_rest) {
+      constexpr int lds = march_lds_bytes<FLUID, RECON>();
+      const dim3 g2((u0.nx1 + 63) / 64, u0.nx3, u0.nblocks);
+      ScopedTiming t(sp.ctx, TS + 1, s);
+      launch_final_march<FLUID, RECON, RS, 2>(u0, u1, sp, extra, g2, lds, s);
+    }
   }
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }

@@ -129,6 +129,18 @@ struct Mesh {
     return true;
   }
 
+  // are the ghost zones of local block lb on side (-1 / +1) of direction d filled only when the
+  // exchange completes (neighbour on another rank, or a physical boundary condition) rather than
+  // by a same-rank copy?
+  bool LateFace(int lb, int d, int side) const {
+    if (!Active(d)) return false;
+    int bc[3], o[3] = {0, 0, 0}, nbc[3];
+    Loc(local_gids[lb], bc);
+    o[d] = side;
+    if (!Neighbor(bc, o, nbc)) return true;  // physical boundary: applied after the unpack
+    return gid_rank[Gid(nbc)] != rank;
+  }
+
   // index range [lo,hi] along dim d of the receiver's ghost region (dst) and of the
   // provider's interior strip (src) for a neighbour at offset o_d
   void Range(int d, int o, bool src, int &lo, int &hi) const {

@@ -631,19 +631,73 @@ int estimate_timestep(apk_sim *s, double *dt_out) {
   return APK_OK;
 }
 
-int exchange_ghosts(apk_sim *s) {
+// Ghost exchange in two halves.  begin: same-rank copies, message packing, post the transfers;
+// end: wait for them, unpack, physical boundaries (x1, x2, x3).
+int exchange_begin(apk_sim *s, bool async) {
   const bool remote = !s->mesh.peers.empty();
-  if (remote) {
-    SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(PH_PACK), s->stream));
-  }
+  if (remote) SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(PH_PACK), s->stream));
   SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(PH_LOCAL), s->stream));
   if (remote) {
     if (!s->have_comm || !s->comm.exchange) return fail(s, APK_ERR_INVALID, "remote neighbours but no comm ops");
-    if (s->comm.exchange(s->comm.user) != 0) return fail(s, APK_ERR_DEVICE, "halo exchange failed");
-    SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(PH_UNPACK), s->stream));
+    if (async) {
+      if (s->comm.exchange_begin(s->comm.user) != 0) return fail(s, APK_ERR_DEVICE, "halo exchange (begin) failed");
+      s->exchange_pending = true;
+    } else if (s->comm.exchange(s->comm.user) != 0) {
+      return fail(s, APK_ERR_DEVICE, "halo exchange failed");
+    }
   }
+  return APK_OK;
+}
+
+int exchange_end(apk_sim *s) {
+  if (s->exchange_pending) {
+    if (s->comm.exchange_end(s->comm.user) != 0) return fail(s, APK_ERR_DEVICE, "halo exchange (end) failed");
+    s->exchange_pending = false;
+  }
+  if (!s->mesh.peers.empty()) SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(PH_UNPACK), s->stream));
   for (int ph = PH_BC1; ph <= PH_BC3; ++ph) SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(ph), s->stream));
   return APK_OK;
+}
+
+int exchange_ghosts(apk_sim *s) {
+  SIM_TRY(s, exchange_begin(s, false));
+  return exchange_end(s);
+}
+
+// column windows of the split x1 sweep, per local block (see apk_stage_args.x1_window)
+int build_x1_windows(apk_sim *s) {
+  const Mesh &m = s->mesh;
+  const int nlb = (int)m.local_gids.size();
+  const int W = m.ng;
+  std::vector<int> win[3];
+  for (auto &w : win) w.assign(4 * (size_t)nlb, 0);
+  s->x1win_rl[0] = m.ni;
+  s->x1win_rl[1] = s->x1win_rl[2] = W + 2;
+  bool any = false;
+  for (int lb = 0; lb < nlb; ++lb) {
+    const bool rlo = m.LateFace(lb, 0, -1), rhi = m.LateFace(lb, 0, +1);
+    any = any || rlo || rhi;
+    int *w0 = &win[0][4 * lb], *w1 = &win[1][4 * lb], *w2 = &win[2][4 * lb];
+    w0[0] = 0, w0[1] = m.ni, w0[2] = m.is + (rlo ? W : 0), w0[3] = m.ie - (rhi ? W : 0);
+    w1[0] = m.is - 1, w1[1] = rlo ? W + 2 : 0, w1[2] = m.is, w1[3] = m.is + W - 1;
+    w2[0] = m.ie - W, w2[1] = rhi ? W + 2 : 0, w2[2] = m.ie - W + 1, w2[3] = m.ie;
+  }
+  (void)any;
+  for (int q = 0; q < 3; ++q) {
+    double *p = nullptr;
+    const char *tags[3] = {"x1win_main", "x1win_lo", "x1win_hi"};
+    SIM_TRY(s, dev_alloc(s, tags[q], sizeof(int) * 4 * (size_t)nlb, &p));
+    s->d_x1win[q] = reinterpret_cast<int *>(p);
+    SIM_HIP(s, hipMemcpy(s->d_x1win[q], win[q].data(), sizeof(int) * 4 * (size_t)nlb, hipMemcpyHostToDevice));
+  }
+  return APK_OK;
+}
+
+// can the exchange posted after this stage stay in flight while the next stage starts?
+bool can_overlap_next(const apk_sim *s, const apk_flux_cfg &next_cfg) {
+  const Mesh &m = s->mesh;
+  return s->overlap && !m.peers.empty() && s->have_comm && s->comm.exchange_begin && s->comm.exchange_end &&
+         stage_can_fuse(s) && m.ndim >= 2 && next_cfg.recon != APK_RC_DC && m.mb[0] >= 4 * m.ng && s->d_x1win[0];
 }
 
 int fill_derived(apk_sim *s) {
@@ -775,6 +829,28 @@ int do_stage(apk_sim *s, int stage) {
     }
     a.fill_derived = fused_fill ? (swap_prim ? 2 : 1) : 0;
     a.estimate_dt = (fused_fill && stage == s->nstages && pkg.calc_dt_hyp) ? 1 : 0;
+    if (s->exchange_pending) {
+      // The previous stage's halo messages are still in flight.  Ghost zones filled by same-rank
+      // copies are ready: convert them, run the x1 sweep wherever it does not touch a remote
+      // face, then complete the exchange and do the thin slabs next to those faces and the rest.
+      const bool full = s->pending_full_c2p;
+      SIM_TRY(s, full ? fill_derived(s) : apk_cons_to_prim_ghosts(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
+      a.phase = 1;
+      a.x1_window = s->d_x1win[0];
+      a.x1_window_rl = s->x1win_rl[0];
+      SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
+      SIM_TRY(s, exchange_end(s));
+      SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
+      for (int q = 1; q <= 2; ++q) {
+        a.x1_window = s->d_x1win[q];
+        a.x1_window_rl = s->x1win_rl[q];
+        SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
+      }
+      a.phase = 2;
+      a.x1_window = nullptr;
+      a.x1_window_rl = 0;
+      s->overlapped += 1;
+    }
     SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
     s->stage_dt_pending = a.estimate_dt != 0;
     if (swap_prim) s->pcur = 1 - s->pcur;
@@ -794,11 +870,17 @@ int do_stage(apk_sim *s, int stage) {
     }
   }
   if (s->fmft && stage == s->nstages) SIM_TRY(s, turbulence_driving(s, s->dt));
-  SIM_TRY(s, exchange_ghosts(s));
-  if (fused_fill) {
-    SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
+  if (stage < s->nstages && can_overlap_next(s, pkg.flux_other_stage)) {
+    // post the messages and leave them in flight: the next stage completes the exchange
+    SIM_TRY(s, exchange_begin(s, true));
+    s->pending_full_c2p = !fused_fill;
   } else {
-    SIM_TRY(s, fill_derived(s));
+    SIM_TRY(s, exchange_ghosts(s));
+    if (fused_fill) {
+      SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
+    } else {
+      SIM_TRY(s, fill_derived(s));
+    }
   }
   if (stage == s->nstages && pkg.calc_c_h) {  // hydro_driver.cpp:589-603
     pkg.mindx = kHuge;
@@ -900,6 +982,7 @@ int apk_sim_create(const char *deck, const char *const *overrides, int noverride
     return bail(rc);
   }
   if ((rc = build_copy_plans(s)) != APK_OK) return bail(rc);
+  if (!s->mesh.peers.empty() && (rc = build_x1_windows(s)) != APK_OK) return bail(rc);
   if (s->fmft && (rc = turbulence_device_setup(s)) != APK_OK) return bail(rc);
   return APK_OK;
 }
@@ -916,6 +999,7 @@ void apk_sim_destroy(apk_sim *s) {
         apk_pack_destroy(s->mu1_of[p][w]);
       }
     apk_fmft_destroy(s->fm_dev);
+    for (int *w : s->d_x1win) dev_free(s, reinterpret_cast<double *>(w));
     dev_free(s, s->d_acc);
     dev_free(s, s->d_phases);
     dev_free(s, s->d_cons2[0]);
@@ -938,6 +1022,14 @@ int apk_sim_set_fused(apk_sim *s, int fused) {
   if (!s->host_only && !stage_can_fuse(s)) return ensure_flux_arrays(s);
   return APK_OK;
 }
+
+int apk_sim_set_overlap(apk_sim *s, int overlap) {
+  if (!s) return APK_ERR_INVALID;
+  s->overlap = overlap != 0;
+  return APK_OK;
+}
+
+long long apk_sim_overlapped_exchanges(const apk_sim *s) { return s ? s->overlapped : 0; }
 
 int apk_sim_initialize(apk_sim *s) {
   if (!s || s->host_only) return APK_ERR_INVALID;

@@ -105,5 +105,15 @@ struct apk_sim {
   double *d_acc = nullptr;     // [nblocks][3][Nk][Nj][Ni]
   double *d_phases = nullptr;  // per block: phases_i | phases_j | phases_k
   apk_fmft *fm_dev = nullptr;
+  // Overlap of the halo exchange between two stages with the x1 sweep of the next stage
+  // (BASELINE north_star / SURVEY 8(e)): after a stage the messages are posted and left in flight
+  // (exchange_pending); the next stage runs its x1 sweep on all cells farther than nghost from a
+  // face with a remote neighbour, completes the exchange, then does the thin slabs and the rest.
+  bool overlap = true;
+  bool exchange_pending = false;
+  bool pending_full_c2p = false;  // the stage that posted the exchange did not fill prim itself
+  int *d_x1win[3] = {nullptr, nullptr, nullptr};  // device {i0, rl, lo, hi} per block: main / low slab / high slab
+  int x1win_rl[3] = {0, 0, 0};
+  long long overlapped = 0;
   std::string err;
 };

@@ -21,25 +21,37 @@ class HaloExchanger:
         self.peers = list(peers)
         self.group = group
 
-    def exchange(self):
+    def begin(self):
+        """post every send / receive of this stage's halo messages; returns without waiting"""
         import torch.distributed as dist
+        self._reqs, self._back = [], []
         if not self.peers:
             return
         # gloo has no device send/recv: development runs that put several ranks on one GPU
         # (tests, `APK_DIST_BACKEND=gloo bench.py`) bounce the messages through host memory
         staged = self.peers[0][1].is_cuda and dist.get_backend(self.group) == "gloo"
-        ops, back = [], []
+        ops = []
         for rank, send_t, recv_t in self.peers:
             if staged:
                 host_recv = torch.empty(recv_t.shape, dtype=recv_t.dtype)
-                back.append((recv_t, host_recv))
+                self._back.append((recv_t, host_recv))
                 send_t, recv_t = send_t.cpu(), host_recv
             ops.append(dist.P2POp(dist.irecv, recv_t, rank, group=self.group))
             ops.append(dist.P2POp(dist.isend, send_t, rank, group=self.group))
-        for req in dist.batch_isend_irecv(ops):
+        self._reqs = dist.batch_isend_irecv(ops)
+
+    def end(self):
+        """work enqueued on the current stream after this call sees the received data (over RCCL
+        Work.wait() is a stream dependency, not a host wait)"""
+        for req in self._reqs:
             req.wait()
-        for dev_t, host_t in back:
+        for dev_t, host_t in self._back:
             dev_t.copy_(host_t)
+        self._reqs, self._back = [], []
+
+    def exchange(self):
+        self.begin()
+        self.end()
 
 
 def _allreduce(vals_ptr, n, op, device, group=None):
@@ -115,6 +127,22 @@ class Simulation(_FmftHost):
                 self._cb_error = e
                 return 1
 
+        def _exchange_begin(user):
+            try:
+                self._halo.begin()
+                return 0
+            except Exception as e:
+                self._cb_error = e
+                return 1
+
+        def _exchange_end(user):
+            try:
+                self._halo.end()
+                return 0
+            except Exception as e:
+                self._cb_error = e
+                return 1
+
         def _amin(user, vals, n):
             try:
                 import torch.distributed as dist
@@ -135,7 +163,8 @@ class Simulation(_FmftHost):
 
         self._cb_error = None
         self._ex_cb, self._amin_cb, self._asum_cb = L.EXCHANGE_FN(_exchange), L.ALLREDUCE_FN(_amin), L.ALLREDUCE_FN(_asum)
-        comm = L.CommOps(None, self._ex_cb, self._amin_cb, self._asum_cb)
+        self._exb_cb, self._exe_cb = L.EXCHANGE_FN(_exchange_begin), L.EXCHANGE_FN(_exchange_end)
+        comm = L.CommOps(None, self._ex_cb, self._amin_cb, self._asum_cb, self._exb_cb, self._exe_cb)
 
         ov = (C.c_char_p * max(1, len(overrides)))(*[o.encode() for o in overrides])
         err = C.create_string_buffer(1024)
@@ -180,6 +209,15 @@ class Simulation(_FmftHost):
             pass
 
     # ---- driver -----------------------------------------------------------------------
+    def set_overlap(self, overlap):
+        """overlap the halo exchange between stages with the next stage's x1 sweep (default on)"""
+        self._check(self.lib.apk_sim_set_overlap(self.h, int(overlap)))
+        return self
+
+    @property
+    def overlapped_exchanges(self):
+        return self.lib.apk_sim_overlapped_exchanges(self.h)
+
     def set_fused(self, fused):
         self._check(self.lib.apk_sim_set_fused(self.h, int(fused)))
         self._check(self.lib.apk_sim_get_info(self.h, C.byref(self.info)))

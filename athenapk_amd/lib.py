@@ -55,7 +55,8 @@ class StageArgs(C.Structure):
     _fields_ = [("cfg", FluxCfg), ("eos", Eos), ("c_h", C.c_double), ("gam0", C.c_double),
                 ("gam1", C.c_double), ("beta_dt", C.c_double), ("dedner", C.c_int),
                 ("glmmhd_alpha", C.c_double), ("mindx", C.c_double), ("fill_derived", C.c_int),
-                ("estimate_dt", C.c_int)]
+                ("estimate_dt", C.c_int), ("phase", C.c_int), ("x1_window", C.c_void_p),
+                ("x1_window_rl", C.c_int)]
 
 
 class FmftBlock(C.Structure):
@@ -94,7 +95,7 @@ class Allocator(C.Structure):
 
 class CommOps(C.Structure):
     _fields_ = [("user", C.c_void_p), ("exchange", EXCHANGE_FN), ("allreduce_min", ALLREDUCE_FN),
-                ("allreduce_sum", ALLREDUCE_FN)]
+                ("allreduce_sum", ALLREDUCE_FN), ("exchange_begin", EXCHANGE_FN), ("exchange_end", EXCHANGE_FN)]
 
 
 class SimInfo(C.Structure):
@@ -179,6 +180,8 @@ def _signatures():
         "apk_sim_ncycle": (i, [vp]),
         "apk_sim_fofc_count": (ll, [vp]),
         "apk_sim_set_fused": (i, [vp, i]),
+        "apk_sim_set_overlap": (i, [vp, i]),
+        "apk_sim_overlapped_exchanges": (ll, [vp]),
         "apk_sim_get_info": (i, [vp, C.POINTER(SimInfo)]),
         "apk_sim_block_location": (i, [vp, i, C.POINTER(C.c_int), C.POINTER(C.c_int * 3)]),
         "apk_sim_block_ptr": (vp, [vp, i, i]),

@@ -36,12 +36,20 @@ typedef struct apk_allocator {
  *            sim's stream when this is called; on return the per-peer receive buffers must
  *            be ready to be read by work enqueued on that stream.
  *  allreduce_min: in-place MIN over ranks of n doubles (dt; mindx/dt_hyp: hydro.cpp:122-128).
- *  allreduce_sum: in-place SUM over ranks (history output). */
+ *  allreduce_sum: in-place SUM over ranks (history output).
+ *  exchange_begin / exchange_end (optional, both or neither): the same exchange in two halves so
+ *            that it can overlap with compute: begin posts the sends/receives (same precondition
+ *            as `exchange`) and returns without waiting; end makes work enqueued on the sim's
+ *            stream afterwards wait for the receives.  Between the two calls the driver runs the
+ *            x1 sweep of the next stage on every cell that does not need the data in flight
+ *            (RCCL executes the transfers on its own stream). */
 typedef struct apk_comm_ops {
   void *user;
   int (*exchange)(void *user);
   int (*allreduce_min)(void *user, double *vals, int n);
   int (*allreduce_sum)(void *user, double *vals, int n);
+  int (*exchange_begin)(void *user);
+  int (*exchange_end)(void *user);
 } apk_comm_ops;
 
 /* ---- creation from an Athena-style input deck ("<block>" / "key = value") -------------
@@ -76,6 +84,12 @@ int apk_sim_ncycle(const apk_sim *sim);
 long long apk_sim_fofc_count(const apk_sim *sim);
 /* 0 = flux-array path (CalculateFluxes + Update + Dedner), 1 = fused stage path */
 int apk_sim_set_fused(apk_sim *sim, int fused);
+/* 1 (default) = overlap the halo exchange between two stages of a cycle with the x1 sweep of the
+ * next stage where possible (remote neighbours, exchange_begin/end given, fused path, >= 2-D, next
+ * stage not donor cell); 0 = always exchange synchronously.  Results are identical. */
+int apk_sim_set_overlap(apk_sim *sim, int overlap);
+/* number of stage boundaries so far at which the exchange was overlapped */
+long long apk_sim_overlapped_exchanges(const apk_sim *sim);
 
 /* ---- introspection ------------------------------------------------------------------- */
 typedef struct apk_sim_info {

@@ -401,6 +401,52 @@ def test_fused_stage_fill_derived_out_of_place(request, oracle, fluid, recon, ri
         assert dt == pytest.approx(want_dt, rel=1e-12)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("fluid,recon,riemann,nx", [("glmmhd", "ppm", "hlld", (70, 9, 7)),
+                                                    ("glmmhd", "wenoz", "hlld", (64, 8, 8)),
+                                                    ("euler", "plm", "hllc", (66, 10, 1))])
+def test_fused_stage_split_around_exchange(request, oracle, fluid, recon, riemann, nx, strict):
+    """phase 1 (x1 sweep on column windows: everything but the cells next to a 'remote' face,
+    then the thin slabs) + phase 2 (remaining sweeps) == the unsplit stage, bit for bit."""
+    import torch
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    ng, prim, g = _case(fluid, recon, nx, kind="smooth", seed=47, nblocks=3)
+    cons = H.prim_to_cons(fluid, prim, GAMMA)
+    ded = 1 if fluid == "glmmhd" else 0
+    eos = hydro.L.make_eos(GAMMA, pfloor=1e-6, dfloor=1e-6)
+    kw = dict(dedner=ded, glmmhd_alpha=0.1, mindx=0.07, fill_derived=True, estimate_dt=True)
+
+    def packs():
+        a = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=cons, prim=prim, with_flux=False)
+        b = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=cons * 1.01, with_flux=False)
+        return a, b
+    r0, r1 = packs()
+    hydro.StageFused(r0, r1, fluid, recon, riemann, eos, C_H, 0.5, 0.5, 0.004, **kw)
+    dt_ref = hydro.StageDt(ctx, 0.3)
+    m0, m1 = packs()
+    is_, ie, ni, W = ng, ng + nx[0] - 1, nx[0] + 2 * ng, ng
+    # block 0: data missing on the low x1 side, block 1: on the high side, block 2: on both
+    missing = [(1, 0), (0, 1), (1, 1)]
+    main = [[0, ni, is_ + W * lo, ie - W * hi] for lo, hi in missing]
+    slab_lo = [[is_ - 1, W + 2, is_, is_ + W - 1] if lo else [0, 0, 0, -1] for lo, hi in missing]
+    slab_hi = [[ie - W, W + 2, ie - W + 1, ie] if hi else [0, 0, 0, -1] for lo, hi in missing]
+    for win in (main, slab_lo, slab_hi):
+        t = torch.tensor(win, dtype=torch.int32, device="cuda")
+        hydro.StageFused(m0, m1, fluid, recon, riemann, eos, C_H, 0.5, 0.5, 0.004, phase=1, x1_window=t, **kw)
+    hydro.StageFused(m0, m1, fluid, recon, riemann, eos, C_H, 0.5, 0.5, 0.004, phase=2, **kw)
+    dt = hydro.StageDt(ctx, 0.3)
+    if strict:
+        assert np.array_equal(m0.cons_host(), r0.cons_host()) and np.array_equal(m0.prim_host(), r0.prim_host())
+        assert dt == dt_ref
+    else:  # the window kernels are the same code: identical in the FMA build as well
+        assert np.array_equal(m0.cons_host(), r0.cons_host())
+    want = H.orc_stage(fluid, recon, riemann, g, cons, cons * 1.01, prim, GAMMA, C_H, 0.5, 0.5, 0.004, dedner=ded,
+                       alpha=0.1, mindx=0.07)
+    _cmp(H.interior(m0.cons_host(), nx, ng), H.interior(want, nx, ng), strict, "cons")
+
+
 def test_fused_fill_derived_rejected_where_unsafe(request):
     from athenapk_amd import hydro
     from athenapk_amd import lib as L

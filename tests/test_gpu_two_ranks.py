@@ -34,10 +34,16 @@ CASES = {
                     dict(fluid="euler", recon="plm", riemann="hllc", integrator="rk2", nx=(64, 8, 8), mb=(16, 8, 8),
                          ng=2, bc=("outflow", "periodic", "periodic"), xmin=(0.0, -0.5, -0.5), xmax=(1.0, 0.5, 0.5),
                          gamma=1.4, cfl=0.3), "sod", {}, 6),
+    "mhd_wenoz_hlld_rk3": ("synthetic_mhd",
+                           ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=16",
+                            "parthenon/meshblock/nx1=16", "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=8",
+                            "parthenon/time/integrator=rk3", "hydro/reconstruction=wenoz"],
+                           dict(fluid="glmmhd", recon="wenoz", riemann="hlld", integrator="rk3", nx=(32, 32, 16),
+                                mb=(16, 16, 8), ng=3, cfl=0.3, gamma=1.666666666666667), "synthetic", {}, 3),
 }
 
 
-def _worker(rank, world, port, case, outdir):
+def _worker(rank, world, port, case, outdir, overlap=True):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -48,11 +54,13 @@ def _worker(rank, world, port, case, outdir):
     try:
         deck, ov, _, _, _, ncyc = CASES[case]
         s = driver.Simulation(decks.load(deck), ov, rank=rank, nranks=world, strict=True)
+        s.set_overlap(overlap)
         s.initialize()
         for _ in range(ncyc):
             s.step()
         blocks = {s.block_gid(lb)[0]: s.read_block(lb, "cons") for lb in range(s.info.nblocks_local)}
         np.savez(os.path.join(outdir, "rank%d.npz" % rank), time=s.time, dt=s.dt, hist=s.history(),
+                 overlapped=s.overlapped_exchanges,
                  **{"b%d" % g: a for g, a in blocks.items()})
         s.close()
     finally:
@@ -60,20 +68,26 @@ def _worker(rank, world, port, case, outdir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world,overlap", [(2, True), (4, True), (2, False)])
 @pytest.mark.parametrize("case", sorted(CASES))
-def test_ranks_sharing_one_gpu_match_oracle(oracle, tmp_path, case, world):
+def test_ranks_sharing_one_gpu_match_oracle(oracle, tmp_path, case, world, overlap):
+    """overlap=True: between the stages of a cycle the halo messages stay in flight while the next
+    stage's x1 sweep runs on the cells that do not need them (apk_stage_args.phase); the result
+    must not change by a bit."""
     import torch.multiprocessing as mp
     deck, ov, okw, pgen, pkw, ncyc = CASES[case]
+    nstages = {"rk1": 1, "rk2": 2, "vl2": 2, "rk3": 3}[okw["integrator"]]
     o = oracle.Sim(nthreads=os.cpu_count(), **okw)
     o.pgen(pgen, **pkw)
     for _ in range(ncyc):
         o.step()
-    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path), overlap), nprocs=world, join=True)
     seen = set()
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         assert z["time"] == o.time and z["dt"] == o.dt
+        # every stage boundary inside a cycle is overlapped (the high-order stages follow it)
+        assert int(z["overlapped"]) == ((nstages - 1) * ncyc if overlap else 0)
         np.testing.assert_allclose(z["hist"], o.history(), rtol=1e-13, atol=1e-15)
         for key in z.files:
             if key.startswith("b"):
