@@ -274,6 +274,17 @@ int apk_cons_to_prim_ghosts(apk_ctx *ctx, const apk_pack *md, int fluid, const a
   return APK_OK;
 }
 
+int apk_cons_to_prim_ghosts_split(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,
+                                  const unsigned *late_regions, int part, apk_stream_t stream) {
+  if (!ctx || !md || !valid_eos(eos) || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||
+      md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9) || !late_regions || (part != 1 && part != 2))
+    return set_err(ctx, APK_ERR_INVALID, "apk_cons_to_prim_ghosts_split: bad argument");
+  ScopedTiming timing(ctx, APK_T_C2P, as_stream(stream));
+  int rc = launch_cons_to_prim(md->view, fluid, *eos, ctx->d_flags, as_stream(stream), true, late_regions, part);
+  if (rc != APK_OK) return set_err(ctx, rc, "cons_to_prim kernel launch failed", hipGetLastError());
+  return APK_OK;
+}
+
 int apk_stage_dt_read(apk_ctx *ctx, double cfl, double *dt_out, apk_stream_t stream) {
   if (!ctx || !dt_out) return APK_ERR_INVALID;
   hipStream_t s = as_stream(stream);

@@ -683,6 +683,26 @@ int build_x1_windows(apk_sim *s) {
     w2[0] = m.ie - W, w2[1] = rhi ? W + 2 : 0, w2[2] = m.ie - W + 1, w2[3] = m.ie;
   }
   (void)any;
+  {
+    std::vector<unsigned> late(nlb, 0u);
+    for (int lb = 0; lb < nlb; ++lb) {
+      int bc[3], nbc[3];
+      m.Loc(m.local_gids[lb], bc);
+      for (int sz = -1; sz <= 1; ++sz)
+        for (int sy = -1; sy <= 1; ++sy)
+          for (int sx = -1; sx <= 1; ++sx) {
+            if (!sx && !sy && !sz) continue;
+            if ((sx && !m.Active(0)) || (sy && !m.Active(1)) || (sz && !m.Active(2))) continue;
+            const int o[3] = {sx, sy, sz};
+            const bool is_late = !m.Neighbor(bc, o, nbc) || m.gid_rank[m.Gid(nbc)] != m.rank;
+            if (is_late) late[lb] |= 1u << ((sx + 1) + 3 * (sy + 1) + 9 * (sz + 1));
+          }
+    }
+    double *p = nullptr;
+    SIM_TRY(s, dev_alloc(s, "late_regions", sizeof(unsigned) * (size_t)nlb, &p));
+    s->d_late_regions = reinterpret_cast<unsigned *>(p);
+    SIM_HIP(s, hipMemcpy(s->d_late_regions, late.data(), sizeof(unsigned) * (size_t)nlb, hipMemcpyHostToDevice));
+  }
   for (int q = 0; q < 3; ++q) {
     double *p = nullptr;
     const char *tags[3] = {"x1win_main", "x1win_lo", "x1win_hi"};
@@ -833,14 +853,16 @@ int do_stage(apk_sim *s, int stage) {
       // The previous stage's halo messages are still in flight.  Ghost zones filled by same-rank
       // copies are ready: convert them, run the x1 sweep wherever it does not touch a remote
       // face, then complete the exchange and do the thin slabs next to those faces and the rest.
-      const bool full = s->pending_full_c2p;
-      SIM_TRY(s, full ? fill_derived(s) : apk_cons_to_prim_ghosts(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
+      // (if the posting stage left FillDerived to us, the interior is converted here as well: the
+      // kernel below only covers ghost zones)
+      if (s->pending_full_c2p) return fail(s, APK_ERR_INVALID, "internal: overlapped exchange after an unfilled stage");
+      SIM_TRY(s, apk_cons_to_prim_ghosts_split(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->d_late_regions, 1, s->stream));
       a.phase = 1;
       a.x1_window = s->d_x1win[0];
       a.x1_window_rl = s->x1win_rl[0];
       SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
       SIM_TRY(s, exchange_end(s));
-      SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
+      SIM_TRY(s, apk_cons_to_prim_ghosts_split(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->d_late_regions, 2, s->stream));
       for (int q = 1; q <= 2; ++q) {
         a.x1_window = s->d_x1win[q];
         a.x1_window_rl = s->x1win_rl[q];
@@ -870,7 +892,7 @@ int do_stage(apk_sim *s, int stage) {
     }
   }
   if (s->fmft && stage == s->nstages) SIM_TRY(s, turbulence_driving(s, s->dt));
-  if (stage < s->nstages && can_overlap_next(s, pkg.flux_other_stage)) {
+  if (stage < s->nstages && fused_fill && can_overlap_next(s, pkg.flux_other_stage)) {
     // post the messages and leave them in flight: the next stage completes the exchange
     SIM_TRY(s, exchange_begin(s, true));
     s->pending_full_c2p = !fused_fill;
@@ -1000,6 +1022,7 @@ void apk_sim_destroy(apk_sim *s) {
       }
     apk_fmft_destroy(s->fm_dev);
     for (int *w : s->d_x1win) dev_free(s, reinterpret_cast<double *>(w));
+    dev_free(s, reinterpret_cast<double *>(s->d_late_regions));
     dev_free(s, s->d_acc);
     dev_free(s, s->d_phases);
     dev_free(s, s->d_cons2[0]);

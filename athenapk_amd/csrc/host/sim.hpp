@@ -114,6 +114,7 @@ struct apk_sim {
   bool pending_full_c2p = false;  // the stage that posted the exchange did not fill prim itself
   int *d_x1win[3] = {nullptr, nullptr, nullptr};  // device {i0, rl, lo, hi} per block: main / low slab / high slab
   int x1win_rl[3] = {0, 0, 0};
+  unsigned *d_late_regions = nullptr;  // per block: bit (sx+1)+3(sy+1)+9(sz+1) = that neighbour region is filled late
   long long overlapped = 0;
   std::string err;
 };

@@ -142,7 +142,8 @@ cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags) {
 // x1 slabs of the interior rows (2 ng cells per row).
 template <int FLUID>
 __global__ void __launch_bounds__(256)
-cons_to_prim_ghosts_kernel(PackView pv, apk_eos eos, unsigned *flags, int64_t na, int64_t nb_, int64_t nc) {
+cons_to_prim_ghosts_kernel(PackView pv, apk_eos eos, unsigned *flags, int64_t na, int64_t nb_, int64_t nc,
+                           const unsigned *late_regions, int part) {
   const int b = blockIdx.y;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int gk = pv.nk - pv.nx3, gj = pv.nj - pv.nx2, gi = pv.ni - pv.nx1;  // ghost layers (both sides)
@@ -172,6 +173,16 @@ cons_to_prim_ghosts_kernel(PackView pv, apk_eos eos, unsigned *flags, int64_t na
     i = (ii < gi / 2) ? ii : pv.ie + 1 + (ii - gi / 2);
   } else {
     return;
+  }
+  if (part != 0) {
+    // split around a halo exchange in flight: bit (sx+1) + 3 (sy+1) + 9 (sz+1) of late_regions[b]
+    // marks the neighbour region at offset (sx, sy, sz) as filled only when the exchange
+    // completes; part 1 converts the ghost cells of the other regions, part 2 those
+    const int sx = (i < pv.is) ? 0 : ((i > pv.ie) ? 2 : 1);
+    const int sy = (j < pv.js) ? 0 : ((j > pv.je) ? 2 : 1);
+    const int sz = (k < pv.ks) ? 0 : ((k > pv.ke) ? 2 : 1);
+    const bool late = (late_regions[b] >> (sx + 3 * sy + 9 * sz)) & 1u;
+    if (late != (part == 2)) return;
   }
   cons_to_prim_at<FLUID>(pv, pv.blocks[b], eos, flags, k * pv.sk + j * pv.sj + i);
 }
@@ -408,16 +419,18 @@ int launch_dedner(const PackView &pv, int extended, double coeff, double beta_dt
 }
 
 int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsigned *d_flags,
-                        hipStream_t s, bool ghosts_only) {
+                        hipStream_t s, bool ghosts_only, const unsigned *late_regions, int part) {
   if (ghosts_only) {
     const int64_t na = (int64_t)(pv.nk - pv.nx3) * pv.nj * pv.ni;
     const int64_t nb = (int64_t)pv.nx3 * (pv.nj - pv.nx2) * pv.ni;
     const int64_t nc = (int64_t)pv.nx3 * pv.nx2 * (pv.ni - pv.nx1);
     const dim3 grid((unsigned)((na + nb + nc + 255) / 256), pv.nblocks, 1);
     if (fluid == APK_FLUID_EULER)
-      hipLaunchKernelGGL(cons_to_prim_ghosts_kernel<APK_FLUID_EULER>, grid, dim3(256), 0, s, pv, eos, d_flags, na, nb, nc);
+      hipLaunchKernelGGL(cons_to_prim_ghosts_kernel<APK_FLUID_EULER>, grid, dim3(256), 0, s, pv, eos, d_flags, na, nb, nc,
+                         late_regions, part);
     else
-      hipLaunchKernelGGL(cons_to_prim_ghosts_kernel<APK_FLUID_GLMMHD>, grid, dim3(256), 0, s, pv, eos, d_flags, na, nb, nc);
+      hipLaunchKernelGGL(cons_to_prim_ghosts_kernel<APK_FLUID_GLMMHD>, grid, dim3(256), 0, s, pv, eos, d_flags, na, nb, nc,
+                         late_regions, part);
     return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
   }
   dim3 grid((pv.ni + 63) / 64, (pv.nj + 3) / 4, pv.nk * pv.nblocks);

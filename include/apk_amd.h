@@ -189,6 +189,14 @@ int apk_cons_to_prim(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos 
  * companion of apk_stage_fused(fill_derived = 1). */
 int apk_cons_to_prim_ghosts(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,
                             apk_stream_t stream);
+/* The same in two parts around a halo exchange that is still in flight (see
+ * apk_stage_args.phase).  late_regions: DEVICE array, one word per block; bit
+ * (sx+1) + 3 (sy+1) + 9 (sz+1) set when the ghost region towards the neighbour at block offset
+ * (sx, sy, sz) is only filled when the exchange completes (neighbour on another rank, physical
+ * boundary).  part = 1 converts the ghost cells of the other regions (same-rank copies, ready
+ * early), part = 2 those. */
+int apk_cons_to_prim_ghosts_split(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,
+                                  const unsigned *late_regions, int part, apk_stream_t stream);
 
 /* Result of the last apk_stage_fused(estimate_dt = 1) on this context: *dt_out = cfl * min.
  * Synchronises `stream`. */
