@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="use the flux-array path (for A/B)")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
     import torch
     import torch.distributed as dist
     from athenapk_amd import decks, driver
@@ -135,6 +136,8 @@ def main():
     sim = driver.Simulation(decks.load(deck), ov, rank=rank, nranks=world, strict=False)
     if args.unfused:
         sim.set_fused(False)
+    if os.environ.get("APK_OVERLAP") == "0":  # A/B switch: exchange synchronously
+        sim.set_overlap(False)
     sim.initialize()
     info = sim.info
 
@@ -168,6 +171,11 @@ def main():
         value = zones_total * args.steps / elapsed
         nstages = len(GAM0[integrator])
         per_kernel = {k: (ms / n if n else 0.0) for k, (ms, n) in timing.items()}
+        # with the exchange overlapped the x1 sweep of a stage is several launches (main window +
+        # slabs): account it per stage (= per finishing-sweep launch)
+        fin = "fused_x3" if info.ndim == 3 else "fused_x2"
+        if timing[fin][1]:
+            per_kernel["fused_x1"] = timing["fused_x1"][0] / timing[fin][1]
         # one "launch" of the fused stage = its three sweep kernels back to back
         if args.unfused:
             stage_ms = per_kernel["fluxes"] + per_kernel["update"] + per_kernel["dedner"]
@@ -207,7 +215,8 @@ def main():
                        "integrator": integrator, "nstages": nstages, "nghost": int(info.ng),
                        "path": "flux-array" if args.unfused else "fused",
                        "parallelism": "domain decomposition, %dx%dx%d GPU grid" % grid,
-                       "comm_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None},
+                       "comm_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
+                       "overlapped_exchanges_per_cycle": (sim.overlapped_exchanges / max(1, sim.ncycle)) if world > 1 else None},
             "cell_stage_updates_per_s": value * nstages,
             "roofline": {
                 "bound": "hbm",
