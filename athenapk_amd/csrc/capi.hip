@@ -233,9 +233,12 @@ int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
     return set_err(ctx, APK_ERR_UNSUPPORTED, "fused stage: none/llf solvers use the flux-array path");
   if (a->dedner != 0 && (a->cfg.fluid != APK_FLUID_GLMMHD || !(a->mindx > 0.0)))
     return set_err(ctx, APK_ERR_INVALID, "fused stage: Dedner source needs glmmhd and mindx > 0");
-  if (a->phase < 0 || a->phase > 2 || (a->phase == 1) != (a->x1_window != nullptr) ||
-      (a->phase == 1 && (a->x1_window_rl < 3 || a->x1_window_rl > u0->view.ni)))
-    return set_err(ctx, APK_ERR_INVALID, "fused stage: phase / x1_window mismatch");
+  if (a->phase < 0 || a->phase > 2 || (a->phase == 1) != (a->window != nullptr) ||
+      (a->phase == 1 && (a->window_rl < 3 || a->window_rl > u0->view.ni || a->window_rows < 1 ||
+                         a->window_rows > u0->view.nx2)))
+    return set_err(ctx, APK_ERR_INVALID, "fused stage: phase / window mismatch");
+  if (a->phase == 1 && a->estimate_dt && a->cfg.recon == APK_RC_DC && u0->view.ndim == 3)
+    return set_err(ctx, APK_ERR_UNSUPPORTED, "fused stage: estimate_dt is not available in a split 3-D donor-cell stage");
   if (a->fill_derived < 0 || a->fill_derived > 2) return set_err(ctx, APK_ERR_INVALID, "fused stage: fill_derived must be 0, 1 or 2");
   if (a->fill_derived == 2) {
     for (const apk_block_desc &b : u1->h_blocks)

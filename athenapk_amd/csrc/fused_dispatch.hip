@@ -23,8 +23,9 @@ int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
   int extra = EXTRA_NONE;
   sp.prim_to_u1 = (a.fill_derived == 2) ? 1 : 0;
   sp.phase = a.phase;
-  sp.x1_window = (a.phase == 1) ? a.x1_window : nullptr;
-  sp.x1_window_rl = a.x1_window_rl;
+  sp.window = (a.phase == 1) ? a.window : nullptr;
+  sp.window_rl = a.window_rl;
+  sp.window_rows = a.window_rows;
   if (a.fill_derived) {
     // in-place prim replacement is only safe when the finishing sweep is a march (x2/x3) and
     // the extended Dedner source does not read neighbouring primitives
@@ -33,7 +34,7 @@ int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
   } else if (a.estimate_dt) {
     return APK_ERR_INVALID;
   }
-  if (extra == EXTRA_C2P_DT) {
+  if (extra == EXTRA_C2P_DT && a.phase != 1) {  // (a split stage reduces dt in phase 2)
     static const double huge = 1.7976931348623157e308;  // +max: neutral element of the min
     if (hipMemcpyAsync(sp.dt_bits, &huge, sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess)
       return APK_ERR_DEVICE;

@@ -34,11 +34,11 @@ struct StageParams {
   unsigned *flags;               // latched APK_FLAG_* word
   unsigned long long *dt_bits;   // min over cells of dx_d/(|v_d|+c_d), as ordered bits
   int prim_to_u1;                // fill_derived = 2: the new primitives go to u1's prim arrays
-  // optional per-block column window of the x1 sweep (apk_stage_args.x1_window): {i0, rl, lo, hi}:
-  // rows are flattened with length rl starting at column i0 and only cells lo..hi retire
-  const int *x1_window;
-  int x1_window_rl;  // largest rl in x1_window (sizes the grid)
-  int phase;         // apk_stage_args.phase
+  // optional per-block index window (apk_stage_args.window): {i0, rl, ilo, ihi, jlo, jhi, klo, khi}:
+  // rows are flattened with length rl starting at column i0 and only cells ilo..ihi retire
+  const int *window;
+  int window_rl, window_rows;  // largest rl / row count in `window` (size the grid)
+  int phase;                   // apk_stage_args.phase
   apk_ctx *ctx;  // host side only (kernel timing); never dereferenced on the device
 };
 
@@ -144,8 +144,8 @@ fused_x1_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_plane) {
   // column i0 (the whole row by default; a thin window next to a face when the sweep is split
   // around a halo exchange that is still in flight).  Ghost / window-edge columns separate the rows.
   int i0 = 0, rl = u0.ni, lo = u0.is, hi = u0.ie;
-  if (sp.x1_window) {
-    const int *w = sp.x1_window + 4 * b;
+  if (sp.window) {
+    const int *w = sp.window + 8 * b;
     i0 = w[0], rl = w[1], lo = w[2], hi = w[3];
     if (rl <= 0) return;  // nothing to do in this block
   }
@@ -529,23 +529,31 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg) {
   const double *c1 = u1.blocks[b].cons;
   double *prim_dst = u1.blocks[b].prim;  // EXTRA != NONE only (never in place here)
 
-  const int64_t run = (int64_t)u0.nx2 * u0.ni;
+  int i0 = 0, rl = u0.ni, ilo = u0.is, ihi = u0.ie, jlo = u0.js, jhi = u0.je, klo = u0.ks, khi = u0.ke;
+  if (sp.window) {  // split around a halo exchange in flight (apk_stage_args.window)
+    const int *w = sp.window + 8 * b;
+    i0 = w[0], rl = w[1], ilo = w[2], ihi = w[3], jlo = w[4], jhi = w[5], klo = w[6], khi = w[7];
+    if (rl <= 0 || jhi < jlo || khi < klo) return;
+  }
+  const int64_t run = (int64_t)(jhi - jlo + 1) * rl;
   const int64_t t = (int64_t)blockIdx.x * 62 + lane - 1;
+  if ((int64_t)blockIdx.x * 62 - 1 >= run) return;  // whole wave beyond this block's run
   const bool in_run = (t >= 0) && (t < run);
   const int64_t tc = in_run ? t : (t < 0 ? 0 : run - 1);  // out-of-run lanes shadow a valid column
-  const int row = (int)(tc / u0.ni);
-  const int i = (int)(tc - (int64_t)row * u0.ni);
-  const bool active = in_run && (lane >= 1) && (lane <= 62) && (i >= u0.is) && (i <= u0.ie);
+  const int row = (int)(tc / rl);
+  const int i = i0 + (int)(tc - (int64_t)row * rl);
+  const bool active = in_run && (lane >= 1) && (lane <= 62) && (i >= ilo) && (i <= ihi);
 
-  const int64_t col = (int64_t)(u0.js + row) * u0.sj + i;
+  const int64_t col = (int64_t)(jlo + row) * u0.sj + i;
   const double *prim = b0.prim + col;
   const double area1 = b0.dx[1] * b0.dx[2], area2 = b0.dx[0] * b0.dx[2], area3 = b0.dx[0] * b0.dx[1];
   const double vol = b0.dx[0] * b0.dx[1] * b0.dx[2];
   // the march is cut into gridDim.y segments of kseg planes: 2216 full-length waves on a machine
   // with 2048 wave slots (256 VGPRs -> 2 per SIMD) would run in two rounds; many short waves
   // keep every slot busy, for one redundant x3 solve per segment
-  const int s = u0.ks + blockIdx.y * kseg;
-  const int e = (s + kseg - 1 < u0.ke) ? s + kseg - 1 : u0.ke;
+  const int s = klo + blockIdx.y * kseg;
+  if (s > khi) return;
+  const int e = (s + kseg - 1 < khi) ? s + kseg - 1 : khi;
 
   // State carried from plane to plane: the previous plane's primitives stay in VGPRs; the lower
   // x3 flux and the (x1 + x2) flux difference wait in a private LDS stash (stash[slot][var][lane],
@@ -671,13 +679,18 @@ template <int FLUID, int RECON, int RS>
 inline int launch_fused_stage(const PackView &u0, const PackView &u1, const StageParams &sp,
                               int extra, hipStream_t s) {
   const int64_t run = (int64_t)u0.nx2 * u0.ni;
-  // a windowed x1 sweep (phase 1) flattens at most x1_window_rl columns per row
-  const int64_t run1 = sp.x1_window ? (int64_t)u0.nx2 * sp.x1_window_rl : run;
+  // a windowed x1 sweep (phase 1) flattens at most window_rl columns per row
+  const int64_t run1 = sp.window ? (int64_t)u0.nx2 * sp.window_rl : run;
   const int wpp = (int)((run1 + 61) / 62);
   const dim3 g1((wpp + 3) / 4, u0.nx3 * u0.nblocks, 1);
   if (sp.phase != 0) {
-    // split stage: only where the x1 sweep is its own, non-finishing kernel
-    if (u0.ndim == 1 || (RECON == APK_RC_DC && u0.ndim == 3)) return APK_ERR_UNSUPPORTED;
+    // split stage: where the x1 sweep is its own, non-finishing kernel, or the single-kernel
+    // 3-D donor-cell stage with out-of-place (or no) FillDerived
+    if (u0.ndim == 1) return APK_ERR_UNSUPPORTED;
+    if (RECON == APK_RC_DC && u0.ndim == 3) {
+      if (!(extra == EXTRA_NONE || (sp.prim_to_u1 && extra == EXTRA_C2P))) return APK_ERR_UNSUPPORTED;
+      if (sp.phase == 2) return APK_OK;  // everything happened in phase 1
+    }
   }
   const bool do_x1 = sp.phase != 2, do_rest = sp.phase != 1;
   // timing slots: donor-cell stages (VL2 predictor) are accounted separately
@@ -690,7 +703,8 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
     if constexpr (RECON == APK_RC_DC) {
       if (extra == EXTRA_NONE || sp.prim_to_u1) {
         // whole donor-cell stage in one march (see fused_dc3_kernel); its FillDerived is out of place
-        const int wpb = (int)((run + 61) / 62);
+        const int64_t run3 = sp.window ? (int64_t)sp.window_rows * sp.window_rl : run;
+        const int wpb = (int)((run3 + 61) / 62);
         const int kseg = (u0.nx3 >= 32) ? 16 : u0.nx3;
         const int nseg = (u0.nx3 + kseg - 1) / kseg;
         const dim3 g(wpb, nseg, u0.nblocks);

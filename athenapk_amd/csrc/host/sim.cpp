@@ -664,60 +664,108 @@ int exchange_ghosts(apk_sim *s) {
   return exchange_end(s);
 }
 
-// column windows of the split x1 sweep, per local block (see apk_stage_args.x1_window)
-int build_x1_windows(apk_sim *s) {
+// index windows of the split stages, per local block (see apk_stage_args.window)
+int upload_window(apk_sim *s, const char *tag, const std::vector<int> &w, apk_sim::WindowTable &t) {
+  const size_t nlb = w.size() / 8;
+  t.rl = t.rows = 0;
+  t.any = false;
+  for (size_t lb = 0; lb < nlb; ++lb) {
+    const int *q = &w[8 * lb];
+    if (q[1] <= 0 || q[3] < q[2] || q[5] < q[4] || q[7] < q[6]) continue;
+    t.any = true;
+    t.rl = std::max(t.rl, q[1]);
+    t.rows = std::max(t.rows, q[5] - q[4] + 1);
+  }
+  double *p = nullptr;
+  SIM_TRY(s, dev_alloc(s, tag, sizeof(int) * w.size(), &p));
+  t.d = reinterpret_cast<int *>(p);
+  SIM_HIP(s, hipMemcpy(t.d, w.data(), sizeof(int) * w.size(), hipMemcpyHostToDevice));
+  return APK_OK;
+}
+
+int build_windows(apk_sim *s) {
   const Mesh &m = s->mesh;
   const int nlb = (int)m.local_gids.size();
   const int W = m.ng;
-  std::vector<int> win[3];
-  for (auto &w : win) w.assign(4 * (size_t)nlb, 0);
-  s->x1win_rl[0] = m.ni;
-  s->x1win_rl[1] = s->x1win_rl[2] = W + 2;
-  bool any = false;
+  const int S[3] = {m.is, m.js, m.ks}, E[3] = {m.ie, m.je, m.ke};
+  auto put = [](std::vector<int> &t, int lb, int i0, int rl, int ilo, int ihi, int jlo, int jhi, int klo, int khi) {
+    int *q = &t[8 * (size_t)lb];
+    q[0] = i0, q[1] = rl, q[2] = ilo, q[3] = ihi, q[4] = jlo, q[5] = jhi, q[6] = klo, q[7] = khi;
+  };
+  std::vector<int> x1[3], dc[7];
+  for (auto &t : x1) t.assign(8 * (size_t)nlb, 0);
+  for (auto &t : dc) t.assign(8 * (size_t)nlb, 0);
+  std::vector<unsigned> late(nlb, 0u);
   for (int lb = 0; lb < nlb; ++lb) {
-    const bool rlo = m.LateFace(lb, 0, -1), rhi = m.LateFace(lb, 0, +1);
-    any = any || rlo || rhi;
-    int *w0 = &win[0][4 * lb], *w1 = &win[1][4 * lb], *w2 = &win[2][4 * lb];
-    w0[0] = 0, w0[1] = m.ni, w0[2] = m.is + (rlo ? W : 0), w0[3] = m.ie - (rhi ? W : 0);
-    w1[0] = m.is - 1, w1[1] = rlo ? W + 2 : 0, w1[2] = m.is, w1[3] = m.is + W - 1;
-    w2[0] = m.ie - W, w2[1] = rhi ? W + 2 : 0, w2[2] = m.ie - W + 1, w2[3] = m.ie;
-  }
-  (void)any;
-  {
-    std::vector<unsigned> late(nlb, 0u);
-    for (int lb = 0; lb < nlb; ++lb) {
-      int bc[3], nbc[3];
-      m.Loc(m.local_gids[lb], bc);
-      for (int sz = -1; sz <= 1; ++sz)
-        for (int sy = -1; sy <= 1; ++sy)
-          for (int sx = -1; sx <= 1; ++sx) {
-            if (!sx && !sy && !sz) continue;
-            if ((sx && !m.Active(0)) || (sy && !m.Active(1)) || (sz && !m.Active(2))) continue;
-            const int o[3] = {sx, sy, sz};
-            const bool is_late = !m.Neighbor(bc, o, nbc) || m.gid_rank[m.Gid(nbc)] != m.rank;
-            if (is_late) late[lb] |= 1u << ((sx + 1) + 3 * (sy + 1) + 9 * (sz + 1));
-          }
+    int L[3][2];
+    for (int d = 0; d < 3; ++d) {
+      L[d][0] = m.LateFace(lb, d, -1) ? 1 : 0;
+      L[d][1] = m.LateFace(lb, d, +1) ? 1 : 0;
     }
+    // x1 sweep of a high-order stage: everything farther than nghost from a late x1 face, then the slabs
+    put(x1[0], lb, 0, m.ni, m.is + W * L[0][0], m.ie - W * L[0][1], m.js, m.je, m.ks, m.ke);
+    put(x1[1], lb, m.is - 1, L[0][0] ? W + 2 : 0, m.is, m.is + W - 1, m.js, m.je, m.ks, m.ke);
+    put(x1[2], lb, m.ie - W, L[0][1] ? W + 2 : 0, m.ie - W + 1, m.ie, m.js, m.je, m.ks, m.ke);
+    // single-kernel donor-cell stage (3-D): everything but the one-cell layers next to late
+    // faces, then disjoint slabs: z (whole planes), y (rows of the remaining planes), x (columns)
+    const int lo[3] = {S[0] + L[0][0], S[1] + L[1][0], S[2] + L[2][0]};
+    const int hi[3] = {E[0] - L[0][1], E[1] - L[1][1], E[2] - L[2][1]};
+    put(dc[0], lb, 0, m.ni, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]);
+    for (int side = 0; side < 2; ++side) {
+      const int kk = side ? E[2] : S[2], jj = side ? E[1] : S[1], ii = side ? E[0] : S[0];
+      put(dc[1 + side], lb, 0, L[2][side] ? m.ni : 0, S[0], E[0], S[1], E[1], kk, kk);
+      put(dc[3 + side], lb, 0, L[1][side] ? m.ni : 0, S[0], E[0], jj, jj, lo[2], hi[2]);
+      put(dc[5 + side], lb, ii - 1, L[0][side] ? 3 : 0, ii, ii, lo[1], hi[1], lo[2], hi[2]);
+    }
+    // lateness per neighbour region for the split ghost ConsToPrim
+    int bc[3], nbc[3];
+    m.Loc(m.local_gids[lb], bc);
+    for (int sz = -1; sz <= 1; ++sz)
+      for (int sy = -1; sy <= 1; ++sy)
+        for (int sx = -1; sx <= 1; ++sx) {
+          if (!sx && !sy && !sz) continue;
+          if ((sx && !m.Active(0)) || (sy && !m.Active(1)) || (sz && !m.Active(2))) continue;
+          const int o[3] = {sx, sy, sz};
+          const bool is_late = !m.Neighbor(bc, o, nbc) || m.gid_rank[m.Gid(nbc)] != m.rank;
+          if (is_late) late[lb] |= 1u << ((sx + 1) + 3 * (sy + 1) + 9 * (sz + 1));
+        }
+  }
+  {
     double *p = nullptr;
     SIM_TRY(s, dev_alloc(s, "late_regions", sizeof(unsigned) * (size_t)nlb, &p));
     s->d_late_regions = reinterpret_cast<unsigned *>(p);
     SIM_HIP(s, hipMemcpy(s->d_late_regions, late.data(), sizeof(unsigned) * (size_t)nlb, hipMemcpyHostToDevice));
   }
-  for (int q = 0; q < 3; ++q) {
-    double *p = nullptr;
-    const char *tags[3] = {"x1win_main", "x1win_lo", "x1win_hi"};
-    SIM_TRY(s, dev_alloc(s, tags[q], sizeof(int) * 4 * (size_t)nlb, &p));
-    s->d_x1win[q] = reinterpret_cast<int *>(p);
-    SIM_HIP(s, hipMemcpy(s->d_x1win[q], win[q].data(), sizeof(int) * 4 * (size_t)nlb, hipMemcpyHostToDevice));
+  const char *x1tags[3] = {"win_x1_main", "win_x1_lo", "win_x1_hi"};
+  for (int q = 0; q < 3; ++q) SIM_TRY(s, upload_window(s, x1tags[q], x1[q], s->x1win[q]));
+  if (m.ndim == 3) {
+    const char *dctags[7] = {"win_dc_main", "win_dc_zlo", "win_dc_zhi", "win_dc_ylo", "win_dc_yhi", "win_dc_xlo", "win_dc_xhi"};
+    for (int q = 0; q < 7; ++q) SIM_TRY(s, upload_window(s, dctags[q], dc[q], s->dcwin[q]));
   }
   return APK_OK;
 }
 
-// can the exchange posted after this stage stay in flight while the next stage starts?
-bool can_overlap_next(const apk_sim *s, const apk_flux_cfg &next_cfg) {
+// can the exchange posted after a stage stay in flight while the stage `next` (1-based) starts?
+bool can_overlap_next(const apk_sim *s, int next) {
   const Mesh &m = s->mesh;
-  return s->overlap && !m.peers.empty() && s->have_comm && s->comm.exchange_begin && s->comm.exchange_end &&
-         stage_can_fuse(s) && m.ndim >= 2 && next_cfg.recon != APK_RC_DC && m.mb[0] >= 4 * m.ng && s->d_x1win[0];
+  if (!(s->overlap && !m.peers.empty() && s->have_comm && s->comm.exchange_begin && s->comm.exchange_end &&
+        stage_can_fuse(s) && m.ndim >= 2 && s->x1win[0].d))
+    return false;
+  const apk_flux_cfg &cfg = (next == 1) ? s->pkg.flux_first_stage : s->pkg.flux_other_stage;
+  const bool ext_dedner = s->pkg.fluid == APK_FLUID_GLMMHD && s->pkg.glmmhd_source_extended;
+  if (cfg.recon == APK_RC_DC) {
+    // single-kernel donor-cell stage: 3-D, out-of-place FillDerived, no dt in the kernel
+    return m.ndim == 3 && !ext_dedner && m.mb[0] >= 4 && m.mb[1] >= 4 && m.mb[2] >= 4 &&
+           !(next == s->nstages && s->pkg.calc_dt_hyp) && !(s->fmft && next == s->nstages);
+  }
+  return m.mb[0] >= 4 * m.ng;
+}
+
+// complete an exchange left in flight (accessors, end of run): ghosts of cons and prim are valid after
+int finish_pending(apk_sim *s) {
+  if (!s->exchange_pending) return APK_OK;
+  SIM_TRY(s, exchange_end(s));
+  return apk_cons_to_prim_ghosts(s->ctx, s->mu0(), s->pkg.fluid, &s->pkg.eos, s->stream);
 }
 
 int fill_derived(apk_sim *s) {
@@ -818,6 +866,8 @@ int do_stage(apk_sim *s, int stage) {
   const apk_flux_cfg cfg = (stage == 1) ? pkg.flux_first_stage : pkg.flux_other_stage;
   bool fused_fill = false;
   s->stage_dt_pending = false;
+  // an exchange left in flight is completed inside the fused stage below; anything else first
+  if (s->exchange_pending && !can_overlap_next(s, stage)) SIM_TRY(s, finish_pending(s));
   if (stage_can_fuse(s)) {
     apk_stage_args a{};
     a.cfg = cfg;
@@ -849,28 +899,31 @@ int do_stage(apk_sim *s, int stage) {
     }
     a.fill_derived = fused_fill ? (swap_prim ? 2 : 1) : 0;
     a.estimate_dt = (fused_fill && stage == s->nstages && pkg.calc_dt_hyp) ? 1 : 0;
+    if (s->exchange_pending && cfg.recon == APK_RC_DC && !(dc3 && swap_prim)) SIM_TRY(s, finish_pending(s));
     if (s->exchange_pending) {
       // The previous stage's halo messages are still in flight.  Ghost zones filled by same-rank
-      // copies are ready: convert them, run the x1 sweep wherever it does not touch a remote
-      // face, then complete the exchange and do the thin slabs next to those faces and the rest.
-      // (if the posting stage left FillDerived to us, the interior is converted here as well: the
-      // kernel below only covers ghost zones)
-      if (s->pending_full_c2p) return fail(s, APK_ERR_INVALID, "internal: overlapped exchange after an unfilled stage");
+      // copies are ready: convert them, run whatever does not touch a late face (the x1 sweep of
+      // a high-order stage / the whole single-kernel donor-cell stage, on index windows), then
+      // complete the exchange and do the thin slabs next to those faces and the rest.
       SIM_TRY(s, apk_cons_to_prim_ghosts_split(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->d_late_regions, 1, s->stream));
+      const bool whole = dc3 && swap_prim;  // single-kernel stage
+      const apk_sim::WindowTable *tabs = whole ? s->dcwin : s->x1win;
+      const int ntabs = whole ? 7 : 3;
       a.phase = 1;
-      a.x1_window = s->d_x1win[0];
-      a.x1_window_rl = s->x1win_rl[0];
-      SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
-      SIM_TRY(s, exchange_end(s));
-      SIM_TRY(s, apk_cons_to_prim_ghosts_split(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->d_late_regions, 2, s->stream));
-      for (int q = 1; q <= 2; ++q) {
-        a.x1_window = s->d_x1win[q];
-        a.x1_window_rl = s->x1win_rl[q];
+      for (int q = 0; q < ntabs; ++q) {
+        if (q == 1) {
+          SIM_TRY(s, exchange_end(s));
+          SIM_TRY(s, apk_cons_to_prim_ghosts_split(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->d_late_regions, 2, s->stream));
+        }
+        if (!tabs[q].any) continue;
+        a.window = tabs[q].d;
+        a.window_rl = tabs[q].rl;
+        a.window_rows = tabs[q].rows;
         SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
       }
       a.phase = 2;
-      a.x1_window = nullptr;
-      a.x1_window_rl = 0;
+      a.window = nullptr;
+      a.window_rl = a.window_rows = 0;
       s->overlapped += 1;
     }
     SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
@@ -892,10 +945,10 @@ int do_stage(apk_sim *s, int stage) {
     }
   }
   if (s->fmft && stage == s->nstages) SIM_TRY(s, turbulence_driving(s, s->dt));
-  if (stage < s->nstages && fused_fill && can_overlap_next(s, pkg.flux_other_stage)) {
-    // post the messages and leave them in flight: the next stage completes the exchange
+  if (fused_fill && can_overlap_next(s, stage < s->nstages ? stage + 1 : 1)) {
+    // post the messages and leave them in flight: the next stage (of this or of the next cycle)
+    // completes the exchange
     SIM_TRY(s, exchange_begin(s, true));
-    s->pending_full_c2p = !fused_fill;
   } else {
     SIM_TRY(s, exchange_ghosts(s));
     if (fused_fill) {
@@ -1004,7 +1057,7 @@ int apk_sim_create(const char *deck, const char *const *overrides, int noverride
     return bail(rc);
   }
   if ((rc = build_copy_plans(s)) != APK_OK) return bail(rc);
-  if (!s->mesh.peers.empty() && (rc = build_x1_windows(s)) != APK_OK) return bail(rc);
+  if (!s->mesh.peers.empty() && (rc = build_windows(s)) != APK_OK) return bail(rc);
   if (s->fmft && (rc = turbulence_device_setup(s)) != APK_OK) return bail(rc);
   return APK_OK;
 }
@@ -1012,6 +1065,7 @@ int apk_sim_create(const char *deck, const char *const *overrides, int noverride
 void apk_sim_destroy(apk_sim *s) {
   if (!s) return;
   if (!s->host_only) {
+    if (s->exchange_pending && s->comm.exchange_end) (void)s->comm.exchange_end(s->comm.user);  // drain
     (void)hipDeviceSynchronize();
     for (auto &pp : s->plans_of)
       for (auto &p : pp) apk_copy_plan_destroy(p);
@@ -1021,7 +1075,8 @@ void apk_sim_destroy(apk_sim *s) {
         apk_pack_destroy(s->mu1_of[p][w]);
       }
     apk_fmft_destroy(s->fm_dev);
-    for (int *w : s->d_x1win) dev_free(s, reinterpret_cast<double *>(w));
+    for (auto &t : s->x1win) dev_free(s, reinterpret_cast<double *>(t.d));
+    for (auto &t : s->dcwin) dev_free(s, reinterpret_cast<double *>(t.d));
     dev_free(s, reinterpret_cast<double *>(s->d_late_regions));
     dev_free(s, s->d_acc);
     dev_free(s, s->d_phases);
@@ -1041,6 +1096,7 @@ const char *apk_sim_last_error(const apk_sim *s) { return s ? s->err.c_str() : "
 
 int apk_sim_set_fused(apk_sim *s, int fused) {
   if (!s) return APK_ERR_INVALID;
+  if (!s->host_only) SIM_TRY(s, finish_pending(s));
   s->fused = fused != 0;
   if (!s->host_only && !stage_can_fuse(s)) return ensure_flux_arrays(s);
   return APK_OK;
@@ -1048,6 +1104,7 @@ int apk_sim_set_fused(apk_sim *s, int fused) {
 
 int apk_sim_set_overlap(apk_sim *s, int overlap) {
   if (!s) return APK_ERR_INVALID;
+  if (!s->host_only) SIM_TRY(s, finish_pending(s));
   s->overlap = overlap != 0;
   return APK_OK;
 }
@@ -1057,6 +1114,7 @@ long long apk_sim_overlapped_exchanges(const apk_sim *s) { return s ? s->overlap
 int apk_sim_initialize(apk_sim *s) {
   if (!s || s->host_only) return APK_ERR_INVALID;
   s->err.clear();
+  SIM_TRY(s, finish_pending(s));
   const int nlb = (int)s->mesh.local_gids.size();
   std::vector<double> host((size_t)s->nper);
   try {
@@ -1173,6 +1231,7 @@ void *apk_sim_block_ptr(const apk_sim *s, int lb, int field) {
 }
 
 int apk_sim_read_block(apk_sim *s, int lb, int field, double *host_out) {
+  if (s && !s->host_only) SIM_TRY(s, finish_pending(s));
   void *p = apk_sim_block_ptr(s, lb, field);
   if (!p || !host_out) return APK_ERR_INVALID;
   SIM_HIP(s, hipStreamSynchronize(hs(s)));
@@ -1181,6 +1240,7 @@ int apk_sim_read_block(apk_sim *s, int lb, int field, double *host_out) {
 }
 
 int apk_sim_write_block(apk_sim *s, int lb, int field, const double *host_in) {
+  if (s && !s->host_only) SIM_TRY(s, finish_pending(s));
   void *p = apk_sim_block_ptr(s, lb, field);
   if (!p || !host_in) return APK_ERR_INVALID;
   SIM_HIP(s, hipStreamSynchronize(hs(s)));
@@ -1431,10 +1491,12 @@ int apk_sim_linear_wave_errors(apk_sim *s, double *rms, double *l1, double *mx) 
 
 int apk_sim_exchange_ghosts(apk_sim *s) {
   if (!s || s->host_only) return APK_ERR_INVALID;
+  SIM_TRY(s, finish_pending(s));
   return exchange_ghosts(s);
 }
 int apk_sim_fill_derived(apk_sim *s) {
   if (!s || s->host_only) return APK_ERR_INVALID;
+  SIM_TRY(s, finish_pending(s));
   return fill_derived(s);
 }
 int apk_sim_estimate_timestep(apk_sim *s, double *dt) {

@@ -111,9 +111,14 @@ struct apk_sim {
   // face with a remote neighbour, completes the exchange, then does the thin slabs and the rest.
   bool overlap = true;
   bool exchange_pending = false;
-  bool pending_full_c2p = false;  // the stage that posted the exchange did not fill prim itself
-  int *d_x1win[3] = {nullptr, nullptr, nullptr};  // device {i0, rl, lo, hi} per block: main / low slab / high slab
-  int x1win_rl[3] = {0, 0, 0};
+  // device window tables (apk_stage_args.window, 8 ints per block) of the split stages:
+  // x1 sweep: main / low slab / high slab; 3-D donor-cell stage: main / z lo,hi / y lo,hi / x lo,hi
+  struct WindowTable {
+    int *d = nullptr;
+    int rl = 0, rows = 0;
+    bool any = false;  // some block has work in this table
+  };
+  WindowTable x1win[3], dcwin[7];
   unsigned *d_late_regions = nullptr;  // per block: bit (sx+1)+3(sy+1)+9(sz+1) = that neighbour region is filled late
   long long overlapped = 0;
   std::string err;

@@ -103,6 +103,15 @@ class Simulation(_FmftHost):
         self._group = group
         dev = torch.device("cuda", torch.cuda.current_device())
         self._dev = dev
+        # The tiny dt / c_h / history reductions go through a host-side (gloo) group: on the RCCL
+        # communicator they would queue behind halo messages that are still in flight and make the
+        # host wait for them, which is exactly what the overlap avoids.
+        red_group = group
+        if nranks > 1:
+            import torch.distributed as dist
+            if dist.get_backend(group) != "gloo":
+                red_group = dist.new_group(backend="gloo")
+        self._red_group = red_group
 
         def _alloc(user, tag, nbytes):
             t = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=dev)
@@ -146,7 +155,7 @@ class Simulation(_FmftHost):
         def _amin(user, vals, n):
             try:
                 import torch.distributed as dist
-                _allreduce(vals, n, dist.ReduceOp.MIN, dev, group)
+                _allreduce(vals, n, dist.ReduceOp.MIN, dev, red_group)
                 return 0
             except Exception as e:
                 self._cb_error = e
@@ -155,7 +164,7 @@ class Simulation(_FmftHost):
         def _asum(user, vals, n):
             try:
                 import torch.distributed as dist
-                _allreduce(vals, n, dist.ReduceOp.SUM, dev, group)
+                _allreduce(vals, n, dist.ReduceOp.SUM, dev, red_group)
                 return 0
             except Exception as e:
                 self._cb_error = e

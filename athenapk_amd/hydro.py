@@ -151,10 +151,11 @@ def DednerSource(md, extended, alpha, c_h, mindx, beta_dt):
 
 
 def StageFused(u0, u1, fluid, recon, riemann, eos, c_h, gam0, gam1, beta_dt, dedner=0,
-               glmmhd_alpha=0.1, mindx=1.0, fill_derived=False, estimate_dt=False, phase=0, x1_window=None):
+               glmmhd_alpha=0.1, mindx=1.0, fill_derived=False, estimate_dt=False, phase=0, window=None):
     """Fused CalculateFluxes -> UpdateWithFluxDivergence -> DednerSource for one RK stage;
     optionally also FillDerived / the dt estimate on the updated cells.  phase / x1_window split
-    the stage around a halo exchange (x1_window: int32 CUDA tensor [nblocks][4] = i0, rl, lo, hi)."""
+    the stage around a halo exchange (window: int32 CUDA tensor [nblocks][8] =
+    i0, rl, ilo, ihi, jlo, jhi, klo, khi)."""
     ctx = u0.ctx
     a = L.StageArgs()
     a.cfg = _cfg(fluid, recon, riemann)
@@ -163,10 +164,11 @@ def StageFused(u0, u1, fluid, recon, riemann, eos, c_h, gam0, gam1, beta_dt, ded
     a.dedner, a.glmmhd_alpha, a.mindx = dedner, glmmhd_alpha, mindx
     a.fill_derived, a.estimate_dt = int(fill_derived), int(estimate_dt)
     a.phase = phase
-    if x1_window is not None:
-        assert x1_window.dtype == torch.int32 and x1_window.is_cuda and x1_window.shape == (u0.nblocks, 4)
-        a.x1_window = x1_window.data_ptr()
-        a.x1_window_rl = int(x1_window[:, 1].max().item())
+    if window is not None:
+        assert window.dtype == torch.int32 and window.is_cuda and window.shape == (u0.nblocks, 8)
+        a.window = window.data_ptr()
+        a.window_rl = int(window[:, 1].max().item())
+        a.window_rows = max(1, int((window[:, 5] - window[:, 4] + 1).max().item()))
     _check(ctx.lib.apk_stage_fused(ctx.h, u0.h, u1.h, C.byref(a), _stream()), ctx.lib, ctx.h)
 
 

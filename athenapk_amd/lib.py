@@ -55,8 +55,8 @@ class StageArgs(C.Structure):
     _fields_ = [("cfg", FluxCfg), ("eos", Eos), ("c_h", C.c_double), ("gam0", C.c_double),
                 ("gam1", C.c_double), ("beta_dt", C.c_double), ("dedner", C.c_int),
                 ("glmmhd_alpha", C.c_double), ("mindx", C.c_double), ("fill_derived", C.c_int),
-                ("estimate_dt", C.c_int), ("phase", C.c_int), ("x1_window", C.c_void_p),
-                ("x1_window_rl", C.c_int)]
+                ("estimate_dt", C.c_int), ("phase", C.c_int), ("window", C.c_void_p),
+                ("window_rl", C.c_int), ("window_rows", C.c_int)]
 
 
 class FmftBlock(C.Structure):

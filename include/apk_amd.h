@@ -161,20 +161,26 @@ typedef struct apk_stage_args {
    *                    apk_stage_dt_read(). */
   int fill_derived;
   int estimate_dt;
-  /* Optional: split the stage around a halo exchange that is still in flight (2-D / 3-D,
-   * reconstruction other than dc).  The x1 sweep only reads x1 ghost zones, so it can run on all
-   * cells that are not within nghost of a face whose neighbour data has not arrived yet:
-   *  phase = 0            the whole stage (x1_window must be NULL)
-   *  phase = 1            only the x1 sweep, restricted per block by x1_window: a DEVICE array of
-   *                       4 ints per block {i0, rl, lo, hi}: the rows are flattened with rl
-   *                       columns starting at column i0 and only the cells lo..hi are updated
-   *                       ({0, Ni, is, ie} is the whole block; rl = 0 skips the block).  May be
-   *                       called several times with disjoint windows.
-   *  phase = 2            the remaining sweeps (x2 [, x3], update, sources, fill_derived, dt).
-   * The union of the phase-1 windows must cover every interior cell exactly once. */
+  /* Optional: split the stage around a halo exchange that is still in flight (2-D / 3-D).  Work
+   * that does not read the ghost zones still in flight runs first on per-block index windows:
+   *  phase = 0   the whole stage (window must be NULL)
+   *  phase = 1   partial work restricted per block by `window`, a DEVICE array of 8 ints per block
+   *              {i0, rl, ilo, ihi, jlo, jhi, klo, khi}: rows jlo..jhi of planes klo..khi are
+   *              flattened with rl columns starting at column i0 and only the cells ilo..ihi of a
+   *              row are updated ({0, Ni, is, ie, js, je, ks, ke} is the whole block; rl = 0 skips
+   *              the block).  May be called several times with disjoint windows whose union covers
+   *              every interior cell exactly once.
+   *                - stages whose x1 sweep is its own kernel (reconstruction other than dc): the
+   *                  x1 sweep only (it reads x1 ghost zones only); j/k ranges must be the full
+   *                  interior.  estimate_dt / fill_derived take effect in phase 2.
+   *                - 3-D donor-cell stages (one kernel for the whole stage): the whole stage on the
+   *                  window; estimate_dt is not available in this mode.
+   *  phase = 2   the remaining sweeps (x2 [, x3], update, sources, fill_derived, dt); nothing for
+   *              3-D donor-cell stages.
+   * window_rl / window_rows: the largest rl and (jhi - jlo + 1) in `window` (size the launch). */
   int phase;
-  const int *x1_window;
-  int x1_window_rl; /* largest rl in x1_window (sizes the launch) */
+  const int *window;
+  int window_rl, window_rows;
 } apk_stage_args;
 int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
                     const apk_stage_args *args, apk_stream_t stream);

@@ -427,14 +427,15 @@ def test_fused_stage_split_around_exchange(request, oracle, fluid, recon, rieman
     dt_ref = hydro.StageDt(ctx, 0.3)
     m0, m1 = packs()
     is_, ie, ni, W = ng, ng + nx[0] - 1, nx[0] + 2 * ng, ng
+    jk = [ng, ng + nx[1] - 1, ng if nx[2] > 1 else 0, ng + nx[2] - 1 if nx[2] > 1 else 0]  # full j, k ranges
     # block 0: data missing on the low x1 side, block 1: on the high side, block 2: on both
     missing = [(1, 0), (0, 1), (1, 1)]
-    main = [[0, ni, is_ + W * lo, ie - W * hi] for lo, hi in missing]
-    slab_lo = [[is_ - 1, W + 2, is_, is_ + W - 1] if lo else [0, 0, 0, -1] for lo, hi in missing]
-    slab_hi = [[ie - W, W + 2, ie - W + 1, ie] if hi else [0, 0, 0, -1] for lo, hi in missing]
+    main = [[0, ni, is_ + W * lo, ie - W * hi] + jk for lo, hi in missing]
+    slab_lo = [([is_ - 1, W + 2, is_, is_ + W - 1] if lo else [0, 0, 0, -1]) + jk for lo, hi in missing]
+    slab_hi = [([ie - W, W + 2, ie - W + 1, ie] if hi else [0, 0, 0, -1]) + jk for lo, hi in missing]
     for win in (main, slab_lo, slab_hi):
         t = torch.tensor(win, dtype=torch.int32, device="cuda")
-        hydro.StageFused(m0, m1, fluid, recon, riemann, eos, C_H, 0.5, 0.5, 0.004, phase=1, x1_window=t, **kw)
+        hydro.StageFused(m0, m1, fluid, recon, riemann, eos, C_H, 0.5, 0.5, 0.004, phase=1, window=t, **kw)
     hydro.StageFused(m0, m1, fluid, recon, riemann, eos, C_H, 0.5, 0.5, 0.004, phase=2, **kw)
     dt = hydro.StageDt(ctx, 0.3)
     if strict:
@@ -444,6 +445,59 @@ def test_fused_stage_split_around_exchange(request, oracle, fluid, recon, rieman
         assert np.array_equal(m0.cons_host(), r0.cons_host())
     want = H.orc_stage(fluid, recon, riemann, g, cons, cons * 1.01, prim, GAMMA, C_H, 0.5, 0.5, 0.004, dedner=ded,
                        alpha=0.1, mindx=0.07)
+    _cmp(H.interior(m0.cons_host(), nx, ng), H.interior(want, nx, ng), strict, "cons")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("fluid,riemann,nx", [("glmmhd", "hlld", (64, 10, 34)), ("euler", "hllc", (66, 9, 7))])
+def test_donor_cell_stage_split_around_exchange(request, oracle, fluid, riemann, nx, strict):
+    """The single-kernel 3-D donor-cell stage on index windows: everything but the one-cell layers
+    next to 'late' faces first, then the six slabs (disjoint, covering every cell once)."""
+    import torch
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    ng, prim, g = _case(fluid, "dc", nx, kind="smooth", seed=53, nblocks=3)
+    cons = H.prim_to_cons(fluid, prim, GAMMA)
+    ded = 1 if fluid == "glmmhd" else 0
+    eos = hydro.L.make_eos(GAMMA, pfloor=1e-6, dfloor=1e-6)
+    kw = dict(dedner=ded, glmmhd_alpha=0.1, mindx=0.07, fill_derived=2)
+    sentinel = np.full_like(prim, -7.0)
+
+    def packs():
+        a = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=cons, prim=prim, with_flux=False)
+        b = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=cons, prim=sentinel, with_flux=False)
+        return a, b
+    r0, r1 = packs()
+    hydro.StageFused(r0, r1, fluid, "dc", riemann, eos, C_H, 0.0, 1.0, 0.004, **kw)
+    m0, m1 = packs()
+    s_ = [ng, ng, ng]
+    e_ = [ng + nx[0] - 1, ng + nx[1] - 1, ng + nx[2] - 1]
+    ni = nx[0] + 2 * ng
+    # late faces per block: (x lo, x hi, y lo, y hi, z lo, z hi)
+    late = [(1, 0, 0, 1, 0, 0), (0, 1, 1, 0, 1, 1), (1, 1, 1, 1, 1, 1)]
+
+    def rng(d, L):  # interior range of direction d minus the late layers
+        return [s_[d] + L[2 * d], e_[d] - L[2 * d + 1]]
+    tables = [[[0, ni] + rng(0, L) + rng(1, L) + rng(2, L) for L in late]]
+    empty = [0, 0, 0, -1, 0, -1, 0, -1]
+    full_i = lambda: [0, ni, s_[0], e_[0]]  # noqa: E731
+    for side in (0, 1):  # z slabs: one plane, all rows and columns
+        kk = s_[2] if side == 0 else e_[2]
+        tables.append([full_i() + [s_[1], e_[1], kk, kk] if L[4 + side] else empty for L in late])
+    for side in (0, 1):  # y slabs: one row, the planes not covered by the z slabs
+        jj = s_[1] if side == 0 else e_[1]
+        tables.append([full_i() + [jj, jj] + rng(2, L) if L[2 + side] else empty for L in late])
+    for side in (0, 1):  # x slabs: one column (+ a halo lane each side)
+        ii = s_[0] if side == 0 else e_[0]
+        tables.append([[ii - 1, 3, ii, ii] + rng(1, L) + rng(2, L) if L[side] else empty for L in late])
+    for win in tables:
+        t = torch.tensor(win, dtype=torch.int32, device="cuda")
+        hydro.StageFused(m0, m1, fluid, "dc", riemann, eos, C_H, 0.0, 1.0, 0.004, phase=1, window=t, **kw)
+    hydro.StageFused(m0, m1, fluid, "dc", riemann, eos, C_H, 0.0, 1.0, 0.004, phase=2, **kw)   # no-op
+    assert np.array_equal(m0.cons_host(), r0.cons_host()) and np.array_equal(m1.prim_host(), r1.prim_host())
+    want = H.orc_stage(fluid, "dc", riemann, g, cons, cons, prim, GAMMA, C_H, 0.0, 1.0, 0.004, dedner=ded, alpha=0.1,
+                       mindx=0.07)
     _cmp(H.interior(m0.cons_host(), nx, ng), H.interior(want, nx, ng), strict, "cons")
 
 
