@@ -642,6 +642,7 @@ int exchange_begin(apk_sim *s, bool async) {
     if (async) {
       if (s->comm.exchange_begin(s->comm.user) != 0) return fail(s, APK_ERR_DEVICE, "halo exchange (begin) failed");
       s->exchange_pending = true;
+      s->pending_cons = s->cur;
     } else if (s->comm.exchange(s->comm.user) != 0) {
       return fail(s, APK_ERR_DEVICE, "halo exchange failed");
     }
@@ -650,12 +651,15 @@ int exchange_begin(apk_sim *s, bool async) {
 }
 
 int exchange_end(apk_sim *s) {
+  // an exchange left in flight targets the buffer that held the state when it was posted: the
+  // first stage of the next cycle has swapped the buffer roles by the time it completes it
+  const int buf = s->exchange_pending ? s->pending_cons : s->cur;
   if (s->exchange_pending) {
     if (s->comm.exchange_end(s->comm.user) != 0) return fail(s, APK_ERR_DEVICE, "halo exchange (end) failed");
     s->exchange_pending = false;
   }
-  if (!s->mesh.peers.empty()) SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(PH_UNPACK), s->stream));
-  for (int ph = PH_BC1; ph <= PH_BC3; ++ph) SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(ph), s->stream));
+  if (!s->mesh.peers.empty()) SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plans_of[buf][PH_UNPACK], s->stream));
+  for (int ph = PH_BC1; ph <= PH_BC3; ++ph) SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plans_of[buf][ph], s->stream));
   return APK_OK;
 }
 
@@ -764,8 +768,9 @@ bool can_overlap_next(const apk_sim *s, int next) {
 // complete an exchange left in flight (accessors, end of run): ghosts of cons and prim are valid after
 int finish_pending(apk_sim *s) {
   if (!s->exchange_pending) return APK_OK;
+  apk_pack *state = s->mu0_of[s->pending_cons][s->pcur];
   SIM_TRY(s, exchange_end(s));
-  return apk_cons_to_prim_ghosts(s->ctx, s->mu0(), s->pkg.fluid, &s->pkg.eos, s->stream);
+  return apk_cons_to_prim_ghosts(s->ctx, state, s->pkg.fluid, &s->pkg.eos, s->stream);
 }
 
 int fill_derived(apk_sim *s) {
@@ -905,7 +910,8 @@ int do_stage(apk_sim *s, int stage) {
       // copies are ready: convert them, run whatever does not touch a late face (the x1 sweep of
       // a high-order stage / the whole single-kernel donor-cell stage, on index windows), then
       // complete the exchange and do the thin slabs next to those faces and the rest.
-      SIM_TRY(s, apk_cons_to_prim_ghosts_split(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->d_late_regions, 1, s->stream));
+      apk_pack *state = s->mu0_of[s->pending_cons][s->pcur];  // (stage 1 has swapped the cons roles already)
+      SIM_TRY(s, apk_cons_to_prim_ghosts_split(s->ctx, state, pkg.fluid, &pkg.eos, s->d_late_regions, 1, s->stream));
       const bool whole = dc3 && swap_prim;  // single-kernel stage
       const apk_sim::WindowTable *tabs = whole ? s->dcwin : s->x1win;
       const int ntabs = whole ? 7 : 3;
@@ -913,7 +919,7 @@ int do_stage(apk_sim *s, int stage) {
       for (int q = 0; q < ntabs; ++q) {
         if (q == 1) {
           SIM_TRY(s, exchange_end(s));
-          SIM_TRY(s, apk_cons_to_prim_ghosts_split(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->d_late_regions, 2, s->stream));
+          SIM_TRY(s, apk_cons_to_prim_ghosts_split(s->ctx, state, pkg.fluid, &pkg.eos, s->d_late_regions, 2, s->stream));
         }
         if (!tabs[q].any) continue;
         a.window = tabs[q].d;
