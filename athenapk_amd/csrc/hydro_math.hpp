@@ -41,6 +41,12 @@ APK_DEV double min2(double a, double b) { return (b < a) ? b : a; }  // std::min
 APK_DEV double max2(double a, double b) { return (a < b) ? b : a; }  // std::max
 // Parthenon SIGN(x) = (x < 0) ? -1 : 1 ; carried as a bool "is negative"
 APK_DEV bool neg(double x) { return x < 0.0; }
+// x > 0 with NaN -> false, decided on the bit pattern so that the default build's finite-math
+// assumption (-fno-honor-nans) cannot fold the NaN case away: a blown-up state must still be flagged
+APK_DEV bool strictly_positive(double x) {
+  const long long b = __double_as_longlong(x);
+  return b > 0 && b <= 0x7ff0000000000000LL;
+}
 APK_DEV double with_sign(bool negative, double mag) { return negative ? -mag : mag; }
 
 template <int FLUID>
@@ -776,7 +782,7 @@ APK_DEV unsigned cons_to_prim_cell(const apk_eos &eos, double (&u)[nvars<FLUID>(
   constexpr bool mhd = (FLUID == APK_FLUID_GLMMHD);
   unsigned flags = 0;
   const double gm1 = eos.gamma - 1.0;
-  if (!(u[IDN] > 0.0 || eos.dfloor > 0.0)) flags |= APK_FLAG_NEG_DENSITY;
+  if (!(strictly_positive(u[IDN]) || eos.dfloor > 0.0)) flags |= APK_FLAG_NEG_DENSITY;
   u[IDN] = (u[IDN] > eos.dfloor) ? u[IDN] : eos.dfloor;
   w[IDN] = u[IDN];
   const double di = 1.0 / u[IDN];
@@ -809,7 +815,7 @@ APK_DEV unsigned cons_to_prim_cell(const apk_eos &eos, double (&u)[nvars<FLUID>(
     u[IEN] -= e_k - e_k_new;
     e_k = e_k_new;
   }
-  if (!(w[IPR] > 0.0 || eos.pfloor > 0.0 || eos.efloor > 0.0)) flags |= APK_FLAG_NEG_PRESSURE;
+  if (!(strictly_positive(w[IPR]) || eos.pfloor > 0.0 || eos.efloor > 0.0)) flags |= APK_FLAG_NEG_PRESSURE;
   if ((eos.pfloor > 0.0) && (w[IPR] < eos.pfloor)) {
     if constexpr (mhd) u[IEN] = (eos.pfloor / gm1) + e_k + e_B;
     else u[IEN] = (eos.pfloor / gm1) + e_k;

@@ -166,10 +166,12 @@ def test_cons_to_prim(request, oracle, fluid, floors):
     assert ctx.poll_flags() == 0
 
 
-def test_cons_to_prim_latches_negative_state_flags(request):
-    """adiabatic_hydro.hpp:77-79,111-113: PARTHENON_REQUIRE -> latched device flag."""
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+def test_cons_to_prim_latches_negative_state_flags(request, strict):
+    """adiabatic_hydro.hpp:77-79,111-113: PARTHENON_REQUIRE -> latched device flag.  A NaN state
+    must be flagged too, also in the default build (compiled with -fno-honor-nans)."""
     from athenapk_amd import hydro
-    ctx = _ctx(request, True)
+    ctx = _ctx(request, strict)
     nx, ng = (8, 4, 4), 2
     w = H.random_prim("euler", nx, ng, seed=8, kind="rough")
     u = H.prim_to_cons("euler", w, 1.4)
@@ -183,6 +185,16 @@ def test_cons_to_prim_latches_negative_state_flags(request):
     md = hydro.MeshData(ctx, nx, ng, 5, cons=u, with_flux=False)
     hydro.ConservedToPrimitive(md, "euler", hydro.L.make_eos(1.4))
     assert ctx.poll_flags() == hydro.L.FLAG_NEG_PRESSURE
+    u[0, 4, 2, 2, 2] = 5.0
+    u[0, 0, 3, 2, 1] = np.nan
+    md = hydro.MeshData(ctx, nx, ng, 5, cons=u, with_flux=False)
+    hydro.ConservedToPrimitive(md, "euler", hydro.L.make_eos(1.4))
+    assert ctx.poll_flags() & hydro.L.FLAG_NEG_DENSITY
+    u[0, 0, 3, 2, 1] = 1.0
+    u[0, 4, 3, 2, 1] = np.nan
+    md = hydro.MeshData(ctx, nx, ng, 5, cons=u, with_flux=False)
+    hydro.ConservedToPrimitive(md, "euler", hydro.L.make_eos(1.4))
+    assert ctx.poll_flags() & hydro.L.FLAG_NEG_PRESSURE
 
 
 @pytest.mark.parametrize("fluid", ["euler", "glmmhd"])
