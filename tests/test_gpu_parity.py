@@ -378,7 +378,7 @@ def test_fused_stage_fill_derived_and_dt(request, oracle, fluid, recon, riemann,
 def test_fused_stage_fill_derived_out_of_place(request, oracle, fluid, recon, riemann, nx, gam0, strict):
     """fill_derived = 2: the new primitives land in u1's prim arrays, u0.prim stays as it was.
     For 3-D donor cell this is the single-march kernel (fused_dc3_kernel), incl. its k segments
-    (nx3 = 34 -> 16 + 16 + 2 planes)."""
+    (nx3 = 34 -> 4 x 8 + 2 planes)."""
     from athenapk_amd import hydro
     ctx = _ctx(request, strict)
     ng, prim, g = _case(fluid, recon, nx, kind="smooth", seed=43)
