@@ -18,6 +18,8 @@
 //  bit-identical to CalculateFluxes + UpdateWithFluxDivergence + DednerSource.
 #pragma once
 
+#include <cstdlib>
+
 #include "apk_internal.hpp"
 #include "hydro_math.hpp"
 
@@ -228,7 +230,7 @@ constexpr int march_lds_bytes() {
 
 template <int FLUID, int RECON, int RS, int DIR, bool FINAL, int EXTRA = EXTRA_NONE>
 __global__ void __launch_bounds__(64, kMarchMinWaves)
-fused_march_kernel(PackView u0, PackView u1, StageParams sp) {
+fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg) {
   static_assert(DIR == 2 || DIR == 3, "march is for x2/x3");
   static_assert(FINAL || EXTRA == EXTRA_NONE, "extras belong to the finishing sweep");
   double lane_min_dt = 1.7976931348623157e308;
@@ -241,13 +243,22 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp) {
   const int trans = blockIdx.y;  // k for DIR==2, j for DIR==3
   const bool active = (i <= u0.ie);
   const int ii = active ? i : u0.ie;  // idle lanes shadow a valid column, never store
-  const int b = blockIdx.z;
+  // the march may be cut into nseg segments (blockIdx.z = block * nseg + segment): few, long
+  // waves cannot fill the machine when the pack is small (one 256^3 block is 1024 waves for 2048
+  // slots); each segment re-reads 2H+1 rows and redoes one face
+  const int b = blockIdx.z / nseg;
+  const int seg = blockIdx.z - b * nseg;
   const apk_block_desc b0 = u0.blocks[b];
   const double *c1 = u1.blocks[b].cons;
 
   const int64_t st = (DIR == 2) ? u0.sj : u0.sk;
-  const int s = (DIR == 2) ? u0.js : u0.ks;  // first / last interior index along the march
-  const int e = (DIR == 2) ? u0.je : u0.ke;
+  const int n_along = (DIR == 2) ? u0.nx2 : u0.nx3;
+  const int seg_len = (n_along + nseg - 1) / nseg;
+  const int s0 = (DIR == 2) ? u0.js : u0.ks;
+  const int s = s0 + seg * seg_len;  // first / last interior index along the march
+  const int e_all = (DIR == 2) ? u0.je : u0.ke;
+  const int e = (s + seg_len - 1 < e_all) ? s + seg_len - 1 : e_all;
+  if (s > e_all) return;
   const int64_t base = (DIR == 2) ? ((int64_t)(u0.ks + trans) * u0.sk + ii)
                                   : ((int64_t)(u0.js + trans) * u0.sj + ii);
   const double dx = b0.dx[DIR - 1];
@@ -664,15 +675,30 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg) {
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------
+// segments per march so that the launch has at least ~2 x 2048 waves (MI355X: 1024 SIMDs x 2
+// resident march waves), never shorter than 16 cells
+inline int march_segments(int64_t waves, int n_along) {
+  static const int forced = std::getenv("APK_MARCH_NSEG") ? std::atoi(std::getenv("APK_MARCH_NSEG")) : 0;  // A/B switch
+  int nseg = forced > 0 ? forced : (int)((4096 + waves - 1) / waves);
+  const int max_seg = n_along / 16 > 0 ? n_along / 16 : 1;
+  if (nseg > max_seg) nseg = max_seg;
+  return nseg < 1 ? 1 : nseg;
+}
+
 template <int FLUID, int RECON, int RS, int DIR>
 inline void launch_final_march(const PackView &u0, const PackView &u1, const StageParams &sp, int extra,
                                dim3 grid, int lds, hipStream_t s) {
+  // (a finishing march that replaces prim in place must own its columns from end to end: the
+  // next segment's stencil rows would be overwritten under it)
+  const bool in_place = (extra != EXTRA_NONE) && !sp.prim_to_u1;
+  const int nseg = in_place ? 1 : march_segments((int64_t)grid.x * grid.y * grid.z, DIR == 2 ? u0.nx2 : u0.nx3);
+  grid.z *= nseg;
   if (extra == EXTRA_C2P_DT)
-    hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, DIR, true, EXTRA_C2P_DT>), grid, dim3(64), lds, s, u0, u1, sp);
+    hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, DIR, true, EXTRA_C2P_DT>), grid, dim3(64), lds, s, u0, u1, sp, nseg);
   else if (extra == EXTRA_C2P)
-    hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, DIR, true, EXTRA_C2P>), grid, dim3(64), lds, s, u0, u1, sp);
+    hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, DIR, true, EXTRA_C2P>), grid, dim3(64), lds, s, u0, u1, sp, nseg);
   else
-    hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, DIR, true, EXTRA_NONE>), grid, dim3(64), lds, s, u0, u1, sp);
+    hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, DIR, true, EXTRA_NONE>), grid, dim3(64), lds, s, u0, u1, sp, nseg);
 }
 
 template <int FLUID, int RECON, int RS>
@@ -734,9 +760,11 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
         hipLaunchKernelGGL((fused_x1_kernel<FLUID, RECON, RS, false>), g1, dim3(256), 0, s, u0, u1, sp, wpp);
       }
       if (do_rest) {
-        const dim3 g2((u0.nx1 + 63) / 64, u0.nx3, u0.nblocks);
+        dim3 g2((u0.nx1 + 63) / 64, u0.nx3, u0.nblocks);
+        const int nseg = march_segments((int64_t)g2.x * g2.y * g2.z, u0.nx2);
+        g2.z *= nseg;
         ScopedTiming t(sp.ctx, TS + 1, s);
-        hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 2, false>), g2, dim3(64), lds, s, u0, u1, sp);
+        hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 2, false>), g2, dim3(64), lds, s, u0, u1, sp, nseg);
       }
     }
     if (do_rest) {

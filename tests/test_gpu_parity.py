@@ -374,11 +374,13 @@ def test_fused_stage_fill_derived_and_dt(request, oracle, fluid, recon, riemann,
                                                          ("euler", "dc", "hllc", (66, 10, 6), 0.0),
                                                          ("euler", "dc", "hlle", (64, 8, 8), 0.0),
                                                          ("glmmhd", "ppm", "hlld", (70, 9, 7), 0.0),
+                                                         ("euler", "plm", "hllc", (64, 34, 36), 0.5),
                                                          ("euler", "plm", "hllc", (66, 10, 1), 0.5)])
 def test_fused_stage_fill_derived_out_of_place(request, oracle, fluid, recon, riemann, nx, gam0, strict):
     """fill_derived = 2: the new primitives land in u1's prim arrays, u0.prim stays as it was.
     For 3-D donor cell this is the single-march kernel (fused_dc3_kernel), incl. its k segments
-    (nx3 = 34 -> 4 x 8 + 2 planes)."""
+    (nx3 = 34 -> 4 x 8 + 2 planes); the (64, 34, 36) case runs the x2 and the finishing x3 march in
+    two segments each (small packs are cut so that the launch fills the machine)."""
     from athenapk_amd import hydro
     ctx = _ctx(request, strict)
     ng, prim, g = _case(fluid, recon, nx, kind="smooth", seed=43)
