@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1116,6 +1117,7 @@ int apk_sim_set_overlap(apk_sim *s, int overlap) {
 }
 
 long long apk_sim_overlapped_exchanges(const apk_sim *s) { return s ? s->overlapped : 0; }
+double apk_sim_loop_seconds(const apk_sim *s) { return s ? s->loop_seconds : 0.0; }
 
 int apk_sim_initialize(apk_sim *s) {
   if (!s || s->host_only) return APK_ERR_INVALID;
@@ -1436,6 +1438,8 @@ int apk_sim_execute(apk_sim *s, const char *outdir, int *ncycles) {
     o.next = o.dt;
   }
   int n = 0;
+  SIM_HIP(s, hipStreamSynchronize(hs(s)));
+  const auto t0 = std::chrono::steady_clock::now();
   while (s->time < s->tlim && (s->nlim < 0 || n < s->nlim)) {
     SIM_TRY(s, apk_sim_step(s));
     ++n;
@@ -1446,6 +1450,9 @@ int apk_sim_execute(apk_sim *s, const char *outdir, int *ncycles) {
         while (o.next <= s->time) o.next += o.dt;
       }
   }
+  SIM_TRY(s, finish_pending(s));
+  SIM_HIP(s, hipStreamSynchronize(hs(s)));
+  s->loop_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (s->problem_id == "linear_wave" && s->lw.compute_error)
     SIM_TRY(s, apk_sim_write_linear_wave_errors(s, (std::string(outdir) + "/linearwave-errors.dat").c_str()));
   if (ncycles) *ncycles = n;

@@ -224,6 +224,10 @@ class Simulation(_FmftHost):
         return self
 
     @property
+    def loop_seconds(self):
+        return self.lib.apk_sim_loop_seconds(self.h)
+
+    @property
     def overlapped_exchanges(self):
         return self.lib.apk_sim_overlapped_exchanges(self.h)
 

@@ -148,6 +148,9 @@ int apk_sim_write_linear_wave_errors(apk_sim *sim, const char *path);
  * <outdir>/<parthenon/job problem_id, default "parthenon">.out<N>.hst at its `dt` cadence (t = 0
  * and the final time included), and, for linear_wave with compute_error, the error file. */
 int apk_sim_execute(apk_sim *sim, const char *outdir, int *ncycles);
+/* wall seconds of the main loop of the last apk_sim_execute (initialisation excluded, device
+ * synchronised): zones * cycles / this = Parthenon's "zone-cycles/wallsecond" */
+double apk_sim_loop_seconds(const apk_sim *sim);
 int apk_sim_linear_wave_errors(apk_sim *sim, double *rms, double *l1_5, double *max_5);
 /* individual driver steps, exposed for tests */
 int apk_sim_exchange_ghosts(apk_sim *sim);
