@@ -100,6 +100,61 @@ def cpu_baseline(fluid, integrator, recon, riemann, target_s=10.0):
                       "serial_value: 1 thread on 64^3" % (cycles, n, mb, best_t, cands, cores, dt)}
 
 
+def general_stage_bench(recon="ppm", riemann="hlld", nb=8, n=128, reps=5):
+    """SURVEY 8(d) "synthetic kernel benchmark (north_star target)": one pack of nb random-smooth
+    128^3 GLM-MHD blocks, the GENERAL RK stage (gam0 = gam1 = 1/2: u0 is read as well, 288 B per
+    cell-stage), timed with events on the stream the kernels run on, through the C-ABI."""
+    import torch
+    from athenapk_amd import hydro, lib as L
+    ng, dev = 3, torch.device("cuda")
+    N = n + 2 * ng
+    ctx = hydro.Context(strict=False)
+    ax = torch.arange(N, dtype=torch.float64, device=dev) * (2.0 * math.pi / n)
+    k, j, i = torch.meshgrid(ax, ax, ax, indexing="ij")
+    w = torch.empty((nb, 9, N, N, N), dtype=torch.float64, device=dev)
+    for b in range(nb):
+        ph = 0.37 * b
+        w[b, 0] = 1.0 + 0.2 * torch.sin(i + 2 * j + k + ph)
+        w[b, 1] = 0.3 * torch.sin(j - k + ph)
+        w[b, 2] = 0.3 * torch.cos(i + k)
+        w[b, 3] = 0.3 * torch.sin(i - 2 * j + ph)
+        w[b, 4] = 1.0 + 0.1 * torch.cos(2 * i + j - k)
+        w[b, 5] = 0.5 * torch.sin(j + ph)
+        w[b, 6] = 0.5 * torch.cos(k - i)
+        w[b, 7] = 0.5 * torch.sin(i + j + ph)
+        w[b, 8] = 0.01 * torch.sin(i + j + k)
+    gamma = 5.0 / 3.0
+    u = w.clone()
+    u[:, 1:4] = w[:, 0:1] * w[:, 1:4]
+    u[:, 4] = (w[:, 4] / (gamma - 1.0) + 0.5 * w[:, 0] * (w[:, 1:4] ** 2).sum(1) + 0.5 * (w[:, 5:8] ** 2).sum(1)
+               + 0.5 * w[:, 8] ** 2)
+    dx = (1.0 / n,) * 3
+    m0 = hydro.MeshData(ctx, (n, n, n), ng, 9, dx=dx, nblocks=nb, cons=u, prim=w, with_flux=False)
+    m1 = hydro.MeshData(ctx, (n, n, n), ng, 9, dx=dx, nblocks=nb, cons=u.clone(), with_flux=False)  # u1 != u0
+    del u, w
+    eos = L.make_eos(gamma)
+
+    def stage():
+        hydro.StageFused(m0, m1, "glmmhd", recon, riemann, eos, 2.0, 0.5, 0.5, 1e-7, dedner=1, glmmhd_alpha=0.1,
+                         mindx=dx[0])
+    for _ in range(2):
+        stage()
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)   # hydro.StageFused launches on torch's current stream
+    for _ in range(reps):
+        stage()
+    e1.record(st)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    cells = nb * n ** 3
+    gbs = 288.0 * cells / (ms * 1e-3) / 1e9
+    return {"description": "one pack of %d smooth %d^3 GLM-MHD blocks, %s+%s general stage (gam0 = gam1 = 1/2), "
+                           "288 B per cell-stage (SURVEY 8(d))" % (nb, n, recon.upper(), riemann.upper()),
+            "ms_per_stage": ms, "cell_stage_updates_per_s": cells / (ms * 1e-3), "achieved": gbs, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS}
+
+
 def measured_traffic(workload):
     """HBM bytes per fused-stage launch from the committed rocprofv3 PMC passes (a live run cannot
     profile itself): profiles/r01_hbm_traffic.json, made by profiles/pmc_traffic.py from
@@ -269,6 +324,12 @@ def main():
                                 "frac": value / world * b_cycle / 1e9 / HBM_PEAK_GBS},
             },
         }
+        if world == 1 and fluid == "glmmhd" and not args.unfused:
+            try:
+                sim.close()
+                out["roofline"]["general_stage"] = general_stage_bench(recon, riemann)
+            except Exception as e:  # supplementary figure; never lose the headline
+                out["roofline"]["general_stage"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(fluid, integrator, recon, riemann)
