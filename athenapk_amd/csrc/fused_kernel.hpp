@@ -531,11 +531,19 @@ fused_march12_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_blo
 // ==============================================================================================
 template <int FLUID, int RS, int EXTRA = EXTRA_NONE>
 __global__ void __launch_bounds__(64, kMarchMinWaves)
-fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg) {
+fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, int nseg, int per_xcd) {
   constexpr int NV = nvars<FLUID>();
   double lane_min_dt = 1.7976931348623157e308;
   const int lane = threadIdx.x;
-  const int b = blockIdx.z;
+  // XCD-aware order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each
+  // with its own L2.  A lane re-reads the rows j-1 and j+1 that the workgroups two chunks away
+  // load as their own row, so neighbouring chunks should share an L2: XCD x gets the contiguous
+  // range [x * per_xcd, (x + 1) * per_xcd) of the (chunk, k segment, block) order.
+  const int vid = (int)(blockIdx.x % 8u) * per_xcd + (int)(blockIdx.x / 8u);
+  if (vid >= wpb * nseg * u0.nblocks) return;
+  const int chunk = vid % wpb;
+  const int segid = (vid / wpb) % nseg;
+  const int b = vid / (wpb * nseg);
   const apk_block_desc b0 = u0.blocks[b];
   const double *c1 = u1.blocks[b].cons;
   double *prim_dst = u1.blocks[b].prim;  // EXTRA != NONE only (never in place here)
@@ -547,8 +555,8 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg) {
     if (rl <= 0 || jhi < jlo || khi < klo) return;
   }
   const int64_t run = (int64_t)(jhi - jlo + 1) * rl;
-  const int64_t t = (int64_t)blockIdx.x * 62 + lane - 1;
-  if ((int64_t)blockIdx.x * 62 - 1 >= run) return;  // whole wave beyond this block's run
+  const int64_t t = (int64_t)chunk * 62 + lane - 1;
+  if ((int64_t)chunk * 62 - 1 >= run) return;  // whole wave beyond this block's run
   const bool in_run = (t >= 0) && (t < run);
   const int64_t tc = in_run ? t : (t < 0 ? 0 : run - 1);  // out-of-run lanes shadow a valid column
   const int row = (int)(tc / rl);
@@ -562,7 +570,7 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg) {
   // the march is cut into gridDim.y segments of kseg planes: 2216 full-length waves on a machine
   // with 2048 wave slots (256 VGPRs -> 2 per SIMD) would run in two rounds; many short waves
   // keep every slot busy, for one redundant x3 solve per segment
-  const int s = klo + blockIdx.y * kseg;
+  const int s = klo + segid * kseg;
   if (s > khi) return;
   const int e = (s + kseg - 1 < khi) ? s + kseg - 1 : khi;
 
@@ -733,15 +741,17 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
         const int wpb = (int)((run3 + 61) / 62);
         const int kseg = (u0.nx3 >= 16) ? 8 : u0.nx3;  // measured on 8 x 128^3: 8 and 16 within 1 %, 64 is 12 % slower
         const int nseg = (u0.nx3 + kseg - 1) / kseg;
-        const dim3 g(wpb, nseg, u0.nblocks);
+        const int64_t total = (int64_t)wpb * nseg * u0.nblocks;
+        const int per_xcd = (int)((total + 7) / 8);
+        const dim3 g((unsigned)(per_xcd * 8), 1, 1);
         constexpr int lds3 = 2 * nvars<FLUID>() * 64 * (int)sizeof(double);
         ScopedTiming t(sp.ctx, TS + 0, s);
         if (extra == EXTRA_C2P_DT)
-          hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_C2P_DT>), g, dim3(64), lds3, s, u0, u1, sp, kseg);
+          hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_C2P_DT>), g, dim3(64), lds3, s, u0, u1, sp, kseg, wpb, nseg, per_xcd);
         else if (extra == EXTRA_C2P)
-          hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_C2P>), g, dim3(64), lds3, s, u0, u1, sp, kseg);
+          hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_C2P>), g, dim3(64), lds3, s, u0, u1, sp, kseg, wpb, nseg, per_xcd);
         else
-          hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_NONE>), g, dim3(64), lds3, s, u0, u1, sp, kseg);
+          hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_NONE>), g, dim3(64), lds3, s, u0, u1, sp, kseg, wpb, nseg, per_xcd);
         return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
       }
       // (with FillDerived fused into the stage) donor cell: the sweeps are HBM-bound, so x1 and x2 share ONE march over (k,i)-flattened

@@ -165,8 +165,11 @@ def measured_traffic(workload):
     try:
         with open(path) as f:
             k = json.load(f)["kernels"]
-        gb = sum(v["hbm_total_GB"] for name, v in k.items()
-                 if name.startswith("fused_x1_kernel<2, 3, 5") or name.startswith("fused_march_kernel<2, 3, 5"))
+        # the three kernels of the VL2 corrector stage as the driver launches it (x3 = finishing sweep
+        # with FillDerived + dt); the profile also holds the general-stage benchmark's variants
+        stage = ("fused_x1_kernel<2, 3, 5, false>", "fused_march_kernel<2, 3, 5, 2, false, 0>",
+                 "fused_march_kernel<2, 3, 5, 3, true, 2>")
+        gb = sum(k[name]["hbm_total_GB"] for name in stage)
         return gb, "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, reads calibrated x1.60)"
     except Exception:
         return None, None
