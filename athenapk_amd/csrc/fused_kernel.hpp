@@ -588,11 +588,8 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
     st_f3[n * 64] = 0.0;
     st_du[n * 64] = 0.0;
   }
-  // The four Riemann problems of a cell are independent; left alone the scheduler interleaves them
-  // (HLLD keeps ~40 temporaries live per solve) and the kernel spills.  APK_CHAIN makes the
-  // inputs of the next solve depend on the outputs of the previous one, so they run back to back.
-#define APK_CHAIN(out, in)                                         \
-  _Pragma("unroll") for (int q_ = 0; q_ < NV; ++q_) asm volatile("" : "+v"(out[q_]), "+v"(in[q_]))
+  // (The four Riemann problems of a cell are independent and the scheduler interleaves them; with
+  // the carried state in the stash that fits in 199 VGPRs without scratch.)
   for (int c = s; c <= e + 1; ++c) {
     const int64_t off = (int64_t)c * u0.sk;
     double wc[NV];
@@ -607,7 +604,6 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
         wr3[q] = wc[perm<3>(q)];
       }
       riemann<FLUID, RS>(wl3, wr3, sp.gamma, sp.c_h, f3);
-      APK_CHAIN(f3, wc);
       if (c >= s + 1) {
         const int64_t done = col + (int64_t)(c - 1) * u0.sk;
         double du[NV], u1v[NV];
@@ -640,7 +636,6 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
           const double fup = wave_shl1(f[q]);
           d1[q] = (area1 * fup - area1 * f[q]);
         }
-        APK_CHAIN(d1, wc);
 #pragma unroll
         for (int q = 0; q < NV; ++q) st_du[perm<1>(q) * 64] = d1[q];
       }
@@ -654,7 +649,6 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
           w2[q] = wc[perm<2>(q)];
         }
         riemann<FLUID, RS>(wm, w2, sp.gamma, sp.c_h, flo);
-        APK_CHAIN(flo, wc);
       }
       {
         double wp[NV], w2[NV], fhi[NV];
@@ -664,7 +658,6 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
           w2[q] = wc[perm<2>(q)];
         }
         riemann<FLUID, RS>(w2, wp, sp.gamma, sp.c_h, fhi);
-        APK_CHAIN(fhi, wc);
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
           const int n = perm<2>(q);
@@ -673,7 +666,6 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
       }
     }
   }
-#undef APK_CHAIN
   if constexpr (EXTRA == EXTRA_C2P_DT) {
     double m = lane_min_dt;
 #pragma unroll
