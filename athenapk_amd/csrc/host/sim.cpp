@@ -304,11 +304,49 @@ void pgen_block(apk_sim *s, int lb, std::vector<double> &u) {
     sod[5] = pin.GetOrAddReal("problem/sod", "u_r", 0.0);
     sod[6] = pin.GetOrAddReal("problem/sod", "x_discont", 0.5);
   }
+  double bl[9] = {0};
+  if (s->problem_id == "blast") {  // src/pgen/blast.cpp:125-138
+    if (pin.GetOrAddString("problem/blast", "input_image", "none") != "none")
+      throw std::runtime_error("problem/blast/input_image is not supported");
+    bl[0] = pin.GetReal("problem/blast", "radius_outer");
+    bl[1] = pin.GetOrAddReal("problem/blast", "radius_inner", bl[0]);
+    bl[2] = pin.GetOrAddReal("problem/blast", "pressure_ambient", 1.0);
+    bl[3] = pin.GetOrAddReal("problem/blast", "density_ambient", 1.0);
+    bl[4] = pin.GetReal("problem/blast", "pressure_ratio");
+    bl[5] = pin.GetOrAddReal("problem/blast", "density_ratio", 1.0);
+    bl[6] = pin.GetOrAddReal("problem/blast", "x1_0", 0.0);
+    bl[7] = pin.GetOrAddReal("problem/blast", "x2_0", 0.0);
+    bl[8] = pin.GetOrAddReal("problem/blast", "x3_0", 0.0);
+  }
   for (int k = m.ks; k <= m.ke; ++k)
     for (int j = m.js; j <= m.je; ++j)
       for (int i = m.is; i <= m.ie; ++i) {
         const double x1 = xc(s, x0, 0, i), x2 = xc(s, x0, 1, j), x3 = xc(s, x0, 2, k);
-        if (s->problem_id == "linear_wave") {
+        if (s->problem_id == "blast") {  // src/pgen/blast.cpp:150-201
+          const double rout = bl[0], rin = bl[1], pa = bl[2], da = bl[3], prat = bl[4], drat = bl[5];
+          double den = da, pres = pa;
+          const double rad = std::sqrt((x1 - bl[6]) * (x1 - bl[6]) + (x2 - bl[7]) * (x2 - bl[7]) + (x3 - bl[8]) * (x3 - bl[8]));
+          if (rad < rout) {
+            if (rad < rin) {
+              den = drat * da;
+            } else {  // smooth ramp in density
+              const double f = (rad - rin) / (rout - rin);
+              const double log_den = (1.0 - f) * std::log(drat * da) + f * std::log(da);
+              den = std::exp(log_den);
+            }
+          }
+          if (rad < rout) {
+            if (rad < rin) {
+              pres = prat * pa;
+            } else {  // smooth ramp in pressure
+              const double f = (rad - rin) / (rout - rin);
+              const double log_pres = (1.0 - f) * std::log(prat * pa) + f * std::log(pa);
+              pres = std::exp(log_pres);
+            }
+          }
+          at(0, k, j, i) = den;
+          at(4, k, j, i) = pres / gm1;
+        } else if (s->problem_id == "linear_wave") {
           double w[5];
           lw_state(s->lw, x1, x2, x3, w);
           for (int n = 0; n < 5; ++n) at(n, k, j, i) = w[n];
@@ -987,7 +1025,8 @@ int create_common(const char *deck, const char *const *overrides, int noverrides
     mesh_initialize(s);
     if (s->problem_id == "linear_wave") lw_setup(s);
     else if (s->problem_id == "turbulence") turbulence_setup(s);
-    else if (s->problem_id != "sod" && s->problem_id != "orszag_tang" && s->problem_id != "synthetic")
+    else if (s->problem_id != "sod" && s->problem_id != "orszag_tang" && s->problem_id != "synthetic" &&
+             s->problem_id != "blast")
       throw std::runtime_error("unknown job/problem_id: " + s->problem_id);
   } catch (const std::exception &e) {
     if (errbuf && errlen) std::snprintf(errbuf, errlen, "%s", e.what());
@@ -1326,6 +1365,42 @@ int apk_sim_read_acc(apk_sim *s, int lb, double *host_out) {
   if (!s || s->host_only || !s->d_acc || !host_out || lb < 0 || lb >= (int)s->mesh.local_gids.size()) return APK_ERR_INVALID;
   SIM_HIP(s, hipStreamSynchronize(hs(s)));
   SIM_HIP(s, hipMemcpy(host_out, s->d_acc + 3 * (int64_t)s->mesh.sn * lb, sizeof(double) * 3 * s->mesh.sn, hipMemcpyDeviceToHost));
+  return APK_OK;
+}
+
+// pkg->CheckRefinementBlock as configured by <refinement> (src/hydro/hydro.cpp:788-816), evaluated
+// for every local block: tags[lb] = +1 refine / 0 same / -1 derefine.  The mesh itself stays uniform
+// here; this is the tagging half of the AMR loop.
+int apk_sim_check_refinement(apk_sim *s, int *tags, double *crit) {
+  if (!s || s->host_only || !tags) return APK_ERR_INVALID;
+  SIM_TRY(s, finish_pending(s));
+  ParameterInput &pin = s->pin;
+  int criterion = -1;
+  double p0 = 0.0, p1 = 0.0;
+  try {
+    const std::string type = pin.GetOrAddString("refinement", "type", "unset");
+    if (type == "pressure_gradient") {
+      criterion = APK_TAG_PRESSURE_GRADIENT;
+      p0 = pin.GetOrAddReal("refinement", "threshold_pressure_gradient", 0.0);
+      if (!(p0 > 0.)) throw std::runtime_error("Make sure to set refinement/threshold_pressure_gradient >0.");
+    } else if (type == "xyvelocity_gradient") {
+      criterion = APK_TAG_VELOCITY_GRADIENT;
+      p0 = pin.GetOrAddReal("refinement", "threshold_xyvelocity_gradient", 0.0);
+      if (!(p0 > 0.)) throw std::runtime_error("Make sure to set refinement/threshold_xyvelocity_gradient >0.");
+    } else if (type == "maxdensity") {
+      criterion = APK_TAG_MAX_DENSITY;
+      p1 = pin.GetOrAddReal("refinement", "maxdensity_deref_below", 0.0);
+      p0 = pin.GetOrAddReal("refinement", "maxdensity_refine_above", 0.0);
+      if (!(p1 > 0.)) throw std::runtime_error("Make sure to set refinement/maxdensity_deref_below > 0.");
+      if (!(p0 > 0.)) throw std::runtime_error("Make sure to set refinement/maxdensity_refine_above > 0.");
+      if (!(p1 < p0)) throw std::runtime_error("Make sure to set refinement/maxdensity_deref_below < refinement/maxdensity_refine_above");
+    } else {
+      throw std::runtime_error("refinement/type is unset: no refinement criterion to evaluate");
+    }
+  } catch (const std::exception &e) {
+    return fail(s, APK_ERR_INVALID, e.what());
+  }
+  SIM_TRY(s, apk_tag_blocks(s->ctx, s->mu0(), criterion, p0, p1, tags, crit, s->stream));
   return APK_OK;
 }
 

@@ -291,6 +291,13 @@ class Simulation(_FmftHost):
         self._check(self.lib.apk_sim_history(self.h, out))
         return np.array(out[:])
 
+    def check_refinement(self):
+        """the deck's <refinement> criterion on every local block: (tags, criterion values)"""
+        n = self.info.nblocks_local
+        tags, crit = (C.c_int * n)(), (C.c_double * n)()
+        self._check(self.lib.apk_sim_check_refinement(self.h, tags, crit))
+        return np.array(tags[:]), np.array(crit[:])
+
     def history_labels(self):
         buf = C.create_string_buffer(256)
         self._check(self.lib.apk_sim_history_labels(self.h, buf, len(buf)))

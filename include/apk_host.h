@@ -130,6 +130,12 @@ int apk_sim_fmft_var_hat(const apk_sim *sim, double *out);
 int apk_sim_fmft_evolve(apk_sim *sim, double dt);
 int apk_sim_fmft_phases(const apk_sim *sim, int axis, int n, int g0, double *out);
 int apk_sim_read_acc(apk_sim *sim, int lb, double *host_out);
+/* The refinement criterion configured by the deck's <refinement> block (src/hydro/hydro.cpp:
+ * 788-816: type = pressure_gradient | xyvelocity_gradient | maxdensity with their thresholds),
+ * evaluated on every local block (pkg->CheckRefinementBlock): tags[lb] = +1 refine, 0 same,
+ * -1 derefine; crit (may be NULL) receives the reduced criterion.  The mesh stays uniform. */
+int apk_sim_check_refinement(apk_sim *sim, int *tags, double *crit);
+
 /* ---- text outputs in the reference's formats ---------------------------------------------
  * History: one row per call, "time dt cycle nbtotal" followed by the package's history list
  * (src/hydro/hydro.cpp:422-441: mass 1-mom 2-mom 3-mom KE tot-E [ME relDivB]; turbulence adds

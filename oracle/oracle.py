@@ -105,6 +105,7 @@ def _declare(lib):
         "orc_pgen_linear_wave": (d, [C.c_void_p, i, d, d]),
         "orc_pgen_sod": (None, [C.c_void_p, d, d, d, d, d, d, d]),
         "orc_pgen_orszag_tang": (None, [C.c_void_p]),
+        "orc_pgen_blast": (None, [C.c_void_p, d, d, d, d, d, d, d, d, d]),
         "orc_pgen_synthetic": (None, [C.c_void_p]),
         "orc_sim_initialize": (None, [C.c_void_p]),
         "orc_sim_step": (d, [C.c_void_p, d]),
@@ -253,6 +254,11 @@ class Sim:
             self.lib.orc_pgen_orszag_tang(self.h)
         elif name == "synthetic":
             self.lib.orc_pgen_synthetic(self.h)
+        elif name == "blast":
+            self.lib.orc_pgen_blast(self.h, kw["radius_outer"], kw.get("radius_inner", kw["radius_outer"]),
+                                    kw.get("pressure_ambient", 1.0), kw.get("density_ambient", 1.0),
+                                    kw["pressure_ratio"], kw.get("density_ratio", 1.0), kw.get("x1_0", 0.0),
+                                    kw.get("x2_0", 0.0), kw.get("x3_0", 0.0))
         elif name == "turbulence":
             kv = np.ascontiguousarray(kw["k_vec"], dtype=np.float64)  # [3][M]
             self._turb_modes = kv.shape[1]

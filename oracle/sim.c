@@ -563,6 +563,48 @@ void orc_pgen_sod(orc_sim *s, double rho_l, double pres_l, double u_l, double rh
   }
 }
 
+/* src/pgen/blast.cpp:124-207 (analytic sphere; the input-image variant is not restated) */
+void orc_pgen_blast(orc_sim *s, double rout, double rin, double pa, double da, double prat, double drat,
+                    double x0c, double y0c, double z0c) {
+  const sb_t bb = sim_bounds(&s->g);
+  const double gm1 = s->p.eos.gamma - 1.0;
+  for (int b = 0; b < s->nblocks; ++b) {
+    double x0[3];
+    orc_sim_block_origin(s, b, x0);
+    double *u = s->cons[b];
+    for (int k = bb.ks; k <= bb.ke; ++k)
+      for (int j = bb.js; j <= bb.je; ++j)
+        for (int i = bb.is; i <= bb.ie; ++i) {
+          double den = da, pres = pa;
+          const double x = xc(s, x0, 0, i), y = xc(s, x0, 1, j), z = xc(s, x0, 2, k);
+          const double rad = sqrt((x - x0c) * (x - x0c) + (y - y0c) * (y - y0c) + (z - z0c) * (z - z0c));
+          if (rad < rout) {
+            if (rad < rin) {
+              den = drat * da;
+            } else {
+              const double f = (rad - rin) / (rout - rin);
+              const double log_den = (1.0 - f) * log(drat * da) + f * log(da);
+              den = exp(log_den);
+            }
+          }
+          if (rad < rout) {
+            if (rad < rin) {
+              pres = prat * pa;
+            } else {
+              const double f = (rad - rin) / (rout - rin);
+              const double log_pres = (1.0 - f) * log(prat * pa) + f * log(pa);
+              pres = exp(log_pres);
+            }
+          }
+          SAT(u, ORC_IDN, k, j, i) = den;
+          SAT(u, ORC_IM1, k, j, i) = 0.0;
+          SAT(u, ORC_IM2, k, j, i) = 0.0;
+          SAT(u, ORC_IM3, k, j, i) = 0.0;
+          SAT(u, ORC_IEN, k, j, i) = pres / gm1;
+        }
+  }
+}
+
 /* src/pgen/orszag_tang.cpp:25-63 */
 void orc_pgen_orszag_tang(orc_sim *s) {
   const sb_t bb = sim_bounds(&s->g);

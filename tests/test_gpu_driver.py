@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+import helpers as H
+
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -320,3 +322,37 @@ def test_cli_linear_wave_error_file(tmp_path, oracle):
     want = [float("%e" % v) for v in [rms] + list(l1) + [np.max(mx / l1)] + list(mx)]
     assert list(data[1, 4:]) == want
     assert data[1, 4] < data[0, 4] / 2.5   # approaching second order (PLM, 16 -> 32 cells per wavelength)
+
+
+# ---- config 5's problem (blast wave) on a uniform grid + the refinement criterion of its deck -------------
+@pytest.mark.gpu
+def test_blast_matches_oracle_and_tags_the_shock(oracle):
+    """inputs/blast.in = the reference's blast_3d_amr.in without the refined mesh: 8^3 meshblocks,
+    PLM + HLLE VL2, pressure ratio 1.6e8.  Bit for bit against the oracle, and the deck's
+    pressure-gradient criterion (threshold 0.1) evaluated per block equals the oracle's: blocks
+    around the blast would refine, the far field would derefine."""
+    ov = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=32", "parthenon/meshblock/nx1=8",
+          "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=8", "problem/blast/radius_outer=0.1",
+          "problem/blast/radius_inner=0.05"]
+    s = _sim("blast", ov, strict=True).initialize()
+    o = oracle.Sim(fluid="euler", recon="plm", riemann="hlle", integrator="vl2", nx=(32, 32, 32), mb=(8, 8, 8), ng=2,
+                   xmin=(-0.5, -0.5, -0.5), xmax=(0.5, 0.5, 0.5), cfl=0.3, gamma=GAMMA_DECK, nthreads=os.cpu_count())
+    o.pgen("blast", radius_outer=0.1, radius_inner=0.05, pressure_ambient=0.001, pressure_ratio=1.6e8)
+    assert np.array_equal(s.gather("cons"), o.gather_cons())
+    for _ in range(12):
+        s.step()
+        o.step()
+    assert s.time == o.time and s.dt == o.dt
+    got = s.gather("cons")
+    assert np.array_equal(got, o.gather_cons())
+    assert np.isfinite(got).all() and got[0].min() > 0
+    # the blast is centred: the solution keeps the octant symmetry of the initial state
+    assert np.allclose(got[0], got[0][::-1, :, :], rtol=1e-12) and np.allclose(got[0], got[0][:, :, ::-1], rtol=1e-12)
+    tags, crit = s.check_refinement()
+    g = H.geom("euler", (8, 8, 8), 2)
+    want = [oracle.tag("pressure_gradient", g, o.prim(s.block_gid(lb)[0]), 0.1) for lb in range(s.info.nblocks_local)]
+    assert list(tags) == [w[0] for w in want] and list(crit) == [w[1] for w in want]
+    assert (tags == 1).sum() >= 8 and (tags == -1).sum() >= 8
+    # refine tags sit at the centre of the box
+    centre = [lb for lb in range(s.info.nblocks_local) if all(c in (1, 2) for c in s.block_gid(lb)[1])]
+    assert all(tags[lb] == 1 for lb in centre)
