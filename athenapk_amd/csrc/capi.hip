@@ -110,6 +110,10 @@ int apk_create(apk_ctx **out) {
   }
   (void)hipMemset(ctx->d_flags, 0, sizeof(unsigned));
   (void)hipMemset(ctx->d_u64, 0, 16 * sizeof(unsigned long long));
+  {
+    const double huge = 1.7976931348623157e308;  // word 15: constant +max, the neutral element of the dt min
+    (void)hipMemcpy(ctx->d_u64 + 15, &huge, sizeof(double), hipMemcpyHostToDevice);
+  }
   *out = ctx;
   return APK_OK;
 }
@@ -376,6 +380,22 @@ int apk_history(apk_ctx *ctx, const apk_pack *md, int fluid, double *out8, apk_s
   APK_HIP_TRY(ctx, hipMemcpyAsync(h, d_out, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
   APK_HIP_TRY(ctx, hipStreamSynchronize(s));
   std::memcpy(out8, h, 8 * sizeof(double));
+  return APK_OK;
+}
+
+int apk_stage_dt_flags_read(apk_ctx *ctx, double cfl, double *dt_out, unsigned *flags, apk_stream_t stream) {
+  if (!ctx || !dt_out || !flags) return APK_ERR_INVALID;
+  hipStream_t s = as_stream(stream);
+  auto *h = static_cast<unsigned long long *>(ctx->h_pinned);
+  auto *hf = reinterpret_cast<unsigned *>(static_cast<char *>(ctx->h_pinned) + 192);
+  APK_HIP_TRY(ctx, hipMemcpyAsync(h + 4, ctx->d_u64 + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  APK_HIP_TRY(ctx, hipMemcpyAsync(hf, ctx->d_flags, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  APK_HIP_TRY(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(unsigned), s));
+  APK_HIP_TRY(ctx, hipStreamSynchronize(s));
+  double m;
+  std::memcpy(&m, h + 4, sizeof(m));
+  *dt_out = cfl * m;  // hydro.cpp:909
+  *flags = *hf;
   return APK_OK;
 }
 

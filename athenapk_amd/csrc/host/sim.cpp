@@ -647,9 +647,12 @@ void set_global_dt(apk_sim *s, double dt_est) {
 // Hydro::EstimateTimestep<fluid> over this rank's pack + global min (hydro.cpp:913-977)
 int estimate_timestep(apk_sim *s, double *dt_out) {
   double dt = kHuge;
+  unsigned flags = 0;
+  bool have_flags = false;
   if (s->pkg.calc_dt_hyp) {
     if (s->stage_dt_pending) {  // already reduced by the finishing sweep of the last stage
-      SIM_TRY(s, apk_stage_dt_read(s->ctx, s->pkg.cfl, &dt, s->stream));
+      SIM_TRY(s, apk_stage_dt_flags_read(s->ctx, s->pkg.cfl, &dt, &flags, s->stream));  // one host round trip
+      have_flags = true;
       s->stage_dt_pending = false;
     } else {
       SIM_TRY(s, apk_estimate_timestep(s->ctx, s->mu0(), s->pkg.fluid, &s->pkg.eos, s->pkg.cfl, &dt, s->stream));
@@ -657,8 +660,7 @@ int estimate_timestep(apk_sim *s, double *dt_out) {
     if (s->pkg.fluid == APK_FLUID_GLMMHD && dt < s->pkg.dt_hyp) s->pkg.dt_hyp = dt;  // hydro.cpp:903-908
   }
   if (s->pkg.max_dt > 0.0 && s->pkg.max_dt < dt) dt = s->pkg.max_dt;
-  unsigned flags = 0;
-  SIM_TRY(s, apk_poll_device_flags(s->ctx, &flags, s->stream));
+  if (!have_flags) SIM_TRY(s, apk_poll_device_flags(s->ctx, &flags, s->stream));
   if (flags & APK_FLAG_NEG_DENSITY)
     return fail(s, APK_ERR_INVALID, "Got negative density. Consider enabling first-order flux correction or setting a reasonble density floor.");
   if (flags & APK_FLAG_NEG_PRESSURE)

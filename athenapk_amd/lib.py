@@ -145,6 +145,7 @@ def _signatures():
         "apk_cons_to_prim_ghosts": (i, [vp, vp, i, E, vp]),
         "apk_cons_to_prim_ghosts_split": (i, [vp, vp, i, E, vp, i, vp]),
         "apk_stage_dt_read": (i, [vp, d, c_dp, vp]),
+        "apk_stage_dt_flags_read": (i, [vp, d, c_dp, C.POINTER(C.c_uint), vp]),
         "apk_estimate_timestep": (i, [vp, vp, i, E, d, c_dp, vp]),
         "apk_first_order_flux_correct": (i, [vp, vp, vp, i, E, d, d, d, d, C.POINTER(ll), vp]),
         "apk_history": (i, [vp, vp, i, c_dp, vp]),

@@ -207,6 +207,10 @@ int apk_cons_to_prim_ghosts_split(apk_ctx *ctx, const apk_pack *md, int fluid, c
 /* Result of the last apk_stage_fused(estimate_dt = 1) on this context: *dt_out = cfl * min.
  * Synchronises `stream`. */
 int apk_stage_dt_read(apk_ctx *ctx, double cfl, double *dt_out, apk_stream_t stream);
+/* apk_stage_dt_read + apk_poll_device_flags with ONE synchronisation (the per-cycle host round
+ * trip of a driver: new dt and the latched negative-density / -pressure flags). */
+int apk_stage_dt_flags_read(apk_ctx *ctx, double cfl, double *dt_out, unsigned *flags,
+                            apk_stream_t stream);
 
 /* Replaces Hydro::EstimateHyperbolicTimestep<fluid>(MeshData<Real>*)
  * src/hydro/hydro.cpp:828-910.  Synchronises `stream`; *dt_out = cfl * min(...). */
