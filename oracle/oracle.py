@@ -194,6 +194,20 @@ def integrator_coeffs(name, lib=None):
     return n, b[:n], g0[:n], g1[:n]
 
 
+def usable_cores():
+    """cores this process may really use (affinity mask and cgroup CPU quota): GPU boxes expose all
+    256 hardware threads of the node to a container that is allowed 16 of them, and an OpenMP
+    team of 256 on 16 cores is several times slower than a team of 16"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 class Sim:
     """Thin OO wrapper over the orc_sim_* mini-driver."""
 
@@ -216,7 +230,8 @@ class Sim:
         p.cfl, p.glmmhd_alpha = cfl, glmmhd_alpha
         p.dedner_extended, p.first_order_flux_correct = int(dedner_extended), int(fofc)
         p.eos = eos or make_eos(gamma)
-        p.nthreads = nthreads
+        cores = usable_cores()
+        p.nthreads = cores if (nthreads <= 0 or nthreads > cores) else nthreads
         self.params = p
         self.h = self.lib.orc_sim_create(C.byref(p))
         if not self.h:
