@@ -318,11 +318,34 @@ void pgen_block(apk_sim *s, int lb, std::vector<double> &u) {
     bl[7] = pin.GetOrAddReal("problem/blast", "x2_0", 0.0);
     bl[8] = pin.GetOrAddReal("problem/blast", "x3_0", 0.0);
   }
+  double lwi[5] = {0};
+  if (s->problem_id == "lw_implode") {  // src/pgen/lw_implode.cpp:24-57
+    if (mhd) throw std::runtime_error("Only hydro runs are supported for LW implosion problem generator.");
+    lwi[0] = pin.GetReal("problem/lw_implode", "d_in");
+    lwi[1] = pin.GetReal("problem/lw_implode", "p_in");
+    lwi[2] = pin.GetReal("problem/lw_implode", "d_out");
+    lwi[3] = pin.GetReal("problem/lw_implode", "p_out");
+    // to keep the ICs symmetric y0 sits between cell centres; the reference adjusts it with a loop
+    // over the rows of the meshblock being initialised
+    double y0 = 0.5 * (s->xmax[1] + s->xmin[1]);
+    for (int j = m.js; j <= m.je; ++j)
+      if (xc(s, x0, 1, j) > y0) {
+        const int ngj = m.Active(1) ? m.ng : 0;
+        const double xf = s->xmin[1] + (x0[1] + (double)(j - ngj)) * s->dx[1];  // lower x2 face of cell j
+        y0 = xf + 0.5 * s->dx[1];
+        break;
+      }
+    lwi[4] = y0;
+  }
   for (int k = m.ks; k <= m.ke; ++k)
     for (int j = m.js; j <= m.je; ++j)
       for (int i = m.is; i <= m.ie; ++i) {
         const double x1 = xc(s, x0, 0, i), x2 = xc(s, x0, 1, j), x3 = xc(s, x0, 2, k);
-        if (s->problem_id == "blast") {  // src/pgen/blast.cpp:150-201
+        if (s->problem_id == "lw_implode") {  // src/pgen/lw_implode.cpp:59-73
+          const bool outside = x2 > (lwi[4] - x1);
+          at(0, k, j, i) = outside ? lwi[2] : lwi[0];
+          at(4, k, j, i) = (outside ? lwi[3] : lwi[1]) / gm1;
+        } else if (s->problem_id == "blast") {  // src/pgen/blast.cpp:150-201
           const double rout = bl[0], rin = bl[1], pa = bl[2], da = bl[3], prat = bl[4], drat = bl[5];
           double den = da, pres = pa;
           const double rad = std::sqrt((x1 - bl[6]) * (x1 - bl[6]) + (x2 - bl[7]) * (x2 - bl[7]) + (x3 - bl[8]) * (x3 - bl[8]));
@@ -1028,7 +1051,7 @@ int create_common(const char *deck, const char *const *overrides, int noverrides
     if (s->problem_id == "linear_wave") lw_setup(s);
     else if (s->problem_id == "turbulence") turbulence_setup(s);
     else if (s->problem_id != "sod" && s->problem_id != "orszag_tang" && s->problem_id != "synthetic" &&
-             s->problem_id != "blast")
+             s->problem_id != "blast" && s->problem_id != "lw_implode")
       throw std::runtime_error("unknown job/problem_id: " + s->problem_id);
   } catch (const std::exception &e) {
     if (errbuf && errlen) std::snprintf(errbuf, errlen, "%s", e.what());

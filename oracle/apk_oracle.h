@@ -161,6 +161,7 @@ void orc_pgen_sod(orc_sim *s, double rho_l, double pres_l, double u_l, double rh
                   double pres_r, double u_r, double x_discont);
 /* src/pgen/orszag_tang.cpp:25-63 */
 void orc_pgen_orszag_tang(orc_sim *s);
+void orc_pgen_lw_implode(orc_sim *s, double d_in, double p_in, double d_out, double p_out);
 void orc_pgen_blast(orc_sim *s, double rout, double rin, double pa, double da, double prat, double drat,
                     double x0, double y0, double z0);
 /* analytic seedless smooth MHD/hydro state (SURVEY.md 8(d) synthetic kernel benchmark) */

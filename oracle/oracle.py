@@ -105,6 +105,7 @@ def _declare(lib):
         "orc_pgen_linear_wave": (d, [C.c_void_p, i, d, d]),
         "orc_pgen_sod": (None, [C.c_void_p, d, d, d, d, d, d, d]),
         "orc_pgen_orszag_tang": (None, [C.c_void_p]),
+        "orc_pgen_lw_implode": (None, [C.c_void_p, d, d, d, d]),
         "orc_pgen_blast": (None, [C.c_void_p, d, d, d, d, d, d, d, d, d]),
         "orc_pgen_synthetic": (None, [C.c_void_p]),
         "orc_sim_initialize": (None, [C.c_void_p]),
@@ -269,6 +270,9 @@ class Sim:
             self.lib.orc_pgen_orszag_tang(self.h)
         elif name == "synthetic":
             self.lib.orc_pgen_synthetic(self.h)
+        elif name == "lw_implode":
+            self.lib.orc_pgen_lw_implode(self.h, kw.get("d_in", 0.125), kw.get("p_in", 0.14), kw.get("d_out", 1.0),
+                                         kw.get("p_out", 1.0))
         elif name == "blast":
             self.lib.orc_pgen_blast(self.h, kw["radius_outer"], kw.get("radius_inner", kw["radius_outer"]),
                                     kw.get("pressure_ambient", 1.0), kw.get("density_ambient", 1.0),

@@ -605,6 +605,41 @@ void orc_pgen_blast(orc_sim *s, double rout, double rin, double pa, double da, d
   }
 }
 
+/* src/pgen/lw_implode.cpp:24-75 (Liska-Wendroff implosion; hydro only).  The diagonal offset y0 is
+ * adjusted per meshblock exactly as the reference's loop over the block's own rows does. */
+void orc_pgen_lw_implode(orc_sim *s, double d_in, double p_in, double d_out, double p_out) {
+  const sb_t bb = sim_bounds(&s->g);
+  const double gm1 = s->p.eos.gamma - 1.0;
+  for (int b = 0; b < s->nblocks; ++b) {
+    double x0[3];
+    orc_sim_block_origin(s, b, x0);
+    double *u = s->cons[b];
+    double y0 = 0.5 * (s->p.xmax[1] + s->p.xmin[1]);
+    for (int j = bb.js; j <= bb.je; ++j) {
+      if (xc(s, x0, 1, j) > y0) {
+        const int ng = (s->g.nx[1] > 1) ? s->g.ng : 0;
+        const double xf = s->p.xmin[1] + (x0[1] + (double)(j - ng)) * s->g.dx[1]; /* lower x2 face of cell j */
+        y0 = xf + 0.5 * s->g.dx[1];
+        break;
+      }
+    }
+    for (int k = bb.ks; k <= bb.ke; ++k)
+      for (int j = bb.js; j <= bb.je; ++j)
+        for (int i = bb.is; i <= bb.ie; ++i) {
+          SAT(u, ORC_IM1, k, j, i) = 0.0;
+          SAT(u, ORC_IM2, k, j, i) = 0.0;
+          SAT(u, ORC_IM3, k, j, i) = 0.0;
+          if (xc(s, x0, 1, j) > (y0 - xc(s, x0, 0, i))) {
+            SAT(u, ORC_IDN, k, j, i) = d_out;
+            SAT(u, ORC_IEN, k, j, i) = p_out / gm1;
+          } else {
+            SAT(u, ORC_IDN, k, j, i) = d_in;
+            SAT(u, ORC_IEN, k, j, i) = p_in / gm1;
+          }
+        }
+  }
+}
+
 /* src/pgen/orszag_tang.cpp:25-63 */
 void orc_pgen_orszag_tang(orc_sim *s) {
   const sb_t bb = sim_bounds(&s->g);

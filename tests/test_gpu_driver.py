@@ -356,3 +356,41 @@ def test_blast_matches_oracle_and_tags_the_shock(oracle):
     # refine tags sit at the centre of the box
     centre = [lb for lb in range(s.info.nblocks_local) if all(c in (1, 2) for c in s.block_gid(lb)[1])]
     assert all(tags[lb] == 1 for lb in centre)
+
+
+# ---- the reference's lw_implode_symmetry regression test ----------------------------------------------------
+def _symmetry_error(rho):
+    return float(np.max(2 * np.abs(rho - rho.T) / (rho + rho.T)))   # lw_implode_symmetry.py:64
+
+
+@pytest.mark.gpu
+def test_lw_implode_matches_oracle(oracle):
+    """64^2 Liska-Wendroff implosion to t = 2.5 (2378 cycles), reflecting walls, PLM + HLLC VL2:
+    bit for bit against the oracle, and exactly symmetric about the diagonal."""
+    ov = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "parthenon/meshblock/nx1=64", "parthenon/meshblock/nx2=64"]
+    s = _sim("lw_implode", ov, strict=True).initialize()
+    o = oracle.Sim(fluid="euler", recon="plm", riemann="hllc", integrator="vl2", nx=(64, 64, 1), ng=3,
+                   bc=("reflecting", "reflecting", "periodic"), xmin=(0.0, 0.0, -0.5), xmax=(0.3, 0.3, 0.5), cfl=0.4,
+                   gamma=1.4)
+    o.pgen("lw_implode")
+    assert s.run() == o.run(2.5)
+    got = s.gather("cons")
+    assert np.array_equal(got, o.gather_cons())
+    assert _symmetry_error(got[0, 0]) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+def test_lw_implode_reference_symmetry_criterion(strict):
+    """tst/regression/test_suites/lw_implode_symmetry/lw_implode_symmetry.py:57-68 on the reference's
+    deck (256^2, one meshblock, t = 2.5): max 2|rho - rho^T| / (rho + rho^T) <= 1e-11.  The parity
+    build is exactly symmetric; the default build contracts FMAs differently in the x1 and x2
+    sweeps and has to stay inside the reference's bound."""
+    s = _sim("lw_implode", [], strict=strict).initialize()
+    n = s.run()
+    rho = s.gather("prim")[0, 0]
+    err = _symmetry_error(rho)
+    assert n > 8000 and np.isfinite(rho).all() and rho.min() > 0
+    assert err <= 1e-11, err
+    if strict:
+        assert err == 0.0
