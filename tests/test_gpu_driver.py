@@ -394,3 +394,47 @@ def test_lw_implode_reference_symmetry_criterion(strict):
     assert err <= 1e-11, err
     if strict:
         assert err == 0.0
+
+
+# ---- the method x initial-condition matrix of the reference's riemann_hydro regression test -----------------
+_RH_METHODS = [(1024, "vl2", "plm", "hllc"), (64, "rk1", "dc", "hlle"), (64, "rk1", "dc", "hllc"),
+               (64, "vl2", "plm", "hlle"), (64, "vl2", "plm", "hllc"), (64, "rk3", "weno3", "hlle"),
+               (64, "rk3", "weno3", "hllc"), (64, "rk3", "limo3", "hlle"), (64, "rk3", "limo3", "hllc"),
+               (64, "rk3", "ppm", "hlle"), (64, "rk3", "ppm", "hllc"), (64, "rk3", "wenoz", "hlle"),
+               (64, "rk3", "wenoz", "hllc")]   # riemann_hydro.py:22-36
+# Toro Sec. 10.8 tests 1, 6, 7: rho_l, u_l, p_l, rho_r, u_r, p_r, x0, t_end   (riemann_hydro.py:40-55)
+_RH_ICS = {"sod_sonic": (1.0, 0.75, 1.0, 0.125, 0.0, 0.1, 0.5, 0.2),
+           "stationary_contact": (1.4, 0.0, 1.0, 1.0, 0.0, 1.0, 0.5, 2.0),
+           "slow_contact": (1.4, 0.1, 1.0, 1.0, 0.1, 1.0, 0.5, 2.0)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ic", sorted(_RH_ICS))
+def test_riemann_hydro_matrix_matches_oracle(oracle, ic):
+    """1-D shock tubes with every method of the reference's riemann_hydro suite: bit for bit against
+    the oracle; HLLC keeps the isolated stationary contact exactly, HLLE smears it."""
+    rl, ul, pl, rr, ur, pr, x0, tend = _RH_ICS[ic]
+    for nx1, integ, recon, riemann in _RH_METHODS:
+        ng = 3 if recon in ("ppm", "wenoz") else 2
+        ov = ["parthenon/mesh/nx1=%d" % nx1, "parthenon/mesh/nx2=1", "parthenon/mesh/nx3=1",
+              "parthenon/meshblock/nx1=%d" % nx1, "parthenon/meshblock/nx2=1", "parthenon/meshblock/nx3=1",
+              "parthenon/mesh/nghost=%d" % ng, "parthenon/time/integrator=%s" % integ, "parthenon/time/tlim=%r" % tend,
+              "hydro/reconstruction=%s" % recon, "hydro/riemann=%s" % riemann, "problem/sod/rho_l=%r" % rl,
+              "problem/sod/u_l=%r" % ul, "problem/sod/pres_l=%r" % pl, "problem/sod/rho_r=%r" % rr,
+              "problem/sod/u_r=%r" % ur, "problem/sod/pres_r=%r" % pr, "problem/sod/x_discont=%r" % x0]
+        s = _sim("sod", ov, strict=True).initialize()
+        o = oracle.Sim(fluid="euler", recon=recon, riemann=riemann, integrator=integ, nx=(nx1, 1, 1), ng=ng,
+                       bc=("outflow", "periodic", "periodic"), xmin=(0.0, -0.5, -0.5), xmax=(1.0, 0.5, 0.5), gamma=1.4,
+                       cfl=0.3)
+        o.pgen("sod", rho_l=rl, u_l=ul, pres_l=pl, rho_r=rr, u_r=ur, pres_r=pr, x_discont=x0)
+        label = "%s %s %s %d" % (integ, recon, riemann, nx1)
+        assert s.run() == o.run(tend), label
+        got = s.gather("cons")
+        assert np.array_equal(got, o.gather_cons()), label
+        if ic == "stationary_contact":
+            rho0 = np.where((np.arange(nx1) + 0.5) / nx1 < x0, rl, rr)
+            drift = np.abs(got[0, 0, 0] - rho0).max()
+            if riemann == "hllc":
+                assert drift < 1e-13, label
+            else:
+                assert drift > 1e-3, label
