@@ -284,6 +284,65 @@ void lw_state(const LinearWaveState &lw, double x1, double x2, double x3, double
 }
 
 // fills the interior of one block's host image [nvar][Nk][Nj][Ni]
+// ---- circularly polarised Alfven wave (src/pgen/cpaw.cpp) -----------------------------------------
+// InitUserMeshData (cpaw.cpp:58-125)
+void cpaw_setup(apk_sim *s) {
+  ParameterInput &pin = s->pin;
+  CpawState &c = s->cpaw;
+  if (s->pkg.fluid != APK_FLUID_GLMMHD) throw std::runtime_error("cpaw requires hydro/fluid = glmmhd");
+  if (s->mesh.ndim != 3) throw std::runtime_error("cpaw is set up for 3-D meshes here");
+  c.b_par = pin.GetReal("problem/cpaw", "b_par");
+  c.b_perp = pin.GetReal("problem/cpaw", "b_perp");
+  c.v_par = pin.GetReal("problem/cpaw", "v_par");
+  double ang_2 = pin.GetOrAddReal("problem/cpaw", "ang_2", -999.9);
+  double ang_3 = pin.GetOrAddReal("problem/cpaw", "ang_3", -999.9);
+  const double dir = pin.GetOrAddReal("problem/cpaw", "dir", 1);  // right (1) / left (2) polarisation
+  c.gm1 = pin.GetReal("hydro", "gamma") - 1.0;
+  c.pres = pin.GetReal("problem/cpaw", "pres");
+  c.den = 1.0;
+  c.compute_error = pin.GetOrAddBoolean("problem/cpaw", "compute_error", false);
+  const double x1size = s->xmax[0] - s->xmin[0], x2size = s->xmax[1] - s->xmin[1], x3size = s->xmax[2] - s->xmin[2];
+  if (ang_3 == -999.9) ang_3 = std::atan(x1size / x2size);
+  c.sin_a3 = std::sin(ang_3);
+  c.cos_a3 = std::cos(ang_3);
+  if (ang_2 == -999.9) ang_2 = std::atan(0.5 * (x1size * c.cos_a3 + x2size * c.sin_a3) / x3size);
+  c.sin_a2 = std::sin(ang_2);
+  c.cos_a2 = std::cos(ang_2);
+  const double x1 = x1size * c.cos_a2 * c.cos_a3, x2 = x2size * c.cos_a2 * c.sin_a3, x3 = x3size * c.sin_a2;
+  c.lambda = x1;  // the smallest of the three
+  if (s->mesh.nx[1] > 1 && ang_3 != 0.0) c.lambda = std::min(c.lambda, x2);
+  if (s->mesh.nx[2] > 1 && ang_2 != 0.0) c.lambda = std::min(c.lambda, x3);
+  c.k_par = 2.0 * (M_PI) / c.lambda;
+  c.v_perp = c.b_perp / std::sqrt(c.den);
+  c.fac = (dir == 1) ? 1.0 : -1.0;
+}
+
+// vector potential, gauge Ax = 0 (cpaw.cpp:310-344)
+void cpaw_potential(const CpawState &c, double x1, double x2, double x3, double A[3]) {
+  const double x = x1 * c.cos_a2 * c.cos_a3 + x2 * c.cos_a2 * c.sin_a3 + x3 * c.sin_a2;
+  const double y = -x1 * c.sin_a3 + x2 * c.cos_a3;
+  const double Ay = c.fac * (c.b_perp / c.k_par) * std::sin(c.k_par * (x));
+  const double Az = (c.b_perp / c.k_par) * std::cos(c.k_par * (x)) + c.b_par * y;
+  A[0] = -Ay * c.sin_a3 - Az * c.sin_a2 * c.cos_a3;
+  A[1] = Ay * c.cos_a3 - Az * c.sin_a2 * c.sin_a3;
+  A[2] = Az * c.cos_a2;
+}
+
+// analytic momenta / fields of the wave at one point (cpaw.cpp:147-175, 262-275)
+void cpaw_state(const CpawState &c, double X1, double X2, double X3, double m[3], double b[3]) {
+  const double x = c.cos_a2 * (X1 * c.cos_a3 + X2 * c.sin_a3) + X3 * c.sin_a2;
+  const double sn = std::sin(c.k_par * x);
+  const double cs = c.fac * std::cos(c.k_par * x);
+  const double mx = c.den * c.v_par, my = -c.fac * c.den * c.v_perp * sn, mz = -c.fac * c.den * c.v_perp * cs;
+  m[0] = mx * c.cos_a2 * c.cos_a3 - my * c.sin_a3 - mz * c.sin_a2 * c.cos_a3;
+  m[1] = mx * c.cos_a2 * c.sin_a3 + my * c.cos_a3 - mz * c.sin_a2 * c.sin_a3;
+  m[2] = mx * c.sin_a2 + mz * c.cos_a2;
+  const double bx = c.b_par, by = c.b_perp * sn, bz = c.b_perp * cs;
+  b[0] = bx * c.cos_a2 * c.cos_a3 - by * c.sin_a3 - bz * c.sin_a2 * c.cos_a3;
+  b[1] = bx * c.cos_a2 * c.sin_a3 + by * c.cos_a3 - bz * c.sin_a2 * c.sin_a3;
+  b[2] = bx * c.sin_a2 + bz * c.cos_a2;
+}
+
 void pgen_block(apk_sim *s, int lb, std::vector<double> &u) {
   const Mesh &m = s->mesh;
   const HydroPackage &pkg = s->pkg;
@@ -341,7 +400,31 @@ void pgen_block(apk_sim *s, int lb, std::vector<double> &u) {
     for (int j = m.js; j <= m.je; ++j)
       for (int i = m.is; i <= m.ie; ++i) {
         const double x1 = xc(s, x0, 0, i), x2 = xc(s, x0, 1, j), x3 = xc(s, x0, 2, k);
-        if (s->problem_id == "lw_implode") {  // src/pgen/lw_implode.cpp:59-73
+        if (s->problem_id == "cpaw") {  // src/pgen/cpaw.cpp:255-300
+          const CpawState &c = s->cpaw;
+          double mom[3], bana[3];
+          cpaw_state(c, x1, x2, x3, mom, bana);
+          at(0, k, j, i) = c.den;
+          at(1, k, j, i) = mom[0];
+          at(2, k, j, i) = mom[1];
+          at(3, k, j, i) = mom[2];
+          // B = curl A by centred differences of the cell-centred potential
+          double Ajp[3], Ajm[3], Akp[3], Akm[3], Aip[3], Aim[3];
+          cpaw_potential(c, x1, xc(s, x0, 1, j + 1), x3, Ajp);
+          cpaw_potential(c, x1, xc(s, x0, 1, j - 1), x3, Ajm);
+          cpaw_potential(c, x1, x2, xc(s, x0, 2, k + 1), Akp);
+          cpaw_potential(c, x1, x2, xc(s, x0, 2, k - 1), Akm);
+          cpaw_potential(c, xc(s, x0, 0, i + 1), x2, x3, Aip);
+          cpaw_potential(c, xc(s, x0, 0, i - 1), x2, x3, Aim);
+          const double b1 = (Ajp[2] - Ajm[2]) / s->dx[1] / 2.0 - (Akp[1] - Akm[1]) / s->dx[2] / 2.0;
+          const double b2 = (Akp[0] - Akm[0]) / s->dx[2] / 2.0 - (Aip[2] - Aim[2]) / s->dx[0] / 2.0;
+          const double b3 = (Aip[1] - Aim[1]) / s->dx[0] / 2.0 - (Ajp[0] - Ajm[0]) / s->dx[1] / 2.0;
+          at(5, k, j, i) = b1;
+          at(6, k, j, i) = b2;
+          at(7, k, j, i) = b3;
+          at(4, k, j, i) = c.pres / c.gm1 + 0.5 * (b1 * b1 + b2 * b2 + b3 * b3) +
+                           (0.5 / c.den) * (mom[0] * mom[0] + mom[1] * mom[1] + mom[2] * mom[2]);
+        } else if (s->problem_id == "lw_implode") {  // src/pgen/lw_implode.cpp:59-73
           const bool outside = x2 > (lwi[4] - x1);
           at(0, k, j, i) = outside ? lwi[2] : lwi[0];
           at(4, k, j, i) = (outside ? lwi[3] : lwi[1]) / gm1;
@@ -1049,9 +1132,10 @@ int create_common(const char *deck, const char *const *overrides, int noverrides
     hydro_initialize(s);
     mesh_initialize(s);
     if (s->problem_id == "linear_wave") lw_setup(s);
+    else if (s->problem_id == "cpaw") cpaw_setup(s);
     else if (s->problem_id == "turbulence") turbulence_setup(s);
     else if (s->problem_id != "sod" && s->problem_id != "orszag_tang" && s->problem_id != "synthetic" &&
-             s->problem_id != "blast" && s->problem_id != "lw_implode")
+             s->problem_id != "blast" && s->problem_id != "lw_implode" && s->problem_id != "cpaw")
       throw std::runtime_error("unknown job/problem_id: " + s->problem_id);
   } catch (const std::exception &e) {
     if (errbuf && errlen) std::snprintf(errbuf, errlen, "%s", e.what());
@@ -1555,6 +1639,8 @@ int apk_sim_execute(apk_sim *s, const char *outdir, int *ncycles) {
   s->loop_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (s->problem_id == "linear_wave" && s->lw.compute_error)
     SIM_TRY(s, apk_sim_write_linear_wave_errors(s, (std::string(outdir) + "/linearwave-errors.dat").c_str()));
+  if (s->problem_id == "cpaw" && s->cpaw.compute_error)
+    SIM_TRY(s, apk_sim_write_cpaw_errors(s, (std::string(outdir) + "/cpaw-errors.dat").c_str()));
   if (ncycles) *ncycles = n;
   return APK_OK;
 }
@@ -1599,6 +1685,74 @@ int apk_sim_linear_wave_errors(apk_sim *s, double *rms, double *l1, double *mx) 
     r += l1[n] * l1[n];
   }
   *rms = std::sqrt(r);
+  return APK_OK;
+}
+
+// cpaw::UserWorkAfterLoop (src/pgen/cpaw.cpp:127-221): L1 errors against the initial state, err8 in
+// the order d, M1, M2, M3, E, B1, B2, B3
+int apk_sim_cpaw_errors(apk_sim *s, double *rms, double *err8) {
+  if (!s || s->host_only || s->problem_id != "cpaw" || !rms || !err8) return APK_ERR_INVALID;
+  const Mesh &m = s->mesh;
+  const CpawState &c = s->cpaw;
+  std::vector<double> host((size_t)s->nper);
+  double err[8] = {0};
+  for (int lb = 0; lb < (int)m.local_gids.size(); ++lb) {
+    int rc = apk_sim_read_block(s, lb, 0, host.data());
+    if (rc != APK_OK) return rc;
+    double x0[3];
+    block_origin(s, lb, x0);
+    auto at = [&](int n, int k, int j, int i) { return host[n * m.sn + k * m.sk + j * m.sj + i]; };
+    for (int k = m.ks; k <= m.ke; ++k)
+      for (int j = m.js; j <= m.je; ++j)
+        for (int i = m.is; i <= m.ie; ++i) {
+          double mom[3], b[3];
+          cpaw_state(c, xc(s, x0, 0, i), xc(s, x0, 1, j), xc(s, x0, 2, k), mom, b);
+          err[0] += std::abs(c.den - at(0, k, j, i));
+          for (int d = 0; d < 3; ++d) err[1 + d] += std::abs(mom[d] - at(1 + d, k, j, i));
+          for (int d = 0; d < 3; ++d) err[5 + d] += std::abs(b[d] - at(5 + d, k, j, i));
+          const double e0 = c.pres / c.gm1 + 0.5 * (mom[0] * mom[0] + mom[1] * mom[1] + mom[2] * mom[2]) / c.den +
+                            0.5 * (b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+          err[4] += std::abs(e0 - at(4, k, j, i));
+        }
+  }
+  if (s->have_comm && s->nranks > 1) {
+    if (s->comm.allreduce_sum(s->comm.user, err, 8) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_sum failed");
+  }
+  const double ncells = (double)m.nx[0] * m.nx[1] * m.nx[2];
+  double r = 0.0;
+  for (int n = 0; n < 8; ++n) {
+    err8[n] = err[n] / ncells;
+    r += err8[n] * err8[n];
+  }
+  *rms = std::sqrt(r);
+  return APK_OK;
+}
+
+// "cpaw-errors.dat" (cpaw.cpp:188-220): header when the file is new, otherwise append
+int apk_sim_write_cpaw_errors(apk_sim *s, const char *path) {
+  if (!s || !path) return APK_ERR_INVALID;
+  double rms = 0.0, err[8];
+  int rc = apk_sim_cpaw_errors(s, &rms, err);
+  if (rc != APK_OK) return rc;
+  if (s->rank != 0) return APK_OK;
+  FILE *f = std::fopen(path, "r");
+  const bool fresh = (f == nullptr);
+  if (f) std::fclose(f);
+  f = std::fopen(path, "a");
+  if (!f) return fail(s, APK_ERR_INVALID, "Error output file could not be opened");
+  if (fresh) {
+    std::fprintf(f, "# Nx1  Nx2  Nx3  Ncycle  RMS-Error  d  M1  M2  M3");
+    std::fprintf(f, "  E");
+    std::fprintf(f, "  B1c  B2c  B3c");
+    std::fprintf(f, "\n");
+  }
+  std::fprintf(f, "%d  %d", s->mesh.nx[0], s->mesh.nx[1]);
+  std::fprintf(f, "  %d  %d  %e", s->mesh.nx[2], s->ncycle, rms);
+  std::fprintf(f, "  %e  %e  %e  %e", err[0], err[1], err[2], err[3]);
+  std::fprintf(f, "  %e", err[4]);
+  std::fprintf(f, "  %e  %e  %e", err[5], err[6], err[7]);
+  std::fprintf(f, "\n");
+  std::fclose(f);
   return APK_OK;
 }
 

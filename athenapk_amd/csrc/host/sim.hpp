@@ -47,6 +47,12 @@ struct LinearWaveState {  // globals of src/pgen/linear_wave.cpp
   bool compute_error = false;
 };
 
+struct CpawState {  // globals of src/pgen/cpaw.cpp
+  double den = 1.0, pres = 0, gm1 = 0, b_par = 0, b_perp = 0, v_perp = 0, v_par = 0, fac = 1.0;
+  double sin_a2 = 0, cos_a2 = 1, sin_a3 = 0, cos_a3 = 1, lambda = 1, k_par = 0;
+  bool compute_error = false;
+};
+
 }  // namespace apk
 
 struct apk_sim {
@@ -55,6 +61,7 @@ struct apk_sim {
   apk::HydroPackage pkg;
   std::string problem_id;
   apk::LinearWaveState lw;
+  apk::CpawState cpaw;
   bool host_only = false;
   bool fused = true;
   int rank = 0, nranks = 1;

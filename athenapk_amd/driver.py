@@ -328,6 +328,12 @@ class Simulation(_FmftHost):
         self._check(self.lib.apk_sim_read_acc(self.h, lb, out.ctypes.data_as(L.c_dp)))
         return out
 
+    def cpaw_errors(self):
+        rms = C.c_double(0.0)
+        err = (C.c_double * 8)()
+        self._check(self.lib.apk_sim_cpaw_errors(self.h, C.byref(rms), err))
+        return rms.value, np.array(err[:])
+
     def linear_wave_errors(self):
         rms = C.c_double(0.0)
         l1, mx = (C.c_double * 5)(), (C.c_double * 5)()

@@ -193,6 +193,8 @@ def _signatures():
         "apk_sim_write_block": (i, [vp, i, i, c_dp]),
         "apk_sim_history": (i, [vp, c_dp]),
         "apk_sim_linear_wave_errors": (i, [vp, c_dp, c_dp, c_dp]),
+        "apk_sim_cpaw_errors": (i, [vp, c_dp, c_dp]),
+        "apk_sim_write_cpaw_errors": (i, [vp, C.c_char_p]),
         "apk_sim_check_refinement": (i, [vp, C.POINTER(C.c_int), c_dp]),
         "apk_sim_history_labels": (i, [vp, C.c_char_p, C.c_size_t]),
         "apk_sim_write_history": (i, [vp, C.c_char_p]),

@@ -161,6 +161,9 @@ void orc_pgen_sod(orc_sim *s, double rho_l, double pres_l, double u_l, double rh
                   double pres_r, double u_r, double x_discont);
 /* src/pgen/orszag_tang.cpp:25-63 */
 void orc_pgen_orszag_tang(orc_sim *s);
+double orc_pgen_cpaw(orc_sim *s, double b_par, double b_perp, double pres, double v_par, int dir, double ang_2,
+                     double ang_3);
+double orc_cpaw_errors(orc_sim *s, double *err8);
 void orc_pgen_lw_implode(orc_sim *s, double d_in, double p_in, double d_out, double p_out);
 void orc_pgen_blast(orc_sim *s, double rout, double rin, double pa, double da, double prat, double drat,
                     double x0, double y0, double z0);

@@ -105,6 +105,8 @@ def _declare(lib):
         "orc_pgen_linear_wave": (d, [C.c_void_p, i, d, d]),
         "orc_pgen_sod": (None, [C.c_void_p, d, d, d, d, d, d, d]),
         "orc_pgen_orszag_tang": (None, [C.c_void_p]),
+        "orc_pgen_cpaw": (d, [C.c_void_p, d, d, d, d, i, d, d]),
+        "orc_cpaw_errors": (d, [C.c_void_p, p]),
         "orc_pgen_lw_implode": (None, [C.c_void_p, d, d, d, d]),
         "orc_pgen_blast": (None, [C.c_void_p, d, d, d, d, d, d, d, d, d]),
         "orc_pgen_synthetic": (None, [C.c_void_p]),
@@ -270,6 +272,10 @@ class Sim:
             self.lib.orc_pgen_orszag_tang(self.h)
         elif name == "synthetic":
             self.lib.orc_pgen_synthetic(self.h)
+        elif name == "cpaw":
+            self.cpaw_lambda = self.lib.orc_pgen_cpaw(self.h, kw.get("b_par", 1.0), kw.get("b_perp", 0.1),
+                                                      kw.get("pres", 0.1), kw.get("v_par", 0.0), kw.get("dir", 1),
+                                                      kw.get("ang_2", -999.9), kw.get("ang_3", -999.9))
         elif name == "lw_implode":
             self.lib.orc_pgen_lw_implode(self.h, kw.get("d_in", 0.125), kw.get("p_in", 0.14), kw.get("d_out", 1.0),
                                          kw.get("p_out", 1.0))
@@ -317,6 +323,11 @@ class Sim:
 
     def acc(self, b):
         return np.ctypeslib.as_array(self.lib.orc_sim_acc(self.h, b), shape=(3,) + self.geom.shape[1:])
+
+    def cpaw_errors(self):
+        err = np.zeros(8)
+        rms = self.lib.orc_cpaw_errors(self.h, dp(err))
+        return rms, err
 
     def linear_wave_errors(self):
         l1, mx = np.zeros(5), np.zeros(5)

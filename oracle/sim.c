@@ -28,6 +28,11 @@ struct orc_sim {
   long fofc_total;
   /* turbulence driver (NULL unless orc_pgen_turbulence was called) */
   orc_fmft *fmft;
+  /* circularly polarised Alfven wave (orc_pgen_cpaw) */
+  struct {
+    double den, pres, gm1, b_par, b_perp, v_perp, v_par, fac;
+    double sin_a2, cos_a2, sin_a3, cos_a3, lambda, k_par;
+  } cpaw;
   double accel_rms;
   double **acc, **ph_i, **ph_j, **ph_k;
   /* linear wave state (src/pgen/linear_wave.cpp globals) */
@@ -638,6 +643,133 @@ void orc_pgen_lw_implode(orc_sim *s, double d_in, double p_in, double d_out, dou
           }
         }
   }
+}
+
+/* ---- circularly polarised Alfven wave (src/pgen/cpaw.cpp) -------------------------------------- */
+/* vector potential in a gauge with Ax = 0 (cpaw.cpp:310-344) */
+static void cpaw_A(const orc_sim *s, double x1, double x2, double x3, double A[3]) {
+  const double x = x1 * s->cpaw.cos_a2 * s->cpaw.cos_a3 + x2 * s->cpaw.cos_a2 * s->cpaw.sin_a3 + x3 * s->cpaw.sin_a2;
+  const double y = -x1 * s->cpaw.sin_a3 + x2 * s->cpaw.cos_a3;
+  const double Ay = s->cpaw.fac * (s->cpaw.b_perp / s->cpaw.k_par) * sin(s->cpaw.k_par * (x));
+  const double Az = (s->cpaw.b_perp / s->cpaw.k_par) * cos(s->cpaw.k_par * (x)) + s->cpaw.b_par * y;
+  A[0] = -Ay * s->cpaw.sin_a3 - Az * s->cpaw.sin_a2 * s->cpaw.cos_a3;
+  A[1] = Ay * s->cpaw.cos_a3 - Az * s->cpaw.sin_a2 * s->cpaw.sin_a3;
+  A[2] = Az * s->cpaw.cos_a2;
+}
+
+/* InitUserMeshData + ProblemGenerator (cpaw.cpp:58-125, 227-303); 3-D only; returns lambda.
+ * ang_2 / ang_3 = -999.9 select the grid-diagonal wavevector like the reference. */
+double orc_pgen_cpaw(orc_sim *s, double b_par, double b_perp, double pres, double v_par, int dir, double ang_2,
+                     double ang_3) {
+  const sb_t bb = sim_bounds(&s->g);
+  s->cpaw.b_par = b_par;
+  s->cpaw.b_perp = b_perp;
+  s->cpaw.v_par = v_par;
+  s->cpaw.gm1 = s->p.eos.gamma - 1.0;
+  s->cpaw.pres = pres;
+  s->cpaw.den = 1.0;
+  const double x1size = s->p.xmax[0] - s->p.xmin[0], x2size = s->p.xmax[1] - s->p.xmin[1],
+               x3size = s->p.xmax[2] - s->p.xmin[2];
+  if (ang_3 == -999.9) ang_3 = atan(x1size / x2size);
+  s->cpaw.sin_a3 = sin(ang_3);
+  s->cpaw.cos_a3 = cos(ang_3);
+  if (ang_2 == -999.9) ang_2 = atan(0.5 * (x1size * s->cpaw.cos_a3 + x2size * s->cpaw.sin_a3) / x3size);
+  s->cpaw.sin_a2 = sin(ang_2);
+  s->cpaw.cos_a2 = cos(ang_2);
+  const double x1 = x1size * s->cpaw.cos_a2 * s->cpaw.cos_a3, x2 = x2size * s->cpaw.cos_a2 * s->cpaw.sin_a3,
+               x3 = x3size * s->cpaw.sin_a2;
+  double lambda = x1;
+  if (s->p.nx[1] > 1 && ang_3 != 0.0) lambda = fmin(lambda, x2);
+  if (s->p.nx[2] > 1 && ang_2 != 0.0) lambda = fmin(lambda, x3);
+  s->cpaw.lambda = lambda;
+  s->cpaw.k_par = 2.0 * (M_PI) / lambda;
+  s->cpaw.v_perp = b_perp / sqrt(s->cpaw.den);
+  s->cpaw.fac = (dir == 1) ? 1.0 : -1.0;
+  const double den = s->cpaw.den, fac = s->cpaw.fac, v_perp = s->cpaw.v_perp;
+  const double sa2 = s->cpaw.sin_a2, ca2 = s->cpaw.cos_a2, sa3 = s->cpaw.sin_a3, ca3 = s->cpaw.cos_a3;
+  for (int b = 0; b < s->nblocks; ++b) {
+    double x0[3];
+    orc_sim_block_origin(s, b, x0);
+    double *u = s->cons[b];
+    for (int k = bb.ks; k <= bb.ke; ++k)
+      for (int j = bb.js; j <= bb.je; ++j)
+        for (int i = bb.is; i <= bb.ie; ++i) {
+          const double X1 = xc(s, x0, 0, i), X2 = xc(s, x0, 1, j), X3 = xc(s, x0, 2, k);
+          const double x = ca2 * (X1 * ca3 + X2 * sa3) + X3 * sa2;
+          const double sn = sin(s->cpaw.k_par * x);
+          const double cs = fac * cos(s->cpaw.k_par * x);
+          SAT(u, ORC_IDN, k, j, i) = den;
+          const double mx = den * v_par, my = -fac * den * v_perp * sn, mz = -fac * den * v_perp * cs;
+          SAT(u, ORC_IM1, k, j, i) = mx * ca2 * ca3 - my * sa3 - mz * sa2 * ca3;
+          SAT(u, ORC_IM2, k, j, i) = mx * ca2 * sa3 + my * ca3 - mz * sa2 * sa3;
+          SAT(u, ORC_IM3, k, j, i) = mx * sa2 + mz * ca2;
+          /* B = curl A by centred differences of the cell-centred potential */
+          double Ajp[3], Ajm[3], Akp[3], Akm[3], Aip[3], Aim[3];
+          cpaw_A(s, X1, xc(s, x0, 1, j + 1), X3, Ajp);
+          cpaw_A(s, X1, xc(s, x0, 1, j - 1), X3, Ajm);
+          cpaw_A(s, X1, X2, xc(s, x0, 2, k + 1), Akp);
+          cpaw_A(s, X1, X2, xc(s, x0, 2, k - 1), Akm);
+          cpaw_A(s, xc(s, x0, 0, i + 1), X2, X3, Aip);
+          cpaw_A(s, xc(s, x0, 0, i - 1), X2, X3, Aim);
+          const double dx1 = s->g.dx[0], dx2 = s->g.dx[1], dx3 = s->g.dx[2];
+          const double b1 = (Ajp[2] - Ajm[2]) / dx2 / 2.0 - (Akp[1] - Akm[1]) / dx3 / 2.0;
+          const double b2 = (Akp[0] - Akm[0]) / dx3 / 2.0 - (Aip[2] - Aim[2]) / dx1 / 2.0;
+          const double b3 = (Aip[1] - Aim[1]) / dx1 / 2.0 - (Ajp[0] - Ajm[0]) / dx2 / 2.0;
+          SAT(u, ORC_IB1, k, j, i) = b1;
+          SAT(u, ORC_IB2, k, j, i) = b2;
+          SAT(u, ORC_IB3, k, j, i) = b3;
+          const double m1 = SAT(u, ORC_IM1, k, j, i), m2 = SAT(u, ORC_IM2, k, j, i), m3 = SAT(u, ORC_IM3, k, j, i);
+          SAT(u, ORC_IEN, k, j, i) = s->cpaw.pres / s->cpaw.gm1 + 0.5 * (b1 * b1 + b2 * b2 + b3 * b3) +
+                                     (0.5 / den) * (m1 * m1 + m2 * m2 + m3 * m3);
+        }
+  }
+  return lambda;
+}
+
+/* UserWorkAfterLoop (cpaw.cpp:127-221): L1 errors against the initial state, err8 in the order
+ * d, M1, M2, M3, E, B1, B2, B3; returns the RMS */
+double orc_cpaw_errors(orc_sim *s, double *err8) {
+  const sb_t bb = sim_bounds(&s->g);
+  const double den = s->cpaw.den, fac = s->cpaw.fac, v_perp = s->cpaw.v_perp, v_par = s->cpaw.v_par;
+  const double sa2 = s->cpaw.sin_a2, ca2 = s->cpaw.cos_a2, sa3 = s->cpaw.sin_a3, ca3 = s->cpaw.cos_a3;
+  for (int n = 0; n < 8; ++n) err8[n] = 0.0;
+  for (int b = 0; b < s->nblocks; ++b) {
+    double x0[3];
+    orc_sim_block_origin(s, b, x0);
+    const double *u = s->cons[b];
+    for (int k = bb.ks; k <= bb.ke; ++k)
+      for (int j = bb.js; j <= bb.je; ++j)
+        for (int i = bb.is; i <= bb.ie; ++i) {
+          const double x = ca2 * (xc(s, x0, 0, i) * ca3 + xc(s, x0, 1, j) * sa3) + xc(s, x0, 2, k) * sa2;
+          const double sn = sin(s->cpaw.k_par * x);
+          const double cs = fac * cos(s->cpaw.k_par * x);
+          err8[ORC_IDN] += fabs(den - SAT(u, ORC_IDN, k, j, i));
+          const double mx = den * v_par, my = -fac * den * v_perp * sn, mz = -fac * den * v_perp * cs;
+          const double m1 = mx * ca2 * ca3 - my * sa3 - mz * sa2 * ca3;
+          const double m2 = mx * ca2 * sa3 + my * ca3 - mz * sa2 * sa3;
+          const double m3 = mx * sa2 + mz * ca2;
+          err8[ORC_IM1] += fabs(m1 - SAT(u, ORC_IM1, k, j, i));
+          err8[ORC_IM2] += fabs(m2 - SAT(u, ORC_IM2, k, j, i));
+          err8[ORC_IM3] += fabs(m3 - SAT(u, ORC_IM3, k, j, i));
+          const double bx = s->cpaw.b_par, by = s->cpaw.b_perp * sn, bz = s->cpaw.b_perp * cs;
+          const double b1 = bx * ca2 * ca3 - by * sa3 - bz * sa2 * ca3;
+          const double b2 = bx * ca2 * sa3 + by * ca3 - bz * sa2 * sa3;
+          const double b3 = bx * sa2 + bz * ca2;
+          err8[ORC_IB1] += fabs(b1 - SAT(u, ORC_IB1, k, j, i));
+          err8[ORC_IB2] += fabs(b2 - SAT(u, ORC_IB2, k, j, i));
+          err8[ORC_IB3] += fabs(b3 - SAT(u, ORC_IB3, k, j, i));
+          const double e0 = s->cpaw.pres / s->cpaw.gm1 + 0.5 * (m1 * m1 + m2 * m2 + m3 * m3) / den +
+                            0.5 * (b1 * b1 + b2 * b2 + b3 * b3);
+          err8[ORC_IEN] += fabs(e0 - SAT(u, ORC_IEN, k, j, i));
+        }
+  }
+  const double ncells = (double)s->p.nx[0] * s->p.nx[1] * s->p.nx[2];
+  double rms = 0.0;
+  for (int n = 0; n < 8; ++n) {
+    err8[n] = err8[n] / ncells;
+    rms += err8[n] * err8[n];
+  }
+  return sqrt(rms);
 }
 
 /* src/pgen/orszag_tang.cpp:25-63 */
