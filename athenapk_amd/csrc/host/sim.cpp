@@ -1133,6 +1133,8 @@ int create_common(const char *deck, const char *const *overrides, int noverrides
     mesh_initialize(s);
     if (s->problem_id == "linear_wave") lw_setup(s);
     else if (s->problem_id == "cpaw") cpaw_setup(s);
+    else if (s->problem_id == "lw_implode" && s->pkg.fluid == APK_FLUID_GLMMHD)
+      throw std::runtime_error("Only hydro runs are supported for LW implosion problem generator.");
     else if (s->problem_id == "turbulence") turbulence_setup(s);
     else if (s->problem_id != "sod" && s->problem_id != "orszag_tang" && s->problem_id != "synthetic" &&
              s->problem_id != "blast" && s->problem_id != "lw_implode" && s->problem_id != "cpaw")

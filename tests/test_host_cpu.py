@@ -265,3 +265,27 @@ def test_turbulence_deck_errors(overrides, msg):
     with pytest.raises(L.ApkError) as e:
         _plan("turbulence", overrides)
     assert e.value.code == L.APK_ERR_INVALID and msg in str(e.value)
+
+
+# ---- decks of the problems added for the reference's other regression suites ---------------------------------
+@pytest.mark.parametrize("deck,fluid,recon,riemann,nx", [("blast", "euler", "plm", "hlle", [64, 64, 64]),
+                                                         ("lw_implode", "euler", "plm", "hllc", [256, 256, 1]),
+                                                         ("cpaw", "glmmhd", "plm", "hlld", [64, 32, 32]),
+                                                         ("turbulence", "glmmhd", "plm", "hlle", [64, 64, 64])])
+def test_problem_decks_parse(deck, fluid, recon, riemann, nx):
+    from athenapk_amd import lib as L
+    p = _plan(deck)
+    assert (p.info.fluid, p.info.recon, p.info.riemann) == (L.FLUID[fluid], L.RECON[recon], L.RIEMANN[riemann])
+    assert list(p.info.nx) == nx
+
+
+@pytest.mark.parametrize("deck,overrides,msg", [
+    ("cpaw", ["hydro/fluid=euler", "hydro/riemann=hllc"], "cpaw requires hydro/fluid = glmmhd"),
+    ("cpaw", ["parthenon/mesh/nx3=1", "parthenon/meshblock/nx3=1"], "3-D"),
+    ("lw_implode", ["hydro/fluid=glmmhd", "hydro/riemann=hlld"], "Only hydro runs are supported"),
+])
+def test_problem_deck_errors(deck, overrides, msg):
+    from athenapk_amd import lib as L
+    with pytest.raises(L.ApkError) as e:
+        _plan(deck, overrides)
+    assert msg in str(e.value)

