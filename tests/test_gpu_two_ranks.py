@@ -121,3 +121,50 @@ def test_ranks_sharing_one_gpu_match_oracle(oracle, tmp_path, case, world, overl
                 seen.add(gid)
                 assert np.array_equal(z[key], o.cons(gid)), "rank %d block %d" % (r, gid)
     assert seen == set(range(o.nblocks))
+
+
+def _turb_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from athenapk_amd import decks, driver
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        ov = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=32", "parthenon/meshblock/nx1=16",
+              "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=16"]
+        s = driver.Simulation(decks.load("turbulence"), ov, rank=rank, nranks=world, strict=True)
+        s.initialize()
+        for _ in range(8):
+            s.step()
+        blocks = {s.block_gid(lb)[0]: s.read_block(lb, "cons") for lb in range(s.info.nblocks_local)}
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), time=s.time, turb=s.turbulence_history(), hist=s.history(),
+                 var_hat=s.fmft_var_hat(), overlapped=s.overlapped_exchanges, **{"b%d" % g: a for g, a in blocks.items()})
+        s.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_turbulence_driver_on_two_ranks(oracle, tmp_path):
+    """The forcing's global sums (mean momentum, RMS normalisation) and the Ms / Ma history are
+    all-reduced over ranks; every rank evolves the same spectral state from the same host RNG."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_driver import _turb_k_vec
+    o = oracle.Sim(fluid="glmmhd", recon="plm", riemann="hlle", integrator="vl2", nx=(32, 32, 32), mb=(16, 16, 16), ng=2,
+                   cfl=0.3, gamma=1.0001)
+    o.pgen("turbulence", k_vec=_turb_k_vec())
+    for _ in range(8):
+        o.step()
+    mp.spawn(_turb_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert np.array_equal(z["var_hat"], o.var_hat())
+        assert abs(z["time"] - o.time) <= 1e-13 * o.time
+        np.testing.assert_allclose(z["turb"], o.turb_history(), rtol=1e-10)
+        np.testing.assert_allclose(z["hist"], o.history(), rtol=1e-11, atol=1e-14)
+        assert int(z["overlapped"]) == 8   # the exchange before each corrector stage; the driven last stage syncs
+        for key in z.files:
+            if key.startswith("b"):
+                np.testing.assert_allclose(z[key], o.cons(int(key[1:])), rtol=1e-11, atol=1e-13)
