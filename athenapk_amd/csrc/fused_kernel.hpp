@@ -230,7 +230,7 @@ constexpr int march_lds_bytes() {
 
 template <int FLUID, int RECON, int RS, int DIR, bool FINAL, int EXTRA = EXTRA_NONE>
 __global__ void __launch_bounds__(64, kMarchMinWaves)
-fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg) {
+fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) {
   static_assert(DIR == 2 || DIR == 3, "march is for x2/x3");
   static_assert(FINAL || EXTRA == EXTRA_NONE, "extras belong to the finishing sweep");
   double lane_min_dt = 1.7976931348623157e308;
@@ -239,10 +239,16 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg) {
   constexpr int NS = 2 * H;  // ring slots
   extern __shared__ __attribute__((aligned(16))) double ring[];
   const int lane = threadIdx.x;
-  const int i = u0.is + blockIdx.x * 64 + lane;
-  const int trans = blockIdx.y;  // k for DIR==2, j for DIR==3
-  const bool active = (i <= u0.ie);
-  const int ii = active ? i : u0.ie;  // idle lanes shadow a valid column, never store
+  // Narrow meshblocks (AMR-sized: nx1 = 16 or 32) would leave 3/4 or 1/2 of the wave idle with one
+  // row of columns per wave: the wave then takes rpw = 4 or 2 transverse rows, 64 / rpw columns each.
+  const int cpr = 64 / rpw;
+  const int sub = lane / cpr;
+  const int i = u0.is + blockIdx.x * cpr + (lane - sub * cpr);
+  const int ntrans = (DIR == 2) ? u0.nx3 : u0.nx2;
+  const int trans_raw = blockIdx.y * rpw + sub;  // k for DIR==2, j for DIR==3
+  const bool active = (i <= u0.ie) && (trans_raw < ntrans);
+  const int ii = (i <= u0.ie) ? i : u0.ie;  // idle lanes shadow a valid column, never store
+  const int trans = (trans_raw < ntrans) ? trans_raw : ntrans - 1;
   // the march may be cut into nseg segments (blockIdx.z = block * nseg + segment): few, long
   // waves cannot fill the machine when the pack is small (one 256^3 block is 1024 waves for 2048
   // slots); each segment re-reads 2H+1 rows and redoes one face
@@ -677,6 +683,13 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
 // ---- launch helpers ---------------------------------------------------------------------------
 // segments per march so that the launch has at least ~2 x 2048 waves (MI355X: 1024 SIMDs x 2
 // resident march waves), never shorter than 16 cells
+// transverse rows per wave of a march: fill the 64 lanes when the block is narrower than a wave
+inline int march_rows_per_wave(int nx1, int ntrans) {
+  int rpw = (nx1 <= 16) ? 4 : ((nx1 <= 32) ? 2 : 1);
+  while (rpw > 1 && rpw > ntrans) rpw /= 2;
+  return rpw;
+}
+
 inline int march_segments(int64_t waves, int n_along) {
   static const int forced = std::getenv("APK_MARCH_NSEG") ? std::atoi(std::getenv("APK_MARCH_NSEG")) : 0;  // A/B switch
   int nseg = forced > 0 ? forced : (int)((4096 + waves - 1) / waves);
@@ -691,14 +704,18 @@ inline void launch_final_march(const PackView &u0, const PackView &u1, const Sta
   // (a finishing march that replaces prim in place must own its columns from end to end: the
   // next segment's stencil rows would be overwritten under it)
   const bool in_place = (extra != EXTRA_NONE) && !sp.prim_to_u1;
+  const int ntrans = (DIR == 2) ? u0.nx3 : u0.nx2;
+  const int rpw = march_rows_per_wave(u0.nx1, ntrans);
+  grid.x = (u0.nx1 + 64 / rpw - 1) / (64 / rpw);
+  grid.y = (ntrans + rpw - 1) / rpw;
   const int nseg = in_place ? 1 : march_segments((int64_t)grid.x * grid.y * grid.z, DIR == 2 ? u0.nx2 : u0.nx3);
   grid.z *= nseg;
   if (extra == EXTRA_C2P_DT)
-    hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, DIR, true, EXTRA_C2P_DT>), grid, dim3(64), lds, s, u0, u1, sp, nseg);
+    hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, DIR, true, EXTRA_C2P_DT>), grid, dim3(64), lds, s, u0, u1, sp, nseg, rpw);
   else if (extra == EXTRA_C2P)
-    hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, DIR, true, EXTRA_C2P>), grid, dim3(64), lds, s, u0, u1, sp, nseg);
+    hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, DIR, true, EXTRA_C2P>), grid, dim3(64), lds, s, u0, u1, sp, nseg, rpw);
   else
-    hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, DIR, true, EXTRA_NONE>), grid, dim3(64), lds, s, u0, u1, sp, nseg);
+    hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, DIR, true, EXTRA_NONE>), grid, dim3(64), lds, s, u0, u1, sp, nseg, rpw);
 }
 
 template <int FLUID, int RECON, int RS>
@@ -762,11 +779,12 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
         hipLaunchKernelGGL((fused_x1_kernel<FLUID, RECON, RS, false>), g1, dim3(256), 0, s, u0, u1, sp, wpp);
       }
       if (do_rest) {
-        dim3 g2((u0.nx1 + 63) / 64, u0.nx3, u0.nblocks);
+        const int rpw = march_rows_per_wave(u0.nx1, u0.nx3);
+        dim3 g2((u0.nx1 + 64 / rpw - 1) / (64 / rpw), (u0.nx3 + rpw - 1) / rpw, u0.nblocks);
         const int nseg = march_segments((int64_t)g2.x * g2.y * g2.z, u0.nx2);
         g2.z *= nseg;
         ScopedTiming t(sp.ctx, TS + 1, s);
-        hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 2, false>), g2, dim3(64), lds, s, u0, u1, sp, nseg);
+        hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 2, false>), g2, dim3(64), lds, s, u0, u1, sp, nseg, rpw);
       }
     }
     if (do_rest) {
