@@ -779,17 +779,37 @@ int estimate_timestep(apk_sim *s, double *dt_out) {
 }
 
 // Ghost exchange in two halves.  begin: same-rank copies, message packing, post the transfers;
-// end: wait for them, unpack, physical boundaries (x1, x2, x3).
-int exchange_begin(apk_sim *s, bool async) {
+// end: wait for them, unpack, physical boundaries (x1, x2, x3).  With c2p the copies that fill
+// ghost zones also convert them to primitives (apk_copy_plan_run_c2p), which replaces the separate
+// ghost ConsToPrim pass -- and, around an exchange in flight, splits it by construction: the
+// same-rank part in `begin`, the rest in `end`.
+bool ghost_c2p_fusable(const apk_sim *s) {
+  const apk_eos &e = s->pkg.eos;
+  return !(e.dfloor > 0.0 || e.pfloor > 0.0 || e.efloor > 0.0 || e.vceil < 1.0e300 || e.eceil < 1.0e300);
+}
+
+int run_ghost_plan(apk_sim *s, int buf, int phase, bool c2p) {
+  if (!c2p) return apk_copy_plan_run(s->ctx, s->plans_of[buf][phase], s->stream);
+  const int64_t delta = s->d_prim2[s->pcur] - s->d_cons2[buf];
+  // a boundary phase that is followed by another non-empty one copies corner cells from ghost
+  // zones only that later phase fills: their (overwritten) primitives must not raise flags
+  int latch = 1;
+  for (int later = phase + 1; phase >= PH_BC1 && later <= PH_BC3; ++later)
+    if (!s->mesh.plan[later].empty()) latch = 0;
+  return apk_copy_plan_run_c2p(s->ctx, s->plans_of[buf][phase], s->pkg.fluid, &s->pkg.eos, delta, latch, s->stream);
+}
+
+int exchange_begin(apk_sim *s, bool async, bool c2p) {
   const bool remote = !s->mesh.peers.empty();
   if (remote) SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(PH_PACK), s->stream));
-  SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(PH_LOCAL), s->stream));
+  SIM_TRY(s, run_ghost_plan(s, s->cur, PH_LOCAL, c2p));
   if (remote) {
     if (!s->have_comm || !s->comm.exchange) return fail(s, APK_ERR_INVALID, "remote neighbours but no comm ops");
     if (async) {
       if (s->comm.exchange_begin(s->comm.user) != 0) return fail(s, APK_ERR_DEVICE, "halo exchange (begin) failed");
       s->exchange_pending = true;
       s->pending_cons = s->cur;
+      s->pending_c2p = c2p;
     } else if (s->comm.exchange(s->comm.user) != 0) {
       return fail(s, APK_ERR_DEVICE, "halo exchange failed");
     }
@@ -797,7 +817,7 @@ int exchange_begin(apk_sim *s, bool async) {
   return APK_OK;
 }
 
-int exchange_end(apk_sim *s) {
+int exchange_end(apk_sim *s, bool c2p) {
   // an exchange left in flight targets the buffer that held the state when it was posted: the
   // first stage of the next cycle has swapped the buffer roles by the time it completes it
   const int buf = s->exchange_pending ? s->pending_cons : s->cur;
@@ -805,14 +825,14 @@ int exchange_end(apk_sim *s) {
     if (s->comm.exchange_end(s->comm.user) != 0) return fail(s, APK_ERR_DEVICE, "halo exchange (end) failed");
     s->exchange_pending = false;
   }
-  if (!s->mesh.peers.empty()) SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plans_of[buf][PH_UNPACK], s->stream));
-  for (int ph = PH_BC1; ph <= PH_BC3; ++ph) SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plans_of[buf][ph], s->stream));
+  if (!s->mesh.peers.empty()) SIM_TRY(s, run_ghost_plan(s, buf, PH_UNPACK, c2p));
+  for (int ph = PH_BC1; ph <= PH_BC3; ++ph) SIM_TRY(s, run_ghost_plan(s, buf, ph, c2p));
   return APK_OK;
 }
 
-int exchange_ghosts(apk_sim *s) {
-  SIM_TRY(s, exchange_begin(s, false));
-  return exchange_end(s);
+int exchange_ghosts(apk_sim *s, bool c2p = false) {
+  SIM_TRY(s, exchange_begin(s, false, c2p));
+  return exchange_end(s, c2p);
 }
 
 // index windows of the split stages, per local block (see apk_stage_args.window)
@@ -916,7 +936,9 @@ bool can_overlap_next(const apk_sim *s, int next) {
 int finish_pending(apk_sim *s) {
   if (!s->exchange_pending) return APK_OK;
   apk_pack *state = s->mu0_of[s->pending_cons][s->pcur];
-  SIM_TRY(s, exchange_end(s));
+  const bool c2p = s->pending_c2p;
+  SIM_TRY(s, exchange_end(s, c2p));
+  if (c2p) return APK_OK;  // the ghost zones were converted as they were filled
   return apk_cons_to_prim_ghosts(s->ctx, state, s->pkg.fluid, &s->pkg.eos, s->stream);
 }
 
@@ -1058,15 +1080,18 @@ int do_stage(apk_sim *s, int stage) {
       // a high-order stage / the whole single-kernel donor-cell stage, on index windows), then
       // complete the exchange and do the thin slabs next to those faces and the rest.
       apk_pack *state = s->mu0_of[s->pending_cons][s->pcur];  // (stage 1 has swapped the cons roles already)
-      SIM_TRY(s, apk_cons_to_prim_ghosts_split(s->ctx, state, pkg.fluid, &pkg.eos, s->d_late_regions, 1, s->stream));
+      const bool c2p_in_copy = s->pending_c2p;  // then the ghost zones are converted as they are filled
+      if (!c2p_in_copy)
+        SIM_TRY(s, apk_cons_to_prim_ghosts_split(s->ctx, state, pkg.fluid, &pkg.eos, s->d_late_regions, 1, s->stream));
       const bool whole = dc3 && swap_prim;  // single-kernel stage
       const apk_sim::WindowTable *tabs = whole ? s->dcwin : s->x1win;
       const int ntabs = whole ? 7 : 3;
       a.phase = 1;
       for (int q = 0; q < ntabs; ++q) {
         if (q == 1) {
-          SIM_TRY(s, exchange_end(s));
-          SIM_TRY(s, apk_cons_to_prim_ghosts_split(s->ctx, state, pkg.fluid, &pkg.eos, s->d_late_regions, 2, s->stream));
+          SIM_TRY(s, exchange_end(s, c2p_in_copy));
+          if (!c2p_in_copy)
+            SIM_TRY(s, apk_cons_to_prim_ghosts_split(s->ctx, state, pkg.fluid, &pkg.eos, s->d_late_regions, 2, s->stream));
         }
         if (!tabs[q].any) continue;
         a.window = tabs[q].d;
@@ -1098,14 +1123,16 @@ int do_stage(apk_sim *s, int stage) {
     }
   }
   if (s->fmft && stage == s->nstages) SIM_TRY(s, turbulence_driving(s, s->dt));
+  static const bool no_copy_c2p = std::getenv("APK_NO_COPY_C2P") != nullptr;  // A/B switch
+  const bool c2p_in_copy = fused_fill && ghost_c2p_fusable(s) && !no_copy_c2p;
   if (fused_fill && can_overlap_next(s, stage < s->nstages ? stage + 1 : 1)) {
     // post the messages and leave them in flight: the next stage (of this or of the next cycle)
     // completes the exchange
-    SIM_TRY(s, exchange_begin(s, true));
+    SIM_TRY(s, exchange_begin(s, true, c2p_in_copy));
   } else {
-    SIM_TRY(s, exchange_ghosts(s));
+    SIM_TRY(s, exchange_ghosts(s, c2p_in_copy));
     if (fused_fill) {
-      SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
+      if (!c2p_in_copy) SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
     } else {
       SIM_TRY(s, fill_derived(s));
     }

@@ -118,6 +118,7 @@ struct apk_sim {
   // face with a remote neighbour, completes the exchange, then does the thin slabs and the rest.
   bool overlap = true;
   bool exchange_pending = false;
+  bool pending_c2p = false;  // the exchange in flight converts ghost zones as it fills them
   int pending_cons = 0;  // cons buffer whose ghost zones the exchange in flight fills (roles may swap meanwhile)
   // device window tables (apk_stage_args.window, 8 ints per block) of the split stages:
   // x1 sweep: main / low slab / high slab; 3-D donor-cell stage: main / z lo,hi / y lo,hi / x lo,hi

@@ -397,6 +397,47 @@ copy_regions_kernel(const apk_copy_region *regions) {
   }
 }
 
+// The same copy with ConservedToPrimitive of every destination cell fused in (ghost-zone fills:
+// same-rank copies, message unpacking, physical boundaries): the thread that moves the nvar values
+// of a cell already holds its conserved state, so the primitives go out with it -- prim lives at
+// dst + prim_delta -- and the separate ghost ConsToPrim pass (one more read of cons) disappears.
+// Only used when no floor / ceiling is active (they would write cons back, and a later boundary
+// phase would read the floored instead of the copied value; the unfused order is kept for that).
+template <int FLUID>
+__global__ void __launch_bounds__(256)
+copy_regions_c2p_kernel(const apk_copy_region *regions, apk_eos eos, unsigned *flags, int64_t prim_delta) {
+  constexpr int NV = nvars<FLUID>();
+  const apk_copy_region r = regions[blockIdx.y];
+  const int64_t plane = (int64_t)r.ext[0] * r.ext[1];
+  const int64_t cells = plane * r.ext[2];
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < cells;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(t / plane);
+    const int64_t rem = t - (int64_t)k * plane;
+    const int j = (int)(rem / r.ext[0]);
+    const int i = (int)(rem - (int64_t)j * r.ext[0]);
+    const int64_t so = i * r.src_stride[0] + j * r.src_stride[1] + k * r.src_stride[2];
+    const int64_t dof = i * r.dst_stride[0] + j * r.dst_stride[1] + k * r.dst_stride[2];
+    double u[NV], w[NV], di;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const double x = r.src[so + v * r.src_stride[3]];
+      u[v] = (v == r.flip_var) ? -x : x;
+      r.dst[dof + v * r.dst_stride[3]] = u[v];
+    }
+    const unsigned fl = cons_to_prim_cell<FLUID>(eos, u, w, di);
+    if (fl && flags) atomicOr(flags, fl);
+    double *p = r.dst + prim_delta + dof;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) p[v * r.dst_stride[3]] = w[v];
+    for (int v = NV; v < r.nvar; ++v) {  // passive scalars
+      const double x = r.src[so + v * r.src_stride[3]];
+      r.dst[dof + v * r.dst_stride[3]] = x;
+      p[v * r.dst_stride[3]] = x * di;
+    }
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -492,7 +533,8 @@ int launch_fofc_fix(const PackView &u0, int fluid, double gamma, double c_h,
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }
 
-int launch_copy_regions(const apk_copy_region *d_regions, int n, int64_t max_cells, hipStream_t s) {
+int launch_copy_regions(const apk_copy_region *d_regions, int n, int64_t max_cells, hipStream_t s, int c2p_fluid,
+                        const apk_eos *eos, unsigned *d_flags, int64_t prim_delta) {
   if (n <= 0) return APK_OK;
   int gx = (int)((max_cells + 255) / 256);
   if (gx < 1) gx = 1;
@@ -500,7 +542,14 @@ int launch_copy_regions(const apk_copy_region *d_regions, int n, int64_t max_cel
   // gridDim.y is limited to 65535
   for (int off = 0; off < n; off += 65535) {
     const int m = (n - off > 65535) ? 65535 : (n - off);
-    hipLaunchKernelGGL(copy_regions_kernel, dim3(gx, m, 1), dim3(256), 0, s, d_regions + off);
+    if (c2p_fluid == APK_FLUID_EULER)
+      hipLaunchKernelGGL(copy_regions_c2p_kernel<APK_FLUID_EULER>, dim3(gx, m, 1), dim3(256), 0, s, d_regions + off, *eos,
+                         d_flags, prim_delta);
+    else if (c2p_fluid == APK_FLUID_GLMMHD)
+      hipLaunchKernelGGL(copy_regions_c2p_kernel<APK_FLUID_GLMMHD>, dim3(gx, m, 1), dim3(256), 0, s, d_regions + off, *eos,
+                         d_flags, prim_delta);
+    else
+      hipLaunchKernelGGL(copy_regions_kernel, dim3(gx, m, 1), dim3(256), 0, s, d_regions + off);
   }
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }

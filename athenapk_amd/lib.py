@@ -164,6 +164,7 @@ def _signatures():
         "apk_copy_plan_create": (i, [vp, C.POINTER(CopyRegion), i, pp]),
         "apk_copy_plan_destroy": (None, [vp]),
         "apk_copy_plan_run": (i, [vp, vp, vp]),
+        "apk_copy_plan_run_c2p": (i, [vp, vp, i, E, C.c_int64, i, vp]),
         "apk_kernel_timing_enable": (i, [vp, i]),
         "apk_kernel_timing_read": (i, [vp, i, c_dp, C.POINTER(ll)]),
         # apk_host.h

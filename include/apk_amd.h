@@ -253,6 +253,16 @@ int apk_copy_plan_create(apk_ctx *ctx, const apk_copy_region *regions, int n,
                          apk_copy_plan **out);
 void apk_copy_plan_destroy(apk_copy_plan *plan);
 int apk_copy_plan_run(apk_ctx *ctx, const apk_copy_plan *plan, apk_stream_t stream);
+/* The same copy for plans whose destinations are ghost zones of cons arrays, with
+ * ConservedToPrimitive of every destination cell fused in: the primitives are written at
+ * dst + prim_delta (in doubles; the distance from a block's cons array to its prim array, the
+ * same for all regions of the plan).  Saves the separate ghost-zone ConsToPrim pass.  Refused
+ * (APK_ERR_UNSUPPORTED) when a floor or ceiling of the EOS is active: those write cons back and
+ * must keep acting after all boundary phases, as in the reference.  latch_flags = 0 keeps the
+ * negative-density / -pressure flags quiet: a physical-boundary phase that is followed by
+ * another one copies corner cells whose sources are only filled by that later phase. */
+int apk_copy_plan_run_c2p(apk_ctx *ctx, const apk_copy_plan *plan, int fluid, const apk_eos *eos,
+                          int64_t prim_delta, int latch_flags, apk_stream_t stream);
 
 /* ---- few-modes turbulence driver (BASELINE config 4 forcing; "next" row of SURVEY 8(f)) -------
  * The device side of turbulence::Driving (src/pgen/turbulence.cpp:373-482), which AthenaPK
