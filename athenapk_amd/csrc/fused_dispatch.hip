@@ -28,8 +28,8 @@ int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
   sp.window_rows = a.window_rows;
   if (a.fill_derived) {
     // in-place prim replacement is only safe when the finishing sweep is a march (x2/x3) and
-    // the extended Dedner source does not read neighbouring primitives
-    if (u0.ndim == 1 || a.dedner == 2) return APK_ERR_UNSUPPORTED;
+    // the extended Dedner source does not read neighbouring primitives (out of place it may)
+    if (u0.ndim == 1 || (a.dedner == 2 && a.fill_derived != 2)) return APK_ERR_UNSUPPORTED;
     extra = a.estimate_dt ? EXTRA_C2P_DT : EXTRA_C2P;
   } else if (a.estimate_dt) {
     return APK_ERR_INVALID;

@@ -1058,14 +1058,15 @@ int do_stage(apk_sim *s, int stage) {
     // (not when the turbulence driver kicks the state after this stage)
     // nor in a 3-D donor-cell stage (the VL2 predictor): its single-march kernel leaves prim
     // untouched and the full ConservedToPrimitive pass is cheaper than the du round trip it avoids
-    fused_fill = (s->mesh.ndim >= 2) && a.dedner != 2 && !(s->fmft && stage == s->nstages);
+    fused_fill = (s->mesh.ndim >= 2) && !(s->fmft && stage == s->nstages);
     // A 3-D donor-cell stage (the VL2 predictor) runs as ONE march whose lanes read their
     // neighbours' primitives from memory, so it cannot replace prim in place: it writes the new
     // primitives into the spare buffer ("u1.prim") and the two prim buffers swap roles.
     static const int dc_mode = std::getenv("APK_DC_MODE") ? std::atoi(std::getenv("APK_DC_MODE")) : 2;  // A/B switch
     const bool dc3 = cfg.recon == APK_RC_DC && s->mesh.ndim == 3 && dc_mode != 0;
     bool swap_prim = false;
-    if (dc3 && fused_fill && dc_mode == 2) {
+    if (fused_fill && ((dc3 && dc_mode == 2) || a.dedner == 2)) {
+      // (the extended Dedner source reads neighbouring primitives as well: out of place, too)
       SIM_TRY(s, ensure_spare_prim(s));
       swap_prim = true;
     } else if (dc3) {

@@ -151,7 +151,7 @@ typedef struct apk_stage_args {
    *                    (Update::FillDerived, hydro_driver.cpp:571-577).  The caller then only
    *                    needs apk_cons_to_prim_ghosts() after the ghost exchange.  Not in 1-D,
    *                    not with dedner == 2 (APK_ERR_UNSUPPORTED).
-   *  fill_derived = 2: the same, but the new primitives are written into u1's prim arrays
+   *  fill_derived = 2: the same (dedner == 2 allowed), but the new primitives are written into u1's prim arrays
    *                    ("u1.prim", which AthenaPK also carries: hydro_driver.cpp:484-493) and
    *                    u0's are left untouched; the caller swaps the roles of the two prim
    *                    arrays afterwards.  This is what lets a 3-D donor-cell stage (the VL2

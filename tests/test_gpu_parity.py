@@ -374,6 +374,7 @@ def test_fused_stage_fill_derived_and_dt(request, oracle, fluid, recon, riemann,
                                                          ("euler", "dc", "hllc", (66, 10, 6), 0.0),
                                                          ("euler", "dc", "hlle", (64, 8, 8), 0.0),
                                                          ("glmmhd", "ppm", "hlld", (70, 9, 7), 0.0),
+                                                         ("glmmhd", "plm", "hlld", (66, 9, 8), -2.0),
                                                          ("euler", "plm", "hllc", (64, 34, 36), 0.5),
                                                          ("euler", "plm", "hllc", (66, 10, 1), 0.5)])
 def test_fused_stage_fill_derived_out_of_place(request, oracle, fluid, recon, riemann, nx, gam0, strict):
@@ -385,8 +386,10 @@ def test_fused_stage_fill_derived_out_of_place(request, oracle, fluid, recon, ri
     ctx = _ctx(request, strict)
     ng, prim, g = _case(fluid, recon, nx, kind="smooth", seed=43)
     cons = H.prim_to_cons(fluid, prim, GAMMA)
-    u1c = cons * 1.01 if gam0 != 0.0 else cons
     ded = 1 if fluid == "glmmhd" else 0
+    if gam0 < 0.0:   # marker: extended Dedner source (reads neighbouring primitives), gam0 = 0
+        ded, gam0 = 2, 0.0
+    u1c = cons * 1.01 if gam0 != 0.0 else cons
     eos_kw = dict(pfloor=1e-6, dfloor=1e-6)
     sentinel = np.full_like(prim, -7.0)
     m0 = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=prim.shape[0], cons=cons, prim=prim,
