@@ -72,6 +72,8 @@ struct apk_ctx {
   void *h_pinned = nullptr;          // 256 B pinned host staging
   double *d_du = nullptr;            // fused path: flux-difference accumulator
   size_t du_cap = 0;                 // in doubles
+  double *d_mflux = nullptr;         // fused path with passive scalars: mass flux per face, [3][nblocks][sn]
+  size_t mflux_cap = 0;
   // optional kernel timing (apk_kernel_timing_*)
   bool timing_on = false;
   struct TimedSpan {

@@ -122,6 +122,7 @@ void apk_destroy(apk_ctx *ctx) {
   if (!ctx) return;
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   if (ctx->d_u64) (void)hipFree(ctx->d_u64);
+  if (ctx->d_mflux) (void)hipFree(ctx->d_mflux);
   if (ctx->d_partial) (void)hipFree(ctx->d_partial);
   if (ctx->d_mark) (void)hipFree(ctx->d_mark);
   if (ctx->d_du) (void)hipFree(ctx->d_du);

@@ -6,8 +6,23 @@ namespace apk {
 
 int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
                        const apk_stage_args &a, double dedner_coeff, hipStream_t s) {
-  if (u0.nvar != u0.nhydro) return APK_ERR_UNSUPPORTED;  // passive scalars: flux-array path
   StageParams sp;
+  sp.mflux = nullptr;
+  if (u0.nvar != u0.nhydro) {
+    // passive scalars: the sweeps leave the mass fluxes in a workspace of the handle
+    const size_t need = 3 * (size_t)u0.nblocks * (size_t)u0.sn;
+    if (need > ctx->mflux_cap) {
+      if (ctx->d_mflux) {
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(ctx->d_mflux);
+      }
+      ctx->d_mflux = nullptr;
+      ctx->mflux_cap = 0;
+      if (hipMalloc(&ctx->d_mflux, need * sizeof(double)) != hipSuccess) return APK_ERR_DEVICE;
+      ctx->mflux_cap = need;
+    }
+    sp.mflux = ctx->d_mflux;
+  }
   sp.gamma = a.eos.gamma;
   sp.c_h = a.c_h;
   sp.gam0 = a.gam0;

@@ -38,11 +38,33 @@ struct StageParams {
   int prim_to_u1;                // fill_derived = 2: the new primitives go to u1's prim arrays
   // optional per-block index window (apk_stage_args.window): {i0, rl, ilo, ihi, jlo, jhi, klo, khi}:
   // rows are flattened with length rl starting at column i0 and only cells ilo..ihi retire
+  // passive scalars: the sweeps store the mass flux through both faces of every cell they retire,
+  // mflux[(d * nblocks + b) * sn + cell] = flux through the lower d-face of `cell`; NULL without scalars
+  double *mflux;
   const int *window;
   int window_rl, window_rows;  // largest rl / row count in `window` (size the grid)
   int phase;                   // apk_stage_args.phase
   apk_ctx *ctx;  // host side only (kernel timing); never dereferenced on the device
 };
+
+// L / R state at the lower `st`-face of the cell c points at (L = ql of the cell below, R = qr of
+// this cell), any reconstruction
+template <int RECON>
+APK_DEV void face_states_any(const double *c, int64_t st, double dx, int var, double &wl, double &wr) {
+  double dummy;
+  if constexpr (RECON == APK_RC_DC) {
+    wl = c[-st];
+    wr = c[0];
+  } else if constexpr (RECON == APK_RC_PPM || RECON == APK_RC_WENOZ) {
+    const double qm3 = c[-3 * st], qm2 = c[-2 * st], qm1 = c[-st], q0 = c[0], qp1 = c[st], qp2 = c[2 * st];
+    reconstruct<RECON>(qm3, qm2, qm1, q0, qp1, dx, var, wl, dummy);
+    reconstruct<RECON>(qm2, qm1, q0, qp1, qp2, dx, var, dummy, wr);
+  } else {
+    const double qm2 = c[-2 * st], qm1 = c[-st], q0 = c[0], qp1 = c[st];
+    reconstruct<RECON>(0.0, qm2, qm1, q0, 0.0, dx, var, wl, dummy);
+    reconstruct<RECON>(0.0, qm1, q0, qp1, 0.0, dx, var, dummy, wr);
+  }
+}
 
 // what the finishing sweep does besides the RK update + Dedner source
 enum { EXTRA_NONE = 0, EXTRA_C2P = 1, EXTRA_C2P_DT = 2 };
@@ -190,14 +212,20 @@ fused_x1_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_plane) {
 
   // cell i needs F(i) (own) and F(i+1) (lane on the right)
   const double a1 = b0.dx[1] * b0.dx[2];
-  double du[NV];
+  double du[NV], fup0 = 0.0;
 #pragma unroll
   for (int s = 0; s < NV; ++s) {
     const double fup = wave_shl1(f[s]);
+    if (s == 0) fup0 = fup;
     du[perm<1>(s)] = (a1 * fup - a1 * f[s]);
   }
   const bool do_cell = in_run && (lane >= 1) && (lane <= 62) && (i >= lo) && (i <= hi);
   if (!do_cell) return;
+  if (sp.mflux) {  // mass flux through both x1 faces of this cell (neighbours store the same values)
+    double *m = sp.mflux + ((int64_t)0 * u0.nblocks + b) * u0.sn + cell;
+    m[0] = f[0];
+    m[1] = fup0;
+  }
   if constexpr (FINAL) {
     const double vol = b0.dx[0] * b0.dx[1] * b0.dx[2];
     double unused_dt = 0.0;
@@ -356,6 +384,11 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
           const int n = perm<DIR>(q);
           du[n] = duv[n] + (area * f[q] - area * f_prev[q]);
         }
+        if (active && sp.mflux) {
+          double *m = sp.mflux + ((int64_t)(DIR - 1) * u0.nblocks + b) * u0.sn + cell;
+          m[0] = f_prev[0];
+          m[st] = f[0];
+        }
         if (active) {
           if constexpr (FINAL) {
             finish_cell<FLUID, EXTRA>(u0, b0, u1v, cell, du, vol, sp, lane_min_dt, prim_dst);
@@ -479,6 +512,11 @@ fused_march12_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_blo
           const int n = perm<2>(q);
           dscratch[n * u0.sn + cell] = du1_prev[n] + (area2 * f[q] - area2 * f_prev[q]);
         }
+        if (sp.mflux) {
+          double *m = sp.mflux + ((int64_t)1 * u0.nblocks + b) * u0.sn + cell;
+          m[0] = f_prev[0];
+          m[st] = f[0];
+        }
       }
 #pragma unroll
       for (int q = 0; q < NV; ++q) f_prev[q] = f[q];
@@ -513,10 +551,17 @@ fused_march12_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_blo
         wr[q] = qr1[perm<1>(q)];
       }
       riemann<FLUID, RS>(wl, wr, sp.gamma, sp.c_h, f);
+      double fup0 = 0.0;
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         const double fup = wave_shl1(f[q]);
+        if (q == 0) fup0 = fup;
         du1_prev[perm<1>(q)] = (area1 * fup - area1 * f[q]);
+      }
+      if (sp.mflux && active) {
+        double *m = sp.mflux + ((int64_t)0 * u0.nblocks + b) * u0.sn + base + (int64_t)c * st;
+        m[0] = f[0];
+        m[1] = fup0;
       }
     }
   }
@@ -620,6 +665,11 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
         }
 #pragma unroll
         for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
+        if (active && sp.mflux) {
+          double *m = sp.mflux + ((int64_t)2 * u0.nblocks + b) * u0.sn + done;
+          m[0] = st_f3[0];
+          m[u0.sk] = f3[0];
+        }
         if (active) finish_cell<FLUID, EXTRA>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst);
       }
 #pragma unroll
@@ -637,10 +687,17 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
           wl[q] = wave_shr1(wr[q]);
         }
         riemann<FLUID, RS>(wl, wr, sp.gamma, sp.c_h, f);
+        double fup0 = 0.0;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
           const double fup = wave_shl1(f[q]);
+          if (q == 0) fup0 = fup;
           d1[q] = (area1 * fup - area1 * f[q]);
+        }
+        if (active && sp.mflux) {
+          double *m = sp.mflux + ((int64_t)0 * u0.nblocks + b) * u0.sn + col + off;
+          m[0] = f[0];
+          m[1] = fup0;
         }
 #pragma unroll
         for (int q = 0; q < NV; ++q) st_du[perm<1>(q) * 64] = d1[q];
@@ -669,6 +726,11 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
           const int n = perm<2>(q);
           st_du[n * 64] = st_du[n * 64] + (area2 * fhi[q] - area2 * flo[q]);
         }
+        if (active && sp.mflux) {
+          double *m = sp.mflux + ((int64_t)1 * u0.nblocks + b) * u0.sn + col + off;
+          m[0] = flo[0];
+          m[u0.sj] = fhi[0];
+        }
       }
     }
   }
@@ -678,6 +740,71 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
     for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_down(m, off, 64));
     if (lane == 0) atomicMin(sp.dt_bits, (unsigned long long)__double_as_longlong(m));
   }
+}
+
+// ==============================================================================================
+// Passive scalars of the fused path.  The sweeps above leave the mass flux through every face in
+// sp.mflux; a scalar's flux is that mass flux times the upwind reconstructed concentration
+// (src/hydro/hydro.cpp:1088-1097,1134-1143,1182-1191), so its whole update is one light kernel:
+// per cell and scalar the six face values, the flux difference in the reference's order and the
+// RK update.  Reads old prim (stencil), writes cons only; the new concentrations (prim) are
+// written by a second kernel once every cell has been updated.
+// ==============================================================================================
+template <int RECON>
+__global__ void __launch_bounds__(256)
+fused_scalar_update_kernel(PackView u0, PackView u1, StageParams sp) {
+  const int i = u0.is + blockIdx.x * 64 + threadIdx.x;
+  const int j = u0.js + blockIdx.y * 4 + threadIdx.y;
+  const int b = blockIdx.z / u0.nx3;
+  const int k = u0.ks + blockIdx.z % u0.nx3;
+  if (i > u0.ie || j > u0.je) return;
+  const apk_block_desc b0 = u0.blocks[b];
+  const double *c1 = u1.blocks[b].cons;
+  const int64_t cell = k * u0.sk + (int64_t)j * u0.sj + i;
+  const double area[3] = {b0.dx[1] * b0.dx[2], b0.dx[0] * b0.dx[2], b0.dx[0] * b0.dx[1]};
+  const double vol = b0.dx[0] * b0.dx[1] * b0.dx[2];
+  const int64_t st[3] = {1, u0.sj, u0.sk};
+  for (int n = u0.nhydro; n < u0.nvar; ++n) {
+    const double *p = b0.prim + n * u0.sn + cell;
+    double du = 0.0;
+    for (int d = 0; d < u0.ndim; ++d) {
+      const double *m = sp.mflux + ((int64_t)d * u0.nblocks + b) * u0.sn + cell;
+      double sl, sr;
+      face_states_any<RECON>(p, st[d], b0.dx[d], n, sl, sr);
+      const double flo = (m[0] >= 0.0) ? m[0] * sl : m[0] * sr;
+      face_states_any<RECON>(p + st[d], st[d], b0.dx[d], n, sl, sr);
+      const double fhi = (m[st[d]] >= 0.0) ? m[st[d]] * sl : m[st[d]] * sr;
+      if (d == 0) du = (area[0] * fhi - area[0] * flo);
+      else du += (area[d] * fhi - area[d] * flo);
+    }
+    const int64_t idx = n * u0.sn + cell;
+    const double old = (sp.gam0 != 0.0) ? b0.cons[idx] : 0.0;
+    b0.cons[idx] = sp.gam0 * old + sp.gam1 * c1[idx] + sp.beta_dt * (-du / vol);
+  }
+}
+
+// prim(scalar) = cons(scalar) / rho of the updated interior (adiabatic_hydro.hpp:139-141)
+// (a template only so that the header can be included from several translation units)
+template <int RECON>
+__global__ void __launch_bounds__(256)
+fused_scalar_prim_kernel(PackView u0, PackView u1, int to_u1) {
+  const int i = u0.is + blockIdx.x * 64 + threadIdx.x;
+  const int j = u0.js + blockIdx.y * 4 + threadIdx.y;
+  const int b = blockIdx.z / u0.nx3;
+  const int k = u0.ks + blockIdx.z % u0.nx3;
+  if (i > u0.ie || j > u0.je) return;
+  const apk_block_desc b0 = u0.blocks[b];
+  double *prim = to_u1 ? u1.blocks[b].prim : b0.prim;
+  const int64_t cell = k * u0.sk + (int64_t)j * u0.sj + i;
+  const double di = 1.0 / b0.cons[IDN * u0.sn + cell];
+  for (int n = u0.nhydro; n < u0.nvar; ++n) prim[n * u0.sn + cell] = b0.cons[n * u0.sn + cell] * di;
+}
+
+template <int RECON>
+inline void launch_scalar_update(const PackView &u0, const PackView &u1, const StageParams &sp, int extra, hipStream_t s) {
+  const dim3 grid((u0.nx1 + 63) / 64, (u0.nx2 + 3) / 4, u0.nx3 * u0.nblocks), block(64, 4, 1);
+  hipLaunchKernelGGL((fused_scalar_update_kernel<RECON>), grid, block, 0, s, u0, u1, sp);
+  if (extra != EXTRA_NONE) hipLaunchKernelGGL((fused_scalar_prim_kernel<RECON>), grid, block, 0, s, u0, u1, sp.prim_to_u1);
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------
@@ -732,7 +859,10 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
     if (u0.ndim == 1) return APK_ERR_UNSUPPORTED;
     if (RECON == APK_RC_DC && u0.ndim == 3) {
       if (!(extra == EXTRA_NONE || (sp.prim_to_u1 && extra == EXTRA_C2P))) return APK_ERR_UNSUPPORTED;
-      if (sp.phase == 2) return APK_OK;  // everything happened in phase 1
+      if (sp.phase == 2) {  // the cells were all retired in phase 1; only the scalars are left
+        if (sp.mflux) launch_scalar_update<RECON>(u0, u1, sp, extra, s);
+        return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
+      }
     }
   }
   const bool do_x1 = sp.phase != 2, do_rest = sp.phase != 1;
@@ -761,6 +891,7 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
           hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_C2P>), g, dim3(64), lds3, s, u0, u1, sp, kseg, wpb, nseg, per_xcd);
         else
           hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_NONE>), g, dim3(64), lds3, s, u0, u1, sp, kseg, wpb, nseg, per_xcd);
+        if (sp.mflux && sp.phase == 0) launch_scalar_update<RECON>(u0, u1, sp, extra, s);
         return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
       }
       // (with FillDerived fused into the stage) donor cell: the sweeps are HBM-bound, so x1 and x2 share ONE march over (k,i)-flattened
@@ -806,6 +937,7 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
       launch_final_march<FLUID, RECON, RS, 2>(u0, u1, sp, extra, g2, lds, s);
     }
   }
+  if (sp.mflux && do_rest) launch_scalar_update<RECON>(u0, u1, sp, extra, s);
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }
 

@@ -709,8 +709,8 @@ int ensure_flux_arrays(apk_sim *s) {
 }
 
 bool stage_can_fuse(const apk_sim *s) {
-  return s->fused && !s->pkg.first_order_flux_correct && s->pkg.nscalars == 0 &&
-         s->pkg.riemann != APK_RS_NONE && s->pkg.riemann != APK_RS_LLF;
+  return s->fused && !s->pkg.first_order_flux_correct && s->pkg.riemann != APK_RS_NONE &&
+         s->pkg.riemann != APK_RS_LLF;
 }
 
 double *region_base(apk_sim *s, int parity, int kind, int block) {

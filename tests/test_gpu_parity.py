@@ -597,3 +597,42 @@ def test_turbulence_perturb_and_history(request, oracle, strict):
         got = hydro.TurbulenceHst(md, fluid, GAMMA)
         want = H.orc_turb_history(fluid, g, prim, GAMMA)
         np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-15)
+
+
+# ---- passive scalars through the fused stage ---------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("fill", [0, 1, 2], ids=["nofill", "inplace", "outofplace"])
+@pytest.mark.parametrize("fluid,recon,riemann,nx", [("glmmhd", "ppm", "hlld", (70, 9, 7)),
+                                                    ("euler", "plm", "hllc", (66, 10, 1)),
+                                                    ("glmmhd", "dc", "hlld", (64, 8, 18)),
+                                                    ("euler", "wenoz", "hlle", (40, 1, 1)),
+                                                    ("euler", "limo3", "hllc", (16, 16, 16))])
+def test_fused_stage_with_passive_scalars(request, oracle, fluid, recon, riemann, nx, fill, strict):
+    """nscalars = 2 through apk_stage_fused: the sweeps leave the mass fluxes behind and one light
+    kernel upwinds the reconstructed concentrations (hydro.cpp:1088-1097) and updates the scalar
+    densities; equal to CalculateFluxes + UpdateWithFluxDivergence + DednerSource (+ ConsToPrim)."""
+    from athenapk_amd import hydro, lib as L
+    ctx = _ctx(request, strict)
+    ndim = sum(1 for n in nx if n > 1)
+    if fill and ndim == 1:
+        pytest.skip("FillDerived is not fused in 1-D")
+    ng, prim, g = _case(fluid, recon, nx, kind="smooth", nscalars=2, seed=61)
+    cons = H.prim_to_cons(fluid, prim, GAMMA)
+    u1c = cons * 1.02
+    ded = 1 if fluid == "glmmhd" else 0
+    eos_kw = dict(pfloor=1e-6, dfloor=1e-6)
+    nh = NHYDRO[fluid]
+    m0 = hydro.MeshData(ctx, nx, ng, nh, nscalars=2, dx=tuple(g.dx), nblocks=prim.shape[0], cons=cons, prim=prim,
+                        with_flux=False)
+    m1 = hydro.MeshData(ctx, nx, ng, nh, nscalars=2, dx=tuple(g.dx), nblocks=prim.shape[0], cons=u1c,
+                        prim=np.full_like(prim, -7.0), with_flux=False)
+    hydro.StageFused(m0, m1, fluid, recon, riemann, L.make_eos(GAMMA, **eos_kw), C_H, 0.5, 0.5, 0.004, dedner=ded,
+                     glmmhd_alpha=0.1, mindx=0.07, fill_derived=fill)
+    want = H.orc_stage(fluid, recon, riemann, g, cons, u1c, prim, GAMMA, C_H, 0.5, 0.5, 0.004, dedner=ded, alpha=0.1,
+                       mindx=0.07)
+    _cmp(H.interior(m0.cons_host(), nx, ng), H.interior(want, nx, ng), strict, "cons incl. scalar densities")
+    if fill:
+        _, want_prim, _ = H.orc_c2p(fluid, g, want, oracle.make_eos(GAMMA, **eos_kw))
+        got = (m1 if fill == 2 else m0).prim_host()
+        _cmp(H.interior(got, nx, ng), H.interior(want_prim, nx, ng), strict, "prim incl. concentrations")
