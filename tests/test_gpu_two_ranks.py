@@ -40,6 +40,13 @@ CASES = {
                             "parthenon/time/integrator=rk3", "hydro/reconstruction=wenoz"],
                            dict(fluid="glmmhd", recon="wenoz", riemann="hlld", integrator="rk3", nx=(32, 32, 16),
                                 mb=(16, 16, 8), ng=3, cfl=0.3, gamma=1.666666666666667), "synthetic", {}, 3),
+    # passive scalars ride the fused stages (mass-flux workspace + scalar kernels), also when split
+    "mhd_scalars_vl2": ("synthetic_mhd",
+                        ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=32",
+                         "parthenon/meshblock/nx1=16", "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=16",
+                         "hydro/nscalars=2"],
+                        dict(fluid="glmmhd", recon="ppm", riemann="hlld", integrator="vl2", nx=(32, 32, 32),
+                             mb=(16, 16, 16), ng=3, cfl=0.3, gamma=1.666666666666667, nscalars=2), "synthetic", {}, 3),
     # 2-D: the donor-cell predictor has no single-kernel form there, so only the exchange before the
     # high-order stage is overlapped
     "ot_2d": ("orszag_tang",
