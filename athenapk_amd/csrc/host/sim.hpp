@@ -130,6 +130,7 @@ struct apk_sim {
   WindowTable x1win[3], dcwin[7];
   unsigned *d_late_regions = nullptr;  // per block: bit (sx+1)+3(sy+1)+9(sz+1) = that neighbour region is filled late
   long long overlapped = 0;
+  int perf_cycles = 0;        // cycles inside loop_seconds (after parthenon/time/perf_cycle_offset)
   double loop_seconds = 0.0;  // wall time of the last apk_sim_execute main loop (device synchronised)
   std::string err;
 };

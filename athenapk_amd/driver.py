@@ -228,6 +228,10 @@ class Simulation(_FmftHost):
         return self.lib.apk_sim_loop_seconds(self.h)
 
     @property
+    def loop_cycles(self):
+        return self.lib.apk_sim_loop_cycles(self.h)
+
+    @property
     def overlapped_exchanges(self):
         return self.lib.apk_sim_overlapped_exchanges(self.h)
 

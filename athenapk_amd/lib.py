@@ -186,6 +186,7 @@ def _signatures():
         "apk_sim_set_overlap": (i, [vp, i]),
         "apk_sim_overlapped_exchanges": (ll, [vp]),
         "apk_sim_loop_seconds": (d, [vp]),
+        "apk_sim_loop_cycles": (i, [vp]),
         "apk_sim_get_info": (i, [vp, C.POINTER(SimInfo)]),
         "apk_sim_block_location": (i, [vp, i, C.POINTER(C.c_int), C.POINTER(C.c_int * 3)]),
         "apk_sim_block_ptr": (vp, [vp, i, i]),

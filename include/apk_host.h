@@ -157,6 +157,8 @@ int apk_sim_execute(apk_sim *sim, const char *outdir, int *ncycles);
 /* wall seconds of the main loop of the last apk_sim_execute (initialisation excluded, device
  * synchronised): zones * cycles / this = Parthenon's "zone-cycles/wallsecond" */
 double apk_sim_loop_seconds(const apk_sim *sim);
+/* cycles covered by apk_sim_loop_seconds: those after parthenon/time/perf_cycle_offset (default 0) */
+int apk_sim_loop_cycles(const apk_sim *sim);
 /* circularly polarised Alfven wave (job/problem_id = cpaw, 3-D): L1 errors against the initial state
  * and their RMS (src/pgen/cpaw.cpp:127-186; err8 = d, M1, M2, M3, E, B1, B2, B3), and the
  * reference's "cpaw-errors.dat" row (cpaw.cpp:188-220). */
