@@ -377,6 +377,18 @@ void pgen_block(apk_sim *s, int lb, std::vector<double> &u) {
     bl[7] = pin.GetOrAddReal("problem/blast", "x2_0", 0.0);
     bl[8] = pin.GetOrAddReal("problem/blast", "x3_0", 0.0);
   }
+  double adv[9] = {0};
+  if (s->problem_id == "advection") {  // src/pgen/advection.cpp:68-79
+    adv[0] = pin.GetOrAddReal("problem/advection", "vx", 0.0);
+    adv[1] = pin.GetOrAddReal("problem/advection", "vy", 0.0);
+    adv[2] = pin.GetOrAddReal("problem/advection", "vz", 0.0);
+    adv[3] = pin.GetOrAddReal("problem/advection", "rho_ratio", 1.0);
+    adv[4] = pin.GetOrAddReal("problem/advection", "rho_radius", 0.0);
+    adv[5] = pin.GetOrAddReal("problem/advection", "rho_fraction_edge", 0.01);
+    adv[6] = pin.GetOrAddReal("problem/advection", "rho0", 1.0);
+    adv[7] = pin.GetOrAddReal("problem/advection", "p0", 1.0);
+    adv[8] = -adv[4] * adv[4] / 2 / std::log(adv[5]);  // sigmasq
+  }
   double lwi[5] = {0};
   if (s->problem_id == "lw_implode") {  // src/pgen/lw_implode.cpp:24-57
     if (mhd) throw std::runtime_error("Only hydro runs are supported for LW implosion problem generator.");
@@ -400,7 +412,17 @@ void pgen_block(apk_sim *s, int lb, std::vector<double> &u) {
     for (int j = m.js; j <= m.je; ++j)
       for (int i = m.is; i <= m.ie; ++i) {
         const double x1 = xc(s, x0, 0, i), x2 = xc(s, x0, 1, j), x3 = xc(s, x0, 2, k);
-        if (s->problem_id == "cpaw") {  // src/pgen/cpaw.cpp:255-300
+        if (s->problem_id == "advection") {  // src/pgen/advection.cpp:91-110
+          double rho = adv[6];
+          const double rsq = x1 * x1 + x2 * x2 + x3 * x3;
+          if (rsq < adv[4] * adv[4]) rho += adv[6] * adv[3] * std::exp(-rsq / 2 / adv[8]);
+          const double mx = rho * adv[0], my = rho * adv[1], mz = rho * adv[2];
+          at(0, k, j, i) = rho;
+          at(1, k, j, i) = mx;
+          at(2, k, j, i) = my;
+          at(3, k, j, i) = mz;
+          at(4, k, j, i) = adv[7] / gm1 + 0.5 * (mx * mx + my * my + mz * mz) / rho;
+        } else if (s->problem_id == "cpaw") {  // src/pgen/cpaw.cpp:255-300
           const CpawState &c = s->cpaw;
           double mom[3], bana[3];
           cpaw_state(c, x1, x2, x3, mom, bana);
@@ -1161,11 +1183,21 @@ int create_common(const char *deck, const char *const *overrides, int noverrides
     mesh_initialize(s);
     if (s->problem_id == "linear_wave") lw_setup(s);
     else if (s->problem_id == "cpaw") cpaw_setup(s);
+    else if (s->problem_id == "advection") {
+      // advection::InitUserMeshData (src/pgen/advection.cpp:34-59): tlim counts box diagonals / |v|
+      const double vx = s->pin.GetOrAddReal("problem/advection", "vx", 0.0), vy = s->pin.GetOrAddReal("problem/advection", "vy", 0.0),
+                   vz = s->pin.GetOrAddReal("problem/advection", "vz", 0.0);
+      const double L[3] = {s->xmax[0] - s->xmin[0], s->xmax[1] - s->xmin[1], s->xmax[2] - s->xmin[2]};
+      const double vmag = std::sqrt(vx * vx + vy * vy + vz * vz) + 1.0e-20;  // TINY_NUMBER
+      const double diag = std::sqrt(L[0] * L[0] + L[1] * L[1] + L[2] * L[2]);
+      s->tlim = diag / vmag * s->tlim;
+    }
     else if (s->problem_id == "lw_implode" && s->pkg.fluid == APK_FLUID_GLMMHD)
       throw std::runtime_error("Only hydro runs are supported for LW implosion problem generator.");
     else if (s->problem_id == "turbulence") turbulence_setup(s);
     else if (s->problem_id != "sod" && s->problem_id != "orszag_tang" && s->problem_id != "synthetic" &&
-             s->problem_id != "blast" && s->problem_id != "lw_implode" && s->problem_id != "cpaw")
+             s->problem_id != "blast" && s->problem_id != "lw_implode" && s->problem_id != "cpaw" &&
+             s->problem_id != "advection")
       throw std::runtime_error("unknown job/problem_id: " + s->problem_id);
   } catch (const std::exception &e) {
     if (errbuf && errlen) std::snprintf(errbuf, errlen, "%s", e.what());

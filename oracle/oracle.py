@@ -105,6 +105,7 @@ def _declare(lib):
         "orc_pgen_linear_wave": (d, [C.c_void_p, i, d, d]),
         "orc_pgen_sod": (None, [C.c_void_p, d, d, d, d, d, d, d]),
         "orc_pgen_orszag_tang": (None, [C.c_void_p]),
+        "orc_pgen_advection": (None, [C.c_void_p, d, d, d, d, d, d, d, d]),
         "orc_pgen_cpaw": (d, [C.c_void_p, d, d, d, d, i, d, d]),
         "orc_cpaw_errors": (d, [C.c_void_p, p]),
         "orc_pgen_lw_implode": (None, [C.c_void_p, d, d, d, d]),
@@ -272,6 +273,10 @@ class Sim:
             self.lib.orc_pgen_orszag_tang(self.h)
         elif name == "synthetic":
             self.lib.orc_pgen_synthetic(self.h)
+        elif name == "advection":
+            self.lib.orc_pgen_advection(self.h, kw.get("vx", 0.0), kw.get("vy", 0.0), kw.get("vz", 0.0),
+                                        kw.get("rho_ratio", 1.0), kw.get("rho_radius", 0.0),
+                                        kw.get("rho_fraction_edge", 0.01), kw.get("rho0", 1.0), kw.get("p0", 1.0))
         elif name == "cpaw":
             self.cpaw_lambda = self.lib.orc_pgen_cpaw(self.h, kw.get("b_par", 1.0), kw.get("b_perp", 0.1),
                                                       kw.get("pres", 0.1), kw.get("v_par", 0.0), kw.get("dir", 1),

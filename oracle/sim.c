@@ -610,6 +610,34 @@ void orc_pgen_blast(orc_sim *s, double rout, double rin, double pa, double da, d
   }
 }
 
+/* src/pgen/advection.cpp:64-115 (smooth density blob advected with a uniform flow); the caller
+ * reinterprets tlim as box diagonals / |v| like InitUserMeshData (:34-59) */
+void orc_pgen_advection(orc_sim *s, double vx, double vy, double vz, double rho_ratio, double rho_radius,
+                        double rho_fraction_edge, double rho0, double p0) {
+  const sb_t bb = sim_bounds(&s->g);
+  const double gm1 = s->p.eos.gamma - 1.0;
+  const double sigmasq = -rho_radius * rho_radius / 2 / log(rho_fraction_edge);
+  for (int b = 0; b < s->nblocks; ++b) {
+    double x0[3];
+    orc_sim_block_origin(s, b, x0);
+    double *u = s->cons[b];
+    for (int k = bb.ks; k <= bb.ke; ++k)
+      for (int j = bb.js; j <= bb.je; ++j)
+        for (int i = bb.is; i <= bb.ie; ++i) {
+          const double x = xc(s, x0, 0, i), y = xc(s, x0, 1, j), z = xc(s, x0, 2, k);
+          double rho = rho0;
+          const double rsq = x * x + y * y + z * z;
+          if (rsq < rho_radius * rho_radius) rho += rho0 * rho_ratio * exp(-rsq / 2 / sigmasq);
+          const double mx = rho * vx, my = rho * vy, mz = rho * vz;
+          SAT(u, ORC_IDN, k, j, i) = rho;
+          SAT(u, ORC_IM1, k, j, i) = mx;
+          SAT(u, ORC_IM2, k, j, i) = my;
+          SAT(u, ORC_IM3, k, j, i) = mz;
+          SAT(u, ORC_IEN, k, j, i) = p0 / gm1 + 0.5 * (mx * mx + my * my + mz * mz) / rho;
+        }
+  }
+}
+
 /* src/pgen/lw_implode.cpp:24-75 (Liska-Wendroff implosion; hydro only).  The diagonal offset y0 is
  * adjusted per meshblock exactly as the reference's loop over the block's own rows does. */
 void orc_pgen_lw_implode(orc_sim *s, double d_in, double p_in, double d_out, double p_out) {

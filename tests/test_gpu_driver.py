@@ -526,3 +526,28 @@ def test_passive_scalars_fused_driver_matches_oracle(oracle, integrator, recon):
     got = s.gather("cons")
     assert np.array_equal(got, o.gather_cons())
     assert np.allclose(got[9:].sum(axis=(1, 2, 3)), c0[9:].sum(axis=(1, 2, 3)), rtol=1e-13)
+
+
+# ---- the reference's advection_3d.in on a uniform grid ----------------------------------------------------------
+@pytest.mark.gpu
+def test_advection_matches_oracle_and_tags_the_blob(oracle):
+    """One crossing of the box diagonal (tlim = 1 -> sqrt(3)/|v|), 8^3 meshblocks, PLM + HLLE VL2:
+    bit for bit against the oracle; mass conserved; the deck's max-density criterion tags the
+    blocks that hold the blob."""
+    s = _sim("advection_3d", [], strict=True).initialize()
+    o = oracle.Sim(fluid="euler", recon="plm", riemann="hlle", integrator="vl2", nx=(32, 32, 32), mb=(8, 8, 8), ng=2,
+                   xmin=(-0.5,) * 3, xmax=(0.5,) * 3, cfl=0.3, gamma=GAMMA_DECK)
+    o.pgen("advection", vx=1.0, vy=1.0, vz=1.0, rho_ratio=1.01, rho_radius=0.0625, rho_fraction_edge=0.01)
+    c0 = s.gather("cons")
+    assert np.array_equal(c0, o.gather_cons())
+    tags0, crit0 = s.check_refinement()
+    assert (tags0 == 1).sum() == 8 and crit0.max() > 1.5      # the blob sits in the 8 central blocks
+    assert s.tlim == pytest.approx(1.0, rel=1e-12)             # sqrt(3) / sqrt(3)
+    assert s.run() == o.run(s.tlim)
+    got = s.gather("cons")
+    assert np.array_equal(got, o.gather_cons())
+    assert abs(got[0].sum() - c0[0].sum()) < 1e-10 * c0[0].sum()
+    tags, crit = s.check_refinement()
+    g = H.geom("euler", (8, 8, 8), 2)
+    want = [oracle.tag("maxdensity", g, o.prim(s.block_gid(lb)[0]), 1.0001, 1.00005) for lb in range(s.info.nblocks_local)]
+    assert list(tags) == [w[0] for w in want] and list(crit) == [w[1] for w in want]
