@@ -1087,8 +1087,10 @@ int do_stage(apk_sim *s, int stage) {
     static const int dc_mode = std::getenv("APK_DC_MODE") ? std::atoi(std::getenv("APK_DC_MODE")) : 2;  // A/B switch
     const bool dc3 = cfg.recon == APK_RC_DC && s->mesh.ndim == 3 && dc_mode != 0;
     bool swap_prim = false;
-    if (fused_fill && ((dc3 && dc_mode == 2) || a.dedner == 2)) {
-      // (the extended Dedner source reads neighbouring primitives as well: out of place, too)
+    if (fused_fill && ((dc3 && dc_mode == 2) || a.dedner == 2 || s->mesh.ndim == 2)) {
+      // (the extended Dedner source reads neighbouring primitives as well: out of place, too; and in
+      // 2-D the finishing x2 march has only nx1/64 waves per block unless it may be cut into
+      // segments, which an in-place ConsToPrim forbids)
       SIM_TRY(s, ensure_spare_prim(s));
       swap_prim = true;
     } else if (dc3) {
