@@ -1087,10 +1087,17 @@ int do_stage(apk_sim *s, int stage) {
     static const int dc_mode = std::getenv("APK_DC_MODE") ? std::atoi(std::getenv("APK_DC_MODE")) : 2;  // A/B switch
     const bool dc3 = cfg.recon == APK_RC_DC && s->mesh.ndim == 3 && dc_mode != 0;
     bool swap_prim = false;
-    if (fused_fill && ((dc3 && dc_mode == 2) || a.dedner == 2 || s->mesh.ndim == 2)) {
-      // (the extended Dedner source reads neighbouring primitives as well: out of place, too; and in
-      // 2-D the finishing x2 march has only nx1/64 waves per block unless it may be cut into
-      // segments, which an in-place ConsToPrim forbids)
+    // waves of the finishing march if it cannot be cut into segments (an in-place ConsToPrim forbids
+    // that): lanes along x1, one wave per transverse row (or 2 / 4 rows for narrow blocks)
+    const Mesh &mm = s->mesh;
+    const int rpw_est = (mm.mb[0] <= 16) ? 4 : ((mm.mb[0] <= 32) ? 2 : 1);
+    const int64_t final_waves = (int64_t)((mm.mb[0] + 64 / rpw_est - 1) / (64 / rpw_est)) *
+                                ((mm.ndim == 3 ? mm.mb[1] : 1) + rpw_est - 1) / rpw_est * (int64_t)mm.local_gids.size();
+    const bool few_waves = mm.ndim >= 2 && final_waves < 2048;
+    if (fused_fill && ((dc3 && dc_mode == 2) || a.dedner == 2 || few_waves)) {
+      // (the extended Dedner source reads neighbouring primitives as well: out of place, too; and a
+      // finishing march with too few waves to fill the GPU -- 2-D meshes, small packs -- runs out of
+      // place so that it can be cut into segments)
       SIM_TRY(s, ensure_spare_prim(s));
       swap_prim = true;
     } else if (dc3) {
