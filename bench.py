@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured with torch: copy 4950, read 6060, fill 6570 GB/s
 
 # algorithmic bytes (fp64, compulsory traffic) -- SURVEY.md 8(d)
 B_STAGE = {"glmmhd": (216.0, 288.0), "euler": (120.0, 160.0)}   # per cell-stage: gam0 == 0 / != 0
