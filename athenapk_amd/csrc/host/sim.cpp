@@ -343,6 +343,53 @@ void cpaw_state(const CpawState &c, double X1, double X2, double X3, double m[3]
   b[2] = bx * c.sin_a2 + bz * c.cos_a2;
 }
 
+// ---- advected field loop (src/pgen/field_loop.cpp) ------------------------------------------------
+void field_loop_setup(apk_sim *s) {  // parameter block :129-170
+  ParameterInput &pin = s->pin;
+  FieldLoopState &f = s->floop;
+  if (s->pkg.fluid != APK_FLUID_GLMMHD) throw std::runtime_error("field_loop requires hydro/fluid = glmmhd");
+  if (s->mesh.ndim < 2) throw std::runtime_error("field_loop needs a 2-D or 3-D mesh");
+  f.rad = pin.GetReal("problem/field_loop", "rad");
+  f.amp = pin.GetReal("problem/field_loop", "amp");
+  f.vflow = pin.GetReal("problem/field_loop", "vflow");
+  f.drat = pin.GetOrAddReal("problem/field_loop", "drat", 1.0);
+  f.iprob = pin.GetInteger("problem/field_loop", "iprob");
+  if (f.iprob == 4) {  // rotated cylinder: one wavelength along each of x1 and x3
+    const double L1 = s->xmax[0] - s->xmin[0], L3 = s->mesh.ndim < 3 ? 0.0 : s->xmax[2] - s->xmin[2];
+    if (L1 == L3) {
+      f.cos_a2 = f.sin_a2 = std::sqrt(0.5);
+    } else {
+      const double ang_2 = std::atan(L1 / L3);
+      f.sin_a2 = std::sin(ang_2);
+      f.cos_a2 = std::cos(ang_2);
+    }
+    f.lambda = f.cos_a2 >= f.sin_a2 ? L1 * f.cos_a2 : L3 * f.sin_a2;
+  }
+}
+
+// cell-centred vector potential of the loop, one branch per iprob (:196-290)
+void field_loop_potential(const FieldLoopState &f, double x1, double x2, double x3, double A[3]) {
+  A[0] = A[1] = A[2] = 0.0;
+  auto cone = [&](double rsq) { return rsq < f.rad * f.rad ? f.amp * (f.rad - std::sqrt(rsq)) : 0.0; };
+  switch (f.iprob) {
+  case 1: A[2] = cone(x1 * x1 + x2 * x2); break;
+  case 2: A[0] = cone(x2 * x2 + x3 * x3); break;
+  case 3: A[1] = cone(x1 * x1 + x3 * x3); break;
+  case 4: {
+    double x = x1 * f.cos_a2 + x3 * f.sin_a2;
+    while (x > 0.5 * f.lambda) x -= f.lambda;
+    while (x < -0.5 * f.lambda) x += f.lambda;
+    if ((x * x + x2 * x2) < f.rad * f.rad) {  // keeps +0 outside the loop
+      A[0] = cone(x * x + x2 * x2) * (-f.sin_a2);
+      A[2] = cone(x * x + x2 * x2) * (f.cos_a2);
+    }
+    break;
+  }
+  case 5: A[1] = A[2] = cone(x1 * x1 + x2 * x2 + x3 * x3); break;
+  default: break;
+  }
+}
+
 void pgen_block(apk_sim *s, int lb, std::vector<double> &u) {
   const Mesh &m = s->mesh;
   const HydroPackage &pkg = s->pkg;
@@ -446,6 +493,34 @@ void pgen_block(apk_sim *s, int lb, std::vector<double> &u) {
           at(7, k, j, i) = b3;
           at(4, k, j, i) = c.pres / c.gm1 + 0.5 * (b1 * b1 + b2 * b2 + b3 * b3) +
                            (0.5 / c.den) * (mom[0] * mom[0] + mom[1] * mom[1] + mom[2] * mom[2]);
+        } else if (s->problem_id == "field_loop") {  // src/pgen/field_loop.cpp:292-322
+          const FieldLoopState &f = s->floop;
+          const bool two_d = m.ndim < 3;
+          const double L[3] = {s->xmax[0] - s->xmin[0], s->xmax[1] - s->xmin[1], two_d ? 0.0 : s->xmax[2] - s->xmin[2]};
+          const double den = (x1 * x1 + x2 * x2 + x3 * x3) < f.rad * f.rad ? f.drat : 1.0;
+          double Ajp[3], Ajm[3], Aip[3], Aim[3], Akp[3] = {0, 0, 0}, Akm[3] = {0, 0, 0};
+          field_loop_potential(f, x1, xc(s, x0, 1, j + 1), x3, Ajp);
+          field_loop_potential(f, x1, xc(s, x0, 1, j - 1), x3, Ajm);
+          field_loop_potential(f, xc(s, x0, 0, i + 1), x2, x3, Aip);
+          field_loop_potential(f, xc(s, x0, 0, i - 1), x2, x3, Aim);
+          if (!two_d) {
+            field_loop_potential(f, x1, x2, xc(s, x0, 2, k + 1), Akp);
+            field_loop_potential(f, x1, x2, xc(s, x0, 2, k - 1), Akm);
+          }
+          const double aydz = two_d ? 0.0 : (Akp[1] - Akm[1]) / s->dx[2] / 2.0;
+          const double axdz = two_d ? 0.0 : (Akp[0] - Akm[0]) / s->dx[2] / 2.0;
+          const double b1 = (Ajp[2] - Ajm[2]) / s->dx[1] / 2.0 - aydz;
+          const double b2 = axdz - (Aip[2] - Aim[2]) / s->dx[0] / 2.0;
+          const double b3 = (Aip[1] - Aim[1]) / s->dx[0] / 2.0 - (Ajp[0] - Ajm[0]) / s->dx[1] / 2.0;
+          const double m1 = den * f.vflow * L[0], m2 = den * f.vflow * L[1], m3 = den * f.vflow * L[2];
+          at(0, k, j, i) = den;
+          at(1, k, j, i) = m1;
+          at(2, k, j, i) = m2;
+          at(3, k, j, i) = m3;
+          at(5, k, j, i) = b1;
+          at(6, k, j, i) = b2;
+          at(7, k, j, i) = b3;
+          at(4, k, j, i) = 1.0 / gm1 + 0.5 * (b1 * b1 + b2 * b2 + b3 * b3) + 0.5 * (m1 * m1 + m2 * m2 + m3 * m3) / den;
         } else if (s->problem_id == "lw_implode") {  // src/pgen/lw_implode.cpp:59-73
           const bool outside = x2 > (lwi[4] - x1);
           at(0, k, j, i) = outside ? lwi[2] : lwi[0];
@@ -1192,6 +1267,7 @@ int create_common(const char *deck, const char *const *overrides, int noverrides
     mesh_initialize(s);
     if (s->problem_id == "linear_wave") lw_setup(s);
     else if (s->problem_id == "cpaw") cpaw_setup(s);
+    else if (s->problem_id == "field_loop") field_loop_setup(s);
     else if (s->problem_id == "advection") {
       // advection::InitUserMeshData (src/pgen/advection.cpp:34-59): tlim counts box diagonals / |v|
       const double vx = s->pin.GetOrAddReal("problem/advection", "vx", 0.0), vy = s->pin.GetOrAddReal("problem/advection", "vy", 0.0),
@@ -1206,7 +1282,7 @@ int create_common(const char *deck, const char *const *overrides, int noverrides
     else if (s->problem_id == "turbulence") turbulence_setup(s);
     else if (s->problem_id != "sod" && s->problem_id != "orszag_tang" && s->problem_id != "synthetic" &&
              s->problem_id != "blast" && s->problem_id != "lw_implode" && s->problem_id != "cpaw" &&
-             s->problem_id != "advection")
+             s->problem_id != "advection" && s->problem_id != "field_loop")
       throw std::runtime_error("unknown job/problem_id: " + s->problem_id);
   } catch (const std::exception &e) {
     if (errbuf && errlen) std::snprintf(errbuf, errlen, "%s", e.what());
@@ -1518,6 +1594,16 @@ int apk_sim_turbulence_history(apk_sim *s, double *out3) {
   return APK_OK;
 }
 
+// field_loop::RelDivBHst (src/pgen/field_loop.cpp:60-95), registered as "UserRelDivB" (:97-103)
+int apk_sim_user_reldivb(apk_sim *s, double *out) {
+  if (!s || s->host_only || !out || s->problem_id != "field_loop") return APK_ERR_INVALID;
+  SIM_TRY(s, apk_history_user_reldivb(s->ctx, s->mu0(), s->floop.amp, out, s->stream));
+  if (s->have_comm && s->nranks > 1) {
+    if (s->comm.allreduce_sum(s->comm.user, out, 1) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_sum failed");
+  }
+  return APK_OK;
+}
+
 int apk_sim_fmft_num_modes(const apk_sim *s) { return (s && s->fmft) ? s->fmft->num_modes() : 0; }
 
 int apk_sim_fmft_var_hat(const apk_sim *s, double *out) {
@@ -1591,6 +1677,7 @@ int apk_sim_history_labels(const apk_sim *s, char *buf, size_t len) {
   const bool mhd = s->pkg.fluid == APK_FLUID_GLMMHD;
   if (mhd) l += " ME relDivB";
   if (s->fmft) l += mhd ? " Ms Ma plasma_beta" : " Ms";
+  if (s->problem_id == "field_loop") l += " UserRelDivB";
   std::snprintf(buf, len, "%s", l.c_str());
   return APK_OK;
 }
@@ -1602,9 +1689,13 @@ int apk_sim_write_history(apk_sim *s, const char *path) {
   int rc = apk_sim_history(s, h);
   if (rc != APK_OK) return rc;
   if (s->fmft && (rc = apk_sim_turbulence_history(s, t3)) != APK_OK) return rc;
+  const bool floop = s->problem_id == "field_loop";
+  double urdb = 0.0;
+  if (floop && (rc = apk_sim_user_reldivb(s, &urdb)) != APK_OK) return rc;
   if (s->rank != 0) return APK_OK;
   std::vector<double> row(h, h + (mhd ? 8 : 6));
   if (s->fmft) row.insert(row.end(), t3, t3 + (mhd ? 3 : 1));
+  if (floop) row.push_back(urdb);
   FILE *f = std::fopen(path, "r");
   const bool fresh = (f == nullptr);
   if (f) std::fclose(f);

@@ -53,6 +53,11 @@ struct CpawState {  // globals of src/pgen/cpaw.cpp
   bool compute_error = false;
 };
 
+struct FieldLoopState {  // parameters of src/pgen/field_loop.cpp:129-170; B0 normalises UserRelDivB
+  int iprob = 1;
+  double rad = 0, amp = 0, vflow = 0, drat = 1.0, cos_a2 = 0, sin_a2 = 0, lambda = 0;
+};
+
 }  // namespace apk
 
 struct apk_sim {
@@ -62,6 +67,7 @@ struct apk_sim {
   std::string problem_id;
   apk::LinearWaveState lw;
   apk::CpawState cpaw;
+  apk::FieldLoopState floop;
   bool host_only = false;
   bool fused = true;
   int rank = 0, nranks = 1;

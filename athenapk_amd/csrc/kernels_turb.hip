@@ -180,6 +180,23 @@ __global__ void __launch_bounds__(256) turb_history_kernel(PackView pv, double g
   store_partials<3>(h, partial);
 }
 
+// field_loop::RelDivBHst (src/pgen/field_loop.cpp:60-95): sum of 0.5 |dx| |div B| / B0 * volume with
+// centred differences of the cell-centred field and a FIXED normalisation B0
+__global__ void __launch_bounds__(256) user_reldivb_kernel(PackView pv, double B0, double *partial) {
+  int b, k, j, i;
+  double h[1] = {0};
+  if (interior_of(pv, b, k, j, i)) {
+    const apk_block_desc blk = pv.blocks[b];
+    const double vol = blk.dx[0] * blk.dx[1] * blk.dx[2];
+    const double *u = blk.cons + k * pv.sk + j * pv.sj + i;
+    const double *b1 = u + IB1 * pv.sn, *b2 = u + IB2 * pv.sn, *b3 = u + IB3 * pv.sn;
+    double divb = (b1[1] - b1[-1]) / blk.dx[0] + (b2[pv.sj] - b2[-pv.sj]) / blk.dx[1];
+    if (pv.ndim == 3) divb += (b3[pv.sk] - b3[-pv.sk]) / blk.dx[2];
+    h[0] = 0.5 * (sqrt(sqr(blk.dx[0]) + sqr(blk.dx[1]) + sqr(blk.dx[2]))) * fabs(divb) / B0 * vol;
+  }
+  store_partials<1>(h, partial);
+}
+
 int ensure_partial_cap(apk_ctx *ctx, size_t n) {
   if (ctx->partial_cap >= n) return APK_OK;
   if (ctx->d_partial) (void)hipFree(ctx->d_partial);
@@ -289,6 +306,17 @@ int apk_turbulence_history(apk_ctx *ctx, const apk_pack *md, int fluid, double g
   else
     hipLaunchKernelGGL(turb_history_kernel<APK_FLUID_GLMMHD>, g, dim3(64, 4, 1), 0, s, md->view, gamma, ctx->d_partial);
   return finish_sums<3>(ctx, nwg, out3, s);
+}
+
+int apk_history_user_reldivb(apk_ctx *ctx, const apk_pack *md, double B0, double *out, apk_stream_t stream) {
+  if (!ctx || !md || !out || md->view.nhydro != 9 || md->view.ndim < 2 || !(B0 > 0.0))
+    return set_err(ctx, APK_ERR_INVALID, "apk_history_user_reldivb: bad argument (GLM-MHD, >= 2-D, B0 > 0)");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 g = igrid(md->view);
+  const int nwg = g.x * g.y * g.z;
+  if (ensure_partial_cap(ctx, (size_t)nwg * 4 + 8) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "partial buffer");
+  hipLaunchKernelGGL(user_reldivb_kernel, g, dim3(64, 4, 1), 0, s, md->view, B0, ctx->d_partial);
+  return finish_sums<1>(ctx, nwg, out, s);
 }
 
 }  // extern "C"

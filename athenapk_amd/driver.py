@@ -327,6 +327,12 @@ class Simulation(_FmftHost):
         self._check(self.lib.apk_sim_turbulence_history(self.h, out))
         return np.array(out[:])
 
+    def user_reldivb(self):
+        """field_loop's "UserRelDivB" history column: fixed-B0 relative div(B) (RelDivBHst)"""
+        out = C.c_double(0.0)
+        self._check(self.lib.apk_sim_user_reldivb(self.h, C.byref(out)))
+        return out.value
+
     def read_acc(self, lb):
         out = np.empty((3,) + self.block_shape[1:])
         self._check(self.lib.apk_sim_read_acc(self.h, lb, out.ctypes.data_as(L.c_dp)))

@@ -156,6 +156,7 @@ def _signatures():
         "apk_turb_remove_mean": (i, [vp, vp, vp, c_dp, c_dp, vp]),
         "apk_turb_apply": (i, [vp, vp, vp, d, d, vp]),
         "apk_turbulence_history": (i, [vp, vp, i, d, c_dp, vp]),
+        "apk_history_user_reldivb": (i, [vp, vp, d, c_dp, vp]),
         "apk_refine_plan_create": (i, [vp, C.POINTER(RefineGeom), i, C.POINTER(RefineOp), i, pp]),
         "apk_refine_plan_destroy": (None, [vp]),
         "apk_refine_plan_run": (i, [vp, vp, vp]),
@@ -203,6 +204,7 @@ def _signatures():
         "apk_sim_write_linear_wave_errors": (i, [vp, C.c_char_p]),
         "apk_sim_execute": (i, [vp, C.c_char_p, C.POINTER(C.c_int)]),
         "apk_sim_turbulence_history": (i, [vp, c_dp]),
+        "apk_sim_user_reldivb": (i, [vp, c_dp]),
         "apk_sim_fmft_num_modes": (i, [vp]),
         "apk_sim_fmft_var_hat": (i, [vp, c_dp]),
         "apk_sim_fmft_evolve": (i, [vp, d]),

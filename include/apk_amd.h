@@ -347,6 +347,11 @@ enum { APK_TAG_PRESSURE_GRADIENT = 0, APK_TAG_VELOCITY_GRADIENT = 1, APK_TAG_MAX
 int apk_tag_blocks(apk_ctx *ctx, const apk_pack *md, int criterion, double p0, double p1, int *tags,
                    double *crit, apk_stream_t stream);
 
+/* field_loop::RelDivBHst (src/pgen/field_loop.cpp:60-95), the "UserRelDivB" history column of the
+ * field-loop problem: sum of 0.5 |dx| |div B| / B0 * volume, B0 fixed.  Synchronises. */
+int apk_history_user_reldivb(apk_ctx *ctx, const apk_pack *md, double B0, double *out,
+                             apk_stream_t stream);
+
 /* ---- in-library kernel timing (HIP events on the caller's stream) ------------------------
  * bench.py needs the average duration of individual kernels measured live on the stream
  * they are launched on.  When enabled, every kernel launch of the listed groups is

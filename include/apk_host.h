@@ -125,6 +125,8 @@ int apk_sim_history(apk_sim *sim, double *out8);
  * (consuming RNG draws exactly as a driven step does); phases fills [2][num_modes][n] for cells
  * g0..g0+n-1 of `axis`.  read_acc copies block lb's acceleration field [3][Nk][Nj][Ni]. */
 int apk_sim_turbulence_history(apk_sim *sim, double *out3);
+/* field_loop's extra history column "UserRelDivB" (src/pgen/field_loop.cpp:60-103), summed over ranks */
+int apk_sim_user_reldivb(apk_sim *s, double *out);
 int apk_sim_fmft_num_modes(const apk_sim *sim);
 int apk_sim_fmft_var_hat(const apk_sim *sim, double *out);
 int apk_sim_fmft_evolve(apk_sim *sim, double dt);

@@ -105,6 +105,8 @@ def _declare(lib):
         "orc_pgen_linear_wave": (d, [C.c_void_p, i, d, d]),
         "orc_pgen_sod": (None, [C.c_void_p, d, d, d, d, d, d, d]),
         "orc_pgen_orszag_tang": (None, [C.c_void_p]),
+        "orc_pgen_field_loop": (None, [C.c_void_p, d, d, d, d, i]),
+        "orc_user_reldivb": (d, [C.c_void_p, d]),
         "orc_pgen_advection": (None, [C.c_void_p, d, d, d, d, d, d, d, d]),
         "orc_pgen_cpaw": (d, [C.c_void_p, d, d, d, d, i, d, d]),
         "orc_cpaw_errors": (d, [C.c_void_p, p]),
@@ -273,6 +275,9 @@ class Sim:
             self.lib.orc_pgen_orszag_tang(self.h)
         elif name == "synthetic":
             self.lib.orc_pgen_synthetic(self.h)
+        elif name == "field_loop":
+            self.lib.orc_pgen_field_loop(self.h, kw.get("rad", 0.3), kw.get("amp", 1e-3), kw.get("vflow", 1.0),
+                                         kw.get("drat", 1.0), kw.get("iprob", 1))
         elif name == "advection":
             self.lib.orc_pgen_advection(self.h, kw.get("vx", 0.0), kw.get("vy", 0.0), kw.get("vz", 0.0),
                                         kw.get("rho_ratio", 1.0), kw.get("rho_radius", 0.0),
@@ -328,6 +333,9 @@ class Sim:
 
     def acc(self, b):
         return np.ctypeslib.as_array(self.lib.orc_sim_acc(self.h, b), shape=(3,) + self.geom.shape[1:])
+
+    def user_reldivb(self, B0):
+        return self.lib.orc_user_reldivb(self.h, B0)
 
     def cpaw_errors(self):
         err = np.zeros(8)

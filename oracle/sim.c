@@ -673,6 +673,114 @@ void orc_pgen_lw_implode(orc_sim *s, double d_in, double p_in, double d_out, dou
   }
 }
 
+/* ---- advected field loop (src/pgen/field_loop.cpp:105-316) ----------------------------------------- */
+typedef struct {
+  int iprob;
+  double rad, amp, cos_a2, sin_a2, lambda;
+} floop_t;
+
+static void floop_A(const floop_t *f, double x1, double x2, double x3, double A[3]) {
+  A[0] = A[1] = A[2] = 0.0;
+  const double rad = f->rad, amp = f->amp;
+  if (f->iprob == 1) {
+    if ((x1 * x1 + x2 * x2) < rad * rad) A[2] = amp * (rad - sqrt(x1 * x1 + x2 * x2));
+  } else if (f->iprob == 2) {
+    if ((x2 * x2 + x3 * x3) < rad * rad) A[0] = amp * (rad - sqrt(x2 * x2 + x3 * x3));
+  } else if (f->iprob == 3) {
+    if ((x1 * x1 + x3 * x3) < rad * rad) A[1] = amp * (rad - sqrt(x1 * x1 + x3 * x3));
+  } else if (f->iprob == 4) {
+    double x = x1 * f->cos_a2 + x3 * f->sin_a2;
+    const double y = x2;
+    while (x > 0.5 * f->lambda) x -= f->lambda;
+    while (x < -0.5 * f->lambda) x += f->lambda;
+    if ((x * x + y * y) < rad * rad) {
+      A[0] = amp * (rad - sqrt(x * x + y * y)) * (-f->sin_a2);
+      A[2] = amp * (rad - sqrt(x * x + y * y)) * (f->cos_a2);
+    }
+  } else if (f->iprob == 5) {
+    if ((x1 * x1 + x2 * x2 + x3 * x3) < rad * rad) {
+      A[1] = amp * (rad - sqrt(x1 * x1 + x2 * x2 + x3 * x3));
+      A[2] = amp * (rad - sqrt(x1 * x1 + x2 * x2 + x3 * x3));
+    }
+  }
+}
+
+void orc_pgen_field_loop(orc_sim *s, double rad, double amp, double vflow, double drat, int iprob) {
+  const sb_t bb = sim_bounds(&s->g);
+  const double gm1 = s->p.eos.gamma - 1.0;
+  const double x1size = s->p.xmax[0] - s->p.xmin[0], x2size = s->p.xmax[1] - s->p.xmin[1];
+  const int two_d = s->p.nx[2] <= 1;
+  const double x3size = two_d ? 0 : s->p.xmax[2] - s->p.xmin[2];
+  floop_t f = {iprob, rad, amp, 0.0, 0.0, 0.0};
+  if (iprob == 4) {
+    if (x1size == x3size) {
+      f.cos_a2 = f.sin_a2 = sqrt(0.5);
+    } else {
+      const double ang_2 = atan(x1size / x3size);
+      f.sin_a2 = sin(ang_2);
+      f.cos_a2 = cos(ang_2);
+    }
+    f.lambda = (f.cos_a2 >= f.sin_a2) ? x1size * f.cos_a2 : x3size * f.sin_a2;
+  }
+  for (int b = 0; b < s->nblocks; ++b) {
+    double x0[3];
+    orc_sim_block_origin(s, b, x0);
+    double *u = s->cons[b];
+    for (int k = bb.ks; k <= bb.ke; ++k)
+      for (int j = bb.js; j <= bb.je; ++j)
+        for (int i = bb.is; i <= bb.ie; ++i) {
+          const double X1 = xc(s, x0, 0, i), X2 = xc(s, x0, 1, j), X3 = xc(s, x0, 2, k);
+          double Ajp[3], Ajm[3], Aip[3], Aim[3], Akp[3] = {0, 0, 0}, Akm[3] = {0, 0, 0};
+          floop_A(&f, X1, xc(s, x0, 1, j + 1), X3, Ajp);
+          floop_A(&f, X1, xc(s, x0, 1, j - 1), X3, Ajm);
+          floop_A(&f, xc(s, x0, 0, i + 1), X2, X3, Aip);
+          floop_A(&f, xc(s, x0, 0, i - 1), X2, X3, Aim);
+          if (!two_d) {
+            floop_A(&f, X1, X2, xc(s, x0, 2, k + 1), Akp);
+            floop_A(&f, X1, X2, xc(s, x0, 2, k - 1), Akm);
+          }
+          const double dx1 = s->g.dx[0], dx2 = s->g.dx[1], dx3 = s->g.dx[2];
+          double den = 1.0;
+          if ((X1 * X1 + X2 * X2 + X3 * X3) < rad * rad) den = drat;
+          SAT(u, ORC_IDN, k, j, i) = den;
+          SAT(u, ORC_IM1, k, j, i) = den * vflow * x1size;
+          SAT(u, ORC_IM2, k, j, i) = den * vflow * x2size;
+          SAT(u, ORC_IM3, k, j, i) = den * vflow * x3size;
+          const double aydz = two_d ? 0.0 : (Akp[1] - Akm[1]) / dx3 / 2.0;
+          const double axdz = two_d ? 0.0 : (Akp[0] - Akm[0]) / dx3 / 2.0;
+          const double b1 = (Ajp[2] - Ajm[2]) / dx2 / 2.0 - aydz;
+          const double b2 = axdz - (Aip[2] - Aim[2]) / dx1 / 2.0;
+          const double b3 = (Aip[1] - Aim[1]) / dx1 / 2.0 - (Ajp[0] - Ajm[0]) / dx2 / 2.0;
+          SAT(u, ORC_IB1, k, j, i) = b1;
+          SAT(u, ORC_IB2, k, j, i) = b2;
+          SAT(u, ORC_IB3, k, j, i) = b3;
+          const double m1 = SAT(u, ORC_IM1, k, j, i), m2 = SAT(u, ORC_IM2, k, j, i), m3 = SAT(u, ORC_IM3, k, j, i);
+          SAT(u, ORC_IEN, k, j, i) = 1.0 / gm1 + 0.5 * (b1 * b1 + b2 * b2 + b3 * b3) + 0.5 * (m1 * m1 + m2 * m2 + m3 * m3) / den;
+        }
+  }
+}
+
+/* field_loop::RelDivBHst (:60-95) summed over all blocks */
+double orc_user_reldivb(orc_sim *s, double B0) {
+  const sb_t bb = sim_bounds(&s->g);
+  const double dx1 = s->g.dx[0], dx2 = s->g.dx[1], dx3 = s->g.dx[2];
+  const double vol = dx1 * dx2 * dx3;
+  const int three_d = s->p.nx[2] > 1;
+  double sum = 0.0;
+  for (int b = 0; b < s->nblocks; ++b) {
+    const double *u = s->cons[b];
+    for (int k = bb.ks; k <= bb.ke; ++k)
+      for (int j = bb.js; j <= bb.je; ++j)
+        for (int i = bb.is; i <= bb.ie; ++i) {
+          double divb = (SAT(u, ORC_IB1, k, j, i + 1) - SAT(u, ORC_IB1, k, j, i - 1)) / dx1 +
+                        (SAT(u, ORC_IB2, k, j + 1, i) - SAT(u, ORC_IB2, k, j - 1, i)) / dx2;
+          if (three_d) divb += (SAT(u, ORC_IB3, k + 1, j, i) - SAT(u, ORC_IB3, k - 1, j, i)) / dx3;
+          sum += 0.5 * (sqrt(dx1 * dx1 + dx2 * dx2 + dx3 * dx3)) * fabs(divb) / B0 * vol;
+        }
+  }
+  return sum;
+}
+
 /* ---- circularly polarised Alfven wave (src/pgen/cpaw.cpp) -------------------------------------- */
 /* vector potential in a gauge with Ax = 0 (cpaw.cpp:310-344) */
 static void cpaw_A(const orc_sim *s, double x1, double x2, double x3, double A[3]) {

@@ -551,3 +551,64 @@ def test_advection_matches_oracle_and_tags_the_blob(oracle):
     g = H.geom("euler", (8, 8, 8), 2)
     want = [oracle.tag("maxdensity", g, o.prim(s.block_gid(lb)[0]), 1.0001, 1.00005) for lb in range(s.info.nblocks_local)]
     assert list(tags) == [w[0] for w in want] and list(crit) == [w[1] for w in want]
+
+
+# ---- field loop advection (src/pgen/field_loop.cpp, tst/regression/test_suites/field_loop) ---------------
+FIELD_LOOP_METHODS = [("rk1", "dc", 2), ("vl2", "plm", 2), ("rk3", "ppm", 3), ("rk3", "weno3", 2)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("integrator,recon,ng", FIELD_LOOP_METHODS)
+def test_field_loop_method_matrix_matches_oracle(oracle, integrator, recon, ng):
+    """the four method configurations of field_loop.py:35-40 at its lowest resolution (64x32 in 32x32
+    blocks, HLLE + plain Dedner, alpha 0.4): state, dt sequence, history row and UserRelDivB bit for bit"""
+    ov = ["parthenon/mesh/nx1=64", "parthenon/meshblock/nx1=32", "parthenon/mesh/nx2=32", "parthenon/meshblock/nx2=32",
+          "parthenon/time/integrator=%s" % integrator, "hydro/reconstruction=%s" % recon,
+          "parthenon/mesh/nghost=%d" % ng, "parthenon/time/tlim=0.25"]
+    s = _sim("field_loop", ov, strict=True).initialize()
+    o = oracle.Sim(fluid="glmmhd", recon=recon, riemann="hlle", integrator=integrator, nx=(64, 32, 1), mb=(32, 32, 1),
+                   ng=ng, xmin=(-1.0, -0.5, -0.5), xmax=(1.0, 0.5, 0.5), cfl=0.3, gamma=GAMMA_DECK, glmmhd_alpha=0.4)
+    o.pgen("field_loop", rad=0.3, amp=1e-3, vflow=1.0, iprob=1)
+    assert np.array_equal(s.gather("cons"), o.gather_cons())
+    assert s.user_reldivb() < 1e-13
+    assert s.run() == o.run(0.25)
+    assert np.array_equal(s.gather("cons"), o.gather_cons())
+    assert np.allclose(s.history(), o.history(), rtol=1e-13, atol=1e-300)
+    assert abs(s.user_reldivb() - o.user_reldivb(1e-3)) <= 1e-12 * o.user_reldivb(1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("iprob", [1, 2, 3, 4, 5])
+def test_field_loop_3d_variants_match_oracle(oracle, iprob):
+    """iprob 1-5 in 3-D (cylinders along each axis, the rotated cylinder, the sphere)"""
+    ov = ["parthenon/mesh/nx1=32", "parthenon/meshblock/nx1=16", "parthenon/mesh/nx2=16", "parthenon/meshblock/nx2=16",
+          "parthenon/mesh/nx3=16", "parthenon/meshblock/nx3=8", "problem/field_loop/iprob=%d" % iprob,
+          "parthenon/time/tlim=0.05"]
+    s = _sim("field_loop", ov, strict=True).initialize()
+    o = oracle.Sim(fluid="glmmhd", recon="plm", riemann="hlle", integrator="vl2", nx=(32, 16, 16), mb=(16, 16, 8),
+                   ng=2, xmin=(-1.0, -0.5, -0.5), xmax=(1.0, 0.5, 0.5), cfl=0.3, gamma=GAMMA_DECK, glmmhd_alpha=0.4)
+    o.pgen("field_loop", rad=0.3, amp=1e-3, vflow=1.0, iprob=iprob)
+    assert np.array_equal(s.gather("cons"), o.gather_cons())
+    assert np.abs(s.gather("cons")[5:8]).max() > 2e-4
+    assert s.run() == o.run(0.05)
+    assert np.array_equal(s.gather("cons"), o.gather_cons())
+    assert abs(s.user_reldivb() - o.user_reldivb(1e-3)) <= 1e-12 * o.user_reldivb(1e-3)
+
+
+@pytest.mark.gpu
+def test_cli_field_loop_history_columns(tmp_path):
+    """the reference's analysis reads Emag = column 10 and UserRelDivB = column 12 of <outname>.out1.hst
+    (field_loop.py:139-143); product (FMA) build, the deck as shipped but a shorter run"""
+    from athenapk_amd import __main__ as cli
+    assert cli.main(["-i", "field_loop", "-d", str(tmp_path), "parthenon/job/problem_id=128_vl2_plm",
+                     "parthenon/time/tlim=0.5"]) == 0
+    path = os.path.join(str(tmp_path), "128_vl2_plm.out1.hst")
+    names = [n.split("=")[1] for n in open(path).readlines()[1].lstrip("#").split()]
+    assert names[10] == "ME" and names[11] == "relDivB" and names[12] == "UserRelDivB"
+    data = np.genfromtxt(path)
+    assert data.shape == (11, 13) and data[-1, 0] == 0.5
+    assert np.all(data[:, 3] == 4)                                    # 128x64 in 64x32 blocks
+    assert data[0, 12] < 1e-13 and np.all(data[1:, 12] > 0) and np.all(data[1:, 12] < 0.2)
+    emag = data[:, 10] / data[0, 10]
+    assert np.all(np.diff(emag) < 0) and emag[-1] > 0.8               # slow numerical decay only
+    assert np.all(np.abs(data[:, 4] - 2.0) < 1e-12)                   # mass

@@ -454,3 +454,47 @@ def test_blast_is_octant_symmetric(oracle):
     assert np.isfinite(c).all()
     for ax in (1, 2, 3):
         assert np.allclose(c[0], np.flip(c[0], axis=ax - 1), rtol=1e-12)
+
+
+def test_field_loop_initial_state(oracle):
+    """pgen/field_loop.cpp: B = curl A of a cone potential -> |B| = amp inside the loop away from the
+    axis and the rim, zero outside, div B = 0 to round-off in the centred-difference sense that
+    UserRelDivB measures; E = 1/(gamma-1) + B^2/2 + m^2/(2 rho)"""
+    amp, rad = 1e-3, 0.3
+    o = oracle.Sim(fluid="glmmhd", recon="plm", riemann="hlle", integrator="vl2", nx=(64, 32, 1), mb=(32, 32, 1), ng=2,
+                   xmin=(-1.0, -0.5, -0.5), xmax=(1.0, 0.5, 0.5), cfl=0.3, gamma=5.0 / 3.0, glmmhd_alpha=0.4)
+    o.pgen("field_loop", rad=rad, amp=amp, vflow=1.0, iprob=1)
+    u = o.gather_cons()[:, 0]
+    x = -1.0 + (np.arange(64) + 0.5) / 32.0
+    y = -0.5 + (np.arange(32) + 0.5) / 32.0
+    r = np.sqrt(x[None, :] ** 2 + y[:, None] ** 2)
+    bmag = np.sqrt(u[5] ** 2 + u[6] ** 2)
+    inside = (r > 3.0 / 32.0) & (r < rad - 2.0 / 32.0)
+    assert np.allclose(bmag[inside], amp, rtol=0.06)
+    assert np.all(bmag[r > rad + 2.0 / 32.0] == 0.0) and np.all(u[7] == 0.0)
+    assert np.all(u[0] == 1.0) and np.all(u[1] == 2.0) and np.all(u[2] == 1.0) and np.all(u[3] == 0.0)
+    assert np.allclose(u[4], 1.5 + 0.5 * bmag ** 2 + 2.5, rtol=1e-14)
+    assert o.user_reldivb(amp) < 1e-13      # the centred divergence of a centred curl vanishes identically
+    # 3-D variants: the loop axis follows iprob
+    for iprob, comp in ((1, 7), (2, 5), (3, 6)):
+        o3 = oracle.Sim(fluid="glmmhd", recon="plm", riemann="hlle", integrator="vl2", nx=(16, 16, 16), mb=(8, 8, 8), ng=2,
+                        xmin=(-0.5, -0.5, -0.5), xmax=(0.5, 0.5, 0.5), cfl=0.3, gamma=5.0 / 3.0, glmmhd_alpha=0.4)
+        o3.pgen("field_loop", rad=rad, amp=amp, vflow=1.0, iprob=iprob)
+        u3 = o3.gather_cons()
+        assert np.all(u3[comp] == 0.0) and np.abs(u3[5:8]).max() > 0.5 * amp
+        assert np.all(u3[3] == 1.0)
+        assert o3.user_reldivb(amp) < 1e-13
+
+
+def test_field_loop_advects_and_keeps_magnetic_energy(oracle):
+    """what the reference's field_loop.py plots: Emag(t)/Emag(0) decays slowly, UserRelDivB stays small"""
+    amp = 1e-3
+    o = oracle.Sim(fluid="glmmhd", recon="plm", riemann="hlle", integrator="vl2", nx=(64, 32, 1), mb=(32, 32, 1), ng=2,
+                   xmin=(-1.0, -0.5, -0.5), xmax=(1.0, 0.5, 0.5), cfl=0.3, gamma=5.0 / 3.0, glmmhd_alpha=0.4)
+    o.pgen("field_loop", rad=0.3, amp=amp, vflow=1.0, iprob=1)
+    me0 = o.history()[6]
+    o.run(0.5)
+    h = o.history()
+    assert 0.6 < h[6] / me0 < 1.0
+    assert abs(h[0] - 1.0 * 2.0) < 1e-12                      # mass = rho * area (volume 2 x 1 x 1)
+    assert 0.0 < o.user_reldivb(amp) < 0.5
