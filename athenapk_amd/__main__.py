@@ -38,7 +38,7 @@ def main(argv=None):
     wall = sim.loop_seconds  # main loop only, like Parthenon's performance line
     if rank == 0:
         print("cycle=%d time=%.14e dt=%.14e" % (n, sim.time, sim.dt))
-        print("zone-cycles/wallsecond = %.3e" % (sim.info.zones_total * sim.loop_cycles / max(wall, 1e-30)))
+        print("zone-cycles/wallsecond = %.3e" % (sim.loop_zone_cycles / max(wall, 1e-30)))
     sim.close()
     if world > 1:
         dist.destroy_process_group()

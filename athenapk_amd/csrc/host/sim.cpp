@@ -156,6 +156,105 @@ void hydro_initialize(apk_sim *s) {
   if (pkg.nscalars < 0) throw std::runtime_error("hydro/nscalars must be >= 0");
 }
 
+// ---- mesh refinement: tree set-up from the deck (parthenon/mesh/refinement, numlevel,
+// derefine_count, <parthenon/static_refinement#> blocks) ------------------------------------------
+// cell width on a refinement level (collapsed dimensions are not refined)
+double level_dx(const apk_sim *s, int level, int d) { return s->mesh.Active(d) ? s->dx[d] / (double)(1 << level) : s->dx[d]; }
+int block_level(const apk_sim *s, int lb) { return s->amr ? s->amr->leaves[lb].level : 0; }
+
+// refresh the uniform-mesh bookkeeping the rest of the driver reads (block counts, ids) from the tree
+void amr_sync_mesh(apk_sim *s) {
+  Mesh &m = s->mesh;
+  const int n = (int)s->amr->leaves.size();
+  m.nblocks_total = n;
+  m.local_gids.resize(n);
+  m.gid_local.clear();
+  m.gid_rank.assign(n, 0);
+  for (int g = 0; g < n; ++g) {
+    m.local_gids[g] = g;
+    m.gid_local[g] = g;
+  }
+  m.peers.clear();
+  for (auto &p : m.plan) p.clear();
+}
+
+void amr_initialize(apk_sim *s, bool adaptive) {
+  ParameterInput &pin = s->pin;
+  Mesh &m = s->mesh;
+  if (s->nranks != 1) throw std::runtime_error("mesh refinement runs on one rank in this build (nranks = 1)");
+  if (s->problem_id == "turbulence") throw std::runtime_error("the turbulence driver needs a uniform mesh");
+  s->amr.reset(new AmrTree());
+  AmrTree &t = *s->amr;
+  for (int d = 0; d < 3; ++d) {
+    t.nrb[d] = m.nb[d];
+    t.act[d] = m.Active(d);
+    t.bc_in[d] = m.bc_in[d];
+    t.bc_out[d] = m.bc_out[d];
+  }
+  t.ndim = m.ndim;
+  s->amr_adaptive = adaptive;
+  int max_level = adaptive ? pin.GetOrAddInteger("parthenon/mesh", "numlevel", 1) - 1 : 0;
+  if (max_level < 0) throw std::runtime_error("parthenon/mesh/numlevel must be at least 1");
+  s->amr_derefine_count = pin.GetOrAddInteger("parthenon/mesh", "derefine_count", 10);
+  s->amr_check_interval = pin.GetOrAddInteger("parthenon/mesh", "check_refine_interval", 1);
+  struct Region {
+    double lo[3], hi[3];
+    int level;
+  };
+  std::vector<Region> regions;
+  const char *mink[3] = {"x1min", "x2min", "x3min"}, *maxk[3] = {"x1max", "x2max", "x3max"};
+  for (const std::string &blk : pin.BlocksWithPrefix("parthenon/static_refinement")) {
+    Region r;
+    for (int d = 0; d < 3; ++d) {
+      r.lo[d] = m.Active(d) ? pin.GetReal(blk, mink[d]) : s->xmin[d];
+      r.hi[d] = m.Active(d) ? pin.GetReal(blk, maxk[d]) : s->xmax[d];
+      if (r.lo[d] > r.hi[d]) throw std::runtime_error("static refinement region of <" + blk + "> is inverted");
+      if (r.lo[d] < s->xmin[d] || r.hi[d] > s->xmax[d]) throw std::runtime_error("static refinement region of <" + blk + "> lies outside of the mesh");
+    }
+    r.level = pin.GetInteger(blk, "level");
+    if (r.level < 1) throw std::runtime_error("static refinement level must be at least 1");
+    max_level = std::max(max_level, r.level);
+    regions.push_back(r);
+  }
+  if (max_level > 12) throw std::runtime_error("more than 12 refinement levels");
+  t.max_level = max_level;
+  AmrGeom &g = s->amr_geom;
+  for (int d = 0; d < 3; ++d) {
+    g.mb[d] = m.mb[d];
+    g.act[d] = m.Active(d);
+  }
+  g.ng = m.ng;
+  g.cng = (m.ng + 1) / 2 + 1;
+  g.nvar = m.nvar;
+  g.Build();
+  t.InitRoot();
+  // static regions: split every block that overlaps a region until it has the region's level
+  for (const Region &r : regions) {
+    for (int lev = 0; lev < r.level; ++lev) {
+      std::vector<AmrLeaf> todo;
+      for (const auto &kv : t.leafmap) {
+        const AmrLeaf &l = kv.second;
+        if (l.level != lev) continue;
+        bool overlap = true;
+        for (int d = 0; d < 3; ++d) {
+          if (!m.Active(d)) continue;
+          const double w = level_dx(s, l.level, d) * m.mb[d];
+          const double lo = s->xmin[d] + l.lx[d] * w, hi = lo + w;
+          if (hi <= r.lo[d] || lo >= r.hi[d]) {
+            // a degenerate region (lo == hi) still selects the block that contains the point
+            if (!(r.lo[d] == r.hi[d] && lo <= r.lo[d] && r.lo[d] < hi)) overlap = false;
+          }
+        }
+        if (overlap) todo.push_back(l);
+      }
+      for (const AmrLeaf &l : todo) t.RefineBalanced(l.level, l.lx);
+    }
+  }
+  t.Reindex();
+  BuildAmrPlans(t, g, s->amr_plans);
+  amr_sync_mesh(s);
+}
+
 void mesh_initialize(apk_sim *s) {
   ParameterInput &pin = s->pin;
   Mesh &m = s->mesh;
@@ -171,14 +270,16 @@ void mesh_initialize(apk_sim *s) {
     m.bc_in[d] = parse_bc(pin.GetOrAddString("parthenon/mesh", ibc[d], "periodic"));
     m.bc_out[d] = parse_bc(pin.GetOrAddString("parthenon/mesh", obc[d], "periodic"));
   }
-  if (pin.GetOrAddString("parthenon/mesh", "refinement", "none") != "none")
-    throw std::runtime_error("mesh refinement is outside this path (uniform meshes only)");
+  const std::string refinement = pin.GetOrAddString("parthenon/mesh", "refinement", "none");
+  if (refinement != "none" && refinement != "static" && refinement != "adaptive")
+    throw std::runtime_error("parthenon/mesh/refinement must be none, static or adaptive");
   m.ng = pin.GetInteger("parthenon/mesh", "nghost");
   m.nvar = s->pkg.nhydro + s->pkg.nscalars;
   m.rank = s->rank;
   m.nranks = s->nranks;
   m.Build();
   s->nper = m.sn * m.nvar;
+  if (refinement != "none") amr_initialize(s, refinement == "adaptive");
   s->tlim = pin.GetOrAddReal("parthenon/time", "tlim", 1.0);
   s->nlim = pin.GetOrAddInteger("parthenon/time", "nlim", -1);
 }
@@ -191,10 +292,29 @@ double xc(const apk_sim *s, const double x0[3], int d, int idx) {
   return s->xmin[d] + ((x0[d] + (double)(idx - ng)) + 0.5) * s->dx[d];
 }
 void block_origin(const apk_sim *s, int lb, double x0[3]) {
+  if (s->amr) {  // in cells of the block's own level (s->dx is set to that level's widths meanwhile)
+    for (int d = 0; d < 3; ++d) x0[d] = (double)s->amr->leaves[lb].lx[d] * s->mesh.mb[d];
+    return;
+  }
   int bc[3];
   s->mesh.Loc(s->mesh.local_gids[lb], bc);
   for (int d = 0; d < 3; ++d) x0[d] = (double)(bc[d] * s->mesh.mb[d]);
 }
+// On refined meshes the problem generators and the error norms see the cell widths of the block
+// they work on through s->dx (restored on scope exit)
+struct LevelDxScope {
+  apk_sim *s;
+  double saved[3];
+  LevelDxScope(apk_sim *sim, int lb) : s(sim) {
+    for (int d = 0; d < 3; ++d) {
+      saved[d] = s->dx[d];
+      if (s->amr && s->mesh.Active(d)) s->dx[d] = saved[d] / (double)(1 << s->amr->leaves[lb].level);
+    }
+  }
+  ~LevelDxScope() {
+    for (int d = 0; d < 3; ++d) s->dx[d] = saved[d];
+  }
+};
 
 // hydro eigensystem, src/pgen/linear_wave.cpp:421-500 (eigenvalues + right eigenvectors)
 void lw_eigensystem(double gm1, double v1, double v2, double v3, double h, double ev[5], double rem[5][5]) {
@@ -391,6 +511,7 @@ void field_loop_potential(const FieldLoopState &f, double x1, double x2, double 
 }
 
 void pgen_block(apk_sim *s, int lb, std::vector<double> &u) {
+  LevelDxScope level_dx_scope(s, lb);
   const Mesh &m = s->mesh;
   const HydroPackage &pkg = s->pkg;
   std::fill(u.begin(), u.end(), 0.0);
@@ -764,7 +885,7 @@ int build_packs(apk_sim *s) {
         for (int d = 0; d < 3; ++d) {
           b0[lb].flux[d] = s->d_flux[d] ? s->d_flux[d] + lb * s->nper : nullptr;
           b1[lb].flux[d] = nullptr;
-          b0[lb].dx[d] = b1[lb].dx[d] = s->dx[d];
+          b0[lb].dx[d] = b1[lb].dx[d] = level_dx(s, block_level(s, lb), d);
         }
       }
       apk_pack_desc d{};
@@ -806,7 +927,8 @@ int ensure_flux_arrays(apk_sim *s) {
 }
 
 bool stage_can_fuse(const apk_sim *s) {
-  return s->fused && !s->pkg.first_order_flux_correct && s->pkg.riemann != APK_RS_NONE &&
+  // refined meshes take the flux-array path: the coarse-fine flux correction needs the face fluxes
+  return s->fused && !s->amr && !s->pkg.first_order_flux_correct && s->pkg.riemann != APK_RS_NONE &&
          s->pkg.riemann != APK_RS_LLF;
 }
 
@@ -927,9 +1049,170 @@ int exchange_end(apk_sim *s, bool c2p) {
   return APK_OK;
 }
 
+int amr_exchange(apk_sim *s, int buf);
 int exchange_ghosts(apk_sim *s, bool c2p = false) {
+  if (s->amr) return amr_exchange(s, s->cur);
   SIM_TRY(s, exchange_begin(s, false, c2p));
   return exchange_end(s, c2p);
+}
+
+
+// ---- mesh refinement on the device --------------------------------------------------------------
+double *amr_base(apk_sim *s, int parity, int kind, int block) {
+  switch (kind) {
+  case RK_BLOCK: return s->d_cons2[parity] + (int64_t)block * s->nper;
+  case RK_COARSE: return s->d_coarse + (int64_t)block * s->amr_geom.coarse_doubles;
+  case RK_FLUX1: case RK_FLUX2: case RK_FLUX3: return s->d_flux[kind - RK_FLUX1] + (int64_t)block * s->nper;
+  default: return nullptr;
+  }
+}
+
+apk_copy_region amr_copy_region(apk_sim *s, int parity, const BoxRegion &r) {
+  apk_copy_region c{};
+  c.src = amr_base(s, parity, r.src_kind, r.src_block) + r.src_off;
+  c.dst = amr_base(s, parity, r.dst_kind, r.dst_block) + r.dst_off;
+  for (int q = 0; q < 3; ++q) c.ext[q] = r.ext[q];
+  c.nvar = r.nvar;
+  for (int q = 0; q < 4; ++q) {
+    c.src_stride[q] = r.src_stride[q];
+    c.dst_stride[q] = r.dst_stride[q];
+  }
+  c.flip_var = r.flip_var;
+  return c;
+}
+
+int amr_make_copy_plan(apk_sim *s, int parity, const std::vector<BoxRegion> &regions, apk_copy_plan **out) {
+  std::vector<apk_copy_region> regs;
+  for (const BoxRegion &r : regions) regs.push_back(amr_copy_region(s, parity, r));
+  return apk_copy_plan_create(s->ctx, regs.data(), (int)regs.size(), out);
+}
+
+// one refine plan per level: the operators difference cell-centre coordinates of that level
+int amr_make_refine_plans(apk_sim *s, int parity, const std::vector<AmrRefOp> &ops, const std::vector<AmrLeaf> &leaves,
+                          std::vector<apk_refine_plan *> &out) {
+  for (apk_refine_plan *p : out) apk_refine_plan_destroy(p);
+  out.clear();
+  const AmrGeom &g = s->amr_geom;
+  for (int level = 0; level <= s->amr->max_level; ++level) {
+    std::vector<apk_refine_op> dev;
+    for (const AmrRefOp &o : ops) {
+      if (o.level != level) continue;
+      apk_refine_op d{};
+      d.kind = o.kind;
+      d.src = amr_base(s, parity, o.src_kind, o.src_block);
+      d.dst = amr_base(s, parity, o.dst_kind, o.dst_block);
+      for (int q = 0; q < 3; ++q) {
+        d.lo[q] = o.lo[q];
+        d.hi[q] = o.hi[q];
+        d.xmin[q] = s->xmin[q] + (double)leaves[o.geom_block].lx[q] * g.mb[q] * level_dx(s, level, q);
+      }
+      dev.push_back(d);
+    }
+    if (dev.empty()) continue;
+    apk_refine_geom rg{};
+    for (int q = 0; q < 3; ++q) {
+      rg.nx[q] = g.mb[q];
+      rg.dx[q] = level_dx(s, level, q);
+    }
+    rg.ng = g.ng;
+    rg.cng = g.cng;
+    apk_refine_plan *p = nullptr;
+    SIM_TRY(s, apk_refine_plan_create(s->ctx, &rg, g.nvar, dev.data(), (int)dev.size(), &p));
+    out.push_back(p);
+  }
+  return APK_OK;
+}
+
+void amr_destroy_device_plans(apk_sim *s) {
+  auto &a = s->amr_dev;
+  for (int par = 0; par < 2; ++par) {
+    for (apk_refine_plan *p : a.restrict_own[par]) apk_refine_plan_destroy(p);
+    for (apk_refine_plan *p : a.prolongate[par]) apk_refine_plan_destroy(p);
+    a.restrict_own[par].clear();
+    a.prolongate[par].clear();
+    apk_copy_plan_destroy(a.fill[par]);
+    a.fill[par] = nullptr;
+    for (int d = 0; d < 3; ++d) {
+      apk_copy_plan_destroy(a.coarse_bc[par][d]);
+      apk_copy_plan_destroy(a.fine_bc[par][d]);
+      a.coarse_bc[par][d] = a.fine_bc[par][d] = nullptr;
+    }
+  }
+  for (int d = 0; d < 3; ++d) {
+    for (apk_refine_plan *p : a.flux_restrict[d]) apk_refine_plan_destroy(p);
+    a.flux_restrict[d].clear();
+    apk_copy_plan_destroy(a.flux_copy[d]);
+    a.flux_copy[d] = nullptr;
+  }
+}
+
+// device arrays of a mesh of n blocks (state, register, primitives, fluxes, coarse buffers)
+int amr_allocate(apk_sim *s, size_t n, double *cons2[2], double **prim, double *flux[3], double **coarse) {
+  const size_t bytes = (size_t)s->nper * n * sizeof(double);
+  const size_t cbytes = (size_t)s->amr_geom.coarse_doubles * n * sizeof(double);
+  SIM_TRY(s, dev_alloc(s, "cons", bytes, &cons2[0]));
+  SIM_TRY(s, dev_alloc(s, "u1", bytes, &cons2[1]));
+  SIM_TRY(s, dev_alloc(s, "prim", bytes, prim));
+  SIM_TRY(s, dev_alloc(s, "coarse", cbytes, coarse));
+  SIM_HIP(s, hipMemsetAsync(cons2[0], 0, bytes, hs(s)));
+  SIM_HIP(s, hipMemsetAsync(cons2[1], 0, bytes, hs(s)));
+  SIM_HIP(s, hipMemsetAsync(*prim, 0, bytes, hs(s)));
+  SIM_HIP(s, hipMemsetAsync(*coarse, 0, cbytes, hs(s)));
+  const char *tags[3] = {"flux1", "flux2", "flux3"};
+  for (int d = 0; d < 3; ++d) {
+    flux[d] = nullptr;
+    if (d >= s->mesh.ndim) continue;
+    SIM_TRY(s, dev_alloc(s, tags[d], bytes, &flux[d]));
+    SIM_HIP(s, hipMemsetAsync(flux[d], 0, bytes, hs(s)));
+  }
+  return APK_OK;
+}
+
+// (re)build everything that depends on the block list: packs and the device plans
+int amr_rebuild(apk_sim *s) {
+  amr_sync_mesh(s);
+  BuildAmrPlans(*s->amr, s->amr_geom, s->amr_plans);
+  amr_destroy_device_plans(s);
+  auto &a = s->amr_dev;
+  const AmrPlans &p = s->amr_plans;
+  const auto &leaves = s->amr->leaves;
+  for (int par = 0; par < 2; ++par) {
+    SIM_TRY(s, amr_make_refine_plans(s, par, p.restrict_own, leaves, a.restrict_own[par]));
+    SIM_TRY(s, amr_make_refine_plans(s, par, p.prolongate, leaves, a.prolongate[par]));
+    SIM_TRY(s, amr_make_copy_plan(s, par, p.fill, &a.fill[par]));
+    for (int d = 0; d < 3; ++d) {
+      SIM_TRY(s, amr_make_copy_plan(s, par, p.coarse_bc[d], &a.coarse_bc[par][d]));
+      SIM_TRY(s, amr_make_copy_plan(s, par, p.fine_bc[d], &a.fine_bc[par][d]));
+    }
+  }
+  for (int d = 0; d < s->mesh.ndim; ++d) {
+    SIM_TRY(s, amr_make_refine_plans(s, 0, p.flux_restrict[d], leaves, a.flux_restrict[d]));
+    SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_copy[d], &a.flux_copy[d]));
+  }
+  return build_packs(s);
+}
+
+// the multilevel ghost exchange of the state in cons buffer `buf` (see amr.hpp)
+int amr_exchange(apk_sim *s, int buf) {
+  auto &a = s->amr_dev;
+  for (apk_refine_plan *p : a.restrict_own[buf]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
+  SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fill[buf], s->stream));
+  for (int d = 0; d < 3; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.coarse_bc[buf][d], s->stream));
+  for (apk_refine_plan *p : a.prolongate[buf]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
+  for (int d = 0; d < 3; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fine_bc[buf][d], s->stream));
+  return APK_OK;
+}
+
+// coarse-fine flux correction (hydro_driver.cpp:527-531): direction by direction, because the
+// restricted fluxes of all three directions share the blocks' coarse buffers
+int amr_flux_correction(apk_sim *s) {
+  auto &a = s->amr_dev;
+  for (int d = 0; d < s->mesh.ndim; ++d) {
+    if (a.flux_restrict[d].empty()) continue;
+    for (apk_refine_plan *p : a.flux_restrict[d]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
+    SIM_TRY(s, apk_copy_plan_run(s->ctx, a.flux_copy[d], s->stream));
+  }
+  return APK_OK;
 }
 
 // index windows of the split stages, per local block (see apk_stage_args.window)
@@ -1046,9 +1329,13 @@ int fill_derived(apk_sim *s) {
 // Hydro::PreStepMeshUserWorkInLoop (hydro.cpp:102-143)
 int pre_step(apk_sim *s) {
   if (!s->pkg.calc_c_h) return APK_OK;
-  double mindx = s->dx[0];  // CalculateGlobalMinDx on a uniform mesh (hydro.cpp:65-95)
-  if (s->mesh.Active(1)) mindx = std::fmin(mindx, s->dx[1]);
-  if (s->mesh.Active(2)) mindx = std::fmin(mindx, s->dx[2]);
+  // CalculateGlobalMinDx (hydro.cpp:65-95): over the blocks that exist, i.e. the finest level present
+  int finest = 0;
+  if (s->amr)
+    for (const AmrLeaf &l : s->amr->leaves) finest = std::max(finest, l.level);
+  double mindx = level_dx(s, finest, 0);
+  if (s->mesh.Active(1)) mindx = std::fmin(mindx, level_dx(s, finest, 1));
+  if (s->mesh.Active(2)) mindx = std::fmin(mindx, level_dx(s, finest, 2));
   double mins[3] = {mindx, s->pkg.dt_hyp, kHuge};
   if (s->have_comm && s->nranks > 1) {
     if (s->comm.allreduce_min(s->comm.user, mins, 3) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_min failed");
@@ -1119,6 +1406,222 @@ int turbulence_driving(apk_sim *s, double dt) {
 }
 
 // one stage of HydroDriver::MakeTaskCollection (hydro_driver.cpp:474-577)
+
+// ---- regridding -----------------------------------------------------------------------------
+int refinement_criterion(apk_sim *s, int *criterion, double *p0, double *p1) {
+  ParameterInput &pin = s->pin;
+  *criterion = -1;
+  *p0 = *p1 = 0.0;
+  try {
+    const std::string type = pin.GetOrAddString("refinement", "type", "unset");
+    if (type == "pressure_gradient") {
+      *criterion = APK_TAG_PRESSURE_GRADIENT;
+      *p0 = pin.GetOrAddReal("refinement", "threshold_pressure_gradient", 0.0);
+      if (!(*p0 > 0.)) throw std::runtime_error("Make sure to set refinement/threshold_pressure_gradient >0.");
+    } else if (type == "xyvelocity_gradient") {
+      *criterion = APK_TAG_VELOCITY_GRADIENT;
+      *p0 = pin.GetOrAddReal("refinement", "threshold_xyvelocity_gradient", 0.0);
+      if (!(*p0 > 0.)) throw std::runtime_error("Make sure to set refinement/threshold_xyvelocity_gradient >0.");
+    } else if (type == "maxdensity") {
+      *criterion = APK_TAG_MAX_DENSITY;
+      *p1 = pin.GetOrAddReal("refinement", "maxdensity_deref_below", 0.0);
+      *p0 = pin.GetOrAddReal("refinement", "maxdensity_refine_above", 0.0);
+      if (!(*p1 > 0.)) throw std::runtime_error("Make sure to set refinement/maxdensity_deref_below > 0.");
+      if (!(*p0 > 0.)) throw std::runtime_error("Make sure to set refinement/maxdensity_refine_above > 0.");
+      if (!(*p1 < *p0)) throw std::runtime_error("Make sure to set refinement/maxdensity_deref_below < refinement/maxdensity_refine_above");
+    } else {
+      throw std::runtime_error("refinement/type is unset: no refinement criterion to evaluate");
+    }
+  } catch (const std::exception &e) {
+    return fail(s, APK_ERR_INVALID, e.what());
+  }
+  return APK_OK;
+}
+
+// Apply per-block tags (+1 refine / -1 derefine / 0) to the tree -- Parthenon's
+// MeshRefinement::CheckRefinementCondition + Mesh::UpdateMeshBlockTree: refinement keeps the 2:1
+// balance by refining coarser neighbours first; a block asks for derefinement only after
+// derefine_count consecutive -1 tags, and 2^ndim siblings merge only if all of them ask and the
+// merged block would not touch a block two levels finer.  Returns whether the tree changed.
+bool amr_update_tree(apk_sim *s, const std::vector<int> &tags, bool allow_derefine) {
+  AmrTree &t = *s->amr;
+  const std::vector<AmrLeaf> old = t.leaves;
+  bool changed = false;
+  for (int lb = 0; lb < (int)old.size(); ++lb) {
+    if (tags[lb] < 0 && allow_derefine) t.SetDerefCount(lb, old[lb].deref_count + 1);
+    else t.SetDerefCount(lb, 0);
+  }
+  for (int lb = 0; lb < (int)old.size(); ++lb)
+    if (tags[lb] > 0 && old[lb].level < t.max_level) t.RefineBalanced(old[lb].level, old[lb].lx);
+  if (allow_derefine) {
+    std::unordered_set<uint64_t> seen;
+    for (int lb = 0; lb < (int)old.size(); ++lb) {
+      const AmrLeaf &l = old[lb];
+      if (l.level == 0 || tags[lb] >= 0) continue;
+      const int plx[3] = {l.lx[0] >> 1, l.lx[1] >> 1, l.lx[2] >> 1};
+      const uint64_t pkey = AmrTree::Key(l.level - 1, plx);
+      if (!seen.insert(pkey).second) continue;
+      bool all_ready = true;
+      t.ForEachChild(plx, [&](const int *, const int cl[3]) {
+        auto it = t.leafmap.find(AmrTree::Key(l.level, cl));
+        if (it == t.leafmap.end() || it->second.deref_count < s->amr_derefine_count) all_ready = false;
+      });
+      if (all_ready && t.CanMerge(l.level - 1, plx)) {
+        t.Merge(l.level - 1, plx);
+        s->amr_derefined += 1;
+      }
+    }
+  }
+  for (const AmrLeaf &l : old) {
+    if (!t.leafmap.count(AmrTree::Key(l.level, l.lx))) changed = true;
+    if (t.internal.count(AmrTree::Key(l.level, l.lx))) s->amr_refined += 1;
+  }
+  t.Reindex();
+  return changed;
+}
+
+// Move the state from the old block list to the new one: surviving blocks are copied, new fine
+// blocks are prolongated from their parent (through their coarse buffer), merged blocks collect
+// their children's restricted interiors.  Then everything that depends on the block list is rebuilt.
+int amr_transfer(apk_sim *s, const std::vector<AmrLeaf> &old) {
+  const AmrGeom &g = s->amr_geom;
+  AmrTree &t = *s->amr;
+  std::unordered_map<uint64_t, int> old_index;
+  for (int n = 0; n < (int)old.size(); ++n) old_index[AmrTree::Key(old[n].level, old[n].lx)] = n;
+  // the children's restricted interiors of the old mesh (ConsToPrim floors may have touched cons since
+  // the last exchange)
+  for (apk_refine_plan *p : s->amr_dev.restrict_own[s->cur]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
+  double *ncons2[2] = {nullptr, nullptr}, *nprim = nullptr, *nflux[3] = {nullptr, nullptr, nullptr}, *ncoarse = nullptr;
+  SIM_TRY(s, amr_allocate(s, t.leaves.size(), ncons2, &nprim, nflux, &ncoarse));
+  double *ocons = s->d_cons2[s->cur], *ocoarse = s->d_coarse;
+  std::vector<apk_copy_region> regs;
+  std::vector<AmrRefOp> prol;
+  auto region = [&](const double *src, const int64_t sst[4], const int slo[3], double *dst, const int64_t dst_st[4], const int dlo[3],
+                    const int ext[3]) {
+    apk_copy_region c{};
+    c.src = src;
+    c.dst = dst;
+    c.nvar = g.nvar;
+    c.flip_var = -1;
+    for (int d = 0; d < 3; ++d) {
+      c.ext[d] = ext[d];
+      c.src += slo[d] * sst[d];
+      c.dst += dlo[d] * dst_st[d];
+    }
+    for (int q = 0; q < 4; ++q) {
+      c.src_stride[q] = sst[q];
+      c.dst_stride[q] = dst_st[q];
+    }
+    regs.push_back(c);
+  };
+  const int zero[3] = {0, 0, 0};
+  for (int nb = 0; nb < (int)t.leaves.size(); ++nb) {
+    const AmrLeaf &l = t.leaves[nb];
+    double *dcons = ncons2[0] + (int64_t)nb * s->nper;
+    auto it = old_index.find(AmrTree::Key(l.level, l.lx));
+    if (it != old_index.end()) {
+      region(ocons + (int64_t)it->second * s->nper, g.fst, zero, dcons, g.fst, zero, g.fn);
+      continue;
+    }
+    const int plx[3] = {l.lx[0] >> 1, l.lx[1] >> 1, l.lx[2] >> 1};
+    it = (l.level > 0) ? old_index.find(AmrTree::Key(l.level - 1, plx)) : old_index.end();
+    if (it != old_index.end()) {  // refined: parent octant (+ cng cells around it) -> my coarse buffer
+      int slo[3], ext[3];
+      for (int d = 0; d < 3; ++d) {
+        ext[d] = g.cn[d];
+        slo[d] = g.act[d] ? g.fs[d] + (l.lx[d] & 1) * (g.mb[d] / 2) - g.cng : 0;
+      }
+      region(ocons + (int64_t)it->second * s->nper, g.fst, slo, ncoarse + (int64_t)nb * g.coarse_doubles, g.cst, zero, ext);
+      AmrRefOp op;
+      op.kind = APK_RO_PROLONGATE;
+      op.level = l.level;
+      op.src_kind = RK_COARSE, op.src_block = nb, op.dst_kind = RK_BLOCK, op.dst_block = nb, op.geom_block = nb;
+      for (int d = 0; d < 3; ++d) op.lo[d] = g.cs[d], op.hi[d] = g.ce[d];
+      prol.push_back(op);
+      continue;
+    }
+    // merged: children's coarse buffers -> my octants
+    bool ok = true;
+    t.ForEachChild(l.lx, [&](const int c[3], const int cl[3]) {
+      auto ci = old_index.find(AmrTree::Key(l.level + 1, cl));
+      if (ci == old_index.end()) {
+        ok = false;
+        return;
+      }
+      int dlo[3], ext[3];
+      for (int d = 0; d < 3; ++d) {
+        ext[d] = g.act[d] ? g.mb[d] / 2 : 1;
+        dlo[d] = g.act[d] ? g.fs[d] + c[d] * (g.mb[d] / 2) : 0;
+      }
+      region(ocoarse + (int64_t)ci->second * g.coarse_doubles, g.cst, g.cs, dcons, g.fst, dlo, ext);
+    });
+    if (!ok) return fail(s, APK_ERR_INVALID, "regridding: a new block has neither itself, its parent nor its children in the old mesh");
+  }
+  apk_copy_plan *cp = nullptr;
+  SIM_TRY(s, apk_copy_plan_create(s->ctx, regs.data(), (int)regs.size(), &cp));
+  int rc = apk_copy_plan_run(s->ctx, cp, s->stream);
+  SIM_HIP(s, hipStreamSynchronize(hs(s)));
+  apk_copy_plan_destroy(cp);
+  if (rc != APK_OK) return rc;
+  // swap in the new arrays
+  for (int p = 0; p < 2; ++p) dev_free(s, s->d_cons2[p]);
+  dev_free(s, s->d_prim2[0]);
+  dev_free(s, s->d_prim2[1]);
+  for (int d = 0; d < 3; ++d) dev_free(s, s->d_flux[d]);
+  dev_free(s, s->d_coarse);
+  s->d_cons2[0] = ncons2[0], s->d_cons2[1] = ncons2[1];
+  s->cur = 0, s->u1buf = 1, s->pcur = 0;
+  s->d_prim2[0] = nprim, s->d_prim2[1] = nullptr;
+  for (int d = 0; d < 3; ++d) s->d_flux[d] = nflux[d];
+  s->d_coarse = ncoarse;
+  SIM_TRY(s, amr_rebuild(s));
+  if (!prol.empty()) {
+    std::vector<apk_refine_plan *> plans;
+    SIM_TRY(s, amr_make_refine_plans(s, 0, prol, t.leaves, plans));
+    for (apk_refine_plan *p : plans) rc = (rc == APK_OK) ? apk_refine_plan_run(s->ctx, p, s->stream) : rc;
+    SIM_HIP(s, hipStreamSynchronize(hs(s)));
+    for (apk_refine_plan *p : plans) apk_refine_plan_destroy(p);
+    if (rc != APK_OK) return rc;
+  }
+  return APK_OK;
+}
+
+// fresh (zeroed) arrays for the current block list; the state is NOT carried over
+int amr_reallocate(apk_sim *s) {
+  SIM_HIP(s, hipStreamSynchronize(hs(s)));
+  for (int p = 0; p < 2; ++p) dev_free(s, s->d_cons2[p]);
+  dev_free(s, s->d_prim2[0]);
+  dev_free(s, s->d_prim2[1]);
+  for (int d = 0; d < 3; ++d) dev_free(s, s->d_flux[d]);
+  dev_free(s, s->d_coarse);
+  s->d_prim2[1] = nullptr;
+  s->cur = 0, s->u1buf = 1, s->pcur = 0;
+  SIM_TRY(s, amr_allocate(s, s->amr->leaves.size(), s->d_cons2, &s->d_prim2[0], s->d_flux, &s->d_coarse));
+  return amr_rebuild(s);
+}
+
+// Mesh::LoadBalancingAndAdaptiveMeshRefinement for one rank: tag, update the tree, move the data,
+// refill ghost zones and primitives on the new mesh
+int amr_regrid(apk_sim *s, bool *changed) {
+  *changed = false;
+  int criterion;
+  double p0, p1;
+  SIM_TRY(s, refinement_criterion(s, &criterion, &p0, &p1));
+  std::vector<int> tags(s->amr->leaves.size(), 0);
+  SIM_TRY(s, apk_tag_blocks(s->ctx, s->mu0(), criterion, p0, p1, tags.data(), nullptr, s->stream));
+  const std::vector<AmrLeaf> old = s->amr->leaves;
+  try {
+    if (!amr_update_tree(s, tags, true)) return APK_OK;
+  } catch (const std::exception &e) {
+    return fail(s, APK_ERR_INVALID, e.what());
+  }
+  SIM_TRY(s, amr_transfer(s, old));
+  SIM_TRY(s, exchange_ghosts(s));
+  SIM_TRY(s, fill_derived(s));
+  *changed = true;
+  return APK_OK;
+}
+
 int do_stage(apk_sim *s, int stage) {
   HydroPackage &pkg = s->pkg;
   const double g0 = s->gam0[stage - 1], g1 = s->gam1[stage - 1];
@@ -1223,6 +1726,7 @@ int do_stage(apk_sim *s, int stage) {
                                               beta_dt, &nfix, s->stream));
       s->fofc_total += nfix;
     }
+    if (s->amr) SIM_TRY(s, amr_flux_correction(s));
     SIM_TRY(s, apk_update_with_flux_divergence(s->ctx, s->mu0(), s->mu1(), g0, g1, beta_dt, s->stream));
     if (pkg.fluid == APK_FLUID_GLMMHD) {
       SIM_TRY(s, apk_dedner_source(s->ctx, s->mu0(), pkg.glmmhd_source_extended ? 1 : 0, pkg.glmmhd_alpha,
@@ -1334,6 +1838,12 @@ int apk_sim_create(const char *deck, const char *const *overrides, int noverride
     s->err = "apk_create failed: no usable gfx950 device (there is no CPU fallback)";
     return bail(rc);
   }
+  if (s->amr) {
+    if ((rc = amr_allocate(s, s->amr->leaves.size(), s->d_cons2, &s->d_prim2[0], s->d_flux, &s->d_coarse)) != APK_OK) return bail(rc);
+    if ((rc = amr_rebuild(s)) != APK_OK) return bail(rc);
+    if ((rc = build_copy_plans(s)) != APK_OK) return bail(rc);  // (empty: the uniform-mesh plans are unused)
+    return APK_OK;
+  }
   const size_t nlb = s->mesh.local_gids.size();
   const size_t bytes = (size_t)s->nper * nlb * sizeof(double);
   if ((rc = dev_alloc(s, "cons", bytes, &s->d_cons2[0])) != APK_OK) return bail(rc);
@@ -1377,6 +1887,8 @@ void apk_sim_destroy(apk_sim *s) {
         apk_pack_destroy(s->mu1_of[p][w]);
       }
     apk_fmft_destroy(s->fm_dev);
+    if (s->amr) amr_destroy_device_plans(s);
+    dev_free(s, s->d_coarse);
     for (auto &t : s->x1win) dev_free(s, reinterpret_cast<double *>(t.d));
     for (auto &t : s->dcwin) dev_free(s, reinterpret_cast<double *>(t.d));
     dev_free(s, reinterpret_cast<double *>(s->d_late_regions));
@@ -1414,6 +1926,7 @@ int apk_sim_set_overlap(apk_sim *s, int overlap) {
 long long apk_sim_overlapped_exchanges(const apk_sim *s) { return s ? s->overlapped : 0; }
 double apk_sim_loop_seconds(const apk_sim *s) { return s ? s->loop_seconds : 0.0; }
 int apk_sim_loop_cycles(const apk_sim *s) { return s ? s->perf_cycles : 0; }
+long long apk_sim_loop_zone_cycles(const apk_sim *s) { return s ? s->zone_cycles - s->perf_zone_mark : 0; }
 
 int apk_sim_initialize(apk_sim *s) {
   if (!s || s->host_only) return APK_ERR_INVALID;
@@ -1442,10 +1955,36 @@ int apk_sim_initialize(apk_sim *s) {
   s->ncycle = 0;
   s->dt = kHuge;
   s->fofc_total = 0;
+  s->zone_cycles = 0;
   s->pkg.mindx = kHuge;
   s->pkg.dt_hyp = kHuge;
   SIM_TRY(s, exchange_ghosts(s));
   SIM_TRY(s, fill_derived(s));
+  // adaptive meshes: tag the initial condition, refine, and evaluate the problem generator again on
+  // the new blocks (not a prolongation), level by level
+  for (int pass = 0; s->amr && s->amr_adaptive && pass < s->amr->max_level; ++pass) {
+    int criterion;
+    double p0, p1;
+    SIM_TRY(s, refinement_criterion(s, &criterion, &p0, &p1));
+    std::vector<int> tags(s->amr->leaves.size(), 0);
+    SIM_TRY(s, apk_tag_blocks(s->ctx, s->mu0(), criterion, p0, p1, tags.data(), nullptr, s->stream));
+    try {
+      if (!amr_update_tree(s, tags, false)) break;
+    } catch (const std::exception &e) {
+      return fail(s, APK_ERR_INVALID, e.what());
+    }
+    SIM_TRY(s, amr_reallocate(s));
+    try {
+      for (int lb = 0; lb < (int)s->mesh.local_gids.size(); ++lb) {
+        pgen_block(s, lb, host);
+        SIM_HIP(s, hipMemcpy(s->d_cons() + (int64_t)lb * s->nper, host.data(), sizeof(double) * s->nper, hipMemcpyHostToDevice));
+      }
+    } catch (const std::exception &e) {
+      return fail(s, APK_ERR_INVALID, e.what());
+    }
+    SIM_TRY(s, exchange_ghosts(s));
+    SIM_TRY(s, fill_derived(s));
+  }
   double est = kHuge;
   SIM_TRY(s, estimate_timestep(s, &est));
   set_global_dt(s, est);
@@ -1460,6 +1999,11 @@ int apk_sim_step(apk_sim *s) {
   for (int stage = 1; stage <= s->nstages; ++stage) SIM_TRY(s, do_stage(s, stage));
   s->time += s->dt;
   s->ncycle += 1;
+  s->zone_cycles += (long long)s->mesh.mb[0] * s->mesh.mb[1] * s->mesh.mb[2] * (long long)s->mesh.nblocks_total;
+  if (s->amr && s->amr_adaptive && s->amr_check_interval > 0 && s->ncycle % s->amr_check_interval == 0) {
+    bool changed = false;
+    SIM_TRY(s, amr_regrid(s, &changed));
+  }
   double est = kHuge;
   SIM_TRY(s, estimate_timestep(s, &est));
   set_global_dt(s, est);
@@ -1517,14 +2061,43 @@ int apk_sim_get_info(const apk_sim *s, apk_sim_info *o) {
   o->glmmhd_alpha = s->pkg.glmmhd_alpha;
   o->cells_per_block = s->mesh.sn;
   o->zones_local = (int64_t)s->mesh.mb[0] * s->mesh.mb[1] * s->mesh.mb[2] * (int64_t)s->mesh.local_gids.size();
-  o->zones_total = (int64_t)s->mesh.nx[0] * s->mesh.nx[1] * s->mesh.nx[2];
+  o->zones_total = s->amr ? o->zones_local : (int64_t)s->mesh.nx[0] * s->mesh.nx[1] * s->mesh.nx[2];
   return APK_OK;
 }
 
 int apk_sim_block_location(const apk_sim *s, int lb, int *gid, int loc[3]) {
   if (!s || lb < 0 || lb >= (int)s->mesh.local_gids.size()) return APK_ERR_INVALID;
   if (gid) *gid = s->mesh.local_gids[lb];
-  if (loc) s->mesh.Loc(s->mesh.local_gids[lb], loc);
+  if (loc && s->amr) {
+    for (int d = 0; d < 3; ++d) loc[d] = s->amr->leaves[lb].lx[d];
+  } else if (loc) {
+    s->mesh.Loc(s->mesh.local_gids[lb], loc);
+  }
+  return APK_OK;
+}
+
+// refinement level of a local block (0 on uniform meshes); with apk_sim_block_location's logical
+// location at that level this places the block: x_min = mesh x_min + loc * nx_block * dx / 2^level
+int apk_sim_block_level(const apk_sim *s, int lb) {
+  if (!s || lb < 0 || lb >= (int)s->mesh.local_gids.size()) return -1;
+  return block_level(s, lb);
+}
+
+int apk_sim_amr_stats(const apk_sim *s, long long *refined, long long *derefined, int *max_level, long long *zone_cycles) {
+  if (!s) return APK_ERR_INVALID;
+  if (refined) *refined = s->amr_refined;
+  if (derefined) *derefined = s->amr_derefined;
+  if (max_level) *max_level = s->amr ? s->amr->max_level : 0;
+  if (zone_cycles) *zone_cycles = s->zone_cycles;
+  return APK_OK;
+}
+
+// one regridding pass on demand (adaptive meshes do this every check_refine_interval cycles)
+int apk_sim_regrid(apk_sim *s, int *changed) {
+  if (!s || s->host_only || !s->amr) return APK_ERR_INVALID;
+  bool ch = false;
+  SIM_TRY(s, amr_regrid(s, &ch));
+  if (changed) *changed = ch ? 1 : 0;
   return APK_OK;
 }
 
@@ -1554,6 +2127,7 @@ int apk_sim_write_block(apk_sim *s, int lb, int field, const double *host_in) {
 
 int apk_sim_gather(apk_sim *s, int field, double *out) {
   if (!s || s->host_only || !out) return APK_ERR_INVALID;
+  if (s->amr) return fail(s, APK_ERR_UNSUPPORTED, "apk_sim_gather needs a uniform mesh: read refined meshes block by block");
   const Mesh &m = s->mesh;
   std::vector<double> host((size_t)s->nper);
   const int64_t NX = m.nx[0], NY = m.nx[1], NZ = m.nx[2];
@@ -1641,32 +2215,9 @@ int apk_sim_read_acc(apk_sim *s, int lb, double *host_out) {
 int apk_sim_check_refinement(apk_sim *s, int *tags, double *crit) {
   if (!s || s->host_only || !tags) return APK_ERR_INVALID;
   SIM_TRY(s, finish_pending(s));
-  ParameterInput &pin = s->pin;
-  int criterion = -1;
-  double p0 = 0.0, p1 = 0.0;
-  try {
-    const std::string type = pin.GetOrAddString("refinement", "type", "unset");
-    if (type == "pressure_gradient") {
-      criterion = APK_TAG_PRESSURE_GRADIENT;
-      p0 = pin.GetOrAddReal("refinement", "threshold_pressure_gradient", 0.0);
-      if (!(p0 > 0.)) throw std::runtime_error("Make sure to set refinement/threshold_pressure_gradient >0.");
-    } else if (type == "xyvelocity_gradient") {
-      criterion = APK_TAG_VELOCITY_GRADIENT;
-      p0 = pin.GetOrAddReal("refinement", "threshold_xyvelocity_gradient", 0.0);
-      if (!(p0 > 0.)) throw std::runtime_error("Make sure to set refinement/threshold_xyvelocity_gradient >0.");
-    } else if (type == "maxdensity") {
-      criterion = APK_TAG_MAX_DENSITY;
-      p1 = pin.GetOrAddReal("refinement", "maxdensity_deref_below", 0.0);
-      p0 = pin.GetOrAddReal("refinement", "maxdensity_refine_above", 0.0);
-      if (!(p1 > 0.)) throw std::runtime_error("Make sure to set refinement/maxdensity_deref_below > 0.");
-      if (!(p0 > 0.)) throw std::runtime_error("Make sure to set refinement/maxdensity_refine_above > 0.");
-      if (!(p1 < p0)) throw std::runtime_error("Make sure to set refinement/maxdensity_deref_below < refinement/maxdensity_refine_above");
-    } else {
-      throw std::runtime_error("refinement/type is unset: no refinement criterion to evaluate");
-    }
-  } catch (const std::exception &e) {
-    return fail(s, APK_ERR_INVALID, e.what());
-  }
+  int criterion;
+  double p0, p1;
+  SIM_TRY(s, refinement_criterion(s, &criterion, &p0, &p1));
   SIM_TRY(s, apk_tag_blocks(s->ctx, s->mu0(), criterion, p0, p1, tags, crit, s->stream));
   return APK_OK;
 }
@@ -1791,10 +2342,12 @@ int apk_sim_execute(apk_sim *s, const char *outdir, int *ncycles) {
   SIM_HIP(s, hipStreamSynchronize(hs(s)));
   auto t0 = std::chrono::steady_clock::now();
   s->perf_cycles = 0;
+  s->perf_zone_mark = s->zone_cycles;
   while (s->time < s->tlim && (s->nlim < 0 || n < s->nlim)) {
     if (n == perf_offset && n > 0) {
       SIM_HIP(s, hipStreamSynchronize(hs(s)));
       t0 = std::chrono::steady_clock::now();
+      s->perf_zone_mark = s->zone_cycles;
     }
     SIM_TRY(s, apk_sim_step(s));
     ++n;
@@ -1822,11 +2375,12 @@ int apk_sim_linear_wave_errors(apk_sim *s, double *rms, double *l1, double *mx) 
   if (!s || s->host_only || s->problem_id != "linear_wave" || !rms || !l1 || !mx) return APK_ERR_INVALID;
   const Mesh &m = s->mesh;
   std::vector<double> host((size_t)s->nper);
-  const double cellvol = s->dx[0] * s->dx[1] * s->dx[2];
   double acc[10] = {0};
   for (int lb = 0; lb < (int)m.local_gids.size(); ++lb) {
     int rc = apk_sim_read_block(s, lb, 0, host.data());
     if (rc != APK_OK) return rc;
+    LevelDxScope level_dx_scope(s, lb);
+    const double cellvol = s->dx[0] * s->dx[1] * s->dx[2];
     double x0[3];
     block_origin(s, lb, x0);
     for (int k = m.ks; k <= m.ke; ++k)
@@ -1962,14 +2516,27 @@ int apk_sim_peer(const apk_sim *s, int p, apk_peer_info *o) {
   return APK_OK;
 }
 
+// phases 0..5: the uniform-mesh plan; 10: multilevel fill copies, 11..13: coarse-buffer boundaries
+// x1..x3, 14..16: block boundaries x1..x3, 17..19: flux-correction copies x1..x3
+const std::vector<BoxRegion> *plan_of_phase(const apk_sim *s, int phase) {
+  if (phase >= 0 && phase < PH_COUNT) return &s->mesh.plan[phase];
+  if (!s->amr) return nullptr;
+  if (phase == 10) return &s->amr_plans.fill;
+  if (phase >= 11 && phase <= 13) return &s->amr_plans.coarse_bc[phase - 11];
+  if (phase >= 14 && phase <= 16) return &s->amr_plans.fine_bc[phase - 14];
+  if (phase >= 17 && phase <= 19) return &s->amr_plans.flux_copy[phase - 17];
+  return nullptr;
+}
+
 int apk_sim_plan_size(const apk_sim *s, int phase) {
-  if (!s || phase < 0 || phase >= PH_COUNT) return APK_ERR_INVALID;
-  return (int)s->mesh.plan[phase].size();
+  const std::vector<BoxRegion> *p = s ? plan_of_phase(s, phase) : nullptr;
+  return p ? (int)p->size() : APK_ERR_INVALID;
 }
 
 int apk_sim_plan_region(const apk_sim *s, int phase, int r, apk_region_info *o) {
-  if (!s || !o || phase < 0 || phase >= PH_COUNT || r < 0 || r >= (int)s->mesh.plan[phase].size()) return APK_ERR_INVALID;
-  const BoxRegion &b = s->mesh.plan[phase][r];
+  const std::vector<BoxRegion> *p = (s && o) ? plan_of_phase(s, phase) : nullptr;
+  if (!p || r < 0 || r >= (int)p->size()) return APK_ERR_INVALID;
+  const BoxRegion &b = (*p)[r];
   o->src_kind = b.src_kind;
   o->src_block = b.src_block;
   o->dst_kind = b.dst_kind;
@@ -1983,6 +2550,41 @@ int apk_sim_plan_region(const apk_sim *s, int phase, int r, apk_region_info *o) 
     o->src_stride[q] = b.src_stride[q];
     o->dst_stride[q] = b.dst_stride[q];
   }
+  return APK_OK;
+}
+
+// operator lists of the multilevel plans: 0 restrict-own, 1 prolongate, 2..4 flux restriction x1..x3
+const std::vector<AmrRefOp> *ops_of(const apk_sim *s, int which) {
+  if (!s->amr) return nullptr;
+  if (which == 0) return &s->amr_plans.restrict_own;
+  if (which == 1) return &s->amr_plans.prolongate;
+  if (which >= 2 && which <= 4) return &s->amr_plans.flux_restrict[which - 2];
+  return nullptr;
+}
+
+int apk_sim_amr_ops_size(const apk_sim *s, int which) {
+  const std::vector<AmrRefOp> *p = s ? ops_of(s, which) : nullptr;
+  return p ? (int)p->size() : APK_ERR_INVALID;
+}
+
+int apk_sim_amr_op(const apk_sim *s, int which, int n, apk_amr_op_info *o) {
+  const std::vector<AmrRefOp> *p = (s && o) ? ops_of(s, which) : nullptr;
+  if (!p || n < 0 || n >= (int)p->size()) return APK_ERR_INVALID;
+  const AmrRefOp &a = (*p)[n];
+  o->kind = a.kind;
+  o->level = a.level;
+  o->src_kind = a.src_kind;
+  o->src_block = a.src_block;
+  o->dst_kind = a.dst_kind;
+  o->dst_block = a.dst_block;
+  for (int q = 0; q < 3; ++q) {
+    o->lo[q] = a.lo[q];
+    o->hi[q] = a.hi[q];
+    o->dx[q] = level_dx(s, a.level, q);
+    o->xmin[q] = s->xmin[q] + (double)s->amr->leaves[a.geom_block].lx[q] * s->mesh.mb[q] * o->dx[q];
+  }
+  o->cng = s->amr_geom.cng;
+  o->coarse_doubles = s->amr_geom.coarse_doubles;
   return APK_OK;
 }
 

@@ -11,6 +11,7 @@
 
 #include "../../../include/apk_amd.h"
 #include "../../../include/apk_host.h"
+#include "amr.hpp"
 #include "mesh.hpp"
 #include "params.hpp"
 #include "turbulence.hpp"
@@ -135,6 +136,25 @@ struct apk_sim {
   };
   WindowTable x1win[3], dcwin[7];
   unsigned *d_late_regions = nullptr;  // per block: bit (sx+1)+3(sy+1)+9(sz+1) = that neighbour region is filled late
+  // mesh refinement (parthenon/mesh/refinement = static | adaptive; one rank): the forest of
+  // blocks, the index-box plans of the multilevel ghost exchange / flux correction and their device
+  // forms, one set per cons buffer the exchange can target
+  std::unique_ptr<apk::AmrTree> amr;
+  apk::AmrGeom amr_geom;
+  apk::AmrPlans amr_plans;
+  bool amr_adaptive = false;
+  int amr_derefine_count = 10, amr_check_interval = 1;
+  long long amr_refined = 0, amr_derefined = 0;  // blocks refined / merged so far
+  long long zone_cycles = 0;                     // sum over cycles of the interior cells updated
+  long long perf_zone_mark = 0;                  // its value where the timed part of apk_sim_execute began
+  double *d_coarse = nullptr;                    // [nblocks][amr_geom.coarse_doubles]
+  struct AmrDevice {
+    std::vector<apk_refine_plan *> restrict_own[2], prolongate[2], flux_restrict[3];
+    apk_copy_plan *fill[2] = {nullptr, nullptr};
+    apk_copy_plan *coarse_bc[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    apk_copy_plan *fine_bc[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    apk_copy_plan *flux_copy[3] = {nullptr, nullptr, nullptr};
+  } amr_dev;
   long long overlapped = 0;
   int perf_cycles = 0;        // cycles inside loop_seconds (after parthenon/time/perf_cycle_offset)
   double loop_seconds = 0.0;  // wall time of the last apk_sim_execute main loop (device synchronised)

@@ -2,7 +2,7 @@
 // fluxes) as batched index-box plans, and block tagging.  All of it is HBM-bound streaming work:
 // one thread per coarse cell and variable, i fastest, so reads of the coarse buffer and the
 // paired (fi, fi+1) writes of the fine array coalesce; one launch covers every box of the plan
-// (blockIdx.y = box), which is what matters for AMR meshes made of many 16^3 blocks.
+// (blockIdx.x = box), which is what matters for AMR meshes made of many 16^3 blocks.
 #include <cstring>
 #include <new>
 #include <vector>
@@ -124,10 +124,12 @@ APK_DEV void prolongate_cell(const apk_refine_geom &g, const RefineDims &r, cons
 }
 
 // RestrictAverage for cells (el = 0) and faces (el = 1..3): uniform weights, pairwise sums
-APK_DEV void restrict_cell(const apk_refine_geom &g, const RefineDims &r, const apk_refine_op &op, int el, int v,
-                           int k, int j, int i) {
+// (face_geom: the arrays have one more entry along the face direction, Parthenon's face fields;
+// otherwise both are cell-shaped and face i is the left face of cell i, apk_block_desc.flux)
+APK_DEV void restrict_cell(const apk_refine_geom &g, const RefineDims &r, const apk_refine_op &op, int el, bool face_geom,
+                           int v, int k, int j, int i) {
   int fn[3] = {r.fn[0], r.fn[1], r.fn[2]}, cn[3] = {r.cn[0], r.cn[1], r.cn[2]};
-  if (el >= 1) {
+  if (el >= 1 && face_geom) {
     fn[el - 1] += 1;
     cn[el - 1] += 1;
   }
@@ -163,11 +165,11 @@ APK_DEV void restrict_cell(const apk_refine_geom &g, const RefineDims &r, const 
 }
 
 __global__ void __launch_bounds__(256) refine_ops_kernel(apk_refine_geom g, int nvar, const apk_refine_op *ops) {
-  const apk_refine_op op = ops[blockIdx.y];
+  const apk_refine_op op = ops[blockIdx.x];
   const RefineDims r = refine_dims(g);
   const int e0 = op.hi[0] - op.lo[0] + 1, e1 = op.hi[1] - op.lo[1] + 1, e2 = op.hi[2] - op.lo[2] + 1;
   const int64_t cells = (int64_t)e0 * e1 * e2, items = cells * nvar;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < items; t += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t t = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; t < items; t += (int64_t)gridDim.y * blockDim.x) {
     const int v = (int)(t / cells);
     int64_t c = t - (int64_t)v * cells;
     const int i = op.lo[0] + (int)(c % e0);
@@ -179,7 +181,9 @@ __global__ void __launch_bounds__(256) refine_ops_kernel(apk_refine_geom g, int 
       else if (r.DIM == 2) prolongate_cell<2>(g, r, op, v, k, j, i);
       else prolongate_cell<1>(g, r, op, v, k, j, i);
     } else {
-      restrict_cell(g, r, op, op.kind - APK_RO_RESTRICT_CELL, v, k, j, i);
+      const bool flux_shaped = op.kind >= APK_RO_RESTRICT_FLUX1;
+      restrict_cell(g, r, op, flux_shaped ? op.kind - APK_RO_RESTRICT_FLUX1 + 1 : op.kind - APK_RO_RESTRICT_CELL,
+                    !flux_shaped, v, k, j, i);
     }
   }
 }
@@ -261,10 +265,12 @@ int apk_refine_plan_create(apk_ctx *ctx, const apk_refine_geom *geom, int nvar, 
   int64_t max_items = 0;
   for (int n = 0; n < nops; ++n) {
     const apk_refine_op &op = ops[n];
-    if (op.kind < APK_RO_PROLONGATE || op.kind > APK_RO_RESTRICT_FACE3 || !op.src || !op.dst)
+    if (op.kind < APK_RO_PROLONGATE || op.kind > APK_RO_RESTRICT_FLUX3 || !op.src || !op.dst)
       return set_err(ctx, APK_ERR_INVALID, "apk_refine_plan_create: bad op");
-    const int el = (op.kind >= APK_RO_RESTRICT_FACE1) ? op.kind - APK_RO_RESTRICT_CELL : 0;
-    if (el > r.DIM) return set_err(ctx, APK_ERR_INVALID, "apk_refine_plan_create: face direction is collapsed");
+    const bool flux_shaped = op.kind >= APK_RO_RESTRICT_FLUX1;
+    const int fdir = flux_shaped ? op.kind - APK_RO_RESTRICT_FLUX1 + 1 : 0;
+    const int el = (op.kind >= APK_RO_RESTRICT_FACE1 && !flux_shaped) ? op.kind - APK_RO_RESTRICT_CELL : 0;
+    if (el > r.DIM || fdir > r.DIM) return set_err(ctx, APK_ERR_INVALID, "apk_refine_plan_create: face direction is collapsed");
     int64_t cells = 1;
     for (int d = 0; d < 3; ++d) {
       // prolongation reads one coarse cell either side in active dimensions
@@ -303,7 +309,7 @@ int apk_refine_plan_run(apk_ctx *ctx, const apk_refine_plan *p, apk_stream_t str
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int64_t gx = (p->max_items + 255) / 256;
   if (gx > 4096) gx = 4096;  // grid-stride beyond that
-  hipLaunchKernelGGL(refine_ops_kernel, dim3((unsigned)gx, (unsigned)p->nops), dim3(256), 0, s, p->geom, p->nvar, p->d_ops);
+  hipLaunchKernelGGL(refine_ops_kernel, dim3((unsigned)p->nops, (unsigned)gx), dim3(256), 0, s, p->geom, p->nvar, p->d_ops);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? APK_OK : set_err(ctx, APK_ERR_DEVICE, "refine_ops launch", e);
 }

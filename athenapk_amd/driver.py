@@ -91,7 +91,56 @@ class _FmftHost:
         return out
 
 
-class Simulation(_FmftHost):
+class _MeshView:
+    """Block placement and ghost-exchange plans of a sim handle (valid without a GPU)."""
+
+    PHASES = {"local": 0, "pack": 1, "unpack": 2, "bc1": 3, "bc2": 4, "bc3": 5,
+              # refined meshes (src/.. host/amr.hpp): all copies of the multilevel exchange, the
+              # physical boundaries of coarse buffers / blocks, the flux-correction copies
+              "amr_fill": 10, "amr_coarse_bc1": 11, "amr_coarse_bc2": 12, "amr_coarse_bc3": 13,
+              "amr_bc1": 14, "amr_bc2": 15, "amr_bc3": 16, "amr_flux1": 17, "amr_flux2": 18, "amr_flux3": 19}
+    AMR_OPS = {"restrict_own": 0, "prolongate": 1, "flux_restrict1": 2, "flux_restrict2": 3, "flux_restrict3": 4}
+
+    def block_gid(self, lb):
+        gid = C.c_int(0)
+        loc = (C.c_int * 3)()
+        self.lib.apk_sim_block_location(self.h, lb, C.byref(gid), C.byref(loc))
+        return gid.value, tuple(loc)
+
+    def block_level(self, lb):
+        return self.lib.apk_sim_block_level(self.h, lb)
+
+    def regions(self, phase):
+        ph = self.PHASES[phase]
+        n = self.lib.apk_sim_plan_size(self.h, ph)
+        out = []
+        for r in range(max(n, 0)):
+            ri = L.RegionInfo()
+            self.lib.apk_sim_plan_region(self.h, ph, r, C.byref(ri))
+            out.append(ri)
+        return out
+
+    def amr_ops(self, which):
+        w = self.AMR_OPS[which]
+        out = []
+        for n in range(max(self.lib.apk_sim_amr_ops_size(self.h, w), 0)):
+            oi = L.AmrOpInfo()
+            self.lib.apk_sim_amr_op(self.h, w, n, C.byref(oi))
+            out.append(oi)
+        return out
+
+    def amr_stats(self):
+        """(blocks refined, sibling groups merged, deepest level allowed, zone-cycles done)"""
+        a, b, c, d = C.c_longlong(0), C.c_longlong(0), C.c_int(0), C.c_longlong(0)
+        self.lib.apk_sim_amr_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return a.value, b.value, c.value, d.value
+
+    def refresh_info(self):
+        self.lib.apk_sim_get_info(self.h, C.byref(self.info))
+        return self.info
+
+
+class Simulation(_FmftHost, _MeshView):
     """apk_sim: deck + overrides -> mesh partition, packs, ghost plans, stage loop (C++)."""
 
     def __init__(self, deck, overrides=(), rank=0, nranks=1, strict=False, use_torch_alloc=True,
@@ -228,6 +277,10 @@ class Simulation(_FmftHost):
         return self.lib.apk_sim_loop_seconds(self.h)
 
     @property
+    def loop_zone_cycles(self):
+        return self.lib.apk_sim_loop_zone_cycles(self.h)
+
+    @property
     def loop_cycles(self):
         return self.lib.apk_sim_loop_cycles(self.h)
 
@@ -284,11 +337,12 @@ class Simulation(_FmftHost):
                                             out.ctypes.data_as(L.c_dp)))
         return out
 
-    def block_gid(self, lb):
-        gid = C.c_int(0)
-        loc = (C.c_int * 3)()
-        self._check(self.lib.apk_sim_block_location(self.h, lb, C.byref(gid), C.byref(loc)))
-        return gid.value, tuple(loc)
+    def regrid(self):
+        """one tag -> refine / derefine -> transfer pass; True if the mesh changed"""
+        ch = C.c_int(0)
+        self._check(self.lib.apk_sim_regrid(self.h, C.byref(ch)))
+        self.refresh_info()
+        return bool(ch.value)
 
     def history(self):
         out = (C.c_double * 8)()
@@ -374,10 +428,8 @@ class Simulation(_FmftHost):
         return dt.value
 
 
-class HostPlan(_FmftHost):
+class HostPlan(_FmftHost, _MeshView):
     """Host-only view of a rank's mesh partition and ghost-exchange plan (no GPU needed)."""
-
-    PHASES = {"local": 0, "pack": 1, "unpack": 2, "bc1": 3, "bc2": 4, "bc3": 5}
 
     def __init__(self, deck, overrides=(), rank=0, nranks=1, strict=False):
         self.lib = L.load(strict)
@@ -400,28 +452,12 @@ class HostPlan(_FmftHost):
         except Exception:
             pass
 
-    def block_gid(self, lb):
-        gid = C.c_int(0)
-        loc = (C.c_int * 3)()
-        self.lib.apk_sim_block_location(self.h, lb, C.byref(gid), C.byref(loc))
-        return gid.value, tuple(loc)
-
     def peers(self):
         out = []
         for p in range(self.info.npeers):
             pi = L.PeerInfo()
             self.lib.apk_sim_peer(self.h, p, C.byref(pi))
             out.append((pi.rank, pi.send_count, pi.recv_count))
-        return out
-
-    def regions(self, phase):
-        ph = self.PHASES[phase]
-        n = self.lib.apk_sim_plan_size(self.h, ph)
-        out = []
-        for r in range(n):
-            ri = L.RegionInfo()
-            self.lib.apk_sim_plan_region(self.h, ph, r, C.byref(ri))
-            out.append(ri)
         return out
 
     @property

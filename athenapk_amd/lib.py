@@ -122,6 +122,12 @@ class RegionInfo(C.Structure):
                 ("src_stride", C.c_int64 * 4), ("dst_stride", C.c_int64 * 4)]
 
 
+class AmrOpInfo(C.Structure):
+    _fields_ = [("kind", C.c_int), ("level", C.c_int), ("src_kind", C.c_int), ("src_block", C.c_int),
+                ("dst_kind", C.c_int), ("dst_block", C.c_int), ("lo", C.c_int * 3), ("hi", C.c_int * 3),
+                ("xmin", C.c_double * 3), ("dx", C.c_double * 3), ("cng", C.c_int), ("coarse_doubles", C.c_int64)]
+
+
 # every symbol include/apk_amd.h and include/apk_host.h declare: name -> (restype, argtypes)
 def _signatures():
     i, d, vp, ll = C.c_int, C.c_double, C.c_void_p, C.c_longlong
@@ -218,6 +224,12 @@ def _signatures():
         "apk_sim_peer": (i, [vp, i, C.POINTER(PeerInfo)]),
         "apk_sim_plan_size": (i, [vp, i]),
         "apk_sim_plan_region": (i, [vp, i, i, C.POINTER(RegionInfo)]),
+        "apk_sim_amr_ops_size": (i, [vp, i]),
+        "apk_sim_amr_op": (i, [vp, i, i, C.POINTER(AmrOpInfo)]),
+        "apk_sim_loop_zone_cycles": (ll, [vp]),
+        "apk_sim_block_level": (i, [vp, i]),
+        "apk_sim_amr_stats": (i, [vp, C.POINTER(ll), C.POINTER(ll), C.POINTER(i), C.POINTER(ll)]),
+        "apk_sim_regrid": (i, [vp, C.POINTER(i)]),
     }
 
 

@@ -322,7 +322,13 @@ enum {
   APK_RO_RESTRICT_CELL = 1, /* src = fine array,   dst = coarse buffer */
   APK_RO_RESTRICT_FACE1 = 2,
   APK_RO_RESTRICT_FACE2 = 3,
-  APK_RO_RESTRICT_FACE3 = 4
+  APK_RO_RESTRICT_FACE3 = 4,
+  /* the same area average for fluxes stored the way apk_block_desc.flux stores them (cell-shaped
+   * arrays, face i = lower face of cell i), into a cell-shaped coarse buffer: the coarse-fine flux
+   * correction of the standalone driver */
+  APK_RO_RESTRICT_FLUX1 = 5,
+  APK_RO_RESTRICT_FLUX2 = 6,
+  APK_RO_RESTRICT_FLUX3 = 7
 };
 typedef struct apk_refine_op {
   int kind;

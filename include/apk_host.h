@@ -107,6 +107,15 @@ typedef struct apk_sim_info {
 int apk_sim_get_info(const apk_sim *sim, apk_sim_info *info);
 /* global block id and logical (bx,by,bz) of local block lb */
 int apk_sim_block_location(const apk_sim *sim, int lb, int *gid, int loc[3]);
+/* Mesh refinement (parthenon/mesh/refinement = static | adaptive, numlevel, derefine_count,
+ * <parthenon/static_refinement#>, <refinement>): refinement level of a local block (0 on uniform
+ * meshes); apk_sim_block_location then returns the logical location at that level.  Statistics:
+ * blocks refined / sibling groups merged so far, deepest level allowed, zone-cycles done.
+ * apk_sim_regrid runs one tag -> refine / derefine -> transfer pass on demand. */
+int apk_sim_block_level(const apk_sim *s, int lb);
+int apk_sim_amr_stats(const apk_sim *s, long long *refined, long long *derefined, int *max_level,
+                      long long *zone_cycles);
+int apk_sim_regrid(apk_sim *s, int *changed);
 /* device pointers of local block lb: field 0 = cons, 1 = prim, 2 = u1.cons */
 void *apk_sim_block_ptr(const apk_sim *sim, int lb, int field);
 /* copy the interior of every local block of `field` into a global-shaped host array
@@ -161,6 +170,9 @@ int apk_sim_execute(apk_sim *sim, const char *outdir, int *ncycles);
 double apk_sim_loop_seconds(const apk_sim *sim);
 /* cycles covered by apk_sim_loop_seconds: those after parthenon/time/perf_cycle_offset (default 0) */
 int apk_sim_loop_cycles(const apk_sim *sim);
+/* interior cells updated inside that timed loop, summed over its cycles (the block count of an
+ * adaptive mesh changes from cycle to cycle): zone-cycles / wallsecond = this / loop_seconds */
+long long apk_sim_loop_zone_cycles(const apk_sim *sim);
 /* circularly polarised Alfven wave (job/problem_id = cpaw, 3-D): L1 errors against the initial state
  * and their RMS (src/pgen/cpaw.cpp:127-186; err8 = d, M1, M2, M3, E, B1, B2, B3), and the
  * reference's "cpaw-errors.dat" row (cpaw.cpp:188-220). */
@@ -183,10 +195,13 @@ typedef struct apk_peer_info {
   void *send_buf, *recv_buf;      /* device pointers (NULL in host-only mode) */
 } apk_peer_info;
 int apk_sim_peer(const apk_sim *sim, int p, apk_peer_info *info);
-/* number of box copies in each phase: 0 local, 1 pack, 2 unpack, 3..5 physical BC x1..x3 */
+/* number of box copies in each phase: 0 local, 1 pack, 2 unpack, 3..5 physical BC x1..x3; on
+ * refined meshes 10 = all copies of the multilevel exchange, 11..13 = coarse-buffer boundaries,
+ * 14..16 = block boundaries, 17..19 = flux-correction copies x1..x3 */
 int apk_sim_plan_size(const apk_sim *sim, int phase);
 /* region r of a phase, with src/dst expressed as (kind, block, element offset):
- * kind 0 = local block cons, 1 = send buffer of peer `block`, 2 = recv buffer of peer `block` */
+ * kind 0 = local block cons, 1 = send buffer of peer `block`, 2 = recv buffer of peer `block`,
+ * 3 = coarse buffer of the block, 4..6 = its x1..x3 flux array */
 typedef struct apk_region_info {
   int src_kind, src_block, dst_kind, dst_block;
   int64_t src_off, dst_off;
@@ -194,6 +209,19 @@ typedef struct apk_region_info {
   int64_t src_stride[4], dst_stride[4];
 } apk_region_info;
 int apk_sim_plan_region(const apk_sim *sim, int phase, int r, apk_region_info *info);
+/* operator lists of the multilevel exchange, in execution order restrict-own (which = 0) ->
+ * phase 10 -> 11..13 -> prolongate (1) -> 14..16; flux correction: per direction d, which = 2 + d
+ * then phase 17 + d.  kind is an APK_RO_* value; index boxes in coarse-buffer indices. */
+typedef struct apk_amr_op_info {
+  int kind, level;
+  int src_kind, src_block, dst_kind, dst_block;
+  int lo[3], hi[3];
+  double xmin[3], dx[3]; /* lower interior corner and cell widths of the block the operator works on */
+  int cng;
+  int64_t coarse_doubles; /* allocation of one coarse buffer */
+} apk_amr_op_info;
+int apk_sim_amr_ops_size(const apk_sim *sim, int which);
+int apk_sim_amr_op(const apk_sim *sim, int which, int n, apk_amr_op_info *info);
 
 #ifdef __cplusplus
 }

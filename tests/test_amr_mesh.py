@@ -1,0 +1,192 @@
+"""Mesh refinement, host logic (no GPU): the block forest built from the deck, the 2:1 balance,
+and the index-box plans of the multilevel ghost exchange executed on the host with the oracle's
+operators (tests/amr_emulator.py)."""
+import numpy as np
+import pytest
+
+from amr_emulator import Emulator, placement
+
+SMR3 = ["parthenon/mesh/refinement=static", "parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=32",
+        "parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=8",
+        "parthenon/static_refinement0/x1min=-0.05", "parthenon/static_refinement0/x1max=0.05",
+        "parthenon/static_refinement0/x2min=-0.05", "parthenon/static_refinement0/x2max=0.05",
+        "parthenon/static_refinement0/x3min=0.05", "parthenon/static_refinement0/x3max=0.2",
+        "parthenon/static_refinement0/level=2"]
+SMR2 = ["parthenon/mesh/refinement=static", "parthenon/mesh/nx1=32", "parthenon/mesh/nx2=24", "parthenon/mesh/nx3=1",
+        "parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=1",
+        "parthenon/static_refinement0/x1min=-0.45", "parthenon/static_refinement0/x1max=-0.3",
+        "parthenon/static_refinement0/x2min=0.3", "parthenon/static_refinement0/x2max=0.45",
+        "parthenon/static_refinement0/level=3"]
+
+
+def _bc(kind):
+    return ["parthenon/mesh/%sx%d_bc=%s" % (io, d, kind) for d in (1, 2, 3) for io in "io"]
+
+
+def _view(overrides):
+    from athenapk_amd import decks, driver
+    return driver.HostPlan(decks.load("blast"), overrides)
+
+
+def _cell_centres(view, lb, pl):
+    i = view.info
+    lev, loc, x0, dx = pl[lb]
+    act = [True, i.mb[1] > 1, i.mb[2] > 1]
+    ax = []
+    for d in range(3):
+        n = i.mb[d] + 2 * i.ng if act[d] else 1
+        g = i.ng if act[d] else 0
+        ax.append(x0[d] + (np.arange(n) - g + 0.5) * dx[d])
+    return np.meshgrid(ax[2], ax[1], ax[0], indexing="ij")   # z, y, x arrays of shape (nk, nj, ni)
+
+
+@pytest.mark.parametrize("ov,nblocks,levels", [(SMR3, None, 2), (SMR2, None, 3)])
+def test_static_refinement_builds_a_balanced_forest(ov, nblocks, levels):
+    v = _view(ov)
+    pl = placement(v)
+    i = v.info
+    assert max(p[0] for p in pl) == levels
+    # the leaves tile the domain exactly once
+    vol = sum(np.prod([i.mb[d] * p[3][d] for d in range(i.ndim)]) for p in pl)
+    dom = np.prod([i.xmax[d] - i.xmin[d] for d in range(i.ndim)])
+    assert abs(vol - dom) < 1e-12
+    assert i.zones_total == i.nblocks_total * i.mb[0] * i.mb[1] * i.mb[2]
+    # 2:1 balance across faces, edges and corners: neighbouring leaves differ by at most one level
+    boxes = []
+    for lev, loc, x0, dx in pl:
+        boxes.append((lev, np.array(x0[:i.ndim]), np.array([x0[d] + i.mb[d] * dx[d] for d in range(i.ndim)])))
+    for a, (la, lo_a, hi_a) in enumerate(boxes):
+        for lb, lo_b, hi_b in boxes[a + 1:]:
+            touch = np.all(lo_a <= hi_b + 1e-12) and np.all(lo_b <= hi_a + 1e-12)
+            if touch:
+                assert abs(la - lb) <= 1
+    # Z-order: a block's children are contiguous
+    levs = [p[0] for p in pl]
+    assert levs.count(levels) % (2 ** i.ndim) == 0
+    # the region asked for is covered at the finest level
+    key = "parthenon/static_refinement0/"
+    reg = {o.split("=")[0][len(key):]: float(o.split("=")[1]) for o in ov if o.startswith(key) and "level" not in o}
+    mid = [0.5 * (reg["x%dmin" % (d + 1)] + reg["x%dmax" % (d + 1)]) for d in range(i.ndim)]
+    inside = [p for p, (lev, lo, hi) in zip(pl, boxes) if np.all(lo <= mid) and np.all(np.array(mid) < hi)]
+    assert len(inside) == 1 and inside[0][0] == levels
+
+
+@pytest.mark.parametrize("ov", [SMR3, SMR2], ids=["3d", "2d"])
+@pytest.mark.parametrize("bc", ["outflow", "reflecting", "periodic"])
+def test_multilevel_exchange_is_exact_for_linear_data(oracle, ov, bc):
+    """cell averages of a linear function are its values at the cell centres on every level, the
+    restriction of those is exact, and so is the minmod prolongation: after the exchange every ghost
+    cell inside the domain must hold the function's value at its own centre"""
+    v = _view(ov + _bc(bc))
+    pl = placement(v)
+    em = Emulator(v, oracle)
+    i = v.info
+    coef = np.array([[1.0, 0.3, -0.2, 0.5], [2.0, -1.1, 0.7, 0.25], [-0.5, 0.05, 0.9, -0.6], [0.1, 1.0, 1.0, 1.0],
+                     [3.0, -0.4, 0.2, 0.8]])
+    ng = i.ng
+    sl = (slice(None), slice(ng, -ng) if i.mb[2] > 1 else slice(None), slice(ng, -ng) if i.mb[1] > 1 else slice(None),
+          slice(ng, -ng))
+    exact = []
+    for lb in range(em.nb):
+        z, y, x = _cell_centres(v, lb, pl)
+        f = np.stack([c[0] + c[1] * x + c[2] * y + c[3] * z for c in coef])
+        exact.append(f)
+        em.cons[lb][:] = np.nan
+        em.cons[lb][sl] = f[sl]
+    em.exchange()
+    nchecked = 0
+    for lb in range(em.nb):
+        z, y, x = _cell_centres(v, lb, pl)
+        # (not next to a physical boundary: there the limited slope of the coarse cell sees the
+        # boundary condition's ghost value -- or, across a periodic boundary, the jump of the
+        # linear function -- and the prolongation is first order)
+        inside = np.ones(x.shape, bool)
+        for d, c in enumerate((x, y, z)):
+            if d < i.ndim:
+                inside &= (c > i.xmin[d] + 2 * pl[lb][3][d]) & (c < i.xmax[d] - 2 * pl[lb][3][d])
+        got = em.cons[lb]
+        assert not np.isnan(got).any(), "block %d has unfilled ghost cells" % lb
+        err = np.abs(got - exact[lb])[:, inside]
+        assert err.max() < 5e-14, "block %d (level %d): %.3e" % (lb, pl[lb][0], err.max())
+        nchecked += inside.sum()
+    assert nchecked > em.nb * i.mb[0] * i.mb[1] * i.mb[2]
+
+
+def test_multilevel_exchange_outflow_and_reflecting_ghosts(oracle):
+    """outside the domain: outflow copies the last interior cell, reflecting mirrors with the normal
+    momentum flipped -- also on blocks whose ghost zones were prolongated"""
+    for bc in ("outflow", "reflecting"):
+        v = _view(SMR2 + _bc(bc))
+        pl = placement(v)
+        em = Emulator(v, oracle)
+        i = v.info
+        ng = i.ng
+        rng = np.random.default_rng(5)
+        for lb in range(em.nb):
+            em.cons[lb][:] = np.nan
+            em.cons[lb][:, :, ng:-ng, ng:-ng] = rng.uniform(1.0, 2.0, (em.nvar, 1, i.mb[1], i.mb[0]))
+        em.exchange()
+        for lb in range(em.nb):
+            lev, loc, x0, dx = pl[lb]
+            u = em.cons[lb]
+            assert not np.isnan(u).any()
+            if loc[0] == 0:                      # inner x1 boundary
+                for g in range(ng):
+                    src = u[:, :, :, ng] if bc == "outflow" else u[:, :, :, 2 * ng - 1 - g]
+                    want = src.copy()
+                    if bc == "reflecting":
+                        want[1] = -want[1]
+                    assert np.array_equal(u[:, :, :, g], want)
+            if loc[1] == (i.nx[1] // i.mb[1]) * 2 ** lev - 1:   # outer x2 boundary
+                e = ng + i.mb[1] - 1
+                for g in range(ng):
+                    src = u[:, :, e, :] if bc == "outflow" else u[:, :, e - g, :]
+                    want = src.copy()
+                    if bc == "reflecting":
+                        want[2] = -want[2]
+                    assert np.array_equal(u[:, :, e + 1 + g, :], want)
+
+
+def test_flux_correction_plan_matches_fine_fluxes(oracle):
+    """after the correction the coarse block's face flux equals the area average of the fine
+    fluxes on every coarse-fine face, and is untouched elsewhere"""
+    v = _view(SMR3)
+    pl = placement(v)
+    em = Emulator(v, oracle)
+    i = v.info
+    rng = np.random.default_rng(11)
+    for d in range(3):
+        for lb in range(em.nb):
+            em.flux[d][lb][:] = rng.standard_normal(em.shape)
+    before = [[f.copy() for f in em.flux[d]] for d in range(3)]
+    em.flux_correction()
+    ng, mb = i.ng, i.mb[0]
+    changed = 0
+    for d in range(3):
+        regs = v.regions("amr_flux%d" % (d + 1))
+        assert len(regs) > 0
+        touched = [np.zeros(em.shape, bool) for _ in range(em.nb)]
+        for reg in regs:
+            cb, fb = reg.dst_block, reg.src_block
+            assert pl[fb][0] == pl[cb][0] + 1
+            # destination plane in (k, j, i)
+            off = reg.dst_off
+            k0, rem = divmod(off, em.shape[2] * em.shape[3])
+            j0, i0 = divmod(rem, em.shape[3])
+            ext = list(reg.ext)
+            sel = (slice(None), slice(k0, k0 + ext[2]), slice(j0, j0 + ext[1]), slice(i0, i0 + ext[0]))
+            touched[cb][sel] = True
+            # the fine block's face: its low face if it sits on my high side
+            lo_side = (i0 if d == 0 else (j0 if d == 1 else k0)) == ng   # my low face -> child's high face
+            fidx = ng + mb if lo_side else ng
+            ff = before[d][fb]
+            fsel = [slice(None), slice(ng, ng + mb), slice(ng, ng + mb), slice(ng, ng + mb)]
+            fsel[3 - d] = fidx
+            plane = ff[tuple(fsel)]          # (nvar, a, b) over the two transverse directions (slower, faster)
+            avg = 0.25 * (plane[:, 0::2, 0::2] + plane[:, 1::2, 0::2] + plane[:, 0::2, 1::2] + plane[:, 1::2, 1::2])
+            got = np.squeeze(em.flux[d][cb][sel], axis=3 - d)
+            assert np.allclose(got, avg, rtol=1e-14, atol=1e-15)
+            changed += 1
+        for lb in range(em.nb):
+            assert np.array_equal(em.flux[d][lb][~touched[lb]], before[d][lb][~touched[lb]])
+    assert changed > 0

@@ -1,0 +1,196 @@
+"""Mesh refinement on the GPU: the device's multilevel ghost exchange against the host emulation
+built on the oracle's operators, a uniformly refined forest against the uniform mesh it is
+equivalent to, conservation across coarse-fine faces, adaptive regridding on the blast problem
+(BASELINE config 5)."""
+import os
+
+import numpy as np
+import pytest
+
+from amr_emulator import Emulator, placement
+from test_amr_mesh import SMR2, SMR3, _bc, _cell_centres
+
+pytestmark = pytest.mark.gpu
+
+
+def _sim(deck, overrides, strict=True):
+    from athenapk_amd import decks, driver
+    return driver.Simulation(decks.load(deck), overrides, strict=strict)
+
+
+def _volumes(s):
+    i = s.refresh_info()
+    return [np.prod(p[3]) for p in placement(s)]
+
+
+def _totals(s, field="cons"):
+    """volume integrals of every conserved variable over the leaves"""
+    i = s.refresh_info()
+    ng = i.ng
+    tot = 0.0
+    for lb, vol in enumerate(_volumes(s)):
+        u = s.read_block(lb, field)
+        sl = (slice(None), slice(ng, -ng) if i.mb[2] > 1 else slice(None), slice(ng, -ng) if i.mb[1] > 1 else slice(None),
+              slice(ng, -ng))
+        tot = tot + u[sl].sum(axis=(1, 2, 3)) * vol
+    return tot
+
+
+@pytest.mark.parametrize("ov", [SMR3, SMR2], ids=["3d", "2d"])
+@pytest.mark.parametrize("bc", ["periodic", "outflow", "reflecting"])
+def test_device_exchange_matches_host_emulation(oracle, ov, bc):
+    s = _sim("blast", ov + _bc(bc)).initialize()
+    em = Emulator(s, oracle)
+    i = s.info
+    rng = np.random.default_rng(3)
+    for lb in range(em.nb):
+        u = rng.uniform(0.5, 2.0, em.shape)
+        em.cons[lb][:] = u
+        s.write_block(lb, u)
+    s.exchange_ghosts()
+    em.exchange()
+    for lb in range(em.nb):
+        assert np.array_equal(s.read_block(lb), em.cons[lb]), "block %d (level %d)" % (lb, s.block_level(lb))
+
+
+def test_uniformly_refined_forest_equals_the_uniform_mesh():
+    """a static region covering the whole domain gives level-1 blocks everywhere: the same cells as
+    the uniform mesh of twice the resolution, through the forest / multilevel code path"""
+    common = ["parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=8",
+              "parthenon/time/tlim=0.01", "problem/blast/radius_outer=0.1", "problem/blast/pressure_ratio=100"]
+    a = _sim("blast", common + ["parthenon/mesh/refinement=static", "parthenon/mesh/nx1=16", "parthenon/mesh/nx2=16",
+                                "parthenon/mesh/nx3=16", "parthenon/static_refinement0/level=1"] +
+             ["parthenon/static_refinement0/x%d%s=%s" % (d, m, v) for d in (1, 2, 3) for m, v in (("min", "-0.5"), ("max", "0.5"))]
+             ).initialize()
+    b = _sim("blast", common + ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=32"])
+    b.set_fused(False)
+    b.initialize()
+    assert a.refresh_info().nblocks_total == 64 and all(a.block_level(lb) == 1 for lb in range(64))
+    na, nb = a.run(), b.run()
+    assert na == nb and a.time == b.time
+    where = {b.block_gid(lb)[1]: lb for lb in range(64)}
+    for lb in range(64):
+        assert np.array_equal(a.read_block(lb), b.read_block(where[a.block_gid(lb)[1]]))
+
+
+@pytest.mark.parametrize("fluid,riemann,integrator", [("euler", "hlle", "vl2"), ("glmmhd", "hlld", "rk2"), ("euler", "hllc", "rk3")])
+def test_static_refinement_conserves_across_coarse_fine_faces(fluid, riemann, integrator):
+    """periodic box, blast through a statically refined region: with the flux correction mass,
+    momentum and energy are conserved to round-off (they are not without it)"""
+    ov = SMR3 + ["hydro/fluid=%s" % fluid, "hydro/riemann=%s" % riemann, "parthenon/time/integrator=%s" % integrator,
+                 "problem/blast/radius_outer=0.2", "problem/blast/pressure_ratio=100", "problem/blast/x3_0=0.1",
+                 "problem/blast/pressure_ambient=1.0", "parthenon/time/tlim=0.05"]
+    s = _sim("blast", ov, strict=False).initialize()
+    t0 = _totals(s)
+    n = s.run()
+    t1 = _totals(s)
+    assert n > 10
+    nh = 5
+    assert abs(t1[0] - t0[0]) < 1e-13 * t0[0]
+    assert abs(t1[4] - t0[4]) < 1e-13 * t0[4]
+    assert np.all(np.abs(t1[1:4] - t0[1:4]) < 1e-13 * t0[4])
+    if fluid == "glmmhd":
+        assert np.all(np.abs(t1[5:8] - t0[5:8]) < 1e-13)
+    # the blast crossed the refined region: the state is not trivial
+    assert s.history()[4] > 1e-4
+    # symmetric initial data about the x3 axis through the blast centre stay symmetric: x1 <-> -x1
+    pl = placement(s)
+    where = {(p[0], tuple(p[1])): lb for lb, p in enumerate(pl)}
+    i = s.info
+    ng = i.ng
+    for lb, (lev, loc, x0, dx) in enumerate(pl):
+        nb1 = (i.nx[0] // i.mb[0]) * 2 ** lev
+        mirror = where[(lev, (nb1 - 1 - loc[0], loc[1], loc[2]))]
+        u, m = s.read_block(lb), s.read_block(mirror)
+        assert np.allclose(u[0, ng:-ng, ng:-ng, ng:-ng], m[0, ng:-ng, ng:-ng, ng:-ng][:, :, ::-1], rtol=1e-11, atol=1e-13)
+
+
+def test_linear_wave_through_a_refined_patch():
+    """a sound wave crossing a statically refined patch: the L1 error stays at the level of the
+    uniform coarse mesh (second-order prolongation, conservative coarse-fine faces)"""
+    base = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=16", "parthenon/mesh/nx3=16", "parthenon/meshblock/nx1=8",
+            "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=8", "parthenon/time/integrator=vl2"]
+    smr = base + ["parthenon/mesh/refinement=static", "parthenon/static_refinement0/level=1",
+                  "parthenon/static_refinement0/x1min=1.0", "parthenon/static_refinement0/x1max=1.6",
+                  "parthenon/static_refinement0/x2min=0.3", "parthenon/static_refinement0/x2max=0.9",
+                  "parthenon/static_refinement0/x3min=0.3", "parthenon/static_refinement0/x3max=0.9"]
+    u = _sim("linear_wave3d", base, strict=False).initialize()
+    u.run()
+    a = _sim("linear_wave3d", smr, strict=False).initialize()
+    assert a.refresh_info().nblocks_total > 16
+    a.run()
+    eu, ea = u.linear_wave_errors()[0], a.linear_wave_errors()[0]
+    assert ea < 1.5 * eu and ea > 0.2 * eu
+
+
+def test_adaptive_blast_refines_the_shock_and_conserves():
+    """inputs/blast_3d_amr.in (the reference's deck: root 32^3 in 8^3 blocks, 3 levels, pressure-gradient
+    criterion): the initial condition is refined to the finest level around the hot sphere, the
+    refined region follows the shock, mass and energy are conserved to round-off, the mesh keeps
+    the problem's octant symmetry"""
+    s = _sim("blast_3d_amr", ["parthenon/time/tlim=0.02", "parthenon/mesh/derefine_count=5"], strict=False).initialize()
+    i = s.refresh_info()
+    pl = placement(s)
+    assert i.nblocks_total > 64 and max(p[0] for p in pl) == 2
+    # the finest blocks sit at the centre
+    for lev, loc, x0, dx in pl:
+        if lev == 2:
+            c = [x0[d] + 4 * dx[d] for d in range(3)]
+            assert max(abs(x) for x in c) < 0.2
+    t0 = _totals(s)
+    nb0 = i.nblocks_total
+    n = s.run()
+    i = s.refresh_info()
+    t1 = _totals(s)
+    refined, merged, maxlev, zc = s.amr_stats()
+    assert maxlev == 2 and refined > 0 and zc > n * 64 * 512
+    assert i.nblocks_total != nb0
+    assert abs(t1[0] - t0[0]) < 1e-12 * t0[0] and abs(t1[4] - t0[4]) < 1e-12 * t0[4]
+    # octant symmetry of the forest
+    pl = placement(s)
+    locs = {(p[0], tuple(p[1])) for p in pl}
+    for lev, loc in list(locs):
+        n1 = 4 * 2 ** lev
+        assert (lev, (n1 - 1 - loc[0], loc[1], loc[2])) in locs
+        assert (lev, (loc[1], loc[0], loc[2])) in locs
+    # the shock sits inside finest-level blocks: the largest pressure gradient is at level 2
+    best = (-1.0, -1)
+    tags, crit = s.check_refinement()
+    for lb, c in enumerate(crit):
+        if c > best[0]:
+            best = (c, s.block_level(lb))
+    assert best[1] == 2
+
+
+def test_adaptive_mesh_follows_an_advected_blob():
+    """inputs/advection_3d.in (the reference's deck: adaptive, 3 levels, maxdensity criterion): the
+    refined patch travels with the density blob -- blocks ahead are refined, blocks behind merge
+    again after derefine_count cycles -- and mass is conserved to round-off throughout"""
+    s = _sim("advection_3d", ["parthenon/time/tlim=0.25", "parthenon/mesh/derefine_count=5"], strict=False).initialize()
+    pl0 = placement(s)
+    assert max(p[0] for p in pl0) == 2
+    m0 = _totals(s)[0]
+
+    def finest_centre():
+        pl = placement(s)
+        c = np.array([[x0[d] + 4 * dx[d] for d in range(3)] for lev, loc, x0, dx in pl if lev == 2])
+        return c.mean(axis=0), len(c)
+
+    c0, n0 = finest_centre()
+    assert np.all(np.abs(c0) < 1e-12)
+    s.run()
+    refined, merged, maxlev, zc = s.amr_stats()
+    assert refined > 0 and merged > 0
+    c1, n1 = finest_centre()
+    # the box diagonal is crossed in tlim = 1: after a quarter of it the blob sits near (0.25, 0.25, 0.25)
+    assert np.all(np.abs(c1 - 0.25) < 0.07)
+    assert abs(_totals(s)[0] - m0) < 1e-13 * m0
+    rho = max(s.read_block(lb, "prim")[0].max() for lb in range(s.refresh_info().nblocks_total))
+    assert 1.3 < rho < 2.0101          # rho0 (1 + rho_ratio exp(..)), smeared by the PLM + HLLE advection
+
+
+def test_cli_runs_the_amr_deck(tmp_path, capsys):
+    from athenapk_amd import __main__ as cli
+    assert cli.main(["-i", "blast_3d_amr", "-d", str(tmp_path), "parthenon/time/tlim=0.01"]) == 0
+    out = capsys.readouterr().out
+    assert "zone-cycles/wallsecond" in out

@@ -534,7 +534,7 @@ def test_advection_matches_oracle_and_tags_the_blob(oracle):
     """One crossing of the box diagonal (tlim = 1 -> sqrt(3)/|v|), 8^3 meshblocks, PLM + HLLE VL2:
     bit for bit against the oracle; mass conserved; the deck's max-density criterion tags the
     blocks that hold the blob."""
-    s = _sim("advection_3d", [], strict=True).initialize()
+    s = _sim("advection_3d", ["parthenon/mesh/refinement=none"], strict=True).initialize()
     o = oracle.Sim(fluid="euler", recon="plm", riemann="hlle", integrator="vl2", nx=(32, 32, 32), mb=(8, 8, 8), ng=2,
                    xmin=(-0.5,) * 3, xmax=(0.5,) * 3, cfl=0.3, gamma=GAMMA_DECK)
     o.pgen("advection", vx=1.0, vy=1.0, vz=1.0, rho_ratio=1.01, rho_radius=0.0625, rho_fraction_edge=0.01)

@@ -82,7 +82,8 @@ def test_deck_defaults_and_overrides():
     (["hydro/fluid=mhd"], "Unknown fluid"),                                  # hydro.cpp:299
     (["hydro/riemann=hlld"], "no flux function"),                            # registry hydro.cpp:386-420
     (["parthenon/meshblock/nx1=48"], "multiple of the meshblock"),
-    (["parthenon/mesh/refinement=adaptive"], "uniform meshes only"),
+    (["parthenon/mesh/refinement=octree"], "none, static or adaptive"),
+    (["parthenon/mesh/refinement=adaptive", "parthenon/mesh/numlevel=2", "parthenon/mesh/nghost=3"], "even number of ghost"),
     (["job/problem_id=cluster"], "unknown job/problem_id"),
 ])
 def test_deck_errors_are_reported_not_fatal(overrides, msg):
