@@ -19,6 +19,13 @@ SMR2 = ["parthenon/mesh/refinement=static", "parthenon/mesh/nx1=32", "parthenon/
         "parthenon/static_refinement0/level=3"]
 
 
+SMR3_NG4 = [o for o in SMR3] + ["parthenon/mesh/nghost=4", "hydro/reconstruction=ppm"]
+SMR1 = ["parthenon/mesh/refinement=static", "parthenon/mesh/nx1=64", "parthenon/mesh/nx2=1", "parthenon/mesh/nx3=1",
+        "parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=1", "parthenon/meshblock/nx3=1",
+        "parthenon/static_refinement0/x1min=0.1", "parthenon/static_refinement0/x1max=0.2",
+        "parthenon/static_refinement0/level=3"]
+
+
 def _bc(kind):
     return ["parthenon/mesh/%sx%d_bc=%s" % (io, d, kind) for d in (1, 2, 3) for io in "io"]
 
@@ -71,7 +78,7 @@ def test_static_refinement_builds_a_balanced_forest(ov, nblocks, levels):
     assert len(inside) == 1 and inside[0][0] == levels
 
 
-@pytest.mark.parametrize("ov", [SMR3, SMR2], ids=["3d", "2d"])
+@pytest.mark.parametrize("ov", [SMR3, SMR2, SMR3_NG4, SMR1], ids=["3d", "2d", "3d_ng4", "1d"])
 @pytest.mark.parametrize("bc", ["outflow", "reflecting", "periodic"])
 def test_multilevel_exchange_is_exact_for_linear_data(oracle, ov, bc):
     """cell averages of a linear function are its values at the cell centres on every level, the

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from amr_emulator import Emulator, placement
-from test_amr_mesh import SMR2, SMR3, _bc, _cell_centres
+from test_amr_mesh import SMR1, SMR2, SMR3, SMR3_NG4, _bc, _cell_centres
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +36,7 @@ def _totals(s, field="cons"):
     return tot
 
 
-@pytest.mark.parametrize("ov", [SMR3, SMR2], ids=["3d", "2d"])
+@pytest.mark.parametrize("ov", [SMR3, SMR2, SMR3_NG4, SMR1], ids=["3d", "2d", "3d_ng4", "1d"])
 @pytest.mark.parametrize("bc", ["periodic", "outflow", "reflecting"])
 def test_device_exchange_matches_host_emulation(oracle, ov, bc):
     s = _sim("blast", ov + _bc(bc)).initialize()
@@ -103,6 +103,98 @@ def test_static_refinement_conserves_across_coarse_fine_faces(fluid, riemann, in
         mirror = where[(lev, (nb1 - 1 - loc[0], loc[1], loc[2]))]
         u, m = s.read_block(lb), s.read_block(mirror)
         assert np.allclose(u[0, ng:-ng, ng:-ng, ng:-ng], m[0, ng:-ng, ng:-ng, ng:-ng][:, :, ::-1], rtol=1e-11, atol=1e-13)
+
+
+def test_single_step_on_a_refined_mesh_conserves_in_the_parity_build():
+    """strict (-ffp-contract=off) build: one cycle with the blast crossing coarse-fine faces changes
+    the mass and energy integrals by round-off only"""
+    s = _sim("blast", SMR3 + ["problem/blast/radius_outer=0.2", "problem/blast/pressure_ratio=100",
+                              "problem/blast/x3_0=0.1", "parthenon/time/tlim=1e-3"]).initialize()
+    t0 = _totals(s)
+    s.step()
+    t1 = _totals(s)
+    assert abs(t1[0] - t0[0]) < 1e-14 and abs(t1[4] - t0[4]) < 1e-13 * t0[4]
+
+
+def test_fofc_scalars_and_ppm_on_a_refined_mesh():
+    """first-order flux correction, passive scalars and a four-ghost-cell stencil (PPM) on a refined
+    mesh: still conservative, scalars stay bounded"""
+    ov = SMR3_NG4 + ["hydro/nscalars=2", "hydro/first_order_flux_correct=true", "problem/blast/radius_outer=0.2",
+                     "problem/blast/pressure_ratio=1000", "problem/blast/x3_0=0.1", "parthenon/time/tlim=0.02",
+                     "parthenon/time/integrator=rk2"]
+    s = _sim("blast", ov, strict=False).initialize()
+    i = s.refresh_info()
+    assert i.ng == 4 and i.nscalars == 2
+    # scalar 0 = density, scalar 1 = 0.5 density: concentrations 1 and 0.5
+    for lb in range(i.nblocks_total):
+        u = s.read_block(lb)
+        u[5] = u[0]
+        u[6] = 0.5 * u[0]
+        s.write_block(lb, u)
+    s.exchange_ghosts()
+    s.fill_derived()
+    t0 = _totals(s)
+    n = s.run()
+    t1 = _totals(s)
+    assert n > 5
+    assert np.all(np.abs(t1[[0, 4, 5, 6]] - t0[[0, 4, 5, 6]]) < 1e-13 * t0[[0, 4, 5, 6]])
+    for lb in range(i.nblocks_total):
+        w = s.read_block(lb, "prim")
+        assert np.allclose(w[5], 1.0, atol=1e-12) and np.allclose(w[6], 0.5, atol=1e-12)
+
+
+def test_adaptive_blast_in_two_dimensions():
+    ov = ["parthenon/mesh/refinement=adaptive", "parthenon/mesh/numlevel=3", "parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64",
+          "parthenon/mesh/nx3=1", "parthenon/meshblock/nx1=16", "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=1",
+          "problem/blast/radius_outer=0.05", "problem/blast/pressure_ratio=1e4", "parthenon/time/tlim=0.02",
+          "parthenon/mesh/derefine_count=4"]
+    s = _sim("blast", ov, strict=False).initialize()
+    pl = placement(s)
+    assert max(p[0] for p in pl) == 2 and s.info.ndim == 2
+    t0 = _totals(s)
+    s.run()
+    t1 = _totals(s)
+    assert abs(t1[0] - t0[0]) < 1e-13 * t0[0] and abs(t1[4] - t0[4]) < 1e-13 * t0[4]
+    refined, merged, maxlev, zc = s.amr_stats()
+    assert refined > 0
+    # quadrant symmetry of the density field
+    pl = placement(s)
+    where = {(p[0], tuple(p[1])): lb for lb, p in enumerate(pl)}
+    ng = s.info.ng
+    for lb, (lev, loc, x0, dx) in enumerate(pl):
+        n1 = 4 * 2 ** lev
+        m = where[(lev, (n1 - 1 - loc[0], n1 - 1 - loc[1], 0))]
+        a, b = s.read_block(lb)[0, 0, ng:-ng, ng:-ng], s.read_block(m)[0, 0, ng:-ng, ng:-ng]
+        assert np.allclose(a, b[::-1, ::-1], rtol=1e-10, atol=1e-13)
+
+
+def test_sod_through_a_refined_patch_in_one_dimension(oracle):
+    """1-D Sod on [0,1] with three levels of static refinement around the contact: close to the
+    uniform fine solution, exactly conservative up to the boundary fluxes (outflow, untouched
+    states there)"""
+    one_d = ["parthenon/mesh/nx2=1", "parthenon/mesh/nx3=1", "parthenon/meshblock/nx2=1", "parthenon/meshblock/nx3=1"]
+    ov = one_d + ["parthenon/mesh/refinement=static", "parthenon/mesh/nx1=64", "parthenon/meshblock/nx1=8",
+          "parthenon/static_refinement0/x1min=0.45", "parthenon/static_refinement0/x1max=0.75",
+          "parthenon/static_refinement0/level=2", "parthenon/time/tlim=0.1"]
+    s = _sim("sod", ov, strict=False).initialize()
+    i = s.refresh_info()
+    assert i.ndim == 1 and max(p[0] for p in placement(s)) == 2
+    t0 = _totals(s)
+    s.run()
+    t1 = _totals(s)
+    assert abs(t1[0] - t0[0]) < 1e-13 and abs(t1[4] - t0[4]) < 1e-13
+    # against the uniform 256-cell run, compared on the finest blocks
+    u = _sim("sod", one_d + ["parthenon/mesh/nx1=256", "parthenon/meshblock/nx1=8", "parthenon/time/tlim=0.1"], strict=False)
+    u.set_fused(False)
+    u.initialize()
+    u.run()
+    ng = i.ng
+    fine = {u.block_gid(lb)[1][0]: u.read_block(lb)[0, 0, 0, ng:-ng] for lb in range(u.info.nblocks_total)}
+    err = 0.0
+    for lb, (lev, loc, x0, dx) in enumerate(placement(s)):
+        if lev == 2:
+            err = max(err, np.abs(s.read_block(lb)[0, 0, 0, ng:-ng] - fine[loc[0]]).max())
+    assert err < 0.02
 
 
 def test_linear_wave_through_a_refined_patch():
