@@ -472,4 +472,79 @@ inline void BuildAmrPlans(const AmrTree &t, const AmrGeom &g, AmrPlans &p) {
   }
 }
 
+
+// ---- distribution over ranks ----------------------------------------------------------------------
+// Contiguous ranges of the Z-ordered leaf list, equal block counts to within one (all blocks of a
+// refined mesh have the same shape, hence the same cost): rank r owns [first[r], first[r + 1]).
+struct AmrPartition {
+  std::vector<int> first;
+  void Build(int nblocks, int nranks) {
+    first.resize(nranks + 1);
+    for (int r = 0; r <= nranks; ++r) first[r] = (int)(((int64_t)r * nblocks) / nranks);
+  }
+  int Owner(int g) const { return (int)(std::upper_bound(first.begin(), first.end(), g) - first.begin()) - 1; }
+  int Local(int g) const { return g - first[Owner(g)]; }
+  int Count(int r) const { return first[r + 1] - first[r]; }
+};
+
+struct AmrMessages {  // one contiguous message per peer and direction
+  std::vector<PeerPlan> peers;  // sorted by rank
+  int PeerIndex(int rank) {
+    for (int p = 0; p < (int)peers.size(); ++p)
+      if (peers[p].rank == rank) return p;
+    PeerPlan pp;
+    pp.rank = rank;
+    auto it = std::lower_bound(peers.begin(), peers.end(), rank, [](const PeerPlan &a, int r) { return a.rank < r; });
+    return (int)(peers.insert(it, pp) - peers.begin());
+  }
+};
+
+// Split a list of box copies between (globally numbered) blocks into this rank's share: copies
+// between two of my blocks stay copies (with local block numbers), a copy out of one of my blocks into
+// another rank's becomes a pack into that peer's send buffer, the reverse an unpack.  Every rank
+// walks the same global list in the same order, so sender and receiver lay a message out alike.
+// Pass 1 (register_peers) must run over ALL lists that share a message set before pass 2, because
+// peer indices shift while peers are being added.
+inline void AmrRegisterPeers(const std::vector<BoxRegion> &global, const AmrPartition &src_part, const AmrPartition &dst_part,
+                             int rank, AmrMessages &msgs) {
+  for (const BoxRegion &r : global) {
+    const int so = src_part.Owner(r.src_block), to = dst_part.Owner(r.dst_block);
+    if (so == to) continue;
+    if (so == rank) msgs.PeerIndex(to);
+    if (to == rank) msgs.PeerIndex(so);
+  }
+}
+inline void AmrLocalize(const std::vector<BoxRegion> &global, const AmrPartition &src_part, const AmrPartition &dst_part, int rank,
+                        AmrMessages &msgs, std::vector<BoxRegion> &local, std::vector<BoxRegion> &pack,
+                        std::vector<BoxRegion> &unpack) {
+  for (const BoxRegion &g : global) {
+    const int so = src_part.Owner(g.src_block), to = dst_part.Owner(g.dst_block);
+    if (so != rank && to != rank) continue;
+    BoxRegion r = g;
+    const int64_t count = (int64_t)g.ext[0] * g.ext[1] * g.ext[2] * g.nvar;
+    if (so == rank) r.src_block = g.src_block - src_part.first[rank];
+    if (to == rank) r.dst_block = g.dst_block - dst_part.first[rank];
+    if (so == to) {
+      local.push_back(r);
+    } else if (so == rank) {
+      const int p = msgs.PeerIndex(to);
+      r.dst_kind = RK_SEND;
+      r.dst_block = p;
+      r.dst_off = msgs.peers[p].send_count;
+      Mesh::Compact(g.ext, r.dst_stride);
+      r.flip_var = -1;  // (boundary conditions are never remote)
+      msgs.peers[p].send_count += count;
+      pack.push_back(r);
+    } else {
+      const int p = msgs.PeerIndex(so);
+      r.src_kind = RK_RECV;
+      r.src_block = p;
+      r.src_off = msgs.peers[p].recv_count;
+      Mesh::Compact(g.ext, r.src_stride);
+      msgs.peers[p].recv_count += count;
+      unpack.push_back(r);
+    }
+  }
+}
+
 }  // namespace apk

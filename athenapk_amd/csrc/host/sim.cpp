@@ -160,28 +160,74 @@ void hydro_initialize(apk_sim *s) {
 // derefine_count, <parthenon/static_refinement#> blocks) ------------------------------------------
 // cell width on a refinement level (collapsed dimensions are not refined)
 double level_dx(const apk_sim *s, int level, int d) { return s->mesh.Active(d) ? s->dx[d] / (double)(1 << level) : s->dx[d]; }
-int block_level(const apk_sim *s, int lb) { return s->amr ? s->amr->leaves[lb].level : 0; }
+// the leaf behind local block lb (this rank owns a contiguous range of the Z-ordered leaf list)
+const AmrLeaf &amr_leaf(const apk_sim *s, int lb) { return s->amr->leaves[s->amr_part.first[s->rank] + lb]; }
+int block_level(const apk_sim *s, int lb) { return s->amr ? amr_leaf(s, lb).level : 0; }
 
 // refresh the uniform-mesh bookkeeping the rest of the driver reads (block counts, ids) from the tree
 void amr_sync_mesh(apk_sim *s) {
   Mesh &m = s->mesh;
   const int n = (int)s->amr->leaves.size();
+  if (n < s->nranks) throw std::runtime_error("fewer meshblocks than ranks");
+  s->amr_part.Build(n, s->nranks);
   m.nblocks_total = n;
-  m.local_gids.resize(n);
+  m.local_gids.clear();
   m.gid_local.clear();
   m.gid_rank.assign(n, 0);
   for (int g = 0; g < n; ++g) {
-    m.local_gids[g] = g;
-    m.gid_local[g] = g;
+    m.gid_rank[g] = s->amr_part.Owner(g);
+    if (m.gid_rank[g] == s->rank) {
+      m.gid_local[g] = (int)m.local_gids.size();
+      m.local_gids.push_back(g);
+    }
   }
   m.peers.clear();
   for (auto &p : m.plan) p.clear();
 }
 
+// the global plans of the current forest and this rank's share of them
+void amr_localize(apk_sim *s) {
+  BuildAmrPlans(*s->amr, s->amr_geom, s->amr_plans);
+  const AmrPlans &g = s->amr_plans;
+  const AmrPartition &part = s->amr_part;
+  auto &l = s->amr_local;
+  l = apk_sim::AmrLocalPlans();
+  const int rank = s->rank;
+  auto take_ops = [&](const std::vector<AmrRefOp> &in, std::vector<AmrRefOp> &out) {
+    for (AmrRefOp o : in) {
+      if (part.Owner(o.dst_block) != rank) continue;  // (these operators work inside one block)
+      o.src_block -= part.first[rank];
+      o.dst_block -= part.first[rank];
+      out.push_back(o);
+    }
+  };
+  auto take_bc = [&](const std::vector<BoxRegion> &in, std::vector<BoxRegion> &out) {
+    for (BoxRegion r : in) {
+      if (part.Owner(r.dst_block) != rank) continue;
+      r.src_block -= part.first[rank];
+      r.dst_block -= part.first[rank];
+      out.push_back(r);
+    }
+  };
+  take_ops(g.restrict_own, l.restrict_own);
+  take_ops(g.prolongate, l.prolongate);
+  for (int d = 0; d < 3; ++d) {
+    take_ops(g.flux_restrict[d], l.flux_restrict[d]);
+    take_bc(g.coarse_bc[d], l.coarse_bc[d]);
+    take_bc(g.fine_bc[d], l.fine_bc[d]);
+  }
+  s->amr_halo.plan = AmrMessages();
+  s->amr_fluxmsg.plan = AmrMessages();
+  AmrRegisterPeers(g.fill, part, part, rank, s->amr_halo.plan);
+  AmrLocalize(g.fill, part, part, rank, s->amr_halo.plan, l.fill, l.fill_pack, l.fill_unpack);
+  for (int d = 0; d < 3; ++d) AmrRegisterPeers(g.flux_copy[d], part, part, rank, s->amr_fluxmsg.plan);
+  for (int d = 0; d < 3; ++d)
+    AmrLocalize(g.flux_copy[d], part, part, rank, s->amr_fluxmsg.plan, l.flux_copy[d], l.flux_pack[d], l.flux_unpack[d]);
+}
+
 void amr_initialize(apk_sim *s, bool adaptive) {
   ParameterInput &pin = s->pin;
   Mesh &m = s->mesh;
-  if (s->nranks != 1) throw std::runtime_error("mesh refinement runs on one rank in this build (nranks = 1)");
   if (s->problem_id == "turbulence") throw std::runtime_error("the turbulence driver needs a uniform mesh");
   s->amr.reset(new AmrTree());
   AmrTree &t = *s->amr;
@@ -251,8 +297,8 @@ void amr_initialize(apk_sim *s, bool adaptive) {
     }
   }
   t.Reindex();
-  BuildAmrPlans(t, g, s->amr_plans);
   amr_sync_mesh(s);
+  amr_localize(s);
 }
 
 void mesh_initialize(apk_sim *s) {
@@ -293,7 +339,7 @@ double xc(const apk_sim *s, const double x0[3], int d, int idx) {
 }
 void block_origin(const apk_sim *s, int lb, double x0[3]) {
   if (s->amr) {  // in cells of the block's own level (s->dx is set to that level's widths meanwhile)
-    for (int d = 0; d < 3; ++d) x0[d] = (double)s->amr->leaves[lb].lx[d] * s->mesh.mb[d];
+    for (int d = 0; d < 3; ++d) x0[d] = (double)amr_leaf(s, lb).lx[d] * s->mesh.mb[d];
     return;
   }
   int bc[3];
@@ -308,7 +354,7 @@ struct LevelDxScope {
   LevelDxScope(apk_sim *sim, int lb) : s(sim) {
     for (int d = 0; d < 3; ++d) {
       saved[d] = s->dx[d];
-      if (s->amr && s->mesh.Active(d)) s->dx[d] = saved[d] / (double)(1 << s->amr->leaves[lb].level);
+      if (s->amr && s->mesh.Active(d)) s->dx[d] = saved[d] / (double)(1 << amr_leaf(s, lb).level);
     }
   }
   ~LevelDxScope() {
@@ -1058,19 +1104,21 @@ int exchange_ghosts(apk_sim *s, bool c2p = false) {
 
 
 // ---- mesh refinement on the device --------------------------------------------------------------
-double *amr_base(apk_sim *s, int parity, int kind, int block) {
+double *amr_base(apk_sim *s, int parity, int kind, int block, const apk_sim::MsgSet *msgs) {
   switch (kind) {
   case RK_BLOCK: return s->d_cons2[parity] + (int64_t)block * s->nper;
   case RK_COARSE: return s->d_coarse + (int64_t)block * s->amr_geom.coarse_doubles;
   case RK_FLUX1: case RK_FLUX2: case RK_FLUX3: return s->d_flux[kind - RK_FLUX1] + (int64_t)block * s->nper;
+  case RK_SEND: return msgs ? msgs->send[block] : nullptr;
+  case RK_RECV: return msgs ? msgs->recv[block] : nullptr;
   default: return nullptr;
   }
 }
 
-apk_copy_region amr_copy_region(apk_sim *s, int parity, const BoxRegion &r) {
+apk_copy_region to_copy_region(const BoxRegion &r, const double *src, double *dst) {
   apk_copy_region c{};
-  c.src = amr_base(s, parity, r.src_kind, r.src_block) + r.src_off;
-  c.dst = amr_base(s, parity, r.dst_kind, r.dst_block) + r.dst_off;
+  c.src = src + r.src_off;
+  c.dst = dst + r.dst_off;
   for (int q = 0; q < 3; ++q) c.ext[q] = r.ext[q];
   c.nvar = r.nvar;
   for (int q = 0; q < 4; ++q) {
@@ -1081,15 +1129,17 @@ apk_copy_region amr_copy_region(apk_sim *s, int parity, const BoxRegion &r) {
   return c;
 }
 
-int amr_make_copy_plan(apk_sim *s, int parity, const std::vector<BoxRegion> &regions, apk_copy_plan **out) {
+int amr_make_copy_plan(apk_sim *s, int parity, const std::vector<BoxRegion> &regions, const apk_sim::MsgSet *msgs,
+                       apk_copy_plan **out) {
   std::vector<apk_copy_region> regs;
-  for (const BoxRegion &r : regions) regs.push_back(amr_copy_region(s, parity, r));
+  for (const BoxRegion &r : regions)
+    regs.push_back(to_copy_region(r, amr_base(s, parity, r.src_kind, r.src_block, msgs), amr_base(s, parity, r.dst_kind, r.dst_block, msgs)));
   return apk_copy_plan_create(s->ctx, regs.data(), (int)regs.size(), out);
 }
 
 // one refine plan per level: the operators difference cell-centre coordinates of that level
-int amr_make_refine_plans(apk_sim *s, int parity, const std::vector<AmrRefOp> &ops, const std::vector<AmrLeaf> &leaves,
-                          std::vector<apk_refine_plan *> &out) {
+// (ops carry LOCAL block numbers for the arrays and the GLOBAL leaf number for the geometry)
+int amr_make_refine_plans(apk_sim *s, int parity, const std::vector<AmrRefOp> &ops, std::vector<apk_refine_plan *> &out) {
   for (apk_refine_plan *p : out) apk_refine_plan_destroy(p);
   out.clear();
   const AmrGeom &g = s->amr_geom;
@@ -1099,12 +1149,12 @@ int amr_make_refine_plans(apk_sim *s, int parity, const std::vector<AmrRefOp> &o
       if (o.level != level) continue;
       apk_refine_op d{};
       d.kind = o.kind;
-      d.src = amr_base(s, parity, o.src_kind, o.src_block);
-      d.dst = amr_base(s, parity, o.dst_kind, o.dst_block);
+      d.src = amr_base(s, parity, o.src_kind, o.src_block, nullptr);
+      d.dst = amr_base(s, parity, o.dst_kind, o.dst_block, nullptr);
       for (int q = 0; q < 3; ++q) {
         d.lo[q] = o.lo[q];
         d.hi[q] = o.hi[q];
-        d.xmin[q] = s->xmin[q] + (double)leaves[o.geom_block].lx[q] * g.mb[q] * level_dx(s, level, q);
+        d.xmin[q] = s->xmin[q] + (double)s->amr->leaves[o.geom_block].lx[q] * g.mb[q] * level_dx(s, level, q);
       }
       dev.push_back(d);
     }
@@ -1131,7 +1181,9 @@ void amr_destroy_device_plans(apk_sim *s) {
     a.restrict_own[par].clear();
     a.prolongate[par].clear();
     apk_copy_plan_destroy(a.fill[par]);
-    a.fill[par] = nullptr;
+    apk_copy_plan_destroy(a.fill_pack[par]);
+    apk_copy_plan_destroy(a.fill_unpack[par]);
+    a.fill[par] = a.fill_pack[par] = a.fill_unpack[par] = nullptr;
     for (int d = 0; d < 3; ++d) {
       apk_copy_plan_destroy(a.coarse_bc[par][d]);
       apk_copy_plan_destroy(a.fine_bc[par][d]);
@@ -1142,11 +1194,63 @@ void amr_destroy_device_plans(apk_sim *s) {
     for (apk_refine_plan *p : a.flux_restrict[d]) apk_refine_plan_destroy(p);
     a.flux_restrict[d].clear();
     apk_copy_plan_destroy(a.flux_copy[d]);
-    a.flux_copy[d] = nullptr;
+    apk_copy_plan_destroy(a.flux_pack[d]);
+    apk_copy_plan_destroy(a.flux_unpack[d]);
+    a.flux_copy[d] = a.flux_pack[d] = a.flux_unpack[d] = nullptr;
   }
 }
 
-// device arrays of a mesh of n blocks (state, register, primitives, fluxes, coarse buffers)
+// message buffers of a set: (re)allocated when a message outgrows its buffer, never shrunk
+int amr_ensure_buffers(apk_sim *s, apk_sim::MsgSet &m, const char *name) {
+  const size_t np = m.plan.peers.size();
+  // (buffers belong to positions in the rank-sorted peer list, not to ranks: they are scratch)
+  if (m.send.size() != np) {
+    for (double *b : m.send) dev_free(s, b);
+    for (double *b : m.recv) dev_free(s, b);
+    m.send.assign(np, nullptr);
+    m.recv.assign(np, nullptr);
+    m.send_cap.assign(np, 0);
+    m.recv_cap.assign(np, 0);
+  }
+  for (size_t p = 0; p < np; ++p) {
+    const PeerPlan &pp = m.plan.peers[p];
+    if (pp.send_count > m.send_cap[p]) {
+      dev_free(s, m.send[p]);
+      m.send_cap[p] = pp.send_count + pp.send_count / 4;
+      SIM_TRY(s, dev_alloc(s, (std::string(name) + ":send:" + std::to_string(pp.rank)).c_str(), m.send_cap[p] * sizeof(double), &m.send[p]));
+    }
+    if (pp.recv_count > m.recv_cap[p]) {
+      dev_free(s, m.recv[p]);
+      m.recv_cap[p] = pp.recv_count + pp.recv_count / 4;
+      SIM_TRY(s, dev_alloc(s, (std::string(name) + ":recv:" + std::to_string(pp.rank)).c_str(), m.recv_cap[p] * sizeof(double), &m.recv[p]));
+    }
+  }
+  s->msg_generation += 1;
+  return APK_OK;
+}
+
+void amr_free_buffers(apk_sim *s, apk_sim::MsgSet &m) {
+  for (double *b : m.send) dev_free(s, b);
+  for (double *b : m.recv) dev_free(s, b);
+  m.send.clear();
+  m.recv.clear();
+  m.send_cap.clear();
+  m.recv_cap.clear();
+}
+
+// one message per peer: hand the set to the comm ops (apk_sim_peer reports the active set)
+int amr_exchange_messages(apk_sim *s, const apk_sim::MsgSet &m) {
+  if (m.plan.peers.empty()) return APK_OK;
+  if (!s->have_comm || !s->comm.exchange) return fail(s, APK_ERR_INVALID, "remote neighbours but no comm ops");
+  if (s->active_msgs != &m) {
+    s->active_msgs = &m;
+    s->msg_generation += 1;
+  }
+  if (s->comm.exchange(s->comm.user) != 0) return fail(s, APK_ERR_DEVICE, "message exchange failed");
+  return APK_OK;
+}
+
+// device arrays of a mesh of n local blocks (state, register, primitives, fluxes, coarse buffers)
 int amr_allocate(apk_sim *s, size_t n, double *cons2[2], double **prim, double *flux[3], double **coarse) {
   const size_t bytes = (size_t)s->nper * n * sizeof(double);
   const size_t cbytes = (size_t)s->amr_geom.coarse_doubles * n * sizeof(double);
@@ -1168,26 +1272,35 @@ int amr_allocate(apk_sim *s, size_t n, double *cons2[2], double **prim, double *
   return APK_OK;
 }
 
-// (re)build everything that depends on the block list: packs and the device plans
+// (re)build everything that depends on the block list: packs, message buffers, device plans
 int amr_rebuild(apk_sim *s) {
-  amr_sync_mesh(s);
-  BuildAmrPlans(*s->amr, s->amr_geom, s->amr_plans);
+  try {
+    amr_sync_mesh(s);
+    amr_localize(s);
+  } catch (const std::exception &e) {
+    return fail(s, APK_ERR_INVALID, e.what());
+  }
+  SIM_TRY(s, amr_ensure_buffers(s, s->amr_halo, "halo"));
+  SIM_TRY(s, amr_ensure_buffers(s, s->amr_fluxmsg, "fluxcorr"));
   amr_destroy_device_plans(s);
   auto &a = s->amr_dev;
-  const AmrPlans &p = s->amr_plans;
-  const auto &leaves = s->amr->leaves;
+  const auto &p = s->amr_local;
   for (int par = 0; par < 2; ++par) {
-    SIM_TRY(s, amr_make_refine_plans(s, par, p.restrict_own, leaves, a.restrict_own[par]));
-    SIM_TRY(s, amr_make_refine_plans(s, par, p.prolongate, leaves, a.prolongate[par]));
-    SIM_TRY(s, amr_make_copy_plan(s, par, p.fill, &a.fill[par]));
+    SIM_TRY(s, amr_make_refine_plans(s, par, p.restrict_own, a.restrict_own[par]));
+    SIM_TRY(s, amr_make_refine_plans(s, par, p.prolongate, a.prolongate[par]));
+    SIM_TRY(s, amr_make_copy_plan(s, par, p.fill, nullptr, &a.fill[par]));
+    SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_pack, &s->amr_halo, &a.fill_pack[par]));
+    SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_unpack, &s->amr_halo, &a.fill_unpack[par]));
     for (int d = 0; d < 3; ++d) {
-      SIM_TRY(s, amr_make_copy_plan(s, par, p.coarse_bc[d], &a.coarse_bc[par][d]));
-      SIM_TRY(s, amr_make_copy_plan(s, par, p.fine_bc[d], &a.fine_bc[par][d]));
+      SIM_TRY(s, amr_make_copy_plan(s, par, p.coarse_bc[d], nullptr, &a.coarse_bc[par][d]));
+      SIM_TRY(s, amr_make_copy_plan(s, par, p.fine_bc[d], nullptr, &a.fine_bc[par][d]));
     }
   }
   for (int d = 0; d < s->mesh.ndim; ++d) {
-    SIM_TRY(s, amr_make_refine_plans(s, 0, p.flux_restrict[d], leaves, a.flux_restrict[d]));
-    SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_copy[d], &a.flux_copy[d]));
+    SIM_TRY(s, amr_make_refine_plans(s, 0, p.flux_restrict[d], a.flux_restrict[d]));
+    SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_copy[d], nullptr, &a.flux_copy[d]));
+    SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_pack[d], &s->amr_fluxmsg, &a.flux_pack[d]));
+    SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_unpack[d], &s->amr_fluxmsg, &a.flux_unpack[d]));
   }
   return build_packs(s);
 }
@@ -1196,7 +1309,10 @@ int amr_rebuild(apk_sim *s) {
 int amr_exchange(apk_sim *s, int buf) {
   auto &a = s->amr_dev;
   for (apk_refine_plan *p : a.restrict_own[buf]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
+  SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fill_pack[buf], s->stream));
   SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fill[buf], s->stream));
+  SIM_TRY(s, amr_exchange_messages(s, s->amr_halo));
+  SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fill_unpack[buf], s->stream));
   for (int d = 0; d < 3; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.coarse_bc[buf][d], s->stream));
   for (apk_refine_plan *p : a.prolongate[buf]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
   for (int d = 0; d < 3; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fine_bc[buf][d], s->stream));
@@ -1204,14 +1320,17 @@ int amr_exchange(apk_sim *s, int buf) {
 }
 
 // coarse-fine flux correction (hydro_driver.cpp:527-531): direction by direction, because the
-// restricted fluxes of all three directions share the blocks' coarse buffers
+// restricted fluxes of all three directions share the blocks' coarse buffers; faces whose coarse
+// side lives on another rank travel in ONE message per peer after the three directions are packed
 int amr_flux_correction(apk_sim *s) {
   auto &a = s->amr_dev;
   for (int d = 0; d < s->mesh.ndim; ++d) {
-    if (a.flux_restrict[d].empty()) continue;
     for (apk_refine_plan *p : a.flux_restrict[d]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
     SIM_TRY(s, apk_copy_plan_run(s->ctx, a.flux_copy[d], s->stream));
+    SIM_TRY(s, apk_copy_plan_run(s->ctx, a.flux_pack[d], s->stream));
   }
+  SIM_TRY(s, amr_exchange_messages(s, s->amr_fluxmsg));
+  for (int d = 0; d < s->mesh.ndim; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.flux_unpack[d], s->stream));
   return APK_OK;
 }
 
@@ -1480,64 +1599,53 @@ bool amr_update_tree(apk_sim *s, const std::vector<int> &tags, bool allow_derefi
   return changed;
 }
 
-// Move the state from the old block list to the new one: surviving blocks are copied, new fine
-// blocks are prolongated from their parent (through their coarse buffer), merged blocks collect
-// their children's restricted interiors.  Then everything that depends on the block list is rebuilt.
-int amr_transfer(apk_sim *s, const std::vector<AmrLeaf> &old) {
+// Move the state from the old block list (and its distribution over ranks) to the new one:
+// surviving blocks are copied, new fine blocks are prolongated from their parent (through their
+// coarse buffer), merged blocks collect their children's restricted interiors; whatever changes
+// rank travels in one message per peer.  Then everything that depends on the block list is rebuilt.
+int amr_transfer(apk_sim *s, const std::vector<AmrLeaf> &old, const AmrPartition &old_part) {
   const AmrGeom &g = s->amr_geom;
   AmrTree &t = *s->amr;
+  const int rank = s->rank;
   std::unordered_map<uint64_t, int> old_index;
   for (int n = 0; n < (int)old.size(); ++n) old_index[AmrTree::Key(old[n].level, old[n].lx)] = n;
+  AmrPartition new_part;
+  new_part.Build((int)t.leaves.size(), s->nranks);
   // the children's restricted interiors of the old mesh (ConsToPrim floors may have touched cons since
   // the last exchange)
   for (apk_refine_plan *p : s->amr_dev.restrict_own[s->cur]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
-  double *ncons2[2] = {nullptr, nullptr}, *nprim = nullptr, *nflux[3] = {nullptr, nullptr, nullptr}, *ncoarse = nullptr;
-  SIM_TRY(s, amr_allocate(s, t.leaves.size(), ncons2, &nprim, nflux, &ncoarse));
-  double *ocons = s->d_cons2[s->cur], *ocoarse = s->d_coarse;
-  std::vector<apk_copy_region> regs;
+  // global transfer list: sources are old blocks (RK_OLD_*), destinations new ones
+  std::vector<BoxRegion> moves;
   std::vector<AmrRefOp> prol;
-  auto region = [&](const double *src, const int64_t sst[4], const int slo[3], double *dst, const int64_t dst_st[4], const int dlo[3],
-                    const int ext[3]) {
-    apk_copy_region c{};
-    c.src = src;
-    c.dst = dst;
-    c.nvar = g.nvar;
-    c.flip_var = -1;
-    for (int d = 0; d < 3; ++d) {
-      c.ext[d] = ext[d];
-      c.src += slo[d] * sst[d];
-      c.dst += dlo[d] * dst_st[d];
-    }
-    for (int q = 0; q < 4; ++q) {
-      c.src_stride[q] = sst[q];
-      c.dst_stride[q] = dst_st[q];
-    }
-    regs.push_back(c);
-  };
   const int zero[3] = {0, 0, 0};
   for (int nb = 0; nb < (int)t.leaves.size(); ++nb) {
     const AmrLeaf &l = t.leaves[nb];
-    double *dcons = ncons2[0] + (int64_t)nb * s->nper;
+    BoxRegion r;
     auto it = old_index.find(AmrTree::Key(l.level, l.lx));
     if (it != old_index.end()) {
-      region(ocons + (int64_t)it->second * s->nper, g.fst, zero, dcons, g.fst, zero, g.fn);
+      r.src_kind = RK_OLD_BLOCK, r.src_block = it->second, r.dst_kind = RK_BLOCK, r.dst_block = nb;
+      amr_box_region(r, g.fst, zero, g.fst, zero, g.fn, g.nvar);
+      moves.push_back(r);
       continue;
     }
     const int plx[3] = {l.lx[0] >> 1, l.lx[1] >> 1, l.lx[2] >> 1};
     it = (l.level > 0) ? old_index.find(AmrTree::Key(l.level - 1, plx)) : old_index.end();
     if (it != old_index.end()) {  // refined: parent octant (+ cng cells around it) -> my coarse buffer
-      int slo[3], ext[3];
-      for (int d = 0; d < 3; ++d) {
-        ext[d] = g.cn[d];
-        slo[d] = g.act[d] ? g.fs[d] + (l.lx[d] & 1) * (g.mb[d] / 2) - g.cng : 0;
+      int slo[3];
+      for (int d = 0; d < 3; ++d) slo[d] = g.act[d] ? g.fs[d] + (l.lx[d] & 1) * (g.mb[d] / 2) - g.cng : 0;
+      r.src_kind = RK_OLD_BLOCK, r.src_block = it->second, r.dst_kind = RK_COARSE, r.dst_block = nb;
+      amr_box_region(r, g.fst, slo, g.cst, zero, g.cn, g.nvar);
+      moves.push_back(r);
+      if (new_part.Owner(nb) == rank) {
+        AmrRefOp op;
+        op.kind = APK_RO_PROLONGATE;
+        op.level = l.level;
+        op.src_kind = RK_COARSE, op.dst_kind = RK_BLOCK;
+        op.src_block = op.dst_block = nb - new_part.first[rank];
+        op.geom_block = nb;
+        for (int d = 0; d < 3; ++d) op.lo[d] = g.cs[d], op.hi[d] = g.ce[d];
+        prol.push_back(op);
       }
-      region(ocons + (int64_t)it->second * s->nper, g.fst, slo, ncoarse + (int64_t)nb * g.coarse_doubles, g.cst, zero, ext);
-      AmrRefOp op;
-      op.kind = APK_RO_PROLONGATE;
-      op.level = l.level;
-      op.src_kind = RK_COARSE, op.src_block = nb, op.dst_kind = RK_BLOCK, op.dst_block = nb, op.geom_block = nb;
-      for (int d = 0; d < 3; ++d) op.lo[d] = g.cs[d], op.hi[d] = g.ce[d];
-      prol.push_back(op);
       continue;
     }
     // merged: children's coarse buffers -> my octants
@@ -1553,16 +1661,46 @@ int amr_transfer(apk_sim *s, const std::vector<AmrLeaf> &old) {
         ext[d] = g.act[d] ? g.mb[d] / 2 : 1;
         dlo[d] = g.act[d] ? g.fs[d] + c[d] * (g.mb[d] / 2) : 0;
       }
-      region(ocoarse + (int64_t)ci->second * g.coarse_doubles, g.cst, g.cs, dcons, g.fst, dlo, ext);
+      BoxRegion m;
+      m.src_kind = RK_OLD_COARSE, m.src_block = ci->second, m.dst_kind = RK_BLOCK, m.dst_block = nb;
+      amr_box_region(m, g.cst, g.cs, g.fst, dlo, ext, g.nvar);
+      moves.push_back(m);
     });
     if (!ok) return fail(s, APK_ERR_INVALID, "regridding: a new block has neither itself, its parent nor its children in the old mesh");
   }
-  apk_copy_plan *cp = nullptr;
-  SIM_TRY(s, apk_copy_plan_create(s->ctx, regs.data(), (int)regs.size(), &cp));
-  int rc = apk_copy_plan_run(s->ctx, cp, s->stream);
-  SIM_HIP(s, hipStreamSynchronize(hs(s)));
-  apk_copy_plan_destroy(cp);
-  if (rc != APK_OK) return rc;
+  std::vector<BoxRegion> local, pack, unpack;
+  s->amr_move.plan = AmrMessages();
+  AmrRegisterPeers(moves, old_part, new_part, rank, s->amr_move.plan);
+  AmrLocalize(moves, old_part, new_part, rank, s->amr_move.plan, local, pack, unpack);
+  SIM_TRY(s, amr_ensure_buffers(s, s->amr_move, "regrid"));
+  double *ncons2[2] = {nullptr, nullptr}, *nprim = nullptr, *nflux[3] = {nullptr, nullptr, nullptr}, *ncoarse = nullptr;
+  SIM_TRY(s, amr_allocate(s, (size_t)new_part.Count(rank), ncons2, &nprim, nflux, &ncoarse));
+  double *ocons = s->d_cons2[s->cur], *ocoarse = s->d_coarse;
+  auto base = [&](int kind, int block) -> double * {
+    switch (kind) {
+    case RK_OLD_BLOCK: return ocons + (int64_t)block * s->nper;
+    case RK_OLD_COARSE: return ocoarse + (int64_t)block * g.coarse_doubles;
+    case RK_BLOCK: return ncons2[0] + (int64_t)block * s->nper;
+    case RK_COARSE: return ncoarse + (int64_t)block * g.coarse_doubles;
+    case RK_SEND: return s->amr_move.send[block];
+    case RK_RECV: return s->amr_move.recv[block];
+    default: return nullptr;
+    }
+  };
+  auto run = [&](const std::vector<BoxRegion> &regions) -> int {
+    std::vector<apk_copy_region> regs;
+    for (const BoxRegion &r : regions) regs.push_back(to_copy_region(r, base(r.src_kind, r.src_block), base(r.dst_kind, r.dst_block)));
+    apk_copy_plan *cp = nullptr;
+    int rc = apk_copy_plan_create(s->ctx, regs.data(), (int)regs.size(), &cp);
+    if (rc == APK_OK) rc = apk_copy_plan_run(s->ctx, cp, s->stream);
+    if (hipStreamSynchronize(hs(s)) != hipSuccess && rc == APK_OK) rc = APK_ERR_DEVICE;
+    apk_copy_plan_destroy(cp);
+    return rc;
+  };
+  SIM_TRY(s, run(pack));
+  SIM_TRY(s, run(local));
+  SIM_TRY(s, amr_exchange_messages(s, s->amr_move));
+  SIM_TRY(s, run(unpack));
   // swap in the new arrays
   for (int p = 0; p < 2; ++p) dev_free(s, s->d_cons2[p]);
   dev_free(s, s->d_prim2[0]);
@@ -1577,11 +1715,30 @@ int amr_transfer(apk_sim *s, const std::vector<AmrLeaf> &old) {
   SIM_TRY(s, amr_rebuild(s));
   if (!prol.empty()) {
     std::vector<apk_refine_plan *> plans;
-    SIM_TRY(s, amr_make_refine_plans(s, 0, prol, t.leaves, plans));
+    SIM_TRY(s, amr_make_refine_plans(s, 0, prol, plans));
+    int rc = APK_OK;
     for (apk_refine_plan *p : plans) rc = (rc == APK_OK) ? apk_refine_plan_run(s->ctx, p, s->stream) : rc;
     SIM_HIP(s, hipStreamSynchronize(hs(s)));
     for (apk_refine_plan *p : plans) apk_refine_plan_destroy(p);
     if (rc != APK_OK) return rc;
+  }
+  return APK_OK;
+}
+
+// the tags of every leaf of the forest: mine from the device, the others' through a sum reduction
+int amr_global_tags(apk_sim *s, std::vector<int> &tags) {
+  int criterion;
+  double p0, p1;
+  SIM_TRY(s, refinement_criterion(s, &criterion, &p0, &p1));
+  const int nlocal = (int)s->mesh.local_gids.size(), first = s->amr_part.first[s->rank];
+  std::vector<int> mine(nlocal, 0);
+  SIM_TRY(s, apk_tag_blocks(s->ctx, s->mu0(), criterion, p0, p1, mine.data(), nullptr, s->stream));
+  tags.assign(s->amr->leaves.size(), 0);
+  for (int lb = 0; lb < nlocal; ++lb) tags[first + lb] = mine[lb];
+  if (s->have_comm && s->nranks > 1) {
+    std::vector<double> buf(tags.begin(), tags.end());
+    if (s->comm.allreduce_sum(s->comm.user, buf.data(), (int)buf.size()) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_sum failed");
+    for (size_t n = 0; n < tags.size(); ++n) tags[n] = (int)std::lround(buf[n]);
   }
   return APK_OK;
 }
@@ -1596,7 +1753,9 @@ int amr_reallocate(apk_sim *s) {
   dev_free(s, s->d_coarse);
   s->d_prim2[1] = nullptr;
   s->cur = 0, s->u1buf = 1, s->pcur = 0;
-  SIM_TRY(s, amr_allocate(s, s->amr->leaves.size(), s->d_cons2, &s->d_prim2[0], s->d_flux, &s->d_coarse));
+  AmrPartition part;
+  part.Build((int)s->amr->leaves.size(), s->nranks);
+  SIM_TRY(s, amr_allocate(s, (size_t)part.Count(s->rank), s->d_cons2, &s->d_prim2[0], s->d_flux, &s->d_coarse));
   return amr_rebuild(s);
 }
 
@@ -1604,18 +1763,17 @@ int amr_reallocate(apk_sim *s) {
 // refill ghost zones and primitives on the new mesh
 int amr_regrid(apk_sim *s, bool *changed) {
   *changed = false;
-  int criterion;
-  double p0, p1;
-  SIM_TRY(s, refinement_criterion(s, &criterion, &p0, &p1));
-  std::vector<int> tags(s->amr->leaves.size(), 0);
-  SIM_TRY(s, apk_tag_blocks(s->ctx, s->mu0(), criterion, p0, p1, tags.data(), nullptr, s->stream));
+  std::vector<int> tags;
+  SIM_TRY(s, amr_global_tags(s, tags));
   const std::vector<AmrLeaf> old = s->amr->leaves;
+  const AmrPartition old_part = s->amr_part;
   try {
     if (!amr_update_tree(s, tags, true)) return APK_OK;
   } catch (const std::exception &e) {
     return fail(s, APK_ERR_INVALID, e.what());
   }
-  SIM_TRY(s, amr_transfer(s, old));
+  if ((int)s->amr->leaves.size() < s->nranks) return fail(s, APK_ERR_INVALID, "fewer meshblocks than ranks");
+  SIM_TRY(s, amr_transfer(s, old, old_part));
   SIM_TRY(s, exchange_ghosts(s));
   SIM_TRY(s, fill_derived(s));
   *changed = true;
@@ -1839,7 +1997,7 @@ int apk_sim_create(const char *deck, const char *const *overrides, int noverride
     return bail(rc);
   }
   if (s->amr) {
-    if ((rc = amr_allocate(s, s->amr->leaves.size(), s->d_cons2, &s->d_prim2[0], s->d_flux, &s->d_coarse)) != APK_OK) return bail(rc);
+    if ((rc = amr_allocate(s, s->mesh.local_gids.size(), s->d_cons2, &s->d_prim2[0], s->d_flux, &s->d_coarse)) != APK_OK) return bail(rc);
     if ((rc = amr_rebuild(s)) != APK_OK) return bail(rc);
     if ((rc = build_copy_plans(s)) != APK_OK) return bail(rc);  // (empty: the uniform-mesh plans are unused)
     return APK_OK;
@@ -1888,6 +2046,9 @@ void apk_sim_destroy(apk_sim *s) {
       }
     apk_fmft_destroy(s->fm_dev);
     if (s->amr) amr_destroy_device_plans(s);
+    amr_free_buffers(s, s->amr_halo);
+    amr_free_buffers(s, s->amr_fluxmsg);
+    amr_free_buffers(s, s->amr_move);
     dev_free(s, s->d_coarse);
     for (auto &t : s->x1win) dev_free(s, reinterpret_cast<double *>(t.d));
     for (auto &t : s->dcwin) dev_free(s, reinterpret_cast<double *>(t.d));
@@ -1963,11 +2124,8 @@ int apk_sim_initialize(apk_sim *s) {
   // adaptive meshes: tag the initial condition, refine, and evaluate the problem generator again on
   // the new blocks (not a prolongation), level by level
   for (int pass = 0; s->amr && s->amr_adaptive && pass < s->amr->max_level; ++pass) {
-    int criterion;
-    double p0, p1;
-    SIM_TRY(s, refinement_criterion(s, &criterion, &p0, &p1));
-    std::vector<int> tags(s->amr->leaves.size(), 0);
-    SIM_TRY(s, apk_tag_blocks(s->ctx, s->mu0(), criterion, p0, p1, tags.data(), nullptr, s->stream));
+    std::vector<int> tags;
+    SIM_TRY(s, amr_global_tags(s, tags));
     try {
       if (!amr_update_tree(s, tags, false)) break;
     } catch (const std::exception &e) {
@@ -2069,7 +2227,7 @@ int apk_sim_block_location(const apk_sim *s, int lb, int *gid, int loc[3]) {
   if (!s || lb < 0 || lb >= (int)s->mesh.local_gids.size()) return APK_ERR_INVALID;
   if (gid) *gid = s->mesh.local_gids[lb];
   if (loc && s->amr) {
-    for (int d = 0; d < 3; ++d) loc[d] = s->amr->leaves[lb].lx[d];
+    for (int d = 0; d < 3; ++d) loc[d] = amr_leaf(s, lb).lx[d];
   } else if (loc) {
     s->mesh.Loc(s->mesh.local_gids[lb], loc);
   }
@@ -2506,8 +2664,25 @@ int apk_sim_kernel_timing_read(apk_sim *s, int slot, double *total_ms, long long
   return apk_kernel_timing_read(s->ctx, slot, total_ms, launches);
 }
 
+// the message set the next comm.exchange moves: the uniform mesh's halo buffers, or -- on refined
+// meshes -- whichever of halo / flux-correction / regridding messages the driver has made current
+int apk_sim_num_peers(const apk_sim *s) {
+  if (!s) return APK_ERR_INVALID;
+  return s->active_msgs ? (int)s->active_msgs->plan.peers.size() : (int)s->mesh.peers.size();
+}
+long long apk_sim_message_generation(const apk_sim *s) { return s ? s->msg_generation : 0; }
+
 int apk_sim_peer(const apk_sim *s, int p, apk_peer_info *o) {
-  if (!s || !o || p < 0 || p >= (int)s->mesh.peers.size()) return APK_ERR_INVALID;
+  if (!s || !o || p < 0 || p >= apk_sim_num_peers(s)) return APK_ERR_INVALID;
+  if (s->active_msgs) {
+    const apk_sim::MsgSet &m = *s->active_msgs;
+    o->rank = m.plan.peers[p].rank;
+    o->send_count = m.plan.peers[p].send_count;
+    o->recv_count = m.plan.peers[p].recv_count;
+    o->send_buf = (p < (int)m.send.size()) ? m.send[p] : nullptr;
+    o->recv_buf = (p < (int)m.recv.size()) ? m.recv[p] : nullptr;
+    return APK_OK;
+  }
   o->rank = s->mesh.peers[p].rank;
   o->send_count = s->mesh.peers[p].send_count;
   o->recv_count = s->mesh.peers[p].recv_count;

@@ -148,9 +148,27 @@ struct apk_sim {
   long long zone_cycles = 0;                     // sum over cycles of the interior cells updated
   long long perf_zone_mark = 0;                  // its value where the timed part of apk_sim_execute began
   double *d_coarse = nullptr;                    // [nblocks][amr_geom.coarse_doubles]
+  // distribution over ranks: contiguous Z-order ranges; amr_plans is the global plan (every rank
+  // builds the same one), amr_local this rank's share with local block numbers, copies that cross
+  // ranks turned into packs / unpacks of one message per peer
+  apk::AmrPartition amr_part;
+  struct AmrLocalPlans {
+    std::vector<apk::AmrRefOp> restrict_own, prolongate, flux_restrict[3];
+    std::vector<apk::BoxRegion> fill, fill_pack, fill_unpack, coarse_bc[3], fine_bc[3];
+    std::vector<apk::BoxRegion> flux_copy[3], flux_pack[3], flux_unpack[3];
+  } amr_local;
+  struct MsgSet {
+    apk::AmrMessages plan;
+    std::vector<double *> send, recv;
+    std::vector<int64_t> send_cap, recv_cap;
+  };
+  MsgSet amr_halo, amr_fluxmsg, amr_move;
+  const MsgSet *active_msgs = nullptr;  // the message set apk_sim_peer reports (null: the uniform mesh's)
+  long long msg_generation = 0;         // bumped whenever that set, its sizes or its buffers change
   struct AmrDevice {
     std::vector<apk_refine_plan *> restrict_own[2], prolongate[2], flux_restrict[3];
-    apk_copy_plan *fill[2] = {nullptr, nullptr};
+    apk_copy_plan *fill[2] = {nullptr, nullptr}, *fill_pack[2] = {nullptr, nullptr}, *fill_unpack[2] = {nullptr, nullptr};
+    apk_copy_plan *flux_pack[3] = {nullptr, nullptr, nullptr}, *flux_unpack[3] = {nullptr, nullptr, nullptr};
     apk_copy_plan *coarse_bc[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     apk_copy_plan *fine_bc[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     apk_copy_plan *flux_copy[3] = {nullptr, nullptr, nullptr};

@@ -29,16 +29,21 @@ class HaloExchanger:
             return
         # gloo has no device send/recv: development runs that put several ranks on one GPU
         # (tests, `APK_DIST_BACKEND=gloo bench.py`) bounce the messages through host memory
-        staged = self.peers[0][1].is_cuda and dist.get_backend(self.group) == "gloo"
+        some = next((t for _, a, b in self.peers for t in (a, b) if t is not None), None)
+        staged = some is not None and some.is_cuda and dist.get_backend(self.group) == "gloo"
         ops = []
-        for rank, send_t, recv_t in self.peers:
-            if staged:
+        for rank, send_t, recv_t in self.peers:  # (a direction without data has no tensor: no op on either side)
+            if staged and recv_t is not None:
                 host_recv = torch.empty(recv_t.shape, dtype=recv_t.dtype)
                 self._back.append((recv_t, host_recv))
-                send_t, recv_t = send_t.cpu(), host_recv
-            ops.append(dist.P2POp(dist.irecv, recv_t, rank, group=self.group))
-            ops.append(dist.P2POp(dist.isend, send_t, rank, group=self.group))
-        self._reqs = dist.batch_isend_irecv(ops)
+                recv_t = host_recv
+            if staged and send_t is not None:
+                send_t = send_t.cpu()
+            if recv_t is not None:
+                ops.append(dist.P2POp(dist.irecv, recv_t, rank, group=self.group))
+            if send_t is not None:
+                ops.append(dist.P2POp(dist.isend, send_t, rank, group=self.group))
+        self._reqs = dist.batch_isend_irecv(ops) if ops else []
 
     def end(self):
         """work enqueued on the current stream after this call sees the received data (over RCCL
@@ -176,10 +181,11 @@ class Simulation(_FmftHost, _MeshView):
         allocator = L.Allocator(None, self._alloc_cb, self._release_cb)
 
         self._halo = None
+        self._halo_generation = None
 
         def _exchange(user):
             try:
-                self._halo.exchange()
+                self._current_halo().exchange()
                 return 0
             except Exception as e:  # surfaced as APK_ERR_DEVICE by the driver
                 self._cb_error = e
@@ -187,7 +193,7 @@ class Simulation(_FmftHost, _MeshView):
 
         def _exchange_begin(user):
             try:
-                self._halo.begin()
+                self._current_halo().begin()
                 return 0
             except Exception as e:
                 self._cb_error = e
@@ -236,15 +242,24 @@ class Simulation(_FmftHost, _MeshView):
         self.h = h
         self.info = L.SimInfo()
         self._check(self.lib.apk_sim_get_info(self.h, C.byref(self.info)))
-        # wire the per-peer message buffers into the exchanger
-        peers = []
-        for p in range(self.info.npeers):
-            pi = L.PeerInfo()
-            self._check(self.lib.apk_sim_peer(self.h, p, C.byref(pi)))
-            st = self._by_tag["send:%d" % pi.rank][:pi.send_count]
-            rt = self._by_tag["recv:%d" % pi.rank][:pi.recv_count]
-            peers.append((pi.rank, st, rt))
-        self._halo = HaloExchanger(peers, group)
+        self._current_halo()
+
+    def _current_halo(self):
+        """the exchanger over the sim's current message set (apk_sim_peer): built once on uniform
+        meshes; refined meshes switch between halo / flux-correction / regridding messages and
+        change them when the mesh does, which the generation counter tells"""
+        gen = self.lib.apk_sim_message_generation(self.h)
+        if self._halo is None or gen != self._halo_generation:
+            peers = []
+            for p in range(self.lib.apk_sim_num_peers(self.h)):
+                pi = L.PeerInfo()
+                self._check(self.lib.apk_sim_peer(self.h, p, C.byref(pi)))
+                st = self._tensors[pi.send_buf][:pi.send_count] if pi.send_count else None
+                rt = self._tensors[pi.recv_buf][:pi.recv_count] if pi.recv_count else None
+                peers.append((pi.rank, st, rt))
+            self._halo = HaloExchanger(peers, self._group)
+            self._halo_generation = gen
+        return self._halo
 
     def _check(self, rc):
         if rc != L.APK_OK:

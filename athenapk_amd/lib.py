@@ -224,6 +224,8 @@ def _signatures():
         "apk_sim_peer": (i, [vp, i, C.POINTER(PeerInfo)]),
         "apk_sim_plan_size": (i, [vp, i]),
         "apk_sim_plan_region": (i, [vp, i, i, C.POINTER(RegionInfo)]),
+        "apk_sim_num_peers": (i, [vp]),
+        "apk_sim_message_generation": (ll, [vp]),
         "apk_sim_amr_ops_size": (i, [vp, i]),
         "apk_sim_amr_op": (i, [vp, i, i, C.POINTER(AmrOpInfo)]),
         "apk_sim_loop_zone_cycles": (ll, [vp]),

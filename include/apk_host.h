@@ -195,6 +195,13 @@ typedef struct apk_peer_info {
   void *send_buf, *recv_buf;      /* device pointers (NULL in host-only mode) */
 } apk_peer_info;
 int apk_sim_peer(const apk_sim *sim, int p, apk_peer_info *info);
+/* The message set the next comm_ops.exchange moves.  On uniform meshes it never changes (the halo
+ * buffers; apk_sim_info.npeers entries).  On refined meshes the driver makes the halo, the
+ * flux-correction or the regridding messages current before it calls exchange, and regridding
+ * changes peers, sizes and buffers: an exchange callback re-reads the set whenever
+ * apk_sim_message_generation has changed since it last looked. */
+int apk_sim_num_peers(const apk_sim *sim);
+long long apk_sim_message_generation(const apk_sim *sim);
 /* number of box copies in each phase: 0 local, 1 pack, 2 unpack, 3..5 physical BC x1..x3; on
  * refined meshes 10 = all copies of the multilevel exchange, 11..13 = coarse-buffer boundaries,
  * 14..16 = block boundaries, 17..19 = flux-correction copies x1..x3 */

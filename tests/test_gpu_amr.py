@@ -286,3 +286,85 @@ def test_cli_runs_the_amr_deck(tmp_path, capsys):
     assert cli.main(["-i", "blast_3d_amr", "-d", str(tmp_path), "parthenon/time/tlim=0.01"]) == 0
     out = capsys.readouterr().out
     assert "zone-cycles/wallsecond" in out
+
+
+# ---- refined meshes distributed over ranks ------------------------------------------------------------
+AMR_RANK_CASES = {
+    # deck, overrides, cycles
+    "smr_mhd": ("blast", SMR3 + ["hydro/fluid=glmmhd", "hydro/riemann=hlld", "parthenon/time/integrator=rk2",
+                                 "problem/blast/radius_outer=0.2", "problem/blast/pressure_ratio=100",
+                                 "problem/blast/x3_0=0.1", "problem/blast/pressure_ambient=1.0"], 5),
+    "smr_outflow_2d": ("blast", SMR2 + _bc("outflow") + ["problem/blast/radius_outer=0.2", "problem/blast/pressure_ratio=50",
+                                                         "problem/blast/x1_0=-0.3", "problem/blast/x2_0=0.3"], 8),
+    "amr_blast": ("blast_3d_amr", ["parthenon/mesh/derefine_count=3"], 25),
+    "amr_advection": ("advection_3d", ["parthenon/mesh/derefine_count=3"], 40),
+}
+
+
+def _amr_worker(rank, world, port, case, outdir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    from athenapk_amd import decks, driver
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        deck, ov, ncyc = AMR_RANK_CASES[case]
+        s = driver.Simulation(decks.load(deck), ov, rank=rank, nranks=world, strict=True)
+        s.initialize()
+        for _ in range(ncyc):
+            s.step()
+        i = s.refresh_info()
+        out = {}
+        for lb in range(i.nblocks_local):
+            lev, loc = s.block_level(lb), s.block_gid(lb)[1]
+            out["b_%d_%d_%d_%d" % ((lev,) + tuple(loc))] = s.read_block(lb, "cons")
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), time=s.time, dt=s.dt, hist=s.history(),
+                 nblocks_total=i.nblocks_total, stats=np.array(s.amr_stats()), **out)
+        s.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", sorted(AMR_RANK_CASES))
+def test_refined_mesh_on_several_ranks_matches_one_rank(tmp_path, case, world):
+    """blocks of the forest distributed over ranks in Z-order ranges (sharing cuda:0, messages
+    staged through the host): level-crossing halo messages, flux-correction messages, replicated
+    forest updates from all-reduced tags and block migration on regridding must reproduce the
+    one-rank run bit for bit"""
+    import socket
+    import torch.multiprocessing as mp
+    deck, ov, ncyc = AMR_RANK_CASES[case]
+    ref = _sim(deck, ov, strict=True).initialize()
+    for _ in range(ncyc):
+        ref.step()
+    ri = ref.refresh_info()
+    want = {}
+    for lb in range(ri.nblocks_local):
+        want["b_%d_%d_%d_%d" % ((ref.block_level(lb),) + tuple(ref.block_gid(lb)[1]))] = ref.read_block(lb, "cons")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    mp.spawn(_amr_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    seen = set()
+    counts = []
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert z["time"] == ref.time and z["dt"] == ref.dt
+        assert int(z["nblocks_total"]) == ri.nblocks_total
+        assert tuple(z["stats"]) == tuple(ref.amr_stats())
+        assert np.allclose(z["hist"], ref.history(), rtol=1e-13, atol=1e-15)
+        keys = [k for k in z.files if k.startswith("b_")]
+        counts.append(len(keys))
+        for k in keys:
+            assert k not in seen
+            seen.add(k)
+            assert np.array_equal(z[k], want[k]), "%s on rank %d" % (k, r)
+    assert seen == set(want)
+    assert max(counts) - min(counts) <= 1          # equal shares of equal-cost blocks
+    if case.startswith("amr"):
+        assert ref.amr_stats()[0] > 0              # the mesh did change on the way
