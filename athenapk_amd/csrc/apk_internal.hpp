@@ -176,4 +176,25 @@ struct ScopedTiming {
   }
 };
 
+// Thread -> (i, j) offset inside an ni x nj index rectangle for the (64, 4) workgroups of the
+// per-cell kernels.  Rows of at least 48 cells: 64 lanes along i, 4 rows per workgroup (every load
+// a full 512-B segment).  Shorter rows -- the 8^3 / 16^3 meshblocks of refined meshes -- are
+// flattened row after row, so that the lanes stay busy; launch with rect_grid().
+#ifdef __HIPCC__
+__device__ __forceinline__ bool rect_ij(int ni, int nj, int &io, int &jo) {
+  if (ni >= 48) {
+    io = blockIdx.x * 64 + threadIdx.x;
+    jo = blockIdx.y * 4 + threadIdx.y;
+  } else {
+    const int f = blockIdx.y * 256 + threadIdx.y * 64 + threadIdx.x;
+    jo = f / ni;
+    io = f - jo * ni;
+  }
+  return io < ni && jo < nj;
+}
+inline dim3 rect_grid(int ni, int nj, int nz) {
+  return ni >= 48 ? dim3((ni + 63) / 64, (nj + 3) / 4, nz) : dim3(1, (ni * nj + 255) / 256, nz);
+}
+#endif
+
 }  // namespace apk

@@ -6,8 +6,9 @@
 // path is in kernels_fused.hip.
 //
 // Mapping: one lane per face, 64 consecutive lanes along x1 so every stencil load is a
-// coalesced 512-B row segment; the 4..6 stencil rows a lane touches along the sweep
-// direction are shared with its neighbours through L1/L2.
+// coalesced 512-B row segment (rows of narrow meshblocks are flattened, rect_ij); the 4..6
+// stencil rows a lane touches along the sweep direction are shared with its neighbours through
+// L1/L2.
 #pragma once
 
 #include "apk_internal.hpp"
@@ -85,12 +86,12 @@ template <int FLUID, int RECON, int RS, int DIR>
 __global__ void __launch_bounds__(256)
 flux_kernel(PackView pv, FluxExtent e, double gamma, double c_h) {
   constexpr int NV = nvars<FLUID>();
-  const int i = e.i0 + blockIdx.x * 64 + threadIdx.x;
-  const int j = e.j0 + blockIdx.y * 4 + threadIdx.y;
+  int io, jo;
+  if (!rect_ij(e.i1 - e.i0 + 1, e.j1 - e.j0 + 1, io, jo)) return;
+  const int i = e.i0 + io, j = e.j0 + jo;
   const int nkext = e.k1 - e.k0 + 1;
   const int b = blockIdx.z / nkext;
   const int k = e.k0 + blockIdx.z % nkext;
-  if (i > e.i1 || j > e.j1) return;
   const apk_block_desc blk = pv.blocks[b];
   const int64_t st = (DIR == 1) ? 1 : ((DIR == 2) ? pv.sj : pv.sk);
   const int64_t cell = k * pv.sk + j * pv.sj + i;
@@ -126,7 +127,7 @@ inline void launch_flux_dir(const PackView &pv, const FluxExtent &e, double gamm
                             hipStream_t s) {
   const int nie = e.i1 - e.i0 + 1, nje = e.j1 - e.j0 + 1, nke = e.k1 - e.k0 + 1;
   dim3 block(64, 4, 1);
-  dim3 grid((nie + 63) / 64, (nje + 3) / 4, nke * pv.nblocks);
+  const dim3 grid = rect_grid(nie, nje, nke * pv.nblocks);
   hipLaunchKernelGGL((flux_kernel<FLUID, RECON, RS, DIR>), grid, block, 0, s, pv, e, gamma, c_h);
 }
 

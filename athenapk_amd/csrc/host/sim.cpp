@@ -1137,39 +1137,38 @@ int amr_make_copy_plan(apk_sim *s, int parity, const std::vector<BoxRegion> &reg
   return apk_copy_plan_create(s->ctx, regs.data(), (int)regs.size(), out);
 }
 
-// one refine plan per level: the operators difference cell-centre coordinates of that level
-// (ops carry LOCAL block numbers for the arrays and the GLOBAL leaf number for the geometry)
+// ONE refine plan for the boxes of all levels: every box carries the cell widths of its level (the
+// operators difference cell-centre coordinates).  Ops carry LOCAL block numbers for the arrays and the
+// GLOBAL leaf number for the geometry.
 int amr_make_refine_plans(apk_sim *s, int parity, const std::vector<AmrRefOp> &ops, std::vector<apk_refine_plan *> &out) {
   for (apk_refine_plan *p : out) apk_refine_plan_destroy(p);
   out.clear();
   const AmrGeom &g = s->amr_geom;
-  for (int level = 0; level <= s->amr->max_level; ++level) {
-    std::vector<apk_refine_op> dev;
-    for (const AmrRefOp &o : ops) {
-      if (o.level != level) continue;
-      apk_refine_op d{};
-      d.kind = o.kind;
-      d.src = amr_base(s, parity, o.src_kind, o.src_block, nullptr);
-      d.dst = amr_base(s, parity, o.dst_kind, o.dst_block, nullptr);
-      for (int q = 0; q < 3; ++q) {
-        d.lo[q] = o.lo[q];
-        d.hi[q] = o.hi[q];
-        d.xmin[q] = s->xmin[q] + (double)s->amr->leaves[o.geom_block].lx[q] * g.mb[q] * level_dx(s, level, q);
-      }
-      dev.push_back(d);
-    }
-    if (dev.empty()) continue;
-    apk_refine_geom rg{};
+  std::vector<apk_refine_op> dev;
+  for (const AmrRefOp &o : ops) {
+    apk_refine_op d{};
+    d.kind = o.kind;
+    d.src = amr_base(s, parity, o.src_kind, o.src_block, nullptr);
+    d.dst = amr_base(s, parity, o.dst_kind, o.dst_block, nullptr);
     for (int q = 0; q < 3; ++q) {
-      rg.nx[q] = g.mb[q];
-      rg.dx[q] = level_dx(s, level, q);
+      d.lo[q] = o.lo[q];
+      d.hi[q] = o.hi[q];
+      d.dx[q] = level_dx(s, o.level, q);
+      d.xmin[q] = s->xmin[q] + (double)s->amr->leaves[o.geom_block].lx[q] * g.mb[q] * d.dx[q];
     }
-    rg.ng = g.ng;
-    rg.cng = g.cng;
-    apk_refine_plan *p = nullptr;
-    SIM_TRY(s, apk_refine_plan_create(s->ctx, &rg, g.nvar, dev.data(), (int)dev.size(), &p));
-    out.push_back(p);
+    dev.push_back(d);
   }
+  if (dev.empty()) return APK_OK;
+  apk_refine_geom rg{};
+  for (int q = 0; q < 3; ++q) {
+    rg.nx[q] = g.mb[q];
+    rg.dx[q] = level_dx(s, 0, q);
+  }
+  rg.ng = g.ng;
+  rg.cng = g.cng;
+  apk_refine_plan *p = nullptr;
+  SIM_TRY(s, apk_refine_plan_create(s->ctx, &rg, g.nvar, dev.data(), (int)dev.size(), &p));
+  out.push_back(p);
   return APK_OK;
 }
 

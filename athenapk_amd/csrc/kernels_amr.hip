@@ -166,6 +166,11 @@ APK_DEV void restrict_cell(const apk_refine_geom &g, const RefineDims &r, const 
 
 __global__ void __launch_bounds__(256) refine_ops_kernel(apk_refine_geom g, int nvar, const apk_refine_op *ops) {
   const apk_refine_op op = ops[blockIdx.x];
+  if (op.dx[0] > 0.0) {  // the box brings its own cell widths (another refinement level)
+    g.dx[0] = op.dx[0];
+    g.dx[1] = op.dx[1];
+    g.dx[2] = op.dx[2];
+  }
   const RefineDims r = refine_dims(g);
   const int e0 = op.hi[0] - op.lo[0] + 1, e1 = op.hi[1] - op.lo[1] + 1, e2 = op.hi[2] - op.lo[2] + 1;
   const int64_t cells = (int64_t)e0 * e1 * e2, items = cells * nvar;
@@ -207,9 +212,10 @@ __global__ void __launch_bounds__(256) tag_kernel(PackView pv, unsigned long lon
     iu += 1;
   }
   double m = 0.0;
-  const int i = il + blockIdx.x * 64 + threadIdx.x;
-  const int j = jl + blockIdx.y * 4 + threadIdx.y;
-  if (i <= iu && j <= ju) {
+  int io, jo;
+  const bool inside = rect_ij(pv.nx1 + 2, pv.nx2 + 2, io, jo);  // (the launch covers the widest extent)
+  const int i = il + io, j = jl + jo;
+  if (inside && i <= iu && j <= ju) {
     for (int k = kl; k <= ku; ++k) {
       const int64_t c = k * pv.sk + j * pv.sj + i;
       if (CRIT == APK_TAG_PRESSURE_GRADIENT) {
@@ -341,7 +347,7 @@ int apk_tag_blocks(apk_ctx *ctx, const apk_pack *md, int criterion, double p0, d
   }
   auto *d_max = reinterpret_cast<unsigned long long *>(ctx->d_partial);
   APK_HIP_TRY(ctx, hipMemsetAsync(d_max, 0, sizeof(unsigned long long) * nb, s));
-  const dim3 grid((pv.nx1 + 2 + 63) / 64, (pv.nx2 + 2 + 3) / 4, nb), block(64, 4, 1);
+  const dim3 grid = rect_grid(pv.nx1 + 2, pv.nx2 + 2, nb), block(64, 4, 1);
   if (criterion == APK_TAG_PRESSURE_GRADIENT)
     hipLaunchKernelGGL(tag_kernel<APK_TAG_PRESSURE_GRADIENT>, grid, block, 0, s, pv, d_max);
   else if (criterion == APK_TAG_VELOCITY_GRADIENT)

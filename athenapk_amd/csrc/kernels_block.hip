@@ -18,17 +18,16 @@ struct CellIdx {
 // interior cell of this lane; grid = (ceil(nx1/64), ceil(nx2/4), nx3*nblocks), block (64,4)
 APK_DEV CellIdx interior_cell(const PackView &pv) {
   CellIdx c;
-  c.i = pv.is + blockIdx.x * 64 + threadIdx.x;
-  c.j = pv.js + blockIdx.y * 4 + threadIdx.y;
+  int io, jo;
+  c.ok = rect_ij(pv.nx1, pv.nx2, io, jo);
+  c.i = pv.is + io;
+  c.j = pv.js + jo;
   c.b = blockIdx.z / pv.nx3;
   c.k = pv.ks + blockIdx.z % pv.nx3;
-  c.ok = (c.i <= pv.ie) && (c.j <= pv.je);
   return c;
 }
 
-inline dim3 interior_grid(const PackView &pv) {
-  return dim3((pv.nx1 + 63) / 64, (pv.nx2 + 3) / 4, pv.nx3 * pv.nblocks);
-}
+inline dim3 interior_grid(const PackView &pv) { return rect_grid(pv.nx1, pv.nx2, pv.nx3 * pv.nblocks); }
 
 // Parthenon Update::FluxDivHelper (un-vendored):
 // du = A1 F1(i+1) - A1 F1(i) [+ A2 ..][+ A3 ..];  return -du / V
@@ -128,11 +127,10 @@ APK_DEV void cons_to_prim_at(const PackView &pv, const apk_block_desc &blk, cons
 template <int FLUID>
 __global__ void __launch_bounds__(256)
 cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  const int j = blockIdx.y * 4 + threadIdx.y;
+  int i, j;
+  if (!rect_ij(pv.ni, pv.nj, i, j)) return;
   const int b = blockIdx.z / pv.nk;
   const int k = blockIdx.z % pv.nk;
-  if (i >= pv.ni || j >= pv.nj) return;
   cons_to_prim_at<FLUID>(pv, pv.blocks[b], eos, flags, k * pv.sk + j * pv.sj + i);
 }
 
@@ -204,17 +202,19 @@ APK_DEV double wave_sum(double v) {
 template <int FLUID>
 __global__ void __launch_bounds__(256)
 min_dt_kernel(PackView pv, double gamma, unsigned long long *min_bits, int kchunks) {
-  // grid = (ceil(nx1/64), ceil(nx2/4), nblocks*kchunks): every workgroup walks a slab of k
-  // planes of its (i,j) tile, so the pack costs ~2k atomics instead of one per plane tile
+  // grid = rect_grid(nx1, nx2, nblocks*kchunks): every workgroup walks a slab of k planes of its
+  // (i,j) tile, so the pack costs ~2k atomics instead of one per plane tile
   CellIdx c;
-  c.i = pv.is + blockIdx.x * 64 + threadIdx.x;
-  c.j = pv.js + blockIdx.y * 4 + threadIdx.y;
+  int io, jo;
+  const bool inside = rect_ij(pv.nx1, pv.nx2, io, jo);
+  c.i = pv.is + io;
+  c.j = pv.js + jo;
   c.b = blockIdx.z / kchunks;
   const int chunk = blockIdx.z % kchunks;
   const int klen = (pv.nx3 + kchunks - 1) / kchunks;
   const int k0 = pv.ks + chunk * klen;
   const int k1 = (k0 + klen - 1 < pv.ke) ? k0 + klen - 1 : pv.ke;
-  c.ok = (c.i <= pv.ie) && (c.j <= pv.je);
+  c.ok = inside;
   double min_dt = 1.7976931348623157e308;
   const apk_block_desc blk = pv.blocks[c.b];
   for (c.k = k0; c.ok && c.k <= k1; ++c.k) {
@@ -474,7 +474,7 @@ int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsig
                          late_regions, part);
     return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
   }
-  dim3 grid((pv.ni + 63) / 64, (pv.nj + 3) / 4, pv.nk * pv.nblocks);
+  const dim3 grid = rect_grid(pv.ni, pv.nj, pv.nk * pv.nblocks);
   if (fluid == APK_FLUID_EULER)
     hipLaunchKernelGGL(cons_to_prim_kernel<APK_FLUID_EULER>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags);
   else
@@ -484,8 +484,10 @@ int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsig
 
 int launch_min_dt(const PackView &pv, int fluid, double gamma, unsigned long long *d_min_bits,
                   hipStream_t s) {
-  const int kchunks = pv.nx3 >= 8 ? 8 : pv.nx3;
-  const dim3 grid((pv.nx1 + 63) / 64, (pv.nx2 + 3) / 4, pv.nblocks * kchunks);
+  // (narrow meshblocks come in large numbers: one slab per block keeps the atomics on the one
+  // result word few)
+  const int kchunks = pv.nx1 < 48 ? 1 : (pv.nx3 >= 8 ? 8 : pv.nx3);
+  const dim3 grid = rect_grid(pv.nx1, pv.nx2, pv.nblocks * kchunks);
   if (fluid == APK_FLUID_EULER)
     hipLaunchKernelGGL(min_dt_kernel<APK_FLUID_EULER>, grid, dim3(64, 4, 1), 0, s, pv, gamma,
                        d_min_bits, kchunks);

@@ -19,13 +19,15 @@ namespace apk {
 namespace {
 
 APK_DEV bool interior_of(const PackView &pv, int &b, int &k, int &j, int &i) {
-  i = pv.is + blockIdx.x * 64 + threadIdx.x;
-  j = pv.js + blockIdx.y * 4 + threadIdx.y;
+  int io, jo;
+  const bool inside = rect_ij(pv.nx1, pv.nx2, io, jo);
+  i = pv.is + io;
+  j = pv.js + jo;
   b = blockIdx.z / pv.nx3;
   k = pv.ks + blockIdx.z % pv.nx3;
-  return (i <= pv.ie) && (j <= pv.je);
+  return inside;
 }
-inline dim3 igrid(const PackView &pv) { return dim3((pv.nx1 + 63) / 64, (pv.nx2 + 3) / 4, pv.nx3 * pv.nblocks); }
+inline dim3 igrid(const PackView &pv) { return rect_grid(pv.nx1, pv.nx2, pv.nx3 * pv.nblocks); }
 
 // few_modes_ft.cpp:330-347
 __global__ void __launch_bounds__(256)

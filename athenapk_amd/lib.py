@@ -70,10 +70,11 @@ class RefineGeom(C.Structure):
 
 class RefineOp(C.Structure):
     _fields_ = [("kind", C.c_int), ("src", C.c_void_p), ("dst", C.c_void_p), ("lo", C.c_int * 3),
-                ("hi", C.c_int * 3), ("xmin", C.c_double * 3)]
+                ("hi", C.c_int * 3), ("xmin", C.c_double * 3), ("dx", C.c_double * 3)]
 
 
-REFINE_OPS = {"prolongate": 0, "restrict_cell": 1, "restrict_face1": 2, "restrict_face2": 3, "restrict_face3": 4}
+REFINE_OPS = {"prolongate": 0, "restrict_cell": 1, "restrict_face1": 2, "restrict_face2": 3, "restrict_face3": 4,
+              "restrict_flux1": 5, "restrict_flux2": 6, "restrict_flux3": 7}
 TAG_CRITERIA = {"pressure_gradient": 0, "xyvelocity_gradient": 1, "maxdensity": 2}
 
 

@@ -337,6 +337,8 @@ typedef struct apk_refine_op {
   int lo[3], hi[3];
   double xmin[3]; /* lower interior corner of the block (enters the slope spacings as in the
                      reference, which differences cell-centre coordinates) */
+  double dx[3];   /* fine cell widths of THIS box; all zero = the plan's apk_refine_geom.dx.  Lets one
+                     plan (one launch) hold boxes of several refinement levels */
 } apk_refine_op;
 typedef struct apk_refine_plan apk_refine_plan;
 int apk_refine_plan_create(apk_ctx *ctx, const apk_refine_geom *geom, int nvar,
