@@ -179,8 +179,9 @@ void apk_pack_destroy(apk_pack *pack) {
   delete pack;
 }
 
-int apk_calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos,
-                         double c_h, apk_stream_t stream) {
+namespace {
+int calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos, double c_h, bool tight,
+                     apk_stream_t stream) {
   if (!ctx || !md || !valid_eos(eos)) return set_err(ctx, APK_ERR_INVALID, "apk_calculate_fluxes: bad argument");
   int rc = check_cfg(ctx, md, cfg);
   if (rc != APK_OK) return rc;
@@ -194,13 +195,24 @@ int apk_calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, con
   if (cfg.riemann == APK_RS_NONE || cfg.riemann == APK_RS_LLF)
     rc = launch_fluxes_misc(pv, cfg.fluid, cfg.riemann, eos->gamma, c_h, s);
   else if (cfg.fluid == APK_FLUID_EULER)
-    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_euler_hlle(pv, cfg.recon, eos->gamma, c_h, s)
-                                      : launch_fluxes_euler_hllc(pv, cfg.recon, eos->gamma, c_h, s);
+    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_euler_hlle(pv, cfg.recon, eos->gamma, c_h, s, tight)
+                                      : launch_fluxes_euler_hllc(pv, cfg.recon, eos->gamma, c_h, s, tight);
   else
-    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_mhd_hlle(pv, cfg.recon, eos->gamma, c_h, s)
-                                      : launch_fluxes_mhd_hlld(pv, cfg.recon, eos->gamma, c_h, s);
+    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_mhd_hlle(pv, cfg.recon, eos->gamma, c_h, s, tight)
+                                      : launch_fluxes_mhd_hlld(pv, cfg.recon, eos->gamma, c_h, s, tight);
   if (rc != APK_OK) return set_err(ctx, rc, "flux kernel launch failed", hipGetLastError());
   return APK_OK;
+}
+}  // namespace
+
+int apk_calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos,
+                         double c_h, apk_stream_t stream) {
+  return calculate_fluxes(ctx, md, cfg, eos, c_h, false, stream);
+}
+
+int apk_calculate_fluxes_tight(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos,
+                               double c_h, apk_stream_t stream) {
+  return calculate_fluxes(ctx, md, cfg, eos, c_h, true, stream);
 }
 
 int apk_update_with_flux_divergence(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,

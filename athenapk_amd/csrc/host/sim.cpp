@@ -1876,7 +1876,8 @@ int do_stage(apk_sim *s, int stage) {
     if (swap_prim) s->pcur = 1 - s->pcur;
   } else {
     SIM_TRY(s, ensure_flux_arrays(s));
-    SIM_TRY(s, apk_calculate_fluxes(s->ctx, s->mu0(), cfg, &pkg.eos, pkg.c_h, s->stream));
+    // (faces of interior cells only: nothing downstream reads the reference's extra transverse rows)
+    SIM_TRY(s, apk_calculate_fluxes_tight(s->ctx, s->mu0(), cfg, &pkg.eos, pkg.c_h, s->stream));
     if (pkg.first_order_flux_correct) {
       long long nfix = 0;
       SIM_TRY(s, apk_first_order_flux_correct(s->ctx, s->mu0(), s->mu1(), pkg.fluid, &pkg.eos, pkg.c_h, g0, g1,

@@ -129,11 +129,12 @@ def _cfg(fluid, recon, riemann):
 
 
 # ---- the task functions ---------------------------------------------------------------------
-def CalculateFluxes(md, fluid, recon, riemann, eos, c_h=0.0):
-    """Hydro::CalculateFluxes<fluid,recon,rsolver>(md)  -- src/hydro/hydro.cpp:1025"""
+def CalculateFluxes(md, fluid, recon, riemann, eos, c_h=0.0, tight=False):
+    """Hydro::CalculateFluxes<fluid,recon,rsolver>(md)  -- src/hydro/hydro.cpp:1025; tight: only the
+    faces of interior cells (the loop limits of CalculateFluxesTight, hydro.cpp:1006-1009)"""
     ctx = md.ctx
-    _check(ctx.lib.apk_calculate_fluxes(ctx.h, md.h, _cfg(fluid, recon, riemann), C.byref(eos),
-                                        float(c_h), _stream()), ctx.lib, ctx.h)
+    fn = ctx.lib.apk_calculate_fluxes_tight if tight else ctx.lib.apk_calculate_fluxes
+    _check(fn(ctx.h, md.h, _cfg(fluid, recon, riemann), C.byref(eos), float(c_h), _stream()), ctx.lib, ctx.h)
 
 
 def UpdateWithFluxDivergence(u0, u1, gam0, gam1, beta_dt):

@@ -145,6 +145,7 @@ def _signatures():
         "apk_pack_create": (i, [vp, C.POINTER(PackDesc), pp]),
         "apk_pack_destroy": (None, [vp]),
         "apk_calculate_fluxes": (i, [vp, vp, FluxCfg, E, d, vp]),
+        "apk_calculate_fluxes_tight": (i, [vp, vp, FluxCfg, E, d, vp]),
         "apk_update_with_flux_divergence": (i, [vp, vp, vp, d, d, d, vp]),
         "apk_dedner_source": (i, [vp, vp, i, d, d, d, d, vp]),
         "apk_stage_fused": (i, [vp, vp, vp, C.POINTER(StageArgs), vp]),

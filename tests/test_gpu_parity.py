@@ -57,6 +57,38 @@ def test_calculate_fluxes_registry_3d(request, fluid, recon, riemann, strict):
         _cmp(md.flux_host(d), want[d], strict, "flux%d %s/%s/%s" % (d + 1, fluid, recon, riemann))
 
 
+@pytest.mark.parametrize("nx", [(16, 8, 8), (8, 8, 8), (40, 12, 1), (72, 6, 4)], ids=["16x8x8", "8x8x8", "2d", "wide"])
+@pytest.mark.parametrize("fluid,recon,riemann", [("euler", "plm", "hlle"), ("glmmhd", "ppm", "hlld")])
+def test_calculate_fluxes_tight_equals_the_reference_extents_on_interior_faces(request, fluid, recon, riemann, nx):
+    """apk_calculate_fluxes_tight: same values on every face of an interior cell, nothing written
+    beyond CalculateFluxesTight's loop limits; narrow blocks (flattened lanes) and wide ones"""
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    ng, prim, g = _case(fluid, recon, nx, kind="rough", seed=5)
+    eos = hydro.L.make_eos(GAMMA)
+    full = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=prim.shape[0], prim=prim)
+    tight = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=prim.shape[0], prim=prim)
+    hydro.CalculateFluxes(full, fluid, recon, riemann, eos, C_H)
+    hydro.CalculateFluxes(tight, fluid, recon, riemann, eos, C_H, tight=True)
+    ndim = 3 if nx[2] > 1 else (2 if nx[1] > 1 else 1)
+    act = [True, nx[1] > 1, nx[2] > 1]
+    for d in range(ndim):
+        a, b = full.flux_host(d), tight.flux_host(d)
+        sl = [slice(None), slice(None)]
+        for q in (2, 1, 0):          # array axes k, j, i
+            if not act[q]:
+                sl.append(slice(None))
+            else:
+                sl.append(slice(ng, ng + nx[q] + (1 if q == d else 0)))
+        sl = tuple(sl)
+        assert np.array_equal(a[sl], b[sl], equal_nan=True)   # (rough data: NaNs in the same places)
+        # (CalculateFluxesTight is one loop nest over [s, e + 1] in every active direction)
+        wide = tuple(sl[:2]) + tuple(slice(None) if not act[q] else slice(ng, ng + nx[q] + 1) for q in (2, 1, 0))
+        mask = np.ones(b.shape, bool)
+        mask[wide] = False
+        assert np.all(b[mask] == 0.0) and np.array_equal(a[wide], b[wide], equal_nan=True)
+
+
 @pytest.mark.parametrize("kind", ["rough", "shock"])
 @pytest.mark.parametrize("fluid,recon,riemann", [("euler", "ppm", "hllc"), ("euler", "wenoz", "hlle"),
                                                  ("glmmhd", "ppm", "hlld"), ("glmmhd", "limo3", "hlld"),
