@@ -2671,6 +2671,14 @@ int apk_sim_num_peers(const apk_sim *s) {
   return s->active_msgs ? (int)s->active_msgs->plan.peers.size() : (int)s->mesh.peers.size();
 }
 long long apk_sim_message_generation(const apk_sim *s) { return s ? s->msg_generation : 0; }
+// plan introspection: make the halo (1) or flux-correction (2) message set of a refined mesh the one
+// apk_sim_peer reports (0: back to the uniform mesh's)
+int apk_sim_select_messages(apk_sim *s, int which) {
+  if (!s || which < 0 || which > 2 || (which > 0 && !s->amr)) return APK_ERR_INVALID;
+  s->active_msgs = which == 0 ? nullptr : (which == 1 ? &s->amr_halo : &s->amr_fluxmsg);
+  s->msg_generation += 1;
+  return APK_OK;
+}
 
 int apk_sim_peer(const apk_sim *s, int p, apk_peer_info *o) {
   if (!s || !o || p < 0 || p >= apk_sim_num_peers(s)) return APK_ERR_INVALID;
@@ -2696,6 +2704,17 @@ int apk_sim_peer(const apk_sim *s, int p, apk_peer_info *o) {
 const std::vector<BoxRegion> *plan_of_phase(const apk_sim *s, int phase) {
   if (phase >= 0 && phase < PH_COUNT) return &s->mesh.plan[phase];
   if (!s->amr) return nullptr;
+  // this rank's share (local block numbers; kinds 1 / 2 = message buffers of the halo set for 20..24,
+  // of the flux-correction set for 25..33)
+  const auto &l = s->amr_local;
+  if (phase == 20) return &l.fill;
+  if (phase == 21) return &l.fill_pack;
+  if (phase == 22) return &l.fill_unpack;
+  if (phase >= 25 && phase <= 27) return &l.flux_copy[phase - 25];
+  if (phase >= 28 && phase <= 30) return &l.flux_pack[phase - 28];
+  if (phase >= 31 && phase <= 33) return &l.flux_unpack[phase - 31];
+  if (phase >= 34 && phase <= 36) return &l.coarse_bc[phase - 34];
+  if (phase >= 37 && phase <= 39) return &l.fine_bc[phase - 37];
   if (phase == 10) return &s->amr_plans.fill;
   if (phase >= 11 && phase <= 13) return &s->amr_plans.coarse_bc[phase - 11];
   if (phase >= 14 && phase <= 16) return &s->amr_plans.fine_bc[phase - 14];
@@ -2731,6 +2750,10 @@ int apk_sim_plan_region(const apk_sim *s, int phase, int r, apk_region_info *o) 
 // operator lists of the multilevel plans: 0 restrict-own, 1 prolongate, 2..4 flux restriction x1..x3
 const std::vector<AmrRefOp> *ops_of(const apk_sim *s, int which) {
   if (!s->amr) return nullptr;
+  // 10..14: this rank's share of 0..4 (local block numbers)
+  if (which == 10) return &s->amr_local.restrict_own;
+  if (which == 11) return &s->amr_local.prolongate;
+  if (which >= 12 && which <= 14) return &s->amr_local.flux_restrict[which - 12];
   if (which == 0) return &s->amr_plans.restrict_own;
   if (which == 1) return &s->amr_plans.prolongate;
   if (which >= 2 && which <= 4) return &s->amr_plans.flux_restrict[which - 2];

@@ -103,8 +103,26 @@ class _MeshView:
               # refined meshes (src/.. host/amr.hpp): all copies of the multilevel exchange, the
               # physical boundaries of coarse buffers / blocks, the flux-correction copies
               "amr_fill": 10, "amr_coarse_bc1": 11, "amr_coarse_bc2": 12, "amr_coarse_bc3": 13,
-              "amr_bc1": 14, "amr_bc2": 15, "amr_bc3": 16, "amr_flux1": 17, "amr_flux2": 18, "amr_flux3": 19}
-    AMR_OPS = {"restrict_own": 0, "prolongate": 1, "flux_restrict1": 2, "flux_restrict2": 3, "flux_restrict3": 4}
+              "amr_bc1": 14, "amr_bc2": 15, "amr_bc3": 16, "amr_flux1": 17, "amr_flux2": 18, "amr_flux3": 19,
+              # this rank's share of them (local block numbers, message buffers)
+              "my_fill": 20, "my_fill_pack": 21, "my_fill_unpack": 22,
+              "my_flux1": 25, "my_flux2": 26, "my_flux3": 27, "my_flux_pack1": 28, "my_flux_pack2": 29,
+              "my_flux_pack3": 30, "my_flux_unpack1": 31, "my_flux_unpack2": 32, "my_flux_unpack3": 33,
+              "my_coarse_bc1": 34, "my_coarse_bc2": 35, "my_coarse_bc3": 36, "my_bc1": 37, "my_bc2": 38, "my_bc3": 39}
+    AMR_OPS = {"restrict_own": 0, "prolongate": 1, "flux_restrict1": 2, "flux_restrict2": 3, "flux_restrict3": 4,
+               "my_restrict_own": 10, "my_prolongate": 11, "my_flux_restrict1": 12, "my_flux_restrict2": 13,
+               "my_flux_restrict3": 14}
+
+    def messages(self, which):
+        """[(peer rank, send doubles, recv doubles)] of a refined mesh's "halo" / "flux" message set"""
+        self.lib.apk_sim_select_messages(self.h, {"uniform": 0, "halo": 1, "flux": 2}[which])
+        out = []
+        for p in range(self.lib.apk_sim_num_peers(self.h)):
+            pi = L.PeerInfo()
+            self.lib.apk_sim_peer(self.h, p, C.byref(pi))
+            out.append((pi.rank, pi.send_count, pi.recv_count))
+        self.lib.apk_sim_select_messages(self.h, 0)
+        return out
 
     def block_gid(self, lb):
         gid = C.c_int(0)

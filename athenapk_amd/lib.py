@@ -227,6 +227,7 @@ def _signatures():
         "apk_sim_plan_size": (i, [vp, i]),
         "apk_sim_plan_region": (i, [vp, i, i, C.POINTER(RegionInfo)]),
         "apk_sim_num_peers": (i, [vp]),
+        "apk_sim_select_messages": (i, [vp, i]),
         "apk_sim_message_generation": (ll, [vp]),
         "apk_sim_amr_ops_size": (i, [vp, i]),
         "apk_sim_amr_op": (i, [vp, i, i, C.POINTER(AmrOpInfo)]),

@@ -201,10 +201,16 @@ int apk_sim_peer(const apk_sim *sim, int p, apk_peer_info *info);
  * changes peers, sizes and buffers: an exchange callback re-reads the set whenever
  * apk_sim_message_generation has changed since it last looked. */
 int apk_sim_num_peers(const apk_sim *sim);
+/* introspection: report the halo (1) / flux-correction (2) message set of a refined mesh through
+ * apk_sim_peer (0 = the uniform mesh's set) */
+int apk_sim_select_messages(apk_sim *sim, int which);
 long long apk_sim_message_generation(const apk_sim *sim);
 /* number of box copies in each phase: 0 local, 1 pack, 2 unpack, 3..5 physical BC x1..x3; on
  * refined meshes 10 = all copies of the multilevel exchange, 11..13 = coarse-buffer boundaries,
- * 14..16 = block boundaries, 17..19 = flux-correction copies x1..x3 */
+ * 14..16 = block boundaries, 17..19 = flux-correction copies x1..x3 (10..19: the global plan
+ * every rank builds, global block numbers); this rank's share with local block numbers and message
+ * buffers: 20 fill copies, 21 packs, 22 unpacks, 25..27 / 28..30 / 31..33 flux-correction copies /
+ * packs / unpacks x1..x3, 34..36 coarse-buffer boundaries, 37..39 block boundaries */
 int apk_sim_plan_size(const apk_sim *sim, int phase);
 /* region r of a phase, with src/dst expressed as (kind, block, element offset):
  * kind 0 = local block cons, 1 = send buffer of peer `block`, 2 = recv buffer of peer `block`,
@@ -218,7 +224,8 @@ typedef struct apk_region_info {
 int apk_sim_plan_region(const apk_sim *sim, int phase, int r, apk_region_info *info);
 /* operator lists of the multilevel exchange, in execution order restrict-own (which = 0) ->
  * phase 10 -> 11..13 -> prolongate (1) -> 14..16; flux correction: per direction d, which = 2 + d
- * then phase 17 + d.  kind is an APK_RO_* value; index boxes in coarse-buffer indices. */
+ * then phase 17 + d.  which + 10 = this rank's share (local block numbers).  kind is an APK_RO_*
+ * value; index boxes in coarse-buffer indices. */
 typedef struct apk_amr_op_info {
   int kind, level;
   int src_kind, src_block, dst_kind, dst_block;

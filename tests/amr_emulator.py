@@ -44,9 +44,20 @@ class Emulator:
     def _base(self, kind, idx):
         if kind == 0:
             return self.cons[idx].reshape(-1)
+        if kind == 1:
+            return self.send[idx]
+        if kind == 2:
+            return self.recv[idx]
         if kind == 3:
             return self.coarse[idx]
         return self.flux[kind - 4][idx].reshape(-1)
+
+    def use_messages(self, which):
+        """allocate the per-peer buffers of the "halo" / "flux" message set; returns the peer list"""
+        self.peers = self.v.messages(which)
+        self.send = [np.full(sc, np.nan) for _, sc, _ in self.peers]
+        self.recv = [np.full(rc, np.nan) for _, _, rc in self.peers]
+        return self.peers
 
     def _copy(self, phase):
         for reg in self.v.regions(phase):
@@ -120,3 +131,43 @@ class Emulator:
         for d in range(self.info.ndim):
             self._ops("flux_restrict%d" % (d + 1))
             self._copy("amr_flux%d" % (d + 1))
+
+
+def _wire(ems):
+    """deliver every send buffer into the matching receive buffer (the comm callback's job)"""
+    for r, e in enumerate(ems):
+        for p, (peer, sc, rc) in enumerate(e.peers):
+            q = [n for n, (pr, _, _) in enumerate(ems[peer].peers) if pr == r]
+            assert len(q) == 1 and ems[peer].peers[q[0]][2] == sc, "message sizes disagree between ranks %d and %d" % (r, peer)
+            ems[peer].recv[q[0]][:] = e.send[p]
+
+
+def exchange_on_ranks(ems):
+    """the multilevel exchange with the blocks distributed over len(ems) ranks (one Emulator per rank
+    over that rank's HostPlan): every rank executes its share of the plans, messages are wired"""
+    for e in ems:
+        e.use_messages("halo")
+        e._ops("my_restrict_own")
+        e._copy("my_fill_pack")
+        e._copy("my_fill")
+    _wire(ems)
+    for e in ems:
+        e._copy("my_fill_unpack")
+        for d in (1, 2, 3):
+            e._copy("my_coarse_bc%d" % d)
+        e._ops("my_prolongate")
+        for d in (1, 2, 3):
+            e._copy("my_bc%d" % d)
+
+
+def flux_correction_on_ranks(ems):
+    for e in ems:
+        e.use_messages("flux")
+        for d in range(e.info.ndim):
+            e._ops("my_flux_restrict%d" % (d + 1))
+            e._copy("my_flux%d" % (d + 1))
+            e._copy("my_flux_pack%d" % (d + 1))
+    _wire(ems)
+    for e in ems:
+        for d in range(e.info.ndim):
+            e._copy("my_flux_unpack%d" % (d + 1))

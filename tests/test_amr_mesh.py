@@ -4,7 +4,7 @@ operators (tests/amr_emulator.py)."""
 import numpy as np
 import pytest
 
-from amr_emulator import Emulator, placement
+from amr_emulator import Emulator, exchange_on_ranks, flux_correction_on_ranks, placement
 
 SMR3 = ["parthenon/mesh/refinement=static", "parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=32",
         "parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=8",
@@ -30,9 +30,9 @@ def _bc(kind):
     return ["parthenon/mesh/%sx%d_bc=%s" % (io, d, kind) for d in (1, 2, 3) for io in "io"]
 
 
-def _view(overrides):
+def _view(overrides, rank=0, nranks=1):
     from athenapk_amd import decks, driver
-    return driver.HostPlan(decks.load("blast"), overrides)
+    return driver.HostPlan(decks.load("blast"), overrides, rank=rank, nranks=nranks)
 
 
 def _cell_centres(view, lb, pl):
@@ -197,3 +197,48 @@ def test_flux_correction_plan_matches_fine_fluxes(oracle):
         for lb in range(em.nb):
             assert np.array_equal(em.flux[d][lb][~touched[lb]], before[d][lb][~touched[lb]])
     assert changed > 0
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 7])
+@pytest.mark.parametrize("ov,bc", [(SMR3, "periodic"), (SMR2, "outflow"), (SMR3_NG4, "reflecting")], ids=["3d", "2d", "3d_ng4"])
+def test_distributed_plans_reproduce_the_one_rank_exchange(oracle, ov, bc, nranks):
+    """the forest's blocks in Z-order ranges over nranks ranks, every rank executing its share of the
+    plans and one halo / one flux-correction message per peer: same ghost zones and corrected fluxes as
+    on one rank, bit for bit; equal shares; symmetric message sizes"""
+    one = _view(ov + _bc(bc))
+    ref = Emulator(one, oracle)
+    rng = np.random.default_rng(17)
+    for lb in range(ref.nb):
+        ref.cons[lb][:] = rng.uniform(0.5, 2.0, ref.shape)
+        for d in range(3):
+            ref.flux[d][lb][:] = rng.standard_normal(ref.shape)
+    where = {(one.block_level(lb), one.block_gid(lb)[1]): lb for lb in range(ref.nb)}
+    views = [_view(ov + _bc(bc), rank=r, nranks=nranks) for r in range(nranks)]
+    ems = [Emulator(v, oracle) for v in views]
+    counts = [e.nb for e in ems]
+    assert sum(counts) == ref.nb and max(counts) - min(counts) <= 1
+    first = 0
+    for v, e in zip(views, ems):
+        for lb in range(e.nb):
+            assert v.block_gid(lb)[0] == first + lb          # contiguous Z-order ranges
+            g = where[(v.block_level(lb), v.block_gid(lb)[1])]
+            assert g == first + lb
+            e.cons[lb][:] = ref.cons[g]
+            for d in range(3):
+                e.flux[d][lb][:] = ref.flux[d][g]
+        first += e.nb
+    ref.exchange()
+    ref.flux_correction()
+    exchange_on_ranks(ems)
+    flux_correction_on_ranks(ems)
+    first = 0
+    for e in ems:
+        for lb in range(e.nb):
+            assert np.array_equal(e.cons[lb], ref.cons[first + lb])
+            for d in range(ref.info.ndim):
+                assert np.array_equal(e.flux[d][lb], ref.flux[d][first + lb])
+        first += e.nb
+    # the halo message carries strips of every kind, the flux message only planes: much smaller
+    halo = sum(sc for v in views for _, sc, _ in v.messages("halo"))
+    flux = sum(sc for v in views for _, sc, _ in v.messages("flux"))
+    assert halo > 0 and 0 < flux < halo
