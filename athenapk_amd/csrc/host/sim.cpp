@@ -556,6 +556,22 @@ void field_loop_potential(const FieldLoopState &f, double x1, double x2, double 
   }
 }
 
+// Kelvin-Helmholtz (src/pgen/kh.cpp): validate the deck when the sim is created
+void kh_setup(apk_sim *s) {
+  ParameterInput &pin = s->pin;
+  if (s->pkg.fluid == APK_FLUID_GLMMHD) throw std::runtime_error("the kh problem generator is hydro only");
+  if (s->mesh.ndim < 2) throw std::runtime_error("kh needs a 2-D or 3-D mesh");
+  (void)pin.GetReal("problem/kh", "vflow");
+  const int iprob = pin.GetInteger("problem/kh", "iprob");
+  if (iprob < 2 || iprob > 5) throw std::runtime_error("Unknow iprob for KHI pgen.");
+  (void)pin.GetReal("problem/kh", "amp");
+  if (iprob == 5) {
+    (void)pin.GetReal("problem/kh", "a");
+    (void)pin.GetReal("problem/kh", "sigma");
+    (void)pin.GetReal("problem/kh", "drat");
+  }
+}
+
 void pgen_block(apk_sim *s, int lb, std::vector<double> &u) {
   LevelDxScope level_dx_scope(s, lb);
   const Mesh &m = s->mesh;
@@ -602,6 +618,24 @@ void pgen_block(apk_sim *s, int lb, std::vector<double> &u) {
     adv[6] = pin.GetOrAddReal("problem/advection", "rho0", 1.0);
     adv[7] = pin.GetOrAddReal("problem/advection", "p0", 1.0);
     adv[8] = -adv[4] * adv[4] / 2 / std::log(adv[5]);  // sigmasq
+  }
+  double kh[8] = {0};
+  int kh_iprob = 0;
+  if (s->problem_id == "kh") {  // src/pgen/kh.cpp:44-45 and the per-iprob parameter reads
+    if (mhd) throw std::runtime_error("the kh problem generator is hydro only");
+    if (m.ndim < 2) throw std::runtime_error("kh needs a 2-D or 3-D mesh");
+    kh[0] = pin.GetReal("problem/kh", "vflow");
+    kh_iprob = pin.GetInteger("problem/kh", "iprob");
+    if (kh_iprob < 2 || kh_iprob > 5) throw std::runtime_error("Unknow iprob for KHI pgen.");
+    kh[1] = pin.GetReal("problem/kh", "amp");
+    if (kh_iprob == 4) {
+      kh[2] = pin.GetOrAddReal("problem/kh", "drho_rho0", 0.0);
+      kh[3] = pin.GetOrAddReal("problem/kh", "vboost", 0.0);
+    } else if (kh_iprob == 5) {
+      kh[4] = pin.GetReal("problem/kh", "a");
+      kh[5] = pin.GetReal("problem/kh", "sigma");
+      kh[6] = pin.GetReal("problem/kh", "drat");
+    }
   }
   double lwi[5] = {0};
   if (s->problem_id == "lw_implode") {  // src/pgen/lw_implode.cpp:24-57
@@ -660,6 +694,47 @@ void pgen_block(apk_sim *s, int lb, std::vector<double> &u) {
           at(7, k, j, i) = b3;
           at(4, k, j, i) = c.pres / c.gm1 + 0.5 * (b1 * b1 + b2 * b2 + b3 * b3) +
                            (0.5 / c.den) * (mom[0] * mom[0] + mom[1] * mom[1] + mom[2] * mom[2]);
+        } else if (s->problem_id == "kh") {  // src/pgen/kh.cpp:61-234
+          const double vflow = kh[0], amp = kh[1];
+          double d = 1.0, m1 = 0.0, m2 = 0.0, pr = 1.0;
+          if (kh_iprob == 2) {  // one tanh shear layer (Frank et al. 1996)
+            const double a = 0.02, sigma = 0.2;
+            m1 = vflow * std::tanh(x2 / a);
+            m2 = amp * std::cos(2.0 * M_PI * x1) * std::exp(-(x2 * x2) / (sigma * sigma));
+          } else if (kh_iprob == 3) {  // two resolved layers at |y| = 0.5 (Beckwith & Stone 2011)
+            const double a = 0.01, sigma = 0.1, s2 = std::abs(x2) - 0.5;
+            d = 0.505 + 0.495 * std::tanh(s2 / a);
+            m1 = vflow * std::tanh(s2 / a);
+            m2 = amp * vflow * std::sin(2.0 * M_PI * x1) * std::exp(-(s2 * s2) / (sigma * sigma));
+            if (x2 < 0.0) m2 *= -1.0;
+            m1 *= d;
+            m2 *= d;
+          } else if (kh_iprob == 4) {  // Lecoanet et al. 2016, domain centred on the origin
+            const double a = 0.05, sigma = 0.2, z1 = -0.5, z2 = 0.5;
+            const double t1 = std::tanh((x2 - z1) / a), t2 = std::tanh((x2 - z2) / a);
+            pr = 10.0;
+            d = 1.0 + 0.5 * kh[2] * (t1 - t2);
+            m1 = (vflow * (t1 - t2 - 1.0) + kh[3]) * d;
+            // the sine averaged with minus its half-period shift, for shift symmetry in floating point
+            double ave_sine = std::sin(2.0 * M_PI * x1);
+            ave_sine -= std::sin(2.0 * M_PI * ((x1 > 0.0 ? -0.5 : 0.5) + x1));
+            ave_sine /= 2.0;
+            const double v2 = -amp * ave_sine *
+                              (std::exp(-((x2 - z1) * (x2 - z1)) / (sigma * sigma)) + std::exp(-((x2 - z2) * (x2 - z2)) / (sigma * sigma)));
+            m2 = v2 * d;
+          } else {  // iprob 5: dense stream in |y| < 1/4, m = 2 perturbation (the AMR test)
+            const double s2 = std::abs(x2) - 0.25;
+            const double w = (std::tanh(s2 / kh[4]) + 1.0) * 0.5;
+            pr = 2.5;
+            d = w + (1.0 - w) * kh[6];
+            m1 = d * vflow * (w - 0.5);
+            m2 = d * amp * std::cos(2.0 * 2.0 * M_PI * x1) * std::exp(-(s2 * s2) / (kh[5] * kh[5]));
+          }
+          at(0, k, j, i) = d;
+          at(1, k, j, i) = m1;
+          at(2, k, j, i) = m2;
+          at(3, k, j, i) = 0.0;
+          at(4, k, j, i) = pr / gm1 + 0.5 * (m1 * m1 + m2 * m2) / d;
         } else if (s->problem_id == "field_loop") {  // src/pgen/field_loop.cpp:292-322
           const FieldLoopState &f = s->floop;
           const bool two_d = m.ndim < 3;
@@ -1930,6 +2005,7 @@ int create_common(const char *deck, const char *const *overrides, int noverrides
     if (s->problem_id == "linear_wave") lw_setup(s);
     else if (s->problem_id == "cpaw") cpaw_setup(s);
     else if (s->problem_id == "field_loop") field_loop_setup(s);
+    else if (s->problem_id == "kh") kh_setup(s);
     else if (s->problem_id == "advection") {
       // advection::InitUserMeshData (src/pgen/advection.cpp:34-59): tlim counts box diagonals / |v|
       const double vx = s->pin.GetOrAddReal("problem/advection", "vx", 0.0), vy = s->pin.GetOrAddReal("problem/advection", "vy", 0.0),
@@ -1944,7 +2020,7 @@ int create_common(const char *deck, const char *const *overrides, int noverrides
     else if (s->problem_id == "turbulence") turbulence_setup(s);
     else if (s->problem_id != "sod" && s->problem_id != "orszag_tang" && s->problem_id != "synthetic" &&
              s->problem_id != "blast" && s->problem_id != "lw_implode" && s->problem_id != "cpaw" &&
-             s->problem_id != "advection" && s->problem_id != "field_loop")
+             s->problem_id != "advection" && s->problem_id != "field_loop" && s->problem_id != "kh")
       throw std::runtime_error("unknown job/problem_id: " + s->problem_id);
   } catch (const std::exception &e) {
     if (errbuf && errlen) std::snprintf(errbuf, errlen, "%s", e.what());

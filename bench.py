@@ -100,6 +100,37 @@ def cpu_baseline(fluid, integrator, recon, riemann, target_s=10.0):
                       "serial_value: 1 thread on 64^3" % (cycles, n, mb, best_t, cands, cores, dt)}
 
 
+def amr_blast_bench(cycles=40):
+    """BASELINE config 5's shape (inputs/blast_3d_amr.in with root 64^3 in 16^3 meshblocks, 4 levels,
+    regridding every cycle) for the hydro deck and for GLM-MHD PPM+HLLD: zone-cycles/s counted over
+    the blocks that exist in each cycle, like Parthenon's performance line.  Supplementary."""
+    import torch
+    from athenapk_amd import decks, driver
+    ov = ["parthenon/mesh/nx%d=64" % d for d in (1, 2, 3)] + ["parthenon/meshblock/nx%d=16" % d for d in (1, 2, 3)]
+    ov += ["parthenon/mesh/numlevel=4"]
+    out = {}
+    for name, extra in (("hydro_plm_hlle_vl2", []),
+                        ("mhd_ppm_hlld_vl2", ["hydro/fluid=glmmhd", "hydro/riemann=hlld", "hydro/reconstruction=ppm",
+                                              "parthenon/mesh/nghost=4"])):
+        s = driver.Simulation(decks.load("blast_3d_amr"), ov + extra).initialize()
+        for _ in range(3):
+            s.step()
+        torch.cuda.synchronize()
+        z0, t0 = s.amr_stats()[3], time.perf_counter()
+        for _ in range(cycles):
+            s.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        refined, merged, maxlev, z1 = s.amr_stats()
+        i = s.refresh_info()
+        out[name] = {"zone_cycles_per_s": (z1 - z0) / dt, "ms_per_cycle": dt / cycles * 1e3,
+                     "meshblocks": int(i.nblocks_total), "levels": maxlev + 1, "blocks_refined": refined,
+                     "sibling_groups_merged": merged}
+        s.close()
+    out["mesh"] = "root 64^3 in 16^3 meshblocks, 4 levels, adaptive (pressure gradient), flux-array path + flux correction"
+    return out
+
+
 def general_stage_bench(recon="ppm", riemann="hlld", nb=8, n=128, reps=5):
     """SURVEY 8(d) "synthetic kernel benchmark (north_star target)": one pack of nb random-smooth
     128^3 GLM-MHD blocks, the GENERAL RK stage (gam0 = gam1 = 1/2: u0 is read as well, 288 B per
@@ -333,6 +364,11 @@ def main():
                 out["roofline"]["general_stage"] = general_stage_bench(recon, riemann)
             except Exception as e:  # supplementary figure; never lose the headline
                 out["roofline"]["general_stage"] = {"error": repr(e)}
+        if world == 1 and fluid == "glmmhd" and not args.unfused:
+            try:
+                out["amr_blast_cfg5"] = amr_blast_bench()
+            except Exception as e:  # supplementary figure
+                out["amr_blast_cfg5"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(fluid, integrator, recon, riemann)

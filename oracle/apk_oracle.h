@@ -161,6 +161,8 @@ void orc_pgen_sod(orc_sim *s, double rho_l, double pres_l, double u_l, double rh
                   double pres_r, double u_r, double x_discont);
 /* src/pgen/orszag_tang.cpp:25-63 */
 void orc_pgen_orszag_tang(orc_sim *s);
+void orc_pgen_kh(orc_sim *s, int iprob, double vflow, double amp, double drho_rho0, double vboost, double a5,
+                 double sigma5, double drat5);
 void orc_pgen_field_loop(orc_sim *s, double rad, double amp, double vflow, double drat, int iprob);
 double orc_user_reldivb(orc_sim *s, double B0);
 void orc_pgen_advection(orc_sim *s, double vx, double vy, double vz, double rho_ratio, double rho_radius,

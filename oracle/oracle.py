@@ -106,6 +106,7 @@ def _declare(lib):
         "orc_pgen_sod": (None, [C.c_void_p, d, d, d, d, d, d, d]),
         "orc_pgen_orszag_tang": (None, [C.c_void_p]),
         "orc_pgen_field_loop": (None, [C.c_void_p, d, d, d, d, i]),
+        "orc_pgen_kh": (None, [C.c_void_p, i, d, d, d, d, d, d, d]),
         "orc_user_reldivb": (d, [C.c_void_p, d]),
         "orc_pgen_advection": (None, [C.c_void_p, d, d, d, d, d, d, d, d]),
         "orc_pgen_cpaw": (d, [C.c_void_p, d, d, d, d, i, d, d]),
@@ -275,6 +276,10 @@ class Sim:
             self.lib.orc_pgen_orszag_tang(self.h)
         elif name == "synthetic":
             self.lib.orc_pgen_synthetic(self.h)
+        elif name == "kh":
+            self.lib.orc_pgen_kh(self.h, kw.get("iprob", 4), kw.get("vflow", 1.0), kw.get("amp", 0.01),
+                                 kw.get("drho_rho0", 0.0), kw.get("vboost", 0.0), kw.get("a", 0.01), kw.get("sigma", 0.1),
+                                 kw.get("drat", 2.0))
         elif name == "field_loop":
             self.lib.orc_pgen_field_loop(self.h, kw.get("rad", 0.3), kw.get("amp", 1e-3), kw.get("vflow", 1.0),
                                          kw.get("drat", 1.0), kw.get("iprob", 1))

@@ -673,6 +673,62 @@ void orc_pgen_lw_implode(orc_sim *s, double d_in, double p_in, double d_out, dou
   }
 }
 
+/* ---- Kelvin-Helmholtz shear layers (src/pgen/kh.cpp:43-239), iprob 2..5 ----------------------------- */
+void orc_pgen_kh(orc_sim *s, int iprob, double vflow, double amp, double drho_rho0, double vboost, double a5,
+                 double sigma5, double drat5) {
+  const sb_t bb = sim_bounds(&s->g);
+  const double gm1 = s->p.eos.gamma - 1.0;
+  for (int b = 0; b < s->nblocks; ++b) {
+    double x0[3];
+    orc_sim_block_origin(s, b, x0);
+    double *u = s->cons[b];
+    for (int k = bb.ks; k <= bb.ke; ++k)
+      for (int j = bb.js; j <= bb.je; ++j)
+        for (int i = bb.is; i <= bb.ie; ++i) {
+          const double x = xc(s, x0, 0, i), y = xc(s, x0, 1, j);
+          double d = 1.0, m1 = 0.0, m2 = 0.0, pr = 1.0;
+          if (iprob == 2) { /* single tanh shear layer, Frank et al. 1996 */
+            const double a = 0.02, sigma = 0.2;
+            m1 = vflow * tanh(y / a);
+            m2 = amp * cos(2.0 * M_PI * x) * exp(-(y * y) / (sigma * sigma));
+          } else if (iprob == 3) { /* two resolved layers at y = +-0.5, Beckwith & Stone 2011 */
+            const double a = 0.01, sigma = 0.1;
+            d = 0.505 + 0.495 * tanh((fabs(y) - 0.5) / a);
+            m1 = vflow * tanh((fabs(y) - 0.5) / a);
+            m2 = amp * vflow * sin(2.0 * M_PI * x) * exp(-((fabs(y) - 0.5) * (fabs(y) - 0.5)) / (sigma * sigma));
+            if (y < 0.0) m2 *= -1.0;
+            m1 *= d;
+            m2 *= d;
+          } else if (iprob == 4) { /* Lecoanet et al. 2016 in coordinates centred on the origin */
+            const double a = 0.05, sigma = 0.2, z1 = -0.5, z2 = 0.5;
+            pr = 10.0;
+            d = 1.0 + 0.5 * drho_rho0 * (tanh((y - z1) / a) - tanh((y - z2) / a));
+            const double v1 = vflow * (tanh((y - z1) / a) - tanh((y - z2) / a) - 1.0) + vboost;
+            m1 = v1 * d;
+            /* sine averaged with minus its half-period shift: exact shift symmetry in floating point */
+            double ave_sine = sin(2.0 * M_PI * x);
+            if (x > 0.0) ave_sine -= sin(2.0 * M_PI * (-0.5 + x));
+            else ave_sine -= sin(2.0 * M_PI * (0.5 + x));
+            ave_sine /= 2.0;
+            const double v2 = -amp * ave_sine *
+                              (exp(-((y - z1) * (y - z1)) / (sigma * sigma)) + exp(-((y - z2) * (y - z2)) / (sigma * sigma)));
+            m2 = v2 * d;
+          } else { /* iprob 5: stream of density drat in |y| < 1/4, m = 2 perturbation (the AMR test) */
+            const double w = (tanh((fabs(y) - 0.25) / a5) + 1.0) * 0.5;
+            pr = 2.5;
+            d = w + (1.0 - w) * drat5;
+            m1 = d * vflow * (w - 0.5);
+            m2 = d * amp * cos(2.0 * 2.0 * M_PI * x) * exp(-((fabs(y) - 0.25) * (fabs(y) - 0.25)) / (sigma5 * sigma5));
+          }
+          SAT(u, ORC_IDN, k, j, i) = d;
+          SAT(u, ORC_IM1, k, j, i) = m1;
+          SAT(u, ORC_IM2, k, j, i) = m2;
+          SAT(u, ORC_IM3, k, j, i) = 0.0;
+          SAT(u, ORC_IEN, k, j, i) = pr / gm1 + 0.5 * (m1 * m1 + m2 * m2) / d;
+        }
+  }
+}
+
 /* ---- advected field loop (src/pgen/field_loop.cpp:105-316) ----------------------------------------- */
 typedef struct {
   int iprob;

@@ -281,6 +281,26 @@ def test_adaptive_mesh_follows_an_advected_blob():
     assert 1.3 < rho < 2.0101          # rho0 (1 + rho_ratio exp(..)), smeared by the PLM + HLLE advection
 
 
+def test_kh_with_velocity_gradient_refinement():
+    """kh iprob 5 is the reference's AMR test problem (kh.cpp:205-210): the xy-velocity-gradient
+    criterion puts the fine blocks on the two slip surfaces and nowhere else"""
+    ov = ["problem/kh/iprob=5", "problem/kh/a=0.01", "problem/kh/sigma=0.2", "problem/kh/drat=2.0", "problem/kh/amp=0.01",
+          "hydro/gamma=1.4", "parthenon/mesh/refinement=adaptive", "parthenon/mesh/numlevel=3", "parthenon/mesh/nx1=64",
+          "parthenon/mesh/nx2=64", "parthenon/mesh/x2min=-0.5", "parthenon/mesh/x2max=0.5", "parthenon/meshblock/nx1=8",
+          "parthenon/meshblock/nx2=8", "refinement/type=xyvelocity_gradient",
+          "refinement/threshold_xyvelocity_gradient=0.01", "parthenon/time/tlim=0.1"]
+    s = _sim("kh-shear-lecoanet_2d", ov, strict=False).initialize()
+    pl = placement(s)
+    fine = [x0[1] + 4 * dx[1] for lev, loc, x0, dx in pl if lev == 2]
+    assert len(fine) > 16 and all(abs(abs(y) - 0.25) < 0.07 for y in fine)
+    assert all(lev == 0 for lev, loc, x0, dx in pl if abs(abs(x0[1] + 4 * dx[1]) - 0.25) > 0.2)
+    m0 = _totals(s)
+    s.run()
+    m1 = _totals(s)
+    assert abs(m1[0] - m0[0]) < 1e-13 * m0[0] and abs(m1[4] - m0[4]) < 1e-13 * m0[4]
+    assert abs(m1[2]) < 1e-12                     # no net x2 momentum from a cosine mode
+
+
 def test_cli_runs_the_amr_deck(tmp_path, capsys):
     from athenapk_amd import __main__ as cli
     assert cli.main(["-i", "blast_3d_amr", "-d", str(tmp_path), "parthenon/time/tlim=0.01"]) == 0

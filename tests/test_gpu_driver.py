@@ -612,3 +612,32 @@ def test_cli_field_loop_history_columns(tmp_path):
     emag = data[:, 10] / data[0, 10]
     assert np.all(np.diff(emag) < 0) and emag[-1] > 0.8               # slow numerical decay only
     assert np.all(np.abs(data[:, 4] - 2.0) < 1e-12)                   # mass
+
+
+# ---- Kelvin-Helmholtz (src/pgen/kh.cpp; inputs/kh-shear-lecoanet_2d.in) ------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("iprob", [2, 3, 4, 5])
+def test_kh_matches_oracle(oracle, iprob):
+    ov = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=64", "parthenon/meshblock/nx1=16", "parthenon/meshblock/nx2=32",
+          "problem/kh/iprob=%d" % iprob, "problem/kh/a=0.01", "problem/kh/sigma=0.1", "problem/kh/drat=2.0",
+          "parthenon/time/tlim=0.05"]
+    s = _sim("kh-shear-lecoanet_2d", ov, strict=True).initialize()
+    o = oracle.Sim(fluid="euler", recon="plm", riemann="hlle", integrator="vl2", nx=(32, 64, 1), mb=(16, 32, 1), ng=2,
+                   xmin=(-0.5, -1.0, -0.5), xmax=(0.5, 1.0, 0.5), cfl=0.4, gamma=GAMMA_DECK)
+    o.pgen("kh", iprob=iprob, vflow=1.0, amp=0.01, a=0.01, sigma=0.1, drat=2.0)
+    assert np.array_equal(s.gather("cons"), o.gather_cons())
+    assert s.run() == o.run(0.05)
+    assert np.array_equal(s.gather("cons"), o.gather_cons())
+
+
+@pytest.mark.gpu
+def test_kh_lecoanet_keeps_its_shift_reflect_symmetry():
+    """the reference builds the initial condition so that x1 -> x1 + 1/2, x2 -> -x2 maps the flow onto
+    itself exactly (kh.cpp:152-188): the deck as shipped (128 x 256, PLM + HLLE, VL2) keeps it to
+    round-off while the layers roll up"""
+    s = _sim("kh-shear-lecoanet_2d", ["parthenon/time/tlim=0.5"], strict=True).initialize()
+    s.run()
+    u = s.gather("cons")[:, 0]
+    shifted = np.roll(u[:, ::-1, :], 64, axis=2)
+    assert np.abs(u[0] - shifted[0]).max() < 1e-12 and np.abs(u[2] + shifted[2]).max() < 1e-12
+    assert np.abs(u[2]).max() > 0.01              # the perturbation is there (and growing)

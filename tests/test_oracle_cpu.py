@@ -498,3 +498,23 @@ def test_field_loop_advects_and_keeps_magnetic_energy(oracle):
     assert 0.6 < h[6] / me0 < 1.0
     assert abs(h[0] - 1.0 * 2.0) < 1e-12                      # mass = rho * area (volume 2 x 1 x 1)
     assert 0.0 < o.user_reldivb(amp) < 0.5
+
+
+@pytest.mark.parametrize("iprob", [2, 3, 4, 5])
+def test_kh_initial_states(oracle, iprob):
+    """pgen/kh.cpp: shear layers with a single-mode transverse perturbation; iprob 4 (Lecoanet) keeps
+    its shift-and-reflect symmetry x1 -> x1 + 1/2, x2 -> -x2 exactly in floating point"""
+    o = oracle.Sim(fluid="euler", recon="plm", riemann="hlle", integrator="vl2", nx=(32, 64, 1), mb=(16, 32, 1), ng=2,
+                   xmin=(-0.5, -1.0, -0.5), xmax=(0.5, 1.0, 0.5), cfl=0.4, gamma=5.0 / 3.0)
+    o.pgen("kh", iprob=iprob, vflow=1.0, amp=0.01, a=0.01, sigma=0.1, drat=2.0)
+    u = o.gather_cons()[:, 0]
+    assert np.all(u[0] > 0) and np.all(u[3] == 0.0) and np.abs(u[2]).max() > 1e-3
+    p = (5.0 / 3.0 - 1.0) * (u[4] - 0.5 * (u[1] ** 2 + u[2] ** 2) / u[0])
+    assert np.allclose(p, {2: 1.0, 3: 1.0, 4: 10.0, 5: 2.5}[iprob], rtol=1e-13)
+    if iprob == 4:
+        shifted = np.roll(u[:, ::-1, :], 16, axis=2)      # x2 -> -x2, x1 -> x1 + 1/2
+        assert np.array_equal(u[0], shifted[0]) and np.array_equal(u[1], shifted[1])
+        assert np.array_equal(u[2], -shifted[2])
+        assert np.allclose(np.abs(u[1] / u[0]).max(), 1.0, atol=1e-6)
+    if iprob == 5:
+        assert abs(u[0].max() - 2.0) < 1e-6 and abs(u[0].min() - 1.0) < 1e-6
