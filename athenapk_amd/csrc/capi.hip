@@ -180,7 +180,7 @@ void apk_pack_destroy(apk_pack *pack) {
 }
 
 namespace {
-int calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos, double c_h, bool tight,
+int calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos, double c_h, int faces,
                      apk_stream_t stream) {
   if (!ctx || !md || !valid_eos(eos)) return set_err(ctx, APK_ERR_INVALID, "apk_calculate_fluxes: bad argument");
   int rc = check_cfg(ctx, md, cfg);
@@ -192,14 +192,16 @@ int calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const a
   hipStream_t s = as_stream(stream);
   const PackView &pv = md->view;
   ScopedTiming timing(ctx, APK_T_FLUXES, s);
+  if ((cfg.riemann == APK_RS_NONE || cfg.riemann == APK_RS_LLF) && faces == 2)
+    return set_err(ctx, APK_ERR_UNSUPPORTED, "boundary-plane fluxes are not offered for the none / llf entries");
   if (cfg.riemann == APK_RS_NONE || cfg.riemann == APK_RS_LLF)
     rc = launch_fluxes_misc(pv, cfg.fluid, cfg.riemann, eos->gamma, c_h, s);
   else if (cfg.fluid == APK_FLUID_EULER)
-    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_euler_hlle(pv, cfg.recon, eos->gamma, c_h, s, tight)
-                                      : launch_fluxes_euler_hllc(pv, cfg.recon, eos->gamma, c_h, s, tight);
+    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_euler_hlle(pv, cfg.recon, eos->gamma, c_h, s, faces)
+                                      : launch_fluxes_euler_hllc(pv, cfg.recon, eos->gamma, c_h, s, faces);
   else
-    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_mhd_hlle(pv, cfg.recon, eos->gamma, c_h, s, tight)
-                                      : launch_fluxes_mhd_hlld(pv, cfg.recon, eos->gamma, c_h, s, tight);
+    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_mhd_hlle(pv, cfg.recon, eos->gamma, c_h, s, faces)
+                                      : launch_fluxes_mhd_hlld(pv, cfg.recon, eos->gamma, c_h, s, faces);
   if (rc != APK_OK) return set_err(ctx, rc, "flux kernel launch failed", hipGetLastError());
   return APK_OK;
 }
@@ -207,12 +209,17 @@ int calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const a
 
 int apk_calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos,
                          double c_h, apk_stream_t stream) {
-  return calculate_fluxes(ctx, md, cfg, eos, c_h, false, stream);
+  return calculate_fluxes(ctx, md, cfg, eos, c_h, 0, stream);
 }
 
 int apk_calculate_fluxes_tight(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos,
                                double c_h, apk_stream_t stream) {
-  return calculate_fluxes(ctx, md, cfg, eos, c_h, true, stream);
+  return calculate_fluxes(ctx, md, cfg, eos, c_h, 1, stream);
+}
+
+int apk_calculate_fluxes_boundary(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos,
+                                  double c_h, apk_stream_t stream) {
+  return calculate_fluxes(ctx, md, cfg, eos, c_h, 2, stream);
 }
 
 int apk_update_with_flux_divergence(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,

@@ -131,31 +131,54 @@ inline void launch_flux_dir(const PackView &pv, const FluxExtent &e, double gamm
   hipLaunchKernelGGL((flux_kernel<FLUID, RECON, RS, DIR>), grid, block, 0, s, pv, e, gamma, c_h);
 }
 
+// which faces a flux call covers
+enum FluxFaces {
+  FLUX_FACES_REFERENCE = 0,  // the reference's loop limits (one transverse ghost row / plane)
+  FLUX_FACES_TIGHT = 1,      // CalculateFluxesTight's limits: [s, e + 1] in every active direction
+  FLUX_FACES_BOUNDARY = 2    // only the two block-boundary planes of each direction, interior transverse
+};
+
+// the lower (side 0) / upper (side 1) boundary plane of direction dir
+inline FluxExtent boundary_extent(const PackView &pv, int dir, int side) {
+  FluxExtent e;
+  e.i0 = pv.is, e.i1 = pv.ie, e.j0 = pv.js, e.j1 = pv.je, e.k0 = pv.ks, e.k1 = pv.ke;
+  if (dir == 1) e.i0 = e.i1 = side ? pv.ie + 1 : pv.is;
+  else if (dir == 2) e.j0 = e.j1 = side ? pv.je + 1 : pv.js;
+  else e.k0 = e.k1 = side ? pv.ke + 1 : pv.ks;
+  return e;
+}
+
+template <int FLUID, int RECON, int RS, int DIR>
+inline void launch_flux_faces(const PackView &pv, double gamma, double c_h, hipStream_t s, int faces) {
+  if (faces == FLUX_FACES_BOUNDARY) {
+    launch_flux_dir<FLUID, RECON, RS, DIR>(pv, boundary_extent(pv, DIR, 0), gamma, c_h, s);
+    launch_flux_dir<FLUID, RECON, RS, DIR>(pv, boundary_extent(pv, DIR, 1), gamma, c_h, s);
+  } else {
+    launch_flux_dir<FLUID, RECON, RS, DIR>(pv, faces == FLUX_FACES_TIGHT ? tight_extent(pv, DIR) : flux_extent(pv, DIR), gamma,
+                                           c_h, s);
+  }
+}
+
 template <int FLUID, int RECON, int RS>
 inline int launch_flux_all_dirs(const PackView &pv, double gamma, double c_h, hipStream_t s,
-                                bool tight = false) {
-  launch_flux_dir<FLUID, RECON, RS, 1>(pv, tight ? tight_extent(pv, 1) : flux_extent(pv, 1),
-                                       gamma, c_h, s);
-  if (pv.ndim >= 2)
-    launch_flux_dir<FLUID, RECON, RS, 2>(pv, tight ? tight_extent(pv, 2) : flux_extent(pv, 2),
-                                         gamma, c_h, s);
-  if (pv.ndim >= 3)
-    launch_flux_dir<FLUID, RECON, RS, 3>(pv, tight ? tight_extent(pv, 3) : flux_extent(pv, 3),
-                                         gamma, c_h, s);
+                                int faces = FLUX_FACES_REFERENCE) {
+  launch_flux_faces<FLUID, RECON, RS, 1>(pv, gamma, c_h, s, faces);
+  if (pv.ndim >= 2) launch_flux_faces<FLUID, RECON, RS, 2>(pv, gamma, c_h, s, faces);
+  if (pv.ndim >= 3) launch_flux_faces<FLUID, RECON, RS, 3>(pv, gamma, c_h, s, faces);
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }
 
 // recon dispatch for one (fluid, riemann) family: the registry of hydro.cpp:386-416
 template <int FLUID, int RS>
 inline int launch_flux_family(const PackView &pv, int recon, double gamma, double c_h,
-                              hipStream_t s, bool tight) {
+                              hipStream_t s, int faces) {
   switch (recon) {
-  case APK_RC_DC: return launch_flux_all_dirs<FLUID, APK_RC_DC, RS>(pv, gamma, c_h, s, tight);
-  case APK_RC_PLM: return launch_flux_all_dirs<FLUID, APK_RC_PLM, RS>(pv, gamma, c_h, s, tight);
-  case APK_RC_PPM: return launch_flux_all_dirs<FLUID, APK_RC_PPM, RS>(pv, gamma, c_h, s, tight);
-  case APK_RC_WENOZ: return launch_flux_all_dirs<FLUID, APK_RC_WENOZ, RS>(pv, gamma, c_h, s, tight);
-  case APK_RC_WENO3: return launch_flux_all_dirs<FLUID, APK_RC_WENO3, RS>(pv, gamma, c_h, s, tight);
-  case APK_RC_LIMO3: return launch_flux_all_dirs<FLUID, APK_RC_LIMO3, RS>(pv, gamma, c_h, s, tight);
+  case APK_RC_DC: return launch_flux_all_dirs<FLUID, APK_RC_DC, RS>(pv, gamma, c_h, s, faces);
+  case APK_RC_PLM: return launch_flux_all_dirs<FLUID, APK_RC_PLM, RS>(pv, gamma, c_h, s, faces);
+  case APK_RC_PPM: return launch_flux_all_dirs<FLUID, APK_RC_PPM, RS>(pv, gamma, c_h, s, faces);
+  case APK_RC_WENOZ: return launch_flux_all_dirs<FLUID, APK_RC_WENOZ, RS>(pv, gamma, c_h, s, faces);
+  case APK_RC_WENO3: return launch_flux_all_dirs<FLUID, APK_RC_WENO3, RS>(pv, gamma, c_h, s, faces);
+  case APK_RC_LIMO3: return launch_flux_all_dirs<FLUID, APK_RC_LIMO3, RS>(pv, gamma, c_h, s, faces);
   default: return APK_ERR_UNSUPPORTED;
   }
 }

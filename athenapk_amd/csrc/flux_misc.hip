@@ -10,12 +10,12 @@ int launch_fluxes_misc(const PackView &pv, int fluid, int riemann, double gamma,
     if (riemann == APK_RS_NONE)
       return launch_flux_all_dirs<APK_FLUID_EULER, APK_RC_DC, APK_RS_NONE>(pv, gamma, c_h, s);
     if (riemann == APK_RS_LLF)
-      return launch_flux_all_dirs<APK_FLUID_EULER, APK_RC_DC, APK_RS_LLF>(pv, gamma, c_h, s, true);
+      return launch_flux_all_dirs<APK_FLUID_EULER, APK_RC_DC, APK_RS_LLF>(pv, gamma, c_h, s, FLUX_FACES_TIGHT);
   } else if (fluid == APK_FLUID_GLMMHD) {
     if (riemann == APK_RS_NONE)
       return launch_flux_all_dirs<APK_FLUID_GLMMHD, APK_RC_DC, APK_RS_NONE>(pv, gamma, c_h, s);
     if (riemann == APK_RS_LLF)
-      return launch_flux_all_dirs<APK_FLUID_GLMMHD, APK_RC_DC, APK_RS_LLF>(pv, gamma, c_h, s, true);
+      return launch_flux_all_dirs<APK_FLUID_GLMMHD, APK_RC_DC, APK_RS_LLF>(pv, gamma, c_h, s, FLUX_FACES_TIGHT);
   }
   return APK_ERR_UNSUPPORTED;
 }

@@ -1048,8 +1048,9 @@ int ensure_flux_arrays(apk_sim *s) {
 }
 
 bool stage_can_fuse(const apk_sim *s) {
-  // refined meshes take the flux-array path: the coarse-fine flux correction needs the face fluxes
-  return s->fused && !s->amr && !s->pkg.first_order_flux_correct && s->pkg.riemann != APK_RS_NONE &&
+  // (refined meshes included: the coarse-fine flux correction is applied after the fused stage from
+  // boundary-plane fluxes, see amr_flux_fix)
+  return s->fused && !s->pkg.first_order_flux_correct && s->pkg.riemann != APK_RS_NONE &&
          s->pkg.riemann != APK_RS_LLF;
 }
 
@@ -1271,7 +1272,36 @@ void amr_destroy_device_plans(apk_sim *s) {
     apk_copy_plan_destroy(a.flux_pack[d]);
     apk_copy_plan_destroy(a.flux_unpack[d]);
     a.flux_copy[d] = a.flux_pack[d] = a.flux_unpack[d] = nullptr;
+    for (int par = 0; par < 2; ++par) {
+      apk_flux_fix_plan_destroy(a.flux_fix[par][d]);
+      apk_flux_fix_plan_destroy(a.flux_fix_unpack[par][d]);
+      a.flux_fix[par][d] = a.flux_fix_unpack[par][d] = nullptr;
+    }
   }
+}
+
+// the flux-correction copies of direction d as corrections of the cells next to the face (fused path)
+int amr_make_fix_plan(apk_sim *s, int parity, int d, const std::vector<BoxRegion> &regions, const apk_sim::MsgSet *msgs,
+                      apk_flux_fix_plan **out) {
+  const AmrGeom &g = s->amr_geom;
+  std::vector<apk_flux_fix_region> regs;
+  for (const BoxRegion &r : regions) {
+    apk_flux_fix_region f{};
+    f.fine_avg = amr_base(s, parity, r.src_kind, r.src_block, msgs) + r.src_off;
+    f.coarse_flux = amr_base(s, parity, r.dst_kind, r.dst_block, msgs) + r.dst_off;
+    const int idx = (int)((r.dst_off / g.fst[d]) % g.fn[d]);  // face index along d inside the block
+    const bool lower = idx == g.fs[d];
+    f.cons = s->d_cons2[parity] + (int64_t)r.dst_block * s->nper + r.dst_off - (lower ? 0 : g.fst[d]);
+    for (int q = 0; q < 3; ++q) f.ext[q] = r.ext[q];
+    f.nvar = r.nvar;
+    for (int q = 0; q < 4; ++q) {
+      f.src_stride[q] = r.src_stride[q];
+      f.dst_stride[q] = r.dst_stride[q];
+    }
+    f.scale = (lower ? 1.0 : -1.0) / level_dx(s, block_level(s, r.dst_block), d);
+    regs.push_back(f);
+  }
+  return apk_flux_fix_plan_create(s->ctx, regs.data(), (int)regs.size(), out);
 }
 
 // message buffers of a set: (re)allocated when a message outgrows its buffer, never shrunk
@@ -1375,6 +1405,10 @@ int amr_rebuild(apk_sim *s) {
     SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_copy[d], nullptr, &a.flux_copy[d]));
     SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_pack[d], &s->amr_fluxmsg, &a.flux_pack[d]));
     SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_unpack[d], &s->amr_fluxmsg, &a.flux_unpack[d]));
+    for (int par = 0; par < 2; ++par) {
+      SIM_TRY(s, amr_make_fix_plan(s, par, d, p.flux_copy[d], nullptr, &a.flux_fix[par][d]));
+      SIM_TRY(s, amr_make_fix_plan(s, par, d, p.flux_unpack[d], &s->amr_fluxmsg, &a.flux_fix_unpack[par][d]));
+    }
   }
   return build_packs(s);
 }
@@ -1390,6 +1424,32 @@ int amr_exchange(apk_sim *s, int buf) {
   for (int d = 0; d < 3; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.coarse_bc[buf][d], s->stream));
   for (apk_refine_plan *p : a.prolongate[buf]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
   for (int d = 0; d < 3; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fine_bc[buf][d], s->stream));
+  return APK_OK;
+}
+
+// does the forest have a coarse-fine face at all?  (the global plan: the same answer on every rank)
+bool amr_has_coarse_fine_faces(const apk_sim *s) {
+  for (int d = 0; d < 3; ++d)
+    if (!s->amr_plans.flux_copy[d].empty()) return true;
+  return false;
+}
+
+// The flux correction for a stage that ran fused: the stage has applied every block's own face
+// fluxes; recompute the fluxes on the block boundaries from the stage's input primitives, average
+// the fine ones and correct the coarse cells next to each coarse-fine face by the difference.
+int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi_factor) {
+  if (!amr_has_coarse_fine_faces(s)) return APK_OK;
+  auto &a = s->amr_dev;
+  const int psi_var = (s->pkg.fluid == APK_FLUID_GLMMHD) ? 8 : -1;
+  SIM_TRY(s, apk_calculate_fluxes_boundary(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, s->stream));
+  for (int d = 0; d < s->mesh.ndim; ++d) {
+    for (apk_refine_plan *p : a.flux_restrict[d]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
+    SIM_TRY(s, apk_flux_fix_plan_run(s->ctx, a.flux_fix[s->cur][d], beta_dt, psi_var, psi_factor, s->stream));
+    SIM_TRY(s, apk_copy_plan_run(s->ctx, a.flux_pack[d], s->stream));
+  }
+  SIM_TRY(s, amr_exchange_messages(s, s->amr_fluxmsg));
+  for (int d = 0; d < s->mesh.ndim; ++d)
+    SIM_TRY(s, apk_flux_fix_plan_run(s->ctx, a.flux_fix_unpack[s->cur][d], beta_dt, psi_var, psi_factor, s->stream));
   return APK_OK;
 }
 
@@ -1890,7 +1950,9 @@ int do_stage(apk_sim *s, int stage) {
     // (not when the turbulence driver kicks the state after this stage)
     // nor in a 3-D donor-cell stage (the VL2 predictor): its single-march kernel leaves prim
     // untouched and the full ConservedToPrimitive pass is cheaper than the du round trip it avoids
-    fused_fill = (s->mesh.ndim >= 2) && !(s->fmft && stage == s->nstages);
+    // nor on refined meshes (the flux correction changes cells after the stage; the full pass after
+    // the multilevel exchange converts everything)
+    fused_fill = (s->mesh.ndim >= 2) && !(s->fmft && stage == s->nstages) && !s->amr;
     // A 3-D donor-cell stage (the VL2 predictor) runs as ONE march whose lanes read their
     // neighbours' primitives from memory, so it cannot replace prim in place: it writes the new
     // primitives into the spare buffer ("u1.prim") and the two prim buffers swap roles.
@@ -1949,6 +2011,11 @@ int do_stage(apk_sim *s, int stage) {
     SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
     s->stage_dt_pending = a.estimate_dt != 0;
     if (swap_prim) s->pcur = 1 - s->pcur;
+    if (s->amr) {
+      SIM_TRY(s, ensure_flux_arrays(s));
+      const double psi_factor = a.dedner != 0 ? std::exp(-pkg.glmmhd_alpha * pkg.c_h * beta_dt / pkg.mindx) : 1.0;
+      SIM_TRY(s, amr_flux_fix(s, cfg, beta_dt, psi_factor));
+    }
   } else {
     SIM_TRY(s, ensure_flux_arrays(s));
     // (faces of interior cells only: nothing downstream reads the reference's extra transverse rows)

@@ -169,6 +169,10 @@ struct apk_sim {
     std::vector<apk_refine_plan *> restrict_own[2], prolongate[2], flux_restrict[3];
     apk_copy_plan *fill[2] = {nullptr, nullptr}, *fill_pack[2] = {nullptr, nullptr}, *fill_unpack[2] = {nullptr, nullptr};
     apk_copy_plan *flux_pack[3] = {nullptr, nullptr, nullptr}, *flux_unpack[3] = {nullptr, nullptr, nullptr};
+    // the correction applied after a fused stage instead (apk_flux_fix_plan): same-rank faces and
+    // faces whose fine side arrived in a message, per cons buffer the stage wrote
+    apk_flux_fix_plan *flux_fix[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    apk_flux_fix_plan *flux_fix_unpack[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     apk_copy_plan *coarse_bc[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     apk_copy_plan *fine_bc[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     apk_copy_plan *flux_copy[3] = {nullptr, nullptr, nullptr};

@@ -10,6 +10,12 @@
 #include "apk_internal.hpp"
 #include "hydro_math.hpp"
 
+struct apk_flux_fix_plan {
+  apk_flux_fix_region *d_regions = nullptr;
+  int n = 0;
+  int64_t max_items = 0;
+};
+
 struct apk_refine_plan {
   apk_refine_geom geom{};
   int nvar = 0, nops = 0;
@@ -193,6 +199,26 @@ __global__ void __launch_bounds__(256) refine_ops_kernel(apk_refine_geom g, int 
   }
 }
 
+// flux correction after a fused stage: one thread per (face cell, variable) of a region
+__global__ void __launch_bounds__(256) flux_fix_kernel(const apk_flux_fix_region *regions, double beta_dt, int psi_var,
+                                                       double psi_factor) {
+  const apk_flux_fix_region r = regions[blockIdx.x];
+  const int64_t cells = (int64_t)r.ext[0] * r.ext[1] * r.ext[2], items = cells * r.nvar;
+  for (int64_t t = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; t < items; t += (int64_t)gridDim.y * blockDim.x) {
+    const int v = (int)(t / cells);
+    int64_t c = t - (int64_t)v * cells;
+    const int i = (int)(c % r.ext[0]);
+    c /= r.ext[0];
+    const int j = (int)(c % r.ext[1]);
+    const int k = (int)(c / r.ext[1]);
+    const int64_t so = i * r.src_stride[0] + j * r.src_stride[1] + k * r.src_stride[2] + v * r.src_stride[3];
+    const int64_t d = i * r.dst_stride[0] + j * r.dst_stride[1] + k * r.dst_stride[2] + v * r.dst_stride[3];
+    double dv = (beta_dt * r.scale) * (r.fine_avg[so] - r.coarse_flux[d]);
+    if (v == psi_var) dv *= psi_factor;
+    r.cons[d] += dv;
+  }
+}
+
 // ---- tagging ---------------------------------------------------------------------------------
 // one workgroup row per (block, k-plane chunk); the criteria are non-negative, so their bit
 // patterns order like unsigned integers and one atomicMax per workgroup suffices
@@ -318,6 +344,55 @@ int apk_refine_plan_run(apk_ctx *ctx, const apk_refine_plan *p, apk_stream_t str
   hipLaunchKernelGGL(refine_ops_kernel, dim3((unsigned)p->nops, (unsigned)gx), dim3(256), 0, s, p->geom, p->nvar, p->d_ops);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? APK_OK : set_err(ctx, APK_ERR_DEVICE, "refine_ops launch", e);
+}
+
+int apk_flux_fix_plan_create(apk_ctx *ctx, const apk_flux_fix_region *regions, int n, apk_flux_fix_plan **out) {
+  if (!ctx || !out || n < 0 || (n > 0 && !regions)) return set_err(ctx, APK_ERR_INVALID, "apk_flux_fix_plan_create: bad argument");
+  *out = nullptr;
+  apk_flux_fix_plan *p = new (std::nothrow) apk_flux_fix_plan();
+  if (!p) return APK_ERR_INVALID;
+  p->n = n;
+  for (int q = 0; q < n; ++q) {
+    const apk_flux_fix_region &r = regions[q];
+    if (!r.fine_avg || !r.coarse_flux || !r.cons || r.nvar <= 0 || r.ext[0] <= 0 || r.ext[1] <= 0 || r.ext[2] <= 0) {
+      delete p;
+      return set_err(ctx, APK_ERR_INVALID, "apk_flux_fix_plan_create: bad region");
+    }
+    const int64_t items = (int64_t)r.ext[0] * r.ext[1] * r.ext[2] * r.nvar;
+    p->max_items = items > p->max_items ? items : p->max_items;
+  }
+  if (n > 0) {
+    hipError_t e = hipMalloc(&p->d_regions, sizeof(apk_flux_fix_region) * n);
+    if (e == hipSuccess) e = hipMemcpy(p->d_regions, regions, sizeof(apk_flux_fix_region) * n, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      apk_flux_fix_plan_destroy(p);
+      return set_err(ctx, APK_ERR_DEVICE, "apk_flux_fix_plan_create", e);
+    }
+  }
+  *out = p;
+  return APK_OK;
+}
+
+void apk_flux_fix_plan_destroy(apk_flux_fix_plan *p) {
+  if (!p) return;
+  if (p->d_regions) (void)hipFree(p->d_regions);
+  delete p;
+}
+
+int apk_flux_fix_plan_run(apk_ctx *ctx, const apk_flux_fix_plan *p, double beta_dt, int psi_var, double psi_factor,
+                          apk_stream_t stream) {
+  if (!ctx || !p) return set_err(ctx, APK_ERR_INVALID, "apk_flux_fix_plan_run: bad argument");
+  if (p->n == 0) return APK_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int64_t gy = (p->max_items + 255) / 256;
+  if (gy > 1024) gy = 1024;
+  for (int off = 0; off < p->n; off += 1 << 20) {  // (gridDim.x is ample; chunked for symmetry with the copy plans)
+    const int m = (p->n - off < (1 << 20)) ? p->n - off : (1 << 20);
+    hipLaunchKernelGGL(flux_fix_kernel, dim3((unsigned)m, (unsigned)gy), dim3(256), 0, s, p->d_regions + off, beta_dt, psi_var,
+                       psi_factor);
+  }
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? APK_OK : set_err(ctx, APK_ERR_DEVICE, "flux_fix launch", e);
 }
 
 int apk_tag_blocks(apk_ctx *ctx, const apk_pack *md, int criterion, double p0, double p1, int *tags, double *crit,

@@ -78,6 +78,11 @@ REFINE_OPS = {"prolongate": 0, "restrict_cell": 1, "restrict_face1": 2, "restric
 TAG_CRITERIA = {"pressure_gradient": 0, "xyvelocity_gradient": 1, "maxdensity": 2}
 
 
+class FluxFixRegion(C.Structure):
+    _fields_ = [("fine_avg", C.c_void_p), ("coarse_flux", C.c_void_p), ("cons", C.c_void_p), ("ext", C.c_int * 3),
+                ("nvar", C.c_int), ("src_stride", C.c_int64 * 4), ("dst_stride", C.c_int64 * 4), ("scale", C.c_double)]
+
+
 class CopyRegion(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("ext", C.c_int * 3),
                 ("nvar", C.c_int), ("src_stride", C.c_int64 * 4),
@@ -146,6 +151,10 @@ def _signatures():
         "apk_pack_destroy": (None, [vp]),
         "apk_calculate_fluxes": (i, [vp, vp, FluxCfg, E, d, vp]),
         "apk_calculate_fluxes_tight": (i, [vp, vp, FluxCfg, E, d, vp]),
+        "apk_calculate_fluxes_boundary": (i, [vp, vp, FluxCfg, E, d, vp]),
+        "apk_flux_fix_plan_create": (i, [vp, C.POINTER(FluxFixRegion), i, pp]),
+        "apk_flux_fix_plan_destroy": (None, [vp]),
+        "apk_flux_fix_plan_run": (i, [vp, vp, d, i, d, vp]),
         "apk_update_with_flux_divergence": (i, [vp, vp, vp, d, d, d, vp]),
         "apk_dedner_source": (i, [vp, vp, i, d, d, d, d, vp]),
         "apk_stage_fused": (i, [vp, vp, vp, C.POINTER(StageArgs), vp]),

@@ -125,6 +125,11 @@ int apk_calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg,
  * the coarse-fine flux correction consume: 27 % of the faces of a 16^3 meshblock, 56 % of an 8^3. */
 int apk_calculate_fluxes_tight(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg,
                                const apk_eos *eos, double c_h, apk_stream_t stream);
+/* Only the faces on the boundary of each meshblock (two planes per active direction, interior
+ * transverse extent): what the coarse-fine flux correction needs when the stage itself ran fused
+ * (apk_stage_fused never materialises face fluxes; see apk_flux_fix_plan below). */
+int apk_calculate_fluxes_boundary(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg,
+                                  const apk_eos *eos, double c_h, apk_stream_t stream);
 
 /* Replaces parthenon::Update::UpdateWithFluxDivergence<MeshData<Real>>(u0,u1,gam0,gam1,
  * beta_dt); call site src/hydro/hydro_driver.cpp:534-537.
@@ -351,6 +356,30 @@ int apk_refine_plan_create(apk_ctx *ctx, const apk_refine_geom *geom, int nvar,
                            const apk_refine_op *ops /* host */, int nops, apk_refine_plan **out);
 void apk_refine_plan_destroy(apk_refine_plan *p);
 int apk_refine_plan_run(apk_ctx *ctx, const apk_refine_plan *p, apk_stream_t stream);
+
+/* Coarse-fine flux correction AFTER a fused stage (hydro_driver.cpp:527-537 puts it before the flux
+ * divergence; the fused stage has already applied the coarse block's own face flux F, so the cells
+ * next to a coarse-fine face are corrected by the difference): for every element of a region
+ *   cons += beta_dt * scale * (fine_avg - coarse_flux)   [times psi_factor for variable psi_var]
+ * with scale = +1/dx for the lower face of the cell, -1/dx for its upper face; fine_avg is the
+ * area average of the fine blocks' fluxes (an APK_RO_RESTRICT_FLUX* result or a message buffer),
+ * coarse_flux the coarse block's flux on the same face (apk_calculate_fluxes_boundary).  psi_factor
+ * is the Dedner damping exp(-alpha c_h beta_dt / mindx) the stage applied after its update. */
+typedef struct apk_flux_fix_region {
+  const double *fine_avg;    /* strides src_stride */
+  const double *coarse_flux; /* strides dst_stride */
+  double *cons;              /* strides dst_stride */
+  int ext[3];
+  int nvar;
+  int64_t src_stride[4], dst_stride[4];
+  double scale;
+} apk_flux_fix_region;
+typedef struct apk_flux_fix_plan apk_flux_fix_plan;
+int apk_flux_fix_plan_create(apk_ctx *ctx, const apk_flux_fix_region *regions /* host */, int n,
+                             apk_flux_fix_plan **out);
+void apk_flux_fix_plan_destroy(apk_flux_fix_plan *p);
+int apk_flux_fix_plan_run(apk_ctx *ctx, const apk_flux_fix_plan *p, double beta_dt, int psi_var,
+                          double psi_factor, apk_stream_t stream);
 
 /* Block tagging, one launch for the whole pack: refinement::gradient::PressureGradient
  * (src/refinement/gradient.cpp:18-61: refine above p0, derefine below 0.25 p0),
