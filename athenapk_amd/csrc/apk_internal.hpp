@@ -90,7 +90,7 @@ struct apk_ctx {
 struct apk_copy_plan {
   apk_copy_region *d_regions = nullptr;
   int n = 0;
-  int64_t max_cells = 0;
+  int64_t max_cells = 0, max_items = 0;  // largest box in cells / in cells x variables
 };
 
 namespace apk {
@@ -141,7 +141,7 @@ int launch_fofc_mark(const PackView &u0, const PackView &u1, int fluid, double g
                      unsigned long long *d_count, hipStream_t s);
 int launch_fofc_fix(const PackView &u0, int fluid, double gamma, double c_h,
                     const unsigned char *d_mark, hipStream_t s);
-int launch_copy_regions(const apk_copy_region *d_regions, int n, int64_t max_cells, hipStream_t s,
+int launch_copy_regions(const apk_copy_region *d_regions, int n, int64_t max_cells, int64_t max_items, hipStream_t s,
                         int c2p_fluid = 0, const apk_eos *eos = nullptr, unsigned *d_flags = nullptr,
                         int64_t prim_delta = 0);
 // fused stage path (fused_dispatch.hip)

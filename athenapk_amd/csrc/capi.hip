@@ -439,6 +439,7 @@ int apk_copy_plan_create(apk_ctx *ctx, const apk_copy_region *regions, int n,
   for (int r = 0; r < n; ++r) {
     const int64_t c = (int64_t)regions[r].ext[0] * regions[r].ext[1] * regions[r].ext[2];
     if (c > p->max_cells) p->max_cells = c;
+    if (c * regions[r].nvar > p->max_items) p->max_items = c * regions[r].nvar;
   }
   if (n > 0) {
     hipError_t e = hipMalloc(&p->d_regions, sizeof(apk_copy_region) * n);
@@ -464,7 +465,7 @@ int apk_copy_plan_run(apk_ctx *ctx, const apk_copy_plan *plan, apk_stream_t stre
   if (!ctx || !plan) return APK_ERR_INVALID;
   if (plan->n <= 0) return APK_OK;
   ScopedTiming timing(ctx, APK_T_COPY, as_stream(stream));
-  int rc = launch_copy_regions(plan->d_regions, plan->n, plan->max_cells, as_stream(stream));
+  int rc = launch_copy_regions(plan->d_regions, plan->n, plan->max_cells, plan->max_items, as_stream(stream));
   if (rc != APK_OK) return set_err(ctx, rc, "copy kernel launch failed", hipGetLastError());
   return APK_OK;
 }
@@ -477,7 +478,7 @@ int apk_copy_plan_run_c2p(apk_ctx *ctx, const apk_copy_plan *plan, int fluid, co
     return set_err(ctx, APK_ERR_UNSUPPORTED, "apk_copy_plan_run_c2p: floors / ceilings are active; copy, then apk_cons_to_prim_ghosts");
   if (plan->n <= 0) return APK_OK;
   ScopedTiming timing(ctx, APK_T_COPY, as_stream(stream));
-  int rc = launch_copy_regions(plan->d_regions, plan->n, plan->max_cells, as_stream(stream), fluid, eos,
+  int rc = launch_copy_regions(plan->d_regions, plan->n, plan->max_cells, plan->max_items, as_stream(stream), fluid, eos,
                                latch_flags ? ctx->d_flags : nullptr, prim_delta);
   if (rc != APK_OK) return set_err(ctx, rc, "copy kernel launch failed", hipGetLastError());
   return APK_OK;

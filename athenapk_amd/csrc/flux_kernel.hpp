@@ -86,12 +86,23 @@ template <int FLUID, int RECON, int RS, int DIR>
 __global__ void __launch_bounds__(256)
 flux_kernel(PackView pv, FluxExtent e, double gamma, double c_h) {
   constexpr int NV = nvars<FLUID>();
-  int io, jo;
-  if (!rect_ij(e.i1 - e.i0 + 1, e.j1 - e.j0 + 1, io, jo)) return;
-  const int i = e.i0 + io, j = e.j0 + jo;
-  const int nkext = e.k1 - e.k0 + 1;
-  const int b = blockIdx.z / nkext;
-  const int k = e.k0 + blockIdx.z % nkext;
+  // the two longest axes of the index box share the workgroup (rect_ij), the third one the grid's z
+  // with the block number: a boundary plane of direction 1 / 2 (one face along i / j) is spread
+  // over (j, k) / (i, k) instead of leaving all but a few lanes idle
+  const int nie = e.i1 - e.i0 + 1, nje = e.j1 - e.j0 + 1, nke = e.k1 - e.k0 + 1;
+  int i, j, k, b, a0, a1;
+  if (nie == 1 && nke > 1) {
+    if (!rect_ij(nje, nke, a0, a1)) return;
+    i = e.i0, j = e.j0 + a0, k = e.k0 + a1, b = blockIdx.z;
+  } else if (nje == 1 && nke > 1) {
+    if (!rect_ij(nie, nke, a0, a1)) return;
+    i = e.i0 + a0, j = e.j0, k = e.k0 + a1, b = blockIdx.z;
+  } else {
+    if (!rect_ij(nie, nje, a0, a1)) return;
+    i = e.i0 + a0, j = e.j0 + a1;
+    b = blockIdx.z / nke;
+    k = e.k0 + blockIdx.z % nke;
+  }
   const apk_block_desc blk = pv.blocks[b];
   const int64_t st = (DIR == 1) ? 1 : ((DIR == 2) ? pv.sj : pv.sk);
   const int64_t cell = k * pv.sk + j * pv.sj + i;
@@ -127,7 +138,8 @@ inline void launch_flux_dir(const PackView &pv, const FluxExtent &e, double gamm
                             hipStream_t s) {
   const int nie = e.i1 - e.i0 + 1, nje = e.j1 - e.j0 + 1, nke = e.k1 - e.k0 + 1;
   dim3 block(64, 4, 1);
-  const dim3 grid = rect_grid(nie, nje, nke * pv.nblocks);
+  const dim3 grid = (nie == 1 && nke > 1) ? rect_grid(nje, nke, pv.nblocks)
+                                           : ((nje == 1 && nke > 1) ? rect_grid(nie, nke, pv.nblocks) : rect_grid(nie, nje, nke * pv.nblocks));
   hipLaunchKernelGGL((flux_kernel<FLUID, RECON, RS, DIR>), grid, block, 0, s, pv, e, gamma, c_h);
 }
 

@@ -379,21 +379,21 @@ fofc_fix_kernel(PackView pv, double gamma, double c_h, const unsigned char *mark
 // ---- strided box copies (ghost exchange / message packing / physical boundaries) -----------
 __global__ void __launch_bounds__(256)
 copy_regions_kernel(const apk_copy_region *regions) {
+  // one thread per (cell, variable), cells fastest: the many small boxes of refined meshes (corner
+  // regions of a few dozen cells) still fill a workgroup
   const apk_copy_region r = regions[blockIdx.y];
   const int64_t plane = (int64_t)r.ext[0] * r.ext[1];
-  const int64_t cells = plane * r.ext[2];
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < cells;
+  const int64_t cells = plane * r.ext[2], items = cells * r.nvar;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < items;
        t += (int64_t)gridDim.x * blockDim.x) {
-    const int k = (int)(t / plane);
-    const int64_t rem = t - (int64_t)k * plane;
+    const int v = (int)(t / cells);
+    const int64_t c = t - (int64_t)v * cells;
+    const int k = (int)(c / plane);
+    const int64_t rem = c - (int64_t)k * plane;
     const int j = (int)(rem / r.ext[0]);
     const int i = (int)(rem - (int64_t)j * r.ext[0]);
-    const int64_t so = i * r.src_stride[0] + j * r.src_stride[1] + k * r.src_stride[2];
-    const int64_t dof = i * r.dst_stride[0] + j * r.dst_stride[1] + k * r.dst_stride[2];
-    for (int v = 0; v < r.nvar; ++v) {
-      const double x = r.src[so + v * r.src_stride[3]];
-      r.dst[dof + v * r.dst_stride[3]] = (v == r.flip_var) ? -x : x;
-    }
+    const double x = r.src[i * r.src_stride[0] + j * r.src_stride[1] + k * r.src_stride[2] + v * r.src_stride[3]];
+    r.dst[i * r.dst_stride[0] + j * r.dst_stride[1] + k * r.dst_stride[2] + v * r.dst_stride[3]] = (v == r.flip_var) ? -x : x;
   }
 }
 
@@ -535,10 +535,11 @@ int launch_fofc_fix(const PackView &u0, int fluid, double gamma, double c_h,
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }
 
-int launch_copy_regions(const apk_copy_region *d_regions, int n, int64_t max_cells, hipStream_t s, int c2p_fluid,
-                        const apk_eos *eos, unsigned *d_flags, int64_t prim_delta) {
+int launch_copy_regions(const apk_copy_region *d_regions, int n, int64_t max_cells, int64_t max_items, hipStream_t s,
+                        int c2p_fluid, const apk_eos *eos, unsigned *d_flags, int64_t prim_delta) {
   if (n <= 0) return APK_OK;
-  int gx = (int)((max_cells + 255) / 256);
+  // the plain copy works per (cell, variable), the ConsToPrim variants per cell
+  int gx = (int)(((c2p_fluid == 0 ? max_items : max_cells) + 255) / 256);
   if (gx < 1) gx = 1;
   if (gx > 64) gx = 64;
   // gridDim.y is limited to 65535
