@@ -1104,18 +1104,23 @@ int estimate_timestep(apk_sim *s, double *dt_out) {
     } else {
       SIM_TRY(s, apk_estimate_timestep(s->ctx, s->mu0(), s->pkg.fluid, &s->pkg.eos, s->pkg.cfl, &dt, s->stream));
     }
-    if (s->pkg.fluid == APK_FLUID_GLMMHD && dt < s->pkg.dt_hyp) s->pkg.dt_hyp = dt;  // hydro.cpp:903-908
   }
+  const double dt_hyp_local = dt;
   if (s->pkg.max_dt > 0.0 && s->pkg.max_dt < dt) dt = s->pkg.max_dt;
   if (!have_flags) SIM_TRY(s, apk_poll_device_flags(s->ctx, &flags, s->stream));
   if (flags & APK_FLAG_NEG_DENSITY)
     return fail(s, APK_ERR_INVALID, "Got negative density. Consider enabling first-order flux correction or setting a reasonble density floor.");
   if (flags & APK_FLAG_NEG_PRESSURE)
     return fail(s, APK_ERR_INVALID, "Got negative pressure. Consider enabling first-order flux correction or setting a reasonble pressure or temperature floor.");
+  // one reduction for both minima: the time step, and the hyperbolic estimate that the next cycle's
+  // c_h needs (hydro.cpp:102-143 reduces it in PreStepMeshUserWorkInLoop; same value, one message less)
+  double mins[2] = {dt, dt_hyp_local};
   if (s->have_comm && s->nranks > 1) {
-    if (s->comm.allreduce_min(s->comm.user, &dt, 1) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_min failed");
+    if (s->comm.allreduce_min(s->comm.user, mins, 2) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_min failed");
   }
-  *dt_out = dt;
+  if (s->pkg.calc_dt_hyp && s->pkg.fluid == APK_FLUID_GLMMHD && mins[1] < s->pkg.dt_hyp) s->pkg.dt_hyp = mins[1];  // hydro.cpp:903-908
+  s->dt_hyp_is_global = true;
+  *dt_out = mins[0];
   return APK_OK;
 }
 
@@ -1590,7 +1595,9 @@ int pre_step(apk_sim *s) {
   if (s->mesh.Active(1)) mindx = std::fmin(mindx, level_dx(s, finest, 1));
   if (s->mesh.Active(2)) mindx = std::fmin(mindx, level_dx(s, finest, 2));
   double mins[3] = {mindx, s->pkg.dt_hyp, kHuge};
-  if (s->have_comm && s->nranks > 1) {
+  // (the cell widths are the same on every rank -- the forest is replicated -- and estimate_timestep
+  // has reduced dt_hyp already)
+  if (s->have_comm && s->nranks > 1 && !s->dt_hyp_is_global) {
     if (s->comm.allreduce_min(s->comm.user, mins, 3) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_min failed");
   }
   s->pkg.mindx = mins[0];
@@ -2051,6 +2058,7 @@ int do_stage(apk_sim *s, int stage) {
   if (stage == s->nstages && pkg.calc_c_h) {  // hydro_driver.cpp:589-603
     pkg.mindx = kHuge;
     pkg.dt_hyp = kHuge;
+    s->dt_hyp_is_global = false;
   }
   return APK_OK;
 }

@@ -78,6 +78,7 @@ struct apk_sim {
   int nlim = -1, ncycle = 0;
   long long fofc_total = 0;
   bool stage_dt_pending = false;  // the last fused stage already reduced the hyperbolic dt
+  bool dt_hyp_is_global = false;  // pkg.dt_hyp holds the minimum over all ranks (no reduction needed in pre_step)
   // integrator (Parthenon LowStorageIntegrator)
   int nstages = 0;
   double beta[4] = {0}, gam0[4] = {0}, gam1[4] = {0};
