@@ -318,6 +318,47 @@ def test_adaptive_mesh_follows_an_advected_blob():
     assert 1.3 < rho < 2.0101          # rho0 (1 + rho_ratio exp(..)), smeared by the PLM + HLLE advection
 
 
+def test_orszag_tang_on_an_adaptive_mesh():
+    """GLM-MHD with B != 0 across coarse-fine faces: 2-D Orszag-Tang, 3 levels following the pressure
+    gradients (PLM + HLLD, nghost 2).  Mass, energy and the magnetic flux integrals are conserved to
+    round-off, the vortex's point symmetry about the centre survives in the forest and in the
+    solution, and the divergence error stays at the level of the uniform run."""
+    ov = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=8",
+          "parthenon/mesh/nghost=2", "hydro/reconstruction=plm", "hydro/first_order_flux_correct=false",
+          "parthenon/mesh/refinement=adaptive", "parthenon/mesh/numlevel=3", "parthenon/mesh/derefine_count=5",
+          "refinement/type=pressure_gradient", "refinement/threshold_pressure_gradient=0.15", "parthenon/time/tlim=0.25"]
+    s = _sim("orszag_tang", ov, strict=False).initialize()
+    t0 = _totals(s)
+    s.run()
+    t1 = _totals(s)
+    i = s.refresh_info()
+    pl = placement(s)
+    refined, merged, maxlev, zc = s.amr_stats()
+    assert refined > 0 and max(p[0] for p in pl) == 2 and i.nblocks_total > 64
+    assert abs(t1[0] - t0[0]) < 1e-13 * t0[0] and abs(t1[4] - t0[4]) < 1e-13 * t0[4]
+    assert np.all(np.abs(t1[5:8] - t0[5:8]) < 1e-13)             # B1, B2, B3 integrals
+    assert np.all(np.abs(t1[1:4] - t0[1:4]) < 1e-12)
+    # point symmetry about the domain centre: (x, y) -> (-x, -y) maps rho onto itself
+    where = {(p[0], tuple(p[1])): lb for lb, p in enumerate(pl)}
+    ng = i.ng
+    for lb, (lev, loc, x0, dx) in enumerate(pl):
+        n1 = 8 * 2 ** lev
+        m = where[(lev, (n1 - 1 - loc[0], n1 - 1 - loc[1], 0))]
+        a, b = s.read_block(lb)[0, 0, ng:-ng, ng:-ng], s.read_block(m)[0, 0, ng:-ng, ng:-ng]
+        assert np.allclose(a, b[::-1, ::-1], rtol=1e-9, atol=1e-12)
+    h = s.history()
+    coarse = _sim("orszag_tang", ov[:7] + ["parthenon/time/tlim=0.25"], strict=False).initialize()
+    coarse.run()
+    fine = _sim("orszag_tang", ["parthenon/mesh/nx1=256", "parthenon/mesh/nx2=256", "parthenon/meshblock/nx1=32",
+                                "parthenon/meshblock/nx2=32"] + ov[4:7] + ["parthenon/time/tlim=0.25"], strict=False).initialize()
+    fine.run()
+    hc, hf = coarse.history(), fine.history()
+    assert h[7] < 3.0 * hc[7] + 1e-3                              # relDivB
+    # less numerical dissipation than the root-level mesh, not more than the uniformly fine one:
+    # magnetic and kinetic energy lie between the two
+    assert hc[6] < h[6] < 1.005 * hf[6] and hc[4] < h[4] < 1.005 * hf[4]
+
+
 def test_kh_with_velocity_gradient_refinement():
     """kh iprob 5 is the reference's AMR test problem (kh.cpp:205-210): the xy-velocity-gradient
     criterion puts the fine blocks on the two slip surfaces and nowhere else"""
