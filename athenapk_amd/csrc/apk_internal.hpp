@@ -139,6 +139,7 @@ int launch_history(const PackView &pv, int fluid, double *d_partial, int *nblock
 int launch_fofc_mark(const PackView &u0, const PackView &u1, int fluid, double gam0,
                      double gam1, double beta_dt, int attempt, unsigned char *d_mark,
                      unsigned long long *d_count, hipStream_t s);
+int launch_count_unphysical(const PackView &u0, int fluid, unsigned long long *d_count, hipStream_t s);
 int launch_fofc_fix(const PackView &u0, int fluid, double gamma, double c_h,
                     const unsigned char *d_mark, hipStream_t s);
 int launch_copy_regions(const apk_copy_region *d_regions, int n, int64_t max_cells, int64_t max_items, hipStream_t s,

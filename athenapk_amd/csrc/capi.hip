@@ -385,6 +385,20 @@ int apk_first_order_flux_correct(apk_ctx *ctx, const apk_pack *u0, const apk_pac
   return APK_OK;
 }
 
+int apk_count_unphysical(apk_ctx *ctx, const apk_pack *md, int fluid, long long *count, apk_stream_t stream) {
+  if (!ctx || !md || !count || md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9))
+    return set_err(ctx, APK_ERR_INVALID, "apk_count_unphysical: bad argument");
+  hipStream_t s = as_stream(stream);
+  auto *h = static_cast<unsigned long long *>(ctx->h_pinned);
+  APK_HIP_TRY(ctx, hipMemsetAsync(ctx->d_u64 + 2, 0, sizeof(unsigned long long), s));
+  int rc = launch_count_unphysical(md->view, fluid, ctx->d_u64 + 2, s);
+  if (rc != APK_OK) return set_err(ctx, rc, "count_unphysical launch failed", hipGetLastError());
+  APK_HIP_TRY(ctx, hipMemcpyAsync(h + 2, ctx->d_u64 + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  APK_HIP_TRY(ctx, hipStreamSynchronize(s));
+  *count = (long long)h[2];
+  return APK_OK;
+}
+
 int apk_history(apk_ctx *ctx, const apk_pack *md, int fluid, double *out8, apk_stream_t stream) {
   if (!ctx || !md || !out8 || md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9))
     return set_err(ctx, APK_ERR_INVALID, "apk_history: bad argument");

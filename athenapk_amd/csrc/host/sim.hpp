@@ -77,6 +77,7 @@ struct apk_sim {
   double time = 0.0, dt = std::numeric_limits<double>::max(), tlim = 1.0;
   int nlim = -1, ncycle = 0;
   long long fofc_total = 0;
+  long long fofc_fallback_stages = 0;
   bool stage_dt_pending = false;  // the last fused stage already reduced the hyperbolic dt
   bool dt_hyp_is_global = false;  // pkg.dt_hyp holds the minimum over all ranks (no reduction needed in pre_step)
   // integrator (Parthenon LowStorageIntegrator)

@@ -334,6 +334,24 @@ fofc_mark_kernel(PackView u0, PackView u1, double gam0, double gam1, double beta
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
 }
 
+// The same test on a state that has been updated already (the fused stage): rho <= 0 or
+// E - KE [- ME] <= 0 (hydro.cpp:1297-1306; no gamma - 1, only the sign matters)
+template <int FLUID>
+__global__ void __launch_bounds__(256) count_unphysical_kernel(PackView u0, unsigned long long *count) {
+  const CellIdx c = interior_cell(u0);
+  bool bad = false;
+  if (c.ok) {
+    const double *u = u0.blocks[c.b].cons + c.k * u0.sk + c.j * u0.sj + c.i;
+    const double d = u[IDN * u0.sn];
+    double new_p = u[IEN * u0.sn] - 0.5 * (sqr(u[IM1 * u0.sn]) + sqr(u[IM2 * u0.sn]) + sqr(u[IM3 * u0.sn])) / d;
+    if constexpr (FLUID == APK_FLUID_GLMMHD)
+      new_p -= 0.5 * (sqr(u[IB1 * u0.sn]) + sqr(u[IB2 * u0.sn]) + sqr(u[IB3 * u0.sn]));
+    bad = !(d > 0.0 && new_p > 0.0);
+  }
+  const unsigned long long m = __ballot(bad);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+}
+
 // DC + LLF flux of one face straight from prim (hydro_dc_llf.hpp:43-142,
 // glmmhd_dc_llf.hpp:46-179), including passive scalars
 template <int FLUID, int DIR>
@@ -521,6 +539,14 @@ int launch_fofc_mark(const PackView &u0, const PackView &u1, int fluid, double g
   else
     hipLaunchKernelGGL(fofc_mark_kernel<APK_FLUID_GLMMHD>, interior_grid(u0), dim3(64, 4, 1), 0, s,
                        u0, u1, gam0, gam1, beta_dt, attempt, d_mark, d_count);
+  return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
+}
+
+int launch_count_unphysical(const PackView &u0, int fluid, unsigned long long *d_count, hipStream_t s) {
+  if (fluid == APK_FLUID_EULER)
+    hipLaunchKernelGGL(count_unphysical_kernel<APK_FLUID_EULER>, interior_grid(u0), dim3(64, 4, 1), 0, s, u0, d_count);
+  else
+    hipLaunchKernelGGL(count_unphysical_kernel<APK_FLUID_GLMMHD>, interior_grid(u0), dim3(64, 4, 1), 0, s, u0, d_count);
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }
 

@@ -370,6 +370,10 @@ class Simulation(_FmftHost, _MeshView):
                                             out.ctypes.data_as(L.c_dp)))
         return out
 
+    @property
+    def fofc_fallback_stages(self):
+        return self.lib.apk_sim_fofc_fallback_stages(self.h)
+
     def regrid(self):
         """one tag -> refine / derefine -> transfer pass; True if the mesh changed"""
         ch = C.c_int(0)

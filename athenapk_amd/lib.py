@@ -165,6 +165,7 @@ def _signatures():
         "apk_stage_dt_flags_read": (i, [vp, d, c_dp, C.POINTER(C.c_uint), vp]),
         "apk_estimate_timestep": (i, [vp, vp, i, E, d, c_dp, vp]),
         "apk_first_order_flux_correct": (i, [vp, vp, vp, i, E, d, d, d, d, C.POINTER(ll), vp]),
+        "apk_count_unphysical": (i, [vp, vp, i, C.POINTER(ll), vp]),
         "apk_history": (i, [vp, vp, i, c_dp, vp]),
         "apk_fmft_create": (i, [vp, C.POINTER(FmftBlock), i, i, pp]),
         "apk_fmft_destroy": (None, [vp]),
@@ -241,6 +242,7 @@ def _signatures():
         "apk_sim_amr_ops_size": (i, [vp, i]),
         "apk_sim_amr_op": (i, [vp, i, i, C.POINTER(AmrOpInfo)]),
         "apk_sim_loop_zone_cycles": (ll, [vp]),
+        "apk_sim_fofc_fallback_stages": (ll, [vp]),
         "apk_sim_block_level": (i, [vp, i]),
         "apk_sim_amr_stats": (i, [vp, C.POINTER(ll), C.POINTER(ll), C.POINTER(i), C.POINTER(ll)]),
         "apk_sim_regrid": (i, [vp, C.POINTER(i)]),

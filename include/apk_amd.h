@@ -235,6 +235,13 @@ int apk_first_order_flux_correct(apk_ctx *ctx, const apk_pack *u0, const apk_pac
                                  int fluid, const apk_eos *eos, double c_h, double gam0,
                                  double gam1, double beta_dt, long long *num_corrected,
                                  apk_stream_t stream);
+/* The admissibility test of FirstOrderFluxCorrect (hydro.cpp:1297-1306: density > 0 and
+ * E - kinetic [- magnetic] energy > 0) on the conserved state of the pack's interior cells; count =
+ * cells that fail it.  Lets a caller run apk_stage_fused optimistically where the reference enables
+ * first_order_flux_correct and fall back to the flux-array sequence only when a cell needs it
+ * (stages with gam0 = 0, whose inputs the fused stage leaves intact).  Synchronises. */
+int apk_count_unphysical(apk_ctx *ctx, const apk_pack *md, int fluid, long long *count,
+                         apk_stream_t stream);
 
 /* Replaces the HydroHst<...> reductions src/hydro/hydro.cpp:145-208:
  * out[8] = mass, 1-mom, 2-mom, 3-mom, KE, tot-E, ME, relDivB.  Synchronises `stream`. */

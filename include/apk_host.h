@@ -112,6 +112,10 @@ int apk_sim_block_location(const apk_sim *sim, int lb, int *gid, int loc[3]);
  * meshes); apk_sim_block_location then returns the logical location at that level.  Statistics:
  * blocks refined / sibling groups merged so far, deepest level allowed, zone-cycles done.
  * apk_sim_regrid runs one tag -> refine / derefine -> transfer pass on demand. */
+/* hydro/first_order_flux_correct = true: stages with gam0 = 0 run fused and are only redone through
+ * the flux-array sequence + FirstOrderFluxCorrect when a cell fails its admissibility test; this counts
+ * those fallbacks */
+long long apk_sim_fofc_fallback_stages(const apk_sim *s);
 int apk_sim_block_level(const apk_sim *s, int lb);
 int apk_sim_amr_stats(const apk_sim *s, long long *refined, long long *derefined, int *max_level,
                       long long *zone_cycles);
