@@ -214,6 +214,9 @@ def main():
     ap.add_argument("--workload", default="mhd_ppm_hlld_vl2_256", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="use the flux-array path (for A/B)")
+    ap.add_argument("--amr-extra", action="store_true",
+                    help="append the adaptive-mesh figure (BASELINE config 5 shape) as 'amr_blast_cfg5'; off by default so "
+                         "that the kernels of the default command are those of the headline workload only")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
@@ -364,7 +367,7 @@ def main():
                 out["roofline"]["general_stage"] = general_stage_bench(recon, riemann)
             except Exception as e:  # supplementary figure; never lose the headline
                 out["roofline"]["general_stage"] = {"error": repr(e)}
-        if world == 1 and fluid == "glmmhd" and not args.unfused:
+        if world == 1 and args.amr_extra:
             try:
                 out["amr_blast_cfg5"] = amr_blast_bench()
             except Exception as e:  # supplementary figure
