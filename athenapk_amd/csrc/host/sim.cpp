@@ -1,44 +1,11 @@
-// sim.cpp -- implementation of the standalone host driver (include/apk_host.h).
-#include "sim.hpp"
-
-#include <hip/hip_runtime.h>
-
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <new>
-#include <sstream>
+// sim.cpp -- the standalone host driver (include/apk_host.h): deck -> packages and mesh, device
+// resources and plans, ghost exchange, the stage loop, outputs and the C API.
+#include "sim_internal.hpp"
 
 using namespace apk;
 
-namespace {
-
-constexpr double kHuge = std::numeric_limits<double>::max();
-
-int fail(apk_sim *s, int code, const std::string &msg) {
-  if (s) s->err = msg;
-  return code;
-}
-
-#define SIM_TRY(s, expr)                                                        \
-  do {                                                                          \
-    int rc__ = (expr);                                                          \
-    if (rc__ != APK_OK) {                                                       \
-      if ((s)->err.empty() && (s)->ctx) (s)->err = apk_last_error((s)->ctx);    \
-      if ((s)->err.empty()) (s)->err = #expr;                                   \
-      return rc__;                                                              \
-    }                                                                           \
-  } while (0)
-
-#define SIM_HIP(s, expr)                                                        \
-  do {                                                                          \
-    hipError_t e__ = (expr);                                                    \
-    if (e__ != hipSuccess) return fail((s), APK_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); \
-  } while (0)
-
-hipStream_t hs(const apk_sim *s) { return reinterpret_cast<hipStream_t>(s->stream); }
+namespace apk {
+namespace host {
 
 int parse_bc(const std::string &v) {
   if (v == "periodic") return BC_PERIODIC;
@@ -156,151 +123,6 @@ void hydro_initialize(apk_sim *s) {
   if (pkg.nscalars < 0) throw std::runtime_error("hydro/nscalars must be >= 0");
 }
 
-// ---- mesh refinement: tree set-up from the deck (parthenon/mesh/refinement, numlevel,
-// derefine_count, <parthenon/static_refinement#> blocks) ------------------------------------------
-// cell width on a refinement level (collapsed dimensions are not refined)
-double level_dx(const apk_sim *s, int level, int d) { return s->mesh.Active(d) ? s->dx[d] / (double)(1 << level) : s->dx[d]; }
-// the leaf behind local block lb (this rank owns a contiguous range of the Z-ordered leaf list)
-const AmrLeaf &amr_leaf(const apk_sim *s, int lb) { return s->amr->leaves[s->amr_part.first[s->rank] + lb]; }
-int block_level(const apk_sim *s, int lb) { return s->amr ? amr_leaf(s, lb).level : 0; }
-
-// refresh the uniform-mesh bookkeeping the rest of the driver reads (block counts, ids) from the tree
-void amr_sync_mesh(apk_sim *s) {
-  Mesh &m = s->mesh;
-  const int n = (int)s->amr->leaves.size();
-  if (n < s->nranks) throw std::runtime_error("fewer meshblocks than ranks");
-  s->amr_part.Build(n, s->nranks);
-  m.nblocks_total = n;
-  m.local_gids.clear();
-  m.gid_local.clear();
-  m.gid_rank.assign(n, 0);
-  for (int g = 0; g < n; ++g) {
-    m.gid_rank[g] = s->amr_part.Owner(g);
-    if (m.gid_rank[g] == s->rank) {
-      m.gid_local[g] = (int)m.local_gids.size();
-      m.local_gids.push_back(g);
-    }
-  }
-  m.peers.clear();
-  for (auto &p : m.plan) p.clear();
-}
-
-// the global plans of the current forest and this rank's share of them
-void amr_localize(apk_sim *s) {
-  BuildAmrPlans(*s->amr, s->amr_geom, s->amr_plans);
-  const AmrPlans &g = s->amr_plans;
-  const AmrPartition &part = s->amr_part;
-  auto &l = s->amr_local;
-  l = apk_sim::AmrLocalPlans();
-  const int rank = s->rank;
-  auto take_ops = [&](const std::vector<AmrRefOp> &in, std::vector<AmrRefOp> &out) {
-    for (AmrRefOp o : in) {
-      if (part.Owner(o.dst_block) != rank) continue;  // (these operators work inside one block)
-      o.src_block -= part.first[rank];
-      o.dst_block -= part.first[rank];
-      out.push_back(o);
-    }
-  };
-  auto take_bc = [&](const std::vector<BoxRegion> &in, std::vector<BoxRegion> &out) {
-    for (BoxRegion r : in) {
-      if (part.Owner(r.dst_block) != rank) continue;
-      r.src_block -= part.first[rank];
-      r.dst_block -= part.first[rank];
-      out.push_back(r);
-    }
-  };
-  take_ops(g.restrict_own, l.restrict_own);
-  take_ops(g.prolongate, l.prolongate);
-  for (int d = 0; d < 3; ++d) {
-    take_ops(g.flux_restrict[d], l.flux_restrict[d]);
-    take_bc(g.coarse_bc[d], l.coarse_bc[d]);
-    take_bc(g.fine_bc[d], l.fine_bc[d]);
-  }
-  s->amr_halo.plan = AmrMessages();
-  s->amr_fluxmsg.plan = AmrMessages();
-  AmrRegisterPeers(g.fill, part, part, rank, s->amr_halo.plan);
-  AmrLocalize(g.fill, part, part, rank, s->amr_halo.plan, l.fill, l.fill_pack, l.fill_unpack);
-  for (int d = 0; d < 3; ++d) AmrRegisterPeers(g.flux_copy[d], part, part, rank, s->amr_fluxmsg.plan);
-  for (int d = 0; d < 3; ++d)
-    AmrLocalize(g.flux_copy[d], part, part, rank, s->amr_fluxmsg.plan, l.flux_copy[d], l.flux_pack[d], l.flux_unpack[d]);
-}
-
-void amr_initialize(apk_sim *s, bool adaptive) {
-  ParameterInput &pin = s->pin;
-  Mesh &m = s->mesh;
-  if (s->problem_id == "turbulence") throw std::runtime_error("the turbulence driver needs a uniform mesh");
-  s->amr.reset(new AmrTree());
-  AmrTree &t = *s->amr;
-  for (int d = 0; d < 3; ++d) {
-    t.nrb[d] = m.nb[d];
-    t.act[d] = m.Active(d);
-    t.bc_in[d] = m.bc_in[d];
-    t.bc_out[d] = m.bc_out[d];
-  }
-  t.ndim = m.ndim;
-  s->amr_adaptive = adaptive;
-  int max_level = adaptive ? pin.GetOrAddInteger("parthenon/mesh", "numlevel", 1) - 1 : 0;
-  if (max_level < 0) throw std::runtime_error("parthenon/mesh/numlevel must be at least 1");
-  s->amr_derefine_count = pin.GetOrAddInteger("parthenon/mesh", "derefine_count", 10);
-  s->amr_check_interval = pin.GetOrAddInteger("parthenon/mesh", "check_refine_interval", 1);
-  struct Region {
-    double lo[3], hi[3];
-    int level;
-  };
-  std::vector<Region> regions;
-  const char *mink[3] = {"x1min", "x2min", "x3min"}, *maxk[3] = {"x1max", "x2max", "x3max"};
-  for (const std::string &blk : pin.BlocksWithPrefix("parthenon/static_refinement")) {
-    Region r;
-    for (int d = 0; d < 3; ++d) {
-      r.lo[d] = m.Active(d) ? pin.GetReal(blk, mink[d]) : s->xmin[d];
-      r.hi[d] = m.Active(d) ? pin.GetReal(blk, maxk[d]) : s->xmax[d];
-      if (r.lo[d] > r.hi[d]) throw std::runtime_error("static refinement region of <" + blk + "> is inverted");
-      if (r.lo[d] < s->xmin[d] || r.hi[d] > s->xmax[d]) throw std::runtime_error("static refinement region of <" + blk + "> lies outside of the mesh");
-    }
-    r.level = pin.GetInteger(blk, "level");
-    if (r.level < 1) throw std::runtime_error("static refinement level must be at least 1");
-    max_level = std::max(max_level, r.level);
-    regions.push_back(r);
-  }
-  if (max_level > 12) throw std::runtime_error("more than 12 refinement levels");
-  t.max_level = max_level;
-  AmrGeom &g = s->amr_geom;
-  for (int d = 0; d < 3; ++d) {
-    g.mb[d] = m.mb[d];
-    g.act[d] = m.Active(d);
-  }
-  g.ng = m.ng;
-  g.cng = (m.ng + 1) / 2 + 1;
-  g.nvar = m.nvar;
-  g.Build();
-  t.InitRoot();
-  // static regions: split every block that overlaps a region until it has the region's level
-  for (const Region &r : regions) {
-    for (int lev = 0; lev < r.level; ++lev) {
-      std::vector<AmrLeaf> todo;
-      for (const auto &kv : t.leafmap) {
-        const AmrLeaf &l = kv.second;
-        if (l.level != lev) continue;
-        bool overlap = true;
-        for (int d = 0; d < 3; ++d) {
-          if (!m.Active(d)) continue;
-          const double w = level_dx(s, l.level, d) * m.mb[d];
-          const double lo = s->xmin[d] + l.lx[d] * w, hi = lo + w;
-          if (hi <= r.lo[d] || lo >= r.hi[d]) {
-            // a degenerate region (lo == hi) still selects the block that contains the point
-            if (!(r.lo[d] == r.hi[d] && lo <= r.lo[d] && r.lo[d] < hi)) overlap = false;
-          }
-        }
-        if (overlap) todo.push_back(l);
-      }
-      for (const AmrLeaf &l : todo) t.RefineBalanced(l.level, l.lx);
-    }
-  }
-  t.Reindex();
-  amr_sync_mesh(s);
-  amr_localize(s);
-}
-
 void mesh_initialize(apk_sim *s) {
   ParameterInput &pin = s->pin;
   Mesh &m = s->mesh;
@@ -328,643 +150,6 @@ void mesh_initialize(apk_sim *s) {
   if (refinement != "none") amr_initialize(s, refinement == "adaptive");
   s->tlim = pin.GetOrAddReal("parthenon/time", "tlim", 1.0);
   s->nlim = pin.GetOrAddInteger("parthenon/time", "nlim", -1);
-}
-
-// ---- problem generators ---------------------------------------------------------------------
-// cell centre: Xc = xmin + (global_index + 1/2) dx.  x0[d] carries the
-// global index of the block's first interior cell, so centres do not depend on the decomposition.
-double xc(const apk_sim *s, const double x0[3], int d, int idx) {
-  const int ng = s->mesh.Active(d) ? s->mesh.ng : 0;
-  return s->xmin[d] + ((x0[d] + (double)(idx - ng)) + 0.5) * s->dx[d];
-}
-void block_origin(const apk_sim *s, int lb, double x0[3]) {
-  if (s->amr) {  // in cells of the block's own level (s->dx is set to that level's widths meanwhile)
-    for (int d = 0; d < 3; ++d) x0[d] = (double)amr_leaf(s, lb).lx[d] * s->mesh.mb[d];
-    return;
-  }
-  int bc[3];
-  s->mesh.Loc(s->mesh.local_gids[lb], bc);
-  for (int d = 0; d < 3; ++d) x0[d] = (double)(bc[d] * s->mesh.mb[d]);
-}
-// On refined meshes the problem generators and the error norms see the cell widths of the block
-// they work on through s->dx (restored on scope exit)
-struct LevelDxScope {
-  apk_sim *s;
-  double saved[3];
-  LevelDxScope(apk_sim *sim, int lb) : s(sim) {
-    for (int d = 0; d < 3; ++d) {
-      saved[d] = s->dx[d];
-      if (s->amr && s->mesh.Active(d)) s->dx[d] = saved[d] / (double)(1 << amr_leaf(s, lb).level);
-    }
-  }
-  ~LevelDxScope() {
-    for (int d = 0; d < 3; ++d) s->dx[d] = saved[d];
-  }
-};
-
-// hydro eigensystem, src/pgen/linear_wave.cpp:421-500 (eigenvalues + right eigenvectors)
-void lw_eigensystem(double gm1, double v1, double v2, double v3, double h, double ev[5], double rem[5][5]) {
-  const double vsq = v1 * v1 + v2 * v2 + v3 * v3;
-  const double asq = gm1 * std::max((h - 0.5 * vsq), 1.0e-20);
-  const double a = std::sqrt(asq);
-  ev[0] = v1 - a;
-  ev[1] = ev[2] = ev[3] = v1;
-  ev[4] = v1 + a;
-  const double col[5][5] = {{1.0, v1 - a, v2, v3, h - v1 * a},
-                            {0.0, 0.0, 1.0, 0.0, v2},
-                            {0.0, 0.0, 0.0, 1.0, v3},
-                            {1.0, v1, v2, v3, 0.5 * vsq},
-                            {1.0, v1 + a, v2, v3, h + v1 * a}};
-  for (int c = 0; c < 5; ++c)
-    for (int r = 0; r < 5; ++r) rem[r][c] = col[c][r];
-}
-
-// src/pgen/linear_wave.cpp:72-176 (InitUserMeshData)
-void lw_setup(apk_sim *s) {
-  ParameterInput &pin = s->pin;
-  LinearWaveState &lw = s->lw;
-  lw.wave_flag = pin.GetInteger("problem/linear_wave", "wave_flag");
-  if (lw.wave_flag < 0 || lw.wave_flag > 4) throw std::runtime_error("problem/linear_wave/wave_flag must be 0..4");
-  lw.amp = pin.GetReal("problem/linear_wave", "amp");
-  lw.vflow = pin.GetOrAddReal("problem/linear_wave", "vflow", 0.0);
-  double ang_2 = pin.GetOrAddReal("problem/linear_wave", "ang_2", -999.9);
-  double ang_3 = pin.GetOrAddReal("problem/linear_wave", "ang_3", -999.9);
-  const bool ang_2_vert = pin.GetOrAddBoolean("problem/linear_wave", "ang_2_vert", false);
-  const bool ang_3_vert = pin.GetOrAddBoolean("problem/linear_wave", "ang_3_vert", false);
-  lw.compute_error = pin.GetOrAddBoolean("problem/linear_wave", "compute_error", false);
-  lw.gam = s->pkg.eos.gamma;
-  lw.gm1 = lw.gam - 1.0;
-  const double x1size = s->xmax[0] - s->xmin[0], x2size = s->xmax[1] - s->xmin[1],
-               x3size = s->xmax[2] - s->xmin[2];
-  if (ang_3 == -999.9) ang_3 = std::atan(x1size / x2size);
-  lw.sin_a3 = std::sin(ang_3);
-  lw.cos_a3 = std::cos(ang_3);
-  if (ang_3_vert) {
-    lw.sin_a3 = 1.0;
-    lw.cos_a3 = 0.0;
-    ang_3 = 0.5 * M_PI;
-  }
-  if (ang_2 == -999.9) ang_2 = std::atan(0.5 * (x1size * lw.cos_a3 + x2size * lw.sin_a3) / x3size);
-  lw.sin_a2 = std::sin(ang_2);
-  lw.cos_a2 = std::cos(ang_2);
-  if (ang_2_vert) {
-    lw.sin_a2 = 1.0;
-    lw.cos_a2 = 0.0;
-    ang_2 = 0.5 * M_PI;
-  }
-  const double x1 = x1size * lw.cos_a2 * lw.cos_a3;
-  const double x2 = x2size * lw.cos_a2 * lw.sin_a3;
-  const double x3 = x3size * lw.sin_a2;
-  const int f2 = (s->mesh.nx[1] > 1) ? 1 : 0, f3 = (s->mesh.nx[2] > 1) ? 1 : 0;
-  lw.lambda = x1;
-  if (f2 && ang_3 != 0.0) lw.lambda = std::min(lw.lambda, x2);
-  if (f3 && ang_2 != 0.0) lw.lambda = std::min(lw.lambda, x3);
-  if (ang_3_vert) lw.lambda = x2;
-  if (ang_2_vert) lw.lambda = x3;
-  lw.k_par = 2.0 * (M_PI) / lw.lambda;
-  lw.d0 = 1.0;
-  lw.u0 = lw.vflow;
-  lw.p0 = 1.0 / lw.gam;
-  const double v0 = 0.0, w0 = 0.0;
-  const double h0 = ((lw.p0 / lw.gm1 + 0.5 * lw.d0 * (lw.u0 * lw.u0 + v0 * v0 + w0 * w0)) + lw.p0) / lw.d0;
-  lw_eigensystem(lw.gm1, lw.u0, v0, w0, h0, lw.ev, lw.rem);
-  if (pin.GetOrAddBoolean("problem/linear_wave", "test", false)) {
-    // reinterpret tlim as the number of wave periods (linear_wave.cpp:169-175)
-    s->tlim = lw.lambda / std::abs(lw.ev[lw.wave_flag]) * s->tlim;
-  }
-}
-
-// analytic conserved state at a cell centre (linear_wave.cpp:355-373 == :206-226)
-void lw_state(const LinearWaveState &lw, double x1, double x2, double x3, double u[5]) {
-  const double x = lw.cos_a2 * (x1 * lw.cos_a3 + x2 * lw.sin_a3) + x3 * lw.sin_a2;
-  const double sn = std::sin(lw.k_par * x);
-  const int wf = lw.wave_flag;
-  u[0] = lw.d0 + lw.amp * sn * lw.rem[0][wf];
-  const double mx = lw.d0 * lw.vflow + lw.amp * sn * lw.rem[1][wf];
-  const double my = lw.amp * sn * lw.rem[2][wf];
-  const double mz = lw.amp * sn * lw.rem[3][wf];
-  u[1] = mx * lw.cos_a2 * lw.cos_a3 - my * lw.sin_a3 - mz * lw.sin_a2 * lw.cos_a3;
-  u[2] = mx * lw.cos_a2 * lw.sin_a3 + my * lw.cos_a3 - mz * lw.sin_a2 * lw.sin_a3;
-  u[3] = mx * lw.sin_a2 + mz * lw.cos_a2;
-  u[4] = lw.p0 / lw.gm1 + 0.5 * lw.d0 * lw.u0 * lw.u0 + lw.amp * sn * lw.rem[4][wf];
-}
-
-// fills the interior of one block's host image [nvar][Nk][Nj][Ni]
-// ---- circularly polarised Alfven wave (src/pgen/cpaw.cpp) -----------------------------------------
-// InitUserMeshData (cpaw.cpp:58-125)
-void cpaw_setup(apk_sim *s) {
-  ParameterInput &pin = s->pin;
-  CpawState &c = s->cpaw;
-  if (s->pkg.fluid != APK_FLUID_GLMMHD) throw std::runtime_error("cpaw requires hydro/fluid = glmmhd");
-  if (s->mesh.ndim != 3) throw std::runtime_error("cpaw is set up for 3-D meshes here");
-  c.b_par = pin.GetReal("problem/cpaw", "b_par");
-  c.b_perp = pin.GetReal("problem/cpaw", "b_perp");
-  c.v_par = pin.GetReal("problem/cpaw", "v_par");
-  double ang_2 = pin.GetOrAddReal("problem/cpaw", "ang_2", -999.9);
-  double ang_3 = pin.GetOrAddReal("problem/cpaw", "ang_3", -999.9);
-  const double dir = pin.GetOrAddReal("problem/cpaw", "dir", 1);  // right (1) / left (2) polarisation
-  c.gm1 = pin.GetReal("hydro", "gamma") - 1.0;
-  c.pres = pin.GetReal("problem/cpaw", "pres");
-  c.den = 1.0;
-  c.compute_error = pin.GetOrAddBoolean("problem/cpaw", "compute_error", false);
-  const double x1size = s->xmax[0] - s->xmin[0], x2size = s->xmax[1] - s->xmin[1], x3size = s->xmax[2] - s->xmin[2];
-  if (ang_3 == -999.9) ang_3 = std::atan(x1size / x2size);
-  c.sin_a3 = std::sin(ang_3);
-  c.cos_a3 = std::cos(ang_3);
-  if (ang_2 == -999.9) ang_2 = std::atan(0.5 * (x1size * c.cos_a3 + x2size * c.sin_a3) / x3size);
-  c.sin_a2 = std::sin(ang_2);
-  c.cos_a2 = std::cos(ang_2);
-  const double x1 = x1size * c.cos_a2 * c.cos_a3, x2 = x2size * c.cos_a2 * c.sin_a3, x3 = x3size * c.sin_a2;
-  c.lambda = x1;  // the smallest of the three
-  if (s->mesh.nx[1] > 1 && ang_3 != 0.0) c.lambda = std::min(c.lambda, x2);
-  if (s->mesh.nx[2] > 1 && ang_2 != 0.0) c.lambda = std::min(c.lambda, x3);
-  c.k_par = 2.0 * (M_PI) / c.lambda;
-  c.v_perp = c.b_perp / std::sqrt(c.den);
-  c.fac = (dir == 1) ? 1.0 : -1.0;
-}
-
-// vector potential, gauge Ax = 0 (cpaw.cpp:310-344)
-void cpaw_potential(const CpawState &c, double x1, double x2, double x3, double A[3]) {
-  const double x = x1 * c.cos_a2 * c.cos_a3 + x2 * c.cos_a2 * c.sin_a3 + x3 * c.sin_a2;
-  const double y = -x1 * c.sin_a3 + x2 * c.cos_a3;
-  const double Ay = c.fac * (c.b_perp / c.k_par) * std::sin(c.k_par * (x));
-  const double Az = (c.b_perp / c.k_par) * std::cos(c.k_par * (x)) + c.b_par * y;
-  A[0] = -Ay * c.sin_a3 - Az * c.sin_a2 * c.cos_a3;
-  A[1] = Ay * c.cos_a3 - Az * c.sin_a2 * c.sin_a3;
-  A[2] = Az * c.cos_a2;
-}
-
-// analytic momenta / fields of the wave at one point (cpaw.cpp:147-175, 262-275)
-void cpaw_state(const CpawState &c, double X1, double X2, double X3, double m[3], double b[3]) {
-  const double x = c.cos_a2 * (X1 * c.cos_a3 + X2 * c.sin_a3) + X3 * c.sin_a2;
-  const double sn = std::sin(c.k_par * x);
-  const double cs = c.fac * std::cos(c.k_par * x);
-  const double mx = c.den * c.v_par, my = -c.fac * c.den * c.v_perp * sn, mz = -c.fac * c.den * c.v_perp * cs;
-  m[0] = mx * c.cos_a2 * c.cos_a3 - my * c.sin_a3 - mz * c.sin_a2 * c.cos_a3;
-  m[1] = mx * c.cos_a2 * c.sin_a3 + my * c.cos_a3 - mz * c.sin_a2 * c.sin_a3;
-  m[2] = mx * c.sin_a2 + mz * c.cos_a2;
-  const double bx = c.b_par, by = c.b_perp * sn, bz = c.b_perp * cs;
-  b[0] = bx * c.cos_a2 * c.cos_a3 - by * c.sin_a3 - bz * c.sin_a2 * c.cos_a3;
-  b[1] = bx * c.cos_a2 * c.sin_a3 + by * c.cos_a3 - bz * c.sin_a2 * c.sin_a3;
-  b[2] = bx * c.sin_a2 + bz * c.cos_a2;
-}
-
-// ---- advected field loop (src/pgen/field_loop.cpp) ------------------------------------------------
-void field_loop_setup(apk_sim *s) {  // parameter block :129-170
-  ParameterInput &pin = s->pin;
-  FieldLoopState &f = s->floop;
-  if (s->pkg.fluid != APK_FLUID_GLMMHD) throw std::runtime_error("field_loop requires hydro/fluid = glmmhd");
-  if (s->mesh.ndim < 2) throw std::runtime_error("field_loop needs a 2-D or 3-D mesh");
-  f.rad = pin.GetReal("problem/field_loop", "rad");
-  f.amp = pin.GetReal("problem/field_loop", "amp");
-  f.vflow = pin.GetReal("problem/field_loop", "vflow");
-  f.drat = pin.GetOrAddReal("problem/field_loop", "drat", 1.0);
-  f.iprob = pin.GetInteger("problem/field_loop", "iprob");
-  if (f.iprob == 4) {  // rotated cylinder: one wavelength along each of x1 and x3
-    const double L1 = s->xmax[0] - s->xmin[0], L3 = s->mesh.ndim < 3 ? 0.0 : s->xmax[2] - s->xmin[2];
-    if (L1 == L3) {
-      f.cos_a2 = f.sin_a2 = std::sqrt(0.5);
-    } else {
-      const double ang_2 = std::atan(L1 / L3);
-      f.sin_a2 = std::sin(ang_2);
-      f.cos_a2 = std::cos(ang_2);
-    }
-    f.lambda = f.cos_a2 >= f.sin_a2 ? L1 * f.cos_a2 : L3 * f.sin_a2;
-  }
-}
-
-// cell-centred vector potential of the loop, one branch per iprob (:196-290)
-void field_loop_potential(const FieldLoopState &f, double x1, double x2, double x3, double A[3]) {
-  A[0] = A[1] = A[2] = 0.0;
-  auto cone = [&](double rsq) { return rsq < f.rad * f.rad ? f.amp * (f.rad - std::sqrt(rsq)) : 0.0; };
-  switch (f.iprob) {
-  case 1: A[2] = cone(x1 * x1 + x2 * x2); break;
-  case 2: A[0] = cone(x2 * x2 + x3 * x3); break;
-  case 3: A[1] = cone(x1 * x1 + x3 * x3); break;
-  case 4: {
-    double x = x1 * f.cos_a2 + x3 * f.sin_a2;
-    while (x > 0.5 * f.lambda) x -= f.lambda;
-    while (x < -0.5 * f.lambda) x += f.lambda;
-    if ((x * x + x2 * x2) < f.rad * f.rad) {  // keeps +0 outside the loop
-      A[0] = cone(x * x + x2 * x2) * (-f.sin_a2);
-      A[2] = cone(x * x + x2 * x2) * (f.cos_a2);
-    }
-    break;
-  }
-  case 5: A[1] = A[2] = cone(x1 * x1 + x2 * x2 + x3 * x3); break;
-  default: break;
-  }
-}
-
-// Kelvin-Helmholtz (src/pgen/kh.cpp): validate the deck when the sim is created
-void kh_setup(apk_sim *s) {
-  ParameterInput &pin = s->pin;
-  if (s->pkg.fluid == APK_FLUID_GLMMHD) throw std::runtime_error("the kh problem generator is hydro only");
-  if (s->mesh.ndim < 2) throw std::runtime_error("kh needs a 2-D or 3-D mesh");
-  (void)pin.GetReal("problem/kh", "vflow");
-  const int iprob = pin.GetInteger("problem/kh", "iprob");
-  if (iprob < 2 || iprob > 5) throw std::runtime_error("Unknow iprob for KHI pgen.");
-  (void)pin.GetReal("problem/kh", "amp");
-  if (iprob == 5) {
-    (void)pin.GetReal("problem/kh", "a");
-    (void)pin.GetReal("problem/kh", "sigma");
-    (void)pin.GetReal("problem/kh", "drat");
-  }
-}
-
-void pgen_block(apk_sim *s, int lb, std::vector<double> &u) {
-  LevelDxScope level_dx_scope(s, lb);
-  const Mesh &m = s->mesh;
-  const HydroPackage &pkg = s->pkg;
-  std::fill(u.begin(), u.end(), 0.0);
-  double x0[3];
-  block_origin(s, lb, x0);
-  auto at = [&](int n, int k, int j, int i) -> double & { return u[n * m.sn + k * m.sk + j * m.sj + i]; };
-  const bool mhd = pkg.fluid == APK_FLUID_GLMMHD;
-  const double gm1 = pkg.eos.gamma - 1.0;
-  ParameterInput &pin = s->pin;
-  double sod[7] = {0};
-  if (s->problem_id == "sod") {  // src/pgen/sod.cpp:24-30
-    sod[0] = pin.GetOrAddReal("problem/sod", "rho_l", 1.0);
-    sod[1] = pin.GetOrAddReal("problem/sod", "pres_l", 1.0);
-    sod[2] = pin.GetOrAddReal("problem/sod", "u_l", 0.0);
-    sod[3] = pin.GetOrAddReal("problem/sod", "rho_r", 0.125);
-    sod[4] = pin.GetOrAddReal("problem/sod", "pres_r", 0.1);
-    sod[5] = pin.GetOrAddReal("problem/sod", "u_r", 0.0);
-    sod[6] = pin.GetOrAddReal("problem/sod", "x_discont", 0.5);
-  }
-  double bl[9] = {0};
-  if (s->problem_id == "blast") {  // src/pgen/blast.cpp:125-138
-    if (pin.GetOrAddString("problem/blast", "input_image", "none") != "none")
-      throw std::runtime_error("problem/blast/input_image is not supported");
-    bl[0] = pin.GetReal("problem/blast", "radius_outer");
-    bl[1] = pin.GetOrAddReal("problem/blast", "radius_inner", bl[0]);
-    bl[2] = pin.GetOrAddReal("problem/blast", "pressure_ambient", 1.0);
-    bl[3] = pin.GetOrAddReal("problem/blast", "density_ambient", 1.0);
-    bl[4] = pin.GetReal("problem/blast", "pressure_ratio");
-    bl[5] = pin.GetOrAddReal("problem/blast", "density_ratio", 1.0);
-    bl[6] = pin.GetOrAddReal("problem/blast", "x1_0", 0.0);
-    bl[7] = pin.GetOrAddReal("problem/blast", "x2_0", 0.0);
-    bl[8] = pin.GetOrAddReal("problem/blast", "x3_0", 0.0);
-  }
-  double adv[9] = {0};
-  if (s->problem_id == "advection") {  // src/pgen/advection.cpp:68-79
-    adv[0] = pin.GetOrAddReal("problem/advection", "vx", 0.0);
-    adv[1] = pin.GetOrAddReal("problem/advection", "vy", 0.0);
-    adv[2] = pin.GetOrAddReal("problem/advection", "vz", 0.0);
-    adv[3] = pin.GetOrAddReal("problem/advection", "rho_ratio", 1.0);
-    adv[4] = pin.GetOrAddReal("problem/advection", "rho_radius", 0.0);
-    adv[5] = pin.GetOrAddReal("problem/advection", "rho_fraction_edge", 0.01);
-    adv[6] = pin.GetOrAddReal("problem/advection", "rho0", 1.0);
-    adv[7] = pin.GetOrAddReal("problem/advection", "p0", 1.0);
-    adv[8] = -adv[4] * adv[4] / 2 / std::log(adv[5]);  // sigmasq
-  }
-  double kh[8] = {0};
-  int kh_iprob = 0;
-  if (s->problem_id == "kh") {  // src/pgen/kh.cpp:44-45 and the per-iprob parameter reads
-    if (mhd) throw std::runtime_error("the kh problem generator is hydro only");
-    if (m.ndim < 2) throw std::runtime_error("kh needs a 2-D or 3-D mesh");
-    kh[0] = pin.GetReal("problem/kh", "vflow");
-    kh_iprob = pin.GetInteger("problem/kh", "iprob");
-    if (kh_iprob < 2 || kh_iprob > 5) throw std::runtime_error("Unknow iprob for KHI pgen.");
-    kh[1] = pin.GetReal("problem/kh", "amp");
-    if (kh_iprob == 4) {
-      kh[2] = pin.GetOrAddReal("problem/kh", "drho_rho0", 0.0);
-      kh[3] = pin.GetOrAddReal("problem/kh", "vboost", 0.0);
-    } else if (kh_iprob == 5) {
-      kh[4] = pin.GetReal("problem/kh", "a");
-      kh[5] = pin.GetReal("problem/kh", "sigma");
-      kh[6] = pin.GetReal("problem/kh", "drat");
-    }
-  }
-  double lwi[5] = {0};
-  if (s->problem_id == "lw_implode") {  // src/pgen/lw_implode.cpp:24-57
-    if (mhd) throw std::runtime_error("Only hydro runs are supported for LW implosion problem generator.");
-    lwi[0] = pin.GetReal("problem/lw_implode", "d_in");
-    lwi[1] = pin.GetReal("problem/lw_implode", "p_in");
-    lwi[2] = pin.GetReal("problem/lw_implode", "d_out");
-    lwi[3] = pin.GetReal("problem/lw_implode", "p_out");
-    // to keep the ICs symmetric y0 sits between cell centres; the reference adjusts it with a loop
-    // over the rows of the meshblock being initialised
-    double y0 = 0.5 * (s->xmax[1] + s->xmin[1]);
-    for (int j = m.js; j <= m.je; ++j)
-      if (xc(s, x0, 1, j) > y0) {
-        const int ngj = m.Active(1) ? m.ng : 0;
-        const double xf = s->xmin[1] + (x0[1] + (double)(j - ngj)) * s->dx[1];  // lower x2 face of cell j
-        y0 = xf + 0.5 * s->dx[1];
-        break;
-      }
-    lwi[4] = y0;
-  }
-  for (int k = m.ks; k <= m.ke; ++k)
-    for (int j = m.js; j <= m.je; ++j)
-      for (int i = m.is; i <= m.ie; ++i) {
-        const double x1 = xc(s, x0, 0, i), x2 = xc(s, x0, 1, j), x3 = xc(s, x0, 2, k);
-        if (s->problem_id == "advection") {  // src/pgen/advection.cpp:91-110
-          double rho = adv[6];
-          const double rsq = x1 * x1 + x2 * x2 + x3 * x3;
-          if (rsq < adv[4] * adv[4]) rho += adv[6] * adv[3] * std::exp(-rsq / 2 / adv[8]);
-          const double mx = rho * adv[0], my = rho * adv[1], mz = rho * adv[2];
-          at(0, k, j, i) = rho;
-          at(1, k, j, i) = mx;
-          at(2, k, j, i) = my;
-          at(3, k, j, i) = mz;
-          at(4, k, j, i) = adv[7] / gm1 + 0.5 * (mx * mx + my * my + mz * mz) / rho;
-        } else if (s->problem_id == "cpaw") {  // src/pgen/cpaw.cpp:255-300
-          const CpawState &c = s->cpaw;
-          double mom[3], bana[3];
-          cpaw_state(c, x1, x2, x3, mom, bana);
-          at(0, k, j, i) = c.den;
-          at(1, k, j, i) = mom[0];
-          at(2, k, j, i) = mom[1];
-          at(3, k, j, i) = mom[2];
-          // B = curl A by centred differences of the cell-centred potential
-          double Ajp[3], Ajm[3], Akp[3], Akm[3], Aip[3], Aim[3];
-          cpaw_potential(c, x1, xc(s, x0, 1, j + 1), x3, Ajp);
-          cpaw_potential(c, x1, xc(s, x0, 1, j - 1), x3, Ajm);
-          cpaw_potential(c, x1, x2, xc(s, x0, 2, k + 1), Akp);
-          cpaw_potential(c, x1, x2, xc(s, x0, 2, k - 1), Akm);
-          cpaw_potential(c, xc(s, x0, 0, i + 1), x2, x3, Aip);
-          cpaw_potential(c, xc(s, x0, 0, i - 1), x2, x3, Aim);
-          const double b1 = (Ajp[2] - Ajm[2]) / s->dx[1] / 2.0 - (Akp[1] - Akm[1]) / s->dx[2] / 2.0;
-          const double b2 = (Akp[0] - Akm[0]) / s->dx[2] / 2.0 - (Aip[2] - Aim[2]) / s->dx[0] / 2.0;
-          const double b3 = (Aip[1] - Aim[1]) / s->dx[0] / 2.0 - (Ajp[0] - Ajm[0]) / s->dx[1] / 2.0;
-          at(5, k, j, i) = b1;
-          at(6, k, j, i) = b2;
-          at(7, k, j, i) = b3;
-          at(4, k, j, i) = c.pres / c.gm1 + 0.5 * (b1 * b1 + b2 * b2 + b3 * b3) +
-                           (0.5 / c.den) * (mom[0] * mom[0] + mom[1] * mom[1] + mom[2] * mom[2]);
-        } else if (s->problem_id == "kh") {  // src/pgen/kh.cpp:61-234
-          const double vflow = kh[0], amp = kh[1];
-          double d = 1.0, m1 = 0.0, m2 = 0.0, pr = 1.0;
-          if (kh_iprob == 2) {  // one tanh shear layer (Frank et al. 1996)
-            const double a = 0.02, sigma = 0.2;
-            m1 = vflow * std::tanh(x2 / a);
-            m2 = amp * std::cos(2.0 * M_PI * x1) * std::exp(-(x2 * x2) / (sigma * sigma));
-          } else if (kh_iprob == 3) {  // two resolved layers at |y| = 0.5 (Beckwith & Stone 2011)
-            const double a = 0.01, sigma = 0.1, s2 = std::abs(x2) - 0.5;
-            d = 0.505 + 0.495 * std::tanh(s2 / a);
-            m1 = vflow * std::tanh(s2 / a);
-            m2 = amp * vflow * std::sin(2.0 * M_PI * x1) * std::exp(-(s2 * s2) / (sigma * sigma));
-            if (x2 < 0.0) m2 *= -1.0;
-            m1 *= d;
-            m2 *= d;
-          } else if (kh_iprob == 4) {  // Lecoanet et al. 2016, domain centred on the origin
-            const double a = 0.05, sigma = 0.2, z1 = -0.5, z2 = 0.5;
-            const double t1 = std::tanh((x2 - z1) / a), t2 = std::tanh((x2 - z2) / a);
-            pr = 10.0;
-            d = 1.0 + 0.5 * kh[2] * (t1 - t2);
-            m1 = (vflow * (t1 - t2 - 1.0) + kh[3]) * d;
-            // the sine averaged with minus its half-period shift, for shift symmetry in floating point
-            double ave_sine = std::sin(2.0 * M_PI * x1);
-            ave_sine -= std::sin(2.0 * M_PI * ((x1 > 0.0 ? -0.5 : 0.5) + x1));
-            ave_sine /= 2.0;
-            const double v2 = -amp * ave_sine *
-                              (std::exp(-((x2 - z1) * (x2 - z1)) / (sigma * sigma)) + std::exp(-((x2 - z2) * (x2 - z2)) / (sigma * sigma)));
-            m2 = v2 * d;
-          } else {  // iprob 5: dense stream in |y| < 1/4, m = 2 perturbation (the AMR test)
-            const double s2 = std::abs(x2) - 0.25;
-            const double w = (std::tanh(s2 / kh[4]) + 1.0) * 0.5;
-            pr = 2.5;
-            d = w + (1.0 - w) * kh[6];
-            m1 = d * vflow * (w - 0.5);
-            m2 = d * amp * std::cos(2.0 * 2.0 * M_PI * x1) * std::exp(-(s2 * s2) / (kh[5] * kh[5]));
-          }
-          at(0, k, j, i) = d;
-          at(1, k, j, i) = m1;
-          at(2, k, j, i) = m2;
-          at(3, k, j, i) = 0.0;
-          at(4, k, j, i) = pr / gm1 + 0.5 * (m1 * m1 + m2 * m2) / d;
-        } else if (s->problem_id == "field_loop") {  // src/pgen/field_loop.cpp:292-322
-          const FieldLoopState &f = s->floop;
-          const bool two_d = m.ndim < 3;
-          const double L[3] = {s->xmax[0] - s->xmin[0], s->xmax[1] - s->xmin[1], two_d ? 0.0 : s->xmax[2] - s->xmin[2]};
-          const double den = (x1 * x1 + x2 * x2 + x3 * x3) < f.rad * f.rad ? f.drat : 1.0;
-          double Ajp[3], Ajm[3], Aip[3], Aim[3], Akp[3] = {0, 0, 0}, Akm[3] = {0, 0, 0};
-          field_loop_potential(f, x1, xc(s, x0, 1, j + 1), x3, Ajp);
-          field_loop_potential(f, x1, xc(s, x0, 1, j - 1), x3, Ajm);
-          field_loop_potential(f, xc(s, x0, 0, i + 1), x2, x3, Aip);
-          field_loop_potential(f, xc(s, x0, 0, i - 1), x2, x3, Aim);
-          if (!two_d) {
-            field_loop_potential(f, x1, x2, xc(s, x0, 2, k + 1), Akp);
-            field_loop_potential(f, x1, x2, xc(s, x0, 2, k - 1), Akm);
-          }
-          const double aydz = two_d ? 0.0 : (Akp[1] - Akm[1]) / s->dx[2] / 2.0;
-          const double axdz = two_d ? 0.0 : (Akp[0] - Akm[0]) / s->dx[2] / 2.0;
-          const double b1 = (Ajp[2] - Ajm[2]) / s->dx[1] / 2.0 - aydz;
-          const double b2 = axdz - (Aip[2] - Aim[2]) / s->dx[0] / 2.0;
-          const double b3 = (Aip[1] - Aim[1]) / s->dx[0] / 2.0 - (Ajp[0] - Ajm[0]) / s->dx[1] / 2.0;
-          const double m1 = den * f.vflow * L[0], m2 = den * f.vflow * L[1], m3 = den * f.vflow * L[2];
-          at(0, k, j, i) = den;
-          at(1, k, j, i) = m1;
-          at(2, k, j, i) = m2;
-          at(3, k, j, i) = m3;
-          at(5, k, j, i) = b1;
-          at(6, k, j, i) = b2;
-          at(7, k, j, i) = b3;
-          at(4, k, j, i) = 1.0 / gm1 + 0.5 * (b1 * b1 + b2 * b2 + b3 * b3) + 0.5 * (m1 * m1 + m2 * m2 + m3 * m3) / den;
-        } else if (s->problem_id == "lw_implode") {  // src/pgen/lw_implode.cpp:59-73
-          const bool outside = x2 > (lwi[4] - x1);
-          at(0, k, j, i) = outside ? lwi[2] : lwi[0];
-          at(4, k, j, i) = (outside ? lwi[3] : lwi[1]) / gm1;
-        } else if (s->problem_id == "blast") {  // src/pgen/blast.cpp:150-201
-          const double rout = bl[0], rin = bl[1], pa = bl[2], da = bl[3], prat = bl[4], drat = bl[5];
-          double den = da, pres = pa;
-          const double rad = std::sqrt((x1 - bl[6]) * (x1 - bl[6]) + (x2 - bl[7]) * (x2 - bl[7]) + (x3 - bl[8]) * (x3 - bl[8]));
-          if (rad < rout) {
-            if (rad < rin) {
-              den = drat * da;
-            } else {  // smooth ramp in density
-              const double f = (rad - rin) / (rout - rin);
-              const double log_den = (1.0 - f) * std::log(drat * da) + f * std::log(da);
-              den = std::exp(log_den);
-            }
-          }
-          if (rad < rout) {
-            if (rad < rin) {
-              pres = prat * pa;
-            } else {  // smooth ramp in pressure
-              const double f = (rad - rin) / (rout - rin);
-              const double log_pres = (1.0 - f) * std::log(prat * pa) + f * std::log(pa);
-              pres = std::exp(log_pres);
-            }
-          }
-          at(0, k, j, i) = den;
-          at(4, k, j, i) = pres / gm1;
-        } else if (s->problem_id == "linear_wave") {
-          double w[5];
-          lw_state(s->lw, x1, x2, x3, w);
-          for (int n = 0; n < 5; ++n) at(n, k, j, i) = w[n];
-        } else if (s->problem_id == "sod") {  // src/pgen/sod.cpp:37-50
-          const bool left = x1 < sod[6];
-          const double rho = left ? sod[0] : sod[3], pr = left ? sod[1] : sod[4], ux = left ? sod[2] : sod[5];
-          at(0, k, j, i) = rho;
-          at(1, k, j, i) = rho * ux;
-          at(4, k, j, i) = 0.5 * rho * ux * ux + pr / (pkg.eos.gamma - 1.0);
-        } else if (s->problem_id == "orszag_tang") {  // src/pgen/orszag_tang.cpp:33-61
-          if (!mhd) throw std::runtime_error("orszag_tang requires hydro/fluid = glmmhd");
-          const double B0 = 1.0 / std::sqrt(4.0 * M_PI), d0 = 25.0 / (36.0 * M_PI), v0 = 1.0,
-                       p0 = 5.0 / (12.0 * M_PI);
-          at(0, k, j, i) = d0;
-          at(1, k, j, i) = d0 * v0 * std::sin(2.0 * M_PI * x2);
-          at(2, k, j, i) = -d0 * v0 * std::sin(2.0 * M_PI * x1);
-          at(3, k, j, i) = 0.0;
-          at(5, k, j, i) = B0 * std::sin(2.0 * M_PI * x2);
-          at(6, k, j, i) = B0 * std::sin(4.0 * M_PI * x1);
-          at(7, k, j, i) = 0.0;
-          const double b1 = at(5, k, j, i), b2 = at(6, k, j, i), b3 = at(7, k, j, i);
-          const double m1 = at(1, k, j, i), m2 = at(2, k, j, i), m3 = at(3, k, j, i);
-          at(4, k, j, i) = p0 / gm1 + 0.5 * (b1 * b1 + b2 * b2 + b3 * b3 + (m1 * m1 + m2 * m2 + m3 * m3) / at(0, k, j, i));
-        } else if (s->problem_id == "synthetic") {
-          // analytic, seedless smooth state (SURVEY.md 8(d) synthetic kernel benchmark)
-          const double tp = 2.0 * M_PI;
-          const double fx = (x1 - s->xmin[0]) / (s->xmax[0] - s->xmin[0]);
-          const double fy = (x2 - s->xmin[1]) / (s->xmax[1] - s->xmin[1]);
-          const double fz = (x3 - s->xmin[2]) / (s->xmax[2] - s->xmin[2]);
-          const double rho = 1.0 + 0.2 * std::sin(tp * (fx + fy + fz));
-          const double p = 1.0 + 0.1 * std::cos(tp * (fx - fy + 2.0 * fz));
-          const double v1 = 0.17 * std::sin(tp * (fy + fz));
-          const double v2 = 0.17 * std::cos(tp * (fx - fz));
-          const double v3 = 0.17 * std::sin(tp * (2.0 * fx + fy));
-          double b1 = 0, b2 = 0, b3 = 0, psi = 0;
-          if (mhd) {
-            b1 = 0.28 * std::cos(tp * (fy - fz));
-            b2 = 0.28 * std::sin(tp * (fx + 2.0 * fz));
-            b3 = 0.28 * std::cos(tp * (fx + fy));
-            psi = 0.01 * std::sin(tp * (fx + fy - fz));
-          }
-          at(0, k, j, i) = rho;
-          at(1, k, j, i) = rho * v1;
-          at(2, k, j, i) = rho * v2;
-          at(3, k, j, i) = rho * v3;
-          double e = p / gm1 + 0.5 * rho * (v1 * v1 + v2 * v2 + v3 * v3);
-          if (mhd) {
-            e += 0.5 * (b1 * b1 + b2 * b2 + b3 * b3);
-            at(5, k, j, i) = b1;
-            at(6, k, j, i) = b2;
-            at(7, k, j, i) = b3;
-            at(8, k, j, i) = psi;
-          }
-          at(4, k, j, i) = e;
-          for (int n = pkg.nhydro; n < m.nvar; ++n)
-            at(n, k, j, i) = rho * (0.5 + 0.25 * std::sin(tp * (fx + (n - pkg.nhydro + 1) * fy)));
-        } else {
-          throw std::runtime_error("unknown job/problem_id: " + s->problem_id);
-        }
-      }
-}
-
-
-// ---- few-modes turbulence driver -----------------------------------------------------------
-// turbulence::ProblemInitPackageData (src/pgen/turbulence.cpp:103-200) + the checks of
-// FewModesFT::SetPhases (src/utils/few_modes_ft.cpp:113-140)
-void turbulence_setup(apk_sim *s) {
-  ParameterInput &pin = s->pin;
-  const int num_modes = pin.GetInteger("problem/turbulence", "num_modes");
-  const uint32_t rseed = static_cast<uint32_t>(pin.GetOrAddInteger("problem/turbulence", "rseed", -1));
-  const double k_peak = pin.GetOrAddReal("problem/turbulence", "kpeak", 0.0);
-  s->accel_rms = pin.GetReal("problem/turbulence", "accel_rms");
-  const double t_corr = pin.GetReal("problem/turbulence", "corr_time");
-  const double sol_weight = pin.GetReal("problem/turbulence", "sol_weight");
-  if (num_modes <= 0) throw std::runtime_error("problem/turbulence/num_modes must be positive");
-  std::vector<double> k_vec(3 * (size_t)num_modes);
-  for (int d = 0; d < 3; ++d)
-    for (int m = 1; m <= num_modes; ++m)
-      k_vec[(size_t)d * num_modes + (m - 1)] = pin.GetInteger("modes", "k_" + std::to_string(m) + "_" + std::to_string(d));
-  if (pin.GetOrAddInteger("parthenon/mesh", "pack_size", -1) != -1)
-    throw std::runtime_error("Few modes FT currently needs parthenon/mesh/pack_size=-1 to work because of global reductions.");
-  const Mesh &m = s->mesh;
-  const double L[3] = {s->xmax[0] - s->xmin[0], s->xmax[1] - s->xmin[1], s->xmax[2] - s->xmin[2]};
-  if (!(m.nx[0] == m.nx[1] && m.nx[1] == m.nx[2] && L[0] == L[1] && L[1] == L[2]))
-    throw std::runtime_error("FMFT has only been tested with cubic meshes and constant dx/dy/dz. "
-                             "Remove this warning at your own risk.");
-  if (pin.DoesParameterExist("problem/turbulence", "accel_hat_0_0_r"))
-    throw std::runtime_error("restarting the turbulence driver state is not supported");
-  if (s->pkg.fluid == APK_FLUID_GLMMHD) {
-    const int b_config = pin.GetInteger("problem/turbulence", "b_config");
-    if (b_config == 3) throw std::runtime_error("Random B fields not implemented yet.");
-    if (b_config < 0 || b_config > 2)
-      throw std::runtime_error("problem/turbulence/b_config = " + std::to_string(b_config) + " is not supported (0, 1, 2 are)");
-  }
-  const int gnx[3] = {m.nx[0], m.nx[1], m.nx[2]};
-  s->fmft = std::make_unique<FewModesFT>(num_modes, std::move(k_vec), k_peak, sol_weight, t_corr, rseed, gnx);
-}
-
-// turbulence::ProblemGenerator (src/pgen/turbulence.cpp:217-370): a MeshData-wide generator --
-// the magnetic field is normalised with a global reduction -- so it fills all local blocks at once
-int pgen_turbulence(apk_sim *s, std::vector<std::vector<double>> &blocks) {
-  const Mesh &m = s->mesh;
-  ParameterInput &pin = s->pin;
-  const bool mhd = s->pkg.fluid == APK_FLUID_GLMMHD;
-  const double gm1 = pin.GetReal("hydro", "gamma") - 1.0;
-  const double p0 = pin.GetReal("problem/turbulence", "p0");
-  const double rho0 = pin.GetReal("problem/turbulence", "rho0");
-  const double Lx = s->xmax[0] - s->xmin[0], Ly = s->xmax[1] - s->xmin[1], Lz = s->xmax[2] - s->xmin[2];
-  const double x3min = s->xmin[2];
-  const double kz = 2.0 * M_PI / Lz;
-  const double vol = s->dx[0] * s->dx[1] * s->dx[2];
-  const int nlb = (int)m.local_gids.size();
-  blocks.assign(nlb, std::vector<double>((size_t)s->nper, 0.0));
-  double b_norm = 0.0;
-  if (mhd) {
-    const double b0 = pin.GetReal("problem/turbulence", "b0");
-    const int b_config = pin.GetInteger("problem/turbulence", "b_config");
-    double mag_en_sum = 0.0;
-    for (int lb = 0; lb < nlb; ++lb) {
-      double x0[3];
-      block_origin(s, lb, x0);
-      std::vector<double> &u = blocks[lb];
-      for (int k = m.ks; k <= m.ke; ++k)
-        for (int j = m.js; j <= m.je; ++j)
-          for (int i = m.is; i <= m.ie; ++i) {
-            double b1 = 0.0;
-            if (b_config == 0) b1 = b0;                                                   // uniform
-            if (b_config == 1) b1 = (xc(s, x0, 2, k) < x3min + Lz / 2.0) ? b0 : -b0;      // no net flux
-            if (b_config == 2) b1 = b0 / std::sqrt(0.5) * std::sin(kz * xc(s, x0, 2, k));  // sin(z)
-            u[5 * m.sn + k * m.sk + j * m.sj + i] = b1;
-            mag_en_sum += 0.5 * (b1 * b1 + 0.0 + 0.0) * vol;
-          }
-    }
-    if (s->have_comm && s->nranks > 1) {
-      if (s->comm.allreduce_sum(s->comm.user, &mag_en_sum, 1) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_sum failed");
-    }
-    b_norm = std::sqrt(mag_en_sum / (Lx * Ly * Lz) / (0.5 * b0 * b0));
-  }
-  double v0[3] = {0., 0., 0.};
-  if (pin.DoesParameterExist("problem/turbulence", "v0")) {
-    std::string txt = pin.GetString("problem/turbulence", "v0");
-    for (char &c : txt)
-      if (c == ',') c = ' ';
-    std::istringstream iss(txt);
-    int n = 0;
-    double v;
-    while (iss >> v) {
-      if (n < 3) v0[n] = v;
-      ++n;
-    }
-    if (n != 3) throw std::runtime_error("Initial velocity vector should have three components.");
-  }
-  for (int lb = 0; lb < nlb; ++lb) {
-    std::vector<double> &u = blocks[lb];
-    for (int k = m.ks; k <= m.ke; ++k)
-      for (int j = m.js; j <= m.je; ++j)
-        for (int i = m.is; i <= m.ie; ++i) {
-          const int64_t c = k * m.sk + j * m.sj + i;
-          u[0 * m.sn + c] = rho0;
-          u[1 * m.sn + c] = rho0 * v0[0];
-          u[2 * m.sn + c] = rho0 * v0[1];
-          u[3 * m.sn + c] = rho0 * v0[2];
-          u[4 * m.sn + c] = p0 / gm1 + 0.5 * rho0 * (v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2]);
-          if (mhd) {
-            u[5 * m.sn + c] /= b_norm;
-            u[6 * m.sn + c] /= b_norm;
-            u[7 * m.sn + c] /= b_norm;
-            const double b1 = u[5 * m.sn + c], b2 = u[6 * m.sn + c], b3 = u[7 * m.sn + c];
-            u[4 * m.sn + c] += 0.5 * (b1 * b1 + b2 * b2 + b3 * b3);
-          }
-        }
-  }
-  return APK_OK;
 }
 
 // ---- device resources -----------------------------------------------------------------------
@@ -1176,302 +361,12 @@ int exchange_end(apk_sim *s, bool c2p) {
   return APK_OK;
 }
 
-int amr_exchange(apk_sim *s, int buf);
-int exchange_ghosts(apk_sim *s, bool c2p = false) {
+int exchange_ghosts(apk_sim *s, bool c2p) {
   if (s->amr) return amr_exchange(s, s->cur);
   SIM_TRY(s, exchange_begin(s, false, c2p));
   return exchange_end(s, c2p);
 }
 
-
-// ---- mesh refinement on the device --------------------------------------------------------------
-double *amr_base(apk_sim *s, int parity, int kind, int block, const apk_sim::MsgSet *msgs) {
-  switch (kind) {
-  case RK_BLOCK: return s->d_cons2[parity] + (int64_t)block * s->nper;
-  case RK_COARSE: return s->d_coarse + (int64_t)block * s->amr_geom.coarse_doubles;
-  case RK_FLUX1: case RK_FLUX2: case RK_FLUX3: return s->d_flux[kind - RK_FLUX1] + (int64_t)block * s->nper;
-  case RK_SEND: return msgs ? msgs->send[block] : nullptr;
-  case RK_RECV: return msgs ? msgs->recv[block] : nullptr;
-  default: return nullptr;
-  }
-}
-
-apk_copy_region to_copy_region(const BoxRegion &r, const double *src, double *dst) {
-  apk_copy_region c{};
-  c.src = src + r.src_off;
-  c.dst = dst + r.dst_off;
-  for (int q = 0; q < 3; ++q) c.ext[q] = r.ext[q];
-  c.nvar = r.nvar;
-  for (int q = 0; q < 4; ++q) {
-    c.src_stride[q] = r.src_stride[q];
-    c.dst_stride[q] = r.dst_stride[q];
-  }
-  c.flip_var = r.flip_var;
-  return c;
-}
-
-int amr_make_copy_plan(apk_sim *s, int parity, const std::vector<BoxRegion> &regions, const apk_sim::MsgSet *msgs,
-                       apk_copy_plan **out) {
-  std::vector<apk_copy_region> regs;
-  for (const BoxRegion &r : regions)
-    regs.push_back(to_copy_region(r, amr_base(s, parity, r.src_kind, r.src_block, msgs), amr_base(s, parity, r.dst_kind, r.dst_block, msgs)));
-  return apk_copy_plan_create(s->ctx, regs.data(), (int)regs.size(), out);
-}
-
-// ONE refine plan for the boxes of all levels: every box carries the cell widths of its level (the
-// operators difference cell-centre coordinates).  Ops carry LOCAL block numbers for the arrays and the
-// GLOBAL leaf number for the geometry.
-int amr_make_refine_plans(apk_sim *s, int parity, const std::vector<AmrRefOp> &ops, std::vector<apk_refine_plan *> &out) {
-  for (apk_refine_plan *p : out) apk_refine_plan_destroy(p);
-  out.clear();
-  const AmrGeom &g = s->amr_geom;
-  std::vector<apk_refine_op> dev;
-  for (const AmrRefOp &o : ops) {
-    apk_refine_op d{};
-    d.kind = o.kind;
-    d.src = amr_base(s, parity, o.src_kind, o.src_block, nullptr);
-    d.dst = amr_base(s, parity, o.dst_kind, o.dst_block, nullptr);
-    for (int q = 0; q < 3; ++q) {
-      d.lo[q] = o.lo[q];
-      d.hi[q] = o.hi[q];
-      d.dx[q] = level_dx(s, o.level, q);
-      d.xmin[q] = s->xmin[q] + (double)s->amr->leaves[o.geom_block].lx[q] * g.mb[q] * d.dx[q];
-    }
-    dev.push_back(d);
-  }
-  if (dev.empty()) return APK_OK;
-  apk_refine_geom rg{};
-  for (int q = 0; q < 3; ++q) {
-    rg.nx[q] = g.mb[q];
-    rg.dx[q] = level_dx(s, 0, q);
-  }
-  rg.ng = g.ng;
-  rg.cng = g.cng;
-  apk_refine_plan *p = nullptr;
-  SIM_TRY(s, apk_refine_plan_create(s->ctx, &rg, g.nvar, dev.data(), (int)dev.size(), &p));
-  out.push_back(p);
-  return APK_OK;
-}
-
-void amr_destroy_device_plans(apk_sim *s) {
-  auto &a = s->amr_dev;
-  for (int par = 0; par < 2; ++par) {
-    for (apk_refine_plan *p : a.restrict_own[par]) apk_refine_plan_destroy(p);
-    for (apk_refine_plan *p : a.prolongate[par]) apk_refine_plan_destroy(p);
-    a.restrict_own[par].clear();
-    a.prolongate[par].clear();
-    apk_copy_plan_destroy(a.fill[par]);
-    apk_copy_plan_destroy(a.fill_pack[par]);
-    apk_copy_plan_destroy(a.fill_unpack[par]);
-    a.fill[par] = a.fill_pack[par] = a.fill_unpack[par] = nullptr;
-    for (int d = 0; d < 3; ++d) {
-      apk_copy_plan_destroy(a.coarse_bc[par][d]);
-      apk_copy_plan_destroy(a.fine_bc[par][d]);
-      a.coarse_bc[par][d] = a.fine_bc[par][d] = nullptr;
-    }
-  }
-  for (int d = 0; d < 3; ++d) {
-    for (apk_refine_plan *p : a.flux_restrict[d]) apk_refine_plan_destroy(p);
-    a.flux_restrict[d].clear();
-    apk_copy_plan_destroy(a.flux_copy[d]);
-    apk_copy_plan_destroy(a.flux_pack[d]);
-    apk_copy_plan_destroy(a.flux_unpack[d]);
-    a.flux_copy[d] = a.flux_pack[d] = a.flux_unpack[d] = nullptr;
-    for (int par = 0; par < 2; ++par) {
-      apk_flux_fix_plan_destroy(a.flux_fix[par][d]);
-      apk_flux_fix_plan_destroy(a.flux_fix_unpack[par][d]);
-      a.flux_fix[par][d] = a.flux_fix_unpack[par][d] = nullptr;
-    }
-  }
-}
-
-// the flux-correction copies of direction d as corrections of the cells next to the face (fused path)
-int amr_make_fix_plan(apk_sim *s, int parity, int d, const std::vector<BoxRegion> &regions, const apk_sim::MsgSet *msgs,
-                      apk_flux_fix_plan **out) {
-  const AmrGeom &g = s->amr_geom;
-  std::vector<apk_flux_fix_region> regs;
-  for (const BoxRegion &r : regions) {
-    apk_flux_fix_region f{};
-    f.fine_avg = amr_base(s, parity, r.src_kind, r.src_block, msgs) + r.src_off;
-    f.coarse_flux = amr_base(s, parity, r.dst_kind, r.dst_block, msgs) + r.dst_off;
-    const int idx = (int)((r.dst_off / g.fst[d]) % g.fn[d]);  // face index along d inside the block
-    const bool lower = idx == g.fs[d];
-    f.cons = s->d_cons2[parity] + (int64_t)r.dst_block * s->nper + r.dst_off - (lower ? 0 : g.fst[d]);
-    for (int q = 0; q < 3; ++q) f.ext[q] = r.ext[q];
-    f.nvar = r.nvar;
-    for (int q = 0; q < 4; ++q) {
-      f.src_stride[q] = r.src_stride[q];
-      f.dst_stride[q] = r.dst_stride[q];
-    }
-    f.scale = (lower ? 1.0 : -1.0) / level_dx(s, block_level(s, r.dst_block), d);
-    regs.push_back(f);
-  }
-  return apk_flux_fix_plan_create(s->ctx, regs.data(), (int)regs.size(), out);
-}
-
-// message buffers of a set: (re)allocated when a message outgrows its buffer, never shrunk
-int amr_ensure_buffers(apk_sim *s, apk_sim::MsgSet &m, const char *name) {
-  const size_t np = m.plan.peers.size();
-  // (buffers belong to positions in the rank-sorted peer list, not to ranks: they are scratch)
-  if (m.send.size() != np) {
-    for (double *b : m.send) dev_free(s, b);
-    for (double *b : m.recv) dev_free(s, b);
-    m.send.assign(np, nullptr);
-    m.recv.assign(np, nullptr);
-    m.send_cap.assign(np, 0);
-    m.recv_cap.assign(np, 0);
-  }
-  for (size_t p = 0; p < np; ++p) {
-    const PeerPlan &pp = m.plan.peers[p];
-    if (pp.send_count > m.send_cap[p]) {
-      dev_free(s, m.send[p]);
-      m.send_cap[p] = pp.send_count + pp.send_count / 4;
-      SIM_TRY(s, dev_alloc(s, (std::string(name) + ":send:" + std::to_string(pp.rank)).c_str(), m.send_cap[p] * sizeof(double), &m.send[p]));
-    }
-    if (pp.recv_count > m.recv_cap[p]) {
-      dev_free(s, m.recv[p]);
-      m.recv_cap[p] = pp.recv_count + pp.recv_count / 4;
-      SIM_TRY(s, dev_alloc(s, (std::string(name) + ":recv:" + std::to_string(pp.rank)).c_str(), m.recv_cap[p] * sizeof(double), &m.recv[p]));
-    }
-  }
-  s->msg_generation += 1;
-  return APK_OK;
-}
-
-void amr_free_buffers(apk_sim *s, apk_sim::MsgSet &m) {
-  for (double *b : m.send) dev_free(s, b);
-  for (double *b : m.recv) dev_free(s, b);
-  m.send.clear();
-  m.recv.clear();
-  m.send_cap.clear();
-  m.recv_cap.clear();
-}
-
-// one message per peer: hand the set to the comm ops (apk_sim_peer reports the active set)
-int amr_exchange_messages(apk_sim *s, const apk_sim::MsgSet &m) {
-  if (m.plan.peers.empty()) return APK_OK;
-  if (!s->have_comm || !s->comm.exchange) return fail(s, APK_ERR_INVALID, "remote neighbours but no comm ops");
-  if (s->active_msgs != &m) {
-    s->active_msgs = &m;
-    s->msg_generation += 1;
-  }
-  if (s->comm.exchange(s->comm.user) != 0) return fail(s, APK_ERR_DEVICE, "message exchange failed");
-  return APK_OK;
-}
-
-// device arrays of a mesh of n local blocks (state, register, primitives, fluxes, coarse buffers)
-int amr_allocate(apk_sim *s, size_t n, double *cons2[2], double **prim, double *flux[3], double **coarse) {
-  const size_t bytes = (size_t)s->nper * n * sizeof(double);
-  const size_t cbytes = (size_t)s->amr_geom.coarse_doubles * n * sizeof(double);
-  SIM_TRY(s, dev_alloc(s, "cons", bytes, &cons2[0]));
-  SIM_TRY(s, dev_alloc(s, "u1", bytes, &cons2[1]));
-  SIM_TRY(s, dev_alloc(s, "prim", bytes, prim));
-  SIM_TRY(s, dev_alloc(s, "coarse", cbytes, coarse));
-  SIM_HIP(s, hipMemsetAsync(cons2[0], 0, bytes, hs(s)));
-  SIM_HIP(s, hipMemsetAsync(cons2[1], 0, bytes, hs(s)));
-  SIM_HIP(s, hipMemsetAsync(*prim, 0, bytes, hs(s)));
-  SIM_HIP(s, hipMemsetAsync(*coarse, 0, cbytes, hs(s)));
-  const char *tags[3] = {"flux1", "flux2", "flux3"};
-  for (int d = 0; d < 3; ++d) {
-    flux[d] = nullptr;
-    if (d >= s->mesh.ndim) continue;
-    SIM_TRY(s, dev_alloc(s, tags[d], bytes, &flux[d]));
-    SIM_HIP(s, hipMemsetAsync(flux[d], 0, bytes, hs(s)));
-  }
-  return APK_OK;
-}
-
-// (re)build everything that depends on the block list: packs, message buffers, device plans
-int amr_rebuild(apk_sim *s) {
-  try {
-    amr_sync_mesh(s);
-    amr_localize(s);
-  } catch (const std::exception &e) {
-    return fail(s, APK_ERR_INVALID, e.what());
-  }
-  SIM_TRY(s, amr_ensure_buffers(s, s->amr_halo, "halo"));
-  SIM_TRY(s, amr_ensure_buffers(s, s->amr_fluxmsg, "fluxcorr"));
-  amr_destroy_device_plans(s);
-  auto &a = s->amr_dev;
-  const auto &p = s->amr_local;
-  for (int par = 0; par < 2; ++par) {
-    SIM_TRY(s, amr_make_refine_plans(s, par, p.restrict_own, a.restrict_own[par]));
-    SIM_TRY(s, amr_make_refine_plans(s, par, p.prolongate, a.prolongate[par]));
-    SIM_TRY(s, amr_make_copy_plan(s, par, p.fill, nullptr, &a.fill[par]));
-    SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_pack, &s->amr_halo, &a.fill_pack[par]));
-    SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_unpack, &s->amr_halo, &a.fill_unpack[par]));
-    for (int d = 0; d < 3; ++d) {
-      SIM_TRY(s, amr_make_copy_plan(s, par, p.coarse_bc[d], nullptr, &a.coarse_bc[par][d]));
-      SIM_TRY(s, amr_make_copy_plan(s, par, p.fine_bc[d], nullptr, &a.fine_bc[par][d]));
-    }
-  }
-  for (int d = 0; d < s->mesh.ndim; ++d) {
-    SIM_TRY(s, amr_make_refine_plans(s, 0, p.flux_restrict[d], a.flux_restrict[d]));
-    SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_copy[d], nullptr, &a.flux_copy[d]));
-    SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_pack[d], &s->amr_fluxmsg, &a.flux_pack[d]));
-    SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_unpack[d], &s->amr_fluxmsg, &a.flux_unpack[d]));
-    for (int par = 0; par < 2; ++par) {
-      SIM_TRY(s, amr_make_fix_plan(s, par, d, p.flux_copy[d], nullptr, &a.flux_fix[par][d]));
-      SIM_TRY(s, amr_make_fix_plan(s, par, d, p.flux_unpack[d], &s->amr_fluxmsg, &a.flux_fix_unpack[par][d]));
-    }
-  }
-  return build_packs(s);
-}
-
-// the multilevel ghost exchange of the state in cons buffer `buf` (see amr.hpp)
-int amr_exchange(apk_sim *s, int buf) {
-  auto &a = s->amr_dev;
-  for (apk_refine_plan *p : a.restrict_own[buf]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
-  SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fill_pack[buf], s->stream));
-  SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fill[buf], s->stream));
-  SIM_TRY(s, amr_exchange_messages(s, s->amr_halo));
-  SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fill_unpack[buf], s->stream));
-  for (int d = 0; d < 3; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.coarse_bc[buf][d], s->stream));
-  for (apk_refine_plan *p : a.prolongate[buf]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
-  for (int d = 0; d < 3; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fine_bc[buf][d], s->stream));
-  return APK_OK;
-}
-
-// does the forest have a coarse-fine face at all?  (the global plan: the same answer on every rank)
-bool amr_has_coarse_fine_faces(const apk_sim *s) {
-  for (int d = 0; d < 3; ++d)
-    if (!s->amr_plans.flux_copy[d].empty()) return true;
-  return false;
-}
-
-// The flux correction for a stage that ran fused: the stage has applied every block's own face
-// fluxes; recompute the fluxes on the block boundaries from the stage's input primitives, average
-// the fine ones and correct the coarse cells next to each coarse-fine face by the difference.
-int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi_factor) {
-  if (!amr_has_coarse_fine_faces(s)) return APK_OK;
-  auto &a = s->amr_dev;
-  const int psi_var = (s->pkg.fluid == APK_FLUID_GLMMHD) ? 8 : -1;
-  SIM_TRY(s, apk_calculate_fluxes_boundary(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, s->stream));
-  for (int d = 0; d < s->mesh.ndim; ++d) {
-    for (apk_refine_plan *p : a.flux_restrict[d]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
-    SIM_TRY(s, apk_flux_fix_plan_run(s->ctx, a.flux_fix[s->cur][d], beta_dt, psi_var, psi_factor, s->stream));
-    SIM_TRY(s, apk_copy_plan_run(s->ctx, a.flux_pack[d], s->stream));
-  }
-  SIM_TRY(s, amr_exchange_messages(s, s->amr_fluxmsg));
-  for (int d = 0; d < s->mesh.ndim; ++d)
-    SIM_TRY(s, apk_flux_fix_plan_run(s->ctx, a.flux_fix_unpack[s->cur][d], beta_dt, psi_var, psi_factor, s->stream));
-  return APK_OK;
-}
-
-// coarse-fine flux correction (hydro_driver.cpp:527-531): direction by direction, because the
-// restricted fluxes of all three directions share the blocks' coarse buffers; faces whose coarse
-// side lives on another rank travel in ONE message per peer after the three directions are packed
-int amr_flux_correction(apk_sim *s) {
-  auto &a = s->amr_dev;
-  for (int d = 0; d < s->mesh.ndim; ++d) {
-    for (apk_refine_plan *p : a.flux_restrict[d]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
-    SIM_TRY(s, apk_copy_plan_run(s->ctx, a.flux_copy[d], s->stream));
-    SIM_TRY(s, apk_copy_plan_run(s->ctx, a.flux_pack[d], s->stream));
-  }
-  SIM_TRY(s, amr_exchange_messages(s, s->amr_fluxmsg));
-  for (int d = 0; d < s->mesh.ndim; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.flux_unpack[d], s->stream));
-  return APK_OK;
-}
 
 // index windows of the split stages, per local block (see apk_stage_args.window)
 int upload_window(apk_sim *s, const char *tag, const std::vector<int> &w, apk_sim::WindowTable &t) {
@@ -1665,261 +560,8 @@ int turbulence_driving(apk_sim *s, double dt) {
   return APK_OK;
 }
 
+
 // one stage of HydroDriver::MakeTaskCollection (hydro_driver.cpp:474-577)
-
-// ---- regridding -----------------------------------------------------------------------------
-int refinement_criterion(apk_sim *s, int *criterion, double *p0, double *p1) {
-  ParameterInput &pin = s->pin;
-  *criterion = -1;
-  *p0 = *p1 = 0.0;
-  try {
-    const std::string type = pin.GetOrAddString("refinement", "type", "unset");
-    if (type == "pressure_gradient") {
-      *criterion = APK_TAG_PRESSURE_GRADIENT;
-      *p0 = pin.GetOrAddReal("refinement", "threshold_pressure_gradient", 0.0);
-      if (!(*p0 > 0.)) throw std::runtime_error("Make sure to set refinement/threshold_pressure_gradient >0.");
-    } else if (type == "xyvelocity_gradient") {
-      *criterion = APK_TAG_VELOCITY_GRADIENT;
-      *p0 = pin.GetOrAddReal("refinement", "threshold_xyvelocity_gradient", 0.0);
-      if (!(*p0 > 0.)) throw std::runtime_error("Make sure to set refinement/threshold_xyvelocity_gradient >0.");
-    } else if (type == "maxdensity") {
-      *criterion = APK_TAG_MAX_DENSITY;
-      *p1 = pin.GetOrAddReal("refinement", "maxdensity_deref_below", 0.0);
-      *p0 = pin.GetOrAddReal("refinement", "maxdensity_refine_above", 0.0);
-      if (!(*p1 > 0.)) throw std::runtime_error("Make sure to set refinement/maxdensity_deref_below > 0.");
-      if (!(*p0 > 0.)) throw std::runtime_error("Make sure to set refinement/maxdensity_refine_above > 0.");
-      if (!(*p1 < *p0)) throw std::runtime_error("Make sure to set refinement/maxdensity_deref_below < refinement/maxdensity_refine_above");
-    } else {
-      throw std::runtime_error("refinement/type is unset: no refinement criterion to evaluate");
-    }
-  } catch (const std::exception &e) {
-    return fail(s, APK_ERR_INVALID, e.what());
-  }
-  return APK_OK;
-}
-
-// Apply per-block tags (+1 refine / -1 derefine / 0) to the tree -- Parthenon's
-// MeshRefinement::CheckRefinementCondition + Mesh::UpdateMeshBlockTree: refinement keeps the 2:1
-// balance by refining coarser neighbours first; a block asks for derefinement only after
-// derefine_count consecutive -1 tags, and 2^ndim siblings merge only if all of them ask and the
-// merged block would not touch a block two levels finer.  Returns whether the tree changed.
-bool amr_update_tree(apk_sim *s, const std::vector<int> &tags, bool allow_derefine) {
-  AmrTree &t = *s->amr;
-  const std::vector<AmrLeaf> old = t.leaves;
-  bool changed = false;
-  for (int lb = 0; lb < (int)old.size(); ++lb) {
-    if (tags[lb] < 0 && allow_derefine) t.SetDerefCount(lb, old[lb].deref_count + 1);
-    else t.SetDerefCount(lb, 0);
-  }
-  for (int lb = 0; lb < (int)old.size(); ++lb)
-    if (tags[lb] > 0 && old[lb].level < t.max_level) t.RefineBalanced(old[lb].level, old[lb].lx);
-  if (allow_derefine) {
-    std::unordered_set<uint64_t> seen;
-    for (int lb = 0; lb < (int)old.size(); ++lb) {
-      const AmrLeaf &l = old[lb];
-      if (l.level == 0 || tags[lb] >= 0) continue;
-      const int plx[3] = {l.lx[0] >> 1, l.lx[1] >> 1, l.lx[2] >> 1};
-      const uint64_t pkey = AmrTree::Key(l.level - 1, plx);
-      if (!seen.insert(pkey).second) continue;
-      bool all_ready = true;
-      t.ForEachChild(plx, [&](const int *, const int cl[3]) {
-        auto it = t.leafmap.find(AmrTree::Key(l.level, cl));
-        if (it == t.leafmap.end() || it->second.deref_count < s->amr_derefine_count) all_ready = false;
-      });
-      if (all_ready && t.CanMerge(l.level - 1, plx)) {
-        t.Merge(l.level - 1, plx);
-        s->amr_derefined += 1;
-      }
-    }
-  }
-  for (const AmrLeaf &l : old) {
-    if (!t.leafmap.count(AmrTree::Key(l.level, l.lx))) changed = true;
-    if (t.internal.count(AmrTree::Key(l.level, l.lx))) s->amr_refined += 1;
-  }
-  t.Reindex();
-  return changed;
-}
-
-// Move the state from the old block list (and its distribution over ranks) to the new one:
-// surviving blocks are copied, new fine blocks are prolongated from their parent (through their
-// coarse buffer), merged blocks collect their children's restricted interiors; whatever changes
-// rank travels in one message per peer.  Then everything that depends on the block list is rebuilt.
-int amr_transfer(apk_sim *s, const std::vector<AmrLeaf> &old, const AmrPartition &old_part) {
-  const AmrGeom &g = s->amr_geom;
-  AmrTree &t = *s->amr;
-  const int rank = s->rank;
-  std::unordered_map<uint64_t, int> old_index;
-  for (int n = 0; n < (int)old.size(); ++n) old_index[AmrTree::Key(old[n].level, old[n].lx)] = n;
-  AmrPartition new_part;
-  new_part.Build((int)t.leaves.size(), s->nranks);
-  // the children's restricted interiors of the old mesh (ConsToPrim floors may have touched cons since
-  // the last exchange)
-  for (apk_refine_plan *p : s->amr_dev.restrict_own[s->cur]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
-  // global transfer list: sources are old blocks (RK_OLD_*), destinations new ones
-  std::vector<BoxRegion> moves;
-  std::vector<AmrRefOp> prol;
-  const int zero[3] = {0, 0, 0};
-  for (int nb = 0; nb < (int)t.leaves.size(); ++nb) {
-    const AmrLeaf &l = t.leaves[nb];
-    BoxRegion r;
-    auto it = old_index.find(AmrTree::Key(l.level, l.lx));
-    if (it != old_index.end()) {
-      r.src_kind = RK_OLD_BLOCK, r.src_block = it->second, r.dst_kind = RK_BLOCK, r.dst_block = nb;
-      amr_box_region(r, g.fst, zero, g.fst, zero, g.fn, g.nvar);
-      moves.push_back(r);
-      continue;
-    }
-    const int plx[3] = {l.lx[0] >> 1, l.lx[1] >> 1, l.lx[2] >> 1};
-    it = (l.level > 0) ? old_index.find(AmrTree::Key(l.level - 1, plx)) : old_index.end();
-    if (it != old_index.end()) {  // refined: parent octant (+ cng cells around it) -> my coarse buffer
-      int slo[3];
-      for (int d = 0; d < 3; ++d) slo[d] = g.act[d] ? g.fs[d] + (l.lx[d] & 1) * (g.mb[d] / 2) - g.cng : 0;
-      r.src_kind = RK_OLD_BLOCK, r.src_block = it->second, r.dst_kind = RK_COARSE, r.dst_block = nb;
-      amr_box_region(r, g.fst, slo, g.cst, zero, g.cn, g.nvar);
-      moves.push_back(r);
-      if (new_part.Owner(nb) == rank) {
-        AmrRefOp op;
-        op.kind = APK_RO_PROLONGATE;
-        op.level = l.level;
-        op.src_kind = RK_COARSE, op.dst_kind = RK_BLOCK;
-        op.src_block = op.dst_block = nb - new_part.first[rank];
-        op.geom_block = nb;
-        for (int d = 0; d < 3; ++d) op.lo[d] = g.cs[d], op.hi[d] = g.ce[d];
-        prol.push_back(op);
-      }
-      continue;
-    }
-    // merged: children's coarse buffers -> my octants
-    bool ok = true;
-    t.ForEachChild(l.lx, [&](const int c[3], const int cl[3]) {
-      auto ci = old_index.find(AmrTree::Key(l.level + 1, cl));
-      if (ci == old_index.end()) {
-        ok = false;
-        return;
-      }
-      int dlo[3], ext[3];
-      for (int d = 0; d < 3; ++d) {
-        ext[d] = g.act[d] ? g.mb[d] / 2 : 1;
-        dlo[d] = g.act[d] ? g.fs[d] + c[d] * (g.mb[d] / 2) : 0;
-      }
-      BoxRegion m;
-      m.src_kind = RK_OLD_COARSE, m.src_block = ci->second, m.dst_kind = RK_BLOCK, m.dst_block = nb;
-      amr_box_region(m, g.cst, g.cs, g.fst, dlo, ext, g.nvar);
-      moves.push_back(m);
-    });
-    if (!ok) return fail(s, APK_ERR_INVALID, "regridding: a new block has neither itself, its parent nor its children in the old mesh");
-  }
-  std::vector<BoxRegion> local, pack, unpack;
-  s->amr_move.plan = AmrMessages();
-  AmrRegisterPeers(moves, old_part, new_part, rank, s->amr_move.plan);
-  AmrLocalize(moves, old_part, new_part, rank, s->amr_move.plan, local, pack, unpack);
-  SIM_TRY(s, amr_ensure_buffers(s, s->amr_move, "regrid"));
-  double *ncons2[2] = {nullptr, nullptr}, *nprim = nullptr, *nflux[3] = {nullptr, nullptr, nullptr}, *ncoarse = nullptr;
-  SIM_TRY(s, amr_allocate(s, (size_t)new_part.Count(rank), ncons2, &nprim, nflux, &ncoarse));
-  double *ocons = s->d_cons2[s->cur], *ocoarse = s->d_coarse;
-  auto base = [&](int kind, int block) -> double * {
-    switch (kind) {
-    case RK_OLD_BLOCK: return ocons + (int64_t)block * s->nper;
-    case RK_OLD_COARSE: return ocoarse + (int64_t)block * g.coarse_doubles;
-    case RK_BLOCK: return ncons2[0] + (int64_t)block * s->nper;
-    case RK_COARSE: return ncoarse + (int64_t)block * g.coarse_doubles;
-    case RK_SEND: return s->amr_move.send[block];
-    case RK_RECV: return s->amr_move.recv[block];
-    default: return nullptr;
-    }
-  };
-  auto run = [&](const std::vector<BoxRegion> &regions) -> int {
-    std::vector<apk_copy_region> regs;
-    for (const BoxRegion &r : regions) regs.push_back(to_copy_region(r, base(r.src_kind, r.src_block), base(r.dst_kind, r.dst_block)));
-    apk_copy_plan *cp = nullptr;
-    int rc = apk_copy_plan_create(s->ctx, regs.data(), (int)regs.size(), &cp);
-    if (rc == APK_OK) rc = apk_copy_plan_run(s->ctx, cp, s->stream);
-    if (hipStreamSynchronize(hs(s)) != hipSuccess && rc == APK_OK) rc = APK_ERR_DEVICE;
-    apk_copy_plan_destroy(cp);
-    return rc;
-  };
-  SIM_TRY(s, run(pack));
-  SIM_TRY(s, run(local));
-  SIM_TRY(s, amr_exchange_messages(s, s->amr_move));
-  SIM_TRY(s, run(unpack));
-  // swap in the new arrays
-  for (int p = 0; p < 2; ++p) dev_free(s, s->d_cons2[p]);
-  dev_free(s, s->d_prim2[0]);
-  dev_free(s, s->d_prim2[1]);
-  for (int d = 0; d < 3; ++d) dev_free(s, s->d_flux[d]);
-  dev_free(s, s->d_coarse);
-  s->d_cons2[0] = ncons2[0], s->d_cons2[1] = ncons2[1];
-  s->cur = 0, s->u1buf = 1, s->pcur = 0;
-  s->d_prim2[0] = nprim, s->d_prim2[1] = nullptr;
-  for (int d = 0; d < 3; ++d) s->d_flux[d] = nflux[d];
-  s->d_coarse = ncoarse;
-  SIM_TRY(s, amr_rebuild(s));
-  if (!prol.empty()) {
-    std::vector<apk_refine_plan *> plans;
-    SIM_TRY(s, amr_make_refine_plans(s, 0, prol, plans));
-    int rc = APK_OK;
-    for (apk_refine_plan *p : plans) rc = (rc == APK_OK) ? apk_refine_plan_run(s->ctx, p, s->stream) : rc;
-    SIM_HIP(s, hipStreamSynchronize(hs(s)));
-    for (apk_refine_plan *p : plans) apk_refine_plan_destroy(p);
-    if (rc != APK_OK) return rc;
-  }
-  return APK_OK;
-}
-
-// the tags of every leaf of the forest: mine from the device, the others' through a sum reduction
-int amr_global_tags(apk_sim *s, std::vector<int> &tags) {
-  int criterion;
-  double p0, p1;
-  SIM_TRY(s, refinement_criterion(s, &criterion, &p0, &p1));
-  const int nlocal = (int)s->mesh.local_gids.size(), first = s->amr_part.first[s->rank];
-  std::vector<int> mine(nlocal, 0);
-  SIM_TRY(s, apk_tag_blocks(s->ctx, s->mu0(), criterion, p0, p1, mine.data(), nullptr, s->stream));
-  tags.assign(s->amr->leaves.size(), 0);
-  for (int lb = 0; lb < nlocal; ++lb) tags[first + lb] = mine[lb];
-  if (s->have_comm && s->nranks > 1) {
-    std::vector<double> buf(tags.begin(), tags.end());
-    if (s->comm.allreduce_sum(s->comm.user, buf.data(), (int)buf.size()) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_sum failed");
-    for (size_t n = 0; n < tags.size(); ++n) tags[n] = (int)std::lround(buf[n]);
-  }
-  return APK_OK;
-}
-
-// fresh (zeroed) arrays for the current block list; the state is NOT carried over
-int amr_reallocate(apk_sim *s) {
-  SIM_HIP(s, hipStreamSynchronize(hs(s)));
-  for (int p = 0; p < 2; ++p) dev_free(s, s->d_cons2[p]);
-  dev_free(s, s->d_prim2[0]);
-  dev_free(s, s->d_prim2[1]);
-  for (int d = 0; d < 3; ++d) dev_free(s, s->d_flux[d]);
-  dev_free(s, s->d_coarse);
-  s->d_prim2[1] = nullptr;
-  s->cur = 0, s->u1buf = 1, s->pcur = 0;
-  AmrPartition part;
-  part.Build((int)s->amr->leaves.size(), s->nranks);
-  SIM_TRY(s, amr_allocate(s, (size_t)part.Count(s->rank), s->d_cons2, &s->d_prim2[0], s->d_flux, &s->d_coarse));
-  return amr_rebuild(s);
-}
-
-// Mesh::LoadBalancingAndAdaptiveMeshRefinement for one rank: tag, update the tree, move the data,
-// refill ghost zones and primitives on the new mesh
-int amr_regrid(apk_sim *s, bool *changed) {
-  *changed = false;
-  std::vector<int> tags;
-  SIM_TRY(s, amr_global_tags(s, tags));
-  const std::vector<AmrLeaf> old = s->amr->leaves;
-  const AmrPartition old_part = s->amr_part;
-  try {
-    if (!amr_update_tree(s, tags, true)) return APK_OK;
-  } catch (const std::exception &e) {
-    return fail(s, APK_ERR_INVALID, e.what());
-  }
-  if ((int)s->amr->leaves.size() < s->nranks) return fail(s, APK_ERR_INVALID, "fewer meshblocks than ranks");
-  SIM_TRY(s, amr_transfer(s, old, old_part));
-  SIM_TRY(s, exchange_ghosts(s));
-  SIM_TRY(s, fill_derived(s));
-  *changed = true;
-  return APK_OK;
-}
 
 int do_stage(apk_sim *s, int stage) {
   HydroPackage &pkg = s->pkg;
@@ -2133,7 +775,11 @@ int create_common(const char *deck, const char *const *overrides, int noverrides
   return APK_OK;
 }
 
-}  // namespace
+
+}  // namespace host
+}  // namespace apk
+
+using namespace apk::host;
 
 extern "C" {
 

@@ -1,0 +1,131 @@
+// sim_internal.hpp -- what the translation units of the standalone host driver share (sim.cpp: set-up,
+// stage loop, C API; sim_pgen.cpp: problem generators; sim_amr.cpp: refined meshes).  Not installed.
+#pragma once
+
+#include "sim.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <sstream>
+#include <unordered_map>
+#include <unordered_set>
+
+namespace apk {
+namespace host {
+
+constexpr double kHuge = std::numeric_limits<double>::max();
+
+inline int fail(apk_sim *s, int code, const std::string &msg) {
+  if (s) s->err = msg;
+  return code;
+}
+
+#define SIM_TRY(s, expr)                                                        \
+  do {                                                                          \
+    int rc__ = (expr);                                                          \
+    if (rc__ != APK_OK) {                                                       \
+      if ((s)->err.empty() && (s)->ctx) (s)->err = apk_last_error((s)->ctx);    \
+      if ((s)->err.empty()) (s)->err = #expr;                                   \
+      return rc__;                                                              \
+    }                                                                           \
+  } while (0)
+
+#define SIM_HIP(s, expr)                                                        \
+  do {                                                                          \
+    hipError_t e__ = (expr);                                                    \
+    if (e__ != hipSuccess) return fail((s), APK_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+inline hipStream_t hs(const apk_sim *s) { return reinterpret_cast<hipStream_t>(s->stream); }
+
+int parse_bc(const std::string &v);
+void hydro_initialize(apk_sim *s);
+void mesh_initialize(apk_sim *s);
+int dev_alloc(apk_sim *s, const char *tag, size_t bytes, double **out);
+void dev_free(apk_sim *s, double *p);
+int build_packs(apk_sim *s);
+int ensure_spare_prim(apk_sim *s);
+int ensure_flux_arrays(apk_sim *s);
+bool stage_can_fuse(const apk_sim *s);
+double *region_base(apk_sim *s, int parity, int kind, int block);
+int build_copy_plans(apk_sim *s);
+void set_global_dt(apk_sim *s, double dt_est);
+int estimate_timestep(apk_sim *s, double *dt_out);
+bool ghost_c2p_fusable(const apk_sim *s);
+int run_ghost_plan(apk_sim *s, int buf, int phase, bool c2p);
+int exchange_begin(apk_sim *s, bool async, bool c2p);
+int exchange_end(apk_sim *s, bool c2p);
+int exchange_ghosts(apk_sim *s, bool c2p = false);
+int upload_window(apk_sim *s, const char *tag, const std::vector<int> &w, apk_sim::WindowTable &t);
+int build_windows(apk_sim *s);
+bool can_overlap_next(const apk_sim *s, int next);
+int finish_pending(apk_sim *s);
+int fill_derived(apk_sim *s);
+int pre_step(apk_sim *s);
+int turbulence_device_setup(apk_sim *s);
+int turbulence_driving(apk_sim *s, double dt);
+int do_stage(apk_sim *s, int stage);
+double xc(const apk_sim *s, const double x0[3], int d, int idx);
+void block_origin(const apk_sim *s, int lb, double x0[3]);
+void lw_eigensystem(double gm1, double v1, double v2, double v3, double h, double ev[5], double rem[5][5]);
+void lw_setup(apk_sim *s);
+void lw_state(const LinearWaveState &lw, double x1, double x2, double x3, double u[5]);
+void cpaw_setup(apk_sim *s);
+void cpaw_potential(const CpawState &c, double x1, double x2, double x3, double A[3]);
+void cpaw_state(const CpawState &c, double X1, double X2, double X3, double m[3], double b[3]);
+void field_loop_potential(const FieldLoopState &f, double x1, double x2, double x3, double A[3]);
+void kh_setup(apk_sim *s);
+void field_loop_setup(apk_sim *s);
+void pgen_block(apk_sim *s, int lb, std::vector<double> &u);
+void turbulence_setup(apk_sim *s);
+int pgen_turbulence(apk_sim *s, std::vector<std::vector<double>> &blocks);
+double level_dx(const apk_sim *s, int level, int d);
+const AmrLeaf &amr_leaf(const apk_sim *s, int lb);
+int block_level(const apk_sim *s, int lb);
+void amr_sync_mesh(apk_sim *s);
+void amr_localize(apk_sim *s);
+void amr_initialize(apk_sim *s, bool adaptive);
+double *amr_base(apk_sim *s, int parity, int kind, int block, const apk_sim::MsgSet *msgs);
+apk_copy_region to_copy_region(const BoxRegion &r, const double *src, double *dst);
+int amr_make_refine_plans(apk_sim *s, int parity, const std::vector<AmrRefOp> &ops, std::vector<apk_refine_plan *> &out);
+void amr_destroy_device_plans(apk_sim *s);
+int amr_ensure_buffers(apk_sim *s, apk_sim::MsgSet &m, const char *name);
+void amr_free_buffers(apk_sim *s, apk_sim::MsgSet &m);
+int amr_exchange_messages(apk_sim *s, const apk_sim::MsgSet &m);
+int amr_allocate(apk_sim *s, size_t n, double *cons2[2], double **prim, double *flux[3], double **coarse);
+int amr_rebuild(apk_sim *s);
+int amr_exchange(apk_sim *s, int buf);
+bool amr_has_coarse_fine_faces(const apk_sim *s);
+int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi_factor);
+int amr_flux_correction(apk_sim *s);
+int refinement_criterion(apk_sim *s, int *criterion, double *p0, double *p1);
+bool amr_update_tree(apk_sim *s, const std::vector<int> &tags, bool allow_derefine);
+int amr_transfer(apk_sim *s, const std::vector<AmrLeaf> &old, const AmrPartition &old_part);
+int amr_global_tags(apk_sim *s, std::vector<int> &tags);
+int amr_reallocate(apk_sim *s);
+int amr_regrid(apk_sim *s, bool *changed);
+
+// On refined meshes the problem generators and the error norms see the cell widths of the block
+// they work on through s->dx (restored on scope exit)
+struct LevelDxScope {
+  apk_sim *s;
+  double saved[3];
+  LevelDxScope(apk_sim *sim, int lb) : s(sim) {
+    for (int d = 0; d < 3; ++d) {
+      saved[d] = s->dx[d];
+      if (s->amr && s->mesh.Active(d)) s->dx[d] = saved[d] / (double)(1 << amr_leaf(s, lb).level);
+    }
+  }
+  ~LevelDxScope() {
+    for (int d = 0; d < 3; ++d) s->dx[d] = saved[d];
+  }
+};
+
+}  // namespace host
+}  // namespace apk
