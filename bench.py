@@ -352,8 +352,9 @@ def main():
                 "cells_per_launch": zones_local,
                 "stage_ms": stage_ms,
                 "dc_predictor_stage_ms": per_kernel["fused_dc_x1"] + per_kernel["fused_dc_x2"] + per_kernel["fused_dc_x3"],
-                "note": "fp64 VALU-issue bound, not HBM bound: ~2.6k VALU instructions per cell per sweep "
-                        "(IEEE divide/sqrt expansions included); see DESIGN.md 'Roofline'",
+                "note": "fp64 VALU-issue bound, not HBM bound: ~1.5k executed VALU instructions per cell per sweep, "
+                        "~4.4k per cell-stage (SQ_INSTS_VALU, profiles/r01_pmc_sq_counter_collection.csv); see "
+                        "DESIGN.md section 7",
                 "per_kernel_avg_ms": per_kernel,
                 "dominant_kernel": dominant,
                 "whole_cycle": {"algorithmic_bytes_per_zone_cycle": b_cycle,
