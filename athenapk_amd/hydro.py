@@ -129,11 +129,13 @@ def _cfg(fluid, recon, riemann):
 
 
 # ---- the task functions ---------------------------------------------------------------------
-def CalculateFluxes(md, fluid, recon, riemann, eos, c_h=0.0, tight=False):
+def CalculateFluxes(md, fluid, recon, riemann, eos, c_h=0.0, tight=False, boundary=False):
     """Hydro::CalculateFluxes<fluid,recon,rsolver>(md)  -- src/hydro/hydro.cpp:1025; tight: only the
-    faces of interior cells (the loop limits of CalculateFluxesTight, hydro.cpp:1006-1009)"""
+    faces of interior cells (the loop limits of CalculateFluxesTight, hydro.cpp:1006-1009); boundary:
+    only the 2 ndim block-boundary planes (for the flux correction after a fused stage)"""
     ctx = md.ctx
-    fn = ctx.lib.apk_calculate_fluxes_tight if tight else ctx.lib.apk_calculate_fluxes
+    fn = (ctx.lib.apk_calculate_fluxes_boundary if boundary else
+          (ctx.lib.apk_calculate_fluxes_tight if tight else ctx.lib.apk_calculate_fluxes))
     _check(fn(ctx.h, md.h, _cfg(fluid, recon, riemann), C.byref(eos), float(c_h), _stream()), ctx.lib, ctx.h)
 
 
@@ -208,6 +210,49 @@ def FirstOrderFluxCorrect(u0, u1, fluid, eos, c_h, gam0, gam1, beta_dt):
     _check(ctx.lib.apk_first_order_flux_correct(ctx.h, u0.h, u1.h, L.FLUID[fluid], C.byref(eos), c_h,
                                                 gam0, gam1, beta_dt, C.byref(n), _stream()), ctx.lib, ctx.h)
     return n.value
+
+
+def CountUnphysical(md, fluid):
+    """cells whose conserved state fails FirstOrderFluxCorrect's test (hydro.cpp:1297-1306)"""
+    ctx = md.ctx
+    n = C.c_longlong(0)
+    _check(ctx.lib.apk_count_unphysical(ctx.h, md.h, L.FLUID[fluid], C.byref(n), _stream()), ctx.lib, ctx.h)
+    return n.value
+
+
+class FluxFixPlan:
+    """Coarse-fine flux correction applied to the cells next to the faces after a fused stage:
+    regions = list of (fine_avg tensor view, coarse_flux tensor view, cons tensor view, scale) where
+    the three views have the same shape [nvar][nk][nj][ni] (strides are taken from the views)."""
+
+    def __init__(self, ctx, regions):
+        self.ctx = ctx
+        arr = (L.FluxFixRegion * max(1, len(regions)))()
+        self._keep = []
+        for n, (fa, cf, cons, scale) in enumerate(regions):
+            assert fa.shape == cf.shape == cons.shape and cf.stride() == cons.stride()
+            arr[n].fine_avg, arr[n].coarse_flux, arr[n].cons = fa.data_ptr(), cf.data_ptr(), cons.data_ptr()
+            arr[n].nvar = fa.shape[0]
+            arr[n].ext[:] = [fa.shape[3], fa.shape[2], fa.shape[1]]
+            arr[n].src_stride[:] = [fa.stride(3), fa.stride(2), fa.stride(1), fa.stride(0)]
+            arr[n].dst_stride[:] = [cons.stride(3), cons.stride(2), cons.stride(1), cons.stride(0)]
+            arr[n].scale = scale
+            self._keep += [fa, cf, cons]
+        h = C.c_void_p()
+        _check(ctx.lib.apk_flux_fix_plan_create(ctx.h, arr, len(regions), C.byref(h)), ctx.lib, ctx.h)
+        self.h = h
+
+    def run(self, beta_dt, psi_var=-1, psi_factor=1.0):
+        _check(self.ctx.lib.apk_flux_fix_plan_run(self.ctx.h, self.h, float(beta_dt), int(psi_var), float(psi_factor), _stream()),
+               self.ctx.lib, self.ctx.h)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.ctx.lib.apk_flux_fix_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 def HydroHst(md, fluid):

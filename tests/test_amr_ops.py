@@ -221,3 +221,90 @@ def test_tag_blocks_matches_oracle(request, oracle, nx):
         assert list(tags) == [w[0] for w in want], crit
         assert list(vals) == [w[1] for w in want], crit       # a max: order independent, bit exact
         assert len(set(tags)) > 1, crit
+
+
+# ---- the pieces of the flux correction after a fused stage, through the C-ABI --------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("fluid,recon,riemann,ng", [("euler", "plm", "hllc", 2), ("glmmhd", "ppm", "hlld", 4),
+                                                    ("glmmhd", "wenoz", "hlle", 3)])
+@pytest.mark.parametrize("nx", [(8, 8, 8), (16, 8, 1), (72, 6, 4)], ids=["8x8x8", "2d", "wide"])
+def test_boundary_plane_fluxes_equal_the_full_sweeps(request, fluid, recon, riemann, ng, nx):
+    """apk_calculate_fluxes_boundary: the two block-boundary planes of every active direction, bit for
+    bit what apk_calculate_fluxes puts there; nothing else is written"""
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    nh = 9 if fluid == "glmmhd" else 5
+    prim = H.random_prim(fluid, nx, ng, nscalars=1, seed=9, kind="smooth", nblocks=3)
+    eos = hydro.L.make_eos(5.0 / 3.0)
+    full = hydro.MeshData(ctx, nx, ng, nh, nscalars=1, dx=(0.1, 0.2, 0.3), nblocks=3, prim=prim)
+    bnd = hydro.MeshData(ctx, nx, ng, nh, nscalars=1, dx=(0.1, 0.2, 0.3), nblocks=3, prim=prim)
+    hydro.CalculateFluxes(full, fluid, recon, riemann, eos, 1.3)
+    hydro.CalculateFluxes(bnd, fluid, recon, riemann, eos, 1.3, boundary=True)
+    act = [True, nx[1] > 1, nx[2] > 1]
+    for d in range(full.ndim):
+        a, b = full.flux_host(d), bnd.flux_host(d)
+        mask = np.zeros(b.shape, bool)
+        for side in (0, 1):
+            sl = [slice(None), slice(None)] + [slice(ng, ng + nx[q]) if act[q] else slice(None) for q in (2, 1, 0)]
+            sl[4 - d] = ng + (nx[d] if side else 0)
+            sl = tuple(sl)
+            assert np.array_equal(a[sl], b[sl]) and np.abs(b[sl]).max() > 0
+            mask[sl] = True
+        assert np.all(b[~mask] == 0.0)
+
+
+@pytest.mark.gpu
+def test_flux_fix_plan_against_numpy(request):
+    """cons += beta_dt * scale * (fine_avg - coarse_flux), psi scaled by its damping factor; strided
+    sources (a message buffer laid out compactly) and destinations (a plane inside a block)"""
+    import torch
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    rng = np.random.default_rng(2)
+    nvar, n = 9, 12
+    cons = torch.from_numpy(rng.standard_normal((nvar, n, n, n))).cuda()
+    flux = torch.from_numpy(rng.standard_normal((nvar, n, n, n))).cuda()
+    buf = torch.from_numpy(rng.standard_normal((2, nvar, 4, 4))).cuda()   # two compact 4x4 planes
+    want = cons.clone()
+    beta_dt, psi_factor = 0.37, 0.8
+    regions = []
+    # lower x face of cells i = 2 (scale +1/dx), upper y face of cells j = 9 (flux at j = 10, scale -1/dx)
+    v0 = (slice(None), slice(3, 7), slice(4, 8), slice(2, 3))
+    regions.append((buf[0].reshape(nvar, 4, 4, 1), flux[v0], cons[v0], +1.0 / 0.25))
+    c1 = (slice(None), slice(2, 6), slice(9, 10), slice(5, 9))
+    f1 = (slice(None), slice(2, 6), slice(10, 11), slice(5, 9))
+    regions.append((buf[1].reshape(nvar, 4, 1, 4), flux[f1], cons[c1], -1.0 / 0.5))
+    for (fa, cf, cc, scale), csel in zip(regions, (v0, c1)):
+        d = beta_dt * scale * (fa - cf)
+        d[8] = d[8] * psi_factor
+        want[csel] += d
+    # the plan needs cons and flux views with equal strides: true for same-shaped contiguous parents
+    hydro.FluxFixPlan(ctx, regions).run(beta_dt, psi_var=8, psi_factor=psi_factor)
+    torch.cuda.synchronize()
+    assert torch.equal(cons, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fluid", ["euler", "glmmhd"])
+def test_count_unphysical_matches_numpy(request, fluid):
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    nx, ng = (16, 8, 8), 2
+    nh = 9 if fluid == "glmmhd" else 5
+    rng = np.random.default_rng(4)
+    cons = rng.uniform(0.5, 1.5, (2, nh, 12, 12, 20))
+    cons[:, 4] += 3.0
+    bad = [(0, 3, 4, 5), (1, 7, 2, 9), (1, 9, 9, 17)]
+    cons[0, 0, 3, 4, 5] = -0.1                    # negative density
+    cons[1, 4, 7, 2, 9] = 0.01                    # energy below kinetic (+ magnetic)
+    cons[1, 0, 9, 9, 17] = 0.0                    # zero density
+    cons[0, 0, 0, 0, 0] = -1.0                    # a ghost cell: not counted
+    md = hydro.MeshData(ctx, nx, ng, nh, nblocks=2, cons=cons, with_flux=False)
+    u = cons[:, :, ng:-ng, ng:-ng, ng:-ng]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        p = u[:, 4] - 0.5 * (u[:, 1] ** 2 + u[:, 2] ** 2 + u[:, 3] ** 2) / u[:, 0]
+        if fluid == "glmmhd":
+            p = p - 0.5 * (u[:, 5] ** 2 + u[:, 6] ** 2 + u[:, 7] ** 2)
+        want = int(np.sum(~((u[:, 0] > 0) & (p > 0))))
+    assert want >= len(bad)
+    assert hydro.CountUnphysical(md, fluid) == want
