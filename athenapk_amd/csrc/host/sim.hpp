@@ -173,6 +173,10 @@ struct apk_sim {
     apk_copy_plan *flux_pack[3] = {nullptr, nullptr, nullptr}, *flux_unpack[3] = {nullptr, nullptr, nullptr};
     // the correction applied after a fused stage instead (apk_flux_fix_plan): same-rank faces and
     // faces whose fine side arrived in a message, per cons buffer the stage wrote
+    // The launches of the multilevel exchange before / after the message exchange take no per-cycle
+    // arguments: each half is captured once per mesh into a hipGraph and replayed as ONE launch
+    // (void* = hipGraphExec_t; null = not captured, the plans are launched one by one)
+    void *xchg_pre[2] = {nullptr, nullptr}, *xchg_post[2] = {nullptr, nullptr};
     apk_flux_fix_plan *flux_fix[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     apk_flux_fix_plan *flux_fix_unpack[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     apk_copy_plan *coarse_bc[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};

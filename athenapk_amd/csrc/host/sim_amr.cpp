@@ -221,8 +221,11 @@ int amr_make_refine_plans(apk_sim *s, int parity, const std::vector<AmrRefOp> &o
   return APK_OK;
 }
 
+void amr_destroy_graphs(apk_sim *s);
+
 void amr_destroy_device_plans(apk_sim *s) {
   auto &a = s->amr_dev;
+  amr_destroy_graphs(s);
   for (int par = 0; par < 2; ++par) {
     for (apk_refine_plan *p : a.restrict_own[par]) apk_refine_plan_destroy(p);
     for (apk_refine_plan *p : a.prolongate[par]) apk_refine_plan_destroy(p);
@@ -383,20 +386,78 @@ int amr_rebuild(apk_sim *s) {
       SIM_TRY(s, amr_make_fix_plan(s, par, d, p.flux_unpack[d], &s->amr_fluxmsg, &a.flux_fix_unpack[par][d]));
     }
   }
+  for (int par = 0; par < 2; ++par) {
+    amr_capture_half(s, par, true, &a.xchg_pre[par]);
+    amr_capture_half(s, par, false, &a.xchg_post[par]);
+  }
   return build_packs(s);
 }
 
-// the multilevel ghost exchange of the state in cons buffer `buf` (see amr.hpp)
-int amr_exchange(apk_sim *s, int buf) {
+// the multilevel ghost exchange of the state in cons buffer `buf` (see amr.hpp), in the two halves
+// either side of the message exchange
+int amr_exchange_pre(apk_sim *s, int buf) {
   auto &a = s->amr_dev;
   for (apk_refine_plan *p : a.restrict_own[buf]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
   SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fill_pack[buf], s->stream));
   SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fill[buf], s->stream));
-  SIM_TRY(s, amr_exchange_messages(s, s->amr_halo));
+  return APK_OK;
+}
+int amr_exchange_post(apk_sim *s, int buf) {
+  auto &a = s->amr_dev;
   SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fill_unpack[buf], s->stream));
   for (int d = 0; d < 3; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.coarse_bc[buf][d], s->stream));
   for (apk_refine_plan *p : a.prolongate[buf]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
   for (int d = 0; d < 3; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fine_bc[buf][d], s->stream));
+  return APK_OK;
+}
+
+// Capture one half into an executable graph.  The sim's stream may be the legacy default stream,
+// which cannot be captured: the launches are recorded on a private stream (nothing executes) and
+// the graph is launched on the sim's stream later.  Any failure leaves *out null: the caller then
+// launches the plans one by one as before.
+void amr_capture_half(apk_sim *s, int buf, bool pre, void **out) {
+  *out = nullptr;
+  static const bool disabled = std::getenv("APK_NO_GRAPH") != nullptr;  // A/B switch
+  if (disabled) return;
+  hipStream_t cs = nullptr;
+  if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  bool ok = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess;
+  if (ok) {
+    const apk_stream_t saved = s->stream;
+    const std::string saved_err = s->err;
+    s->stream = reinterpret_cast<apk_stream_t>(cs);
+    const int rc = pre ? amr_exchange_pre(s, buf) : amr_exchange_post(s, buf);
+    s->stream = saved;
+    ok = hipStreamEndCapture(cs, &graph) == hipSuccess && rc == APK_OK && graph != nullptr;
+    if (rc != APK_OK) s->err = saved_err;
+  }
+  size_t nodes = 0;
+  if (ok) ok = hipGraphGetNodes(graph, nullptr, &nodes) == hipSuccess && nodes > 1;  // (a single launch gains nothing)
+  if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+  if (graph) (void)hipGraphDestroy(graph);
+  (void)hipStreamDestroy(cs);
+  (void)hipGetLastError();
+  if (ok) *out = exec;
+}
+
+void amr_destroy_graphs(apk_sim *s) {
+  auto &a = s->amr_dev;
+  for (int buf = 0; buf < 2; ++buf) {
+    if (a.xchg_pre[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_pre[buf]));
+    if (a.xchg_post[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_post[buf]));
+    a.xchg_pre[buf] = a.xchg_post[buf] = nullptr;
+  }
+}
+
+int amr_exchange(apk_sim *s, int buf) {
+  auto &a = s->amr_dev;
+  if (a.xchg_pre[buf]) SIM_HIP(s, hipGraphLaunch(static_cast<hipGraphExec_t>(a.xchg_pre[buf]), hs(s)));
+  else SIM_TRY(s, amr_exchange_pre(s, buf));
+  SIM_TRY(s, amr_exchange_messages(s, s->amr_halo));
+  if (a.xchg_post[buf]) SIM_HIP(s, hipGraphLaunch(static_cast<hipGraphExec_t>(a.xchg_post[buf]), hs(s)));
+  else SIM_TRY(s, amr_exchange_post(s, buf));
   return APK_OK;
 }
 

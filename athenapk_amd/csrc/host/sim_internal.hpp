@@ -101,6 +101,10 @@ int amr_exchange_messages(apk_sim *s, const apk_sim::MsgSet &m);
 int amr_allocate(apk_sim *s, size_t n, double *cons2[2], double **prim, double *flux[3], double **coarse);
 int amr_rebuild(apk_sim *s);
 int amr_exchange(apk_sim *s, int buf);
+int amr_exchange_pre(apk_sim *s, int buf);
+int amr_exchange_post(apk_sim *s, int buf);
+void amr_capture_half(apk_sim *s, int buf, bool pre, void **out);
+void amr_destroy_graphs(apk_sim *s);
 bool amr_has_coarse_fine_faces(const apk_sim *s);
 int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi_factor);
 int amr_flux_correction(apk_sim *s);
