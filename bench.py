@@ -130,7 +130,7 @@ def amr_blast_bench(cycles=40):
                      "meshblocks": int(i.nblocks_total), "levels": maxlev + 1, "blocks_refined": refined,
                      "sibling_groups_merged": merged}
         s.close()
-    out["mesh"] = "root 64^3 in 16^3 meshblocks, 4 levels, adaptive (pressure gradient), flux-array path + flux correction"
+    out["mesh"] = "root 64^3 in 16^3 meshblocks, 4 levels, adaptive (pressure gradient), fused stages + post-stage flux correction"
     return out
 
 
