@@ -37,8 +37,14 @@ enum { IV1 = 1, IV2 = 2, IV3 = 3, IPR = 4 };
 #endif
 
 APK_DEV double sqr(double x) { return x * x; }
+#ifdef APK_FP_STRICT
 APK_DEV double min2(double a, double b) { return (b < a) ? b : a; }  // std::min
 APK_DEV double max2(double a, double b) { return (a < b) ? b : a; }  // std::max
+#else
+// one v_min_f64 / v_max_f64 (IEEE minNum / maxNum: same value for ordered operands)
+APK_DEV double min2(double a, double b) { return fmin(a, b); }
+APK_DEV double max2(double a, double b) { return fmax(a, b); }
+#endif
 // Parthenon SIGN(x) = (x < 0) ? -1 : 1 ; carried as a bool "is negative"
 APK_DEV bool neg(double x) { return x < 0.0; }
 // x > 0 with NaN -> false, decided on the bit pattern so that the default build's finite-math
