@@ -1079,6 +1079,22 @@ int apk_sim_amr_stats(const apk_sim *s, long long *refined, long long *derefined
   return APK_OK;
 }
 
+// Host logic of a regridding pass for given tags (+1 refine / -1 derefine / 0 per block of the
+// forest, global numbering): forest update, new distribution, new plans -- no field data is
+// touched, so this is for sims created with apk_sim_create_host_only (plan introspection, tests)
+int apk_sim_amr_apply_tags(apk_sim *s, const int *tags, int ntags, int *changed) {
+  if (!s || !s->amr || !s->host_only || !tags || ntags != (int)s->amr->leaves.size()) return APK_ERR_INVALID;
+  try {
+    const bool ch = amr_update_tree(s, std::vector<int>(tags, tags + ntags), true);
+    amr_sync_mesh(s);
+    amr_localize(s);
+    if (changed) *changed = ch ? 1 : 0;
+  } catch (const std::exception &e) {
+    return fail(s, APK_ERR_INVALID, e.what());
+  }
+  return APK_OK;
+}
+
 // one regridding pass on demand (adaptive meshes do this every check_refine_interval cycles)
 int apk_sim_regrid(apk_sim *s, int *changed) {
   if (!s || s->host_only || !s->amr) return APK_ERR_INVALID;

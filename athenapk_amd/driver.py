@@ -503,6 +503,16 @@ class HostPlan(_FmftHost, _MeshView):
             out.append((pi.rank, pi.send_count, pi.recv_count))
         return out
 
+    def apply_tags(self, tags):
+        """host logic of one regridding pass (forest, distribution, plans) for per-block tags"""
+        arr = (C.c_int * len(tags))(*[int(t) for t in tags])
+        ch = C.c_int(0)
+        rc = self.lib.apk_sim_amr_apply_tags(self.h, arr, len(tags), C.byref(ch))
+        if rc != L.APK_OK:
+            raise L.ApkError(rc, self.lib.apk_sim_last_error(self.h).decode())
+        self.refresh_info()
+        return bool(ch.value)
+
     @property
     def tlim(self):
         return self.lib.apk_sim_tlim(self.h)

@@ -246,6 +246,7 @@ def _signatures():
         "apk_sim_block_level": (i, [vp, i]),
         "apk_sim_amr_stats": (i, [vp, C.POINTER(ll), C.POINTER(ll), C.POINTER(i), C.POINTER(ll)]),
         "apk_sim_regrid": (i, [vp, C.POINTER(i)]),
+        "apk_sim_amr_apply_tags": (i, [vp, C.POINTER(i), i, C.POINTER(i)]),
     }
 
 

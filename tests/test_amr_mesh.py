@@ -242,3 +242,77 @@ def test_distributed_plans_reproduce_the_one_rank_exchange(oracle, ov, bc, nrank
     halo = sum(sc for v in views for _, sc, _ in v.messages("halo"))
     flux = sum(sc for v in views for _, sc, _ in v.messages("flux"))
     assert halo > 0 and 0 < flux < halo
+
+
+def _check_forest(v):
+    """tiling, 2:1 balance across faces / edges / corners (periodic wrap included)"""
+    pl = placement(v)
+    i = v.info
+    nd = i.ndim
+    vol = sum(np.prod([i.mb[d] * p[3][d] for d in range(nd)]) for p in pl)
+    assert abs(vol - np.prod([i.xmax[d] - i.xmin[d] for d in range(nd)])) < 1e-12
+    leaves = {(p[0],) + tuple(p[1][:nd]) for p in pl}
+    assert len(leaves) == len(pl)
+    nroot = [i.nx[d] // i.mb[d] for d in range(nd)]
+    finest = max(p[0] for p in pl)
+    # occupancy map at the finest level -> level of the covering leaf
+    shape = [nroot[d] << finest for d in range(nd)]
+    lev = -np.ones(shape, int)
+    for p in pl:
+        w = 1 << (finest - p[0])
+        sl = tuple(slice(p[1][d] * w, (p[1][d] + 1) * w) for d in range(nd))
+        assert np.all(lev[sl] == -1)
+        lev[sl] = p[0]
+    assert np.all(lev >= 0)
+    for shift in np.ndindex(*([3] * nd)):
+        off = [s - 1 for s in shift]
+        nb = np.roll(lev, off, axis=tuple(range(nd)))
+        assert np.abs(nb - lev).max() <= 1
+    return pl
+
+
+@pytest.mark.parametrize("dims", [2, 3])
+def test_random_regridding_keeps_the_forest_balanced(oracle, dims):
+    """random refine / derefine requests for 12 rounds (derefine_count = 2): after every round the
+    leaves tile the domain, touching leaves differ by at most one level (periodic wrap included), blocks
+    only merge after two consecutive requests of all siblings, and the multilevel exchange built for
+    the new forest is still exact for linear data"""
+    ov = ["parthenon/mesh/refinement=adaptive", "parthenon/mesh/numlevel=4", "parthenon/mesh/derefine_count=2",
+          "parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=8"]
+    ov += ["parthenon/mesh/nx3=16", "parthenon/meshblock/nx3=8"] if dims == 3 else ["parthenon/mesh/nx3=1", "parthenon/meshblock/nx3=1"]
+    v = _view(ov + _bc("periodic"))        # (the balance check wraps around: neighbours across the boundary count)
+    rng = np.random.default_rng(100 + dims)
+    sizes = []
+    for rnd in range(12):
+        n = v.refresh_info().nblocks_total
+        p_ref = 0.15 if rnd < 5 else 0.03
+        tags = rng.choice([1, 0, -1], size=n, p=[p_ref, 0.35, 0.65 - p_ref])
+        before = {(p[0],) + tuple(p[1]) for p in placement(v)}
+        v.apply_tags(tags)
+        pl = _check_forest(v)
+        after = {(p[0],) + tuple(p[1]) for p in pl}
+        if rnd == 0:
+            assert not any(k[0] < min(b[0] for b in before) for k in after)    # nothing merges in the first round
+        sizes.append(len(pl))
+    assert max(sizes) > sizes[0] and max(p[0] for p in pl) >= 1 and min(sizes[6:]) < max(sizes)
+    # the plans of the final forest: linear data exact
+    pl = placement(v)
+    em = Emulator(v, oracle)
+    i = v.info
+    ng = i.ng
+    sl = (slice(None), slice(ng, -ng) if i.mb[2] > 1 else slice(None), slice(ng, -ng), slice(ng, -ng))
+    for lb in range(em.nb):
+        z, y, x = _cell_centres(v, lb, pl)
+        f = np.stack([1.0 + 0.3 * x - 0.2 * y + 0.5 * z * (dims == 3)] * em.nvar)
+        em.cons[lb][:] = np.nan
+        em.cons[lb][sl] = f[sl]
+    em.exchange()
+    for lb in range(em.nb):
+        z, y, x = _cell_centres(v, lb, pl)
+        f = 1.0 + 0.3 * x - 0.2 * y + 0.5 * z * (dims == 3)
+        inside = np.ones(x.shape, bool)
+        for d, c in enumerate((x, y, z)):
+            if d < i.ndim:
+                inside &= (c > i.xmin[d] + 2 * pl[lb][3][d]) & (c < i.xmax[d] - 2 * pl[lb][3][d])
+        assert not np.isnan(em.cons[lb]).any()
+        assert np.abs(em.cons[lb][0] - f)[inside].max() < 5e-14
