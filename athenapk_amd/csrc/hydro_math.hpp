@@ -47,8 +47,8 @@ APK_DEV double max2(double a, double b) { return fmax(a, b); }
 #endif
 // Parthenon SIGN(x) = (x < 0) ? -1 : 1 ; carried as a bool "is negative"
 APK_DEV bool neg(double x) { return x < 0.0; }
-// x > 0 with NaN -> false, decided on the bit pattern so that the default build's finite-math
-// assumption (-fno-honor-nans) cannot fold the NaN case away: a blown-up state must still be flagged
+// x > 0 with NaN -> false, decided on the bit pattern so that no fast-math assumption a build may
+// be given can fold the NaN case away: a blown-up state must still be flagged
 APK_DEV bool strictly_positive(double x) {
   const long long b = __double_as_longlong(x);
   return b > 0 && b <= 0x7ff0000000000000LL;
