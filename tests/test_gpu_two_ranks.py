@@ -50,7 +50,8 @@ CASES = {
     # 2-D: the donor-cell predictor has no single-kernel form there, so only the exchange before the
     # high-order stage is overlapped
     "ot_2d": ("orszag_tang",
-              ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "parthenon/meshblock/nx1=32", "parthenon/meshblock/nx2=32"],
+              ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "parthenon/meshblock/nx1=32", "parthenon/meshblock/nx2=32",
+               "hydro/first_order_flux_correct=false"],
               dict(fluid="glmmhd", recon="ppm", riemann="hlld", integrator="vl2", nx=(64, 64, 1), mb=(32, 32, 1), ng=3,
                    xmin=(-0.5, -0.5, -0.5), xmax=(0.5, 0.5, 0.5), cfl=0.4, gamma=1.666666666666667), "orszag_tang", {}, 6),
     # first-order flux correction: flux-array path, synchronous exchanges
