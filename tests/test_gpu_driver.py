@@ -753,3 +753,16 @@ def test_every_deck_runs_in_the_product_build_close_to_the_parity_build(deck):
         assert np.isfinite(a).all() and a[0].min() > 0
         for n in range(nh):
             assert np.abs(a[n] - b[n]).max() <= 1e-6 * max(np.abs(b[n]).max(), 1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("deck,extra", [("orszag_tang", []), ("lw_implode", []), ("field_loop", []), ("cpaw", []),
+                                        ("linear_wave3d", []), ("blast", []), ("blast_3d_amr", []),
+                                        ("kh-shear-lecoanet_2d", ["parthenon/time/tlim=1.0"])])
+def test_shipped_decks_run_to_their_time_limit(tmp_path, capsys, deck, extra):
+    """`python -m athenapk_amd -i <deck>` as shipped, product build, all the way to tlim (thousands of
+    cycles for some): no negative state, no NaN, the performance line at the end"""
+    from athenapk_amd import __main__ as cli
+    assert cli.main(["-i", deck, "-d", str(tmp_path)] + extra) == 0
+    out = capsys.readouterr().out
+    assert "zone-cycles/wallsecond" in out and "cycle=" in out
