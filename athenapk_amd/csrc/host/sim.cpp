@@ -671,10 +671,13 @@ int do_stage(apk_sim *s, int stage) {
     // (prim, u1) intact -- and test the new state the way FirstOrderFluxCorrect tests its trial
     // update.  No cell fails (the rule, away from strong shocks): done, with the result the
     // flux-array sequence would have produced bit for bit.  Otherwise that sequence runs after all.
-    // (3-D only: measured +82 % on 256^3 MHD PPM+HLLD; in 2-D the flux-array sequence is as fast.)
+    // The optimistic stage also does FillDerived (out of place: the old primitives are the fallback's
+    // input) and, in the last stage, the dt estimate, exactly like a stage without flux correction.
     bool done = false;
-    if (s->fused && pkg.first_order_flux_correct && g0 == 0.0 && !s->amr && !pkg.glmmhd_source_extended && s->mesh.ndim == 3 &&
+    if (s->fused && pkg.first_order_flux_correct && g0 == 0.0 && !s->amr && !pkg.glmmhd_source_extended && s->mesh.ndim >= 2 &&
         pkg.riemann != APK_RS_NONE && pkg.riemann != APK_RS_LLF) {
+      const bool fill = !(s->fmft && stage == s->nstages);
+      if (fill) SIM_TRY(s, ensure_spare_prim(s));
       apk_stage_args a{};
       a.cfg = cfg;
       a.eos = pkg.eos;
@@ -685,11 +688,24 @@ int do_stage(apk_sim *s, int stage) {
       a.dedner = (pkg.fluid == APK_FLUID_GLMMHD) ? 1 : 0;
       a.glmmhd_alpha = pkg.glmmhd_alpha;
       a.mindx = pkg.mindx;
+      a.fill_derived = fill ? 2 : 0;
+      a.estimate_dt = (fill && stage == s->nstages && pkg.calc_dt_hyp) ? 1 : 0;
       SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
       long long bad = 0;
       SIM_TRY(s, apk_count_unphysical(s->ctx, s->mu0(), pkg.fluid, &bad, s->stream));
       done = bad == 0;
-      if (!done) s->fofc_fallback_stages += 1;
+      if (done) {
+        if (fill) {
+          s->pcur = 1 - s->pcur;
+          fused_fill = true;
+        }
+        s->stage_dt_pending = a.estimate_dt != 0;
+      } else {
+        s->fofc_fallback_stages += 1;
+        // the ConsToPrim of the discarded result has latched negative-state flags: drop them
+        unsigned discard = 0;
+        if (fill) SIM_TRY(s, apk_poll_device_flags(s->ctx, &discard, s->stream));
+      }
     }
     if (!done) {
     SIM_TRY(s, ensure_flux_arrays(s));
