@@ -1095,19 +1095,29 @@ int apk_sim_amr_stats(const apk_sim *s, long long *refined, long long *derefined
   return APK_OK;
 }
 
-// Host logic of a regridding pass for given tags (+1 refine / -1 derefine / 0 per block of the
-// forest, global numbering): forest update, new distribution, new plans -- no field data is
-// touched, so this is for sims created with apk_sim_create_host_only (plan introspection, tests)
+// A regridding pass for GIVEN tags (+1 refine / -1 derefine / 0 per block of the forest, global
+// numbering; every rank passes the same array): forest update, new distribution, new plans and --
+// on a device sim -- the transfer of the state, ghost exchange and ConsToPrim on the new mesh
 int apk_sim_amr_apply_tags(apk_sim *s, const int *tags, int ntags, int *changed) {
-  if (!s || !s->amr || !s->host_only || !tags || ntags != (int)s->amr->leaves.size()) return APK_ERR_INVALID;
+  if (!s || !s->amr || !tags || ntags != (int)s->amr->leaves.size()) return APK_ERR_INVALID;
+  const std::vector<AmrLeaf> old = s->amr->leaves;
+  const AmrPartition old_part = s->amr_part;
+  bool ch = false;
   try {
-    const bool ch = amr_update_tree(s, std::vector<int>(tags, tags + ntags), true);
-    amr_sync_mesh(s);
-    amr_localize(s);
-    if (changed) *changed = ch ? 1 : 0;
+    ch = amr_update_tree(s, std::vector<int>(tags, tags + ntags), true);
+    if (s->host_only) {
+      amr_sync_mesh(s);
+      amr_localize(s);
+    }
   } catch (const std::exception &e) {
     return fail(s, APK_ERR_INVALID, e.what());
   }
+  if (!s->host_only && ch) {  // move the state as a regridding pass of the run does
+    SIM_TRY(s, amr_transfer(s, old, old_part));
+    SIM_TRY(s, exchange_ghosts(s));
+    SIM_TRY(s, fill_derived(s));
+  }
+  if (changed) *changed = ch ? 1 : 0;
   return APK_OK;
 }
 

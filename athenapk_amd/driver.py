@@ -380,6 +380,14 @@ class Simulation(_FmftHost, _MeshView):
     def fofc_fallback_stages(self):
         return self.lib.apk_sim_fofc_fallback_stages(self.h)
 
+    def apply_tags(self, tags):
+        """one regridding pass for given per-block tags (+1 / 0 / -1 for every block of the forest)"""
+        arr = (C.c_int * len(tags))(*[int(t) for t in tags])
+        ch = C.c_int(0)
+        self._check(self.lib.apk_sim_amr_apply_tags(self.h, arr, len(tags), C.byref(ch)))
+        self.refresh_info()
+        return bool(ch.value)
+
     def regrid(self):
         """one tag -> refine / derefine -> transfer pass; True if the mesh changed"""
         ch = C.c_int(0)

@@ -120,9 +120,10 @@ int apk_sim_block_level(const apk_sim *s, int lb);
 int apk_sim_amr_stats(const apk_sim *s, long long *refined, long long *derefined, int *max_level,
                       long long *zone_cycles);
 int apk_sim_regrid(apk_sim *s, int *changed);
-/* the host logic of a regridding pass for given per-block tags (+1 / 0 / -1, one per block of the
- * whole forest): forest update with 2:1 balance and derefine_count, new distribution, new plans.
- * Host-only sims only (no field data moves). */
+/* a regridding pass for given per-block tags (+1 / 0 / -1, one per block of the whole forest, the
+ * same array on every rank): forest update with 2:1 balance and derefine_count, new distribution,
+ * new plans; on a device sim also the transfer of the state (copy / prolongate / restrict), ghost
+ * exchange and ConsToPrim on the new mesh */
 int apk_sim_amr_apply_tags(apk_sim *s, const int *tags, int ntags, int *changed);
 /* device pointers of local block lb: field 0 = cons, 1 = prim, 2 = u1.cons */
 void *apk_sim_block_ptr(const apk_sim *sim, int lb, int field);

@@ -379,6 +379,61 @@ def test_kh_with_velocity_gradient_refinement():
     assert abs(m1[2]) < 1e-12                     # no net x2 momentum from a cosine mode
 
 
+@pytest.mark.parametrize("dims", [2, 3])
+def test_regridding_with_random_tags_moves_the_state_exactly(dims):
+    """ten regridding passes with random refine / derefine requests (derefine_count = 2) on a mesh
+    holding a linear function plus a random field: copies are exact, restriction and the
+    minmod prolongation are exact for the linear part and conservative for everything, so after
+    every pass each variable's volume integral is unchanged to round-off and the linear variable still
+    equals the function of the cell centres (away from the periodic seam, where its jump sits)"""
+    ov = ["parthenon/mesh/refinement=adaptive", "parthenon/mesh/numlevel=4", "parthenon/mesh/derefine_count=2",
+          "parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=8",
+          "refinement/threshold_pressure_gradient=1e9"]
+    ov += ["parthenon/mesh/nx3=16", "parthenon/meshblock/nx3=8"] if dims == 3 else ["parthenon/mesh/nx3=1", "parthenon/meshblock/nx3=1"]
+    s = _sim("blast", ov, strict=True).initialize()
+    rng = np.random.default_rng(40 + dims)
+    i = s.refresh_info()
+    ng = i.ng
+
+    def lin(lb, pl):
+        z, y, x = _cell_centres(s, lb, pl)
+        return 2.0 + 0.3 * x - 0.2 * y + (0.5 * z if dims == 3 else 0.0)
+
+    pl = placement(s)
+    for lb in range(i.nblocks_total):
+        u = s.read_block(lb)
+        u[0] = lin(lb, pl)
+        u[1:4] = rng.uniform(-1.0, 1.0, u[1:4].shape)
+        u[4] = 10.0 + rng.uniform(0.0, 1.0, u[4].shape)
+        s.write_block(lb, u)
+    s.exchange_ghosts()
+    s.fill_derived()
+    t0 = _totals(s)
+    sizes = []
+    for rnd in range(10):
+        n = s.refresh_info().nblocks_total
+        p_ref = 0.2 if rnd < 4 else 0.03
+        tags = rng.choice([1, 0, -1], size=n, p=[p_ref, 0.3, 0.7 - p_ref])
+        s.apply_tags(tags)
+        i = s.refresh_info()
+        sizes.append(i.nblocks_total)
+        t1 = _totals(s)
+        assert np.all(np.abs(t1 - t0) < 1e-12 * np.abs(t0).max())
+        pl = placement(s)
+        for lb in range(i.nblocks_total):
+            z, y, x = _cell_centres(s, lb, pl)
+            away = np.ones(x.shape, bool)
+            for d, c in enumerate((x, y, z)[:i.ndim]):
+                away &= (c > i.xmin[d] + 4 * pl[lb][3][d] * 2 ** pl[lb][0]) & (c < i.xmax[d] - 4 * pl[lb][3][d] * 2 ** pl[lb][0])
+            sl = (slice(ng, -ng) if i.mb[2] > 1 else slice(None), slice(ng, -ng), slice(ng, -ng))
+            got, want = s.read_block(lb)[0][sl], lin(lb, pl)[sl]
+            m = away[sl]
+            if m.any():
+                assert np.abs(got - want)[m].max() < 1e-13
+    assert max(sizes) > sizes[0] or sizes[0] > 16
+    assert s.amr_stats()[0] > 0 and s.amr_stats()[1] > 0
+
+
 def test_cli_runs_the_amr_deck(tmp_path, capsys):
     from athenapk_amd import __main__ as cli
     assert cli.main(["-i", "blast_3d_amr", "-d", str(tmp_path), "parthenon/time/tlim=0.01"]) == 0
