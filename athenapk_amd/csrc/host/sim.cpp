@@ -674,9 +674,12 @@ int do_stage(apk_sim *s, int stage) {
     // The optimistic stage also does FillDerived (out of place: the old primitives are the fallback's
     // input) and, in the last stage, the dt estimate, exactly like a stage without flux correction.
     bool done = false;
-    if (s->fused && pkg.first_order_flux_correct && g0 == 0.0 && !s->amr && !pkg.glmmhd_source_extended && s->mesh.ndim >= 2 &&
+    // (Refined meshes: the test sees the update before the coarse-fine flux correction, as
+    // FirstOrderFluxCorrect does in the reference's task order; the correction follows, and ConsToPrim
+    // stays the full pass after the exchange.)
+    if (s->fused && pkg.first_order_flux_correct && g0 == 0.0 && !pkg.glmmhd_source_extended && s->mesh.ndim >= 2 &&
         pkg.riemann != APK_RS_NONE && pkg.riemann != APK_RS_LLF) {
-      const bool fill = !(s->fmft && stage == s->nstages);
+      const bool fill = !(s->fmft && stage == s->nstages) && !s->amr;
       if (fill) SIM_TRY(s, ensure_spare_prim(s));
       apk_stage_args a{};
       a.cfg = cfg;
@@ -700,6 +703,11 @@ int do_stage(apk_sim *s, int stage) {
           fused_fill = true;
         }
         s->stage_dt_pending = a.estimate_dt != 0;
+        if (s->amr) {
+          SIM_TRY(s, ensure_flux_arrays(s));
+          const double psi_factor = a.dedner != 0 ? std::exp(-pkg.glmmhd_alpha * pkg.c_h * beta_dt / pkg.mindx) : 1.0;
+          SIM_TRY(s, amr_flux_fix(s, cfg, beta_dt, psi_factor));
+        }
       } else {
         s->fofc_fallback_stages += 1;
         // the ConsToPrim of the discarded result has latched negative-state flags: drop them

@@ -180,6 +180,31 @@ def test_fofc_scalars_and_ppm_on_a_refined_mesh():
         assert np.allclose(w[5], 1.0, atol=1e-12) and np.allclose(w[6], 0.5, atol=1e-12)
 
 
+def test_fofc_on_a_refined_mesh_optimistic_and_flux_array_paths_agree():
+    """first_order_flux_correct on a refined mesh: stages with gam0 = 0 run fused, are tested, get the
+    coarse-fine correction applied afterwards; `set_fused(False)` runs the reference's task order through
+    the flux arrays.  Same results to round-off (off-centre blast: no limiter ties), conservation on both"""
+    ov = SMR3 + ["hydro/first_order_flux_correct=true", "hydro/fluid=glmmhd", "hydro/riemann=hlld",
+                 "problem/blast/radius_outer=0.2", "problem/blast/radius_inner=0.1", "problem/blast/pressure_ratio=100",
+                 "problem/blast/x3_0=0.1", "problem/blast/x1_0=0.013", "problem/blast/x2_0=-0.021",
+                 "problem/blast/pressure_ambient=1.0"]
+    runs = []
+    for fused in (True, False):
+        s = _sim("blast", ov, strict=True)
+        s.set_fused(fused)
+        s.initialize()
+        t0 = _totals(s)
+        for _ in range(8):
+            s.step()
+        t1 = _totals(s)
+        assert abs(t1[0] - t0[0]) < 1e-13 * t0[0] and abs(t1[4] - t0[4]) < 1e-13 * t0[4]
+        runs.append((s.time, s.fofc_fallback_stages, [s.read_block(lb) for lb in range(s.refresh_info().nblocks_total)]))
+    assert abs(runs[0][0] - runs[1][0]) < 1e-14 and runs[0][1] == 0
+    ng = 2
+    for a, b in zip(runs[0][2], runs[1][2]):
+        assert np.abs(a - b)[:, ng:-ng, ng:-ng, ng:-ng].max() < 1e-12 * np.abs(b).max()
+
+
 def test_adaptive_blast_in_two_dimensions():
     ov = ["parthenon/mesh/refinement=adaptive", "parthenon/mesh/numlevel=3", "parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64",
           "parthenon/mesh/nx3=1", "parthenon/meshblock/nx1=16", "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=1",
