@@ -102,13 +102,13 @@ int apk_create(apk_ctx **out) {
     delete ctx;
     return APK_ERR_NO_DEVICE;
   }
-  if (hipMalloc(&ctx->d_flags, sizeof(unsigned)) != hipSuccess ||
+  if (hipMalloc(&ctx->d_flags, 2 * sizeof(unsigned)) != hipSuccess ||  // [0] latched, [1] trial stage
       hipMalloc(&ctx->d_u64, 16 * sizeof(unsigned long long)) != hipSuccess ||
       hipHostMalloc(&ctx->h_pinned, 256, hipHostMallocDefault) != hipSuccess) {
     apk_destroy(ctx);
     return APK_ERR_DEVICE;
   }
-  (void)hipMemset(ctx->d_flags, 0, sizeof(unsigned));
+  (void)hipMemset(ctx->d_flags, 0, 2 * sizeof(unsigned));
   (void)hipMemset(ctx->d_u64, 0, 16 * sizeof(unsigned long long));
   {
     const double huge = 1.7976931348623157e308;  // word 15: constant +max, the neutral element of the dt min
@@ -430,6 +430,25 @@ int apk_stage_dt_flags_read(apk_ctx *ctx, double cfl, double *dt_out, unsigned *
   std::memcpy(&m, h + 4, sizeof(m));
   *dt_out = cfl * m;  // hydro.cpp:909
   *flags = *hf;
+  return APK_OK;
+}
+
+namespace {
+__global__ void commit_trial_flags_kernel(unsigned *f) {
+  if (f[1]) atomicOr(f, f[1]);
+  f[1] = 0u;
+}
+}  // namespace
+
+int apk_trial_flags(apk_ctx *ctx, int keep, apk_stream_t stream) {
+  if (!ctx) return APK_ERR_INVALID;
+  hipStream_t s = as_stream(stream);
+  if (keep) {
+    hipLaunchKernelGGL(commit_trial_flags_kernel, dim3(1), dim3(1), 0, s, ctx->d_flags);
+    if (hipGetLastError() != hipSuccess) return set_err(ctx, APK_ERR_DEVICE, "apk_trial_flags: launch failed");
+  } else {
+    APK_HIP_TRY(ctx, hipMemsetAsync(ctx->d_flags + 1, 0, sizeof(unsigned), s));
+  }
   return APK_OK;
 }
 

@@ -33,7 +33,7 @@ int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
   sp.du = nullptr;
   sp.ctx = ctx;
   sp.eos = a.eos;
-  sp.flags = ctx->d_flags;
+  sp.flags = ctx->d_flags + (a.trial ? 1 : 0);
   sp.dt_bits = ctx->d_u64 + 4;  // word 4: min of the finishing sweep (apk_stage_dt_read)
   int extra = EXTRA_NONE;
   sp.prim_to_u1 = (a.fill_derived == 2) ? 1 : 0;

@@ -679,7 +679,10 @@ int do_stage(apk_sim *s, int stage) {
     // stays the full pass after the exchange.)
     if (s->fused && pkg.first_order_flux_correct && g0 == 0.0 && !pkg.glmmhd_source_extended && s->mesh.ndim >= 2 &&
         pkg.riemann != APK_RS_NONE && pkg.riemann != APK_RS_LLF) {
-      const bool fill = !(s->fmft && stage == s->nstages) && !s->amr;
+      // FillDerived inside the trial stage only while no floor / ceiling is active: those change the
+      // updated state before it is stored, and FirstOrderFluxCorrect tests the UNfloored trial
+      // update (hydro.cpp:1283-1306; floors only act in the ConsToPrim that follows the stage)
+      const bool fill = !(s->fmft && stage == s->nstages) && !s->amr && ghost_c2p_fusable(s);
       if (fill) SIM_TRY(s, ensure_spare_prim(s));
       apk_stage_args a{};
       a.cfg = cfg;
@@ -693,10 +696,12 @@ int do_stage(apk_sim *s, int stage) {
       a.mindx = pkg.mindx;
       a.fill_derived = fill ? 2 : 0;
       a.estimate_dt = (fill && stage == s->nstages && pkg.calc_dt_hyp) ? 1 : 0;
+      a.trial = 1;  // its ConsToPrim latches flags into the trial word: kept or dropped below
       SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
       long long bad = 0;
       SIM_TRY(s, apk_count_unphysical(s->ctx, s->mu0(), pkg.fluid, &bad, s->stream));
       done = bad == 0;
+      if (fill) SIM_TRY(s, apk_trial_flags(s->ctx, done ? 1 : 0, s->stream));
       if (done) {
         if (fill) {
           s->pcur = 1 - s->pcur;
@@ -710,9 +715,6 @@ int do_stage(apk_sim *s, int stage) {
         }
       } else {
         s->fofc_fallback_stages += 1;
-        // the ConsToPrim of the discarded result has latched negative-state flags: drop them
-        unsigned discard = 0;
-        if (fill) SIM_TRY(s, apk_poll_device_flags(s->ctx, &discard, s->stream));
       }
     }
     if (!done) {
@@ -790,6 +792,11 @@ int create_common(const char *deck, const char *const *overrides, int noverrides
              s->problem_id != "blast" && s->problem_id != "lw_implode" && s->problem_id != "cpaw" &&
              s->problem_id != "advection" && s->problem_id != "field_loop" && s->problem_id != "kh")
       throw std::runtime_error("unknown job/problem_id: " + s->problem_id);
+    // src/bvals/boundary_conditions_apk.hpp:47-50 (raised when the wall is first applied, i.e. after
+    // the problem generator's own checks): the wall only mirrors the normal momentum
+    for (int d = 0; d < 3; ++d)
+      if ((s->mesh.bc_in[d] == BC_REFLECT || s->mesh.bc_out[d] == BC_REFLECT) && s->pkg.fluid != APK_FLUID_EULER)
+        throw std::runtime_error("Reflecting boundary conditions for MHD need special treatment.");
   } catch (const std::exception &e) {
     if (errbuf && errlen) std::snprintf(errbuf, errlen, "%s", e.what());
     delete s;
@@ -1359,7 +1366,9 @@ int apk_sim_execute(apk_sim *s, const char *outdir, int *ncycles) {
       if (blk == "parthenon/output_defaults" || !s->pin.DoesParameterExist(blk, "file_type")) continue;
       if (s->pin.GetString(blk, "file_type") != "hst") continue;  // hdf5 / rst outputs are out of scope
       const std::string num = blk.substr(std::string("parthenon/output").size());
-      outs.push_back({std::string(outdir) + "/" + base + ".out" + num + ".hst", s->pin.GetReal(blk, "dt"), 0.0});
+      const double out_dt = s->pin.GetReal(blk, "dt");
+      if (!(out_dt > 0.0)) throw std::runtime_error("<" + blk + ">: dt must be positive for hst outputs");
+      outs.push_back({std::string(outdir) + "/" + base + ".out" + num + ".hst", out_dt, 0.0});
       if (s->pin.DoesParameterExist(blk, "data_format"))
         s->pin.ApplyOverride("parthenon/output_defaults/data_format=" + s->pin.GetString(blk, "data_format"));
     }

@@ -56,7 +56,7 @@ class StageArgs(C.Structure):
                 ("gam1", C.c_double), ("beta_dt", C.c_double), ("dedner", C.c_int),
                 ("glmmhd_alpha", C.c_double), ("mindx", C.c_double), ("fill_derived", C.c_int),
                 ("estimate_dt", C.c_int), ("phase", C.c_int), ("window", C.c_void_p),
-                ("window_rl", C.c_int), ("window_rows", C.c_int)]
+                ("window_rl", C.c_int), ("window_rows", C.c_int), ("trial", C.c_int)]
 
 
 class FmftBlock(C.Structure):
@@ -180,6 +180,7 @@ def _signatures():
         "apk_refine_plan_run": (i, [vp, vp, vp]),
         "apk_tag_blocks": (i, [vp, vp, i, d, d, C.POINTER(C.c_int), c_dp, vp]),
         "apk_poll_device_flags": (i, [vp, C.POINTER(C.c_uint), vp]),
+        "apk_trial_flags": (i, [vp, i, vp]),
         "apk_copy_plan_create": (i, [vp, C.POINTER(CopyRegion), i, pp]),
         "apk_copy_plan_destroy": (None, [vp]),
         "apk_copy_plan_run": (i, [vp, vp, vp]),

@@ -192,6 +192,11 @@ typedef struct apk_stage_args {
   int phase;
   const int *window;
   int window_rl, window_rows;
+  /* trial = 1: the caller may discard this stage's result (the optimistic stage of first-order
+   * flux correction): the negative-density / -pressure flags its FillDerived latches go to a
+   * separate trial word, which apk_trial_flags() merges into the latched word (keep = 1) or drops
+   * (keep = 0).  Flags latched by earlier kernels are never touched by a discarded stage. */
+  int trial;
 } apk_stage_args;
 int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
                     const apk_stage_args *args, apk_stream_t stream);
@@ -250,6 +255,10 @@ int apk_history(apk_ctx *ctx, const apk_pack *md, int fluid, double *out8,
 
 /* Reads-and-clears the device flag word (APK_FLAG_*).  Synchronises `stream`. */
 int apk_poll_device_flags(apk_ctx *ctx, unsigned *flags, apk_stream_t stream);
+/* commit (keep = 1) or drop (keep = 0) the flags of stages run with apk_stage_args.trial = 1;
+ * asynchronous on `stream`.  Mirrors the reference, where the FOFC trial update
+ * (hydro.cpp:1283-1306) never reaches ConservedToPrimitive unless it is accepted. */
+int apk_trial_flags(apk_ctx *ctx, int keep, apk_stream_t stream);
 
 /* ---- ghost zones (the step either side of the path; Parthenon bvals, call sites
  *      src/hydro/hydro_driver.cpp:506,567-568) ------------------------------------------ */
