@@ -69,6 +69,12 @@ APK_DEV void face_states_any(const double *c, int64_t st, double dx, int var, do
 // what the finishing sweep does besides the RK update + Dedner source
 enum { EXTRA_NONE = 0, EXTRA_C2P = 1, EXTRA_C2P_DT = 2 };
 
+// x1 sweep (lanes along the flattened rows): first lane of a wave that retires a cell and the
+// number of cells a wave retires.  Lane l needs the L state of lane l-1 and the flux of lane l+1;
+// with PPM lane l-1's state in turn needs the interface value of lane l-2 (face sharing).
+constexpr int x1_first_lane(int recon) { return recon == APK_RC_PPM ? 2 : 1; }
+constexpr int x1_cells_per_wave(int recon) { return 63 - x1_first_lane(recon); }
+
 // ---- DPP wave shifts (gfx9: wave_shr:1 = 0x138, wave_shl:1 = 0x130) ------------------------
 APK_DEV double wave_shr1(double x) {  // lane l receives lane l-1 (lane 0 keeps its own)
   int lo = __double2loint(x), hi = __double2hiint(x);
@@ -173,13 +179,15 @@ fused_x1_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_plane) {
     i0 = w[0], rl = w[1], lo = w[2], hi = w[3];
     if (rl <= 0) return;  // nothing to do in this block
   }
+  // lanes that retire a cell: FIRST .. 62 (x1_cells_per_wave of them); waves overlap accordingly
+  constexpr int FIRST = x1_first_lane(RECON), CPW = x1_cells_per_wave(RECON);
   const int64_t run = (int64_t)u0.nx2 * rl;
-  const int64_t t = (int64_t)wave * 62 + lane - 1;
-  if ((int64_t)wave * 62 - 1 >= run) return;  // whole wave beyond this block's run
+  const int64_t t = (int64_t)wave * CPW + lane - FIRST;
+  if ((int64_t)wave * CPW - FIRST >= run) return;  // whole wave beyond this block's run
   const int row = (int)((t >= 0 ? t : 0) / rl);
   const int i = i0 + (int)(t - (int64_t)row * rl);
   const bool in_run = (t >= 0) && (t < run);
-  const bool do_recon = in_run && (i >= u0.is - 1) && (i <= u0.ie + 1);
+  const bool do_recon = in_run && (i >= u0.is - FIRST) && (i <= u0.ie + 1);
   const int64_t cell = k * u0.sk + (int64_t)(u0.js + row) * u0.sj + i;
   const double dx = b0.dx[0];
 
@@ -199,7 +207,16 @@ fused_x1_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_plane) {
         qp2 = c[2];
       }
     }
-    reconstruct<RECON>(qm2, qm1, q0, qp1, qp2, dx, n, qln[n], qrn[n]);
+    if constexpr (RECON == APK_RC_PPM) {
+      // every limited interface value once: the lane computes the one above its cell and receives
+      // the one below from the lane on its left (see ppm_interface); lane 0 has no left neighbour
+      // and produces no valid state, which is why PPM waves retire lanes 2..62
+      const double face_p = ppm_interface(qm1, q0, qp1, qp2);
+      const double face_m = wave_shr1(face_p);
+      ppm_cell(qm2, qm1, q0, qp1, qp2, face_m, face_p, qln[n], qrn[n]);
+    } else {
+      reconstruct<RECON>(qm2, qm1, q0, qp1, qp2, dx, n, qln[n], qrn[n]);
+    }
   }
   // face i: L state from the lane on the left
   double wl[NV], wr[NV], f[NV];
@@ -219,7 +236,7 @@ fused_x1_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_plane) {
     if (s == 0) fup0 = fup;
     du[perm<1>(s)] = (a1 * fup - a1 * f[s]);
   }
-  const bool do_cell = in_run && (lane >= 1) && (lane <= 62) && (i >= lo) && (i <= hi);
+  const bool do_cell = in_run && (lane >= FIRST) && (lane <= 62) && (i >= lo) && (i <= hi);
   if (!do_cell) return;
   if (sp.mflux) {  // mass flux through both x1 faces of this cell (neighbours store the same values)
     double *m = sp.mflux + ((int64_t)0 * u0.nblocks + b) * u0.sn + cell;
@@ -320,6 +337,15 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
     wl_prev[q] = 0.0;
     f_prev[q] = 0.0;
   }
+  // PPM: the limited interface value above cell c is the one below cell c+1 (see ppm_interface):
+  // every interface is evaluated once and carried to the next iteration
+  double face_carry[NV];
+  if constexpr (RECON == APK_RC_PPM) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n)
+      face_carry[n] = ppm_interface(ring[(0 * NV + n) * 64 + lane], ring[(1 * NV + n) * 64 + lane],
+                                    ring[(2 * NV + n) * 64 + lane], ring[(3 * NV + n) * 64 + lane]);
+  }
 
   int slot0 = 0;  // slot holding row c-H
   for (; c <= e + 1; ++c) {
@@ -350,7 +376,13 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
         const double a1 = ring[(((slot0 + 1) & 3) * NV + n) * 64 + lane];
         const double a2 = ring[(((slot0 + 2) & 3) * NV + n) * 64 + lane];
         const double a3 = ring[(((slot0 + 3) & 3) * NV + n) * 64 + lane];
-        reconstruct<RECON>(a0, a1, a2, a3, Pn[n], dx, n, qln[n], qrn[n]);
+        if constexpr (RECON == APK_RC_PPM) {
+          const double face_p = ppm_interface(a1, a2, a3, Pn[n]);
+          ppm_cell(a0, a1, a2, a3, Pn[n], face_carry[n], face_p, qln[n], qrn[n]);
+          face_carry[n] = face_p;
+        } else {
+          reconstruct<RECON>(a0, a1, a2, a3, Pn[n], dx, n, qln[n], qrn[n]);
+        }
       }
       // The 9 reconstructions are independent; left alone the scheduler interleaves them all and
       // the weighted schemes (WENO-Z: 5 divisions and ~40 live values per call) spill.  An empty
@@ -851,7 +883,8 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
   const int64_t run = (int64_t)u0.nx2 * u0.ni;
   // a windowed x1 sweep (phase 1) flattens at most window_rl columns per row
   const int64_t run1 = sp.window ? (int64_t)u0.nx2 * sp.window_rl : run;
-  const int wpp = (int)((run1 + 61) / 62);
+  constexpr int cpw1 = x1_cells_per_wave(RECON);
+  const int wpp = (int)((run1 + cpw1 - 1) / cpw1);
   const dim3 g1((wpp + 3) / 4, u0.nx3 * u0.nblocks, 1);
   if (sp.phase != 0) {
     // split stage: where the x1 sweep is its own, non-finishing kernel, or the single-kernel

@@ -408,8 +408,10 @@ int build_windows(apk_sim *s) {
     }
     // x1 sweep of a high-order stage: everything farther than nghost from a late x1 face, then the slabs
     put(x1[0], lb, 0, m.ni, m.is + W * L[0][0], m.ie - W * L[0][1], m.js, m.je, m.ks, m.ke);
-    put(x1[1], lb, m.is - 1, L[0][0] ? W + 2 : 0, m.is, m.is + W - 1, m.js, m.je, m.ks, m.ke);
-    put(x1[2], lb, m.ie - W, L[0][1] ? W + 2 : 0, m.ie - W + 1, m.ie, m.js, m.je, m.ks, m.ke);
+    // (two columns of margin on the left: the L state of the cell below the first retired one needs, with
+    // PPM's shared interface values, the lane below it as well -- x1_first_lane in fused_kernel.hpp)
+    put(x1[1], lb, m.is - 2, L[0][0] ? W + 3 : 0, m.is, m.is + W - 1, m.js, m.je, m.ks, m.ke);
+    put(x1[2], lb, m.ie - W - 1, L[0][1] ? W + 3 : 0, m.ie - W + 1, m.ie, m.js, m.je, m.ks, m.ke);
     // single-kernel donor-cell stage (3-D): everything but the one-cell layers next to late
     // faces, then disjoint slabs: z (whole planes), y (rows of the remaining planes), x (columns)
     const int lo[3] = {S[0] + L[0][0], S[1] + L[1][0], S[2] + L[2][0]};

@@ -37,6 +37,56 @@ enum { IV1 = 1, IV2 = 2, IV3 = 3, IPR = 4 };
 #endif
 
 APK_DEV double sqr(double x) { return x * x; }
+
+// ---- square roots and reciprocals ---------------------------------------------------------------
+// The parity build evaluates the reference's IEEE operations.  In the product build hipcc expands
+// an fp64 sqrt into 18 instructions around one v_rsq_f64 (range scaling for denormals, class
+// checks, a Goldschmidt step and two residual corrections) and a divide into 8 around one
+// v_rcp_f64, and the transcendental unit issues at a quarter of the fp64 rate (measured: 16 cycles
+// per wave instruction against 4.3, tools/ubench): the 14 divides and 6 roots of one HLLD solve
+// were ~40 % of its issue time.  The forms below keep the same Newton / Goldschmidt refinement
+// (results within 1-2 ulp) without the range scaling -- the arguments here are densities,
+// pressures and squared speeds, never denormal -- and hand out the by-products (1/sqrt(x) comes
+// for free with sqrt(x); several quotients share one reciprocal).
+#ifdef APK_FP_STRICT
+APK_DEV double fsqrt(double x) { return sqrt(x); }
+APK_DEV double frcp(double x) { return 1.0 / x; }
+#else
+APK_DEV void fsqrt_rsqrt(double x, double &root, double &inv_root) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  d = fma(-g, g, x);
+  g = fma(d, h, g);
+  const double rs = h + h;
+  const double e = fma(-g, rs, 1.0);
+  root = g;
+  inv_root = fma(rs, e, rs);
+}
+APK_DEV double fsqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  d = fma(-g, g, x);
+  g = fma(d, h, g);
+  return (x == 0.0) ? 0.0 : g;  // rsq(0) = inf
+}
+APK_DEV double frcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+#endif
 #ifdef APK_FP_STRICT
 APK_DEV double min2(double a, double b) { return (b < a) ? b : a; }  // std::min
 APK_DEV double max2(double a, double b) { return (a < b) ? b : a; }  // std::max
@@ -86,44 +136,50 @@ APK_DEV void plm(double qm1, double q0, double qp1, double &ql, double &qr) {
   qr = q0 - slope;
 }
 
-// one interface of PPM step 2a (src/recon/ppm_simple.hpp:66-98); the reference states it
-// twice, for (q_im1,q_i) and (q_i,q_ip1).
-APK_DEV double ppm_limit_interface(double qlo, double qhi, double face, double d2lo,
-                                   double d2hi) {
-  constexpr double C2 = 1.25;
-  const double below = face - qlo;
-  const double above = qhi - face;
-  // The limited value only replaces `face` at a local extremum (CD eq 84); evaluating it lazily
-  // changes no result and lets a wave without extrema skip the limiter and its division.
+// PPM, split so that a sweep evaluates every interface ONCE (src/recon/ppm_simple.hpp:39-162 computes
+// the limited interface value q_{i+1/2} twice, as "qr_ip1 side" of cell i and as "ql_i side" of cell
+// i+1, from the same four cells with the same expressions):
+//   ppm_interface(q_{i-1}, q_i, q_{i+1}, q_{i+2})  steps 1 + 2a for the interface between cells i and i+1
+//       (:50-98); written from the perspective of cell i ("face_p"); from the perspective of cell
+//       i+1 the reference's "face_m" expressions dd_m / dd_c / d2_m / d2_c are the SAME operations
+//       on the same operands (dd_m' = 0.5*da' + 0.5*(qm1'-qm2') = 0.5*db + 0.5*da = dd_c, ...), so
+//       the value is bit-identical whichever cell asks for it;
+//   ppm_cell(...)  steps 3 + 4 for one cell given its two limited interface values (:100-162).
+// A march keeps face_p of the cell it just reconstructed as face_m of the next one; the x1 sweep
+// passes it one lane to the right.
+APK_DEV double ppm_interface(double qm1, double q0, double qp1, double qp2) {
+#ifdef APK_FP_STRICT
+  const double da = q0 - qm1;
+  const double db = qp1 - q0;
+  const double dd_c = 0.5 * db + 0.5 * da;
+  const double dd_p = 0.5 * (qp2 - qp1) + 0.5 * db;
+  const double face = 0.5 * (q0 + qp1) + APK_DIV6(dd_c - dd_p);
+#else
+  // the same fourth-order value, (7 (q_i + q_i+1) - (q_i-1 + q_i+2)) / 12 (CW eq 1.6), in 4
+  // operations instead of 10; differs from the parity build's grouping in the last bits
+  const double face = (7.0 / 12.0) * (q0 + qp1) - (1.0 / 12.0) * (qm1 + qp2);
+#endif
+  // step 2a (:66-98): the limited value only replaces `face` at a local extremum (CD eq 84), so
+  // the second differences and the limiter (one division) are evaluated inside that branch only
+  const double below = face - q0;
+  const double above = qp1 - face;
   if (below * above < 0.0) {
-    const double d2f = 3.0 * (qlo + qhi - 2.0 * face);
-    const bool s = neg(d2f);
-    const bool agree = (s == neg(d2lo)) && (s == neg(d2hi));
-    const double mag = min2(C2 * fabs(d2lo), min2(C2 * fabs(d2hi), fabs(d2f)));
-    const double lim = agree ? with_sign(s, mag) : 0.0;
-    return 0.5 * (qlo + qhi) - APK_DIV6(lim);
+    constexpr double C2 = 1.25;
+    const double d2_c = qm1 + qp1 - 2.0 * q0;
+    const double d2_p = q0 + qp2 - 2.0 * qp1;
+    const double d2f = 3.0 * (q0 + qp1 - 2.0 * face);
+    const bool sg = neg(d2f);
+    const bool agree = (sg == neg(d2_c)) && (sg == neg(d2_p));
+    const double mag = min2(C2 * fabs(d2_c), min2(C2 * fabs(d2_p), fabs(d2f)));
+    const double lim = agree ? with_sign(sg, mag) : 0.0;
+    return 0.5 * (q0 + qp1) - APK_DIV6(lim);
   }
   return face;
 }
 
-// src/recon/ppm_simple.hpp:39-162
-APK_DEV void ppm(double qm2, double qm1, double q0, double qp1, double qp2, double &ql,
-                 double &qr) {
+APK_DEV void ppm_cell(double qm2, double qm1, double q0, double qp1, double qp2, double face_m,
+                      double face_p, double &ql, double &qr) {
   constexpr double C2 = 1.25;
-  const double da = q0 - qm1;
-  const double db = qp1 - q0;
-  const double dd_m = 0.5 * da + 0.5 * (qm1 - qm2);
-  const double dd_c = 0.5 * db + 0.5 * da;
-  const double dd_p = 0.5 * (qp2 - qp1) + 0.5 * db;
-  double face_m = 0.5 * (qm1 + q0) + APK_DIV6(dd_m - dd_c);
-  double face_p = 0.5 * (q0 + qp1) + APK_DIV6(dd_c - dd_p);
-
-  const double d2_m = qm2 + q0 - 2.0 * qm1;
-  const double d2_c = qm1 + qp1 - 2.0 * q0;
-  const double d2_p = q0 + qp2 - 2.0 * qp1;
-  face_m = ppm_limit_interface(qm1, q0, face_m, d2_m, d2_c);
-  face_p = ppm_limit_interface(q0, qp1, face_p, d2_c, d2_p);
-
   const double dminus = q0 - face_m;
   const double dplus = face_p - q0;
   const double ext_a = dminus * dplus;
@@ -131,8 +187,11 @@ APK_DEV void ppm(double qm2, double qm1, double q0, double qp1, double qp2, doub
 
   double r = face_m, l = face_p;
   if (ext_a <= 0.0 || ext_b <= 0.0) {
-    // local extremum: CS limiter on the parabola (steps 4 of ppm_simple.hpp:104-150).  The
-    // limited second-derivative ratio is only consumed here, so it is only computed here.
+    // local extremum: CS limiter on the parabola (steps 4 of ppm_simple.hpp:104-150).  The second
+    // differences and the limited ratio are only consumed here, so they are only computed here.
+    const double d2_m = qm2 + q0 - 2.0 * qm1;
+    const double d2_c = qm1 + qp1 - 2.0 * q0;
+    const double d2_p = q0 + qp2 - 2.0 * qp1;
     const double d2_face = 6.0 * (face_m + face_p - 2.0 * q0);
     const bool s = neg(d2_m);
     const bool agree = (s == neg(d2_c)) && (s == neg(d2_p)) && (s == neg(d2_face));
@@ -152,6 +211,14 @@ APK_DEV void ppm(double qm2, double qm1, double q0, double qp1, double qp2, doub
   }
   ql = l;
   qr = r;
+}
+
+// src/recon/ppm_simple.hpp:39-162, one cell on its own (flux-array kernels, passive scalars)
+APK_DEV void ppm(double qm2, double qm1, double q0, double qp1, double qp2, double &ql,
+                 double &qr) {
+  const double face_m = ppm_interface(qm2, qm1, q0, qp1);
+  const double face_p = ppm_interface(qm1, q0, qp1, qp2);
+  ppm_cell(qm2, qm1, q0, qp1, qp2, face_m, face_p, ql, qr);
 }
 
 // src/recon/wenoz_simple.hpp:28-81
@@ -271,14 +338,22 @@ APK_DEV void reconstruct(double qm2, double qm1, double q0, double qp1, double q
 // EOS helpers
 // ======================================================================================
 // src/eos/adiabatic_hydro.hpp:43-45
-APK_DEV double sound_speed(double gamma, double d, double p) { return sqrt(gamma * p / d); }
+APK_DEV double sound_speed(double gamma, double d, double p) { return fsqrt(gamma * p / d); }
 // src/eos/adiabatic_glmmhd.hpp:47-54
 APK_DEV double fast_speed(double gamma, double d, double p, double bx, double by, double bz) {
   const double asq = gamma * p;
   const double ct2 = by * by + bz * bz;
   const double qsq = bx * bx + ct2 + asq;
   const double tmp = bx * bx + ct2 - asq;
+#ifdef APK_FP_STRICT
   return sqrt(0.5 * (qsq + sqrt(tmp * tmp + 4.0 * asq * ct2)) / d);
+#else
+  // sqrt(x / d) = x / sqrt(x d): one rsq instead of a divide and a root
+  const double x = 0.5 * (qsq + fsqrt(tmp * tmp + 4.0 * asq * ct2));
+  double root, inv_root;
+  fsqrt_rsqrt(x * d, root, inv_root);
+  return x * inv_root;
+#endif
 }
 
 // ======================================================================================
@@ -294,8 +369,8 @@ APK_DEV void hydro_hlle(const double (&wl)[NHYDRO], const double (&wr)[NHYDRO], 
                         double (&f)[NHYDRO]) {
   const double gm1 = gamma - 1.0;
   const double igm1 = 1.0 / gm1;
-  const double sdl = sqrt(wl[IDN]);
-  const double sdr = sqrt(wr[IDN]);
+  const double sdl = fsqrt(wl[IDN]);
+  const double sdr = fsqrt(wr[IDN]);
   const double isum = 1.0 / (sdl + sdr);
   const double roe_v1 = (sdl * wl[IV1] + sdr * wr[IV1]) * isum;
   const double roe_v2 = (sdl * wl[IV2] + sdr * wr[IV2]) * isum;
@@ -306,7 +381,7 @@ APK_DEV void hydro_hlle(const double (&wl)[NHYDRO], const double (&wr)[NHYDRO], 
   const double cl = sound_speed(gamma, wl[IDN], wl[IPR]);
   const double cr = sound_speed(gamma, wr[IDN], wr[IPR]);
   const double q = hroe - 0.5 * (sqr(roe_v1) + sqr(roe_v2) + sqr(roe_v3));
-  const double a = (q < 0.0) ? 0.0 : sqrt(gm1 * q);
+  const double a = (q < 0.0) ? 0.0 : fsqrt(gm1 * q);
   const double al = min2((roe_v1 - a), (wl[IV1] - cl));
   const double ar = max2((roe_v1 + a), (wr[IV1] + cr));
   const double bp = ar > 0.0 ? ar : kTiny;
@@ -346,10 +421,10 @@ APK_DEV void hydro_hllc(const double (&wl)[NHYDRO], const double (&wr)[NHYDRO], 
   const double pmid = .5 * (wl[IPR] + wr[IPR] + (wl[IV1] - wr[IV1]) * rhoa * ca);
   const double ql = (pmid <= wl[IPR])
                         ? 1.0
-                        : sqrt(1.0 + (gamma + 1) / (2 * gamma) * (pmid / wl[IPR] - 1.0));
+                        : fsqrt(1.0 + (gamma + 1) / (2 * gamma) * (pmid / wl[IPR] - 1.0));
   const double qr = (pmid <= wr[IPR])
                         ? 1.0
-                        : sqrt(1.0 + (gamma + 1) / (2 * gamma) * (pmid / wr[IPR] - 1.0));
+                        : fsqrt(1.0 + (gamma + 1) / (2 * gamma) * (pmid / wr[IPR] - 1.0));
   const double al = wl[IV1] - cl * ql;
   const double ar = wr[IV1] + cr * qr;
   const double bp = ar > 0.0 ? ar : (kTiny);
@@ -438,8 +513,8 @@ APK_DEV void glmmhd_hlle(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD
   f[IB1] = psii;
   f[IPS] = sqr(c_h) * bxi;
 
-  const double sdl = sqrt(wl[IDN]);
-  const double sdr = sqrt(wr[IDN]);
+  const double sdl = fsqrt(wl[IDN]);
+  const double sdr = fsqrt(wr[IDN]);
   const double isum = 1.0 / (sdl + sdr);
   const double roe_d = sdl * sdr;
   const double roe_v1 = (sdl * wl[IV1] + sdr * wr[IV1]) * isum;
@@ -467,9 +542,9 @@ APK_DEV void glmmhd_hlle(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD
   const double ct2 = bt_starsq / roe_d;
   const double tsum = vaxsq + ct2 + twid_asq;
   const double tdif = vaxsq + ct2 - twid_asq;
-  const double cf2_cs2 = sqrt(tdif * tdif + 4.0 * twid_asq * ct2);
+  const double cf2_cs2 = fsqrt(tdif * tdif + 4.0 * twid_asq * ct2);
   const double cfsq = 0.5 * (tsum + cf2_cs2);
-  const double a = sqrt(cfsq);
+  const double a = fsqrt(cfsq);
   const double al = min2((roe_v1 - a), (wl[IV1] - cl));
   const double ar = max2((roe_v1 + a), (wr[IV1] + cr));
   const double bp = ar > 0.0 ? ar : 0.0;  // MHD HLLE: 0.0 (:134-135)
@@ -533,29 +608,27 @@ APK_DEV void hlld_side_flux(const double (&w)[NGLMMHD], const Cons1D &u, double 
   fx.by = u.by * w[IV1] - bxi * w[IV2];
   fx.bz = u.bz * w[IV1] - bxi * w[IV3];
 }
-// star state of one side, eqns (39),(43)-(48) of M&K (:187-250); ust.d is set by the caller
-APK_DEV void hlld_star_side(const double (&w)[NGLMMHD], const Cons1D &u, double sd, double sdm,
-                            double sdm_inv, double sm, double pt, double ptst, double bxi,
-                            double bxsq, double ust_d_inv, Cons1D &ust, double &vbst) {
-  ust.mx = ust.d * sm;
+// true if the predicate holds in any active lane of the wave (scalar branch condition)
+APK_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
+// transverse components of the star state of one side, eqns (44)-(47) of M&K (:193-211, :225-243);
+// ust.d is set by the caller
+APK_DEV void hlld_star_transverse(const double (&w)[NGLMMHD], const Cons1D &u, double sd, double sdm,
+                                  double ptst, double bxi, double bxsq, Cons1D &ust) {
   const double denom = u.d * sd * sdm - bxsq;
-  if (fabs(denom) < (kHlldSmall)*ptst) {
-    ust.my = ust.d * w[IV2];
-    ust.mz = ust.d * w[IV3];
-    ust.by = u.by;
-    ust.bz = u.bz;
-  } else {
-    double tmp = bxi * (sd - sdm) / denom;
-    ust.my = ust.d * (w[IV2] - u.by * tmp);
-    ust.mz = ust.d * (w[IV3] - u.bz * tmp);
-    tmp = (u.d * sqr(sd) - bxsq) / denom;
-    ust.by = u.by * tmp;
-    ust.bz = u.bz * tmp;
-  }
-  vbst = (ust.mx * bxi + (ust.my * ust.by + ust.mz * ust.bz)) * ust_d_inv;
-  ust.e = (sd * u.e - pt * w[IV1] + ptst * sm +
-           bxi * (w[IV1] * bxi + (w[IV2] * u.by + w[IV3] * u.bz) - vbst)) *
-          sdm_inv;
+#ifdef APK_FP_STRICT
+  const double t1 = bxi * (sd - sdm) / denom;
+  const double t2 = (u.d * sqr(sd) - bxsq) / denom;
+#else
+  const double inv = frcp(denom);
+  const double t1 = bxi * (sd - sdm) * inv;
+  const double t2 = (u.d * sqr(sd) - bxsq) * inv;
+#endif
+  const bool degenerate = fabs(denom) < (kHlldSmall)*ptst;
+  ust.my = degenerate ? ust.d * w[IV2] : ust.d * (w[IV2] - u.by * t1);
+  ust.mz = degenerate ? ust.d * w[IV3] : ust.d * (w[IV3] - u.bz * t1);
+  ust.by = degenerate ? u.by : u.by * t2;
+  ust.bz = degenerate ? u.bz : u.bz * t2;
 }
 // a <- s * (a - b)  (:297-327)
 APK_DEV void hlld_jump(Cons1D &a, const Cons1D &b, double s) {
@@ -567,7 +640,17 @@ APK_DEV void hlld_jump(Cons1D &a, const Cons1D &b, double s) {
   a.by = s * (a.by - b.by);
   a.bz = s * (a.bz - b.bz);
 }
+APK_DEV double pick(bool left, double l, double r) { return left ? l : r; }
 
+// HLLD (glmmhd_hlld.hpp:39-396).  The reference evaluates both star energies, both physical
+// fluxes and all four wave jumps for every face and then picks one of six sums.  A lane's flux
+// is built from ONE side of the contact only (left: F_L [+ jump over s0 [+ jump over s1]],
+// right: F_R [+ jump over s4 [+ jump over s3]]), so the side is chosen first -- from the same
+// comparisons in the same order -- the operands of that side are selected per lane, and the
+// side-specific part (physical flux, star energy, two jumps) is evaluated once.  What both sides
+// need (wave speeds, transverse star components: the double-star states mix them) is computed for
+// both.  Every value that reaches the result comes from the reference's expressions in the
+// reference's order: bit-identical in the parity build.
 APK_DEV void glmmhd_hlld(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD],
                          double gamma, double c_h, double (&f)[NGLMMHD]) {
   const double gm1 = gamma - 1.0;
@@ -578,7 +661,7 @@ APK_DEV void glmmhd_hlld(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD
   f[IPS] = sqr(c_h) * bxi;
   const double bxsq = bxi * bxi;
 
-  Cons1D ul, ur, fl, fr;
+  Cons1D ul, ur;
   double pbl, pbr;
   hlld_side_state(wl, igm1, bxsq, ul, pbl);
   hlld_side_state(wr, igm1, bxsq, ur, pbr);
@@ -591,17 +674,16 @@ APK_DEV void glmmhd_hlld(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD
 
   const double ptl = wl[IPR] + pbl;
   const double ptr = wr[IPR] + pbr;
-  hlld_side_flux(wl, ul, ptl, bxi, bxsq, fl);
-  hlld_side_flux(wr, ur, ptr, bxi, bxsq, fr);
 
   const double sdl = s0 - wl[IV1];
   const double sdr = s4 - wr[IV1];
   const double s2 = (sdr * ur.mx - sdl * ul.mx + (ptl - ptr)) / (sdr * ur.d - sdl * ul.d);
   const double sdml = s0 - s2;
   const double sdmr = s4 - s2;
+  Cons1D ulst, urst;
+#ifdef APK_FP_STRICT
   const double sdml_inv = 1.0 / sdml;
   const double sdmr_inv = 1.0 / sdmr;
-  Cons1D ulst, urst, uldst, urdst;
   ulst.d = ul.d * sdl * sdml_inv;
   urst.d = ur.d * sdr * sdmr_inv;
   const double ulst_d_inv = 1.0 / ulst.d;
@@ -610,95 +692,122 @@ APK_DEV void glmmhd_hlld(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD
   const double sqrtdr = sqrt(urst.d);
   const double s1 = s2 - fabs(bxi) / sqrtdl;
   const double s3 = s2 + fabs(bxi) / sqrtdr;
+#else
+  // one reciprocal for both 1/(s0 - s2) and 1/(s4 - s2); sqrt(d*), 1/sqrt(d*) and 1/d* from one rsq
+  const double inv_prod = frcp(sdml * sdmr);
+  const double sdml_inv = sdmr * inv_prod;
+  const double sdmr_inv = sdml * inv_prod;
+  ulst.d = ul.d * sdl * sdml_inv;
+  urst.d = ur.d * sdr * sdmr_inv;
+  double sqrtdl, sqrtdr, rsl, rsr;
+  fsqrt_rsqrt(ulst.d, sqrtdl, rsl);
+  fsqrt_rsqrt(urst.d, sqrtdr, rsr);
+  const double ulst_d_inv = rsl * rsl;
+  const double urst_d_inv = rsr * rsr;
+  const double s1 = s2 - fabs(bxi) * rsl;
+  const double s3 = s2 + fabs(bxi) * rsr;
+#endif
 
   const double ptstl = ptl + ul.d * sdl * (s2 - wl[IV1]);
   const double ptstr = ptr + ur.d * sdr * (s2 - wr[IV1]);
   const double ptst = 0.5 * (ptstr + ptstl);
 
-  double vbstl, vbstr;
-  hlld_star_side(wl, ul, sdl, sdml, sdml_inv, s2, ptl, ptst, bxi, bxsq, ulst_d_inv, ulst, vbstl);
-  hlld_star_side(wr, ur, sdr, sdmr, sdmr_inv, s2, ptr, ptst, bxi, bxsq, urst_d_inv, urst, vbstr);
+  // which of the six sums the lane returns (:330-387), decided before anything side-specific:
+  //   s0 >= 0: F_L | s4 <= 0: F_R | s1 >= 0: F_L + j0 | s2 >= 0: F_L + j0 + j1 | s3 > 0: F_R + j4 + j3 | F_R + j4
+  const bool c0 = s0 >= 0.0, c4 = s4 <= 0.0, c1 = s1 >= 0.0, c2 = s2 >= 0.0, c3 = s3 > 0.0;
+  const bool fan = !c0 && !c4;
+  const bool left = c0 || (fan && (c1 || c2));
+  const bool outer = c0 || c4;                        // physical flux alone
+  const bool with_dstar = fan && !c1 && (c2 || c3);   // the jump across the Alfven wave takes part
 
-  if (0.5 * bxsq < (kHlldSmall)*ptst) {
-    uldst = ulst;
-    urdst = urst;
-  } else {
+  hlld_star_transverse(wl, ul, sdl, sdml, ptst, bxi, bxsq, ulst);
+  hlld_star_transverse(wr, ur, sdr, sdmr, ptst, bxi, bxsq, urst);
+
+  // ---- operands of the lane's side
+  double w1, w2, w3;
+  Cons1D u, ust;
+  w1 = pick(left, wl[IV1], wr[IV1]);
+  w2 = pick(left, wl[IV2], wr[IV2]);
+  w3 = pick(left, wl[IV3], wr[IV3]);
+  u.d = pick(left, ul.d, ur.d);
+  u.mx = pick(left, ul.mx, ur.mx);
+  u.my = pick(left, ul.my, ur.my);
+  u.mz = pick(left, ul.mz, ur.mz);
+  u.e = pick(left, ul.e, ur.e);
+  u.by = pick(left, ul.by, ur.by);
+  u.bz = pick(left, ul.bz, ur.bz);
+  ust.d = pick(left, ulst.d, urst.d);
+  ust.my = pick(left, ulst.my, urst.my);
+  ust.mz = pick(left, ulst.mz, urst.mz);
+  ust.by = pick(left, ulst.by, urst.by);
+  ust.bz = pick(left, ulst.bz, urst.bz);
+  const double pt = pick(left, ptl, ptr);
+  const double sd = pick(left, sdl, sdr);
+  const double sdm_inv = pick(left, sdml_inv, sdmr_inv);
+  const double ust_d_inv = pick(left, ulst_d_inv, urst_d_inv);
+  const double s_outer = pick(left, s0, s4);
+  const double s_inner = pick(left, s1, s3);
+
+  // physical flux of that side (:141-155)
+  Cons1D fx;
+  fx.d = u.mx;
+  fx.mx = u.mx * w1 + pt - bxsq;
+  fx.my = u.my * w1 - bxi * u.by;
+  fx.mz = u.mz * w1 - bxi * u.bz;
+  fx.e = w1 * (u.e + pt - bxsq) - bxi * (w2 * u.by + w3 * u.bz);
+  fx.by = u.by * w1 - bxi * w2;
+  fx.bz = u.bz * w1 - bxi * w3;
+
+  // star state of that side: eqns (39), (48) (:192, :212-219)
+  ust.mx = ust.d * s2;
+  const double vbst = (ust.mx * bxi + (ust.my * ust.by + ust.mz * ust.bz)) * ust_d_inv;
+  ust.e = (sd * u.e - pt * w1 + ptst * s2 + bxi * (w1 * bxi + (w2 * u.by + w3 * u.bz) - vbst)) * sdm_inv;
+
+  // double-star state of that side (:252-294); same as the star state where Bx is near zero.
+  // Only lanes between the two Alfven waves use it: waves without such a lane skip the block.
+  Cons1D udst = ust;
+  if (wave_any(with_dstar)) {
+    const bool dst_degenerate = 0.5 * bxsq < (kHlldSmall)*ptst;
     const double invsumd = 1.0 / (sqrtdl + sqrtdr);
     const double bxsig = (bxi > 0.0 ? 1.0 : -1.0);
-    uldst.d = ulst.d;
-    urdst.d = urst.d;
-    uldst.mx = ulst.mx;
-    urdst.mx = urst.mx;
-    double tmp = invsumd * (sqrtdl * (ulst.my * ulst_d_inv) + sqrtdr * (urst.my * urst_d_inv) +
-                            bxsig * (urst.by - ulst.by));
-    uldst.my = uldst.d * tmp;
-    urdst.my = urdst.d * tmp;
-    tmp = invsumd * (sqrtdl * (ulst.mz * ulst_d_inv) + sqrtdr * (urst.mz * urst_d_inv) +
-                     bxsig * (urst.bz - ulst.bz));
-    uldst.mz = uldst.d * tmp;
-    urdst.mz = urdst.d * tmp;
-    tmp = invsumd * (sqrtdl * urst.by + sqrtdr * ulst.by +
-                     bxsig * sqrtdl * sqrtdr * ((urst.my * urst_d_inv) - (ulst.my * ulst_d_inv)));
-    uldst.by = urdst.by = tmp;
-    tmp = invsumd * (sqrtdl * urst.bz + sqrtdr * ulst.bz +
-                     bxsig * sqrtdl * sqrtdr * ((urst.mz * urst_d_inv) - (ulst.mz * ulst_d_inv)));
-    uldst.bz = urdst.bz = tmp;
-    tmp = s2 * bxi + (uldst.my * uldst.by + uldst.mz * uldst.bz) / uldst.d;
-    uldst.e = ulst.e - sqrtdl * bxsig * (vbstl - tmp);
-    urdst.e = urst.e + sqrtdr * bxsig * (vbstr - tmp);
+    const double tmy = invsumd * (sqrtdl * (ulst.my * ulst_d_inv) + sqrtdr * (urst.my * urst_d_inv) +
+                                  bxsig * (urst.by - ulst.by));
+    const double tmz = invsumd * (sqrtdl * (ulst.mz * ulst_d_inv) + sqrtdr * (urst.mz * urst_d_inv) +
+                                  bxsig * (urst.bz - ulst.bz));
+    const double tby = invsumd * (sqrtdl * urst.by + sqrtdr * ulst.by +
+                                  bxsig * sqrtdl * sqrtdr * ((urst.my * urst_d_inv) - (ulst.my * ulst_d_inv)));
+    const double tbz = invsumd * (sqrtdl * urst.bz + sqrtdr * ulst.bz +
+                                  bxsig * sqrtdl * sqrtdr * ((urst.mz * urst_d_inv) - (ulst.mz * ulst_d_inv)));
+    // eqn (63): the bracket is formed with the LEFT double-star momenta on both sides (:289)
+    const double dl_my = ulst.d * tmy, dl_mz = ulst.d * tmz;
+#ifdef APK_FP_STRICT
+    const double tmp_e = s2 * bxi + (dl_my * tby + dl_mz * tbz) / ulst.d;
+#else
+    const double tmp_e = s2 * bxi + (dl_my * tby + dl_mz * tbz) * ulst_d_inv;
+#endif
+    const double sq_sig = pick(left, sqrtdl, sqrtdr) * bxsig;
+    const double e_l = ust.e - sq_sig * (vbst - tmp_e);
+    const double e_r = ust.e + sq_sig * (vbst - tmp_e);
+    if (!dst_degenerate) {
+      udst.my = ust.d * tmy;
+      udst.mz = ust.d * tmz;
+      udst.by = tby;
+      udst.bz = tbz;
+      udst.e = left ? e_l : e_r;
+    }
   }
 
-  // jumps across the waves in the reference's order (double-star before star)
-  hlld_jump(uldst, ulst, s1);
-  hlld_jump(ulst, ul, s0);
-  hlld_jump(urdst, urst, s3);
-  hlld_jump(urst, ur, s4);
-
-  Cons1D r;
-  if (s0 >= 0.0) {
-    r = fl;
-  } else if (s4 <= 0.0) {
-    r = fr;
-  } else if (s1 >= 0.0) {
-    r.d = fl.d + ulst.d;
-    r.mx = fl.mx + ulst.mx;
-    r.my = fl.my + ulst.my;
-    r.mz = fl.mz + ulst.mz;
-    r.e = fl.e + ulst.e;
-    r.by = fl.by + ulst.by;
-    r.bz = fl.bz + ulst.bz;
-  } else if (s2 >= 0.0) {
-    r.d = fl.d + ulst.d + uldst.d;
-    r.mx = fl.mx + ulst.mx + uldst.mx;
-    r.my = fl.my + ulst.my + uldst.my;
-    r.mz = fl.mz + ulst.mz + uldst.mz;
-    r.e = fl.e + ulst.e + uldst.e;
-    r.by = fl.by + ulst.by + uldst.by;
-    r.bz = fl.bz + ulst.bz + uldst.bz;
-  } else if (s3 > 0.0) {
-    r.d = fr.d + urst.d + urdst.d;
-    r.mx = fr.mx + urst.mx + urdst.mx;
-    r.my = fr.my + urst.my + urdst.my;
-    r.mz = fr.mz + urst.mz + urdst.mz;
-    r.e = fr.e + urst.e + urdst.e;
-    r.by = fr.by + urst.by + urdst.by;
-    r.bz = fr.bz + urst.bz + urdst.bz;
-  } else {
-    r.d = fr.d + urst.d;
-    r.mx = fr.mx + urst.mx;
-    r.my = fr.my + urst.my;
-    r.mz = fr.mz + urst.mz;
-    r.e = fr.e + urst.e;
-    r.by = fr.by + urst.by;
-    r.bz = fr.bz + urst.bz;
-  }
-  f[IDN] = r.d;
-  f[IV1] = r.mx;
-  f[IV2] = r.my;
-  f[IV3] = r.mz;
-  f[IEN] = r.e;
-  f[IB2] = r.by;
-  f[IB3] = r.bz;
+  hlld_jump(udst, ust, s_inner);  // double-star before star: the star state is overwritten next
+  hlld_jump(ust, u, s_outer);
+#define APK_HLLD_SUM(c) (outer ? fx.c : (with_dstar ? (fx.c + ust.c + udst.c) : (fx.c + ust.c)))
+  f[IDN] = APK_HLLD_SUM(d);
+  f[IV1] = APK_HLLD_SUM(mx);
+  f[IV2] = APK_HLLD_SUM(my);
+  f[IV3] = APK_HLLD_SUM(mz);
+  f[IEN] = APK_HLLD_SUM(e);
+  f[IB2] = APK_HLLD_SUM(by);
+  f[IB3] = APK_HLLD_SUM(bz);
+#undef APK_HLLD_SUM
 }
 
 // src/hydro/rsolvers/glmmhd_dc_llf.hpp:46-179

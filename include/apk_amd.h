@@ -180,7 +180,9 @@ typedef struct apk_stage_args {
    *              flattened with rl columns starting at column i0 and only the cells ilo..ihi of a
    *              row are updated ({0, Ni, is, ie, js, je, ks, ke} is the whole block; rl = 0 skips
    *              the block).  May be called several times with disjoint windows whose union covers
-   *              every interior cell exactly once.
+   *              every interior cell exactly once.  An x1-sweep window must start two columns
+   *              below ilo and end one above ihi (i0 <= ilo - 2, i0 + rl - 1 >= ihi + 1): the
+   *              sweep hands states / PPM interface values from lane to lane.
    *                - stages whose x1 sweep is its own kernel (reconstruction other than dc): the
    *                  x1 sweep only (it reads x1 ghost zones only); j/k ranges must be the full
    *                  interior.  estimate_dt / fill_derived take effect in phase 2.

@@ -480,8 +480,8 @@ def test_fused_stage_split_around_exchange(request, oracle, fluid, recon, rieman
     # block 0: data missing on the low x1 side, block 1: on the high side, block 2: on both
     missing = [(1, 0), (0, 1), (1, 1)]
     main = [[0, ni, is_ + W * lo, ie - W * hi] + jk for lo, hi in missing]
-    slab_lo = [([is_ - 1, W + 2, is_, is_ + W - 1] if lo else [0, 0, 0, -1]) + jk for lo, hi in missing]
-    slab_hi = [([ie - W, W + 2, ie - W + 1, ie] if hi else [0, 0, 0, -1]) + jk for lo, hi in missing]
+    slab_lo = [([is_ - 2, W + 3, is_, is_ + W - 1] if lo else [0, 0, 0, -1]) + jk for lo, hi in missing]
+    slab_hi = [([ie - W - 1, W + 3, ie - W + 1, ie] if hi else [0, 0, 0, -1]) + jk for lo, hi in missing]
     for win in (main, slab_lo, slab_hi):
         t = torch.tensor(win, dtype=torch.int32, device="cuda")
         hydro.StageFused(m0, m1, fluid, recon, riemann, eos, C_H, 0.5, 0.5, 0.004, phase=1, window=t, **kw)

@@ -22,7 +22,7 @@ def kernels(path):
     """{demangled name: [instruction lines]}"""
     cur, body, res = None, [], {}
     for line in open(path):
-        m = re.match(r"^(_Z\w+):", line)
+        m = re.match(r"^(_Z\w+|k_\w+):", line)
         if m:
             cur, body = m.group(1), []
             continue
