@@ -7,6 +7,7 @@
 #include <new>
 
 #include "apk_internal.hpp"
+#include "fused_kernel.hpp"
 
 using namespace apk;
 
@@ -277,6 +278,25 @@ int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
   if (rc == APK_ERR_UNSUPPORTED) return set_err(ctx, rc, "fused stage: option combination not supported (scalars, 1-D/extended-Dedner fill_derived, split 1-D or 3-D donor-cell stage)");
   if (rc != APK_OK) return set_err(ctx, rc, "fused stage kernel launch failed", hipGetLastError());
   return APK_OK;
+}
+
+int apk_stage_unphysical_read(apk_ctx *ctx, long long *count, apk_stream_t stream) {
+  if (!ctx || !count) return APK_ERR_INVALID;
+  hipStream_t s = as_stream(stream);
+  auto *h = static_cast<unsigned long long *>(ctx->h_pinned);
+  APK_HIP_TRY(ctx, hipMemcpyAsync(h + 6, ctx->d_u64 + 6, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  APK_HIP_TRY(ctx, hipStreamSynchronize(s));
+  *count = (long long)h[6];
+  return APK_OK;
+}
+
+int apk_stage_split_axis(const apk_pack *u0, const apk_flux_cfg *cfg, int fill_derived) {
+  if (!u0 || !cfg) return 0;
+  apk::StageParams sp{};
+  sp.prim_to_u1 = (fill_derived == 2) ? 1 : 0;
+  const int extra = fill_derived ? apk::EXTRA_C2P : apk::EXTRA_NONE;
+  if (u0->view.ndim == 3 && cfg->recon == APK_RC_DC) return 0;  // single-kernel stage: 3-D index windows
+  return apk::two_kernel_stage_applies(u0->view, cfg->recon, extra, sp) ? 3 : 1;
 }
 
 int apk_cons_to_prim(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,

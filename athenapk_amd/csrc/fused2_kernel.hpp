@@ -1,0 +1,345 @@
+// fused2_kernel.hpp -- the two-kernel form of the fused 3-D stage (no flux-difference round trips).
+//
+// The three-sweep schedule of fused_kernel.hpp moves `du` through HBM one and a half times and reads
+// `prim` three times: 13.2 GB per PPM+HLLD stage on 8 x 128^3 against 3.6 GB of algorithmic traffic
+// (profiles/r01_hbm_traffic.json), and after the instruction diet of round 2 its x2 and x3 marches
+// run at the HBM rate, not the VALU rate.  Here a stage is
+//
+//   K1  fused_march_kernel<.., DIR = 3, FINAL = false> with StageParams.du_first: the x3 sweep alone,
+//       writing its flux difference d3 = A3 (F3(k+1) - F3(k)) once            (prim in, d3 out)
+//   K2  fused_m12f_kernel (this file): x1 AND x2 in one march along j that also finishes the stage,
+//       du = (d1 + d2) + d3 -- the reference's accumulation order x1, x2, x3 (hydro.cpp:1070-1199;
+//       floating-point addition is evaluated in that association whichever kernel ran first) --
+//       then RK update, Dedner source, ConsToPrim (out of place) and the dt reduction
+//                                                 (prim, d3, u1 [, u0] in; u0, prim' out)
+//
+// = 8.6 GB instead of 13.2 GB, and each kernel's VALU time now about equals its HBM time.
+//
+// K2's lanes are the (k, i)-flattened cells of one j-row of a block, 64 consecutive cells of the
+// flattened run per wave (x1_cells_per_wave(RECON) of them retire, as in the x1 sweep: states and
+// fluxes travel between neighbouring lanes by DPP wave shifts); the wave marches along j with the
+// x2 stencil rows in its private LDS ring exactly as fused_march_kernel does.  In iteration c it
+// solves the x2 face between rows c-1 and c and the x1 faces of row c-1 and retires row c-1.
+//
+// Scheduling: the (block, chunk) columns x nx2 rows are one global list of wave-rows, cut into
+// EQUAL contiguous ranges, one per launched wave, and exactly as many waves are launched as the GPU
+// holds at once (2 per SIMD).  Every wave therefore does the same amount of work in one round (a
+// grid of 2256 full-length marches on 2048 slots would run in two rounds), at the price of one
+// extra stencil prologue per range boundary.  Consecutive ranges go to the same XCD (the hardware
+// deals workgroup ids round-robin over the 8 XCDs), so the rows a wave re-reads for the x1 stencil
+// and its neighbours' overlap columns are in that XCD's L2.
+// (included by fused_kernel.hpp after its kernels, before its launch helpers)
+#pragma once
+
+namespace apk {
+
+// Lanes of a K2 wave that retire a cell.  A cell needs the fluxes of both its x1 faces; a face needs
+// the reconstructed states of the two cells it separates; a state needs the cell's stencil (H lanes
+// either side, fetched by wave shifts) and, with PPM, the interface value of the lane below:
+//   stencil half width 2 (PPM, WENO-Z): states valid in lanes 2..61, faces 3..61, cells 3..60
+//   stencil half width 1:               states valid in lanes 1..62, faces 2..62, cells 2..61
+constexpr int m12_first_lane(int recon) { return recon_halfwidth(recon) + 1; }
+constexpr int m12_last_lane(int recon) { return 62 - recon_halfwidth(recon); }
+
+#ifndef APK_M12F_LOADS
+// where the d3 / u1 loads of the retiring cell are issued (A/B switch): 0 top of the iteration,
+// 1 after the x1 phase, 2 after the x2 solve.  Measured on 8 x 128^3 PPM+HLLD: 3.44 / 3.10 / 2.36 ms
+// with two waves per SIMD -- the earlier the loads, the more of the 256 VGPRs they hold through an
+// HLLD solve and the more the compiler spills (148 / 156 / 12 B of scratch per lane); with one wave
+// per SIMD (512 VGPRs, APK_M12F_WAVES = 1) nothing spills but 2.63 ms at best.
+#define APK_M12F_LOADS 2
+#endif
+#ifndef APK_M12F_WAVES
+#define APK_M12F_WAVES 2  // resident waves per SIMD the kernel is compiled for (A/B: 1 = 512 VGPRs)
+#endif
+
+template <int FLUID, int RECON, int RS, int EXTRA>
+__global__ void __launch_bounds__(64, APK_M12F_WAVES)
+fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves, int per_xcd,
+                  long long total_rows) {
+  static_assert(RECON != APK_RC_DC, "donor-cell stages have their own single-kernel form");
+  constexpr int NV = nvars<FLUID>();
+  constexpr int H = recon_halfwidth(RECON);
+  constexpr int NS = 2 * H;
+  constexpr int FIRST = m12_first_lane(RECON), LAST = m12_last_lane(RECON), CPW = LAST - FIRST + 1;
+  extern __shared__ __attribute__((aligned(16))) double ring[];
+  const int lane = threadIdx.x;
+  const int w = (int)(blockIdx.x % 8u) * per_xcd + (int)(blockIdx.x / 8u);
+  if (w >= nwaves) return;
+  double lane_min_dt = 1.7976931348623157e308;
+  const int64_t st = u0.sj;
+  const int64_t run = (int64_t)u0.nx3 * u0.ni;
+
+  long long r = total_rows * w / nwaves;
+  const long long r_end = total_rows * (w + 1) / nwaves;
+  while (r < r_end) {  // wave-uniform
+    // ---- this piece: rows s..e of column chunk `chunk` of block b
+    const int item = (int)(r / u0.nx2);
+    const int j0 = (int)(r - (long long)item * u0.nx2);
+    const long long left = r_end - r;
+    const int nrows = (left < (long long)(u0.nx2 - j0)) ? (int)left : (u0.nx2 - j0);
+    r += nrows;
+    const int b = item / wpb;
+    const int chunk = item - b * wpb;
+    const apk_block_desc b0 = u0.blocks[b];
+    const double *c1 = u1.blocks[b].cons;
+    double *prim_dst = (EXTRA != EXTRA_NONE) ? u1.blocks[b].prim : nullptr;
+    const double *d3 = sp.du + (int64_t)b * u0.sn * u0.nvar;
+
+    const int64_t t = (int64_t)chunk * CPW + lane - FIRST;
+    const bool in_run = (t >= 0) && (t < run);
+    const int64_t tc = in_run ? t : (t < 0 ? 0 : run - 1);  // out-of-run lanes shadow a valid column
+    const int krow = (int)(tc / u0.ni);
+    const int i = (int)(tc - (int64_t)krow * u0.ni);
+    const bool active = in_run && (lane >= FIRST) && (lane <= LAST) && (i >= u0.is) && (i <= u0.ie);
+    const int s = u0.js + j0, e = s + nrows - 1;
+    const int64_t base = (int64_t)(u0.ks + krow) * u0.sk + i;
+    const double dx1 = b0.dx[0], dx2 = b0.dx[1];
+    const double area1 = b0.dx[1] * b0.dx[2];
+    const double area2 = b0.dx[0] * b0.dx[2];
+    const double vol = b0.dx[0] * b0.dx[1] * b0.dx[2];
+    const double *prim = b0.prim + base;
+
+    int c = s - 1;
+    const int r0 = c - H;
+    {
+      // stencil rows of the first cell: all loads in flight together, then the ring writes
+      double init[NS][NV];
+#pragma unroll
+      for (int m = 0; m < NS; ++m)
+#pragma unroll
+        for (int n = 0; n < NV; ++n) init[m][n] = prim[n * u0.sn + (int64_t)(r0 + m) * st];
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int m = 0; m < NS; ++m)
+#pragma unroll
+        for (int n = 0; n < NV; ++n) ring[(m * NV + n) * 64 + lane] = init[m][n];
+    }
+    double Pn[NV];  // row c+H
+#pragma unroll
+    for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + (int64_t)(c + H) * st];
+
+    double wl_prev[NV], f_prev[NV];  // x2: permuted L state at face c / flux at face c-1
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      wl_prev[q] = 0.0;
+      f_prev[q] = 0.0;
+    }
+    double face_carry[NV];  // PPM: the limited x2 interface value below cell c (see ppm_interface)
+    if constexpr (RECON == APK_RC_PPM) {
+#pragma unroll
+      for (int n = 0; n < NV; ++n)
+        face_carry[n] = ppm_interface(ring[(0 * NV + n) * 64 + lane], ring[(1 * NV + n) * 64 + lane],
+                                      ring[(2 * NV + n) * 64 + lane], ring[(3 * NV + n) * 64 + lane]);
+    }
+
+    int slot0 = 0;  // slot holding row c-H
+    for (; c <= e + 1; ++c) {
+      const int64_t done = base + (int64_t)(c - 1) * st;  // the cell this iteration retires
+      const bool retire = (c >= s + 1);                   // wave-uniform
+      // ---- (1) x1 faces of row c-1 (every lane takes part in the wave shifts).  The row's own
+      // values are still in the ring (slot of row c-1: c-1 = (c-H) + H-1); the lanes are
+      // consecutive cells of the row, so the stencil neighbours i-2 .. i+2 come from the
+      // neighbouring lanes by DPP wave shifts: no memory access at all (re-reading the row from
+      // memory three iterations after it was loaded misses the L2 -- 256 waves per XCD stream ~5 MB
+      // per iteration through it -- and left the waves parked on s_waitcnt for 3/4 of the kernel).
+      // The x1 phase comes first so that its working set does not overlap the x2 solve's: only
+      // its 9 flux differences stay live.
+      double du[NV], d3v[NV], u1v[NV];
+      if constexpr (APK_M12F_LOADS == 0) {
+        if (retire) {
+#pragma unroll
+          for (int n = 0; n < NV; ++n) d3v[n] = d3[n * u0.sn + done];
+#pragma unroll
+          for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
+        }
+      }
+      if (retire) {
+        const int slot_cm1 = (slot0 + H - 1) & (NS - 1);
+        double ql1[NV], qr1[NV];
+        // (the ring read of variable n+1 is issued before variable n is processed: the branchy PPM
+        // code keeps the compiler from hoisting it, and with two waves per SIMD an exposed LDS round
+        // trip per variable is a visible share of the iteration)
+        double q0_next = ring[(slot_cm1 * NV + 0) * 64 + lane];
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+          const double q0 = q0_next;
+          if (n + 1 < NV) q0_next = ring[(slot_cm1 * NV + n + 1) * 64 + lane];
+          const double qm1 = wave_shr1(q0), qp1 = wave_shl1(q0);
+          if constexpr (RECON == APK_RC_PPM) {
+            const double qm2 = wave_shr1(qm1), qp2 = wave_shl1(qp1);
+            const double face_p = ppm_interface(qm1, q0, qp1, qp2);
+            const double face_m = wave_shr1(face_p);
+            ppm_cell(qm2, qm1, q0, qp1, qp2, face_m, face_p, ql1[n], qr1[n]);
+          } else if constexpr (H >= 2) {
+            const double qm2 = wave_shr1(qm1), qp2 = wave_shl1(qp1);
+            reconstruct<RECON>(qm2, qm1, q0, qp1, qp2, dx1, n, ql1[n], qr1[n]);
+          } else {
+            reconstruct<RECON>(0.0, qm1, q0, qp1, 0.0, dx1, n, ql1[n], qr1[n]);
+          }
+          if constexpr (RECON == APK_RC_WENOZ || RECON == APK_RC_WENO3 || RECON == APK_RC_LIMO3)
+            asm volatile("" : "+v"(ql1[n]), "+v"(qr1[n]));
+        }
+        double wl[NV], wr[NV], f1[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          wl[q] = wave_shr1(ql1[perm<1>(q)]);
+          wr[q] = qr1[perm<1>(q)];
+        }
+        riemann<FLUID, RS>(wl, wr, sp.gamma, sp.c_h, f1);
+        double fup0 = 0.0;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const double fup = wave_shl1(f1[q]);
+          if (q == 0) fup0 = fup;
+          du[perm<1>(q)] = (area1 * fup - area1 * f1[q]);
+        }
+        if (sp.mflux && active) {
+          double *m = sp.mflux + ((int64_t)0 * u0.nblocks + b) * u0.sn + done;
+          m[0] = f1[0];
+          m[1] = fup0;
+        }
+        // (2) streaming operands of the cell being retired: in flight during the x2 phase
+        if constexpr (APK_M12F_LOADS == 1) {
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int n = 0; n < NV; ++n) d3v[n] = d3[n * u0.sn + done];
+#pragma unroll
+          for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
+        }
+      }
+      // ---- (3) x2: reconstruct cell c from ring rows c-H..c+H-1 and the register row c+H
+      double qln[NV], qrn[NV];
+      double an[NS];  // ring rows of the next variable (software-pipelined LDS reads)
+#pragma unroll
+      for (int m = 0; m < NS; ++m) an[m] = ring[(((slot0 + m) & (NS - 1)) * NV + 0) * 64 + lane];
+#pragma unroll
+      for (int n = 0; n < NV; ++n) {
+        double a[NS];
+#pragma unroll
+        for (int m = 0; m < NS; ++m) a[m] = an[m];
+        if (n + 1 < NV) {
+#pragma unroll
+          for (int m = 0; m < NS; ++m) an[m] = ring[(((slot0 + m) & (NS - 1)) * NV + n + 1) * 64 + lane];
+        }
+        if constexpr (H == 1) {
+          const double a0 = a[0], a1 = a[1];
+          reconstruct<RECON>(0.0, a0, a1, Pn[n], 0.0, dx2, n, qln[n], qrn[n]);
+        } else {
+          const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+          if constexpr (RECON == APK_RC_PPM) {
+            const double face_p = ppm_interface(a1, a2, a3, Pn[n]);
+            ppm_cell(a0, a1, a2, a3, Pn[n], face_carry[n], face_p, qln[n], qrn[n]);
+            face_carry[n] = face_p;
+          } else {
+            reconstruct<RECON>(a0, a1, a2, a3, Pn[n], dx2, n, qln[n], qrn[n]);
+          }
+        }
+        if constexpr (RECON == APK_RC_WENOZ || RECON == APK_RC_WENO3 || RECON == APK_RC_LIMO3)
+          asm volatile("" : "+v"(qln[n]), "+v"(qrn[n]));  // (see fused_march_kernel)
+      }
+      const bool more = (c < e + 1);
+      if (more) {
+#pragma unroll
+        for (int n = 0; n < NV; ++n) ring[(slot0 * NV + n) * 64 + lane] = Pn[n];
+        slot0 = (slot0 + 1) & (NS - 1);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + (int64_t)(c + 1 + H) * st];
+      }
+      // ---- (4) x2 face between rows c-1 and c; retire row c-1
+      if (c >= s) {
+        double f[NV];
+        {
+          double wr[NV];
+#pragma unroll
+          for (int q = 0; q < NV; ++q) wr[q] = qrn[perm<2>(q)];
+          riemann<FLUID, RS>(wl_prev, wr, sp.gamma, sp.c_h, f);
+        }
+        if (retire) {
+          if constexpr (APK_M12F_LOADS == 2) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int n = 0; n < NV; ++n) d3v[n] = d3[n * u0.sn + done];
+#pragma unroll
+            for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
+          }
+          // du = (x1 term + x2 term) + x3 term, the reference's accumulation order
+#pragma unroll
+          for (int q = 0; q < NV; ++q) {
+            const int n = perm<2>(q);
+            du[n] = du[n] + (area2 * f[q] - area2 * f_prev[q]);
+          }
+#pragma unroll
+          for (int n = 0; n < NV; ++n) du[n] = du[n] + d3v[n];
+          if (active) {
+            if (sp.mflux) {
+              double *m = sp.mflux + ((int64_t)1 * u0.nblocks + b) * u0.sn + done;
+              m[0] = f_prev[0];
+              m[st] = f[0];
+            }
+            finish_cell<FLUID, EXTRA>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NV; ++q) f_prev[q] = f[q];
+      }
+#pragma unroll
+      for (int q = 0; q < NV; ++q) wl_prev[q] = qln[perm<2>(q)];
+    }
+  }
+  if constexpr (EXTRA == EXTRA_C2P_DT) {
+    double m = lane_min_dt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_down(m, off, 64));
+    if (lane == 0) atomicMin(sp.dt_bits, (unsigned long long)__double_as_longlong(m));
+  }
+}
+
+// number of waves the device holds at once with two march waves per SIMD
+inline int resident_march_waves() {
+  static const int n = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    }
+    return cus * 4 * APK_M12F_WAVES;
+  }();
+  return n;
+}
+
+// can / should a stage take the two-kernel form?  3-D, a reconstruction with a stencil (ghost
+// layers), FillDerived out of place or absent (K2's lanes read their x1 neighbours' primitives from
+// memory), and rows long enough that the flattened (k, i) run keeps most lanes on interior cells
+// (nx1 / (nx1 + 2 ng): 128 -> 96 %, 32 -> 84 %; narrower meshblocks keep the three-sweep schedule
+// with several rows per wave).
+inline bool two_kernel_stage_applies(const PackView &u0, int recon, int extra, const StageParams &sp) {
+  static const int mode = std::getenv("APK_STAGE_MODE") ? std::atoi(std::getenv("APK_STAGE_MODE")) : 2;  // A/B switch: 3 = three sweeps
+  if (mode == 3) return false;
+  return u0.ndim == 3 && recon != APK_RC_DC && u0.nx1 >= 32 && (extra == EXTRA_NONE || sp.prim_to_u1);
+}
+
+template <int FLUID, int RECON, int RS>
+inline void launch_m12f(const PackView &u0, const PackView &u1, const StageParams &sp, int extra, hipStream_t s) {
+  if constexpr (RECON != APK_RC_DC) {
+    constexpr int lds = march_lds_bytes<FLUID, RECON>();
+    constexpr int cpw = m12_last_lane(RECON) - m12_first_lane(RECON) + 1;
+    const int64_t run = (int64_t)u0.nx3 * u0.ni;
+    const int wpb = (int)((run + cpw - 1) / cpw);
+    const long long total_rows = (long long)u0.nblocks * wpb * u0.nx2;
+    // as many waves as the device holds, but no ranges shorter than ~16 rows
+    long long nw = resident_march_waves();
+    if (total_rows / 16 < nw) nw = total_rows / 16 > 0 ? total_rows / 16 : 1;
+    const int nwaves = (int)nw;
+    const int per_xcd = (nwaves + 7) / 8;
+    const dim3 g((unsigned)(per_xcd * 8), 1, 1);
+    if (extra == EXTRA_C2P_DT)
+      hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_C2P_DT>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows);
+    else if (extra == EXTRA_C2P)
+      hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_C2P>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows);
+    else
+      hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_NONE>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows);
+  }
+}
+
+}  // namespace apk

@@ -31,10 +31,17 @@ int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
   sp.dedner = a.dedner;
   sp.dedner_coeff = dedner_coeff;
   sp.du = nullptr;
+  sp.du_first = 0;
   sp.ctx = ctx;
   sp.eos = a.eos;
   sp.flags = ctx->d_flags + (a.trial ? 1 : 0);
   sp.dt_bits = ctx->d_u64 + 4;  // word 4: min of the finishing sweep (apk_stage_dt_read)
+  sp.bad_count = nullptr;
+  if (a.count_unphysical) {     // word 6: cells failing FirstOrderFluxCorrect's test (apk_stage_unphysical_read)
+    if (u0.nvar != u0.nhydro) return APK_ERR_UNSUPPORTED;  // (scalars are updated by their own kernel)
+    sp.bad_count = ctx->d_u64 + 6;
+    if (a.phase != 2 && hipMemsetAsync(sp.bad_count, 0, sizeof(unsigned long long), s) != hipSuccess) return APK_ERR_DEVICE;
+  }
   int extra = EXTRA_NONE;
   sp.prim_to_u1 = (a.fill_derived == 2) ? 1 : 0;
   sp.phase = a.phase;

@@ -31,10 +31,12 @@ struct StageParams {
   double dedner_coeff;
   int dedner;  // 0 off, 1 plain, 2 extended
   double *du;  // scratch: [nblocks][nvar][Nk][Nj][Ni]
+  int du_first;  // non-finishing march: WRITE its flux difference to du instead of adding to it
   // optional work of the finishing sweep (apk_stage_args.fill_derived / estimate_dt)
   apk_eos eos;                   // floors / ceilings for the in-place ConsToPrim
   unsigned *flags;               // latched APK_FLAG_* word
   unsigned long long *dt_bits;   // min over cells of dx_d/(|v_d|+c_d), as ordered bits
+  unsigned long long *bad_count;  // trial stage: number of cells failing FirstOrderFluxCorrect's test (or NULL)
   int prim_to_u1;                // fill_derived = 2: the new primitives go to u1's prim arrays
   // optional per-block index window (apk_stage_args.window): {i0, rl, ilo, ihi, jlo, jhi, klo, khi}:
   // rows are flattened with length rl starting at column i0 and only cells ilo..ihi retire
@@ -123,6 +125,15 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
     }
     if (sp.dedner != 0) un[IPS] *= sp.dedner_coeff;
   }
+  // Trial stage of first-order flux correction: FirstOrderFluxCorrect's admissibility test
+  // (hydro.cpp:1297-1306: rho <= 0 or E - KE [- ME] <= 0, on the update BEFORE any floor) applied to
+  // the very `un` this kernel computed.
+  bool bad = false;
+  if (sp.bad_count) {
+    double new_p = un[IEN] - 0.5 * (sqr(un[IM1]) + sqr(un[IM2]) + sqr(un[IM3])) / un[IDN];
+    if constexpr (FLUID == APK_FLUID_GLMMHD) new_p -= 0.5 * (sqr(un[IB1]) + sqr(un[IB2]) + sqr(un[IB3]));
+    bad = !(un[IDN] > 0.0 && new_p > 0.0);
+  }
   if constexpr (EXTRA != EXTRA_NONE) {
     // FillDerived for this cell (adiabatic_hydro.hpp:52-142): in a march along x2/x3 no other lane
     // reads this column of prim during the sweep and this lane's stencil copy sits in its LDS
@@ -132,6 +143,9 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
     double w[NV], di;
     const unsigned fl = cons_to_prim_cell<FLUID>(sp.eos, un, w, di);
     if (fl) atomicOr(sp.flags, fl);
+    // (ConsToPrim forms the pressure with 1/rho where the test above divides: a trial stage is
+    // only accepted if neither sees a negative state, so an accepted stage never raises flags)
+    if (sp.bad_count && fl) bad = true;
 #pragma unroll
     for (int n = 0; n < NV; ++n) prim_dst[n * pv.sn + cell] = w[n];
     if constexpr (EXTRA == EXTRA_C2P_DT) {
@@ -153,6 +167,7 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
   }
 #pragma unroll
   for (int n = 0; n < NV; ++n) b0.cons[n * pv.sn + cell] = un[n];
+  if (bad) atomicAdd(sp.bad_count, 1ull);
 }
 
 // ==============================================================================================
@@ -303,11 +318,17 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
   const double *c1 = u1.blocks[b].cons;
 
   const int64_t st = (DIR == 2) ? u0.sj : u0.sk;
-  const int n_along = (DIR == 2) ? u0.nx2 : u0.nx3;
+  int s0 = (DIR == 2) ? u0.js : u0.ks;
+  int e_all = (DIR == 2) ? u0.je : u0.ke;
+  if (sp.window) {  // x3 sweep of a split two-kernel stage: the planes klo..khi of this block only
+    const int *w = sp.window + 8 * b;
+    if (w[1] <= 0 || w[7] < w[6]) return;
+    s0 = w[6];
+    e_all = w[7];
+  }
+  const int n_along = e_all - s0 + 1;
   const int seg_len = (n_along + nseg - 1) / nseg;
-  const int s0 = (DIR == 2) ? u0.js : u0.ks;
   const int s = s0 + seg * seg_len;  // first / last interior index along the march
-  const int e_all = (DIR == 2) ? u0.je : u0.ke;
   const int e = (s + seg_len - 1 < e_all) ? s + seg_len - 1 : e_all;
   if (s > e_all) return;
   const int64_t base = (DIR == 2) ? ((int64_t)(u0.ks + trans) * u0.sk + ii)
@@ -354,28 +375,42 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
     const int64_t done = base + (int64_t)(c - 1) * st;
     double duv[NV], u1v[NV];
     if (c >= s + 1) {
+      if (FINAL || !sp.du_first) {
 #pragma unroll
-      for (int n = 0; n < NV; ++n) duv[n] = dscratch[n * u0.sn + done];
+        for (int n = 0; n < NV; ++n) duv[n] = dscratch[n * u0.sn + done];
+      }
       if constexpr (FINAL) {
 #pragma unroll
         for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
       }
     }
-    // reconstruct cell c from ring rows c-H..c+H-1 and the register row c+H
+    // reconstruct cell c from ring rows c-H..c+H-1 and the register row c+H.  The ring rows of
+    // variable n+1 are requested before variable n is processed (software-pipelined LDS reads: the
+    // branchy limiter code keeps the compiler from hoisting them by itself).
     double qln[NV], qrn[NV];
+    double an[NS > 0 ? NS : 1];
+    if constexpr (NS > 0) {
+#pragma unroll
+      for (int m = 0; m < NS; ++m) an[m] = ring[(((slot0 + m) & (NS - 1)) * NV + 0) * 64 + lane];
+    }
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
+      double a[NS > 0 ? NS : 1];
+      if constexpr (NS > 0) {
+#pragma unroll
+        for (int m = 0; m < NS; ++m) a[m] = an[m];
+        if (n + 1 < NV) {
+#pragma unroll
+          for (int m = 0; m < NS; ++m) an[m] = ring[(((slot0 + m) & (NS - 1)) * NV + n + 1) * 64 + lane];
+        }
+      }
       if constexpr (H == 0) {
         reconstruct<RECON>(0.0, 0.0, Pn[n], 0.0, 0.0, dx, n, qln[n], qrn[n]);
       } else if constexpr (H == 1) {
-        const double a0 = ring[(slot0 * NV + n) * 64 + lane];
-        const double a1 = ring[(((slot0 + 1) & 1) * NV + n) * 64 + lane];
+        const double a0 = a[0], a1 = a[1];
         reconstruct<RECON>(0.0, a0, a1, Pn[n], 0.0, dx, n, qln[n], qrn[n]);
       } else {
-        const double a0 = ring[(slot0 * NV + n) * 64 + lane];
-        const double a1 = ring[(((slot0 + 1) & 3) * NV + n) * 64 + lane];
-        const double a2 = ring[(((slot0 + 2) & 3) * NV + n) * 64 + lane];
-        const double a3 = ring[(((slot0 + 3) & 3) * NV + n) * 64 + lane];
+        const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
         if constexpr (RECON == APK_RC_PPM) {
           const double face_p = ppm_interface(a1, a2, a3, Pn[n]);
           ppm_cell(a0, a1, a2, a3, Pn[n], face_carry[n], face_p, qln[n], qrn[n]);
@@ -414,7 +449,8 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
           const int n = perm<DIR>(q);
-          du[n] = duv[n] + (area * f[q] - area * f_prev[q]);
+          const double diff = (area * f[q] - area * f_prev[q]);
+          du[n] = (!FINAL && sp.du_first) ? diff : duv[n] + diff;
         }
         if (active && sp.mflux) {
           double *m = sp.mflux + ((int64_t)(DIR - 1) * u0.nblocks + b) * u0.sn + cell;
@@ -839,6 +875,10 @@ inline void launch_scalar_update(const PackView &u0, const PackView &u1, const S
   if (extra != EXTRA_NONE) hipLaunchKernelGGL((fused_scalar_prim_kernel<RECON>), grid, block, 0, s, u0, u1, sp.prim_to_u1);
 }
 
+}  // namespace apk
+#include "fused2_kernel.hpp"
+namespace apk {
+
 // ---- launch helpers ---------------------------------------------------------------------------
 // segments per march so that the launch has at least ~2 x 2048 waves (MI355X: 1024 SIMDs x 2
 // resident march waves), never shorter than 16 cells
@@ -937,6 +977,28 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
       ScopedTiming t(sp.ctx, TS + 0, s);
       hipLaunchKernelGGL((fused_march12_kernel<FLUID, RECON, RS>), dim3(wpb, 1, u0.nblocks), dim3(64), lds, s,
                          u0, u1, sp, wpb);
+    } else if (two_kernel_stage_applies(u0, RECON, extra, sp)) {
+      // two-kernel stage (fused2_kernel.hpp): the x3 sweep writes its flux difference, then one
+      // march does x1 + x2 and finishes.  A split stage runs the x3 sweep on plane windows in
+      // phase 1 (it reads x3 ghost zones only) and the finishing march in phase 2.
+      if (do_x1) {
+        StageParams sp1 = sp;
+        sp1.du_first = 1;
+        const int rpw = march_rows_per_wave(u0.nx1, u0.nx2);
+        dim3 g3((u0.nx1 + 64 / rpw - 1) / (64 / rpw), (u0.nx2 + rpw - 1) / rpw, u0.nblocks);
+        const int nseg = march_segments((int64_t)g3.x * g3.y * g3.z, u0.nx3);
+        g3.z *= nseg;
+        ScopedTiming t(sp.ctx, TS + 2, s);
+        hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 3, false>), g3, dim3(64), lds, s, u0, u1, sp1, nseg, rpw);
+      }
+      if (do_rest) {
+        StageParams sp2 = sp;
+        sp2.window = nullptr;
+        ScopedTiming t(sp.ctx, TS + 0, s);
+        launch_m12f<FLUID, RECON, RS>(u0, u1, sp2, extra, s);
+      }
+      if (sp.mflux && do_rest) launch_scalar_update<RECON>(u0, u1, sp, extra, s);
+      return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
     } else {
       if (do_x1) {
         ScopedTiming t(sp.ctx, TS + 0, s);

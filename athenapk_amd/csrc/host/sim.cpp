@@ -396,8 +396,9 @@ int build_windows(apk_sim *s) {
     int *q = &t[8 * (size_t)lb];
     q[0] = i0, q[1] = rl, q[2] = ilo, q[3] = ihi, q[4] = jlo, q[5] = jhi, q[6] = klo, q[7] = khi;
   };
-  std::vector<int> x1[3], dc[7];
+  std::vector<int> x1[3], dc[7], k3[3];
   for (auto &t : x1) t.assign(8 * (size_t)nlb, 0);
+  for (auto &t : k3) t.assign(8 * (size_t)nlb, 0);
   for (auto &t : dc) t.assign(8 * (size_t)nlb, 0);
   std::vector<unsigned> late(nlb, 0u);
   for (int lb = 0; lb < nlb; ++lb) {
@@ -412,6 +413,11 @@ int build_windows(apk_sim *s) {
     // PPM's shared interface values, the lane below it as well -- x1_first_lane in fused_kernel.hpp)
     put(x1[1], lb, m.is - 2, L[0][0] ? W + 3 : 0, m.is, m.is + W - 1, m.js, m.je, m.ks, m.ke);
     put(x1[2], lb, m.ie - W - 1, L[0][1] ? W + 3 : 0, m.ie - W + 1, m.ie, m.js, m.je, m.ks, m.ke);
+    // two-kernel stage (3-D): its first kernel is the x3 sweep, which reads x3 ghost zones only --
+    // every plane farther than nghost from a late x3 face, then the slabs next to those faces
+    put(k3[0], lb, 0, m.ni, m.is, m.ie, m.js, m.je, m.ks + W * L[2][0], m.ke - W * L[2][1]);
+    put(k3[1], lb, 0, L[2][0] ? m.ni : 0, m.is, m.ie, m.js, m.je, m.ks, m.ks + W - 1);
+    put(k3[2], lb, 0, L[2][1] ? m.ni : 0, m.is, m.ie, m.js, m.je, m.ke - W + 1, m.ke);
     // single-kernel donor-cell stage (3-D): everything but the one-cell layers next to late
     // faces, then disjoint slabs: z (whole planes), y (rows of the remaining planes), x (columns)
     const int lo[3] = {S[0] + L[0][0], S[1] + L[1][0], S[2] + L[2][0]};
@@ -445,6 +451,8 @@ int build_windows(apk_sim *s) {
   const char *x1tags[3] = {"win_x1_main", "win_x1_lo", "win_x1_hi"};
   for (int q = 0; q < 3; ++q) SIM_TRY(s, upload_window(s, x1tags[q], x1[q], s->x1win[q]));
   if (m.ndim == 3) {
+    const char *k3tags[3] = {"win_k3_main", "win_k3_lo", "win_k3_hi"};
+    for (int q = 0; q < 3; ++q) SIM_TRY(s, upload_window(s, k3tags[q], k3[q], s->k3win[q]));
     const char *dctags[7] = {"win_dc_main", "win_dc_zlo", "win_dc_zhi", "win_dc_ylo", "win_dc_yhi", "win_dc_xlo", "win_dc_xhi"};
     for (int q = 0; q < 7; ++q) SIM_TRY(s, upload_window(s, dctags[q], dc[q], s->dcwin[q]));
   }
@@ -464,7 +472,9 @@ bool can_overlap_next(const apk_sim *s, int next) {
     return m.ndim == 3 && !ext_dedner && m.mb[0] >= 4 && m.mb[1] >= 4 && m.mb[2] >= 4 &&
            !(next == s->nstages && s->pkg.calc_dt_hyp) && !(s->fmft && next == s->nstages);
   }
-  return m.mb[0] >= 4 * m.ng;
+  // x1 column windows of the three-sweep schedule / x3 plane windows of the two-kernel one
+  const bool planes = m.ndim == 3 && apk_stage_split_axis(s->mu0(), &cfg, 2) == 3;
+  return planes ? m.mb[2] >= 4 * m.ng : m.mb[0] >= 4 * m.ng;
 }
 
 // complete an exchange left in flight (accessors, end of run): ghosts of cons and prim are valid after
@@ -617,7 +627,9 @@ int do_stage(apk_sim *s, int stage) {
     const int64_t final_waves = (int64_t)((mm.mb[0] + 64 / rpw_est - 1) / (64 / rpw_est)) *
                                 ((mm.ndim == 3 ? mm.mb[1] : 1) + rpw_est - 1) / rpw_est * (int64_t)mm.local_gids.size();
     const bool few_waves = mm.ndim >= 2 && final_waves < 2048;
-    if (fused_fill && ((dc3 && dc_mode == 2) || a.dedner == 2 || few_waves)) {
+    // (the two-kernel 3-D stage: its finishing march reads x1 neighbours from memory -- out of place)
+    const bool two_kernel = mm.ndim == 3 && cfg.recon != APK_RC_DC && apk_stage_split_axis(s->mu0(), &cfg, 2) == 3;
+    if (fused_fill && ((dc3 && dc_mode == 2) || a.dedner == 2 || few_waves || two_kernel)) {
       // (the extended Dedner source reads neighbouring primitives as well: out of place, too; and a
       // finishing march with too few waves to fill the GPU -- 2-D meshes, small packs -- runs out of
       // place so that it can be cut into segments)
@@ -639,7 +651,8 @@ int do_stage(apk_sim *s, int stage) {
       if (!c2p_in_copy)
         SIM_TRY(s, apk_cons_to_prim_ghosts_split(s->ctx, state, pkg.fluid, &pkg.eos, s->d_late_regions, 1, s->stream));
       const bool whole = dc3 && swap_prim;  // single-kernel stage
-      const apk_sim::WindowTable *tabs = whole ? s->dcwin : s->x1win;
+      const bool planes = !whole && apk_stage_split_axis(s->mu0(), &cfg, a.fill_derived) == 3;
+      const apk_sim::WindowTable *tabs = whole ? s->dcwin : (planes ? s->k3win : s->x1win);
       const int ntabs = whole ? 7 : 3;
       a.phase = 1;
       for (int q = 0; q < ntabs; ++q) {
@@ -681,10 +694,12 @@ int do_stage(apk_sim *s, int stage) {
     // stays the full pass after the exchange.)
     if (s->fused && pkg.first_order_flux_correct && g0 == 0.0 && !pkg.glmmhd_source_extended && s->mesh.ndim >= 2 &&
         pkg.riemann != APK_RS_NONE && pkg.riemann != APK_RS_LLF) {
-      // FillDerived inside the trial stage only while no floor / ceiling is active: those change the
-      // updated state before it is stored, and FirstOrderFluxCorrect tests the UNfloored trial
-      // update (hydro.cpp:1283-1306; floors only act in the ConsToPrim that follows the stage)
-      const bool fill = !(s->fmft && stage == s->nstages) && !s->amr && ghost_c2p_fusable(s);
+      // FirstOrderFluxCorrect tests the UNfloored trial update (hydro.cpp:1283-1306; floors only act
+      // in the ConsToPrim that follows the stage)
+      // (the finishing sweep tests the update it holds in registers, before its own ConsToPrim floors
+      // it; with passive scalars the stored state is tested after the stage, so nothing may floor it)
+      const bool test_in_kernel = pkg.nscalars == 0;
+      const bool fill = !(s->fmft && stage == s->nstages) && !s->amr && (test_in_kernel || ghost_c2p_fusable(s));
       if (fill) SIM_TRY(s, ensure_spare_prim(s));
       apk_stage_args a{};
       a.cfg = cfg;
@@ -699,9 +714,13 @@ int do_stage(apk_sim *s, int stage) {
       a.fill_derived = fill ? 2 : 0;
       a.estimate_dt = (fill && stage == s->nstages && pkg.calc_dt_hyp) ? 1 : 0;
       a.trial = 1;  // its ConsToPrim latches flags into the trial word: kept or dropped below
+      // the finishing sweep applies FirstOrderFluxCorrect's test to the update it has in registers
+      // (passive scalars ride a separate kernel: there the stored state is tested afterwards)
+      a.count_unphysical = test_in_kernel ? 1 : 0;
       SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
       long long bad = 0;
-      SIM_TRY(s, apk_count_unphysical(s->ctx, s->mu0(), pkg.fluid, &bad, s->stream));
+      if (a.count_unphysical) SIM_TRY(s, apk_stage_unphysical_read(s->ctx, &bad, s->stream));
+      else SIM_TRY(s, apk_count_unphysical(s->ctx, s->mu0(), pkg.fluid, &bad, s->stream));
       done = bad == 0;
       if (fill) SIM_TRY(s, apk_trial_flags(s->ctx, done ? 1 : 0, s->stream));
       if (done) {
@@ -909,6 +928,7 @@ void apk_sim_destroy(apk_sim *s) {
     dev_free(s, s->d_coarse);
     for (auto &t : s->x1win) dev_free(s, reinterpret_cast<double *>(t.d));
     for (auto &t : s->dcwin) dev_free(s, reinterpret_cast<double *>(t.d));
+    for (auto &t : s->k3win) dev_free(s, reinterpret_cast<double *>(t.d));
     dev_free(s, reinterpret_cast<double *>(s->d_late_regions));
     dev_free(s, s->d_acc);
     dev_free(s, s->d_phases);

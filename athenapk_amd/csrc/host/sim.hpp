@@ -137,6 +137,7 @@ struct apk_sim {
     bool any = false;  // some block has work in this table
   };
   WindowTable x1win[3], dcwin[7];
+  WindowTable k3win[3];  // two-kernel stages: plane windows of the x3 sweep (main, low slab, high slab)
   unsigned *d_late_regions = nullptr;  // per block: bit (sx+1)+3(sy+1)+9(sz+1) = that neighbour region is filled late
   // mesh refinement (parthenon/mesh/refinement = static | adaptive; one rank): the forest of
   // blocks, the index-box plans of the multilevel ghost exchange / flux correction and their device

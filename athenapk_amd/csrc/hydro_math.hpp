@@ -48,10 +48,14 @@ APK_DEV double sqr(double x) { return x * x; }
 // (results within 1-2 ulp) without the range scaling -- the arguments here are densities,
 // pressures and squared speeds, never denormal -- and hand out the by-products (1/sqrt(x) comes
 // for free with sqrt(x); several quotients share one reciprocal).
-#ifdef APK_FP_STRICT
+#if defined(APK_FP_STRICT) || defined(APK_NO_FAST_SQRT)
+#define APK_PLAIN_SQRT 1
 APK_DEV double fsqrt(double x) { return sqrt(x); }
 APK_DEV double frcp(double x) { return 1.0 / x; }
 #else
+// v_rsq_f64 / v_rcp_f64 deliver roughly 8-10 good bits (hipcc itself follows them with three
+// quadratically converging steps): Goldschmidt + two residual corrections for the root, three
+// Newton steps for a reciprocal.
 APK_DEV void fsqrt_rsqrt(double x, double &root, double &inv_root) {
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
@@ -62,8 +66,11 @@ APK_DEV void fsqrt_rsqrt(double x, double &root, double &inv_root) {
   g = fma(d, h, g);
   d = fma(-g, g, x);
   g = fma(d, h, g);
-  const double rs = h + h;
-  const double e = fma(-g, rs, 1.0);
+  // 1/sqrt(x) from the converged root: two Newton steps on rs -> rs (2 - g rs)
+  double rs = h + h;
+  double e = fma(-g, rs, 1.0);
+  rs = fma(rs, e, rs);
+  e = fma(-g, rs, 1.0);
   root = g;
   inv_root = fma(rs, e, rs);
 }
@@ -82,6 +89,8 @@ APK_DEV double fsqrt(double x) {
 APK_DEV double frcp(double x) {
   double y = __builtin_amdgcn_rcp(x);
   double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
   y = fma(y, e, y);
   e = fma(-x, y, 1.0);
   return fma(y, e, y);
@@ -148,17 +157,15 @@ APK_DEV void plm(double qm1, double q0, double qp1, double &ql, double &qr) {
 // A march keeps face_p of the cell it just reconstructed as face_m of the next one; the x1 sweep
 // passes it one lane to the right.
 APK_DEV double ppm_interface(double qm1, double q0, double qp1, double qp2) {
-#ifdef APK_FP_STRICT
+  // (Both builds evaluate the reference's grouping.  The algebraically equal 4-operation form
+  // (7 (q_i + q_i+1) - (q_i-1 + q_i+2)) / 12 differs in the last bits, which is enough to flip the
+  // extremum tests below on smooth data -- 3e-9 after two cycles of the 256^3 benchmark state, far
+  // outside the 1e-12 agreement with the parity build -- so it is not used.)
   const double da = q0 - qm1;
   const double db = qp1 - q0;
   const double dd_c = 0.5 * db + 0.5 * da;
   const double dd_p = 0.5 * (qp2 - qp1) + 0.5 * db;
   const double face = 0.5 * (q0 + qp1) + APK_DIV6(dd_c - dd_p);
-#else
-  // the same fourth-order value, (7 (q_i + q_i+1) - (q_i-1 + q_i+2)) / 12 (CW eq 1.6), in 4
-  // operations instead of 10; differs from the parity build's grouping in the last bits
-  const double face = (7.0 / 12.0) * (q0 + qp1) - (1.0 / 12.0) * (qm1 + qp2);
-#endif
   // step 2a (:66-98): the limited value only replaces `face` at a local extremum (CD eq 84), so
   // the second differences and the limiter (one division) are evaluated inside that branch only
   const double below = face - q0;
@@ -345,15 +352,13 @@ APK_DEV double fast_speed(double gamma, double d, double p, double bx, double by
   const double ct2 = by * by + bz * bz;
   const double qsq = bx * bx + ct2 + asq;
   const double tmp = bx * bx + ct2 - asq;
-#ifdef APK_FP_STRICT
-  return sqrt(0.5 * (qsq + sqrt(tmp * tmp + 4.0 * asq * ct2)) / d);
-#else
-  // sqrt(x / d) = x / sqrt(x d): one rsq instead of a divide and a root
-  const double x = 0.5 * (qsq + fsqrt(tmp * tmp + 4.0 * asq * ct2));
-  double root, inv_root;
-  fsqrt_rsqrt(x * d, root, inv_root);
-  return x * inv_root;
-#endif
+  // (Kept in the reference's form in both builds, each operation rounded like IEEE's: the HLLD star
+  // states divide by rho (s - v)(s - s*) - Bx^2, which vanishes where the fast speed equals the Alfven
+  // speed (By = Bz = 0), and next to such faces a last-bit difference in c_f is amplified up to the
+  // 1e-8 of the solver's degeneracy threshold.  sqrt(x / d) = x rsqrt(x d) saves a divide per call
+  // and agrees to 6e-16, but moved the 256^3 benchmark state by 1e-10 per cycle against the parity
+  // build along the planes where By and Bz change sign.)
+  return fsqrt(0.5 * (qsq + fsqrt(tmp * tmp + 4.0 * asq * ct2)) / d);
 }
 
 // ======================================================================================
@@ -616,7 +621,7 @@ APK_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 APK_DEV void hlld_star_transverse(const double (&w)[NGLMMHD], const Cons1D &u, double sd, double sdm,
                                   double ptst, double bxi, double bxsq, Cons1D &ust) {
   const double denom = u.d * sd * sdm - bxsq;
-#ifdef APK_FP_STRICT
+#ifdef APK_PLAIN_SQRT
   const double t1 = bxi * (sd - sdm) / denom;
   const double t2 = (u.d * sqr(sd) - bxsq) / denom;
 #else
@@ -681,7 +686,7 @@ APK_DEV void glmmhd_hlld(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD
   const double sdml = s0 - s2;
   const double sdmr = s4 - s2;
   Cons1D ulst, urst;
-#ifdef APK_FP_STRICT
+#ifdef APK_PLAIN_SQRT
   const double sdml_inv = 1.0 / sdml;
   const double sdmr_inv = 1.0 / sdmr;
   ulst.d = ul.d * sdl * sdml_inv;
@@ -780,7 +785,7 @@ APK_DEV void glmmhd_hlld(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD
                                   bxsig * sqrtdl * sqrtdr * ((urst.mz * urst_d_inv) - (ulst.mz * ulst_d_inv)));
     // eqn (63): the bracket is formed with the LEFT double-star momenta on both sides (:289)
     const double dl_my = ulst.d * tmy, dl_mz = ulst.d * tmz;
-#ifdef APK_FP_STRICT
+#ifdef APK_PLAIN_SQRT
     const double tmp_e = s2 * bxi + (dl_my * tby + dl_mz * tbz) / ulst.d;
 #else
     const double tmp_e = s2 * bxi + (dl_my * tby + dl_mz * tbz) * ulst_d_inv;

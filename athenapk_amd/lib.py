@@ -56,7 +56,7 @@ class StageArgs(C.Structure):
                 ("gam1", C.c_double), ("beta_dt", C.c_double), ("dedner", C.c_int),
                 ("glmmhd_alpha", C.c_double), ("mindx", C.c_double), ("fill_derived", C.c_int),
                 ("estimate_dt", C.c_int), ("phase", C.c_int), ("window", C.c_void_p),
-                ("window_rl", C.c_int), ("window_rows", C.c_int), ("trial", C.c_int)]
+                ("window_rl", C.c_int), ("window_rows", C.c_int), ("trial", C.c_int), ("count_unphysical", C.c_int)]
 
 
 class FmftBlock(C.Structure):
@@ -181,6 +181,8 @@ def _signatures():
         "apk_tag_blocks": (i, [vp, vp, i, d, d, C.POINTER(C.c_int), c_dp, vp]),
         "apk_poll_device_flags": (i, [vp, C.POINTER(C.c_uint), vp]),
         "apk_trial_flags": (i, [vp, i, vp]),
+        "apk_stage_split_axis": (i, [vp, vp, i]),
+        "apk_stage_unphysical_read": (i, [vp, C.POINTER(C.c_longlong), vp]),
         "apk_copy_plan_create": (i, [vp, C.POINTER(CopyRegion), i, pp]),
         "apk_copy_plan_destroy": (None, [vp]),
         "apk_copy_plan_run": (i, [vp, vp, vp]),
@@ -255,6 +257,9 @@ SYMBOLS = tuple(_signatures().keys())
 
 
 def lib_path(strict=False):
+    # APK_LIB_PATH: profiling aid, an A/B variant of the product build (csrc/Makefile `variant`)
+    if not strict and os.environ.get("APK_LIB_PATH"):
+        return os.path.abspath(os.environ["APK_LIB_PATH"])
     return os.path.join(_HERE, "libapk_amd_strict.so" if strict else "libapk_amd.so")
 
 

@@ -199,9 +199,26 @@ typedef struct apk_stage_args {
    * separate trial word, which apk_trial_flags() merges into the latched word (keep = 1) or drops
    * (keep = 0).  Flags latched by earlier kernels are never touched by a discarded stage. */
   int trial;
+  /* count_unphysical = 1: the finishing sweep also applies FirstOrderFluxCorrect's admissibility
+   * test (hydro.cpp:1297-1306: rho <= 0 or E - KE [- ME] <= 0) to every updated cell BEFORE any
+   * floor acts (and, with fill_derived, counts cells whose ConsToPrim latched a flag); read the
+   * number of failing cells with apk_stage_unphysical_read().  Not with passive scalars. */
+  int count_unphysical;
 } apk_stage_args;
 int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
                     const apk_stage_args *args, apk_stream_t stream);
+/* Which ghost zones phase 1 of a split stage does NOT need, i.e. how its windows are laid out:
+ *   1  the x1 sweep is its own kernel: column windows, late x1 faces matter (see `phase` above)
+ *   3  two-kernel stage (3-D, reconstruction with a stencil, fill_derived 0 or 2, meshblocks at
+ *      least 32 cells wide): phase 1 is the x3 sweep, which writes its flux difference and reads x3
+ *      ghost zones only -- windows {0, Ni, is, ie, js, je, klo, khi} select whole planes klo..khi,
+ *      late x3 faces matter; phase 2 is ONE march doing x1 + x2 and finishing the stage
+ *   0  3-D donor-cell stage: one kernel for the whole stage, 3-D index windows
+ * The two-kernel form moves 8.6 GB instead of 13.2 GB per PPM + HLLD stage of 8 x 128^3. */
+/* number of cells that failed the test of the last apk_stage_fused(count_unphysical = 1);
+ * synchronises the stream */
+int apk_stage_unphysical_read(apk_ctx *ctx, long long *count, apk_stream_t stream);
+int apk_stage_split_axis(const apk_pack *u0, const apk_flux_cfg *cfg, int fill_derived);
 
 /* Replaces EquationOfState::ConservedToPrimitive(MeshData<Real>*) over the ENTIRE block
  * src/eos/adiabatic_hydro.cpp:33-55, adiabatic_glmmhd.cpp:33-56 (pkg->FillDerivedMesh,

@@ -499,6 +499,56 @@ def test_fused_stage_split_around_exchange(request, oracle, fluid, recon, rieman
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("fluid,recon,riemann,nx,gam0", [("glmmhd", "ppm", "hlld", (70, 9, 14), 0.0),
+                                                        ("glmmhd", "wenoz", "hlld", (64, 8, 13), 0.5),
+                                                        ("euler", "plm", "hllc", (40, 10, 9), 0.5)])
+def test_two_kernel_stage_split_on_plane_windows(request, oracle, fluid, recon, riemann, nx, gam0, strict):
+    """The two-kernel 3-D stage (x3 sweep writing its flux difference, then ONE march doing x1 + x2 and
+    finishing; apk_stage_split_axis == 3): unsplit == oracle, and phase 1 on plane windows (all planes
+    farther than nghost from a 'remote' x3 face, then the slabs) + phase 2 == unsplit, bit for bit."""
+    import ctypes as C
+    import torch
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    ng, prim, g = _case(fluid, recon, nx, kind="smooth", seed=59, nblocks=3)
+    cons = H.prim_to_cons(fluid, prim, GAMMA)
+    ded = 1 if fluid == "glmmhd" else 0
+    eos = hydro.L.make_eos(GAMMA)
+    gam1 = 1.0 - gam0 if gam0 else 1.0
+    kw = dict(dedner=ded, glmmhd_alpha=0.1, mindx=0.07, fill_derived=2, estimate_dt=True)
+    sentinel = np.full_like(prim, -7.0)
+
+    def packs():
+        a = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=cons, prim=prim, with_flux=False)
+        b = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=cons * 1.01, prim=sentinel, with_flux=False)
+        return a, b
+    r0, r1 = packs()
+    cfg = hydro._cfg(fluid, recon, riemann)
+    assert ctx.lib.apk_stage_split_axis(r0.h, C.byref(cfg), 2) == 3      # this IS the two-kernel form
+    hydro.StageFused(r0, r1, fluid, recon, riemann, eos, C_H, gam0, gam1, 0.004, **kw)
+    dt_ref = hydro.StageDt(ctx, 0.3)
+    want = H.orc_stage(fluid, recon, riemann, g, cons, cons * 1.01, prim, GAMMA, C_H, gam0, gam1, 0.004, dedner=ded,
+                       alpha=0.1, mindx=0.07)
+    _cmp(H.interior(r0.cons_host(), nx, ng), H.interior(want, nx, ng), strict, "cons")
+    assert np.all(H.interior(r1.prim_host(), nx, ng) != -7.0)            # FillDerived went out of place, everywhere
+    m0, m1 = packs()
+    is_, ie, ni, W = ng, ng + nx[0] - 1, nx[0] + 2 * ng, ng
+    js, je, ks, ke = ng, ng + nx[1] - 1, ng, ng + nx[2] - 1
+    missing = [(1, 0), (0, 1), (1, 1)]   # block 0: data missing below, block 1: above, block 2: both
+    main = [[0, ni, is_, ie, js, je, ks + W * lo, ke - W * hi] for lo, hi in missing]
+    slab_lo = [[0, ni if lo else 0, is_, ie, js, je, ks, ks + W - 1] for lo, hi in missing]
+    slab_hi = [[0, ni if hi else 0, is_, ie, js, je, ke - W + 1, ke] for lo, hi in missing]
+    for win in (main, slab_lo, slab_hi):
+        t = torch.tensor(win, dtype=torch.int32, device="cuda")
+        hydro.StageFused(m0, m1, fluid, recon, riemann, eos, C_H, gam0, gam1, 0.004, phase=1, window=t, **kw)
+    hydro.StageFused(m0, m1, fluid, recon, riemann, eos, C_H, gam0, gam1, 0.004, phase=2, **kw)
+    assert np.array_equal(m0.cons_host(), r0.cons_host())
+    assert np.array_equal(H.interior(m1.prim_host(), nx, ng), H.interior(r1.prim_host(), nx, ng))
+    assert hydro.StageDt(ctx, 0.3) == dt_ref
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
 @pytest.mark.parametrize("fluid,riemann,nx", [("glmmhd", "hlld", (64, 10, 34)), ("euler", "hllc", (66, 9, 7))])
 def test_donor_cell_stage_split_around_exchange(request, oracle, fluid, riemann, nx, strict):
     """The single-kernel 3-D donor-cell stage on index windows: everything but the one-cell layers

@@ -69,6 +69,19 @@ CASES = {
                            ng=3, bc=("reflecting", "reflecting", "periodic"), xmin=(0.0, 0.0, -0.5),
                            xmax=(0.3, 0.3, 0.5), cfl=0.4, gamma=1.4), "lw_implode", {}, 40),
 }
+# meshblocks wide enough (nx1 >= 32) for the two-kernel stage: the split runs the x3 sweep on plane
+# windows while the halo messages fly, then the finishing x1 + x2 march (apk_stage_split_axis == 3)
+CASES["mhd_ppm_two_kernel"] = ("synthetic_mhd",
+                               ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=32",
+                                "parthenon/meshblock/nx1=32", "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=16"],
+                               dict(fluid="glmmhd", recon="ppm", riemann="hlld", integrator="vl2", nx=(64, 32, 32),
+                                    mb=(32, 16, 16), ng=3, cfl=0.3, gamma=1.666666666666667), "synthetic", {}, 3)
+CASES["mhd_wenoz_rk3_two_kernel"] = ("synthetic_mhd",
+                                     ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=32",
+                                      "parthenon/meshblock/nx1=32", "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=16",
+                                      "parthenon/time/integrator=rk3", "hydro/reconstruction=wenoz"],
+                                     dict(fluid="glmmhd", recon="wenoz", riemann="hlld", integrator="rk3", nx=(64, 32, 32),
+                                          mb=(32, 16, 16), ng=3, cfl=0.3, gamma=1.666666666666667), "synthetic", {}, 2)
 # the layout of the 8-GPU benchmark in small: 64 meshblocks, a 2x2x2 brick of them per rank, 7 peers
 CASES["mhd_8_ranks"] = ("synthetic_mhd",
                         ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "parthenon/mesh/nx3=64",
