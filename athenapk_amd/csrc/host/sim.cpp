@@ -337,7 +337,7 @@ int exchange_begin(apk_sim *s, bool async, bool c2p) {
   if (remote) {
     if (!s->have_comm || !s->comm.exchange) return fail(s, APK_ERR_INVALID, "remote neighbours but no comm ops");
     if (async) {
-      if (s->comm.exchange_begin(s->comm.user) != 0) return fail(s, APK_ERR_DEVICE, "halo exchange (begin) failed");
+      if (s->comm.exchange_begin(s->comm.user) != 0) return fail(s, APK_ERR_DEVICE, std::string("halo exchange (begin) failed ") + apk_sim_comm_error(s));
       s->exchange_pending = true;
       s->pending_cons = s->cur;
       s->pending_c2p = c2p;
@@ -353,7 +353,7 @@ int exchange_end(apk_sim *s, bool c2p) {
   // first stage of the next cycle has swapped the buffer roles by the time it completes it
   const int buf = s->exchange_pending ? s->pending_cons : s->cur;
   if (s->exchange_pending) {
-    if (s->comm.exchange_end(s->comm.user) != 0) return fail(s, APK_ERR_DEVICE, "halo exchange (end) failed");
+    if (s->comm.exchange_end(s->comm.user) != 0) return fail(s, APK_ERR_DEVICE, std::string("halo exchange (end) failed ") + apk_sim_comm_error(s));
     s->exchange_pending = false;
   }
   if (!s->mesh.peers.empty()) SIM_TRY(s, run_ghost_plan(s, buf, PH_UNPACK, c2p));
@@ -863,7 +863,9 @@ int apk_sim_create(const char *deck, const char *const *overrides, int noverride
     s->comm = *comm;
     s->have_comm = true;
   }
-  if (nranks > 1 && !(comm && comm->exchange && comm->allreduce_min && comm->allreduce_sum)) {
+  // (comm == NULL with nranks > 1: the native RCCL transport is attached by apk_sim_comm_rccl
+  // before apk_sim_initialize, which checks)
+  if (nranks > 1 && comm && !(comm->exchange && comm->allreduce_min && comm->allreduce_sum)) {
     s->err = "nranks > 1 requires comm ops";
     return bail(APK_ERR_INVALID);
   }
@@ -913,6 +915,8 @@ void apk_sim_destroy(apk_sim *s) {
   if (!s->host_only) {
     if (s->exchange_pending && s->comm.exchange_end) (void)s->comm.exchange_end(s->comm.user);  // drain
     (void)hipDeviceSynchronize();
+    rccl_transport_destroy(s->rccl);
+    s->rccl = nullptr;
     for (auto &pp : s->plans_of)
       for (auto &p : pp) apk_copy_plan_destroy(p);
     for (int p = 0; p < 2; ++p)
@@ -969,6 +973,8 @@ long long apk_sim_loop_zone_cycles(const apk_sim *s) { return s ? s->zone_cycles
 int apk_sim_initialize(apk_sim *s) {
   if (!s || s->host_only) return APK_ERR_INVALID;
   s->err.clear();
+  if (s->nranks > 1 && !(s->have_comm && s->comm.exchange && s->comm.allreduce_min && s->comm.allreduce_sum))
+    return fail(s, APK_ERR_INVALID, "nranks > 1 requires comm ops (apk_sim_create) or the native transport (apk_sim_comm_rccl)");
   SIM_TRY(s, finish_pending(s));
   const int nlb = (int)s->mesh.local_gids.size();
   std::vector<double> host((size_t)s->nper);

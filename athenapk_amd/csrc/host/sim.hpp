@@ -61,7 +61,15 @@ struct FieldLoopState {  // parameters of src/pgen/field_loop.cpp:129-170; B0 no
 
 }  // namespace apk
 
+namespace apk {
+namespace host {
+struct RcclTransport;  // comm_rccl.cpp
+void rccl_transport_destroy(RcclTransport *t);
+}  // namespace host
+}  // namespace apk
+
 struct apk_sim {
+  apk::host::RcclTransport *rccl = nullptr;  // native transport (apk_sim_comm_rccl); comm.* point into it
   apk::ParameterInput pin;
   apk::Mesh mesh;
   apk::HydroPackage pkg;

@@ -5,6 +5,8 @@ per-stage halo exchange and the tiny min/sum all-reduces (src/hydro/hydro.cpp:12
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import torch
 
@@ -173,9 +175,18 @@ class Simulation(_FmftHost, _MeshView):
     """apk_sim: deck + overrides -> mesh partition, packs, ghost plans, stage loop (C++)."""
 
     def __init__(self, deck, overrides=(), rank=0, nranks=1, strict=False, use_torch_alloc=True,
-                 group=None):
+                 group=None, comm=None):
+        """comm (nranks > 1): "rccl" = the native transport of the C++ host (grouped ncclSend /
+        ncclRecv on its own HIP stream, csrc/host/comm_rccl.cpp; one GPU per rank; torch.distributed
+        only carries the 256-byte bootstrap ids), "torch" = callbacks into torch.distributed
+        (any backend; the way several ranks can share one GPU through gloo for tests).  Default:
+        APK_COMM, else "rccl" when the process group's backend is nccl, else "torch"."""
         self.lib = L.load(strict)
         self.rank, self.nranks = rank, nranks
+        if nranks > 1 and comm is None:
+            import torch.distributed as dist
+            comm = os.environ.get("APK_COMM") or ("rccl" if dist.get_backend(group) == "nccl" else "torch")
+        self.comm_kind = comm if nranks > 1 else None
         self._tensors = {}   # ptr -> tensor (keeps allocations alive)
         self._by_tag = {}
         self._group = group
@@ -185,7 +196,7 @@ class Simulation(_FmftHost, _MeshView):
         # communicator they would queue behind halo messages that are still in flight and make the
         # host wait for them, which is exactly what the overlap avoids.
         red_group = group
-        if nranks > 1:
+        if nranks > 1 and self.comm_kind == "torch":
             import torch.distributed as dist
             if dist.get_backend(group) != "gloo":
                 red_group = dist.new_group(backend="gloo")
@@ -260,10 +271,33 @@ class Simulation(_FmftHost, _MeshView):
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         rc = self.lib.apk_sim_create(deck.encode(), ov, len(overrides), rank, nranks,
                                      C.byref(allocator) if use_torch_alloc else None,
-                                     C.byref(comm) if nranks > 1 else None, stream, C.byref(h), err, len(err))
+                                     C.byref(comm) if (nranks > 1 and self.comm_kind == "torch") else None, stream,
+                                     C.byref(h), err, len(err))
         if rc != L.APK_OK:
             raise L.ApkError(rc, err.value.decode())
         self.h = h
+        if self.comm_kind == "rccl":
+            # bootstrap: rank 0 makes the two ncclUniqueIds, torch.distributed hands them round
+            import torch.distributed as dist
+            ids = C.create_string_buffer(2 * L.APK_RCCL_ID_BYTES)
+            if dist.get_rank(group) == 0:
+                self._check(self.lib.apk_rccl_unique_ids(ids, len(ids)))
+            box = [ids.raw]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            rc = self.lib.apk_sim_comm_rccl(self.h, box[0], len(box[0]))
+            # every rank must end up on the same transport: if the native one could not start anywhere
+            # (no librccl, communicator creation failed), all ranks fall back to the callbacks -- loudly
+            okt = torch.tensor([1 if rc == L.APK_OK else 0], dtype=torch.int32,
+                               device=dev if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=group)
+            if int(okt.item()) == 0:
+                import sys
+                why = self.lib.apk_sim_last_error(self.h).decode()
+                print("[athenapk_amd] rank %d: native RCCL transport unavailable (%s); using torch.distributed callbacks"
+                      % (rank, why or "failed on another rank"), file=sys.stderr, flush=True)
+                self.close()
+                self.__init__(deck, overrides, rank, nranks, strict, use_torch_alloc, group, comm="torch")
+                return
         self.info = L.SimInfo()
         self._check(self.lib.apk_sim_get_info(self.h, C.byref(self.info)))
         self._current_halo()

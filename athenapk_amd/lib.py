@@ -21,6 +21,7 @@ TIMING_SLOTS = ("fused_x1", "fused_x2", "fused_x3", "fluxes", "update", "dedner"
                 "min_dt", "copy_regions", "fused_dc_x1", "fused_dc_x2", "fused_dc_x3")
 
 APK_OK = 0
+APK_RCCL_ID_BYTES = 128
 APK_ERR_INVALID, APK_ERR_UNSUPPORTED, APK_ERR_NGHOST, APK_ERR_DEVICE, APK_ERR_NO_DEVICE = -1, -2, -3, -4, -5
 FLAG_NEG_DENSITY, FLAG_NEG_PRESSURE = 1, 2
 
@@ -249,6 +250,11 @@ def _signatures():
         "apk_sim_block_level": (i, [vp, i]),
         "apk_sim_amr_stats": (i, [vp, C.POINTER(ll), C.POINTER(ll), C.POINTER(i), C.POINTER(ll)]),
         "apk_sim_regrid": (i, [vp, C.POINTER(i)]),
+        "apk_rccl_unique_ids": (i, [C.c_char_p, C.c_size_t]),
+        "apk_sim_comm_rccl": (i, [vp, C.c_char_p, C.c_size_t]),
+        "apk_sim_comm_stats": (i, [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+        "apk_sim_comm_error": (C.c_char_p, [vp]),
+        "apk_rccl_selftest": (i, [i, C.c_char_p, C.c_size_t]),
         "apk_sim_amr_apply_tags": (i, [vp, C.POINTER(i), i, C.POINTER(i)]),
     }
 

@@ -63,6 +63,26 @@ int apk_sim_create(const char *deck, const char *const *overrides, int noverride
 void apk_sim_destroy(apk_sim *sim);
 const char *apk_sim_last_error(const apk_sim *sim);
 
+/* ---- native RCCL transport (csrc/host/comm_rccl.cpp) -------------------------------------
+ * Instead of callbacks the driver can move its messages itself: grouped ncclSend / ncclRecv per
+ * peer on a dedicated halo stream (overlapped with compute through events), ncclAllReduce on a second
+ * communicator for the per-cycle reductions.  Create the sim with comm = NULL and nranks > 1, then:
+ *   rank 0:    apk_rccl_unique_ids(ids, sizeof ids)      two ncclUniqueIds (2 x 128 bytes)
+ *   launcher:  broadcast `ids` to all ranks (torch.distributed / MPI / a file)
+ *   all ranks: apk_sim_comm_rccl(sim, ids, sizeof ids)    (collective: ncclCommInitRank)
+ * before apk_sim_initialize.  One GPU per rank (RCCL refuses two ranks on one device).
+ * Replaces Parthenon's boundary communication (hydro_driver.cpp:506, 567-568) and the
+ * MPI_Allreduce calls of the package (hydro.cpp:127-128). */
+#define APK_RCCL_ID_BYTES 128
+int apk_rccl_unique_ids(char *ids, size_t len);
+int apk_sim_comm_rccl(apk_sim *sim, const char *ids, size_t len);
+/* exchanges posted / reductions done by the native transport so far */
+int apk_sim_comm_stats(const apk_sim *sim, long long *exchanges, long long *reductions);
+const char *apk_sim_comm_error(const apk_sim *sim);
+/* one-rank exercise of the transport on the current device (n doubles sent to self, min / sum
+ * reductions); writes "ok" or the failure into msg */
+int apk_rccl_selftest(int n, char *msg, size_t len);
+
 /* host-only mode: builds mesh / partition / ghost plans without touching a GPU (used by the
  * CPU tests of the host logic and the world_size-2 gloo tests). */
 int apk_sim_create_host_only(const char *deck, const char *const *overrides, int noverrides,
