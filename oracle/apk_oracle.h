@@ -256,4 +256,44 @@ int orc_tag_velocity_gradient(const orc_geom *g, const double *prim, double thre
 int orc_tag_max_density(const orc_geom *g, const double *prim, double refine_above, double deref_below,
                         double *crit);
 
+
+/* ---- branch tracing (test infrastructure for the crafted edge-case fixture) ---------------------
+ * When orc_trace_sink points at a word, the pointwise functions OR the bits of the branches they
+ * take into it.  tests/golden/make_edge_cases.py records, per crafted case, which of the
+ * reference's special-case branches it exercises. */
+enum {
+  ORC_TR_PPM_LIM_M = 1 << 0,     /* step 2a replaced the lower interface value (ppm_simple.hpp:66-80) */
+  ORC_TR_PPM_LIM_P = 1 << 1,     /* ... the upper one (:82-98) */
+  ORC_TR_PPM_EXTREMUM = 1 << 2,  /* local extremum branch of step 4 (:139) */
+  ORC_TR_PPM_ROUNDOFF = 1 << 3,  /* second derivative within 1e-12 of round-off: ratio forced to 0 (:129-136) */
+  ORC_TR_PPM_RATIO_BIG = 1 << 4, /* extremum kept because the limited ratio is ~1 (:141) */
+  ORC_TR_PPM_OVER_M = 1 << 5,    /* overshoot limiter on the lower state (:150) */
+  ORC_TR_PPM_OVER_P = 1 << 6,    /* ... on the upper state (:154) */
+  ORC_TR_HLLD_FL = 1 << 8,       /* returned F_L (s0 >= 0) */
+  ORC_TR_HLLD_FR = 1 << 9,       /* F_R (s4 <= 0) */
+  ORC_TR_HLLD_LSTAR = 1 << 10,
+  ORC_TR_HLLD_LDSTAR = 1 << 11,
+  ORC_TR_HLLD_RDSTAR = 1 << 12,
+  ORC_TR_HLLD_RSTAR = 1 << 13,
+  ORC_TR_HLLD_DEG_L = 1 << 14,   /* degenerate left star state (glmmhd_hlld.hpp:196-202) */
+  ORC_TR_HLLD_DEG_R = 1 << 15,   /* degenerate right star state (:228-234) */
+  ORC_TR_HLLD_DEG_DST = 1 << 16, /* Bx ~ 0: double-star states = star states (:252-255) */
+  ORC_TR_HLLC_AM_POS = 1 << 18,  /* contact moves right (hydro_hllc.hpp:126) */
+  ORC_TR_HLLC_CP_CLIP = 1 << 19, /* contact pressure clipped to 0 (:112) */
+  ORC_TR_HLLC_QL = 1 << 20,      /* left shock correction q_l > 1 (:63) */
+  ORC_TR_HLLC_QR = 1 << 21,
+  ORC_TR_HLLE_BP_EQ_BM = 1 << 22, /* bp == bm: no averaging weight (hydro_hlle.hpp:127, glmmhd_hlle.hpp:180) */
+  ORC_TR_C2P_DFLOOR = 1 << 24,
+  ORC_TR_C2P_VCEIL = 1 << 25,
+  ORC_TR_C2P_PFLOOR = 1 << 26,
+  ORC_TR_C2P_EFLOOR = 1 << 27,
+  ORC_TR_C2P_ECEIL = 1 << 28
+};
+extern __thread unsigned *orc_trace_sink;
+#define ORC_TRACE(bit) do { if (orc_trace_sink) *orc_trace_sink |= (unsigned)(bit); } while (0)
+void orc_recon_many_traced(int recon, long m, const double *q5, double dx, int n, double *ql, double *qr, unsigned *masks);
+void orc_c2p_many_traced(int fluid, const orc_eos *eos, long m, double *u, double *w, int *status, unsigned *masks);
+void orc_riemann_many_traced(int fluid, int riemann, int ivx, long m, const double *wl, const double *wr, double gamma,
+                             double c_h, double *flux, unsigned *masks);
+
 #endif /* APK_ORACLE_H_ */

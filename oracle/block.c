@@ -318,6 +318,7 @@ int orc_cons_to_prim_cell(int fluid, const orc_eos *eos, int nhydro, int nscalar
   const double gm1 = eos->gamma - 1.0;
   const int mhd = (fluid == ORC_FLUID_GLMMHD);
   if (!(u[ORC_IDN] > 0.0 || eos->dfloor > 0.0)) status = 1;
+  if (!(u[ORC_IDN] > eos->dfloor)) ORC_TRACE(ORC_TR_C2P_DFLOOR);
   u[ORC_IDN] = (u[ORC_IDN] > eos->dfloor) ? u[ORC_IDN] : eos->dfloor;
   w[ORC_IDN] = u[ORC_IDN];
   const double di = 1.0 / u[ORC_IDN];
@@ -340,6 +341,7 @@ int orc_cons_to_prim_cell(int fluid, const orc_eos *eos, int nhydro, int nscalar
   }
   const double v2 = sq(w[ORC_IV1]) + sq(w[ORC_IV2]) + sq(w[ORC_IV3]);
   if (v2 > sq(eos->vceil)) {
+    ORC_TRACE(ORC_TR_C2P_VCEIL);
     const double v = sqrt(v2);
     w[ORC_IV1] *= eos->vceil / v;
     w[ORC_IV2] *= eos->vceil / v;
@@ -356,16 +358,19 @@ int orc_cons_to_prim_cell(int fluid, const orc_eos *eos, int nhydro, int nscalar
   }
   /* the reference writes (p/gm1) + e_k [+ e_B]: left-to-right addition */
   if ((eos->pfloor > 0.0) && (w[ORC_IPR] < eos->pfloor)) {
+    ORC_TRACE(ORC_TR_C2P_PFLOOR);
     u[ORC_IEN] = mhd ? (eos->pfloor / gm1) + e_k + e_B : (eos->pfloor / gm1) + e_k;
     w[ORC_IPR] = eos->pfloor;
   }
   const double eff_floor = gm1 * u[ORC_IDN] * eos->efloor;
   if (w[ORC_IPR] < eff_floor) {
+    ORC_TRACE(ORC_TR_C2P_EFLOOR);
     u[ORC_IEN] = mhd ? (u[ORC_IDN] * eos->efloor) + e_k + e_B : (u[ORC_IDN] * eos->efloor) + e_k;
     w[ORC_IPR] = eff_floor;
   }
   const double eff_ceil = gm1 * u[ORC_IDN] * eos->eceil;
   if (w[ORC_IPR] > eff_ceil) {
+    ORC_TRACE(ORC_TR_C2P_ECEIL);
     u[ORC_IEN] = mhd ? (u[ORC_IDN] * eos->eceil) + e_k + e_B : (u[ORC_IDN] * eos->eceil) + e_k;
     w[ORC_IPR] = eff_ceil;
   }
@@ -523,4 +528,16 @@ void orc_history(const orc_geom *g, int fluid, const double *cons, double *out) 
                                  : 0;
         }
       }
+}
+
+
+/* ConsToPrim of m cells given as [m][nhydro] rows, with the branch mask of each (apk_oracle.h) */
+void orc_c2p_many_traced(int fluid, const orc_eos *eos, long m, double *u, double *w, int *status, unsigned *masks) {
+  const int nh = (fluid == ORC_FLUID_EULER) ? ORC_NHYDRO : ORC_NGLMMHD;
+  for (long s = 0; s < m; ++s) {
+    masks[s] = 0u;
+    orc_trace_sink = masks + s;
+    status[s] = orc_cons_to_prim_cell(fluid, eos, nh, 0, u + nh * s, w + nh * s);
+  }
+  orc_trace_sink = 0;
 }

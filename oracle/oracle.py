@@ -84,6 +84,9 @@ def _declare(lib):
     sig = {
         "orc_recon_many": (None, [i, l, p, d, i, p, p]),
         "orc_riemann_many": (None, [i, i, i, l, p, p, d, d, p]),
+        "orc_recon_many_traced": (None, [i, l, p, d, i, p, p, C.POINTER(C.c_uint)]),
+        "orc_riemann_many_traced": (None, [i, i, i, l, p, p, d, d, p, C.POINTER(C.c_uint)]),
+        "orc_c2p_many_traced": (None, [i, E, l, p, p, C.POINTER(C.c_int), C.POINTER(C.c_uint)]),
         "orc_sound_speed": (d, [d, d, d]),
         "orc_fast_speed": (d, [d, d, d, d, d, d]),
         "orc_cons_to_prim_cell": (i, [i, E, i, i, p, p]),
@@ -192,6 +195,52 @@ def riemann_many(fluid, riemann, ivx, wl, wr, gamma, c_h=0.0, lib=None):
     lib.orc_riemann_many(FLUID[fluid], RIEMANN[riemann], ivx, wl.shape[0], dp(wl), dp(wr),
                          gamma, c_h, dp(out))
     return out
+
+
+TRACE_BITS = {"ppm_lim_m": 1 << 0, "ppm_lim_p": 1 << 1, "ppm_extremum": 1 << 2, "ppm_roundoff": 1 << 3,
+              "ppm_ratio_big": 1 << 4, "ppm_over_m": 1 << 5, "ppm_over_p": 1 << 6,
+              "hlld_fl": 1 << 8, "hlld_fr": 1 << 9, "hlld_lstar": 1 << 10, "hlld_ldstar": 1 << 11, "hlld_rdstar": 1 << 12,
+              "hlld_rstar": 1 << 13, "hlld_deg_l": 1 << 14, "hlld_deg_r": 1 << 15, "hlld_deg_dst": 1 << 16,
+              "hllc_am_pos": 1 << 18, "hllc_cp_clip": 1 << 19, "hllc_ql": 1 << 20, "hllc_qr": 1 << 21,
+              "hlle_bp_eq_bm": 1 << 22, "c2p_dfloor": 1 << 24, "c2p_vceil": 1 << 25, "c2p_pfloor": 1 << 26,
+              "c2p_efloor": 1 << 27, "c2p_eceil": 1 << 28}
+
+
+def trace_names(mask):
+    return [k for k, b in TRACE_BITS.items() if mask & b]
+
+
+def recon_many_traced(recon, q, dx=1.0, n=0, lib=None):
+    """(ql, qr, branch masks) -- the reference's special-case branches each stencil takes (apk_oracle.h)"""
+    lib = lib or load()
+    q = np.ascontiguousarray(q, dtype=np.float64).reshape(-1, 5)
+    m = q.shape[0]
+    ql, qr, masks = np.empty(m), np.empty(m), np.zeros(m, dtype=np.uint32)
+    lib.orc_recon_many_traced(RECON[recon], m, dp(q), dx, n, dp(ql), dp(qr), masks.ctypes.data_as(C.POINTER(C.c_uint)))
+    return ql, qr, masks
+
+
+def riemann_many_traced(fluid, riemann, ivx, wl, wr, gamma, c_h=0.0, lib=None):
+    lib = lib or load()
+    nv = 5 if fluid == "euler" else 9
+    wl = np.ascontiguousarray(wl, dtype=np.float64).reshape(-1, nv)
+    wr = np.ascontiguousarray(wr, dtype=np.float64).reshape(-1, nv)
+    out, masks = np.empty_like(wl), np.zeros(wl.shape[0], dtype=np.uint32)
+    lib.orc_riemann_many_traced(FLUID[fluid], RIEMANN[riemann], ivx, wl.shape[0], dp(wl), dp(wr), gamma, c_h, dp(out),
+                                masks.ctypes.data_as(C.POINTER(C.c_uint)))
+    return out, masks
+
+
+def c2p_many_traced(fluid, eos, u, lib=None):
+    """ConsToPrim of rows [m][nhydro]: (u after floors, w, status, branch masks)"""
+    lib = lib or load()
+    nv = 5 if fluid == "euler" else 9
+    u = np.array(u, dtype=np.float64).reshape(-1, nv).copy()
+    w = np.empty_like(u)
+    st, masks = np.zeros(u.shape[0], dtype=np.int32), np.zeros(u.shape[0], dtype=np.uint32)
+    lib.orc_c2p_many_traced(FLUID[fluid], C.byref(eos), u.shape[0], dp(u), dp(w), st.ctypes.data_as(C.POINTER(C.c_int)),
+                            masks.ctypes.data_as(C.POINTER(C.c_uint)))
+    return u, w, st, masks
 
 
 def integrator_coeffs(name, lib=None):

@@ -30,7 +30,7 @@ void orc_plm(double qm1, double q0, double qp1, double *ql_ip1, double *qr_i) {
  * blocks of the reference are the same arithmetic on (lo,hi) = (q_im1,q_i) resp.
  * (q_i,q_ip1).  Returns the possibly limited interface value. */
 static double ppm_limit_interface(double qlo, double qhi, double face, double d2lo,
-                                  double d2hi) {
+                                  double d2hi, unsigned trace_bit) {
   const double C2 = 1.25;
   const double below = face - qlo; /* (CD eq 84a) */
   const double above = qhi - face; /* (CD eq 84b) */
@@ -40,7 +40,10 @@ static double ppm_limit_interface(double qlo, double qhi, double face, double d2
     lim = sgn(d2f) * dmin(C2 * fabs(d2lo), dmin(C2 * fabs(d2hi), fabs(d2f)));
   }
   const double alt = 0.5 * (qlo + qhi) - lim / 6.0;
-  if (below * above < 0.0) return alt; /* local extremum at this face */
+  if (below * above < 0.0) {
+    ORC_TRACE(trace_bit);
+    return alt; /* local extremum at this face */
+  }
   return face;
 }
 
@@ -61,8 +64,8 @@ void orc_ppm(double qm2, double qm1, double q0, double qp1, double qp2, double *
   const double d2_m = qm2 + q0 - 2.0 * qm1;
   const double d2_c = qm1 + qp1 - 2.0 * q0;
   const double d2_p = q0 + qp2 - 2.0 * qp1;
-  face_m = ppm_limit_interface(qm1, q0, face_m, d2_m, d2_c);
-  face_p = ppm_limit_interface(q0, qp1, face_p, d2_c, d2_p);
+  face_m = ppm_limit_interface(qm1, q0, face_m, d2_m, d2_c, ORC_TR_PPM_LIM_M);
+  face_p = ppm_limit_interface(q0, qp1, face_p, d2_c, d2_p, ORC_TR_PPM_LIM_P);
 
   const double d2_face = 6.0 * (face_m + face_p - 2.0 * q0);
 
@@ -86,6 +89,7 @@ void orc_ppm(double qm2, double qm1, double q0, double qp1, double qp2, double *
   const double scale_hi = dmax(dmax(fabs(q0), fabs(qp1)), fabs(qp2));
   double ratio = 0.0;
   if (fabs(d2_face) > (1.0e-12) * dmax(scale_lo, scale_hi)) ratio = d2lim / d2_face;
+  else if (ext_a <= 0.0 || ext_b <= 0.0) ORC_TRACE(ORC_TR_PPM_ROUNDOFF);
 
   const double ext_m = q0 - ratio * dminus;
   const double ext_p = q0 + ratio * dplus;
@@ -93,13 +97,22 @@ void orc_ppm(double qm2, double qm1, double q0, double qp1, double qp2, double *
   const double over_p = q0 + 2.0 * dminus;
 
   if (ext_a <= 0.0 || ext_b <= 0.0) {
+    ORC_TRACE(ORC_TR_PPM_EXTREMUM);
     if (ratio <= (1.0 - (1.0e-12))) {
       qr = ext_m;
       ql = ext_p;
+    } else {
+      ORC_TRACE(ORC_TR_PPM_RATIO_BIG);
     }
   } else {
-    if (fabs(dminus) >= 2.0 * fabs(dplus)) qr = over_m;
-    if (fabs(dplus) >= 2.0 * fabs(dminus)) ql = over_p;
+    if (fabs(dminus) >= 2.0 * fabs(dplus)) {
+      ORC_TRACE(ORC_TR_PPM_OVER_M);
+      qr = over_m;
+    }
+    if (fabs(dplus) >= 2.0 * fabs(dminus)) {
+      ORC_TRACE(ORC_TR_PPM_OVER_P);
+      ql = over_p;
+    }
   }
   *ql_ip1 = ql;
   *qr_i = qr;
@@ -243,4 +256,16 @@ void orc_recon_point(int recon, const double q[5], double dx, int n, double *ql_
 void orc_recon_many(int recon, long m, const double *q, double dx, int n, double *ql_ip1,
                     double *qr_i) {
   for (long s = 0; s < m; ++s) orc_recon_point(recon, q + 5 * s, dx, n, ql_ip1 + s, qr_i + s);
+}
+
+
+/* ---- branch tracing (apk_oracle.h) */
+__thread unsigned *orc_trace_sink = 0;
+void orc_recon_many_traced(int recon, long m, const double *q5, double dx, int n, double *ql, double *qr, unsigned *masks) {
+  for (long s = 0; s < m; ++s) {
+    masks[s] = 0u;
+    orc_trace_sink = masks + s;
+    orc_recon_many(recon, 1, q5 + 5 * s, dx, n, ql + s, qr + s);
+  }
+  orc_trace_sink = 0;
 }

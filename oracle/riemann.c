@@ -122,6 +122,7 @@ static void hydro_hlle(const double *wl, const double *wr, double gamma, double 
 
   double tmp = 0.0;
   if (bp != bm) tmp = 0.5 * (bp + bm) / (bp - bm);
+  else ORC_TRACE(ORC_TR_HLLE_BP_EQ_BM);
   for (int n = 0; n < ORC_NHYDRO; ++n) f[n] = 0.5 * (fl[n] + fr[n]) + (fl[n] - fr[n]) * tmp;
 }
 
@@ -165,6 +166,9 @@ static void hydro_hllc(const double *wl, const double *wr, double gamma, double 
   const double mr = -(wr[ORC_IDN] * vxr);
   const double am = (tl - tr) / (ml + mr);
   double cp = (ml * tr + mr * tl) / (ml + mr);
+  if (!(cp > 0.0)) ORC_TRACE(ORC_TR_HLLC_CP_CLIP);
+  if (ql != 1.0) ORC_TRACE(ORC_TR_HLLC_QL);
+  if (qr != 1.0) ORC_TRACE(ORC_TR_HLLC_QR);
   cp = cp > 0.0 ? cp : 0.0;
 
   vxl = wl[ORC_IV1] - bm;
@@ -182,6 +186,7 @@ static void hydro_hllc(const double *wl, const double *wr, double gamma, double 
 
   double sl, sr, sm;
   if (am >= 0.0) {
+    ORC_TRACE(ORC_TR_HLLC_AM_POS);
     sl = am / (am - bm);
     sr = 0.0;
     sm = -bm / (am - bm);
@@ -319,6 +324,7 @@ static void glmmhd_hlle(const double *wl, const double *wr, double gamma, double
 
   double tmp = 0.0;
   if (bp != bm) tmp = 0.5 * (bp + bm) / (bp - bm);
+  else ORC_TRACE(ORC_TR_HLLE_BP_EQ_BM);
   static const int comps[7] = {ORC_IDN, ORC_IV1, ORC_IV2, ORC_IV3, ORC_IEN, ORC_IB2, ORC_IB3};
   for (int c = 0; c < 7; ++c) {
     const int n = comps[c];
@@ -338,9 +344,10 @@ typedef struct {
 /* star state of one side: eqns (39),(43)-(48) of Miyoshi & Kusano; glmmhd_hlld.hpp:187-250 */
 static void hlld_star_side(const double *w, const c1d *u, double sd, double sdm,
                            double sdm_inv, double sm, double pt, double ptst, double bxi,
-                           double bxsq, c1d *ust, double ust_d_inv, double *vbst) {
+                           double bxsq, c1d *ust, double ust_d_inv, double *vbst, unsigned trace_bit) {
   ust->mx = ust->d * sm;
   if (fabs(u->d * sd * sdm - bxsq) < (HLLD_SMALL)*ptst) {
+    ORC_TRACE(trace_bit);
     ust->my = ust->d * w[ORC_IV2];
     ust->mz = ust->d * w[ORC_IV3];
     ust->by = u->by;
@@ -449,11 +456,12 @@ static void glmmhd_hlld(const double *wl, const double *wr, double gamma, double
 
   double vbstl, vbstr;
   hlld_star_side(wl, &ul, sdl, sdml, sdml_inv, spd[2], ptl, ptst, bxi, bxsq, &ulst,
-                 ulst_d_inv, &vbstl);
+                 ulst_d_inv, &vbstl, ORC_TR_HLLD_DEG_L);
   hlld_star_side(wr, &ur, sdr, sdmr, sdmr_inv, spd[2], ptr, ptst, bxi, bxsq, &urst,
-                 urst_d_inv, &vbstr);
+                 urst_d_inv, &vbstr, ORC_TR_HLLD_DEG_R);
 
   if (0.5 * bxsq < (HLLD_SMALL)*ptst) {
+    ORC_TRACE(ORC_TR_HLLD_DEG_DST);
     uldst = ulst;
     urdst = urst;
   } else {
@@ -492,10 +500,13 @@ static void glmmhd_hlld(const double *wl, const double *wr, double gamma, double
 
   c1d r;
   if (spd[0] >= 0.0) {
+    ORC_TRACE(ORC_TR_HLLD_FL);
     r = fl;
   } else if (spd[4] <= 0.0) {
+    ORC_TRACE(ORC_TR_HLLD_FR);
     r = fr;
   } else if (spd[1] >= 0.0) {
+    ORC_TRACE(ORC_TR_HLLD_LSTAR);
     r.d = fl.d + ulst.d;
     r.mx = fl.mx + ulst.mx;
     r.my = fl.my + ulst.my;
@@ -504,6 +515,7 @@ static void glmmhd_hlld(const double *wl, const double *wr, double gamma, double
     r.by = fl.by + ulst.by;
     r.bz = fl.bz + ulst.bz;
   } else if (spd[2] >= 0.0) {
+    ORC_TRACE(ORC_TR_HLLD_LDSTAR);
     r.d = fl.d + ulst.d + uldst.d;
     r.mx = fl.mx + ulst.mx + uldst.mx;
     r.my = fl.my + ulst.my + uldst.my;
@@ -512,6 +524,7 @@ static void glmmhd_hlld(const double *wl, const double *wr, double gamma, double
     r.by = fl.by + ulst.by + uldst.by;
     r.bz = fl.bz + ulst.bz + uldst.bz;
   } else if (spd[3] > 0.0) {
+    ORC_TRACE(ORC_TR_HLLD_RDSTAR);
     r.d = fr.d + urst.d + urdst.d;
     r.mx = fr.mx + urst.mx + urdst.mx;
     r.my = fr.my + urst.my + urdst.my;
@@ -520,6 +533,7 @@ static void glmmhd_hlld(const double *wl, const double *wr, double gamma, double
     r.by = fr.by + urst.by + urdst.by;
     r.bz = fr.bz + urst.bz + urdst.bz;
   } else {
+    ORC_TRACE(ORC_TR_HLLD_RSTAR);
     r.d = fr.d + urst.d;
     r.mx = fr.mx + urst.mx;
     r.my = fr.my + urst.my;
@@ -635,4 +649,16 @@ void orc_riemann_many(int fluid, int riemann, int ivx, long m, const double *wl,
   for (long s = 0; s < m; ++s)
     orc_riemann_point(fluid, riemann, ivx, wl + nv * s, wr + nv * s, gamma, c_h,
                       flux + nv * s);
+}
+
+
+void orc_riemann_many_traced(int fluid, int riemann, int ivx, long m, const double *wl, const double *wr, double gamma,
+                             double c_h, double *flux, unsigned *masks) {
+  const int nv = (fluid == ORC_FLUID_EULER) ? ORC_NHYDRO : ORC_NGLMMHD;
+  for (long s = 0; s < m; ++s) {
+    masks[s] = 0u;
+    orc_trace_sink = masks + s;
+    orc_riemann_point(fluid, riemann, ivx, wl + nv * s, wr + nv * s, gamma, c_h, flux + nv * s);
+  }
+  orc_trace_sink = 0;
 }
