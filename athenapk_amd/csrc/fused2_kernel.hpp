@@ -258,10 +258,15 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
         if (retire) {
           if constexpr (APK_M12F_LOADS == 2) {
             asm volatile("" ::: "memory");
+            if (active) {  // (ghost-column and overlap lanes retire nothing: 13 % of the lanes)
 #pragma unroll
-            for (int n = 0; n < NV; ++n) d3v[n] = d3[n * u0.sn + done];
+              for (int n = 0; n < NV; ++n) d3v[n] = d3[n * u0.sn + done];
 #pragma unroll
-            for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
+              for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
+            } else {
+#pragma unroll
+              for (int n = 0; n < NV; ++n) d3v[n] = 0.0, u1v[n] = 0.0;
+            }
           }
           // du = (x1 term + x2 term) + x3 term, the reference's accumulation order
 #pragma unroll

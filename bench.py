@@ -28,7 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured with torch: copy 4950, read 6060, fill 6570 GB/s
+HBM_PEAK_GBS = 8000.0
+HBM_COPY_GBS = 6290.0   # measured float4 copy (MI355X_MICROARCH.md, HBM section)  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured with torch: copy 4950, read 6060, fill 6570 GB/s
 
 # algorithmic bytes (fp64, compulsory traffic) -- SURVEY.md 8(d)
 B_STAGE = {"glmmhd": (216.0, 288.0), "euler": (120.0, 160.0)}   # per cell-stage: gam0 == 0 / != 0
@@ -186,27 +187,32 @@ def general_stage_bench(recon="ppm", riemann="hlld", nb=8, n=128, reps=5):
     return {"description": "one pack of %d smooth %d^3 GLM-MHD blocks, %s+%s general stage (gam0 = gam1 = 1/2), "
                            "288 B per cell-stage (SURVEY 8(d))" % (nb, n, recon.upper(), riemann.upper()),
             "ms_per_stage": ms, "cell_stage_updates_per_s": cells / (ms * 1e-3), "achieved": gbs, "unit": "GB/s",
-            "frac": gbs / HBM_PEAK_GBS}
+            "frac": gbs / HBM_PEAK_GBS, "frac_of_measured_copy_bandwidth": gbs / HBM_COPY_GBS}
 
 
 def measured_traffic(workload):
     """HBM bytes per fused-stage launch from the committed rocprofv3 PMC passes (a live run cannot
     profile itself): profiles/r01_hbm_traffic.json, made by profiles/pmc_traffic.py from
     FETCH_SIZE / WRITE_SIZE of this same command.  Returns (GB, source) or (None, None)."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if workload != "mhd_ppm_hlld_vl2_256" or not os.path.exists(path):
+    if workload != "mhd_ppm_hlld_vl2_256":
         return None, None
-    try:
-        with open(path) as f:
-            k = json.load(f)["kernels"]
-        # the three kernels of the VL2 corrector stage as the driver launches it (x3 = finishing sweep
-        # with FillDerived + dt); the profile also holds the general-stage benchmark's variants
-        stage = ("fused_x1_kernel<2, 3, 5, false>", "fused_march_kernel<2, 3, 5, 2, false, 0>",
-                 "fused_march_kernel<2, 3, 5, 3, true, 2>")
-        gb = sum(k[name]["hbm_total_GB"] for name in stage)
-        return gb, "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, reads calibrated x1.60)"
-    except Exception:
-        return None, None
+    # round 2: the two-kernel stage (x3 sweep + finishing x1/x2 march); round 1: three sweeps
+    for fname, stage, note in (
+            ("r02_hbm_traffic.json", ("fused_march_kernel<2, 3, 5, 3, false, 0>", "fused_m12f_kernel<2, 3, 5, 2>"),
+             "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, reads calibrated on the dt kernel's known bytes"),
+            ("r01_hbm_traffic.json", ("fused_x1_kernel<2, 3, 5, false>", "fused_march_kernel<2, 3, 5, 2, false, 0>",
+                                      "fused_march_kernel<2, 3, 5, 3, true, 2>"),
+             "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, reads calibrated x1.60; THREE-SWEEP schedule of round 1")):
+        path = os.path.join(ROOT, "profiles", fname)
+        if not os.path.exists(path):
+            continue
+        try:
+            with open(path) as f:
+                k = json.load(f)["kernels"]
+            return sum(k[name]["hbm_total_GB"] for name in stage), "profiles/%s (%s)" % (fname, note)
+        except Exception:
+            continue
+    return None, None
 
 
 def main():
@@ -306,9 +312,16 @@ def main():
         else:
             # the high-order (PPM+HLLD) stage; the VL2 donor-cell predictor is timed in its own slots
             stage_ms = per_kernel["fused_x1"] + per_kernel["fused_x2"] + per_kernel["fused_x3"]
-            stage_name = ("fused %s+%s stage: x1 DPP sweep + x2 march + x3 march (+RK update%s, +ConsToPrim of "
-                          "the interior, +dt in the last stage)" % (recon.upper(), riemann.upper(),
-                                                                    " +Dedner" if fluid == "glmmhd" else ""))
+            two_kernel = info.ndim == 3 and per_kernel["fused_x2"] == 0.0 and per_kernel["fused_x3"] > 0.0
+            if two_kernel:
+                stage_name = ("fused %s+%s stage, two kernels: x3 sweep writing its flux difference (timing slot fused_x3) "
+                              "+ ONE march doing x1 (DPP stencil) and x2 (LDS ring) that finishes the stage: RK update%s, "
+                              "ConsToPrim of the interior, dt in the last stage (slot fused_x1)"
+                              % (recon.upper(), riemann.upper(), ", Dedner" if fluid == "glmmhd" else ""))
+            else:
+                stage_name = ("fused %s+%s stage: x1 DPP sweep + x2 march + x3 march (+RK update%s, +ConsToPrim of "
+                              "the interior, +dt in the last stage)" % (recon.upper(), riemann.upper(),
+                                                                        " +Dedner" if fluid == "glmmhd" else ""))
         # high-order stages only (for vl2: the corrector, gam0 = 0)
         ho = [g0 for n, g0 in enumerate(GAM0[integrator]) if not (integrator == "vl2" and n == 0)]
         b_stage = sum(B_STAGE[fluid][0 if g0 == 0.0 else 1] for g0 in ho) / len(ho)
@@ -338,7 +351,9 @@ def main():
                        "integrator": integrator, "nstages": nstages, "nghost": int(info.ng),
                        "path": "flux-array" if args.unfused else "fused",
                        "parallelism": "domain decomposition, %dx%dx%d GPU grid" % grid,
-                       "comm_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
+                       "comm_backend": (("rccl, native transport of the C++ host (ncclSend/ncclRecv groups on a halo stream)"
+                                         if sim.comm_kind == "rccl" else "torch.distributed callbacks over " + backend)
+                                        if world > 1 else None),
                        "overlapped_exchanges_per_cycle": (sim.overlapped_exchanges / max(1, sim.ncycle)) if world > 1 else None},
             "cell_stage_updates_per_s": value * nstages,
             "roofline": {
@@ -355,9 +370,13 @@ def main():
                 "cells_per_launch": zones_local,
                 "stage_ms": stage_ms,
                 "dc_predictor_stage_ms": per_kernel["fused_dc_x1"] + per_kernel["fused_dc_x2"] + per_kernel["fused_dc_x3"],
-                "note": "fp64 VALU-issue bound, not HBM bound: ~1.5k executed VALU instructions per cell per sweep, "
-                        "~4.4k per cell-stage (SQ_INSTS_VALU, profiles/r01_pmc_sq_counter_collection.csv); see "
-                        "DESIGN.md section 7",
+                "frac_of_measured_copy_bandwidth": achieved / HBM_COPY_GBS,
+                "note": "fp64 VALU-issue bound: ~4.3k executed VALU instructions per cell-stage (SQ_INSTS_VALU, "
+                        "profiles/r02_pmc_sq.json) at a measured 4.3 cycles per wave64 fp64 instruction and 2.06 GHz "
+                        "(profiles/r02_clock_and_issue_rate.json); `peak` is the 8 TB/s spec, "
+                        "frac_of_measured_copy_bandwidth prices against the 6.29 TB/s a float4 copy reaches "
+                        "(MI355X_MICROARCH.md); product build: FMA contraction, rsq/rcp-based roots and reciprocals "
+                        "(<= 1e-12 of the bit-exact parity build, which is what the parity tests pin); see DESIGN.md section 7",
                 "per_kernel_avg_ms": per_kernel,
                 "dominant_kernel": dominant,
                 "whole_cycle": {"algorithmic_bytes_per_zone_cycle": b_cycle,
