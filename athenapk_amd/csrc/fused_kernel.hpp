@@ -37,6 +37,7 @@ struct StageParams {
   unsigned *flags;               // latched APK_FLAG_* word
   unsigned long long *dt_bits;   // min over cells of dx_d/(|v_d|+c_d), as ordered bits
   unsigned long long *bad_count;  // trial stage: number of cells failing FirstOrderFluxCorrect's test (or NULL)
+  int64_t out_delta;  // the updated conserved state goes to cons + out_delta (elements; 0 = in place)
   int prim_to_u1;                // fill_derived = 2: the new primitives go to u1's prim arrays
   // optional per-block index window (apk_stage_args.window): {i0, rl, ilo, ihi, jlo, jhi, klo, khi}:
   // rows are flattened with length rl starting at column i0 and only cells ilo..ihi retire
@@ -166,7 +167,7 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
     }
   }
 #pragma unroll
-  for (int n = 0; n < NV; ++n) b0.cons[n * pv.sn + cell] = un[n];
+  for (int n = 0; n < NV; ++n) b0.cons[n * pv.sn + cell + sp.out_delta] = un[n];
   if (bad) atomicAdd(sp.bad_count, 1ull);
 }
 

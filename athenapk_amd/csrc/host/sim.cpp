@@ -175,12 +175,12 @@ void dev_free(apk_sim *s, double *p) {
 
 int build_packs(apk_sim *s) {
   const int nlb = (int)s->mesh.local_gids.size();
-  for (int p = 0; p < 2; ++p)
+  for (int p = 0; p < 3; ++p)
     for (int w = 0; w < 2; ++w) {
       if (s->mu0_of[p][w]) apk_pack_destroy(s->mu0_of[p][w]);
       if (s->mu1_of[p][w]) apk_pack_destroy(s->mu1_of[p][w]);
       s->mu0_of[p][w] = s->mu1_of[p][w] = nullptr;
-      if (!s->d_prim2[w]) continue;
+      if (!s->d_prim2[w] || !s->d_cons2[p]) continue;
       double *spare = s->d_prim2[1 - w];  // may be null: then u1 carries no prim
       std::vector<apk_block_desc> b0(nlb), b1(nlb);
       for (int lb = 0; lb < nlb; ++lb) {
@@ -206,6 +206,16 @@ int build_packs(apk_sim *s) {
       SIM_TRY(s, apk_pack_create(s->ctx, &d, &s->mu1_of[p][w]));
     }
   return APK_OK;
+}
+
+// third conserved buffer (output of trial stages that must keep their input), on first use
+int ensure_trial_cons(apk_sim *s) {
+  if (s->d_cons2[2]) return APK_OK;
+  const size_t bytes = (size_t)s->nper * s->mesh.local_gids.size() * sizeof(double);
+  SIM_TRY(s, dev_alloc(s, "cons3", bytes, &s->d_cons2[2]));
+  SIM_HIP(s, hipMemsetAsync(s->d_cons2[2], 0, bytes, hs(s)));
+  SIM_TRY(s, build_packs(s));
+  return build_copy_plans(s);
 }
 
 // second primitive buffer, on first use
@@ -246,8 +256,13 @@ double *region_base(apk_sim *s, int parity, int kind, int block) {
 }
 
 int build_copy_plans(apk_sim *s) {
-  for (int par = 0; par < 2; ++par)
+  for (int par = 0; par < 3; ++par)
   for (int ph = 0; ph < PH_COUNT; ++ph) {
+    if (s->plans_of[par][ph]) {
+      apk_copy_plan_destroy(s->plans_of[par][ph]);
+      s->plans_of[par][ph] = nullptr;
+    }
+    if (!s->d_cons2[par]) continue;
     std::vector<apk_copy_region> regs;
     for (const BoxRegion &r : s->mesh.plan[ph]) {
       apk_copy_region c{};
@@ -585,10 +600,13 @@ int do_stage(apk_sim *s, int stage) {
     // register u1 and the stage writes the new u0 into the other buffer.  Valid because
     // gam0[0] == 0 for rk1/rk2/vl2/rk3, i.e. stage 1 never reads the old contents of its output.
     if (g0 != 0.0) {
-      SIM_HIP(s, hipMemcpyAsync(s->d_cons2[1 - s->cur], s->d_cons2[s->cur], field_bytes, hipMemcpyDeviceToDevice, hs(s)));
+      SIM_HIP(s, hipMemcpyAsync(s->d_cons2[s->u1buf], s->d_cons2[s->cur], field_bytes, hipMemcpyDeviceToDevice, hs(s)));
     }
-    s->u1buf = s->cur;
-    s->cur = 1 - s->cur;
+    {
+      const int was_u1 = s->u1buf;
+      s->u1buf = s->cur;
+      s->cur = was_u1;
+    }
   }
   const apk_flux_cfg cfg = (stage == 1) ? pkg.flux_first_stage : pkg.flux_other_stage;
   bool fused_fill = false;
@@ -692,8 +710,14 @@ int do_stage(apk_sim *s, int stage) {
     // (Refined meshes: the test sees the update before the coarse-fine flux correction, as
     // FirstOrderFluxCorrect does in the reference's task order; the correction follows, and ConsToPrim
     // stays the full pass after the exchange.)
-    if (s->fused && pkg.first_order_flux_correct && g0 == 0.0 && !pkg.glmmhd_source_extended && s->mesh.ndim >= 2 &&
-        pkg.riemann != APK_RS_NONE && pkg.riemann != APK_RS_LLF) {
+    // A stage that does read the old u0 (gam0 != 0: the later stages of RK2 / RK3) writes its trial
+    // result into a third buffer instead, so that u0 survives a rejected trial; an accepted one makes
+    // that buffer the current state.  (Not with passive scalars: their kernel updates in place; not on
+    // refined meshes: the flux correction after the stage addresses the current buffer.)
+    const bool trial_out_of_place = g0 != 0.0;
+    if (s->fused && pkg.first_order_flux_correct && (g0 == 0.0 || (pkg.nscalars == 0 && !s->amr)) &&
+        !pkg.glmmhd_source_extended && s->mesh.ndim >= 2 && pkg.riemann != APK_RS_NONE && pkg.riemann != APK_RS_LLF) {
+      if (trial_out_of_place) SIM_TRY(s, ensure_trial_cons(s));
       // FirstOrderFluxCorrect tests the UNfloored trial update (hydro.cpp:1283-1306; floors only act
       // in the ConsToPrim that follows the stage)
       // (the finishing sweep tests the update it holds in registers, before its own ConsToPrim floors
@@ -717,6 +741,8 @@ int do_stage(apk_sim *s, int stage) {
       // the finishing sweep applies FirstOrderFluxCorrect's test to the update it has in registers
       // (passive scalars ride a separate kernel: there the stored state is tested afterwards)
       a.count_unphysical = test_in_kernel ? 1 : 0;
+      const int outbuf = trial_out_of_place ? s->freebuf() : s->cur;
+      a.cons_out_delta = s->d_cons2[outbuf] - s->d_cons2[s->cur];
       SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
       long long bad = 0;
       if (a.count_unphysical) SIM_TRY(s, apk_stage_unphysical_read(s->ctx, &bad, s->stream));
@@ -724,6 +750,7 @@ int do_stage(apk_sim *s, int stage) {
       done = bad == 0;
       if (fill) SIM_TRY(s, apk_trial_flags(s->ctx, done ? 1 : 0, s->stream));
       if (done) {
+        s->cur = outbuf;  // (its ghost zones are filled by the exchange below)
         if (fill) {
           s->pcur = 1 - s->pcur;
           fused_fill = true;
@@ -919,7 +946,7 @@ void apk_sim_destroy(apk_sim *s) {
     s->rccl = nullptr;
     for (auto &pp : s->plans_of)
       for (auto &p : pp) apk_copy_plan_destroy(p);
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < 3; ++p)
       for (int w = 0; w < 2; ++w) {
         apk_pack_destroy(s->mu0_of[p][w]);
         apk_pack_destroy(s->mu1_of[p][w]);
@@ -940,6 +967,7 @@ void apk_sim_destroy(apk_sim *s) {
     dev_free(s, s->d_prim2[0]);
     dev_free(s, s->d_prim2[1]);
     dev_free(s, s->d_cons2[1]);
+    dev_free(s, s->d_cons2[2]);
     for (auto *f : s->d_flux) dev_free(s, f);
     for (auto *b : s->send_buf) dev_free(s, b);
     for (auto *b : s->recv_buf) dev_free(s, b);

@@ -102,7 +102,11 @@ struct apk_sim {
   // Two conserved-variable buffers: the stage-1 "u1 <- u0" DeepCopy of the reference
   // (hydro_driver.cpp:474-495) is a buffer-role swap here -- stage 1 has gam0 = 0 for every
   // integrator, so it reads the old state as u1 and writes the new state into the other buffer.
-  double *d_cons2[2] = {nullptr, nullptr};
+  // (a third buffer of the same layout is allocated on first use as the output of trial stages with
+  // gam0 != 0 -- first-order flux correction in the later stages of RK2 / RK3 -- whose input u0 must
+  // survive a rejected trial; an accepted trial just makes it the current buffer)
+  double *d_cons2[3] = {nullptr, nullptr, nullptr};
+  int freebuf() const { return 3 - cur - u1buf; }  // the buffer that is neither u0 nor u1
   int cur = 0;    // buffer holding the current state u0 ("base")
   int u1buf = 1;  // buffer holding the register u1 of the step in flight
   // Two primitive-variable buffers as well (the second one is allocated on first use): a stage
@@ -115,8 +119,10 @@ struct apk_sim {
   // per buffer: the pack presenting it as MeshData "base" (with prim/flux), the pack presenting it
   // as "u1" (cons, plus the spare prim buffer when there is one), and the ghost-exchange plans that target it
   // [cons buffer][prim buffer]; mu1 packs carry the OTHER prim buffer's arrays as "u1.prim"
-  apk_pack *mu0_of[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *mu1_of[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-  apk_copy_plan *plans_of[2][apk::PH_COUNT] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
+  apk_pack *mu0_of[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}},
+           *mu1_of[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  apk_copy_plan *plans_of[3][apk::PH_COUNT] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
+                                               {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
                                                {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
   apk_pack *mu0() const { return mu0_of[cur][pcur]; }
   apk_pack *mu1() const { return mu1_of[u1buf][pcur]; }

@@ -57,7 +57,7 @@ class StageArgs(C.Structure):
                 ("gam1", C.c_double), ("beta_dt", C.c_double), ("dedner", C.c_int),
                 ("glmmhd_alpha", C.c_double), ("mindx", C.c_double), ("fill_derived", C.c_int),
                 ("estimate_dt", C.c_int), ("phase", C.c_int), ("window", C.c_void_p),
-                ("window_rl", C.c_int), ("window_rows", C.c_int), ("trial", C.c_int), ("count_unphysical", C.c_int)]
+                ("window_rl", C.c_int), ("window_rows", C.c_int), ("trial", C.c_int), ("count_unphysical", C.c_int), ("cons_out_delta", C.c_int64)]
 
 
 class FmftBlock(C.Structure):

@@ -204,6 +204,12 @@ typedef struct apk_stage_args {
    * floor acts (and, with fill_derived, counts cells whose ConsToPrim latched a flag); read the
    * number of failing cells with apk_stage_unphysical_read().  Not with passive scalars. */
   int count_unphysical;
+  /* cons_out_delta != 0: the updated conserved state is written to cons + cons_out_delta (in
+   * elements, the same offset for every block: a second allocation of identical layout) instead of
+   * over u0, which stays intact -- the trial stage of first-order flux correction when gam0 != 0
+   * (RK2 / RK3 later stages), whose fallback needs the old u0.  Interior cells only; not with
+   * passive scalars. */
+  int64_t cons_out_delta;
 } apk_stage_args;
 int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
                     const apk_stage_args *args, apk_stream_t stream);
