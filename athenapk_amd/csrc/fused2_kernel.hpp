@@ -33,6 +33,40 @@
 
 namespace apk {
 
+// Neighbour-lane access of K2: value of lane (l - K) for K = 1, 2 (shr) / lane (l + K) (shl); lanes
+// without such a neighbour get an unspecified valid lane's value (they never retire a cell).
+// APK_M12F_BPERMUTE (A/B): through the LDS crossbar (ds_bpermute_b32: no VALU issue slot, two per
+// double) instead of DPP wave shifts (v_mov_b32_dpp: 4.4 cycles of VALU issue each, measured).
+#ifndef APK_M12F_BPERMUTE
+#define APK_M12F_BPERMUTE 0  // measured on 8 x 128^3: 3.26 ms per stage against 3.11 with DPP
+#endif
+template <int K>
+APK_DEV double lane_below(double x, int lane) {
+  if constexpr (APK_M12F_BPERMUTE != 0) {
+    const int src = (lane >= K ? lane - K : lane) << 2;
+    const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(x));
+    const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+  } else {
+    double r = wave_shr1(x);
+    if constexpr (K == 2) r = wave_shr1(r);
+    return r;
+  }
+}
+template <int K>
+APK_DEV double lane_above(double x, int lane) {
+  if constexpr (APK_M12F_BPERMUTE != 0) {
+    const int src = (lane + K <= 63 ? lane + K : lane) << 2;
+    const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(x));
+    const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+  } else {
+    double r = wave_shl1(x);
+    if constexpr (K == 2) r = wave_shl1(r);
+    return r;
+  }
+}
+
 // Lanes of a K2 wave that retire a cell.  A cell needs the fluxes of both its x1 faces; a face needs
 // the reconstructed states of the two cells it separates; a state needs the cell's stencil (H lanes
 // either side, fetched by wave shifts) and, with PPM, the interface value of the lane below:
@@ -165,14 +199,14 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
         for (int n = 0; n < NV; ++n) {
           const double q0 = q0_next;
           if (n + 1 < NV) q0_next = ring[(slot_cm1 * NV + n + 1) * 64 + lane];
-          const double qm1 = wave_shr1(q0), qp1 = wave_shl1(q0);
+          const double qm1 = lane_below<1>(q0, lane), qp1 = lane_above<1>(q0, lane);
           if constexpr (RECON == APK_RC_PPM) {
-            const double qm2 = wave_shr1(qm1), qp2 = wave_shl1(qp1);
+            const double qm2 = lane_below<2>(q0, lane), qp2 = lane_above<2>(q0, lane);
             const double face_p = ppm_interface(qm1, q0, qp1, qp2);
-            const double face_m = wave_shr1(face_p);
+            const double face_m = lane_below<1>(face_p, lane);
             ppm_cell(qm2, qm1, q0, qp1, qp2, face_m, face_p, ql1[n], qr1[n]);
           } else if constexpr (H >= 2) {
-            const double qm2 = wave_shr1(qm1), qp2 = wave_shl1(qp1);
+            const double qm2 = lane_below<2>(q0, lane), qp2 = lane_above<2>(q0, lane);
             reconstruct<RECON>(qm2, qm1, q0, qp1, qp2, dx1, n, ql1[n], qr1[n]);
           } else {
             reconstruct<RECON>(0.0, qm1, q0, qp1, 0.0, dx1, n, ql1[n], qr1[n]);
@@ -183,14 +217,14 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
         double wl[NV], wr[NV], f1[NV];
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-          wl[q] = wave_shr1(ql1[perm<1>(q)]);
+          wl[q] = lane_below<1>(ql1[perm<1>(q)], lane);
           wr[q] = qr1[perm<1>(q)];
         }
         riemann<FLUID, RS>(wl, wr, sp.gamma, sp.c_h, f1);
         double fup0 = 0.0;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-          const double fup = wave_shl1(f1[q]);
+          const double fup = lane_above<1>(f1[q], lane);
           if (q == 0) fup0 = fup;
           du[perm<1>(q)] = (area1 * fup - area1 * f1[q]);
         }
