@@ -140,6 +140,13 @@ struct apk_sim {
   // (exchange_pending); the next stage runs its x1 sweep on all cells farther than nghost from a
   // face with a remote neighbour, completes the exchange, then does the thin slabs and the rest.
   bool overlap = true;
+  // APK_COPY_STREAM=1 (A/B, off by default: measured slower, see apk_sim_create): same-rank ghost copies
+  // (and the ConsToPrim fused into them) on a second HIP stream, ordered against the sim's stream by two
+  // events, overlapping with the part of the next stage that needs no ghost zone -- like messages in
+  // flight; every face of every block then counts as "late" in the window tables.
+  void *copy_stream = nullptr;                            // hipStream_t
+  void *ev_stage_done = nullptr, *ev_copies_done = nullptr;  // hipEvent_t
+  bool copies_in_flight = false;
   bool exchange_pending = false;
   bool pending_c2p = false;  // the exchange in flight converts ghost zones as it fills them
   int pending_cons = 0;  // cons buffer whose ghost zones the exchange in flight fills (roles may swap meanwhile)

@@ -58,7 +58,7 @@ int build_copy_plans(apk_sim *s);
 void set_global_dt(apk_sim *s, double dt_est);
 int estimate_timestep(apk_sim *s, double *dt_out);
 bool ghost_c2p_fusable(const apk_sim *s);
-int run_ghost_plan(apk_sim *s, int buf, int phase, bool c2p);
+int run_ghost_plan(apk_sim *s, int buf, int phase, bool c2p, apk_stream_t stream = nullptr);
 int exchange_begin(apk_sim *s, bool async, bool c2p);
 int exchange_end(apk_sim *s, bool c2p);
 int exchange_ghosts(apk_sim *s, bool c2p = false);
