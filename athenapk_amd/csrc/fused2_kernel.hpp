@@ -133,6 +133,26 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     const double area2 = b0.dx[0] * b0.dx[2];
     const double vol = b0.dx[0] * b0.dx[1] * b0.dx[2];
     const double *prim = b0.prim + base;
+    // Direct neighbour addressing (sp.face_nbr): a lane on a ghost column reads the interior column
+    // of the block behind that x1 face; the stencil rows below js / above je of an interior column
+    // come from the block behind the x2 face (wave-uniform offset, not applied on ghost columns:
+    // those lanes retire nothing and may read their neighbour's stale ghost rows).
+    int64_t nbr_lo = 0, nbr_hi = 0;
+    bool gcol = false;
+    if (sp.face_nbr) {
+      const int *fn = sp.face_nbr + 6 * b;
+      if (fn[2] >= 0) nbr_lo = (u0.blocks[fn[2]].prim - b0.prim) + (int64_t)u0.nx2 * st;
+      if (fn[3] >= 0) nbr_hi = (u0.blocks[fn[3]].prim - b0.prim) - (int64_t)u0.nx2 * st;
+      gcol = (i < u0.is) || (i > u0.ie);
+      if (gcol) {
+        const int nb = fn[i < u0.is ? 0 : 1];
+        if (nb >= 0) prim = u0.blocks[nb].prim + base + (i < u0.is ? u0.nx1 : -u0.nx1);
+      }
+    }
+    auto row_off = [&](int r) -> int64_t {
+      const int64_t d = (r < u0.js) ? nbr_lo : ((r > u0.je) ? nbr_hi : (int64_t)0);  // wave-uniform
+      return (int64_t)r * st + (gcol ? (int64_t)0 : d);
+    };
 
     int c = s - 1;
     const int r0 = c - H;
@@ -142,7 +162,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
 #pragma unroll
       for (int m = 0; m < NS; ++m)
 #pragma unroll
-        for (int n = 0; n < NV; ++n) init[m][n] = prim[n * u0.sn + (int64_t)(r0 + m) * st];
+        for (int n = 0; n < NV; ++n) init[m][n] = prim[n * u0.sn + row_off(r0 + m)];
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int m = 0; m < NS; ++m)
@@ -151,7 +171,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     }
     double Pn[NV];  // row c+H
 #pragma unroll
-    for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + (int64_t)(c + H) * st];
+    for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + row_off(c + H)];
 
     double wl_prev[NV], f_prev[NV];  // x2: permuted L state at face c / flux at face c-1
 #pragma unroll
@@ -278,7 +298,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
         for (int n = 0; n < NV; ++n) ring[(slot0 * NV + n) * 64 + lane] = Pn[n];
         slot0 = (slot0 + 1) & (NS - 1);
 #pragma unroll
-        for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + (int64_t)(c + 1 + H) * st];
+        for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + row_off(c + 1 + H)];
       }
       // ---- (4) x2 face between rows c-1 and c; retire row c-1
       if (c >= s) {

@@ -38,6 +38,7 @@ int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
   sp.dt_bits = ctx->d_u64 + 4;  // word 4: min of the finishing sweep (apk_stage_dt_read)
   sp.bad_count = nullptr;
   sp.out_delta = a.cons_out_delta;
+  sp.face_nbr = a.face_neighbor;
   if (a.cons_out_delta != 0 && u0.nvar != u0.nhydro) return APK_ERR_UNSUPPORTED;  // (the scalar kernels update in place)
   if (a.count_unphysical) {     // word 6: cells failing FirstOrderFluxCorrect's test (apk_stage_unphysical_read)
     if (u0.nvar != u0.nhydro) return APK_ERR_UNSUPPORTED;  // (scalars are updated by their own kernel)

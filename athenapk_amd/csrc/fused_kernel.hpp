@@ -47,6 +47,9 @@ struct StageParams {
   const int *window;
   int window_rl, window_rows;  // largest rl / row count in `window` (size the grid)
   int phase;                   // apk_stage_args.phase
+  // apk_stage_args.face_neighbor: [nblocks][6] pack index of the block behind each face whose interior
+  // stands in for this block's ghost zone there (-1: the ghost zone itself), or NULL
+  const int *face_nbr;
   apk_ctx *ctx;  // host side only (kernel timing); never dereferenced on the device
 };
 
@@ -344,6 +347,20 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
   double *dscratch = sp.du + (int64_t)b * u0.sn * u0.nvar;
   const double *prim = b0.prim + base;
   double *prim_dst = (EXTRA != EXTRA_NONE && sp.prim_to_u1) ? u1.blocks[b].prim : b0.prim;
+  // Direct neighbour addressing (sp.face_nbr): the stencil rows below / above the interior come
+  // from the interior of the block behind that face (the lanes are interior columns, so the
+  // choice is wave-uniform: an offset added to the row's address).
+  const int lo_int = (DIR == 2) ? u0.js : u0.ks, hi_int = (DIR == 2) ? u0.je : u0.ke;
+  int64_t nbr_lo = 0, nbr_hi = 0;
+  if (sp.face_nbr) {
+    const int n_int = (DIR == 2) ? u0.nx2 : u0.nx3;
+    const int nlo = sp.face_nbr[6 * b + 2 * (DIR - 1)], nhi = sp.face_nbr[6 * b + 2 * (DIR - 1) + 1];
+    if (nlo >= 0) nbr_lo = (u0.blocks[nlo].prim - b0.prim) + (int64_t)n_int * st;
+    if (nhi >= 0) nbr_hi = (u0.blocks[nhi].prim - b0.prim) - (int64_t)n_int * st;
+  }
+  auto row_off = [&](int r) -> int64_t {
+    return (int64_t)r * st + (r < lo_int ? nbr_lo : (r > hi_int ? nbr_hi : (int64_t)0));
+  };
 
   // row r of the stencil lives in slot (r - (s-1-H)) mod NS
   int c = s - 1;
@@ -351,10 +368,10 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
 #pragma unroll
   for (int m = 0; m < NS; ++m)
 #pragma unroll
-    for (int n = 0; n < NV; ++n) ring[(m * NV + n) * 64 + lane] = prim[n * u0.sn + (int64_t)(r0 + m) * st];
+    for (int n = 0; n < NV; ++n) ring[(m * NV + n) * 64 + lane] = prim[n * u0.sn + row_off(r0 + m)];
   double Pn[NV];  // row c+H
 #pragma unroll
-  for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + (int64_t)(c + H) * st];
+  for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + row_off(c + H)];
 
   double wl_prev[NV];  // permuted L state at face c (from cell c-1)
   double f_prev[NV];   // permuted flux at face c-1
@@ -440,7 +457,7 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
         slot0 = (slot0 + 1) & (NS - 1);
       }
 #pragma unroll
-      for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + (int64_t)(c + 1 + H) * st];
+      for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + row_off(c + 1 + H)];
     }
     if (c >= s) {
       double wr[NV], f[NV];
@@ -689,6 +706,29 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
 
   const int64_t col = (int64_t)(jlo + row) * u0.sj + i;
   const double *prim = b0.prim + col;
+  // Direct neighbour addressing (sp.face_nbr): a lane on a ghost column reads the x1 neighbour's
+  // interior column instead, the x2 / x3 neighbours of an interior column come from the block
+  // behind that face.  Only face neighbours are ever needed: a donor-cell flux reads the two cells
+  // of its face, and lanes on ghost columns retire nothing (their own x2 / x3 neighbours may be
+  // stale ghost cells: valid memory, unused results).
+  const double *prim_jm = prim - u0.sj, *prim_jp = prim + u0.sj;
+  const double *prim_klo = prim, *prim_khi = prim;  // base of the planes below ks / above ke
+  if (sp.face_nbr) {
+    const int *fn = sp.face_nbr + 6 * b;
+    const int j = jlo + row;
+    if (i < u0.is || i > u0.ie) {
+      const int nb = fn[i < u0.is ? 0 : 1];
+      if (nb >= 0) prim = u0.blocks[nb].prim + col + (i < u0.is ? u0.nx1 : -u0.nx1);
+      prim_jm = prim - u0.sj;
+      prim_jp = prim + u0.sj;
+      prim_klo = prim_khi = prim;
+    } else {
+      if (j - 1 < u0.js && fn[2] >= 0) prim_jm = u0.blocks[fn[2]].prim + col + (int64_t)(u0.nx2 - 1) * u0.sj;
+      if (j + 1 > u0.je && fn[3] >= 0) prim_jp = u0.blocks[fn[3]].prim + col - (int64_t)(u0.nx2 - 1) * u0.sj;
+      if (fn[4] >= 0) prim_klo = u0.blocks[fn[4]].prim + col + (int64_t)u0.nx3 * u0.sk;
+      if (fn[5] >= 0) prim_khi = u0.blocks[fn[5]].prim + col - (int64_t)u0.nx3 * u0.sk;
+    }
+  }
   const double area1 = b0.dx[1] * b0.dx[2], area2 = b0.dx[0] * b0.dx[2], area3 = b0.dx[0] * b0.dx[1];
   const double vol = b0.dx[0] * b0.dx[1] * b0.dx[2];
   // the march is cut into gridDim.y segments of kseg planes: 2216 full-length waves on a machine
@@ -708,7 +748,7 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
   double wprev[NV];                        // natural-order state of plane c-1
 #pragma unroll
   for (int n = 0; n < NV; ++n) {
-    wprev[n] = prim[n * u0.sn + (int64_t)(s - 1) * u0.sk];
+    wprev[n] = ((s - 1 < u0.ks) ? prim_klo : prim)[n * u0.sn + (int64_t)(s - 1) * u0.sk];
     st_f3[n * 64] = 0.0;
     st_du[n * 64] = 0.0;
   }
@@ -717,8 +757,11 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
   for (int c = s; c <= e + 1; ++c) {
     const int64_t off = (int64_t)c * u0.sk;
     double wc[NV];
+    {
+      const double *pc = (c > u0.ke) ? prim_khi : prim;  // wave-uniform choice (c >= s >= ks)
 #pragma unroll
-    for (int n = 0; n < NV; ++n) wc[n] = prim[n * u0.sn + off];
+      for (int n = 0; n < NV; ++n) wc[n] = pc[n * u0.sn + off];
+    }
     // ---- x3 face c (between planes c-1 and c)
     {
       double wl3[NV], wr3[NV], f3[NV];
@@ -781,7 +824,7 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
         double wm[NV], w2[NV];
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-          wm[q] = prim[perm<2>(q) * u0.sn + off - u0.sj];
+          wm[q] = prim_jm[perm<2>(q) * u0.sn + off];
           w2[q] = wc[perm<2>(q)];
         }
         riemann<FLUID, RS>(wm, w2, sp.gamma, sp.c_h, flo);
@@ -790,7 +833,7 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
         double wp[NV], w2[NV], fhi[NV];
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-          wp[q] = prim[perm<2>(q) * u0.sn + off + u0.sj];
+          wp[q] = prim_jp[perm<2>(q) * u0.sn + off];
           w2[q] = wc[perm<2>(q)];
         }
         riemann<FLUID, RS>(w2, wp, sp.gamma, sp.c_h, fhi);
@@ -942,6 +985,13 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
         return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
       }
     }
+  }
+  if (sp.face_nbr) {
+    // only the kernels that follow the table: the single-march donor-cell stage and the two-kernel
+    // stage; nothing that reads neighbouring cells from memory by plain index arithmetic
+    const bool form_ok = (RECON == APK_RC_DC) ? (extra == EXTRA_NONE || sp.prim_to_u1 != 0)
+                                              : two_kernel_stage_applies(u0, RECON, extra, sp);
+    if (u0.ndim != 3 || sp.mflux || sp.dedner == 2 || !form_ok) return APK_ERR_UNSUPPORTED;
   }
   const bool do_x1 = sp.phase != 2, do_rest = sp.phase != 1;
   // timing slots: donor-cell stages (VL2 predictor) are accounted separately

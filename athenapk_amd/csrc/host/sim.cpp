@@ -343,13 +343,20 @@ int run_ghost_plan(apk_sim *s, int buf, int phase, bool c2p, apk_stream_t stream
   int latch = 1;
   for (int later = phase + 1; phase >= PH_BC1 && later <= PH_BC3; ++later)
     if (!s->mesh.plan[later].empty()) latch = 0;
+  // direct neighbour addressing: the corner cells of a boundary phase are copied out of same-rank ghost
+  // zones nobody fills (or reads); the other cells repeat interior cells, whose flags are latched there
+  if (phase >= PH_BC1 && s->local_ghosts_stale) latch = 0;
   return apk_copy_plan_run_c2p(s->ctx, s->plans_of[buf][phase], s->pkg.fluid, &s->pkg.eos, delta, latch, stream);
 }
 
-int exchange_begin(apk_sim *s, bool async, bool c2p) {
+int exchange_begin(apk_sim *s, bool async, bool c2p, bool skip_local) {
   const bool remote = !s->mesh.peers.empty();
   if (remote) SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(PH_PACK), s->stream));
-  if (async && s->copy_stream) {
+  if (skip_local) {
+    // direct neighbour addressing: the stages read their same-rank neighbours' interiors
+    s->local_ghosts_stale = true;
+    s->skipped_local_exchanges += 1;
+  } else if (async && s->copy_stream) {
     // same-rank copies on the copy stream, behind everything enqueued so far (the stage that
     // produced the state; the kernels of the previous stage that read these ghost zones)
     SIM_HIP(s, hipEventRecord(static_cast<hipEvent_t>(s->ev_stage_done), hs(s)));
@@ -394,10 +401,48 @@ int exchange_end(apk_sim *s, bool c2p) {
   return APK_OK;
 }
 
-int exchange_ghosts(apk_sim *s, bool c2p) {
+int exchange_ghosts(apk_sim *s, bool c2p, bool skip_local) {
   if (s->amr) return amr_exchange(s, s->cur);
-  SIM_TRY(s, exchange_begin(s, false, c2p));
+  if (!skip_local) s->local_ghosts_stale = false;  // (a full exchange of the current state)
+  SIM_TRY(s, exchange_begin(s, false, c2p, skip_local));
   return exchange_end(s, c2p);
+}
+
+// Can the stages of this simulation read same-rank neighbours directly (apk_stage_args.face_neighbor)
+// so that the same-rank ghost copies can be skipped?  Every stage of the cycle must be one of the
+// kernels that follow the table, and nothing else in the cycle may read ghost zones.
+bool direct_neighbors(const apk_sim *s) {
+  static const int mode = std::getenv("APK_DIRECT_NEIGHBORS") ? std::atoi(std::getenv("APK_DIRECT_NEIGHBORS")) : 1;  // A/B switch
+  static const int dc_mode = std::getenv("APK_DC_MODE") ? std::atoi(std::getenv("APK_DC_MODE")) : 2;
+  static const bool no_copy_c2p = std::getenv("APK_NO_COPY_C2P") != nullptr;
+  const HydroPackage &pkg = s->pkg;
+  if (!mode || !s->direct_on || !s->d_face_nbr || s->amr || s->mesh.ndim != 3 || !stage_can_fuse(s)) return false;
+  if (s->fmft || pkg.nscalars != 0 || s->copy_stream || no_copy_c2p || !ghost_c2p_fusable(s)) return false;
+  if (pkg.fluid == APK_FLUID_GLMMHD && pkg.glmmhd_source_extended) return false;
+  const apk_flux_cfg *cfgs[2] = {&pkg.flux_first_stage, &pkg.flux_other_stage};
+  for (const apk_flux_cfg *cfg : cfgs) {
+    if (cfg->recon == APK_RC_DC) {
+      if (dc_mode != 2) return false;
+    } else if (apk_stage_split_axis(s->mu0(), cfg, 2) != 3) {
+      return false;
+    }
+  }
+  return true;
+}
+
+// fill the ghost zones that direct neighbour addressing left stale (cons and prim of the current state)
+int materialize_local_ghosts(apk_sim *s) {
+  if (!s->local_ghosts_stale) return APK_OK;
+  s->local_ghosts_stale = false;
+  SIM_TRY(s, run_ghost_plan(s, s->cur, PH_LOCAL, true));
+  // (physical boundaries copy corner cells out of ghost zones the same-rank copies fill)
+  for (int ph = PH_BC1; ph <= PH_BC3; ++ph) SIM_TRY(s, run_ghost_plan(s, s->cur, ph, true));
+  return APK_OK;
+}
+
+int sync_ghosts(apk_sim *s) {
+  SIM_TRY(s, finish_pending(s));
+  return materialize_local_ghosts(s);
 }
 
 
@@ -490,6 +535,31 @@ int build_windows(apk_sim *s) {
     const char *dctags[7] = {"win_dc_main", "win_dc_zlo", "win_dc_zhi", "win_dc_ylo", "win_dc_yhi", "win_dc_xlo", "win_dc_xhi"};
     for (int q = 0; q < 7; ++q) SIM_TRY(s, upload_window(s, dctags[q], dc[q], s->dcwin[q]));
   }
+  return APK_OK;
+}
+
+// apk_stage_args.face_neighbor of this rank's pack: the same-rank block behind every face, or -1
+// (a physical boundary, a block of another rank: those ghost zones are filled by the exchange)
+int build_face_table(apk_sim *s) {
+  const Mesh &m = s->mesh;
+  const int nlb = (int)m.local_gids.size();
+  std::vector<int> tab(6 * (size_t)nlb, -1);
+  for (int lb = 0; lb < nlb; ++lb) {
+    int bc[3], nbc[3];
+    m.Loc(m.local_gids[lb], bc);
+    for (int d = 0; d < 3; ++d)
+      for (int side = 0; side < 2; ++side) {
+        int o[3] = {0, 0, 0};
+        o[d] = side ? 1 : -1;
+        if (!m.Active(d) || !m.Neighbor(bc, o, nbc)) continue;
+        const int ngid = m.Gid(nbc);
+        if (m.gid_rank[ngid] == m.rank) tab[6 * (size_t)lb + 2 * d + side] = m.gid_local.at(ngid);
+      }
+  }
+  double *p = nullptr;
+  SIM_TRY(s, dev_alloc(s, "face_neighbors", sizeof(int) * tab.size(), &p));
+  s->d_face_nbr = reinterpret_cast<int *>(p);
+  SIM_HIP(s, hipMemcpy(s->d_face_nbr, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
   return APK_OK;
 }
 
@@ -615,6 +685,9 @@ int do_stage(apk_sim *s, int stage) {
   const double g0 = s->gam0[stage - 1], g1 = s->gam1[stage - 1];
   const double beta_dt = s->beta[stage - 1] * s->dt;
   const size_t field_bytes = (size_t)s->nper * s->mesh.local_gids.size() * sizeof(double);
+  // (a stage form that reads ghost zones after stages that did not fill the same-rank ones)
+  const bool direct = direct_neighbors(s);
+  if (!direct && s->local_ghosts_stale) SIM_TRY(s, sync_ghosts(s));
   if (stage == 1) {
     // "init u1" (hydro_driver.cpp:474-495) without the copy: the buffer holding u0 becomes the
     // register u1 and the stage writes the new u0 into the other buffer.  Valid because
@@ -631,6 +704,7 @@ int do_stage(apk_sim *s, int stage) {
   const apk_flux_cfg cfg = (stage == 1) ? pkg.flux_first_stage : pkg.flux_other_stage;
   bool fused_fill = false;
   s->stage_dt_pending = false;
+
   // an exchange left in flight is completed inside the fused stage below; anything else first
   if (s->exchange_pending && !can_overlap_next(s, stage)) SIM_TRY(s, finish_pending(s));
   if (stage_can_fuse(s)) {
@@ -644,6 +718,7 @@ int do_stage(apk_sim *s, int stage) {
     a.dedner = (pkg.fluid == APK_FLUID_GLMMHD) ? (pkg.glmmhd_source_extended ? 2 : 1) : 0;
     a.glmmhd_alpha = pkg.glmmhd_alpha;
     a.mindx = pkg.mindx;
+    a.face_neighbor = direct ? s->d_face_nbr : nullptr;
     // let the finishing sweep do FillDerived (and, in the last stage, the dt estimate) on the
     // cells it updates; only the ghost zones are converted after the exchange
     // (not when the turbulence driver kicks the state after this stage)
@@ -809,9 +884,9 @@ int do_stage(apk_sim *s, int stage) {
   if (fused_fill && can_overlap_next(s, stage < s->nstages ? stage + 1 : 1)) {
     // post the messages and leave them in flight: the next stage (of this or of the next cycle)
     // completes the exchange
-    SIM_TRY(s, exchange_begin(s, true, c2p_in_copy));
+    SIM_TRY(s, exchange_begin(s, true, c2p_in_copy, direct));
   } else {
-    SIM_TRY(s, exchange_ghosts(s, c2p_in_copy));
+    SIM_TRY(s, exchange_ghosts(s, c2p_in_copy, direct));
     if (fused_fill) {
       if (!c2p_in_copy) SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
     } else {
@@ -972,6 +1047,7 @@ int apk_sim_create(const char *deck, const char *const *overrides, int noverride
     }
   }
   if ((s->copy_stream || !s->mesh.peers.empty()) && (rc = build_windows(s)) != APK_OK) return bail(rc);
+  if (s->mesh.ndim == 3 && (rc = build_face_table(s)) != APK_OK) return bail(rc);
   if (s->fmft && (rc = turbulence_device_setup(s)) != APK_OK) return bail(rc);
   return APK_OK;
 }
@@ -1003,6 +1079,7 @@ void apk_sim_destroy(apk_sim *s) {
     for (auto &t : s->dcwin) dev_free(s, reinterpret_cast<double *>(t.d));
     for (auto &t : s->k3win) dev_free(s, reinterpret_cast<double *>(t.d));
     dev_free(s, reinterpret_cast<double *>(s->d_late_regions));
+    dev_free(s, reinterpret_cast<double *>(s->d_face_nbr));
     dev_free(s, s->d_acc);
     dev_free(s, s->d_phases);
     dev_free(s, s->d_cons2[0]);
@@ -1022,7 +1099,7 @@ const char *apk_sim_last_error(const apk_sim *s) { return s ? s->err.c_str() : "
 
 int apk_sim_set_fused(apk_sim *s, int fused) {
   if (!s) return APK_ERR_INVALID;
-  if (!s->host_only) SIM_TRY(s, finish_pending(s));
+  if (!s->host_only) SIM_TRY(s, sync_ghosts(s));
   s->fused = fused != 0;
   if (!s->host_only && !stage_can_fuse(s)) return ensure_flux_arrays(s);
   return APK_OK;
@@ -1030,12 +1107,19 @@ int apk_sim_set_fused(apk_sim *s, int fused) {
 
 int apk_sim_set_overlap(apk_sim *s, int overlap) {
   if (!s) return APK_ERR_INVALID;
-  if (!s->host_only) SIM_TRY(s, finish_pending(s));
+  if (!s->host_only) SIM_TRY(s, sync_ghosts(s));
   s->overlap = overlap != 0;
   return APK_OK;
 }
 
 long long apk_sim_overlapped_exchanges(const apk_sim *s) { return s ? s->overlapped : 0; }
+long long apk_sim_skipped_local_exchanges(const apk_sim *s) { return s ? s->skipped_local_exchanges : 0; }
+int apk_sim_set_direct_neighbors(apk_sim *s, int on) {
+  if (!s) return APK_ERR_INVALID;
+  if (!s->host_only) SIM_TRY(s, sync_ghosts(s));
+  s->direct_on = on != 0;
+  return APK_OK;
+}
 double apk_sim_loop_seconds(const apk_sim *s) { return s ? s->loop_seconds : 0.0; }
 int apk_sim_loop_cycles(const apk_sim *s) { return s ? s->perf_cycles : 0; }
 long long apk_sim_loop_zone_cycles(const apk_sim *s) { return s ? s->zone_cycles - s->perf_zone_mark : 0; }
@@ -1045,7 +1129,7 @@ int apk_sim_initialize(apk_sim *s) {
   s->err.clear();
   if (s->nranks > 1 && !(s->have_comm && s->comm.exchange && s->comm.allreduce_min && s->comm.allreduce_sum))
     return fail(s, APK_ERR_INVALID, "nranks > 1 requires comm ops (apk_sim_create) or the native transport (apk_sim_comm_rccl)");
-  SIM_TRY(s, finish_pending(s));
+  SIM_TRY(s, sync_ghosts(s));
   const int nlb = (int)s->mesh.local_gids.size();
   std::vector<double> host((size_t)s->nper);
   try {
@@ -1250,7 +1334,7 @@ void *apk_sim_block_ptr(const apk_sim *s, int lb, int field) {
 }
 
 int apk_sim_read_block(apk_sim *s, int lb, int field, double *host_out) {
-  if (s && !s->host_only) SIM_TRY(s, finish_pending(s));
+  if (s && !s->host_only) SIM_TRY(s, sync_ghosts(s));
   void *p = apk_sim_block_ptr(s, lb, field);
   if (!p || !host_out) return APK_ERR_INVALID;
   SIM_HIP(s, hipStreamSynchronize(hs(s)));
@@ -1259,7 +1343,7 @@ int apk_sim_read_block(apk_sim *s, int lb, int field, double *host_out) {
 }
 
 int apk_sim_write_block(apk_sim *s, int lb, int field, const double *host_in) {
-  if (s && !s->host_only) SIM_TRY(s, finish_pending(s));
+  if (s && !s->host_only) SIM_TRY(s, sync_ghosts(s));
   void *p = apk_sim_block_ptr(s, lb, field);
   if (!p || !host_in) return APK_ERR_INVALID;
   SIM_HIP(s, hipStreamSynchronize(hs(s)));
@@ -1356,7 +1440,7 @@ int apk_sim_read_acc(apk_sim *s, int lb, double *host_out) {
 // here; this is the tagging half of the AMR loop.
 int apk_sim_check_refinement(apk_sim *s, int *tags, double *crit) {
   if (!s || s->host_only || !tags) return APK_ERR_INVALID;
-  SIM_TRY(s, finish_pending(s));
+  SIM_TRY(s, sync_ghosts(s));
   int criterion;
   double p0, p1;
   SIM_TRY(s, refinement_criterion(s, &criterion, &p0, &p1));
@@ -1503,7 +1587,7 @@ int apk_sim_execute(apk_sim *s, const char *outdir, int *ncycles) {
         while (o.next <= s->time) o.next += o.dt;
       }
   }
-  SIM_TRY(s, finish_pending(s));
+  SIM_TRY(s, sync_ghosts(s));
   SIM_HIP(s, hipStreamSynchronize(hs(s)));
   s->loop_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (s->problem_id == "linear_wave" && s->lw.compute_error)
@@ -1628,12 +1712,12 @@ int apk_sim_write_cpaw_errors(apk_sim *s, const char *path) {
 
 int apk_sim_exchange_ghosts(apk_sim *s) {
   if (!s || s->host_only) return APK_ERR_INVALID;
-  SIM_TRY(s, finish_pending(s));
+  SIM_TRY(s, sync_ghosts(s));
   return exchange_ghosts(s);
 }
 int apk_sim_fill_derived(apk_sim *s) {
   if (!s || s->host_only) return APK_ERR_INVALID;
-  SIM_TRY(s, finish_pending(s));
+  SIM_TRY(s, sync_ghosts(s));
   return fill_derived(s);
 }
 int apk_sim_estimate_timestep(apk_sim *s, double *dt) {

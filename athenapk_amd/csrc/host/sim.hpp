@@ -160,6 +160,15 @@ struct apk_sim {
   WindowTable x1win[3], dcwin[7];
   WindowTable k3win[3];  // two-kernel stages: plane windows of the x3 sweep (main, low slab, high slab)
   unsigned *d_late_regions = nullptr;  // per block: bit (sx+1)+3(sy+1)+9(sz+1) = that neighbour region is filled late
+  // Direct neighbour addressing (apk_stage_args.face_neighbor; uniform 3-D meshes): per local block
+  // and face the local index of the same-rank block behind it, or -1.  While every stage of the
+  // cycle is one of the kernels that follow the table, the same-rank ghost copies are skipped
+  // altogether and the ghost zones behind those faces go stale; whoever needs them (accessors, a
+  // stage form that reads ghost zones) calls sync_ghosts() / materialize_local_ghosts() first.
+  int *d_face_nbr = nullptr;
+  bool local_ghosts_stale = false;
+  bool direct_on = true;  // apk_sim_set_direct_neighbors
+  long long skipped_local_exchanges = 0;
   // mesh refinement (parthenon/mesh/refinement = static | adaptive; one rank): the forest of
   // blocks, the index-box plans of the multilevel ghost exchange / flux correction and their device
   // forms, one set per cons buffer the exchange can target

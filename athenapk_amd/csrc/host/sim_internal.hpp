@@ -59,13 +59,16 @@ void set_global_dt(apk_sim *s, double dt_est);
 int estimate_timestep(apk_sim *s, double *dt_out);
 bool ghost_c2p_fusable(const apk_sim *s);
 int run_ghost_plan(apk_sim *s, int buf, int phase, bool c2p, apk_stream_t stream = nullptr);
-int exchange_begin(apk_sim *s, bool async, bool c2p);
+int exchange_begin(apk_sim *s, bool async, bool c2p, bool skip_local = false);
 int exchange_end(apk_sim *s, bool c2p);
-int exchange_ghosts(apk_sim *s, bool c2p = false);
+int exchange_ghosts(apk_sim *s, bool c2p = false, bool skip_local = false);
 int upload_window(apk_sim *s, const char *tag, const std::vector<int> &w, apk_sim::WindowTable &t);
 int build_windows(apk_sim *s);
 bool can_overlap_next(const apk_sim *s, int next);
 int finish_pending(apk_sim *s);
+bool direct_neighbors(const apk_sim *s);
+int materialize_local_ghosts(apk_sim *s);
+int sync_ghosts(apk_sim *s);  // finish_pending + materialize_local_ghosts
 int fill_derived(apk_sim *s);
 int pre_step(apk_sim *s);
 int turbulence_device_setup(apk_sim *s);

@@ -361,6 +361,13 @@ class Simulation(_FmftHost, _MeshView):
     def overlapped_exchanges(self):
         return self.lib.apk_sim_overlapped_exchanges(self.h)
 
+    def skipped_local_exchanges(self):
+        return self.lib.apk_sim_skipped_local_exchanges(self.h)
+
+    def set_direct_neighbors(self, on):
+        self._check(self.lib.apk_sim_set_direct_neighbors(self.h, int(on)))
+        return self
+
     def set_fused(self, fused):
         self._check(self.lib.apk_sim_set_fused(self.h, int(fused)))
         self._check(self.lib.apk_sim_get_info(self.h, C.byref(self.info)))

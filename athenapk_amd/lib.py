@@ -57,7 +57,8 @@ class StageArgs(C.Structure):
                 ("gam1", C.c_double), ("beta_dt", C.c_double), ("dedner", C.c_int),
                 ("glmmhd_alpha", C.c_double), ("mindx", C.c_double), ("fill_derived", C.c_int),
                 ("estimate_dt", C.c_int), ("phase", C.c_int), ("window", C.c_void_p),
-                ("window_rl", C.c_int), ("window_rows", C.c_int), ("trial", C.c_int), ("count_unphysical", C.c_int), ("cons_out_delta", C.c_int64)]
+                ("window_rl", C.c_int), ("window_rows", C.c_int), ("trial", C.c_int), ("count_unphysical", C.c_int), ("cons_out_delta", C.c_int64),
+                ("face_neighbor", C.c_void_p)]
 
 
 class FmftBlock(C.Structure):
@@ -208,6 +209,8 @@ def _signatures():
         "apk_sim_set_fused": (i, [vp, i]),
         "apk_sim_set_overlap": (i, [vp, i]),
         "apk_sim_overlapped_exchanges": (ll, [vp]),
+        "apk_sim_skipped_local_exchanges": (ll, [vp]),
+        "apk_sim_set_direct_neighbors": (C.c_int, [vp, C.c_int]),
         "apk_sim_loop_seconds": (d, [vp]),
         "apk_sim_loop_cycles": (i, [vp]),
         "apk_sim_get_info": (i, [vp, C.POINTER(SimInfo)]),

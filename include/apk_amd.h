@@ -210,6 +210,19 @@ typedef struct apk_stage_args {
    * (RK2 / RK3 later stages), whose fallback needs the old u0.  Interior cells only; not with
    * passive scalars. */
   int64_t cons_out_delta;
+  /* face_neighbor != NULL: direct neighbour addressing.  A DEVICE array of 6 ints per block of the
+   * pack {x1 lower, x1 upper, x2 lower, x2 upper, x3 lower, x3 upper}: the pack index of the block
+   * of the same size behind that face whose INTERIOR stands in for this block's ghost zone there,
+   * or -1 to read the ghost zone itself (a physical boundary, a neighbour on another rank).  With
+   * it the same-rank ghost-zone copies of a uniform mesh -- 11 % of a VL2 cycle on 8 x 128^3 --
+   * are not needed at all: the reference fills every ghost zone through boundary buffers
+   * (hydro_driver.cpp:506-569 SendBoundBufs / SetBounds), the stage kernels here follow the table.
+   * Only the face neighbours are read (the unsplit sweeps never touch edge or corner ghost cells);
+   * the ghost zones behind faces with an entry >= 0 are neither read nor written.  3-D only, for the
+   * stage forms whose kernels follow the table: donor cell (single march, fill_derived 0 or 2) and
+   * the two-kernel stage (apk_stage_split_axis() == 3); not with passive scalars nor dedner = 2
+   * (APK_ERR_UNSUPPORTED). */
+  const int *face_neighbor;
 } apk_stage_args;
 int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
                     const apk_stage_args *args, apk_stream_t stream);

@@ -718,3 +718,108 @@ def test_fused_stage_with_passive_scalars(request, oracle, fluid, recon, riemann
         _, want_prim, _ = H.orc_c2p(fluid, g, want, oracle.make_eos(GAMMA, **eos_kw))
         got = (m1 if fill == 2 else m0).prim_host()
         _cmp(H.interior(got, nx, ng), H.interior(want_prim, nx, ng), strict, "prim incl. concentrations")
+
+
+# ---- direct neighbour addressing (apk_stage_args.face_neighbor) ------------------------------------------------
+def _fill_faces_from_neighbors(a, table, nx, ng):
+    """host reference of the table's meaning: the ghost zone behind face f of block b (interior extent in the other
+    two directions) := the adjacent interior layers of block table[b][f], shifted by one block length"""
+    out = a.copy()
+    I = [slice(ng, ng + nx[0]), slice(ng, ng + nx[1]), slice(ng, ng + nx[2])]   # interior ranges along x1, x2, x3
+    for b, row in enumerate(table):
+        for f, nb in enumerate(row):
+            if nb < 0:
+                continue
+            d, hi = f // 2, f % 2
+            dst, src = list(I), list(I)
+            dst[d] = slice(ng + nx[d], ng + nx[d] + ng) if hi else slice(0, ng)
+            src[d] = slice(ng, 2 * ng) if hi else slice(nx[d], nx[d] + ng)
+            out[b][:, dst[2], dst[1], dst[0]] = a[nb][:, src[2], src[1], src[0]]
+    return out
+
+
+def _poison_faces(a, table, nx, ng):
+    out = a.copy()
+    I = [slice(ng, ng + nx[0]), slice(ng, ng + nx[1]), slice(ng, ng + nx[2])]
+    for b, row in enumerate(table):
+        for f, nb in enumerate(row):
+            if nb < 0:
+                continue
+            d, hi = f // 2, f % 2
+            dst = list(I)
+            dst[d] = slice(ng + nx[d], ng + nx[d] + ng) if hi else slice(0, ng)
+            out[b][:, dst[2], dst[1], dst[0]] = np.nan
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("fluid,recon,riemann,gam0", [("glmmhd", "dc", "hlld", 0.0), ("glmmhd", "ppm", "hlld", 0.0),
+                                                      ("glmmhd", "ppm", "hlld", 0.5), ("glmmhd", "wenoz", "hlld", 0.25),
+                                                      ("euler", "plm", "hllc", 0.0), ("euler", "dc", "hlle", 0.0),
+                                                      ("glmmhd", "plm", "hlle", 0.5)])
+@pytest.mark.parametrize("nx", [(36, 9, 10), (64, 8, 8)], ids=["36x9x10", "64x8x8"])
+def test_direct_neighbor_addressing_equals_filled_ghost_zones(request, fluid, recon, riemann, gam0, nx, strict):
+    """apk_stage_args.face_neighbor: the stage that reads its neighbours' interiors through the table, with the
+    ghost zones behind those faces poisoned, equals the stage on ghost zones filled from the same neighbours -- bit
+    for bit, in the updated state, the out-of-place primitives and the time step.  The table mixes other blocks, a
+    block that is its own periodic neighbour and faces without an entry (their ghost zones are read as before)."""
+    import ctypes as C
+    import torch
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    ng, prim, g = _case(fluid, recon, nx, kind="smooth", seed=67, nblocks=3)
+    table = [[1, 1, 2, -1, 0, -1],
+             [0, 2, -1, 2, 1, 1],
+             [-1, 0, 1, 0, -1, 2]]
+    prim_ref = _fill_faces_from_neighbors(prim, table, nx, ng)
+    prim_dir = _poison_faces(prim_ref, table, nx, ng)
+    cons = H.prim_to_cons(fluid, prim_ref, GAMMA)
+    ded = 1 if fluid == "glmmhd" else 0
+    eos = hydro.L.make_eos(GAMMA)
+    gam1 = 1.0 - gam0 if gam0 else 1.0
+    last = recon != "dc"
+    kw = dict(dedner=ded, glmmhd_alpha=0.1, mindx=0.07, fill_derived=2, estimate_dt=last)
+    cfg = hydro._cfg(fluid, recon, riemann)
+
+    def run(w, tab):
+        a = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=cons, prim=w, with_flux=False)
+        b = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=cons * 1.01, prim=np.full_like(w, -7.0),
+                           with_flux=False)
+        if recon != "dc":
+            assert ctx.lib.apk_stage_split_axis(a.h, C.byref(cfg), 2) == 3
+        hydro.StageFused(a, b, fluid, recon, riemann, eos, C_H, gam0, gam1, 0.004, face_neighbor=tab, **kw)
+        dt = hydro.StageDt(ctx, 0.3) if last else 0.0
+        return H.interior(a.cons_host(), nx, ng), H.interior(b.prim_host(), nx, ng), dt
+    want = run(prim_ref, None)
+    got = run(prim_dir, torch.tensor(table, dtype=torch.int32, device="cuda"))
+    assert np.all(np.isfinite(got[0])) and np.all(np.isfinite(got[1]))
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2]
+    # and the unsplit stage on filled ghost zones is the oracle's
+    ref = H.orc_stage(fluid, recon, riemann, g, cons, cons * 1.01, prim_ref, GAMMA, C_H, gam0, gam1, 0.004, dedner=ded,
+                      alpha=0.1, mindx=0.07)
+    _cmp(want[0], H.interior(ref, nx, ng), strict, "cons")
+
+
+@pytest.mark.gpu
+def test_direct_neighbor_addressing_rejects_stage_forms_that_read_ghost_zones(request):
+    import torch
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    nx = (16, 8, 8)                                  # narrower than the two-kernel stage wants: three sweeps
+    ng, prim, g = _case("glmmhd", "ppm", nx, nblocks=1)
+    cons = H.prim_to_cons("glmmhd", prim, GAMMA)
+    a = hydro.MeshData(ctx, nx, ng, 9, dx=tuple(g.dx), nblocks=1, cons=cons, prim=prim, with_flux=False)
+    b = hydro.MeshData(ctx, nx, ng, 9, dx=tuple(g.dx), nblocks=1, cons=cons, prim=prim, with_flux=False)
+    tab = torch.zeros((1, 6), dtype=torch.int32, device="cuda")
+    with pytest.raises(Exception):
+        hydro.StageFused(a, b, "glmmhd", "ppm", "hlld", hydro.L.make_eos(GAMMA), C_H, 0.0, 1.0, 0.004, dedner=1,
+                         fill_derived=2, face_neighbor=tab)
+    with pytest.raises(Exception):                   # the extended Dedner source reads neighbouring primitives
+        nx2 = (64, 8, 8)
+        ng2, p2, g2 = _case("glmmhd", "ppm", nx2, nblocks=1)
+        c2 = H.prim_to_cons("glmmhd", p2, GAMMA)
+        a2 = hydro.MeshData(ctx, nx2, ng2, 9, dx=tuple(g2.dx), nblocks=1, cons=c2, prim=p2, with_flux=False)
+        b2 = hydro.MeshData(ctx, nx2, ng2, 9, dx=tuple(g2.dx), nblocks=1, cons=c2, prim=p2, with_flux=False)
+        hydro.StageFused(a2, b2, "glmmhd", "ppm", "hlld", hydro.L.make_eos(GAMMA), C_H, 0.0, 1.0, 0.004, dedner=2,
+                         fill_derived=2, face_neighbor=tab)
