@@ -182,7 +182,7 @@ void apk_pack_destroy(apk_pack *pack) {
 
 namespace {
 int calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos, double c_h, int faces,
-                     apk_stream_t stream) {
+                     apk_stream_t stream, const unsigned char *face_mask = nullptr) {
   if (!ctx || !md || !valid_eos(eos)) return set_err(ctx, APK_ERR_INVALID, "apk_calculate_fluxes: bad argument");
   int rc = check_cfg(ctx, md, cfg);
   if (rc != APK_OK) return rc;
@@ -198,11 +198,11 @@ int calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const a
   if (cfg.riemann == APK_RS_NONE || cfg.riemann == APK_RS_LLF)
     rc = launch_fluxes_misc(pv, cfg.fluid, cfg.riemann, eos->gamma, c_h, s);
   else if (cfg.fluid == APK_FLUID_EULER)
-    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_euler_hlle(pv, cfg.recon, eos->gamma, c_h, s, faces)
-                                      : launch_fluxes_euler_hllc(pv, cfg.recon, eos->gamma, c_h, s, faces);
+    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_euler_hlle(pv, cfg.recon, eos->gamma, c_h, s, faces, face_mask)
+                                      : launch_fluxes_euler_hllc(pv, cfg.recon, eos->gamma, c_h, s, faces, face_mask);
   else
-    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_mhd_hlle(pv, cfg.recon, eos->gamma, c_h, s, faces)
-                                      : launch_fluxes_mhd_hlld(pv, cfg.recon, eos->gamma, c_h, s, faces);
+    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_mhd_hlle(pv, cfg.recon, eos->gamma, c_h, s, faces, face_mask)
+                                      : launch_fluxes_mhd_hlld(pv, cfg.recon, eos->gamma, c_h, s, faces, face_mask);
   if (rc != APK_OK) return set_err(ctx, rc, "flux kernel launch failed", hipGetLastError());
   return APK_OK;
 }
@@ -221,6 +221,11 @@ int apk_calculate_fluxes_tight(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cf
 int apk_calculate_fluxes_boundary(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos,
                                   double c_h, apk_stream_t stream) {
   return calculate_fluxes(ctx, md, cfg, eos, c_h, 2, stream);
+}
+
+int apk_calculate_fluxes_boundary_masked(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos,
+                                         double c_h, const unsigned char *face_mask, apk_stream_t stream) {
+  return calculate_fluxes(ctx, md, cfg, eos, c_h, 2, stream, face_mask);
 }
 
 int apk_update_with_flux_divergence(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,

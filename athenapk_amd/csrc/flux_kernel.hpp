@@ -18,6 +18,10 @@ namespace apk {
 
 struct FluxExtent {
   int i0, i1, j0, j1, k0, k1;
+  // boundary planes only: mask[6 * block + face] == 0 skips that block (its face has no coarse-fine
+  // neighbour, nothing reads the plane); NULL = every block
+  const unsigned char *mask = nullptr;
+  int face = 0;
 };
 
 // the reference's loop limits (hydro.cpp:1031-1039, 1106-1110, 1158)
@@ -103,6 +107,7 @@ flux_kernel(PackView pv, FluxExtent e, double gamma, double c_h) {
     b = blockIdx.z / nke;
     k = e.k0 + blockIdx.z % nke;
   }
+  if (e.mask && !e.mask[6 * b + e.face]) return;  // (workgroup-uniform)
   const apk_block_desc blk = pv.blocks[b];
   const int64_t st = (DIR == 1) ? 1 : ((DIR == 2) ? pv.sj : pv.sk);
   const int64_t cell = k * pv.sk + j * pv.sj + i;
@@ -161,10 +166,15 @@ inline FluxExtent boundary_extent(const PackView &pv, int dir, int side) {
 }
 
 template <int FLUID, int RECON, int RS, int DIR>
-inline void launch_flux_faces(const PackView &pv, double gamma, double c_h, hipStream_t s, int faces) {
+inline void launch_flux_faces(const PackView &pv, double gamma, double c_h, hipStream_t s, int faces,
+                              const unsigned char *face_mask) {
   if (faces == FLUX_FACES_BOUNDARY) {
-    launch_flux_dir<FLUID, RECON, RS, DIR>(pv, boundary_extent(pv, DIR, 0), gamma, c_h, s);
-    launch_flux_dir<FLUID, RECON, RS, DIR>(pv, boundary_extent(pv, DIR, 1), gamma, c_h, s);
+    for (int side = 0; side < 2; ++side) {
+      FluxExtent e = boundary_extent(pv, DIR, side);
+      e.mask = face_mask;
+      e.face = 2 * (DIR - 1) + side;
+      launch_flux_dir<FLUID, RECON, RS, DIR>(pv, e, gamma, c_h, s);
+    }
   } else {
     launch_flux_dir<FLUID, RECON, RS, DIR>(pv, faces == FLUX_FACES_TIGHT ? tight_extent(pv, DIR) : flux_extent(pv, DIR), gamma,
                                            c_h, s);
@@ -173,24 +183,24 @@ inline void launch_flux_faces(const PackView &pv, double gamma, double c_h, hipS
 
 template <int FLUID, int RECON, int RS>
 inline int launch_flux_all_dirs(const PackView &pv, double gamma, double c_h, hipStream_t s,
-                                int faces = FLUX_FACES_REFERENCE) {
-  launch_flux_faces<FLUID, RECON, RS, 1>(pv, gamma, c_h, s, faces);
-  if (pv.ndim >= 2) launch_flux_faces<FLUID, RECON, RS, 2>(pv, gamma, c_h, s, faces);
-  if (pv.ndim >= 3) launch_flux_faces<FLUID, RECON, RS, 3>(pv, gamma, c_h, s, faces);
+                                int faces = FLUX_FACES_REFERENCE, const unsigned char *face_mask = nullptr) {
+  launch_flux_faces<FLUID, RECON, RS, 1>(pv, gamma, c_h, s, faces, face_mask);
+  if (pv.ndim >= 2) launch_flux_faces<FLUID, RECON, RS, 2>(pv, gamma, c_h, s, faces, face_mask);
+  if (pv.ndim >= 3) launch_flux_faces<FLUID, RECON, RS, 3>(pv, gamma, c_h, s, faces, face_mask);
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }
 
 // recon dispatch for one (fluid, riemann) family: the registry of hydro.cpp:386-416
 template <int FLUID, int RS>
 inline int launch_flux_family(const PackView &pv, int recon, double gamma, double c_h,
-                              hipStream_t s, int faces) {
+                              hipStream_t s, int faces, const unsigned char *face_mask = nullptr) {
   switch (recon) {
-  case APK_RC_DC: return launch_flux_all_dirs<FLUID, APK_RC_DC, RS>(pv, gamma, c_h, s, faces);
-  case APK_RC_PLM: return launch_flux_all_dirs<FLUID, APK_RC_PLM, RS>(pv, gamma, c_h, s, faces);
-  case APK_RC_PPM: return launch_flux_all_dirs<FLUID, APK_RC_PPM, RS>(pv, gamma, c_h, s, faces);
-  case APK_RC_WENOZ: return launch_flux_all_dirs<FLUID, APK_RC_WENOZ, RS>(pv, gamma, c_h, s, faces);
-  case APK_RC_WENO3: return launch_flux_all_dirs<FLUID, APK_RC_WENO3, RS>(pv, gamma, c_h, s, faces);
-  case APK_RC_LIMO3: return launch_flux_all_dirs<FLUID, APK_RC_LIMO3, RS>(pv, gamma, c_h, s, faces);
+  case APK_RC_DC: return launch_flux_all_dirs<FLUID, APK_RC_DC, RS>(pv, gamma, c_h, s, faces, face_mask);
+  case APK_RC_PLM: return launch_flux_all_dirs<FLUID, APK_RC_PLM, RS>(pv, gamma, c_h, s, faces, face_mask);
+  case APK_RC_PPM: return launch_flux_all_dirs<FLUID, APK_RC_PPM, RS>(pv, gamma, c_h, s, faces, face_mask);
+  case APK_RC_WENOZ: return launch_flux_all_dirs<FLUID, APK_RC_WENOZ, RS>(pv, gamma, c_h, s, faces, face_mask);
+  case APK_RC_WENO3: return launch_flux_all_dirs<FLUID, APK_RC_WENO3, RS>(pv, gamma, c_h, s, faces, face_mask);
+  case APK_RC_LIMO3: return launch_flux_all_dirs<FLUID, APK_RC_LIMO3, RS>(pv, gamma, c_h, s, faces, face_mask);
   default: return APK_ERR_UNSUPPORTED;
   }
 }

@@ -670,8 +670,11 @@ fused_march12_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_blo
 // against 504 B/cell of the two-march schedule.  prim is only read, so no lane can observe a
 // half-updated state; FillDerived of the stage is left to ConservedToPrimitive.
 // ==============================================================================================
+#ifndef APK_DC3_WAVES
+#define APK_DC3_WAVES 2  // resident waves per SIMD the donor-cell march is compiled for (A/B)
+#endif
 template <int FLUID, int RS, int EXTRA = EXTRA_NONE>
-__global__ void __launch_bounds__(64, kMarchMinWaves)
+__global__ void __launch_bounds__(64, APK_DC3_WAVES)
 fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, int nseg, int per_xcd) {
   constexpr int NV = nvars<FLUID>();
   double lane_min_dt = 1.7976931348623157e308;

@@ -226,6 +226,8 @@ void amr_destroy_graphs(apk_sim *s);
 void amr_destroy_device_plans(apk_sim *s) {
   auto &a = s->amr_dev;
   amr_destroy_graphs(s);
+  dev_free(s, reinterpret_cast<double *>(a.d_cf_faces));
+  a.d_cf_faces = nullptr;
   for (int par = 0; par < 2; ++par) {
     for (apk_refine_plan *p : a.restrict_own[par]) apk_refine_plan_destroy(p);
     for (apk_refine_plan *p : a.prolongate[par]) apk_refine_plan_destroy(p);
@@ -386,6 +388,25 @@ int amr_rebuild(apk_sim *s) {
       SIM_TRY(s, amr_make_fix_plan(s, par, d, p.flux_unpack[d], &s->amr_fluxmsg, &a.flux_fix_unpack[par][d]));
     }
   }
+  {  // faces with a level change behind them
+    const int nlb = (int)s->mesh.local_gids.size(), first = s->amr_part.first[s->rank];
+    const AmrTree &t = *s->amr;
+    std::vector<unsigned char> cf(6 * (size_t)nlb, 0);
+    for (int lb = 0; lb < nlb; ++lb) {
+      const AmrLeaf &l = t.leaves[first + lb];
+      for (int d = 0; d < 3; ++d)
+        for (int side = 0; side < 2 && t.act[d]; ++side) {
+          int pos[3] = {l.lx[0], l.lx[1], l.lx[2]}, leaf;
+          pos[d] += side ? 1 : -1;
+          const int kind = t.Classify(l.level, pos, &leaf);
+          cf[6 * (size_t)lb + 2 * d + side] = (kind == NB_FINER || kind == NB_COARSER) ? 1 : 0;
+        }
+    }
+    double *p8 = nullptr;
+    SIM_TRY(s, dev_alloc(s, "cf_faces", cf.size() + 8, &p8));
+    a.d_cf_faces = reinterpret_cast<unsigned char *>(p8);
+    SIM_HIP(s, hipMemcpy(a.d_cf_faces, cf.data(), cf.size(), hipMemcpyHostToDevice));
+  }
   for (int par = 0; par < 2; ++par) {
     amr_capture_half(s, par, true, &a.xchg_pre[par]);
     amr_capture_half(s, par, false, &a.xchg_post[par]);
@@ -475,7 +496,9 @@ int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi
   if (!amr_has_coarse_fine_faces(s)) return APK_OK;
   auto &a = s->amr_dev;
   const int psi_var = (s->pkg.fluid == APK_FLUID_GLMMHD) ? 8 : -1;
-  SIM_TRY(s, apk_calculate_fluxes_boundary(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, s->stream));
+  static const bool all_planes = std::getenv("APK_AMR_ALL_PLANES") != nullptr;  // A/B switch
+  SIM_TRY(s, apk_calculate_fluxes_boundary_masked(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h,
+                                                  all_planes ? nullptr : a.d_cf_faces, s->stream));
   for (int d = 0; d < s->mesh.ndim; ++d) {
     for (apk_refine_plan *p : a.flux_restrict[d]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
     SIM_TRY(s, apk_flux_fix_plan_run(s->ctx, a.flux_fix[s->cur][d], beta_dt, psi_var, psi_factor, s->stream));

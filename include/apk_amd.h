@@ -130,6 +130,12 @@ int apk_calculate_fluxes_tight(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cf
  * (apk_stage_fused never materialises face fluxes; see apk_flux_fix_plan below). */
 int apk_calculate_fluxes_boundary(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg,
                                   const apk_eos *eos, double c_h, apk_stream_t stream);
+/* The same with a DEVICE mask of 6 bytes per block {x1 lower, x1 upper, x2 lower, ...}: a plane is only
+ * computed where its byte is non-zero -- on a refined mesh the faces with a coarser or finer block
+ * behind them (the fine side's fluxes are averaged, the coarse side's own flux is what the average
+ * replaces); the planes of the other faces are left untouched.  face_mask == NULL: every plane. */
+int apk_calculate_fluxes_boundary_masked(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos,
+                                         double c_h, const unsigned char *face_mask, apk_stream_t stream);
 
 /* Replaces parthenon::Update::UpdateWithFluxDivergence<MeshData<Real>>(u0,u1,gam0,gam1,
  * beta_dt); call site src/hydro/hydro_driver.cpp:534-537.

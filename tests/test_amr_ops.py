@@ -251,6 +251,22 @@ def test_boundary_plane_fluxes_equal_the_full_sweeps(request, fluid, recon, riem
             assert np.array_equal(a[sl], b[sl]) and np.abs(b[sl]).max() > 0
             mask[sl] = True
         assert np.all(b[~mask] == 0.0)
+    # ... and with a face mask only the planes asked for (the coarse-fine faces of a refined mesh)
+    import torch
+    want = np.array([[1, 0, 0, 1, 1, 0], [0, 0, 0, 0, 0, 0], [0, 1, 1, 1, 0, 1]], dtype=np.uint8)
+    msk = hydro.MeshData(ctx, nx, ng, nh, nscalars=1, dx=(0.1, 0.2, 0.3), nblocks=3, prim=prim)
+    hydro.CalculateFluxes(msk, fluid, recon, riemann, eos, 1.3, boundary=True, face_mask=torch.tensor(want, device="cuda"))
+    for d in range(full.ndim):
+        a, m = bnd.flux_host(d), msk.flux_host(d)
+        for blk in range(3):
+            for side in (0, 1):
+                sl = [blk, slice(None)] + [slice(ng, ng + nx[q]) if act[q] else slice(None) for q in (2, 1, 0)]
+                sl[4 - d] = ng + (nx[d] if side else 0)
+                sl = tuple(sl)
+                if want[blk, 2 * d + side]:
+                    assert np.array_equal(m[sl], a[sl])
+                else:
+                    assert np.all(m[sl] == 0.0)
 
 
 @pytest.mark.gpu
