@@ -70,6 +70,8 @@ struct apk_ctx {
   unsigned char *d_mark = nullptr;   // FOFC cell marks
   size_t mark_cap = 0;
   void *h_pinned = nullptr;          // 256 B pinned host staging
+  double *h_partial = nullptr;       // pinned host mirror of d_partial (per-block reductions read back every cycle)
+  size_t h_partial_cap = 0;
   double *d_du = nullptr;            // fused path: flux-difference accumulator
   size_t du_cap = 0;                 // in doubles
   double *d_mflux = nullptr;         // fused path with passive scalars: mass flux per face, [3][nblocks][sn]

@@ -128,6 +128,7 @@ void apk_destroy(apk_ctx *ctx) {
   if (ctx->d_mark) (void)hipFree(ctx->d_mark);
   if (ctx->d_du) (void)hipFree(ctx->d_du);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  if (ctx->h_partial) (void)hipHostFree(ctx->h_partial);
   for (auto &sp : ctx->spans) {
     (void)hipEventDestroy(sp.start);
     (void)hipEventDestroy(sp.stop);

@@ -68,6 +68,7 @@ struct AmrTree {
   std::unordered_set<uint64_t> internal;
   std::vector<AmrLeaf> leaves;
   std::unordered_map<uint64_t, int> index;
+  long long modifications = 0;  // blocks split or merged so far (an unchanged count = an unchanged forest)
 
   static uint64_t Key(int level, const int lx[3]) {
     return ((uint64_t)level << 57) | ((uint64_t)lx[2] << 38) | ((uint64_t)lx[1] << 19) | (uint64_t)lx[0];
@@ -183,6 +184,7 @@ struct AmrTree {
     });
     leafmap.erase(key);
     internal.insert(key);
+    ++modifications;
     ForEachChild(lx, [&](const int *, const int cl[3]) {
       AmrLeaf c;
       c.level = level + 1;
@@ -214,6 +216,7 @@ struct AmrTree {
   }
 
   void Merge(int level, const int plx[3]) {
+    ++modifications;
     internal.erase(Key(level, plx));
     ForEachChild(plx, [&](const int *, const int cl[3]) { leafmap.erase(Key(level + 1, cl)); });
     AmrLeaf p;

@@ -564,6 +564,7 @@ int refinement_criterion(apk_sim *s, int *criterion, double *p0, double *p1) {
 bool amr_update_tree(apk_sim *s, const std::vector<int> &tags, bool allow_derefine) {
   AmrTree &t = *s->amr;
   const std::vector<AmrLeaf> old = t.leaves;
+  const long long mods_before = t.modifications;
   bool changed = false;
   for (int lb = 0; lb < (int)old.size(); ++lb) {
     if (tags[lb] < 0 && allow_derefine) t.SetDerefCount(lb, old[lb].deref_count + 1);
@@ -590,6 +591,8 @@ bool amr_update_tree(apk_sim *s, const std::vector<int> &tags, bool allow_derefi
       }
     }
   }
+  // (the common case, every cycle of a run: nothing split, nothing merged -- `leaves` and `index` are current)
+  if (t.modifications == mods_before) return false;
   for (const AmrLeaf &l : old) {
     if (!t.leafmap.count(AmrTree::Key(l.level, l.lx))) changed = true;
     if (t.internal.count(AmrTree::Key(l.level, l.lx))) s->amr_refined += 1;

@@ -429,8 +429,15 @@ int apk_tag_blocks(apk_ctx *ctx, const apk_pack *md, int criterion, double p0, d
     hipLaunchKernelGGL(tag_kernel<APK_TAG_VELOCITY_GRADIENT>, grid, block, 0, s, pv, d_max);
   else
     hipLaunchKernelGGL(tag_kernel<APK_TAG_MAX_DENSITY>, grid, block, 0, s, pv, d_max);
-  std::vector<double> h(nb);
-  APK_HIP_TRY(ctx, hipMemcpyAsync(h.data(), d_max, sizeof(double) * nb, hipMemcpyDeviceToHost, s));
+  if (ctx->h_partial_cap < (size_t)nb) {  // (pinned: a pageable destination costs a staging copy every cycle)
+    if (ctx->h_partial) (void)hipHostFree(ctx->h_partial);
+    ctx->h_partial = nullptr;
+    ctx->h_partial_cap = 0;
+    APK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_partial), sizeof(double) * (nb + 64), hipHostMallocDefault));
+    ctx->h_partial_cap = nb + 64;
+  }
+  const double *h = ctx->h_partial;
+  APK_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partial, d_max, sizeof(double) * nb, hipMemcpyDeviceToHost, s));
   APK_HIP_TRY(ctx, hipStreamSynchronize(s));
   const double refine_above = p0;
   const double deref_below = (criterion == APK_TAG_PRESSURE_GRADIENT) ? 0.25 * p0

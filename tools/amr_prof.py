@@ -4,7 +4,7 @@ sys.path.insert(0, ".")
 from athenapk_amd import decks, driver
 ov = ["parthenon/mesh/nx%d=64" % d for d in (1, 2, 3)] + ["parthenon/meshblock/nx%d=16" % d for d in (1, 2, 3)] + [
     "parthenon/mesh/numlevel=4", "parthenon/time/tlim=1.0", "hydro/fluid=glmmhd", "hydro/riemann=hlld", "hydro/reconstruction=ppm",
-    "parthenon/mesh/nghost=4", "problem/blast/pressure_ambient=1.0", "problem/blast/pressure_ratio=100"]
+    "parthenon/mesh/nghost=4", "problem/blast/pressure_ambient=1.0", "problem/blast/pressure_ratio=100"] + sys.argv[1:]
 s = driver.Simulation(decks.load("blast_3d_amr"), ov).initialize()
 for _ in range(3): s.step()
 torch.cuda.synchronize(); z0 = s.amr_stats()[3]; t = time.perf_counter(); n = 0
