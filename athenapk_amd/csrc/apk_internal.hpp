@@ -89,10 +89,19 @@ struct apk_ctx {
   char err[512] = {0};
 };
 
+// A copy plan's work list: the regions cut into chunks of at most kCopyChunkItems (cell, variable)
+// items / kCopyChunkCells cells, one workgroup per chunk -- the boxes of a plan range from 64-cell
+// corners to whole faces, and a (largest box) x (regions) grid leaves most workgroups empty.
+constexpr int kCopyChunkItems = 1024, kCopyChunkCells = 256;
+struct apk_copy_chunk {
+  int region, first;  // first item (plain copy) / first cell (ConsToPrim variant) of the chunk
+};
 struct apk_copy_plan {
   apk_copy_region *d_regions = nullptr;
   int n = 0;
   int64_t max_cells = 0, max_items = 0;  // largest box in cells / in cells x variables
+  apk_copy_chunk *d_chunks_items = nullptr, *d_chunks_cells = nullptr;
+  int nchunks_items = 0, nchunks_cells = 0;
 };
 
 namespace apk {
@@ -144,9 +153,8 @@ int launch_fofc_mark(const PackView &u0, const PackView &u1, int fluid, double g
 int launch_count_unphysical(const PackView &u0, int fluid, unsigned long long *d_count, hipStream_t s);
 int launch_fofc_fix(const PackView &u0, int fluid, double gamma, double c_h,
                     const unsigned char *d_mark, hipStream_t s);
-int launch_copy_regions(const apk_copy_region *d_regions, int n, int64_t max_cells, int64_t max_items, hipStream_t s,
-                        int c2p_fluid = 0, const apk_eos *eos = nullptr, unsigned *d_flags = nullptr,
-                        int64_t prim_delta = 0);
+int launch_copy_regions(const apk_copy_plan &plan, hipStream_t s, int c2p_fluid = 0, const apk_eos *eos = nullptr,
+                        unsigned *d_flags = nullptr, int64_t prim_delta = 0);
 // fused stage path (fused_dispatch.hip)
 int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
                        const apk_stage_args &a, double dedner_coeff, hipStream_t s);

@@ -501,12 +501,34 @@ int apk_copy_plan_create(apk_ctx *ctx, const apk_copy_region *regions, int n,
     if (c * regions[r].nvar > p->max_items) p->max_items = c * regions[r].nvar;
   }
   if (n > 0) {
+    std::vector<apk_copy_chunk> by_items, by_cells;
+    for (int r = 0; r < n; ++r) {
+      const int64_t c = (int64_t)regions[r].ext[0] * regions[r].ext[1] * regions[r].ext[2];
+      const int64_t items = c * regions[r].nvar;
+      if (items >= (int64_t)1 << 31) {
+        delete p;
+        return set_err(ctx, APK_ERR_INVALID, "apk_copy_plan_create: box too large");
+      }
+      for (int64_t f = 0; f < items; f += kCopyChunkItems) by_items.push_back({r, (int)f});
+      for (int64_t f = 0; f < c; f += kCopyChunkCells) by_cells.push_back({r, (int)f});
+    }
+    p->nchunks_items = (int)by_items.size();
+    p->nchunks_cells = (int)by_cells.size();
     hipError_t e = hipMalloc(&p->d_regions, sizeof(apk_copy_region) * n);
     if (e == hipSuccess)
       e = hipMemcpy(p->d_regions, regions, sizeof(apk_copy_region) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !by_items.empty()) {
+      e = hipMalloc(&p->d_chunks_items, sizeof(apk_copy_chunk) * by_items.size());
+      if (e == hipSuccess)
+        e = hipMemcpy(p->d_chunks_items, by_items.data(), sizeof(apk_copy_chunk) * by_items.size(), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && !by_cells.empty()) {
+      e = hipMalloc(&p->d_chunks_cells, sizeof(apk_copy_chunk) * by_cells.size());
+      if (e == hipSuccess)
+        e = hipMemcpy(p->d_chunks_cells, by_cells.data(), sizeof(apk_copy_chunk) * by_cells.size(), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
-      if (p->d_regions) (void)hipFree(p->d_regions);
-      delete p;
+      apk_copy_plan_destroy(p);
       return set_err(ctx, APK_ERR_DEVICE, "apk_copy_plan_create", e);
     }
   }
@@ -517,6 +539,8 @@ int apk_copy_plan_create(apk_ctx *ctx, const apk_copy_region *regions, int n,
 void apk_copy_plan_destroy(apk_copy_plan *plan) {
   if (!plan) return;
   if (plan->d_regions) (void)hipFree(plan->d_regions);
+  if (plan->d_chunks_items) (void)hipFree(plan->d_chunks_items);
+  if (plan->d_chunks_cells) (void)hipFree(plan->d_chunks_cells);
   delete plan;
 }
 
@@ -524,7 +548,7 @@ int apk_copy_plan_run(apk_ctx *ctx, const apk_copy_plan *plan, apk_stream_t stre
   if (!ctx || !plan) return APK_ERR_INVALID;
   if (plan->n <= 0) return APK_OK;
   ScopedTiming timing(ctx, APK_T_COPY, as_stream(stream));
-  int rc = launch_copy_regions(plan->d_regions, plan->n, plan->max_cells, plan->max_items, as_stream(stream));
+  int rc = launch_copy_regions(*plan, as_stream(stream));
   if (rc != APK_OK) return set_err(ctx, rc, "copy kernel launch failed", hipGetLastError());
   return APK_OK;
 }
@@ -537,8 +561,7 @@ int apk_copy_plan_run_c2p(apk_ctx *ctx, const apk_copy_plan *plan, int fluid, co
     return set_err(ctx, APK_ERR_UNSUPPORTED, "apk_copy_plan_run_c2p: floors / ceilings are active; copy, then apk_cons_to_prim_ghosts");
   if (plan->n <= 0) return APK_OK;
   ScopedTiming timing(ctx, APK_T_COPY, as_stream(stream));
-  int rc = launch_copy_regions(plan->d_regions, plan->n, plan->max_cells, plan->max_items, as_stream(stream), fluid, eos,
-                               latch_flags ? ctx->d_flags : nullptr, prim_delta);
+  int rc = launch_copy_regions(*plan, as_stream(stream), fluid, eos, latch_flags ? ctx->d_flags : nullptr, prim_delta);
   if (rc != APK_OK) return set_err(ctx, rc, "copy kernel launch failed", hipGetLastError());
   return APK_OK;
 }

@@ -395,21 +395,22 @@ fofc_fix_kernel(PackView pv, double gamma, double c_h, const unsigned char *mark
 }
 
 // ---- strided box copies (ghost exchange / message packing / physical boundaries) -----------
+// One workgroup per chunk of the plan's work list (apk_copy_chunk): at most kCopyChunkItems
+// (cell, variable) items of one box, cells fastest.
 __global__ void __launch_bounds__(256)
-copy_regions_kernel(const apk_copy_region *regions) {
-  // one thread per (cell, variable), cells fastest: the many small boxes of refined meshes (corner
-  // regions of a few dozen cells) still fill a workgroup
-  const apk_copy_region r = regions[blockIdx.y];
-  const int64_t plane = (int64_t)r.ext[0] * r.ext[1];
-  const int64_t cells = plane * r.ext[2], items = cells * r.nvar;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < items;
-       t += (int64_t)gridDim.x * blockDim.x) {
-    const int v = (int)(t / cells);
-    const int64_t c = t - (int64_t)v * cells;
-    const int k = (int)(c / plane);
-    const int64_t rem = c - (int64_t)k * plane;
-    const int j = (int)(rem / r.ext[0]);
-    const int i = (int)(rem - (int64_t)j * r.ext[0]);
+copy_regions_kernel(const apk_copy_region *regions, const apk_copy_chunk *chunks) {
+  const apk_copy_chunk ch = chunks[blockIdx.x];
+  const apk_copy_region r = regions[ch.region];
+  const int plane = r.ext[0] * r.ext[1];
+  const int cells = plane * r.ext[2], items = cells * r.nvar;
+  const int end = (ch.first + kCopyChunkItems < items) ? ch.first + kCopyChunkItems : items;
+  for (int t = ch.first + (int)threadIdx.x; t < end; t += 256) {
+    const int v = t / cells;
+    const int c = t - v * cells;
+    const int k = c / plane;
+    const int rem = c - k * plane;
+    const int j = rem / r.ext[0];
+    const int i = rem - j * r.ext[0];
     const double x = r.src[i * r.src_stride[0] + j * r.src_stride[1] + k * r.src_stride[2] + v * r.src_stride[3]];
     r.dst[i * r.dst_stride[0] + j * r.dst_stride[1] + k * r.dst_stride[2] + v * r.dst_stride[3]] = (v == r.flip_var) ? -x : x;
   }
@@ -421,19 +422,22 @@ copy_regions_kernel(const apk_copy_region *regions) {
 // dst + prim_delta -- and the separate ghost ConsToPrim pass (one more read of cons) disappears.
 // Only used when no floor / ceiling is active (they would write cons back, and a later boundary
 // phase would read the floored instead of the copied value; the unfused order is kept for that).
+// One workgroup per chunk of at most kCopyChunkCells cells.
 template <int FLUID>
 __global__ void __launch_bounds__(256)
-copy_regions_c2p_kernel(const apk_copy_region *regions, apk_eos eos, unsigned *flags, int64_t prim_delta) {
+copy_regions_c2p_kernel(const apk_copy_region *regions, const apk_copy_chunk *chunks, apk_eos eos, unsigned *flags,
+                        int64_t prim_delta) {
   constexpr int NV = nvars<FLUID>();
-  const apk_copy_region r = regions[blockIdx.y];
-  const int64_t plane = (int64_t)r.ext[0] * r.ext[1];
-  const int64_t cells = plane * r.ext[2];
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < cells;
-       t += (int64_t)gridDim.x * blockDim.x) {
-    const int k = (int)(t / plane);
-    const int64_t rem = t - (int64_t)k * plane;
-    const int j = (int)(rem / r.ext[0]);
-    const int i = (int)(rem - (int64_t)j * r.ext[0]);
+  const apk_copy_chunk ch = chunks[blockIdx.x];
+  const apk_copy_region r = regions[ch.region];
+  const int plane = r.ext[0] * r.ext[1];
+  const int cells = plane * r.ext[2];
+  const int t = ch.first + (int)threadIdx.x;
+  if (t < cells) {
+    const int k = t / plane;
+    const int rem = t - k * plane;
+    const int j = rem / r.ext[0];
+    const int i = rem - j * r.ext[0];
     const int64_t so = i * r.src_stride[0] + j * r.src_stride[1] + k * r.src_stride[2];
     const int64_t dof = i * r.dst_stride[0] + j * r.dst_stride[1] + k * r.dst_stride[2];
     double u[NV], w[NV], di;
@@ -561,24 +565,20 @@ int launch_fofc_fix(const PackView &u0, int fluid, double gamma, double c_h,
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }
 
-int launch_copy_regions(const apk_copy_region *d_regions, int n, int64_t max_cells, int64_t max_items, hipStream_t s,
-                        int c2p_fluid, const apk_eos *eos, unsigned *d_flags, int64_t prim_delta) {
-  if (n <= 0) return APK_OK;
+int launch_copy_regions(const apk_copy_plan &plan, hipStream_t s, int c2p_fluid, const apk_eos *eos, unsigned *d_flags,
+                        int64_t prim_delta) {
+  if (plan.n <= 0) return APK_OK;
   // the plain copy works per (cell, variable), the ConsToPrim variants per cell
-  int gx = (int)(((c2p_fluid == 0 ? max_items : max_cells) + 255) / 256);
-  if (gx < 1) gx = 1;
-  if (gx > 64) gx = 64;
-  // gridDim.y is limited to 65535
-  for (int off = 0; off < n; off += 65535) {
-    const int m = (n - off > 65535) ? 65535 : (n - off);
-    if (c2p_fluid == APK_FLUID_EULER)
-      hipLaunchKernelGGL(copy_regions_c2p_kernel<APK_FLUID_EULER>, dim3(gx, m, 1), dim3(256), 0, s, d_regions + off, *eos,
-                         d_flags, prim_delta);
-    else if (c2p_fluid == APK_FLUID_GLMMHD)
-      hipLaunchKernelGGL(copy_regions_c2p_kernel<APK_FLUID_GLMMHD>, dim3(gx, m, 1), dim3(256), 0, s, d_regions + off, *eos,
-                         d_flags, prim_delta);
-    else
-      hipLaunchKernelGGL(copy_regions_kernel, dim3(gx, m, 1), dim3(256), 0, s, d_regions + off);
+  if (c2p_fluid == APK_FLUID_EULER) {
+    if (plan.nchunks_cells > 0)
+      hipLaunchKernelGGL(copy_regions_c2p_kernel<APK_FLUID_EULER>, dim3(plan.nchunks_cells), dim3(256), 0, s, plan.d_regions,
+                         plan.d_chunks_cells, *eos, d_flags, prim_delta);
+  } else if (c2p_fluid == APK_FLUID_GLMMHD) {
+    if (plan.nchunks_cells > 0)
+      hipLaunchKernelGGL(copy_regions_c2p_kernel<APK_FLUID_GLMMHD>, dim3(plan.nchunks_cells), dim3(256), 0, s, plan.d_regions,
+                         plan.d_chunks_cells, *eos, d_flags, prim_delta);
+  } else if (plan.nchunks_items > 0) {
+    hipLaunchKernelGGL(copy_regions_kernel, dim3(plan.nchunks_items), dim3(256), 0, s, plan.d_regions, plan.d_chunks_items);
   }
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }
