@@ -125,13 +125,13 @@ inline int set_err(apk_ctx *ctx, int code, const char *what, hipError_t e = hipS
 // ---- kernel launchers implemented in the .hip translation units ---------------------
 // flux arrays path (one TU per (fluid, riemann) family to keep compile times parallel)
 int launch_fluxes_euler_hlle(const PackView &pv, int recon, double gamma, double c_h,
-                             hipStream_t s, int faces = 0, const unsigned char *face_mask = nullptr);
+                             hipStream_t s, int faces = 0, const int *face_list = nullptr, int nlist = 0);
 int launch_fluxes_euler_hllc(const PackView &pv, int recon, double gamma, double c_h,
-                             hipStream_t s, int faces = 0, const unsigned char *face_mask = nullptr);
+                             hipStream_t s, int faces = 0, const int *face_list = nullptr, int nlist = 0);
 int launch_fluxes_mhd_hlle(const PackView &pv, int recon, double gamma, double c_h,
-                           hipStream_t s, int faces = 0, const unsigned char *face_mask = nullptr);
+                           hipStream_t s, int faces = 0, const int *face_list = nullptr, int nlist = 0);
 int launch_fluxes_mhd_hlld(const PackView &pv, int recon, double gamma, double c_h,
-                           hipStream_t s, int faces = 0, const unsigned char *face_mask = nullptr);
+                           hipStream_t s, int faces = 0, const int *face_list = nullptr, int nlist = 0);
 // (dc,none) and (dc,llf = CalculateFluxesTight) for both fluids
 int launch_fluxes_misc(const PackView &pv, int fluid, int riemann, double gamma, double c_h,
                        hipStream_t s);

@@ -183,7 +183,7 @@ void apk_pack_destroy(apk_pack *pack) {
 
 namespace {
 int calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos, double c_h, int faces,
-                     apk_stream_t stream, const unsigned char *face_mask = nullptr) {
+                     apk_stream_t stream, const int *face_list = nullptr, int nlist = 0) {
   if (!ctx || !md || !valid_eos(eos)) return set_err(ctx, APK_ERR_INVALID, "apk_calculate_fluxes: bad argument");
   int rc = check_cfg(ctx, md, cfg);
   if (rc != APK_OK) return rc;
@@ -199,11 +199,11 @@ int calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const a
   if (cfg.riemann == APK_RS_NONE || cfg.riemann == APK_RS_LLF)
     rc = launch_fluxes_misc(pv, cfg.fluid, cfg.riemann, eos->gamma, c_h, s);
   else if (cfg.fluid == APK_FLUID_EULER)
-    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_euler_hlle(pv, cfg.recon, eos->gamma, c_h, s, faces, face_mask)
-                                      : launch_fluxes_euler_hllc(pv, cfg.recon, eos->gamma, c_h, s, faces, face_mask);
+    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_euler_hlle(pv, cfg.recon, eos->gamma, c_h, s, faces, face_list, nlist)
+                                      : launch_fluxes_euler_hllc(pv, cfg.recon, eos->gamma, c_h, s, faces, face_list, nlist);
   else
-    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_mhd_hlle(pv, cfg.recon, eos->gamma, c_h, s, faces, face_mask)
-                                      : launch_fluxes_mhd_hlld(pv, cfg.recon, eos->gamma, c_h, s, faces, face_mask);
+    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_mhd_hlle(pv, cfg.recon, eos->gamma, c_h, s, faces, face_list, nlist)
+                                      : launch_fluxes_mhd_hlld(pv, cfg.recon, eos->gamma, c_h, s, faces, face_list, nlist);
   if (rc != APK_OK) return set_err(ctx, rc, "flux kernel launch failed", hipGetLastError());
   return APK_OK;
 }
@@ -224,9 +224,10 @@ int apk_calculate_fluxes_boundary(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg
   return calculate_fluxes(ctx, md, cfg, eos, c_h, 2, stream);
 }
 
-int apk_calculate_fluxes_boundary_masked(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos,
-                                         double c_h, const unsigned char *face_mask, apk_stream_t stream) {
-  return calculate_fluxes(ctx, md, cfg, eos, c_h, 2, stream, face_mask);
+int apk_calculate_fluxes_boundary_list(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos,
+                                       double c_h, const int *faces, int nfaces, apk_stream_t stream) {
+  if (!faces || nfaces < 0) return set_err(ctx, APK_ERR_INVALID, "apk_calculate_fluxes_boundary_list: bad argument");
+  return calculate_fluxes(ctx, md, cfg, eos, c_h, 2, stream, faces, nfaces);
 }
 
 int apk_update_with_flux_divergence(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,

@@ -18,10 +18,6 @@ namespace apk {
 
 struct FluxExtent {
   int i0, i1, j0, j1, k0, k1;
-  // boundary planes only: mask[6 * block + face] == 0 skips that block (its face has no coarse-fine
-  // neighbour, nothing reads the plane); NULL = every block
-  const unsigned char *mask = nullptr;
-  int face = 0;
 };
 
 // the reference's loop limits (hydro.cpp:1031-1039, 1106-1110, 1158)
@@ -86,29 +82,10 @@ APK_DEV void face_states(const double *c, int64_t st, double dx, int var, double
   }
 }
 
+// the flux through the lower DIR-face of cell (k, j, i) of one block
 template <int FLUID, int RECON, int RS, int DIR>
-__global__ void __launch_bounds__(256)
-flux_kernel(PackView pv, FluxExtent e, double gamma, double c_h) {
+APK_DEV void flux_face(const PackView &pv, const apk_block_desc &blk, int i, int j, int k, double gamma, double c_h) {
   constexpr int NV = nvars<FLUID>();
-  // the two longest axes of the index box share the workgroup (rect_ij), the third one the grid's z
-  // with the block number: a boundary plane of direction 1 / 2 (one face along i / j) is spread
-  // over (j, k) / (i, k) instead of leaving all but a few lanes idle
-  const int nie = e.i1 - e.i0 + 1, nje = e.j1 - e.j0 + 1, nke = e.k1 - e.k0 + 1;
-  int i, j, k, b, a0, a1;
-  if (nie == 1 && nke > 1) {
-    if (!rect_ij(nje, nke, a0, a1)) return;
-    i = e.i0, j = e.j0 + a0, k = e.k0 + a1, b = blockIdx.z;
-  } else if (nje == 1 && nke > 1) {
-    if (!rect_ij(nie, nke, a0, a1)) return;
-    i = e.i0 + a0, j = e.j0, k = e.k0 + a1, b = blockIdx.z;
-  } else {
-    if (!rect_ij(nie, nje, a0, a1)) return;
-    i = e.i0 + a0, j = e.j0 + a1;
-    b = blockIdx.z / nke;
-    k = e.k0 + blockIdx.z % nke;
-  }
-  if (e.mask && !e.mask[6 * b + e.face]) return;  // (workgroup-uniform)
-  const apk_block_desc blk = pv.blocks[b];
   const int64_t st = (DIR == 1) ? 1 : ((DIR == 2) ? pv.sj : pv.sk);
   const int64_t cell = k * pv.sk + j * pv.sj + i;
   const double *p = blk.prim + cell;
@@ -139,6 +116,30 @@ flux_kernel(PackView pv, FluxExtent e, double gamma, double c_h) {
 }
 
 template <int FLUID, int RECON, int RS, int DIR>
+__global__ void __launch_bounds__(256)
+flux_kernel(PackView pv, FluxExtent e, double gamma, double c_h) {
+  constexpr int NV = nvars<FLUID>();
+  // the two longest axes of the index box share the workgroup (rect_ij), the third one the grid's z
+  // with the block number: a boundary plane of direction 1 / 2 (one face along i / j) is spread
+  // over (j, k) / (i, k) instead of leaving all but a few lanes idle
+  const int nie = e.i1 - e.i0 + 1, nje = e.j1 - e.j0 + 1, nke = e.k1 - e.k0 + 1;
+  int i, j, k, b, a0, a1;
+  if (nie == 1 && nke > 1) {
+    if (!rect_ij(nje, nke, a0, a1)) return;
+    i = e.i0, j = e.j0 + a0, k = e.k0 + a1, b = blockIdx.z;
+  } else if (nje == 1 && nke > 1) {
+    if (!rect_ij(nie, nke, a0, a1)) return;
+    i = e.i0 + a0, j = e.j0, k = e.k0 + a1, b = blockIdx.z;
+  } else {
+    if (!rect_ij(nie, nje, a0, a1)) return;
+    i = e.i0 + a0, j = e.j0 + a1;
+    b = blockIdx.z / nke;
+    k = e.k0 + blockIdx.z % nke;
+  }
+  flux_face<FLUID, RECON, RS, DIR>(pv, pv.blocks[b], i, j, k, gamma, c_h);
+}
+
+template <int FLUID, int RECON, int RS, int DIR>
 inline void launch_flux_dir(const PackView &pv, const FluxExtent &e, double gamma, double c_h,
                             hipStream_t s) {
   const int nie = e.i1 - e.i0 + 1, nje = e.j1 - e.j0 + 1, nke = e.k1 - e.k0 + 1;
@@ -146,6 +147,26 @@ inline void launch_flux_dir(const PackView &pv, const FluxExtent &e, double gamm
   const dim3 grid = (nie == 1 && nke > 1) ? rect_grid(nje, nke, pv.nblocks)
                                            : ((nje == 1 && nke > 1) ? rect_grid(nie, nke, pv.nblocks) : rect_grid(nie, nje, nke * pv.nblocks));
   hipLaunchKernelGGL((flux_kernel<FLUID, RECON, RS, DIR>), grid, block, 0, s, pv, e, gamma, c_h);
+}
+
+// Boundary planes of a LIST of (block, face) pairs in one launch: faces[n] = 6 * block + face with
+// face = {x1 lower, x1 upper, x2 lower, ...} -- on a refined mesh the faces with a coarser or finer
+// block behind them, a fraction of all faces, and six launches of a few dozen small planes each
+// would run at the launch-latency floor.
+template <int FLUID, int RECON, int RS>
+__global__ void __launch_bounds__(256)
+flux_planes_kernel(PackView pv, const int *faces, double gamma, double c_h) {
+  const int code = faces[blockIdx.y];
+  const int b = code / 6, f = code - 6 * b, dir = f / 2 + 1, side = f & 1;
+  const int na = (dir == 1) ? pv.nx2 : pv.nx1;
+  const int nb = (dir == 3) ? pv.nx2 : pv.nx3;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int a1 = t / na, a0 = t - a1 * na;
+  if (a1 >= nb) return;
+  const apk_block_desc blk = pv.blocks[b];
+  if (dir == 1) flux_face<FLUID, RECON, RS, 1>(pv, blk, side ? pv.ie + 1 : pv.is, pv.js + a0, pv.ks + a1, gamma, c_h);
+  else if (dir == 2) flux_face<FLUID, RECON, RS, 2>(pv, blk, pv.is + a0, side ? pv.je + 1 : pv.js, pv.ks + a1, gamma, c_h);
+  else flux_face<FLUID, RECON, RS, 3>(pv, blk, pv.is + a0, pv.js + a1, side ? pv.ke + 1 : pv.ks, gamma, c_h);
 }
 
 // which faces a flux call covers
@@ -166,41 +187,50 @@ inline FluxExtent boundary_extent(const PackView &pv, int dir, int side) {
 }
 
 template <int FLUID, int RECON, int RS, int DIR>
-inline void launch_flux_faces(const PackView &pv, double gamma, double c_h, hipStream_t s, int faces,
-                              const unsigned char *face_mask) {
+inline void launch_flux_faces(const PackView &pv, double gamma, double c_h, hipStream_t s, int faces) {
   if (faces == FLUX_FACES_BOUNDARY) {
-    for (int side = 0; side < 2; ++side) {
-      FluxExtent e = boundary_extent(pv, DIR, side);
-      e.mask = face_mask;
-      e.face = 2 * (DIR - 1) + side;
-      launch_flux_dir<FLUID, RECON, RS, DIR>(pv, e, gamma, c_h, s);
-    }
+    launch_flux_dir<FLUID, RECON, RS, DIR>(pv, boundary_extent(pv, DIR, 0), gamma, c_h, s);
+    launch_flux_dir<FLUID, RECON, RS, DIR>(pv, boundary_extent(pv, DIR, 1), gamma, c_h, s);
   } else {
     launch_flux_dir<FLUID, RECON, RS, DIR>(pv, faces == FLUX_FACES_TIGHT ? tight_extent(pv, DIR) : flux_extent(pv, DIR), gamma,
                                            c_h, s);
   }
 }
 
+// face_list != NULL (with faces == FLUX_FACES_BOUNDARY): only the listed (block, face) planes, one launch
 template <int FLUID, int RECON, int RS>
 inline int launch_flux_all_dirs(const PackView &pv, double gamma, double c_h, hipStream_t s,
-                                int faces = FLUX_FACES_REFERENCE, const unsigned char *face_mask = nullptr) {
-  launch_flux_faces<FLUID, RECON, RS, 1>(pv, gamma, c_h, s, faces, face_mask);
-  if (pv.ndim >= 2) launch_flux_faces<FLUID, RECON, RS, 2>(pv, gamma, c_h, s, faces, face_mask);
-  if (pv.ndim >= 3) launch_flux_faces<FLUID, RECON, RS, 3>(pv, gamma, c_h, s, faces, face_mask);
+                                int faces = FLUX_FACES_REFERENCE, const int *face_list = nullptr, int nlist = 0) {
+  if (face_list) {
+    if (faces != FLUX_FACES_BOUNDARY) return APK_ERR_UNSUPPORTED;
+    if (nlist <= 0) return APK_OK;
+    int64_t plane = (int64_t)pv.nx1 * pv.nx2;
+    if ((int64_t)pv.nx1 * pv.nx3 > plane) plane = (int64_t)pv.nx1 * pv.nx3;
+    if ((int64_t)pv.nx2 * pv.nx3 > plane) plane = (int64_t)pv.nx2 * pv.nx3;
+    for (int off = 0; off < nlist; off += 65535) {  // gridDim.y is limited to 65535
+      const int m = (nlist - off > 65535) ? 65535 : nlist - off;
+      hipLaunchKernelGGL((flux_planes_kernel<FLUID, RECON, RS>), dim3((unsigned)((plane + 255) / 256), (unsigned)m, 1), dim3(256), 0, s,
+                         pv, face_list + off, gamma, c_h);
+    }
+    return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
+  }
+  launch_flux_faces<FLUID, RECON, RS, 1>(pv, gamma, c_h, s, faces);
+  if (pv.ndim >= 2) launch_flux_faces<FLUID, RECON, RS, 2>(pv, gamma, c_h, s, faces);
+  if (pv.ndim >= 3) launch_flux_faces<FLUID, RECON, RS, 3>(pv, gamma, c_h, s, faces);
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }
 
 // recon dispatch for one (fluid, riemann) family: the registry of hydro.cpp:386-416
 template <int FLUID, int RS>
 inline int launch_flux_family(const PackView &pv, int recon, double gamma, double c_h,
-                              hipStream_t s, int faces, const unsigned char *face_mask = nullptr) {
+                              hipStream_t s, int faces, const int *face_list = nullptr, int nlist = 0) {
   switch (recon) {
-  case APK_RC_DC: return launch_flux_all_dirs<FLUID, APK_RC_DC, RS>(pv, gamma, c_h, s, faces, face_mask);
-  case APK_RC_PLM: return launch_flux_all_dirs<FLUID, APK_RC_PLM, RS>(pv, gamma, c_h, s, faces, face_mask);
-  case APK_RC_PPM: return launch_flux_all_dirs<FLUID, APK_RC_PPM, RS>(pv, gamma, c_h, s, faces, face_mask);
-  case APK_RC_WENOZ: return launch_flux_all_dirs<FLUID, APK_RC_WENOZ, RS>(pv, gamma, c_h, s, faces, face_mask);
-  case APK_RC_WENO3: return launch_flux_all_dirs<FLUID, APK_RC_WENO3, RS>(pv, gamma, c_h, s, faces, face_mask);
-  case APK_RC_LIMO3: return launch_flux_all_dirs<FLUID, APK_RC_LIMO3, RS>(pv, gamma, c_h, s, faces, face_mask);
+  case APK_RC_DC: return launch_flux_all_dirs<FLUID, APK_RC_DC, RS>(pv, gamma, c_h, s, faces, face_list, nlist);
+  case APK_RC_PLM: return launch_flux_all_dirs<FLUID, APK_RC_PLM, RS>(pv, gamma, c_h, s, faces, face_list, nlist);
+  case APK_RC_PPM: return launch_flux_all_dirs<FLUID, APK_RC_PPM, RS>(pv, gamma, c_h, s, faces, face_list, nlist);
+  case APK_RC_WENOZ: return launch_flux_all_dirs<FLUID, APK_RC_WENOZ, RS>(pv, gamma, c_h, s, faces, face_list, nlist);
+  case APK_RC_WENO3: return launch_flux_all_dirs<FLUID, APK_RC_WENO3, RS>(pv, gamma, c_h, s, faces, face_list, nlist);
+  case APK_RC_LIMO3: return launch_flux_all_dirs<FLUID, APK_RC_LIMO3, RS>(pv, gamma, c_h, s, faces, face_list, nlist);
   default: return APK_ERR_UNSUPPORTED;
   }
 }

@@ -1196,12 +1196,27 @@ int apk_sim_step(apk_sim *s) {
   s->time += s->dt;
   s->ncycle += 1;
   s->zone_cycles += (long long)s->mesh.mb[0] * s->mesh.mb[1] * s->mesh.mb[2] * (long long)s->mesh.nblocks_total;
-  if (s->amr && s->amr_adaptive && s->amr_check_interval > 0 && s->ncycle % s->amr_check_interval == 0) {
-    bool changed = false;
-    SIM_TRY(s, amr_regrid(s, &changed));
-  }
   double est = kHuge;
-  SIM_TRY(s, estimate_timestep(s, &est));
+  if (s->amr && s->amr_adaptive && s->amr_check_interval > 0 && s->ncycle % s->amr_check_interval == 0) {
+    // Mesh::LoadBalancingAndAdaptiveMeshRefinement, then the new time step (the reference's order).  The tag
+    // reduction and the time-step reduction are enqueued back to back and read in ONE host round trip; the
+    // estimate is only kept if the mesh stays as it is (every cycle but a few), else it is redone on the new one.
+    AmrTagRequest req;
+    SIM_TRY(s, amr_tags_begin(s, &req));
+    const double dt_hyp_before = s->pkg.dt_hyp;
+    const bool global_before = s->dt_hyp_is_global;
+    SIM_TRY(s, estimate_timestep(s, &est));
+    bool changed = false;
+    SIM_TRY(s, amr_regrid(s, &changed, &req));
+    if (changed) {
+      s->pkg.dt_hyp = dt_hyp_before;
+      s->dt_hyp_is_global = global_before;
+      est = kHuge;
+      SIM_TRY(s, estimate_timestep(s, &est));
+    }
+  } else {
+    SIM_TRY(s, estimate_timestep(s, &est));
+  }
   set_global_dt(s, est);
   return APK_OK;
 }

@@ -209,9 +209,10 @@ struct apk_sim {
     // (void* = hipGraphExec_t; null = not captured, the plans are launched one by one)
     void *xchg_pre[2] = {nullptr, nullptr}, *xchg_post[2] = {nullptr, nullptr};
     apk_flux_fix_plan *flux_fix[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-    // [local block][6]: does the face have a coarser or finer block behind it?  (the only boundary-plane
-    // fluxes the correction after a fused stage reads: apk_calculate_fluxes_boundary_masked)
-    unsigned char *d_cf_faces = nullptr;
+    // the faces (6 * local block + face) with a coarser or finer block behind them: the only boundary-plane
+    // fluxes the correction after a fused stage reads (apk_calculate_fluxes_boundary_list)
+    int *d_cf_faces = nullptr;
+    int n_cf_faces = 0;
     apk_flux_fix_plan *flux_fix_unpack[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     apk_copy_plan *coarse_bc[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     apk_copy_plan *fine_bc[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};

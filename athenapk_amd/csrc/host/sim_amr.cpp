@@ -391,7 +391,7 @@ int amr_rebuild(apk_sim *s) {
   {  // faces with a level change behind them
     const int nlb = (int)s->mesh.local_gids.size(), first = s->amr_part.first[s->rank];
     const AmrTree &t = *s->amr;
-    std::vector<unsigned char> cf(6 * (size_t)nlb, 0);
+    std::vector<int> cf;
     for (int lb = 0; lb < nlb; ++lb) {
       const AmrLeaf &l = t.leaves[first + lb];
       for (int d = 0; d < 3; ++d)
@@ -399,13 +399,14 @@ int amr_rebuild(apk_sim *s) {
           int pos[3] = {l.lx[0], l.lx[1], l.lx[2]}, leaf;
           pos[d] += side ? 1 : -1;
           const int kind = t.Classify(l.level, pos, &leaf);
-          cf[6 * (size_t)lb + 2 * d + side] = (kind == NB_FINER || kind == NB_COARSER) ? 1 : 0;
+          if (kind == NB_FINER || kind == NB_COARSER) cf.push_back(6 * lb + 2 * d + side);
         }
     }
+    a.n_cf_faces = (int)cf.size();
     double *p8 = nullptr;
-    SIM_TRY(s, dev_alloc(s, "cf_faces", cf.size() + 8, &p8));
-    a.d_cf_faces = reinterpret_cast<unsigned char *>(p8);
-    SIM_HIP(s, hipMemcpy(a.d_cf_faces, cf.data(), cf.size(), hipMemcpyHostToDevice));
+    SIM_TRY(s, dev_alloc(s, "cf_faces", sizeof(int) * (cf.size() + 2), &p8));
+    a.d_cf_faces = reinterpret_cast<int *>(p8);
+    if (!cf.empty()) SIM_HIP(s, hipMemcpy(a.d_cf_faces, cf.data(), sizeof(int) * cf.size(), hipMemcpyHostToDevice));
   }
   for (int par = 0; par < 2; ++par) {
     amr_capture_half(s, par, true, &a.xchg_pre[par]);
@@ -497,8 +498,8 @@ int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi
   auto &a = s->amr_dev;
   const int psi_var = (s->pkg.fluid == APK_FLUID_GLMMHD) ? 8 : -1;
   static const bool all_planes = std::getenv("APK_AMR_ALL_PLANES") != nullptr;  // A/B switch
-  SIM_TRY(s, apk_calculate_fluxes_boundary_masked(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h,
-                                                  all_planes ? nullptr : a.d_cf_faces, s->stream));
+  if (all_planes) SIM_TRY(s, apk_calculate_fluxes_boundary(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, s->stream));
+  else SIM_TRY(s, apk_calculate_fluxes_boundary_list(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, a.d_cf_faces, a.n_cf_faces, s->stream));
   for (int d = 0; d < s->mesh.ndim; ++d) {
     for (apk_refine_plan *p : a.flux_restrict[d]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
     SIM_TRY(s, apk_flux_fix_plan_run(s->ctx, a.flux_fix[s->cur][d], beta_dt, psi_var, psi_factor, s->stream));
@@ -727,14 +728,19 @@ int amr_transfer(apk_sim *s, const std::vector<AmrLeaf> &old, const AmrPartition
   return APK_OK;
 }
 
-// the tags of every leaf of the forest: mine from the device, the others' through a sum reduction
-int amr_global_tags(apk_sim *s, std::vector<int> &tags) {
-  int criterion;
-  double p0, p1;
-  SIM_TRY(s, refinement_criterion(s, &criterion, &p0, &p1));
+// the tags of every leaf of the forest: mine from the device, the others' through a sum reduction.
+// In two halves: _begin launches the reduction and its read-back, _end waits and converts -- whatever the
+// caller reads back in between (the time-step estimate at the end of a cycle) shares the host round trip.
+int amr_tags_begin(apk_sim *s, AmrTagRequest *req) {
+  SIM_TRY(s, refinement_criterion(s, &req->criterion, &req->p0, &req->p1));
+  SIM_TRY(s, apk_tag_blocks_begin(s->ctx, s->mu0(), req->criterion, &req->pending, s->stream));
+  return APK_OK;
+}
+
+int amr_tags_end(apk_sim *s, const AmrTagRequest &req, std::vector<int> &tags) {
   const int nlocal = (int)s->mesh.local_gids.size(), first = s->amr_part.first[s->rank];
   std::vector<int> mine(nlocal, 0);
-  SIM_TRY(s, apk_tag_blocks(s->ctx, s->mu0(), criterion, p0, p1, mine.data(), nullptr, s->stream));
+  SIM_TRY(s, apk_tag_blocks_end(s->ctx, nlocal, req.criterion, req.pending, req.p0, req.p1, mine.data(), nullptr, s->stream));
   tags.assign(s->amr->leaves.size(), 0);
   for (int lb = 0; lb < nlocal; ++lb) tags[first + lb] = mine[lb];
   if (s->have_comm && s->nranks > 1) {
@@ -743,6 +749,12 @@ int amr_global_tags(apk_sim *s, std::vector<int> &tags) {
     for (size_t n = 0; n < tags.size(); ++n) tags[n] = (int)std::lround(buf[n]);
   }
   return APK_OK;
+}
+
+int amr_global_tags(apk_sim *s, std::vector<int> &tags) {
+  AmrTagRequest req;
+  SIM_TRY(s, amr_tags_begin(s, &req));
+  return amr_tags_end(s, req, tags);
 }
 
 // fresh (zeroed) arrays for the current block list; the state is NOT carried over
@@ -763,10 +775,11 @@ int amr_reallocate(apk_sim *s) {
 
 // Mesh::LoadBalancingAndAdaptiveMeshRefinement for one rank: tag, update the tree, move the data,
 // refill ghost zones and primitives on the new mesh
-int amr_regrid(apk_sim *s, bool *changed) {
+int amr_regrid(apk_sim *s, bool *changed, const AmrTagRequest *posted) {
   *changed = false;
   std::vector<int> tags;
-  SIM_TRY(s, amr_global_tags(s, tags));
+  if (posted) SIM_TRY(s, amr_tags_end(s, *posted, tags));
+  else SIM_TRY(s, amr_global_tags(s, tags));
   const std::vector<AmrLeaf> old = s->amr->leaves;
   const AmrPartition old_part = s->amr_part;
   try {

@@ -114,9 +114,15 @@ int amr_flux_correction(apk_sim *s);
 int refinement_criterion(apk_sim *s, int *criterion, double *p0, double *p1);
 bool amr_update_tree(apk_sim *s, const std::vector<int> &tags, bool allow_derefine);
 int amr_transfer(apk_sim *s, const std::vector<AmrLeaf> &old, const AmrPartition &old_part);
+struct AmrTagRequest {  // a tag reduction in flight (amr_tags_begin .. amr_tags_end)
+  int criterion = -1, pending = 0;
+  double p0 = 0.0, p1 = 0.0;
+};
+int amr_tags_begin(apk_sim *s, AmrTagRequest *req);
+int amr_tags_end(apk_sim *s, const AmrTagRequest &req, std::vector<int> &tags);
 int amr_global_tags(apk_sim *s, std::vector<int> &tags);
 int amr_reallocate(apk_sim *s);
-int amr_regrid(apk_sim *s, bool *changed);
+int amr_regrid(apk_sim *s, bool *changed, const AmrTagRequest *posted = nullptr);
 
 // On refined meshes the problem generators and the error norms see the cell widths of the block
 // they work on through s->dx (restored on scope exit)

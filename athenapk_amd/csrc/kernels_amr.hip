@@ -395,22 +395,19 @@ int apk_flux_fix_plan_run(apk_ctx *ctx, const apk_flux_fix_plan *p, double beta_
   return e == hipSuccess ? APK_OK : set_err(ctx, APK_ERR_DEVICE, "flux_fix launch", e);
 }
 
-int apk_tag_blocks(apk_ctx *ctx, const apk_pack *md, int criterion, double p0, double p1, int *tags, double *crit,
-                   apk_stream_t stream) {
-  if (!ctx || !md || !tags || criterion < APK_TAG_PRESSURE_GRADIENT || criterion > APK_TAG_MAX_DENSITY)
+// The launch half of apk_tag_blocks: reduce the criterion per block and request the read-back into
+// pinned host memory; nothing is waited for.  *pending = 0 when there is nothing to read (1-D
+// pressure gradient: "same" everywhere).
+int apk_tag_blocks_begin(apk_ctx *ctx, const apk_pack *md, int criterion, int *pending, apk_stream_t stream) {
+  if (!ctx || !md || !pending || criterion < APK_TAG_PRESSURE_GRADIENT || criterion > APK_TAG_MAX_DENSITY)
     return set_err(ctx, APK_ERR_INVALID, "apk_tag_blocks: bad argument");
   const PackView &pv = md->view;
   if (pv.ng < 1) return set_err(ctx, APK_ERR_NGHOST, "apk_tag_blocks needs one ghost cell");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int nb = pv.nblocks;
   const int ndim = (pv.nx3 > 1) ? 3 : ((pv.nx2 > 1) ? 2 : 1);
-  if (criterion == APK_TAG_PRESSURE_GRADIENT && ndim == 1) {  // gradient.cpp:56-58: AmrTag::same
-    for (int b = 0; b < nb; ++b) {
-      tags[b] = 0;
-      if (crit) crit[b] = 0.0;
-    }
-    return APK_OK;
-  }
+  *pending = 0;
+  if (criterion == APK_TAG_PRESSURE_GRADIENT && ndim == 1) return APK_OK;  // gradient.cpp:56-58: AmrTag::same
   if (criterion == APK_TAG_VELOCITY_GRADIENT && ndim == 1)
     return set_err(ctx, APK_ERR_UNSUPPORTED, "xyvelocity_gradient needs at least two dimensions");
   if (ctx->partial_cap < (size_t)nb) {
@@ -419,6 +416,13 @@ int apk_tag_blocks(apk_ctx *ctx, const apk_pack *md, int criterion, double p0, d
     ctx->partial_cap = 0;
     APK_HIP_TRY(ctx, hipMalloc(&ctx->d_partial, sizeof(double) * (nb + 64)));
     ctx->partial_cap = nb + 64;
+  }
+  if (ctx->h_partial_cap < (size_t)nb) {  // (pinned: a pageable destination costs a staging copy every cycle)
+    if (ctx->h_partial) (void)hipHostFree(ctx->h_partial);
+    ctx->h_partial = nullptr;
+    ctx->h_partial_cap = 0;
+    APK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_partial), sizeof(double) * (nb + 64), hipHostMallocDefault));
+    ctx->h_partial_cap = nb + 64;
   }
   auto *d_max = reinterpret_cast<unsigned long long *>(ctx->d_partial);
   APK_HIP_TRY(ctx, hipMemsetAsync(d_max, 0, sizeof(unsigned long long) * nb, s));
@@ -429,24 +433,43 @@ int apk_tag_blocks(apk_ctx *ctx, const apk_pack *md, int criterion, double p0, d
     hipLaunchKernelGGL(tag_kernel<APK_TAG_VELOCITY_GRADIENT>, grid, block, 0, s, pv, d_max);
   else
     hipLaunchKernelGGL(tag_kernel<APK_TAG_MAX_DENSITY>, grid, block, 0, s, pv, d_max);
-  if (ctx->h_partial_cap < (size_t)nb) {  // (pinned: a pageable destination costs a staging copy every cycle)
-    if (ctx->h_partial) (void)hipHostFree(ctx->h_partial);
-    ctx->h_partial = nullptr;
-    ctx->h_partial_cap = 0;
-    APK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_partial), sizeof(double) * (nb + 64), hipHostMallocDefault));
-    ctx->h_partial_cap = nb + 64;
-  }
-  const double *h = ctx->h_partial;
   APK_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partial, d_max, sizeof(double) * nb, hipMemcpyDeviceToHost, s));
-  APK_HIP_TRY(ctx, hipStreamSynchronize(s));
+  *pending = 1;
+  return APK_OK;
+}
+
+// The read half: waits for the stream (a no-op if the caller synchronised it meanwhile, e.g. by reading
+// the time-step estimate enqueued after apk_tag_blocks_begin) and turns the criteria into tags.
+int apk_tag_blocks_end(apk_ctx *ctx, int nblocks, int criterion, int pending, double p0, double p1, int *tags, double *crit,
+                       apk_stream_t stream) {
+  if (!ctx || !tags || nblocks < 0) return set_err(ctx, APK_ERR_INVALID, "apk_tag_blocks: bad argument");
+  if (!pending) {
+    for (int b = 0; b < nblocks; ++b) {
+      tags[b] = 0;
+      if (crit) crit[b] = 0.0;
+    }
+    return APK_OK;
+  }
+  if ((size_t)nblocks > ctx->h_partial_cap) return set_err(ctx, APK_ERR_INVALID, "apk_tag_blocks_end without apk_tag_blocks_begin");
+  APK_HIP_TRY(ctx, hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+  const double *h = ctx->h_partial;
   const double refine_above = p0;
   const double deref_below = (criterion == APK_TAG_PRESSURE_GRADIENT) ? 0.25 * p0
                              : (criterion == APK_TAG_VELOCITY_GRADIENT) ? 0.5 * p0 : p1;
-  for (int b = 0; b < nb; ++b) {
+  for (int b = 0; b < nblocks; ++b) {
     tags[b] = (h[b] > refine_above) ? 1 : ((h[b] < deref_below) ? -1 : 0);
     if (crit) crit[b] = h[b];
   }
   return APK_OK;
+}
+
+int apk_tag_blocks(apk_ctx *ctx, const apk_pack *md, int criterion, double p0, double p1, int *tags, double *crit,
+                   apk_stream_t stream) {
+  if (!tags) return set_err(ctx, APK_ERR_INVALID, "apk_tag_blocks: bad argument");
+  int pending = 0;
+  const int rc = apk_tag_blocks_begin(ctx, md, criterion, &pending, stream);
+  if (rc != APK_OK) return rc;
+  return apk_tag_blocks_end(ctx, md->view.nblocks, criterion, pending, p0, p1, tags, crit, stream);
 }
 
 }  // extern "C"

@@ -129,16 +129,16 @@ def _cfg(fluid, recon, riemann):
 
 
 # ---- the task functions ---------------------------------------------------------------------
-def CalculateFluxes(md, fluid, recon, riemann, eos, c_h=0.0, tight=False, boundary=False, face_mask=None):
+def CalculateFluxes(md, fluid, recon, riemann, eos, c_h=0.0, tight=False, boundary=False, face_list=None):
     """Hydro::CalculateFluxes<fluid,recon,rsolver>(md)  -- src/hydro/hydro.cpp:1025; tight: only the
     faces of interior cells (the loop limits of CalculateFluxesTight, hydro.cpp:1006-1009); boundary:
-    only the 2 ndim block-boundary planes (for the flux correction after a fused stage), with face_mask
-    (uint8 CUDA tensor [nblocks][6]) only the planes whose byte is non-zero"""
+    only the 2 ndim block-boundary planes (for the flux correction after a fused stage), with face_list
+    (int32 CUDA tensor of 6 * block + face codes) only the listed planes, in one launch"""
     ctx = md.ctx
-    if face_mask is not None:
-        assert boundary and face_mask.dtype == torch.uint8 and face_mask.is_cuda and face_mask.shape == (md.nblocks, 6)
-        _check(ctx.lib.apk_calculate_fluxes_boundary_masked(ctx.h, md.h, _cfg(fluid, recon, riemann), C.byref(eos), float(c_h),
-                                                            face_mask.data_ptr(), _stream()), ctx.lib, ctx.h)
+    if face_list is not None:
+        assert boundary and face_list.dtype == torch.int32 and face_list.is_cuda and face_list.dim() == 1
+        _check(ctx.lib.apk_calculate_fluxes_boundary_list(ctx.h, md.h, _cfg(fluid, recon, riemann), C.byref(eos), float(c_h),
+                                                          face_list.data_ptr(), int(face_list.numel()), _stream()), ctx.lib, ctx.h)
         return
     fn = (ctx.lib.apk_calculate_fluxes_boundary if boundary else
           (ctx.lib.apk_calculate_fluxes_tight if tight else ctx.lib.apk_calculate_fluxes))

@@ -154,7 +154,7 @@ def _signatures():
         "apk_calculate_fluxes": (i, [vp, vp, FluxCfg, E, d, vp]),
         "apk_calculate_fluxes_tight": (i, [vp, vp, FluxCfg, E, d, vp]),
         "apk_calculate_fluxes_boundary": (i, [vp, vp, FluxCfg, E, d, vp]),
-        "apk_calculate_fluxes_boundary_masked": (i, [vp, vp, FluxCfg, E, d, vp, vp]),
+        "apk_calculate_fluxes_boundary_list": (i, [vp, vp, FluxCfg, E, d, vp, C.c_int, vp]),
         "apk_flux_fix_plan_create": (i, [vp, C.POINTER(FluxFixRegion), i, pp]),
         "apk_flux_fix_plan_destroy": (None, [vp]),
         "apk_flux_fix_plan_run": (i, [vp, vp, d, i, d, vp]),

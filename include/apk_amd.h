@@ -130,12 +130,12 @@ int apk_calculate_fluxes_tight(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cf
  * (apk_stage_fused never materialises face fluxes; see apk_flux_fix_plan below). */
 int apk_calculate_fluxes_boundary(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg,
                                   const apk_eos *eos, double c_h, apk_stream_t stream);
-/* The same with a DEVICE mask of 6 bytes per block {x1 lower, x1 upper, x2 lower, ...}: a plane is only
- * computed where its byte is non-zero -- on a refined mesh the faces with a coarser or finer block
- * behind them (the fine side's fluxes are averaged, the coarse side's own flux is what the average
- * replaces); the planes of the other faces are left untouched.  face_mask == NULL: every plane. */
-int apk_calculate_fluxes_boundary_masked(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos,
-                                         double c_h, const unsigned char *face_mask, apk_stream_t stream);
+/* The same for a DEVICE list of (block, face) pairs only, in ONE launch: faces[n] = 6 * block + face,
+ * face = {x1 lower, x1 upper, x2 lower, x2 upper, x3 lower, x3 upper} -- on a refined mesh the faces
+ * with a coarser or finer block behind them (the fine side's fluxes are averaged, the coarse side's own
+ * flux is what the average replaces); the planes of unlisted faces are left untouched. */
+int apk_calculate_fluxes_boundary_list(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos,
+                                       double c_h, const int *faces, int nfaces, apk_stream_t stream);
 
 /* Replaces parthenon::Update::UpdateWithFluxDivergence<MeshData<Real>>(u0,u1,gam0,gam1,
  * beta_dt); call site src/hydro/hydro_driver.cpp:534-537.
@@ -449,6 +449,13 @@ int apk_flux_fix_plan_run(apk_ctx *ctx, const apk_flux_fix_plan *p, double beta_
 enum { APK_TAG_PRESSURE_GRADIENT = 0, APK_TAG_VELOCITY_GRADIENT = 1, APK_TAG_MAX_DENSITY = 2 };
 int apk_tag_blocks(apk_ctx *ctx, const apk_pack *md, int criterion, double p0, double p1, int *tags,
                    double *crit, apk_stream_t stream);
+/* The same in two halves, so that the tags share a host round trip with whatever else the caller
+ * reads back at the end of a cycle (the driver enqueues the time-step reduction between the two):
+ * _begin launches the reduction and the read-back into pinned memory without waiting; _end waits
+ * for the stream and converts (pending = what _begin returned). */
+int apk_tag_blocks_begin(apk_ctx *ctx, const apk_pack *md, int criterion, int *pending, apk_stream_t stream);
+int apk_tag_blocks_end(apk_ctx *ctx, int nblocks, int criterion, int pending, double p0, double p1, int *tags,
+                       double *crit, apk_stream_t stream);
 
 /* field_loop::RelDivBHst (src/pgen/field_loop.cpp:60-95), the "UserRelDivB" history column of the
  * field-loop problem: sum of 0.5 |dx| |div B| / B0 * volume, B0 fixed.  Synchronises. */
