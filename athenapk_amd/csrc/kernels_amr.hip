@@ -21,10 +21,17 @@ struct apk_refine_plan {
   int nvar = 0, nops = 0;
   int64_t max_items = 0;
   apk_refine_op *d_ops = nullptr;
+  // work list: the boxes cut into chunks of kRefineChunkItems (cell, variable) items, one workgroup
+  // each, one item per thread (a plan mixes 16 x 16 x 4 faces with 4^3 corners; several items per
+  // thread measured slower for these operators)
+  apk_copy_chunk *d_chunks = nullptr;
+  int nchunks = 0;
 };
 
 namespace apk {
 namespace {
+
+constexpr int kRefineChunkItems = 256;
 
 struct RefineDims {
   int DIM;
@@ -170,8 +177,10 @@ APK_DEV void restrict_cell(const apk_refine_geom &g, const RefineDims &r, const 
                                             tvol;
 }
 
-__global__ void __launch_bounds__(256) refine_ops_kernel(apk_refine_geom g, int nvar, const apk_refine_op *ops) {
-  const apk_refine_op op = ops[blockIdx.x];
+__global__ void __launch_bounds__(256) refine_ops_kernel(apk_refine_geom g, int nvar, const apk_refine_op *ops,
+                                                         const apk_copy_chunk *chunks) {
+  const apk_copy_chunk ch = chunks[blockIdx.x];
+  const apk_refine_op op = ops[ch.region];
   if (op.dx[0] > 0.0) {  // the box brings its own cell widths (another refinement level)
     g.dx[0] = op.dx[0];
     g.dx[1] = op.dx[1];
@@ -180,7 +189,8 @@ __global__ void __launch_bounds__(256) refine_ops_kernel(apk_refine_geom g, int 
   const RefineDims r = refine_dims(g);
   const int e0 = op.hi[0] - op.lo[0] + 1, e1 = op.hi[1] - op.lo[1] + 1, e2 = op.hi[2] - op.lo[2] + 1;
   const int64_t cells = (int64_t)e0 * e1 * e2, items = cells * nvar;
-  for (int64_t t = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; t < items; t += (int64_t)gridDim.y * blockDim.x) {
+  const int64_t end = (ch.first + (int64_t)kRefineChunkItems < items) ? ch.first + (int64_t)kRefineChunkItems : items;
+  for (int64_t t = (int64_t)ch.first + threadIdx.x; t < end; t += 256) {
     const int v = (int)(t / cells);
     int64_t c = t - (int64_t)v * cells;
     const int i = op.lo[0] + (int)(c % e0);
@@ -320,8 +330,19 @@ int apk_refine_plan_create(apk_ctx *ctx, const apk_refine_geom *geom, int nvar, 
   p->nvar = nvar;
   p->nops = nops;
   p->max_items = max_items;
+  std::vector<apk_copy_chunk> chunks;
+  for (int q = 0; q < nops; ++q) {
+    int64_t items = nvar;
+    for (int d = 0; d < 3; ++d) items *= ops[q].hi[d] - ops[q].lo[d] + 1;
+    for (int64_t f = 0; f < items; f += apk::kRefineChunkItems) chunks.push_back({q, (int)f});
+  }
+  p->nchunks = (int)chunks.size();
   hipError_t e = hipMalloc(&p->d_ops, sizeof(apk_refine_op) * nops);
   if (e == hipSuccess) e = hipMemcpy(p->d_ops, ops, sizeof(apk_refine_op) * nops, hipMemcpyHostToDevice);
+  if (e == hipSuccess && !chunks.empty()) {
+    e = hipMalloc(&p->d_chunks, sizeof(apk_copy_chunk) * chunks.size());
+    if (e == hipSuccess) e = hipMemcpy(p->d_chunks, chunks.data(), sizeof(apk_copy_chunk) * chunks.size(), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     apk_refine_plan_destroy(p);
     return set_err(ctx, APK_ERR_DEVICE, "apk_refine_plan_create", e);
@@ -333,15 +354,15 @@ int apk_refine_plan_create(apk_ctx *ctx, const apk_refine_geom *geom, int nvar, 
 void apk_refine_plan_destroy(apk_refine_plan *p) {
   if (!p) return;
   if (p->d_ops) (void)hipFree(p->d_ops);
+  if (p->d_chunks) (void)hipFree(p->d_chunks);
   delete p;
 }
 
 int apk_refine_plan_run(apk_ctx *ctx, const apk_refine_plan *p, apk_stream_t stream) {
   if (!ctx || !p) return set_err(ctx, APK_ERR_INVALID, "apk_refine_plan_run: bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  int64_t gx = (p->max_items + 255) / 256;
-  if (gx > 4096) gx = 4096;  // grid-stride beyond that
-  hipLaunchKernelGGL(refine_ops_kernel, dim3((unsigned)p->nops, (unsigned)gx), dim3(256), 0, s, p->geom, p->nvar, p->d_ops);
+  if (p->nchunks <= 0) return APK_OK;
+  hipLaunchKernelGGL(refine_ops_kernel, dim3((unsigned)p->nchunks), dim3(256), 0, s, p->geom, p->nvar, p->d_ops, p->d_chunks);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? APK_OK : set_err(ctx, APK_ERR_DEVICE, "refine_ops launch", e);
 }
