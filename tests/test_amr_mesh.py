@@ -316,3 +316,68 @@ def test_random_regridding_keeps_the_forest_balanced(oracle, dims):
                 inside &= (c > i.xmin[d] + 2 * pl[lb][3][d]) & (c < i.xmax[d] - 2 * pl[lb][3][d])
         assert not np.isnan(em.cons[lb]).any()
         assert np.abs(em.cons[lb][0] - f)[inside].max() < 5e-14
+
+
+# ---- the plans against a restatement that knows only the forest (tests/amr_oracle.py) ------------------------------
+def _forest_oracle(view, oracle, fluid="euler", recon="plm", riemann="hlle", integrator="vl2"):
+    from amr_oracle import RefinedMeshOracle
+    i = view.refresh_info()
+    pl = placement(view)
+    nrb = [i.nx[d] // i.mb[d] for d in range(3)]
+    return RefinedMeshOracle(oracle, fluid, recon, riemann, integrator, nrb, tuple(i.mb), i.ng, tuple(i.xmin), tuple(i.xmax),
+                             [(p[0], p[1]) for p in pl], i.gamma, i.cfl)
+
+
+@pytest.mark.parametrize("ov", [SMR3, SMR3_NG4], ids=["3d", "3d_ng4"])
+def test_plans_reproduce_the_forest_oracle(oracle, ov):
+    """The driver's index-box plans (executed by the emulator) and the restatement that classifies every ghost region
+    by looking up who covers the neighbouring slot fill every ghost cell, every coarse-buffer cell the prolongation
+    reads and every coarse face flux with the same bits."""
+    v = _view(ov + _bc("periodic"))
+    em = Emulator(v, oracle)
+    fo = _forest_oracle(v, oracle)
+    assert fo.cng == em.cng and fo.shape == em.shape and max(l for l, _ in fo.leaves) == 2
+    rng = np.random.default_rng(5)
+    for lb in range(em.nb):
+        u = rng.uniform(0.5, 2.0, em.shape)
+        em.cons[lb][:] = u
+        fo.cons[lb][:] = u
+    em.exchange()
+    fo.exchange()
+    for lb in range(em.nb):
+        assert np.array_equal(em.cons[lb], fo.cons[lb]), "block %d (level %d)" % (lb, fo.leaves[lb][0])
+    flux = [[rng.standard_normal(em.shape) for _ in range(em.nb)] for _ in range(3)]
+    for d in range(3):
+        for lb in range(em.nb):
+            em.flux[d][lb][:] = flux[d][lb]
+    em.flux_correction()
+    fo.flux_correction(flux)
+    nfix = 0
+    for d in range(3):
+        for lb in range(em.nb):
+            assert np.array_equal(em.flux[d][lb], flux[d][lb]), "flux%d of block %d" % (d + 1, lb)
+    assert any(fo.classify(l, tuple(lx[q] + (1 if q == 0 else 0) for q in range(3)))[0] == "finer" for l, lx in fo.leaves)
+
+
+@pytest.mark.parametrize("fluid,recon,riemann,integ,ng", [("euler", "plm", "hlle", "vl2", 2), ("glmmhd", "ppm", "hlld", "vl2", 4),
+                                                          ("glmmhd", "wenoz", "hlle", "rk3", 4)])
+def test_forest_oracle_on_a_one_level_forest_is_the_uniform_mini_driver(oracle, fluid, recon, riemann, integ, ng):
+    """pins the time loop of tests/amr_oracle.py: on a forest of root blocks only it must reproduce the oracle's
+    uniform-mesh mini-driver (oracle/sim.c) bit for bit -- state, time step and c_h"""
+    from amr_oracle import RefinedMeshOracle
+    box = dict(xmin=(-0.5, -0.5, -0.5), xmax=(0.5, 0.5, 0.5))
+    o = oracle.Sim(fluid=fluid, recon=recon, riemann=riemann, integrator=integ, nx=(16, 16, 16), mb=(8, 8, 8), ng=ng, cfl=0.3,
+                   gamma=5.0 / 3.0, **box)
+    o.pgen("blast", radius_outer=0.2, radius_inner=0.1, pressure_ratio=100.0, x1_0=0.013, x2_0=-0.021, x3_0=0.1)
+    nb = o.nblocks
+    leaves = [(0, (b % 2, (b // 2) % 2, b // 4)) for b in range(nb)]
+    fo = RefinedMeshOracle(oracle, fluid, recon, riemann, integ, (2, 2, 2), (8, 8, 8), ng, box["xmin"], box["xmax"], leaves,
+                           5.0 / 3.0, 0.3)
+    fo.initialize([np.array(o.cons(b)) for b in range(nb)])
+    for _ in range(3):
+        assert fo.dt == o.dt
+        o.step()
+        fo.step()
+        assert fo.c_h == o.c_h
+        for b in range(nb):
+            assert np.array_equal(fo.cons[b], o.cons(b)) and np.array_equal(fo.prim[b], o.prim(b), equal_nan=True)

@@ -116,6 +116,48 @@ def test_single_step_on_a_refined_mesh_conserves_in_the_parity_build():
     assert abs(t1[0] - t0[0]) < 1e-14 and abs(t1[4] - t0[4]) < 1e-13 * t0[4]
 
 
+@pytest.mark.parametrize("fluid,riemann,recon,ng,integrator", [("euler", "hlle", "plm", 2, "vl2"), ("glmmhd", "hlld", "ppm", 4, "vl2"),
+                                                               ("euler", "hllc", "plm", 2, "rk3"), ("glmmhd", "hlle", "wenoz", 4, "rk3")])
+def test_refined_mesh_stage_loop_matches_the_forest_oracle(oracle, fluid, riemann, recon, ng, integrator):
+    """The time loop on a statically refined periodic mesh (3 levels: multilevel ghost exchange, coarse-fine flux
+    correction, per-level cell widths in the sweeps, the time step and c_h) against tests/amr_oracle.py -- a restatement
+    that knows the forest and the oracle's pointwise functions, none of the driver's plans.  Flux-array task order
+    (set_fused(0), the reference's: correct the face fluxes, then the flux divergence): every cell of every block, ghost
+    zones included, bit for bit in the parity build, cycle after cycle; the fused stage with its post-stage correction:
+    the same arithmetic in another order, to round-off."""
+    from test_amr_mesh import _forest_oracle
+    ov = SMR3 + _bc("periodic") + ["hydro/fluid=%s" % fluid, "hydro/riemann=%s" % riemann, "hydro/reconstruction=%s" % recon,
+                                   "parthenon/mesh/nghost=%d" % ng, "parthenon/time/integrator=%s" % integrator,
+                                   "problem/blast/radius_outer=0.2", "problem/blast/pressure_ratio=100", "problem/blast/x3_0=0.1",
+                                   "problem/blast/x1_0=0.013", "problem/blast/x2_0=-0.021", "problem/blast/radius_inner=0.1",
+                                   "problem/blast/pressure_ambient=1.0"]
+    s = _sim("blast", ov, strict=True)
+    s.set_fused(False)
+    s.initialize()
+    nb = s.info.nblocks_total
+    fo = _forest_oracle(s, oracle, fluid, recon, riemann, integrator)
+    assert len(fo.levels) == 3
+    fo.initialize([s.read_block(lb) for lb in range(nb)])
+    assert fo.dt == s.dt
+    for cycle in range(4):
+        s.step()
+        fo.step()
+        assert fo.dt == s.dt and fo.time == s.time and fo.c_h == s.c_h, cycle
+        for lb in range(nb):
+            assert np.array_equal(s.read_block(lb), fo.cons[lb]), "cycle %d block %d (level %d)" % (cycle, lb, fo.leaves[lb][0])
+            assert np.array_equal(s.read_block(lb, "prim"), fo.prim[lb], equal_nan=True), "prim, cycle %d block %d" % (cycle, lb)
+    # the fused stages + post-stage correction
+    f = _sim("blast", ov, strict=True).initialize()
+    assert bool(f.refresh_info().fused)
+    for cycle in range(4):
+        f.step()
+    assert abs(f.time - fo.time) <= 1e-14 * fo.time
+    scale = max(np.abs(c).max() for c in fo.cons)
+    for lb in range(nb):
+        a, b = f.read_block(lb)[:, ng:-ng, ng:-ng, ng:-ng], fo.cons[lb][:, ng:-ng, ng:-ng, ng:-ng]
+        assert np.abs(a - b).max() <= 1e-12 * scale, (lb, np.abs(a - b).max())
+
+
 @pytest.mark.parametrize("fluid,riemann,recon,ng,integrator", [("euler", "hllc", "plm", 2, "rk3"), ("glmmhd", "hlld", "ppm", 4, "vl2")])
 def test_fused_stage_with_post_correction_agrees_with_the_flux_array_path(fluid, riemann, recon, ng, integrator):
     """refined meshes run the fused stage and correct the cells next to coarse-fine faces afterwards
