@@ -137,6 +137,42 @@ class RefinedMeshOracle:
         for n, lo, hi in needs_prolongation:
             self.o.prolongate(self.rgeom(n), self.coarse[n], u[n], tuple(lo), tuple(hi))
 
+    # ---- regridding: the state on a new forest -------------------------------------------------------------------
+    def regrid(self, new_leaves):
+        """Mesh::LoadBalancingAndAdaptiveMeshRefinement's data movement, given the new forest: surviving blocks keep
+        their data; a new fine block is the minmod prolongation of its parent's octant (through a coarse buffer cut
+        out of the parent: the octant plus cng cells of the parent's -- valid -- ghost zones and interior all round);
+        a merged block collects the restricted interiors of its children.  Then exchange + FillDerived on the new
+        mesh.  Returns the oracle of the new forest (time, dt and c_h carried over)."""
+        new = RefinedMeshOracle(self.o, self.fluid, self.recon, self.riemann, self.integrator, self.nrb, self.mb, self.ng,
+                                self.xmin, self.xmax, new_leaves, self.gamma, self.cfl, self.alpha, self.tlim)
+        mb, cng, fs, cs, ce = self.mb, self.cng, self.fs, self.cs, self.ce
+        for n, (level, lx) in enumerate(new.leaves):
+            if (level, lx) in self.index:
+                new.cons[n] = np.array(self.cons[self.index[(level, lx)]], copy=True)
+                continue
+            parent = (level - 1, tuple(x >> 1 for x in lx)) if level > 0 else None
+            if parent in self.index:
+                p = self.index[parent]
+                c = [lx[d] & 1 for d in range(3)]
+                clo = [cs[d] - cng for d in range(3)]
+                ext = [mb[d] // 2 + 2 * cng for d in range(3)]
+                slo = [fs[d] + c[d] * (mb[d] // 2) - cng for d in range(3)]
+                new.coarse[n][self.box(clo, ext)] = self.cons[p][self.box(slo, ext)]
+                self.o.prolongate(new.rgeom(n), new.coarse[n], new.cons[n], tuple(cs), tuple(ce))
+            else:
+                for c in itertools.product((0, 1), repeat=3):
+                    child = self.index[(level + 1, tuple(2 * lx[d] + c[d] for d in range(3)))]
+                    tmp = np.zeros(self.cshape)
+                    self.o.restrict(self.rgeom(child), 0, self.cons[child], tmp, tuple(cs), tuple(ce))
+                    dlo = [fs[d] + c[d] * (mb[d] // 2) for d in range(3)]
+                    ext = [mb[d] // 2 for d in range(3)]
+                    new.cons[n][self.box(dlo, ext)] = tmp[self.box(cs, ext)]
+        new.exchange()
+        new.fill_derived()
+        new.time, new.dt, new.ncycle, new.dt_hyp, new.c_h = self.time, self.dt, self.ncycle, self.dt_hyp, self.c_h
+        return new
+
     # ---- coarse-fine flux correction ----------------------------------------------------------------------------
     def restricted_face_flux(self, d, fine):
         """area average of the 2 x 2 fine faces of direction d behind every coarse face, in the pairwise order of the

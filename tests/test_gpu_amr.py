@@ -501,6 +501,57 @@ def test_regridding_with_random_tags_moves_the_state_exactly(dims):
     assert s.amr_stats()[0] > 0 and s.amr_stats()[1] > 0
 
 
+def test_regridding_moves_the_state_as_the_forest_oracle_does(oracle):
+    """seven regridding passes with random refine / derefine requests on a periodic 3-D mesh holding a random positive
+    state: whatever forest the driver's tree update arrives at, the state it hands over (copies, prolongated new fine
+    blocks, merged blocks, ghost zones and primitives on the new mesh) is the one tests/amr_oracle.py builds from the
+    old state and the new forest alone -- every cell of every block, bit for bit -- and two cycles of the time loop on
+    each new mesh stay identical."""
+    from test_amr_mesh import _forest_oracle
+    ov = ["parthenon/mesh/refinement=adaptive", "parthenon/mesh/numlevel=3", "parthenon/mesh/derefine_count=2",
+          "parthenon/mesh/nx1=32", "parthenon/mesh/nx2=16", "parthenon/mesh/nx3=16", "parthenon/meshblock/nx1=8",
+          "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=8", "refinement/threshold_pressure_gradient=1e9",
+          "parthenon/mesh/check_refine_interval=1000000", "problem/blast/pressure_ambient=1.0", "problem/blast/pressure_ratio=10",
+          "problem/blast/radius_outer=0.2", "problem/blast/radius_inner=0.1"] + _bc("periodic")
+    s = _sim("blast", ov, strict=True)
+    s.set_fused(False)
+    s.initialize()
+    rng = np.random.default_rng(77)
+    nb = s.refresh_info().nblocks_total
+    for lb in range(nb):
+        u = s.read_block(lb)
+        u[0] = rng.uniform(0.8, 1.2, u[0].shape)
+        u[1:4] = rng.uniform(-0.1, 0.1, u[1:4].shape)
+        u[4] = 2.0 + rng.uniform(0.0, 0.2, u[4].shape)
+        s.write_block(lb, u)
+    s.exchange_ghosts()
+    s.fill_derived()
+    fo = _forest_oracle(s, oracle, "euler", "plm", "hlle", "vl2")
+    fo.initialize([s.read_block(lb) for lb in range(nb)])
+    fo.dt = s.dt   # (the driver's is still the estimate on the problem generator's state)
+    sizes, levels = [], set()
+    for rnd in range(7):
+        n = s.refresh_info().nblocks_total
+        # three passes that mostly refine, one mixed, then everybody asks to merge (granted after derefine_count = 2 requests)
+        tags = rng.choice([1, 0, -1], size=n, p=[0.15, 0.25, 0.6]) if rnd < 4 else -np.ones(n, int)
+        s.apply_tags(tags)
+        pl = placement(s)
+        fo = fo.regrid([(p[0], p[1]) for p in pl])
+        sizes.append(len(pl))
+        levels |= set(fo.levels)
+        for lb in range(len(pl)):
+            assert np.array_equal(s.read_block(lb), fo.cons[lb]), "pass %d block %d (level %d)" % (rnd, lb, pl[lb][0])
+            assert np.array_equal(s.read_block(lb, "prim"), fo.prim[lb]), "prim, pass %d block %d" % (rnd, lb)
+        if rnd in (1, 4):   # the time loop on the new mesh (both sides enter it with the time step of the old one)
+            for _ in range(2):
+                s.step()
+                fo.step()
+                assert s.dt == fo.dt
+            for lb in range(len(pl)):
+                assert np.array_equal(s.read_block(lb), fo.cons[lb]), "after steps: pass %d block %d" % (rnd, lb)
+    assert max(sizes) > sizes[0] and sizes[-1] < max(sizes) and levels == {0, 1, 2} and s.amr_stats()[0] > 0 and s.amr_stats()[1] > 0
+
+
 def test_cli_runs_the_amr_deck(tmp_path, capsys):
     from athenapk_amd import __main__ as cli
     assert cli.main(["-i", "blast_3d_amr", "-d", str(tmp_path), "parthenon/time/tlim=0.01"]) == 0
