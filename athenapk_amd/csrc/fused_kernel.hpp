@@ -692,7 +692,9 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
   const double *c1 = u1.blocks[b].cons;
   double *prim_dst = u1.blocks[b].prim;  // EXTRA != NONE only (never in place here)
 
-  int i0 = 0, rl = u0.ni, ilo = u0.is, ihi = u0.ie, jlo = u0.js, jhi = u0.je, klo = u0.ks, khi = u0.ke;
+  // (a donor-cell flux reads one cell either side: the flattened rows need one ghost column each, not nghost --
+  // 16 of 18 lanes on interior cells of a 16-cell AMR block with nghost = 4 instead of 16 of 24)
+  int i0 = u0.is - 1, rl = u0.nx1 + 2, ilo = u0.is, ihi = u0.ie, jlo = u0.js, jhi = u0.je, klo = u0.ks, khi = u0.ke;
   if (sp.window) {  // split around a halo exchange in flight (apk_stage_args.window)
     const int *w = sp.window + 8 * b;
     i0 = w[0], rl = w[1], ilo = w[2], ihi = w[3], jlo = w[4], jhi = w[5], klo = w[6], khi = w[7];
@@ -1007,7 +1009,7 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
     if constexpr (RECON == APK_RC_DC) {
       if (extra == EXTRA_NONE || sp.prim_to_u1) {
         // whole donor-cell stage in one march (see fused_dc3_kernel); its FillDerived is out of place
-        const int64_t run3 = sp.window ? (int64_t)sp.window_rows * sp.window_rl : run;
+        const int64_t run3 = sp.window ? (int64_t)sp.window_rows * sp.window_rl : (int64_t)u0.nx2 * (u0.nx1 + 2);
         const int wpb = (int)((run3 + 61) / 62);
         const int kseg = (u0.nx3 >= 16) ? 8 : u0.nx3;  // measured on 8 x 128^3: 8 and 16 within 1 %, 64 is 12 % slower
         const int nseg = (u0.nx3 + kseg - 1) / kseg;
