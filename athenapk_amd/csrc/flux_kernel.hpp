@@ -118,7 +118,6 @@ APK_DEV void flux_face(const PackView &pv, const apk_block_desc &blk, int i, int
 template <int FLUID, int RECON, int RS, int DIR>
 __global__ void __launch_bounds__(256)
 flux_kernel(PackView pv, FluxExtent e, double gamma, double c_h) {
-  constexpr int NV = nvars<FLUID>();
   // the two longest axes of the index box share the workgroup (rect_ij), the third one the grid's z
   // with the block number: a boundary plane of direction 1 / 2 (one face along i / j) is spread
   // over (j, k) / (i, k) instead of leaving all but a few lanes idle

@@ -670,6 +670,9 @@ fused_march12_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_blo
 // against 504 B/cell of the two-march schedule.  prim is only read, so no lane can observe a
 // half-updated state; FillDerived of the stage is left to ConservedToPrimitive.
 // ==============================================================================================
+#ifndef APK_DC3_PREFETCH
+#define APK_DC3_PREFETCH 1  // A/B switch
+#endif
 #ifndef APK_DC3_WAVES
 #define APK_DC3_WAVES 2  // resident waves per SIMD the donor-cell march is compiled for (A/B)
 #endif
@@ -759,10 +762,27 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
   }
   // (The four Riemann problems of a cell are independent and the scheduler interleaves them; with
   // the carried state in the stash that fits in 199 VGPRs without scratch.)
+  // The next plane is requested one iteration ahead (its 9 loads have a whole iteration of four Riemann
+  // solves to land: 1.69 -> 1.62 ms on 8 x 128^3) where the registers allow it: with FillDerived in the
+  // kernel 243 VGPRs; without (refined meshes) the 18 extra registers would spill.
+  constexpr bool PF = (APK_DC3_PREFETCH != 0) && (EXTRA != EXTRA_NONE);
+  double wnext[NV];
+  if constexpr (PF) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) wnext[n] = ((s > u0.ke) ? prim_khi : prim)[n * u0.sn + (int64_t)s * u0.sk];
+  }
   for (int c = s; c <= e + 1; ++c) {
     const int64_t off = (int64_t)c * u0.sk;
     double wc[NV];
-    {
+    if constexpr (PF) {
+#pragma unroll
+      for (int n = 0; n < NV; ++n) wc[n] = wnext[n];
+      if (c <= e) {
+        const double *pn = (c + 1 > u0.ke) ? prim_khi : prim;  // wave-uniform choice
+#pragma unroll
+        for (int n = 0; n < NV; ++n) wnext[n] = pn[n * u0.sn + off + u0.sk];
+      }
+    } else {
       const double *pc = (c > u0.ke) ? prim_khi : prim;  // wave-uniform choice (c >= s >= ks)
 #pragma unroll
       for (int n = 0; n < NV; ++n) wc[n] = pc[n * u0.sn + off];
