@@ -182,6 +182,8 @@ def _signatures():
         "apk_refine_plan_destroy": (None, [vp]),
         "apk_refine_plan_run": (i, [vp, vp, vp]),
         "apk_tag_blocks": (i, [vp, vp, i, d, d, C.POINTER(C.c_int), c_dp, vp]),
+        "apk_tag_blocks_begin": (i, [vp, vp, i, C.POINTER(C.c_int), vp]),
+        "apk_tag_blocks_end": (i, [vp, i, i, i, d, d, C.POINTER(C.c_int), c_dp, vp]),
         "apk_poll_device_flags": (i, [vp, C.POINTER(C.c_uint), vp]),
         "apk_trial_flags": (i, [vp, i, vp]),
         "apk_stage_split_axis": (i, [vp, vp, i]),

@@ -221,6 +221,13 @@ def test_tag_blocks_matches_oracle(request, oracle, nx):
         assert list(tags) == [w[0] for w in want], crit
         assert list(vals) == [w[1] for w in want], crit       # a max: order independent, bit exact
         assert len(set(tags)) > 1, crit
+        # the two halves (launch / read back: the driver reads the time-step estimate in between) give the same
+        import ctypes as C
+        pending, t2, v2 = C.c_int(0), (C.c_int * nb)(), (C.c_double * nb)()
+        code = hydro.L.TAG_CRITERIA[crit]
+        assert ctx.lib.apk_tag_blocks_begin(ctx.h, md.h, code, C.byref(pending), hydro._stream()) == 0 and pending.value == 1
+        assert ctx.lib.apk_tag_blocks_end(ctx.h, nb, code, pending.value, p0, p1, t2, v2, hydro._stream()) == 0
+        assert list(t2) == list(tags) and list(v2) == list(vals)
 
 
 # ---- the pieces of the flux correction after a fused stage, through the C-ABI --------------------------------
