@@ -45,8 +45,10 @@ def test_config1_linear_wave_matches_oracle(oracle, strict):
     _assert_same(s.gather("cons"), o.gather_cons(), strict)
     rms, l1, _ = s.linear_wave_errors()
     rms_o, l1_o, _ = o.linear_wave_errors()
-    # north_star: linear-wave L1 error within 1e-12 of the reference arithmetic
-    assert abs(rms - rms_o) <= 1e-12 and np.all(np.abs(l1 - l1_o) <= 1e-12)
+    # north_star: linear-wave L1 error within 1e-12 of the reference arithmetic.  The error itself is 7.9e-8, so the
+    # bound that means something is relative to it: the product build (FMA contraction, reciprocal-based divides)
+    # measures 8.8e-17 absolute = 1.1e-9 of the error norm; the test allows 1e-15 / 2e-8.
+    assert abs(rms - rms_o) <= 1e-15 and abs(rms - rms_o) <= 2e-8 * rms_o and np.all(np.abs(l1 - l1_o) <= 1e-15)
     if strict:
         assert rms == rms_o
 
@@ -140,7 +142,7 @@ def test_config3_fma_build_totals_within_tolerance(oracle):
     h, ho = s.history(), o.history()
     np.testing.assert_allclose(h[[0, 4, 5, 6]], ho[[0, 4, 5, 6]], rtol=1e-12)
     u, uo = s.gather(), o.gather_cons()
-    assert np.max(np.abs(u - uo)) <= 1e-10 * np.max(np.abs(uo))  # FMA deviation after 30+ cycles
+    assert np.max(np.abs(u - uo)) <= 1e-13 * np.max(np.abs(uo))  # product-build deviation after 38 cycles (measured: 1.9e-15)
 
 
 def test_config3_full_size_orszag_tang_symmetry_and_conservation():
