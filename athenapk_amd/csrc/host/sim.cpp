@@ -1412,6 +1412,7 @@ int apk_sim_turbulence_history(apk_sim *s, double *out3) {
 // field_loop::RelDivBHst (src/pgen/field_loop.cpp:60-95), registered as "UserRelDivB" (:97-103)
 int apk_sim_user_reldivb(apk_sim *s, double *out) {
   if (!s || s->host_only || !out || s->problem_id != "field_loop") return APK_ERR_INVALID;
+  SIM_TRY(s, sync_ghosts(s));  // (div B differences reach into the ghost zones)
   SIM_TRY(s, apk_history_user_reldivb(s->ctx, s->mu0(), s->floop.amp, out, s->stream));
   if (s->have_comm && s->nranks > 1) {
     if (s->comm.allreduce_sum(s->comm.user, out, 1) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_sum failed");
