@@ -410,14 +410,16 @@ int exchange_ghosts(apk_sim *s, bool c2p, bool skip_local) {
 
 // Can the stages of this simulation read same-rank neighbours directly (apk_stage_args.face_neighbor)
 // so that the same-rank ghost copies can be skipped?  Every stage of the cycle must be one of the
-// kernels that follow the table, and nothing else in the cycle may read ghost zones.
+// kernels that follow the table, and nothing else in the cycle may read ghost zones.  (With the
+// turbulence driver the last stage is followed by the kick and a full-block ConsToPrim: that one
+// exchange is a complete one -- do_stage skips the copies only after stages with a fused FillDerived.)
 bool direct_neighbors(const apk_sim *s) {
   static const int mode = std::getenv("APK_DIRECT_NEIGHBORS") ? std::atoi(std::getenv("APK_DIRECT_NEIGHBORS")) : 1;  // A/B switch
   static const int dc_mode = std::getenv("APK_DC_MODE") ? std::atoi(std::getenv("APK_DC_MODE")) : 2;
   static const bool no_copy_c2p = std::getenv("APK_NO_COPY_C2P") != nullptr;
   const HydroPackage &pkg = s->pkg;
   if (!mode || !s->direct_on || !s->d_face_nbr || s->amr || s->mesh.ndim != 3 || !stage_can_fuse(s)) return false;
-  if (s->fmft || pkg.nscalars != 0 || s->copy_stream || no_copy_c2p || !ghost_c2p_fusable(s)) return false;
+  if (pkg.nscalars != 0 || s->copy_stream || no_copy_c2p || !ghost_c2p_fusable(s)) return false;
   if (pkg.fluid == APK_FLUID_GLMMHD && pkg.glmmhd_source_extended) return false;
   const apk_flux_cfg *cfgs[2] = {&pkg.flux_first_stage, &pkg.flux_other_stage};
   for (const apk_flux_cfg *cfg : cfgs) {
@@ -886,7 +888,8 @@ int do_stage(apk_sim *s, int stage) {
     // completes the exchange
     SIM_TRY(s, exchange_begin(s, true, c2p_in_copy, direct));
   } else {
-    SIM_TRY(s, exchange_ghosts(s, c2p_in_copy, direct));
+    // (without a fused FillDerived the full-block ConsToPrim below reads every ghost zone)
+    SIM_TRY(s, exchange_ghosts(s, c2p_in_copy, direct && fused_fill));
     if (fused_fill) {
       if (!c2p_in_copy) SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
     } else {

@@ -111,8 +111,8 @@ int apk_sim_set_overlap(apk_sim *sim, int overlap);
 /* number of stage boundaries so far at which the exchange was overlapped */
 long long apk_sim_overlapped_exchanges(const apk_sim *sim);
 /* Direct neighbour addressing (apk_stage_args.face_neighbor): on uniform 3-D meshes whose stages are
- * all single-march donor-cell or two-kernel stages (no passive scalars, floors, extended Dedner source,
- * flux correction or turbulence driver) the stage kernels read the interiors of same-rank neighbour
+ * all single-march donor-cell or two-kernel stages (no passive scalars, floors, extended Dedner source
+ * or flux correction) the stage kernels read the interiors of same-rank neighbour
  * blocks directly and the same-rank ghost-zone copies are skipped; ghost zones are brought up to date
  * on demand (every accessor does).  Results are identical.  APK_DIRECT_NEIGHBORS=0 in the environment
  * switches it off.  Returns the number of stage boundaries so far whose same-rank copies were skipped. */

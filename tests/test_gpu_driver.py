@@ -277,19 +277,24 @@ def _turb_k_vec():
 @pytest.mark.gpu
 @pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
 @pytest.mark.parametrize("b_config", [0, 2])
-def test_turbulence_driver_matches_oracle(oracle, strict, b_config):
-    """32^3 in 8 meshblocks, 12 driven cycles.  The spectral state is bit-identical (same host RNG);
-    the fields agree to round-off (the Perturb sums are reduced in a different order)."""
-    ov = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=32", "parthenon/meshblock/nx1=16",
+@pytest.mark.parametrize("mb1", [16, 32], ids=["16cubed_blocks", "wide_blocks_direct_neighbours"])
+def test_turbulence_driver_matches_oracle(oracle, strict, b_config, mb1):
+    """32^3 in 8 (4) meshblocks, 12 driven cycles.  The spectral state is bit-identical (same host RNG);
+    the fields agree to round-off (the Perturb sums are reduced in a different order).  With 32-cell-wide
+    blocks the stages are the two-kernel / single-march forms that read same-rank neighbours directly: the
+    first stage's exchange skips the same-rank copies, the last one (followed by the kick and a full-block
+    ConsToPrim) is complete."""
+    ov = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=32", "parthenon/meshblock/nx1=%d" % mb1,
           "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=16", "problem/turbulence/b_config=%d" % b_config]
     s = _sim("turbulence", ov, strict=strict).initialize()
-    o = oracle.Sim(fluid="glmmhd", recon="plm", riemann="hlle", integrator="vl2", nx=(32, 32, 32), mb=(16, 16, 16),
+    o = oracle.Sim(fluid="glmmhd", recon="plm", riemann="hlle", integrator="vl2", nx=(32, 32, 32), mb=(mb1, 16, 16),
                    ng=2, cfl=0.3, gamma=1.0001, nthreads=os.cpu_count())
     o.pgen("turbulence", k_vec=_turb_k_vec(), b_config=b_config)
     np.testing.assert_allclose(s.gather("cons"), o.gather_cons(), rtol=1e-14, atol=0)
     for _ in range(12):
         s.step()
         o.step()
+    assert s.skipped_local_exchanges() == (12 if mb1 == 32 else 0)
     assert np.array_equal(s.fmft_var_hat(), o.var_hat())
     assert abs(s.time - o.time) <= 1e-13 * o.time
     np.testing.assert_allclose(s.gather("cons"), o.gather_cons(), rtol=1e-11, atol=1e-13)
