@@ -196,14 +196,16 @@ fused_x1_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_plane) {
   // The interior rows of this plane are flattened into one run of cells, `rl` per row starting at
   // column i0 (the whole row by default; a thin window next to a face when the sweep is split
   // around a halo exchange that is still in flight).  Ghost / window-edge columns separate the rows.
-  int i0 = 0, rl = u0.ni, lo = u0.is, hi = u0.ie;
+  // lanes that retire a cell: FIRST .. 62 (x1_cells_per_wave of them); waves overlap accordingly
+  constexpr int FIRST = x1_first_lane(RECON), CPW = x1_cells_per_wave(RECON);
+  // (only the columns whose lanes reconstruct take part: is - FIRST .. ie + 1, not all nghost ghost
+  // columns -- 16 of 19 lanes on interior cells of a 16-cell block with nghost = 4 instead of 16 of 24)
+  int i0 = u0.is - FIRST, rl = u0.nx1 + FIRST + 1, lo = u0.is, hi = u0.ie;
   if (sp.window) {
     const int *w = sp.window + 8 * b;
     i0 = w[0], rl = w[1], lo = w[2], hi = w[3];
     if (rl <= 0) return;  // nothing to do in this block
   }
-  // lanes that retire a cell: FIRST .. 62 (x1_cells_per_wave of them); waves overlap accordingly
-  constexpr int FIRST = x1_first_lane(RECON), CPW = x1_cells_per_wave(RECON);
   const int64_t run = (int64_t)u0.nx2 * rl;
   const int64_t t = (int64_t)wave * CPW + lane - FIRST;
   if ((int64_t)wave * CPW - FIRST >= run) return;  // whole wave beyond this block's run
@@ -993,9 +995,8 @@ inline void launch_final_march(const PackView &u0, const PackView &u1, const Sta
 template <int FLUID, int RECON, int RS>
 inline int launch_fused_stage(const PackView &u0, const PackView &u1, const StageParams &sp,
                               int extra, hipStream_t s) {
-  const int64_t run = (int64_t)u0.nx2 * u0.ni;
   // a windowed x1 sweep (phase 1) flattens at most window_rl columns per row
-  const int64_t run1 = sp.window ? (int64_t)u0.nx2 * sp.window_rl : run;
+  const int64_t run1 = (int64_t)u0.nx2 * (sp.window ? sp.window_rl : u0.nx1 + x1_first_lane(RECON) + 1);
   constexpr int cpw1 = x1_cells_per_wave(RECON);
   const int wpp = (int)((run1 + cpw1 - 1) / cpw1);
   const dim3 g1((wpp + 3) / 4, u0.nx3 * u0.nblocks, 1);
