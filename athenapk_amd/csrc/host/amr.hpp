@@ -45,6 +45,7 @@ struct AmrRefOp {  // one apk_refine_op in terms of block indices
   int src_kind = 0, src_block = 0, dst_kind = 0, dst_block = 0;
   int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
   int geom_block = 0;  // block whose lower corner / cell widths the operator uses
+  int corner = 0;      // prolongation into a ghost zone behind an edge or a corner (see BoxRegion::corner)
 };
 
 struct AmrPlans {
@@ -336,6 +337,11 @@ inline void BuildAmrPlans(const AmrTree &t, const AmrGeom &g, AmrPlans &p) {
       const int kind = t.Classify(l.level, pos, &nbr);
       if (kind == NB_PHYSICAL) return;
       int slo[3], dlo[3], ext[3];
+      // The unsplit sweeps, the flux correction and the tagging criteria read ghost cells straight behind a
+      // FACE only: whatever fills the block's ghost zone behind an edge or a corner is marked, and the stage
+      // loop runs the plans without those boxes (coarse-buffer fills are always complete: the prolongation
+      // stencil reaches sideways).
+      const int behind_corner = ((o[0] != 0) + (o[1] != 0) + (o[2] != 0)) != 1;
       if (kind == NB_SAME) {
         // fine ghost zone <- neighbour interior
         for (int d = 0; d < 3; ++d) {
@@ -350,6 +356,7 @@ inline void BuildAmrPlans(const AmrTree &t, const AmrGeom &g, AmrPlans &p) {
         BoxRegion r;
         r.src_kind = RK_BLOCK, r.src_block = nbr, r.dst_kind = RK_BLOCK, r.dst_block = lb;
         amr_box_region(r, g.fst, slo, g.fst, dlo, ext, g.nvar);
+        r.corner = behind_corner;
         p.fill.push_back(r);
         if (has_coarser[lb]) {  // coarse-buffer ghost zone <- neighbour's restricted interior
           for (int d = 0; d < 3; ++d) {
@@ -401,6 +408,7 @@ inline void BuildAmrPlans(const AmrTree &t, const AmrGeom &g, AmrPlans &p) {
               BoxRegion r;
               r.src_kind = RK_COARSE, r.src_block = fb, r.dst_kind = RK_BLOCK, r.dst_block = lb;
               amr_box_region(r, g.cst, slo, g.fst, dlo, ext, g.nvar);
+              r.corner = behind_corner;
               p.fill.push_back(r);
               if (nface == 1) {  // flux correction across the shared face
                 const int d = fdir;
@@ -467,6 +475,7 @@ inline void BuildAmrPlans(const AmrTree &t, const AmrGeom &g, AmrPlans &p) {
             op.lo[d] = g.ce[d] + 1, op.hi[d] = g.ce[d] + g.ng / 2;
           }
         }
+        op.corner = behind_corner;
         p.prolongate.push_back(op);
       }
     });

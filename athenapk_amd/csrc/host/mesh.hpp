@@ -26,6 +26,7 @@ struct BoxRegion {
   int ext[3] = {1, 1, 1};
   int nvar = 0, flip_var = -1;
   int64_t src_stride[4] = {0, 0, 0, 0}, dst_stride[4] = {0, 0, 0, 0};
+  int corner = 0;  // refined meshes: fills a block's ghost zone behind an EDGE or a CORNER (nothing in the stage loop reads it)
 };
 
 struct PeerPlan {

@@ -189,13 +189,20 @@ struct apk_sim {
     std::vector<apk::AmrRefOp> restrict_own, prolongate, flux_restrict[3];
     std::vector<apk::BoxRegion> fill, fill_pack, fill_unpack, coarse_bc[3], fine_bc[3];
     std::vector<apk::BoxRegion> flux_copy[3], flux_pack[3], flux_unpack[3];
+    // the exchange of the stage loop: without the boxes that fill ghost zones behind edges and corners
+    // (BoxRegion::corner); its messages are laid out by the same walk over the filtered global list
+    std::vector<apk::AmrRefOp> prolongate_faces;
+    std::vector<apk::BoxRegion> fill_faces, fill_pack_faces, fill_unpack_faces;
   } amr_local;
   struct MsgSet {
     apk::AmrMessages plan;
     std::vector<double *> send, recv;
     std::vector<int64_t> send_cap, recv_cap;
   };
-  MsgSet amr_halo, amr_fluxmsg, amr_move;
+  MsgSet amr_halo, amr_fluxmsg, amr_move, amr_halo_faces;
+  // refined meshes: the stage loop fills (and converts to primitives) only the ghost zones behind block FACES;
+  // accessors and regridding complete them first (sync_ghosts)
+  bool amr_ghosts_partial = false;
   const MsgSet *active_msgs = nullptr;  // the message set apk_sim_peer reports (null: the uniform mesh's)
   long long msg_generation = 0;         // bumped whenever that set, its sizes or its buffers change
   struct AmrDevice {
@@ -208,6 +215,10 @@ struct apk_sim {
     // arguments: each half is captured once per mesh into a hipGraph and replayed as ONE launch
     // (void* = hipGraphExec_t; null = not captured, the plans are launched one by one)
     void *xchg_pre[2] = {nullptr, nullptr}, *xchg_post[2] = {nullptr, nullptr};
+    // the faces-only exchange of the stage loop (AmrLocalPlans::fill_faces ...)
+    std::vector<apk_refine_plan *> prolongate_faces[2];
+    apk_copy_plan *fill_faces[2] = {nullptr, nullptr}, *fill_pack_faces[2] = {nullptr, nullptr}, *fill_unpack_faces[2] = {nullptr, nullptr};
+    void *xchg_pre_faces[2] = {nullptr, nullptr}, *xchg_post_faces[2] = {nullptr, nullptr};
     apk_flux_fix_plan *flux_fix[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     // the faces (6 * local block + face) with a coarser or finer block behind them: the only boundary-plane
     // fluxes the correction after a fused stage reads (apk_calculate_fluxes_boundary_list)

@@ -69,8 +69,18 @@ void amr_localize(apk_sim *s) {
   }
   s->amr_halo.plan = AmrMessages();
   s->amr_fluxmsg.plan = AmrMessages();
+  s->amr_halo_faces.plan = AmrMessages();
   AmrRegisterPeers(g.fill, part, part, rank, s->amr_halo.plan);
   AmrLocalize(g.fill, part, part, rank, s->amr_halo.plan, l.fill, l.fill_pack, l.fill_unpack);
+  {  // the stage loop's exchange: the same lists without the boxes behind edges and corners
+    std::vector<BoxRegion> faces;
+    for (const BoxRegion &r : g.fill)
+      if (!r.corner) faces.push_back(r);
+    AmrRegisterPeers(faces, part, part, rank, s->amr_halo_faces.plan);
+    AmrLocalize(faces, part, part, rank, s->amr_halo_faces.plan, l.fill_faces, l.fill_pack_faces, l.fill_unpack_faces);
+    for (const AmrRefOp &o : l.prolongate)
+      if (!o.corner) l.prolongate_faces.push_back(o);
+  }
   for (int d = 0; d < 3; ++d) AmrRegisterPeers(g.flux_copy[d], part, part, rank, s->amr_fluxmsg.plan);
   for (int d = 0; d < 3; ++d)
     AmrLocalize(g.flux_copy[d], part, part, rank, s->amr_fluxmsg.plan, l.flux_copy[d], l.flux_pack[d], l.flux_unpack[d]);
@@ -237,6 +247,12 @@ void amr_destroy_device_plans(apk_sim *s) {
     apk_copy_plan_destroy(a.fill_pack[par]);
     apk_copy_plan_destroy(a.fill_unpack[par]);
     a.fill[par] = a.fill_pack[par] = a.fill_unpack[par] = nullptr;
+    for (apk_refine_plan *p : a.prolongate_faces[par]) apk_refine_plan_destroy(p);
+    a.prolongate_faces[par].clear();
+    apk_copy_plan_destroy(a.fill_faces[par]);
+    apk_copy_plan_destroy(a.fill_pack_faces[par]);
+    apk_copy_plan_destroy(a.fill_unpack_faces[par]);
+    a.fill_faces[par] = a.fill_pack_faces[par] = a.fill_unpack_faces[par] = nullptr;
     for (int d = 0; d < 3; ++d) {
       apk_copy_plan_destroy(a.coarse_bc[par][d]);
       apk_copy_plan_destroy(a.fine_bc[par][d]);
@@ -363,6 +379,7 @@ int amr_rebuild(apk_sim *s) {
     return fail(s, APK_ERR_INVALID, e.what());
   }
   SIM_TRY(s, amr_ensure_buffers(s, s->amr_halo, "halo"));
+  SIM_TRY(s, amr_ensure_buffers(s, s->amr_halo_faces, "halo_faces"));
   SIM_TRY(s, amr_ensure_buffers(s, s->amr_fluxmsg, "fluxcorr"));
   amr_destroy_device_plans(s);
   auto &a = s->amr_dev;
@@ -373,6 +390,10 @@ int amr_rebuild(apk_sim *s) {
     SIM_TRY(s, amr_make_copy_plan(s, par, p.fill, nullptr, &a.fill[par]));
     SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_pack, &s->amr_halo, &a.fill_pack[par]));
     SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_unpack, &s->amr_halo, &a.fill_unpack[par]));
+    SIM_TRY(s, amr_make_refine_plans(s, par, p.prolongate_faces, a.prolongate_faces[par]));
+    SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_faces, nullptr, &a.fill_faces[par]));
+    SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_pack_faces, &s->amr_halo_faces, &a.fill_pack_faces[par]));
+    SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_unpack_faces, &s->amr_halo_faces, &a.fill_unpack_faces[par]));
     for (int d = 0; d < 3; ++d) {
       SIM_TRY(s, amr_make_copy_plan(s, par, p.coarse_bc[d], nullptr, &a.coarse_bc[par][d]));
       SIM_TRY(s, amr_make_copy_plan(s, par, p.fine_bc[d], nullptr, &a.fine_bc[par][d]));
@@ -409,26 +430,29 @@ int amr_rebuild(apk_sim *s) {
     if (!cf.empty()) SIM_HIP(s, hipMemcpy(a.d_cf_faces, cf.data(), sizeof(int) * cf.size(), hipMemcpyHostToDevice));
   }
   for (int par = 0; par < 2; ++par) {
-    amr_capture_half(s, par, true, &a.xchg_pre[par]);
-    amr_capture_half(s, par, false, &a.xchg_post[par]);
+    amr_capture_half(s, par, true, false, &a.xchg_pre[par]);
+    amr_capture_half(s, par, false, false, &a.xchg_post[par]);
+    amr_capture_half(s, par, true, true, &a.xchg_pre_faces[par]);
+    amr_capture_half(s, par, false, true, &a.xchg_post_faces[par]);
   }
+  s->amr_ghosts_partial = false;  // (whoever rebuilt the plans fills the new mesh completely next)
   return build_packs(s);
 }
 
 // the multilevel ghost exchange of the state in cons buffer `buf` (see amr.hpp), in the two halves
 // either side of the message exchange
-int amr_exchange_pre(apk_sim *s, int buf) {
+int amr_exchange_pre(apk_sim *s, int buf, bool faces) {
   auto &a = s->amr_dev;
   for (apk_refine_plan *p : a.restrict_own[buf]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
-  SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fill_pack[buf], s->stream));
-  SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fill[buf], s->stream));
+  SIM_TRY(s, apk_copy_plan_run(s->ctx, faces ? a.fill_pack_faces[buf] : a.fill_pack[buf], s->stream));
+  SIM_TRY(s, apk_copy_plan_run(s->ctx, faces ? a.fill_faces[buf] : a.fill[buf], s->stream));
   return APK_OK;
 }
-int amr_exchange_post(apk_sim *s, int buf) {
+int amr_exchange_post(apk_sim *s, int buf, bool faces) {
   auto &a = s->amr_dev;
-  SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fill_unpack[buf], s->stream));
+  SIM_TRY(s, apk_copy_plan_run(s->ctx, faces ? a.fill_unpack_faces[buf] : a.fill_unpack[buf], s->stream));
   for (int d = 0; d < 3; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.coarse_bc[buf][d], s->stream));
-  for (apk_refine_plan *p : a.prolongate[buf]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
+  for (apk_refine_plan *p : (faces ? a.prolongate_faces[buf] : a.prolongate[buf])) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
   for (int d = 0; d < 3; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fine_bc[buf][d], s->stream));
   return APK_OK;
 }
@@ -437,7 +461,7 @@ int amr_exchange_post(apk_sim *s, int buf) {
 // which cannot be captured: the launches are recorded on a private stream (nothing executes) and
 // the graph is launched on the sim's stream later.  Any failure leaves *out null: the caller then
 // launches the plans one by one as before.
-void amr_capture_half(apk_sim *s, int buf, bool pre, void **out) {
+void amr_capture_half(apk_sim *s, int buf, bool pre, bool faces, void **out) {
   *out = nullptr;
   static const bool disabled = std::getenv("APK_NO_GRAPH") != nullptr;  // A/B switch
   if (disabled) return;
@@ -450,7 +474,7 @@ void amr_capture_half(apk_sim *s, int buf, bool pre, void **out) {
     const apk_stream_t saved = s->stream;
     const std::string saved_err = s->err;
     s->stream = reinterpret_cast<apk_stream_t>(cs);
-    const int rc = pre ? amr_exchange_pre(s, buf) : amr_exchange_post(s, buf);
+    const int rc = pre ? amr_exchange_pre(s, buf, faces) : amr_exchange_post(s, buf, faces);
     s->stream = saved;
     ok = hipStreamEndCapture(cs, &graph) == hipSuccess && rc == APK_OK && graph != nullptr;
     if (rc != APK_OK) s->err = saved_err;
@@ -469,17 +493,24 @@ void amr_destroy_graphs(apk_sim *s) {
   for (int buf = 0; buf < 2; ++buf) {
     if (a.xchg_pre[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_pre[buf]));
     if (a.xchg_post[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_post[buf]));
-    a.xchg_pre[buf] = a.xchg_post[buf] = nullptr;
+    if (a.xchg_pre_faces[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_pre_faces[buf]));
+    if (a.xchg_post_faces[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_post_faces[buf]));
+    a.xchg_pre[buf] = a.xchg_post[buf] = a.xchg_pre_faces[buf] = a.xchg_post_faces[buf] = nullptr;
   }
 }
 
-int amr_exchange(apk_sim *s, int buf) {
+// faces = true: the stage loop's exchange -- everything but the ghost zones behind edges and corners,
+// which no sweep, flux correction or tagging criterion reads (sync_ghosts completes them for accessors
+// and before regridding)
+int amr_exchange(apk_sim *s, int buf, bool faces) {
   auto &a = s->amr_dev;
-  if (a.xchg_pre[buf]) SIM_HIP(s, hipGraphLaunch(static_cast<hipGraphExec_t>(a.xchg_pre[buf]), hs(s)));
-  else SIM_TRY(s, amr_exchange_pre(s, buf));
-  SIM_TRY(s, amr_exchange_messages(s, s->amr_halo));
-  if (a.xchg_post[buf]) SIM_HIP(s, hipGraphLaunch(static_cast<hipGraphExec_t>(a.xchg_post[buf]), hs(s)));
-  else SIM_TRY(s, amr_exchange_post(s, buf));
+  void *pre = faces ? a.xchg_pre_faces[buf] : a.xchg_pre[buf], *post = faces ? a.xchg_post_faces[buf] : a.xchg_post[buf];
+  if (pre) SIM_HIP(s, hipGraphLaunch(static_cast<hipGraphExec_t>(pre), hs(s)));
+  else SIM_TRY(s, amr_exchange_pre(s, buf, faces));
+  SIM_TRY(s, amr_exchange_messages(s, faces ? s->amr_halo_faces : s->amr_halo));
+  if (post) SIM_HIP(s, hipGraphLaunch(static_cast<hipGraphExec_t>(post), hs(s)));
+  else SIM_TRY(s, amr_exchange_post(s, buf, faces));
+  if (!faces) s->amr_ghosts_partial = false;  // (of cons; the caller converts to primitives)
   return APK_OK;
 }
 
@@ -607,6 +638,9 @@ bool amr_update_tree(apk_sim *s, const std::vector<int> &tags, bool allow_derefi
 // coarse buffer), merged blocks collect their children's restricted interiors; whatever changes
 // rank travels in one message per peer.  Then everything that depends on the block list is rebuilt.
 int amr_transfer(apk_sim *s, const std::vector<AmrLeaf> &old, const AmrPartition &old_part) {
+  // (a new fine block is prolongated out of its parent's octant PLUS cng cells all round, edges and corners of
+  // the parent's ghost zones included: complete them on the old mesh -- its plans and packs are still in place)
+  SIM_TRY(s, sync_ghosts(s));
   const AmrGeom &g = s->amr_geom;
   AmrTree &t = *s->amr;
   const int rank = s->rank;

@@ -67,6 +67,7 @@ int build_windows(apk_sim *s);
 bool can_overlap_next(const apk_sim *s, int next);
 int finish_pending(apk_sim *s);
 bool direct_neighbors(const apk_sim *s);
+bool amr_faces_only(const apk_sim *s);
 int materialize_local_ghosts(apk_sim *s);
 int sync_ghosts(apk_sim *s);  // finish_pending + materialize_local_ghosts
 int fill_derived(apk_sim *s);
@@ -103,10 +104,10 @@ void amr_free_buffers(apk_sim *s, apk_sim::MsgSet &m);
 int amr_exchange_messages(apk_sim *s, const apk_sim::MsgSet &m);
 int amr_allocate(apk_sim *s, size_t n, double *cons2[2], double **prim, double *flux[3], double **coarse);
 int amr_rebuild(apk_sim *s);
-int amr_exchange(apk_sim *s, int buf);
-int amr_exchange_pre(apk_sim *s, int buf);
-int amr_exchange_post(apk_sim *s, int buf);
-void amr_capture_half(apk_sim *s, int buf, bool pre, void **out);
+int amr_exchange(apk_sim *s, int buf, bool faces = false);
+int amr_exchange_pre(apk_sim *s, int buf, bool faces);
+int amr_exchange_post(apk_sim *s, int buf, bool faces);
+void amr_capture_half(apk_sim *s, int buf, bool pre, bool faces, void **out);
 void amr_destroy_graphs(apk_sim *s);
 bool amr_has_coarse_fine_faces(const apk_sim *s);
 int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi_factor);

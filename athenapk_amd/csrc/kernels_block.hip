@@ -134,6 +134,21 @@ cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags) {
   cons_to_prim_at<FLUID>(pv, pv.blocks[b], eos, flags, k * pv.sk + j * pv.sj + i);
 }
 
+// Interior cells and the ghost cells straight behind a FACE of the block (at most one ghost coordinate):
+// what the sweeps of the next stage read.  Rows behind edges and corners are skipped whole (no memory
+// traffic): 26 % of the cells of a 16^3 block with nghost = 4.
+template <int FLUID>
+__global__ void __launch_bounds__(256)
+cons_to_prim_faces_kernel(PackView pv, apk_eos eos, unsigned *flags) {
+  int i, j;
+  if (!rect_ij(pv.ni, pv.nj, i, j)) return;
+  const int b = blockIdx.z / pv.nk;
+  const int k = blockIdx.z % pv.nk;
+  const int ghost = ((i < pv.is) || (i > pv.ie)) + ((j < pv.js) || (j > pv.je)) + ((k < pv.ks) || (k > pv.ke));
+  if (ghost > 1) return;
+  cons_to_prim_at<FLUID>(pv, pv.blocks[b], eos, flags, k * pv.sk + j * pv.sj + i);
+}
+
 // Ghost zones only (the interior was converted by the finishing sweep of the fused stage).  The
 // ghost shell of a block is enumerated as three groups of slabs so that no thread is launched
 // for an interior cell: x3 slabs (whole planes), x2 slabs of the interior planes (whole rows),
@@ -482,7 +497,7 @@ int launch_dedner(const PackView &pv, int extended, double coeff, double beta_dt
 }
 
 int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsigned *d_flags,
-                        hipStream_t s, bool ghosts_only, const unsigned *late_regions, int part) {
+                        hipStream_t s, bool ghosts_only, const unsigned *late_regions, int part, bool faces_only) {
   if (ghosts_only) {
     const int64_t na = (int64_t)(pv.nk - pv.nx3) * pv.nj * pv.ni;
     const int64_t nb = (int64_t)pv.nx3 * (pv.nj - pv.nx2) * pv.ni;
@@ -497,7 +512,12 @@ int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsig
     return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
   }
   const dim3 grid = rect_grid(pv.ni, pv.nj, pv.nk * pv.nblocks);
-  if (fluid == APK_FLUID_EULER)
+  if (faces_only) {
+    if (fluid == APK_FLUID_EULER)
+      hipLaunchKernelGGL(cons_to_prim_faces_kernel<APK_FLUID_EULER>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags);
+    else
+      hipLaunchKernelGGL(cons_to_prim_faces_kernel<APK_FLUID_GLMMHD>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags);
+  } else if (fluid == APK_FLUID_EULER)
     hipLaunchKernelGGL(cons_to_prim_kernel<APK_FLUID_EULER>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags);
   else
     hipLaunchKernelGGL(cons_to_prim_kernel<APK_FLUID_GLMMHD>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags);

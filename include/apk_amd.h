@@ -251,6 +251,12 @@ int apk_stage_split_axis(const apk_pack *u0, const apk_flux_cfg *cfg, int fill_d
 int apk_cons_to_prim(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,
                      apk_stream_t stream);
 
+/* ConsToPrim of the interior and of the ghost cells straight behind a block FACE only (at most one ghost
+ * coordinate): what the unsplit sweeps, the flux correction and the tagging criteria read.  The refined-
+ * mesh stage loop of the standalone driver fills and converts only those (edges and corners are 37 % of
+ * the ghost cells of a 16^3 block with nghost = 4); primitives behind edges and corners are left as
+ * they were. */
+int apk_cons_to_prim_faces(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, apk_stream_t stream);
 /* ConsToPrim restricted to the ghost zones of every block (interior cells untouched): the
  * companion of apk_stage_fused(fill_derived = 1). */
 int apk_cons_to_prim_ghosts(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,
