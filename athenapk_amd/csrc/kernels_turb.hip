@@ -94,6 +94,33 @@ __global__ void __launch_bounds__(256) final_sum_kernel(const double *partial, i
   if (lane == 0) out[q] = s;
 }
 
+// first level of the final sum when there are many partials (one per 256 cells: 65536 on 256^3, which
+// the single workgroup above walks in 2048 dependent steps = 0.6 ms): kMidGroups workgroups each sum a
+// contiguous share in a fixed order; the single workgroup then adds kMidGroups values per quantity
+constexpr int kMidGroups = 256;
+template <int NQ>
+__global__ void __launch_bounds__(256) mid_sum_kernel(const double *partial, int nwg, double *out) {
+  const int chunk = (nwg + kMidGroups - 1) / kMidGroups;
+  const int lo = blockIdx.x * chunk, hi = (lo + chunk < nwg) ? lo + chunk : nwg;
+  double h[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) h[q] = 0.0;
+  for (int w = lo + (int)threadIdx.x; w < hi; w += 256) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) h[q] += partial[(int64_t)w * NQ + q];
+  }
+  __shared__ double part[4][NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const double v = wsum(h[q]);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NQ)
+    out[(int64_t)blockIdx.x * NQ + threadIdx.x] =
+        (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
 // turbulence.cpp:395-413
 __global__ void __launch_bounds__(256)
 turb_mean_momentum_kernel(PackView pv, const apk_fmft_block *blocks, double *partial) {
@@ -213,7 +240,13 @@ int ensure_partial_cap(apk_ctx *ctx, size_t n) {
 template <int NQ>
 int finish_sums(apk_ctx *ctx, int nwg, double *out, hipStream_t s) {
   double *d_out = ctx->d_partial + (size_t)nwg * NQ;
-  hipLaunchKernelGGL(final_sum_kernel<NQ>, dim3(1), dim3(256), 0, s, ctx->d_partial, nwg, d_out);
+  if (nwg > 8 * kMidGroups) {  // (callers reserve nwg * 4 + kMidGroups * 4 + 8 doubles)
+    double *d_mid = d_out + NQ;
+    hipLaunchKernelGGL(mid_sum_kernel<NQ>, dim3(kMidGroups), dim3(256), 0, s, ctx->d_partial, nwg, d_mid);
+    hipLaunchKernelGGL(final_sum_kernel<NQ>, dim3(1), dim3(256), 0, s, d_mid, kMidGroups, d_out);
+  } else {
+    hipLaunchKernelGGL(final_sum_kernel<NQ>, dim3(1), dim3(256), 0, s, ctx->d_partial, nwg, d_out);
+  }
   auto *h = static_cast<double *>(ctx->h_pinned) + 16;
   if (hipMemcpyAsync(h, d_out, NQ * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return APK_ERR_DEVICE;
   if (hipStreamSynchronize(s) != hipSuccess) return APK_ERR_DEVICE;
@@ -271,7 +304,7 @@ int apk_turb_mean_momentum(apk_ctx *ctx, const apk_pack *md, const apk_fmft *f, 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const dim3 g = igrid(md->view);
   const int nwg = g.x * g.y * g.z;
-  if (ensure_partial_cap(ctx, (size_t)nwg * 4 + 8) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "partial buffer");
+  if (ensure_partial_cap(ctx, (size_t)nwg * 4 + kMidGroups * 4 + 8) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "partial buffer");
   hipLaunchKernelGGL(turb_mean_momentum_kernel, g, dim3(64, 4, 1), 0, s, md->view, f->d_blocks, ctx->d_partial);
   return finish_sums<4>(ctx, nwg, sums4, s);
 }
@@ -283,7 +316,7 @@ int apk_turb_remove_mean(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, const do
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const dim3 g = igrid(md->view);
   const int nwg = g.x * g.y * g.z;
-  if (ensure_partial_cap(ctx, (size_t)nwg * 4 + 8) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "partial buffer");
+  if (ensure_partial_cap(ctx, (size_t)nwg * 4 + kMidGroups * 4 + 8) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "partial buffer");
   hipLaunchKernelGGL(turb_remove_mean_kernel, g, dim3(64, 4, 1), 0, s, md->view, f->d_blocks, sums4[1] / sums4[0],
                      sums4[2] / sums4[0], sums4[3] / sums4[0], ctx->d_partial);
   return finish_sums<1>(ctx, nwg, ampl_sum, s);
@@ -302,7 +335,7 @@ int apk_turbulence_history(apk_ctx *ctx, const apk_pack *md, int fluid, double g
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const dim3 g = igrid(md->view);
   const int nwg = g.x * g.y * g.z;
-  if (ensure_partial_cap(ctx, (size_t)nwg * 4 + 8) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "partial buffer");
+  if (ensure_partial_cap(ctx, (size_t)nwg * 4 + kMidGroups * 4 + 8) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "partial buffer");
   if (fluid == APK_FLUID_EULER)
     hipLaunchKernelGGL(turb_history_kernel<APK_FLUID_EULER>, g, dim3(64, 4, 1), 0, s, md->view, gamma, ctx->d_partial);
   else
@@ -316,7 +349,7 @@ int apk_history_user_reldivb(apk_ctx *ctx, const apk_pack *md, double B0, double
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const dim3 g = igrid(md->view);
   const int nwg = g.x * g.y * g.z;
-  if (ensure_partial_cap(ctx, (size_t)nwg * 4 + 8) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "partial buffer");
+  if (ensure_partial_cap(ctx, (size_t)nwg * 4 + kMidGroups * 4 + 8) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "partial buffer");
   hipLaunchKernelGGL(user_reldivb_kernel, g, dim3(64, 4, 1), 0, s, md->view, B0, ctx->d_partial);
   return finish_sums<1>(ctx, nwg, out, s);
 }
