@@ -410,9 +410,9 @@ int exchange_ghosts(apk_sim *s, bool c2p, bool skip_local) {
 
 // Can the stages of this simulation read same-rank neighbours directly (apk_stage_args.face_neighbor)
 // so that the same-rank ghost copies can be skipped?  Every stage of the cycle must be one of the
-// kernels that follow the table, and nothing else in the cycle may read ghost zones.  (With the
-// turbulence driver the last stage is followed by the kick and a full-block ConsToPrim: that one
-// exchange is a complete one -- do_stage skips the copies only after stages with a fused FillDerived.)
+// kernels that follow the table, and nothing else in the cycle may read ghost zones.  (do_stage skips
+// the copies only after stages whose FillDerived was fused -- into the finishing sweep or, with the
+// turbulence driver, into the kick; an exchange followed by a full-block ConsToPrim is a complete one.)
 bool direct_neighbors(const apk_sim *s) {
   static const int mode = std::getenv("APK_DIRECT_NEIGHBORS") ? std::atoi(std::getenv("APK_DIRECT_NEIGHBORS")) : 1;  // A/B switch
   static const int dc_mode = std::getenv("APK_DC_MODE") ? std::atoi(std::getenv("APK_DC_MODE")) : 2;
@@ -669,7 +669,7 @@ int turbulence_device_setup(apk_sim *s) {
 
 // turbulence::Driving = Generate + Perturb (src/pgen/turbulence.cpp:373-482), the first-order
 // operator-split source run after the last stage (src/hydro/hydro_driver.cpp:559-560)
-int turbulence_driving(apk_sim *s, double dt) {
+int turbulence_driving(apk_sim *s, double dt, bool fill) {
   s->fmft->Evolve(dt);
   const auto &vh = s->fmft->var_hat();
   std::vector<double> flat(vh.size() * 2);
@@ -687,7 +687,10 @@ int turbulence_driving(apk_sim *s, double dt) {
   if (mpi && s->comm.allreduce_sum(s->comm.user, &ampl, 1) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_sum failed");
   const double box = (s->xmax[0] - s->xmin[0]) * (s->xmax[1] - s->xmin[1]) * (s->xmax[2] - s->xmin[2]);
   const double norm = s->accel_rms / std::sqrt(ampl / box);
-  SIM_TRY(s, apk_turb_apply(s->ctx, s->mu0(), s->fm_dev, norm, dt, s->stream));
+  // (fill: the kick also does FillDerived and the time-step estimate of the cells it touches -- the two tasks that
+  // follow it, hydro_driver.cpp:559-577, 589-603 -- instead of a full ConsToPrim pass and a dt pass afterwards)
+  if (fill) SIM_TRY(s, apk_turb_apply_fill(s->ctx, s->mu0(), s->fm_dev, norm, dt, s->pkg.fluid, &s->pkg.eos, s->pkg.calc_dt_hyp ? 1 : 0, s->stream));
+  else SIM_TRY(s, apk_turb_apply(s->ctx, s->mu0(), s->fm_dev, norm, dt, s->stream));
   return APK_OK;
 }
 
@@ -892,7 +895,15 @@ int do_stage(apk_sim *s, int stage) {
     }
     }
   }
-  if (s->fmft && stage == s->nstages) SIM_TRY(s, turbulence_driving(s, s->dt));
+  if (s->fmft && stage == s->nstages) {
+    static const bool plain_kick = std::getenv("APK_TURB_PLAIN_KICK") != nullptr;  // A/B switch
+    const bool kick_fills = !fused_fill && !s->amr && !plain_kick;
+    SIM_TRY(s, turbulence_driving(s, s->dt, kick_fills));
+    if (kick_fills) {  // as after a stage whose finishing sweep did FillDerived and the dt estimate
+      fused_fill = true;
+      s->stage_dt_pending = pkg.calc_dt_hyp;
+    }
+  }
   static const bool no_copy_c2p = std::getenv("APK_NO_COPY_C2P") != nullptr;  // A/B switch
   const bool c2p_in_copy = fused_fill && ghost_c2p_fusable(s) && !no_copy_c2p;
   if (fused_fill && can_overlap_next(s, stage < s->nstages ? stage + 1 : 1)) {

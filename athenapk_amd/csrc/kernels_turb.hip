@@ -237,6 +237,76 @@ int ensure_partial_cap(apk_ctx *ctx, size_t n) {
 }
 
 // run a partial-sum kernel result through the final reduction and bring NQ doubles to the host
+// The kick with the work of the two tasks that follow it on the same cell: FillDerived (ConsToPrim, floors
+// included, prim in place: the kick is the last thing to touch the cell before the next stage reads it) and
+// the time-step estimate -- one pass over cons instead of three.
+template <int FLUID, bool WITH_DT>
+__global__ void __launch_bounds__(256)
+turb_apply_fill_kernel(PackView pv, const apk_fmft_block *blocks, double norm, double dt, apk_eos eos, unsigned *flags,
+                       unsigned long long *dt_bits) {
+  constexpr int NV = nvars<FLUID>();
+  int b, k, j, i;
+  double lane_min = 1.7976931348623157e308;
+  if (interior_of(pv, b, k, j, i)) {
+    const apk_block_desc blk = pv.blocks[b];
+    const int64_t cell = k * pv.sk + j * pv.sj + i;
+    double *acc = blocks[b].acc + cell;
+    double *u = blk.cons + cell;
+    const double a0 = acc[0 * pv.sn] * norm, a1 = acc[1 * pv.sn] * norm, a2 = acc[2 * pv.sn] * norm;
+    acc[0 * pv.sn] = a0;
+    acc[1 * pv.sn] = a1;
+    acc[2 * pv.sn] = a2;
+    double un[NV], w[NV], di;
+#pragma unroll
+    for (int n = 0; n < NV; ++n) un[n] = u[n * pv.sn];
+    const double den = un[IDN];
+    const double qa = dt * den;
+    const double m1 = un[IM1], m2 = un[IM2], m3 = un[IM3];
+    un[IEN] += (m1 * dt * a0 + m2 * dt * a1 + m3 * dt * a2 + (sqr(a0) + sqr(a1) + sqr(a2)) * qa * qa / (2 * den));
+    un[IM1] = m1 + qa * a0;
+    un[IM2] = m2 + qa * a1;
+    un[IM3] = m3 + qa * a2;
+    const unsigned fl = cons_to_prim_cell<FLUID>(eos, un, w, di);
+    if (fl) atomicOr(flags, fl);
+    double *p = blk.prim + cell;
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      u[n * pv.sn] = un[n];
+      p[n * pv.sn] = w[n];
+    }
+    for (int n = NV; n < pv.nvar; ++n) p[n * pv.sn] = u[n * pv.sn] * di;  // passive scalars
+    if constexpr (WITH_DT) {  // EstimateHyperbolicTimestep (hydro.cpp:845-895) on the fresh primitives
+      double lx, ly = 0.0, lz = 0.0;
+      if constexpr (FLUID == APK_FLUID_EULER) {
+        lx = ly = lz = sound_speed(eos.gamma, w[IDN], w[IPR]);
+      } else {
+        lx = fast_speed(eos.gamma, w[IDN], w[IPR], w[IB1], w[IB2], w[IB3]);
+        if (pv.ndim > 1) ly = fast_speed(eos.gamma, w[IDN], w[IPR], w[IB2], w[IB3], w[IB1]);
+        if (pv.ndim > 2) lz = fast_speed(eos.gamma, w[IDN], w[IPR], w[IB3], w[IB1], w[IB2]);
+      }
+      lane_min = fmin(lane_min, blk.dx[0] / (fabs(w[IV1]) + lx));
+      if (pv.ndim > 1) lane_min = fmin(lane_min, blk.dx[1] / (fabs(w[IV2]) + ly));
+      if (pv.ndim > 2) lane_min = fmin(lane_min, blk.dx[2] / (fabs(w[IV3]) + lz));
+    }
+  }
+  if constexpr (WITH_DT) {
+    // one candidate per workgroup, and an atomic only if it beats the word's current value (a plain read: a
+    // stale, larger value merely costs an atomic that changes nothing) -- 65536 workgroups on 256^3 would
+    // otherwise queue on one address for milliseconds
+    __shared__ double wmin[4];
+    double m = lane_min;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_down(m, off, 64));
+    if (threadIdx.x == 0) wmin[threadIdx.y] = m;
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+      m = fmin(fmin(wmin[0], wmin[1]), fmin(wmin[2], wmin[3]));
+      const double cur = __longlong_as_double((long long)*reinterpret_cast<volatile unsigned long long *>(dt_bits));
+      if (m < cur) atomicMin(dt_bits, (unsigned long long)__double_as_longlong(m));
+    }
+  }
+}
+
 template <int NQ>
 int finish_sums(apk_ctx *ctx, int nwg, double *out, hipStream_t s) {
   double *d_out = ctx->d_partial + (size_t)nwg * NQ;
@@ -327,6 +397,28 @@ int apk_turb_apply(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, double norm, d
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(turb_apply_kernel, igrid(md->view), dim3(64, 4, 1), 0, s, md->view, f->d_blocks, norm, dt);
   return hipGetLastError() == hipSuccess ? APK_OK : set_err(ctx, APK_ERR_DEVICE, "turb_apply launch", hipGetLastError());
+}
+
+int apk_turb_apply_fill(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, double norm, double dt, int fluid, const apk_eos *eos,
+                        int estimate_dt, apk_stream_t stream) {
+  if (!ctx || !md || !f || !eos || f->nblocks != md->view.nblocks || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||
+      md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9))
+    return set_err(ctx, APK_ERR_INVALID, "apk_turb_apply_fill: bad argument");
+  for (const auto &b : md->h_blocks)
+    if (!b.prim) return set_err(ctx, APK_ERR_INVALID, "apk_turb_apply_fill: block without prim pointer");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  unsigned long long *dt_bits = ctx->d_u64 + 4;  // the stage's word: apk_stage_dt_read / apk_stage_dt_flags_read
+  if (estimate_dt && hipMemcpyAsync(dt_bits, ctx->d_u64 + 15, sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return set_err(ctx, APK_ERR_DEVICE, "apk_turb_apply_fill", hipGetLastError());
+  const dim3 g = igrid(md->view), blk(64, 4, 1);
+  if (fluid == APK_FLUID_EULER) {
+    if (estimate_dt) hipLaunchKernelGGL((turb_apply_fill_kernel<APK_FLUID_EULER, true>), g, blk, 0, s, md->view, f->d_blocks, norm, dt, *eos, ctx->d_flags, dt_bits);
+    else hipLaunchKernelGGL((turb_apply_fill_kernel<APK_FLUID_EULER, false>), g, blk, 0, s, md->view, f->d_blocks, norm, dt, *eos, ctx->d_flags, dt_bits);
+  } else {
+    if (estimate_dt) hipLaunchKernelGGL((turb_apply_fill_kernel<APK_FLUID_GLMMHD, true>), g, blk, 0, s, md->view, f->d_blocks, norm, dt, *eos, ctx->d_flags, dt_bits);
+    else hipLaunchKernelGGL((turb_apply_fill_kernel<APK_FLUID_GLMMHD, false>), g, blk, 0, s, md->view, f->d_blocks, norm, dt, *eos, ctx->d_flags, dt_bits);
+  }
+  return hipGetLastError() == hipSuccess ? APK_OK : set_err(ctx, APK_ERR_DEVICE, "turb_apply_fill launch", hipGetLastError());
 }
 
 int apk_turbulence_history(apk_ctx *ctx, const apk_pack *md, int fluid, double gamma, double *out3,

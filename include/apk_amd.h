@@ -373,6 +373,13 @@ int apk_turb_remove_mean(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, const do
                          double *ampl_sum, apk_stream_t stream);
 int apk_turb_apply(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, double norm, double dt,
                    apk_stream_t stream);
+/* apk_turb_apply plus the two tasks that follow the kick on the same cells (hydro_driver.cpp:559-577, 589-603):
+ * FillDerived -- ConsToPrim with the floors of `eos`, prim replaced in place -- and, with estimate_dt, the
+ * min-reduction of dx_d / (|v_d| + c_d) into the stage's word (read it with apk_stage_dt_read); the caller
+ * then converts ghost zones only (apk_copy_plan_run_c2p / apk_cons_to_prim_ghosts).  One pass over cons
+ * instead of three. */
+int apk_turb_apply_fill(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, double norm, double dt, int fluid,
+                        const apk_eos *eos, int estimate_dt, apk_stream_t stream);
 /* TurbulenceHst<Ms|Ma|pb> (turbulence.cpp:47-101): out3 = volume sums of sonic Mach number,
  * Alfvenic Mach number, plasma beta.  Synchronises. */
 int apk_turbulence_history(apk_ctx *ctx, const apk_pack *md, int fluid, double gamma, double *out3,

@@ -281,9 +281,9 @@ def _turb_k_vec():
 def test_turbulence_driver_matches_oracle(oracle, strict, b_config, mb1):
     """32^3 in 8 (4) meshblocks, 12 driven cycles.  The spectral state is bit-identical (same host RNG);
     the fields agree to round-off (the Perturb sums are reduced in a different order).  With 32-cell-wide
-    blocks the stages are the two-kernel / single-march forms that read same-rank neighbours directly: the
-    first stage's exchange skips the same-rank copies, the last one (followed by the kick and a full-block
-    ConsToPrim) is complete."""
+    blocks the stages are the two-kernel / single-march forms that read same-rank neighbours directly and no
+    exchange copies same-rank ghost zones: the kick after the last stage converts the cells it touches to
+    primitives and estimates the time step itself (apk_turb_apply_fill)."""
     ov = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=32", "parthenon/meshblock/nx1=%d" % mb1,
           "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=16", "problem/turbulence/b_config=%d" % b_config]
     s = _sim("turbulence", ov, strict=strict).initialize()
@@ -294,7 +294,7 @@ def test_turbulence_driver_matches_oracle(oracle, strict, b_config, mb1):
     for _ in range(12):
         s.step()
         o.step()
-    assert s.skipped_local_exchanges() == (12 if mb1 == 32 else 0)
+    assert s.skipped_local_exchanges() == (24 if mb1 == 32 else 0)
     assert np.array_equal(s.fmft_var_hat(), o.var_hat())
     assert abs(s.time - o.time) <= 1e-13 * o.time
     np.testing.assert_allclose(s.gather("cons"), o.gather_cons(), rtol=1e-11, atol=1e-13)
