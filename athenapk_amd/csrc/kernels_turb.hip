@@ -3,6 +3,7 @@
 // The inverse transform is ALU-bound (3 x num_modes complex MACs per cell): one lane per cell,
 // x1 along the lanes so phases_i is a coalesced read, phases_j / phases_k and var_hat are
 // wave-uniform (scalar loads).
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -28,6 +29,55 @@ APK_DEV bool interior_of(const PackView &pv, int &b, int &k, int &j, int &i) {
   return inside;
 }
 inline dim3 igrid(const PackView &pv) { return rect_grid(pv.nx1, pv.nx2, pv.nx3 * pv.nblocks); }
+
+#ifndef APK_FP_STRICT
+// Product build: the same sum with the products regrouped, acc_c = 2 Re sum_m (var_hat_c[m] phase_j[m] phase_k[m])
+// phase_i[m] -- the bracket does not depend on i, so each wave (one (j, k) row of a block) forms it once per mode
+// (lane m, kept in LDS) and every cell costs 6 FMAs, 2 coalesced loads and 3 broadcast LDS reads per mode
+// instead of two complex products, three complex MACs and 8 loads (1.45 -> 0.5 ms on 256^3 with 30 modes).
+// Differs from the reference's grouping (few_modes_ft.cpp:330-347, kept by the parity build below) in the last
+// bits only.
+constexpr int kMaxRowModes = 64;
+__global__ void __launch_bounds__(256)
+fmft_inverse_rows_kernel(PackView pv, const apk_fmft_block *blocks, const double *var_hat, int M) {
+  __shared__ __attribute__((aligned(16))) double A[4][kMaxRowModes][6];
+  const int lane = threadIdx.x, wv = threadIdx.y;
+  const int jo = blockIdx.x * 4 + wv;
+  const int b = blockIdx.y / pv.nx3, ko = blockIdx.y % pv.nx3;
+  const bool row = jo < pv.nx2;
+  const apk_fmft_block blk = blocks[b];
+  const int64_t n1 = pv.nx1, n2 = pv.nx2, n3 = pv.nx3;
+  if (row && lane < M) {
+    const int m = lane;
+    const double jr = blk.phases_j[m * n2 + jo], ji = blk.phases_j[(M + m) * n2 + jo];
+    const double kr = blk.phases_k[m * n3 + ko], ki = blk.phases_k[(M + m) * n3 + ko];
+    const double pr = jr * kr - ji * ki, pim = jr * ki + ji * kr;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double vr = var_hat[(c * M + m) * 2], vi = var_hat[(c * M + m) * 2 + 1];
+      A[wv][m][2 * c] = vr * pr - vi * pim;
+      A[wv][m][2 * c + 1] = vr * pim + vi * pr;
+    }
+  }
+  __syncthreads();
+  if (!row) return;
+  const int64_t rowcell = (int64_t)(pv.ks + ko) * pv.sk + (int64_t)(pv.js + jo) * pv.sj + pv.is;
+  for (int io = lane; io < pv.nx1; io += 64) {
+    const double *pi = blk.phases_i + io;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int m = 0; m < M; ++m) {
+      const double ir = pi[m * n1], ii = pi[(M + m) * n1];
+      const double *a = A[wv][m];
+      s0 += a[0] * ir - a[1] * ii;
+      s1 += a[2] * ir - a[3] * ii;
+      s2 += a[4] * ir - a[5] * ii;
+    }
+    blk.acc[0 * pv.sn + rowcell + io] = 2. * s0;
+    blk.acc[1 * pv.sn + rowcell + io] = 2. * s1;
+    blk.acc[2 * pv.sn + rowcell + io] = 2. * s2;
+  }
+}
+#endif
 
 // few_modes_ft.cpp:330-347
 __global__ void __launch_bounds__(256)
@@ -363,6 +413,15 @@ int apk_fmft_inverse(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, const double
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   APK_HIP_TRY(ctx, hipMemcpyAsync(f->d_var_hat, var_hat_host, sizeof(double) * 3 * f->num_modes * 2,
                                   hipMemcpyHostToDevice, s));
+#ifndef APK_FP_STRICT
+  static const bool plain = std::getenv("APK_FMFT_PLAIN") != nullptr;  // A/B switch
+  if (!plain && f->num_modes <= kMaxRowModes) {
+    const PackView &pv = md->view;
+    hipLaunchKernelGGL(fmft_inverse_rows_kernel, dim3((pv.nx2 + 3) / 4, pv.nx3 * pv.nblocks, 1), dim3(64, 4, 1), 0, s, pv,
+                       f->d_blocks, f->d_var_hat, f->num_modes);
+    return hipGetLastError() == hipSuccess ? APK_OK : set_err(ctx, APK_ERR_DEVICE, "fmft_inverse launch", hipGetLastError());
+  }
+#endif
   hipLaunchKernelGGL(fmft_inverse_kernel, igrid(md->view), dim3(64, 4, 1), 0, s, md->view, f->d_blocks,
                      f->d_var_hat, f->num_modes);
   return hipGetLastError() == hipSuccess ? APK_OK : set_err(ctx, APK_ERR_DEVICE, "fmft_inverse launch", hipGetLastError());
