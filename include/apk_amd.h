@@ -130,7 +130,8 @@ int apk_calculate_fluxes_tight(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cf
  * (apk_stage_fused never materialises face fluxes; see apk_flux_fix_plan below). */
 int apk_calculate_fluxes_boundary(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg,
                                   const apk_eos *eos, double c_h, apk_stream_t stream);
-/* The same for a DEVICE list of (block, face) pairs only, in ONE launch: faces[n] = 6 * block + face,
+/* The same for a DEVICE list of (block, face) pairs only, in ONE launch (the input of the coarse-fine flux
+ * correction, hydro_driver.cpp:527-531, when the stage ran fused): faces[n] = 6 * block + face,
  * face = {x1 lower, x1 upper, x2 lower, x2 upper, x3 lower, x3 upper} -- on a refined mesh the faces
  * with a coarser or finer block behind them (the fine side's fluxes are averaged, the coarse side's own
  * flux is what the average replaces); the planes of unlisted faces are left untouched. */
@@ -251,8 +252,9 @@ int apk_stage_split_axis(const apk_pack *u0, const apk_flux_cfg *cfg, int fill_d
 int apk_cons_to_prim(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,
                      apk_stream_t stream);
 
-/* ConsToPrim of the interior and of the ghost cells straight behind a block FACE only (at most one ghost
- * coordinate): what the unsplit sweeps, the flux correction and the tagging criteria read.  The refined-
+/* ConsToPrim (Update::FillDerived, hydro_driver.cpp:571-577; src/eos/adiabatic_hydro.cpp:33) of the interior
+ * and of the ghost cells straight behind a block FACE only (at most one ghost coordinate): what the unsplit
+ * sweeps (hydro.cpp:1025-1199), the flux correction and the tagging criteria (refinement/gradient.cpp) read.  The refined-
  * mesh stage loop of the standalone driver fills and converts only those (edges and corners are 37 % of
  * the ghost cells of a 16^3 block with nghost = 4); primitives behind edges and corners are left as
  * they were. */
