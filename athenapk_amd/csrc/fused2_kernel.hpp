@@ -80,7 +80,8 @@ constexpr int m12_last_lane(int recon) { return 62 - recon_halfwidth(recon); }
 // 1 after the x1 phase, 2 after the x2 solve.  Measured on 8 x 128^3 PPM+HLLD: 3.44 / 3.10 / 2.36 ms
 // with two waves per SIMD -- the earlier the loads, the more of the 256 VGPRs they hold through an
 // HLLD solve and the more the compiler spills (148 / 156 / 12 B of scratch per lane); with one wave
-// per SIMD (512 VGPRs, APK_M12F_WAVES = 1) nothing spills but 2.63 ms at best.
+// per SIMD (512 VGPRs, APK_M12F_WAVES = 1) nothing spills but 2.63 ms at best.  3 = u1 after the x1
+// phase, d3 after the x2 solve: 100 B of scratch, 2.81 against 2.60 ms on the same box.
 #define APK_M12F_LOADS 2
 #endif
 #ifndef APK_M12F_WAVES
@@ -261,6 +262,11 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
 #pragma unroll
           for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
         }
+        if constexpr (APK_M12F_LOADS == 3) {  // (A/B) u1 early, d3 late
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
+        }
       }
       // ---- (3) x2: reconstruct cell c from ring rows c-H..c+H-1 and the register row c+H
       double qln[NV], qrn[NV];
@@ -310,6 +316,11 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
           riemann<FLUID, RS>(wl_prev, wr, sp.gamma, sp.c_h, f);
         }
         if (retire) {
+          if constexpr (APK_M12F_LOADS == 3) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int n = 0; n < NV; ++n) d3v[n] = active ? d3[n * u0.sn + done] : 0.0;
+          }
           if constexpr (APK_M12F_LOADS == 2) {
             asm volatile("" ::: "memory");
             // (Timing experiment: without these 18 loads a general stage takes 2.65 instead of 2.91 ms
