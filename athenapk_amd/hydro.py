@@ -314,9 +314,10 @@ class FewModesFT:
         _check(ctx.lib.apk_fmft_inverse(ctx.h, self.md.h, self.h, vh.ctypes.data_as(L.c_dp), _stream()), ctx.lib, ctx.h)
         torch.cuda.current_stream().synchronize()  # vh must outlive the copy
 
-    def Perturb(self, dt, accel_rms, box_volume, allreduce_sum=None):
+    def Perturb(self, dt, accel_rms, box_volume, allreduce_sum=None, fill=None):
         """turbulence::Perturb -- src/pgen/turbulence.cpp:384-470.  `allreduce_sum(np.ndarray)`
-        stands where the reference calls MPI_Allreduce."""
+        stands where the reference calls MPI_Allreduce.  fill = (fluid, eos, estimate_dt): the kick also does
+        FillDerived (prim in place) and the time-step estimate of its cells (apk_turb_apply_fill)."""
         ctx = self.md.ctx
         sums = np.zeros(4)
         _check(ctx.lib.apk_turb_mean_momentum(ctx.h, self.md.h, self.h, sums.ctypes.data_as(L.c_dp), _stream()),
@@ -329,7 +330,12 @@ class FewModesFT:
         if allreduce_sum is not None:
             allreduce_sum(ampl)
         norm = accel_rms / np.sqrt(ampl[0] / box_volume)
-        _check(ctx.lib.apk_turb_apply(ctx.h, self.md.h, self.h, float(norm), float(dt), _stream()), ctx.lib, ctx.h)
+        if fill is not None:
+            fluid, eos, estimate_dt = fill
+            _check(ctx.lib.apk_turb_apply_fill(ctx.h, self.md.h, self.h, float(norm), float(dt), L.FLUID[fluid], C.byref(eos),
+                                               int(estimate_dt), _stream()), ctx.lib, ctx.h)
+        else:
+            _check(ctx.lib.apk_turb_apply(ctx.h, self.md.h, self.h, float(norm), float(dt), _stream()), ctx.lib, ctx.h)
         return norm
 
     def acc_host(self):

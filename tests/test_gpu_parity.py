@@ -653,6 +653,54 @@ def test_fmft_inverse(request, oracle, strict):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("floors", [False, True], ids=["nofloor", "floors"])
+def test_turbulence_kick_with_fill_derived_and_dt(request, oracle, strict, floors):
+    """apk_turb_apply_fill = apk_turb_apply, then ConsToPrim of the interior, then the dt estimate: the same
+    bits in cons, acc, the interior primitives (ghost zones untouched) and the reduced time step."""
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    f, g, mb, phases = _turb_case(oracle)
+    nb = len(phases)
+    nx = (mb, mb, mb)
+    prim = H.random_prim("glmmhd", nx, 2, seed=23, kind="smooth", nblocks=nb)
+    cons = H.prim_to_cons("glmmhd", prim, GAMMA)
+    eos = hydro.L.make_eos(GAMMA, pfloor=0.9, dfloor=0.95) if floors else hydro.L.make_eos(GAMMA)
+
+    def run(fill):
+        md = hydro.MeshData(ctx, nx, 2, 9, dx=tuple(g.dx), nblocks=nb, cons=cons, prim=np.full_like(prim, -3.0), with_flux=False)
+        drv = hydro.FewModesFT(md, [[p.transpose(2, 1, 0) for p in blk] for blk in phases])
+        drv.Inverse(f.var_hat())
+        if fill:
+            drv.Perturb(0.01, 0.5, 1.0, fill=("glmmhd", eos, True))
+            dt = hydro.StageDt(ctx, 0.3)
+        else:
+            drv.Perturb(0.01, 0.5, 1.0)
+            hydro.ConservedToPrimitive(md, "glmmhd", eos)
+            dt = hydro.EstimateTimestep(md, "glmmhd", eos, 0.3)
+        ctx.poll_flags()
+        return md.cons_host(), md.prim_host(), drv.acc_host(), dt
+    a, b = run(True), run(False)
+    assert np.array_equal(H.interior(a[0], nx, 2), H.interior(b[0], nx, 2)) and np.array_equal(a[2], b[2])
+    # (product build: ConsToPrim inlined behind the kick contracts into FMAs differently from the separate kernel)
+    _cmp(H.interior(a[1], nx, 2), H.interior(b[1], nx, 2), strict, "prim")
+    assert a[3] == b[3] if strict else abs(a[3] - b[3]) <= 1e-12 * b[3]
+    ghost = np.ones(a[1].shape, bool)
+    ghost[..., 2:-2, 2:-2, 2:-2] = False
+    assert np.all(a[1][ghost] == -3.0) and np.array_equal(a[0][ghost], cons[ghost])   # ghost zones untouched
+    if floors:
+        assert not np.array_equal(H.interior(a[0], nx, 2)[:, 0], H.interior(run_unfloored(ctx, hydro, f, g, phases, nx, cons, prim), nx, 2)[:, 0])
+
+
+def run_unfloored(ctx, hydro, f, g, phases, nx, cons, prim):
+    md = hydro.MeshData(ctx, nx, 2, 9, dx=tuple(g.dx), nblocks=len(phases), cons=cons, prim=prim, with_flux=False)
+    drv = hydro.FewModesFT(md, [[p.transpose(2, 1, 0) for p in blk] for blk in phases])
+    drv.Inverse(f.var_hat())
+    drv.Perturb(0.01, 0.5, 1.0)
+    return md.cons_host()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
 def test_turbulence_perturb_and_history(request, oracle, strict):
     from athenapk_amd import hydro
     ctx = _ctx(request, strict)
