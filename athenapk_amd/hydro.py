@@ -191,6 +191,12 @@ def ConservedToPrimitive(md, fluid, eos):
     _check(ctx.lib.apk_cons_to_prim(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), _stream()), ctx.lib, ctx.h)
 
 
+def ConservedToPrimitiveFaces(md, fluid, eos):
+    """ConsToPrim of the interior and of the ghost cells straight behind a block face (at most one ghost coordinate)."""
+    ctx = md.ctx
+    _check(ctx.lib.apk_cons_to_prim_faces(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), _stream()), ctx.lib, ctx.h)
+
+
 def ConservedToPrimitiveGhosts(md, fluid, eos):
     """ConsToPrim on the ghost zones only (companion of StageFused(fill_derived=True))."""
     ctx = md.ctx

@@ -198,6 +198,32 @@ def test_cons_to_prim(request, oracle, fluid, floors):
     assert ctx.poll_flags() == 0
 
 
+@pytest.mark.parametrize("nx", [(12, 6, 5), (16, 8, 1)], ids=["3d", "2d"])
+def test_cons_to_prim_faces_converts_everything_but_edges_and_corners(request, nx):
+    """apk_cons_to_prim_faces: the full ConsToPrim's bits on every cell with at most one ghost coordinate, nothing
+    written (and no flag raised by the garbage there) behind edges and corners"""
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    ng = 2
+    w = H.random_prim("glmmhd", nx, ng, seed=12, kind="rough", nblocks=2)
+    u = H.prim_to_cons("glmmhd", w, 1.4)
+    eos = hydro.L.make_eos(1.4)
+    full = hydro.MeshData(ctx, nx, ng, 9, nblocks=2, cons=u, with_flux=False)
+    hydro.ConservedToPrimitive(full, "glmmhd", eos)
+    act = [True, nx[1] > 1, nx[2] > 1]
+    K, J, I = np.meshgrid(*[np.arange(n + 2 * ng if a else 1) for n, a in zip(nx[::-1], act[::-1])], indexing="ij")
+    nghost = sum(((c < ng) | (c >= ng + n)).astype(int) if a else 0 for c, n, a in ((I, nx[0], True), (J, nx[1], act[1]), (K, nx[2], act[2])))
+    corner = np.broadcast_to(nghost > 1, u.shape[2:])
+    u2 = u.copy()
+    u2[:, 0][:, corner] = -1.0                       # negative densities behind edges and corners
+    md = hydro.MeshData(ctx, nx, ng, 9, nblocks=2, cons=u2, prim=np.full_like(u, -3.0), with_flux=False)
+    ctx.poll_flags()
+    hydro.ConservedToPrimitiveFaces(md, "glmmhd", eos)
+    got, want = md.prim_host(), full.prim_host()
+    assert np.array_equal(got[:, :, ~corner], want[:, :, ~corner]) and np.all(got[:, :, corner] == -3.0)
+    assert ctx.poll_flags() == 0 and corner.any()
+
+
 @pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
 def test_cons_to_prim_latches_negative_state_flags(request, strict):
     """adiabatic_hydro.hpp:77-79,111-113: PARTHENON_REQUIRE -> latched device flag.  A NaN state
