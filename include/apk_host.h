@@ -158,7 +158,11 @@ void *apk_sim_block_ptr(const apk_sim *sim, int lb, int field);
 /* copy the interior of every local block of `field` into a global-shaped host array
  * [nvar][nx3][nx2][nx1] (only this rank's cells are written) */
 int apk_sim_gather(apk_sim *sim, int field, double *host_out);
-/* copy one full block (incl. ghosts) host<->device */
+/* copy one full block (incl. ghosts) host<->device.  Ghost zones are brought up to date first: the stage loop
+ * leaves same-rank ghost zones of uniform meshes (direct neighbour addressing) and the ghost zones behind edges
+ * and corners of refined meshes unfilled.  On a REFINED mesh distributed over several ranks that completion
+ * is a halo exchange, i.e. collective: the first accessor after a cycle must be called on every rank (as the
+ * outputs of apk_sim_execute are).  On uniform meshes it is local. */
 int apk_sim_read_block(apk_sim *sim, int lb, int field, double *host_out);
 int apk_sim_write_block(apk_sim *sim, int lb, int field, const double *host_in);
 /* history sums over the whole mesh (allreduce'd): mass,1-mom,2-mom,3-mom,KE,tot-E,ME,relDivB */
