@@ -656,8 +656,22 @@ APK_DEV double pick(bool left, double l, double r) { return left ? l : r; }
 // need (wave speeds, transverse star components: the double-star states mix them) is computed for
 // both.  Every value that reaches the result comes from the reference's expressions in the
 // reference's order: bit-identical in the parity build.
+// glmmhd_hlld with the fast speeds of the two states handed in (cfl, cfr = fast_speed of wl / wr along the
+// face normal): a donor-cell sweep solves two faces per cell with the SAME cell-centre state on one side, so
+// the caller evaluates that state's fast speed once (same function of the same values: bit-identical).
+APK_DEV void glmmhd_hlld_cf(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD], double gamma, double c_h,
+                            double cfl, double cfr, double (&f)[NGLMMHD]);
+
 APK_DEV void glmmhd_hlld(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD],
                          double gamma, double c_h, double (&f)[NGLMMHD]) {
+  // fast speeds from the RECONSTRUCTED normal field, not bxi (:122-125)
+  const double cfl = fast_speed(gamma, wl[IDN], wl[IPR], wl[IB1], wl[IB2], wl[IB3]);
+  const double cfr = fast_speed(gamma, wr[IDN], wr[IPR], wr[IB1], wr[IB2], wr[IB3]);
+  glmmhd_hlld_cf(wl, wr, gamma, c_h, cfl, cfr, f);
+}
+
+APK_DEV void glmmhd_hlld_cf(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD], double gamma, double c_h,
+                            double cfl, double cfr, double (&f)[NGLMMHD]) {
   const double gm1 = gamma - 1.0;
   const double igm1 = 1.0 / gm1;
   double bxi, psii;
@@ -671,9 +685,6 @@ APK_DEV void glmmhd_hlld(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD
   hlld_side_state(wl, igm1, bxsq, ul, pbl);
   hlld_side_state(wr, igm1, bxsq, ur, pbr);
 
-  // fast speeds from the RECONSTRUCTED normal field, not bxi (:122-125)
-  const double cfl = fast_speed(gamma, wl[IDN], wl[IPR], wl[IB1], wl[IB2], wl[IB3]);
-  const double cfr = fast_speed(gamma, wr[IDN], wr[IPR], wr[IB1], wr[IB2], wr[IB3]);
   const double s0 = min2(wl[IV1] - cfl, wr[IV1] - cfr);
   const double s4 = max2(wl[IV1] + cfl, wr[IV1] + cfr);
 
