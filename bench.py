@@ -354,7 +354,9 @@ def main():
                        "comm_backend": (("rccl, native transport of the C++ host (ncclSend/ncclRecv groups on a halo stream)"
                                          if sim.comm_kind == "rccl" else "torch.distributed callbacks over " + backend)
                                         if world > 1 else None),
-                       "overlapped_exchanges_per_cycle": (sim.overlapped_exchanges / max(1, sim.ncycle)) if world > 1 else None},
+                       "overlapped_exchanges_per_cycle": (sim.overlapped_exchanges / max(1, sim.ncycle)) if world > 1 else None,
+                       # stage boundaries per cycle whose same-rank ghost copies were skipped (direct neighbour addressing)
+                       "same_rank_ghost_copies_skipped_per_cycle": sim.skipped_local_exchanges() / max(1, sim.ncycle)},
             "cell_stage_updates_per_s": value * nstages,
             "roofline": {
                 "bound": "hbm",
