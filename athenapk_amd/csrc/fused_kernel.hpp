@@ -992,7 +992,10 @@ inline int march_rows_per_wave(int nx1, int ntrans) {
 inline int march_segments(int64_t waves, int n_along) {
   static const int forced = std::getenv("APK_MARCH_NSEG") ? std::atoi(std::getenv("APK_MARCH_NSEG")) : 0;  // A/B switch
   int nseg = forced > 0 ? forced : (int)((4096 + waves - 1) / waves);
-  const int max_seg = n_along / 16 > 0 ? n_along / 16 : 1;
+  // (segments no shorter than 8 rows: a pack of 232 16^3 blocks is 928 march waves on 2048 slots in one piece,
+  // 1856 in two -- 1.14 -> 1.09 ms per cycle of the refined MHD blast; 4-row segments lose it again)
+  static const int min_rows = std::getenv("APK_MARCH_MIN_ROWS") ? std::atoi(std::getenv("APK_MARCH_MIN_ROWS")) : 8;  // A/B switch
+  const int max_seg = n_along / min_rows > 0 ? n_along / min_rows : 1;
   if (nseg > max_seg) nseg = max_seg;
   return nseg < 1 ? 1 : nseg;
 }
