@@ -1774,6 +1774,23 @@ int apk_sim_estimate_timestep(apk_sim *s, double *dt) {
   return estimate_timestep(s, dt);
 }
 
+// after the caller replaced the state (apk_sim_write_block + apk_sim_exchange_ghosts + apk_sim_fill_derived): the time
+// step as apk_sim_initialize derives it from a problem generator's state -- no growth limit from an earlier step
+int apk_sim_reset_time_step(apk_sim *s) {
+  if (!s || s->host_only) return APK_ERR_INVALID;
+  s->err.clear();
+  SIM_TRY(s, sync_ghosts(s));
+  s->dt = kHuge;
+  s->pkg.mindx = kHuge;
+  s->pkg.dt_hyp = kHuge;
+  s->dt_hyp_is_global = false;
+  s->stage_dt_pending = false;
+  double est = kHuge;
+  SIM_TRY(s, estimate_timestep(s, &est));
+  set_global_dt(s, est);
+  return APK_OK;
+}
+
 int apk_sim_kernel_timing_enable(apk_sim *s, int on) {
   if (!s || s->host_only) return APK_ERR_INVALID;
   return apk_kernel_timing_enable(s->ctx, on);

@@ -519,6 +519,11 @@ class Simulation(_FmftHost, _MeshView):
         self._check(self.lib.apk_sim_estimate_timestep(self.h, C.byref(dt)))
         return dt.value
 
+    def reset_time_step(self):
+        """after write_block + exchange_ghosts + fill_derived: the time step as initialize() derives it"""
+        self._check(self.lib.apk_sim_reset_time_step(self.h))
+        return self.dt
+
 
 class HostPlan(_FmftHost, _MeshView):
     """Host-only view of a rank's mesh partition and ghost-exchange plan (no GPU needed)."""

@@ -243,6 +243,7 @@ def _signatures():
         "apk_sim_exchange_ghosts": (i, [vp]),
         "apk_sim_fill_derived": (i, [vp]),
         "apk_sim_estimate_timestep": (i, [vp, c_dp]),
+        "apk_sim_reset_time_step": (C.c_int, [vp]),
         "apk_sim_kernel_timing_enable": (i, [vp, i]),
         "apk_sim_kernel_timing_read": (i, [vp, i, c_dp, C.POINTER(ll)]),
         "apk_sim_peer": (i, [vp, i, C.POINTER(PeerInfo)]),

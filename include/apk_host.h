@@ -224,6 +224,9 @@ int apk_sim_linear_wave_errors(apk_sim *sim, double *rms, double *l1_5, double *
 int apk_sim_exchange_ghosts(apk_sim *sim);
 int apk_sim_fill_derived(apk_sim *sim);
 int apk_sim_estimate_timestep(apk_sim *sim, double *dt);
+/* after replacing the state through apk_sim_write_block (+ exchange_ghosts + fill_derived): derive the time step
+ * as apk_sim_initialize does after the problem generator (no growth limit from earlier steps) */
+int apk_sim_reset_time_step(apk_sim *sim);
 
 /* kernel timing of the sim's hot-path handle (apk_kernel_timing_* of apk_amd.h) */
 int apk_sim_kernel_timing_enable(apk_sim *sim, int on);

@@ -1,6 +1,8 @@
 """Mesh refinement, host logic (no GPU): the block forest built from the deck, the 2:1 balance,
 and the index-box plans of the multilevel ghost exchange executed on the host with the oracle's
 operators (tests/amr_emulator.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -381,3 +383,24 @@ def test_forest_oracle_on_a_one_level_forest_is_the_uniform_mini_driver(oracle, 
         assert fo.c_h == o.c_h
         for b in range(nb):
             assert np.array_equal(fo.cons[b], o.cons(b)) and np.array_equal(fo.prim[b], o.prim(b), equal_nan=True)
+
+
+# ---- frozen refined-mesh fixture (tests/golden/amr_fixture.npz, made by tests/golden/make_amr_fixture.py) -----------
+def _amr_fixture():
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_amr_fixture", os.path.join(here, "golden", "make_amr_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, np.load(os.path.join(here, "golden", "amr_fixture.npz"))
+
+
+@pytest.mark.parametrize("case", ["mhd_ppm_hlld_vl2", "hydro_plm_hllc_rk3"])
+def test_forest_oracle_reproduces_the_frozen_refined_mesh_fixture(oracle, case):
+    """the driver's tree still builds the stored forest, and the live refined-mesh oracle still produces the stored
+    state and time steps from the closed-form initial state -- bit for bit"""
+    mod, gold = _amr_fixture()
+    leaves = mod.forest()
+    assert [l for l, _ in leaves] == list(gold["levels"]) and [list(lx) for _, lx in leaves] == gold["lx"].tolist()
+    final, dts, t = mod.run(case, leaves)
+    assert np.array_equal(final, gold[case + "_final"]) and np.array_equal(dts, gold[case + "_dt"]) and t == float(gold[case + "_time"])

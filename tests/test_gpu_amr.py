@@ -501,6 +501,40 @@ def test_regridding_with_random_tags_moves_the_state_exactly(dims):
     assert s.amr_stats()[0] > 0 and s.amr_stats()[1] > 0
 
 
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("case", ["mhd_ppm_hlld_vl2", "hydro_plm_hllc_rk3"])
+def test_device_reproduces_the_frozen_refined_mesh_fixture(case, strict):
+    """tests/golden/amr_fixture.npz (forest, closed-form initial state, state and time steps after three cycles as the
+    refined-mesh oracle computed them when the fixture was made): the device's flux-array task order reproduces the
+    STORED numbers -- bit for bit in the parity build, to 1e-12 in the product build -- without the live oracle."""
+    from test_amr_mesh import _amr_fixture
+    mod, gold = _amr_fixture()
+    fluid, recon, riemann, integ, ng = mod.CASES[case]
+    s = _sim("blast", mod.overrides(case), strict=strict)
+    s.set_fused(False)
+    s.initialize()
+    pl = placement(s)
+    assert [p[0] for p in pl] == list(gold["levels"]) and [list(p[1]) for p in pl] == gold["lx"].tolist()
+    u0 = mod.initial_state(fluid, [(p[0], tuple(p[1])) for p in pl], (8, 8, 8), ng)
+    for lb, u in enumerate(u0):
+        s.write_block(lb, u)
+    s.exchange_ghosts()
+    s.fill_derived()
+    s.reset_time_step()
+    dts = []
+    for _ in range(mod.NCYCLES):
+        dts.append(s.dt)
+        s.step()
+    got = np.stack([s.read_block(lb)[:, ng:-ng, ng:-ng, ng:-ng] for lb in range(len(pl))])
+    want = gold[case + "_final"]
+    if strict:
+        assert np.array_equal(dts, gold[case + "_dt"]) and s.time == float(gold[case + "_time"])
+        assert np.array_equal(got, want)
+    else:
+        assert np.allclose(dts, gold[case + "_dt"], rtol=1e-12, atol=0)
+        assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+
+
 def test_regridding_moves_the_state_as_the_forest_oracle_does(oracle):
     """seven regridding passes with random refine / derefine requests on a periodic 3-D mesh holding a random positive
     state: whatever forest the driver's tree update arrives at, the state it hands over (copies, prolongated new fine
