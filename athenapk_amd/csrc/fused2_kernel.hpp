@@ -367,6 +367,18 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
   }
 }
 
+// Round 3, measured and NOT kept (same box, general stage of 8 x 128^3, 3.39 ms with this kernel):
+//  * the finish of a row software-pipelined over the loop's back edge (operands requested at the end of iteration c,
+//    consumed in iteration c+1 between the x1 reconstruction and the x1 solve, behind ~600 low-pressure instructions):
+//    72 more VGPRs live across the back edge than 256 hold next to an HLLD solve -- 580 B of scratch per lane, 8.4 ms;
+//  * scalar-base addressing of d3 / u1 / u0 / prim' (one SGPR base per array advanced by the scalar unit + ONE 32-bit
+//    per-lane byte offset: global_load_dwordx2 v, v_off, s[base:base+1] instead of a 64-bit VALU add per access): the
+//    compiler emits exactly that, but the extra SGPR pairs push the scalar spills from 87 to 124 and the vector spills
+//    from 6 to 36 registers -- 3.50 ms;
+//  * the x1 stencil from the ring row at lane offsets -2 .. +2 (5 ds_read_b64 instead of 1 + 8 DPP moves per variable,
+//    -72 VALU instructions per iteration): 3.40 ms, no change -- the kernel is not short of VALU issue slots alone;
+//  * PPM's extremum branches switched off altogether (wrong results; the ceiling of any scheme that makes them
+//    cheaper, e.g. compacting the few lanes that take them): 2.97 ms, -12 %.
 // number of waves the device holds at once with two march waves per SIMD
 inline int resident_march_waves() {
   static const int n = [] {

@@ -337,10 +337,11 @@ inline void BuildAmrPlans(const AmrTree &t, const AmrGeom &g, AmrPlans &p) {
       const int kind = t.Classify(l.level, pos, &nbr);
       if (kind == NB_PHYSICAL) return;
       int slo[3], dlo[3], ext[3];
-      // The unsplit sweeps, the flux correction and the tagging criteria read ghost cells straight behind a
-      // FACE only: whatever fills the block's ghost zone behind an edge or a corner is marked, and the stage
-      // loop runs the plans without those boxes (coarse-buffer fills are always complete: the prolongation
-      // stencil reaches sideways).
+      // The unsplit sweeps and the flux correction read ghost cells straight behind a FACE only: whatever
+      // fills the block's ghost zone behind an edge or a corner is marked, and the stage loop runs the plans
+      // without those boxes (coarse-buffer fills are always complete: the prolongation stencil reaches
+      // sideways).  The tagging criteria DO read behind edges and corners (gradient.cpp:33-36): a cycle that
+      // ends with a refinement check exchanges in full after its last stage (regrid_check_follows).
       const int behind_corner = ((o[0] != 0) + (o[1] != 0) + (o[2] != 0)) != 1;
       if (kind == NB_SAME) {
         // fine ghost zone <- neighbour interior

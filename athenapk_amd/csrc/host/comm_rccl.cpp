@@ -19,9 +19,19 @@
 // every rank by whatever means it has (the Python driver: torch.distributed.broadcast_object_list;
 // an MPI launcher: MPI_Bcast), every rank calls apk_sim_comm_rccl before apk_sim_initialize.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <cstring>
+
+// The handful of RCCL types and constants this file passes through function pointers, declared here so
+// that the build does not need RCCL's headers either (values: rccl.h of ROCm 7.2 = NCCL's public ABI;
+// ncclUniqueId is 128 opaque bytes, checked against APK_RCCL_ID_BYTES below).
+extern "C" {
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
+typedef enum { ncclDouble = 8 } ncclDataType_t;
+}
 
 #include "sim_internal.hpp"
 
@@ -53,7 +63,8 @@ RcclApi *rccl_api(std::string *why) {
       if (api.lib) break;
     }
     if (!api.lib) {
-      err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
+      const char *e = dlerror();  // (a second call returns NULL: the first one clears the error)
+      err = std::string("librccl not found: ") + (e ? e : "");
     } else {
       auto sym = [&](const char *n) {
         void *p = dlsym(api.lib, n);

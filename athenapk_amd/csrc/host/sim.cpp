@@ -292,7 +292,13 @@ void set_global_dt(apk_sim *s, double dt_est) {
 }
 
 // Hydro::EstimateTimestep<fluid> over this rank's pack + global min (hydro.cpp:913-977)
-int estimate_timestep(apk_sim *s, double *dt_out) {
+// The time-step estimate in two halves (round-2 advisor finding: a regridding pass between "measure" and
+// "use" must not inherit side effects of an estimate made on the old mesh).
+//   _read    device work + ONE host round trip: the local minimum and the device flag word.  Consumes the
+//            finishing sweep's pending reduction; touches nothing of the package.
+//   _commit  the reference's reaction to the flags (PARTHENON_REQUIRE in ConsToPrim), the reduction over
+//            ranks, and the hyperbolic estimate the next cycle's c_h needs (hydro.cpp:102-143, 903-908).
+int estimate_timestep_read(apk_sim *s, DtEstimate *e) {
   double dt = kHuge;
   unsigned flags = 0;
   bool have_flags = false;
@@ -305,16 +311,22 @@ int estimate_timestep(apk_sim *s, double *dt_out) {
       SIM_TRY(s, apk_estimate_timestep(s->ctx, s->mu0(), s->pkg.fluid, &s->pkg.eos, s->pkg.cfl, &dt, s->stream));
     }
   }
-  const double dt_hyp_local = dt;
-  if (s->pkg.max_dt > 0.0 && s->pkg.max_dt < dt) dt = s->pkg.max_dt;
   if (!have_flags) SIM_TRY(s, apk_poll_device_flags(s->ctx, &flags, s->stream));
-  if (flags & APK_FLAG_NEG_DENSITY)
+  e->dt_hyp_local = dt;
+  e->flags |= flags;  // (flags latched before an earlier read of the same cycle stay raised)
+  return APK_OK;
+}
+
+int estimate_timestep_commit(apk_sim *s, const DtEstimate &e, double *dt_out) {
+  if (e.flags & APK_FLAG_NEG_DENSITY)
     return fail(s, APK_ERR_INVALID, "Got negative density. Consider enabling first-order flux correction or setting a reasonble density floor.");
-  if (flags & APK_FLAG_NEG_PRESSURE)
+  if (e.flags & APK_FLAG_NEG_PRESSURE)
     return fail(s, APK_ERR_INVALID, "Got negative pressure. Consider enabling first-order flux correction or setting a reasonble pressure or temperature floor.");
+  double dt = e.dt_hyp_local;
+  if (s->pkg.max_dt > 0.0 && s->pkg.max_dt < dt) dt = s->pkg.max_dt;
   // one reduction for both minima: the time step, and the hyperbolic estimate that the next cycle's
   // c_h needs (hydro.cpp:102-143 reduces it in PreStepMeshUserWorkInLoop; same value, one message less)
-  double mins[2] = {dt, dt_hyp_local};
+  double mins[2] = {dt, e.dt_hyp_local};
   if (s->have_comm && s->nranks > 1) {
     if (s->comm.allreduce_min(s->comm.user, mins, 2) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_min failed");
   }
@@ -322,6 +334,12 @@ int estimate_timestep(apk_sim *s, double *dt_out) {
   s->dt_hyp_is_global = true;
   *dt_out = mins[0];
   return APK_OK;
+}
+
+int estimate_timestep(apk_sim *s, double *dt_out) {
+  DtEstimate e;
+  SIM_TRY(s, estimate_timestep_read(s, &e));
+  return estimate_timestep_commit(s, e, dt_out);
 }
 
 // Ghost exchange in two halves.  begin: same-rank copies, message packing, post the transfers;
@@ -433,9 +451,15 @@ bool direct_neighbors(const apk_sim *s) {
 }
 
 // may the stage loop of a refined mesh skip the ghost zones behind edges and corners?  (A/B: APK_AMR_FULL_EXCHANGE=1)
+// does the cycle in progress end with a check of the refinement criteria?  Those read the full ring of ghost
+// cells round a block -- edges and corners too (refinement/gradient.cpp:33-36 loops k, j, i over [s-1, e+1]
+// and differences each of them) -- so the exchange after the last stage of such a cycle is a complete one.
+bool regrid_check_follows(const apk_sim *s) {
+  return s->amr && s->amr_adaptive && s->amr_check_interval > 0 && (s->ncycle + 1) % s->amr_check_interval == 0;
+}
+
 bool amr_faces_only(const apk_sim *s) {
-  static const bool full = std::getenv("APK_AMR_FULL_EXCHANGE") != nullptr;
-  return s->amr && !full && s->mesh.ndim >= 2;
+  return s->amr && !s->amr_full_exchange && s->mesh.ndim >= 2;
 }
 
 // fill the ghost zones that direct neighbour addressing left stale (cons and prim of the current state)
@@ -910,7 +934,7 @@ int do_stage(apk_sim *s, int stage) {
     // post the messages and leave them in flight: the next stage (of this or of the next cycle)
     // completes the exchange
     SIM_TRY(s, exchange_begin(s, true, c2p_in_copy, direct));
-  } else if (s->amr && amr_faces_only(s)) {
+  } else if (s->amr && amr_faces_only(s) && !(stage == s->nstages && regrid_check_follows(s))) {
     // refined meshes: nothing in the stage loop reads a ghost cell behind an edge or a corner of a block -- the
     // exchange skips those boxes (37 % of the ghost cells of a 16^3 block with nghost = 4) and ConsToPrim the cells
     SIM_TRY(s, amr_exchange(s, s->cur, true));
@@ -948,6 +972,7 @@ int create_common(const char *deck, const char *const *overrides, int noverrides
     hydro_initialize(s);
     mesh_initialize(s);
     if (s->problem_id == "linear_wave") lw_setup(s);
+    else if (s->problem_id == "linear_wave_mhd") lwm_setup(s);
     else if (s->problem_id == "cpaw") cpaw_setup(s);
     else if (s->problem_id == "field_loop") field_loop_setup(s);
     else if (s->problem_id == "kh") kh_setup(s);
@@ -965,7 +990,8 @@ int create_common(const char *deck, const char *const *overrides, int noverrides
     else if (s->problem_id == "turbulence") turbulence_setup(s);
     else if (s->problem_id != "sod" && s->problem_id != "orszag_tang" && s->problem_id != "synthetic" &&
              s->problem_id != "blast" && s->problem_id != "lw_implode" && s->problem_id != "cpaw" &&
-             s->problem_id != "advection" && s->problem_id != "field_loop" && s->problem_id != "kh")
+             s->problem_id != "advection" && s->problem_id != "field_loop" && s->problem_id != "kh" &&
+             s->problem_id != "linear_wave" && s->problem_id != "linear_wave_mhd")
       throw std::runtime_error("unknown job/problem_id: " + s->problem_id);
     // src/bvals/boundary_conditions_apk.hpp:47-50 (raised when the wall is first applied, i.e. after
     // the problem generator's own checks): the wall only mirrors the normal momentum
@@ -1153,6 +1179,12 @@ int apk_sim_set_direct_neighbors(apk_sim *s, int on) {
   s->direct_on = on != 0;
   return APK_OK;
 }
+int apk_sim_set_amr_full_exchange(apk_sim *s, int on) {
+  if (!s) return APK_ERR_INVALID;
+  if (!s->host_only) SIM_TRY(s, sync_ghosts(s));
+  s->amr_full_exchange = on != 0;
+  return APK_OK;
+}
 double apk_sim_loop_seconds(const apk_sim *s) { return s ? s->loop_seconds : 0.0; }
 int apk_sim_loop_cycles(const apk_sim *s) { return s ? s->perf_cycles : 0; }
 long long apk_sim_loop_zone_cycles(const apk_sim *s) { return s ? s->zone_cycles - s->perf_zone_mark : 0; }
@@ -1236,17 +1268,15 @@ int apk_sim_step(apk_sim *s) {
     // estimate is only kept if the mesh stays as it is (every cycle but a few), else it is redone on the new one.
     AmrTagRequest req;
     SIM_TRY(s, amr_tags_begin(s, &req));
-    const double dt_hyp_before = s->pkg.dt_hyp;
-    const bool global_before = s->dt_hyp_is_global;
-    SIM_TRY(s, estimate_timestep(s, &est));
+    DtEstimate e;
+    SIM_TRY(s, estimate_timestep_read(s, &e));
     bool changed = false;
     SIM_TRY(s, amr_regrid(s, &changed, &req));
-    if (changed) {
-      s->pkg.dt_hyp = dt_hyp_before;
-      s->dt_hyp_is_global = global_before;
-      est = kHuge;
-      SIM_TRY(s, estimate_timestep(s, &est));
+    if (changed) {  // measure again on the new mesh; flags raised during the cycle stay raised
+      e.dt_hyp_local = kHuge;
+      SIM_TRY(s, estimate_timestep_read(s, &e));
     }
+    SIM_TRY(s, estimate_timestep_commit(s, e, &est));
   } else {
     SIM_TRY(s, estimate_timestep(s, &est));
   }
@@ -1553,32 +1583,38 @@ int apk_sim_write_history(apk_sim *s, const char *path) {
 
 int apk_sim_write_linear_wave_errors(apk_sim *s, const char *path) {
   if (!s || !path) return APK_ERR_INVALID;
-  double rms = 0.0, l1[5], mx[5];
-  int rc = apk_sim_linear_wave_errors(s, &rms, l1, mx);
+  const bool mhd_wave = s->problem_id == "linear_wave_mhd";
+  const int ncol = mhd_wave ? 8 : 5;
+  double rms = 0.0, l1[8], mx[8];
+  int rc = mhd_wave ? apk_sim_linear_wave_mhd_errors(s, &rms, l1, mx) : apk_sim_linear_wave_errors(s, &rms, l1, mx);
   if (rc != APK_OK) return rc;
   if (s->rank != 0) return APK_OK;
   double max_max_over_l1 = 0.0;
-  for (int n = 0; n < 5; ++n) max_max_over_l1 = std::fmax(max_max_over_l1, mx[n] / l1[n]);
+  for (int n = 0; n < ncol; ++n) max_max_over_l1 = std::fmax(max_max_over_l1, mx[n] / l1[n]);
   FILE *f = std::fopen(path, "r");
   const bool fresh = (f == nullptr);
   if (f) std::fclose(f);
   f = std::fopen(path, "a");
   if (!f) return fail(s, APK_ERR_INVALID, "Error output file could not be opened");
-  if (fresh) {
+  if (fresh) {  // linear_wave.cpp:315-320 / linear_wave_mhd.cpp:318-326
     std::fprintf(f, "# Nx1  Nx2  Nx3  Ncycle  ");
     std::fprintf(f, "RMS-L1-Error  d_L1  M1_L1  M2_L1  M3_L1  E_L1 ");
+    if (mhd_wave) std::fprintf(f, "  B1c_L1  B2c_L1  B3c_L1");
     std::fprintf(f, "  Largest-Max/L1  d_max  M1_max  M2_max  M3_max  E_max ");
+    if (mhd_wave) std::fprintf(f, "  B1c_max  B2c_max  B3c_max");
     std::fprintf(f, "\n");
   }
-  // column 3 repeats Nx2: that is what linear_wave.cpp:323-324 prints
+  // the hydro file's column 3 repeats Nx2 (that is what linear_wave.cpp:323-324 prints); the MHD file's holds Nx3
   std::fprintf(f, "%d  %d", s->mesh.nx[0], s->mesh.nx[1]);
-  std::fprintf(f, "  %d  %d", s->mesh.nx[1], s->ncycle);
+  std::fprintf(f, "  %d  %d", mhd_wave ? s->mesh.nx[2] : s->mesh.nx[1], s->ncycle);
   std::fprintf(f, "  %e  %e", rms, l1[0]);
   std::fprintf(f, "  %e  %e  %e", l1[1], l1[2], l1[3]);
   std::fprintf(f, "  %e", l1[4]);
+  for (int n = 5; n < ncol; ++n) std::fprintf(f, "  %e", l1[n]);
   std::fprintf(f, "  %e  %e  ", max_max_over_l1, mx[0]);
   std::fprintf(f, "%e  %e  %e", mx[1], mx[2], mx[3]);
   std::fprintf(f, "  %e", mx[4]);
+  for (int n = 5; n < ncol; ++n) std::fprintf(f, "  %e", mx[n]);
   std::fprintf(f, "\n");
   std::fclose(f);
   return APK_OK;
@@ -1639,7 +1675,7 @@ int apk_sim_execute(apk_sim *s, const char *outdir, int *ncycles) {
   SIM_TRY(s, sync_ghosts(s));
   SIM_HIP(s, hipStreamSynchronize(hs(s)));
   s->loop_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  if (s->problem_id == "linear_wave" && s->lw.compute_error)
+  if ((s->problem_id == "linear_wave" || s->problem_id == "linear_wave_mhd") && s->lw.compute_error)
     SIM_TRY(s, apk_sim_write_linear_wave_errors(s, (std::string(outdir) + "/linearwave-errors.dat").c_str()));
   if (s->problem_id == "cpaw" && s->cpaw.compute_error)
     SIM_TRY(s, apk_sim_write_cpaw_errors(s, (std::string(outdir) + "/cpaw-errors.dat").c_str()));
@@ -1647,12 +1683,14 @@ int apk_sim_execute(apk_sim *s, const char *outdir, int *ncycles) {
   return APK_OK;
 }
 
-// src/pgen/linear_wave.cpp:183-335
-int apk_sim_linear_wave_errors(apk_sim *s, double *rms, double *l1, double *mx) {
-  if (!s || s->host_only || s->problem_id != "linear_wave" || !rms || !l1 || !mx) return APK_ERR_INVALID;
+// src/pgen/linear_wave.cpp:183-335 (5 columns: d, M1, M2, M3, E) and src/pgen/linear_wave_mhd.cpp:177-276 (8 columns:
+// + B1, B2, B3 against the ANALYTIC field; psi is not part of the norm): volume-weighted L1 and max errors of the
+// interior cells against the wave at the initial phase, L1 normalised by the domain volume, RMS over the columns
+static int linear_wave_errors_n(apk_sim *s, int ncol, double *rms, double *l1, double *mx) {
   const Mesh &m = s->mesh;
+  const bool mhd_wave = ncol == 8;
   std::vector<double> host((size_t)s->nper);
-  double acc[10] = {0};
+  double acc[16] = {0};
   for (int lb = 0; lb < (int)m.local_gids.size(); ++lb) {
     int rc = apk_sim_read_block(s, lb, 0, host.data());
     if (rc != APK_OK) return rc;
@@ -1663,32 +1701,43 @@ int apk_sim_linear_wave_errors(apk_sim *s, double *rms, double *l1, double *mx) 
     for (int k = m.ks; k <= m.ke; ++k)
       for (int j = m.js; j <= m.je; ++j)
         for (int i = m.is; i <= m.ie; ++i) {
-          double u[5];
-          lw_state(s->lw, xc(s, x0, 0, i), xc(s, x0, 1, j), xc(s, x0, 2, k), u);
-          for (int n = 0; n < 5; ++n) {
+          double u[8];
+          if (mhd_wave) lwm_state(s, xc(s, x0, 0, i), xc(s, x0, 1, j), xc(s, x0, 2, k), u);
+          else lw_state(s->lw, xc(s, x0, 0, i), xc(s, x0, 1, j), xc(s, x0, 2, k), u);
+          for (int n = 0; n < ncol; ++n) {
             const double e = std::abs(u[n] - host[n * m.sn + k * m.sk + j * m.sj + i]);
             acc[n] += e * cellvol;
-            if (e > acc[5 + n]) acc[5 + n] = e;
+            if (e > acc[8 + n]) acc[8 + n] = e;
           }
         }
   }
   if (s->have_comm && s->nranks > 1) {
-    if (s->comm.allreduce_sum(s->comm.user, acc, 5) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_sum failed");
+    if (s->comm.allreduce_sum(s->comm.user, acc, ncol) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_sum failed");
     // MAX of non-negative values through the MIN callback
-    double neg[5];
-    for (int n = 0; n < 5; ++n) neg[n] = -acc[5 + n];
-    if (s->comm.allreduce_min(s->comm.user, neg, 5) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_min failed");
-    for (int n = 0; n < 5; ++n) acc[5 + n] = -neg[n];
+    double neg[8];
+    for (int n = 0; n < ncol; ++n) neg[n] = -acc[8 + n];
+    if (s->comm.allreduce_min(s->comm.user, neg, ncol) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_min failed");
+    for (int n = 0; n < ncol; ++n) acc[8 + n] = -neg[n];
   }
   const double vol = (s->xmax[0] - s->xmin[0]) * (s->xmax[1] - s->xmin[1]) * (s->xmax[2] - s->xmin[2]);
   double r = 0.0;
-  for (int n = 0; n < 5; ++n) {
+  for (int n = 0; n < ncol; ++n) {
     l1[n] = acc[n] / vol;
-    mx[n] = acc[5 + n];
+    mx[n] = acc[8 + n];
     r += l1[n] * l1[n];
   }
   *rms = std::sqrt(r);
   return APK_OK;
+}
+
+int apk_sim_linear_wave_errors(apk_sim *s, double *rms, double *l1, double *mx) {
+  if (!s || s->host_only || s->problem_id != "linear_wave" || !rms || !l1 || !mx) return APK_ERR_INVALID;
+  return linear_wave_errors_n(s, 5, rms, l1, mx);
+}
+
+int apk_sim_linear_wave_mhd_errors(apk_sim *s, double *rms, double *l1, double *mx) {
+  if (!s || s->host_only || s->problem_id != "linear_wave_mhd" || !rms || !l1 || !mx) return APK_ERR_INVALID;
+  return linear_wave_errors_n(s, 8, rms, l1, mx);
 }
 
 // cpaw::UserWorkAfterLoop (src/pgen/cpaw.cpp:127-221): L1 errors against the initial state, err8 in

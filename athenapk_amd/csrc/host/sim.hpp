@@ -48,6 +48,10 @@ struct LinearWaveState {  // globals of src/pgen/linear_wave.cpp
   bool compute_error = false;
 };
 
+struct LinearWaveMhdState {  // what src/pgen/linear_wave_mhd.cpp keeps besides the hydro wave's geometry (LinearWaveState)
+  double bx0 = 1.0, by0 = 0.0, bz0 = 0.0, dby = 0.0, dbz = 0.0, ev[7] = {0}, rem[7][7] = {{0}};
+};
+
 struct CpawState {  // globals of src/pgen/cpaw.cpp
   double den = 1.0, pres = 0, gm1 = 0, b_par = 0, b_perp = 0, v_perp = 0, v_par = 0, fac = 1.0;
   double sin_a2 = 0, cos_a2 = 1, sin_a3 = 0, cos_a3 = 1, lambda = 1, k_par = 0;
@@ -75,6 +79,7 @@ struct apk_sim {
   apk::HydroPackage pkg;
   std::string problem_id;
   apk::LinearWaveState lw;
+  apk::LinearWaveMhdState lwm;
   apk::CpawState cpaw;
   apk::FieldLoopState floop;
   bool host_only = false;
@@ -203,6 +208,7 @@ struct apk_sim {
   // refined meshes: the stage loop fills (and converts to primitives) only the ghost zones behind block FACES;
   // accessors and regridding complete them first (sync_ghosts)
   bool amr_ghosts_partial = false;
+  bool amr_full_exchange = std::getenv("APK_AMR_FULL_EXCHANGE") != nullptr;  // apk_sim_set_amr_full_exchange
   const MsgSet *active_msgs = nullptr;  // the message set apk_sim_peer reports (null: the uniform mesh's)
   long long msg_generation = 0;         // bumped whenever that set, its sizes or its buffers change
   struct AmrDevice {

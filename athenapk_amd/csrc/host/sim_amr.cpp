@@ -500,8 +500,8 @@ void amr_destroy_graphs(apk_sim *s) {
 }
 
 // faces = true: the stage loop's exchange -- everything but the ghost zones behind edges and corners,
-// which no sweep, flux correction or tagging criterion reads (sync_ghosts completes them for accessors
-// and before regridding)
+// which no sweep or flux correction reads (sync_ghosts completes them for accessors, tagging and regridding;
+// the last stage of a cycle that checks the refinement criteria exchanges in full)
 int amr_exchange(apk_sim *s, int buf, bool faces) {
   auto &a = s->amr_dev;
   void *pre = faces ? a.xchg_pre_faces[buf] : a.xchg_pre[buf], *post = faces ? a.xchg_post_faces[buf] : a.xchg_post[buf];
@@ -766,6 +766,11 @@ int amr_transfer(apk_sim *s, const std::vector<AmrLeaf> &old, const AmrPartition
 // In two halves: _begin launches the reduction and its read-back, _end waits and converts -- whatever the
 // caller reads back in between (the time-step estimate at the end of a cycle) shares the host round trip.
 int amr_tags_begin(apk_sim *s, AmrTagRequest *req) {
+  // the criteria difference every cell of the ring [s-1, e+1]^3 (refinement/gradient.cpp:33-36): ghost cells
+  // behind edges and corners included, which the stage loop's faces-only exchange leaves stale.  The last
+  // stage of a checking cycle exchanges in full (do_stage), so this is a no-op there; it is what covers
+  // apk_sim_regrid / apk_sim_check_refinement between cycles.
+  SIM_TRY(s, sync_ghosts(s));
   SIM_TRY(s, refinement_criterion(s, &req->criterion, &req->p0, &req->p1));
   SIM_TRY(s, apk_tag_blocks_begin(s->ctx, s->mu0(), req->criterion, &req->pending, s->stream));
   return APK_OK;

@@ -56,7 +56,13 @@ bool stage_can_fuse(const apk_sim *s);
 double *region_base(apk_sim *s, int parity, int kind, int block);
 int build_copy_plans(apk_sim *s);
 void set_global_dt(apk_sim *s, double dt_est);
-int estimate_timestep(apk_sim *s, double *dt_out);
+struct DtEstimate {  // what one rank measured: see estimate_timestep_read / _commit
+  double dt_hyp_local = kHuge;
+  unsigned flags = 0;
+};
+int estimate_timestep_read(apk_sim *s, DtEstimate *e);
+int estimate_timestep_commit(apk_sim *s, const DtEstimate &e, double *dt_out);
+int estimate_timestep(apk_sim *s, double *dt_out);  // read + commit
 bool ghost_c2p_fusable(const apk_sim *s);
 int run_ghost_plan(apk_sim *s, int buf, int phase, bool c2p, apk_stream_t stream = nullptr);
 int exchange_begin(apk_sim *s, bool async, bool c2p, bool skip_local = false);
@@ -68,6 +74,7 @@ bool can_overlap_next(const apk_sim *s, int next);
 int finish_pending(apk_sim *s);
 bool direct_neighbors(const apk_sim *s);
 bool amr_faces_only(const apk_sim *s);
+bool regrid_check_follows(const apk_sim *s);
 int materialize_local_ghosts(apk_sim *s);
 int sync_ghosts(apk_sim *s);  // finish_pending + materialize_local_ghosts
 int fill_derived(apk_sim *s);
@@ -80,6 +87,8 @@ void block_origin(const apk_sim *s, int lb, double x0[3]);
 void lw_eigensystem(double gm1, double v1, double v2, double v3, double h, double ev[5], double rem[5][5]);
 void lw_setup(apk_sim *s);
 void lw_state(const LinearWaveState &lw, double x1, double x2, double x3, double u[5]);
+void lwm_setup(apk_sim *s);
+void lwm_state(const apk_sim *s, double x1, double x2, double x3, double u[8]);  // analytic d, M, E, B (no psi)
 void cpaw_setup(apk_sim *s);
 void cpaw_potential(const CpawState &c, double x1, double x2, double x3, double A[3]);
 void cpaw_state(const CpawState &c, double X1, double X2, double X3, double m[3], double b[3]);

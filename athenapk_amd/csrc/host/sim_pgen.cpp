@@ -46,7 +46,9 @@ void lw_setup(apk_sim *s) {
   ParameterInput &pin = s->pin;
   LinearWaveState &lw = s->lw;
   lw.wave_flag = pin.GetInteger("problem/linear_wave", "wave_flag");
-  if (lw.wave_flag < 0 || lw.wave_flag > 4) throw std::runtime_error("problem/linear_wave/wave_flag must be 0..4");
+  const int nwave = (s->problem_id == "linear_wave_mhd") ? 7 : 5;
+  if (lw.wave_flag < 0 || lw.wave_flag >= nwave)
+    throw std::runtime_error("problem/linear_wave/wave_flag must be 0.." + std::to_string(nwave - 1));
   lw.amp = pin.GetReal("problem/linear_wave", "amp");
   lw.vflow = pin.GetOrAddReal("problem/linear_wave", "vflow", 0.0);
   double ang_2 = pin.GetOrAddReal("problem/linear_wave", "ang_2", -999.9);
@@ -90,7 +92,7 @@ void lw_setup(apk_sim *s) {
   const double v0 = 0.0, w0 = 0.0;
   const double h0 = ((lw.p0 / lw.gm1 + 0.5 * lw.d0 * (lw.u0 * lw.u0 + v0 * v0 + w0 * w0)) + lw.p0) / lw.d0;
   lw_eigensystem(lw.gm1, lw.u0, v0, w0, h0, lw.ev, lw.rem);
-  if (pin.GetOrAddBoolean("problem/linear_wave", "test", false)) {
+  if (s->problem_id == "linear_wave" && pin.GetOrAddBoolean("problem/linear_wave", "test", false)) {
     // reinterpret tlim as the number of wave periods (linear_wave.cpp:169-175)
     s->tlim = lw.lambda / std::abs(lw.ev[lw.wave_flag]) * s->tlim;
   }
@@ -109,6 +111,144 @@ void lw_state(const LinearWaveState &lw, double x1, double x2, double x3, double
   u[2] = mx * lw.cos_a2 * lw.sin_a3 + my * lw.cos_a3 - mz * lw.sin_a2 * lw.sin_a3;
   u[3] = mx * lw.sin_a2 + mz * lw.cos_a2;
   u[4] = lw.p0 / lw.gm1 + 0.5 * lw.d0 * lw.u0 * lw.u0 + lw.amp * sn * lw.rem[4][wf];
+}
+
+// ---- MHD linear wave (src/pgen/linear_wave_mhd.cpp) ---------------------------------------------
+// Adiabatic MHD eigensystem in the conserved variables (d, mx, my, mz, E, by, bz): eigenvalues and RIGHT
+// eigenvectors (linear_wave_mhd.cpp:486-625; the problem generator never reads the left ones).  One row of
+// `fam` per wave family -- fast-, Alfven-, slow-, entropy, slow+, Alfven+, fast+ -- is one column of rem.
+void lwm_eigensystem(double gm1, double d, double v1, double v2, double v3, double h, double b1, double b2, double b3,
+                     double x, double y, double ev[7], double rem[7][7]) {
+  const double vsq = v1 * v1 + v2 * v2 + v3 * v3;
+  const double btsq = b2 * b2 + b3 * b3;
+  const double bt_starsq = (gm1 - (gm1 - 1.0) * y) * btsq;
+  const double vaxsq = b1 * b1 / d;
+  const double hp = h - (vaxsq + btsq / d);
+  const double twid_asq = std::max((gm1 * (hp - 0.5 * vsq) - (gm1 - 1.0) * x), 1.0e-20);
+  const double ct2 = bt_starsq / d;
+  const double tsum = vaxsq + ct2 + twid_asq;
+  const double tdif = vaxsq + ct2 - twid_asq;
+  const double cf2_cs2 = std::sqrt(tdif * tdif + 4.0 * twid_asq * ct2);
+  const double cfsq = 0.5 * (tsum + cf2_cs2);
+  const double cf = std::sqrt(cfsq);
+  const double cssq = twid_asq * vaxsq / cfsq;
+  const double cs = std::sqrt(cssq);
+  const double bt = std::sqrt(btsq);
+  const double bt_star = std::sqrt(bt_starsq);
+  double bet2 = 1.0, bet3 = 0.0;
+  if (bt != 0.0) {
+    bet2 = b2 / bt;
+    bet3 = b3 / bt;
+  }
+  const double bet2_star = bet2 / std::sqrt(gm1 - (gm1 - 1.0) * y);
+  const double bet3_star = bet3 / std::sqrt(gm1 - (gm1 - 1.0) * y);
+  const double bet_starsq = bet2_star * bet2_star + bet3_star * bet3_star;
+  const double vbet = v2 * bet2_star + v3 * bet3_star;
+  double alpha_f, alpha_s;
+  if ((cfsq - cssq) == 0.0) {
+    alpha_f = 1.0;
+    alpha_s = 0.0;
+  } else if ((twid_asq - cssq) <= 0.0) {
+    alpha_f = 0.0;
+    alpha_s = 1.0;
+  } else if ((cfsq - twid_asq) <= 0.0) {
+    alpha_f = 1.0;
+    alpha_s = 0.0;
+  } else {
+    alpha_f = std::sqrt((twid_asq - cssq) / (cfsq - cssq));
+    alpha_s = std::sqrt((cfsq - twid_asq) / (cfsq - cssq));
+  }
+  const double sqrtd = std::sqrt(d);
+  const double isqrtd = 1.0 / sqrtd;
+  const double sgn = (b1 < 0.0) ? -1.0 : 1.0;  // Parthenon SIGN
+  const double twid_a = std::sqrt(twid_asq);
+  const double qf = cf * alpha_f * sgn;
+  const double qs = cs * alpha_s * sgn;
+  const double af_prime = twid_a * alpha_f * isqrtd;
+  const double as_prime = twid_a * alpha_s * isqrtd;
+  const double afpbb = af_prime * bt_star * bet_starsq;
+  const double aspbb = as_prime * bt_star * bet_starsq;
+  const double vax = std::sqrt(vaxsq);
+  const double lam[7] = {v1 - cf, v1 - vax, v1 - cs, v1, v1 + cs, v1 + vax, v1 + cf};
+  for (int w = 0; w < 7; ++w) ev[w] = lam[w];
+  const double af_v2 = alpha_f * v2, as_v2 = alpha_s * v2, qs_b2 = qs * bet2_star, qf_b2 = qf * bet2_star;
+  const double af_v3 = alpha_f * v3, as_v3 = alpha_s * v3, qs_b3 = qs * bet3_star, qf_b3 = qf * bet3_star;
+  const double e_alf = -(v2 * bet3 - v3 * bet2);
+  const double fam[7][7] = {
+      {alpha_f, alpha_f * lam[0], af_v2 + qs_b2, af_v3 + qs_b3, alpha_f * (hp - v1 * cf) + qs * vbet + aspbb,
+       as_prime * bet2_star, as_prime * bet3_star},
+      {0.0, 0.0, -bet3, bet2, e_alf, -bet3 * sgn * isqrtd, bet2 * sgn * isqrtd},
+      {alpha_s, alpha_s * lam[2], as_v2 - qf_b2, as_v3 - qf_b3, alpha_s * (hp - v1 * cs) - qf * vbet - afpbb,
+       -af_prime * bet2_star, -af_prime * bet3_star},
+      {1.0, v1, v2, v3, 0.5 * vsq + (gm1 - 1.0) * x / gm1, 0.0, 0.0},
+      {alpha_s, alpha_s * lam[4], as_v2 + qf_b2, as_v3 + qf_b3, alpha_s * (hp + v1 * cs) + qf * vbet - afpbb,
+       -af_prime * bet2_star, -af_prime * bet3_star},
+      {0.0, 0.0, bet3, -bet2, -e_alf, -bet3 * sgn * isqrtd, bet2 * sgn * isqrtd},
+      {alpha_f, alpha_f * lam[6], af_v2 - qs_b2, af_v3 - qs_b3, alpha_f * (hp + v1 * cf) - qs * vbet + aspbb,
+       as_prime * bet2_star, as_prime * bet3_star}};
+  for (int w = 0; w < 7; ++w)
+    for (int r = 0; r < 7; ++r) rem[r][w] = fam[w][r];
+}
+
+// InitUserMeshData (linear_wave_mhd.cpp:68-172): the hydro wave's geometry and background (the same
+// expressions: :91-143 == linear_wave.cpp:86-140) plus B = (1, sqrt 2, 1/2) in the wave frame
+void lwm_setup(apk_sim *s) {
+  if (s->pkg.fluid != APK_FLUID_GLMMHD) throw std::runtime_error("linear_wave_mhd requires hydro/fluid = glmmhd");
+  lw_setup(s);
+  LinearWaveState &lw = s->lw;
+  LinearWaveMhdState &m = s->lwm;
+  m.bx0 = 1.0;
+  m.by0 = std::sqrt(2.0);
+  m.bz0 = 0.5;
+  const double v0 = 0.0, w0 = 0.0;
+  double h0 = ((lw.p0 / lw.gm1 + 0.5 * lw.d0 * (lw.u0 * lw.u0 + v0 * v0 + w0 * w0)) + lw.p0) / lw.d0;
+  h0 += (m.bx0 * m.bx0 + m.by0 * m.by0 + m.bz0 * m.bz0) / lw.d0;
+  lwm_eigensystem(lw.gm1, lw.d0, lw.u0, v0, w0, h0, m.bx0, m.by0, m.bz0, 0.0, 1.0, m.ev, m.rem);
+  m.dby = lw.amp * m.rem[5][lw.wave_flag];  // (ProblemGenerator :392-393)
+  m.dbz = lw.amp * m.rem[6][lw.wave_flag];
+  if (s->pin.GetOrAddBoolean("problem/linear_wave", "test", false)) {
+    // tlim counts wave periods (:165-171); the entropy wave of a fluid at rest has none
+    s->tlim = lw.lambda / std::abs(m.ev[lw.wave_flag]) * s->tlim;
+  }
+}
+
+// vector potential in the gauge Ax = 0 (linear_wave_mhd.cpp:443-479)
+static void lwm_potential(const apk_sim *s, double x1, double x2, double x3, double A[3]) {
+  const LinearWaveState &lw = s->lw;
+  const LinearWaveMhdState &m = s->lwm;
+  const double x = x1 * lw.cos_a2 * lw.cos_a3 + x2 * lw.cos_a2 * lw.sin_a3 + x3 * lw.sin_a2;
+  const double y = -x1 * lw.sin_a3 + x2 * lw.cos_a3;
+  const double Ay = m.bz0 * x - (m.dbz / lw.k_par) * std::cos(lw.k_par * (x));
+  const double Az = -m.by0 * x + (m.dby / lw.k_par) * std::cos(lw.k_par * (x)) + m.bx0 * y;
+  A[0] = -Ay * lw.sin_a3 - Az * lw.sin_a2 * lw.cos_a3;
+  A[1] = Ay * lw.cos_a3 - Az * lw.sin_a2 * lw.sin_a3;
+  A[2] = Az * lw.cos_a2;
+}
+
+// the analytic wave at a cell centre: d, M1, M2, M3, E (linear_wave_mhd.cpp:407-436) and the ANALYTIC field
+// B1, B2, B3 of the error norm (:213-224); the problem generator differences the potential instead
+void lwm_state(const apk_sim *s, double x1, double x2, double x3, double u[8]) {
+  const LinearWaveState &lw = s->lw;
+  const LinearWaveMhdState &m = s->lwm;
+  const int wf = lw.wave_flag;
+  const double x = lw.cos_a2 * (x1 * lw.cos_a3 + x2 * lw.sin_a3) + x3 * lw.sin_a2;
+  const double sn = std::sin(lw.k_par * x);
+  u[0] = lw.d0 + lw.amp * sn * m.rem[0][wf];
+  const double mx = lw.d0 * lw.vflow + lw.amp * sn * m.rem[1][wf];
+  const double my = lw.amp * sn * m.rem[2][wf];
+  const double mz = lw.amp * sn * m.rem[3][wf];
+  u[1] = mx * lw.cos_a2 * lw.cos_a3 - my * lw.sin_a3 - mz * lw.sin_a2 * lw.cos_a3;
+  u[2] = mx * lw.cos_a2 * lw.sin_a3 + my * lw.cos_a3 - mz * lw.sin_a2 * lw.sin_a3;
+  u[3] = mx * lw.sin_a2 + mz * lw.cos_a2;
+  double e0 = lw.p0 / lw.gm1 + 0.5 * lw.d0 * lw.u0 * lw.u0 + lw.amp * sn * m.rem[4][wf];
+  e0 += 0.5 * (m.bx0 * m.bx0 + m.by0 * m.by0 + m.bz0 * m.bz0);
+  u[4] = e0;
+  const double bx = m.bx0;
+  const double by = m.by0 + lw.amp * sn * m.rem[5][wf];
+  const double bz = m.bz0 + lw.amp * sn * m.rem[6][wf];
+  u[5] = bx * lw.cos_a2 * lw.cos_a3 - by * lw.sin_a3 - bz * lw.sin_a2 * lw.cos_a3;
+  u[6] = bx * lw.cos_a2 * lw.sin_a3 + by * lw.cos_a3 - bz * lw.sin_a2 * lw.sin_a3;
+  u[7] = bx * lw.sin_a2 + bz * lw.cos_a2;
 }
 
 // fills the interior of one block's host image [nvar][Nk][Nj][Ni]
@@ -457,6 +597,21 @@ void pgen_block(apk_sim *s, int lb, std::vector<double> &u) {
           double w[5];
           lw_state(s->lw, x1, x2, x3, w);
           for (int n = 0; n < 5; ++n) at(n, k, j, i) = w[n];
+        } else if (s->problem_id == "linear_wave_mhd") {  // src/pgen/linear_wave_mhd.cpp:395-437
+          double w[8];
+          lwm_state(s, x1, x2, x3, w);
+          for (int n = 0; n < 5; ++n) at(n, k, j, i) = w[n];
+          // B = curl A by centred differences of the cell-centred potential
+          double Ajp[3], Ajm[3], Akp[3], Akm[3], Aip[3], Aim[3];
+          lwm_potential(s, x1, xc(s, x0, 1, j + 1), x3, Ajp);
+          lwm_potential(s, x1, xc(s, x0, 1, j - 1), x3, Ajm);
+          lwm_potential(s, x1, x2, xc(s, x0, 2, k + 1), Akp);
+          lwm_potential(s, x1, x2, xc(s, x0, 2, k - 1), Akm);
+          lwm_potential(s, xc(s, x0, 0, i + 1), x2, x3, Aip);
+          lwm_potential(s, xc(s, x0, 0, i - 1), x2, x3, Aim);
+          at(5, k, j, i) = (Ajp[2] - Ajm[2]) / s->dx[1] / 2.0 - (Akp[1] - Akm[1]) / s->dx[2] / 2.0;
+          at(6, k, j, i) = (Akp[0] - Akm[0]) / s->dx[2] / 2.0 - (Aip[2] - Aim[2]) / s->dx[0] / 2.0;
+          at(7, k, j, i) = (Aip[1] - Aim[1]) / s->dx[0] / 2.0 - (Ajp[0] - Ajm[0]) / s->dx[1] / 2.0;
         } else if (s->problem_id == "sod") {  // src/pgen/sod.cpp:37-50
           const bool left = x1 < sod[6];
           const double rho = left ? sod[0] : sod[3], pr = left ? sod[1] : sod[4], ux = left ? sod[2] : sod[5];

@@ -53,24 +53,33 @@ APK_DEV double sqr(double x) { return x * x; }
 APK_DEV double fsqrt(double x) { return sqrt(x); }
 APK_DEV double frcp(double x) { return 1.0 / x; }
 #else
-// v_rsq_f64 / v_rcp_f64 deliver roughly 8-10 good bits (hipcc itself follows them with three
-// quadratically converging steps): Goldschmidt + two residual corrections for the root, three
-// Newton steps for a reciprocal.
+// v_rsq_f64 / v_rcp_f64 deliver 24 good bits (measured on gfx950 over 1e-12 .. 1e12, tools/ubench/ubench_lat.hip:
+// max relative error 4.6e-8 / 5.2e-8; round 2 assumed 8-10 bits and spent one quadratically converging step
+// too many everywhere): 24 -> 48 -> 96 bits, i.e. TWO Newton steps for a reciprocal, one Goldschmidt step +
+// ONE residual correction for a root, one Newton step for 1/sqrt from the converged pair.  APK_NEWTON_EXTRA=1
+// restores the round-2 sequences (A/B).
+#ifndef APK_NEWTON_EXTRA
+#define APK_NEWTON_EXTRA 0
+#endif
 APK_DEV void fsqrt_rsqrt(double x, double &root, double &inv_root) {
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
   const double r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
+  g = fma(g, r, g);  // 48 bits
   h = fma(h, r, h);
   double d = fma(-g, g, x);
-  g = fma(d, h, g);
-  d = fma(-g, g, x);
-  g = fma(d, h, g);
-  // 1/sqrt(x) from the converged root: two Newton steps on rs -> rs (2 - g rs)
+  g = fma(d, h, g);  // full
+  if constexpr (APK_NEWTON_EXTRA != 0) {
+    d = fma(-g, g, x);
+    g = fma(d, h, g);
+  }
+  // 1/sqrt(x) from the converged root: Newton on rs -> rs (2 - g rs), rs = 2 h has 48 bits
   double rs = h + h;
   double e = fma(-g, rs, 1.0);
-  rs = fma(rs, e, rs);
-  e = fma(-g, rs, 1.0);
+  if constexpr (APK_NEWTON_EXTRA != 0) {
+    rs = fma(rs, e, rs);
+    e = fma(-g, rs, 1.0);
+  }
   root = g;
   inv_root = fma(rs, e, rs);
 }
@@ -82,17 +91,21 @@ APK_DEV double fsqrt(double x) {
   h = fma(h, r, h);
   double d = fma(-g, g, x);
   g = fma(d, h, g);
-  d = fma(-g, g, x);
-  g = fma(d, h, g);
+  if constexpr (APK_NEWTON_EXTRA != 0) {
+    d = fma(-g, g, x);
+    g = fma(d, h, g);
+  }
   return (x == 0.0) ? 0.0 : g;  // rsq(0) = inf
 }
 APK_DEV double frcp(double x) {
   double y = __builtin_amdgcn_rcp(x);
   double e = fma(-x, y, 1.0);
-  y = fma(y, e, y);
+  y = fma(y, e, y);  // 48 bits
   e = fma(-x, y, 1.0);
-  y = fma(y, e, y);
-  e = fma(-x, y, 1.0);
+  if constexpr (APK_NEWTON_EXTRA != 0) {
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+  }
   return fma(y, e, y);
 }
 #endif

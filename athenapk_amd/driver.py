@@ -217,9 +217,11 @@ class Simulation(_FmftHost, _MeshView):
 
         self._halo = None
         self._halo_generation = None
+        self._cb_counts = {"exchanges": 0, "reductions": 0}  # callback transport (the native one keeps its own)
 
         def _exchange(user):
             try:
+                self._cb_counts["exchanges"] += 1
                 self._current_halo().exchange()
                 return 0
             except Exception as e:  # surfaced as APK_ERR_DEVICE by the driver
@@ -228,6 +230,7 @@ class Simulation(_FmftHost, _MeshView):
 
         def _exchange_begin(user):
             try:
+                self._cb_counts["exchanges"] += 1
                 self._current_halo().begin()
                 return 0
             except Exception as e:
@@ -245,6 +248,7 @@ class Simulation(_FmftHost, _MeshView):
         def _amin(user, vals, n):
             try:
                 import torch.distributed as dist
+                self._cb_counts["reductions"] += 1
                 _allreduce(vals, n, dist.ReduceOp.MIN, dev, red_group)
                 return 0
             except Exception as e:
@@ -254,6 +258,7 @@ class Simulation(_FmftHost, _MeshView):
         def _asum(user, vals, n):
             try:
                 import torch.distributed as dist
+                self._cb_counts["reductions"] += 1
                 _allreduce(vals, n, dist.ReduceOp.SUM, dev, red_group)
                 return 0
             except Exception as e:
@@ -280,11 +285,15 @@ class Simulation(_FmftHost, _MeshView):
             # bootstrap: rank 0 makes the two ncclUniqueIds, torch.distributed hands them round
             import torch.distributed as dist
             ids = C.create_string_buffer(2 * L.APK_RCCL_ID_BYTES)
+            rc0 = L.APK_OK
             if dist.get_rank(group) == 0:
-                self._check(self.lib.apk_rccl_unique_ids(ids, len(ids)))
-            box = [ids.raw]
+                # (a failure here -- no librccl -- must not raise before the broadcast: the other ranks are
+                # waiting in it; rank 0 hands its status round with the ids and everybody falls back together)
+                rc0 = self.lib.apk_rccl_unique_ids(ids, len(ids))
+            box = [(rc0, ids.raw)]
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            rc = self.lib.apk_sim_comm_rccl(self.h, box[0], len(box[0]))
+            rc0, raw = box[0]
+            rc = self.lib.apk_sim_comm_rccl(self.h, raw, len(raw)) if rc0 == L.APK_OK else rc0
             # every rank must end up on the same transport: if the native one could not start anywhere
             # (no librccl, communicator creation failed), all ranks fall back to the callbacks -- loudly
             okt = torch.tensor([1 if rc == L.APK_OK else 0], dtype=torch.int32,
@@ -361,12 +370,24 @@ class Simulation(_FmftHost, _MeshView):
     def overlapped_exchanges(self):
         return self.lib.apk_sim_overlapped_exchanges(self.h)
 
+    def comm_stats(self):
+        """{"exchanges", "reductions"}: halo exchanges posted and collectives done so far by this rank's transport"""
+        if self.comm_kind == "rccl":
+            ex, red = C.c_longlong(0), C.c_longlong(0)
+            self._check(self.lib.apk_sim_comm_stats(self.h, C.byref(ex), C.byref(red)))
+            return {"exchanges": int(ex.value), "reductions": int(red.value)}
+        return dict(self._cb_counts)
+
     def skipped_local_exchanges(self):
         return self.lib.apk_sim_skipped_local_exchanges(self.h)
 
     def set_direct_neighbors(self, on):
         self._check(self.lib.apk_sim_set_direct_neighbors(self.h, int(on)))
         return self
+
+    def set_amr_full_exchange(self, on):
+        """refined meshes: 1 = the stage loop exchanges every ghost zone, not only those behind block faces"""
+        self._check(self.lib.apk_sim_set_amr_full_exchange(self.h, int(on)))
 
     def set_fused(self, fused):
         self._check(self.lib.apk_sim_set_fused(self.h, int(fused)))
@@ -494,6 +515,13 @@ class Simulation(_FmftHost, _MeshView):
         rms = C.c_double(0.0)
         l1, mx = (C.c_double * 5)(), (C.c_double * 5)()
         self._check(self.lib.apk_sim_linear_wave_errors(self.h, C.byref(rms), l1, mx))
+        return rms.value, np.array(l1[:]), np.array(mx[:])
+
+    def linear_wave_mhd_errors(self):
+        """(RMS, L1[8], max[8]) of d, M1, M2, M3, E, B1, B2, B3 against the analytic MHD wave (linear_wave_mhd.cpp:177-276)"""
+        rms = C.c_double(0.0)
+        l1, mx = (C.c_double * 8)(), (C.c_double * 8)()
+        self._check(self.lib.apk_sim_linear_wave_mhd_errors(self.h, C.byref(rms), l1, mx))
         return rms.value, np.array(l1[:]), np.array(mx[:])
 
     def kernel_timing(self, on):

@@ -216,6 +216,7 @@ def _signatures():
         "apk_sim_overlapped_exchanges": (ll, [vp]),
         "apk_sim_skipped_local_exchanges": (ll, [vp]),
         "apk_sim_set_direct_neighbors": (C.c_int, [vp, C.c_int]),
+        "apk_sim_set_amr_full_exchange": (C.c_int, [vp, C.c_int]),
         "apk_sim_loop_seconds": (d, [vp]),
         "apk_sim_loop_cycles": (i, [vp]),
         "apk_sim_get_info": (i, [vp, C.POINTER(SimInfo)]),
@@ -226,6 +227,7 @@ def _signatures():
         "apk_sim_write_block": (i, [vp, i, i, c_dp]),
         "apk_sim_history": (i, [vp, c_dp]),
         "apk_sim_linear_wave_errors": (i, [vp, c_dp, c_dp, c_dp]),
+        "apk_sim_linear_wave_mhd_errors": (i, [vp, c_dp, c_dp, c_dp]),
         "apk_sim_cpaw_errors": (i, [vp, c_dp, c_dp]),
         "apk_sim_write_cpaw_errors": (i, [vp, C.c_char_p]),
         "apk_sim_check_refinement": (i, [vp, C.POINTER(C.c_int), c_dp]),

@@ -29,7 +29,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
-HBM_COPY_GBS = 6290.0   # measured float4 copy (MI355X_MICROARCH.md, HBM section)  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured with torch: copy 4950, read 6060, fill 6570 GB/s
+# HBM_PEAK_GBS: the MI355X HBM3E spec the roofline is priced against (MI355X_MICROARCH.md).
+# HBM_COPY_GBS: what a float4 copy kernel reaches (same guide, HBM section); torch elementwise kernels on the
+# bench boxes: copy 4950, read 6060, fill 6570 GB/s.
+HBM_COPY_GBS = 6290.0
 
 # algorithmic bytes (fp64, compulsory traffic) -- SURVEY.md 8(d)
 B_STAGE = {"glmmhd": (216.0, 288.0), "euler": (120.0, 160.0)}   # per cell-stage: gam0 == 0 / != 0
@@ -103,11 +106,11 @@ def cpu_baseline(fluid, integrator, recon, riemann, target_s=10.0):
 
 def amr_blast_bench(cycles=40):
     """BASELINE config 5's shape (inputs/blast_3d_amr.in with root 64^3 in 16^3 meshblocks, 4 levels,
-    regridding every cycle) for the hydro deck and for GLM-MHD PPM+HLLD (ambient pressure 1, pressure ratio
-    100 there: with the deck's near-vacuum ambient medium PPM + GLM-MHD needs first_order_flux_correct
-    to stay positive, on uniform meshes as well):
-    zone-cycles/s counted over the blocks that exist in each cycle, like Parthenon's performance
-    line.  Supplementary."""
+    regridding every cycle) for the hydro deck as it is and for GLM-MHD PPM+HLLD on the deck's own blast
+    (near-vacuum ambient medium, pressure ratio 1.6e8, no first-order flux correction: the deck has none and
+    tests/test_gpu_configs.py::test_config5_adaptive_mhd_blast_as_decked runs it for 400 cycles without a
+    negative state): zone-cycles/s counted over the blocks that exist in each cycle, like Parthenon's
+    performance line.  Supplementary."""
     import torch
     from athenapk_amd import decks, driver
     ov = ["parthenon/mesh/nx%d=64" % d for d in (1, 2, 3)] + ["parthenon/meshblock/nx%d=16" % d for d in (1, 2, 3)]
@@ -115,7 +118,7 @@ def amr_blast_bench(cycles=40):
     out = {}
     for name, extra in (("hydro_plm_hlle_vl2", []),
                         ("mhd_ppm_hlld_vl2", ["hydro/fluid=glmmhd", "hydro/riemann=hlld", "hydro/reconstruction=ppm",
-                                              "parthenon/mesh/nghost=4", "problem/blast/pressure_ambient=1.0", "problem/blast/pressure_ratio=100"])):
+                                              "parthenon/mesh/nghost=4"])):
         s = driver.Simulation(decks.load("blast_3d_amr"), ov + extra).initialize()
         for _ in range(3):
             s.step()
@@ -190,14 +193,33 @@ def general_stage_bench(recon="ppm", riemann="hlld", nb=8, n=128, reps=5):
             "frac": gbs / HBM_PEAK_GBS, "frac_of_measured_copy_bandwidth": gbs / HBM_COPY_GBS}
 
 
+# rocprofv3 names of the kernels behind the driver's timing slots (3-D GLM-MHD PPM+HLLD two-kernel stage)
+ROCPROF_KERNEL = {"fused_x1": "fused_m12f_kernel<2, 3, 5, 2> / <2, 3, 5, 0> (x1 + x2 finishing march)",
+                  "fused_x3": "fused_march_kernel<2, 3, 5, 3, false, 0> (x3 sweep)",
+                  "fused_dc_x1": "fused_dc3_kernel<2, 5, 1> (donor-cell predictor stage)"}
+
+
+def _profile_commit(path):
+    """the commit that last touched a committed profile (None outside a git checkout, e.g. on the GPU box)"""
+    try:
+        import subprocess
+        r = subprocess.run(["git", "log", "-1", "--format=%h", "--", path], cwd=ROOT, capture_output=True, text=True, timeout=10)
+        return r.stdout.strip() or None
+    except Exception:
+        return None
+
+
 def measured_traffic(workload):
-    """HBM bytes per fused-stage launch from the committed rocprofv3 PMC passes (a live run cannot
-    profile itself): profiles/r01_hbm_traffic.json, made by profiles/pmc_traffic.py from
-    FETCH_SIZE / WRITE_SIZE of this same command.  Returns (GB, source) or (None, None)."""
+    """HBM bytes per fused-stage launch.  A live run cannot profile itself, so this is read from the newest
+    COMMITTED rocprofv3 PMC summary of this same command (profiles/rNN_hbm_traffic.json, made by
+    profiles/pmc_traffic.py from FETCH_SIZE / WRITE_SIZE collected in separate passes); the source string names
+    the file.  Returns (GB, source) or (None, None)."""
     if workload != "mhd_ppm_hlld_vl2_256":
         return None, None
-    # round 2: the two-kernel stage (x3 sweep + finishing x1/x2 march); round 1: three sweeps
+    # round 2 / 3: the two-kernel stage (x3 sweep + finishing x1/x2 march); round 1: three sweeps
     for fname, stage, note in (
+            ("r03_hbm_traffic.json", ("fused_march_kernel<2, 3, 5, 3, false, 0>", "fused_m12f_kernel<2, 3, 5, 2>"),
+             "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, reads calibrated on the dt kernel's known bytes"),
             ("r02_hbm_traffic.json", ("fused_march_kernel<2, 3, 5, 3, false, 0>", "fused_m12f_kernel<2, 3, 5, 2>"),
              "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, reads calibrated on the dt kernel's known bytes"),
             ("r01_hbm_traffic.json", ("fused_x1_kernel<2, 3, 5, false>", "fused_march_kernel<2, 3, 5, 2, false, 0>",
@@ -209,7 +231,10 @@ def measured_traffic(workload):
         try:
             with open(path) as f:
                 k = json.load(f)["kernels"]
-            return sum(k[name]["hbm_total_GB"] for name in stage), "profiles/%s (%s)" % (fname, note)
+            commit = _profile_commit(path)
+            return (sum(k[name]["hbm_total_GB"] for name in stage),
+                    "profiles/%s%s -- a COMMITTED profile of this command, not this run (%s)"
+                    % (fname, " @ " + commit if commit else "", note))
         except Exception:
             continue
     return None, None
@@ -222,7 +247,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="mhd_ppm_hlld_vl2_256", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-copies-base", action="store_true",
+                    help="skip the second N = 1 figure (same steps with the same-rank ghost copies of an N > 1 run)")
     ap.add_argument("--unfused", action="store_true", help="use the flux-array path (for A/B)")
+    ap.add_argument("--brick", type=int, default=0, help="cells per GPU and direction instead of the workload's 256 (tests)")
+    ap.add_argument("--meshblock", type=int, default=0, help="meshblock size instead of the workload's 128 (tests)")
     ap.add_argument("--amr-extra", action="store_true",
                     help="append the adaptive-mesh figure (BASELINE config 5 shape) as 'amr_blast_cfg5'; off by default so "
                          "that the kernels of the default command are those of the headline workload only")
@@ -256,6 +285,9 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     deck, fluid, integrator, recon, riemann, brick, mb, desc = WORKLOADS[args.workload]
+    if args.brick or args.meshblock:  # (a reduced copy of the workload for the launch tests: NOT the benchmark)
+        brick, mb = args.brick or brick, args.meshblock or mb
+        desc += " -- REDUCED to %d^3 per GPU in %d^3 meshblocks" % (brick, mb)
     if world not in RANK_GRID:
         raise SystemExit("supported GPU counts: %s" % sorted(RANK_GRID))
     grid = RANK_GRID[world]
@@ -281,6 +313,7 @@ def main():
     sim.kernel_timing(True)
     sim.read_kernel_timing()
     barrier()
+    comm_before = sim.comm_stats() if world > 1 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sim.step()
@@ -289,10 +322,31 @@ def main():
     elapsed = time.perf_counter() - t0
     timing = sim.read_kernel_timing()
     sim.kernel_timing(False)
+    comm_stats = sim.comm_stats() if world > 1 else None
+    skipped_per_cycle = sim.skipped_local_exchanges() / max(1, sim.ncycle)
+    overlapped_per_cycle = sim.overlapped_exchanges / max(1, sim.ncycle)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # The honest base of a weak-scaling curve: at N = 1 every block face is a same-rank face and direct
+    # neighbour addressing skips ALL ghost copies, while at N > 1 the faces between bricks are packed, sent
+    # and unpacked.  Same workload once more with the same-rank ghost copies done as at N > 1 (a second
+    # figure; `value` stays the default configuration's).
+    copies_base = None
+    if world == 1 and not args.unfused and not args.no_copies_base and sim.skipped_local_exchanges() > 0:
+        sim.set_direct_neighbors(False)
+        for _ in range(max(1, args.warmup)):
+            sim.step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            sim.step()
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t1
+        copies_base = {"value": int(info.zones_total) * args.steps / e2, "unit": "cell-updates/s", "ms_per_step": e2 / args.steps * 1e3,
+                       "what": "the same %d steps with APK_DIRECT_NEIGHBORS=0: same-rank ghost zones copied (+ ConsToPrim) after every "
+                               "stage as they are between the bricks of an N > 1 run" % args.steps}
 
     if rank == 0:
         zones_total = int(info.zones_total)
@@ -354,9 +408,12 @@ def main():
                        "comm_backend": (("rccl, native transport of the C++ host (ncclSend/ncclRecv groups on a halo stream)"
                                          if sim.comm_kind == "rccl" else "torch.distributed callbacks over " + backend)
                                         if world > 1 else None),
-                       "overlapped_exchanges_per_cycle": (sim.overlapped_exchanges / max(1, sim.ncycle)) if world > 1 else None,
+                       "overlapped_exchanges_per_cycle": overlapped_per_cycle if world > 1 else None,
+                       # collectives per cycle on the reduction communicator (dt and the c_h estimate travel together)
+                       "reductions_per_cycle": ((comm_stats["reductions"] - comm_before["reductions"]) / args.steps) if comm_stats else None,
+                       "halo_exchanges_per_cycle": ((comm_stats["exchanges"] - comm_before["exchanges"]) / args.steps) if comm_stats else None,
                        # stage boundaries per cycle whose same-rank ghost copies were skipped (direct neighbour addressing)
-                       "same_rank_ghost_copies_skipped_per_cycle": sim.skipped_local_exchanges() / max(1, sim.ncycle)},
+                       "same_rank_ghost_copies_skipped_per_cycle": skipped_per_cycle},
             "cell_stage_updates_per_s": value * nstages,
             "roofline": {
                 "bound": "hbm",
@@ -373,19 +430,22 @@ def main():
                 "stage_ms": stage_ms,
                 "dc_predictor_stage_ms": per_kernel["fused_dc_x1"] + per_kernel["fused_dc_x2"] + per_kernel["fused_dc_x3"],
                 "frac_of_measured_copy_bandwidth": achieved / HBM_COPY_GBS,
-                "note": "fp64 VALU-issue bound: ~4.3k executed VALU instructions per cell-stage (SQ_INSTS_VALU, "
-                        "profiles/r02_pmc_sq.json) at a measured 4.3 cycles per wave64 fp64 instruction and 2.06 GHz "
+                "note": "fp64 VALU-issue bound (executed VALU instructions per cell-stage: SQ_INSTS_VALU in the newest "
+                        "profiles/rNN_pmc_sq.json) at a measured 4.3 cycles per wave64 fp64 instruction and ~2.0 GHz "
                         "(profiles/r02_clock_and_issue_rate.json); `peak` is the 8 TB/s spec, "
                         "frac_of_measured_copy_bandwidth prices against the 6.29 TB/s a float4 copy reaches "
                         "(MI355X_MICROARCH.md); product build: FMA contraction, rsq/rcp-based roots and reciprocals "
                         "(<= 1e-12 of the bit-exact parity build, which is what the parity tests pin); see DESIGN.md section 7",
                 "per_kernel_avg_ms": per_kernel,
-                "dominant_kernel": dominant,
+                "dominant_kernel": ROCPROF_KERNEL.get(dominant, dominant) if fluid == "glmmhd" and recon == "ppm" else dominant,
+                "dominant_timing_slot": dominant,
                 "whole_cycle": {"algorithmic_bytes_per_zone_cycle": b_cycle,
                                 "achieved": value / world * b_cycle / 1e9,
                                 "frac": value / world * b_cycle / 1e9 / HBM_PEAK_GBS},
             },
         }
+        if copies_base:
+            out["weak_scaling_base_with_ghost_copies"] = copies_base
         if world == 1 and fluid == "glmmhd" and not args.unfused:
             try:
                 sim.close()

@@ -118,6 +118,11 @@ long long apk_sim_overlapped_exchanges(const apk_sim *sim);
  * switches it off.  Returns the number of stage boundaries so far whose same-rank copies were skipped. */
 long long apk_sim_skipped_local_exchanges(const apk_sim *sim);
 int apk_sim_set_direct_neighbors(apk_sim *sim, int on); /* 1 (default) / 0 = always copy */
+/* Refined meshes: the stage loop's exchange leaves out the ghost zones behind block edges and corners
+ * (no sweep or flux correction reads them; accessors, tagging and the last exchange of a cycle that
+ * checks the refinement criteria complete them).  1 = always exchange in full (what APK_AMR_FULL_EXCHANGE=1
+ * in the environment selects): same results, for A/B timing and for the tests of that statement. */
+int apk_sim_set_amr_full_exchange(apk_sim *sim, int on);
 
 /* ---- introspection ------------------------------------------------------------------- */
 typedef struct apk_sim_info {
@@ -220,6 +225,11 @@ long long apk_sim_loop_zone_cycles(const apk_sim *sim);
 int apk_sim_cpaw_errors(apk_sim *sim, double *rms, double *err8);
 int apk_sim_write_cpaw_errors(apk_sim *sim, const char *path);
 int apk_sim_linear_wave_errors(apk_sim *sim, double *rms, double *l1_5, double *max_5);
+/* MHD linear waves (job/problem_id = linear_wave_mhd, src/pgen/linear_wave_mhd.cpp: the seven wave families of
+ * adiabatic MHD on a magnetised background, wave_flag 0..6 = fast-, Alfven-, slow-, entropy, slow+, Alfven+, fast+;
+ * B = curl A of the cell-centred potential :370-441): L1 / max errors of d, M1, M2, M3, E, B1, B2, B3 against the
+ * analytic wave and their RMS (:177-276).  apk_sim_write_linear_wave_errors writes this problem's 8-column row. */
+int apk_sim_linear_wave_mhd_errors(apk_sim *sim, double *rms, double *l1_8, double *max_8);
 /* individual driver steps, exposed for tests */
 int apk_sim_exchange_ghosts(apk_sim *sim);
 int apk_sim_fill_derived(apk_sim *sim);

@@ -156,6 +156,10 @@ void orc_sim_block_origin(const orc_sim *s, int b, double x0[3]); /* global inde
 /* problem generators: fill interior cons of every block */
 /* src/pgen/linear_wave.cpp:72-176,342-376 ; returns period-scaled tlim factor lambda/|ev| */
 double orc_pgen_linear_wave(orc_sim *s, int wave_flag, double amp, double vflow);
+/* src/pgen/linear_wave_mhd.cpp: wave_flag 0..6 = fast-, Alfven-, slow-, entropy, slow+, Alfven+, fast+; returns the period */
+double orc_pgen_linear_wave_mhd(orc_sim *s, int wave_flag, double amp, double vflow);
+void orc_linear_wave_mhd_eigen(const orc_sim *s, double *ev7, double *rem49);
+double orc_linear_wave_mhd_errors(orc_sim *s, int wave_flag, double amp, double vflow, double *l1_8, double *max_8);
 /* src/pgen/sod.cpp:17-51 */
 void orc_pgen_sod(orc_sim *s, double rho_l, double pres_l, double u_l, double rho_r,
                   double pres_r, double u_r, double x_discont);

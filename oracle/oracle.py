@@ -106,6 +106,9 @@ def _declare(lib):
         "orc_sim_prim": (p, [C.c_void_p, i]),
         "orc_sim_block_origin": (None, [C.c_void_p, i, p]),
         "orc_pgen_linear_wave": (d, [C.c_void_p, i, d, d]),
+        "orc_pgen_linear_wave_mhd": (d, [C.c_void_p, i, d, d]),
+        "orc_linear_wave_mhd_errors": (d, [C.c_void_p, i, d, d, p, p]),
+        "orc_linear_wave_mhd_eigen": (None, [C.c_void_p, p, p]),
         "orc_pgen_sod": (None, [C.c_void_p, d, d, d, d, d, d, d]),
         "orc_pgen_orszag_tang": (None, [C.c_void_p]),
         "orc_pgen_field_loop": (None, [C.c_void_p, d, d, d, d, i]),
@@ -316,6 +319,10 @@ class Sim:
         if name == "linear_wave":
             self._lw = (kw.get("wave_flag", 0), kw.get("amp", 1e-6), kw.get("vflow", 0.0))
             self.period = self.lib.orc_pgen_linear_wave(self.h, *self._lw)
+        elif name == "linear_wave_mhd":
+            self._lw = (kw.get("wave_flag", 0), kw.get("amp", 1e-6), kw.get("vflow", 0.0))
+            self._lw_mhd = True
+            self.period = self.lib.orc_pgen_linear_wave_mhd(self.h, *self._lw)
         elif name == "sod":
             self.lib.orc_pgen_sod(self.h, kw.get("rho_l", 1.0), kw.get("pres_l", 1.0),
                                   kw.get("u_l", 0.0), kw.get("rho_r", 0.125),
@@ -396,7 +403,17 @@ class Sim:
         rms = self.lib.orc_cpaw_errors(self.h, dp(err))
         return rms, err
 
+    def linear_wave_mhd_eigen(self):
+        """(ev[7], rem[7][7]) of the MHD linear-wave background: columns of rem are the right eigenvectors"""
+        ev, rem = np.zeros(7), np.zeros((7, 7))
+        self.lib.orc_linear_wave_mhd_eigen(self.h, dp(ev), dp(rem))
+        return ev, rem
+
     def linear_wave_errors(self):
+        if getattr(self, "_lw_mhd", False):   # d, M1, M2, M3, E, B1, B2, B3
+            l1, mx = np.zeros(8), np.zeros(8)
+            rms = self.lib.orc_linear_wave_mhd_errors(self.h, *self._lw, dp(l1), dp(mx))
+            return rms, l1, mx
         l1, mx = np.zeros(5), np.zeros(5)
         rms = self.lib.orc_linear_wave_errors(self.h, *self._lw, dp(l1), dp(mx))
         return rms, l1, mx

@@ -38,6 +38,9 @@ struct orc_sim {
   /* linear wave state (src/pgen/linear_wave.cpp globals) */
   double lw_sin_a2, lw_cos_a2, lw_sin_a3, lw_cos_a3, lw_kpar, lw_lambda;
   double lw_d0, lw_p0, lw_u0, lw_gam, lw_gm1, lw_ev[5], lw_rem[5][5];
+  /* MHD linear wave (src/pgen/linear_wave_mhd.cpp globals): background field in the wave frame,
+   * transverse field amplitudes of the chosen family, 7-wave eigensystem */
+  double lwm_bx0, lwm_by0, lwm_bz0, lwm_dby, lwm_dbz, lwm_ev[7], lwm_rem[7][7];
 };
 
 /* SURVEY.md App. A.2 */
@@ -537,6 +540,209 @@ double orc_linear_wave_errors(orc_sim *s, int wave_flag, double amp, double vflo
                      (s->p.xmax[2] - s->p.xmin[2]);
   double rms = 0.0;
   for (int n = 0; n < 5; ++n) {
+    l1[n] = l1[n] / vol;
+    rms += l1[n] * l1[n];
+  }
+  return sqrt(rms);
+}
+
+/* ---- MHD linear wave (src/pgen/linear_wave_mhd.cpp) ------------------------------------------- */
+/* adiabatic MHD eigensystem in the conserved variables (d, mx, my, mz, E, by, bz), eigenvalues and RIGHT
+ * eigenvectors only (linear_wave_mhd.cpp:486-625; the left eigenvectors :627-710 are never read by the
+ * problem generator).  x, y are the reference's xfact / yfact. */
+static void lwm_eigensystem(double gm1, double d, double v1, double v2, double v3, double h, double b1,
+                            double b2, double b3, double x, double y, double ev[7], double rem[7][7]) {
+  const double vsq = v1 * v1 + v2 * v2 + v3 * v3;
+  const double btsq = b2 * b2 + b3 * b3;
+  const double bt_starsq = (gm1 - (gm1 - 1.0) * y) * btsq;
+  const double vaxsq = b1 * b1 / d;
+  const double hp = h - (vaxsq + btsq / d);
+  const double twid_asq = fmax((gm1 * (hp - 0.5 * vsq) - (gm1 - 1.0) * x), ORC_TINY_NUMBER);
+  /* fast and slow speeds (eq. B18) */
+  const double ct2 = bt_starsq / d;
+  const double tsum = vaxsq + ct2 + twid_asq;
+  const double tdif = vaxsq + ct2 - twid_asq;
+  const double cf2_cs2 = sqrt(tdif * tdif + 4.0 * twid_asq * ct2);
+  const double cfsq = 0.5 * (tsum + cf2_cs2);
+  const double cf = sqrt(cfsq);
+  const double cssq = twid_asq * vaxsq / cfsq;
+  const double cs = sqrt(cssq);
+  /* betas (eqs. A17, B20, B28) */
+  const double bt = sqrt(btsq);
+  const double bt_star = sqrt(bt_starsq);
+  double bet2 = 1.0, bet3 = 0.0;
+  if (bt != 0.0) {
+    bet2 = b2 / bt;
+    bet3 = b3 / bt;
+  }
+  const double bet2_star = bet2 / sqrt(gm1 - (gm1 - 1.0) * y);
+  const double bet3_star = bet3 / sqrt(gm1 - (gm1 - 1.0) * y);
+  const double bet_starsq = bet2_star * bet2_star + bet3_star * bet3_star;
+  const double vbet = v2 * bet2_star + v3 * bet3_star;
+  /* alphas (eq. A16) */
+  double alpha_f, alpha_s;
+  if ((cfsq - cssq) == 0.0) {
+    alpha_f = 1.0;
+    alpha_s = 0.0;
+  } else if ((twid_asq - cssq) <= 0.0) {
+    alpha_f = 0.0;
+    alpha_s = 1.0;
+  } else if ((cfsq - twid_asq) <= 0.0) {
+    alpha_f = 1.0;
+    alpha_s = 0.0;
+  } else {
+    alpha_f = sqrt((twid_asq - cssq) / (cfsq - cssq));
+    alpha_s = sqrt((cfsq - twid_asq) / (cfsq - cssq));
+  }
+  /* Q and A (eqs. A14-15) */
+  const double sqrtd = sqrt(d);
+  const double isqrtd = 1.0 / sqrtd;
+  const double sgn = (b1 < 0.0) ? -1.0 : 1.0; /* Parthenon SIGN */
+  const double twid_a = sqrt(twid_asq);
+  const double qf = cf * alpha_f * sgn;
+  const double qs = cs * alpha_s * sgn;
+  const double af_prime = twid_a * alpha_f * isqrtd;
+  const double as_prime = twid_a * alpha_s * isqrtd;
+  const double afpbb = af_prime * bt_star * bet_starsq;
+  const double aspbb = as_prime * bt_star * bet_starsq;
+  const double vax = sqrt(vaxsq);
+  /* eigenvalues (eq. B17): fast-, Alfven-, slow-, entropy, slow+, Alfven+, fast+ */
+  const double lam[7] = {v1 - cf, v1 - vax, v1 - cs, v1, v1 + cs, v1 + vax, v1 + cf};
+  for (int w = 0; w < 7; ++w) ev[w] = lam[w];
+  /* right eigenvectors (eq. B21), one ROW of this table per wave family = one COLUMN of rem */
+  const double af_v2 = alpha_f * v2, as_v2 = alpha_s * v2, qs_b2 = qs * bet2_star, qf_b2 = qf * bet2_star;
+  const double af_v3 = alpha_f * v3, as_v3 = alpha_s * v3, qs_b3 = qs * bet3_star, qf_b3 = qf * bet3_star;
+  const double e_alf = -(v2 * bet3 - v3 * bet2);
+  const double fam[7][7] = {
+      {alpha_f, alpha_f * lam[0], af_v2 + qs_b2, af_v3 + qs_b3, alpha_f * (hp - v1 * cf) + qs * vbet + aspbb,
+       as_prime * bet2_star, as_prime * bet3_star},
+      {0.0, 0.0, -bet3, bet2, e_alf, -bet3 * sgn * isqrtd, bet2 * sgn * isqrtd},
+      {alpha_s, alpha_s * lam[2], as_v2 - qf_b2, as_v3 - qf_b3, alpha_s * (hp - v1 * cs) - qf * vbet - afpbb,
+       -af_prime * bet2_star, -af_prime * bet3_star},
+      {1.0, v1, v2, v3, 0.5 * vsq + (gm1 - 1.0) * x / gm1, 0.0, 0.0},
+      {alpha_s, alpha_s * lam[4], as_v2 + qf_b2, as_v3 + qf_b3, alpha_s * (hp + v1 * cs) + qf * vbet - afpbb,
+       -af_prime * bet2_star, -af_prime * bet3_star},
+      {0.0, 0.0, bet3, -bet2, -e_alf, -bet3 * sgn * isqrtd, bet2 * sgn * isqrtd},
+      {alpha_f, alpha_f * lam[6], af_v2 - qs_b2, af_v3 - qs_b3, alpha_f * (hp + v1 * cf) - qs * vbet + aspbb,
+       as_prime * bet2_star, as_prime * bet3_star}};
+  for (int w = 0; w < 7; ++w)
+    for (int r = 0; r < 7; ++r) rem[r][w] = fam[w][r];
+}
+
+/* InitUserMeshData (linear_wave_mhd.cpp:68-172): the hydro wave's geometry (lw_setup) and the magnetised
+ * background d0 = 1, p0 = 1/gamma, B = (1, sqrt 2, 1/2) in the wave frame */
+static void lwm_setup(orc_sim *s, double vflow) {
+  lw_setup(s, vflow); /* angles, lambda, k_par, d0, u0, p0: the same expressions (:91-143 == linear_wave.cpp:86-140) */
+  s->lwm_bx0 = 1.0;
+  s->lwm_by0 = sqrt(2.0);
+  s->lwm_bz0 = 0.5;
+  const double d0 = s->lw_d0, u0 = s->lw_u0, p0 = s->lw_p0, v0 = 0.0, w0 = 0.0;
+  double h0 = ((p0 / s->lw_gm1 + 0.5 * d0 * (u0 * u0 + v0 * v0 + w0 * w0)) + p0) / d0;
+  h0 += (s->lwm_bx0 * s->lwm_bx0 + s->lwm_by0 * s->lwm_by0 + s->lwm_bz0 * s->lwm_bz0) / d0;
+  lwm_eigensystem(s->lw_gm1, d0, u0, v0, w0, h0, s->lwm_bx0, s->lwm_by0, s->lwm_bz0, 0.0, 1.0, s->lwm_ev, s->lwm_rem);
+}
+
+/* vector potential in the gauge Ax = 0 (linear_wave_mhd.cpp:443-479) */
+static void lwm_A(const orc_sim *s, double x1, double x2, double x3, double A[3]) {
+  const double x = x1 * s->lw_cos_a2 * s->lw_cos_a3 + x2 * s->lw_cos_a2 * s->lw_sin_a3 + x3 * s->lw_sin_a2;
+  const double y = -x1 * s->lw_sin_a3 + x2 * s->lw_cos_a3;
+  const double Ay = s->lwm_bz0 * x - (s->lwm_dbz / s->lw_kpar) * cos(s->lw_kpar * (x));
+  const double Az = -s->lwm_by0 * x + (s->lwm_dby / s->lw_kpar) * cos(s->lw_kpar * (x)) + s->lwm_bx0 * y;
+  A[0] = -Ay * s->lw_sin_a3 - Az * s->lw_sin_a2 * s->lw_cos_a3;
+  A[1] = Ay * s->lw_cos_a3 - Az * s->lw_sin_a2 * s->lw_sin_a3;
+  A[2] = Az * s->lw_cos_a2;
+}
+
+/* analytic d, m1, m2, m3, E at a cell centre (linear_wave_mhd.cpp:407-436 == :199-224) */
+static void lwm_hydro_part(const orc_sim *s, int wf, double amp, double vflow, double x1, double x2, double x3, double u[5],
+                           double *sn_out) {
+  const double x = s->lw_cos_a2 * (x1 * s->lw_cos_a3 + x2 * s->lw_sin_a3) + x3 * s->lw_sin_a2;
+  const double sn = sin(s->lw_kpar * x);
+  u[ORC_IDN] = s->lw_d0 + amp * sn * s->lwm_rem[0][wf];
+  const double mx = s->lw_d0 * vflow + amp * sn * s->lwm_rem[1][wf];
+  const double my = amp * sn * s->lwm_rem[2][wf];
+  const double mz = amp * sn * s->lwm_rem[3][wf];
+  u[ORC_IM1] = mx * s->lw_cos_a2 * s->lw_cos_a3 - my * s->lw_sin_a3 - mz * s->lw_sin_a2 * s->lw_cos_a3;
+  u[ORC_IM2] = mx * s->lw_cos_a2 * s->lw_sin_a3 + my * s->lw_cos_a3 - mz * s->lw_sin_a2 * s->lw_sin_a3;
+  u[ORC_IM3] = mx * s->lw_sin_a2 + mz * s->lw_cos_a2;
+  double e0 = s->lw_p0 / s->lw_gm1 + 0.5 * s->lw_d0 * s->lw_u0 * s->lw_u0 + amp * sn * s->lwm_rem[4][wf];
+  e0 += 0.5 * (s->lwm_bx0 * s->lwm_bx0 + s->lwm_by0 * s->lwm_by0 + s->lwm_bz0 * s->lwm_bz0);
+  u[ORC_IEN] = e0;
+  *sn_out = sn;
+}
+
+/* ProblemGenerator (linear_wave_mhd.cpp:370-441): B = curl A by centred differences of the cell-centred
+ * potential; returns the wave period lambda / |ev[wave_flag]| ("test = true" reinterprets tlim in periods) */
+double orc_pgen_linear_wave_mhd(orc_sim *s, int wave_flag, double amp, double vflow) {
+  lwm_setup(s, vflow);
+  s->lwm_dby = amp * s->lwm_rem[5][wave_flag];
+  s->lwm_dbz = amp * s->lwm_rem[6][wave_flag];
+  const sb_t bb = sim_bounds(&s->g);
+  const double dx1 = s->g.dx[0], dx2 = s->g.dx[1], dx3 = s->g.dx[2];
+  for (int b = 0; b < s->nblocks; ++b) {
+    double x0[3];
+    orc_sim_block_origin(s, b, x0);
+    double *u = s->cons[b];
+    for (int k = bb.ks; k <= bb.ke; ++k)
+      for (int j = bb.js; j <= bb.je; ++j)
+        for (int i = bb.is; i <= bb.ie; ++i) {
+          const double X1 = xc(s, x0, 0, i), X2 = xc(s, x0, 1, j), X3 = xc(s, x0, 2, k);
+          double w[5], sn;
+          lwm_hydro_part(s, wave_flag, amp, vflow, X1, X2, X3, w, &sn);
+          for (int n = 0; n < 5; ++n) SAT(u, n, k, j, i) = w[n];
+          double Ajp[3], Ajm[3], Akp[3], Akm[3], Aip[3], Aim[3];
+          lwm_A(s, X1, xc(s, x0, 1, j + 1), X3, Ajp);
+          lwm_A(s, X1, xc(s, x0, 1, j - 1), X3, Ajm);
+          lwm_A(s, X1, X2, xc(s, x0, 2, k + 1), Akp);
+          lwm_A(s, X1, X2, xc(s, x0, 2, k - 1), Akm);
+          lwm_A(s, xc(s, x0, 0, i + 1), X2, X3, Aip);
+          lwm_A(s, xc(s, x0, 0, i - 1), X2, X3, Aim);
+          SAT(u, ORC_IB1, k, j, i) = (Ajp[2] - Ajm[2]) / dx2 / 2.0 - (Akp[1] - Akm[1]) / dx3 / 2.0;
+          SAT(u, ORC_IB2, k, j, i) = (Akp[0] - Akm[0]) / dx3 / 2.0 - (Aip[2] - Aim[2]) / dx1 / 2.0;
+          SAT(u, ORC_IB3, k, j, i) = (Aip[1] - Aim[1]) / dx1 / 2.0 - (Ajp[0] - Ajm[0]) / dx2 / 2.0;
+        }
+  }
+  return s->lw_lambda / fabs(s->lwm_ev[wave_flag]);
+}
+
+/* the eigensystem the last orc_pgen_linear_wave_mhd used: ev[7], rem[7][7] row-major (tests) */
+void orc_linear_wave_mhd_eigen(const orc_sim *s, double *ev7, double *rem49) {
+  for (int w = 0; w < 7; ++w) ev7[w] = s->lwm_ev[w];
+  for (int r = 0; r < 7; ++r)
+    for (int w = 0; w < 7; ++w) rem49[r * 7 + w] = s->lwm_rem[r][w];
+}
+
+/* UserWorkAfterLoop (linear_wave_mhd.cpp:177-276): volume-weighted L1 and max errors of d, M1, M2, M3, E, B1, B2, B3
+ * (psi excluded) against the analytic wave with the ANALYTIC field (not curl A); returns the RMS of the L1 errors */
+double orc_linear_wave_mhd_errors(orc_sim *s, int wave_flag, double amp, double vflow, double *l1, double *maxerr) {
+  const sb_t bb = sim_bounds(&s->g);
+  const double cellvol = s->g.dx[0] * s->g.dx[1] * s->g.dx[2];
+  const double ca2 = s->lw_cos_a2, sa2 = s->lw_sin_a2, ca3 = s->lw_cos_a3, sa3 = s->lw_sin_a3;
+  for (int n = 0; n < 8; ++n) l1[n] = maxerr[n] = 0.0;
+  for (int b = 0; b < s->nblocks; ++b) {
+    double x0[3];
+    orc_sim_block_origin(s, b, x0);
+    for (int k = bb.ks; k <= bb.ke; ++k)
+      for (int j = bb.js; j <= bb.je; ++j)
+        for (int i = bb.is; i <= bb.ie; ++i) {
+          double a[8], sn;
+          lwm_hydro_part(s, wave_flag, amp, vflow, xc(s, x0, 0, i), xc(s, x0, 1, j), xc(s, x0, 2, k), a, &sn);
+          const double bx = s->lwm_bx0;
+          const double by = s->lwm_by0 + amp * sn * s->lwm_rem[5][wave_flag];
+          const double bz = s->lwm_bz0 + amp * sn * s->lwm_rem[6][wave_flag];
+          a[ORC_IB1] = bx * ca2 * ca3 - by * sa3 - bz * sa2 * ca3;
+          a[ORC_IB2] = bx * ca2 * sa3 + by * ca3 - bz * sa2 * sa3;
+          a[ORC_IB3] = bx * sa2 + bz * ca2;
+          for (int n = 0; n < 8; ++n) {
+            const double e = fabs(a[n] - SAT(s->cons[b], n, k, j, i));
+            l1[n] += e * cellvol;
+            if (e > maxerr[n]) maxerr[n] = e;
+          }
+        }
+  }
+  const double vol = (s->p.xmax[0] - s->p.xmin[0]) * (s->p.xmax[1] - s->p.xmin[1]) * (s->p.xmax[2] - s->p.xmin[2]);
+  double rms = 0.0;
+  for (int n = 0; n < 8; ++n) {
     l1[n] = l1[n] / vol;
     rms += l1[n] * l1[n];
   }

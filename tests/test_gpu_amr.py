@@ -586,6 +586,55 @@ def test_regridding_moves_the_state_as_the_forest_oracle_does(oracle):
     assert max(sizes) > sizes[0] and sizes[-1] < max(sizes) and levels == {0, 1, 2} and s.amr_stats()[0] > 0 and s.amr_stats()[1] > 0
 
 
+@pytest.mark.parametrize("interval", [1, 3])
+@pytest.mark.parametrize("criterion", ["pressure_gradient", "xyvelocity_gradient"])
+def test_adaptive_tagging_reads_complete_ghost_zones(oracle, criterion, interval):
+    """The gradient criteria difference every cell of the ring [s-1, e+1]^3 round a block (refinement/gradient.cpp:33-36),
+    ghost cells behind edges and corners included -- which the stage loop's faces-only exchange does not fill (round-2
+    advisor finding: the in-step tagging read them stale).  An adaptive blast run with the faces-only exchange must
+    arrive at the forest, the state and the criterion values of the same run with every exchange complete, cycle by cycle
+    and bit for bit, and the tags the step acted on must be the oracle's on the complete blocks."""
+    import helpers as H
+    from athenapk_amd import lib as L
+    # (blasts on which the forest keeps changing: the pressure-gradient patch grows and flaps between 323 and 512
+    # blocks from cycle 27 on, the velocity-gradient patch grows 64 -> 120 -> 176 -> 400 in the first 12 cycles)
+    ov = ["parthenon/mesh/numlevel=3", "parthenon/mesh/derefine_count=2", "parthenon/mesh/check_refine_interval=%d" % interval,
+          "problem/blast/pressure_ambient=1.0", "refinement/type=%s" % criterion]
+    if criterion == "pressure_gradient":
+        thr, ncycles = 0.5, 36
+        ov += ["problem/blast/pressure_ratio=1000", "problem/blast/radius_outer=0.1", "problem/blast/radius_inner=0.05"]
+    else:
+        thr, ncycles = 0.4, 15
+        ov += ["problem/blast/pressure_ratio=100", "problem/blast/radius_outer=0.12", "problem/blast/radius_inner=0.072"]
+    ov.append("refinement/threshold_%s=%g" % (criterion, thr))
+    a = _sim("blast_3d_amr", ov, strict=True).initialize()
+    b = _sim("blast_3d_amr", ov, strict=True)
+    b.set_amr_full_exchange(True)
+    b.initialize()
+    sizes = set()
+    for cyc in range(ncycles):
+        a.step()
+        b.step()
+        pa, pb = placement(a), placement(b)
+        assert [(p[0], tuple(p[1])) for p in pa] == [(p[0], tuple(p[1])) for p in pb], "forests differ after cycle %d" % (cyc + 1)
+        assert a.dt == b.dt
+        sizes.add(len(pa))
+    assert len(sizes) > 1, "the mesh never changed (%s): the test does not exercise regridding" % sorted(sizes)
+    ta, ca = a.check_refinement()
+    tb, cb = b.check_refinement()
+    assert list(ta) == list(tb) and np.array_equal(np.asarray(ca), np.asarray(cb))
+    i = a.refresh_info()
+    for lb in range(i.nblocks_total):
+        assert np.array_equal(a.read_block(lb), b.read_block(lb)), "block %d" % lb
+    # the oracle's criterion on the complete blocks (accessors complete the ghost zones)
+    pl = placement(a)
+    fluid = "glmmhd" if i.fluid == L.FLUID["glmmhd"] else "euler"
+    for lb in range(0, i.nblocks_total, 7):
+        g = H.geom(fluid, tuple(i.mb), i.ng, 0, tuple(pl[lb][3]))
+        t, c = oracle.tag(criterion, g, np.ascontiguousarray(a.read_block(lb, "prim")), thr)
+        assert t == ta[lb] and c == ca[lb], "block %d: oracle tag %d crit %.17g, device %d %.17g" % (lb, t, c, ta[lb], ca[lb])
+
+
 def test_cli_runs_the_amr_deck(tmp_path, capsys):
     from athenapk_amd import __main__ as cli
     assert cli.main(["-i", "blast_3d_amr", "-d", str(tmp_path), "parthenon/time/tlim=0.01"]) == 0

@@ -6,8 +6,10 @@
         overrides; wenoz => nghost = 3, src/hydro/hydro.cpp:334-336; driver src/pgen/turbulence.cpp:373-482)
         -- against the oracle at 32^3 on 1 and 2 ranks, by properties at the full 512^3
   cfg5  blast_3d_amr: 4 levels, 64^3 root in 16^3 meshblocks, GLM-MHD PPM + HLLD, the deck's own
-        near-vacuum ambient medium and pressure ratio 1.6e8 with first_order_flux_correct
-        (inputs/blast_3d_amr.in:12-56, IC src/pgen/blast.cpp:151-199)
+        near-vacuum ambient medium and pressure ratio 1.6e8 (inputs/blast_3d_amr.in:12-56, IC
+        src/pgen/blast.cpp:151-199).  The deck sets no first_order_flux_correct and the run needs none
+        (400 cycles below); a second test switches the option on and must reproduce the run without it
+        while no cell fails FirstOrderFluxCorrect's test
 """
 import os
 import socket
@@ -180,7 +182,7 @@ def test_config4_full_size_512_cubed_forced_turbulence_properties():
 # ---- config 5: the adaptive blast as specified ---------------------------------------------------------------
 CFG5 = ["parthenon/mesh/nx%d=64" % d for d in (1, 2, 3)] + ["parthenon/meshblock/nx%d=16" % d for d in (1, 2, 3)] + [
     "parthenon/mesh/numlevel=4", "hydro/fluid=glmmhd", "hydro/riemann=hlld", "hydro/reconstruction=ppm",
-    "parthenon/mesh/nghost=4", "hydro/first_order_flux_correct=true"]
+    "parthenon/mesh/nghost=4"]
 
 
 def _forest_is_octant_symmetric(s, root_blocks):
@@ -206,7 +208,7 @@ def test_config5_adaptive_mhd_blast_as_decked():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_gpu_amr import _totals
     from amr_emulator import placement
-    ov = [o for o in CFG5 if "first_order" not in o] + ["parthenon/time/tlim=1.0"]
+    ov = CFG5 + ["parthenon/time/tlim=1.0"]
     s = _sim("blast_3d_amr", ov, strict=False).initialize()
     i = s.refresh_info()
     pl = placement(s)
@@ -238,7 +240,7 @@ def test_config5_with_first_order_flux_correct_enabled():
     optimistic fused stage and is tested like FirstOrderFluxCorrect's trial update before the
     coarse-fine correction.  While no cell fails the test the run must equal the run without the
     option bit for bit (parity build); the number of corrected cells is reported either way."""
-    ov = [o for o in CFG5 if "first_order" not in o] + ["parthenon/time/tlim=1.0"]
+    ov = CFG5 + ["parthenon/time/tlim=1.0"]
     a = _sim("blast_3d_amr", ov + ["hydro/first_order_flux_correct=true"], strict=True).initialize()
     b = _sim("blast_3d_amr", ov + ["hydro/first_order_flux_correct=false"], strict=True).initialize()
     for _ in range(60):

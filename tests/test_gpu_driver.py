@@ -53,6 +53,65 @@ def test_config1_linear_wave_matches_oracle(oracle, strict):
         assert rms == rms_o
 
 
+# ---- MHD linear waves (src/pgen/linear_wave_mhd.cpp): north_star's "linear-wave L1 error within 1e-12" on the MHD path ----
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("wave_flag,vflow", [(0, 0.0), (1, 0.0), (2, 0.0), (3, 1.0), (6, 0.0)],
+                         ids=["fast", "alfven", "slow", "entropy", "fast_plus"])
+def test_mhd_linear_wave_matches_oracle(oracle, wave_flag, vflow, strict):
+    """inputs/linear_wave_mhd3d.in at 32 x 16 x 16 (two meshblocks), PPM + HLLD + Dedner, RK3, one wave period: problem
+    generator (B = curl A), time step, every cycle and the error norms of d, M1..3, E, B1..3 -- bit for bit in the parity
+    build; in the product build (FMA contraction, reciprocal-based divides) the L1 norms within north_star's 1e-12
+    (1e-4 of the error of 1e-8 itself)."""
+    ov = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=16", "parthenon/mesh/nx3=16", "parthenon/meshblock/nx1=16",
+          "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=16", "problem/linear_wave/wave_flag=%d" % wave_flag,
+          "problem/linear_wave/vflow=%g" % vflow]
+    s = _sim("linear_wave_mhd3d", ov, strict=strict).initialize()
+    o = oracle.Sim(fluid="glmmhd", recon="ppm", riemann="hlld", integrator="rk3", nx=(32, 16, 16), mb=(16, 16, 16), ng=3,
+                   xmax=(3.0, 1.5, 1.5), cfl=0.3, gamma=GAMMA_DECK, nthreads=os.cpu_count())
+    o.pgen("linear_wave_mhd", wave_flag=wave_flag, amp=1e-6, vflow=vflow)
+    assert s.tlim == o.period  # "test = true": one wave period
+    _assert_same(s.gather("cons"), o.gather_cons(), strict)      # the problem generator (host arithmetic; FMAs in the product build)
+    if strict:
+        assert s.dt == o.dt
+    n_gpu = s.run()
+    n_cpu = o.run(o.period)
+    assert n_gpu == n_cpu
+    # Product build (FMA contraction, reciprocal-based divides): a 1e-6 wave on an O(1) background puts PPM's extremum
+    # tests within round-off of their thresholds in a few cells per cycle; a flipped limiter branch moves a cell by
+    # ~1e-10 (1 % of the truncation error), so after a period the two builds sit up to ~1e-10 apart (measured: 1e-12
+    # after one cycle, 1.2e-10 after the slow wave's 143).  Bound: 1e-3 of the wave amplitude.  What north_star bounds
+    # -- the L1 error norm -- is compared to 1e-12 below.
+    if strict:
+        _assert_same(s.gather("cons"), o.gather_cons(), True)
+    else:
+        assert np.max(np.abs(s.gather("cons") - o.gather_cons())) <= 1e-9
+    rms, l1, mx = s.linear_wave_mhd_errors()
+    rms_o, l1_o, mx_o = o.linear_wave_errors()
+    assert l1.shape == (8,) and rms_o > 1e-10
+    assert abs(rms - rms_o) <= 1e-12 and np.all(np.abs(l1 - l1_o) <= 1e-12) and np.all(np.abs(mx - mx_o) <= 1e-9)
+    if strict:
+        assert rms == rms_o and np.array_equal(l1, l1_o) and np.array_equal(mx, mx_o)
+
+
+def test_mhd_linear_wave_error_file(tmp_path):
+    """the MHD problem's linearwave-errors.dat: 4 + (1 + 8) + (1 + 8) columns, read the way the reference's
+    convergence scripts read the file (np.genfromtxt; column 4 = RMS-L1), one row appended per run"""
+    ov = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=16", "parthenon/mesh/nx3=16", "parthenon/meshblock/nx1=16",
+          "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=16", "parthenon/time/tlim=0.1"]
+    path = tmp_path / "linearwave-errors.dat"
+    for n in range(2):
+        s = _sim("linear_wave_mhd3d", ov).initialize()
+        s.run()
+        s.write_linear_wave_errors(path)
+        rms, l1, mx = s.linear_wave_mhd_errors()
+    data = np.atleast_2d(np.genfromtxt(path))
+    assert data.shape == (2, 22) and tuple(data[1, :3]) == (32, 16, 16)
+    assert data[1, 4] == float("%e" % rms) and data[1, 10] == float("%e" % l1[5])
+    with open(path) as f:
+        head = f.readline()
+    assert head.startswith("# Nx1  Nx2  Nx3  Ncycle  RMS-L1-Error  d_L1") and "B3c_L1" in head and "B3c_max" in head
+
+
 def test_meshblock_decomposition_and_fused_path_do_not_change_a_bit(oracle):
     base = ["parthenon/time/integrator=vl2", "parthenon/time/tlim=0.1"]
     a = _sim("linear_wave3d", base, fused=True).initialize()

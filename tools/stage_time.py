@@ -23,6 +23,7 @@ ap.add_argument("--riemann", default="hlld")
 ap.add_argument("--nb", type=int, default=8)
 ap.add_argument("--n", type=int, default=128)
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--generic", action="store_true", help="no variable exactly constant along an axis (PPM's extremum test fires on exact ties)")
 a = ap.parse_args()
 ng = 3 if a.recon in ("ppm", "wenoz") else 2
 nb, n = a.nb, a.n
@@ -43,6 +44,9 @@ for b in range(nb):
     w[b, 6] = 0.5 * torch.cos(k - i)
     w[b, 7] = 0.5 * torch.sin(i + j + ph)
     w[b, 8] = 0.01 * torch.sin(i + j + k)
+if a.generic:
+    for v in range(9):
+        w[:, v] += 0.003 * torch.sin(i + 1.3 * j + 0.7 * k + 0.9 * v)
 gamma = 5.0 / 3.0
 u = w.clone()
 u[:, 1:4] = w[:, 0:1] * w[:, 1:4]
