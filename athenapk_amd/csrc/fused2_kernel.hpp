@@ -378,7 +378,13 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
 //  * the x1 stencil from the ring row at lane offsets -2 .. +2 (5 ds_read_b64 instead of 1 + 8 DPP moves per variable,
 //    -72 VALU instructions per iteration): 3.40 ms, no change -- the kernel is not short of VALU issue slots alone;
 //  * PPM's extremum branches switched off altogether (wrong results; the ceiling of any scheme that makes them
-//    cheaper, e.g. compacting the few lanes that take them): 2.97 ms, -12 %.
+//    cheaper): 2.97 ms, -12 %.  COMPACTING the cells that take them -- the lanes park the seven operands of
+//    ppm_cell's extremum limiter in 2 KB of LDS beside the ring, item after item across the nine variables, the first
+//    lanes of the wave then run the limiter once for all of them and the owners read their results back; bit-exact --
+//    was built for the x3 sweep and measured: 0.809 against 0.770 ms.  Ballots, rank computation, the staging writes
+//    and the second pass cost more than the seven-odd masked executions of the ~60-instruction branch they replace;
+//  * the nine per-variable offsets n * sn of d3 / u1 / u0 / prim' as ONE walking pointer (8 SGPR pairs fewer: scalar
+//    spills 87 -> 72, scratch 28 -> 20 B per lane): no change (2.60 against 2.58 ms for this kernel).
 // number of waves the device holds at once with two march waves per SIMD
 inline int resident_march_waves() {
   static const int n = [] {
@@ -400,7 +406,8 @@ inline int resident_march_waves() {
 inline bool two_kernel_stage_applies(const PackView &u0, int recon, int extra, const StageParams &sp) {
   static const int mode = std::getenv("APK_STAGE_MODE") ? std::atoi(std::getenv("APK_STAGE_MODE")) : 2;  // A/B switch: 3 = three sweeps
   if (mode == 3) return false;
-  return u0.ndim == 3 && recon != APK_RC_DC && u0.nx1 >= 32 && (extra == EXTRA_NONE || sp.prim_to_u1);
+  static const int min_nx1 = std::getenv("APK_M12_MIN_NX1") ? std::atoi(std::getenv("APK_M12_MIN_NX1")) : 32;  // A/B switch
+  return u0.ndim == 3 && recon != APK_RC_DC && u0.nx1 >= min_nx1 && (extra == EXTRA_NONE || sp.prim_to_u1);
 }
 
 template <int FLUID, int RECON, int RS>

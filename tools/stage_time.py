@@ -64,6 +64,8 @@ def stage():
 
 for _ in range(2):
     stage()
+import ctypes as C
+ctx.lib.apk_kernel_timing_enable(ctx.h, 1)
 st = torch.cuda.current_stream()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(st)
@@ -72,6 +74,14 @@ for _ in range(a.reps):
 e1.record(st)
 e1.synchronize()
 ms = e0.elapsed_time(e1) / a.reps
+per = []
+for slot, name in enumerate(L.TIMING_SLOTS):
+    tms, n = C.c_double(0.0), C.c_longlong(0)
+    ctx.lib.apk_kernel_timing_read(ctx.h, slot, C.byref(tms), C.byref(n))
+    if n.value:
+        per.append("%s %.3f" % (name, tms.value / n.value))
+ctx.lib.apk_kernel_timing_enable(ctx.h, 0)
+print("per kernel (ms):", ", ".join(per))
 cells = nb * n ** 3
 bytes_per = 288.0 if a.gam0 else 216.0
 print("stage %.3f ms | %.3e cell-stage-updates/s | %.1f GB/s at %d B = %.2f %% of 8 TB/s" % (
