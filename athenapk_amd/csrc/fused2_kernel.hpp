@@ -130,9 +130,9 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     const int s = u0.js + j0, e = s + nrows - 1;
     const int64_t base = (int64_t)(u0.ks + krow) * u0.sk + i;
     const double dx1 = b0.dx[0], dx2 = b0.dx[1];
-    const double area1 = b0.dx[1] * b0.dx[2];
-    const double area2 = b0.dx[0] * b0.dx[2];
-    const double vol = b0.dx[0] * b0.dx[1] * b0.dx[2];
+    const double area1 = to_sgpr(b0.dx[1] * b0.dx[2]);  // (per block: wave-uniform)
+    const double area2 = to_sgpr(b0.dx[0] * b0.dx[2]);
+    const double vol = to_sgpr(b0.dx[0] * b0.dx[1] * b0.dx[2]);
     const double *prim = b0.prim + base;
     // Direct neighbour addressing (sp.face_nbr): a lane on a ghost column reads the interior column
     // of the block behind that x1 face; the stencil rows below js / above je of an interior column
@@ -241,7 +241,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
           wl[q] = lane_below<1>(ql1[perm<1>(q)], lane);
           wr[q] = qr1[perm<1>(q)];
         }
-        riemann<FLUID, RS>(wl, wr, sp.gamma, sp.c_h, f1);
+        riemann<FLUID, RS>(wl, wr, sp.k, f1);
         double fup0 = 0.0;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
@@ -313,7 +313,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
           double wr[NV];
 #pragma unroll
           for (int q = 0; q < NV; ++q) wr[q] = qrn[perm<2>(q)];
-          riemann<FLUID, RS>(wl_prev, wr, sp.gamma, sp.c_h, f);
+          riemann<FLUID, RS>(wl_prev, wr, sp.k, f);
         }
         if (retire) {
           if constexpr (APK_M12F_LOADS == 3) {
@@ -401,13 +401,17 @@ inline int resident_march_waves() {
 // can / should a stage take the two-kernel form?  3-D, a reconstruction with a stencil (ghost
 // layers), FillDerived out of place or absent (K2's lanes read their x1 neighbours' primitives from
 // memory), and rows long enough that the flattened (k, i) run keeps most lanes on interior cells
-// (nx1 / (nx1 + 2 ng): 128 -> 96 %, 32 -> 84 %; narrower meshblocks keep the three-sweep schedule
-// with several rows per wave).
+// (nx1 / (nx1 + 2 ng): 128 -> 96 %, 32 -> 84 %, 16 with nghost 4 -> 67 %).  Measured on the refined mesh of
+// BASELINE config 5 (232 blocks of 16^3, MHD PPM+HLLD, nghost 4): 8.52e8 against 8.36e8 zone-cycles/s for the
+// three-sweep schedule with several rows per wave, so 16-cell blocks take it too; narrower ones do not.
 inline bool two_kernel_stage_applies(const PackView &u0, int recon, int extra, const StageParams &sp) {
   static const int mode = std::getenv("APK_STAGE_MODE") ? std::atoi(std::getenv("APK_STAGE_MODE")) : 2;  // A/B switch: 3 = three sweeps
   if (mode == 3) return false;
-  static const int min_nx1 = std::getenv("APK_M12_MIN_NX1") ? std::atoi(std::getenv("APK_M12_MIN_NX1")) : 32;  // A/B switch
-  return u0.ndim == 3 && recon != APK_RC_DC && u0.nx1 >= min_nx1 && (extra == EXTRA_NONE || sp.prim_to_u1);
+  static const int min_nx1 = std::getenv("APK_M12_MIN_NX1") ? std::atoi(std::getenv("APK_M12_MIN_NX1")) : 16;  // A/B switch
+  // (blocks narrower than 32 cells only if they are deep enough along x3 for the plane windows of a split stage --
+  // 4 nghost planes: the driver's overlap rule -- so that taking this form never costs an overlapped exchange)
+  const bool wide_enough = u0.nx1 >= 32 || (u0.nx1 >= min_nx1 && u0.nx3 >= 4 * u0.ng);
+  return u0.ndim == 3 && recon != APK_RC_DC && wide_enough && (extra == EXTRA_NONE || sp.prim_to_u1);
 }
 
 template <int FLUID, int RECON, int RS>

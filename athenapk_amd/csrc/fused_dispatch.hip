@@ -25,6 +25,7 @@ int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
   }
   sp.gamma = a.eos.gamma;
   sp.c_h = a.c_h;
+  sp.k = make_stage_consts(a.eos.gamma, a.c_h, a.eos);
   sp.gam0 = a.gam0;
   sp.gam1 = a.gam1;
   sp.beta_dt = a.beta_dt;

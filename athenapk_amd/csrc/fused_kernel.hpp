@@ -26,6 +26,7 @@
 namespace apk {
 
 struct StageParams {
+  StageConsts k;  // gamma, c_h and what the pointwise functions derive from them (host-evaluated: hydro_math.hpp)
   double gamma, c_h;
   double gam0, gam1, beta_dt;
   double dedner_coeff;
@@ -149,7 +150,7 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
     // read neighbouring columns from memory get prim_dst = u1's prim arrays instead.
     // Floors/ceilings act on `un` before it is stored.
     double w[NV], di;
-    const unsigned fl = cons_to_prim_cell<FLUID>(sp.eos, un, w, di);
+    const unsigned fl = cons_to_prim_cell<FLUID>(sp.eos, sp.k, un, w, di);
     if (fl) atomicOr(sp.flags, fl);
     // (ConsToPrim forms the pressure with 1/rho where the test above divides: a trial stage is
     // only accepted if neither sees a negative state, so an accepted stage never raises flags)
@@ -250,7 +251,7 @@ fused_x1_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_plane) {
     wl[s] = wave_shr1(qln[perm<1>(s)]);
     wr[s] = qrn[perm<1>(s)];
   }
-  riemann<FLUID, RS>(wl, wr, sp.gamma, sp.c_h, f);
+  riemann<FLUID, RS>(wl, wr, sp.k, f);
 
   // cell i needs F(i) (own) and F(i+1) (lane on the right)
   const double a1 = b0.dx[1] * b0.dx[2];
@@ -465,7 +466,7 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
       double wr[NV], f[NV];
 #pragma unroll
       for (int q = 0; q < NV; ++q) wr[q] = qrn[perm<DIR>(q)];
-      riemann<FLUID, RS>(wl_prev, wr, sp.gamma, sp.c_h, f);
+      riemann<FLUID, RS>(wl_prev, wr, sp.k, f);
       if (c >= s + 1) {
         // cell c-1 is complete: (A F(c) - A F(c-1)) joins du
         const int64_t cell = done;
@@ -595,7 +596,7 @@ fused_march12_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_blo
       double wr[NV], f[NV];
 #pragma unroll
       for (int q = 0; q < NV; ++q) wr[q] = qrn[perm<2>(q)];
-      riemann<FLUID, RS>(wl_prev, wr, sp.gamma, sp.c_h, f);
+      riemann<FLUID, RS>(wl_prev, wr, sp.k, f);
       if (c >= s + 1 && active) {
         // cell c-1: du = (x1 term) + (x2 term), the reference's accumulation order
         const int64_t cell = base + (int64_t)(c - 1) * st;
@@ -642,7 +643,7 @@ fused_march12_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_blo
         wl[q] = wave_shr1(ql1[perm<1>(q)]);
         wr[q] = qr1[perm<1>(q)];
       }
-      riemann<FLUID, RS>(wl, wr, sp.gamma, sp.c_h, f);
+      riemann<FLUID, RS>(wl, wr, sp.k, f);
       double fup0 = 0.0;
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
@@ -774,8 +775,8 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
     else return 0.0;
   };
   auto solve = [&](const double (&wl)[NV], const double (&wr)[NV], double cfl, double cfr, double (&f)[NV]) {
-    if constexpr (CF) glmmhd_hlld_cf(wl, wr, sp.gamma, sp.c_h, cfl, cfr, f);
-    else riemann<FLUID, RS>(wl, wr, sp.gamma, sp.c_h, f);
+    if constexpr (CF) glmmhd_hlld_cf(wl, wr, sp.k, cfl, cfr, f);
+    else riemann<FLUID, RS>(wl, wr, sp.k, f);
   };
   double cf3_prev = 0.0;
   if constexpr (CF) {

@@ -37,6 +37,14 @@ enum { IV1 = 1, IV2 = 2, IV3 = 3, IPR = 4 };
 #endif
 
 APK_DEV double sqr(double x) { return x * x; }
+// a wave-uniform value the vector ALU had to compute (there is no scalar fp64 unit), moved into a scalar register
+// pair: it stops occupying two VGPRs of every lane for as long as it lives
+APK_DEV double to_sgpr(double x) {
+#ifdef APK_NO_STAGE_CONSTS  // (A/B)
+  return x;
+#endif
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
 
 // ---- square roots and reciprocals ---------------------------------------------------------------
 // The parity build evaluates the reference's IEEE operations.  In the product build hipcc expands
@@ -532,6 +540,40 @@ APK_DEV void glm_interface(const double (&wl)[NGLMMHD], const double (&wr)[NGLMM
   psii = 0.5 * (wl[IPS] + wr[IPS]) - 0.5 * c_h * (wr[IB1] - wl[IB1]);
 }
 
+// Wave-uniform constants of a fused stage that the pointwise functions derive from gamma, c_h and the EOS limits.
+// There is no scalar fp64 unit: left to the kernels, 1 / (gamma - 1), 0.5 / c_h, c_h^2, vceil^2 ... are computed by
+// the vector ALU in the prologue and then HELD IN VECTOR REGISTERS across the marches -- seven values = 14 VGPRs of
+// kernels that sit at the 256-register limit (the finishing march spilled two of them to scratch and re-read them
+// three times per iteration, each time behind an s_waitcnt vmcnt(0) that also waits for the iteration's stores).
+// The host evaluates the same IEEE expressions once per launch (make_stage_consts, fused_dispatch.hip); as kernel
+// arguments they live in SGPRs and fp64 instructions take them as scalar operands.  Bit-identical in the parity
+// build (same correctly rounded operations); the product build's in-kernel reciprocals were within an ulp of these.
+struct StageConsts {
+  double gamma, c_h;
+  double gm1, igm1;                  // gamma - 1, 1 / (gamma - 1)
+  double half_over_ch, half_ch, ch_sq;  // 0.5 / c_h, 0.5 * c_h, c_h^2 (glm_interface, the psi flux)
+  double eos_gm1, vceil_sq, pfloor_over_gm1;  // ConsToPrim: eos.gamma - 1, eos.vceil^2, eos.pfloor / (eos.gamma - 1)
+};
+inline __host__ __device__ StageConsts make_stage_consts(double gamma, double c_h, const apk_eos &eos) {
+  StageConsts k;
+  k.gamma = gamma;
+  k.c_h = c_h;
+  k.gm1 = gamma - 1.0;
+  k.igm1 = 1.0 / k.gm1;
+  k.half_over_ch = 0.5 / c_h;
+  k.half_ch = 0.5 * c_h;
+  k.ch_sq = c_h * c_h;
+  k.eos_gm1 = eos.gamma - 1.0;
+  k.vceil_sq = eos.vceil * eos.vceil;
+  k.pfloor_over_gm1 = eos.pfloor / k.eos_gm1;
+  return k;
+}
+APK_DEV void glm_interface(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD], const StageConsts &k,
+                           double &bxi, double &psii) {
+  bxi = 0.5 * (wl[IB1] + wr[IB1]) - k.half_over_ch * (wr[IPS] - wl[IPS]);
+  psii = 0.5 * (wl[IPS] + wr[IPS]) - k.half_ch * (wr[IB1] - wl[IB1]);
+}
+
 // src/hydro/rsolvers/glmmhd_hlle.hpp:27-192
 APK_DEV void glmmhd_hlle(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD],
                          double gamma, double c_h, double (&f)[NGLMMHD]) {
@@ -693,14 +735,40 @@ APK_DEV void glmmhd_hlld(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD
   glmmhd_hlld_cf(wl, wr, gamma, c_h, cfl, cfr, f);
 }
 
+// (the solver proper: igm1 = 1 / (gamma - 1), the GLM interface state and c_h^2 handed in)
+APK_DEV void glmmhd_hlld_core(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD], double igm1, double bxi,
+                              double psii, double ch_sq, double cfl, double cfr, double (&f)[NGLMMHD]);
+
 APK_DEV void glmmhd_hlld_cf(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD], double gamma, double c_h,
                             double cfl, double cfr, double (&f)[NGLMMHD]) {
   const double gm1 = gamma - 1.0;
   const double igm1 = 1.0 / gm1;
   double bxi, psii;
   glm_interface(wl, wr, c_h, bxi, psii);
+  glmmhd_hlld_core(wl, wr, igm1, bxi, psii, sqr(c_h), cfl, cfr, f);
+}
+// the same with the stage's constants from the host (StageConsts)
+APK_DEV void glmmhd_hlld_cf(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD], const StageConsts &k,
+                            double cfl, double cfr, double (&f)[NGLMMHD]) {
+#ifdef APK_NO_STAGE_CONSTS
+  glmmhd_hlld_cf(wl, wr, k.gamma, k.c_h, cfl, cfr, f);
+#else
+  double bxi, psii;
+  glm_interface(wl, wr, k, bxi, psii);
+  glmmhd_hlld_core(wl, wr, k.igm1, bxi, psii, k.ch_sq, cfl, cfr, f);
+#endif
+}
+APK_DEV void glmmhd_hlld(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD], const StageConsts &k,
+                         double (&f)[NGLMMHD]) {
+  const double cfl = fast_speed(k.gamma, wl[IDN], wl[IPR], wl[IB1], wl[IB2], wl[IB3]);
+  const double cfr = fast_speed(k.gamma, wr[IDN], wr[IPR], wr[IB1], wr[IB2], wr[IB3]);
+  glmmhd_hlld_cf(wl, wr, k, cfl, cfr, f);
+}
+
+APK_DEV void glmmhd_hlld_core(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD], double igm1, double bxi,
+                              double psii, double ch_sq, double cfl, double cfr, double (&f)[NGLMMHD]) {
   f[IB1] = psii;
-  f[IPS] = sqr(c_h) * bxi;
+  f[IPS] = ch_sq * bxi;
   const double bxsq = bxi * bxi;
 
   Cons1D ul, ur;
@@ -912,6 +980,18 @@ APK_DEV void riemann(const double (&wl)[nvars<FLUID>()], const double (&wr)[nvar
   }
 }
 
+// the same for the fused stage kernels, which carry the stage's derived constants in scalar registers
+template <int FLUID, int RS>
+APK_DEV void riemann(const double (&wl)[nvars<FLUID>()], const double (&wr)[nvars<FLUID>()], const StageConsts &k,
+                     double (&f)[nvars<FLUID>()]) {
+#ifdef APK_NO_STAGE_CONSTS  // (A/B: the constants derived in the kernel, as in round 2)
+  riemann<FLUID, RS>(wl, wr, k.gamma, k.c_h, f);
+#else
+  if constexpr (FLUID == APK_FLUID_GLMMHD && RS == APK_RS_HLLD) glmmhd_hlld(wl, wr, k, f);
+  else riemann<FLUID, RS>(wl, wr, k.gamma, k.c_h, f);
+#endif
+}
+
 // Direction permutation (e.g. glmmhd_hlld.hpp:45-49): natural index of the permuted slot.
 // DIR = 1,2,3 ; slot in {IDN,IV1,IV2,IV3,IPR/IEN,IB1,IB2,IB3,IPS}
 template <int DIR>
@@ -931,11 +1011,29 @@ constexpr int perm(int slot) {
 // u/w hold the NH hydro/MHD variables; returns APK_FLAG_* bits.  u may be modified.
 // ======================================================================================
 template <int FLUID>
+APK_DEV unsigned cons_to_prim_core(const apk_eos &eos, double gm1, double vceil_sq, double pfloor_over_gm1,
+                                   double (&u)[nvars<FLUID>()], double (&w)[nvars<FLUID>()], double &di_out);
+template <int FLUID>
 APK_DEV unsigned cons_to_prim_cell(const apk_eos &eos, double (&u)[nvars<FLUID>()],
                                    double (&w)[nvars<FLUID>()], double &di_out) {
+  const double gm1 = eos.gamma - 1.0;
+  return cons_to_prim_core<FLUID>(eos, gm1, sqr(eos.vceil), eos.pfloor / gm1, u, w, di_out);
+}
+// with the stage's constants from the host (StageConsts)
+template <int FLUID>
+APK_DEV unsigned cons_to_prim_cell(const apk_eos &eos, const StageConsts &k, double (&u)[nvars<FLUID>()],
+                                   double (&w)[nvars<FLUID>()], double &di_out) {
+#ifdef APK_NO_STAGE_CONSTS
+  return cons_to_prim_cell<FLUID>(eos, u, w, di_out);
+#else
+  return cons_to_prim_core<FLUID>(eos, k.eos_gm1, k.vceil_sq, k.pfloor_over_gm1, u, w, di_out);
+#endif
+}
+template <int FLUID>
+APK_DEV unsigned cons_to_prim_core(const apk_eos &eos, double gm1, double vceil_sq, double pfloor_over_gm1,
+                                   double (&u)[nvars<FLUID>()], double (&w)[nvars<FLUID>()], double &di_out) {
   constexpr bool mhd = (FLUID == APK_FLUID_GLMMHD);
   unsigned flags = 0;
-  const double gm1 = eos.gamma - 1.0;
   if (!(strictly_positive(u[IDN]) || eos.dfloor > 0.0)) flags |= APK_FLAG_NEG_DENSITY;
   u[IDN] = (u[IDN] > eos.dfloor) ? u[IDN] : eos.dfloor;
   w[IDN] = u[IDN];
@@ -957,7 +1055,7 @@ APK_DEV unsigned cons_to_prim_cell(const apk_eos &eos, double (&u)[nvars<FLUID>(
     w[IPR] = gm1 * (u[IEN] - e_k);
   }
   const double v2 = sqr(w[IV1]) + sqr(w[IV2]) + sqr(w[IV3]);
-  if (v2 > sqr(eos.vceil)) {
+  if (v2 > vceil_sq) {
     const double v = sqrt(v2);
     w[IV1] *= eos.vceil / v;
     w[IV2] *= eos.vceil / v;
@@ -965,14 +1063,14 @@ APK_DEV unsigned cons_to_prim_cell(const apk_eos &eos, double (&u)[nvars<FLUID>(
     u[IM1] *= eos.vceil / v;
     u[IM2] *= eos.vceil / v;
     u[IM3] *= eos.vceil / v;
-    const double e_k_new = 0.5 * u[IDN] * sqr(eos.vceil);
+    const double e_k_new = 0.5 * u[IDN] * vceil_sq;
     u[IEN] -= e_k - e_k_new;
     e_k = e_k_new;
   }
   if (!(strictly_positive(w[IPR]) || eos.pfloor > 0.0 || eos.efloor > 0.0)) flags |= APK_FLAG_NEG_PRESSURE;
   if ((eos.pfloor > 0.0) && (w[IPR] < eos.pfloor)) {
-    if constexpr (mhd) u[IEN] = (eos.pfloor / gm1) + e_k + e_B;
-    else u[IEN] = (eos.pfloor / gm1) + e_k;
+    if constexpr (mhd) u[IEN] = pfloor_over_gm1 + e_k + e_B;
+    else u[IEN] = pfloor_over_gm1 + e_k;
     w[IPR] = eos.pfloor;
   }
   const double eff_floor = gm1 * u[IDN] * eos.efloor;

@@ -294,22 +294,52 @@ def main():
     ov = ["parthenon/mesh/nx%d=%d" % (d + 1, brick * grid[d]) for d in range(3)]
     ov += ["parthenon/meshblock/nx%d=%d" % (d + 1, mb) for d in range(3)]
     ov += ["parthenon/time/integrator=%s" % integrator, "hydro/reconstruction=%s" % recon, "hydro/riemann=%s" % riemann]
-    sim = driver.Simulation(decks.load(deck), ov, rank=rank, nranks=world, strict=False)
-    if args.unfused:
-        sim.set_fused(False)
-    if os.environ.get("APK_OVERLAP") == "0":  # A/B switch: exchange synchronously
-        sim.set_overlap(False)
-    sim.initialize()
-    info = sim.info
-
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        sim.step()
+    def start(comm):
+        """the sim initialised and warmed up; (sim, error) -- an error leaves no sim behind"""
+        sim = None
+        try:
+            sim = driver.Simulation(decks.load(deck), ov, rank=rank, nranks=world, strict=False, comm=comm)
+            if args.unfused:
+                sim.set_fused(False)
+            if os.environ.get("APK_OVERLAP") == "0":  # A/B switch: exchange synchronously
+                sim.set_overlap(False)
+            sim.initialize()
+            for _ in range(args.warmup):
+                sim.step()
+            torch.cuda.synchronize()
+            if comm is None and os.environ.get("APK_BENCH_INJECT_START_FAILURE") == str(rank):  # (test hook)
+                raise RuntimeError("injected start-up failure on rank %d" % rank)
+            return sim, None
+        except Exception as e:  # noqa: BLE001 -- whatever it is, the other ranks must hear about it
+            try:
+                if sim is not None:
+                    sim.close()
+            except Exception:
+                pass
+            return None, e
+
+    sim, err = start(None)
+    if world > 1:
+        # The native RCCL transport has its first multi-GPU exchange HERE (one-GPU boxes can only self-test it): if
+        # it fails on ANY rank during initialisation or warm-up, every rank starts over on the torch.distributed
+        # callback transport -- loudly, and the line says which transport carried the timed steps.
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            print("[bench] rank %d: start-up failed on some rank (%r here); retrying with comm='torch'" % (rank, err),
+                  file=sys.stderr, flush=True)
+            if sim is not None:
+                sim.close()
+            sim, err = start("torch")
+    if err is not None:
+        raise err
+    info = sim.info
     sim.kernel_timing(True)
     sim.read_kernel_timing()
     barrier()

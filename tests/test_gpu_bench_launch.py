@@ -60,6 +60,24 @@ def test_bench_on_two_ranks_through_the_launcher():
     assert abs(d["value"] - 256 * 128 * 128 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
 
 
+def test_bench_restarts_on_the_callback_transport_when_a_rank_fails_to_start():
+    """a failure on ONE rank during initialisation / warm-up (injected here; on a node it would be the native RCCL
+    transport's first real exchange) makes EVERY rank start over with comm='torch' instead of hanging or dying"""
+    env = dict(os.environ, APK_SHARE_GPU="1", APK_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1",
+               APK_BENCH_INJECT_START_FAILURE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--brick", "64",
+           "--meshblock", "32", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "retrying with comm='torch'" in r.stderr and "injected start-up failure on rank 1" in r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    _check_contract(d, 2, 2, 1)
+    assert "torch.distributed callbacks" in d["config"]["comm_backend"]
+
+
 def test_bench_on_eight_ranks_through_the_launcher():
     """the 2 x 2 x 2 rank grid of the 8-GPU run on 64^3 per rank (one GPU shared by eight processes: slow, but every
     rank has 7 peers, three late faces per block and the same message pattern as on the node)"""

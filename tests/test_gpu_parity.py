@@ -880,7 +880,7 @@ def test_direct_neighbor_addressing_rejects_stage_forms_that_read_ghost_zones(re
     import torch
     from athenapk_amd import hydro
     ctx = _ctx(request, True)
-    nx = (16, 8, 8)                                  # narrower than the two-kernel stage wants: three sweeps
+    nx = (8, 8, 8)                                   # narrower than the two-kernel stage wants: three sweeps
     ng, prim, g = _case("glmmhd", "ppm", nx, nblocks=1)
     cons = H.prim_to_cons("glmmhd", prim, GAMMA)
     a = hydro.MeshData(ctx, nx, ng, 9, dx=tuple(g.dx), nblocks=1, cons=cons, prim=prim, with_flux=False)
