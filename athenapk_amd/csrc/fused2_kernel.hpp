@@ -88,6 +88,26 @@ constexpr int m12_last_lane(int recon) { return 62 - recon_halfwidth(recon); }
 #define APK_M12F_WAVES 2  // resident waves per SIMD the kernel is compiled for (A/B: 1 = 512 VGPRs)
 #endif
 
+#ifndef APK_M12F_TIMING
+// 1 (diagnostic variant build, `make variant VAR=tm VARFLAGS=-DAPK_M12F_TIMING=1`): per-phase shader-clock sums of the
+// march, printed by launch_m12f.  Round 3, general PPM+HLLD stage with FillDerived + dt on 8 x 128^3: x1 reconstruction
+// 28 %, x1 Riemann 8.4 %, x2 reconstruction 21.5 %, x2 Riemann 9.8 %, wait for d3 / u1 9.5 %, finish (incl. the wait for
+// the old u0 the explicit s_waitcnt of this build splits off) 20 %, loop control 2.8 % -- the two HLLD solves, a third of
+// the instructions, take 18 % of the time; PPM with its divergent extremum branches takes half.
+#define APK_M12F_TIMING 0
+#endif
+#if APK_M12F_TIMING
+__device__ unsigned long long g_m12f_phase[8];
+#define APK_TICK(slot)                                            \
+  do {                                                            \
+    const unsigned long long now_ = clock64();                    \
+    if (lane == 0) phase_acc[slot] += now_ - tick_;               \
+    tick_ = now_;                                                 \
+  } while (0)
+#else
+#define APK_TICK(slot) do { } while (0)
+#endif
+
 template <int FLUID, int RECON, int RS, int EXTRA>
 __global__ void __launch_bounds__(64, APK_M12F_WAVES)
 fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves, int per_xcd,
@@ -104,6 +124,10 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
   double lane_min_dt = 1.7976931348623157e308;
   const int64_t st = u0.sj;
   const int64_t run = (int64_t)u0.nx3 * u0.ni;
+#if APK_M12F_TIMING
+  unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tick_ = clock64();
+#endif
 
   long long r = total_rows * w / nwaves;
   const long long r_end = total_rows * (w + 1) / nwaves;
@@ -133,7 +157,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     const double area1 = to_sgpr(b0.dx[1] * b0.dx[2]);  // (per block: wave-uniform)
     const double area2 = to_sgpr(b0.dx[0] * b0.dx[2]);
     const double vol = to_sgpr(b0.dx[0] * b0.dx[1] * b0.dx[2]);
-    const double *prim = b0.prim + base;
+    const double *prim_generic = b0.prim + base;
     // Direct neighbour addressing (sp.face_nbr): a lane on a ghost column reads the interior column
     // of the block behind that x1 face; the stencil rows below js / above je of an interior column
     // come from the block behind the x2 face (wave-uniform offset, not applied on ghost columns:
@@ -147,9 +171,10 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
       gcol = (i < u0.is) || (i > u0.ie);
       if (gcol) {
         const int nb = fn[i < u0.is ? 0 : 1];
-        if (nb >= 0) prim = u0.blocks[nb].prim + base + (i < u0.is ? u0.nx1 : -u0.nx1);
+        if (nb >= 0) prim_generic = u0.blocks[nb].prim + base + (i < u0.is ? u0.nx1 : -u0.nx1);
       }
     }
+    const auto prim = as_global(prim_generic);
     auto row_off = [&](int r) -> int64_t {
       const int64_t d = (r < u0.js) ? nbr_lo : ((r > u0.je) ? nbr_hi : (int64_t)0);  // wave-uniform
       return (int64_t)r * st + (gcol ? (int64_t)0 : d);
@@ -192,6 +217,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     for (; c <= e + 1; ++c) {
       const int64_t done = base + (int64_t)(c - 1) * st;  // the cell this iteration retires
       const bool retire = (c >= s + 1);                   // wave-uniform
+      APK_TICK(0);
       // ---- (1) x1 faces of row c-1 (every lane takes part in the wave shifts).  The row's own
       // values are still in the ring (slot of row c-1: c-1 = (c-H) + H-1); the lanes are
       // consecutive cells of the row, so the stencil neighbours i-2 .. i+2 come from the
@@ -235,6 +261,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
           if constexpr (RECON == APK_RC_WENOZ || RECON == APK_RC_WENO3 || RECON == APK_RC_LIMO3)
             asm volatile("" : "+v"(ql1[n]), "+v"(qr1[n]));
         }
+        APK_TICK(1);  // x1 reconstruction
         double wl[NV], wr[NV], f1[NV];
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
@@ -268,6 +295,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
           for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
         }
       }
+      APK_TICK(2);  // x1 Riemann + flux difference
       // ---- (3) x2: reconstruct cell c from ring rows c-H..c+H-1 and the register row c+H
       double qln[NV], qrn[NV];
       double an[NS];  // ring rows of the next variable (software-pipelined LDS reads)
@@ -306,6 +334,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
 #pragma unroll
         for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + row_off(c + 1 + H)];
       }
+      APK_TICK(3);  // x2 reconstruction, ring write, next-row loads issued
       // ---- (4) x2 face between rows c-1 and c; retire row c-1
       if (c >= s) {
         double f[NV];
@@ -315,6 +344,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
           for (int q = 0; q < NV; ++q) wr[q] = qrn[perm<2>(q)];
           riemann<FLUID, RS>(wl_prev, wr, sp.k, f);
         }
+        APK_TICK(4);  // x2 Riemann
         if (retire) {
           if constexpr (APK_M12F_LOADS == 3) {
             asm volatile("" ::: "memory");
@@ -327,14 +357,18 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
             // -- their exposed latency is the price of not holding 36 VGPRs through the x2 solve.)
             if (active) {  // (ghost-column and overlap lanes retire nothing: 13 % of the lanes)
 #pragma unroll
-              for (int n = 0; n < NV; ++n) d3v[n] = d3[n * u0.sn + done];
+              for (int n = 0; n < NV; ++n) d3v[n] = as_global(d3)[n * u0.sn + done];
 #pragma unroll
-              for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
+              for (int n = 0; n < NV; ++n) u1v[n] = as_global(c1)[n * u0.sn + done];
             } else {
 #pragma unroll
               for (int n = 0; n < NV; ++n) d3v[n] = 0.0, u1v[n] = 0.0;
             }
           }
+#if APK_M12F_TIMING
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          APK_TICK(5);  // d3 / u1 requested and arrived
+#endif
           // du = (x1 term + x2 term) + x3 term, the reference's accumulation order
 #pragma unroll
           for (int q = 0; q < NV; ++q) {
@@ -351,6 +385,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
             }
             finish_cell<FLUID, EXTRA>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst);
           }
+          APK_TICK(6);  // update, Dedner, ConsToPrim, dt, stores issued
         }
 #pragma unroll
         for (int q = 0; q < NV; ++q) f_prev[q] = f[q];
@@ -359,6 +394,13 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
       for (int q = 0; q < NV; ++q) wl_prev[q] = qln[perm<2>(q)];
     }
   }
+#if APK_M12F_TIMING
+  if (lane == 0) {
+    phase_acc[0] += clock64() - tick_;  // everything outside the ticked phases: prologues, loop control
+#pragma unroll
+    for (int p = 0; p < 8; ++p) atomicAdd(&g_m12f_phase[p], phase_acc[p]);
+  }
+#endif
   if constexpr (EXTRA == EXTRA_C2P_DT) {
     double m = lane_min_dt;
 #pragma unroll
@@ -383,6 +425,8 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
 //    lanes of the wave then run the limiter once for all of them and the owners read their results back; bit-exact --
 //    was built for the x3 sweep and measured: 0.809 against 0.770 ms.  Ballots, rank computation, the staging writes
 //    and the second pass cost more than the seven-odd masked executions of the ~60-instruction branch they replace;
+//  * host-evaluated stage constants (hydro_math.hpp: StageConsts; no scratch left in this kernel, 14 VGPRs fewer)
+//    and global_ instead of flat_ accesses (as_global): both kept, both within 1 % (same-box bench A/B);
 //  * the nine per-variable offsets n * sn of d3 / u1 / u0 / prim' as ONE walking pointer (8 SGPR pairs fewer: scalar
 //    spills 87 -> 72, scratch 28 -> 20 B per lane): no change (2.60 against 2.58 ms for this kernel).
 // number of waves the device holds at once with two march waves per SIMD
@@ -434,6 +478,24 @@ inline void launch_m12f(const PackView &u0, const PackView &u1, const StageParam
       hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_C2P>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows);
     else
       hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_NONE>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows);
+#if APK_M12F_TIMING
+    {
+      static int calls = 0;
+      if (++calls % 8 == 0) {
+        (void)hipStreamSynchronize(s);
+        unsigned long long h[8] = {0};
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_m12f_phase), sizeof(h));
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_m12f_phase), z, sizeof(z));
+        static const char *name[8] = {"other", "x1_recon", "x1_riemann", "x2_recon", "x2_riemann", "load_wait", "finish", "-"};
+        double tot = 0;
+        for (int p = 0; p < 7; ++p) tot += (double)h[p];
+        std::fprintf(stderr, "[m12f phases, shader clocks per wave over 8 launches, recon %d extra %d]", RECON, extra);
+        for (int p = 0; p < 7; ++p) std::fprintf(stderr, " %s %.1f%% (%.3e)", name[p], 100.0 * h[p] / tot, (double)h[p] / nwaves / 8.0);
+        std::fprintf(stderr, "\n");
+      }
+    }
+#endif
   }
 }
 

@@ -113,7 +113,7 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
 #pragma unroll
   for (int n = 0; n < NV; ++n) {
     const int64_t idx = n * pv.sn + cell;
-    const double old = (sp.gam0 != 0.0) ? b0.cons[idx] : 0.0;
+    const double old = (sp.gam0 != 0.0) ? as_global(b0.cons)[idx] : 0.0;
     un[n] = sp.gam0 * old + sp.gam1 * u1v[n] + sp.beta_dt * (-du[n] / vol);
   }
   if constexpr (FLUID == APK_FLUID_GLMMHD) {
@@ -156,7 +156,7 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
     // only accepted if neither sees a negative state, so an accepted stage never raises flags)
     if (sp.bad_count && fl) bad = true;
 #pragma unroll
-    for (int n = 0; n < NV; ++n) prim_dst[n * pv.sn + cell] = w[n];
+    for (int n = 0; n < NV; ++n) as_global(prim_dst)[n * pv.sn + cell] = w[n];
     if constexpr (EXTRA == EXTRA_C2P_DT) {
       // EstimateHyperbolicTimestep (hydro.cpp:845-895) on the fresh primitives
       double lx, ly = 0.0, lz = 0.0;
@@ -175,7 +175,7 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
     }
   }
 #pragma unroll
-  for (int n = 0; n < NV; ++n) b0.cons[n * pv.sn + cell + sp.out_delta] = un[n];
+  for (int n = 0; n < NV; ++n) as_global(b0.cons)[n * pv.sn + cell + sp.out_delta] = un[n];
   if (bad) atomicAdd(sp.bad_count, 1ull);
 }
 
@@ -947,7 +947,7 @@ fused_scalar_update_kernel(PackView u0, PackView u1, StageParams sp) {
       else du += (area[d] * fhi - area[d] * flo);
     }
     const int64_t idx = n * u0.sn + cell;
-    const double old = (sp.gam0 != 0.0) ? b0.cons[idx] : 0.0;
+    const double old = (sp.gam0 != 0.0) ? as_global(b0.cons)[idx] : 0.0;
     b0.cons[idx] = sp.gam0 * old + sp.gam1 * c1[idx] + sp.beta_dt * (-du / vol);
   }
 }

@@ -37,6 +37,18 @@ enum { IV1 = 1, IV2 = 2, IV3 = 3, IPR = 4 };
 #endif
 
 APK_DEV double sqr(double x) { return x * x; }
+// Field pointers come out of the block descriptors (memory), so the compiler knows them as generic pointers and emits
+// flat_load / flat_store -- which count on lgkmcnt as well as vmcnt (a flat access may turn out to be LDS), so every
+// s_waitcnt lgkmcnt(0) in front of a ring read also waits for the stores of the previous row to be acknowledged.
+// Every field lives in global memory: say so.
+#ifdef APK_NO_GLOBAL_CAST  // (A/B)
+template <class T> APK_DEV T *as_global(T *p) { return p; }
+#else
+template <class T>
+APK_DEV __attribute__((address_space(1))) T *as_global(T *p) {
+  return (__attribute__((address_space(1))) T *)p;
+}
+#endif
 // a wave-uniform value the vector ALU had to compute (there is no scalar fp64 unit), moved into a scalar register
 // pair: it stops occupying two VGPRs of every lane for as long as it lives
 APK_DEV double to_sgpr(double x) {

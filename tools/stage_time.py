@@ -76,10 +76,10 @@ e1.synchronize()
 ms = e0.elapsed_time(e1) / a.reps
 per = []
 for slot, name in enumerate(L.TIMING_SLOTS):
-    tms, n = C.c_double(0.0), C.c_longlong(0)
-    ctx.lib.apk_kernel_timing_read(ctx.h, slot, C.byref(tms), C.byref(n))
-    if n.value:
-        per.append("%s %.3f" % (name, tms.value / n.value))
+    tms, cnt = C.c_double(0.0), C.c_longlong(0)
+    ctx.lib.apk_kernel_timing_read(ctx.h, slot, C.byref(tms), C.byref(cnt))
+    if cnt.value:
+        per.append("%s %.3f" % (name, tms.value / cnt.value))
 ctx.lib.apk_kernel_timing_enable(ctx.h, 0)
 print("per kernel (ms):", ", ".join(per))
 cells = nb * n ** 3
