@@ -425,6 +425,10 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
 //    lanes of the wave then run the limiter once for all of them and the owners read their results back; bit-exact --
 //    was built for the x3 sweep and measured: 0.809 against 0.770 ms.  Ballots, rank computation, the staging writes
 //    and the second pass cost more than the seven-odd masked executions of the ~60-instruction branch they replace;
+//  * PPM without divergent branches (the extremum limiters of ppm_interface / ppm_cell evaluated by every lane and
+//    selected, one scheduling pin per variable so that nothing spills): x3 sweep 0.76 -> 0.93 ms, this kernel 2.31 ->
+//    2.55 ms.  The masked branches are CHEAP: an instruction with one or two live lanes does not cost a full wave's
+//    issue time (which is also why switching them off altogether buys 12 %, not the 30 % their instruction count suggests);
 //  * host-evaluated stage constants (hydro_math.hpp: StageConsts; no scratch left in this kernel, 14 VGPRs fewer)
 //    and global_ instead of flat_ accesses (as_global): both kept, both within 1 % (same-box bench A/B);
 //  * the nine per-variable offsets n * sn of d3 / u1 / u0 / prim' as ONE walking pointer (8 SGPR pairs fewer: scalar
