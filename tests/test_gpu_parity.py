@@ -897,3 +897,65 @@ def test_direct_neighbor_addressing_rejects_stage_forms_that_read_ghost_zones(re
         b2 = hydro.MeshData(ctx, nx2, ng2, 9, dx=tuple(g2.dx), nblocks=1, cons=c2, prim=p2, with_flux=False)
         hydro.StageFused(a2, b2, "glmmhd", "ppm", "hlld", hydro.L.make_eos(GAMMA), C_H, 0.0, 1.0, 0.004, dedner=2,
                          fill_derived=2, face_neighbor=tab)
+
+
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_hip_hlld_resolves_isolated_contact_and_rotational_discontinuities(request, strict, d):
+    """The HIP HLLD kernels against the SOLVER'S DEFINING PROPERTY instead of against the oracle (whose PPM / HLLD the
+    reference pins with no numbers): an isolated contact and an isolated Alfven (rotational) discontinuity are resolved
+    exactly -- the face flux is the physical flux of the upwind state (Miyoshi & Kusano 2005, sections 5.2 - 5.3) --
+    in every sweep direction, through the flux-array kernel (donor-cell states = the cell values)."""
+    from athenapk_amd import hydro
+    from test_oracle_cpu import _mhd_state, _phys_flux
+    ctx = _ctx(request, strict)
+    gamma, c_h, ng = 5.0 / 3.0, 2.0, 2
+    dens, p, bn = 1.44, 0.7, 0.9
+    ca = abs(bn) / np.sqrt(dens)
+    cases = []
+    # contact moving right / left: density jump only
+    for u in (0.37, -0.29):
+        v, b = (u, 0.21, -0.13), (0.8, 0.6, -0.4)
+        cases.append((_mhd_state(1.3, v, p, b), _mhd_state(0.4, v, p, b), u > 0.0))
+    # rotational discontinuity of the (vn + ca) family drifting right / left
+    for drift in (0.2, -0.2):
+        vn = drift - ca
+        btl = np.array([0.5, 0.3])
+        ang = 1.1
+        btr = np.array([np.cos(ang) * btl[0] - np.sin(ang) * btl[1], np.sin(ang) * btl[0] + np.cos(ang) * btl[1]])
+        vtl = np.array([0.1, -0.2])
+        vtr = vtl - np.sign(bn) * (btr - btl) / np.sqrt(dens)
+        cases.append((_mhd_state(dens, (vn, vtl[0], vtl[1]), p, (bn, btl[0], btl[1])),
+                      _mhd_state(dens, (vn, vtr[0], vtr[1]), p, (bn, btr[0], btr[1])), drift > 0.0))
+
+    def rot(w):     # the x1-normal state turned so that direction d is the normal: (n, t1, t2) -> components (d, d+1, d+2)
+        r = w.copy()
+        for base in (1, 5):
+            for c in range(3):
+                r[base + (d - 1 + c) % 3] = w[base + c]
+        return r
+
+    n = len(cases)
+    nx = [2, 2, 2]
+    nx[d - 1] = 2 * n
+    N = [m + 2 * ng for m in nx]
+    line = np.zeros((9, N[d - 1]))
+    for c, (wl, wr, _) in enumerate(cases):
+        line[:, ng + 2 * c] = rot(wl)
+        line[:, ng + 2 * c + 1] = rot(wr)
+    line[:, :ng] = line[:, ng:ng + 1]
+    line[:, -ng:] = line[:, -ng - 1:-ng]
+    shape = [1, 1, 1]
+    shape[3 - d] = N[d - 1]
+    w = np.zeros((1, 9, N[2], N[1], N[0]))
+    w[0] = line.reshape((9,) + tuple(shape))
+    md = hydro.MeshData(ctx, tuple(nx), ng, 9, dx=(0.1, 0.1, 0.1), prim=w)
+    hydro.CalculateFluxes(md, "glmmhd", "dc", "hlld", hydro.L.make_eos(gamma), c_h)
+    f = md.flux_host(d - 1)[0]
+    ivx = d
+    for c, (wl, wr, upwind_left) in enumerate(cases):
+        at = [ng, ng, ng]
+        at[d - 1] = ng + 2 * c + 1
+        got = f[:, at[2], at[1], at[0]]
+        exact = _phys_flux("glmmhd", rot(wl if upwind_left else wr), gamma, ivx, c_h)
+        np.testing.assert_allclose(got, exact, rtol=1e-13, atol=3e-14, err_msg="case %d direction %d" % (c, d))

@@ -265,6 +265,99 @@ def test_hydro_wave_through_mhd_solver_with_zero_field(oracle):
     assert np.all(fm[:, 5:] == 0.0)
 
 
+# ---- (4b) what HLLD and the high-order reconstructions are DEFINED by (independent of the restatement: round-2 verdict,
+# row (c) -- the reference holds no numbers for PPM / HLLD, so these pin the oracle to the methods' published properties)
+def _mhd_state(d, v, p, b, psi=0.0):
+    return np.array([d, v[0], v[1], v[2], p, b[0], b[1], b[2], psi])
+
+
+@pytest.mark.parametrize("u", [0.37, -0.29, 0.0])
+def test_hlld_resolves_an_isolated_contact_discontinuity_exactly(oracle, u):
+    """Miyoshi & Kusano (2005) section 5.2: HLLD is exact for an isolated contact (density jump, everything else continuous,
+    Bx != 0) moving with the fluid -- the flux on the face is the physical flux of the upwind state; HLLE smears it."""
+    gamma, c_h = 5.0 / 3.0, 2.0
+    v, b, p = (u, 0.21, -0.13), (0.8, 0.6, -0.4), 0.9
+    wl, wr = _mhd_state(1.3, v, p, b), _mhd_state(0.4, v, p, b)
+    f = oracle.riemann_many("glmmhd", "hlld", 1, wl, wr, gamma, c_h)[0]
+    exact = _phys_flux("glmmhd", wl if u >= 0.0 else wr, gamma, 1, c_h)
+    if u == 0.0:    # the contact sits on the face: no mass crosses it, both sides give the same momentum / induction fluxes
+        assert abs(f[0]) < 1e-15
+        np.testing.assert_allclose(f[[1, 2, 3, 5, 6, 7]], exact[[1, 2, 3, 5, 6, 7]], rtol=1e-13, atol=1e-14)
+    else:
+        np.testing.assert_allclose(f, exact, rtol=1e-13, atol=1e-14)
+    fe = oracle.riemann_many("glmmhd", "hlle", 1, wl, wr, gamma, c_h)[0]
+    assert abs(fe[0] - exact[0]) > 1e-3       # (the two-wave solver diffuses the contact)
+
+
+@pytest.mark.parametrize("direction", [+1, -1])
+@pytest.mark.parametrize("frame", ["upwind_left", "upwind_right"])
+def test_hlld_resolves_an_isolated_rotational_discontinuity_exactly(oracle, direction, frame):
+    """M&K section 5.3: across an Alfven (rotational) discontinuity d, p, vx, Bx and |Bt| are continuous, Bt turns and
+    vt jumps by -/+ (Bt_R - Bt_L) / sqrt(d) for the wave running with vx +/- ca; HLLD's four intermediate states
+    reproduce it exactly, so the face flux is the physical flux of the side the wave has not reached."""
+    gamma, c_h = 5.0 / 3.0, 2.0
+    d, p, bx = 1.44, 0.7, 0.9 * direction
+    ca = abs(bx) / np.sqrt(d)
+    sgn = 1.0 if frame == "upwind_left" else -1.0     # the discontinuity moves to the right / to the left
+    # the wave running in the +x sense relative to the fluid has speed vx + ca; pick vx so that its speed is +/- 0.2
+    vx = 0.2 * sgn - ca
+    btl = np.array([0.5, 0.3])
+    ang = 1.1
+    btr = np.array([np.cos(ang) * btl[0] - np.sin(ang) * btl[1], np.sin(ang) * btl[0] + np.cos(ang) * btl[1]])
+    vtl = np.array([0.1, -0.2])
+    vtr = vtl - np.sign(bx) * (btr - btl) / np.sqrt(d)         # the (vx + ca) family
+    wl = _mhd_state(d, (vx, vtl[0], vtl[1]), p, (bx, btl[0], btl[1]))
+    wr = _mhd_state(d, (vx, vtr[0], vtr[1]), p, (bx, btr[0], btr[1]))
+    # Rankine-Hugoniot sanity of the construction itself: F_R - F_L = s (U_R - U_L) with s = vx + ca
+    s_wave = vx + ca
+    ul = prim_to_cons("glmmhd", wl.reshape(9, 1, 1, 1), gamma).reshape(9)
+    ur = prim_to_cons("glmmhd", wr.reshape(9, 1, 1, 1), gamma).reshape(9)
+    fl, fr = _phys_flux("glmmhd", wl, gamma, 1, c_h), _phys_flux("glmmhd", wr, gamma, 1, c_h)
+    np.testing.assert_allclose((fr - fl)[[0, 1, 2, 3, 4, 6, 7]], s_wave * (ur - ul)[[0, 1, 2, 3, 4, 6, 7]], rtol=0, atol=2e-15)
+    f = oracle.riemann_many("glmmhd", "hlld", 1, wl, wr, gamma, c_h)[0]
+    exact = fl if s_wave > 0.0 else fr
+    np.testing.assert_allclose(f, exact, rtol=1e-13, atol=2e-14)
+
+
+def _cell_averages(coef, centres):
+    """exact averages over [x - 1/2, x + 1/2] of the polynomial sum coef[k] x^k"""
+    prim = np.polynomial.polynomial.polyint(coef)
+    return np.polynomial.polynomial.polyval(centres + 0.5, prim) - np.polynomial.polynomial.polyval(centres - 0.5, prim)
+
+
+def test_ppm_interface_values_are_exact_for_cubic_profiles(oracle):
+    """Colella & Woodward's fourth-order interface value (ppm_simple.hpp:50-57) reproduces the point values of any cubic
+    from its cell averages; on a monotone profile away from extrema none of the limiters acts, so the L / R states of a
+    cell ARE the profile's values on its two faces."""
+    rng = np.random.default_rng(11)
+    for _ in range(200):
+        coef = np.array([rng.uniform(-1, 1), rng.uniform(1.0, 2.0), rng.uniform(-0.05, 0.05), rng.uniform(0.0, 0.02)])
+        x0 = rng.uniform(-2.0, 2.0)
+        centres = x0 + np.arange(-2, 3)
+        if np.polynomial.polynomial.polyval(centres, np.polynomial.polynomial.polyder(coef)).min() < 0.5:
+            continue                                    # keep the stencil strictly monotone and gently curved
+        q = _cell_averages(coef, centres)
+        ql, qr = oracle.recon_many("ppm", q)
+        assert abs(ql[0] - np.polynomial.polynomial.polyval(x0 + 0.5, coef)) < 2e-14
+        assert abs(qr[0] - np.polynomial.polynomial.polyval(x0 - 0.5, coef)) < 2e-14
+
+
+@pytest.mark.parametrize("method,degree", [("wenoz", 2), ("plm", 1), ("weno3", 1), ("limo3", 1)])
+def test_weighted_reconstructions_are_exact_on_the_polynomials_their_stencils_resolve(oracle, method, degree):
+    """every candidate stencil of WENO-Z reproduces quadratics from cell averages, so any convex combination does
+    (wenoz_simple.hpp:44-81); the three-point schemes reproduce linear profiles"""
+    rng = np.random.default_rng(12)
+    for _ in range(100):
+        coef = np.zeros(3)
+        coef[:degree + 1] = rng.uniform(-1, 1, degree + 1)
+        coef[1] = rng.uniform(0.5, 1.5)
+        x0 = rng.uniform(-2.0, 2.0)
+        q = _cell_averages(coef, x0 + np.arange(-2, 3))
+        ql, qr = oracle.recon_many(method, q, dx=1.0, n=1)
+        assert abs(ql[0] - np.polynomial.polynomial.polyval(x0 + 0.5, coef)) < 5e-14, (method, coef)
+        assert abs(qr[0] - np.polynomial.polynomial.polyval(x0 - 0.5, coef)) < 5e-14, (method, coef)
+
+
 # ---- (5) block-level structure ----------------------------------------------------------------------
 @pytest.mark.parametrize("fluid,recon,riemann", [c for c in REGISTRY if c[2] != "none"][::3])
 def test_update_conserves_on_periodic_data(oracle, fluid, recon, riemann):
