@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+import helpers as H
+
 from helpers import (NGHOST, NHYDRO, REGISTRY, geom, interior, orc_c2p, orc_fluxes, orc_history,
                      orc_update, prim_to_cons, random_prim)
 
@@ -356,6 +358,38 @@ def test_weighted_reconstructions_are_exact_on_the_polynomials_their_stencils_re
         ql, qr = oracle.recon_many(method, q, dx=1.0, n=1)
         assert abs(ql[0] - np.polynomial.polynomial.polyval(x0 + 0.5, coef)) < 5e-14, (method, coef)
         assert abs(qr[0] - np.polynomial.polynomial.polyval(x0 - 0.5, coef)) < 5e-14, (method, coef)
+
+
+def test_dedner_source_on_linear_fields_has_its_closed_form(oracle):
+    """dedner_source.cpp:31-74 on fields that are linear in x, y, z (centred differences are then exact): psi decays by
+    exp(-alpha c_h beta dt / mindx) (Mignone & Tzeferacos 2010, eq. 27); the extended source takes (div B) B from the
+    momentum and B . grad psi from the energy -- values written down here from the formulas, not from the oracle"""
+    nx, ng, dx = (6, 5, 4), 2, (0.1, 0.07, 0.13)
+    g = H.geom("glmmhd", nx, ng, 0, dx)
+    N = [n + 2 * ng for n in nx]
+    k, j, i = np.meshgrid(np.arange(N[2]) * dx[2], np.arange(N[1]) * dx[1], np.arange(N[0]) * dx[0], indexing="ij")
+    a = (0.3, -0.2, 0.45)          # dB1/dx, dB2/dy, dB3/dz: div B = 0.55
+    gp = (0.7, -1.1, 0.25)         # grad psi
+    w = np.zeros((1, 9) + k.shape)
+    w[0, 0], w[0, 4] = 1.0, 1.0
+    w[0, 5] = 1.0 + a[0] * i + 0.05 * j
+    w[0, 6] = -0.5 + a[1] * j + 0.02 * k
+    w[0, 7] = 0.25 + a[2] * k - 0.03 * i
+    w[0, 8] = 0.1 + gp[0] * i + gp[1] * j + gp[2] * k
+    cons = H.prim_to_cons("glmmhd", w, 5.0 / 3.0)
+    alpha, c_h, mindx, beta_dt = 0.1, 1.9, 0.07, 0.004
+    sl = (slice(ng, -ng),) * 3
+    for extended in (0, 1):
+        out = H.orc_dedner(g, cons, w, extended, alpha, c_h, mindx, beta_dt)[0]
+        want = cons[0].copy()
+        if extended:
+            divb = a[0] + a[1] + a[2]
+            for c in range(3):
+                want[1 + c] -= beta_dt * divb * w[0, 5 + c]
+            want[4] -= beta_dt * (w[0, 5] * gp[0] + w[0, 6] * gp[1] + w[0, 7] * gp[2])
+        want[8] = want[8] * np.exp(-alpha * c_h * beta_dt / mindx)
+        for n in range(9):
+            np.testing.assert_allclose(out[n][sl], want[n][sl], rtol=2e-13, atol=1e-15, err_msg="variable %d extended %d" % (n, extended))
 
 
 # ---- (5) block-level structure ----------------------------------------------------------------------
