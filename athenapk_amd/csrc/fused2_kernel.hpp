@@ -429,6 +429,11 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
 //    selected, one scheduling pin per variable so that nothing spills): x3 sweep 0.76 -> 0.93 ms, this kernel 2.31 ->
 //    2.55 ms.  The masked branches are CHEAP: an instruction with one or two live lanes does not cost a full wave's
 //    issue time (which is also why switching them off altogether buys 12 %, not the 30 % their instruction count suggests);
+//  * a hardware fact found on the way (tools/ubench/ubench_mask.hip): an fp64 VALU instruction with 1 - 8 live lanes takes
+//    16 shader cycles of its wave against 4 with 12 - 64 lanes, two waves doing such work serialise on it, and a
+//    full-width wave next to them is NOT held up.  Letting lanes 0 .. 11 come along into PPM's extremum branches (so that
+//    they run at the full-width rate) makes the kernels SLOWER -- x3 sweep 0.78 -> 0.82 ms, this kernel 2.40 -> 2.49 --
+//    because the few-lane instructions cost their wave time but the pipe next to nothing, and padded they cost the pipe;
 //  * host-evaluated stage constants (hydro_math.hpp: StageConsts; no scratch left in this kernel, 14 VGPRs fewer)
 //    and global_ instead of flat_ accesses (as_global): both kept, both within 1 % (same-box bench A/B);
 //  * the nine per-variable offsets n * sn of d3 / u1 / u0 / prim' as ONE walking pointer (8 SGPR pairs fewer: scalar
