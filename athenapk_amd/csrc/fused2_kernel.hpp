@@ -434,6 +434,8 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
 //    full-width wave next to them is NOT held up.  Letting lanes 0 .. 11 come along into PPM's extremum branches (so that
 //    they run at the full-width rate) makes the kernels SLOWER -- x3 sweep 0.78 -> 0.82 ms, this kernel 2.40 -> 2.49 --
 //    because the few-lane instructions cost their wave time but the pipe next to nothing, and padded they cost the pipe;
+//  * three waves per SIMD for the HYDRO variants of this kernel (129 - 145 VGPRs, 5 - 10 KB of ring: the wave count sized
+//    from hipFuncGetAttributes instead of two everywhere): PLM+HLLC 1.33 -> 1.35 ms, no gain from occupancy either;
 //  * host-evaluated stage constants (hydro_math.hpp: StageConsts; no scratch left in this kernel, 14 VGPRs fewer)
 //    and global_ instead of flat_ accesses (as_global): both kept, both within 1 % (same-box bench A/B);
 //  * the nine per-variable offsets n * sn of d3 / u1 / u0 / prim' as ONE walking pointer (8 SGPR pairs fewer: scalar
