@@ -84,6 +84,13 @@ constexpr int m12_last_lane(int recon) { return 62 - recon_halfwidth(recon); }
 // phase, d3 after the x2 solve: 100 B of scratch, 2.81 against 2.60 ms on the same box.
 #define APK_M12F_LOADS 2
 #endif
+#ifndef APK_M12F_MASK_IDLE
+// 1: lanes that retire no cell (overlap lanes at the ends of the wave, ghost columns: 13 % of the lanes on 128^3 blocks)
+// sit out the x2 reconstruction and both Riemann solves -- they only have to carry their column through the ring as the
+// x1 stencil of their neighbours.  The stage runs at 94 % of the socket's 1400 W (rocm-smi while it loops; effective clock
+// 1.8 - 2.0 of 2.4 GHz), so energy per cell is what the clock answers to: every lane-operation not executed counts.
+#define APK_M12F_MASK_IDLE 1
+#endif
 #ifndef APK_M12F_WAVES
 #define APK_M12F_WAVES 2  // resident waves per SIMD the kernel is compiled for (A/B: 1 = 512 VGPRs)
 #endif
@@ -153,6 +160,11 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     const bool active = in_run && (lane >= FIRST) && (lane <= LAST) && (i >= u0.is) && (i <= u0.ie);
     const int s = u0.js + j0, e = s + nrows - 1;
     const int64_t base = (int64_t)(u0.ks + krow) * u0.sk + i;
+    // lanes whose x1 face flux somebody uses: a retiring cell needs the flux of its own lower face and that of the lane above
+    const bool need_f1 = !(APK_M12F_MASK_IDLE & 2) || active ||
+                         (__builtin_amdgcn_update_dpp(0, active ? 1 : 0, 0x138, 0xf, 0xf, true) != 0);  // wave_shr:1 = lane l-1
+    const bool need_x2 = !(APK_M12F_MASK_IDLE & 1) || active;       // x2 Riemann
+    const bool need_r2 = !(APK_M12F_MASK_IDLE & 4) || active;       // x2 reconstruction
     const double dx1 = b0.dx[0], dx2 = b0.dx[1];
     const double area1 = to_sgpr(b0.dx[1] * b0.dx[2]);  // (per block: wave-uniform)
     const double area2 = to_sgpr(b0.dx[0] * b0.dx[2]);
@@ -268,7 +280,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
           wl[q] = lane_below<1>(ql1[perm<1>(q)], lane);
           wr[q] = qr1[perm<1>(q)];
         }
-        riemann<FLUID, RS>(wl, wr, sp.k, f1);
+        if (need_f1) riemann<FLUID, RS>(wl, wr, sp.k, f1);
         double fup0 = 0.0;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
@@ -298,6 +310,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
       APK_TICK(2);  // x1 Riemann + flux difference
       // ---- (3) x2: reconstruct cell c from ring rows c-H..c+H-1 and the register row c+H
       double qln[NV], qrn[NV];
+      if (need_r2) {
       double an[NS];  // ring rows of the next variable (software-pipelined LDS reads)
 #pragma unroll
       for (int m = 0; m < NS; ++m) an[m] = ring[(((slot0 + m) & (NS - 1)) * NV + 0) * 64 + lane];
@@ -326,6 +339,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
         if constexpr (RECON == APK_RC_WENOZ || RECON == APK_RC_WENO3 || RECON == APK_RC_LIMO3)
           asm volatile("" : "+v"(qln[n]), "+v"(qrn[n]));  // (see fused_march_kernel)
       }
+      }
       const bool more = (c < e + 1);
       if (more) {
 #pragma unroll
@@ -342,7 +356,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
           double wr[NV];
 #pragma unroll
           for (int q = 0; q < NV; ++q) wr[q] = qrn[perm<2>(q)];
-          riemann<FLUID, RS>(wl_prev, wr, sp.k, f);
+          if (need_x2) riemann<FLUID, RS>(wl_prev, wr, sp.k, f);
         }
         APK_TICK(4);  // x2 Riemann
         if (retire) {
