@@ -450,7 +450,6 @@ bool direct_neighbors(const apk_sim *s) {
   return true;
 }
 
-// may the stage loop of a refined mesh skip the ghost zones behind edges and corners?  (A/B: APK_AMR_FULL_EXCHANGE=1)
 // does the cycle in progress end with a check of the refinement criteria?  Those read the full ring of ghost
 // cells round a block -- edges and corners too (refinement/gradient.cpp:33-36 loops k, j, i over [s-1, e+1]
 // and differences each of them) -- so the exchange after the last stage of such a cycle is a complete one.
@@ -458,6 +457,8 @@ bool regrid_check_follows(const apk_sim *s) {
   return s->amr && s->amr_adaptive && s->amr_check_interval > 0 && (s->ncycle + 1) % s->amr_check_interval == 0;
 }
 
+// may the stage loop of a refined mesh skip the ghost zones behind edges and corners?  (apk_sim_set_amr_full_exchange /
+// APK_AMR_FULL_EXCHANGE=1: never)
 bool amr_faces_only(const apk_sim *s) {
   return s->amr && !s->amr_full_exchange && s->mesh.ndim >= 2;
 }
