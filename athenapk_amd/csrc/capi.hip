@@ -327,6 +327,17 @@ int apk_cons_to_prim_faces(apk_ctx *ctx, const apk_pack *md, int fluid, const ap
   return APK_OK;
 }
 
+int apk_cons_to_prim_faces_skip(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, const int *face_neighbor,
+                                apk_stream_t stream) {
+  if (!ctx || !md || !valid_eos(eos) || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||
+      md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9) || !face_neighbor)
+    return set_err(ctx, APK_ERR_INVALID, "apk_cons_to_prim_faces_skip: bad argument");
+  ScopedTiming timing(ctx, APK_T_C2P, as_stream(stream));
+  int rc = launch_cons_to_prim(md->view, fluid, *eos, ctx->d_flags, as_stream(stream), false, nullptr, 0, true, face_neighbor);
+  if (rc != APK_OK) return set_err(ctx, rc, "cons_to_prim kernel launch failed", hipGetLastError());
+  return APK_OK;
+}
+
 int apk_cons_to_prim_ghosts(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,
                             apk_stream_t stream) {
   if (!ctx || !md || !valid_eos(eos) || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||

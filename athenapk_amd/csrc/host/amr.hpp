@@ -358,6 +358,7 @@ inline void BuildAmrPlans(const AmrTree &t, const AmrGeom &g, AmrPlans &p) {
         r.src_kind = RK_BLOCK, r.src_block = nbr, r.dst_kind = RK_BLOCK, r.dst_block = lb;
         amr_box_region(r, g.fst, slo, g.fst, dlo, ext, g.nvar);
         r.corner = behind_corner;
+        r.same_face = !behind_corner;
         p.fill.push_back(r);
         if (has_coarser[lb]) {  // coarse-buffer ghost zone <- neighbour's restricted interior
           for (int d = 0; d < 3; ++d) {

@@ -27,6 +27,8 @@ struct BoxRegion {
   int nvar = 0, flip_var = -1;
   int64_t src_stride[4] = {0, 0, 0, 0}, dst_stride[4] = {0, 0, 0, 0};
   int corner = 0;  // refined meshes: fills a block's ghost zone behind an EDGE or a CORNER (nothing in the stage loop reads it)
+  int same_face = 0;  // refined meshes: fills the ghost zone behind a FACE from the interior of a block of the same level
+                      // (not needed by a stage that reads that block directly, apk_stage_args.face_neighbor)
 };
 
 struct PeerPlan {

@@ -450,6 +450,21 @@ bool direct_neighbors(const apk_sim *s) {
   return true;
 }
 
+// Refined meshes: may the stages read a same-rank neighbour of the SAME level through the face table (built in
+// amr_rebuild) instead of the ghost zone behind that face?  Then the faces-only exchange of the stage loop skips
+// those copies and their ConsToPrim (AMR_XCHG_DIRECT).  The stage forms that follow the table: the single-march
+// donor-cell stage and the two-kernel stage (launch_fused_stage); refined-mesh stages run without FillDerived.
+bool amr_direct(const apk_sim *s) {
+  static const int mode = std::getenv("APK_DIRECT_NEIGHBORS") ? std::atoi(std::getenv("APK_DIRECT_NEIGHBORS")) : 1;  // A/B switch
+  const HydroPackage &pkg = s->pkg;
+  if (!mode || !s->direct_on || !s->amr || !s->d_face_nbr || s->mesh.ndim != 3 || !stage_can_fuse(s) || !amr_faces_only(s)) return false;
+  if (pkg.nscalars != 0 || (pkg.fluid == APK_FLUID_GLMMHD && pkg.glmmhd_source_extended)) return false;
+  const apk_flux_cfg *cfgs[2] = {&pkg.flux_first_stage, &pkg.flux_other_stage};
+  for (const apk_flux_cfg *cfg : cfgs)
+    if (cfg->recon != APK_RC_DC && apk_stage_split_axis(s->mu0(), cfg, 0) != 3) return false;
+  return true;
+}
+
 // does the cycle in progress end with a check of the refinement criteria?  Those read the full ring of ghost
 // cells round a block -- edges and corners too (refinement/gradient.cpp:33-36 loops k, j, i over [s-1, e+1]
 // and differences each of them) -- so the exchange after the last stage of such a cycle is a complete one.
@@ -477,7 +492,7 @@ int sync_ghosts(apk_sim *s) {
   if (s->amr) {
     if (!s->amr_ghosts_partial) return APK_OK;
     // the stage loop left the ghost zones behind edges and corners alone: complete exchange + ConsToPrim
-    SIM_TRY(s, amr_exchange(s, s->cur, false));
+    SIM_TRY(s, amr_exchange(s, s->cur, AMR_XCHG_FULL));
     return fill_derived(s);
   }
   SIM_TRY(s, finish_pending(s));
@@ -760,7 +775,7 @@ int do_stage(apk_sim *s, int stage) {
     a.dedner = (pkg.fluid == APK_FLUID_GLMMHD) ? (pkg.glmmhd_source_extended ? 2 : 1) : 0;
     a.glmmhd_alpha = pkg.glmmhd_alpha;
     a.mindx = pkg.mindx;
-    a.face_neighbor = direct ? s->d_face_nbr : nullptr;
+    a.face_neighbor = (direct || amr_direct(s)) ? s->d_face_nbr : nullptr;
     // let the finishing sweep do FillDerived (and, in the last stage, the dt estimate) on the
     // cells it updates; only the ghost zones are converted after the exchange
     // (not when the turbulence driver kicks the state after this stage)
@@ -938,8 +953,15 @@ int do_stage(apk_sim *s, int stage) {
   } else if (s->amr && amr_faces_only(s) && !(stage == s->nstages && regrid_check_follows(s))) {
     // refined meshes: nothing in the stage loop reads a ghost cell behind an edge or a corner of a block -- the
     // exchange skips those boxes (37 % of the ghost cells of a 16^3 block with nghost = 4) and ConsToPrim the cells
-    SIM_TRY(s, amr_exchange(s, s->cur, true));
-    SIM_TRY(s, apk_cons_to_prim_faces(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
+    // (nor, with amr_direct, the ghost zones behind faces the stages cross by the face table)
+    if (amr_direct(s)) {
+      SIM_TRY(s, amr_exchange(s, s->cur, AMR_XCHG_DIRECT));
+      SIM_TRY(s, apk_cons_to_prim_faces_skip(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->d_face_nbr, s->stream));
+      s->skipped_local_exchanges += 1;
+    } else {
+      SIM_TRY(s, amr_exchange(s, s->cur, AMR_XCHG_FACES));
+      SIM_TRY(s, apk_cons_to_prim_faces(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
+    }
     s->amr_ghosts_partial = true;
   } else {
     // (without a fused FillDerived the full-block ConsToPrim below reads every ghost zone)

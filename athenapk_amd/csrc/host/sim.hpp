@@ -198,6 +198,9 @@ struct apk_sim {
     // (BoxRegion::corner); its messages are laid out by the same walk over the filtered global list
     std::vector<apk::AmrRefOp> prolongate_faces;
     std::vector<apk::BoxRegion> fill_faces, fill_pack_faces, fill_unpack_faces;
+    // ... and without the same-rank copies between blocks of one level either (BoxRegion::same_face): the exchange
+    // after a stage when the next one reads those neighbours through the face table (amr_direct)
+    std::vector<apk::BoxRegion> fill_direct;
   } amr_local;
   struct MsgSet {
     apk::AmrMessages plan;
@@ -225,6 +228,8 @@ struct apk_sim {
     std::vector<apk_refine_plan *> prolongate_faces[2];
     apk_copy_plan *fill_faces[2] = {nullptr, nullptr}, *fill_pack_faces[2] = {nullptr, nullptr}, *fill_unpack_faces[2] = {nullptr, nullptr};
     void *xchg_pre_faces[2] = {nullptr, nullptr}, *xchg_post_faces[2] = {nullptr, nullptr};
+    apk_copy_plan *fill_direct[2] = {nullptr, nullptr};  // (AmrLocalPlans::fill_direct; the other plans of the faces-only exchange)
+    void *xchg_pre_direct[2] = {nullptr, nullptr};
     apk_flux_fix_plan *flux_fix[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     // the faces (6 * local block + face) with a coarser or finer block behind them: the only boundary-plane
     // fluxes the correction after a fused stage reads (apk_calculate_fluxes_boundary_list)

@@ -80,6 +80,8 @@ void amr_localize(apk_sim *s) {
     AmrLocalize(faces, part, part, rank, s->amr_halo_faces.plan, l.fill_faces, l.fill_pack_faces, l.fill_unpack_faces);
     for (const AmrRefOp &o : l.prolongate)
       if (!o.corner) l.prolongate_faces.push_back(o);
+    for (const BoxRegion &r : l.fill_faces)
+      if (!r.same_face) l.fill_direct.push_back(r);
   }
   for (int d = 0; d < 3; ++d) AmrRegisterPeers(g.flux_copy[d], part, part, rank, s->amr_fluxmsg.plan);
   for (int d = 0; d < 3; ++d)
@@ -253,6 +255,8 @@ void amr_destroy_device_plans(apk_sim *s) {
     apk_copy_plan_destroy(a.fill_pack_faces[par]);
     apk_copy_plan_destroy(a.fill_unpack_faces[par]);
     a.fill_faces[par] = a.fill_pack_faces[par] = a.fill_unpack_faces[par] = nullptr;
+    apk_copy_plan_destroy(a.fill_direct[par]);
+    a.fill_direct[par] = nullptr;
     for (int d = 0; d < 3; ++d) {
       apk_copy_plan_destroy(a.coarse_bc[par][d]);
       apk_copy_plan_destroy(a.fine_bc[par][d]);
@@ -394,6 +398,7 @@ int amr_rebuild(apk_sim *s) {
     SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_faces, nullptr, &a.fill_faces[par]));
     SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_pack_faces, &s->amr_halo_faces, &a.fill_pack_faces[par]));
     SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_unpack_faces, &s->amr_halo_faces, &a.fill_unpack_faces[par]));
+    SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_direct, nullptr, &a.fill_direct[par]));
     for (int d = 0; d < 3; ++d) {
       SIM_TRY(s, amr_make_copy_plan(s, par, p.coarse_bc[d], nullptr, &a.coarse_bc[par][d]));
       SIM_TRY(s, amr_make_copy_plan(s, par, p.fine_bc[d], nullptr, &a.fine_bc[par][d]));
@@ -429,11 +434,32 @@ int amr_rebuild(apk_sim *s) {
     a.d_cf_faces = reinterpret_cast<int *>(p8);
     if (!cf.empty()) SIM_HIP(s, hipMemcpy(a.d_cf_faces, cf.data(), sizeof(int) * cf.size(), hipMemcpyHostToDevice));
   }
+  {  // apk_stage_args.face_neighbor of the refined mesh: the same-rank block of the SAME level behind each face, or -1
+    const int nlb = (int)s->mesh.local_gids.size(), first = s->amr_part.first[s->rank];
+    const AmrTree &t = *s->amr;
+    std::vector<int> tab(6 * (size_t)nlb + 2, -1);
+    for (int lb = 0; lb < nlb; ++lb) {
+      const AmrLeaf &l = t.leaves[first + lb];
+      for (int d = 0; d < 3; ++d)
+        for (int side = 0; side < 2 && t.act[d]; ++side) {
+          int pos[3] = {l.lx[0], l.lx[1], l.lx[2]}, leaf = -1;
+          pos[d] += side ? 1 : -1;
+          if (t.Classify(l.level, pos, &leaf) == NB_SAME && s->amr_part.Owner(leaf) == s->rank) tab[6 * (size_t)lb + 2 * d + side] = leaf - first;
+        }
+    }
+    dev_free(s, reinterpret_cast<double *>(s->d_face_nbr));
+    s->d_face_nbr = nullptr;
+    double *p8 = nullptr;
+    SIM_TRY(s, dev_alloc(s, "face_neighbors", sizeof(int) * tab.size(), &p8));
+    s->d_face_nbr = reinterpret_cast<int *>(p8);
+    SIM_HIP(s, hipMemcpy(s->d_face_nbr, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
+  }
   for (int par = 0; par < 2; ++par) {
-    amr_capture_half(s, par, true, false, &a.xchg_pre[par]);
-    amr_capture_half(s, par, false, false, &a.xchg_post[par]);
-    amr_capture_half(s, par, true, true, &a.xchg_pre_faces[par]);
-    amr_capture_half(s, par, false, true, &a.xchg_post_faces[par]);
+    amr_capture_half(s, par, true, 0, &a.xchg_pre[par]);
+    amr_capture_half(s, par, false, 0, &a.xchg_post[par]);
+    amr_capture_half(s, par, true, 1, &a.xchg_pre_faces[par]);
+    amr_capture_half(s, par, false, 1, &a.xchg_post_faces[par]);
+    amr_capture_half(s, par, true, 2, &a.xchg_pre_direct[par]);
   }
   s->amr_ghosts_partial = false;  // (whoever rebuilt the plans fills the new mesh completely next)
   return build_packs(s);
@@ -441,15 +467,18 @@ int amr_rebuild(apk_sim *s) {
 
 // the multilevel ghost exchange of the state in cons buffer `buf` (see amr.hpp), in the two halves
 // either side of the message exchange
-int amr_exchange_pre(apk_sim *s, int buf, bool faces) {
+// (mode: AMR_XCHG_FULL, AMR_XCHG_FACES or AMR_XCHG_DIRECT)
+int amr_exchange_pre(apk_sim *s, int buf, int mode) {
   auto &a = s->amr_dev;
+  const bool faces = mode != AMR_XCHG_FULL;
   for (apk_refine_plan *p : a.restrict_own[buf]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
   SIM_TRY(s, apk_copy_plan_run(s->ctx, faces ? a.fill_pack_faces[buf] : a.fill_pack[buf], s->stream));
-  SIM_TRY(s, apk_copy_plan_run(s->ctx, faces ? a.fill_faces[buf] : a.fill[buf], s->stream));
+  SIM_TRY(s, apk_copy_plan_run(s->ctx, mode == AMR_XCHG_DIRECT ? a.fill_direct[buf] : (faces ? a.fill_faces[buf] : a.fill[buf]), s->stream));
   return APK_OK;
 }
-int amr_exchange_post(apk_sim *s, int buf, bool faces) {
+int amr_exchange_post(apk_sim *s, int buf, int mode) {
   auto &a = s->amr_dev;
+  const bool faces = mode != AMR_XCHG_FULL;
   SIM_TRY(s, apk_copy_plan_run(s->ctx, faces ? a.fill_unpack_faces[buf] : a.fill_unpack[buf], s->stream));
   for (int d = 0; d < 3; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.coarse_bc[buf][d], s->stream));
   for (apk_refine_plan *p : (faces ? a.prolongate_faces[buf] : a.prolongate[buf])) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
@@ -461,7 +490,7 @@ int amr_exchange_post(apk_sim *s, int buf, bool faces) {
 // which cannot be captured: the launches are recorded on a private stream (nothing executes) and
 // the graph is launched on the sim's stream later.  Any failure leaves *out null: the caller then
 // launches the plans one by one as before.
-void amr_capture_half(apk_sim *s, int buf, bool pre, bool faces, void **out) {
+void amr_capture_half(apk_sim *s, int buf, bool pre, int mode, void **out) {
   *out = nullptr;
   static const bool disabled = std::getenv("APK_NO_GRAPH") != nullptr;  // A/B switch
   if (disabled) return;
@@ -474,7 +503,7 @@ void amr_capture_half(apk_sim *s, int buf, bool pre, bool faces, void **out) {
     const apk_stream_t saved = s->stream;
     const std::string saved_err = s->err;
     s->stream = reinterpret_cast<apk_stream_t>(cs);
-    const int rc = pre ? amr_exchange_pre(s, buf, faces) : amr_exchange_post(s, buf, faces);
+    const int rc = pre ? amr_exchange_pre(s, buf, mode) : amr_exchange_post(s, buf, mode);
     s->stream = saved;
     ok = hipStreamEndCapture(cs, &graph) == hipSuccess && rc == APK_OK && graph != nullptr;
     if (rc != APK_OK) s->err = saved_err;
@@ -495,21 +524,27 @@ void amr_destroy_graphs(apk_sim *s) {
     if (a.xchg_post[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_post[buf]));
     if (a.xchg_pre_faces[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_pre_faces[buf]));
     if (a.xchg_post_faces[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_post_faces[buf]));
-    a.xchg_pre[buf] = a.xchg_post[buf] = a.xchg_pre_faces[buf] = a.xchg_post_faces[buf] = nullptr;
+    if (a.xchg_pre_direct[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_pre_direct[buf]));
+    a.xchg_pre[buf] = a.xchg_post[buf] = a.xchg_pre_faces[buf] = a.xchg_post_faces[buf] = a.xchg_pre_direct[buf] = nullptr;
   }
 }
 
-// faces = true: the stage loop's exchange -- everything but the ghost zones behind edges and corners,
+// AMR_XCHG_FACES: the stage loop's exchange -- everything but the ghost zones behind edges and corners,
 // which no sweep or flux correction reads (sync_ghosts completes them for accessors, tagging and regridding;
-// the last stage of a cycle that checks the refinement criteria exchanges in full)
-int amr_exchange(apk_sim *s, int buf, bool faces) {
+// the last stage of a cycle that checks the refinement criteria exchanges in full).  AMR_XCHG_DIRECT: nor the
+// ghost zones behind faces shared with a same-rank block of the same level, which the stages then read from
+// that block's interior (the face table built in amr_rebuild; same-level faces of OTHER ranks still arrive
+// in the messages).
+int amr_exchange(apk_sim *s, int buf, int mode) {
   auto &a = s->amr_dev;
-  void *pre = faces ? a.xchg_pre_faces[buf] : a.xchg_pre[buf], *post = faces ? a.xchg_post_faces[buf] : a.xchg_post[buf];
+  const bool faces = mode != AMR_XCHG_FULL;
+  void *pre = mode == AMR_XCHG_DIRECT ? a.xchg_pre_direct[buf] : (faces ? a.xchg_pre_faces[buf] : a.xchg_pre[buf]);
+  void *post = faces ? a.xchg_post_faces[buf] : a.xchg_post[buf];
   if (pre) SIM_HIP(s, hipGraphLaunch(static_cast<hipGraphExec_t>(pre), hs(s)));
-  else SIM_TRY(s, amr_exchange_pre(s, buf, faces));
+  else SIM_TRY(s, amr_exchange_pre(s, buf, mode));
   SIM_TRY(s, amr_exchange_messages(s, faces ? s->amr_halo_faces : s->amr_halo));
   if (post) SIM_HIP(s, hipGraphLaunch(static_cast<hipGraphExec_t>(post), hs(s)));
-  else SIM_TRY(s, amr_exchange_post(s, buf, faces));
+  else SIM_TRY(s, amr_exchange_post(s, buf, mode));
   if (!faces) s->amr_ghosts_partial = false;  // (of cons; the caller converts to primitives)
   return APK_OK;
 }

@@ -113,10 +113,12 @@ void amr_free_buffers(apk_sim *s, apk_sim::MsgSet &m);
 int amr_exchange_messages(apk_sim *s, const apk_sim::MsgSet &m);
 int amr_allocate(apk_sim *s, size_t n, double *cons2[2], double **prim, double *flux[3], double **coarse);
 int amr_rebuild(apk_sim *s);
-int amr_exchange(apk_sim *s, int buf, bool faces = false);
-int amr_exchange_pre(apk_sim *s, int buf, bool faces);
-int amr_exchange_post(apk_sim *s, int buf, bool faces);
-void amr_capture_half(apk_sim *s, int buf, bool pre, bool faces, void **out);
+enum { AMR_XCHG_FULL = 0, AMR_XCHG_FACES = 1, AMR_XCHG_DIRECT = 2 };  // which ghost zones the multilevel exchange fills
+int amr_exchange(apk_sim *s, int buf, int mode = AMR_XCHG_FULL);
+bool amr_direct(const apk_sim *s);
+int amr_exchange_pre(apk_sim *s, int buf, int mode);
+int amr_exchange_post(apk_sim *s, int buf, int mode);
+void amr_capture_half(apk_sim *s, int buf, bool pre, int mode, void **out);
 void amr_destroy_graphs(apk_sim *s);
 bool amr_has_coarse_fine_faces(const apk_sim *s);
 int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi_factor);

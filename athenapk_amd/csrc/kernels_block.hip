@@ -139,13 +139,17 @@ cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags) {
 // traffic): 26 % of the cells of a 16^3 block with nghost = 4.
 template <int FLUID>
 __global__ void __launch_bounds__(256)
-cons_to_prim_faces_kernel(PackView pv, apk_eos eos, unsigned *flags) {
+cons_to_prim_faces_kernel(PackView pv, apk_eos eos, unsigned *flags, const int *face_nbr) {
   int i, j;
   if (!rect_ij(pv.ni, pv.nj, i, j)) return;
   const int b = blockIdx.z / pv.nk;
   const int k = blockIdx.z % pv.nk;
   const int ghost = ((i < pv.is) || (i > pv.ie)) + ((j < pv.js) || (j > pv.je)) + ((k < pv.ks) || (k > pv.ke));
   if (ghost > 1) return;
+  if (ghost == 1 && face_nbr) {  // a zone the stages do not read (they follow the face table to that neighbour's interior)
+    const int f = (i < pv.is) ? 0 : (i > pv.ie) ? 1 : (j < pv.js) ? 2 : (j > pv.je) ? 3 : (k < pv.ks) ? 4 : 5;
+    if (face_nbr[6 * b + f] >= 0) return;
+  }
   cons_to_prim_at<FLUID>(pv, pv.blocks[b], eos, flags, k * pv.sk + j * pv.sj + i);
 }
 
@@ -497,7 +501,8 @@ int launch_dedner(const PackView &pv, int extended, double coeff, double beta_dt
 }
 
 int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsigned *d_flags,
-                        hipStream_t s, bool ghosts_only, const unsigned *late_regions, int part, bool faces_only) {
+                        hipStream_t s, bool ghosts_only, const unsigned *late_regions, int part, bool faces_only,
+                        const int *face_nbr) {
   if (ghosts_only) {
     const int64_t na = (int64_t)(pv.nk - pv.nx3) * pv.nj * pv.ni;
     const int64_t nb = (int64_t)pv.nx3 * (pv.nj - pv.nx2) * pv.ni;
@@ -514,9 +519,9 @@ int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsig
   const dim3 grid = rect_grid(pv.ni, pv.nj, pv.nk * pv.nblocks);
   if (faces_only) {
     if (fluid == APK_FLUID_EULER)
-      hipLaunchKernelGGL(cons_to_prim_faces_kernel<APK_FLUID_EULER>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags);
+      hipLaunchKernelGGL(cons_to_prim_faces_kernel<APK_FLUID_EULER>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, face_nbr);
     else
-      hipLaunchKernelGGL(cons_to_prim_faces_kernel<APK_FLUID_GLMMHD>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags);
+      hipLaunchKernelGGL(cons_to_prim_faces_kernel<APK_FLUID_GLMMHD>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, face_nbr);
   } else if (fluid == APK_FLUID_EULER)
     hipLaunchKernelGGL(cons_to_prim_kernel<APK_FLUID_EULER>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags);
   else

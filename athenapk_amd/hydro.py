@@ -191,10 +191,15 @@ def ConservedToPrimitive(md, fluid, eos):
     _check(ctx.lib.apk_cons_to_prim(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), _stream()), ctx.lib, ctx.h)
 
 
-def ConservedToPrimitiveFaces(md, fluid, eos):
-    """ConsToPrim of the interior and of the ghost cells straight behind a block face (at most one ghost coordinate)."""
+def ConservedToPrimitiveFaces(md, fluid, eos, face_neighbor=None):
+    """ConsToPrim of the interior and of the ghost cells straight behind a block face (at most one ghost coordinate);
+    face_neighbor (int32 device tensor [nblocks, 6]): not behind the faces whose entry is >= 0."""
     ctx = md.ctx
-    _check(ctx.lib.apk_cons_to_prim_faces(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), _stream()), ctx.lib, ctx.h)
+    if face_neighbor is None:
+        _check(ctx.lib.apk_cons_to_prim_faces(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), _stream()), ctx.lib, ctx.h)
+    else:
+        _check(ctx.lib.apk_cons_to_prim_faces_skip(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), C.c_void_p(face_neighbor.data_ptr()),
+                                                   _stream()), ctx.lib, ctx.h)
 
 
 def ConservedToPrimitiveGhosts(md, fluid, eos):

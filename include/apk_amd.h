@@ -254,11 +254,17 @@ int apk_cons_to_prim(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos 
 
 /* ConsToPrim (Update::FillDerived, hydro_driver.cpp:571-577; src/eos/adiabatic_hydro.cpp:33) of the interior
  * and of the ghost cells straight behind a block FACE only (at most one ghost coordinate): what the unsplit
- * sweeps (hydro.cpp:1025-1199), the flux correction and the tagging criteria (refinement/gradient.cpp) read.  The refined-
- * mesh stage loop of the standalone driver fills and converts only those (edges and corners are 37 % of
- * the ghost cells of a 16^3 block with nghost = 4); primitives behind edges and corners are left as
- * they were. */
+ * sweeps (hydro.cpp:1025-1199) and the flux correction read.  The refined-mesh stage loop of the standalone
+ * driver fills and converts only those (edges and corners are 37 % of the ghost cells of a 16^3 block with
+ * nghost = 4); primitives behind edges and corners are left as they were.  (The tagging criteria,
+ * refinement/gradient.cpp:33-36, DO read behind edges and corners: a cycle that ends with a refinement check
+ * exchanges and converts in full.) */
 int apk_cons_to_prim_faces(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, apk_stream_t stream);
+/* The same, leaving alone the ghost zone behind every face f of block b with face_neighbor[6 b + f] >= 0
+ * (apk_stage_args.face_neighbor: the stages read that neighbour's interior instead, so nobody fills or
+ * converts the zone).  face_neighbor: device pointer, [nblocks][6]. */
+int apk_cons_to_prim_faces_skip(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, const int *face_neighbor,
+                                apk_stream_t stream);
 /* ConsToPrim restricted to the ghost zones of every block (interior cells untouched): the
  * companion of apk_stage_fused(fill_derived = 1). */
 int apk_cons_to_prim_ghosts(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,

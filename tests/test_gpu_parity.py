@@ -222,6 +222,27 @@ def test_cons_to_prim_faces_converts_everything_but_edges_and_corners(request, n
     got, want = md.prim_host(), full.prim_host()
     assert np.array_equal(got[:, :, ~corner], want[:, :, ~corner]) and np.all(got[:, :, corner] == -3.0)
     assert ctx.poll_flags() == 0 and corner.any()
+    if nx[2] == 1:
+        return
+    # apk_cons_to_prim_faces_skip: nor behind the faces a face table marks as read from the neighbour's interior
+    import torch
+    tab = np.array([[1, -1, -1, 0, -1, -1], [-1, 0, 1, -1, -1, 1]], dtype=np.int32)
+    behind = np.zeros((2,) + u.shape[2:], dtype=bool)
+    zones = ((I < ng), (I >= ng + nx[0]), (J < ng), (J >= ng + nx[1]), (K < ng), (K >= ng + nx[2]))
+    for b in range(2):
+        for f in range(6):
+            if tab[b, f] >= 0:
+                behind[b] |= np.broadcast_to(zones[f] & (nghost == 1), u.shape[2:])
+    u3 = u2.copy()
+    for b in range(2):
+        u3[b, 0][behind[b]] = -1.0                   # garbage in the zones nobody fills
+    md = hydro.MeshData(ctx, nx, ng, 9, nblocks=2, cons=u3, prim=np.full_like(u, -3.0), with_flux=False)
+    hydro.ConservedToPrimitiveFaces(md, "glmmhd", eos, face_neighbor=torch.from_numpy(tab).cuda())
+    got = md.prim_host()
+    for b in range(2):
+        skip = corner | behind[b]
+        assert np.array_equal(got[b][:, ~skip], want[b][:, ~skip]) and np.all(got[b][:, skip] == -3.0) and behind[b].any()
+    assert ctx.poll_flags() == 0
 
 
 @pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
