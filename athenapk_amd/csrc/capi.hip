@@ -317,6 +317,19 @@ int apk_cons_to_prim(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos 
   return APK_OK;
 }
 
+int apk_cons_to_prim_dt(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, apk_stream_t stream) {
+  if (!ctx || !md || !valid_eos(eos) || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||
+      md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9))
+    return set_err(ctx, APK_ERR_INVALID, "apk_cons_to_prim_dt: bad argument");
+  hipStream_t s = as_stream(stream);
+  unsigned long long *dt_bits = ctx->d_u64 + 4;  // the stage's word: apk_stage_dt_read / apk_stage_dt_flags_read
+  APK_HIP_TRY(ctx, hipMemcpyAsync(dt_bits, ctx->d_u64 + 15, sizeof(double), hipMemcpyDeviceToDevice, s));
+  ScopedTiming timing(ctx, APK_T_C2P, s);
+  int rc = launch_cons_to_prim(md->view, fluid, *eos, ctx->d_flags, s, false, nullptr, 0, false, nullptr, dt_bits);
+  if (rc != APK_OK) return set_err(ctx, rc, "cons_to_prim kernel launch failed", hipGetLastError());
+  return APK_OK;
+}
+
 int apk_cons_to_prim_faces(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, apk_stream_t stream) {
   if (!ctx || !md || !valid_eos(eos) || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||
       md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9))

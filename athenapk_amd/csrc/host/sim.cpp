@@ -966,8 +966,14 @@ int do_stage(apk_sim *s, int stage) {
   } else {
     // (without a fused FillDerived the full-block ConsToPrim below reads every ghost zone)
     SIM_TRY(s, exchange_ghosts(s, c2p_in_copy, direct && fused_fill));
+    static const bool no_c2p_dt = std::getenv("APK_NO_C2P_DT") != nullptr;  // A/B switch
     if (fused_fill) {
       if (!c2p_in_copy) SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
+    } else if (stage == s->nstages && pkg.calc_dt_hyp && !no_c2p_dt) {
+      // the last FillDerived of the cycle and the time-step estimate that follows it (hydro_driver.cpp:571-603) in
+      // one pass: the interior cells' primitives are in registers anyway (refined meshes, flux-array stages)
+      SIM_TRY(s, apk_cons_to_prim_dt(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
+      s->stage_dt_pending = true;
     } else {
       SIM_TRY(s, fill_derived(s));
     }

@@ -99,12 +99,24 @@ dedner_kernel(PackView pv, double coeff, double beta_dt) {
   u[IPS * pv.sn] *= coeff;
 }
 
+// ---- wave/workgroup reductions -------------------------------------------------------------
+APK_DEV double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
+  return v;
+}
+APK_DEV double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
 // ---- ConservedToPrimitive over the ENTIRE block (src/eos/adiabatic_hydro.cpp:33-55) -----
 template <int FLUID>
-APK_DEV void cons_to_prim_at(const PackView &pv, const apk_block_desc &blk, const apk_eos &eos, unsigned *flags,
-                             int64_t cell) {
+APK_DEV void cons_to_prim_at_w(const PackView &pv, const apk_block_desc &blk, const apk_eos &eos, unsigned *flags,
+                               int64_t cell, double (&w)[nvars<FLUID>()]) {
   constexpr int NV = nvars<FLUID>();
-  double u[NV], w[NV];
+  double u[NV];
 #pragma unroll
   for (int n = 0; n < NV; ++n) u[n] = blk.cons[n * pv.sn + cell];
   const double d_in = u[IDN], m1 = u[IM1], m2 = u[IM2], m3 = u[IM3], e_in = u[IEN];
@@ -123,15 +135,57 @@ APK_DEV void cons_to_prim_at(const PackView &pv, const apk_block_desc &blk, cons
   for (int n = NV; n < pv.nvar; ++n)  // passive scalars (:139-141)
     blk.prim[n * pv.sn + cell] = blk.cons[n * pv.sn + cell] * di;
 }
-
 template <int FLUID>
+APK_DEV void cons_to_prim_at(const PackView &pv, const apk_block_desc &blk, const apk_eos &eos, unsigned *flags,
+                             int64_t cell) {
+  double w[nvars<FLUID>()];
+  cons_to_prim_at_w<FLUID>(pv, blk, eos, flags, cell, w);
+}
+
+// WITH_DT: EstimateHyperbolicTimestep (hydro.cpp:845-895) of the interior cells on the way, from the primitives in
+// registers -- the values min_dt_kernel would read back -- reduced into *dt_bits (apk_cons_to_prim_dt).
+template <int FLUID, bool WITH_DT>
 __global__ void __launch_bounds__(256)
-cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags) {
+cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags, unsigned long long *dt_bits) {
   int i, j;
-  if (!rect_ij(pv.ni, pv.nj, i, j)) return;
+  const bool ok = rect_ij(pv.ni, pv.nj, i, j);
+  if (!WITH_DT && !ok) return;
   const int b = blockIdx.z / pv.nk;
   const int k = blockIdx.z % pv.nk;
-  cons_to_prim_at<FLUID>(pv, pv.blocks[b], eos, flags, k * pv.sk + j * pv.sj + i);
+  double lane_min = 1.7976931348623157e308;
+  if (ok) {
+    const apk_block_desc blk = pv.blocks[b];
+    double w[nvars<FLUID>()];
+    cons_to_prim_at_w<FLUID>(pv, blk, eos, flags, k * pv.sk + j * pv.sj + i, w);
+    if constexpr (WITH_DT) {
+      if (i >= pv.is && i <= pv.ie && j >= pv.js && j <= pv.je && k >= pv.ks && k <= pv.ke) {
+        double lx, ly = 0.0, lz = 0.0;
+        if constexpr (FLUID == APK_FLUID_EULER) {
+          lx = ly = lz = sound_speed(eos.gamma, w[IDN], w[IPR]);
+        } else {
+          lx = fast_speed(eos.gamma, w[IDN], w[IPR], w[IB1], w[IB2], w[IB3]);
+          if (pv.ndim > 1) ly = fast_speed(eos.gamma, w[IDN], w[IPR], w[IB2], w[IB3], w[IB1]);
+          if (pv.ndim > 2) lz = fast_speed(eos.gamma, w[IDN], w[IPR], w[IB3], w[IB1], w[IB2]);
+        }
+        lane_min = fmin(lane_min, blk.dx[0] / (fabs(w[IV1]) + lx));
+        if (pv.ndim > 1) lane_min = fmin(lane_min, blk.dx[1] / (fabs(w[IV2]) + ly));
+        if (pv.ndim > 2) lane_min = fmin(lane_min, blk.dx[2] / (fabs(w[IV3]) + lz));
+      }
+    }
+  }
+  if constexpr (WITH_DT) {
+    // one candidate per workgroup, and an atomic only if it beats the word's current value (a plain read: a stale,
+    // larger value merely costs an atomic that changes nothing)
+    __shared__ double wmin[4];
+    const double m = wave_min(lane_min);
+    if (threadIdx.x == 0) wmin[threadIdx.y] = m;
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+      const double g = fmin(fmin(wmin[0], wmin[1]), fmin(wmin[2], wmin[3]));
+      const double cur = __longlong_as_double((long long)*reinterpret_cast<volatile unsigned long long *>(dt_bits));
+      if (g < cur) atomicMin(dt_bits, (unsigned long long)__double_as_longlong(g));
+    }
+  }
 }
 
 // Interior cells and the ghost cells straight behind a FACE of the block (at most one ghost coordinate):
@@ -202,18 +256,6 @@ cons_to_prim_ghosts_kernel(PackView pv, apk_eos eos, unsigned *flags, int64_t na
     if (late != (part == 2)) return;
   }
   cons_to_prim_at<FLUID>(pv, pv.blocks[b], eos, flags, k * pv.sk + j * pv.sj + i);
-}
-
-// ---- wave/workgroup reductions -------------------------------------------------------------
-APK_DEV double wave_min(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
-  return v;
-}
-APK_DEV double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
 }
 
 // ---- EstimateHyperbolicTimestep (src/hydro/hydro.cpp:828-896) ----------------------------
@@ -502,7 +544,7 @@ int launch_dedner(const PackView &pv, int extended, double coeff, double beta_dt
 
 int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsigned *d_flags,
                         hipStream_t s, bool ghosts_only, const unsigned *late_regions, int part, bool faces_only,
-                        const int *face_nbr) {
+                        const int *face_nbr, unsigned long long *dt_bits) {
   if (ghosts_only) {
     const int64_t na = (int64_t)(pv.nk - pv.nx3) * pv.nj * pv.ni;
     const int64_t nb = (int64_t)pv.nx3 * (pv.nj - pv.nx2) * pv.ni;
@@ -522,10 +564,15 @@ int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsig
       hipLaunchKernelGGL(cons_to_prim_faces_kernel<APK_FLUID_EULER>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, face_nbr);
     else
       hipLaunchKernelGGL(cons_to_prim_faces_kernel<APK_FLUID_GLMMHD>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, face_nbr);
+  } else if (dt_bits) {
+    if (fluid == APK_FLUID_EULER)
+      hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_EULER, true>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits);
+    else
+      hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_GLMMHD, true>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits);
   } else if (fluid == APK_FLUID_EULER)
-    hipLaunchKernelGGL(cons_to_prim_kernel<APK_FLUID_EULER>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags);
+    hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_EULER, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits);
   else
-    hipLaunchKernelGGL(cons_to_prim_kernel<APK_FLUID_GLMMHD>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags);
+    hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_GLMMHD, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits);
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }
 

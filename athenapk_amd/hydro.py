@@ -191,6 +191,13 @@ def ConservedToPrimitive(md, fluid, eos):
     _check(ctx.lib.apk_cons_to_prim(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), _stream()), ctx.lib, ctx.h)
 
 
+def ConservedToPrimitiveDt(md, fluid, eos, cfl):
+    """ConsToPrim of every cell and the hyperbolic time-step estimate of the interior in one pass (apk_cons_to_prim_dt)."""
+    ctx = md.ctx
+    _check(ctx.lib.apk_cons_to_prim_dt(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), _stream()), ctx.lib, ctx.h)
+    return StageDt(ctx, cfl)
+
+
 def ConservedToPrimitiveFaces(md, fluid, eos, face_neighbor=None):
     """ConsToPrim of the interior and of the ghost cells straight behind a block face (at most one ghost coordinate);
     face_neighbor (int32 device tensor [nblocks, 6]): not behind the faces whose entry is >= 0."""

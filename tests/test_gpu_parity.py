@@ -289,6 +289,39 @@ def test_estimate_timestep(request, fluid, nx):
     assert dt == 0.3 * H.orc_min_dt(fluid, g, prim, GAMMA)
 
 
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("fluid", ["euler", "glmmhd"])
+@pytest.mark.parametrize("nx", [(16, 8, 8), (64, 6, 5), (16, 10, 1), (40, 1, 1)], ids=["3d", "3d_wide", "2d", "1d"])
+def test_cons_to_prim_with_time_step_estimate(request, fluid, nx, strict):
+    """apk_cons_to_prim_dt = apk_cons_to_prim + apk_estimate_timestep in one pass: the same primitives in every cell
+    (ghost zones included), and the minimum over the INTERIOR cells only -- the ghost zones hold faster states here --
+    equal to the oracle's estimate on the oracle's primitives (bit for bit in the parity build)."""
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    ng = 2
+    g = H.geom(fluid, nx, ng, 0, (0.1, 0.07, 0.13))
+    w = H.random_prim(fluid, nx, ng, seed=16, kind="rough", nblocks=3)
+    act = [True, nx[1] > 1, nx[2] > 1]
+    inner = tuple(slice(ng, -ng) if a else slice(None) for a in act[::-1])
+    fast = w.copy()
+    fast[:, 1:4] *= 50.0                               # ghost cells that would win the minimum if they were read
+    fast[(slice(None), slice(None)) + inner] = w[(slice(None), slice(None)) + inner]
+    u = H.prim_to_cons(fluid, fast, GAMMA)
+    eos = hydro.L.make_eos(GAMMA)
+    ref = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=u, with_flux=False)
+    hydro.ConservedToPrimitive(ref, fluid, eos)
+    md = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=u, with_flux=False)
+    dt = hydro.ConservedToPrimitiveDt(md, fluid, eos, 0.3)
+    assert np.array_equal(md.prim_host(), ref.prim_host())
+    want = hydro.EstimateTimestep(ref, fluid, eos, 0.3)
+    if strict:
+        _, w_orc, bad = H.orc_c2p(fluid, g, u, H.O.make_eos(GAMMA))
+        assert bad == 0 and np.array_equal(w_orc, ref.prim_host())
+        assert dt == want == 0.3 * H.orc_min_dt(fluid, g, w_orc, GAMMA)
+    else:
+        assert abs(dt - want) <= 4e-16 * want
+
+
 @pytest.mark.parametrize("fluid", ["euler", "glmmhd"])
 def test_history(request, fluid):
     from athenapk_amd import hydro
