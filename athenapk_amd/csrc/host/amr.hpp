@@ -304,8 +304,14 @@ inline void amr_bc_regions(const AmrTree &t, int lb, int kind, const int n[3], c
   }
 }
 
-inline void BuildAmrPlans(const AmrTree &t, const AmrGeom &g, AmrPlans &p) {
+// fill_depth > 0: the fills of the blocks' own ghost zones (copies, restricted fine data, prolongation, physical
+// boundaries) reach only that many layers deep -- the "shell" exchange that precedes a refinement check when the
+// first stage of the next cycle needs no more (the gradient criteria read 2 layers, edges and corners included).
+// Coarse-buffer fills are always complete.  Even, at most nghost.
+inline void BuildAmrPlans(const AmrTree &t, const AmrGeom &g, AmrPlans &p, int fill_depth = 0) {
   p = AmrPlans();
+  const int gd = (fill_depth > 0 && fill_depth < g.ng) ? fill_depth : g.ng;
+  if (gd % 2 != 0) throw std::runtime_error("the ghost fill depth must be even");
   const int nb = (int)t.leaves.size();
   for (int d = 0; d < 3; ++d)
     if (g.act[d] && (g.mb[d] % 2 != 0 || g.mb[d] / 2 < g.cng || g.mb[d] / 2 < g.ng))
@@ -349,9 +355,9 @@ inline void BuildAmrPlans(const AmrTree &t, const AmrGeom &g, AmrPlans &p) {
           if (!g.act[d] || o[d] == 0) {
             dlo[d] = slo[d] = g.fs[d], ext[d] = g.act[d] ? g.mb[d] : 1;
           } else {
-            ext[d] = g.ng;
-            dlo[d] = (o[d] < 0) ? g.fs[d] - g.ng : g.fe[d] + 1;
-            slo[d] = (o[d] < 0) ? g.fe[d] - g.ng + 1 : g.fs[d];
+            ext[d] = gd;
+            dlo[d] = (o[d] < 0) ? g.fs[d] - gd : g.fe[d] + 1;
+            slo[d] = (o[d] < 0) ? g.fe[d] - gd + 1 : g.fs[d];
           }
         }
         BoxRegion r;
@@ -402,9 +408,9 @@ inline void BuildAmrPlans(const AmrTree &t, const AmrGeom &g, AmrPlans &p) {
                   dlo[d] = g.fs[d] + c[d] * (g.mb[d] / 2);
                   slo[d] = g.cs[d];
                 } else {
-                  ext[d] = g.ng;
-                  dlo[d] = (o[d] < 0) ? g.fs[d] - g.ng : g.fe[d] + 1;
-                  slo[d] = (o[d] < 0) ? g.ce[d] - g.ng + 1 : g.cs[d];
+                  ext[d] = gd;
+                  dlo[d] = (o[d] < 0) ? g.fs[d] - gd : g.fe[d] + 1;
+                  slo[d] = (o[d] < 0) ? g.ce[d] - gd + 1 : g.cs[d];
                 }
               }
               BoxRegion r;
@@ -472,16 +478,16 @@ inline void BuildAmrPlans(const AmrTree &t, const AmrGeom &g, AmrPlans &p) {
           if (!g.act[d] || o[d] == 0) {
             op.lo[d] = g.cs[d], op.hi[d] = g.ce[d];
           } else if (o[d] < 0) {
-            op.lo[d] = g.cs[d] - g.ng / 2, op.hi[d] = g.cs[d] - 1;
+            op.lo[d] = g.cs[d] - gd / 2, op.hi[d] = g.cs[d] - 1;
           } else {
-            op.lo[d] = g.ce[d] + 1, op.hi[d] = g.ce[d] + g.ng / 2;
+            op.lo[d] = g.ce[d] + 1, op.hi[d] = g.ce[d] + gd / 2;
           }
         }
         op.corner = behind_corner;
         p.prolongate.push_back(op);
       }
     });
-    amr_bc_regions(t, lb, RK_BLOCK, g.fn, g.fs, g.fe, g.ng, g.fst, g.nvar, p.fine_bc);
+    amr_bc_regions(t, lb, RK_BLOCK, g.fn, g.fs, g.fe, gd, g.fst, g.nvar, p.fine_bc);
     if (has_coarser[lb]) amr_bc_regions(t, lb, RK_COARSE, g.cn, g.cs, g.ce, g.cng, g.cst, g.nvar, p.coarse_bc);
   }
 }

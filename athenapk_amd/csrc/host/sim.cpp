@@ -478,6 +478,19 @@ bool amr_faces_only(const apk_sim *s) {
   return s->amr && !s->amr_full_exchange && s->mesh.ndim >= 2;
 }
 
+// Refined meshes, the exchange after the last stage of a cycle that ends with a refinement check (regrid_check_follows):
+// may it fill the ghost zones AMR_SHELL_DEPTH layers deep only?  Tagging reads that far (refinement/gradient.cpp:33-36),
+// and so must the first stage of the next cycle: a donor-cell stage (the VL2 predictor) reads one layer, PLM two.
+// (Whoever needs more -- accessors, the data transfer of a regridding that does change the mesh -- calls sync_ghosts.)
+bool amr_shell_before_check(const apk_sim *s) {
+  static const bool off = std::getenv("APK_NO_AMR_SHELL") != nullptr;      // A/B switches
+  static const bool no_c2p_dt = std::getenv("APK_NO_C2P_DT") != nullptr;
+  const HydroPackage &pkg = s->pkg;
+  if (off || no_c2p_dt || !s->amr || !amr_faces_only(s) || !amr_has_shell(s) || !stage_can_fuse(s) || !pkg.calc_dt_hyp) return false;
+  const int recon = pkg.flux_first_stage.recon;
+  return recon == APK_RC_DC || recon == APK_RC_PLM;
+}
+
 // fill the ghost zones that direct neighbour addressing left stale (cons and prim of the current state)
 int materialize_local_ghosts(apk_sim *s) {
   if (!s->local_ghosts_stale) return APK_OK;
@@ -490,8 +503,9 @@ int materialize_local_ghosts(apk_sim *s) {
 
 int sync_ghosts(apk_sim *s) {
   if (s->amr) {
-    if (!s->amr_ghosts_partial) return APK_OK;
-    // the stage loop left the ghost zones behind edges and corners alone: complete exchange + ConsToPrim
+    if (s->amr_ghost_state == AMR_GHOSTS_COMPLETE) return APK_OK;
+    // the stage loop left the ghost zones behind edges and corners alone (or filled all of them a few layers deep):
+    // complete exchange + ConsToPrim
     SIM_TRY(s, amr_exchange(s, s->cur, AMR_XCHG_FULL));
     return fill_derived(s);
   }
@@ -962,7 +976,12 @@ int do_stage(apk_sim *s, int stage) {
       SIM_TRY(s, amr_exchange(s, s->cur, AMR_XCHG_FACES));
       SIM_TRY(s, apk_cons_to_prim_faces(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
     }
-    s->amr_ghosts_partial = true;
+  } else if (s->amr && stage == s->nstages && amr_shell_before_check(s)) {
+    // the last exchange of a cycle that ends with a refinement check: every ghost zone, but only as deep as the tagging
+    // criteria and the first stage of the next cycle read; ConsToPrim of that shell with the time-step estimate
+    SIM_TRY(s, amr_exchange(s, s->cur, AMR_XCHG_SHELL));
+    SIM_TRY(s, apk_cons_to_prim_dt(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, AMR_SHELL_DEPTH, s->stream));
+    s->stage_dt_pending = true;
   } else {
     // (without a fused FillDerived the full-block ConsToPrim below reads every ghost zone)
     SIM_TRY(s, exchange_ghosts(s, c2p_in_copy, direct && fused_fill));
@@ -972,7 +991,7 @@ int do_stage(apk_sim *s, int stage) {
     } else if (stage == s->nstages && pkg.calc_dt_hyp && !no_c2p_dt) {
       // the last FillDerived of the cycle and the time-step estimate that follows it (hydro_driver.cpp:571-603) in
       // one pass: the interior cells' primitives are in registers anyway (refined meshes, flux-array stages)
-      SIM_TRY(s, apk_cons_to_prim_dt(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
+      SIM_TRY(s, apk_cons_to_prim_dt(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, -1, s->stream));
       s->stage_dt_pending = true;
     } else {
       SIM_TRY(s, fill_derived(s));
@@ -1160,6 +1179,7 @@ void apk_sim_destroy(apk_sim *s) {
     if (s->amr) amr_destroy_device_plans(s);
     amr_free_buffers(s, s->amr_halo);
     amr_free_buffers(s, s->amr_halo_faces);
+    amr_free_buffers(s, s->amr_halo_shell);
     amr_free_buffers(s, s->amr_fluxmsg);
     amr_free_buffers(s, s->amr_move);
     dev_free(s, s->d_coarse);

@@ -201,16 +201,22 @@ struct apk_sim {
     // ... and without the same-rank copies between blocks of one level either (BoxRegion::same_face): the exchange
     // after a stage when the next one reads those neighbours through the face table (amr_direct)
     std::vector<apk::BoxRegion> fill_direct;
+    // the exchange before a refinement check when the next cycle's first stage reads at most AMR_SHELL_DEPTH ghost
+    // layers: every ghost zone, edges and corners too, but only that deep (BuildAmrPlans(fill_depth))
+    std::vector<apk::AmrRefOp> prolongate_shell;
+    std::vector<apk::BoxRegion> fill_shell, fill_pack_shell, fill_unpack_shell, fine_bc_shell[3];
   } amr_local;
   struct MsgSet {
     apk::AmrMessages plan;
     std::vector<double *> send, recv;
     std::vector<int64_t> send_cap, recv_cap;
   };
-  MsgSet amr_halo, amr_fluxmsg, amr_move, amr_halo_faces;
-  // refined meshes: the stage loop fills (and converts to primitives) only the ghost zones behind block FACES;
-  // accessors and regridding complete them first (sync_ghosts)
-  bool amr_ghosts_partial = false;
+  MsgSet amr_halo, amr_fluxmsg, amr_move, amr_halo_faces, amr_halo_shell;
+  // refined meshes: the stage loop fills (and converts to primitives) only the ghost zones behind block FACES
+  // (AMR_GHOSTS_FACES), or all of them AMR_SHELL_DEPTH layers deep before a refinement check (AMR_GHOSTS_SHELL: what
+  // the tagging criteria and a donor-cell / PLM first stage read); accessors and regridding complete them first
+  // (sync_ghosts)
+  int amr_ghost_state = 0;  // AMR_GHOSTS_COMPLETE
   bool amr_full_exchange = std::getenv("APK_AMR_FULL_EXCHANGE") != nullptr;  // apk_sim_set_amr_full_exchange
   const MsgSet *active_msgs = nullptr;  // the message set apk_sim_peer reports (null: the uniform mesh's)
   long long msg_generation = 0;         // bumped whenever that set, its sizes or its buffers change
@@ -230,6 +236,11 @@ struct apk_sim {
     void *xchg_pre_faces[2] = {nullptr, nullptr}, *xchg_post_faces[2] = {nullptr, nullptr};
     apk_copy_plan *fill_direct[2] = {nullptr, nullptr};  // (AmrLocalPlans::fill_direct; the other plans of the faces-only exchange)
     void *xchg_pre_direct[2] = {nullptr, nullptr};
+    // the shell exchange (AmrLocalPlans::fill_shell ...)
+    std::vector<apk_refine_plan *> prolongate_shell[2];
+    apk_copy_plan *fill_shell[2] = {nullptr, nullptr}, *fill_pack_shell[2] = {nullptr, nullptr}, *fill_unpack_shell[2] = {nullptr, nullptr};
+    apk_copy_plan *fine_bc_shell[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    void *xchg_pre_shell[2] = {nullptr, nullptr}, *xchg_post_shell[2] = {nullptr, nullptr};
     apk_flux_fix_plan *flux_fix[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     // the faces (6 * local block + face) with a coarser or finer block behind them: the only boundary-plane
     // fluxes the correction after a fused stage reads (apk_calculate_fluxes_boundary_list)

@@ -83,6 +83,15 @@ void amr_localize(apk_sim *s) {
     for (const BoxRegion &r : l.fill_faces)
       if (!r.same_face) l.fill_direct.push_back(r);
   }
+  s->amr_halo_shell.plan = AmrMessages();
+  if (s->amr_geom.ng > AMR_SHELL_DEPTH) {  // the shell exchange: the same walk with shallower boxes
+    AmrPlans shell;
+    BuildAmrPlans(*s->amr, s->amr_geom, shell, AMR_SHELL_DEPTH);
+    AmrRegisterPeers(shell.fill, part, part, rank, s->amr_halo_shell.plan);
+    AmrLocalize(shell.fill, part, part, rank, s->amr_halo_shell.plan, l.fill_shell, l.fill_pack_shell, l.fill_unpack_shell);
+    take_ops(shell.prolongate, l.prolongate_shell);
+    for (int d = 0; d < 3; ++d) take_bc(shell.fine_bc[d], l.fine_bc_shell[d]);
+  }
   for (int d = 0; d < 3; ++d) AmrRegisterPeers(g.flux_copy[d], part, part, rank, s->amr_fluxmsg.plan);
   for (int d = 0; d < 3; ++d)
     AmrLocalize(g.flux_copy[d], part, part, rank, s->amr_fluxmsg.plan, l.flux_copy[d], l.flux_pack[d], l.flux_unpack[d]);
@@ -257,6 +266,16 @@ void amr_destroy_device_plans(apk_sim *s) {
     a.fill_faces[par] = a.fill_pack_faces[par] = a.fill_unpack_faces[par] = nullptr;
     apk_copy_plan_destroy(a.fill_direct[par]);
     a.fill_direct[par] = nullptr;
+    for (apk_refine_plan *p : a.prolongate_shell[par]) apk_refine_plan_destroy(p);
+    a.prolongate_shell[par].clear();
+    apk_copy_plan_destroy(a.fill_shell[par]);
+    apk_copy_plan_destroy(a.fill_pack_shell[par]);
+    apk_copy_plan_destroy(a.fill_unpack_shell[par]);
+    a.fill_shell[par] = a.fill_pack_shell[par] = a.fill_unpack_shell[par] = nullptr;
+    for (int d = 0; d < 3; ++d) {
+      apk_copy_plan_destroy(a.fine_bc_shell[par][d]);
+      a.fine_bc_shell[par][d] = nullptr;
+    }
     for (int d = 0; d < 3; ++d) {
       apk_copy_plan_destroy(a.coarse_bc[par][d]);
       apk_copy_plan_destroy(a.fine_bc[par][d]);
@@ -384,6 +403,7 @@ int amr_rebuild(apk_sim *s) {
   }
   SIM_TRY(s, amr_ensure_buffers(s, s->amr_halo, "halo"));
   SIM_TRY(s, amr_ensure_buffers(s, s->amr_halo_faces, "halo_faces"));
+  SIM_TRY(s, amr_ensure_buffers(s, s->amr_halo_shell, "halo_shell"));
   SIM_TRY(s, amr_ensure_buffers(s, s->amr_fluxmsg, "fluxcorr"));
   amr_destroy_device_plans(s);
   auto &a = s->amr_dev;
@@ -399,6 +419,13 @@ int amr_rebuild(apk_sim *s) {
     SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_pack_faces, &s->amr_halo_faces, &a.fill_pack_faces[par]));
     SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_unpack_faces, &s->amr_halo_faces, &a.fill_unpack_faces[par]));
     SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_direct, nullptr, &a.fill_direct[par]));
+    if (amr_has_shell(s)) {
+      SIM_TRY(s, amr_make_refine_plans(s, par, p.prolongate_shell, a.prolongate_shell[par]));
+      SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_shell, nullptr, &a.fill_shell[par]));
+      SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_pack_shell, &s->amr_halo_shell, &a.fill_pack_shell[par]));
+      SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_unpack_shell, &s->amr_halo_shell, &a.fill_unpack_shell[par]));
+      for (int d = 0; d < 3; ++d) SIM_TRY(s, amr_make_copy_plan(s, par, p.fine_bc_shell[d], nullptr, &a.fine_bc_shell[par][d]));
+    }
     for (int d = 0; d < 3; ++d) {
       SIM_TRY(s, amr_make_copy_plan(s, par, p.coarse_bc[d], nullptr, &a.coarse_bc[par][d]));
       SIM_TRY(s, amr_make_copy_plan(s, par, p.fine_bc[d], nullptr, &a.fine_bc[par][d]));
@@ -460,24 +487,42 @@ int amr_rebuild(apk_sim *s) {
     amr_capture_half(s, par, true, 1, &a.xchg_pre_faces[par]);
     amr_capture_half(s, par, false, 1, &a.xchg_post_faces[par]);
     amr_capture_half(s, par, true, 2, &a.xchg_pre_direct[par]);
+    if (amr_has_shell(s)) {
+      amr_capture_half(s, par, true, AMR_XCHG_SHELL, &a.xchg_pre_shell[par]);
+      amr_capture_half(s, par, false, AMR_XCHG_SHELL, &a.xchg_post_shell[par]);
+    }
   }
-  s->amr_ghosts_partial = false;  // (whoever rebuilt the plans fills the new mesh completely next)
+  s->amr_ghost_state = AMR_GHOSTS_COMPLETE;  // (whoever rebuilt the plans fills the new mesh completely next)
   return build_packs(s);
 }
 
 // the multilevel ghost exchange of the state in cons buffer `buf` (see amr.hpp), in the two halves
 // either side of the message exchange
-// (mode: AMR_XCHG_FULL, AMR_XCHG_FACES or AMR_XCHG_DIRECT)
+// is there a shell exchange (more ghost layers than it fills)?
+bool amr_has_shell(const apk_sim *s) { return s->amr_geom.ng > AMR_SHELL_DEPTH; }
+
+// (mode: AMR_XCHG_FULL, AMR_XCHG_FACES, AMR_XCHG_DIRECT or AMR_XCHG_SHELL)
 int amr_exchange_pre(apk_sim *s, int buf, int mode) {
   auto &a = s->amr_dev;
-  const bool faces = mode != AMR_XCHG_FULL;
   for (apk_refine_plan *p : a.restrict_own[buf]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
+  if (mode == AMR_XCHG_SHELL) {
+    SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fill_pack_shell[buf], s->stream));
+    return apk_copy_plan_run(s->ctx, a.fill_shell[buf], s->stream);
+  }
+  const bool faces = mode != AMR_XCHG_FULL;
   SIM_TRY(s, apk_copy_plan_run(s->ctx, faces ? a.fill_pack_faces[buf] : a.fill_pack[buf], s->stream));
   SIM_TRY(s, apk_copy_plan_run(s->ctx, mode == AMR_XCHG_DIRECT ? a.fill_direct[buf] : (faces ? a.fill_faces[buf] : a.fill[buf]), s->stream));
   return APK_OK;
 }
 int amr_exchange_post(apk_sim *s, int buf, int mode) {
   auto &a = s->amr_dev;
+  if (mode == AMR_XCHG_SHELL) {
+    SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fill_unpack_shell[buf], s->stream));
+    for (int d = 0; d < 3; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.coarse_bc[buf][d], s->stream));
+    for (apk_refine_plan *p : a.prolongate_shell[buf]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
+    for (int d = 0; d < 3; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fine_bc_shell[buf][d], s->stream));
+    return APK_OK;
+  }
   const bool faces = mode != AMR_XCHG_FULL;
   SIM_TRY(s, apk_copy_plan_run(s->ctx, faces ? a.fill_unpack_faces[buf] : a.fill_unpack[buf], s->stream));
   for (int d = 0; d < 3; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.coarse_bc[buf][d], s->stream));
@@ -525,7 +570,10 @@ void amr_destroy_graphs(apk_sim *s) {
     if (a.xchg_pre_faces[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_pre_faces[buf]));
     if (a.xchg_post_faces[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_post_faces[buf]));
     if (a.xchg_pre_direct[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_pre_direct[buf]));
+    if (a.xchg_pre_shell[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_pre_shell[buf]));
+    if (a.xchg_post_shell[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_post_shell[buf]));
     a.xchg_pre[buf] = a.xchg_post[buf] = a.xchg_pre_faces[buf] = a.xchg_post_faces[buf] = a.xchg_pre_direct[buf] = nullptr;
+    a.xchg_pre_shell[buf] = a.xchg_post_shell[buf] = nullptr;
   }
 }
 
@@ -537,15 +585,18 @@ void amr_destroy_graphs(apk_sim *s) {
 // in the messages).
 int amr_exchange(apk_sim *s, int buf, int mode) {
   auto &a = s->amr_dev;
-  const bool faces = mode != AMR_XCHG_FULL;
-  void *pre = mode == AMR_XCHG_DIRECT ? a.xchg_pre_direct[buf] : (faces ? a.xchg_pre_faces[buf] : a.xchg_pre[buf]);
-  void *post = faces ? a.xchg_post_faces[buf] : a.xchg_post[buf];
+  if (mode == AMR_XCHG_SHELL && !amr_has_shell(s)) mode = AMR_XCHG_FULL;
+  const bool faces = mode == AMR_XCHG_FACES || mode == AMR_XCHG_DIRECT;
+  void *pre = mode == AMR_XCHG_SHELL ? a.xchg_pre_shell[buf]
+              : mode == AMR_XCHG_DIRECT ? a.xchg_pre_direct[buf] : (faces ? a.xchg_pre_faces[buf] : a.xchg_pre[buf]);
+  void *post = mode == AMR_XCHG_SHELL ? a.xchg_post_shell[buf] : (faces ? a.xchg_post_faces[buf] : a.xchg_post[buf]);
   if (pre) SIM_HIP(s, hipGraphLaunch(static_cast<hipGraphExec_t>(pre), hs(s)));
   else SIM_TRY(s, amr_exchange_pre(s, buf, mode));
-  SIM_TRY(s, amr_exchange_messages(s, faces ? s->amr_halo_faces : s->amr_halo));
+  SIM_TRY(s, amr_exchange_messages(s, mode == AMR_XCHG_SHELL ? s->amr_halo_shell : (faces ? s->amr_halo_faces : s->amr_halo)));
   if (post) SIM_HIP(s, hipGraphLaunch(static_cast<hipGraphExec_t>(post), hs(s)));
   else SIM_TRY(s, amr_exchange_post(s, buf, mode));
-  if (!faces) s->amr_ghosts_partial = false;  // (of cons; the caller converts to primitives)
+  // (of cons; the caller converts to primitives)
+  s->amr_ghost_state = mode == AMR_XCHG_FULL ? AMR_GHOSTS_COMPLETE : (mode == AMR_XCHG_SHELL ? AMR_GHOSTS_SHELL : AMR_GHOSTS_FACES);
   return APK_OK;
 }
 
@@ -803,9 +854,9 @@ int amr_transfer(apk_sim *s, const std::vector<AmrLeaf> &old, const AmrPartition
 int amr_tags_begin(apk_sim *s, AmrTagRequest *req) {
   // the criteria difference every cell of the ring [s-1, e+1]^3 (refinement/gradient.cpp:33-36): ghost cells
   // behind edges and corners included, which the stage loop's faces-only exchange leaves stale.  The last
-  // stage of a checking cycle exchanges in full (do_stage), so this is a no-op there; it is what covers
-  // apk_sim_regrid / apk_sim_check_refinement between cycles.
-  SIM_TRY(s, sync_ghosts(s));
+  // stage of a checking cycle exchanges in full or AMR_SHELL_DEPTH (= the criteria's reach) layers deep (do_stage),
+  // so this is a no-op there; it is what covers apk_sim_regrid / apk_sim_check_refinement between cycles.
+  if (s->amr_ghost_state == AMR_GHOSTS_FACES) SIM_TRY(s, sync_ghosts(s));
   SIM_TRY(s, refinement_criterion(s, &req->criterion, &req->p0, &req->p1));
   SIM_TRY(s, apk_tag_blocks_begin(s->ctx, s->mu0(), req->criterion, &req->pending, s->stream));
   return APK_OK;

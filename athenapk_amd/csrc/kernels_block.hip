@@ -146,12 +146,16 @@ APK_DEV void cons_to_prim_at(const PackView &pv, const apk_block_desc &blk, cons
 // registers -- the values min_dt_kernel would read back -- reduced into *dt_bits (apk_cons_to_prim_dt).
 template <int FLUID, bool WITH_DT>
 __global__ void __launch_bounds__(256)
-cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags, unsigned long long *dt_bits) {
+cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags, unsigned long long *dt_bits, int depth) {
   int i, j;
-  const bool ok = rect_ij(pv.ni, pv.nj, i, j);
+  bool ok = rect_ij(pv.ni, pv.nj, i, j);
   if (!WITH_DT && !ok) return;
   const int b = blockIdx.z / pv.nk;
   const int k = blockIdx.z % pv.nk;
+  // depth >= 0: only the cells within that many layers of the interior (the shell a shallow ghost exchange has filled)
+  if (WITH_DT && depth >= 0)
+    ok = ok && i >= pv.is - depth && i <= pv.ie + depth && (pv.ndim < 2 || (j >= pv.js - depth && j <= pv.je + depth)) &&
+         (pv.ndim < 3 || (k >= pv.ks - depth && k <= pv.ke + depth));
   double lane_min = 1.7976931348623157e308;
   if (ok) {
     const apk_block_desc blk = pv.blocks[b];
@@ -544,7 +548,7 @@ int launch_dedner(const PackView &pv, int extended, double coeff, double beta_dt
 
 int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsigned *d_flags,
                         hipStream_t s, bool ghosts_only, const unsigned *late_regions, int part, bool faces_only,
-                        const int *face_nbr, unsigned long long *dt_bits) {
+                        const int *face_nbr, unsigned long long *dt_bits, int depth) {
   if (ghosts_only) {
     const int64_t na = (int64_t)(pv.nk - pv.nx3) * pv.nj * pv.ni;
     const int64_t nb = (int64_t)pv.nx3 * (pv.nj - pv.nx2) * pv.ni;
@@ -566,13 +570,13 @@ int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsig
       hipLaunchKernelGGL(cons_to_prim_faces_kernel<APK_FLUID_GLMMHD>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, face_nbr);
   } else if (dt_bits) {
     if (fluid == APK_FLUID_EULER)
-      hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_EULER, true>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits);
+      hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_EULER, true>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, depth);
     else
-      hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_GLMMHD, true>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits);
+      hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_GLMMHD, true>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, depth);
   } else if (fluid == APK_FLUID_EULER)
-    hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_EULER, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits);
+    hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_EULER, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, -1);
   else
-    hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_GLMMHD, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits);
+    hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_GLMMHD, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, -1);
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }
 

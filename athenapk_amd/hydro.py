@@ -191,10 +191,11 @@ def ConservedToPrimitive(md, fluid, eos):
     _check(ctx.lib.apk_cons_to_prim(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), _stream()), ctx.lib, ctx.h)
 
 
-def ConservedToPrimitiveDt(md, fluid, eos, cfl):
-    """ConsToPrim of every cell and the hyperbolic time-step estimate of the interior in one pass (apk_cons_to_prim_dt)."""
+def ConservedToPrimitiveDt(md, fluid, eos, cfl, ghost_depth=-1):
+    """ConsToPrim of every cell (ghost_depth >= 0: of the cells at most that many layers outside the interior) and the
+    hyperbolic time-step estimate of the interior in one pass (apk_cons_to_prim_dt)."""
     ctx = md.ctx
-    _check(ctx.lib.apk_cons_to_prim_dt(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), _stream()), ctx.lib, ctx.h)
+    _check(ctx.lib.apk_cons_to_prim_dt(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), ghost_depth, _stream()), ctx.lib, ctx.h)
     return StageDt(ctx, cfl)
 
 

@@ -164,7 +164,7 @@ def _signatures():
         "apk_cons_to_prim": (i, [vp, vp, i, E, vp]),
         "apk_cons_to_prim_ghosts": (i, [vp, vp, i, E, vp]),
         "apk_cons_to_prim_faces": (i, [vp, vp, i, E, vp]),
-        "apk_cons_to_prim_dt": (i, [vp, vp, i, E, vp]),
+        "apk_cons_to_prim_dt": (i, [vp, vp, i, E, i, vp]),
         "apk_cons_to_prim_faces_skip": (i, [vp, vp, i, E, vp, vp]),
         "apk_cons_to_prim_ghosts_split": (i, [vp, vp, i, E, vp, i, vp]),
         "apk_stage_dt_read": (i, [vp, d, c_dp, vp]),

@@ -256,8 +256,10 @@ int apk_cons_to_prim(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos 
  * interior cells from the primitives it has just computed: the last FillDerived of a cycle and the time-step
  * estimate that follows it (hydro_driver.cpp:571-603) as one kernel.  The minimum goes to the context's stage
  * word: read it (times cfl) with apk_stage_dt_read() / apk_stage_dt_flags_read(), as after
- * apk_stage_fused(estimate_dt = 1). */
-int apk_cons_to_prim_dt(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, apk_stream_t stream);
+ * apk_stage_fused(estimate_dt = 1).  ghost_depth < 0: every cell; >= 0: the interior and the ghost cells at
+ * most that many layers outside it (edges and corners included) -- the shell a shallow ghost exchange has
+ * filled; primitives further out are left as they were. */
+int apk_cons_to_prim_dt(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, int ghost_depth, apk_stream_t stream);
 /* ConsToPrim (Update::FillDerived, hydro_driver.cpp:571-577; src/eos/adiabatic_hydro.cpp:33) of the interior
  * and of the ghost cells straight behind a block FACE only (at most one ghost coordinate): what the unsplit
  * sweeps (hydro.cpp:1025-1199) and the flux correction read.  The refined-mesh stage loop of the standalone

@@ -320,6 +320,16 @@ def test_cons_to_prim_with_time_step_estimate(request, fluid, nx, strict):
         assert dt == want == 0.3 * H.orc_min_dt(fluid, g, w_orc, GAMMA)
     else:
         assert abs(dt - want) <= 4e-16 * want
+    # ghost_depth = 1: the same estimate; primitives only in the cells at most one layer outside the interior
+    K, J, I = np.meshgrid(*[np.arange(n + 2 * ng if a else 1) for n, a in zip(nx[::-1], act[::-1])], indexing="ij")
+    deep = np.zeros(u.shape[2:], dtype=bool)
+    for c, n, a in ((I, nx[0], True), (J, nx[1], act[1]), (K, nx[2], act[2])):
+        if a:
+            deep |= (c < ng - 1) | (c > ng + n)
+    md = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=u, prim=np.full_like(u, -3.0), with_flux=False)
+    assert hydro.ConservedToPrimitiveDt(md, fluid, eos, 0.3, ghost_depth=1) == dt
+    got = md.prim_host()
+    assert np.array_equal(got[:, :, ~deep], ref.prim_host()[:, :, ~deep]) and np.all(got[:, :, deep] == -3.0) and deep.any()
 
 
 @pytest.mark.parametrize("fluid", ["euler", "glmmhd"])
