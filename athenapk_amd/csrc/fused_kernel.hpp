@@ -1061,7 +1061,22 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
         // whole donor-cell stage in one march (see fused_dc3_kernel); its FillDerived is out of place
         const int64_t run3 = sp.window ? (int64_t)sp.window_rows * sp.window_rl : (int64_t)u0.nx2 * (u0.nx1 + 2);
         const int wpb = (int)((run3 + 61) / 62);
-        const int kseg = (u0.nx3 >= 16) ? 8 : u0.nx3;  // measured on 8 x 128^3: 8 and 16 within 1 %, 64 is 12 % slower
+        static const int forced_kseg = std::getenv("APK_DC3_KSEG") ? std::atoi(std::getenv("APK_DC3_KSEG")) : 0;  // A/B switch
+        int kseg = (u0.nx3 >= 16) ? 8 : u0.nx3;  // measured on 8 x 128^3: 8 and 16 within 1 %, 64 is 12 % slower
+        if (forced_kseg > 0) {
+          kseg = forced_kseg < u0.nx3 ? forced_kseg : u0.nx3;
+        } else if (u0.nx3 >= 16 && (int64_t)wpb * ((u0.nx3 + 7) / 8) * u0.nblocks < 4 * 2048) {
+          // small packs (refined meshes of 16^3 blocks): the march waves run in a few rounds of the 2048 resident ones
+          // (2 per SIMD), so pick the segment length with the fewest plane-steps over all rounds -- a segment costs its
+          // planes plus about 1.5 for the prologue (232 blocks: 2320 waves of 8 planes = 2 rounds x 9.5; of 6 = 2 x 7.5)
+          double best = 1.0e300;
+          for (const int cand : {4, 6, 8, 16}) {
+            if (cand > u0.nx3) continue;
+            const int64_t waves = (int64_t)wpb * ((u0.nx3 + cand - 1) / cand) * u0.nblocks;
+            const double cost = (double)((waves + 2047) / 2048) * (cand + 1.5);
+            if (cost < best) best = cost, kseg = cand;
+          }
+        }
         const int nseg = (u0.nx3 + kseg - 1) / kseg;
         const int64_t total = (int64_t)wpb * nseg * u0.nblocks;
         const int per_xcd = (int)((total + 7) / 8);
