@@ -310,13 +310,14 @@ inline void amr_bc_regions(const AmrTree &t, int lb, int kind, const int n[3], c
 // Coarse-buffer fills are always complete.  Even, at most nghost.
 inline void BuildAmrPlans(const AmrTree &t, const AmrGeom &g, AmrPlans &p, int fill_depth = 0) {
   p = AmrPlans();
-  const int gd = (fill_depth > 0 && fill_depth < g.ng) ? fill_depth : g.ng;
-  if (gd % 2 != 0) throw std::runtime_error("the ghost fill depth must be even");
+
   const int nb = (int)t.leaves.size();
   for (int d = 0; d < 3; ++d)
     if (g.act[d] && (g.mb[d] % 2 != 0 || g.mb[d] / 2 < g.cng || g.mb[d] / 2 < g.ng))
       throw std::runtime_error("mesh refinement needs even meshblock sizes of at least 2 * nghost cells per dimension");
   if (g.ng % 2 != 0) throw std::runtime_error("mesh refinement needs an even number of ghost cells (use nghost = 4 with ppm / wenoz)");
+  const int gd = (fill_depth > 0 && fill_depth < g.ng) ? fill_depth : g.ng;
+  if (gd % 2 != 0) throw std::runtime_error("the ghost fill depth must be even");
   // pass 1: which blocks face a coarser one
   std::vector<char> has_coarser(nb, 0);
   for (int lb = 0; lb < nb; ++lb) {

@@ -1908,8 +1908,9 @@ long long apk_sim_message_generation(const apk_sim *s) { return s ? s->msg_gener
 // plan introspection: make the halo (1) or flux-correction (2) message set of a refined mesh the one
 // apk_sim_peer reports (0: back to the uniform mesh's)
 int apk_sim_select_messages(apk_sim *s, int which) {
-  if (!s || which < 0 || which > 2 || (which > 0 && !s->amr)) return APK_ERR_INVALID;
-  s->active_msgs = which == 0 ? nullptr : (which == 1 ? &s->amr_halo : &s->amr_fluxmsg);
+  if (!s || which < 0 || which > 4 || (which > 0 && !s->amr)) return APK_ERR_INVALID;
+  const apk_sim::MsgSet *sets[5] = {nullptr, &s->amr_halo, &s->amr_fluxmsg, &s->amr_halo_faces, &s->amr_halo_shell};
+  s->active_msgs = sets[which];
   s->msg_generation += 1;
   return APK_OK;
 }
@@ -1949,6 +1950,17 @@ const std::vector<BoxRegion> *plan_of_phase(const apk_sim *s, int phase) {
   if (phase >= 31 && phase <= 33) return &l.flux_unpack[phase - 31];
   if (phase >= 34 && phase <= 36) return &l.coarse_bc[phase - 34];
   if (phase >= 37 && phase <= 39) return &l.fine_bc[phase - 37];
+  // the exchanges of the stage loop: 40..42 faces only (fill copies, packs, unpacks), 43 the fill copies of 40 without
+  // the same-level same-rank ones (direct neighbour addressing), 44..46 the shell (fill copies, packs, unpacks),
+  // 47..49 its block boundaries
+  if (phase == 40) return &l.fill_faces;
+  if (phase == 41) return &l.fill_pack_faces;
+  if (phase == 42) return &l.fill_unpack_faces;
+  if (phase == 43) return &l.fill_direct;
+  if (phase == 44) return &l.fill_shell;
+  if (phase == 45) return &l.fill_pack_shell;
+  if (phase == 46) return &l.fill_unpack_shell;
+  if (phase >= 47 && phase <= 49) return &l.fine_bc_shell[phase - 47];
   if (phase == 10) return &s->amr_plans.fill;
   if (phase >= 11 && phase <= 13) return &s->amr_plans.coarse_bc[phase - 11];
   if (phase >= 14 && phase <= 16) return &s->amr_plans.fine_bc[phase - 14];
@@ -1988,6 +2000,8 @@ const std::vector<AmrRefOp> *ops_of(const apk_sim *s, int which) {
   if (which == 10) return &s->amr_local.restrict_own;
   if (which == 11) return &s->amr_local.prolongate;
   if (which >= 12 && which <= 14) return &s->amr_local.flux_restrict[which - 12];
+  if (which == 15) return &s->amr_local.prolongate_faces;  // (of the faces-only exchange / of the shell exchange)
+  if (which == 16) return &s->amr_local.prolongate_shell;
   if (which == 0) return &s->amr_plans.restrict_own;
   if (which == 1) return &s->amr_plans.prolongate;
   if (which >= 2 && which <= 4) return &s->amr_plans.flux_restrict[which - 2];

@@ -116,14 +116,18 @@ class _MeshView:
               "my_fill": 20, "my_fill_pack": 21, "my_fill_unpack": 22,
               "my_flux1": 25, "my_flux2": 26, "my_flux3": 27, "my_flux_pack1": 28, "my_flux_pack2": 29,
               "my_flux_pack3": 30, "my_flux_unpack1": 31, "my_flux_unpack2": 32, "my_flux_unpack3": 33,
-              "my_coarse_bc1": 34, "my_coarse_bc2": 35, "my_coarse_bc3": 36, "my_bc1": 37, "my_bc2": 38, "my_bc3": 39}
+              "my_coarse_bc1": 34, "my_coarse_bc2": 35, "my_coarse_bc3": 36, "my_bc1": 37, "my_bc2": 38, "my_bc3": 39,
+              # the exchanges of the stage loop: faces only, faces without same-level same-rank copies, two-layer shell
+              "my_fill_faces": 40, "my_fill_pack_faces": 41, "my_fill_unpack_faces": 42, "my_fill_direct": 43,
+              "my_fill_shell": 44, "my_fill_pack_shell": 45, "my_fill_unpack_shell": 46,
+              "my_bc_shell1": 47, "my_bc_shell2": 48, "my_bc_shell3": 49}
     AMR_OPS = {"restrict_own": 0, "prolongate": 1, "flux_restrict1": 2, "flux_restrict2": 3, "flux_restrict3": 4,
                "my_restrict_own": 10, "my_prolongate": 11, "my_flux_restrict1": 12, "my_flux_restrict2": 13,
-               "my_flux_restrict3": 14}
+               "my_flux_restrict3": 14, "my_prolongate_faces": 15, "my_prolongate_shell": 16}
 
     def messages(self, which):
         """[(peer rank, send doubles, recv doubles)] of a refined mesh's "halo" / "flux" message set"""
-        self.lib.apk_sim_select_messages(self.h, {"uniform": 0, "halo": 1, "flux": 2}[which])
+        self.lib.apk_sim_select_messages(self.h, {"uniform": 0, "halo": 1, "flux": 2, "halo_faces": 3, "halo_shell": 4}[which])
         out = []
         for p in range(self.lib.apk_sim_num_peers(self.h)):
             pi = L.PeerInfo()

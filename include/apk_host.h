@@ -256,7 +256,8 @@ int apk_sim_peer(const apk_sim *sim, int p, apk_peer_info *info);
  * apk_sim_message_generation has changed since it last looked. */
 int apk_sim_num_peers(const apk_sim *sim);
 /* introspection: report the halo (1) / flux-correction (2) message set of a refined mesh through
- * apk_sim_peer (0 = the uniform mesh's set) */
+ * apk_sim_peer (0 = the uniform mesh's set); 3 / 4: the halo sets of the faces-only and of the shell
+ * exchange of the stage loop */
 int apk_sim_select_messages(apk_sim *sim, int which);
 long long apk_sim_message_generation(const apk_sim *sim);
 /* number of box copies in each phase: 0 local, 1 pack, 2 unpack, 3..5 physical BC x1..x3; on
@@ -264,7 +265,12 @@ long long apk_sim_message_generation(const apk_sim *sim);
  * 14..16 = block boundaries, 17..19 = flux-correction copies x1..x3 (10..19: the global plan
  * every rank builds, global block numbers); this rank's share with local block numbers and message
  * buffers: 20 fill copies, 21 packs, 22 unpacks, 25..27 / 28..30 / 31..33 flux-correction copies /
- * packs / unpacks x1..x3, 34..36 coarse-buffer boundaries, 37..39 block boundaries */
+ * packs / unpacks x1..x3, 34..36 coarse-buffer boundaries, 37..39 block boundaries; the exchanges of
+ * the stage loop: 40..42 fill copies / packs / unpacks without the boxes behind edges and corners, 43
+ * the copies of 40 without those between same-rank blocks of one level (the stages read these
+ * neighbours through apk_stage_args.face_neighbor), 44..46 / 47..49 fill copies, packs, unpacks /
+ * block boundaries of the exchange that fills every ghost zone two layers deep only (before a
+ * refinement check) */
 int apk_sim_plan_size(const apk_sim *sim, int phase);
 /* region r of a phase, with src/dst expressed as (kind, block, element offset):
  * kind 0 = local block cons, 1 = send buffer of peer `block`, 2 = recv buffer of peer `block`,
@@ -278,8 +284,9 @@ typedef struct apk_region_info {
 int apk_sim_plan_region(const apk_sim *sim, int phase, int r, apk_region_info *info);
 /* operator lists of the multilevel exchange, in execution order restrict-own (which = 0) ->
  * phase 10 -> 11..13 -> prolongate (1) -> 14..16; flux correction: per direction d, which = 2 + d
- * then phase 17 + d.  which + 10 = this rank's share (local block numbers).  kind is an APK_RO_*
- * value; index boxes in coarse-buffer indices. */
+ * then phase 17 + d.  which + 10 = this rank's share (local block numbers); 15 / 16: this rank's
+ * prolongations of the faces-only and of the shell exchange.  kind is an APK_RO_* value; index boxes in
+ * coarse-buffer indices. */
 typedef struct apk_amr_op_info {
   int kind, level;
   int src_kind, src_block, dst_kind, dst_block;

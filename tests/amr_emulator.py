@@ -160,6 +160,25 @@ def exchange_on_ranks(ems):
             e._copy("my_bc%d" % d)
 
 
+def stage_loop_exchange_on_ranks(ems, mode):
+    """the exchanges of the stage loop (sim_amr.cpp amr_exchange): mode "faces" = without the boxes behind edges and
+    corners, "direct" = nor the copies between same-rank blocks of one level, "shell" = every ghost zone two layers deep"""
+    tag = "shell" if mode == "shell" else "faces"
+    for e in ems:
+        e.use_messages("halo_" + tag)
+        e._ops("my_restrict_own")
+        e._copy("my_fill_pack_" + tag)
+        e._copy({"faces": "my_fill_faces", "direct": "my_fill_direct", "shell": "my_fill_shell"}[mode])
+    _wire(ems)
+    for e in ems:
+        e._copy("my_fill_unpack_" + tag)
+        for d in (1, 2, 3):
+            e._copy("my_coarse_bc%d" % d)
+        e._ops("my_prolongate_" + tag)
+        for d in (1, 2, 3):
+            e._copy(("my_bc_shell%d" if mode == "shell" else "my_bc%d") % d)
+
+
 def flux_correction_on_ranks(ems):
     for e in ems:
         e.use_messages("flux")

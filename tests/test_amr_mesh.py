@@ -246,6 +246,74 @@ def test_distributed_plans_reproduce_the_one_rank_exchange(oracle, ov, bc, nrank
     assert halo > 0 and 0 < flux < halo
 
 
+@pytest.mark.parametrize("nranks", [1, 3])
+@pytest.mark.parametrize("bc", ["periodic", "reflecting"])
+def test_stage_loop_exchanges_fill_what_they_promise(oracle, bc, nranks):
+    """The three cheaper exchanges of the refined-mesh stage loop against the complete one on the same random state
+    (four ghost layers, three levels, blocks over 1 and 3 ranks).  Faces only: every ghost cell straight behind a face
+    as in the complete exchange, nothing else written.  Direct: the same, minus exactly the zones behind faces shared
+    with a same-rank block of the same level.  Shell: every ghost cell at most two layers outside the interior --
+    edges and corners included -- as in the complete exchange, nothing deeper written (on the periodic mesh; physical
+    boundaries copy whole transverse extents)."""
+    from amr_emulator import stage_loop_exchange_on_ranks
+    views = [_view(SMR3_NG4 + _bc(bc), rank=r, nranks=nranks) for r in range(nranks)]
+    info = views[0].refresh_info()
+    ng, mb = info.ng, info.mb
+    rng = np.random.default_rng(23)
+
+    def fresh():
+        ems = [Emulator(v, oracle) for v in views]
+        r2 = np.random.default_rng(23)
+        for e in ems:
+            for lb in range(e.nb):
+                e.cons[lb][:] = r2.uniform(0.5, 2.0, e.shape)
+        return ems
+
+    ref = fresh()
+    exchange_on_ranks(ref)
+    start = fresh()
+    K, J, I = np.meshgrid(*[np.arange(mb[d] + 2 * ng) for d in (2, 1, 0)], indexing="ij")
+    depth = [np.maximum(ng - c, 0) + np.maximum(c - (ng + n - 1), 0) for c, n in ((I, mb[0]), (J, mb[1]), (K, mb[2]))]
+    nghost = sum((d > 0).astype(int) for d in depth)
+    zone = [(I < ng), (I >= ng + mb[0]), (J < ng), (J >= ng + mb[1]), (K < ng), (K >= ng + mb[2])]
+    # the same-level same-rank neighbours, from the forest
+    where = [{(v.block_level(lb), v.block_gid(lb)[1]): lb for lb in range(e.nb)} for v, e in zip(views, start)]
+    nroot = [info.nx[d] // mb[d] for d in range(3)]
+    for mode in ("faces", "direct", "shell"):
+        ems = fresh()
+        stage_loop_exchange_on_ranks(ems, mode)
+        skipped = 0
+        for r, (v, e) in enumerate(zip(views, ems)):
+            for lb in range(e.nb):
+                if mode == "shell":
+                    filled = (nghost > 0) & (np.maximum(np.maximum(depth[0], depth[1]), depth[2]) <= 2)
+                else:
+                    filled = nghost == 1
+                    if mode == "direct":
+                        lev, loc = v.block_level(lb), v.block_gid(lb)[1]
+                        for f in range(6):
+                            nloc = list(loc)
+                            nloc[f // 2] += 1 if f % 2 else -1
+                            n = nroot[f // 2] << lev
+                            if bc == "periodic":
+                                nloc[f // 2] %= n
+                            if (lev, tuple(nloc)) in where[r]:
+                                filled = filled & ~zone[f]
+                                skipped += 1
+                got, want, was = e.cons[lb], ref[r].cons[lb], start[r].cons[lb]
+                assert np.array_equal(got[:, filled], want[:, filled]), (mode, r, lb)
+                untouched = (nghost > 0) & ~filled
+                if bc == "periodic":  # (physical boundaries copy whole transverse extents, stale rows included)
+                    assert np.array_equal(got[:, untouched], was[:, untouched]), (mode, r, lb)
+                assert np.array_equal(got[:, nghost == 0], was[:, nghost == 0])
+        assert mode != "direct" or skipped > 0
+    if nranks > 1:  # the shallow exchange sends less
+        full = sum(sc for v in views for _, sc, _ in v.messages("halo"))
+        faces = sum(sc for v in views for _, sc, _ in v.messages("halo_faces"))
+        shell = sum(sc for v in views for _, sc, _ in v.messages("halo_shell"))
+        assert 0 < faces < full and 0 < shell < full
+
+
 def _check_forest(v):
     """tiling, 2:1 balance across faces / edges / corners (periodic wrap included)"""
     pl = placement(v)
