@@ -194,6 +194,10 @@ struct apk_sim {
     std::vector<apk::AmrRefOp> restrict_own, prolongate, flux_restrict[3];
     std::vector<apk::BoxRegion> fill, fill_pack, fill_unpack, coarse_bc[3], fine_bc[3];
     std::vector<apk::BoxRegion> flux_copy[3], flux_pack[3], flux_unpack[3];
+    // the correction after a fused stage averages the fine fluxes of same-rank faces inside the fix kernel: the
+    // restriction operators of flux_copy[d], entry for entry, and those whose coarse side lives on another rank (the
+    // only ones that still run as operators there)
+    std::vector<apk::AmrRefOp> flux_fused_ops[3], flux_restrict_remote[3];
     // the exchange of the stage loop: without the boxes that fill ghost zones behind edges and corners
     // (BoxRegion::corner); its messages are laid out by the same walk over the filtered global list
     std::vector<apk::AmrRefOp> prolongate_faces;
@@ -221,7 +225,7 @@ struct apk_sim {
   const MsgSet *active_msgs = nullptr;  // the message set apk_sim_peer reports (null: the uniform mesh's)
   long long msg_generation = 0;         // bumped whenever that set, its sizes or its buffers change
   struct AmrDevice {
-    std::vector<apk_refine_plan *> restrict_own[2], prolongate[2], flux_restrict[3];
+    std::vector<apk_refine_plan *> restrict_own[2], prolongate[2], flux_restrict[3], flux_restrict_remote[3];
     apk_copy_plan *fill[2] = {nullptr, nullptr}, *fill_pack[2] = {nullptr, nullptr}, *fill_unpack[2] = {nullptr, nullptr};
     apk_copy_plan *flux_pack[3] = {nullptr, nullptr, nullptr}, *flux_unpack[3] = {nullptr, nullptr, nullptr};
     // the correction applied after a fused stage instead (apk_flux_fix_plan): same-rank faces and

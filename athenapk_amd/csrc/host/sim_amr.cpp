@@ -92,6 +92,16 @@ void amr_localize(apk_sim *s) {
     take_ops(shell.prolongate, l.prolongate_shell);
     for (int d = 0; d < 3; ++d) take_bc(shell.fine_bc[d], l.fine_bc_shell[d]);
   }
+  for (int d = 0; d < 3; ++d) {  // (BuildAmrPlans appends a face's restriction and its copy together: same index)
+    for (size_t n = 0; n < g.flux_copy[d].size(); ++n) {
+      const int fine_owner = part.Owner(g.flux_copy[d][n].src_block), coarse_owner = part.Owner(g.flux_copy[d][n].dst_block);
+      if (fine_owner != rank) continue;
+      AmrRefOp o = g.flux_restrict[d][n];
+      o.src_block -= part.first[rank];
+      o.dst_block -= part.first[rank];
+      (coarse_owner == rank ? l.flux_fused_ops[d] : l.flux_restrict_remote[d]).push_back(o);
+    }
+  }
   for (int d = 0; d < 3; ++d) AmrRegisterPeers(g.flux_copy[d], part, part, rank, s->amr_fluxmsg.plan);
   for (int d = 0; d < 3; ++d)
     AmrLocalize(g.flux_copy[d], part, part, rank, s->amr_fluxmsg.plan, l.flux_copy[d], l.flux_pack[d], l.flux_unpack[d]);
@@ -285,6 +295,8 @@ void amr_destroy_device_plans(apk_sim *s) {
   for (int d = 0; d < 3; ++d) {
     for (apk_refine_plan *p : a.flux_restrict[d]) apk_refine_plan_destroy(p);
     a.flux_restrict[d].clear();
+    for (apk_refine_plan *p : a.flux_restrict_remote[d]) apk_refine_plan_destroy(p);
+    a.flux_restrict_remote[d].clear();
     apk_copy_plan_destroy(a.flux_copy[d]);
     apk_copy_plan_destroy(a.flux_pack[d]);
     apk_copy_plan_destroy(a.flux_unpack[d]);
@@ -298,13 +310,31 @@ void amr_destroy_device_plans(apk_sim *s) {
 }
 
 // the flux-correction copies of direction d as corrections of the cells next to the face (fused path)
+// (ops: the restriction operator of every region -- same-rank faces: the kernel averages the fine block's fluxes
+// itself, no restricted plane in between; null: the regions' sources hold the averages)
 int amr_make_fix_plan(apk_sim *s, int parity, int d, const std::vector<BoxRegion> &regions, const apk_sim::MsgSet *msgs,
-                      apk_flux_fix_plan **out) {
+                      apk_flux_fix_plan **out, const std::vector<AmrRefOp> *ops = nullptr) {
   const AmrGeom &g = s->amr_geom;
   std::vector<apk_flux_fix_region> regs;
-  for (const BoxRegion &r : regions) {
+  if (ops && ops->size() != regions.size()) return fail(s, APK_ERR_INVALID, "flux correction: operators and copies out of step");
+  for (size_t n = 0; n < regions.size(); ++n) {
+    const BoxRegion &r = regions[n];
     apk_flux_fix_region f{};
     f.fine_avg = amr_base(s, parity, r.src_kind, r.src_block, msgs) + r.src_off;
+    if (ops) {
+      const AmrRefOp &o = (*ops)[n];
+      if (o.kind != APK_RO_RESTRICT_FLUX1 + d || o.dst_block != r.src_block) return fail(s, APK_ERR_INVALID, "flux correction: operator does not belong to the copy");
+      int64_t off = 0;
+      for (int q = 0; q < 3; ++q) off += (g.act[q] ? (int64_t)(o.lo[q] - g.cs[q]) * 2 + g.fs[q] : 0) * g.fst[q];
+      f.fine_avg = s->d_flux[d] + (int64_t)o.src_block * s->nper + off;
+      f.average = d + 1;
+      f.ndim = s->mesh.ndim;
+      double w = 1.0;  // (restrict_cell's order of the factors)
+      for (int q = 0; q < 3; ++q)
+        if (q != d) w *= level_dx(s, o.level, q);
+      f.fine_area = w;
+      for (int q = 0; q < 3; ++q) f.fine_stride[q] = g.act[q] ? g.fst[q] : 0;
+    }
     f.coarse_flux = amr_base(s, parity, r.dst_kind, r.dst_block, msgs) + r.dst_off;
     const int idx = (int)((r.dst_off / g.fst[d]) % g.fn[d]);  // face index along d inside the block
     const bool lower = idx == g.fs[d];
@@ -314,6 +344,10 @@ int amr_make_fix_plan(apk_sim *s, int parity, int d, const std::vector<BoxRegion
     for (int q = 0; q < 4; ++q) {
       f.src_stride[q] = r.src_stride[q];
       f.dst_stride[q] = r.dst_stride[q];
+    }
+    if (ops) {
+      for (int q = 0; q < 3; ++q) f.src_stride[q] = g.act[q] ? 2 * g.fst[q] : 0;
+      f.src_stride[3] = g.fst[3];
     }
     f.scale = (lower ? 1.0 : -1.0) / level_dx(s, block_level(s, r.dst_block), d);
     regs.push_back(f);
@@ -431,13 +465,15 @@ int amr_rebuild(apk_sim *s) {
       SIM_TRY(s, amr_make_copy_plan(s, par, p.fine_bc[d], nullptr, &a.fine_bc[par][d]));
     }
   }
+  static const bool fix_averages = std::getenv("APK_NO_FIX_AVERAGE") == nullptr;  // A/B switch
   for (int d = 0; d < s->mesh.ndim; ++d) {
     SIM_TRY(s, amr_make_refine_plans(s, 0, p.flux_restrict[d], a.flux_restrict[d]));
+    SIM_TRY(s, amr_make_refine_plans(s, 0, p.flux_restrict_remote[d], a.flux_restrict_remote[d]));
     SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_copy[d], nullptr, &a.flux_copy[d]));
     SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_pack[d], &s->amr_fluxmsg, &a.flux_pack[d]));
     SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_unpack[d], &s->amr_fluxmsg, &a.flux_unpack[d]));
     for (int par = 0; par < 2; ++par) {
-      SIM_TRY(s, amr_make_fix_plan(s, par, d, p.flux_copy[d], nullptr, &a.flux_fix[par][d]));
+      SIM_TRY(s, amr_make_fix_plan(s, par, d, p.flux_copy[d], nullptr, &a.flux_fix[par][d], fix_averages ? &p.flux_fused_ops[d] : nullptr));
       SIM_TRY(s, amr_make_fix_plan(s, par, d, p.flux_unpack[d], &s->amr_fluxmsg, &a.flux_fix_unpack[par][d]));
     }
   }
@@ -617,8 +653,11 @@ int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi
   static const bool all_planes = std::getenv("APK_AMR_ALL_PLANES") != nullptr;  // A/B switch
   if (all_planes) SIM_TRY(s, apk_calculate_fluxes_boundary(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, s->stream));
   else SIM_TRY(s, apk_calculate_fluxes_boundary_list(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, a.d_cf_faces, a.n_cf_faces, s->stream));
+  static const bool fix_averages = std::getenv("APK_NO_FIX_AVERAGE") == nullptr;  // A/B switch (see amr_rebuild)
   for (int d = 0; d < s->mesh.ndim; ++d) {
-    for (apk_refine_plan *p : a.flux_restrict[d]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
+    // (same-rank faces: the fix kernel averages the fine fluxes itself; only faces whose coarse side lives elsewhere
+    // are restricted into the coarse buffer, for the message)
+    for (apk_refine_plan *p : (fix_averages ? a.flux_restrict_remote[d] : a.flux_restrict[d])) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
     SIM_TRY(s, apk_flux_fix_plan_run(s->ctx, a.flux_fix[s->cur][d], beta_dt, psi_var, psi_factor, s->stream));
     SIM_TRY(s, apk_copy_plan_run(s->ctx, a.flux_pack[d], s->stream));
   }

@@ -223,7 +223,33 @@ __global__ void __launch_bounds__(256) flux_fix_kernel(const apk_flux_fix_region
     const int k = (int)(c / r.ext[1]);
     const int64_t so = i * r.src_stride[0] + j * r.src_stride[1] + k * r.src_stride[2] + v * r.src_stride[3];
     const int64_t d = i * r.dst_stride[0] + j * r.dst_stride[1] + k * r.dst_stride[2] + v * r.dst_stride[3];
-    double dv = (beta_dt * r.scale) * (r.fine_avg[so] - r.coarse_flux[d]);
+    double avg;
+    if (r.average == 0) {
+      avg = r.fine_avg[so];
+    } else {  // restrict_cell(el = r.average, cell-shaped arrays) on the fine block's flux array, value for value
+      const double *f = r.fine_avg + so;
+      const int el = r.average;
+      const int oi1 = (el != 1) ? 1 : 0;
+      const int oj1 = (r.ndim > 1 && el != 2) ? 1 : 0;
+      const int ok1 = (r.ndim > 2 && el != 3) ? 1 : 0;
+      const double w = r.fine_area;
+      double vol[2][2][2], tt[2][2][2];
+#pragma unroll
+      for (int ok = 0; ok < 2; ++ok)
+#pragma unroll
+        for (int oj = 0; oj < 2; ++oj)
+#pragma unroll
+          for (int oi = 0; oi < 2; ++oi) {
+            const bool in = !(ok > ok1 || oj > oj1 || oi > oi1);
+            vol[ok][oj][oi] = in ? w : 0.0;
+            tt[ok][oj][oi] = in ? w * f[ok * r.fine_stride[2] + oj * r.fine_stride[1] + oi * r.fine_stride[0]] : 0.0;
+          }
+      const double tvol = ((vol[0][0][0] + vol[0][1][0]) + (vol[0][0][1] + vol[0][1][1])) +
+                          ((vol[1][0][0] + vol[1][1][0]) + (vol[1][0][1] + vol[1][1][1]));
+      avg = (((tt[0][0][0] + tt[0][1][0]) + (tt[0][0][1] + tt[0][1][1])) + ((tt[1][0][0] + tt[1][1][0]) + (tt[1][0][1] + tt[1][1][1]))) /
+            tvol;
+    }
+    double dv = (beta_dt * r.scale) * (avg - r.coarse_flux[d]);
     if (v == psi_var) dv *= psi_factor;
     r.cons[d] += dv;
   }
@@ -375,7 +401,8 @@ int apk_flux_fix_plan_create(apk_ctx *ctx, const apk_flux_fix_region *regions, i
   p->n = n;
   for (int q = 0; q < n; ++q) {
     const apk_flux_fix_region &r = regions[q];
-    if (!r.fine_avg || !r.coarse_flux || !r.cons || r.nvar <= 0 || r.ext[0] <= 0 || r.ext[1] <= 0 || r.ext[2] <= 0) {
+    if (!r.fine_avg || !r.coarse_flux || !r.cons || r.nvar <= 0 || r.ext[0] <= 0 || r.ext[1] <= 0 || r.ext[2] <= 0 ||
+        r.average < 0 || r.average > 3 || (r.average != 0 && (r.ndim < 1 || r.ndim > 3 || r.average > r.ndim || !(r.fine_area > 0.0)))) {
       delete p;
       return set_err(ctx, APK_ERR_INVALID, "apk_flux_fix_plan_create: bad region");
     }

@@ -258,8 +258,13 @@ class FluxFixPlan:
         self.ctx = ctx
         arr = (L.FluxFixRegion * max(1, len(regions)))()
         self._keep = []
-        for n, (fa, cf, cons, scale) in enumerate(regions):
+        for n, reg in enumerate(regions):
+            fa, cf, cons, scale = reg[:4]
             assert fa.shape == cf.shape == cons.shape and cf.stride() == cons.stride()
+            if len(reg) > 4:  # (direction 1..3, ndim, fine_area, fine array): fa = its every-second-face view; average in the kernel
+                arr[n].average, arr[n].ndim, arr[n].fine_area = int(reg[4]), int(reg[5]), float(reg[6])
+                arr[n].fine_stride[:] = [reg[7].stride(3), reg[7].stride(2), reg[7].stride(1)]
+                self._keep.append(reg[7])
             arr[n].fine_avg, arr[n].coarse_flux, arr[n].cons = fa.data_ptr(), cf.data_ptr(), cons.data_ptr()
             arr[n].nvar = fa.shape[0]
             arr[n].ext[:] = [fa.shape[3], fa.shape[2], fa.shape[1]]

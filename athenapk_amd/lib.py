@@ -82,7 +82,8 @@ TAG_CRITERIA = {"pressure_gradient": 0, "xyvelocity_gradient": 1, "maxdensity": 
 
 class FluxFixRegion(C.Structure):
     _fields_ = [("fine_avg", C.c_void_p), ("coarse_flux", C.c_void_p), ("cons", C.c_void_p), ("ext", C.c_int * 3),
-                ("nvar", C.c_int), ("src_stride", C.c_int64 * 4), ("dst_stride", C.c_int64 * 4), ("scale", C.c_double)]
+                ("nvar", C.c_int), ("src_stride", C.c_int64 * 4), ("dst_stride", C.c_int64 * 4), ("scale", C.c_double),
+                ("average", C.c_int), ("ndim", C.c_int), ("fine_stride", C.c_int64 * 3), ("fine_area", C.c_double)]
 
 
 class CopyRegion(C.Structure):

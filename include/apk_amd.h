@@ -453,7 +453,12 @@ int apk_refine_plan_run(apk_ctx *ctx, const apk_refine_plan *p, apk_stream_t str
  * with scale = +1/dx for the lower face of the cell, -1/dx for its upper face; fine_avg is the
  * area average of the fine blocks' fluxes (an APK_RO_RESTRICT_FLUX* result or a message buffer),
  * coarse_flux the coarse block's flux on the same face (apk_calculate_fluxes_boundary).  psi_factor
- * is the Dedner damping exp(-alpha c_h beta_dt / mindx) the stage applied after its update. */
+ * is the Dedner damping exp(-alpha c_h beta_dt / mindx) the stage applied after its update.
+ * average = 0: fine_avg holds the averages, one per element.  average = d + 1 (1..3): fine_avg is the
+ * fine block's own cell-shaped x_d flux array at the first fine face under the region (src_stride =
+ * twice that array's strides), and each element averages the 2 (2-D) or 4 (3-D) fine faces under its
+ * coarse face at fine_stride[], weighted with fine_area -- the arithmetic of APK_RO_RESTRICT_FLUX1 + d,
+ * bit for bit, without the restricted plane in between (same-rank faces). */
 typedef struct apk_flux_fix_region {
   const double *fine_avg;    /* strides src_stride */
   const double *coarse_flux; /* strides dst_stride */
@@ -462,6 +467,9 @@ typedef struct apk_flux_fix_region {
   int nvar;
   int64_t src_stride[4], dst_stride[4];
   double scale;
+  int average, ndim;
+  int64_t fine_stride[3];
+  double fine_area;
 } apk_flux_fix_region;
 typedef struct apk_flux_fix_plan apk_flux_fix_plan;
 int apk_flux_fix_plan_create(apk_ctx *ctx, const apk_flux_fix_region *regions /* host */, int n,

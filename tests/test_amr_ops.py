@@ -311,6 +311,56 @@ def test_flux_fix_plan_against_numpy(request):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("direction", [1, 2, 3])
+def test_flux_fix_plan_averages_fine_fluxes_like_the_restriction(request, direction):
+    """average = d + 1: the fix kernel reads the fine block's x_d flux array and averages the four fine faces under each
+    coarse face itself -- the restriction operator's weights and pairwise sums (RestrictAverage on a face), bit for bit."""
+    import torch
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    rng = np.random.default_rng(3 + direction)
+    nvar, n, nf = 9, 12, 16
+    cons = torch.from_numpy(rng.standard_normal((nvar, n, n, n))).cuda()
+    flux = torch.from_numpy(rng.standard_normal((nvar, n, n, n))).cuda()
+    fine = torch.from_numpy(rng.standard_normal((nvar, nf, nf, nf))).cuda()
+    dxf = (0.125, 0.0625, 0.25)
+    w = 1.0
+    for q in range(3):
+        if q != direction - 1:
+            w *= dxf[q]
+    ax = 3 - (direction - 1)                      # tensor axis of the face normal ([nvar][k][j][i])
+    csel, fsel = [slice(None)] * 4, [slice(None)] * 4
+    for a in (1, 2, 3):
+        if a == ax:
+            csel[a], fsel[a] = slice(4, 5), slice(3, 4)          # coarse cells next to face 4 / fine face index 3
+        else:
+            csel[a], fsel[a] = slice(2, 6), slice(4, 12, 2)      # 4 coarse cells <- fine cells 4..11
+    csel, fsel = tuple(csel), tuple(fsel)
+    beta_dt, scale, psi_factor = 0.21, 1.0 / 0.5, 0.9
+    f = fine.cpu().numpy()
+    t = {}
+    for ok in range(2):
+        for oj in range(2):
+            for oi in range(2):
+                off = {1: ok, 2: oj, 3: oi}
+                inside = off[ax] == 0
+                sl = tuple(slice(None) if a == 0 else (slice(3, 4) if a == ax else slice(4 + off[a], 12 + off[a], 2)) for a in range(4))
+                t[ok, oj, oi] = w * f[sl] if inside else 0.0
+                t["v", ok, oj, oi] = w if inside else 0.0
+    tot = ((t[0, 0, 0] + t[0, 1, 0]) + (t[0, 0, 1] + t[0, 1, 1])) + ((t[1, 0, 0] + t[1, 1, 0]) + (t[1, 0, 1] + t[1, 1, 1]))
+    vol = ((t["v", 0, 0, 0] + t["v", 0, 1, 0]) + (t["v", 0, 0, 1] + t["v", 0, 1, 1])) + \
+          ((t["v", 1, 0, 0] + t["v", 1, 1, 0]) + (t["v", 1, 0, 1] + t["v", 1, 1, 1]))
+    avg = tot / vol
+    want = cons.cpu().numpy().copy()
+    d = (beta_dt * scale) * (avg - flux.cpu().numpy()[csel])
+    d[8] = d[8] * psi_factor
+    want[csel] += d
+    hydro.FluxFixPlan(ctx, [(fine[fsel], flux[csel], cons[csel], scale, direction, 3, w, fine)]).run(beta_dt, psi_var=8, psi_factor=psi_factor)
+    torch.cuda.synchronize()
+    assert np.array_equal(cons.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fluid", ["euler", "glmmhd"])
 def test_count_unphysical_matches_numpy(request, fluid):
     from athenapk_amd import hydro
