@@ -644,6 +644,8 @@ DIRECT_CASES = {
     "mhd_ppm_hlld_vl2_check3": ("glmmhd", "hlld", "ppm", 4, "vl2", 3),
     "hydro_plm_hllc_rk3_check2": ("euler", "hllc", "plm", 2, "rk3", 2),
     "mhd_wenoz_hlle_rk2_check4": ("glmmhd", "hlle", "wenoz", 4, "rk2", 4),
+    # four ghost layers and a PLM first stage: the two-layer shell exchange before every check is all that stage reads
+    "hydro_plm_hlle_rk2_ng4_check1": ("euler", "hlle", "plm", 4, "rk2", 1),
 }
 
 
