@@ -467,7 +467,8 @@ bool amr_direct(const apk_sim *s) {
 
 // does the cycle in progress end with a check of the refinement criteria?  Those read the full ring of ghost
 // cells round a block -- edges and corners too (refinement/gradient.cpp:33-36 loops k, j, i over [s-1, e+1]
-// and differences each of them) -- so the exchange after the last stage of such a cycle is a complete one.
+// and differences each of them) -- so the exchange after the last stage of such a cycle is a complete one, or at
+// least two layers deep all round (amr_shell_before_check).
 bool regrid_check_follows(const apk_sim *s) {
   return s->amr && s->amr_adaptive && s->amr_check_interval > 0 && (s->ncycle + 1) % s->amr_check_interval == 0;
 }
