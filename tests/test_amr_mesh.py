@@ -246,20 +246,24 @@ def test_distributed_plans_reproduce_the_one_rank_exchange(oracle, ov, bc, nrank
     assert halo > 0 and 0 < flux < halo
 
 
+SMR2_NG4 = [o for o in SMR2] + ["parthenon/mesh/nghost=4", "hydro/reconstruction=ppm"]
+
+
 @pytest.mark.parametrize("nranks", [1, 3])
 @pytest.mark.parametrize("bc", ["periodic", "reflecting"])
-def test_stage_loop_exchanges_fill_what_they_promise(oracle, bc, nranks):
+@pytest.mark.parametrize("ov", [SMR3_NG4, SMR2_NG4], ids=["3d", "2d"])
+def test_stage_loop_exchanges_fill_what_they_promise(oracle, ov, bc, nranks):
     """The three cheaper exchanges of the refined-mesh stage loop against the complete one on the same random state
-    (four ghost layers, three levels, blocks over 1 and 3 ranks).  Faces only: every ghost cell straight behind a face
-    as in the complete exchange, nothing else written.  Direct: the same, minus exactly the zones behind faces shared
+    (four ghost layers, three / four levels, blocks over 1 and 3 ranks).  Faces only: every ghost cell straight behind a
+    face as in the complete exchange, nothing else written.  Direct: the same, minus exactly the zones behind faces shared
     with a same-rank block of the same level.  Shell: every ghost cell at most two layers outside the interior --
     edges and corners included -- as in the complete exchange, nothing deeper written (on the periodic mesh; physical
     boundaries copy whole transverse extents)."""
     from amr_emulator import stage_loop_exchange_on_ranks
-    views = [_view(SMR3_NG4 + _bc(bc), rank=r, nranks=nranks) for r in range(nranks)]
+    views = [_view(ov + _bc(bc), rank=r, nranks=nranks) for r in range(nranks)]
     info = views[0].refresh_info()
     ng, mb = info.ng, info.mb
-    rng = np.random.default_rng(23)
+    act = [True, mb[1] > 1, mb[2] > 1]
 
     def fresh():
         ems = [Emulator(v, oracle) for v in views]
@@ -272,10 +276,12 @@ def test_stage_loop_exchanges_fill_what_they_promise(oracle, bc, nranks):
     ref = fresh()
     exchange_on_ranks(ref)
     start = fresh()
-    K, J, I = np.meshgrid(*[np.arange(mb[d] + 2 * ng) for d in (2, 1, 0)], indexing="ij")
-    depth = [np.maximum(ng - c, 0) + np.maximum(c - (ng + n - 1), 0) for c, n in ((I, mb[0]), (J, mb[1]), (K, mb[2]))]
+    K, J, I = np.meshgrid(*[np.arange(mb[d] + 2 * ng if act[d] else 1) for d in (2, 1, 0)], indexing="ij")
+    depth = [np.maximum(ng - c, 0) + np.maximum(c - (ng + n - 1), 0) if a else 0 * c
+             for c, n, a in ((I, mb[0], act[0]), (J, mb[1], act[1]), (K, mb[2], act[2]))]
     nghost = sum((d > 0).astype(int) for d in depth)
-    zone = [(I < ng), (I >= ng + mb[0]), (J < ng), (J >= ng + mb[1]), (K < ng), (K >= ng + mb[2])]
+    zone = [depth[0] * (I < ng) > 0, depth[0] * (I >= ng) > 0, depth[1] * (J < ng) > 0, depth[1] * (J >= ng) > 0,
+            depth[2] * (K < ng) > 0, depth[2] * (K >= ng) > 0]
     # the same-level same-rank neighbours, from the forest
     where = [{(v.block_level(lb), v.block_gid(lb)[1]): lb for lb in range(e.nb)} for v, e in zip(views, start)]
     nroot = [info.nx[d] // mb[d] for d in range(3)]
@@ -292,6 +298,8 @@ def test_stage_loop_exchanges_fill_what_they_promise(oracle, bc, nranks):
                     if mode == "direct":
                         lev, loc = v.block_level(lb), v.block_gid(lb)[1]
                         for f in range(6):
+                            if not act[f // 2]:
+                                continue
                             nloc = list(loc)
                             nloc[f // 2] += 1 if f % 2 else -1
                             n = nroot[f // 2] << lev
