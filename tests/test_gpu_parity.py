@@ -450,6 +450,38 @@ def test_boundary_error_codes(request):
 
 # ---- fused stage with FillDerived + dt estimate folded into the finishing sweep -----------------------
 @pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("fill", [0, 2], ids=["nofill", "outofplace"])
+@pytest.mark.parametrize("fluid,recon,riemann,nx", [("glmmhd", "ppm", "hlld", (16, 16, 16)), ("glmmhd", "ppm", "hlld", (40, 9, 16)),
+                                                    ("euler", "plm", "hllc", (16, 16, 16)), ("glmmhd", "dc", "hlld", (16, 16, 16)),
+                                                    ("glmmhd", "wenoz", "hlle", (32, 8, 16))])
+def test_fused_stage_with_more_ghost_layers_than_the_stencil(request, oracle, fluid, recon, riemann, nx, fill, strict):
+    """Refined meshes run PPM / WENO-Z with nghost = 4 (Parthenon wants it even) and donor-cell / PLM stages on the same
+    blocks: the stage kernels -- the two-kernel form on these shapes -- must not depend on the ghost zone being exactly
+    as deep as the stencil.  Against the oracle's tasks on the same blocks."""
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    ng = 4
+    prim = H.random_prim(fluid, nx, ng, seed=29, kind="smooth", nblocks=3)
+    g = H.geom(fluid, nx, ng, 0, (0.1, 0.07, 0.13))
+    cons = H.prim_to_cons(fluid, prim, GAMMA)
+    rng = np.random.default_rng(6)
+    u1 = cons * (1.0 + 1e-3 * rng.standard_normal(cons.shape))
+    ded = 1 if fluid == "glmmhd" else 0
+    m0 = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=cons, prim=prim, with_flux=False)
+    m1 = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=u1, with_flux=False)
+    hydro.StageFused(m0, m1, fluid, recon, riemann, hydro.L.make_eos(GAMMA), C_H, 0.25, 0.75, 0.004, dedner=ded,
+                     glmmhd_alpha=0.1, mindx=0.07, fill_derived=fill, estimate_dt=bool(fill))
+    want = H.orc_stage(fluid, recon, riemann, g, cons, u1, prim, GAMMA, C_H, 0.25, 0.75, 0.004, dedner=ded, alpha=0.1, mindx=0.07)
+    _cmp(H.interior(m0.cons_host(), nx, ng), H.interior(want, nx, ng), strict, "cons")
+    if fill:
+        want_cons, want_prim, bad = H.orc_c2p(fluid, g, want, oracle.make_eos(GAMMA))
+        assert bad == 0
+        _cmp(H.interior(m1.prim_host(), nx, ng), H.interior(want_prim, nx, ng), strict, "prim (out of place)")
+        dt, want_dt = hydro.StageDt(ctx, 0.3), 0.3 * H.orc_min_dt(fluid, g, want_prim, GAMMA)
+        assert dt == want_dt if strict else dt == pytest.approx(want_dt, rel=1e-12)
+
+
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
 @pytest.mark.parametrize("fluid,recon,riemann,nx", [("glmmhd", "ppm", "hlld", (70, 9, 7)),
                                                     ("euler", "plm", "hllc", (66, 10, 6)),
                                                     ("glmmhd", "dc", "hlld", (64, 8, 8)),
