@@ -351,6 +351,20 @@ int apk_cons_to_prim_faces_skip(apk_ctx *ctx, const apk_pack *md, int fluid, con
   return APK_OK;
 }
 
+int apk_cons_to_prim_faces_dt(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, const int *face_neighbor,
+                              apk_stream_t stream) {
+  if (!ctx || !md || !valid_eos(eos) || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||
+      md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9))
+    return set_err(ctx, APK_ERR_INVALID, "apk_cons_to_prim_faces_dt: bad argument");
+  hipStream_t s = as_stream(stream);
+  unsigned long long *dt_bits = ctx->d_u64 + 4;  // the stage's word: apk_stage_dt_read / apk_stage_dt_flags_read
+  APK_HIP_TRY(ctx, hipMemcpyAsync(dt_bits, ctx->d_u64 + 15, sizeof(double), hipMemcpyDeviceToDevice, s));
+  ScopedTiming timing(ctx, APK_T_C2P, s);
+  int rc = launch_cons_to_prim(md->view, fluid, *eos, ctx->d_flags, s, false, nullptr, 0, true, face_neighbor, dt_bits);
+  if (rc != APK_OK) return set_err(ctx, rc, "cons_to_prim kernel launch failed", hipGetLastError());
+  return APK_OK;
+}
+
 int apk_cons_to_prim_ghosts(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,
                             apk_stream_t stream) {
   if (!ctx || !md || !valid_eos(eos) || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||

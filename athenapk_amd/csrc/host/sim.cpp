@@ -969,12 +969,16 @@ int do_stage(apk_sim *s, int stage) {
     // refined meshes: nothing in the stage loop reads a ghost cell behind an edge or a corner of a block -- the
     // exchange skips those boxes (37 % of the ghost cells of a 16^3 block with nghost = 4) and ConsToPrim the cells
     // (nor, with amr_direct, the ghost zones behind faces the stages cross by the face table)
-    if (amr_direct(s)) {
-      SIM_TRY(s, amr_exchange(s, s->cur, AMR_XCHG_DIRECT));
+    static const bool no_c2p_dt = std::getenv("APK_NO_C2P_DT") != nullptr;  // A/B switch
+    const bool dir = amr_direct(s);
+    SIM_TRY(s, amr_exchange(s, s->cur, dir ? AMR_XCHG_DIRECT : AMR_XCHG_FACES));
+    if (dir) s->skipped_local_exchanges += 1;
+    if (stage == s->nstages && pkg.calc_dt_hyp && !no_c2p_dt) {  // (the time-step estimate on the way, as below)
+      SIM_TRY(s, apk_cons_to_prim_faces_dt(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, dir ? s->d_face_nbr : nullptr, s->stream));
+      s->stage_dt_pending = true;
+    } else if (dir) {
       SIM_TRY(s, apk_cons_to_prim_faces_skip(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->d_face_nbr, s->stream));
-      s->skipped_local_exchanges += 1;
     } else {
-      SIM_TRY(s, amr_exchange(s, s->cur, AMR_XCHG_FACES));
       SIM_TRY(s, apk_cons_to_prim_faces(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
     }
   } else if (s->amr && stage == s->nstages && amr_shell_before_check(s)) {

@@ -142,6 +142,37 @@ APK_DEV void cons_to_prim_at(const PackView &pv, const apk_block_desc &blk, cons
   cons_to_prim_at_w<FLUID>(pv, blk, eos, flags, cell, w);
 }
 
+// EstimateHyperbolicTimestep (hydro.cpp:845-895) of one cell from its primitives in registers: min over the active
+// directions of dx_d / (|v_d| + c_d) -- the expressions of min_dt_kernel
+template <int FLUID>
+APK_DEV double cell_dt_hyp(const PackView &pv, const apk_block_desc &blk, double gamma, const double (&w)[nvars<FLUID>()]) {
+  double lx, ly = 0.0, lz = 0.0;
+  if constexpr (FLUID == APK_FLUID_EULER) {
+    lx = ly = lz = sound_speed(gamma, w[IDN], w[IPR]);
+  } else {
+    lx = fast_speed(gamma, w[IDN], w[IPR], w[IB1], w[IB2], w[IB3]);
+    if (pv.ndim > 1) ly = fast_speed(gamma, w[IDN], w[IPR], w[IB2], w[IB3], w[IB1]);
+    if (pv.ndim > 2) lz = fast_speed(gamma, w[IDN], w[IPR], w[IB3], w[IB1], w[IB2]);
+  }
+  double m = blk.dx[0] / (fabs(w[IV1]) + lx);
+  if (pv.ndim > 1) m = fmin(m, blk.dx[1] / (fabs(w[IV2]) + ly));
+  if (pv.ndim > 2) m = fmin(m, blk.dx[2] / (fabs(w[IV3]) + lz));
+  return m;
+}
+// (64, 4) workgroups: one candidate per workgroup, and an atomic only if it beats the word's current value (a plain
+// read: a stale, larger value merely costs an atomic that changes nothing).  Every thread of the workgroup calls it.
+APK_DEV void block_min_to_word(double lane_min, unsigned long long *word) {
+  __shared__ double wmin[4];
+  const double m = wave_min(lane_min);
+  if (threadIdx.x == 0) wmin[threadIdx.y] = m;
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    const double g = fmin(fmin(wmin[0], wmin[1]), fmin(wmin[2], wmin[3]));
+    const double cur = __longlong_as_double((long long)*reinterpret_cast<volatile unsigned long long *>(word));
+    if (g < cur) atomicMin(word, (unsigned long long)__double_as_longlong(g));
+  }
+}
+
 // WITH_DT: EstimateHyperbolicTimestep (hydro.cpp:845-895) of the interior cells on the way, from the primitives in
 // registers -- the values min_dt_kernel would read back -- reduced into *dt_bits (apk_cons_to_prim_dt).
 template <int FLUID, bool WITH_DT>
@@ -162,53 +193,40 @@ cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags, unsigned long lon
     double w[nvars<FLUID>()];
     cons_to_prim_at_w<FLUID>(pv, blk, eos, flags, k * pv.sk + j * pv.sj + i, w);
     if constexpr (WITH_DT) {
-      if (i >= pv.is && i <= pv.ie && j >= pv.js && j <= pv.je && k >= pv.ks && k <= pv.ke) {
-        double lx, ly = 0.0, lz = 0.0;
-        if constexpr (FLUID == APK_FLUID_EULER) {
-          lx = ly = lz = sound_speed(eos.gamma, w[IDN], w[IPR]);
-        } else {
-          lx = fast_speed(eos.gamma, w[IDN], w[IPR], w[IB1], w[IB2], w[IB3]);
-          if (pv.ndim > 1) ly = fast_speed(eos.gamma, w[IDN], w[IPR], w[IB2], w[IB3], w[IB1]);
-          if (pv.ndim > 2) lz = fast_speed(eos.gamma, w[IDN], w[IPR], w[IB3], w[IB1], w[IB2]);
-        }
-        lane_min = fmin(lane_min, blk.dx[0] / (fabs(w[IV1]) + lx));
-        if (pv.ndim > 1) lane_min = fmin(lane_min, blk.dx[1] / (fabs(w[IV2]) + ly));
-        if (pv.ndim > 2) lane_min = fmin(lane_min, blk.dx[2] / (fabs(w[IV3]) + lz));
-      }
+      if (i >= pv.is && i <= pv.ie && j >= pv.js && j <= pv.je && k >= pv.ks && k <= pv.ke) lane_min = cell_dt_hyp<FLUID>(pv, blk, eos.gamma, w);
     }
   }
-  if constexpr (WITH_DT) {
-    // one candidate per workgroup, and an atomic only if it beats the word's current value (a plain read: a stale,
-    // larger value merely costs an atomic that changes nothing)
-    __shared__ double wmin[4];
-    const double m = wave_min(lane_min);
-    if (threadIdx.x == 0) wmin[threadIdx.y] = m;
-    __syncthreads();
-    if (threadIdx.x == 0 && threadIdx.y == 0) {
-      const double g = fmin(fmin(wmin[0], wmin[1]), fmin(wmin[2], wmin[3]));
-      const double cur = __longlong_as_double((long long)*reinterpret_cast<volatile unsigned long long *>(dt_bits));
-      if (g < cur) atomicMin(dt_bits, (unsigned long long)__double_as_longlong(g));
-    }
-  }
+  if constexpr (WITH_DT) block_min_to_word(lane_min, dt_bits);
 }
 
 // Interior cells and the ghost cells straight behind a FACE of the block (at most one ghost coordinate):
 // what the sweeps of the next stage read.  Rows behind edges and corners are skipped whole (no memory
 // traffic): 26 % of the cells of a 16^3 block with nghost = 4.
-template <int FLUID>
+template <int FLUID, bool WITH_DT>
 __global__ void __launch_bounds__(256)
-cons_to_prim_faces_kernel(PackView pv, apk_eos eos, unsigned *flags, const int *face_nbr) {
+cons_to_prim_faces_kernel(PackView pv, apk_eos eos, unsigned *flags, const int *face_nbr, unsigned long long *dt_bits) {
   int i, j;
-  if (!rect_ij(pv.ni, pv.nj, i, j)) return;
+  bool ok = rect_ij(pv.ni, pv.nj, i, j);
+  if (!WITH_DT && !ok) return;
   const int b = blockIdx.z / pv.nk;
   const int k = blockIdx.z % pv.nk;
   const int ghost = ((i < pv.is) || (i > pv.ie)) + ((j < pv.js) || (j > pv.je)) + ((k < pv.ks) || (k > pv.ke));
-  if (ghost > 1) return;
-  if (ghost == 1 && face_nbr) {  // a zone the stages do not read (they follow the face table to that neighbour's interior)
+  if (ghost > 1) ok = false;
+  if (ok && ghost == 1 && face_nbr) {  // a zone the stages do not read (they follow the face table to that neighbour's interior)
     const int f = (i < pv.is) ? 0 : (i > pv.ie) ? 1 : (j < pv.js) ? 2 : (j > pv.je) ? 3 : (k < pv.ks) ? 4 : 5;
-    if (face_nbr[6 * b + f] >= 0) return;
+    if (face_nbr[6 * b + f] >= 0) ok = false;
   }
-  cons_to_prim_at<FLUID>(pv, pv.blocks[b], eos, flags, k * pv.sk + j * pv.sj + i);
+  if (!WITH_DT && !ok) return;
+  double lane_min = 1.7976931348623157e308;
+  if (ok) {
+    const apk_block_desc blk = pv.blocks[b];
+    double w[nvars<FLUID>()];
+    cons_to_prim_at_w<FLUID>(pv, blk, eos, flags, k * pv.sk + j * pv.sj + i, w);
+    if constexpr (WITH_DT) {
+      if (ghost == 0) lane_min = cell_dt_hyp<FLUID>(pv, blk, eos.gamma, w);
+    }
+  }
+  if constexpr (WITH_DT) block_min_to_word(lane_min, dt_bits);
 }
 
 // Ghost zones only (the interior was converted by the finishing sweep of the fused stage).  The
@@ -564,10 +582,15 @@ int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsig
   }
   const dim3 grid = rect_grid(pv.ni, pv.nj, pv.nk * pv.nblocks);
   if (faces_only) {
-    if (fluid == APK_FLUID_EULER)
-      hipLaunchKernelGGL(cons_to_prim_faces_kernel<APK_FLUID_EULER>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, face_nbr);
+    const bool euler = fluid == APK_FLUID_EULER;
+    if (euler && dt_bits)
+      hipLaunchKernelGGL((cons_to_prim_faces_kernel<APK_FLUID_EULER, true>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, face_nbr, dt_bits);
+    else if (euler)
+      hipLaunchKernelGGL((cons_to_prim_faces_kernel<APK_FLUID_EULER, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, face_nbr, dt_bits);
+    else if (dt_bits)
+      hipLaunchKernelGGL((cons_to_prim_faces_kernel<APK_FLUID_GLMMHD, true>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, face_nbr, dt_bits);
     else
-      hipLaunchKernelGGL(cons_to_prim_faces_kernel<APK_FLUID_GLMMHD>, grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, face_nbr);
+      hipLaunchKernelGGL((cons_to_prim_faces_kernel<APK_FLUID_GLMMHD, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, face_nbr, dt_bits);
   } else if (dt_bits) {
     if (fluid == APK_FLUID_EULER)
       hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_EULER, true>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, depth);

@@ -199,6 +199,14 @@ def ConservedToPrimitiveDt(md, fluid, eos, cfl, ghost_depth=-1):
     return StageDt(ctx, cfl)
 
 
+def ConservedToPrimitiveFacesDt(md, fluid, eos, cfl, face_neighbor=None):
+    """ConservedToPrimitiveFaces with the hyperbolic time-step estimate of the interior (apk_cons_to_prim_faces_dt)."""
+    ctx = md.ctx
+    fn = C.c_void_p(face_neighbor.data_ptr()) if face_neighbor is not None else None
+    _check(ctx.lib.apk_cons_to_prim_faces_dt(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), fn, _stream()), ctx.lib, ctx.h)
+    return StageDt(ctx, cfl)
+
+
 def ConservedToPrimitiveFaces(md, fluid, eos, face_neighbor=None):
     """ConsToPrim of the interior and of the ghost cells straight behind a block face (at most one ghost coordinate);
     face_neighbor (int32 device tensor [nblocks, 6]): not behind the faces whose entry is >= 0."""

@@ -167,6 +167,7 @@ def _signatures():
         "apk_cons_to_prim_faces": (i, [vp, vp, i, E, vp]),
         "apk_cons_to_prim_dt": (i, [vp, vp, i, E, i, vp]),
         "apk_cons_to_prim_faces_skip": (i, [vp, vp, i, E, vp, vp]),
+        "apk_cons_to_prim_faces_dt": (i, [vp, vp, i, E, vp, vp]),
         "apk_cons_to_prim_ghosts_split": (i, [vp, vp, i, E, vp, i, vp]),
         "apk_stage_dt_read": (i, [vp, d, c_dp, vp]),
         "apk_stage_dt_flags_read": (i, [vp, d, c_dp, C.POINTER(C.c_uint), vp]),

@@ -273,6 +273,11 @@ int apk_cons_to_prim_faces(apk_ctx *ctx, const apk_pack *md, int fluid, const ap
  * converts the zone).  face_neighbor: device pointer, [nblocks][6]. */
 int apk_cons_to_prim_faces_skip(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, const int *face_neighbor,
                                 apk_stream_t stream);
+/* apk_cons_to_prim_faces() / apk_cons_to_prim_faces_skip() (face_neighbor may be NULL) with the time-step
+ * estimate of the interior cells reduced on the way, as apk_cons_to_prim_dt() does: the last stage of a
+ * refined-mesh cycle that is not followed by a refinement check. */
+int apk_cons_to_prim_faces_dt(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, const int *face_neighbor,
+                              apk_stream_t stream);
 /* ConsToPrim restricted to the ghost zones of every block (interior cells untouched): the
  * companion of apk_stage_fused(fill_derived = 1). */
 int apk_cons_to_prim_ghosts(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,

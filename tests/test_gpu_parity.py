@@ -330,6 +330,12 @@ def test_cons_to_prim_with_time_step_estimate(request, fluid, nx, strict):
     assert hydro.ConservedToPrimitiveDt(md, fluid, eos, 0.3, ghost_depth=1) == dt
     got = md.prim_host()
     assert np.array_equal(got[:, :, ~deep], ref.prim_host()[:, :, ~deep]) and np.all(got[:, :, deep] == -3.0) and deep.any()
+    # apk_cons_to_prim_faces_dt: what apk_cons_to_prim_faces converts, and the same estimate
+    a = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=u, prim=np.full_like(u, -3.0), with_flux=False)
+    b = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=u, prim=np.full_like(u, -3.0), with_flux=False)
+    hydro.ConservedToPrimitiveFaces(a, fluid, eos)
+    assert hydro.ConservedToPrimitiveFacesDt(b, fluid, eos, 0.3) == dt
+    assert np.array_equal(a.prim_host(), b.prim_host())
 
 
 @pytest.mark.parametrize("fluid", ["euler", "glmmhd"])
