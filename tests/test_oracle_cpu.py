@@ -114,7 +114,7 @@ def test_mhd_linear_wave_eigensystem_diagonalises_the_flux_jacobian(oracle, vflo
         assert np.allclose(jac @ r, ev[w] * r, rtol=0, atol=2e-8), (w, jac @ r - ev[w] * r)
 
 
-@pytest.mark.parametrize("wave_flag,vflow,sizes", [(0, 0.0, (16, 32, 64)), (1, 0.0, (16, 32)), (2, 0.0, (16, 32)), (3, 1.0, (16, 32))],
+@pytest.mark.parametrize("wave_flag,vflow,sizes", [(0, 0.0, (16, 32)), (1, 0.0, (16, 32)), (2, 0.0, (16, 32)), (3, 1.0, (16, 32))],
                          ids=["fast", "alfven", "slow", "entropy"])
 def test_mhd_linear_waves_converge_at_second_order(oracle, wave_flag, vflow, sizes):
     """PPM + HLLD + Dedner, RK3, one wave period on 2N x N x N: the RMS-L1 error of (d, M, E, B) falls by ~4 per doubling
