@@ -103,13 +103,14 @@ int apk_create(apk_ctx **out) {
     delete ctx;
     return APK_ERR_NO_DEVICE;
   }
-  if (hipMalloc(&ctx->d_flags, 2 * sizeof(unsigned)) != hipSuccess ||  // [0] latched, [1] trial stage
-      hipMalloc(&ctx->d_u64, 16 * sizeof(unsigned long long)) != hipSuccess ||
+  if (hipMalloc(&ctx->d_u64, 16 * sizeof(unsigned long long)) != hipSuccess ||
       hipHostMalloc(&ctx->h_pinned, 256, hipHostMallocDefault) != hipSuccess) {
     apk_destroy(ctx);
     return APK_ERR_DEVICE;
   }
-  (void)hipMemset(ctx->d_flags, 0, 2 * sizeof(unsigned));
+  // the flag words ([0] latched, [1] trial stage) are word 5 of d_u64, next to the stage's time-step word 4: one
+  // 16-byte read-back fetches both at the end of a cycle (apk_stage_dt_flags_read)
+  ctx->d_flags = reinterpret_cast<unsigned *>(ctx->d_u64 + 5);
   (void)hipMemset(ctx->d_u64, 0, 16 * sizeof(unsigned long long));
   {
     const double huge = 1.7976931348623157e308;  // word 15: constant +max, the neutral element of the dt min
@@ -121,8 +122,7 @@ int apk_create(apk_ctx **out) {
 
 void apk_destroy(apk_ctx *ctx) {
   if (!ctx) return;
-  if (ctx->d_flags) (void)hipFree(ctx->d_flags);
-  if (ctx->d_u64) (void)hipFree(ctx->d_u64);
+  if (ctx->d_u64) (void)hipFree(ctx->d_u64);  // (d_flags points into it)
   if (ctx->d_mflux) (void)hipFree(ctx->d_mflux);
   if (ctx->d_partial) (void)hipFree(ctx->d_partial);
   if (ctx->d_mark) (void)hipFree(ctx->d_mark);
@@ -496,15 +496,16 @@ int apk_stage_dt_flags_read(apk_ctx *ctx, double cfl, double *dt_out, unsigned *
   if (!ctx || !dt_out || !flags) return APK_ERR_INVALID;
   hipStream_t s = as_stream(stream);
   auto *h = static_cast<unsigned long long *>(ctx->h_pinned);
-  auto *hf = reinterpret_cast<unsigned *>(static_cast<char *>(ctx->h_pinned) + 192);
-  APK_HIP_TRY(ctx, hipMemcpyAsync(h + 4, ctx->d_u64 + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-  APK_HIP_TRY(ctx, hipMemcpyAsync(hf, ctx->d_flags, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  // words 4 (the stage's minimum) and 5 (the flag words) in one copy
+  APK_HIP_TRY(ctx, hipMemcpyAsync(h + 4, ctx->d_u64 + 4, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   APK_HIP_TRY(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(unsigned), s));
   APK_HIP_TRY(ctx, hipStreamSynchronize(s));
   double m;
   std::memcpy(&m, h + 4, sizeof(m));
   *dt_out = cfl * m;  // hydro.cpp:909
-  *flags = *hf;
+  unsigned f[2];
+  std::memcpy(f, h + 5, sizeof(f));
+  *flags = f[0];
   return APK_OK;
 }
 
