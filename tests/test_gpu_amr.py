@@ -650,8 +650,9 @@ DIRECT_CASES = {
 
 
 @pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("bc", ["outflow", "periodic"])
 @pytest.mark.parametrize("case", sorted(DIRECT_CASES))
-def test_face_table_on_a_refined_mesh_changes_nothing(case, strict):
+def test_face_table_on_a_refined_mesh_changes_nothing(case, bc, strict):
     """Refined meshes of 16^3 blocks (BASELINE config 5's): the stages read a same-rank neighbour of the same level
     through the face table, and the faces-only exchange of the stage loop neither copies nor converts the ghost zone
     behind such a face (amr_direct, AMR_XCHG_DIRECT).  Forest, time steps and every cell of every block -- ghost zones
@@ -664,6 +665,7 @@ def test_face_table_on_a_refined_mesh_changes_nothing(case, strict):
         "parthenon/time/integrator=%s" % integrator, "parthenon/mesh/check_refine_interval=%d" % interval,
         "parthenon/mesh/derefine_count=2", "problem/blast/pressure_ambient=1.0", "problem/blast/pressure_ratio=1000",
         "problem/blast/radius_outer=0.1", "problem/blast/radius_inner=0.05", "refinement/threshold_pressure_gradient=0.5"]
+    ov += _bc(bc)  # (periodic: two root blocks per direction -- the block behind the lower and the upper face is the same one)
     a = _sim("blast_3d_amr", ov, strict=strict).initialize()
     b = _sim("blast_3d_amr", ov, strict=strict)
     b.set_direct_neighbors(False)
