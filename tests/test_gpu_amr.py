@@ -116,9 +116,10 @@ def test_single_step_on_a_refined_mesh_conserves_in_the_parity_build():
     assert abs(t1[0] - t0[0]) < 1e-14 and abs(t1[4] - t0[4]) < 1e-13 * t0[4]
 
 
+@pytest.mark.parametrize("mb", [8, 16])
 @pytest.mark.parametrize("fluid,riemann,recon,ng,integrator", [("euler", "hlle", "plm", 2, "vl2"), ("glmmhd", "hlld", "ppm", 4, "vl2"),
                                                                ("euler", "hllc", "plm", 2, "rk3"), ("glmmhd", "hlle", "wenoz", 4, "rk3")])
-def test_refined_mesh_stage_loop_matches_the_forest_oracle(oracle, fluid, riemann, recon, ng, integrator):
+def test_refined_mesh_stage_loop_matches_the_forest_oracle(oracle, fluid, riemann, recon, ng, integrator, mb):
     """The time loop on a statically refined periodic mesh (3 levels: multilevel ghost exchange, coarse-fine flux
     correction, per-level cell widths in the sweeps, the time step and c_h) against tests/amr_oracle.py -- a restatement
     that knows the forest and the oracle's pointwise functions, none of the driver's plans.  Flux-array task order
@@ -126,7 +127,10 @@ def test_refined_mesh_stage_loop_matches_the_forest_oracle(oracle, fluid, rieman
     zones included, bit for bit in the parity build, cycle after cycle; the fused stage with its post-stage correction:
     the same arithmetic in another order, to round-off."""
     from test_amr_mesh import _forest_oracle
-    ov = SMR3 + _bc("periodic") + ["hydro/fluid=%s" % fluid, "hydro/riemann=%s" % riemann, "hydro/reconstruction=%s" % recon,
+    if mb == 16 and integrator != "vl2":
+        pytest.skip("16^3 blocks: the VL2 cases (two-kernel stage, donor-cell march, face table)")
+    # (16^3 blocks: the fused stages run the two-kernel form and read same-level neighbours through the face table)
+    ov = SMR3 + ["parthenon/meshblock/nx%d=%d" % (d, mb) for d in (1, 2, 3)] + _bc("periodic") + ["hydro/fluid=%s" % fluid, "hydro/riemann=%s" % riemann, "hydro/reconstruction=%s" % recon,
                                    "parthenon/mesh/nghost=%d" % ng, "parthenon/time/integrator=%s" % integrator,
                                    "problem/blast/radius_outer=0.2", "problem/blast/pressure_ratio=100", "problem/blast/x3_0=0.1",
                                    "problem/blast/x1_0=0.013", "problem/blast/x2_0=-0.021", "problem/blast/radius_inner=0.1",
@@ -136,7 +140,7 @@ def test_refined_mesh_stage_loop_matches_the_forest_oracle(oracle, fluid, rieman
     s.initialize()
     nb = s.info.nblocks_total
     fo = _forest_oracle(s, oracle, fluid, recon, riemann, integrator)
-    assert len(fo.levels) == 3
+    assert len(fo.levels) == (3 if mb == 8 else 2)
     fo.initialize([s.read_block(lb) for lb in range(nb)])
     assert fo.dt == s.dt
     for cycle in range(4):
@@ -149,13 +153,29 @@ def test_refined_mesh_stage_loop_matches_the_forest_oracle(oracle, fluid, rieman
     # the fused stages + post-stage correction
     f = _sim("blast", ov, strict=True).initialize()
     assert bool(f.refresh_info().fused)
-    for cycle in range(4):
-        f.step()
-    assert abs(f.time - fo.time) <= 1e-14 * fo.time
     scale = max(np.abs(c).max() for c in fo.cons)
+    tol = 1e-12
+    if mb == 16:
+        # One cycle against the flux-array order: round-off.  Over four cycles that round-off flips PPM's extremum
+        # tests in the flat ambient medium next to the blast on this mesh (2.8e-14 after the first cycle, 2e-8 absolute
+        # after the second -- the same numbers with and without the face table, with the faces-only and with the
+        # complete exchange), so the four-cycle bound is looser here.
+        g = _sim("blast", ov, strict=True)
+        g.set_fused(False)
+        g.initialize()
+        f.step()
+        g.step()
+        for lb in range(nb):
+            a, b = f.read_block(lb)[:, ng:-ng, ng:-ng, ng:-ng], g.read_block(lb)[:, ng:-ng, ng:-ng, ng:-ng]
+            assert np.abs(a - b).max() <= 1e-12 * scale, (lb, np.abs(a - b).max())
+        tol = 1e-9 if recon == "ppm" else 1e-12
+    for cycle in range(3 if mb == 16 else 4):
+        f.step()
+    assert (f.skipped_local_exchanges() > 0) == (mb == 16)
+    assert abs(f.time - fo.time) <= 1e-14 * fo.time
     for lb in range(nb):
         a, b = f.read_block(lb)[:, ng:-ng, ng:-ng, ng:-ng], fo.cons[lb][:, ng:-ng, ng:-ng, ng:-ng]
-        assert np.abs(a - b).max() <= 1e-12 * scale, (lb, np.abs(a - b).max())
+        assert np.abs(a - b).max() <= tol * scale, (lb, np.abs(a - b).max())
 
 
 @pytest.mark.parametrize("fluid,riemann,recon,ng,integrator", [("euler", "hllc", "plm", 2, "rk3"), ("glmmhd", "hlld", "ppm", 4, "vl2")])
