@@ -127,8 +127,6 @@ def test_refined_mesh_stage_loop_matches_the_forest_oracle(oracle, fluid, rieman
     zones included, bit for bit in the parity build, cycle after cycle; the fused stage with its post-stage correction:
     the same arithmetic in another order, to round-off."""
     from test_amr_mesh import _forest_oracle
-    if mb == 16 and integrator != "vl2":
-        pytest.skip("16^3 blocks: the VL2 cases (two-kernel stage, donor-cell march, face table)")
     # (16^3 blocks: the fused stages run the two-kernel form and read same-level neighbours through the face table)
     ov = SMR3 + ["parthenon/meshblock/nx%d=%d" % (d, mb) for d in (1, 2, 3)] + _bc("periodic") + ["hydro/fluid=%s" % fluid, "hydro/riemann=%s" % riemann, "hydro/reconstruction=%s" % recon,
                                    "parthenon/mesh/nghost=%d" % ng, "parthenon/time/integrator=%s" % integrator,
