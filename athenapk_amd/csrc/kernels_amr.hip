@@ -259,8 +259,9 @@ __global__ void __launch_bounds__(256) flux_fix_kernel(const apk_flux_fix_region
 // one workgroup row per (block, k-plane chunk); the criteria are non-negative, so their bit
 // patterns order like unsigned integers and one atomicMax per workgroup suffices
 template <int CRIT>
-__global__ void __launch_bounds__(256) tag_kernel(PackView pv, unsigned long long *block_max) {
-  const int b = blockIdx.z;
+__global__ void __launch_bounds__(256) tag_kernel(PackView pv, unsigned long long *block_max, int kchunks) {
+  const int b = blockIdx.z / kchunks;
+  const int chunk = blockIdx.z - b * kchunks;
   const apk_block_desc blk = pv.blocks[b];
   const int ndim = (pv.nx3 > 1) ? 3 : ((pv.nx2 > 1) ? 2 : 1);
   // extents per criterion (gradient.cpp:33-36,45-46,79-81; other.cpp:31-32)
@@ -277,8 +278,12 @@ __global__ void __launch_bounds__(256) tag_kernel(PackView pv, unsigned long lon
   int io, jo;
   const bool inside = rect_ij(pv.nx1 + 2, pv.nx2 + 2, io, jo);  // (the launch covers the widest extent)
   const int i = il + io, j = jl + jo;
+  // (the k range in kchunks pieces, one workgroup each: a pack of a few hundred narrow blocks is too few workgroups
+  // of 18 dependent plane-steps otherwise; the block's maximum is an atomicMax either way)
+  const int klen = (ku - kl + kchunks) / kchunks;
+  const int k0 = kl + chunk * klen, k1 = (k0 + klen - 1 < ku) ? k0 + klen - 1 : ku;
   if (inside && i <= iu && j <= ju) {
-    for (int k = kl; k <= ku; ++k) {
+    for (int k = k0; k <= k1; ++k) {
       const int64_t c = k * pv.sk + j * pv.sj + i;
       if (CRIT == APK_TAG_PRESSURE_GRADIENT) {
         const double *p = blk.prim + IPR * pv.sn + c;
@@ -474,13 +479,15 @@ int apk_tag_blocks_begin(apk_ctx *ctx, const apk_pack *md, int criterion, int *p
   }
   auto *d_max = reinterpret_cast<unsigned long long *>(ctx->d_partial);
   APK_HIP_TRY(ctx, hipMemsetAsync(d_max, 0, sizeof(unsigned long long) * nb, s));
-  const dim3 grid = rect_grid(pv.nx1 + 2, pv.nx2 + 2, nb), block(64, 4, 1);
+  static const int forced = std::getenv("APK_TAG_KCHUNKS") ? std::atoi(std::getenv("APK_TAG_KCHUNKS")) : 0;  // A/B switch
+  const int kchunks = forced > 0 ? forced : ((pv.nx3 >= 12 && nb < 4096) ? 3 : 1);
+  const dim3 grid = rect_grid(pv.nx1 + 2, pv.nx2 + 2, nb * kchunks), block(64, 4, 1);
   if (criterion == APK_TAG_PRESSURE_GRADIENT)
-    hipLaunchKernelGGL(tag_kernel<APK_TAG_PRESSURE_GRADIENT>, grid, block, 0, s, pv, d_max);
+    hipLaunchKernelGGL(tag_kernel<APK_TAG_PRESSURE_GRADIENT>, grid, block, 0, s, pv, d_max, kchunks);
   else if (criterion == APK_TAG_VELOCITY_GRADIENT)
-    hipLaunchKernelGGL(tag_kernel<APK_TAG_VELOCITY_GRADIENT>, grid, block, 0, s, pv, d_max);
+    hipLaunchKernelGGL(tag_kernel<APK_TAG_VELOCITY_GRADIENT>, grid, block, 0, s, pv, d_max, kchunks);
   else
-    hipLaunchKernelGGL(tag_kernel<APK_TAG_MAX_DENSITY>, grid, block, 0, s, pv, d_max);
+    hipLaunchKernelGGL(tag_kernel<APK_TAG_MAX_DENSITY>, grid, block, 0, s, pv, d_max, kchunks);
   APK_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partial, d_max, sizeof(double) * nb, hipMemcpyDeviceToHost, s));
   *pending = 1;
   return APK_OK;
