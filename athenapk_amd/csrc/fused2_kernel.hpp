@@ -111,11 +111,15 @@ __device__ unsigned long long g_m12f_phase[8];
     if (lane == 0) phase_acc[slot] += now_ - tick_;               \
     tick_ = now_;                                                 \
   } while (0)
+#elif defined(APK_PHASE_MARKERS)
+// (tools/ledger.sh: an assembler comment at every phase boundary, for the per-phase instruction ledger of
+// tools/isa_loop_ledger.py; no instruction, but volatile asm statements pin the phase order like the ticks do)
+#define APK_TICK(slot) asm volatile(";;APK_PHASE " #slot ::: "memory")
 #else
 #define APK_TICK(slot) do { } while (0)
 #endif
 
-template <int FLUID, int RECON, int RS, int EXTRA>
+template <int FLUID, int RECON, int RS, int EXTRA, bool LEAN>
 __global__ void __launch_bounds__(64, APK_M12F_WAVES)
 fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves, int per_xcd,
                   long long total_rows) {
@@ -169,6 +173,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     const double area1 = to_sgpr(b0.dx[1] * b0.dx[2]);  // (per block: wave-uniform)
     const double area2 = to_sgpr(b0.dx[0] * b0.dx[2]);
     const double vol = to_sgpr(b0.dx[0] * b0.dx[1] * b0.dx[2]);
+    const double upd = LEAN ? update_coefficient(sp, vol) : 0.0;
     const double *prim_generic = b0.prim + base;
     // Direct neighbour addressing (sp.face_nbr): a lane on a ghost column reads the interior column
     // of the block behind that x1 face; the stencil rows below js / above je of an interior column
@@ -288,10 +293,12 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
           if (q == 0) fup0 = fup;
           du[perm<1>(q)] = (area1 * fup - area1 * f1[q]);
         }
-        if (sp.mflux && active) {
-          double *m = sp.mflux + ((int64_t)0 * u0.nblocks + b) * u0.sn + done;
-          m[0] = f1[0];
-          m[1] = fup0;
+        if constexpr (!LEAN) {
+          if (sp.mflux && active) {
+            double *m = sp.mflux + ((int64_t)0 * u0.nblocks + b) * u0.sn + done;
+            m[0] = f1[0];
+            m[1] = fup0;
+          }
         }
         // (2) streaming operands of the cell being retired: in flight during the x2 phase
         if constexpr (APK_M12F_LOADS == 1) {
@@ -392,12 +399,14 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
 #pragma unroll
           for (int n = 0; n < NV; ++n) du[n] = du[n] + d3v[n];
           if (active) {
-            if (sp.mflux) {
-              double *m = sp.mflux + ((int64_t)1 * u0.nblocks + b) * u0.sn + done;
-              m[0] = f_prev[0];
-              m[st] = f[0];
+            if constexpr (!LEAN) {
+              if (sp.mflux) {
+                double *m = sp.mflux + ((int64_t)1 * u0.nblocks + b) * u0.sn + done;
+                m[0] = f_prev[0];
+                m[st] = f[0];
+              }
             }
-            finish_cell<FLUID, EXTRA>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst);
+            finish_cell<FLUID, EXTRA, LEAN>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd);
           }
           APK_TICK(6);  // update, Dedner, ConsToPrim, dt, stores issued
         }
@@ -497,12 +506,22 @@ inline void launch_m12f(const PackView &u0, const PackView &u1, const StageParam
     const int nwaves = (int)nw;
     const int per_xcd = (nwaves + 7) / 8;
     const dim3 g((unsigned)(per_xcd * 8), 1, 1);
-    if (extra == EXTRA_C2P_DT)
-      hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_C2P_DT>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows);
-    else if (extra == EXTRA_C2P)
-      hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_C2P>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows);
-    else
-      hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_NONE>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows);
+    // (APK_NO_LEAN=1: the general kernel also where the lean one applies, A/B)
+    static const bool no_lean = std::getenv("APK_NO_LEAN") && std::atoi(std::getenv("APK_NO_LEAN")) != 0;
+    const bool lean = stage_is_lean(sp) && !no_lean;
+#define APK_LAUNCH_M12F(EXTRA_, LEAN_) \
+  hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, LEAN_>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows)
+    if (extra == EXTRA_C2P_DT) {
+      if (lean) APK_LAUNCH_M12F(EXTRA_C2P_DT, true);
+      else APK_LAUNCH_M12F(EXTRA_C2P_DT, false);
+    } else if (extra == EXTRA_C2P) {
+      if (lean) APK_LAUNCH_M12F(EXTRA_C2P, true);
+      else APK_LAUNCH_M12F(EXTRA_C2P, false);
+    } else {
+      if (lean) APK_LAUNCH_M12F(EXTRA_NONE, true);
+      else APK_LAUNCH_M12F(EXTRA_NONE, false);
+    }
+#undef APK_LAUNCH_M12F
 #if APK_M12F_TIMING
     {
       static int calls = 0;

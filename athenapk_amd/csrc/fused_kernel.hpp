@@ -103,20 +103,54 @@ APK_DEV double wave_shl1(double x) {  // lane l receives lane l+1 (lane 63: 0.0)
 // ---- end-of-stage update of one cell (FINAL sweep) -------------------------------------------
 // UpdateWithFluxDivergence (hydro_driver.cpp:534-537) then DednerSource
 // (dedner_source.cpp:42-74), in that order, exactly as the task list runs them.
-template <int FLUID, int EXTRA = EXTRA_NONE>
+// A stage is LEAN when none of the finishing sweep's optional work is asked for: no mass-flux workspace (passive
+// scalars), no trial count (first-order flux correction), no extended Dedner source, and an equation of state whose
+// velocity ceiling, pressure floor and energy ceiling are off (eos_is_lean).  The uniform-mesh cycles of the decks and
+// of the benchmark are all of this kind.  finish_cell<.., LEAN = true> compiles none of that work: no scalar
+// registers for its parameters (the finishing march spills ~100 of them to vector lanes, one v_readlane per use), one
+// wave-uniform branch around the nine loads of the old state instead of nine, and -- product build -- the update as
+// one fused multiply-add per variable on the wave-uniform coefficient `upd` = -beta_dt / V.
+inline bool stage_is_lean(const StageParams &sp) {
+  return sp.mflux == nullptr && sp.bad_count == nullptr && sp.dedner != 2 && eos_is_lean(sp.eos);
+}
+// -beta_dt / V of a block (product build; the parity build divides by V per cell as the reference does)
+APK_DEV double update_coefficient(const StageParams &sp, double vol) { return to_sgpr(-sp.beta_dt / vol); }
+
+template <int FLUID, int EXTRA = EXTRA_NONE, bool LEAN = false>
 APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
                          const double (&u1v)[nvars<FLUID>()], int64_t cell,
                          const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp,
-                         double &lane_min_dt, double *prim_dst = nullptr) {
+                         double &lane_min_dt, double *prim_dst = nullptr, double upd = 0.0) {
   constexpr int NV = nvars<FLUID>();
   double un[NV];
+  if constexpr (LEAN) {
+#ifdef APK_FP_STRICT
+#define APK_UPD_TERM(n) (sp.beta_dt * (-du[n] / vol))
+#else
+#define APK_UPD_TERM(n) (upd * du[n])
+#endif
+    if (sp.gam0 != 0.0) {  // wave-uniform
+      double old[NV];
+#pragma unroll
+      for (int n = 0; n < NV; ++n) old[n] = as_global(b0.cons)[n * pv.sn + cell];
+#pragma unroll
+      for (int n = 0; n < NV; ++n) un[n] = sp.gam0 * old[n] + sp.gam1 * u1v[n] + APK_UPD_TERM(n);
+    } else {
+      // (gam0 = 0: the reference's 0 * u0 + gam1 * u1 + ... is gam1 * u1 + ... to the bit -- x + 0 = x)
+#pragma unroll
+      for (int n = 0; n < NV; ++n) un[n] = sp.gam1 * u1v[n] + APK_UPD_TERM(n);
+    }
+#undef APK_UPD_TERM
+  } else {
 #pragma unroll
   for (int n = 0; n < NV; ++n) {
     const int64_t idx = n * pv.sn + cell;
     const double old = (sp.gam0 != 0.0) ? as_global(b0.cons)[idx] : 0.0;
     un[n] = sp.gam0 * old + sp.gam1 * u1v[n] + sp.beta_dt * (-du[n] / vol);
   }
+  }
   if constexpr (FLUID == APK_FLUID_GLMMHD) {
+    if constexpr (!LEAN) {
     if (sp.dedner == 2) {
       const double *w = b0.prim + cell;
       const int64_t so = (pv.ndim >= 2) ? pv.sj : 0;
@@ -132,16 +166,19 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
                  (b1[0] * (ps[1] - ps[-1]) / b0.dx[0] + b2[0] * (ps[so] - ps[-so]) / b0.dx[1] +
                   b3[0] * (ps[ko] - ps[-ko]) / b0.dx[2]);
     }
+    }
     if (sp.dedner != 0) un[IPS] *= sp.dedner_coeff;
   }
   // Trial stage of first-order flux correction: FirstOrderFluxCorrect's admissibility test
   // (hydro.cpp:1297-1306: rho <= 0 or E - KE [- ME] <= 0, on the update BEFORE any floor) applied to
   // the very `un` this kernel computed.
   bool bad = false;
+  if constexpr (!LEAN) {
   if (sp.bad_count) {
     double new_p = un[IEN] - 0.5 * (sqr(un[IM1]) + sqr(un[IM2]) + sqr(un[IM3])) / un[IDN];
     if constexpr (FLUID == APK_FLUID_GLMMHD) new_p -= 0.5 * (sqr(un[IB1]) + sqr(un[IB2]) + sqr(un[IB3]));
     bad = !(un[IDN] > 0.0 && new_p > 0.0);
+  }
   }
   if constexpr (EXTRA != EXTRA_NONE) {
     // FillDerived for this cell (adiabatic_hydro.hpp:52-142): in a march along x2/x3 no other lane
@@ -150,33 +187,25 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
     // read neighbouring columns from memory get prim_dst = u1's prim arrays instead.
     // Floors/ceilings act on `un` before it is stored.
     double w[NV], di;
-    const unsigned fl = cons_to_prim_cell<FLUID>(sp.eos, sp.k, un, w, di);
+    const unsigned fl = cons_to_prim_cell<FLUID, LEAN>(sp.eos, sp.k, un, w, di);
     if (fl) atomicOr(sp.flags, fl);
     // (ConsToPrim forms the pressure with 1/rho where the test above divides: a trial stage is
     // only accepted if neither sees a negative state, so an accepted stage never raises flags)
-    if (sp.bad_count && fl) bad = true;
+    if constexpr (!LEAN) {
+      if (sp.bad_count && fl) bad = true;
+    }
 #pragma unroll
     for (int n = 0; n < NV; ++n) as_global(prim_dst)[n * pv.sn + cell] = w[n];
     if constexpr (EXTRA == EXTRA_C2P_DT) {
       // EstimateHyperbolicTimestep (hydro.cpp:845-895) on the fresh primitives
-      double lx, ly = 0.0, lz = 0.0;
-      if constexpr (FLUID == APK_FLUID_EULER) {
-        lx = sound_speed(sp.eos.gamma, w[IDN], w[IPR]);
-        ly = lx;
-        lz = lx;
-      } else {
-        lx = fast_speed(sp.eos.gamma, w[IDN], w[IPR], w[IB1], w[IB2], w[IB3]);
-        if (pv.ndim > 1) ly = fast_speed(sp.eos.gamma, w[IDN], w[IPR], w[IB2], w[IB3], w[IB1]);
-        if (pv.ndim > 2) lz = fast_speed(sp.eos.gamma, w[IDN], w[IPR], w[IB3], w[IB1], w[IB2]);
-      }
-      lane_min_dt = fmin(lane_min_dt, b0.dx[0] / (fabs(w[IV1]) + lx));
-      if (pv.ndim > 1) lane_min_dt = fmin(lane_min_dt, b0.dx[1] / (fabs(w[IV2]) + ly));
-      if (pv.ndim > 2) lane_min_dt = fmin(lane_min_dt, b0.dx[2] / (fabs(w[IV3]) + lz));
+      lane_min_dt = fmin(lane_min_dt, cell_dt_hyp<FLUID>(sp.eos.gamma, w, di, pv.ndim, b0.dx[0], b0.dx[1], b0.dx[2]));
     }
   }
 #pragma unroll
   for (int n = 0; n < NV; ++n) as_global(b0.cons)[n * pv.sn + cell + sp.out_delta] = un[n];
-  if (bad) atomicAdd(sp.bad_count, 1ull);
+  if constexpr (!LEAN) {
+    if (bad) atomicAdd(sp.bad_count, 1ull);
+  }
 }
 
 // ==============================================================================================
@@ -679,7 +708,7 @@ fused_march12_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_blo
 #ifndef APK_DC3_WAVES
 #define APK_DC3_WAVES 2  // resident waves per SIMD the donor-cell march is compiled for (A/B)
 #endif
-template <int FLUID, int RS, int EXTRA = EXTRA_NONE>
+template <int FLUID, int RS, int EXTRA = EXTRA_NONE, bool LEAN = false>
 __global__ void __launch_bounds__(64, APK_DC3_WAVES)
 fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, int nseg, int per_xcd) {
   constexpr int NV = nvars<FLUID>();
@@ -742,6 +771,7 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
   }
   const double area1 = b0.dx[1] * b0.dx[2], area2 = b0.dx[0] * b0.dx[2], area3 = b0.dx[0] * b0.dx[1];
   const double vol = b0.dx[0] * b0.dx[1] * b0.dx[2];
+  const double upd = LEAN ? update_coefficient(sp, vol) : 0.0;
   // the march is cut into gridDim.y segments of kseg planes: 2216 full-length waves on a machine
   // with 2048 wave slots (256 VGPRs -> 2 per SIMD) would run in two rounds; many short waves
   // keep every slot busy, for one redundant x3 solve per segment
@@ -831,12 +861,14 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
         }
 #pragma unroll
         for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
-        if (active && sp.mflux) {
-          double *m = sp.mflux + ((int64_t)2 * u0.nblocks + b) * u0.sn + done;
-          m[0] = st_f3[0];
-          m[u0.sk] = f3[0];
+        if constexpr (!LEAN) {
+          if (active && sp.mflux) {
+            double *m = sp.mflux + ((int64_t)2 * u0.nblocks + b) * u0.sn + done;
+            m[0] = st_f3[0];
+            m[u0.sk] = f3[0];
+          }
         }
-        if (active) finish_cell<FLUID, EXTRA>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst);
+        if (active) finish_cell<FLUID, EXTRA, LEAN>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd);
       }
 #pragma unroll
       for (int q = 0; q < NV; ++q) st_f3[q * 64] = f3[q];
@@ -861,10 +893,12 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
           if (q == 0) fup0 = fup;
           d1[q] = (area1 * fup - area1 * f[q]);
         }
-        if (active && sp.mflux) {
-          double *m = sp.mflux + ((int64_t)0 * u0.nblocks + b) * u0.sn + col + off;
-          m[0] = f[0];
-          m[1] = fup0;
+        if constexpr (!LEAN) {
+          if (active && sp.mflux) {
+            double *m = sp.mflux + ((int64_t)0 * u0.nblocks + b) * u0.sn + col + off;
+            m[0] = f[0];
+            m[1] = fup0;
+          }
         }
 #pragma unroll
         for (int q = 0; q < NV; ++q) st_du[perm<1>(q) * 64] = d1[q];
@@ -895,10 +929,12 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
           const int n = perm<2>(q);
           st_du[n * 64] = st_du[n * 64] + (area2 * fhi[q] - area2 * flo[q]);
         }
-        if (active && sp.mflux) {
-          double *m = sp.mflux + ((int64_t)1 * u0.nblocks + b) * u0.sn + col + off;
-          m[0] = flo[0];
-          m[u0.sj] = fhi[0];
+        if constexpr (!LEAN) {
+          if (active && sp.mflux) {
+            double *m = sp.mflux + ((int64_t)1 * u0.nblocks + b) * u0.sn + col + off;
+            m[0] = flo[0];
+            m[u0.sj] = fhi[0];
+          }
         }
       }
     }
@@ -1083,12 +1119,21 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
         const dim3 g((unsigned)(per_xcd * 8), 1, 1);
         constexpr int lds3 = 2 * nvars<FLUID>() * 64 * (int)sizeof(double);
         ScopedTiming t(sp.ctx, TS + 0, s);
-        if (extra == EXTRA_C2P_DT)
-          hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_C2P_DT>), g, dim3(64), lds3, s, u0, u1, sp, kseg, wpb, nseg, per_xcd);
-        else if (extra == EXTRA_C2P)
-          hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_C2P>), g, dim3(64), lds3, s, u0, u1, sp, kseg, wpb, nseg, per_xcd);
-        else
-          hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_NONE>), g, dim3(64), lds3, s, u0, u1, sp, kseg, wpb, nseg, per_xcd);
+        static const bool no_lean = std::getenv("APK_NO_LEAN") && std::atoi(std::getenv("APK_NO_LEAN")) != 0;  // (A/B)
+        const bool lean = stage_is_lean(sp) && !no_lean;
+#define APK_LAUNCH_DC3(EXTRA_, LEAN_) \
+  hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_, LEAN_>), g, dim3(64), lds3, s, u0, u1, sp, kseg, wpb, nseg, per_xcd)
+        if (extra == EXTRA_C2P_DT) {
+          if (lean) APK_LAUNCH_DC3(EXTRA_C2P_DT, true);
+          else APK_LAUNCH_DC3(EXTRA_C2P_DT, false);
+        } else if (extra == EXTRA_C2P) {
+          if (lean) APK_LAUNCH_DC3(EXTRA_C2P, true);
+          else APK_LAUNCH_DC3(EXTRA_C2P, false);
+        } else {
+          if (lean) APK_LAUNCH_DC3(EXTRA_NONE, true);
+          else APK_LAUNCH_DC3(EXTRA_NONE, false);
+        }
+#undef APK_LAUNCH_DC3
         if (sp.mflux && sp.phase == 0) launch_scalar_update<RECON>(u0, u1, sp, extra, s);
         return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
       }

@@ -99,6 +99,7 @@ struct RcclTransport {
   static constexpr int kRedMax = 64;
   int rank = 0, nranks = 1;
   long long exchanges = 0, reductions = 0;
+  long long loopback_bytes = 0;  // loopback transport: bytes "sent" so far
   std::string err;
 };
 
@@ -146,6 +147,33 @@ int rccl_exchange_begin(void *user) {
   return 0;
 }
 
+// Loopback (one-GPU rehearsal of a rank of the 2 x 2 x 2 run, mesh.hpp "rehearse"): the same ordering as above --
+// the halo stream waits for the pack kernel, the sim's stream later waits for the halo stream -- with one
+// device-to-device copy per peer standing in for the ncclSend / ncclRecv pair: the message the periodic image of this
+// rank would send is this rank's own send buffer.  Everything but the wire (xGMI) is as in the 8-GPU run.
+int loopback_exchange_begin(void *user) {
+  apk_sim *s = static_cast<apk_sim *>(user);
+  RcclTransport *t = s->rccl;
+  if (!hip_ok(t, hipEventRecord(t->ev_ready, hs(s)), "hipEventRecord")) return 1;
+  if (!hip_ok(t, hipStreamWaitEvent(t->s_halo, t->ev_ready, 0), "hipStreamWaitEvent")) return 1;
+  const int np = apk_sim_num_peers(s);
+  for (int p = 0; p < np; ++p) {
+    apk_peer_info pi;
+    if (apk_sim_peer(s, p, &pi) != APK_OK || pi.send_count != pi.recv_count) {
+      t->err = "loopback: a peer's send and receive sizes differ";
+      return 1;
+    }
+    if (pi.send_count > 0 &&
+        !hip_ok(t, hipMemcpyAsync(pi.recv_buf, pi.send_buf, sizeof(double) * (size_t)pi.send_count, hipMemcpyDeviceToDevice, t->s_halo),
+                "hipMemcpyAsync"))
+      return 1;
+    t->loopback_bytes += (long long)sizeof(double) * pi.send_count;
+  }
+  if (!hip_ok(t, hipEventRecord(t->ev_done, t->s_halo), "hipEventRecord")) return 1;
+  t->exchanges += 1;
+  return 0;
+}
+
 // work enqueued on the sim's stream from now on (unpack kernel, boundary conditions) waits for the receives
 int rccl_exchange_end(void *user) {
   apk_sim *s = static_cast<apk_sim *>(user);
@@ -156,6 +184,15 @@ int rccl_exchange_end(void *user) {
 int rccl_exchange(void *user) {
   if (rccl_exchange_begin(user) != 0) return 1;
   return rccl_exchange_end(user);
+}
+int loopback_exchange(void *user) {
+  if (loopback_exchange_begin(user) != 0) return 1;
+  return rccl_exchange_end(user);
+}
+// (one rank: a reduction over the ranks is the identity)
+int loopback_allreduce(void *user, double *, int) {
+  static_cast<apk_sim *>(user)->rccl->reductions += 1;
+  return 0;
 }
 
 // vals live on the host (the driver has synchronised its stream to read them): stage them through
@@ -195,6 +232,28 @@ void rccl_transport_destroy(RcclTransport *t) {
   if (t->d_red) (void)hipFree(t->d_red);
   if (t->h_red) (void)hipHostFree(t->h_red);
   delete t;
+}
+
+int comm_loopback_attach(apk_sim *s) {
+  if (!s || s->rccl || s->have_comm) return fail(s, APK_ERR_INVALID, "loopback transport: the sim has a transport already");
+  RcclTransport *t = new RcclTransport();
+  const bool ok = hip_ok(t, hipStreamCreateWithFlags(&t->s_halo, hipStreamNonBlocking), "hipStreamCreate") &&
+                  hip_ok(t, hipEventCreateWithFlags(&t->ev_ready, hipEventDisableTiming), "hipEventCreate") &&
+                  hip_ok(t, hipEventCreateWithFlags(&t->ev_done, hipEventDisableTiming), "hipEventCreate");
+  if (!ok) {
+    const std::string why = t->err;
+    rccl_transport_destroy(t);
+    return fail(s, APK_ERR_DEVICE, "loopback transport: " + why);
+  }
+  s->rccl = t;
+  s->comm.user = s;
+  s->comm.exchange = loopback_exchange;
+  s->comm.exchange_begin = loopback_exchange_begin;
+  s->comm.exchange_end = rccl_exchange_end;
+  s->comm.allreduce_min = loopback_allreduce;
+  s->comm.allreduce_sum = loopback_allreduce;
+  s->have_comm = true;
+  return APK_OK;
 }
 
 RcclTransport *rccl_transport_create(const char *ids, int rank, int nranks, std::string *why) {

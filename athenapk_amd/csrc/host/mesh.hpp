@@ -41,6 +41,13 @@ struct Mesh {
   int nx[3] = {1, 1, 1}, mb[3] = {1, 1, 1}, ng = 2, nvar = 5;
   int bc_in[3] = {0, 0, 0}, bc_out[3] = {0, 0, 0};
   int rank = 0, nranks = 1;
+  // One-GPU rehearsal of a rank of the 2 x 2 x 2 run (apk_amd/rehearse_remote_faces): a neighbour reached across the
+  // periodic boundary of the mesh counts as a block of ANOTHER rank -- pseudo rank nranks + (wrap code), one per
+  // combination of wrapped directions: the 7 peers (3 faces, 3 edges, 1 corner) a brick has in the 2 x 2 x 2 rank
+  // grid -- so that its ghost zones travel through pack -> message -> unpack like those between bricks.  The
+  // messages are delivered by the loopback transport (comm_rccl.cpp): with the sender's and the receiver's
+  // segment lists ordered by the same key, a rank's own send buffer IS the message its periodic image would send.
+  int rehearse = 0;
   // derived
   int nb[3] = {1, 1, 1}, nblocks_total = 1, ndim = 1;
   int ni = 1, nj = 1, nk = 1, is = 0, ie = 0, js = 0, je = 0, ks = 0, ke = 0;
@@ -80,6 +87,7 @@ struct Mesh {
     ndim = Active(2) ? 3 : (Active(1) ? 2 : 1);
     nblocks_total = nb[0] * nb[1] * nb[2];
     if (nranks < 1 || rank < 0 || rank >= nranks) throw std::runtime_error("bad rank / nranks");
+    if (rehearse && nranks != 1) throw std::runtime_error("apk_amd/rehearse_remote_faces is a one-rank rehearsal");
     if (nblocks_total < nranks) throw std::runtime_error("fewer meshblocks than ranks");
     ni = mb[0] + 2 * ng;
     nj = Active(1) ? mb[1] + 2 * ng : 1;
@@ -132,6 +140,17 @@ struct Mesh {
     return true;
   }
 
+  // rank that owns the neighbour of block bc at offset o (Neighbor(bc, o, nbc) was true)
+  int NeighborRank(const int bc[3], const int o[3], const int nbc[3]) const {
+    if (rehearse) {
+      int wrap = 0;
+      for (int d = 0; d < 3; ++d)
+        if (bc[d] + o[d] < 0 || bc[d] + o[d] >= nb[d]) wrap |= 1 << d;
+      if (wrap) return nranks + wrap - 1;
+    }
+    return gid_rank[Gid(nbc)];
+  }
+
   // are the ghost zones of local block lb on side (-1 / +1) of direction d filled only when the
   // exchange completes (neighbour on another rank, or a physical boundary condition) rather than
   // by a same-rank copy?
@@ -141,7 +160,7 @@ struct Mesh {
     Loc(local_gids[lb], bc);
     o[d] = side;
     if (!Neighbor(bc, o, nbc)) return true;  // physical boundary: applied after the unpack
-    return gid_rank[Gid(nbc)] != rank;
+    return NeighborRank(bc, o, nbc) != rank;
   }
 
   // index range [lo,hi] along dim d of the receiver's ghost region (dst) and of the
@@ -194,7 +213,8 @@ struct Mesh {
             const int code = (oz + 1) * 9 + (oy + 1) * 3 + (ox + 1);
             const int mo[3] = {-ox, -oy, -oz};
             const int mcode = (mo[2] + 1) * 9 + (mo[1] + 1) * 3 + (mo[0] + 1);
-            if (gid_rank[ngid] == rank) {
+            const int owner = NeighborRank(bc, o, nbc);
+            if (owner == rank) {
               // same-rank neighbour: direct box copy into my ghost region
               BoxRegion r;
               r.src_kind = RK_BLOCK;
@@ -215,7 +235,7 @@ struct Mesh {
               }
               plan[PH_LOCAL].push_back(r);
             } else {
-              const int peer = gid_rank[ngid];
+              const int peer = owner;
               // I receive my ghost region at offset o from block ngid ...
               recvs[peer].push_back({(int64_t)local_gids[lb] * 27 + code, lb, {ox, oy, oz}});
               // ... and block ngid receives, at its offset -o, a strip of my interior

@@ -145,6 +145,9 @@ void mesh_initialize(apk_sim *s) {
   m.nvar = s->pkg.nhydro + s->pkg.nscalars;
   m.rank = s->rank;
   m.nranks = s->nranks;
+  // (not a reference parameter: the one-GPU rehearsal of a rank of the 2 x 2 x 2 run, mesh.hpp "rehearse")
+  m.rehearse = pin.GetOrAddBoolean("apk_amd", "rehearse_remote_faces", false) ? 1 : 0;
+  if (m.rehearse && refinement != "none") throw std::runtime_error("apk_amd/rehearse_remote_faces needs a uniform mesh");
   m.Build();
   s->nper = m.sn * m.nvar;
   if (refinement != "none") amr_initialize(s, refinement == "adaptive");
@@ -586,7 +589,7 @@ int build_windows(apk_sim *s) {
           if (!sx && !sy && !sz) continue;
           if ((sx && !m.Active(0)) || (sy && !m.Active(1)) || (sz && !m.Active(2))) continue;
           const int o[3] = {sx, sy, sz};
-          const bool is_late = s->copy_stream != nullptr || !m.Neighbor(bc, o, nbc) || m.gid_rank[m.Gid(nbc)] != m.rank;
+          const bool is_late = s->copy_stream != nullptr || !m.Neighbor(bc, o, nbc) || m.NeighborRank(bc, o, nbc) != m.rank;
           if (is_late) late[lb] |= 1u << ((sx + 1) + 3 * (sy + 1) + 9 * (sz + 1));
         }
   }
@@ -622,7 +625,7 @@ int build_face_table(apk_sim *s) {
         o[d] = side ? 1 : -1;
         if (!m.Active(d) || !m.Neighbor(bc, o, nbc)) continue;
         const int ngid = m.Gid(nbc);
-        if (m.gid_rank[ngid] == m.rank) tab[6 * (size_t)lb + 2 * d + side] = m.gid_local.at(ngid);
+        if (m.NeighborRank(bc, o, nbc) == m.rank) tab[6 * (size_t)lb + 2 * d + side] = m.gid_local.at(ngid);
       }
   }
   double *p = nullptr;
@@ -1102,6 +1105,10 @@ int apk_sim_create(const char *deck, const char *const *overrides, int noverride
     s->err = "nranks > 1 requires comm ops";
     return bail(APK_ERR_INVALID);
   }
+  if (s->mesh.rehearse && comm) {
+    s->err = "apk_amd/rehearse_remote_faces brings its own (loopback) transport";
+    return bail(APK_ERR_INVALID);
+  }
   rc = apk_create(&s->ctx);
   if (rc != APK_OK) {
     s->err = "apk_create failed: no usable gfx950 device (there is no CPU fallback)";
@@ -1157,6 +1164,7 @@ int apk_sim_create(const char *deck, const char *const *overrides, int noverride
       }
     }
   }
+  if (s->mesh.rehearse && (rc = comm_loopback_attach(s)) != APK_OK) return bail(rc);
   if ((s->copy_stream || !s->mesh.peers.empty()) && (rc = build_windows(s)) != APK_OK) return bail(rc);
   if (s->mesh.ndim == 3 && (rc = build_face_table(s)) != APK_OK) return bail(rc);
   if (s->fmft && (rc = turbulence_device_setup(s)) != APK_OK) return bail(rc);

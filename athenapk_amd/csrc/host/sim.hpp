@@ -69,6 +69,9 @@ namespace apk {
 namespace host {
 struct RcclTransport;  // comm_rccl.cpp
 void rccl_transport_destroy(RcclTransport *t);
+// one-GPU rehearsal (mesh.hpp "rehearse"): the transport's streams and events without RCCL, every peer's message
+// delivered by a device copy on the halo stream from this rank's own send buffer
+int comm_loopback_attach(apk_sim *s);
 }  // namespace host
 }  // namespace apk
 

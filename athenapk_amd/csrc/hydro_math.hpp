@@ -71,6 +71,8 @@ APK_DEV double to_sgpr(double x) {
 #if defined(APK_FP_STRICT) || defined(APK_NO_FAST_SQRT)
 #define APK_PLAIN_SQRT 1
 APK_DEV double fsqrt(double x) { return sqrt(x); }
+APK_DEV double fsqrt_pos(double x) { return sqrt(x); }
+APK_DEV double fsqrt_nonneg(double x) { return sqrt(x); }
 APK_DEV double frcp(double x) { return 1.0 / x; }
 #else
 // v_rsq_f64 / v_rcp_f64 deliver 24 good bits (measured on gfx950 over 1e-12 .. 1e12, tools/ubench/ubench_lat.hip:
@@ -117,6 +119,24 @@ APK_DEV double fsqrt(double x) {
   }
   return (x == 0.0) ? 0.0 : g;  // rsq(0) = inf
 }
+// fsqrt without the `x == 0 ? 0 : ...` guard (a compare and two selects): for arguments that are positive whenever the
+// state is valid (a squared speed).  fsqrt_nonneg clamps an argument that may be exactly zero -- a sum of squares --
+// at 1e-300 instead (one v_max_f64): sqrt(0) comes out as 1e-150, far below anything it is added to.
+APK_DEV double fsqrt_pos(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  if constexpr (APK_NEWTON_EXTRA != 0) {
+    d = fma(-g, g, x);
+    g = fma(d, h, g);
+  }
+  return g;
+}
+APK_DEV double fsqrt_nonneg(double x) { return fsqrt_pos(fmax(x, 1.0e-300)); }
 APK_DEV double frcp(double x) {
   double y = __builtin_amdgcn_rcp(x);
   double e = fma(-x, y, 1.0);
@@ -147,13 +167,51 @@ APK_DEV double max2(double a, double b) { return (a < b) ? b : a; }  // std::max
 APK_DEV double min2(double a, double b) { return fmin(a, b); }
 APK_DEV double max2(double a, double b) { return fmax(a, b); }
 #endif
+// max(|a|, |b|) / max(a, |b|) of values that come straight out of memory, LDS or a DPP move.  fmax on such operands
+// makes the compiler canonicalise each of them first (v_max_f64 x, x, x: IEEE mode must quiet a signalling NaN it cannot
+// rule out) -- five extra instructions in PPM's extremum limiter, whose scale is a maximum over the five stencil cells.
+// v_max_f64 itself quiets its operands in IEEE mode, so the product build issues the instruction directly.
+#if defined(APK_FP_STRICT) || defined(APK_NO_ASM_MINMAX)  // (A/B)
+APK_DEV double max_abs2(double a, double b) { return max2(fabs(a), fabs(b)); }
+APK_DEV double max_with_abs(double a, double b) { return max2(a, fabs(b)); }
+APK_DEV double max_plain(double a, double b) { return max2(a, b); }
+#else
+APK_DEV double max_abs2(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+APK_DEV double max_with_abs(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+APK_DEV double max_plain(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+#endif
+// An opaque copy of x (no instruction): expressions built on it are not recognised as equal to expressions built on x,
+// which keeps the compiler from hoisting code that two rarely taken branches share in front of both of them.
+APK_DEV double opaque(double x) {
+#ifndef APK_NO_OPAQUE  // (A/B)
+  asm("" : "+v"(x));
+#endif
+  return x;
+}
 // Parthenon SIGN(x) = (x < 0) ? -1 : 1 ; carried as a bool "is negative"
 APK_DEV bool neg(double x) { return x < 0.0; }
 // x > 0 with NaN -> false, decided on the bit pattern so that no fast-math assumption a build may
 // be given can fold the NaN case away: a blown-up state must still be flagged
 APK_DEV bool strictly_positive(double x) {
+#ifdef APK_NO_CLASS_TEST  // (A/B: two 64-bit integer compares)
   const long long b = __double_as_longlong(x);
   return b > 0 && b <= 0x7ff0000000000000LL;
+#else
+  // one v_cmp_class_f64: +denormal | +normal | +infinity (bits 7, 8, 9 of the class mask)
+  return __builtin_amdgcn_class(x, 0x380);
+#endif
 }
 APK_DEV double with_sign(bool negative, double mag) { return negative ? -mag : mag; }
 
@@ -239,18 +297,22 @@ APK_DEV void ppm_cell(double qm2, double qm1, double q0, double qp1, double qp2,
   if (ext_a <= 0.0 || ext_b <= 0.0) {
     // local extremum: CS limiter on the parabola (steps 4 of ppm_simple.hpp:104-150).  The second
     // differences and the limited ratio are only consumed here, so they are only computed here.
-    const double d2_m = qm2 + q0 - 2.0 * qm1;
-    const double d2_c = qm1 + qp1 - 2.0 * q0;
-    const double d2_p = q0 + qp2 - 2.0 * qp1;
-    const double d2_face = 6.0 * (face_m + face_p - 2.0 * q0);
+    // (d2_c and d2_p are also what ppm_interface's extremum branch computes for the interface above this cell: left
+    // alone, the compiler evaluates them in front of BOTH branches, i.e. in every lane of every pencil -- 4 full-width
+    // instructions per variable and direction to save 4 few-lane ones where both limiters engage)
+    const double q0x = opaque(q0), qp1x = opaque(qp1);
+    const double d2_m = qm2 + q0x - 2.0 * qm1;
+    const double d2_c = qm1 + qp1x - 2.0 * q0x;
+    const double d2_p = q0x + qp2 - 2.0 * qp1x;
+    const double d2_face = 6.0 * (face_m + face_p - 2.0 * q0x);
     const bool s = neg(d2_m);
     const bool agree = (s == neg(d2_c)) && (s == neg(d2_p)) && (s == neg(d2_face));
     const double mag = min2(min2(C2 * fabs(d2_m), C2 * fabs(d2_c)), min2(C2 * fabs(d2_p), fabs(d2_face)));
     const double d2lim = agree ? with_sign(neg(d2_face), mag) : 0.0;
-    const double scale_lo = max2(fabs(qm1), fabs(qm2));
-    const double scale_hi = max2(max2(fabs(q0), fabs(qp1)), fabs(qp2));
+    const double scale_lo = max_abs2(qm1, qm2);
+    const double scale_hi = max_with_abs(max_abs2(q0, qp1), qp2);
     double ratio = 0.0;
-    if (fabs(d2_face) > (1.0e-12) * max2(scale_lo, scale_hi)) ratio = d2lim / d2_face;
+    if (fabs(d2_face) > (1.0e-12) * max_plain(scale_lo, scale_hi)) ratio = d2lim / d2_face;
     if (ratio <= (1.0 - (1.0e-12))) {
       r = q0 - ratio * dminus;
       l = q0 + ratio * dplus;
@@ -401,7 +463,13 @@ APK_DEV double fast_speed(double gamma, double d, double p, double bx, double by
   // 1e-8 of the solver's degeneracy threshold.  sqrt(x / d) = x rsqrt(x d) saves a divide per call
   // and agrees to 6e-16, but moved the 256^3 benchmark state by 1e-10 per cycle against the parity
   // build along the planes where By and Bz change sign.)
+  // (the inner argument is a sum of squares -- zero only where Bx^2 = gamma p and By = Bz = 0 exactly --, the outer
+  // one a squared speed, positive whenever rho and p are: the product build drops fsqrt's zero guards, see fsqrt_pos)
+#ifdef APK_SQRT_GUARDS  // (A/B)
   return fsqrt(0.5 * (qsq + fsqrt(tmp * tmp + 4.0 * asq * ct2)) / d);
+#else
+  return fsqrt_pos(0.5 * (qsq + fsqrt_nonneg(tmp * tmp + 4.0 * asq * ct2)) / d);
+#endif
 }
 
 // ======================================================================================
@@ -707,10 +775,20 @@ APK_DEV void hlld_star_transverse(const double (&w)[NGLMMHD], const Cons1D &u, d
   const double t2 = (u.d * sqr(sd) - bxsq) * inv;
 #endif
   const bool degenerate = fabs(denom) < (kHlldSmall)*ptst;
+#if defined(APK_FP_STRICT) || defined(APK_HLLD_SELECT_OUTPUTS)  // (A/B)
   ust.my = degenerate ? ust.d * w[IV2] : ust.d * (w[IV2] - u.by * t1);
   ust.mz = degenerate ? ust.d * w[IV3] : ust.d * (w[IV3] - u.bz * t1);
   ust.by = degenerate ? u.by : u.by * t2;
   ust.bz = degenerate ? u.bz : u.bz * t2;
+#else
+  // the degenerate case selected on the two factors instead of on the four results (w - B * 0 = w and B * 1 = B to
+  // the bit for finite B): 4 selects instead of 8
+  const double t1s = degenerate ? 0.0 : t1, t2s = degenerate ? 1.0 : t2;
+  ust.my = ust.d * (w[IV2] - u.by * t1s);
+  ust.mz = ust.d * (w[IV3] - u.bz * t1s);
+  ust.by = u.by * t2s;
+  ust.bz = u.bz * t2s;
+#endif
 }
 // a <- s * (a - b)  (:297-327)
 APK_DEV void hlld_jump(Cons1D &a, const Cons1D &b, double s) {
@@ -887,7 +965,11 @@ APK_DEV void glmmhd_hlld_core(const double (&wl)[NGLMMHD], const double (&wr)[NG
   Cons1D udst = ust;
   if (wave_any(with_dstar)) {
     const bool dst_degenerate = 0.5 * bxsq < (kHlldSmall)*ptst;
+#ifdef APK_PLAIN_SQRT
     const double invsumd = 1.0 / (sqrtdl + sqrtdr);
+#else
+    const double invsumd = frcp(sqrtdl + sqrtdr);
+#endif
     const double bxsig = (bxi > 0.0 ? 1.0 : -1.0);
     const double tmy = invsumd * (sqrtdl * (ulst.my * ulst_d_inv) + sqrtdr * (urst.my * urst_d_inv) +
                                   bxsig * (urst.by - ulst.by));
@@ -918,6 +1000,7 @@ APK_DEV void glmmhd_hlld_core(const double (&wl)[NGLMMHD], const double (&wr)[NG
 
   hlld_jump(udst, ust, s_inner);  // double-star before star: the star state is overwritten next
   hlld_jump(ust, u, s_outer);
+#ifdef APK_HLLD_SELECT_SUMS  // (A/B: round 3's form, two selects per component on the three candidate sums)
 #define APK_HLLD_SUM(c) (outer ? fx.c : (with_dstar ? (fx.c + ust.c + udst.c) : (fx.c + ust.c)))
   f[IDN] = APK_HLLD_SUM(d);
   f[IV1] = APK_HLLD_SUM(mx);
@@ -927,6 +1010,40 @@ APK_DEV void glmmhd_hlld_core(const double (&wl)[NGLMMHD], const double (&wr)[NG
   f[IB2] = APK_HLLD_SUM(by);
   f[IB3] = APK_HLLD_SUM(bz);
 #undef APK_HLLD_SUM
+#else
+  // F, F + j_outer or (F + j_outer) + j_inner: the additions run under the lanes' execution mask instead of selecting
+  // among three sums afterwards -- 14 masked v_add_f64 and a few scalar instructions instead of 14 additions + 28
+  // v_cndmask_b32.  (The empty volatile asm statements keep the compiler from turning the branches back into
+  // selects; the association (F + j_outer) + j_inner is the reference's, glmmhd_hlld.hpp:340-383.)
+  Cons1D fl = fx;
+  if (!outer) {
+    asm volatile("" ::: );
+    fl.d += ust.d;
+    fl.mx += ust.mx;
+    fl.my += ust.my;
+    fl.mz += ust.mz;
+    fl.e += ust.e;
+    fl.by += ust.by;
+    fl.bz += ust.bz;
+    if (with_dstar) {
+      asm volatile("" ::: );
+      fl.d += udst.d;
+      fl.mx += udst.mx;
+      fl.my += udst.my;
+      fl.mz += udst.mz;
+      fl.e += udst.e;
+      fl.by += udst.by;
+      fl.bz += udst.bz;
+    }
+  }
+  f[IDN] = fl.d;
+  f[IV1] = fl.mx;
+  f[IV2] = fl.my;
+  f[IV3] = fl.mz;
+  f[IEN] = fl.e;
+  f[IB2] = fl.by;
+  f[IB3] = fl.bz;
+#endif
 }
 
 // src/hydro/rsolvers/glmmhd_dc_llf.hpp:46-179
@@ -1022,9 +1139,16 @@ constexpr int perm(int slot) {
 // cons -> prim for one cell (src/eos/adiabatic_hydro.hpp:52-142, adiabatic_glmmhd.hpp:62-167)
 // u/w hold the NH hydro/MHD variables; returns APK_FLAG_* bits.  u may be modified.
 // ======================================================================================
-template <int FLUID>
+// LEAN: the caller guarantees eos.vceil = eos.eceil = +inf and eos.pfloor <= 0 (eos_is_lean: the defaults of
+// hydro.cpp:507-537, no velocity ceiling, no pressure floor, no internal-energy ceiling), so the three blocks those
+// parameters guard can never act and are not compiled: same results, no registers for their constants, and `u` is
+// only ever modified by the density floor and the internal-energy floor.
+template <int FLUID, bool LEAN = false>
 APK_DEV unsigned cons_to_prim_core(const apk_eos &eos, double gm1, double vceil_sq, double pfloor_over_gm1,
                                    double (&u)[nvars<FLUID>()], double (&w)[nvars<FLUID>()], double &di_out);
+inline __host__ __device__ bool eos_is_lean(const apk_eos &eos) {
+  return eos.vceil == __builtin_inf() && eos.eceil == __builtin_inf() && eos.pfloor <= 0.0;
+}
 template <int FLUID>
 APK_DEV unsigned cons_to_prim_cell(const apk_eos &eos, double (&u)[nvars<FLUID>()],
                                    double (&w)[nvars<FLUID>()], double &di_out) {
@@ -1032,16 +1156,16 @@ APK_DEV unsigned cons_to_prim_cell(const apk_eos &eos, double (&u)[nvars<FLUID>(
   return cons_to_prim_core<FLUID>(eos, gm1, sqr(eos.vceil), eos.pfloor / gm1, u, w, di_out);
 }
 // with the stage's constants from the host (StageConsts)
-template <int FLUID>
+template <int FLUID, bool LEAN = false>
 APK_DEV unsigned cons_to_prim_cell(const apk_eos &eos, const StageConsts &k, double (&u)[nvars<FLUID>()],
                                    double (&w)[nvars<FLUID>()], double &di_out) {
 #ifdef APK_NO_STAGE_CONSTS
   return cons_to_prim_cell<FLUID>(eos, u, w, di_out);
 #else
-  return cons_to_prim_core<FLUID>(eos, k.eos_gm1, k.vceil_sq, k.pfloor_over_gm1, u, w, di_out);
+  return cons_to_prim_core<FLUID, LEAN>(eos, k.eos_gm1, k.vceil_sq, k.pfloor_over_gm1, u, w, di_out);
 #endif
 }
-template <int FLUID>
+template <int FLUID, bool LEAN>
 APK_DEV unsigned cons_to_prim_core(const apk_eos &eos, double gm1, double vceil_sq, double pfloor_over_gm1,
                                    double (&u)[nvars<FLUID>()], double (&w)[nvars<FLUID>()], double &di_out) {
   constexpr bool mhd = (FLUID == APK_FLUID_GLMMHD);
@@ -1049,7 +1173,11 @@ APK_DEV unsigned cons_to_prim_core(const apk_eos &eos, double gm1, double vceil_
   if (!(strictly_positive(u[IDN]) || eos.dfloor > 0.0)) flags |= APK_FLAG_NEG_DENSITY;
   u[IDN] = (u[IDN] > eos.dfloor) ? u[IDN] : eos.dfloor;
   w[IDN] = u[IDN];
+#ifdef APK_PLAIN_SQRT
   const double di = 1.0 / u[IDN];
+#else
+  const double di = frcp(u[IDN]);  // (the compiler's own reciprocal-math quotient takes one Newton step more)
+#endif
   di_out = di;
   w[IV1] = u[IM1] * di;
   w[IV2] = u[IM2] * di;
@@ -1066,6 +1194,7 @@ APK_DEV unsigned cons_to_prim_core(const apk_eos &eos, double gm1, double vceil_
   } else {
     w[IPR] = gm1 * (u[IEN] - e_k);
   }
+  if constexpr (!LEAN) {
   const double v2 = sqr(w[IV1]) + sqr(w[IV2]) + sqr(w[IV3]);
   if (v2 > vceil_sq) {
     const double v = sqrt(v2);
@@ -1079,11 +1208,16 @@ APK_DEV unsigned cons_to_prim_core(const apk_eos &eos, double gm1, double vceil_
     u[IEN] -= e_k - e_k_new;
     e_k = e_k_new;
   }
-  if (!(strictly_positive(w[IPR]) || eos.pfloor > 0.0 || eos.efloor > 0.0)) flags |= APK_FLAG_NEG_PRESSURE;
-  if ((eos.pfloor > 0.0) && (w[IPR] < eos.pfloor)) {
-    if constexpr (mhd) u[IEN] = pfloor_over_gm1 + e_k + e_B;
-    else u[IEN] = pfloor_over_gm1 + e_k;
-    w[IPR] = eos.pfloor;
+  }
+  if constexpr (LEAN) {
+    if (!(strictly_positive(w[IPR]) || eos.efloor > 0.0)) flags |= APK_FLAG_NEG_PRESSURE;
+  } else {
+    if (!(strictly_positive(w[IPR]) || eos.pfloor > 0.0 || eos.efloor > 0.0)) flags |= APK_FLAG_NEG_PRESSURE;
+    if ((eos.pfloor > 0.0) && (w[IPR] < eos.pfloor)) {
+      if constexpr (mhd) u[IEN] = pfloor_over_gm1 + e_k + e_B;
+      else u[IEN] = pfloor_over_gm1 + e_k;
+      w[IPR] = eos.pfloor;
+    }
   }
   const double eff_floor = gm1 * u[IDN] * eos.efloor;
   if (w[IPR] < eff_floor) {
@@ -1091,13 +1225,66 @@ APK_DEV unsigned cons_to_prim_core(const apk_eos &eos, double gm1, double vceil_
     else u[IEN] = (u[IDN] * eos.efloor) + e_k;
     w[IPR] = eff_floor;
   }
-  const double eff_ceil = gm1 * u[IDN] * eos.eceil;
-  if (w[IPR] > eff_ceil) {
-    if constexpr (mhd) u[IEN] = (u[IDN] * eos.eceil) + e_k + e_B;
-    else u[IEN] = (u[IDN] * eos.eceil) + e_k;
-    w[IPR] = eff_ceil;
+  if constexpr (!LEAN) {
+    const double eff_ceil = gm1 * u[IDN] * eos.eceil;
+    if (w[IPR] > eff_ceil) {
+      if constexpr (mhd) u[IEN] = (u[IDN] * eos.eceil) + e_k + e_B;
+      else u[IEN] = (u[IDN] * eos.eceil) + e_k;
+      w[IPR] = eff_ceil;
+    }
   }
   return flags;
+}
+
+// ======================================================================================
+// EstimateHyperbolicTimestep of one cell (src/hydro/hydro.cpp:845-895): min over the active directions of
+// dx_d / (|v_d| + c_d), c_d the sound speed / the fast speed along d.  `di` = 1 / w[IDN] as ConsToPrim left it.
+// The parity build evaluates the reference's expressions (three independent fast speeds).  In the product build the
+// three fast speeds share what does not depend on the direction -- gamma p, |B|^2, the sum and the difference of the
+// two, their square, and the reciprocal of the density ConsToPrim already has: 2 roots + 5 operations per direction
+// instead of 2 roots + a divide + 12 -- and the quotients dx / s multiply by a Newton reciprocal (fdiv).  The result
+// agrees with the parity build's to a few ulp (a time step: every cell of the mesh sees the same dt).
+// ======================================================================================
+template <int FLUID>
+APK_DEV double cell_dt_hyp(double gamma, const double (&w)[nvars<FLUID>()], double di, int ndim, double dx0, double dx1,
+                           double dx2) {
+#if defined(APK_FP_STRICT) || defined(APK_NO_FAST_DT)  // (A/B)
+  double lx, ly = 0.0, lz = 0.0;
+  if constexpr (FLUID == APK_FLUID_EULER) {
+    lx = sound_speed(gamma, w[IDN], w[IPR]);
+    ly = lx;
+    lz = lx;
+  } else {
+    lx = fast_speed(gamma, w[IDN], w[IPR], w[IB1], w[IB2], w[IB3]);
+    if (ndim > 1) ly = fast_speed(gamma, w[IDN], w[IPR], w[IB2], w[IB3], w[IB1]);
+    if (ndim > 2) lz = fast_speed(gamma, w[IDN], w[IPR], w[IB3], w[IB1], w[IB2]);
+  }
+  double m = dx0 / (fabs(w[IV1]) + lx);
+  if (ndim > 1) m = fmin(m, dx1 / (fabs(w[IV2]) + ly));
+  if (ndim > 2) m = fmin(m, dx2 / (fabs(w[IV3]) + lz));
+  return m;
+#else
+  const double asq = gamma * w[IPR];
+  if constexpr (FLUID == APK_FLUID_EULER) {
+    const double cs = fsqrt(asq * di);
+    double m = fdiv(dx0, fabs(w[IV1]) + cs);
+    if (ndim > 1) m = fmin(m, fdiv(dx1, fabs(w[IV2]) + cs));
+    if (ndim > 2) m = fmin(m, fdiv(dx2, fabs(w[IV3]) + cs));
+    return m;
+  } else {
+    const double bsq = w[IB1] * w[IB1] + (w[IB2] * w[IB2] + w[IB3] * w[IB3]);
+    const double qsq = bsq + asq, dif = bsq - asq;
+    const double dif2 = dif * dif, a4 = 4.0 * asq, hdi = 0.5 * di;
+    // c_f^2 = (q + sqrt(dif^2 + 4 a^2 (|B|^2 - B_d^2))) / (2 rho); the transverse field energy is clamped at zero
+    // (|B|^2 - B_d^2 may round to -1 ulp of |B|^2 when the field is along d, which would put a negative number under
+    // the root where dif = 0)
+    auto cf = [&](double bn) { return fsqrt((qsq + fsqrt(fma(a4, fmax(fma(-bn, bn, bsq), 0.0), dif2))) * hdi); };
+    double m = fdiv(dx0, fabs(w[IV1]) + cf(w[IB1]));
+    if (ndim > 1) m = fmin(m, fdiv(dx1, fabs(w[IV2]) + cf(w[IB2])));
+    if (ndim > 2) m = fmin(m, fdiv(dx2, fabs(w[IV3]) + cf(w[IB3])));
+    return m;
+  }
+#endif
 }
 
 }  // namespace apk

@@ -170,6 +170,15 @@ class _MeshView:
         self.lib.apk_sim_amr_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
         return a.value, b.value, c.value, d.value
 
+    def peers(self):
+        """[(peer rank, doubles sent, doubles received)] of this rank's halo exchange"""
+        out = []
+        for p in range(self.info.npeers):
+            pi = L.PeerInfo()
+            self.lib.apk_sim_peer(self.h, p, C.byref(pi))
+            out.append((pi.rank, pi.send_count, pi.recv_count))
+        return out
+
     def refresh_info(self):
         self.lib.apk_sim_get_info(self.h, C.byref(self.info))
         return self.info
@@ -580,14 +589,6 @@ class HostPlan(_FmftHost, _MeshView):
                 self.h = None
         except Exception:
             pass
-
-    def peers(self):
-        out = []
-        for p in range(self.info.npeers):
-            pi = L.PeerInfo()
-            self.lib.apk_sim_peer(self.h, p, C.byref(pi))
-            out.append((pi.rank, pi.send_count, pi.recv_count))
-        return out
 
     def apply_tags(self, tags):
         """host logic of one regridding pass (forest, distribution, plans) for per-block tags"""

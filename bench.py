@@ -104,7 +104,7 @@ def cpu_baseline(fluid, integrator, recon, riemann, target_s=10.0):
                       "serial_value: 1 thread on 64^3" % (cycles, n, mb, best_t, cands, cores, dt)}
 
 
-def amr_blast_bench(cycles=40):
+def amr_blast_bench(cycles=40, variants=("hydro_plm_hlle_vl2", "mhd_ppm_hlld_vl2")):
     """BASELINE config 5's shape (inputs/blast_3d_amr.in with root 64^3 in 16^3 meshblocks, 4 levels,
     regridding every cycle) for the hydro deck as it is and for GLM-MHD PPM+HLLD on the deck's own blast
     (near-vacuum ambient medium, pressure ratio 1.6e8, no first-order flux correction: the deck has none and
@@ -119,6 +119,8 @@ def amr_blast_bench(cycles=40):
     for name, extra in (("hydro_plm_hlle_vl2", []),
                         ("mhd_ppm_hlld_vl2", ["hydro/fluid=glmmhd", "hydro/riemann=hlld", "hydro/reconstruction=ppm",
                                               "parthenon/mesh/nghost=4"])):
+        if name not in variants:
+            continue
         s = driver.Simulation(decks.load("blast_3d_amr"), ov + extra).initialize()
         for _ in range(3):
             s.step()
@@ -193,10 +195,149 @@ def general_stage_bench(recon="ppm", riemann="hlld", nb=8, n=128, reps=5):
             "frac": gbs / HBM_PEAK_GBS, "frac_of_measured_copy_bandwidth": gbs / HBM_COPY_GBS}
 
 
-# rocprofv3 names of the kernels behind the driver's timing slots (3-D GLM-MHD PPM+HLLD two-kernel stage)
-ROCPROF_KERNEL = {"fused_x1": "fused_m12f_kernel<2, 3, 5, 2> / <2, 3, 5, 0> (x1 + x2 finishing march)",
-                  "fused_x3": "fused_march_kernel<2, 3, 5, 3, false, 0> (x3 sweep)",
-                  "fused_dc_x1": "fused_dc3_kernel<2, 5, 1> (donor-cell predictor stage)"}
+# rocprofv3 names of the kernels behind the driver's timing slots (3-D two-kernel stage; template arguments are
+# <fluid, recon, riemann, extra, lean> with the enum values of include/apk_amd.h)
+_FLUID_ID = {"euler": 1, "glmmhd": 2}
+_RECON_ID = {"dc": 1, "plm": 2, "ppm": 3, "wenoz": 4, "weno3": 5, "limo3": 6}
+_RIEMANN_ID = {"hlle": 2, "llf": 3, "hllc": 4, "hlld": 5}
+
+
+def rocprof_kernels(fluid, recon, riemann):
+    f, r, s = _FLUID_ID[fluid], _RECON_ID[recon], _RIEMANN_ID[riemann]
+    return {"fused_x1": "fused_m12f_kernel<%d, %d, %d, 2, true> / <%d, %d, %d, 0, true> (x1 + x2 finishing march; "
+                        "last stage of a cycle with ConsToPrim + dt / other stages)" % (f, r, s, f, r, s),
+            "fused_x3": "fused_march_kernel<%d, %d, %d, 3, false, 0> (x3 sweep)" % (f, r, s),
+            "fused_dc_x1": "fused_dc3_kernel<%d, %d, 1, true> (donor-cell predictor stage)" % (f, s)}
+
+
+ROCPROF_KERNEL = rocprof_kernels("glmmhd", "ppm", "hlld")
+
+
+def stage_figures(timing, fluid, integrator, zones_local, ndim=3):
+    """per-kernel averages and the high-order stage's roofline figures from the driver's HIP-event timing slots"""
+    per_kernel = {k: (ms / n if n else 0.0) for k, (ms, n) in timing.items()}
+    fin = "fused_x3" if ndim == 3 else "fused_x2"
+    if timing[fin][1]:  # (with the exchange overlapped the first sweep of a stage is several launches)
+        per_kernel["fused_x1"] = timing["fused_x1"][0] / timing[fin][1]
+    stage_ms = per_kernel["fused_x1"] + per_kernel["fused_x2"] + per_kernel["fused_x3"]
+    ho = [g0 for n, g0 in enumerate(GAM0[integrator]) if not (integrator == "vl2" and n == 0)]
+    b_stage = sum(B_STAGE[fluid][0 if g0 == 0.0 else 1] for g0 in ho) / len(ho)
+    achieved = b_stage * zones_local / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
+    dominant = max(per_kernel, key=lambda k: timing[k][0])
+    return per_kernel, stage_ms, b_stage, achieved, dominant
+
+
+def other_workload(name, steps=4, warmup=2):
+    """One of the non-headline workloads of WORKLOADS on this GPU, a few cycles: rate, ms per cycle, the high-order
+    stage against the HBM roofline and the dominant kernel (the reference's own performance suite is a matrix of
+    schemes, tst/regression/test_suites/performance/performance.py:32-54)."""
+    import torch
+    from athenapk_amd import decks, driver
+    deck, fluid, integrator, recon, riemann, brick, mb, desc = WORKLOADS[name]
+    ov = ["parthenon/mesh/nx%d=%d" % (d + 1, brick) for d in range(3)] + ["parthenon/meshblock/nx%d=%d" % (d + 1, mb) for d in range(3)]
+    ov += ["parthenon/time/integrator=%s" % integrator, "hydro/reconstruction=%s" % recon, "hydro/riemann=%s" % riemann]
+    sim = driver.Simulation(decks.load(deck), ov, strict=False).initialize()
+    try:
+        for _ in range(warmup):
+            sim.step()
+        torch.cuda.synchronize()
+        sim.kernel_timing(True)
+        sim.read_kernel_timing()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sim.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        timing = sim.read_kernel_timing()
+        info = sim.info
+        per_kernel, stage_ms, b_stage, achieved, dominant = stage_figures(timing, fluid, integrator, int(info.zones_local), info.ndim)
+        return {"description": desc, "value": int(info.zones_total) * steps / dt, "unit": "cell-updates/s", "steps": steps,
+                "ms_per_step": dt / steps * 1e3, "high_order_stage_ms": stage_ms,
+                "dc_predictor_stage_ms": per_kernel["fused_dc_x1"] + per_kernel["fused_dc_x2"] + per_kernel["fused_dc_x3"],
+                "algorithmic_bytes_per_cell_stage": b_stage, "stage_achieved_GBps": achieved, "stage_frac": achieved / HBM_PEAK_GBS,
+                "dominant_timing_slot": dominant, "dominant_kernel": rocprof_kernels(fluid, recon, riemann).get(dominant, dominant),
+                "per_kernel_avg_ms": {k: v for k, v in per_kernel.items() if v > 0.0}}
+    finally:
+        sim.close()
+
+
+XGMI_LINK_GBS = 153.0  # one xGMI link per peer GPU (MI355X_MICROARCH.md: 7 links x ~153 GB/s per direction)
+
+
+def rehearsal_8gpu_rank(workload, n1_ms, steps=10, warmup=2):
+    """One-GPU rehearsal of ONE RANK of the 8-GPU run of `workload` (the driver runs the real curve; a one-GPU box
+    cannot): the same 256^3 brick with the three outer faces of every meshblock -- and the brick's edges and corner --
+    treated as faces to other ranks (deck parameter apk_amd/rehearse_remote_faces): pack kernel -> one message per
+    peer on the halo stream -> unpack + ghost ConsToPrim, overlapped with the next stage's plane windows exactly as
+    exchange_begin / exchange_end do between bricks (hydro_driver.cpp:506, 567-568).  The seven messages are delivered
+    by device copies on the halo stream (loopback transport, csrc/host/comm_rccl.cpp) instead of ncclSend / ncclRecv
+    over xGMI: everything but the wire is timed; the wire time is modelled next to it."""
+    import torch
+    from athenapk_amd import decks, driver
+    deck, fluid, integrator, recon, riemann, brick, mb, desc = WORKLOADS[workload]
+    ov = ["parthenon/mesh/nx%d=%d" % (d + 1, brick) for d in range(3)] + ["parthenon/meshblock/nx%d=%d" % (d + 1, mb) for d in range(3)]
+    ov += ["parthenon/time/integrator=%s" % integrator, "hydro/reconstruction=%s" % recon, "hydro/riemann=%s" % riemann,
+           "apk_amd/rehearse_remote_faces=true"]
+    out = {}
+    for label, overlap in (("overlapped", True), ("synchronous", False)):
+        sim = driver.Simulation(decks.load(deck), ov, strict=False)
+        sim.set_overlap(overlap)
+        sim.initialize()
+        try:
+            for _ in range(warmup):
+                sim.step()
+            torch.cuda.synchronize()
+            sim.kernel_timing(True)
+            sim.read_kernel_timing()
+            ov0, t0 = sim.overlapped_exchanges, time.perf_counter()
+            for _ in range(steps):
+                sim.step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            timing = sim.read_kernel_timing()
+            peers = sim.peers()
+            out[label] = {"ms_per_step": dt / steps * 1e3, "value": int(sim.info.zones_total) * steps / dt,
+                          "overlapped_exchanges_per_cycle": (sim.overlapped_exchanges - ov0) / steps,
+                          "pack_unpack_copy_kernels_ms_per_cycle": timing["copy_regions"][0] / steps}
+        finally:
+            sim.close()
+    nst = len(GAM0[integrator])
+    msg = sorted((8.0 * sc for _, sc, _ in peers), reverse=True)
+    wire_ms = msg[0] / (XGMI_LINK_GBS * 1e9) * 1e3  # the three face messages travel on three links at once
+    ms = out["overlapped"]["ms_per_step"]
+    out.update({
+        "what": "one rank of the 2 x 2 x 2 run rehearsed on one GPU: 7 peers (3 faces, 3 edges, 1 corner), messages delivered by "
+                "device copies on the halo stream (loopback) instead of xGMI; n1_ms_per_step is the plain N = 1 run of this line",
+        "n1_ms_per_step": n1_ms,
+        "exchanges_per_cycle": nst,
+        "message_MB_per_peer": [m / 1e6 for m in msg],
+        "exposed_exchange_ms_per_cycle": ms - n1_ms,
+        "exposed_exchange_ms_per_cycle_without_overlap": out["synchronous"]["ms_per_step"] - n1_ms,
+        "wire_ms_per_exchange_modelled": wire_ms,
+        "wire_model": "largest message / %.0f GB/s (one xGMI link per face peer, the three face messages on three links at once; "
+                      "edge and corner messages are 1 - 3 %% of a face's)" % XGMI_LINK_GBS,
+        # the loopback copies already occupy the halo stream for message_bytes / (HBM copy rate); the wire is slower:
+        # what a real link adds is hidden as long as it fits behind the stage's first kernel (DESIGN.md section 6)
+        "predicted_weak_scaling_efficiency_if_wire_hidden": n1_ms / ms,
+        "predicted_weak_scaling_efficiency_if_wire_fully_exposed": n1_ms / (ms + nst * wire_ms),
+    })
+    return out
+
+
+def other_workloads():
+    """BASELINE configs 2, 4 (its scheme, unforced) and 5 (its mesh) next to the headline: a few cycles each, after the
+    headline's timed region so that nothing perturbs it."""
+    out = {}
+    for name in ("hydro_plm_hllc_rk2_256", "mhd_wenoz_hlld_rk3_256"):
+        try:
+            out[name] = other_workload(name)
+        except Exception as e:  # supplementary figures; never lose the headline
+            out[name] = {"error": repr(e)}
+    try:
+        out["amr_blast_cfg5_mesh"] = amr_blast_bench(cycles=30, variants=("mhd_ppm_hlld_vl2",))
+    except Exception as e:
+        out["amr_blast_cfg5_mesh"] = {"error": repr(e)}
+    return out
 
 
 def _profile_commit(path):
@@ -218,6 +359,8 @@ def measured_traffic(workload):
         return None, None
     # round 2 / 3: the two-kernel stage (x3 sweep + finishing x1/x2 march); round 1: three sweeps
     for fname, stage, note in (
+            ("r04_hbm_traffic.json", ("fused_march_kernel<2, 3, 5, 3, false, 0>", "fused_m12f_kernel<2, 3, 5, 2, true>"),
+             "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, reads calibrated on the dt kernel's known bytes"),
             ("r03_hbm_traffic.json", ("fused_march_kernel<2, 3, 5, 3, false, 0>", "fused_m12f_kernel<2, 3, 5, 2>"),
              "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, reads calibrated on the dt kernel's known bytes"),
             ("r02_hbm_traffic.json", ("fused_march_kernel<2, 3, 5, 3, false, 0>", "fused_m12f_kernel<2, 3, 5, 2>"),
@@ -252,6 +395,10 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="use the flux-array path (for A/B)")
     ap.add_argument("--brick", type=int, default=0, help="cells per GPU and direction instead of the workload's 256 (tests)")
     ap.add_argument("--meshblock", type=int, default=0, help="meshblock size instead of the workload's 128 (tests)")
+    ap.add_argument("--no-rehearsal", action="store_true",
+                    help="skip 'rehearsal_8gpu_rank' (the N = 1 brick with its outer faces exchanged like those between bricks; ~10 s)")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the 'other_workloads' figures of the default N = 1 run (BASELINE configs 2, 4's scheme, 5's mesh; ~20 s)")
     ap.add_argument("--amr-extra", action="store_true",
                     help="append the adaptive-mesh figure (BASELINE config 5 shape) as 'amr_blast_cfg5'; off by default so "
                          "that the kernels of the default command are those of the headline workload only")
@@ -460,12 +607,13 @@ def main():
                 "stage_ms": stage_ms,
                 "dc_predictor_stage_ms": per_kernel["fused_dc_x1"] + per_kernel["fused_dc_x2"] + per_kernel["fused_dc_x3"],
                 "frac_of_measured_copy_bandwidth": achieved / HBM_COPY_GBS,
-                "note": "fp64 VALU-issue bound (executed VALU instructions per cell-stage: SQ_INSTS_VALU in the newest "
-                        "profiles/rNN_pmc_sq.json) at a measured 4.3 cycles per wave64 fp64 instruction and ~2.0 GHz "
-                        "(profiles/r02_clock_and_issue_rate.json); `peak` is the 8 TB/s spec, "
-                        "frac_of_measured_copy_bandwidth prices against the 6.29 TB/s a float4 copy reaches "
-                        "(MI355X_MICROARCH.md); product build: FMA contraction, rsq/rcp-based roots and reciprocals "
-                        "(<= 1e-12 of the bit-exact parity build, which is what the parity tests pin); see DESIGN.md section 7",
+                "note": "fp64 VALU-issue bound and power-limited (executed VALU instructions per cell-stage: SQ_INSTS_VALU in "
+                        "the newest profiles/rNN_pmc_sq.json; effective clock 1.8 - 2.0 GHz of a nominal 2.4 under these kernels, "
+                        "profiles/r03_clock_and_latency.json, at 1320 W of the 1400 W cap, profiles/r03_power_while_stage_loops.txt; "
+                        "issue rates of the instruction classes: profiles/r02_clock_and_issue_rate.json); `peak` is the 8 TB/s "
+                        "spec, frac_of_measured_copy_bandwidth prices against the 6.29 TB/s a float4 copy reaches "
+                        "(MI355X_MICROARCH.md); PRODUCT build: FMA contraction, rsq/rcp-based roots and reciprocals, "
+                        "<= 1e-12 of the bit-exact parity build (which is what the parity tests pin); see DESIGN.md section 7",
                 "per_kernel_avg_ms": per_kernel,
                 "dominant_kernel": ROCPROF_KERNEL.get(dominant, dominant) if fluid == "glmmhd" and recon == "ppm" else dominant,
                 "dominant_timing_slot": dominant,
@@ -482,6 +630,14 @@ def main():
                 out["roofline"]["general_stage"] = general_stage_bench(recon, riemann)
             except Exception as e:  # supplementary figure; never lose the headline
                 out["roofline"]["general_stage"] = {"error": repr(e)}
+        if world == 1 and not args.unfused and not args.no_rehearsal and not (args.brick or args.meshblock):
+            try:
+                out["rehearsal_8gpu_rank"] = rehearsal_8gpu_rank(args.workload, elapsed / args.steps * 1e3)
+            except Exception as e:  # supplementary figure
+                out["rehearsal_8gpu_rank"] = {"error": repr(e)}
+        if world == 1 and not args.unfused and not args.no_other_workloads and not (args.brick or args.meshblock) \
+                and args.workload == "mhd_ppm_hlld_vl2_256":
+            out["other_workloads"] = other_workloads()
         if world == 1 and args.amr_extra:
             try:
                 out["amr_blast_cfg5"] = amr_blast_bench()

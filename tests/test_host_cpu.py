@@ -93,6 +93,24 @@ def test_deck_errors_are_reported_not_fatal(overrides, msg):
     assert e.value.code == L.APK_ERR_INVALID and msg in str(e.value)
 
 
+def test_rehearsal_of_an_eight_rank_brick_has_that_ranks_messages():
+    """apk_amd/rehearse_remote_faces on ONE rank (bench.py's one-GPU rehearsal of the 2 x 2 x 2 run): the faces of the
+    brick count as faces to other ranks, so the plan has the 7 peers -- 3 faces, 3 edges, 1 corner -- with exactly
+    the message sizes rank 0 of the real 8-rank run has towards ranks 1 .. 7, send = receive."""
+    mb = ["parthenon/meshblock/nx%d=16" % d for d in (1, 2, 3)]
+    real = _plan("synthetic_mhd", ["parthenon/mesh/nx%d=64" % d for d in (1, 2, 3)] + mb, rank=0, nranks=8)
+    one = _plan("synthetic_mhd", ["parthenon/mesh/nx%d=32" % d for d in (1, 2, 3)] + mb + ["apk_amd/rehearse_remote_faces=true"])
+    plain = _plan("synthetic_mhd", ["parthenon/mesh/nx%d=32" % d for d in (1, 2, 3)] + mb)
+    assert plain.peers() == [] and one.info.nblocks_local == real.info.nblocks_local == 8
+    want = sorted((s, r) for _, s, r in real.peers())
+    got = sorted((s, r) for _, s, r in one.peers())
+    assert len(got) == 7 and got == want and all(s == r for s, r in got)
+    # pseudo ranks are outside the real rank range and distinct
+    assert sorted(q[0] for q in one.peers()) == list(range(1, 8))
+    with pytest.raises(Exception):
+        _plan("synthetic_mhd", ["parthenon/mesh/nx%d=64" % d for d in (1, 2, 3)] + mb + ["apk_amd/rehearse_remote_faces=true"], rank=0, nranks=8)
+
+
 def test_morton_partition_gives_bricks():
     """4x4x4 meshblocks over 8 ranks: each rank owns a 2x2x2 brick."""
     ov = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "parthenon/mesh/nx3=64",
