@@ -322,6 +322,9 @@ fused_x1_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_plane) {
 // the Riemann problem of the previous face is solved.  Keeping the ring out of the VGPR file
 // (it would be 2H*NV doubles = 72 VGPRs for PPM/GLM-MHD) is what lets two waves share a SIMD.
 constexpr int kMarchMinWaves = 2;
+#ifndef APK_PPM_PAIRS
+#define APK_PPM_PAIRS 0  // 1: PPM reconstructs two variables per pass in the marches (hydro_math.hpp: ppm_interface2 / ppm_cell2), A/B
+#endif
 
 template <int FLUID, int RECON>
 constexpr int march_lds_bytes() {
@@ -447,6 +450,37 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
 #pragma unroll
       for (int m = 0; m < NS; ++m) an[m] = ring[(((slot0 + m) & (NS - 1)) * NV + 0) * 64 + lane];
     }
+#if APK_PPM_PAIRS
+    if constexpr (RECON == APK_RC_PPM) {
+      // two variables per pass (ppm_interface2 / ppm_cell2): the ring rows of the NEXT pair are requested first
+      auto ring_rows = [&](int n, double (&q)[5]) {
+#pragma unroll
+        for (int m = 0; m < NS; ++m) q[m] = ring[(((slot0 + m) & (NS - 1)) * NV + n) * 64 + lane];
+        q[4] = Pn[n];
+      };
+      double qa[5], qb[5], na[5], nb[5];
+      ring_rows(0, na);
+      ring_rows(1, nb);
+#pragma unroll
+      for (int n = 0; n + 1 < NV; n += 2) {
+#pragma unroll
+        for (int m = 0; m < 5; ++m) qa[m] = na[m], qb[m] = nb[m];
+        if (n + 2 < NV) ring_rows(n + 2, na);
+        if (n + 3 < NV) ring_rows(n + 3, nb);
+        double fa, fb;
+        ppm_interface2(qa[1], qa[2], qa[3], qa[4], qb[1], qb[2], qb[3], qb[4], fa, fb);
+        ppm_cell2(qa, face_carry[n], fa, qb, face_carry[n + 1], fb, qln[n], qrn[n], qln[n + 1], qrn[n + 1]);
+        face_carry[n] = fa;
+        face_carry[n + 1] = fb;
+      }
+      if constexpr (NV % 2 == 1) {
+        constexpr int n = NV - 1;
+        const double face_p = ppm_interface(na[1], na[2], na[3], na[4]);
+        ppm_cell(na[0], na[1], na[2], na[3], na[4], face_carry[n], face_p, qln[n], qrn[n]);
+        face_carry[n] = face_p;
+      }
+    } else
+#endif
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
       double a[NS > 0 ? NS : 1];

@@ -325,6 +325,105 @@ APK_DEV void ppm_cell(double qm2, double qm1, double q0, double qp1, double qp2,
   qr = r;
 }
 
+// ---- PPM for TWO variables at once (APK_PPM_PAIRS) ----------------------------------------------------------------
+// The limiter branches of ppm_interface / ppm_cell are entered by the wave whenever SOME lane sits at an extremum of
+// the variable -- on smooth data about one lane per wave-row and variable, i.e. nearly always -- and then run as one
+// dependent chain of masked instructions per variable, nine times per direction.  Two variables share their branch
+// regions here: the region is entered when a lane needs either limiter, both limiter chains run inside it on those
+// lanes (independent chains the scheduler interleaves: the latency of one instead of two), and each lane keeps the
+// result of the variable it needed.  Same operations on the same operands per variable: bit-identical results.
+struct PpmFace {
+  double face, half_sum, below;
+  bool need;
+};
+APK_DEV PpmFace ppm_interface_open(double qm1, double q0, double qp1, double qp2) {
+  const double da = q0 - qm1;
+  const double db = qp1 - q0;
+  const double dd_c = 0.5 * db + 0.5 * da;
+  const double dd_p = 0.5 * (qp2 - qp1) + 0.5 * db;
+  PpmFace f;
+  f.half_sum = 0.5 * (q0 + qp1);
+  f.face = f.half_sum + APK_DIV6(dd_c - dd_p);
+  f.below = f.face - q0;
+  const double above = qp1 - f.face;
+  f.need = f.below * above < 0.0;
+  return f;
+}
+APK_DEV double ppm_interface_limited(double qm1, double q0, double qp1, double qp2, double face) {
+  constexpr double C2 = 1.25;
+  const double d2_c = qm1 + qp1 - 2.0 * q0;
+  const double d2_p = q0 + qp2 - 2.0 * qp1;
+  const double d2f = 3.0 * (q0 + qp1 - 2.0 * face);
+  const bool sg = neg(d2f);
+  const bool agree = (sg == neg(d2_c)) && (sg == neg(d2_p));
+  const double mag = min2(C2 * fabs(d2_c), min2(C2 * fabs(d2_p), fabs(d2f)));
+  const double lim = agree ? with_sign(sg, mag) : 0.0;
+  return 0.5 * (q0 + qp1) - APK_DIV6(lim);
+}
+APK_DEV void ppm_interface2(double am1, double a0, double ap1, double ap2, double bm1, double b0, double bp1, double bp2,
+                            double &face_a, double &face_b) {
+  const PpmFace fa = ppm_interface_open(am1, a0, ap1, ap2);
+  const PpmFace fb = ppm_interface_open(bm1, b0, bp1, bp2);
+  face_a = fa.face;
+  face_b = fb.face;
+  if (fa.need || fb.need) {
+    const double la = ppm_interface_limited(opaque(am1), a0, ap1, ap2, fa.face);
+    const double lb = ppm_interface_limited(opaque(bm1), b0, bp1, bp2, fb.face);
+    if (fa.need) face_a = la;
+    if (fb.need) face_b = lb;
+  }
+}
+// the extremum limiter of ppm_cell (steps 4 of ppm_simple.hpp:104-150): the limited states, or the interface values
+// where the limited ratio stays above 1 - 1e-12
+APK_DEV void ppm_cell_extremum(double qm2, double qm1, double q0, double qp1, double qp2, double face_m, double face_p,
+                               double dminus, double dplus, double &l, double &r) {
+  constexpr double C2 = 1.25;
+  const double q0x = opaque(q0), qp1x = opaque(qp1);
+  const double d2_m = qm2 + q0x - 2.0 * qm1;
+  const double d2_c = qm1 + qp1x - 2.0 * q0x;
+  const double d2_p = q0x + qp2 - 2.0 * qp1x;
+  const double d2_face = 6.0 * (face_m + face_p - 2.0 * q0x);
+  const bool s = neg(d2_m);
+  const bool agree = (s == neg(d2_c)) && (s == neg(d2_p)) && (s == neg(d2_face));
+  const double mag = min2(min2(C2 * fabs(d2_m), C2 * fabs(d2_c)), min2(C2 * fabs(d2_p), fabs(d2_face)));
+  const double d2lim = agree ? with_sign(neg(d2_face), mag) : 0.0;
+  const double scale_lo = max_abs2(qm1, qm2);
+  const double scale_hi = max_with_abs(max_abs2(q0, qp1), qp2);
+  double ratio = 0.0;
+  if (fabs(d2_face) > (1.0e-12) * max_plain(scale_lo, scale_hi)) ratio = d2lim / d2_face;
+  l = face_p;
+  r = face_m;
+  if (ratio <= (1.0 - (1.0e-12))) {
+    r = q0 - ratio * dminus;
+    l = q0 + ratio * dplus;
+  }
+}
+APK_DEV void ppm_cell2(const double (&a)[5], double fa_m, double fa_p, const double (&b)[5], double fb_m, double fb_p,
+                       double &ql_a, double &qr_a, double &ql_b, double &qr_b) {
+  // a[0..4] = qm2, qm1, q0, qp1, qp2
+  const double dma = a[2] - fa_m, dpa = fa_p - a[2];
+  const double dmb = b[2] - fb_m, dpb = fb_p - b[2];
+  const bool xa = (dma * dpa <= 0.0) || ((a[3] - a[2]) * (a[2] - a[1]) <= 0.0);
+  const bool xb = (dmb * dpb <= 0.0) || ((b[3] - b[2]) * (b[2] - b[1]) <= 0.0);
+  // the monotone case (every other lane)
+  double ra = fa_m, la = fa_p, rb = fb_m, lb = fb_p;
+  if (fabs(dma) >= 2.0 * fabs(dpa)) ra = a[2] - 2.0 * dpa;
+  if (fabs(dpa) >= 2.0 * fabs(dma)) la = a[2] + 2.0 * dma;
+  if (fabs(dmb) >= 2.0 * fabs(dpb)) rb = b[2] - 2.0 * dpb;
+  if (fabs(dpb) >= 2.0 * fabs(dmb)) lb = b[2] + 2.0 * dmb;
+  if (xa || xb) {
+    double lea, rea, leb, reb;
+    ppm_cell_extremum(a[0], a[1], a[2], a[3], a[4], fa_m, fa_p, dma, dpa, lea, rea);
+    ppm_cell_extremum(b[0], b[1], b[2], b[3], b[4], fb_m, fb_p, dmb, dpb, leb, reb);
+    if (xa) la = lea, ra = rea;
+    if (xb) lb = leb, rb = reb;
+  }
+  ql_a = la;
+  qr_a = ra;
+  ql_b = lb;
+  qr_b = rb;
+}
+
 // src/recon/ppm_simple.hpp:39-162, one cell on its own (flux-array kernels, passive scalars)
 APK_DEV void ppm(double qm2, double qm1, double q0, double qp1, double qp2, double &ql,
                  double &qr) {
