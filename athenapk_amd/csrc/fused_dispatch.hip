@@ -40,6 +40,9 @@ int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
   sp.bad_count = nullptr;
   sp.out_delta = a.cons_out_delta;
   sp.face_nbr = a.face_neighbor;
+  if (a.cons_store < 0 || a.cons_store > 2) return APK_ERR_INVALID;
+  // (only the stage whose primitives go out of place may drop its conserved result; a windowed phase keeps everything)
+  sp.cons_store = (a.fill_derived == 2 && a.phase == 0 && !a.trial && a.cons_out_delta == 0) ? a.cons_store : 0;
   if (a.cons_out_delta != 0 && u0.nvar != u0.nhydro) return APK_ERR_UNSUPPORTED;  // (the scalar kernels update in place)
   if (a.count_unphysical) {     // word 6: cells failing FirstOrderFluxCorrect's test (apk_stage_unphysical_read)
     if (u0.nvar != u0.nhydro) return APK_ERR_UNSUPPORTED;  // (scalars are updated by their own kernel)

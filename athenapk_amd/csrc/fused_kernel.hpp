@@ -51,6 +51,7 @@ struct StageParams {
   // apk_stage_args.face_neighbor: [nblocks][6] pack index of the block behind each face whose interior
   // stands in for this block's ghost zone there (-1: the ghost zone itself), or NULL
   const int *face_nbr;
+  int cons_store;  // apk_stage_args.cons_store (0 all cells, 1 the nghost-deep shell of every block, 2 none)
   apk_ctx *ctx;  // host side only (kernel timing); never dereferenced on the device
 };
 
@@ -120,7 +121,7 @@ template <int FLUID, int EXTRA = EXTRA_NONE, bool LEAN = false>
 APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
                          const double (&u1v)[nvars<FLUID>()], int64_t cell,
                          const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp,
-                         double &lane_min_dt, double *prim_dst = nullptr, double upd = 0.0) {
+                         double &lane_min_dt, double *prim_dst = nullptr, double upd = 0.0, bool store_cons = true) {
   constexpr int NV = nvars<FLUID>();
   double un[NV];
   if constexpr (LEAN) {
@@ -194,6 +195,9 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
     if constexpr (!LEAN) {
       if (sp.bad_count && fl) bad = true;
     }
+#ifdef APK_DBG_NO_PRIM_STORE  // (timing experiment only: WRONG results)
+    if (sp.dedner == 77)
+#endif
 #pragma unroll
     for (int n = 0; n < NV; ++n) as_global(prim_dst)[n * pv.sn + cell] = w[n];
     if constexpr (EXTRA == EXTRA_C2P_DT) {
@@ -201,8 +205,10 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
       lane_min_dt = fmin(lane_min_dt, cell_dt_hyp<FLUID>(sp.eos.gamma, w, di, pv.ndim, b0.dx[0], b0.dx[1], b0.dx[2]));
     }
   }
+  if (store_cons) {
 #pragma unroll
-  for (int n = 0; n < NV; ++n) as_global(b0.cons)[n * pv.sn + cell + sp.out_delta] = un[n];
+    for (int n = 0; n < NV; ++n) as_global(b0.cons)[n * pv.sn + cell + sp.out_delta] = un[n];
+  }
   if constexpr (!LEAN) {
     if (bad) atomicAdd(sp.bad_count, 1ull);
   }
@@ -779,6 +785,9 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
   const bool active = in_run && (lane >= 1) && (lane <= 62) && (i >= ilo) && (i <= ihi);
 
   const int64_t col = (int64_t)(jlo + row) * u0.sj + i;
+  // apk_stage_args.cons_store (lean form): does this lane's column lie in the nghost-deep shell of its block?
+  const int jrow = jlo + row;
+  const bool shell_ij = (i < u0.is + u0.ng) || (i > u0.ie - u0.ng) || (jrow < u0.js + u0.ng) || (jrow > u0.je - u0.ng);
   const double *prim = b0.prim + col;
   // Direct neighbour addressing (sp.face_nbr): a lane on a ghost column reads the x1 neighbour's
   // interior column instead, the x2 / x3 neighbours of an interior column come from the block
@@ -902,7 +911,10 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
             m[u0.sk] = f3[0];
           }
         }
-        if (active) finish_cell<FLUID, EXTRA, LEAN>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd);
+        bool store = true;
+        if constexpr (LEAN)
+          store = sp.cons_store == 0 || (sp.cons_store == 1 && (shell_ij || c - 1 < u0.ks + u0.ng || c - 1 > u0.ke - u0.ng));
+        if (active) finish_cell<FLUID, EXTRA, LEAN>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd, store);
       }
 #pragma unroll
       for (int q = 0; q < NV; ++q) st_f3[q * 64] = f3[q];
@@ -969,6 +981,205 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
             m[0] = flo[0];
             m[u0.sj] = fhi[0];
           }
+        }
+      }
+    }
+  }
+  if constexpr (EXTRA == EXTRA_C2P_DT) {
+    double m = lane_min_dt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_down(m, off, 64));
+    if (lane == 0) atomicMin(sp.dt_bits, (unsigned long long)__double_as_longlong(m));
+  }
+}
+
+// ==============================================================================================
+// The 3-D donor-cell stage with TWO j-rows per lane (lean stages on whole blocks with an even number of rows).
+//
+// fused_dc3_kernel solves four Riemann problems per cell: x1 faces are shared between neighbouring lanes (DPP), x3
+// faces are carried along the march, but BOTH x2 faces are solved by the lane itself -- the lane that owns the cell
+// across the face sits 130 lanes away in another wave.  Here a lane owns the cells (2m, i) and (2m + 1, i): the x2 face
+// between them is solved once and used twice, 3 x2 solves for 2 cells, i.e. 3.5 solves per cell instead of 4
+// (-12.5 % of a kernel that is Riemann solves and little else) and 4 fast speeds along x2 for 2 cells instead of 6.
+// Same values: the shared flux is the one both cells computed for themselves before (same function of the same two
+// states), the accumulation order per cell is unchanged.  The two cells are processed one after the other, so the
+// working set of a solve stays what it was; the carried state doubles: 2 x 9 doubles of the previous plane in VGPRs,
+// 4 x 9 rows in the LDS stash (18.4 KB per wave, inside the 20 KB two waves per SIMD leave).
+// ==============================================================================================
+#ifndef APK_DC3_ROWS
+#define APK_DC3_ROWS 2  // 1: always the one-row kernel (A/B)
+#endif
+template <int FLUID, int RS, int EXTRA>
+__global__ void __launch_bounds__(64, 2)
+fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, int nseg, int per_xcd) {
+  constexpr int NV = nvars<FLUID>();
+  double lane_min_dt = 1.7976931348623157e308;
+  const int lane = threadIdx.x;
+  const int vid = (int)(blockIdx.x % 8u) * per_xcd + (int)(blockIdx.x / 8u);  // XCD-aware order (see fused_dc3_kernel)
+  if (vid >= wpb * nseg * u0.nblocks) return;
+  const int chunk = vid % wpb;
+  const int segid = (vid / wpb) % nseg;
+  const int b = vid / (wpb * nseg);
+  const apk_block_desc b0 = u0.blocks[b];
+  const double *c1 = u1.blocks[b].cons;
+  double *prim_dst = u1.blocks[b].prim;
+
+  const int i0 = u0.is - 1, rl = u0.nx1 + 2;
+  const int64_t run = (int64_t)(u0.nx2 / 2) * rl;
+  const int64_t t = (int64_t)chunk * 62 + lane - 1;
+  if ((int64_t)chunk * 62 - 1 >= run) return;
+  const bool in_run = (t >= 0) && (t < run);
+  const int64_t tc = in_run ? t : (t < 0 ? 0 : run - 1);
+  const int rowpair = (int)(tc / rl);
+  const int i = i0 + (int)(tc - (int64_t)rowpair * rl);
+  const bool active = in_run && (lane >= 1) && (lane <= 62) && (i >= u0.is) && (i <= u0.ie);
+  const int ja = u0.js + 2 * rowpair;  // rows ja (cell A) and ja + 1 (cell B)
+
+  const int64_t col = (int64_t)ja * u0.sj + i;
+  const bool shell_i = (i < u0.is + u0.ng) || (i > u0.ie - u0.ng);
+  const bool shell_ij[2] = {shell_i || (ja < u0.js + u0.ng) || (ja > u0.je - u0.ng),
+                            shell_i || (ja + 1 < u0.js + u0.ng) || (ja + 1 > u0.je - u0.ng)};  // (apk_stage_args.cons_store)
+  const double *prim = b0.prim + col;  // cell A's column; cell B's is prim + sj
+  const double *prim_jm = prim - u0.sj, *prim_jp = prim + 2 * u0.sj;
+  const double *prim_klo = prim, *prim_khi = prim;
+  if (sp.face_nbr) {  // direct neighbour addressing, as in fused_dc3_kernel
+    const int *fn = sp.face_nbr + 6 * b;
+    if (i < u0.is || i > u0.ie) {
+      const int nb = fn[i < u0.is ? 0 : 1];
+      if (nb >= 0) prim = u0.blocks[nb].prim + col + (i < u0.is ? u0.nx1 : -u0.nx1);
+      prim_jm = prim - u0.sj;
+      prim_jp = prim + 2 * u0.sj;
+      prim_klo = prim_khi = prim;
+    } else {
+      if (ja - 1 < u0.js && fn[2] >= 0) prim_jm = u0.blocks[fn[2]].prim + col + (int64_t)(u0.nx2 - 1) * u0.sj;
+      if (ja + 2 > u0.je && fn[3] >= 0) prim_jp = u0.blocks[fn[3]].prim + col + 2 * u0.sj - (int64_t)u0.nx2 * u0.sj;
+      if (fn[4] >= 0) prim_klo = u0.blocks[fn[4]].prim + col + (int64_t)u0.nx3 * u0.sk;
+      if (fn[5] >= 0) prim_khi = u0.blocks[fn[5]].prim + col - (int64_t)u0.nx3 * u0.sk;
+    }
+  }
+  const double area1 = b0.dx[1] * b0.dx[2], area2 = b0.dx[0] * b0.dx[2], area3 = b0.dx[0] * b0.dx[1];
+  const double vol = b0.dx[0] * b0.dx[1] * b0.dx[2];
+  const double upd = update_coefficient(sp, vol);
+  const int s = u0.ks + segid * kseg;
+  if (s > u0.ke) return;
+  const int e = (s + kseg - 1 < u0.ke) ? s + kseg - 1 : u0.ke;
+
+  extern __shared__ __attribute__((aligned(16))) double stash[];
+  // [cell][f3 | du][var][lane]
+  double *st_f3[2] = {stash + lane, stash + 2 * NV * 64 + lane};
+  double *st_du[2] = {stash + NV * 64 + lane, stash + 3 * NV * 64 + lane};
+  constexpr bool CF = (FLUID == APK_FLUID_GLMMHD) && (RS == APK_RS_HLLD);
+  auto cf_of = [&](const double (&w)[NV]) -> double {
+    if constexpr (CF) return fast_speed(sp.gamma, w[IDN], w[IPR], w[IB1], w[IB2], w[IB3]);
+    else return 0.0;
+  };
+  auto solve = [&](const double (&wl)[NV], const double (&wr)[NV], double cfl, double cfr, double (&f)[NV]) {
+    if constexpr (CF) glmmhd_hlld_cf(wl, wr, sp.k, cfl, cfr, f);
+    else riemann<FLUID, RS>(wl, wr, sp.k, f);
+  };
+  double wprev[2][NV], cf3_prev[2] = {0.0, 0.0};
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      wprev[r][n] = ((s - 1 < u0.ks) ? prim_klo : prim)[n * u0.sn + (int64_t)(s - 1) * u0.sk + r * u0.sj];
+      st_f3[r][n * 64] = 0.0;
+      st_du[r][n * 64] = 0.0;
+    }
+    if constexpr (CF) {
+      double wp3[NV];
+#pragma unroll
+      for (int q = 0; q < NV; ++q) wp3[q] = wprev[r][perm<3>(q)];
+      cf3_prev[r] = cf_of(wp3);
+    }
+  }
+  for (int c = s; c <= e + 1; ++c) {
+    const int64_t off = (int64_t)c * u0.sk;
+    double wc[2][NV];
+    {
+      const double *pc = (c > u0.ke) ? prim_khi : prim;  // wave-uniform
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int n = 0; n < NV; ++n) wc[r][n] = pc[n * u0.sn + off + r * u0.sj];
+    }
+    // ---- x3 faces c of both cells; plane c-1 is complete
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      double wl3[NV], wr3[NV], f3[NV];
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        wl3[q] = wprev[r][perm<3>(q)];
+        wr3[q] = wc[r][perm<3>(q)];
+      }
+      const double cf3_c = cf_of(wr3);
+      solve(wl3, wr3, cf3_prev[r], cf3_c, f3);
+      cf3_prev[r] = cf3_c;
+      if (c >= s + 1) {
+        const int64_t done = col + (int64_t)(c - 1) * u0.sk + r * u0.sj;
+        double du[NV], u1v[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const int n = perm<3>(q);
+          du[n] = st_du[r][n * 64] + (area3 * f3[q] - area3 * st_f3[r][q * 64]);
+        }
+#pragma unroll
+        for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
+        const bool store = sp.cons_store == 0 || (sp.cons_store == 1 && (shell_ij[r] || c - 1 < u0.ks + u0.ng || c - 1 > u0.ke - u0.ng));
+        if (active) finish_cell<FLUID, EXTRA, true>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd, store);
+      }
+#pragma unroll
+      for (int q = 0; q < NV; ++q) st_f3[r][q * 64] = f3[q];
+#pragma unroll
+      for (int n = 0; n < NV; ++n) wprev[r][n] = wc[r][n];
+    }
+    if (c <= e) {  // wave-uniform
+      // ---- x1 faces of both rows of plane c
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        double wl[NV], wr[NV], f[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          wr[q] = wc[r][perm<1>(q)];
+          wl[q] = wave_shr1(wr[q]);
+        }
+        const double cf1_c = cf_of(wr);
+        solve(wl, wr, CF ? wave_shr1(cf1_c) : 0.0, cf1_c, f);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const double fup = wave_shl1(f[q]);
+          st_du[r][perm<1>(q) * 64] = (area1 * fup - area1 * f[q]);
+        }
+      }
+      // ---- x2 faces: below A, between A and B (ONE solve, both cells use it), above B
+      double wa[NV], wb[NV], fmid[NV];
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        wa[q] = wc[0][perm<2>(q)];
+        wb[q] = wc[1][perm<2>(q)];
+      }
+      const double cfa = cf_of(wa), cfb = cf_of(wb);
+      solve(wa, wb, cfa, cfb, fmid);
+      {
+        double wm[NV], flo[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) wm[q] = prim_jm[perm<2>(q) * u0.sn + off];
+        solve(wm, wa, cf_of(wm), cfa, flo);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const int n = perm<2>(q);
+          st_du[0][n * 64] = st_du[0][n * 64] + (area2 * fmid[q] - area2 * flo[q]);
+        }
+      }
+      {
+        double wp[NV], fhi[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) wp[q] = prim_jp[perm<2>(q) * u0.sn + off];
+        solve(wb, wp, cfb, cf_of(wp), fhi);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const int n = perm<2>(q);
+          st_du[1][n * 64] = st_du[1][n * 64] + (area2 * fhi[q] - area2 * fmid[q]);
         }
       }
     }
@@ -1155,6 +1366,24 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
         ScopedTiming t(sp.ctx, TS + 0, s);
         static const bool no_lean = std::getenv("APK_NO_LEAN") && std::atoi(std::getenv("APK_NO_LEAN")) != 0;  // (A/B)
         const bool lean = stage_is_lean(sp) && !no_lean;
+        static const int dc_rows = std::getenv("APK_DC3_ROWS") ? std::atoi(std::getenv("APK_DC3_ROWS")) : APK_DC3_ROWS;  // (A/B)
+        if (lean && dc_rows == 2 && !sp.window && u0.nx2 % 2 == 0 && u0.nx2 >= 4) {
+          // two rows per lane (fused_dc3r2_kernel): whole blocks only -- a split stage's windows keep the one-row kernel
+          const int64_t run2 = (int64_t)(u0.nx2 / 2) * (u0.nx1 + 2);
+          const int wpb2 = (int)((run2 + 61) / 62);
+          const int64_t total2 = (int64_t)wpb2 * nseg * u0.nblocks;
+          const int per_xcd2 = (int)((total2 + 7) / 8);
+          const dim3 g2((unsigned)(per_xcd2 * 8), 1, 1);
+          constexpr int lds4 = 4 * nvars<FLUID>() * 64 * (int)sizeof(double);
+          ScopedTiming t2(sp.ctx, TS + 0, s);
+          if (extra == EXTRA_C2P_DT)
+            hipLaunchKernelGGL((fused_dc3r2_kernel<FLUID, RS, EXTRA_C2P_DT>), g2, dim3(64), lds4, s, u0, u1, sp, kseg, wpb2, nseg, per_xcd2);
+          else if (extra == EXTRA_C2P)
+            hipLaunchKernelGGL((fused_dc3r2_kernel<FLUID, RS, EXTRA_C2P>), g2, dim3(64), lds4, s, u0, u1, sp, kseg, wpb2, nseg, per_xcd2);
+          else
+            hipLaunchKernelGGL((fused_dc3r2_kernel<FLUID, RS, EXTRA_NONE>), g2, dim3(64), lds4, s, u0, u1, sp, kseg, wpb2, nseg, per_xcd2);
+          return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
+        }
 #define APK_LAUNCH_DC3(EXTRA_, LEAN_) \
   hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_, LEAN_>), g, dim3(64), lds3, s, u0, u1, sp, kseg, wpb, nseg, per_xcd)
         if (extra == EXTRA_C2P_DT) {

@@ -828,6 +828,17 @@ int do_stage(apk_sim *s, int stage) {
     }
     a.fill_derived = fused_fill ? (swap_prim ? 2 : 1) : 0;
     a.estimate_dt = (fused_fill && stage == s->nstages && pkg.calc_dt_hyp) ? 1 : 0;
+    {
+      // The predictor of VL2: the corrector has gam0 = 0 and takes its fluxes from the predictor's primitives, so the
+      // half-step CONSERVED state is read by nobody but the ghost exchange -- the nghost-deep shell of every block --
+      // and by nothing at all when every face is crossed through the face table (apk_stage_args.cons_store).
+      static const int mode = std::getenv("APK_CONS_STORE") ? std::atoi(std::getenv("APK_CONS_STORE")) : 2;  // A/B switch: 0 stores all
+      const bool dead = dc3 && swap_prim && stage < s->nstages && s->gam0[stage] == 0.0 && !s->amr && !s->fmft && pkg.nscalars == 0;
+      bool all_periodic = true;
+      for (int d = 0; d < 3; ++d)
+        if (mm.Active(d) && (mm.bc_in[d] != BC_PERIODIC || mm.bc_out[d] != BC_PERIODIC)) all_periodic = false;
+      if (dead && mode > 0) a.cons_store = (direct && mm.peers.empty() && all_periodic && mode > 1) ? 2 : 1;
+    }
     if (s->exchange_pending && cfg.recon == APK_RC_DC && !(dc3 && swap_prim)) SIM_TRY(s, finish_pending(s));
     if (s->exchange_pending) {
       // The previous stage's halo messages are still in flight.  Ghost zones filled by same-rank

@@ -58,7 +58,7 @@ class StageArgs(C.Structure):
                 ("glmmhd_alpha", C.c_double), ("mindx", C.c_double), ("fill_derived", C.c_int),
                 ("estimate_dt", C.c_int), ("phase", C.c_int), ("window", C.c_void_p),
                 ("window_rl", C.c_int), ("window_rows", C.c_int), ("trial", C.c_int), ("count_unphysical", C.c_int), ("cons_out_delta", C.c_int64),
-                ("face_neighbor", C.c_void_p)]
+                ("face_neighbor", C.c_void_p), ("cons_store", C.c_int)]
 
 
 class FmftBlock(C.Structure):

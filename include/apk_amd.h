@@ -230,6 +230,18 @@ typedef struct apk_stage_args {
    * the two-kernel stage (apk_stage_split_axis() == 3); not with passive scalars nor dedner = 2
    * (APK_ERR_UNSUPPORTED). */
   const int *face_neighbor;
+  /* cons_store: which cells of the updated CONSERVED state the stage must leave in memory.
+   *   0  every interior cell (the reference's semantics).
+   *   1  only the cells within nghost layers of a face of their meshblock -- what ghost-zone copies, message packing
+   *      and physical boundary conditions read.
+   *   2  none.
+   * For a stage whose conserved result nobody reads in full: the predictor of VL2, whose corrector has gam0 = 0 and
+   * takes its fluxes from the predictor's PRIMITIVES (fill_derived = 2) -- the half-step conserved state is then
+   * dead but for the strips the exchange reads (1), or altogether when every neighbour is read directly through
+   * face_neighbor (2): 72 of the 288 bytes the donor-cell stage moves per cell, and that stage runs at the memory
+   * system's rate.  Honoured by the 3-D single-march donor-cell stage in its lean form; every other stage form
+   * stores all cells (always a valid reading of 1 and 2).  The cells not stored keep whatever they held. */
+  int cons_store;
 } apk_stage_args;
 int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
                     const apk_stage_args *args, apk_stream_t stream);

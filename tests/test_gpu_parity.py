@@ -580,6 +580,59 @@ def test_fused_stage_fill_derived_out_of_place(request, oracle, fluid, recon, ri
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("cons_store", [0, 1, 2], ids=["all_cells", "shell", "none"])
+@pytest.mark.parametrize("fluid,recon,riemann,nx,gam0", [("glmmhd", "dc", "hlld", (64, 8, 34), 0.0),    # two rows per lane
+                                                         ("glmmhd", "dc", "hlld", (40, 9, 10), 0.0),    # odd nx2: one row per lane
+                                                         ("euler", "dc", "hllc", (66, 12, 9), 0.0),
+                                                         ("glmmhd", "dc", "hlle", (34, 10, 8), 0.5),
+                                                         ("glmmhd", "ppm", "hlld", (70, 9, 7), 0.25),    # lean finishing march
+                                                         ("glmmhd", "wenoz", "hlld", (64, 8, 8), 0.0)])
+def test_lean_stage_forms_and_conserved_store_modes(request, oracle, fluid, recon, riemann, nx, gam0, cons_store, strict):
+    """The stage kernels' LEAN forms (default equation of state: no floors, no ceilings; plain Dedner source; nothing
+    optional asked for) -- the finishing x1 + x2 march, the donor-cell march with one and with two rows per lane --
+    against the oracle, and apk_stage_args.cons_store: 1 leaves the updated conserved state in the nghost-deep shell of
+    every block only, 2 nowhere (the primitives are the stage's product); the cells not stored keep what they held."""
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    ng, prim, g = _case(fluid, recon, nx, kind="smooth", seed=143, nblocks=2)
+    cons = H.prim_to_cons(fluid, prim, GAMMA)
+    ded = 1 if fluid == "glmmhd" else 0
+    u1c = cons * 1.01 if gam0 != 0.0 else cons
+    sentinel = np.full_like(prim, -7.0)
+    m0 = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=2, cons=cons, prim=prim, with_flux=False)
+    m1 = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=2, cons=u1c, prim=sentinel, with_flux=False)
+    ctx.poll_flags()
+    hydro.StageFused(m0, m1, fluid, recon, riemann, hydro.L.make_eos(GAMMA), C_H, gam0, 1.0 - gam0, 0.004,
+                     dedner=ded, glmmhd_alpha=0.1, mindx=0.07, fill_derived=2, estimate_dt=True, cons_store=cons_store)
+    dt = hydro.StageDt(ctx, 0.3)
+    want_cons = H.orc_stage(fluid, recon, riemann, g, cons, u1c, prim, GAMMA, C_H, gam0, 1.0 - gam0, 0.004,
+                            dedner=ded, alpha=0.1, mindx=0.07)
+    want_cons, want_prim, bad = H.orc_c2p(fluid, g, want_cons, oracle.make_eos(GAMMA))
+    assert bad == 0 and ctx.poll_flags() == 0
+    _cmp(H.interior(m1.prim_host(), nx, ng), H.interior(want_prim, nx, ng), strict, "u1.prim (interior)")
+    assert np.array_equal(m0.prim_host(), prim), "u0.prim must not be touched"
+    want_dt = 0.3 * H.orc_min_dt(fluid, g, want_prim, GAMMA)
+    assert dt == want_dt if strict else dt == pytest.approx(want_dt, rel=1e-12)
+    got = H.interior(m0.cons_host(), nx, ng)
+    full = H.interior(want_cons, nx, ng)
+    old = H.interior(cons, nx, ng)
+    honoured = recon == "dc" and nx[2] > 1          # the single-march donor-cell stage in its lean form
+    if cons_store == 0 or not honoured:
+        _cmp(got, full, strict, "cons")
+    else:
+        shell = np.ones(got.shape, dtype=bool)
+        if cons_store == 1:
+            shell[..., ng:-ng, ng:-ng, ng:-ng] = False
+        else:
+            shell[...] = False
+        if shell.any():
+            _cmp(got[shell], full[shell], strict, "cons (shell)")
+        assert np.array_equal(got[~shell], old[~shell]), "cells outside the shell must keep their old contents"
+        assert (~shell).any() or cons_store == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
 @pytest.mark.parametrize("fluid,recon,riemann,nx", [("glmmhd", "ppm", "hlld", (70, 9, 7)),
                                                     ("glmmhd", "wenoz", "hlld", (64, 8, 8)),
                                                     ("euler", "plm", "hllc", (66, 10, 1))])
