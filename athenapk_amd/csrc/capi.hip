@@ -271,7 +271,13 @@ int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
     return set_err(ctx, APK_ERR_INVALID, "fused stage: phase / window mismatch");
   if (a->phase == 1 && a->estimate_dt && a->cfg.recon == APK_RC_DC && u0->view.ndim == 3)
     return set_err(ctx, APK_ERR_UNSUPPORTED, "fused stage: estimate_dt is not available in a split 3-D donor-cell stage");
-  if (a->fill_derived < 0 || a->fill_derived > 2) return set_err(ctx, APK_ERR_INVALID, "fused stage: fill_derived must be 0, 1 or 2");
+  if (a->fill_derived < 0 || a->fill_derived > 3) return set_err(ctx, APK_ERR_INVALID, "fused stage: fill_derived must be 0, 1, 2 or 3");
+  if (a->fill_derived == 3 && !a->estimate_dt)
+    return set_err(ctx, APK_ERR_INVALID, "fused stage: fill_derived = 3 (primitives for the time-step estimate only) needs estimate_dt");
+  if (a->prim_from_cons) {
+    for (const apk_block_desc &b : u1->h_blocks)
+      if (!b.cons) return set_err(ctx, APK_ERR_INVALID, "fused stage: prim_from_cons needs u1.cons");
+  }
   if (a->fill_derived == 2) {
     for (const apk_block_desc &b : u1->h_blocks)
       if (!b.prim) return set_err(ctx, APK_ERR_INVALID, "fused stage: fill_derived = 2 needs prim arrays in u1");
@@ -282,7 +288,7 @@ int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
   double coeff = 1.0;
   if (a->dedner != 0) coeff = std::exp(-a->glmmhd_alpha * a->c_h * a->beta_dt / a->mindx);
   rc = launch_stage_fused(ctx, u0->view, u1->view, *a, coeff, as_stream(stream));
-  if (rc == APK_ERR_UNSUPPORTED) return set_err(ctx, rc, "fused stage: option combination not supported (scalars, 1-D/extended-Dedner fill_derived, split 1-D or 3-D donor-cell stage)");
+  if (rc == APK_ERR_UNSUPPORTED) return set_err(ctx, rc, "fused stage: option combination not supported (scalars, 1-D/extended-Dedner fill_derived, split 1-D or 3-D donor-cell stage, fill_derived = 3 / prim_from_cons outside the lean two-kernel / donor-cell stage)");
   if (rc != APK_OK) return set_err(ctx, rc, "fused stage kernel launch failed", hipGetLastError());
   return APK_OK;
 }
@@ -300,7 +306,7 @@ int apk_stage_unphysical_read(apk_ctx *ctx, long long *count, apk_stream_t strea
 int apk_stage_split_axis(const apk_pack *u0, const apk_flux_cfg *cfg, int fill_derived) {
   if (!u0 || !cfg) return 0;
   apk::StageParams sp{};
-  sp.prim_to_u1 = (fill_derived == 2) ? 1 : 0;
+  sp.prim_to_u1 = (fill_derived >= 2) ? 1 : 0;
   const int extra = fill_derived ? apk::EXTRA_C2P : apk::EXTRA_NONE;
   if (u0->view.ndim == 3 && cfg->recon == APK_RC_DC) return 0;  // single-kernel stage: 3-D index windows
   return apk::two_kernel_stage_applies(u0->view, cfg->recon, extra, sp) ? 3 : 1;

@@ -153,7 +153,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     const int chunk = item - b * wpb;
     const apk_block_desc b0 = u0.blocks[b];
     const double *c1 = u1.blocks[b].cons;
-    double *prim_dst = (EXTRA != EXTRA_NONE) ? u1.blocks[b].prim : nullptr;
+    double *prim_dst = (EXTRA != EXTRA_NONE && !sp.no_prim_store) ? u1.blocks[b].prim : nullptr;
     const double *d3 = sp.du + (int64_t)b * u0.sn * u0.nvar;
 
     const int64_t t = (int64_t)chunk * CPW + lane - FIRST;

@@ -42,7 +42,7 @@ int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
   sp.face_nbr = a.face_neighbor;
   if (a.cons_store < 0 || a.cons_store > 2) return APK_ERR_INVALID;
   // (only the stage whose primitives go out of place may drop its conserved result; a windowed phase keeps everything)
-  sp.cons_store = (a.fill_derived == 2 && a.phase == 0 && !a.trial && a.cons_out_delta == 0) ? a.cons_store : 0;
+  sp.cons_store = (a.fill_derived == 2 && !a.trial && a.cons_out_delta == 0) ? a.cons_store : 0;
   if (a.cons_out_delta != 0 && u0.nvar != u0.nhydro) return APK_ERR_UNSUPPORTED;  // (the scalar kernels update in place)
   if (a.count_unphysical) {     // word 6: cells failing FirstOrderFluxCorrect's test (apk_stage_unphysical_read)
     if (u0.nvar != u0.nhydro) return APK_ERR_UNSUPPORTED;  // (scalars are updated by their own kernel)
@@ -50,7 +50,10 @@ int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
     if (a.phase != 2 && hipMemsetAsync(sp.bad_count, 0, sizeof(unsigned long long), s) != hipSuccess) return APK_ERR_DEVICE;
   }
   int extra = EXTRA_NONE;
-  sp.prim_to_u1 = (a.fill_derived == 2) ? 1 : 0;
+  if (a.fill_derived < 0 || a.fill_derived > 3 || (a.fill_derived == 3 && !a.estimate_dt)) return APK_ERR_INVALID;
+  sp.prim_to_u1 = (a.fill_derived >= 2) ? 1 : 0;
+  sp.no_prim_store = (a.fill_derived == 3) ? 1 : 0;  // (the stage forms that cannot honour it refuse: launch_fused_stage)
+  sp.prim_from_cons = a.prim_from_cons ? 1 : 0;
   sp.phase = a.phase;
   sp.window = (a.phase == 1) ? a.window : nullptr;
   sp.window_rl = a.window_rl;

@@ -52,6 +52,8 @@ struct StageParams {
   // stands in for this block's ghost zone there (-1: the ghost zone itself), or NULL
   const int *face_nbr;
   int cons_store;  // apk_stage_args.cons_store (0 all cells, 1 the nghost-deep shell of every block, 2 none)
+  int no_prim_store;   // apk_stage_args.fill_derived = 3: ConsToPrim for the dt estimate only
+  int prim_from_cons;  // apk_stage_args.prim_from_cons
   apk_ctx *ctx;  // host side only (kernel timing); never dereferenced on the device
 };
 
@@ -195,11 +197,10 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
     if constexpr (!LEAN) {
       if (sp.bad_count && fl) bad = true;
     }
-#ifdef APK_DBG_NO_PRIM_STORE  // (timing experiment only: WRONG results)
-    if (sp.dedner == 77)
-#endif
+    if (prim_dst) {  // (wave-uniform; NULL: fill_derived = 3, the primitives only feed the time-step estimate)
 #pragma unroll
-    for (int n = 0; n < NV; ++n) as_global(prim_dst)[n * pv.sn + cell] = w[n];
+      for (int n = 0; n < NV; ++n) as_global(prim_dst)[n * pv.sn + cell] = w[n];
+    }
     if constexpr (EXTRA == EXTRA_C2P_DT) {
       // EstimateHyperbolicTimestep (hydro.cpp:845-895) on the fresh primitives
       lane_min_dt = fmin(lane_min_dt, cell_dt_hyp<FLUID>(sp.eos.gamma, w, di, pv.ndim, b0.dx[0], b0.dx[1], b0.dx[2]));
@@ -748,7 +749,25 @@ fused_march12_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_blo
 #ifndef APK_DC3_WAVES
 #define APK_DC3_WAVES 2  // resident waves per SIMD the donor-cell march is compiled for (A/B)
 #endif
-template <int FLUID, int RS, int EXTRA = EXTRA_NONE, bool LEAN = false>
+// Input state of a donor-cell march lane: nine loads at `p` and, when the stage derives its primitives from the
+// conserved state (apk_stage_args.prim_from_cons), ConsToPrim of what was loaded -- the function the finishing sweep of the
+// previous stage applied to the same values (lean form: no floor but the density / energy ones, no flags: the state was
+// checked when it was produced).
+template <int FLUID, bool FROM_CONS>
+APK_DEV void load_input_state(const double *p, int64_t sn, const StageParams &sp, double (&w)[nvars<FLUID>()]) {
+  constexpr int NV = nvars<FLUID>();
+  if constexpr (FROM_CONS) {
+    double u[NV], di;
+#pragma unroll
+    for (int n = 0; n < NV; ++n) u[n] = p[n * sn];
+    (void)cons_to_prim_core<FLUID, true>(sp.eos, sp.k.eos_gm1, sp.k.vceil_sq, sp.k.pfloor_over_gm1, u, w, di);
+  } else {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) w[n] = p[n * sn];
+  }
+}
+
+template <int FLUID, int RS, int EXTRA = EXTRA_NONE, bool LEAN = false, bool FROM_CONS = false>
 __global__ void __launch_bounds__(64, APK_DC3_WAVES)
 fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, int nseg, int per_xcd) {
   constexpr int NV = nvars<FLUID>();
@@ -788,7 +807,10 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
   // apk_stage_args.cons_store (lean form): does this lane's column lie in the nghost-deep shell of its block?
   const int jrow = jlo + row;
   const bool shell_ij = (i < u0.is + u0.ng) || (i > u0.ie - u0.ng) || (jrow < u0.js + u0.ng) || (jrow > u0.je - u0.ng);
-  const double *prim = b0.prim + col;
+  static_assert(!FROM_CONS || LEAN, "prim_from_cons: lean form only");
+  // the stage's input: u0's primitives, or u1's conserved state (apk_stage_args.prim_from_cons, see load_input_state)
+  auto input_of = [&](int blk) -> const double * { return FROM_CONS ? u1.blocks[blk].cons : u0.blocks[blk].prim; };
+  const double *prim = input_of(b) + col;
   // Direct neighbour addressing (sp.face_nbr): a lane on a ghost column reads the x1 neighbour's
   // interior column instead, the x2 / x3 neighbours of an interior column come from the block
   // behind that face.  Only face neighbours are ever needed: a donor-cell flux reads the two cells
@@ -801,15 +823,15 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
     const int j = jlo + row;
     if (i < u0.is || i > u0.ie) {
       const int nb = fn[i < u0.is ? 0 : 1];
-      if (nb >= 0) prim = u0.blocks[nb].prim + col + (i < u0.is ? u0.nx1 : -u0.nx1);
+      if (nb >= 0) prim = input_of(nb) + col + (i < u0.is ? u0.nx1 : -u0.nx1);
       prim_jm = prim - u0.sj;
       prim_jp = prim + u0.sj;
       prim_klo = prim_khi = prim;
     } else {
-      if (j - 1 < u0.js && fn[2] >= 0) prim_jm = u0.blocks[fn[2]].prim + col + (int64_t)(u0.nx2 - 1) * u0.sj;
-      if (j + 1 > u0.je && fn[3] >= 0) prim_jp = u0.blocks[fn[3]].prim + col - (int64_t)(u0.nx2 - 1) * u0.sj;
-      if (fn[4] >= 0) prim_klo = u0.blocks[fn[4]].prim + col + (int64_t)u0.nx3 * u0.sk;
-      if (fn[5] >= 0) prim_khi = u0.blocks[fn[5]].prim + col - (int64_t)u0.nx3 * u0.sk;
+      if (j - 1 < u0.js && fn[2] >= 0) prim_jm = input_of(fn[2]) + col + (int64_t)(u0.nx2 - 1) * u0.sj;
+      if (j + 1 > u0.je && fn[3] >= 0) prim_jp = input_of(fn[3]) + col - (int64_t)(u0.nx2 - 1) * u0.sj;
+      if (fn[4] >= 0) prim_klo = input_of(fn[4]) + col + (int64_t)u0.nx3 * u0.sk;
+      if (fn[5] >= 0) prim_khi = input_of(fn[5]) + col - (int64_t)u0.nx3 * u0.sk;
     }
   }
   const double area1 = b0.dx[1] * b0.dx[2], area2 = b0.dx[0] * b0.dx[2], area3 = b0.dx[0] * b0.dx[1];
@@ -830,9 +852,9 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
   double *st_f3 = stash + lane;            // [q * 64]: permuted x3 flux at face c-1
   double *st_du = stash + NV * 64 + lane;  // [n * 64]: (x1 term + x2 term) of plane c-1, natural order
   double wprev[NV];                        // natural-order state of plane c-1
+  load_input_state<FLUID, FROM_CONS>(((s - 1 < u0.ks) ? prim_klo : prim) + (int64_t)(s - 1) * u0.sk, u0.sn, sp, wprev);
 #pragma unroll
   for (int n = 0; n < NV; ++n) {
-    wprev[n] = ((s - 1 < u0.ks) ? prim_klo : prim)[n * u0.sn + (int64_t)(s - 1) * u0.sk];
     st_f3[n * 64] = 0.0;
     st_du[n * 64] = 0.0;
   }
@@ -861,7 +883,7 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
   // The next plane is requested one iteration ahead (its 9 loads have a whole iteration of four Riemann
   // solves to land: 1.69 -> 1.62 ms on 8 x 128^3) where the registers allow it: with FillDerived in the
   // kernel 243 VGPRs; without (refined meshes) the 18 extra registers would spill.
-  constexpr bool PF = (APK_DC3_PREFETCH != 0) && (EXTRA != EXTRA_NONE);
+  constexpr bool PF = (APK_DC3_PREFETCH != 0) && (EXTRA != EXTRA_NONE) && !FROM_CONS;
   double wnext[NV];
   if constexpr (PF) {
 #pragma unroll
@@ -880,8 +902,7 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
       }
     } else {
       const double *pc = (c > u0.ke) ? prim_khi : prim;  // wave-uniform choice (c >= s >= ks)
-#pragma unroll
-      for (int n = 0; n < NV; ++n) wc[n] = pc[n * u0.sn + off];
+      load_input_state<FLUID, FROM_CONS>(pc + off, u0.sn, sp, wc);
     }
     // ---- x3 face c (between planes c-1 and c)
     {
@@ -953,20 +974,22 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
       double flo[NV];
       double cf2_c = 0.0;
       {
-        double wm[NV], w2[NV];
+        double wm[NV], w2[NV], wnat[NV];
+        load_input_state<FLUID, FROM_CONS>(prim_jm + off, u0.sn, sp, wnat);
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-          wm[q] = prim_jm[perm<2>(q) * u0.sn + off];
+          wm[q] = wnat[perm<2>(q)];
           w2[q] = wc[perm<2>(q)];
         }
         cf2_c = cf_of(w2);
         solve(wm, w2, cf_of(wm), cf2_c, flo);
       }
       {
-        double wp[NV], w2[NV], fhi[NV];
+        double wp[NV], w2[NV], fhi[NV], wnat[NV];
+        load_input_state<FLUID, FROM_CONS>(prim_jp + off, u0.sn, sp, wnat);
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-          wp[q] = prim_jp[perm<2>(q) * u0.sn + off];
+          wp[q] = wnat[perm<2>(q)];
           w2[q] = wc[perm<2>(q)];
         }
         solve(w2, wp, cf2_c, cf_of(wp), fhi);
@@ -1009,7 +1032,7 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
 #ifndef APK_DC3_ROWS
 #define APK_DC3_ROWS 2  // 1: always the one-row kernel (A/B)
 #endif
-template <int FLUID, int RS, int EXTRA>
+template <int FLUID, int RS, int EXTRA, bool FROM_CONS = false>
 __global__ void __launch_bounds__(64, 2)
 fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, int nseg, int per_xcd) {
   constexpr int NV = nvars<FLUID>();
@@ -1039,22 +1062,23 @@ fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, 
   const bool shell_i = (i < u0.is + u0.ng) || (i > u0.ie - u0.ng);
   const bool shell_ij[2] = {shell_i || (ja < u0.js + u0.ng) || (ja > u0.je - u0.ng),
                             shell_i || (ja + 1 < u0.js + u0.ng) || (ja + 1 > u0.je - u0.ng)};  // (apk_stage_args.cons_store)
-  const double *prim = b0.prim + col;  // cell A's column; cell B's is prim + sj
+  auto input_of = [&](int blk) -> const double * { return FROM_CONS ? u1.blocks[blk].cons : u0.blocks[blk].prim; };  // (see fused_dc3_kernel)
+  const double *prim = input_of(b) + col;  // cell A's column; cell B's is prim + sj
   const double *prim_jm = prim - u0.sj, *prim_jp = prim + 2 * u0.sj;
   const double *prim_klo = prim, *prim_khi = prim;
   if (sp.face_nbr) {  // direct neighbour addressing, as in fused_dc3_kernel
     const int *fn = sp.face_nbr + 6 * b;
     if (i < u0.is || i > u0.ie) {
       const int nb = fn[i < u0.is ? 0 : 1];
-      if (nb >= 0) prim = u0.blocks[nb].prim + col + (i < u0.is ? u0.nx1 : -u0.nx1);
+      if (nb >= 0) prim = input_of(nb) + col + (i < u0.is ? u0.nx1 : -u0.nx1);
       prim_jm = prim - u0.sj;
       prim_jp = prim + 2 * u0.sj;
       prim_klo = prim_khi = prim;
     } else {
-      if (ja - 1 < u0.js && fn[2] >= 0) prim_jm = u0.blocks[fn[2]].prim + col + (int64_t)(u0.nx2 - 1) * u0.sj;
-      if (ja + 2 > u0.je && fn[3] >= 0) prim_jp = u0.blocks[fn[3]].prim + col + 2 * u0.sj - (int64_t)u0.nx2 * u0.sj;
-      if (fn[4] >= 0) prim_klo = u0.blocks[fn[4]].prim + col + (int64_t)u0.nx3 * u0.sk;
-      if (fn[5] >= 0) prim_khi = u0.blocks[fn[5]].prim + col - (int64_t)u0.nx3 * u0.sk;
+      if (ja - 1 < u0.js && fn[2] >= 0) prim_jm = input_of(fn[2]) + col + (int64_t)(u0.nx2 - 1) * u0.sj;
+      if (ja + 2 > u0.je && fn[3] >= 0) prim_jp = input_of(fn[3]) + col + 2 * u0.sj - (int64_t)u0.nx2 * u0.sj;
+      if (fn[4] >= 0) prim_klo = input_of(fn[4]) + col + (int64_t)u0.nx3 * u0.sk;
+      if (fn[5] >= 0) prim_khi = input_of(fn[5]) + col - (int64_t)u0.nx3 * u0.sk;
     }
   }
   const double area1 = b0.dx[1] * b0.dx[2], area2 = b0.dx[0] * b0.dx[2], area3 = b0.dx[0] * b0.dx[1];
@@ -1080,9 +1104,9 @@ fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, 
   double wprev[2][NV], cf3_prev[2] = {0.0, 0.0};
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
+    load_input_state<FLUID, FROM_CONS>(((s - 1 < u0.ks) ? prim_klo : prim) + (int64_t)(s - 1) * u0.sk + r * u0.sj, u0.sn, sp, wprev[r]);
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
-      wprev[r][n] = ((s - 1 < u0.ks) ? prim_klo : prim)[n * u0.sn + (int64_t)(s - 1) * u0.sk + r * u0.sj];
       st_f3[r][n * 64] = 0.0;
       st_du[r][n * 64] = 0.0;
     }
@@ -1099,9 +1123,7 @@ fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, 
     {
       const double *pc = (c > u0.ke) ? prim_khi : prim;  // wave-uniform
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int n = 0; n < NV; ++n) wc[r][n] = pc[n * u0.sn + off + r * u0.sj];
+      for (int r = 0; r < 2; ++r) load_input_state<FLUID, FROM_CONS>(pc + off + r * u0.sj, u0.sn, sp, wc[r]);
     }
     // ---- x3 faces c of both cells; plane c-1 is complete
 #pragma unroll
@@ -1161,9 +1183,10 @@ fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, 
       const double cfa = cf_of(wa), cfb = cf_of(wb);
       solve(wa, wb, cfa, cfb, fmid);
       {
-        double wm[NV], flo[NV];
+        double wm[NV], flo[NV], wnat[NV];
+        load_input_state<FLUID, FROM_CONS>(prim_jm + off, u0.sn, sp, wnat);
 #pragma unroll
-        for (int q = 0; q < NV; ++q) wm[q] = prim_jm[perm<2>(q) * u0.sn + off];
+        for (int q = 0; q < NV; ++q) wm[q] = wnat[perm<2>(q)];
         solve(wm, wa, cf_of(wm), cfa, flo);
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
@@ -1172,9 +1195,10 @@ fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, 
         }
       }
       {
-        double wp[NV], fhi[NV];
+        double wp[NV], fhi[NV], wnat[NV];
+        load_input_state<FLUID, FROM_CONS>(prim_jp + off, u0.sn, sp, wnat);
 #pragma unroll
-        for (int q = 0; q < NV; ++q) wp[q] = prim_jp[perm<2>(q) * u0.sn + off];
+        for (int q = 0; q < NV; ++q) wp[q] = wnat[perm<2>(q)];
         solve(wb, wp, cfb, cf_of(wp), fhi);
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
@@ -1329,6 +1353,11 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
                                               : two_kernel_stage_applies(u0, RECON, extra, sp);
     if (u0.ndim != 3 || sp.mflux || sp.dedner == 2 || !form_ok) return APK_ERR_UNSUPPORTED;
   }
+  // apk_stage_args.fill_derived = 3 / prim_from_cons: the lean two-kernel stage / the lean single-march donor-cell stage only
+  if (sp.no_prim_store && !(u0.ndim == 3 && RECON != APK_RC_DC && stage_is_lean(sp) && two_kernel_stage_applies(u0, RECON, extra, sp)))
+    return APK_ERR_UNSUPPORTED;
+  if (sp.prim_from_cons && !(u0.ndim == 3 && RECON == APK_RC_DC && stage_is_lean(sp) && (extra == EXTRA_NONE || sp.prim_to_u1)))
+    return APK_ERR_UNSUPPORTED;
   const bool do_x1 = sp.phase != 2, do_rest = sp.phase != 1;
   // timing slots: donor-cell stages (VL2 predictor) are accounted separately
   constexpr int TS = (RECON == APK_RC_DC) ? (int)APK_T_FUSED_DC_X1 : (int)APK_T_FUSED_X1;
@@ -1375,13 +1404,28 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
           const int per_xcd2 = (int)((total2 + 7) / 8);
           const dim3 g2((unsigned)(per_xcd2 * 8), 1, 1);
           constexpr int lds4 = 4 * nvars<FLUID>() * 64 * (int)sizeof(double);
-          ScopedTiming t2(sp.ctx, TS + 0, s);
-          if (extra == EXTRA_C2P_DT)
-            hipLaunchKernelGGL((fused_dc3r2_kernel<FLUID, RS, EXTRA_C2P_DT>), g2, dim3(64), lds4, s, u0, u1, sp, kseg, wpb2, nseg, per_xcd2);
-          else if (extra == EXTRA_C2P)
-            hipLaunchKernelGGL((fused_dc3r2_kernel<FLUID, RS, EXTRA_C2P>), g2, dim3(64), lds4, s, u0, u1, sp, kseg, wpb2, nseg, per_xcd2);
-          else
-            hipLaunchKernelGGL((fused_dc3r2_kernel<FLUID, RS, EXTRA_NONE>), g2, dim3(64), lds4, s, u0, u1, sp, kseg, wpb2, nseg, per_xcd2);
+#define APK_LAUNCH_DC3R2(EXTRA_, FC_) \
+  hipLaunchKernelGGL((fused_dc3r2_kernel<FLUID, RS, EXTRA_, FC_>), g2, dim3(64), lds4, s, u0, u1, sp, kseg, wpb2, nseg, per_xcd2)
+          if (extra == EXTRA_C2P_DT) {
+            if (sp.prim_from_cons) APK_LAUNCH_DC3R2(EXTRA_C2P_DT, true);
+            else APK_LAUNCH_DC3R2(EXTRA_C2P_DT, false);
+          } else if (extra == EXTRA_C2P) {
+            if (sp.prim_from_cons) APK_LAUNCH_DC3R2(EXTRA_C2P, true);
+            else APK_LAUNCH_DC3R2(EXTRA_C2P, false);
+          } else {
+            if (sp.prim_from_cons) APK_LAUNCH_DC3R2(EXTRA_NONE, true);
+            else APK_LAUNCH_DC3R2(EXTRA_NONE, false);
+          }
+#undef APK_LAUNCH_DC3R2
+          return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
+        }
+        if (sp.prim_from_cons) {  // (one row per lane: odd row counts, the windows of a split stage)
+#define APK_LAUNCH_DC3FC(EXTRA_) \
+  hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_, true, true>), g, dim3(64), lds3, s, u0, u1, sp, kseg, wpb, nseg, per_xcd)
+          if (extra == EXTRA_C2P_DT) APK_LAUNCH_DC3FC(EXTRA_C2P_DT);
+          else if (extra == EXTRA_C2P) APK_LAUNCH_DC3FC(EXTRA_C2P);
+          else APK_LAUNCH_DC3FC(EXTRA_NONE);
+#undef APK_LAUNCH_DC3FC
           return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
         }
 #define APK_LAUNCH_DC3(EXTRA_, LEAN_) \

@@ -505,7 +505,33 @@ int materialize_local_ghosts(apk_sim *s) {
   return APK_OK;
 }
 
+// Can stage 1 of a cycle take its input from the conserved state, so that the last stage of the cycle before it need
+// not store primitives?  The single-march donor-cell stage in its lean form (uniform 3-D mesh, VL2), and a last stage
+// that is the lean two-kernel stage with the time-step estimate fused in.
+bool prim_free_cycle(const apk_sim *s) {
+  static const int mode = std::getenv("APK_PRIM_FREE") ? std::atoi(std::getenv("APK_PRIM_FREE")) : 1;  // A/B switch
+  static const int dc_mode = std::getenv("APK_DC_MODE") ? std::atoi(std::getenv("APK_DC_MODE")) : 2;
+  const HydroPackage &pkg = s->pkg;
+  if (!mode || !s->prim_free_on || s->amr || s->fmft || s->mesh.ndim != 3 || !stage_can_fuse(s) || dc_mode != 2) return false;
+  if (pkg.nscalars != 0 || (pkg.fluid == APK_FLUID_GLMMHD && pkg.glmmhd_source_extended) || !pkg.calc_dt_hyp) return false;
+  const apk_eos &e = pkg.eos;
+  if (!(e.vceil > 1.0e300 && e.eceil > 1.0e300 && e.pfloor <= 0.0)) return false;  // (eos_is_lean)
+  if (pkg.flux_first_stage.recon != APK_RC_DC || pkg.flux_other_stage.recon == APK_RC_DC || s->nstages < 2) return false;
+  return apk_stage_split_axis(s->mu0(), &pkg.flux_other_stage, 2) == 3;
+}
+
+int materialize_prim(apk_sim *s) {
+  if (!s->prim_stale) return APK_OK;
+  s->prim_stale = false;
+  return fill_derived(s);  // (every cell of every block: the ghost zones have been brought up to date by the caller)
+}
+
 int sync_ghosts(apk_sim *s) {
+  if (!s->amr && s->prim_stale) {
+    SIM_TRY(s, finish_pending(s));
+    SIM_TRY(s, materialize_local_ghosts(s));
+    return materialize_prim(s);
+  }
   if (s->amr) {
     if (s->amr_ghost_state == AMR_GHOSTS_COMPLETE) return APK_OK;
     // the stage loop left the ghost zones behind edges and corners alone (or filled all of them a few layers deep):
@@ -763,6 +789,10 @@ int do_stage(apk_sim *s, int stage) {
   // (a stage form that reads ghost zones after stages that did not fill the same-rank ones)
   const bool direct = direct_neighbors(s);
   if (!direct && s->local_ghosts_stale) SIM_TRY(s, sync_ghosts(s));
+  // (the full-step primitives were not stored: only the donor-cell predictor can do without them)
+  const bool prim_free = prim_free_cycle(s);
+  const bool from_cons = s->prim_stale && stage == 1 && prim_free;
+  if (s->prim_stale && !from_cons) SIM_TRY(s, sync_ghosts(s));
   if (stage == 1) {
     // "init u1" (hydro_driver.cpp:474-495) without the copy: the buffer holding u0 becomes the
     // register u1 and the stage writes the new u0 into the other buffer.  Valid because
@@ -828,6 +858,10 @@ int do_stage(apk_sim *s, int stage) {
     }
     a.fill_derived = fused_fill ? (swap_prim ? 2 : 1) : 0;
     a.estimate_dt = (fused_fill && stage == s->nstages && pkg.calc_dt_hyp) ? 1 : 0;
+    a.prim_from_cons = from_cons ? 1 : 0;
+    // the last stage of a cycle whose successor's predictor reads the conserved state: primitives for the dt estimate only
+    const bool no_prim = prim_free && stage == s->nstages && two_kernel && swap_prim && a.estimate_dt;
+    if (no_prim) a.fill_derived = 3;
     {
       // The predictor of VL2: the corrector has gam0 = 0 and takes its fluxes from the predictor's primitives, so the
       // half-step CONSERVED state is read by nobody but the ghost exchange -- the nghost-deep shell of every block --
@@ -873,7 +907,9 @@ int do_stage(apk_sim *s, int stage) {
     }
     SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
     s->stage_dt_pending = a.estimate_dt != 0;
-    if (swap_prim) s->pcur = 1 - s->pcur;
+    if (from_cons) s->prim_stale = false;  // (the predictor has written the half-step primitives: the current buffer is valid again)
+    if (no_prim) s->prim_stale = true;
+    else if (swap_prim) s->pcur = 1 - s->pcur;
     if (s->amr) {
       SIM_TRY(s, ensure_flux_arrays(s));
       const double psi_factor = a.dedner != 0 ? std::exp(-pkg.glmmhd_alpha * pkg.c_h * beta_dt / pkg.mindx) : 1.0;
@@ -1252,6 +1288,13 @@ int apk_sim_set_direct_neighbors(apk_sim *s, int on) {
   s->direct_on = on != 0;
   return APK_OK;
 }
+int apk_sim_set_prim_free(apk_sim *s, int on) {
+  if (!s) return APK_ERR_INVALID;
+  if (!s->host_only) SIM_TRY(s, sync_ghosts(s));
+  s->prim_free_on = on != 0;
+  return APK_OK;
+}
+int apk_sim_prim_is_stale(const apk_sim *s) { return (s && s->prim_stale) ? 1 : 0; }
 int apk_sim_set_amr_full_exchange(apk_sim *s, int on) {
   if (!s) return APK_ERR_INVALID;
   if (!s->host_only) SIM_TRY(s, sync_ghosts(s));

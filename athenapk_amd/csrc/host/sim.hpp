@@ -176,6 +176,12 @@ struct apk_sim {
   int *d_face_nbr = nullptr;
   bool local_ghosts_stale = false;
   bool direct_on = true;  // apk_sim_set_direct_neighbors
+  // The primitives of the current (full-step) state are not in memory: the last stage of the cycle computed them for
+  // the time-step estimate only (apk_stage_args.fill_derived = 3) because the first stage of the next cycle -- the
+  // donor-cell predictor -- derives its input from the conserved state (prim_from_cons).  Whatever else reads
+  // primitives goes through sync_ghosts(), which materialises them (ConsToPrim of every block).
+  bool prim_stale = false;
+  bool prim_free_on = true;  // apk_sim_set_prim_free / APK_PRIM_FREE=0 (A/B)
   long long skipped_local_exchanges = 0;
   // mesh refinement (parthenon/mesh/refinement = static | adaptive; one rank): the forest of
   // blocks, the index-box plans of the multilevel ghost exchange / flux correction and their device

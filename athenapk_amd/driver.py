@@ -398,6 +398,15 @@ class Simulation(_FmftHost, _MeshView):
         self._check(self.lib.apk_sim_set_direct_neighbors(self.h, int(on)))
         return self
 
+    def set_prim_free(self, on):
+        """full-step primitives kept out of memory where the cycle allows it (apk_sim_set_prim_free)"""
+        self._check(self.lib.apk_sim_set_prim_free(self.h, int(on)))
+        return self
+
+    @property
+    def prim_is_stale(self):
+        return bool(self.lib.apk_sim_prim_is_stale(self.h))
+
     def set_amr_full_exchange(self, on):
         """refined meshes: 1 = the stage loop exchanges every ghost zone, not only those behind block faces"""
         self._check(self.lib.apk_sim_set_amr_full_exchange(self.h, int(on)))

@@ -58,7 +58,7 @@ class StageArgs(C.Structure):
                 ("glmmhd_alpha", C.c_double), ("mindx", C.c_double), ("fill_derived", C.c_int),
                 ("estimate_dt", C.c_int), ("phase", C.c_int), ("window", C.c_void_p),
                 ("window_rl", C.c_int), ("window_rows", C.c_int), ("trial", C.c_int), ("count_unphysical", C.c_int), ("cons_out_delta", C.c_int64),
-                ("face_neighbor", C.c_void_p), ("cons_store", C.c_int)]
+                ("face_neighbor", C.c_void_p), ("cons_store", C.c_int), ("prim_from_cons", C.c_int)]
 
 
 class FmftBlock(C.Structure):
@@ -221,6 +221,8 @@ def _signatures():
         "apk_sim_skipped_local_exchanges": (ll, [vp]),
         "apk_sim_set_direct_neighbors": (C.c_int, [vp, C.c_int]),
         "apk_sim_set_amr_full_exchange": (C.c_int, [vp, C.c_int]),
+        "apk_sim_set_prim_free": (C.c_int, [vp, C.c_int]),
+        "apk_sim_prim_is_stale": (C.c_int, [vp]),
         "apk_sim_loop_seconds": (d, [vp]),
         "apk_sim_loop_cycles": (i, [vp]),
         "apk_sim_get_info": (i, [vp, C.POINTER(SimInfo)]),

@@ -242,6 +242,15 @@ typedef struct apk_stage_args {
    * system's rate.  Honoured by the 3-D single-march donor-cell stage in its lean form; every other stage form
    * stores all cells (always a valid reading of 1 and 2).  The cells not stored keep whatever they held. */
   int cons_store;
+  /* prim_from_cons = 1: u0.prim does NOT hold the primitives of the stage's input state; the kernel derives them from
+   * u1.cons, which must be that state (true in stage 1 of every integrator: u1 = u0 there, hydro_driver.cpp:474-495).
+   * The single-march 3-D donor-cell stage in its lean form only (else APK_ERR_UNSUPPORTED).  Together with
+   * fill_derived = 3 in the last stage of the previous cycle it removes the full-step primitives from memory
+   * altogether: 72 B per cell less to store there and 72 B less to load here, both on kernels that run at the memory
+   * system's rate.
+   * fill_derived = 3 (listed here, with estimate_dt = 1): ConsToPrim of the updated cells for the time-step estimate
+   * only; neither u0.prim nor u1.prim is written.  Two-kernel 3-D stage in its lean form only. */
+  int prim_from_cons;
 } apk_stage_args;
 int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
                     const apk_stage_args *args, apk_stream_t stream);

@@ -117,7 +117,16 @@ long long apk_sim_overlapped_exchanges(const apk_sim *sim);
  * on demand (every accessor does).  Results are identical.  APK_DIRECT_NEIGHBORS=0 in the environment
  * switches it off.  Returns the number of stage boundaries so far whose same-rank copies were skipped. */
 long long apk_sim_skipped_local_exchanges(const apk_sim *sim);
-int apk_sim_set_direct_neighbors(apk_sim *sim, int on); /* 1 (default) / 0 = always copy */
+int apk_sim_set_direct_neighbors(apk_sim *sim, int on);
+/* Full-step primitives kept out of memory (on by default where it applies: uniform 3-D meshes, VL2 -- a donor-cell
+ * predictor followed by a two-kernel stage --, default equation-of-state limits, no passive scalars, no extended Dedner
+ * source, no forcing): the last stage of a cycle computes the primitives of the new state for the time-step estimate
+ * only (apk_stage_args.fill_derived = 3) and the predictor of the next cycle derives its input from the conserved state
+ * (prim_from_cons) -- the reference stores them in FillDerived (hydro_driver.cpp:571-577) and reads them back in
+ * CalculateFluxes.  Every accessor materialises them on demand; results are identical.  APK_PRIM_FREE=0 in the
+ * environment switches it off.  apk_sim_prim_is_stale: 1 while the primitives of the current state are not in memory. */
+int apk_sim_set_prim_free(apk_sim *sim, int on);
+int apk_sim_prim_is_stale(const apk_sim *sim); /* 1 (default) / 0 = always copy */
 /* Refined meshes: the stage loop's exchange leaves out the ghost zones behind block edges and corners
  * (no sweep or flux correction reads them; accessors, tagging and the last exchange of a cycle that
  * checks the refinement criteria complete them).  1 = always exchange in full (what APK_AMR_FULL_EXCHANGE=1

@@ -304,6 +304,49 @@ def test_rehearsed_remote_faces_give_the_periodic_box(strict, scheme, overlap):
     _assert_same(b.gather("prim"), a.gather("prim"), strict)
 
 
+# ---- full-step primitives kept out of memory --------------------------------------------------------------------
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("layout", [((64, 64, 64), (32, 32, 32), []), ((64, 32, 32), (32, 32, 16), []),
+                                    ((64, 64, 64), (32, 32, 32), ["apk_amd/rehearse_remote_faces=true"]),
+                                    ((64, 32, 34), (32, 16, 17), [])],
+                         ids=["2x2x2", "2x1x2", "rehearsed_remote_faces", "odd_nx3_and_row_pairs"])
+def test_cycle_without_stored_primitives_equals_the_cycle_with_them(strict, layout):
+    """VL2 on a uniform 3-D mesh: the corrector computes the new primitives for the time-step estimate only and the
+    predictor of the next cycle derives its input from the conserved state (apk_sim_set_prim_free; also the conserved
+    half-step state is only stored where it is read).  Same bits as the cycle that stores and re-reads everything, at
+    every accessor, which materialises the primitives on demand."""
+    (n1, n2, n3), (m1, m2, m3), extra = layout
+    ov = ["parthenon/mesh/nx1=%d" % n1, "parthenon/mesh/nx2=%d" % n2, "parthenon/mesh/nx3=%d" % n3,
+          "parthenon/meshblock/nx1=%d" % m1, "parthenon/meshblock/nx2=%d" % m2, "parthenon/meshblock/nx3=%d" % m3] + extra
+    a = _sim("synthetic_mhd", ov, strict=strict).initialize()
+    b = _sim("synthetic_mhd", ov, strict=strict)
+    b.set_prim_free(False)
+    b.initialize()
+    for _ in range(3):
+        a.step()
+        b.step()
+    assert a.prim_is_stale and not b.prim_is_stale
+    _assert_same(np.asarray(a.dt), np.asarray(b.dt), strict)
+    _assert_same(a.gather(), b.gather(), strict)
+    _assert_same(a.gather("prim"), b.gather("prim"), strict)   # (materialised by the accessor)
+    assert not a.prim_is_stale
+    a.step()                                                    # the predictor reads stored primitives again ...
+    b.step()
+    assert a.prim_is_stale                                      # ... and the cycle ends without them
+    for lb in range(a.info.nblocks_local):
+        for field in ("cons", "prim"):
+            _assert_same(a.read_block(lb, field), b.read_block(lb, field), strict)   # ghost zones included
+    # switching it off in mid-run
+    a.step()
+    a.set_prim_free(False)
+    b.step()
+    a.step()
+    b.step()
+    assert not a.prim_is_stale
+    _assert_same(a.gather(), b.gather(), strict)
+    _assert_same(np.asarray(a.dt), np.asarray(b.dt), strict)
+
+
 # ---- direct neighbour addressing: the uniform-mesh cycle without same-rank ghost copies ------------------
 @pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
 @pytest.mark.parametrize("scheme", [("vl2", "ppm", 3), ("rk3", "wenoz", 3), ("rk2", "plm", 2)], ids=["vl2_ppm", "rk3_wenoz", "rk2_plm"])

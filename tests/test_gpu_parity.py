@@ -633,6 +633,66 @@ def test_lean_stage_forms_and_conserved_store_modes(request, oracle, fluid, reco
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("fluid,riemann,nx", [("glmmhd", "hlld", (64, 8, 34)), ("glmmhd", "hlld", (40, 9, 10)),
+                                              ("euler", "hllc", (66, 12, 9)), ("glmmhd", "hlle", (34, 10, 8))])
+def test_donor_cell_stage_takes_its_input_from_the_conserved_state(request, oracle, fluid, riemann, nx, strict):
+    """apk_stage_args.prim_from_cons: u0.prim holds garbage, u1.cons the state; the lean single-march donor-cell stage
+    (one and two rows per lane) derives the primitives itself and must give what the stage gives when handed them."""
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    ng, prim, g = _case(fluid, "dc", nx, kind="smooth", seed=151, nblocks=2)
+    cons = H.prim_to_cons(fluid, prim, GAMMA)
+    # (the primitives the finishing sweep of the previous stage would have stored: ConsToPrim of the conserved state)
+    _, prim_of_cons, bad = H.orc_c2p(fluid, g, cons.copy(), oracle.make_eos(GAMMA))
+    assert bad == 0
+    ded = 1 if fluid == "glmmhd" else 0
+    garbage = np.full_like(prim, np.nan)
+    m0 = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=2, cons=cons, prim=garbage, with_flux=False)
+    m1 = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=2, cons=cons, prim=np.full_like(prim, -7.0), with_flux=False)
+    ctx.poll_flags()
+    hydro.StageFused(m0, m1, fluid, "dc", riemann, hydro.L.make_eos(GAMMA), C_H, 0.0, 1.0, 0.004, dedner=ded, glmmhd_alpha=0.1,
+                     mindx=0.07, fill_derived=2, prim_from_cons=True)
+    want_cons = H.orc_stage(fluid, "dc", riemann, g, cons, cons, prim_of_cons, GAMMA, C_H, 0.0, 1.0, 0.004, dedner=ded, alpha=0.1, mindx=0.07)
+    want_cons, want_prim, bad = H.orc_c2p(fluid, g, want_cons, oracle.make_eos(GAMMA))
+    assert bad == 0 and ctx.poll_flags() == 0
+    _cmp(H.interior(m0.cons_host(), nx, ng), H.interior(want_cons, nx, ng), strict, "cons")
+    _cmp(H.interior(m1.prim_host(), nx, ng), H.interior(want_prim, nx, ng), strict, "u1.prim")
+    # a non-lean stage refuses
+    with pytest.raises(Exception):
+        hydro.StageFused(m0, m1, fluid, "dc", riemann, hydro.L.make_eos(GAMMA, pfloor=1e-6), C_H, 0.0, 1.0, 0.004, dedner=ded,
+                         glmmhd_alpha=0.1, mindx=0.07, fill_derived=2, prim_from_cons=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("recon,gam0", [("ppm", 0.0), ("wenoz", 0.25)])
+def test_time_step_estimate_without_stored_primitives(request, oracle, recon, gam0, strict):
+    """fill_derived = 3: the finishing march of the lean two-kernel stage computes the primitives of the cells it updates
+    for the time-step estimate only -- same estimate, same conserved state as fill_derived = 2, and neither prim array
+    is written."""
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    fluid, riemann, nx = "glmmhd", "hlld", (70, 9, 7)
+    ng, prim, g = _case(fluid, recon, nx, kind="smooth", seed=157, nblocks=2)
+    cons = H.prim_to_cons(fluid, prim, GAMMA)
+    u1c = cons * 1.01 if gam0 != 0.0 else cons
+    out = {}
+    for fd in (2, 3):
+        m0 = hydro.MeshData(ctx, nx, ng, 9, dx=tuple(g.dx), nblocks=2, cons=cons, prim=prim, with_flux=False)
+        m1 = hydro.MeshData(ctx, nx, ng, 9, dx=tuple(g.dx), nblocks=2, cons=u1c, prim=np.full_like(prim, -7.0), with_flux=False)
+        hydro.StageFused(m0, m1, fluid, recon, riemann, hydro.L.make_eos(GAMMA), C_H, gam0, 1.0 - gam0, 0.004, dedner=1,
+                         glmmhd_alpha=0.1, mindx=0.07, fill_derived=fd, estimate_dt=True)
+        out[fd] = (hydro.StageDt(ctx, 0.3), m0.cons_host(), m0.prim_host(), m1.prim_host())
+    assert out[3][0] == out[2][0] and np.array_equal(out[3][1], out[2][1])
+    assert np.array_equal(out[3][2], prim) and np.all(out[3][3] == -7.0), "fill_derived = 3 must not write primitives"
+    assert not np.all(out[2][3] == -7.0)
+    with pytest.raises(Exception):   # nothing to do without the estimate
+        hydro.StageFused(m0, m1, fluid, recon, riemann, hydro.L.make_eos(GAMMA), C_H, gam0, 1.0 - gam0, 0.004, dedner=1,
+                         glmmhd_alpha=0.1, mindx=0.07, fill_derived=3, estimate_dt=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
 @pytest.mark.parametrize("fluid,recon,riemann,nx", [("glmmhd", "ppm", "hlld", (70, 9, 7)),
                                                     ("glmmhd", "wenoz", "hlld", (64, 8, 8)),
                                                     ("euler", "plm", "hllc", (66, 10, 1))])
