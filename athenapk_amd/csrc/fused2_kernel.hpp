@@ -122,7 +122,7 @@ __device__ unsigned long long g_m12f_phase[8];
 template <int FLUID, int RECON, int RS, int EXTRA, bool LEAN>
 __global__ void __launch_bounds__(64, APK_M12F_WAVES)
 fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves, int per_xcd,
-                  long long total_rows) {
+                  long long total_rows, int sched_lockstep) {
   static_assert(RECON != APK_RC_DC, "donor-cell stages have their own single-kernel form");
   constexpr int NV = nvars<FLUID>();
   constexpr int H = recon_halfwidth(RECON);
@@ -140,15 +140,42 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
   unsigned long long tick_ = clock64();
 #endif
 
+  // Work of this wave (wave-uniform).  sched_lockstep = 0: the (block, chunk) columns x nx2 rows as one list cut into
+  // equal contiguous ranges.  1 (default): wave w marches WHOLE columns w, w + nwaves, ... and then a segment of the
+  // columns left over, neighbouring waves taking neighbouring columns over the same rows -- all waves of an XCD are then
+  // at (about) the same row at the same time, and the two waves that share a cache line at the seam of their 58-cell
+  // chunks write it within an iteration of each other: the L2 merges the two partial writes into one full line.  Written
+  // apart (ranges that start 20 rows apart, as in the equal split) every seam line goes to memory twice as a partial
+  // write.  tools/ubench/ubench_march_traffic.hip: the march's 27 load + 18 store streams, no arithmetic, 1.86 ms with
+  // the equal split and 1.36 ms in lockstep (profiles/r04_ubench_march_traffic.jsonl).
+  const int ncol = (int)(total_rows / u0.nx2);
+  const int full = sched_lockstep ? ncol / nwaves : 0, left_cols = ncol - full * nwaves;
+  const int per_col = (sched_lockstep && left_cols > 0) ? nwaves / left_cols : 0;  // segments per leftover column (>= 1)
+  const int seg = per_col > 0 ? (u0.nx2 + per_col - 1) / per_col : 0;
   long long r = total_rows * w / nwaves;
   const long long r_end = total_rows * (w + 1) / nwaves;
-  while (r < r_end) {  // wave-uniform
+  int piece = 0;
+  while (sched_lockstep ? piece <= full : r < r_end) {  // wave-uniform
     // ---- this piece: rows s..e of column chunk `chunk` of block b
-    const int item = (int)(r / u0.nx2);
-    const int j0 = (int)(r - (long long)item * u0.nx2);
-    const long long left = r_end - r;
-    const int nrows = (left < (long long)(u0.nx2 - j0)) ? (int)left : (u0.nx2 - j0);
-    r += nrows;
+    int item, j0, nrows;
+    if (sched_lockstep) {
+      if (piece < full) {
+        item = piece * nwaves + w, j0 = 0, nrows = u0.nx2;
+      } else {
+        if (left_cols <= 0) break;
+        const int sidx = w / left_cols, lc = w - sidx * left_cols;
+        if (sidx >= per_col || sidx * seg >= u0.nx2) break;
+        item = full * nwaves + lc, j0 = sidx * seg;
+        nrows = (j0 + seg <= u0.nx2) ? seg : u0.nx2 - j0;
+      }
+      ++piece;
+    } else {
+      item = (int)(r / u0.nx2);
+      j0 = (int)(r - (long long)item * u0.nx2);
+      const long long left = r_end - r;
+      nrows = (left < (long long)(u0.nx2 - j0)) ? (int)left : (u0.nx2 - j0);
+      r += nrows;
+    }
     const int b = item / wpb;
     const int chunk = item - b * wpb;
     const apk_block_desc b0 = u0.blocks[b];
@@ -509,8 +536,9 @@ inline void launch_m12f(const PackView &u0, const PackView &u1, const StageParam
     // (APK_NO_LEAN=1: the general kernel also where the lean one applies, A/B)
     static const bool no_lean = std::getenv("APK_NO_LEAN") && std::atoi(std::getenv("APK_NO_LEAN")) != 0;
     const bool lean = stage_is_lean(sp) && !no_lean;
+    static const int lockstep = std::getenv("APK_M12F_LOCKSTEP") ? std::atoi(std::getenv("APK_M12F_LOCKSTEP")) : 1;  // A/B switch
 #define APK_LAUNCH_M12F(EXTRA_, LEAN_) \
-  hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, LEAN_>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows)
+  hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, LEAN_>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows, lockstep)
     if (extra == EXTRA_C2P_DT) {
       if (lean) APK_LAUNCH_M12F(EXTRA_C2P_DT, true);
       else APK_LAUNCH_M12F(EXTRA_C2P_DT, false);

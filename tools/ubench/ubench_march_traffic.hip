@@ -11,7 +11,7 @@
 
 constexpr int NV = 9, N = 134, NI = 128;
 
-template <int NLOAD_ARR, int NSTORE_ARR, bool INTERLEAVED, int MODE = 0>
+template <int NLOAD_ARR, int NSTORE_ARR, bool INTERLEAVED, int MODE = 0, int SCHED = 0>
 __global__ void __launch_bounds__(64, 2) march(const double *in, double *out, long long sn_block, int nwaves, long long total_rows, int wpb) {
   extern __shared__ double pad[];  // 18 KB: two waves per SIMD, as the march
   const int lane = threadIdx.x;
@@ -23,14 +23,33 @@ __global__ void __launch_bounds__(64, 2) march(const double *in, double *out, lo
   constexpr int P = (MODE == 3) ? 160 : N, I0 = (MODE == 3) ? 16 : 3;
   const long long sj = INTERLEAVED ? (long long)NV * P : P, sk = sj * N, sn = INTERLEAVED ? P : (long long)P * N * N;
   long long r = total_rows * w / nwaves;
-  const long long r_end = total_rows * (w + 1) / nwaves;
+  long long r_end = total_rows * (w + 1) / nwaves;
   double acc = 0.0;
-  while (r < r_end) {
-    const int item = (int)(r / NI);
-    const int j0 = (int)(r - (long long)item * NI);
-    const long long left = r_end - r;
-    const int nrows = left < NI - j0 ? (int)left : NI - j0;
-    r += nrows;
+  // SCHED 1: wave w takes column w whole (all waves at the same row at the same time: the two waves that share a
+  // partially written cache line write it within one iteration of each other), then a share of the leftover columns
+  const int ncol = (int)(total_rows / NI);
+  int piece = 0;
+  const int left_cols = ncol - nwaves, seg = left_cols > 0 ? (left_cols * NI + nwaves - 1) / nwaves : 0;
+  while (SCHED == 1 ? piece < 2 : r < r_end) {
+    int item, j0, nrows;
+    if (SCHED == 1) {
+      if (piece == 0) {
+        item = w, j0 = 0, nrows = NI;
+      } else {
+        if (left_cols <= 0) break;
+        const int per_col = (NI + seg - 1) / seg;       // segments per leftover column
+        const int sidx = w / left_cols, lc = w - sidx * left_cols;  // adjacent waves: adjacent columns, same rows
+        if (sidx >= per_col) break;
+        item = nwaves + lc, j0 = sidx * seg, nrows = (j0 + seg <= NI) ? seg : NI - j0;
+      }
+      ++piece;
+    } else {
+      item = (int)(r / NI);
+      j0 = (int)(r - (long long)item * NI);
+      const long long left = r_end - r;
+      nrows = left < NI - j0 ? (int)left : NI - j0;
+      r += nrows;
+    }
     const int b = item / wpb, chunk = item - b * wpb;
     int k, i;
     if (MODE >= 2) {
@@ -71,7 +90,7 @@ __global__ void __launch_bounds__(64, 2) march(const double *in, double *out, lo
   if (acc == 12345.678) pad[lane] = acc, out[0] = pad[lane];
 }
 
-template <int L, int S, bool I, int MODE = 0>
+template <int L, int S, bool I, int MODE = 0, int SCHED = 0>
 static void run(const char *name, const double *in, double *out, long long snb) {
   const int wpb = (MODE >= 2) ? NI * NI / 64 : (NI * N + 57) / 58, nwaves = 2048;
   const long long total_rows = 8LL * wpb * NI;
@@ -81,7 +100,7 @@ static void run(const char *name, const double *in, double *out, long long snb) 
   float best = 1e30f;
   for (int rep = 0; rep < 4; ++rep) {
     CHECK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL((march<L, S, I, MODE>), dim3(((nwaves + 7) / 8) * 8), dim3(64), 18432, 0, in, out, snb, nwaves, total_rows, wpb);
+    hipLaunchKernelGGL((march<L, S, I, MODE, SCHED>), dim3(((nwaves + 7) / 8) * 8), dim3(64), 18432, 0, in, out, snb, nwaves, total_rows, wpb);
     CHECK(hipEventRecord(e1, 0));
     CHECK(hipEventSynchronize(e1));
     float ms;
@@ -107,6 +126,9 @@ int main() {
   run<1, 1, false>("9 load + 9 store", in, out, snb);
   run<3, 2, false, 1>("march, lanes 3..60 store", in, out, snb);
   run<1, 1, false, 1>("9 + 9, lanes 3..60 store", in, out, snb);
+  run<3, 2, false, 1, 1>("march, lanes 3..60 store, one column per wave in lockstep", in, out, snb);
+  run<3, 1, false, 1, 0>("27 + 9, lanes 3..60 store, equal split", in, out, snb);
+  run<3, 1, false, 1, 1>("27 + 9, lanes 3..60 store, lockstep", in, out, snb);
   run<3, 2, false, 2>("64-cell interior chunks, pitch 134", in, out, snb);
   run<1, 1, false, 2>("9 + 9, 64-cell interior chunks, pitch 134", in, out, snb);
   run<3, 2, false, 3>("64-cell interior chunks, pitch 160 aligned", in, out, snb);
