@@ -1117,13 +1117,39 @@ fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, 
       cf3_prev[r] = cf_of(wp3);
     }
   }
+  // (APK_DC3R2_PREFETCH: the raw values of the next plane's two cells are requested one iteration ahead, A/B)
+#ifndef APK_DC3R2_PREFETCH
+#define APK_DC3R2_PREFETCH 0
+#endif
+  constexpr bool PF = APK_DC3R2_PREFETCH != 0;
+  double raw[2][NV];
+  auto load_raw = [&](int c) {
+    const double *pc = ((c > u0.ke) ? prim_khi : prim) + (int64_t)c * u0.sk;  // wave-uniform
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int n = 0; n < NV; ++n) raw[r][n] = pc[n * u0.sn + r * u0.sj];
+  };
+  auto to_input = [&](const double (&u)[NV], double (&w)[NV]) {
+    if constexpr (FROM_CONS) {
+      double t[NV], di;
+#pragma unroll
+      for (int n = 0; n < NV; ++n) t[n] = u[n];
+      (void)cons_to_prim_core<FLUID, true>(sp.eos, sp.k.eos_gm1, sp.k.vceil_sq, sp.k.pfloor_over_gm1, t, w, di);
+    } else {
+#pragma unroll
+      for (int n = 0; n < NV; ++n) w[n] = u[n];
+    }
+  };
+  if constexpr (PF) load_raw(s);
   for (int c = s; c <= e + 1; ++c) {
     const int64_t off = (int64_t)c * u0.sk;
     double wc[2][NV];
-    {
-      const double *pc = (c > u0.ke) ? prim_khi : prim;  // wave-uniform
-#pragma unroll
-      for (int r = 0; r < 2; ++r) load_input_state<FLUID, FROM_CONS>(pc + off + r * u0.sj, u0.sn, sp, wc[r]);
+    if constexpr (!PF) load_raw(c);
+    to_input(raw[0], wc[0]);
+    to_input(raw[1], wc[1]);
+    if constexpr (PF) {
+      if (c <= e) load_raw(c + 1);
     }
     // ---- x3 faces c of both cells; plane c-1 is complete
 #pragma unroll

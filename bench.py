@@ -207,7 +207,8 @@ def rocprof_kernels(fluid, recon, riemann):
     return {"fused_x1": "fused_m12f_kernel<%d, %d, %d, 2, true> / <%d, %d, %d, 0, true> (x1 + x2 finishing march; "
                         "last stage of a cycle with ConsToPrim + dt / other stages)" % (f, r, s, f, r, s),
             "fused_x3": "fused_march_kernel<%d, %d, %d, 3, false, 0> (x3 sweep)" % (f, r, s),
-            "fused_dc_x1": "fused_dc3_kernel<%d, %d, 1, true> (donor-cell predictor stage)" % (f, s)}
+            "fused_dc_x1": "fused_dc3r2_kernel<%d, %d, 1, true> (donor-cell predictor stage, two rows per lane, input derived from the "
+                           "conserved state; <.., false> in the first cycle)" % (f, s)}
 
 
 ROCPROF_KERNEL = rocprof_kernels("glmmhd", "ppm", "hlld")
