@@ -321,18 +321,20 @@ int estimate_timestep_read(apk_sim *s, DtEstimate *e) {
 }
 
 int estimate_timestep_commit(apk_sim *s, const DtEstimate &e, double *dt_out) {
-  if (e.flags & APK_FLAG_NEG_DENSITY)
-    return fail(s, APK_ERR_INVALID, "Got negative density. Consider enabling first-order flux correction or setting a reasonble density floor.");
-  if (e.flags & APK_FLAG_NEG_PRESSURE)
-    return fail(s, APK_ERR_INVALID, "Got negative pressure. Consider enabling first-order flux correction or setting a reasonble pressure or temperature floor.");
   double dt = e.dt_hyp_local;
   if (s->pkg.max_dt > 0.0 && s->pkg.max_dt < dt) dt = s->pkg.max_dt;
   // one reduction for both minima: the time step, and the hyperbolic estimate that the next cycle's
-  // c_h needs (hydro.cpp:102-143 reduces it in PreStepMeshUserWorkInLoop; same value, one message less)
-  double mins[2] = {dt, e.dt_hyp_local};
+  // c_h needs (hydro.cpp:102-143 reduces it in PreStepMeshUserWorkInLoop; same value, one message less).
+  // The negative-state flags travel with them (two more slots, MIN of -1 / 0): a rank that latched a flag must not
+  // leave the collective to its peers -- every rank takes part, then every rank fails.
+  double mins[4] = {dt, e.dt_hyp_local, (e.flags & APK_FLAG_NEG_DENSITY) ? -1.0 : 0.0, (e.flags & APK_FLAG_NEG_PRESSURE) ? -1.0 : 0.0};
   if (s->have_comm && s->nranks > 1) {
-    if (s->comm.allreduce_min(s->comm.user, mins, 2) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_min failed");
+    if (s->comm.allreduce_min(s->comm.user, mins, 4) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_min failed");
   }
+  if (mins[2] < 0.0)
+    return fail(s, APK_ERR_INVALID, "Got negative density. Consider enabling first-order flux correction or setting a reasonble density floor.");
+  if (mins[3] < 0.0)
+    return fail(s, APK_ERR_INVALID, "Got negative pressure. Consider enabling first-order flux correction or setting a reasonble pressure or temperature floor.");
   if (s->pkg.calc_dt_hyp && s->pkg.fluid == APK_FLUID_GLMMHD && mins[1] < s->pkg.dt_hyp) s->pkg.dt_hyp = mins[1];  // hydro.cpp:903-908
   s->dt_hyp_is_global = true;
   *dt_out = mins[0];
@@ -491,8 +493,11 @@ bool amr_shell_before_check(const apk_sim *s) {
   static const bool no_c2p_dt = std::getenv("APK_NO_C2P_DT") != nullptr;
   const HydroPackage &pkg = s->pkg;
   if (off || no_c2p_dt || !s->amr || !amr_faces_only(s) || !amr_has_shell(s) || !stage_can_fuse(s) || !pkg.calc_dt_hyp) return false;
+  // the shell is AMR_SHELL_DEPTH layers deep: the first stage of the next cycle may read no deeper -- its stencil
+  // half width plus the face it reconstructs for (DC 1 layer, PLM 2; PPM / WENO-Z 3 would read stale cells)
   const int recon = pkg.flux_first_stage.recon;
-  return recon == APK_RC_DC || recon == APK_RC_PLM;
+  const int reach = (recon == APK_RC_DC) ? 1 : ((recon == APK_RC_PPM || recon == APK_RC_WENOZ) ? 3 : 2);
+  return reach <= AMR_SHELL_DEPTH && !(pkg.fluid == APK_FLUID_GLMMHD && pkg.glmmhd_source_extended && AMR_SHELL_DEPTH < 2);
 }
 
 // fill the ghost zones that direct neighbour addressing left stale (cons and prim of the current state)

@@ -495,7 +495,9 @@ APK_DEV double minmod(double a, double b) {
 APK_DEV double limo3_limiter(double dvp, double dvm, double dx) {
   constexpr double r = 0.1;
   constexpr double eps = 10.0 * 2.220446049250313e-16;
-  const double theta = fdiv(dvm, (dvp + kTiny));
+  // (a plain quotient: dvp = -kTiny makes the divisor zero, where a / 0 is +-inf and the limiter's min / max chain
+  // still ends in a number, but a * rcp-with-Newton(0) is NaN)
+  const double theta = dvm / (dvp + kTiny);
   const double q = (2.0 + theta) / 3.0;
   const double phi =
       max2(0.0, min2(q, max2(-0.5 * theta, min2(2.0 * theta, min2(q, 1.6)))));

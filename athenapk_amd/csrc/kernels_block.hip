@@ -168,7 +168,8 @@ APK_DEV void block_min_to_word(double lane_min, unsigned long long *word) {
   __syncthreads();
   if (threadIdx.x == 0 && threadIdx.y == 0) {
     const double g = fmin(fmin(wmin[0], wmin[1]), fmin(wmin[2], wmin[3]));
-    const double cur = __longlong_as_double((long long)*reinterpret_cast<volatile unsigned long long *>(word));
+    // (blockDim must be (64, 4, 1): wmin[4] / threadIdx.y above)
+    const double cur = __longlong_as_double((long long)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (g < cur) atomicMin(word, (unsigned long long)__double_as_longlong(g));
   }
 }

@@ -12,6 +12,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest tests/...` on a box without a GPU skips the tests marked gpu instead of failing them with
+    "no usable gfx950 device" (the two documented runs select with -m gpu / -m "not gpu" anyway)."""
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:
+        have_gpu = False
+    if have_gpu:
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (there is no CPU fallback)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure): built on demand with gcc."""

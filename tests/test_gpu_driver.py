@@ -93,6 +93,33 @@ def test_mhd_linear_wave_matches_oracle(oracle, wave_flag, vflow, strict):
         assert rms == rms_o and np.array_equal(l1, l1_o) and np.array_equal(mx, mx_o)
 
 
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("family", ["fast", "alfven", "slow", "entropy", "fast_plus"])
+def test_mhd_linear_wave_reproduces_the_frozen_numbers(family, strict):
+    """The same runs against tests/golden/mhd_linear_wave.json (made by tests/golden/make_mhd_linear_wave.py from the
+    oracle): no live oracle involved.  Parity build: cycle count, time step, every error norm and the final conserved
+    state bit for bit; product build: the L1 norms within north_star's 1e-12."""
+    import hashlib
+    with open(os.path.join(GOLD, "mhd_linear_wave.json")) as f:
+        g = json.load(f)["cases"][family]
+    ov = ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=16", "parthenon/mesh/nx3=16", "parthenon/meshblock/nx1=16",
+          "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=16", "problem/linear_wave/wave_flag=%d" % g["wave_flag"],
+          "problem/linear_wave/vflow=%g" % g["vflow"]]
+    s = _sim("linear_wave_mhd3d", ov, strict=strict).initialize()
+    assert s.run() == g["cycles"]
+    rms, l1, mx = s.linear_wave_mhd_errors()
+    want_l1 = np.array([float.fromhex(x) for x in g["l1"]])
+    want_mx = np.array([float.fromhex(x) for x in g["max"]])
+    if strict:
+        assert s.dt == float.fromhex(g["dt"]) and rms == float.fromhex(g["rms_l1"])
+        assert np.array_equal(l1, want_l1) and np.array_equal(mx, want_mx)
+        assert hashlib.sha256(np.ascontiguousarray(s.gather("cons")).tobytes()).hexdigest() == g["cons_sha256"]
+    else:
+        assert abs(rms - float.fromhex(g["rms_l1"])) <= 1e-12 and np.all(np.abs(l1 - want_l1) <= 1e-12)
+        assert np.all(np.abs(mx - want_mx) <= 1e-9)
+        assert "%.3e" % rms == "%.3e" % float.fromhex(g["rms_l1"])   # the figure the reference's script reads, to 4 digits
+
+
 def test_mhd_linear_wave_error_file(tmp_path):
     """the MHD problem's linearwave-errors.dat: 4 + (1 + 8) + (1 + 8) columns, read the way the reference's
     convergence scripts read the file (np.genfromtxt; column 4 = RMS-L1), one row appended per run"""

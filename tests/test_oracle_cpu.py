@@ -62,6 +62,22 @@ def test_recorded_mhd_pin_is_within_reference_bound(probes):
     assert pin["rms_l1"] <= probes["reference_regression_bounds"]["glmmhd_rk3_wenoz_hlle_256x128x128_rms_l1_max"]
 
 
+@pytest.mark.parametrize("family", ["fast", "entropy"])
+def test_oracle_reproduces_the_frozen_mhd_linear_wave_numbers(oracle, family):
+    """tests/golden/mhd_linear_wave.json is what the oracle gives (tests/golden/make_mhd_linear_wave.py): the GPU suite
+    holds both HIP builds to it without running the oracle."""
+    import hashlib
+    with open(os.path.join(GOLD, "mhd_linear_wave.json")) as f:
+        g = json.load(f)["cases"][family]
+    o = oracle.Sim(fluid="glmmhd", recon="ppm", riemann="hlld", integrator="rk3", nx=(32, 16, 16), mb=(16, 16, 16), ng=3,
+                   xmax=(3.0, 1.5, 1.5), cfl=0.3, gamma=1.666666666666667, nthreads=os.cpu_count())
+    o.pgen("linear_wave_mhd", wave_flag=g["wave_flag"], amp=1e-6, vflow=g["vflow"])
+    assert o.run(o.period) == g["cycles"]
+    rms, l1, mx = o.linear_wave_errors()
+    assert rms == float.fromhex(g["rms_l1"]) and [float(x).hex() for x in l1] == g["l1"] and [float(x).hex() for x in mx] == g["max"]
+    assert hashlib.sha256(np.ascontiguousarray(o.gather_cons()).tobytes()).hexdigest() == g["cons_sha256"]
+
+
 def test_linear_wave_converges_at_second_order(oracle):
     errs = []
     for n in (16, 32):
