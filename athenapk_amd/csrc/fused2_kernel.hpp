@@ -128,6 +128,13 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
   constexpr int H = recon_halfwidth(RECON);
   constexpr int NS = 2 * H;
   constexpr int FIRST = m12_first_lane(RECON), LAST = m12_last_lane(RECON), CPW = LAST - FIRST + 1;
+  // where d3 / u1 are requested (APK_M12F_LOADS above).  The lean march WITHOUT ConsToPrim (the stages of RK2 / RK3 that
+  // are not the last, the north-star stage benchmark) has the registers to request u1 after the x1 phase without
+  // scratch (244 VGPRs): general stage 3.07 -> 2.98 ms, same box.  (A/B: -DAPK_M12F_LOADS_GENERAL=0)
+#ifndef APK_M12F_LOADS_GENERAL
+#define APK_M12F_LOADS_GENERAL 1
+#endif
+  constexpr int LOADS = (APK_M12F_LOADS_GENERAL != 0 && APK_M12F_LOADS == 2 && LEAN && EXTRA == EXTRA_NONE) ? 3 : APK_M12F_LOADS;
   extern __shared__ __attribute__((aligned(16))) double ring[];
   const int lane = threadIdx.x;
   const int w = (int)(blockIdx.x % 8u) * per_xcd + (int)(blockIdx.x / 8u);
@@ -271,7 +278,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
       // The x1 phase comes first so that its working set does not overlap the x2 solve's: only
       // its 9 flux differences stay live.
       double du[NV], d3v[NV], u1v[NV];
-      if constexpr (APK_M12F_LOADS == 0) {
+      if constexpr (LOADS == 0) {
         if (retire) {
 #pragma unroll
           for (int n = 0; n < NV; ++n) d3v[n] = d3[n * u0.sn + done];
@@ -328,14 +335,14 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
           }
         }
         // (2) streaming operands of the cell being retired: in flight during the x2 phase
-        if constexpr (APK_M12F_LOADS == 1) {
+        if constexpr (LOADS == 1) {
           asm volatile("" ::: "memory");
 #pragma unroll
           for (int n = 0; n < NV; ++n) d3v[n] = d3[n * u0.sn + done];
 #pragma unroll
           for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
         }
-        if constexpr (APK_M12F_LOADS == 3) {  // (A/B) u1 early, d3 late
+        if constexpr (LOADS == 3) {  // (A/B) u1 early, d3 late
           asm volatile("" ::: "memory");
 #pragma unroll
           for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
@@ -394,12 +401,12 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
         }
         APK_TICK(4);  // x2 Riemann
         if (retire) {
-          if constexpr (APK_M12F_LOADS == 3) {
+          if constexpr (LOADS == 3) {
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int n = 0; n < NV; ++n) d3v[n] = active ? d3[n * u0.sn + done] : 0.0;
           }
-          if constexpr (APK_M12F_LOADS == 2) {
+          if constexpr (LOADS == 2) {
             asm volatile("" ::: "memory");
             // (Timing experiment: without these 18 loads a general stage takes 2.65 instead of 2.91 ms
             // -- their exposed latency is the price of not holding 36 VGPRs through the x2 solve.)
