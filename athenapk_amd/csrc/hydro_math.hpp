@@ -441,9 +441,21 @@ APK_DEV void wenoz(double qm2, double qm1, double q0, double qp1, double qp2, do
   const double b2 = c0 * sqr(qp2 + q0 - 2.0 * qp1) + c1 * sqr(qp2 + 3.0 * q0 - 4.0 * qp1);
   constexpr double eps = 1.0e-42;
   const double tau5 = fabs(b0 - b2);
+#if defined(APK_PLAIN_SQRT) || defined(APK_NO_FDIV) || defined(APK_WENOZ_SEPARATE_QUOTIENTS)  // (A/B)
   const double i0 = fdiv(tau5, (b0 + eps));
   const double i1 = fdiv(tau5, (b1 + eps));
   const double i2 = fdiv(tau5, (b2 + eps));
+#else
+  // the three quotients share one reciprocal, evaluated per lane: tau5 / p_k = tau5 (p_l p_m) / (p_0 p_1 p_2) -- one
+  // v_rcp_f64 + Newton steps instead of three (the transcendental unit issues at a quarter of the fp64 rate), <= 2 ulp.
+  // (p_k >= 1e-42 and p_k <= ~ q^2: the product stays between 1e-126 and the square of anything a state holds)
+  const double p0 = b0 + eps, p1 = b1 + eps, p2 = b2 + eps;
+  const double p01 = p0 * p1;
+  const double tinv = tau5 * frcp(p01 * p2);
+  const double i0 = tinv * (p1 * p2);
+  const double i1 = tinv * (p0 * p2);
+  const double i2 = tinv * p01;
+#endif
 
   double f0 = (2.0 * qm2 - 7.0 * qm1 + 11.0 * q0);
   double f1 = (-1.0 * qm1 + 5.0 * q0 + 2.0 * qp1);
@@ -452,7 +464,7 @@ APK_DEV void wenoz(double qm2, double qm1, double q0, double qp1, double qp2, do
   double a1 = 0.6 * (1.0 + sqr(i1));
   double a2 = 0.3 * (1.0 + sqr(i2));
   double asum = 6.0 * (a0 + a1 + a2);
-  ql = fdiv((f0 * a0 + f1 * a1 + f2 * a2), asum);
+  const double num_l = (f0 * a0 + f1 * a1 + f2 * a2), asum_l = asum;
 
   f0 = (2.0 * qp2 - 7.0 * qp1 + 11.0 * q0);
   f1 = (-1.0 * qp1 + 5.0 * q0 + 2.0 * qm1);
@@ -461,7 +473,11 @@ APK_DEV void wenoz(double qm2, double qm1, double q0, double qp1, double qp2, do
   a1 = 0.6 * (1.0 + sqr(i1));
   a2 = 0.3 * (1.0 + sqr(i0));
   asum = 6.0 * (a0 + a1 + a2);
-  qr = fdiv((f0 * a0 + f1 * a1 + f2 * a2), asum);
+  const double num_r = (f0 * a0 + f1 * a1 + f2 * a2);
+  // (the two weight sums keep a reciprocal each: they grow like (tau5 / eps)^2 next to a discontinuity and their
+  // product can leave the range of a double)
+  ql = fdiv(num_l, asum_l);
+  qr = fdiv(num_r, asum);
 }
 
 // src/recon/weno3_simple.hpp:26-63

@@ -183,6 +183,25 @@ def test_config2_sod_matches_oracle(oracle):
     assert np.array_equal(s.gather(), o.gather_cons())
 
 
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+def test_vl2_with_walls_and_outflow_matches_oracle(oracle, strict):
+    """3-D hydro VL2 (donor-cell predictor + two-kernel PLM corrector) in 32^3 meshblocks with outflow in x1 and
+    reflecting walls in x2: the predictor stores its conserved result only in the shell the boundary conditions and
+    the ghost copies read (apk_stage_args.cons_store = 1), the full-step primitives are never stored -- against the
+    oracle, which stores everything."""
+    ov = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=32", "parthenon/meshblock/nx1=32",
+          "parthenon/meshblock/nx2=32", "parthenon/meshblock/nx3=32", "parthenon/time/integrator=vl2",
+          "parthenon/mesh/ix2_bc=reflecting", "parthenon/mesh/ox2_bc=reflecting", "parthenon/time/tlim=0.05"]
+    s = _sim("sod", ov, strict=strict).initialize()
+    o = oracle.Sim(fluid="euler", recon="plm", riemann="hllc", integrator="vl2", nx=(64, 32, 32), mb=(32, 32, 32), ng=2,
+                   bc=("outflow", "reflecting", "periodic"), xmin=(0.0, -0.5, -0.5), xmax=(1.0, 0.5, 0.5),
+                   gamma=1.4, cfl=0.3).pgen("sod")
+    assert s.run() == o.run(0.05)
+    assert s.prim_is_stale
+    _assert_same(s.gather(), o.gather_cons(), strict)
+    _assert_same(np.asarray(s.dt), np.asarray(o.dt), strict)
+
+
 def test_config2_full_size_sod_stays_one_dimensional():
     """256^3, 8 meshblocks of 128^3 (BASELINE config 2).  Size-independent property: a
     planar problem keeps zero transverse momentum and no transverse structure, bitwise."""
