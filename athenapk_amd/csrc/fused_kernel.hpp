@@ -329,6 +329,9 @@ fused_x1_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_plane) {
 // the Riemann problem of the previous face is solved.  Keeping the ring out of the VGPR file
 // (it would be 2H*NV doubles = 72 VGPRs for PPM/GLM-MHD) is what lets two waves share a SIMD.
 constexpr int kMarchMinWaves = 2;
+#ifndef APK_PPM_DEFER
+#define APK_PPM_DEFER 0  // 1: PPM's extremum limiter deferred to one pass per direction in the marches (hydro_math.hpp: ppm_cell_defer), A/B
+#endif
 #ifndef APK_PPM_PAIRS
 #define APK_PPM_PAIRS 0  // 1: PPM reconstructs two variables per pass in the marches (hydro_math.hpp: ppm_interface2 / ppm_cell2), A/B
 #endif
@@ -457,7 +460,33 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
 #pragma unroll
       for (int m = 0; m < NS; ++m) an[m] = ring[(((slot0 + m) & (NS - 1)) * NV + 0) * 64 + lane];
     }
-#if APK_PPM_PAIRS
+#if APK_PPM_DEFER
+    if constexpr (RECON == APK_RC_PPM) {
+      PpmPending pend;
+      ppm_pending_clear(pend);
+#pragma unroll
+      for (int n = 0; n < NV; ++n) {
+        double a[NS];
+#pragma unroll
+        for (int m = 0; m < NS; ++m) a[m] = an[m];
+        if (n + 1 < NV) {
+#pragma unroll
+          for (int m = 0; m < NS; ++m) an[m] = ring[(((slot0 + m) & (NS - 1)) * NV + n + 1) * 64 + lane];
+        }
+        const double face_p = ppm_interface(a[1], a[2], a[3], Pn[n]);
+        ppm_cell_defer(a[0], a[1], a[2], a[3], Pn[n], face_carry[n], face_p, n, pend, qln[n], qrn[n]);
+        face_carry[n] = face_p;
+      }
+      double le, re;
+      ppm_pending_limit(pend, le, re);
+#pragma unroll
+      for (int n = 0; n < NV; ++n) {
+        const bool mine = pend.full && pend.var == n;
+        qln[n] = mine ? le : qln[n];
+        qrn[n] = mine ? re : qrn[n];
+      }
+    } else
+#elif APK_PPM_PAIRS
     if constexpr (RECON == APK_RC_PPM) {
       // two variables per pass (ppm_interface2 / ppm_cell2): the ring rows of the NEXT pair are requested first
       auto ring_rows = [&](int n, double (&q)[5]) {

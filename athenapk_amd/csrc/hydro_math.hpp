@@ -424,6 +424,66 @@ APK_DEV void ppm_cell2(const double (&a)[5], double fa_m, double fa_p, const dou
   qr_b = rb;
 }
 
+// ---- PPM with the extremum limiter DEFERRED (APK_PPM_DEFER) ----------------------------------------------------------
+// Every VALU instruction costs a wave the same issue slot however few of its lanes are live, and on smooth data about
+// one lane per wave-row sits at an extremum of each variable: the 52-instruction limiter of ppm_cell runs nine times per
+// direction for nine lanes' worth of work.  Here a lane that needs the limiter for variable n parks that variable's
+// seven operands in a pending slot (15 selects) and goes on; after the ninth variable ONE masked pass limits every
+// pending item at once -- different lanes, different variables -- and each lane copies its result into the states of
+// the variable it was for.  A lane that already holds a pending item when another of its variables needs the limiter (an
+// extremum of two variables in one cell) runs that one on the spot, as before.  Same operations on the same operands
+// per item: bit-identical.
+struct PpmPending {
+  double qm2, qm1, q0, qp1, qp2, face_m, face_p;
+  int var;     // variable the item belongs to
+  bool full;   // the lane holds an item
+};
+APK_DEV void ppm_pending_clear(PpmPending &p) {
+  p.qm2 = p.qm1 = p.q0 = p.qp1 = p.qp2 = p.face_m = p.face_p = 0.0;
+  p.var = -1;
+  p.full = false;
+}
+APK_DEV void ppm_cell_defer(double qm2, double qm1, double q0, double qp1, double qp2, double face_m, double face_p, int var,
+                            PpmPending &pend, double &ql, double &qr) {
+  const double dminus = q0 - face_m;
+  const double dplus = face_p - q0;
+  const bool extremum = (dminus * dplus <= 0.0) || ((qp1 - q0) * (q0 - qm1) <= 0.0);
+  // the monotone case (what every other lane takes)
+  double r = face_m, l = face_p;
+  if (fabs(dminus) >= 2.0 * fabs(dplus)) r = q0 - 2.0 * dplus;
+  if (fabs(dplus) >= 2.0 * fabs(dminus)) l = q0 + 2.0 * dminus;
+  const bool take = extremum && !pend.full;
+  const bool collide = extremum && pend.full;
+  pend.qm2 = take ? qm2 : pend.qm2;
+  pend.qm1 = take ? qm1 : pend.qm1;
+  pend.q0 = take ? q0 : pend.q0;
+  pend.qp1 = take ? qp1 : pend.qp1;
+  pend.qp2 = take ? qp2 : pend.qp2;
+  pend.face_m = take ? face_m : pend.face_m;
+  pend.face_p = take ? face_p : pend.face_p;
+  pend.var = take ? var : pend.var;
+  pend.full = pend.full || take;
+  if (collide) {
+    asm volatile("" ::: );
+    double le, re;
+    ppm_cell_extremum(qm2, qm1, q0, qp1, qp2, face_m, face_p, dminus, dplus, le, re);
+    l = le;
+    r = re;
+  }
+  ql = l;
+  qr = r;
+}
+// the one masked pass over the pending items; (l, r) are valid in the lanes with pend.full
+APK_DEV void ppm_pending_limit(const PpmPending &pend, double &l, double &r) {
+  l = 0.0;
+  r = 0.0;
+  if (pend.full) {
+    asm volatile("" ::: );
+    ppm_cell_extremum(pend.qm2, pend.qm1, pend.q0, pend.qp1, pend.qp2, pend.face_m, pend.face_p, pend.q0 - pend.face_m,
+                      pend.face_p - pend.q0, l, r);
+  }
+}
+
 // src/recon/ppm_simple.hpp:39-162, one cell on its own (flux-array kernels, passive scalars)
 APK_DEV void ppm(double qm2, double qm1, double q0, double qp1, double qp2, double &ql,
                  double &qr) {
