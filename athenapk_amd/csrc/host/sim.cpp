@@ -879,6 +879,15 @@ int do_stage(apk_sim *s, int stage) {
       if (dead && mode > 0) a.cons_store = (direct && mm.peers.empty() && all_periodic && mode > 1) ? 2 : 1;
     }
     if (s->exchange_pending && cfg.recon == APK_RC_DC && !(dc3 && swap_prim)) SIM_TRY(s, finish_pending(s));
+    {
+      // The single-march donor-cell stage split into windows (one main window + six slabs) runs one row per lane and
+      // seven launches; whole, it runs two rows per lane (3.5 Riemann problems per cell instead of 4).  The one-GPU
+      // rehearsal of an 8-GPU rank (bench.py) measures the split at +0.3 ms per cycle against 0.19 ms of wire time it
+      // could hide: the exchange in flight at the start of a cycle is completed before the predictor instead
+      // (APK_OVERLAP_DC=1: split it as in round 3, A/B).
+      static const bool overlap_dc = std::getenv("APK_OVERLAP_DC") && std::atoi(std::getenv("APK_OVERLAP_DC")) != 0;
+      if (s->exchange_pending && dc3 && swap_prim && !overlap_dc) SIM_TRY(s, finish_pending(s));
+    }
     if (s->exchange_pending) {
       // The previous stage's halo messages are still in flight.  Ghost zones filled by same-rank
       // copies are ready: convert them, run whatever does not touch a late face (the x1 sweep of

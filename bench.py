@@ -317,10 +317,10 @@ def rehearsal_8gpu_rank(workload, n1_ms, steps=10, warmup=2):
         "wire_ms_per_exchange_modelled": wire_ms,
         "wire_model": "largest message / %.0f GB/s (one xGMI link per face peer, the three face messages on three links at once; "
                       "edge and corner messages are 1 - 3 %% of a face's)" % XGMI_LINK_GBS,
-        # the loopback copies already occupy the halo stream for message_bytes / (HBM copy rate); the wire is slower:
-        # what a real link adds is hidden as long as it fits behind the stage's first kernel
-        "predicted_weak_scaling_efficiency_if_wire_hidden": n1_ms / ms,
-        "predicted_weak_scaling_efficiency_if_wire_fully_exposed": n1_ms / (ms + nst * wire_ms),
+        # exchanges left in flight behind the next stage's first kernel hide their wire time there (or not: second figure);
+        # the others -- the one before the donor-cell predictor, which runs whole -- pay it in full
+        "predicted_weak_scaling_efficiency": n1_ms / (ms + max(0.0, nst - out["overlapped"]["overlapped_exchanges_per_cycle"]) * wire_ms),
+        "predicted_weak_scaling_efficiency_if_no_wire_time_is_hidden": n1_ms / (ms + nst * wire_ms),
     })
     return out
 
