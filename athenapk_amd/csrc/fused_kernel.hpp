@@ -265,7 +265,11 @@ fused_x1_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_plane) {
         qp1 = c[1];
       }
       if constexpr (H >= 2) {
-        qm2 = c[-2];
+        // (PPM's first reconstructing column is is - 2: with nghost = 3 its i - 2 lies one element in front of the row,
+        // which in 1-D -- one row per block, no rows below it -- is in front of the ARRAY for the first variable of the
+        // first block: an 8-byte read outside the allocation, a fault whenever that allocation starts a mapping.  The
+        // value only feeds that lane's own states, which nothing uses (PPM waves retire lanes 2 .. 62).)
+        qm2 = (i >= 2) ? c[-2] : q0;
         qp2 = c[2];
       }
     }
