@@ -155,7 +155,7 @@ int launch_count_unphysical(const PackView &u0, int fluid, unsigned long long *d
 int launch_fofc_fix(const PackView &u0, int fluid, double gamma, double c_h,
                     const unsigned char *d_mark, hipStream_t s);
 int launch_copy_regions(const apk_copy_plan &plan, hipStream_t s, int c2p_fluid = 0, const apk_eos *eos = nullptr,
-                        unsigned *d_flags = nullptr, int64_t prim_delta = 0);
+                        unsigned *d_flags = nullptr, int64_t prim_delta = 0, bool prim_only = false);
 // fused stage path (fused_dispatch.hip)
 int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
                        const apk_stage_args &a, double dedner_coeff, hipStream_t s);

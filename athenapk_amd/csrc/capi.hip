@@ -609,17 +609,29 @@ int apk_copy_plan_run(apk_ctx *ctx, const apk_copy_plan *plan, apk_stream_t stre
   return APK_OK;
 }
 
-int apk_copy_plan_run_c2p(apk_ctx *ctx, const apk_copy_plan *plan, int fluid, const apk_eos *eos, int64_t prim_delta,
-                          int latch_flags, apk_stream_t stream) {
+namespace {
+int copy_plan_run_c2p(apk_ctx *ctx, const apk_copy_plan *plan, int fluid, const apk_eos *eos, int64_t prim_delta, int latch_flags,
+                      bool prim_only, apk_stream_t stream) {
   if (!ctx || !plan || !valid_eos(eos) || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD))
     return set_err(ctx, APK_ERR_INVALID, "apk_copy_plan_run_c2p: bad argument");
   if (eos->dfloor > 0.0 || eos->pfloor > 0.0 || eos->efloor > 0.0 || eos->vceil < 1.0e300 || eos->eceil < 1.0e300)
     return set_err(ctx, APK_ERR_UNSUPPORTED, "apk_copy_plan_run_c2p: floors / ceilings are active; copy, then apk_cons_to_prim_ghosts");
   if (plan->n <= 0) return APK_OK;
   ScopedTiming timing(ctx, APK_T_COPY, as_stream(stream));
-  int rc = launch_copy_regions(*plan, as_stream(stream), fluid, eos, latch_flags ? ctx->d_flags : nullptr, prim_delta);
+  int rc = launch_copy_regions(*plan, as_stream(stream), fluid, eos, latch_flags ? ctx->d_flags : nullptr, prim_delta, prim_only);
   if (rc != APK_OK) return set_err(ctx, rc, "copy kernel launch failed", hipGetLastError());
   return APK_OK;
+}
+}  // namespace
+
+int apk_copy_plan_run_c2p(apk_ctx *ctx, const apk_copy_plan *plan, int fluid, const apk_eos *eos, int64_t prim_delta,
+                          int latch_flags, apk_stream_t stream) {
+  return copy_plan_run_c2p(ctx, plan, fluid, eos, prim_delta, latch_flags, false, stream);
+}
+
+int apk_copy_plan_run_c2p_prim_only(apk_ctx *ctx, const apk_copy_plan *plan, int fluid, const apk_eos *eos, int64_t prim_delta,
+                                    int latch_flags, apk_stream_t stream) {
+  return copy_plan_run_c2p(ctx, plan, fluid, eos, prim_delta, latch_flags, true, stream);
 }
 
 int apk_kernel_timing_enable(apk_ctx *ctx, int on) {

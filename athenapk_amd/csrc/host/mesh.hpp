@@ -18,7 +18,10 @@ namespace apk {
 
 enum BcKind { BC_PERIODIC = 0, BC_OUTFLOW = 1, BC_REFLECT = 2 };
 enum RegionKind { RK_BLOCK = 0, RK_SEND = 1, RK_RECV = 2 };
-enum PlanPhase { PH_LOCAL = 0, PH_PACK = 1, PH_UNPACK = 2, PH_BC1 = 3, PH_BC2 = 4, PH_BC3 = 5, PH_COUNT = 6 };
+// PH_PACK_THIN / PH_UNPACK_THIN: the same messages ONE layer deep (kThinDepth) -- all that the exchange in front of a
+// donor-cell stage has to deliver (VL2: the one at the end of a cycle); same buffers, a prefix of them.
+enum PlanPhase { PH_LOCAL = 0, PH_PACK = 1, PH_UNPACK = 2, PH_BC1 = 3, PH_BC2 = 4, PH_BC3 = 5, PH_PACK_THIN = 6, PH_UNPACK_THIN = 7, PH_COUNT = 8 };
+constexpr int kThinDepth = 1;
 
 struct BoxRegion {
   int src_kind = 0, src_block = 0, dst_kind = 0, dst_block = 0;
@@ -34,6 +37,7 @@ struct BoxRegion {
 struct PeerPlan {
   int rank = -1;
   int64_t send_count = 0, recv_count = 0;
+  int64_t send_count_thin = 0, recv_count_thin = 0;  // the one-layer form (PH_PACK_THIN / PH_UNPACK_THIN)
 };
 
 struct Mesh {
@@ -165,18 +169,20 @@ struct Mesh {
 
   // index range [lo,hi] along dim d of the receiver's ghost region (dst) and of the
   // provider's interior strip (src) for a neighbour at offset o_d
-  void Range(int d, int o, bool src, int &lo, int &hi) const {
+  // (depth: how many layers, counted from the face; 0 = all nghost of them)
+  void Range(int d, int o, bool src, int &lo, int &hi, int depth = 0) const {
     const int s = (d == 0) ? is : (d == 1 ? js : ks);
     const int e = (d == 0) ? ie : (d == 1 ? je : ke);
+    const int n = (depth > 0 && depth < ng) ? depth : ng;
     if (!Active(d) || o == 0) {
       lo = s;
       hi = e;
     } else if (!src) {
-      lo = (o < 0) ? s - ng : e + 1;
-      hi = (o < 0) ? s - 1 : e + ng;
+      lo = (o < 0) ? s - n : e + 1;
+      hi = (o < 0) ? s - 1 : e + n;
     } else {
-      lo = (o < 0) ? e - ng + 1 : s;
-      hi = (o < 0) ? e : s + ng - 1;
+      lo = (o < 0) ? e - n + 1 : s;
+      hi = (o < 0) ? e : s + n - 1;
     }
   }
 
@@ -275,6 +281,17 @@ struct Mesh {
         r.dst_off = pp.send_count;
         pp.send_count += (int64_t)r.ext[0] * r.ext[1] * r.ext[2] * nvar;
         plan[PH_PACK].push_back(r);
+        BoxRegion t = r;  // the one-layer form of the same strip
+        t.src_off = 0;
+        for (int d = 0; d < 3; ++d) {
+          Range(d, sgm.o[d], true, lo[d], hi[d], kThinDepth);
+          t.ext[d] = hi[d] - lo[d] + 1;
+          t.src_off += lo[d] * t.src_stride[d];
+        }
+        Compact(t.ext, t.dst_stride);
+        t.dst_off = pp.send_count_thin;
+        pp.send_count_thin += (int64_t)t.ext[0] * t.ext[1] * t.ext[2] * nvar;
+        plan[PH_PACK_THIN].push_back(t);
       }
       for (const auto &sgm : rv) {  // unpack into my ghost region at offset sgm.o
         BoxRegion r;
@@ -293,6 +310,17 @@ struct Mesh {
         r.src_off = pp.recv_count;
         pp.recv_count += (int64_t)r.ext[0] * r.ext[1] * r.ext[2] * nvar;
         plan[PH_UNPACK].push_back(r);
+        BoxRegion t = r;
+        t.dst_off = 0;
+        for (int d = 0; d < 3; ++d) {
+          Range(d, sgm.o[d], false, lo[d], hi[d], kThinDepth);
+          t.ext[d] = hi[d] - lo[d] + 1;
+          t.dst_off += lo[d] * t.dst_stride[d];
+        }
+        Compact(t.ext, t.src_stride);
+        t.src_off = pp.recv_count_thin;
+        pp.recv_count_thin += (int64_t)t.ext[0] * t.ext[1] * t.ext[2] * nvar;
+        plan[PH_UNPACK_THIN].push_back(t);
       }
       peers.push_back(pp);
     }

@@ -357,7 +357,8 @@ bool ghost_c2p_fusable(const apk_sim *s) {
   return !(e.dfloor > 0.0 || e.pfloor > 0.0 || e.efloor > 0.0 || e.vceil < 1.0e300 || e.eceil < 1.0e300);
 }
 
-int run_ghost_plan(apk_sim *s, int buf, int phase, bool c2p, apk_stream_t stream) {
+// c2p: GHOST_COPY (plain), GHOST_C2P (cons and prim), GHOST_PRIM_ONLY (sim_internal.hpp)
+int run_ghost_plan(apk_sim *s, int buf, int phase, int c2p, apk_stream_t stream) {
   if (!stream) stream = s->stream;
   if (!c2p) return apk_copy_plan_run(s->ctx, s->plans_of[buf][phase], stream);
   const int64_t delta = s->d_prim2[s->pcur] - s->d_cons2[buf];
@@ -369,12 +370,27 @@ int run_ghost_plan(apk_sim *s, int buf, int phase, bool c2p, apk_stream_t stream
   // direct neighbour addressing: the corner cells of a boundary phase are copied out of same-rank ghost
   // zones nobody fills (or reads); the other cells repeat interior cells, whose flags are latched there
   if (phase >= PH_BC1 && s->local_ghosts_stale) latch = 0;
+  if (c2p == GHOST_PRIM_ONLY) return apk_copy_plan_run_c2p_prim_only(s->ctx, s->plans_of[buf][phase], s->pkg.fluid, &s->pkg.eos, delta, latch, stream);
   return apk_copy_plan_run_c2p(s->ctx, s->plans_of[buf][phase], s->pkg.fluid, &s->pkg.eos, delta, latch, stream);
 }
 
-int exchange_begin(apk_sim *s, bool async, bool c2p, bool skip_local) {
+// make the one-layer (or the full) message set the one the transports see (apk_sim_peer)
+void select_thin_messages(apk_sim *s, bool thin) {
+  if (s->thin_msgs == thin) return;
+  s->thin_msgs = thin;
+  s->msg_generation += 1;
+}
+
+int exchange_begin(apk_sim *s, bool async, int c2p, bool skip_local, bool thin) {
   const bool remote = !s->mesh.peers.empty();
-  if (remote) SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(PH_PACK), s->stream));
+  thin = thin && remote;
+  s->xchg_thin = thin;
+  if (remote) {
+    select_thin_messages(s, thin);
+    s->remote_ghosts_thin = thin;  // (once this exchange is complete)
+    if (thin) s->thin_exchanges += 1;
+    SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(thin ? PH_PACK_THIN : PH_PACK), s->stream));
+  }
   if (skip_local) {
     // direct neighbour addressing: the stages read their same-rank neighbours' interiors
     s->local_ghosts_stale = true;
@@ -406,7 +422,7 @@ int exchange_begin(apk_sim *s, bool async, bool c2p, bool skip_local) {
   return APK_OK;
 }
 
-int exchange_end(apk_sim *s, bool c2p) {
+int exchange_end(apk_sim *s, int c2p) {
   // an exchange left in flight targets the buffer that held the state when it was posted: the
   // first stage of the next cycle has swapped the buffer roles by the time it completes it
   const int buf = s->exchange_pending ? s->pending_cons : s->cur;
@@ -419,15 +435,15 @@ int exchange_end(apk_sim *s, bool c2p) {
       return fail(s, APK_ERR_DEVICE, std::string("halo exchange (end) failed ") + apk_sim_comm_error(s));
     s->exchange_pending = false;
   }
-  if (!s->mesh.peers.empty()) SIM_TRY(s, run_ghost_plan(s, buf, PH_UNPACK, c2p));
+  if (!s->mesh.peers.empty()) SIM_TRY(s, run_ghost_plan(s, buf, s->xchg_thin ? PH_UNPACK_THIN : PH_UNPACK, c2p));
   for (int ph = PH_BC1; ph <= PH_BC3; ++ph) SIM_TRY(s, run_ghost_plan(s, buf, ph, c2p));
   return APK_OK;
 }
 
-int exchange_ghosts(apk_sim *s, bool c2p, bool skip_local) {
+int exchange_ghosts(apk_sim *s, int c2p, bool skip_local, bool thin) {
   if (s->amr) return amr_exchange(s, s->cur);
   if (!skip_local) s->local_ghosts_stale = false;  // (a full exchange of the current state)
-  SIM_TRY(s, exchange_begin(s, false, c2p, skip_local));
+  SIM_TRY(s, exchange_begin(s, false, c2p, skip_local, thin));
   return exchange_end(s, c2p);
 }
 
@@ -504,9 +520,9 @@ bool amr_shell_before_check(const apk_sim *s) {
 int materialize_local_ghosts(apk_sim *s) {
   if (!s->local_ghosts_stale) return APK_OK;
   s->local_ghosts_stale = false;
-  SIM_TRY(s, run_ghost_plan(s, s->cur, PH_LOCAL, true));
+  SIM_TRY(s, run_ghost_plan(s, s->cur, PH_LOCAL, GHOST_C2P));
   // (physical boundaries copy corner cells out of ghost zones the same-rank copies fill)
-  for (int ph = PH_BC1; ph <= PH_BC3; ++ph) SIM_TRY(s, run_ghost_plan(s, s->cur, ph, true));
+  for (int ph = PH_BC1; ph <= PH_BC3; ++ph) SIM_TRY(s, run_ghost_plan(s, s->cur, ph, GHOST_C2P));
   return APK_OK;
 }
 
@@ -525,15 +541,50 @@ bool prim_free_cycle(const apk_sim *s) {
   return apk_stage_split_axis(s->mu0(), &pkg.flux_other_stage, 2) == 3;
 }
 
+// May the exchange at the end of a cycle deliver ONE layer of ghost cells (mesh.hpp PH_PACK_THIN)?  The first stage of the
+// next cycle must be the single-march donor-cell stage (it reads one layer; the corrector's exchange stays a full one),
+// nothing else in a cycle may read ghost zones (no forcing, no refinement), and the box must be periodic: a physical
+// boundary phase copies corner cells out of ghost zones the messages fill.  Uniform 3-D meshes, exchanges left in
+// flight (the path of N > 1 runs).  APK_THIN_EXCHANGE=0 switches it off (A/B).
+bool thin_exchange_cycle(const apk_sim *s) {
+  static const int mode = std::getenv("APK_THIN_EXCHANGE") ? std::atoi(std::getenv("APK_THIN_EXCHANGE")) : 1;
+  static const int dc_mode = std::getenv("APK_DC_MODE") ? std::atoi(std::getenv("APK_DC_MODE")) : 2;
+  const HydroPackage &pkg = s->pkg;
+  const Mesh &mm = s->mesh;
+  if (!mode || !s->thin_on || s->amr || s->fmft || mm.ndim != 3 || mm.peers.empty() || !stage_can_fuse(s) || dc_mode != 2) return false;
+  if (mm.ng <= kThinDepth || pkg.nscalars != 0 || (pkg.fluid == APK_FLUID_GLMMHD && pkg.glmmhd_source_extended)) return false;
+  if (pkg.flux_first_stage.recon != APK_RC_DC || s->nstages < 2) return false;
+  for (int d = 0; d < 3; ++d)
+    if (mm.bc_in[d] != BC_PERIODIC || mm.bc_out[d] != BC_PERIODIC) return false;
+  return true;
+}
+
 int materialize_prim(apk_sim *s) {
   if (!s->prim_stale) return APK_OK;
   s->prim_stale = false;
   return fill_derived(s);  // (every cell of every block: the ghost zones have been brought up to date by the caller)
 }
 
+// The last exchange was a one-layer one: repeat it in full (cons; and prim unless no primitives of this state are
+// stored).  A collective over the ranks, like the completion of a refined mesh's ghost zones below: accessors that
+// reach it are to be called on every rank.
+int materialize_remote_ghosts(apk_sim *s) {
+  if (!s->remote_ghosts_thin) return APK_OK;
+  if (s->exchange_pending) return fail(s, APK_ERR_INVALID, "materialize_remote_ghosts: an exchange is in flight");
+  const bool keep_local = s->local_ghosts_stale;
+  const int mode = (!s->prim_stale && ghost_c2p_fusable(s)) ? GHOST_C2P : GHOST_COPY;
+  SIM_TRY(s, exchange_begin(s, false, mode, true, false));
+  s->skipped_local_exchanges -= 1;  // (not a stage boundary)
+  s->local_ghosts_stale = keep_local;
+  SIM_TRY(s, exchange_end(s, mode));
+  if (mode == GHOST_COPY && !s->prim_stale) SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), s->pkg.fluid, &s->pkg.eos, s->stream));
+  return APK_OK;
+}
+
 int sync_ghosts(apk_sim *s) {
   if (!s->amr && s->prim_stale) {
     SIM_TRY(s, finish_pending(s));
+    SIM_TRY(s, materialize_remote_ghosts(s));
     SIM_TRY(s, materialize_local_ghosts(s));
     return materialize_prim(s);
   }
@@ -545,6 +596,7 @@ int sync_ghosts(apk_sim *s) {
     return fill_derived(s);
   }
   SIM_TRY(s, finish_pending(s));
+  SIM_TRY(s, materialize_remote_ghosts(s));
   return materialize_local_ghosts(s);
 }
 
@@ -689,9 +741,11 @@ bool can_overlap_next(const apk_sim *s, int next) {
 int finish_pending(apk_sim *s) {
   if (!s->exchange_pending) return APK_OK;
   apk_pack *state = s->mu0_of[s->pending_cons][s->pcur];
-  const bool c2p = s->pending_c2p;
+  const int c2p = s->pending_c2p;
   SIM_TRY(s, exchange_end(s, c2p));
   if (c2p) return APK_OK;  // the ghost zones were converted as they were filled
+  // (no primitives of this state are stored anywhere: whoever wants them runs materialize_prim over whole blocks)
+  if (s->prim_stale) return APK_OK;
   return apk_cons_to_prim_ghosts(s->ctx, state, s->pkg.fluid, &s->pkg.eos, s->stream);
 }
 
@@ -798,6 +852,8 @@ int do_stage(apk_sim *s, int stage) {
   const bool prim_free = prim_free_cycle(s);
   const bool from_cons = s->prim_stale && stage == 1 && prim_free;
   if (s->prim_stale && !from_cons) SIM_TRY(s, sync_ghosts(s));
+  // (ghost zones one layer deep: enough for the donor-cell predictor they were left for, and for nothing else)
+  if (s->remote_ghosts_thin && !(stage == 1 && thin_exchange_cycle(s))) SIM_TRY(s, sync_ghosts(s));
   if (stage == 1) {
     // "init u1" (hydro_driver.cpp:474-495) without the copy: the buffer holding u0 becomes the
     // register u1 and the stage writes the new u0 into the other buffer.  Valid because
@@ -813,6 +869,7 @@ int do_stage(apk_sim *s, int stage) {
   }
   const apk_flux_cfg cfg = (stage == 1) ? pkg.flux_first_stage : pkg.flux_other_stage;
   bool fused_fill = false;
+  bool ghost_cons_dead = false;  // the conserved values of this stage's result are read in no ghost zone
   s->stage_dt_pending = false;
 
   // an exchange left in flight is completed inside the fused stage below; anything else first
@@ -877,6 +934,8 @@ int do_stage(apk_sim *s, int stage) {
       for (int d = 0; d < 3; ++d)
         if (mm.Active(d) && (mm.bc_in[d] != BC_PERIODIC || mm.bc_out[d] != BC_PERIODIC)) all_periodic = false;
       if (dead && mode > 0) a.cons_store = (direct && mm.peers.empty() && all_periodic && mode > 1) ? 2 : 1;
+      // (physical boundary phases copy conserved values out of ghost zones filled before them: periodic boxes only)
+      ghost_cons_dead = a.cons_store != 0 && all_periodic;
     }
     if (s->exchange_pending && cfg.recon == APK_RC_DC && !(dc3 && swap_prim)) SIM_TRY(s, finish_pending(s));
     {
@@ -894,8 +953,9 @@ int do_stage(apk_sim *s, int stage) {
       // a high-order stage / the whole single-kernel donor-cell stage, on index windows), then
       // complete the exchange and do the thin slabs next to those faces and the rest.
       apk_pack *state = s->mu0_of[s->pending_cons][s->pcur];  // (stage 1 has swapped the cons roles already)
-      const bool c2p_in_copy = s->pending_c2p;  // then the ghost zones are converted as they are filled
-      if (!c2p_in_copy)
+      const int c2p_in_copy = s->pending_c2p;  // then the ghost zones are converted as they are filled
+      const bool convert_ghosts = !c2p_in_copy && !s->prim_stale;  // (stale: the predictor reads the conserved state)
+      if (convert_ghosts)
         SIM_TRY(s, apk_cons_to_prim_ghosts_split(s->ctx, state, pkg.fluid, &pkg.eos, s->d_late_regions, 1, s->stream));
       const bool whole = dc3 && swap_prim;  // single-kernel stage
       const bool planes = !whole && apk_stage_split_axis(s->mu0(), &cfg, a.fill_derived) == 3;
@@ -905,7 +965,7 @@ int do_stage(apk_sim *s, int stage) {
       for (int q = 0; q < ntabs; ++q) {
         if (q == 1) {
           SIM_TRY(s, exchange_end(s, c2p_in_copy));
-          if (!c2p_in_copy)
+          if (convert_ghosts)
             SIM_TRY(s, apk_cons_to_prim_ghosts_split(s->ctx, state, pkg.fluid, &pkg.eos, s->d_late_regions, 2, s->stream));
         }
         if (!tabs[q].any) continue;
@@ -1024,11 +1084,18 @@ int do_stage(apk_sim *s, int stage) {
     }
   }
   static const bool no_copy_c2p = std::getenv("APK_NO_COPY_C2P") != nullptr;  // A/B switch
-  const bool c2p_in_copy = fused_fill && ghost_c2p_fusable(s) && !no_copy_c2p;
+  // (a last stage that stored no primitives: the ghost zones get none either -- the next predictor reads the conserved
+  // state there as everywhere; APK_STALE_GHOST_C2P=1 converts them as before, A/B)
+  static const bool stale_c2p = std::getenv("APK_STALE_GHOST_C2P") != nullptr;
+  const bool ghost_prims = !s->prim_stale || stale_c2p;
+  static const bool no_prim_only = std::getenv("APK_NO_PRIM_ONLY_GHOSTS") != nullptr;  // A/B switch
+  const int c2p_in_copy = !(fused_fill && ghost_c2p_fusable(s) && !no_copy_c2p && ghost_prims)
+                              ? GHOST_COPY
+                              : ((ghost_cons_dead && !no_prim_only) ? GHOST_PRIM_ONLY : GHOST_C2P);
   if (fused_fill && can_overlap_next(s, stage < s->nstages ? stage + 1 : 1)) {
     // post the messages and leave them in flight: the next stage (of this or of the next cycle)
     // completes the exchange
-    SIM_TRY(s, exchange_begin(s, true, c2p_in_copy, direct));
+    SIM_TRY(s, exchange_begin(s, true, c2p_in_copy, direct, stage == s->nstages && thin_exchange_cycle(s)));
   } else if (s->amr && amr_faces_only(s) && !(stage == s->nstages && regrid_check_follows(s))) {
     // refined meshes: nothing in the stage loop reads a ghost cell behind an edge or a corner of a block -- the
     // exchange skips those boxes (37 % of the ghost cells of a 16^3 block with nghost = 4) and ConsToPrim the cells
@@ -1053,10 +1120,10 @@ int do_stage(apk_sim *s, int stage) {
     s->stage_dt_pending = true;
   } else {
     // (without a fused FillDerived the full-block ConsToPrim below reads every ghost zone)
-    SIM_TRY(s, exchange_ghosts(s, c2p_in_copy, direct && fused_fill));
+    SIM_TRY(s, exchange_ghosts(s, c2p_in_copy, direct && fused_fill, fused_fill && stage == s->nstages && thin_exchange_cycle(s)));
     static const bool no_c2p_dt = std::getenv("APK_NO_C2P_DT") != nullptr;  // A/B switch
     if (fused_fill) {
-      if (!c2p_in_copy) SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
+      if (!c2p_in_copy && ghost_prims) SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
     } else if (stage == s->nstages && pkg.calc_dt_hyp && !no_c2p_dt) {
       // the last FillDerived of the cycle and the time-step estimate that follows it (hydro_driver.cpp:571-603) in
       // one pass: the interior cells' primitives are in registers anyway (refined meshes, flux-array stages)
@@ -1308,6 +1375,12 @@ int apk_sim_set_prim_free(apk_sim *s, int on) {
   s->prim_free_on = on != 0;
   return APK_OK;
 }
+int apk_sim_set_thin_exchange(apk_sim *s, int on) {
+  if (!s) return APK_ERR_INVALID;
+  s->thin_on = on != 0;
+  return APK_OK;
+}
+long long apk_sim_thin_exchanges(const apk_sim *s) { return s ? s->thin_exchanges : 0; }
 int apk_sim_prim_is_stale(const apk_sim *s) { return (s && s->prim_stale) ? 1 : 0; }
 int apk_sim_set_amr_full_exchange(apk_sim *s, int on) {
   if (!s) return APK_ERR_INVALID;
@@ -1989,9 +2062,10 @@ long long apk_sim_message_generation(const apk_sim *s) { return s ? s->msg_gener
 // plan introspection: make the halo (1) or flux-correction (2) message set of a refined mesh the one
 // apk_sim_peer reports (0: back to the uniform mesh's)
 int apk_sim_select_messages(apk_sim *s, int which) {
-  if (!s || which < 0 || which > 4 || (which > 0 && !s->amr)) return APK_ERR_INVALID;
-  const apk_sim::MsgSet *sets[5] = {nullptr, &s->amr_halo, &s->amr_fluxmsg, &s->amr_halo_faces, &s->amr_halo_shell};
+  if (!s || which < 0 || which > 5 || (which > 0 && which < 5 && !s->amr) || (which == 5 && s->amr)) return APK_ERR_INVALID;
+  const apk_sim::MsgSet *sets[6] = {nullptr, &s->amr_halo, &s->amr_fluxmsg, &s->amr_halo_faces, &s->amr_halo_shell, nullptr};
   s->active_msgs = sets[which];
+  s->thin_msgs = which == 5;  // (the one-layer set of a uniform mesh; every exchange selects the set it moves anyway)
   s->msg_generation += 1;
   return APK_OK;
 }
@@ -2008,8 +2082,8 @@ int apk_sim_peer(const apk_sim *s, int p, apk_peer_info *o) {
     return APK_OK;
   }
   o->rank = s->mesh.peers[p].rank;
-  o->send_count = s->mesh.peers[p].send_count;
-  o->recv_count = s->mesh.peers[p].recv_count;
+  o->send_count = s->thin_msgs ? s->mesh.peers[p].send_count_thin : s->mesh.peers[p].send_count;
+  o->recv_count = s->thin_msgs ? s->mesh.peers[p].recv_count_thin : s->mesh.peers[p].recv_count;
   o->send_buf = (p < (int)s->send_buf.size()) ? s->send_buf[p] : nullptr;
   o->recv_buf = (p < (int)s->recv_buf.size()) ? s->recv_buf[p] : nullptr;
   return APK_OK;

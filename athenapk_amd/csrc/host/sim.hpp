@@ -129,9 +129,7 @@ struct apk_sim {
   // [cons buffer][prim buffer]; mu1 packs carry the OTHER prim buffer's arrays as "u1.prim"
   apk_pack *mu0_of[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}},
            *mu1_of[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-  apk_copy_plan *plans_of[3][apk::PH_COUNT] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
-                                               {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
-                                               {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
+  apk_copy_plan *plans_of[3][apk::PH_COUNT] = {};
   apk_pack *mu0() const { return mu0_of[cur][pcur]; }
   apk_pack *mu1() const { return mu1_of[u1buf][pcur]; }
   double *d_prim() const { return d_prim2[pcur]; }
@@ -156,7 +154,13 @@ struct apk_sim {
   void *ev_stage_done = nullptr, *ev_copies_done = nullptr;  // hipEvent_t
   bool copies_in_flight = false;
   bool exchange_pending = false;
-  bool pending_c2p = false;  // the exchange in flight converts ghost zones as it fills them
+  // One-layer exchanges (mesh.hpp PH_PACK_THIN): the exchange at the end of a cycle whose first stage is the
+  // donor-cell predictor.  thin_msgs: the message set apk_sim_peer reports is the one-layer one (transports read it at
+  // every exchange); xchg_thin: the exchange begun last; remote_ghosts_thin: the ghost zones filled by messages are up
+  // to date one layer deep only -- sync_ghosts completes them (a collective, like the one of refined meshes).
+  bool thin_on = true, thin_msgs = false, xchg_thin = false, remote_ghosts_thin = false;
+  long long thin_exchanges = 0;
+  int pending_c2p = 0;  // the exchange in flight converts ghost zones as it fills them (GHOST_C2P / GHOST_PRIM_ONLY)
   int pending_cons = 0;  // cons buffer whose ghost zones the exchange in flight fills (roles may swap meanwhile)
   // device window tables (apk_stage_args.window, 8 ints per block) of the split stages:
   // x1 sweep: main / low slab / high slab; 3-D donor-cell stage: main / z lo,hi / y lo,hi / x lo,hi

@@ -64,10 +64,15 @@ int estimate_timestep_read(apk_sim *s, DtEstimate *e);
 int estimate_timestep_commit(apk_sim *s, const DtEstimate &e, double *dt_out);
 int estimate_timestep(apk_sim *s, double *dt_out);  // read + commit
 bool ghost_c2p_fusable(const apk_sim *s);
-int run_ghost_plan(apk_sim *s, int buf, int phase, bool c2p, apk_stream_t stream = nullptr);
-int exchange_begin(apk_sim *s, bool async, bool c2p, bool skip_local = false);
-int exchange_end(apk_sim *s, bool c2p);
-int exchange_ghosts(apk_sim *s, bool c2p = false, bool skip_local = false);
+// how a ghost-zone fill treats the primitives: not at all / ConsToPrim of every cell it fills / that, without storing the
+// conserved values (ghost zones of a state whose conserved values nothing reads: VL2's half step)
+enum { GHOST_COPY = 0, GHOST_C2P = 1, GHOST_PRIM_ONLY = 2 };
+int run_ghost_plan(apk_sim *s, int buf, int phase, int c2p, apk_stream_t stream = nullptr);
+int exchange_begin(apk_sim *s, bool async, int c2p, bool skip_local = false, bool thin = false);
+bool thin_exchange_cycle(const apk_sim *s);
+int materialize_remote_ghosts(apk_sim *s);
+int exchange_end(apk_sim *s, int c2p);
+int exchange_ghosts(apk_sim *s, int c2p = GHOST_COPY, bool skip_local = false, bool thin = false);
 int upload_window(apk_sim *s, const char *tag, const std::vector<int> &w, apk_sim::WindowTable &t);
 int build_windows(apk_sim *s);
 bool can_overlap_next(const apk_sim *s, int next);

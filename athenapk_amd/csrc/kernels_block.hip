@@ -518,9 +518,18 @@ copy_regions_cells_kernel(const apk_copy_region *regions, const apk_copy_chunk *
   const int i = rem - j * r.ext[0];
   const double *src = r.src + (i * r.src_stride[0] + j * r.src_stride[1] + k * r.src_stride[2]);
   double *dst = r.dst + (i * r.dst_stride[0] + j * r.dst_stride[1] + k * r.dst_stride[2]);
-  for (int v = 0; v < r.nvar; ++v) {
-    const double x = src[v * r.src_stride[3]];
-    dst[v * r.dst_stride[3]] = (v == r.flip_var) ? -x : x;
+  // (all loads of a batch are issued before its first store: with the variable count a run-time number the plain
+  // loop waited for every value in turn -- nine memory round trips per cell; message packing of a 128^3 brick's
+  // outer faces: 182 -> see DESIGN.md section 6)
+  constexpr int kBatch = 12;
+  for (int v0 = 0; v0 < r.nvar; v0 += kBatch) {
+    double x[kBatch];
+#pragma unroll
+    for (int q = 0; q < kBatch; ++q)
+      if (v0 + q < r.nvar) x[q] = src[(v0 + q) * r.src_stride[3]];
+#pragma unroll
+    for (int q = 0; q < kBatch; ++q)
+      if (v0 + q < r.nvar) dst[(v0 + q) * r.dst_stride[3]] = (v0 + q == r.flip_var) ? -x[q] : x[q];
   }
 }
 
@@ -531,7 +540,9 @@ copy_regions_cells_kernel(const apk_copy_region *regions, const apk_copy_chunk *
 // Only used when no floor / ceiling is active (they would write cons back, and a later boundary
 // phase would read the floored instead of the copied value; the unfused order is kept for that).
 // One workgroup per chunk of at most kCopyChunkCells cells.
-template <int FLUID>
+// STORE_CONS = false: the primitives only (ghost zones whose conserved values nobody reads: the half-step state of
+// VL2, apk_copy_plan_run_c2p_prim_only) -- half the strided stores.
+template <int FLUID, bool STORE_CONS>
 __global__ void __launch_bounds__(256)
 copy_regions_c2p_kernel(const apk_copy_region *regions, const apk_copy_chunk *chunks, apk_eos eos, unsigned *flags,
                         int64_t prim_delta) {
@@ -553,7 +564,7 @@ copy_regions_c2p_kernel(const apk_copy_region *regions, const apk_copy_chunk *ch
     for (int v = 0; v < NV; ++v) {
       const double x = r.src[so + v * r.src_stride[3]];
       u[v] = (v == r.flip_var) ? -x : x;
-      r.dst[dof + v * r.dst_stride[3]] = u[v];
+      if constexpr (STORE_CONS) r.dst[dof + v * r.dst_stride[3]] = u[v];
     }
     const unsigned fl = cons_to_prim_cell<FLUID>(eos, u, w, di);
     if (fl && flags) atomicOr(flags, fl);
@@ -562,7 +573,7 @@ copy_regions_c2p_kernel(const apk_copy_region *regions, const apk_copy_chunk *ch
     for (int v = 0; v < NV; ++v) p[v * r.dst_stride[3]] = w[v];
     for (int v = NV; v < r.nvar; ++v) {  // passive scalars
       const double x = r.src[so + v * r.src_stride[3]];
-      r.dst[dof + v * r.dst_stride[3]] = x;
+      if constexpr (STORE_CONS) r.dst[dof + v * r.dst_stride[3]] = x;
       p[v * r.dst_stride[3]] = x * di;
     }
   }
@@ -690,17 +701,23 @@ int launch_fofc_fix(const PackView &u0, int fluid, double gamma, double c_h,
 }
 
 int launch_copy_regions(const apk_copy_plan &plan, hipStream_t s, int c2p_fluid, const apk_eos *eos, unsigned *d_flags,
-                        int64_t prim_delta) {
+                        int64_t prim_delta, bool prim_only) {
   if (plan.n <= 0) return APK_OK;
   // the plain copy works per (cell, variable), the ConsToPrim variants per cell
-  if (c2p_fluid == APK_FLUID_EULER) {
-    if (plan.nchunks_cells > 0)
-      hipLaunchKernelGGL(copy_regions_c2p_kernel<APK_FLUID_EULER>, dim3(plan.nchunks_cells), dim3(256), 0, s, plan.d_regions,
-                         plan.d_chunks_cells, *eos, d_flags, prim_delta);
-  } else if (c2p_fluid == APK_FLUID_GLMMHD) {
-    if (plan.nchunks_cells > 0)
-      hipLaunchKernelGGL(copy_regions_c2p_kernel<APK_FLUID_GLMMHD>, dim3(plan.nchunks_cells), dim3(256), 0, s, plan.d_regions,
-                         plan.d_chunks_cells, *eos, d_flags, prim_delta);
+  if (c2p_fluid == APK_FLUID_EULER || c2p_fluid == APK_FLUID_GLMMHD) {
+    if (plan.nchunks_cells > 0) {
+      const dim3 grid(plan.nchunks_cells), block(256);
+#define APK_LAUNCH_COPY_C2P(FL, SC) \
+  hipLaunchKernelGGL((copy_regions_c2p_kernel<FL, SC>), grid, block, 0, s, plan.d_regions, plan.d_chunks_cells, *eos, d_flags, prim_delta)
+      if (c2p_fluid == APK_FLUID_EULER) {
+        if (prim_only) APK_LAUNCH_COPY_C2P(APK_FLUID_EULER, false);
+        else APK_LAUNCH_COPY_C2P(APK_FLUID_EULER, true);
+      } else {
+        if (prim_only) APK_LAUNCH_COPY_C2P(APK_FLUID_GLMMHD, false);
+        else APK_LAUNCH_COPY_C2P(APK_FLUID_GLMMHD, true);
+      }
+#undef APK_LAUNCH_COPY_C2P
+    }
   } else {
     static const bool per_item = std::getenv("APK_COPY_PER_ITEM") != nullptr;  // A/B switch
     if (per_item && plan.nchunks_items > 0)

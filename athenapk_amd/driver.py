@@ -107,7 +107,7 @@ class _FmftHost:
 class _MeshView:
     """Block placement and ghost-exchange plans of a sim handle (valid without a GPU)."""
 
-    PHASES = {"local": 0, "pack": 1, "unpack": 2, "bc1": 3, "bc2": 4, "bc3": 5,
+    PHASES = {"local": 0, "pack": 1, "unpack": 2, "bc1": 3, "bc2": 4, "bc3": 5, "pack_thin": 6, "unpack_thin": 7,
               # refined meshes (src/.. host/amr.hpp): all copies of the multilevel exchange, the
               # physical boundaries of coarse buffers / blocks, the flux-correction copies
               "amr_fill": 10, "amr_coarse_bc1": 11, "amr_coarse_bc2": 12, "amr_coarse_bc3": 13,
@@ -127,7 +127,7 @@ class _MeshView:
 
     def messages(self, which):
         """[(peer rank, send doubles, recv doubles)] of a refined mesh's "halo" / "flux" message set"""
-        self.lib.apk_sim_select_messages(self.h, {"uniform": 0, "halo": 1, "flux": 2, "halo_faces": 3, "halo_shell": 4}[which])
+        self.lib.apk_sim_select_messages(self.h, {"uniform": 0, "halo": 1, "flux": 2, "halo_faces": 3, "halo_shell": 4, "uniform_thin": 5}[which])
         out = []
         for p in range(self.lib.apk_sim_num_peers(self.h)):
             pi = L.PeerInfo()
@@ -230,6 +230,7 @@ class Simulation(_FmftHost, _MeshView):
 
         self._halo = None
         self._halo_generation = None
+        self._halo_cache = {}
         self._cb_counts = {"exchanges": 0, "reductions": 0}  # callback transport (the native one keeps its own)
 
         def _exchange(user):
@@ -330,14 +331,21 @@ class Simulation(_FmftHost, _MeshView):
         change them when the mesh does, which the generation counter tells"""
         gen = self.lib.apk_sim_message_generation(self.h)
         if self._halo is None or gen != self._halo_generation:
-            peers = []
+            peers, key = [], []
             for p in range(self.lib.apk_sim_num_peers(self.h)):
                 pi = L.PeerInfo()
                 self._check(self.lib.apk_sim_peer(self.h, p, C.byref(pi)))
                 st = self._tensors[pi.send_buf][:pi.send_count] if pi.send_count else None
                 rt = self._tensors[pi.recv_buf][:pi.recv_count] if pi.recv_count else None
                 peers.append((pi.rank, st, rt))
-            self._halo = HaloExchanger(peers, self._group)
+                key.append((pi.rank, pi.send_buf, pi.send_count, pi.recv_buf, pi.recv_count))
+            # (a uniform mesh alternates between its full and its one-layer message set: keep both exchangers)
+            key = tuple(key)
+            if key not in self._halo_cache:
+                if len(self._halo_cache) >= 4:  # (refined meshes change their sets with every regridding)
+                    self._halo_cache.clear()
+                self._halo_cache[key] = HaloExchanger(peers, self._group)
+            self._halo = self._halo_cache[key]
             self._halo_generation = gen
         return self._halo
 
@@ -393,6 +401,14 @@ class Simulation(_FmftHost, _MeshView):
 
     def skipped_local_exchanges(self):
         return self.lib.apk_sim_skipped_local_exchanges(self.h)
+
+    def thin_exchanges(self):
+        """one-layer exchanges so far (apk_sim_set_thin_exchange)"""
+        return self.lib.apk_sim_thin_exchanges(self.h)
+
+    def set_thin_exchange(self, on):
+        self._check(self.lib.apk_sim_set_thin_exchange(self.h, int(on)))
+        return self
 
     def set_direct_neighbors(self, on):
         self._check(self.lib.apk_sim_set_direct_neighbors(self.h, int(on)))

@@ -198,6 +198,7 @@ def _signatures():
         "apk_copy_plan_destroy": (None, [vp]),
         "apk_copy_plan_run": (i, [vp, vp, vp]),
         "apk_copy_plan_run_c2p": (i, [vp, vp, i, E, C.c_int64, i, vp]),
+        "apk_copy_plan_run_c2p_prim_only": (i, [vp, vp, i, E, C.c_int64, i, vp]),
         "apk_kernel_timing_enable": (i, [vp, i]),
         "apk_kernel_timing_read": (i, [vp, i, c_dp, C.POINTER(ll)]),
         # apk_host.h
@@ -219,6 +220,8 @@ def _signatures():
         "apk_sim_set_overlap": (i, [vp, i]),
         "apk_sim_overlapped_exchanges": (ll, [vp]),
         "apk_sim_skipped_local_exchanges": (ll, [vp]),
+        "apk_sim_set_thin_exchange": (i, [vp, i]),
+        "apk_sim_thin_exchanges": (ll, [vp]),
         "apk_sim_set_direct_neighbors": (C.c_int, [vp, C.c_int]),
         "apk_sim_set_amr_full_exchange": (C.c_int, [vp, C.c_int]),
         "apk_sim_set_prim_free": (C.c_int, [vp, C.c_int]),

@@ -382,6 +382,12 @@ int apk_copy_plan_run(apk_ctx *ctx, const apk_copy_plan *plan, apk_stream_t stre
  * another one copies corner cells whose sources are only filled by that later phase. */
 int apk_copy_plan_run_c2p(apk_ctx *ctx, const apk_copy_plan *plan, int fluid, const apk_eos *eos,
                           int64_t prim_delta, int latch_flags, apk_stream_t stream);
+/* The same, storing the primitives ONLY: for ghost zones whose conserved values nothing reads -- the half-step
+ * state of VL2, whose corrector (gam0 = 0) takes its fluxes from the primitives and updates the full-step state
+ * (apk_stage_args.cons_store).  `dst` still names the cons array of the destination block (the primitives go to
+ * dst + prim_delta); nothing is written at dst itself. */
+int apk_copy_plan_run_c2p_prim_only(apk_ctx *ctx, const apk_copy_plan *plan, int fluid, const apk_eos *eos,
+                                    int64_t prim_delta, int latch_flags, apk_stream_t stream);
 
 /* ---- few-modes turbulence driver (BASELINE config 4 forcing; "next" row of SURVEY 8(f)) -------
  * The device side of turbulence::Driving (src/pgen/turbulence.cpp:373-482), which AthenaPK

@@ -126,6 +126,17 @@ int apk_sim_set_direct_neighbors(apk_sim *sim, int on);
  * CalculateFluxes.  Every accessor materialises them on demand; results are identical.  APK_PRIM_FREE=0 in the
  * environment switches it off.  apk_sim_prim_is_stale: 1 while the primitives of the current state are not in memory. */
 int apk_sim_set_prim_free(apk_sim *sim, int on);
+/* One-layer exchanges (on by default where they apply: N > 1 ranks, uniform periodic 3-D meshes, VL2, no passive
+ * scalars, no extended Dedner source, no forcing): the exchange at the end of a cycle delivers ONE layer of ghost
+ * cells -- all the donor-cell predictor of the next cycle reads; the reference exchanges nghost layers after every
+ * stage (hydro_driver.cpp:567-568) -- and the corrector's exchange stays a full one.  The messages are a prefix of
+ * the same buffers; the transports find the current sizes in apk_sim_peer at every exchange
+ * (apk_sim_message_generation tells when they changed).  Accessors that read ghost zones complete them with a full
+ * exchange first: a COLLECTIVE then, to be called on every rank, like the accessors of a refined mesh.  Results are
+ * identical.  APK_THIN_EXCHANGE=0 in the environment switches it off.  Returns (apk_sim_thin_exchanges) the number
+ * of one-layer exchanges so far. */
+int apk_sim_set_thin_exchange(apk_sim *sim, int on);
+long long apk_sim_thin_exchanges(const apk_sim *sim);
 int apk_sim_prim_is_stale(const apk_sim *sim); /* 1 (default) / 0 = always copy */
 /* Refined meshes: the stage loop's exchange leaves out the ghost zones behind block edges and corners
  * (no sweep or flux correction reads them; accessors, tagging and the last exchange of a cycle that
@@ -266,10 +277,11 @@ int apk_sim_peer(const apk_sim *sim, int p, apk_peer_info *info);
 int apk_sim_num_peers(const apk_sim *sim);
 /* introspection: report the halo (1) / flux-correction (2) message set of a refined mesh through
  * apk_sim_peer (0 = the uniform mesh's set); 3 / 4: the halo sets of the faces-only and of the shell
- * exchange of the stage loop */
+ * exchange of the stage loop; 5 = the one-layer set of a uniform mesh (apk_sim_set_thin_exchange) */
 int apk_sim_select_messages(apk_sim *sim, int which);
 long long apk_sim_message_generation(const apk_sim *sim);
-/* number of box copies in each phase: 0 local, 1 pack, 2 unpack, 3..5 physical BC x1..x3; on
+/* number of box copies in each phase: 0 local, 1 pack, 2 unpack, 3..5 physical BC x1..x3, 6 / 7 pack / unpack of the
+ * one-layer exchange; on
  * refined meshes 10 = all copies of the multilevel exchange, 11..13 = coarse-buffer boundaries,
  * 14..16 = block boundaries, 17..19 = flux-correction copies x1..x3 (10..19: the global plan
  * every rank builds, global block numbers); this rank's share with local block numbers and message

@@ -345,9 +345,40 @@ def test_rehearsed_remote_faces_give_the_periodic_box(strict, scheme, overlap):
     nstages = {"vl2": 2, "rk3": 3}[integ]
     assert a.skipped_local_exchanges() == 4 * nstages and b.skipped_local_exchanges() == 4 * nstages  # (same-rank faces still direct)
     assert (b.overlapped_exchanges > 0) == overlap
+    assert b.thin_exchanges() == (4 if integ == "vl2" else 0)
     _assert_same(np.asarray(b.dt), np.asarray(a.dt), strict)
     _assert_same(b.gather(), a.gather(), strict)
     _assert_same(b.gather("prim"), a.gather("prim"), strict)
+
+
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("overlap", [True, False], ids=["overlapped", "synchronous"])
+@pytest.mark.parametrize("prim_free", [True, False], ids=["prim_free", "stored_prims"])
+def test_one_layer_exchange_before_the_predictor_and_its_completion(strict, overlap, prim_free):
+    """VL2 on a periodic box with remote faces: the exchange at the end of a cycle delivers one layer of ghost cells
+    (apk_sim_set_thin_exchange) -- all the donor-cell predictor reads.  Same bits as with full exchanges throughout, in
+    the interior and -- after an accessor has completed them -- in every ghost zone, and the run carries on from there."""
+    ov = ["parthenon/mesh/nx%d=64" % d for d in (1, 2, 3)] + ["parthenon/meshblock/nx%d=32" % d for d in (1, 2, 3)] + [
+        "apk_amd/rehearse_remote_faces=true"]
+    sims = []
+    for thin in (True, False):
+        s = _sim("synthetic_mhd", ov, strict=strict)
+        s.set_overlap(overlap)
+        s.set_thin_exchange(thin)
+        s.set_prim_free(prim_free)
+        sims.append(s.initialize())
+    a, b = sims
+    for rounds in range(2):
+        for _ in range(3):
+            a.step()
+            b.step()
+        assert a.thin_exchanges() == 3 * (rounds + 1) and b.thin_exchanges() == 0
+        assert np.array_equal(np.asarray(a.dt), np.asarray(b.dt))
+        for lb in range(8):
+            for field in ("cons", "prim"):
+                assert np.array_equal(a.read_block(lb, field), b.read_block(lb, field)), (rounds, lb, field)  # (ghost zones included)
+    full, thin = a.messages("uniform"), a.messages("uniform_thin")
+    assert all(t[1] * 3 <= f[1] for f, t in zip(full, thin))  # (nghost = 3: a third of a face, a ninth of an edge)
 
 
 # ---- full-step primitives kept out of memory --------------------------------------------------------------------

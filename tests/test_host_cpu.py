@@ -128,7 +128,7 @@ def test_morton_partition_gives_bricks():
 
 
 # ---- ghost-exchange plans, executed on the host -------------------------------------------------------
-def _run_plans(deck, overrides, nranks, fill, nvar):
+def _run_plans(deck, overrides, nranks, fill, nvar, pack="pack", unpack="unpack", msgs="uniform"):
     """Emulates all ranks in one process: returns {gid: block array} after the exchange."""
     plans = [_plan(deck, overrides, rank=r, nranks=nranks) for r in range(nranks)]
     i0 = plans[0].info
@@ -141,8 +141,8 @@ def _run_plans(deck, overrides, nranks, fill, nvar):
             gid, loc = p.block_gid(lb)
             blk.append(fill(gid, loc, shape))
         blocks.append(blk)
-        sendb.append({q: np.zeros(sc) for q, sc, rc in p.peers()})
-        recvb.append({q: np.zeros(rc) for q, sc, rc in p.peers()})
+        sendb.append({q: np.zeros(sc) for q, sc, rc in p.messages(msgs)})
+        recvb.append({q: np.zeros(rc) for q, sc, rc in p.messages(msgs)})
 
     def base(r, kind, idx):
         p = plans[r]
@@ -164,14 +164,14 @@ def _run_plans(deck, overrides, nranks, fill, nvar):
             dst[do] = val
 
     for r in range(nranks):
-        run(r, "pack")
+        run(r, pack)
         run(r, "local")
     for r, p in enumerate(plans):  # the "wire": my send buffer to q is q's recv buffer from me
-        for q, sc, rc in p.peers():
+        for q, sc, rc in p.messages(msgs):
             assert sendb[r][q].size == recvb[q][r].size
             recvb[q][r][:] = sendb[r][q]
     for r in range(nranks):
-        run(r, "unpack")
+        run(r, unpack)
         for ph in ("bc1", "bc2", "bc3"):
             run(r, ph)
     out = {}
@@ -179,6 +179,31 @@ def _run_plans(deck, overrides, nranks, fill, nvar):
         for lb in range(p.info.nblocks_local):
             out[p.block_gid(lb)[0]] = blocks[r][lb]
     return out, plans[0].info
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+def test_one_layer_plans_fill_the_first_ghost_layer(nranks):
+    """The one-layer exchange (mesh.hpp PH_PACK_THIN / PH_UNPACK_THIN; the exchange in front of VL2's donor-cell
+    predictor): the first layer of ghost cells all round every block equals the full exchange's, deeper layers filled by
+    messages keep what they held, and a face message is a third of the full one (nghost = 3)."""
+    ov = ["parthenon/mesh/nx1=24", "parthenon/mesh/nx2=16", "parthenon/mesh/nx3=16", "parthenon/meshblock/nx1=12",
+          "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=8"]
+
+    def fill(gid, loc, shape):
+        return np.random.default_rng(100 + gid).standard_normal(shape)
+
+    full, info = _run_plans("synthetic_mhd", ov, nranks, fill, 9)
+    thin, _ = _run_plans("synthetic_mhd", ov, nranks, fill, 9, pack="pack_thin", unpack="unpack_thin", msgs="uniform_thin")
+    ng = info.ng
+    for gid in full:
+        a, b, c = full[gid], thin[gid], fill(gid, None, full[gid].shape)
+        first = (slice(None),) + tuple(slice(ng - 1, n - ng + 1) for n in a.shape[1:])
+        assert np.array_equal(a[first], b[first])
+        assert np.all((b == a) | (b == c))  # deeper: the full exchange's value (same-rank copy) or untouched
+    p = _plan("synthetic_mhd", ov, rank=0, nranks=nranks)
+    sizes, sizes1 = p.messages("uniform"), p.messages("uniform_thin")
+    assert [q[0] for q in sizes] == [q[0] for q in sizes1] and all(0 < t[1] < f[1] and 0 < t[2] < f[2] for f, t in zip(sizes, sizes1))
+    assert p.peers() == sizes  # (introspection leaves the full set selected)
 
 
 @pytest.mark.parametrize("nranks", [1, 2, 3, 8])
