@@ -199,7 +199,7 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
     }
     if (prim_dst) {  // (wave-uniform; NULL: fill_derived = 3, the primitives only feed the time-step estimate)
 #pragma unroll
-      for (int n = 0; n < NV; ++n) as_global(prim_dst)[n * pv.sn + cell] = w[n];
+      for (int n = 0; n < NV; ++n) store_result(&as_global(prim_dst)[n * pv.sn + cell], w[n]);
     }
     if constexpr (EXTRA == EXTRA_C2P_DT) {
       // EstimateHyperbolicTimestep (hydro.cpp:845-895) on the fresh primitives
@@ -208,7 +208,7 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
   }
   if (store_cons) {
 #pragma unroll
-    for (int n = 0; n < NV; ++n) as_global(b0.cons)[n * pv.sn + cell + sp.out_delta] = un[n];
+    for (int n = 0; n < NV; ++n) store_result(&as_global(b0.cons)[n * pv.sn + cell + sp.out_delta], un[n]);
   }
   if constexpr (!LEAN) {
     if (bad) atomicAdd(sp.bad_count, 1ull);
@@ -590,7 +590,7 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
             finish_cell<FLUID, EXTRA>(u0, b0, u1v, cell, du, vol, sp, lane_min_dt, prim_dst);
           } else {
 #pragma unroll
-            for (int n = 0; n < NV; ++n) dscratch[n * u0.sn + cell] = du[n];
+            for (int n = 0; n < NV; ++n) store_result(&dscratch[n * u0.sn + cell], du[n]);
           }
         }
       }

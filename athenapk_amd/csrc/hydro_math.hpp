@@ -49,6 +49,20 @@ APK_DEV __attribute__((address_space(1))) T *as_global(T *p) {
   return (__attribute__((address_space(1))) T *)p;
 }
 #endif
+// Results of a stage kernel (new conserved state, new primitives, the x3 sweep's partial divergences): never read again by
+// the kernel that writes them.  APK_NT_STORES=1 marks those stores non-temporal (A/B: do they leave more of the L2 to the
+// rows neighbouring waves share?).
+#ifndef APK_NT_STORES
+#define APK_NT_STORES 0
+#endif
+template <class P>
+APK_DEV void store_result(P p, double v) {
+#if APK_NT_STORES
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 // a wave-uniform value the vector ALU had to compute (there is no scalar fp64 unit), moved into a scalar register
 // pair: it stops occupying two VGPRs of every lane for as long as it lives
 APK_DEV double to_sgpr(double x) {
