@@ -571,12 +571,15 @@ int materialize_prim(apk_sim *s) {
 int materialize_remote_ghosts(apk_sim *s) {
   if (!s->remote_ghosts_thin) return APK_OK;
   if (s->exchange_pending) return fail(s, APK_ERR_INVALID, "materialize_remote_ghosts: an exchange is in flight");
-  const bool keep_local = s->local_ghosts_stale;
+  if (!s->have_comm || !s->comm.exchange) return fail(s, APK_ERR_INVALID, "remote neighbours but no comm ops");
+  // (the message half of exchange_begin / exchange_end: same-rank ghost zones are none of its business)
   const int mode = (!s->prim_stale && ghost_c2p_fusable(s)) ? GHOST_C2P : GHOST_COPY;
-  SIM_TRY(s, exchange_begin(s, false, mode, true, false));
-  s->skipped_local_exchanges -= 1;  // (not a stage boundary)
-  s->local_ghosts_stale = keep_local;
-  SIM_TRY(s, exchange_end(s, mode));
+  select_thin_messages(s, false);
+  s->xchg_thin = s->remote_ghosts_thin = false;
+  SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(PH_PACK), s->stream));
+  if (s->comm.exchange(s->comm.user) != 0) return fail(s, APK_ERR_DEVICE, "halo exchange failed");
+  SIM_TRY(s, run_ghost_plan(s, s->cur, PH_UNPACK, mode));
+  for (int ph = PH_BC1; ph <= PH_BC3; ++ph) SIM_TRY(s, run_ghost_plan(s, s->cur, ph, mode));
   if (mode == GHOST_COPY && !s->prim_stale) SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), s->pkg.fluid, &s->pkg.eos, s->stream));
   return APK_OK;
 }
