@@ -128,6 +128,43 @@ def _cfg(fluid, recon, riemann):
     return L.FluxCfg(L.FLUID[fluid], L.RECON[recon], L.RIEMANN[riemann])
 
 
+class CopyPlan:
+    """apk_copy_plan: a list of strided box copies (ghost-zone fills, message packing / unpacking, physical boundaries)
+    executed in one launch.  regions: dicts with src / dst (device addresses), ext (ni, nj, nk), nvar, src_stride /
+    dst_stride (elements, for i, j, k, variable) and optionally flip_var."""
+
+    def __init__(self, ctx, regions):
+        self.ctx = ctx
+        regs = (L.CopyRegion * len(regions))()
+        for r, q in zip(regs, regions):
+            r.src, r.dst, r.nvar = q["src"], q["dst"], q["nvar"]
+            r.ext[:] = list(q["ext"])
+            r.src_stride[:] = list(q["src_stride"])
+            r.dst_stride[:] = list(q["dst_stride"])
+            r.flip_var = q.get("flip_var", -1)
+        h = C.c_void_p()
+        _check(ctx.lib.apk_copy_plan_create(ctx.h, regs, len(regions), C.byref(h)), ctx.lib, ctx.h)
+        self.h = h
+
+    def run(self):
+        _check(self.ctx.lib.apk_copy_plan_run(self.ctx.h, self.h, _stream()), self.ctx.lib, self.ctx.h)
+
+    def run_c2p(self, fluid, eos, prim_delta, latch_flags=True, prim_only=False):
+        """the copy with ConservedToPrimitive of every destination cell (primitives at dst + prim_delta elements);
+        prim_only: nothing is stored at dst itself"""
+        fn = self.ctx.lib.apk_copy_plan_run_c2p_prim_only if prim_only else self.ctx.lib.apk_copy_plan_run_c2p
+        _check(fn(self.ctx.h, self.h, L.FLUID[fluid], C.byref(eos), int(prim_delta), 1 if latch_flags else 0, _stream()),
+               self.ctx.lib, self.ctx.h)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.ctx.lib.apk_copy_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 # ---- the task functions ---------------------------------------------------------------------
 def CalculateFluxes(md, fluid, recon, riemann, eos, c_h=0.0, tight=False, boundary=False, face_list=None):
     """Hydro::CalculateFluxes<fluid,recon,rsolver>(md)  -- src/hydro/hydro.cpp:1025; tight: only the

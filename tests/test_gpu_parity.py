@@ -198,6 +198,74 @@ def test_cons_to_prim(request, oracle, fluid, floors):
     assert ctx.poll_flags() == 0
 
 
+@pytest.mark.parametrize("fluid", ["euler", "glmmhd"])
+def test_copy_plans_with_and_without_cons_to_prim(request, oracle, fluid):
+    """apk_copy_plan_run / _run_c2p / _run_c2p_prim_only on an x1 ghost strip (3 cells of every row: the worst box for
+    the memory system), an x3 slab filled from a compact message buffer and a reflecting strip with the normal momentum
+    flipped: the copies bit for bit, the primitives the oracle's ConservedToPrimitive of the copied values, and with
+    prim_only nothing written at the destination itself."""
+    import torch
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    nx, ng, nv = (12, 6, 5), 3, NHYDRO[fluid]
+    g = H.geom(fluid, nx, ng, 0)
+    w = H.random_prim(fluid, nx, ng, nscalars=0, seed=21, kind="rough", nblocks=2)
+    u = H.prim_to_cons(fluid, w, 1.4)
+    ni, nj, nk = nx[0] + 2 * ng, nx[1] + 2 * ng, nx[2] + 2 * ng
+    sj, sk, sn = ni, ni * nj, ni * nj * nk
+    per = nv * sn
+    msg_ext = (nx[0], nx[1], ng)
+    msg_cells = msg_ext[0] * msg_ext[1] * msg_ext[2]
+    msg = H.prim_to_cons(fluid, H.random_prim(fluid, (msg_ext[0], msg_ext[1], msg_ext[2]), 0, nscalars=0, seed=22, kind="rough", nblocks=1), 1.4)
+    msg = np.ascontiguousarray(msg.reshape(nv, msg_ext[2], msg_ext[1], msg_ext[0]))
+    eos = hydro.L.make_eos(1.4)
+
+    def run(mode):
+        cons = torch.from_numpy(u.copy()).cuda()
+        prim = torch.full_like(cons, -777.0)
+        buf = torch.from_numpy(msg.copy()).cuda()
+        base = cons.data_ptr()
+        blk = lambda b, i, j, k: base + 8 * (b * per + k * sk + j * sj + i)
+        big = (1, sj, sk, sn)
+        regs = [
+            # block 0's upper x1 ghost strip <- block 1's first interior columns
+            dict(src=blk(1, ng, ng, ng), dst=blk(0, ng + nx[0], ng, ng), ext=(ng, nx[1], nx[2]), nvar=nv, src_stride=big, dst_stride=big),
+            # block 1's lower x3 ghost slab <- a compact message
+            dict(src=buf.data_ptr(), dst=blk(1, ng, ng, 0), ext=msg_ext, nvar=nv,
+                 src_stride=(1, msg_ext[0], msg_ext[0] * msg_ext[1], msg_cells), dst_stride=big),
+            # block 1's lower x2 ghost strip: reflecting (mirror of the first interior rows, normal momentum flipped)
+            dict(src=blk(1, ng, 2 * ng - 1, ng), dst=blk(1, ng, 0, ng), ext=(nx[0], ng, nx[2]), nvar=nv,
+                 src_stride=(1, -sj, sk, sn), dst_stride=big, flip_var=2),
+        ]
+        plan = hydro.CopyPlan(ctx, regs)
+        ctx.poll_flags()
+        if mode == "copy":
+            plan.run()
+        else:
+            plan.run_c2p(fluid, eos, (prim.data_ptr() - cons.data_ptr()) // 8, prim_only=(mode == "prim_only"))
+        torch.cuda.synchronize()
+        assert ctx.poll_flags() == 0
+        return cons.cpu().numpy(), prim.cpu().numpy()
+
+    want = u.copy()
+    want[0, :, ng:ng + nx[2], ng:ng + nx[1], ng + nx[0]:] = u[1, :, ng:ng + nx[2], ng:ng + nx[1], ng:2 * ng]
+    want[1, :, 0:ng, ng:ng + nx[1], ng:ng + nx[0]] = msg
+    want[1, :, ng:ng + nx[2], 0:ng, ng:ng + nx[0]] = u[1, :, ng:ng + nx[2], 2 * ng - 1:ng - 1:-1, ng:ng + nx[0]]
+    want[1, 2, ng:ng + nx[2], 0:ng, ng:ng + nx[0]] *= -1.0
+    touched = want != u
+    _, w_want, bad = H.orc_c2p(fluid, g, want, oracle.make_eos(1.4))
+    assert bad == 0 and touched.any()
+    cell_touched = touched.any(axis=1, keepdims=True) & np.ones_like(touched)
+    got_c, got_p = run("copy")
+    assert np.array_equal(got_c, want) and np.all(got_p == -777.0)
+    got_c, got_p = run("c2p")
+    assert np.array_equal(got_c, want)
+    assert np.array_equal(got_p[cell_touched], w_want[cell_touched]) and np.all(got_p[~cell_touched] == -777.0)
+    got_c, got_p = run("prim_only")
+    assert np.array_equal(got_c, u)  # (nothing stored at the destination itself)
+    assert np.array_equal(got_p[cell_touched], w_want[cell_touched]) and np.all(got_p[~cell_touched] == -777.0)
+
+
 @pytest.mark.parametrize("nx", [(12, 6, 5), (16, 8, 1)], ids=["3d", "2d"])
 def test_cons_to_prim_faces_converts_everything_but_edges_and_corners(request, nx):
     """apk_cons_to_prim_faces: the full ConsToPrim's bits on every cell with at most one ghost coordinate, nothing
