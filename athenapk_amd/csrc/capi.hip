@@ -274,6 +274,9 @@ int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
   if (a->fill_derived < 0 || a->fill_derived > 3) return set_err(ctx, APK_ERR_INVALID, "fused stage: fill_derived must be 0, 1, 2 or 3");
   if (a->fill_derived == 3 && !a->estimate_dt)
     return set_err(ctx, APK_ERR_INVALID, "fused stage: fill_derived = 3 (primitives for the time-step estimate only) needs estimate_dt");
+  if (a->prim_from_cons < 0 || a->prim_from_cons > 2) return set_err(ctx, APK_ERR_INVALID, "fused stage: prim_from_cons must be 0, 1 or 2");
+  if (a->prim_from_cons == 2 && a->cons_out_delta == 0)
+    return set_err(ctx, APK_ERR_INVALID, "fused stage: prim_from_cons = 2 (input = u0.cons) needs an out-of-place result (cons_out_delta)");
   if (a->prim_from_cons) {
     for (const apk_block_desc &b : u1->h_blocks)
       if (!b.cons) return set_err(ctx, APK_ERR_INVALID, "fused stage: prim_from_cons needs u1.cons");

@@ -119,11 +119,12 @@ __device__ unsigned long long g_m12f_phase[8];
 #define APK_TICK(slot) do { } while (0)
 #endif
 
-template <int FLUID, int RECON, int RS, int EXTRA, bool LEAN>
+template <int FLUID, int RECON, int RS, int EXTRA, bool LEAN, bool FC = false>
 __global__ void __launch_bounds__(64, APK_M12F_WAVES)
 fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves, int per_xcd,
                   long long total_rows, int sched_lockstep) {
   static_assert(RECON != APK_RC_DC, "donor-cell stages have their own single-kernel form");
+  static_assert(!FC || LEAN, "prim_from_cons: lean form only");
   constexpr int NV = nvars<FLUID>();
   constexpr int H = recon_halfwidth(RECON);
   constexpr int NS = 2 * H;
@@ -208,7 +209,11 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     const double area2 = to_sgpr(b0.dx[0] * b0.dx[2]);
     const double vol = to_sgpr(b0.dx[0] * b0.dx[1] * b0.dx[2]);
     const double upd = LEAN ? update_coefficient(sp, vol) : 0.0;
-    const double *prim_generic = b0.prim + base;
+    // the stage's input: u0's primitives, or the conserved state of u1 / u0 (FC, fused_kernel.hpp: cons_row_to_prim)
+    const apk_block_desc *srcb = (FC && sp.prim_from_cons != 2) ? u1.blocks : u0.blocks;  // (wave-uniform)
+    auto input_of = [&](int blk) -> const double * { return FC ? srcb[blk].cons : u0.blocks[blk].prim; };
+    const double *in0 = input_of(b);
+    const double *prim_generic = in0 + base;
     // Direct neighbour addressing (sp.face_nbr): a lane on a ghost column reads the interior column
     // of the block behind that x1 face; the stencil rows below js / above je of an interior column
     // come from the block behind the x2 face (wave-uniform offset, not applied on ghost columns:
@@ -217,12 +222,12 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     bool gcol = false;
     if (sp.face_nbr) {
       const int *fn = sp.face_nbr + 6 * b;
-      if (fn[2] >= 0) nbr_lo = (u0.blocks[fn[2]].prim - b0.prim) + (int64_t)u0.nx2 * st;
-      if (fn[3] >= 0) nbr_hi = (u0.blocks[fn[3]].prim - b0.prim) - (int64_t)u0.nx2 * st;
+      if (fn[2] >= 0) nbr_lo = (input_of(fn[2]) - in0) + (int64_t)u0.nx2 * st;
+      if (fn[3] >= 0) nbr_hi = (input_of(fn[3]) - in0) - (int64_t)u0.nx2 * st;
       gcol = (i < u0.is) || (i > u0.ie);
       if (gcol) {
         const int nb = fn[i < u0.is ? 0 : 1];
-        if (nb >= 0) prim_generic = u0.blocks[nb].prim + base + (i < u0.is ? u0.nx1 : -u0.nx1);
+        if (nb >= 0) prim_generic = input_of(nb) + base + (i < u0.is ? u0.nx1 : -u0.nx1);
       }
     }
     const auto prim = as_global(prim_generic);
@@ -242,11 +247,13 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
         for (int n = 0; n < NV; ++n) init[m][n] = prim[n * u0.sn + row_off(r0 + m)];
       asm volatile("" ::: "memory");
 #pragma unroll
-      for (int m = 0; m < NS; ++m)
+      for (int m = 0; m < NS; ++m) {
+        if constexpr (FC) cons_row_to_prim<FLUID>(sp, init[m]);
 #pragma unroll
         for (int n = 0; n < NV; ++n) ring[(m * NV + n) * 64 + lane] = init[m][n];
+      }
     }
-    double Pn[NV];  // row c+H
+    double Pn[NV];  // row c+H (FC: as loaded until the x2 reconstruction that first uses it)
 #pragma unroll
     for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + row_off(c + H)];
 
@@ -350,6 +357,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
       }
       APK_TICK(2);  // x1 Riemann + flux difference
       // ---- (3) x2: reconstruct cell c from ring rows c-H..c+H-1 and the register row c+H
+      if constexpr (FC) cons_row_to_prim<FLUID>(sp, Pn);  // (every lane: the row goes into the ring as the x1 stencil of its neighbours)
       double qln[NV], qrn[NV];
       if (need_r2) {
       double an[NS];  // ring rows of the next variable (software-pipelined LDS reads)
@@ -546,7 +554,13 @@ inline void launch_m12f(const PackView &u0, const PackView &u1, const StageParam
     static const int lockstep = std::getenv("APK_M12F_LOCKSTEP") ? std::atoi(std::getenv("APK_M12F_LOCKSTEP")) : 1;  // A/B switch
 #define APK_LAUNCH_M12F(EXTRA_, LEAN_) \
   hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, LEAN_>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows, lockstep)
-    if (extra == EXTRA_C2P_DT) {
+#define APK_LAUNCH_M12F_FC(EXTRA_) \
+  hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, true, true>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows, lockstep)
+    if (sp.prim_from_cons) {  // (lean forms only: launch_fused_stage has checked)
+      if (extra == EXTRA_C2P_DT) APK_LAUNCH_M12F_FC(EXTRA_C2P_DT);
+      else if (extra == EXTRA_C2P) APK_LAUNCH_M12F_FC(EXTRA_C2P);
+      else APK_LAUNCH_M12F_FC(EXTRA_NONE);
+    } else if (extra == EXTRA_C2P_DT) {
       if (lean) APK_LAUNCH_M12F(EXTRA_C2P_DT, true);
       else APK_LAUNCH_M12F(EXTRA_C2P_DT, false);
     } else if (extra == EXTRA_C2P) {
@@ -557,6 +571,7 @@ inline void launch_m12f(const PackView &u0, const PackView &u1, const StageParam
       else APK_LAUNCH_M12F(EXTRA_NONE, false);
     }
 #undef APK_LAUNCH_M12F
+#undef APK_LAUNCH_M12F_FC
 #if APK_M12F_TIMING
     {
       static int calls = 0;

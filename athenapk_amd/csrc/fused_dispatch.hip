@@ -53,7 +53,7 @@ int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
   if (a.fill_derived < 0 || a.fill_derived > 3 || (a.fill_derived == 3 && !a.estimate_dt)) return APK_ERR_INVALID;
   sp.prim_to_u1 = (a.fill_derived >= 2) ? 1 : 0;
   sp.no_prim_store = (a.fill_derived == 3) ? 1 : 0;  // (the stage forms that cannot honour it refuse: launch_fused_stage)
-  sp.prim_from_cons = a.prim_from_cons ? 1 : 0;
+  sp.prim_from_cons = a.prim_from_cons;  // (0, 1 or 2: apk_stage_fused has checked)
   sp.phase = a.phase;
   sp.window = (a.phase == 1) ? a.window : nullptr;
   sp.window_rl = a.window_rl;

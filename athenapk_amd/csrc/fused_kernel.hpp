@@ -340,16 +340,33 @@ constexpr int kMarchMinWaves = 2;
 #define APK_PPM_PAIRS 0  // 1: PPM reconstructs two variables per pass in the marches (hydro_math.hpp: ppm_interface2 / ppm_cell2), A/B
 #endif
 
+// apk_stage_args.prim_from_cons in the two-kernel stage: the sweeps load rows of the CONSERVED input state and convert
+// them (ConsToPrim in its lean form, the function the stage that produced the state would have applied: same bits) --
+// a row is requested one iteration ahead and converted in registers where it is first used.  The input state is u1's
+// (prim_from_cons = 1: stages with gam0 = 0, whose output is another buffer) or u0's (2: the stage then writes its
+// result out of place, cons_out_delta != 0, because neighbouring waves still read the old values).
+template <int FLUID>
+APK_DEV void cons_row_to_prim(const StageParams &sp, double (&q)[nvars<FLUID>()]) {
+  constexpr int NV = nvars<FLUID>();
+  double u[NV], w[NV], di;
+#pragma unroll
+  for (int n = 0; n < NV; ++n) u[n] = q[n];
+  (void)cons_to_prim_core<FLUID, true>(sp.eos, sp.k.eos_gm1, sp.k.vceil_sq, sp.k.pfloor_over_gm1, u, w, di);
+#pragma unroll
+  for (int n = 0; n < NV; ++n) q[n] = w[n];
+}
+
 template <int FLUID, int RECON>
 constexpr int march_lds_bytes() {
   return 2 * recon_halfwidth(RECON) * nvars<FLUID>() * 64 * (int)sizeof(double);
 }
 
-template <int FLUID, int RECON, int RS, int DIR, bool FINAL, int EXTRA = EXTRA_NONE>
+template <int FLUID, int RECON, int RS, int DIR, bool FINAL, int EXTRA = EXTRA_NONE, bool FC = false>
 __global__ void __launch_bounds__(64, kMarchMinWaves)
 fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) {
   static_assert(DIR == 2 || DIR == 3, "march is for x2/x3");
   static_assert(FINAL || EXTRA == EXTRA_NONE, "extras belong to the finishing sweep");
+  static_assert(!FC || (DIR == 3 && !FINAL), "prim_from_cons: the x3 sweep of the two-kernel stage");
   double lane_min_dt = 1.7976931348623157e308;
   constexpr int NV = nvars<FLUID>();
   constexpr int H = recon_halfwidth(RECON);
@@ -394,7 +411,11 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
   const double area = (DIR == 2) ? b0.dx[0] * b0.dx[2] : b0.dx[0] * b0.dx[1];
   const double vol = b0.dx[0] * b0.dx[1] * b0.dx[2];
   double *dscratch = sp.du + (int64_t)b * u0.sn * u0.nvar;
-  const double *prim = b0.prim + base;
+  // the stage's input: u0's primitives, or the conserved state of u1 / u0 (FC, see cons_row_to_prim)
+  const apk_block_desc *srcb = (FC && sp.prim_from_cons != 2) ? u1.blocks : u0.blocks;  // (wave-uniform)
+  auto input_of = [&](int blk) -> const double * { return FC ? srcb[blk].cons : u0.blocks[blk].prim; };
+  const double *in0 = input_of(b);
+  const double *prim = in0 + base;
   double *prim_dst = (EXTRA != EXTRA_NONE && sp.prim_to_u1) ? u1.blocks[b].prim : b0.prim;
   // Direct neighbour addressing (sp.face_nbr): the stencil rows below / above the interior come
   // from the interior of the block behind that face (the lanes are interior columns, so the
@@ -404,8 +425,8 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
   if (sp.face_nbr) {
     const int n_int = (DIR == 2) ? u0.nx2 : u0.nx3;
     const int nlo = sp.face_nbr[6 * b + 2 * (DIR - 1)], nhi = sp.face_nbr[6 * b + 2 * (DIR - 1) + 1];
-    if (nlo >= 0) nbr_lo = (u0.blocks[nlo].prim - b0.prim) + (int64_t)n_int * st;
-    if (nhi >= 0) nbr_hi = (u0.blocks[nhi].prim - b0.prim) - (int64_t)n_int * st;
+    if (nlo >= 0) nbr_lo = (input_of(nlo) - in0) + (int64_t)n_int * st;
+    if (nhi >= 0) nbr_hi = (input_of(nhi) - in0) - (int64_t)n_int * st;
   }
   auto row_off = [&](int r) -> int64_t {
     return (int64_t)r * st + (r < lo_int ? nbr_lo : (r > hi_int ? nbr_hi : (int64_t)0));
@@ -415,10 +436,15 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
   int c = s - 1;
   const int r0 = c - H;
 #pragma unroll
-  for (int m = 0; m < NS; ++m)
+  for (int m = 0; m < NS; ++m) {
+    double row[NV];
 #pragma unroll
-    for (int n = 0; n < NV; ++n) ring[(m * NV + n) * 64 + lane] = prim[n * u0.sn + row_off(r0 + m)];
-  double Pn[NV];  // row c+H
+    for (int n = 0; n < NV; ++n) row[n] = prim[n * u0.sn + row_off(r0 + m)];
+    if constexpr (FC) cons_row_to_prim<FLUID>(sp, row);
+#pragma unroll
+    for (int n = 0; n < NV; ++n) ring[(m * NV + n) * 64 + lane] = row[n];
+  }
+  double Pn[NV];  // row c+H (FC: as loaded until the top of the iteration that uses it)
 #pragma unroll
   for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + row_off(c + H)];
 
@@ -444,6 +470,7 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
     // the streaming operands of the cell that completes in this iteration (c-1) are requested
     // first, so they are in flight during the reconstruction and the Riemann solve
     const int64_t done = base + (int64_t)(c - 1) * st;
+    if constexpr (FC) cons_row_to_prim<FLUID>(sp, Pn);
     double duv[NV], u1v[NV];
     if (c >= s + 1) {
       if (FINAL || !sp.du_first) {
@@ -1415,8 +1442,13 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
   // apk_stage_args.fill_derived = 3 / prim_from_cons: the lean two-kernel stage / the lean single-march donor-cell stage only
   if (sp.no_prim_store && !(u0.ndim == 3 && RECON != APK_RC_DC && stage_is_lean(sp) && two_kernel_stage_applies(u0, RECON, extra, sp)))
     return APK_ERR_UNSUPPORTED;
-  if (sp.prim_from_cons && !(u0.ndim == 3 && RECON == APK_RC_DC && stage_is_lean(sp) && (extra == EXTRA_NONE || sp.prim_to_u1)))
-    return APK_ERR_UNSUPPORTED;
+  if (sp.prim_from_cons) {
+    const bool dc_ok = RECON == APK_RC_DC && sp.prim_from_cons == 1 && (extra == EXTRA_NONE || sp.prim_to_u1);
+    // the two-kernel stage, whole or split (a stage that reads u0's conserved state writes its result elsewhere)
+    const bool two_ok = RECON != APK_RC_DC && two_kernel_stage_applies(u0, RECON, extra, sp) && !sp.mflux &&
+                        (sp.prim_from_cons == 1 || sp.out_delta != 0);
+    if (!(u0.ndim == 3 && stage_is_lean(sp) && (dc_ok || two_ok))) return APK_ERR_UNSUPPORTED;
+  }
   const bool do_x1 = sp.phase != 2, do_rest = sp.phase != 1;
   // timing slots: donor-cell stages (VL2 predictor) are accounted separately
   constexpr int TS = (RECON == APK_RC_DC) ? (int)APK_T_FUSED_DC_X1 : (int)APK_T_FUSED_X1;
@@ -1525,7 +1557,10 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
         const int nseg = march_segments((int64_t)g3.x * g3.y * g3.z, u0.nx3);
         g3.z *= nseg;
         ScopedTiming t(sp.ctx, TS + 2, s);
-        hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 3, false>), g3, dim3(64), lds, s, u0, u1, sp1, nseg, rpw);
+        if (sp.prim_from_cons)
+          hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 3, false, EXTRA_NONE, true>), g3, dim3(64), lds, s, u0, u1, sp1, nseg, rpw);
+        else
+          hipLaunchKernelGGL((fused_march_kernel<FLUID, RECON, RS, 3, false>), g3, dim3(64), lds, s, u0, u1, sp1, nseg, rpw);
       }
       if (do_rest) {
         StageParams sp2 = sp;

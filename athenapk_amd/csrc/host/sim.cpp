@@ -541,6 +541,22 @@ bool prim_free_cycle(const apk_sim *s) {
   return apk_stage_split_axis(s->mu0(), &pkg.flux_other_stage, 2) == 3;
 }
 
+// The same for integrators whose stages are all two-kernel stages (RK1 / RK2 / RK3 with PLM, PPM, WENO-Z ...): every
+// stage derives its input from the conserved state (apk_stage_args.prim_from_cons: u1's in stages with gam0 = 0, u0's
+// with an out-of-place result in the others -- a third buffer in rotation, as for the trial stages of first-order flux
+// correction) and stores no primitives; the last one computes them for the time-step estimate (fill_derived = 3).
+// APK_RK_PRIM_FREE=0 switches it off (A/B).
+bool rk_prim_free_cycle(const apk_sim *s) {
+  static const int mode = std::getenv("APK_RK_PRIM_FREE") ? std::atoi(std::getenv("APK_RK_PRIM_FREE")) : 1;  // A/B switch
+  const HydroPackage &pkg = s->pkg;
+  if (!mode || !s->prim_free_on || s->amr || s->fmft || s->mesh.ndim != 3 || !stage_can_fuse(s)) return false;
+  if (pkg.nscalars != 0 || (pkg.fluid == APK_FLUID_GLMMHD && pkg.glmmhd_source_extended) || !pkg.calc_dt_hyp) return false;
+  const apk_eos &e = pkg.eos;
+  if (!(e.vceil > 1.0e300 && e.eceil > 1.0e300 && e.pfloor <= 0.0)) return false;  // (eos_is_lean)
+  if (pkg.flux_first_stage.recon == APK_RC_DC || pkg.flux_other_stage.recon == APK_RC_DC) return false;
+  return apk_stage_split_axis(s->mu0(), &pkg.flux_first_stage, 0) == 3 && apk_stage_split_axis(s->mu0(), &pkg.flux_other_stage, 0) == 3;
+}
+
 // May the exchange at the end of a cycle deliver ONE layer of ghost cells (mesh.hpp PH_PACK_THIN)?  The first stage of the
 // next cycle must be the single-march donor-cell stage (it reads one layer; the corrector's exchange stays a full one),
 // nothing else in a cycle may read ghost zones (no forcing, no refinement), and the box must be periodic: a physical
@@ -853,7 +869,8 @@ int do_stage(apk_sim *s, int stage) {
   if (!direct && s->local_ghosts_stale) SIM_TRY(s, sync_ghosts(s));
   // (the full-step primitives were not stored: only the donor-cell predictor can do without them)
   const bool prim_free = prim_free_cycle(s);
-  const bool from_cons = s->prim_stale && stage == 1 && prim_free;
+  const bool rk_free = rk_prim_free_cycle(s);
+  const bool from_cons = s->prim_stale && ((stage == 1 && prim_free) || rk_free);
   if (s->prim_stale && !from_cons) SIM_TRY(s, sync_ghosts(s));
   // (ghost zones one layer deep: enough for the donor-cell predictor they were left for, and for nothing else)
   if (s->remote_ghosts_thin && !(stage == 1 && thin_exchange_cycle(s))) SIM_TRY(s, sync_ghosts(s));
@@ -925,8 +942,16 @@ int do_stage(apk_sim *s, int stage) {
     a.estimate_dt = (fused_fill && stage == s->nstages && pkg.calc_dt_hyp) ? 1 : 0;
     a.prim_from_cons = from_cons ? 1 : 0;
     // the last stage of a cycle whose successor's predictor reads the conserved state: primitives for the dt estimate only
-    const bool no_prim = prim_free && stage == s->nstages && two_kernel && swap_prim && a.estimate_dt;
-    if (no_prim) a.fill_derived = 3;
+    const bool no_prim = (prim_free && stage == s->nstages && two_kernel && swap_prim && a.estimate_dt) || (rk_free && two_kernel && fused_fill);
+    if (no_prim) a.fill_derived = a.estimate_dt ? 3 : 0;  // (rk_free: stages that are not the last compute no primitives at all)
+    int outbuf = s->cur;
+    if (rk_free && from_cons && g0 != 0.0) {
+      // the input is the state this stage updates: its result goes to the free buffer, which becomes the current one
+      SIM_TRY(s, ensure_trial_cons(s));
+      outbuf = s->freebuf();
+      a.prim_from_cons = 2;
+      a.cons_out_delta = s->d_cons2[outbuf] - s->d_cons2[s->cur];
+    }
     {
       // The predictor of VL2: the corrector has gam0 = 0 and takes its fluxes from the predictor's primitives, so the
       // half-step CONSERVED state is read by nobody but the ghost exchange -- the nghost-deep shell of every block --
@@ -987,6 +1012,7 @@ int do_stage(apk_sim *s, int stage) {
     if (from_cons) s->prim_stale = false;  // (the predictor has written the half-step primitives: the current buffer is valid again)
     if (no_prim) s->prim_stale = true;
     else if (swap_prim) s->pcur = 1 - s->pcur;
+    s->cur = outbuf;  // (its ghost zones are filled by the exchange below)
     if (s->amr) {
       SIM_TRY(s, ensure_flux_arrays(s));
       const double psi_factor = a.dedner != 0 ? std::exp(-pkg.glmmhd_alpha * pkg.c_h * beta_dt / pkg.mindx) : 1.0;

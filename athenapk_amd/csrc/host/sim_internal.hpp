@@ -70,6 +70,7 @@ enum { GHOST_COPY = 0, GHOST_C2P = 1, GHOST_PRIM_ONLY = 2 };
 int run_ghost_plan(apk_sim *s, int buf, int phase, int c2p, apk_stream_t stream = nullptr);
 int exchange_begin(apk_sim *s, bool async, int c2p, bool skip_local = false, bool thin = false);
 bool thin_exchange_cycle(const apk_sim *s);
+bool rk_prim_free_cycle(const apk_sim *s);
 int materialize_remote_ghosts(apk_sim *s);
 int exchange_end(apk_sim *s, int c2p);
 int exchange_ghosts(apk_sim *s, int c2p = GHOST_COPY, bool skip_local = false, bool thin = false);

@@ -244,10 +244,14 @@ typedef struct apk_stage_args {
   int cons_store;
   /* prim_from_cons = 1: u0.prim does NOT hold the primitives of the stage's input state; the kernel derives them from
    * u1.cons, which must be that state (true in stage 1 of every integrator: u1 = u0 there, hydro_driver.cpp:474-495).
-   * The single-march 3-D donor-cell stage in its lean form only (else APK_ERR_UNSUPPORTED).  Together with
-   * fill_derived = 3 in the last stage of the previous cycle it removes the full-step primitives from memory
-   * altogether: 72 B per cell less to store there and 72 B less to load here, both on kernels that run at the memory
-   * system's rate.
+   * The single-march 3-D donor-cell stage and the two-kernel 3-D stage, in their lean forms only (else
+   * APK_ERR_UNSUPPORTED).  Together with fill_derived = 3 in the last stage of the previous cycle it removes the
+   * full-step primitives from memory altogether: 72 B per cell less to store there and 72 B less to load here, both on
+   * kernels that run at the memory system's rate.
+   * prim_from_cons = 2 (two-kernel stage): the input state is u0.cons itself -- the stages with gam0 != 0 of RK2 / RK3,
+   * whose input is the state they update.  Neighbouring waves read the old values while a wave writes new ones, so the
+   * result must go elsewhere: cons_out_delta != 0 is required.  With 1 / 2 in every stage and fill_derived = 0 (3 in the
+   * last) an RK integrator keeps no primitives in memory at all.
    * fill_derived = 3 (listed here, with estimate_dt = 1): ConsToPrim of the updated cells for the time-step estimate
    * only; neither u0.prim nor u1.prim is written.  Two-kernel 3-D stage in its lean form only. */
   int prim_from_cons;

@@ -424,6 +424,53 @@ def test_cycle_without_stored_primitives_equals_the_cycle_with_them(strict, layo
     _assert_same(np.asarray(a.dt), np.asarray(b.dt), strict)
 
 
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("scheme", [("synthetic_mhd", "rk3", "wenoz", "hlld", 3), ("synthetic_mhd", "rk2", "ppm", "hlld", 3),
+                                    ("synthetic_mhd", "rk1", "plm", "hlle", 2), ("linear_wave3d", "rk2", "plm", "hllc", 2),
+                                    ("linear_wave3d", "rk3", "ppm", "hlle", 3)],
+                         ids=["mhd_rk3_wenoz", "mhd_rk2_ppm", "mhd_rk1_plm", "hydro_rk2_plm_hllc", "hydro_rk3_ppm"])
+@pytest.mark.parametrize("layout", [((64, 64, 64), (32, 32, 32), []), ((64, 32, 32), (32, 32, 16), []),
+                                    ((64, 64, 64), (32, 32, 32), ["apk_amd/rehearse_remote_faces=true"])],
+                         ids=["2x2x2", "2x1x2", "rehearsed_remote_faces"])
+def test_rk_cycle_without_stored_primitives_equals_the_cycle_with_them(strict, scheme, layout):
+    """RK1 / RK2 / RK3 on a uniform 3-D mesh whose stages are all two-kernel stages: every stage derives its input from
+    the conserved state (apk_stage_args.prim_from_cons = 1 where gam0 = 0, = 2 with the result in a third buffer where
+    the stage updates its own input) and stores no primitives; the last one computes them for the time-step estimate.
+    Same bits as the cycle that stores and re-reads them, at every accessor, with same-rank and with remote faces."""
+    deck, integ, recon, riemann, ng = scheme
+    (n1, n2, n3), (m1, m2, m3), extra = layout
+    ov = ["parthenon/mesh/nx1=%d" % n1, "parthenon/mesh/nx2=%d" % n2, "parthenon/mesh/nx3=%d" % n3,
+          "parthenon/meshblock/nx1=%d" % m1, "parthenon/meshblock/nx2=%d" % m2, "parthenon/meshblock/nx3=%d" % m3,
+          "parthenon/time/integrator=%s" % integ, "hydro/reconstruction=%s" % recon, "hydro/riemann=%s" % riemann,
+          "parthenon/mesh/nghost=%d" % ng] + extra
+    a = _sim(deck, ov, strict=strict).initialize()
+    b = _sim(deck, ov, strict=strict)
+    b.set_prim_free(False)
+    b.initialize()
+    for _ in range(3):
+        a.step()
+        b.step()
+    assert a.prim_is_stale and not b.prim_is_stale
+    _assert_same(np.asarray(a.dt), np.asarray(b.dt), strict)
+    _assert_same(a.gather(), b.gather(), strict)
+    _assert_same(a.gather("prim"), b.gather("prim"), strict)   # (materialised by the accessor)
+    assert not a.prim_is_stale
+    a.step()                                                    # stage 1 reads stored primitives again ...
+    b.step()
+    assert a.prim_is_stale                                      # ... and the cycle ends without them
+    for lb in range(a.info.nblocks_local):
+        for field in ("cons", "prim"):
+            _assert_same(a.read_block(lb, field), b.read_block(lb, field), strict)   # ghost zones included
+    a.step()
+    a.set_prim_free(False)                                      # switching it off in mid-run
+    b.step()
+    a.step()
+    b.step()
+    assert not a.prim_is_stale
+    _assert_same(a.gather(), b.gather(), strict)
+    _assert_same(np.asarray(a.dt), np.asarray(b.dt), strict)
+
+
 # ---- direct neighbour addressing: the uniform-mesh cycle without same-rank ghost copies ------------------
 @pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
 @pytest.mark.parametrize("scheme", [("vl2", "ppm", 3), ("rk3", "wenoz", 3), ("rk2", "plm", 2)], ids=["vl2_ppm", "rk3_wenoz", "rk2_plm"])
