@@ -544,6 +544,12 @@ inline void launch_m12f(const PackView &u0, const PackView &u1, const StageParam
     const long long total_rows = (long long)u0.nblocks * wpb * u0.nx2;
     // as many waves as the device holds, but no ranges shorter than ~16 rows
     long long nw = resident_march_waves();
+    {
+      // (A/B: waves per SIMD the grid is sized for -- the hydro marches need 130 - 144 VGPRs and 5 - 10 KB of LDS per wave,
+      // three of them fit a SIMD)
+      static const int per_simd = std::getenv("APK_M12F_GRID_WAVES") ? std::atoi(std::getenv("APK_M12F_GRID_WAVES")) : 0;
+      if (per_simd > 0) nw = nw / APK_M12F_WAVES * per_simd;
+    }
     if (total_rows / 16 < nw) nw = total_rows / 16 > 0 ? total_rows / 16 : 1;
     const int nwaves = (int)nw;
     const int per_xcd = (nwaves + 7) / 8;

@@ -204,9 +204,10 @@ _RIEMANN_ID = {"hlle": 2, "llf": 3, "hllc": 4, "hlld": 5}
 
 def rocprof_kernels(fluid, recon, riemann):
     f, r, s = _FLUID_ID[fluid], _RECON_ID[recon], _RIEMANN_ID[riemann]
-    return {"fused_x1": "fused_m12f_kernel<%d, %d, %d, 2, true> / <%d, %d, %d, 0, true> (x1 + x2 finishing march; "
-                        "last stage of a cycle with ConsToPrim + dt / other stages)" % (f, r, s, f, r, s),
-            "fused_x3": "fused_march_kernel<%d, %d, %d, 3, false, 0> (x3 sweep)" % (f, r, s),
+    return {"fused_x1": "fused_m12f_kernel<%d, %d, %d, 2, true, FC> / <%d, %d, %d, 0, true, FC> (x1 + x2 finishing march; "
+                        "last stage of a cycle with ConsToPrim + dt / other stages; FC = true where the stage derives its "
+                        "input from the conserved state: the RK integrators)" % (f, r, s, f, r, s),
+            "fused_x3": "fused_march_kernel<%d, %d, %d, 3, false, 0, FC> (x3 sweep)" % (f, r, s),
             "fused_dc_x1": "fused_dc3r2_kernel<%d, %d, 1, true> (donor-cell predictor stage, two rows per lane, input derived from the "
                            "conserved state; <.., false> in the first cycle)" % (f, s)}
 
@@ -371,7 +372,7 @@ def measured_traffic(workload):
         return None, None
     # round 2 / 3: the two-kernel stage (x3 sweep + finishing x1/x2 march); round 1: three sweeps
     for fname, stage, note in (
-            ("r04_hbm_traffic.json", ("fused_march_kernel<2, 3, 5, 3, false, 0>", "fused_m12f_kernel<2, 3, 5, 2, true>"),
+            ("r04_hbm_traffic.json", ("fused_march_kernel<2, 3, 5, 3, false, 0, false>", "fused_m12f_kernel<2, 3, 5, 2, true, false>"),
              "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, reads calibrated on the dt kernel's known bytes"),
             ("r03_hbm_traffic.json", ("fused_march_kernel<2, 3, 5, 3, false, 0>", "fused_m12f_kernel<2, 3, 5, 2>"),
              "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, reads calibrated on the dt kernel's known bytes"),
@@ -387,7 +388,7 @@ def measured_traffic(workload):
             with open(path) as f:
                 k = json.load(f)["kernels"]
             commit = _profile_commit(path)
-            return (sum(k[name]["hbm_total_GB"] for name in stage),
+            return (sum(k[name]["hbm_total_GB"] for name in stage),  # (KeyError -> the next older profile)
                     "profiles/%s%s -- a COMMITTED profile of this command, not this run (%s)"
                     % (fname, " @ " + commit if commit else "", note))
         except Exception:
