@@ -549,7 +549,9 @@ bool prim_free_cycle(const apk_sim *s) {
 bool rk_prim_free_cycle(const apk_sim *s) {
   static const int mode = std::getenv("APK_RK_PRIM_FREE") ? std::atoi(std::getenv("APK_RK_PRIM_FREE")) : 1;  // A/B switch
   const HydroPackage &pkg = s->pkg;
-  if (!mode || !s->prim_free_on || s->amr || s->fmft || s->mesh.ndim != 3 || !stage_can_fuse(s)) return false;
+  // (forced turbulence included: its kick after the last stage estimates the time step without storing primitives,
+  // apk_turb_apply_dt)
+  if (!mode || !s->prim_free_on || s->amr || s->mesh.ndim != 3 || !stage_can_fuse(s)) return false;
   if (pkg.nscalars != 0 || (pkg.fluid == APK_FLUID_GLMMHD && pkg.glmmhd_source_extended) || !pkg.calc_dt_hyp) return false;
   const apk_eos &e = pkg.eos;
   if (!(e.vceil > 1.0e300 && e.eceil > 1.0e300 && e.pfloor <= 0.0)) return false;  // (eos_is_lean)
@@ -831,7 +833,7 @@ int turbulence_device_setup(apk_sim *s) {
 
 // turbulence::Driving = Generate + Perturb (src/pgen/turbulence.cpp:373-482), the first-order
 // operator-split source run after the last stage (src/hydro/hydro_driver.cpp:559-560)
-int turbulence_driving(apk_sim *s, double dt, bool fill) {
+int turbulence_driving(apk_sim *s, double dt, bool fill, bool no_prim) {
   s->fmft->Evolve(dt);
   const auto &vh = s->fmft->var_hat();
   std::vector<double> flat(vh.size() * 2);
@@ -851,7 +853,10 @@ int turbulence_driving(apk_sim *s, double dt, bool fill) {
   const double norm = s->accel_rms / std::sqrt(ampl / box);
   // (fill: the kick also does FillDerived and the time-step estimate of the cells it touches -- the two tasks that
   // follow it, hydro_driver.cpp:559-577, 589-603 -- instead of a full ConsToPrim pass and a dt pass afterwards)
-  if (fill) SIM_TRY(s, apk_turb_apply_fill(s->ctx, s->mu0(), s->fm_dev, norm, dt, s->pkg.fluid, &s->pkg.eos, s->pkg.calc_dt_hyp ? 1 : 0, s->stream));
+  // (no_prim: the stages of this cycle stored no primitives and the next one derives its input from the conserved state --
+  // rk_prim_free_cycle --: the kick estimates the time step and leaves the primitives where they are, stale)
+  if (fill && no_prim) SIM_TRY(s, apk_turb_apply_dt(s->ctx, s->mu0(), s->fm_dev, norm, dt, s->pkg.fluid, &s->pkg.eos, s->stream));
+  else if (fill) SIM_TRY(s, apk_turb_apply_fill(s->ctx, s->mu0(), s->fm_dev, norm, dt, s->pkg.fluid, &s->pkg.eos, s->pkg.calc_dt_hyp ? 1 : 0, s->stream));
   else SIM_TRY(s, apk_turb_apply(s->ctx, s->mu0(), s->fm_dev, norm, dt, s->stream));
   return APK_OK;
 }
@@ -1106,7 +1111,11 @@ int do_stage(apk_sim *s, int stage) {
   if (s->fmft && stage == s->nstages) {
     static const bool plain_kick = std::getenv("APK_TURB_PLAIN_KICK") != nullptr;  // A/B switch
     const bool kick_fills = !fused_fill && !s->amr && !plain_kick;
-    SIM_TRY(s, turbulence_driving(s, s->dt, kick_fills));
+    // (a cycle whose stages store no primitives: the kick leaves them stale too, the next stage 1 reads the conserved state)
+    static const bool kick_stores = std::getenv("APK_KICK_STORES_PRIM") != nullptr;  // A/B switch
+    const bool kick_no_prim = kick_fills && s->prim_stale && rk_prim_free_cycle(s) && !kick_stores;
+    SIM_TRY(s, turbulence_driving(s, s->dt, kick_fills, kick_no_prim));
+    if (kick_fills && !kick_no_prim) s->prim_stale = false;  // (the kick wrote the primitives of every cell it touched)
     if (kick_fills) {  // as after a stage whose finishing sweep did FillDerived and the dt estimate
       fused_fill = true;
       s->stage_dt_pending = pkg.calc_dt_hyp;
@@ -1158,8 +1167,10 @@ int do_stage(apk_sim *s, int stage) {
       // one pass: the interior cells' primitives are in registers anyway (refined meshes, flux-array stages)
       SIM_TRY(s, apk_cons_to_prim_dt(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, -1, s->stream));
       s->stage_dt_pending = true;
+      s->prim_stale = false;  // (every cell of every block)
     } else {
       SIM_TRY(s, fill_derived(s));
+      s->prim_stale = false;
     }
   }
   if (stage == s->nstages && pkg.calc_c_h) {  // hydro_driver.cpp:589-603

@@ -86,7 +86,7 @@ int sync_ghosts(apk_sim *s);  // finish_pending + materialize_local_ghosts
 int fill_derived(apk_sim *s);
 int pre_step(apk_sim *s);
 int turbulence_device_setup(apk_sim *s);
-int turbulence_driving(apk_sim *s, double dt, bool fill = false);
+int turbulence_driving(apk_sim *s, double dt, bool fill = false, bool no_prim = false);
 int do_stage(apk_sim *s, int stage);
 double xc(const apk_sim *s, const double x0[3], int d, int idx);
 void block_origin(const apk_sim *s, int lb, double x0[3]);

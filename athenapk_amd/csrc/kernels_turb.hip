@@ -290,7 +290,10 @@ int ensure_partial_cap(apk_ctx *ctx, size_t n) {
 // The kick with the work of the two tasks that follow it on the same cell: FillDerived (ConsToPrim, floors
 // included, prim in place: the kick is the last thing to touch the cell before the next stage reads it) and
 // the time-step estimate -- one pass over cons instead of three.
-template <int FLUID, bool WITH_DT>
+// STORE_PRIM = false (apk_turb_apply_dt): the primitives feed the time-step estimate only -- the next stage derives its
+// input from the conserved state (apk_stage_args.prim_from_cons).  Of the conserved variables only the kicked ones
+// (momenta, energy) and whatever a floor changed are written back.
+template <int FLUID, bool WITH_DT, bool STORE_PRIM = true>
 __global__ void __launch_bounds__(256)
 turb_apply_fill_kernel(PackView pv, const apk_fmft_block *blocks, double norm, double dt, apk_eos eos, unsigned *flags,
                        unsigned long long *dt_bits) {
@@ -306,9 +309,9 @@ turb_apply_fill_kernel(PackView pv, const apk_fmft_block *blocks, double norm, d
     acc[0 * pv.sn] = a0;
     acc[1 * pv.sn] = a1;
     acc[2 * pv.sn] = a2;
-    double un[NV], w[NV], di;
+    double un[NV], was[NV], w[NV], di;
 #pragma unroll
-    for (int n = 0; n < NV; ++n) un[n] = u[n * pv.sn];
+    for (int n = 0; n < NV; ++n) was[n] = un[n] = u[n * pv.sn];
     const double den = un[IDN];
     const double qa = dt * den;
     const double m1 = un[IM1], m2 = un[IM2], m3 = un[IM3];
@@ -318,13 +321,17 @@ turb_apply_fill_kernel(PackView pv, const apk_fmft_block *blocks, double norm, d
     un[IM3] = m3 + qa * a2;
     const unsigned fl = cons_to_prim_cell<FLUID>(eos, un, w, di);
     if (fl) atomicOr(flags, fl);
-    double *p = blk.prim + cell;
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
-      u[n * pv.sn] = un[n];
-      p[n * pv.sn] = w[n];
+      const bool kicked = (n == IM1 || n == IM2 || n == IM3 || n == IEN);
+      if (kicked || un[n] != was[n]) u[n * pv.sn] = un[n];  // (the others: only where a floor acted)
     }
-    for (int n = NV; n < pv.nvar; ++n) p[n * pv.sn] = u[n * pv.sn] * di;  // passive scalars
+    if constexpr (STORE_PRIM) {
+      double *p = blk.prim + cell;
+#pragma unroll
+      for (int n = 0; n < NV; ++n) p[n * pv.sn] = w[n];
+      for (int n = NV; n < pv.nvar; ++n) p[n * pv.sn] = u[n * pv.sn] * di;  // passive scalars
+    }
     if constexpr (WITH_DT) {  // EstimateHyperbolicTimestep (hydro.cpp:845-895) on the fresh primitives
       double lx, ly = 0.0, lz = 0.0;
       if constexpr (FLUID == APK_FLUID_EULER) {
@@ -378,6 +385,35 @@ int finish_sums(apk_ctx *ctx, int nwg, double *out, hipStream_t s) {
 }  // namespace apk
 
 using namespace apk;
+
+namespace {
+int turb_apply_fill_impl(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, double norm, double dt, int fluid, const apk_eos *eos,
+                         int estimate_dt, bool store_prim, apk_stream_t stream) {
+  if (!ctx || !md || !f || !eos || f->nblocks != md->view.nblocks || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||
+      md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9) || (!store_prim && md->view.nvar != md->view.nhydro))
+    return set_err(ctx, APK_ERR_INVALID, "apk_turb_apply_fill: bad argument");
+  for (const auto &b : md->h_blocks)
+    if (store_prim && !b.prim) return set_err(ctx, APK_ERR_INVALID, "apk_turb_apply_fill: block without prim pointer");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  unsigned long long *dt_bits = ctx->d_u64 + 4;  // the stage's word: apk_stage_dt_read / apk_stage_dt_flags_read
+  if (estimate_dt && hipMemcpyAsync(dt_bits, ctx->d_u64 + 15, sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return set_err(ctx, APK_ERR_DEVICE, "apk_turb_apply_fill", hipGetLastError());
+  const dim3 g = igrid(md->view), blk(64, 4, 1);
+#define APK_LAUNCH_KICK(FL, DT, SP) \
+  hipLaunchKernelGGL((turb_apply_fill_kernel<FL, DT, SP>), g, blk, 0, s, md->view, f->d_blocks, norm, dt, *eos, ctx->d_flags, dt_bits)
+  if (fluid == APK_FLUID_EULER) {
+    if (!store_prim) APK_LAUNCH_KICK(APK_FLUID_EULER, true, false);
+    else if (estimate_dt) APK_LAUNCH_KICK(APK_FLUID_EULER, true, true);
+    else APK_LAUNCH_KICK(APK_FLUID_EULER, false, true);
+  } else {
+    if (!store_prim) APK_LAUNCH_KICK(APK_FLUID_GLMMHD, true, false);
+    else if (estimate_dt) APK_LAUNCH_KICK(APK_FLUID_GLMMHD, true, true);
+    else APK_LAUNCH_KICK(APK_FLUID_GLMMHD, false, true);
+  }
+#undef APK_LAUNCH_KICK
+  return hipGetLastError() == hipSuccess ? APK_OK : set_err(ctx, APK_ERR_DEVICE, "turb_apply_fill launch", hipGetLastError());
+}
+}  // namespace
 
 extern "C" {
 
@@ -460,24 +496,11 @@ int apk_turb_apply(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, double norm, d
 
 int apk_turb_apply_fill(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, double norm, double dt, int fluid, const apk_eos *eos,
                         int estimate_dt, apk_stream_t stream) {
-  if (!ctx || !md || !f || !eos || f->nblocks != md->view.nblocks || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||
-      md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9))
-    return set_err(ctx, APK_ERR_INVALID, "apk_turb_apply_fill: bad argument");
-  for (const auto &b : md->h_blocks)
-    if (!b.prim) return set_err(ctx, APK_ERR_INVALID, "apk_turb_apply_fill: block without prim pointer");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  unsigned long long *dt_bits = ctx->d_u64 + 4;  // the stage's word: apk_stage_dt_read / apk_stage_dt_flags_read
-  if (estimate_dt && hipMemcpyAsync(dt_bits, ctx->d_u64 + 15, sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
-    return set_err(ctx, APK_ERR_DEVICE, "apk_turb_apply_fill", hipGetLastError());
-  const dim3 g = igrid(md->view), blk(64, 4, 1);
-  if (fluid == APK_FLUID_EULER) {
-    if (estimate_dt) hipLaunchKernelGGL((turb_apply_fill_kernel<APK_FLUID_EULER, true>), g, blk, 0, s, md->view, f->d_blocks, norm, dt, *eos, ctx->d_flags, dt_bits);
-    else hipLaunchKernelGGL((turb_apply_fill_kernel<APK_FLUID_EULER, false>), g, blk, 0, s, md->view, f->d_blocks, norm, dt, *eos, ctx->d_flags, dt_bits);
-  } else {
-    if (estimate_dt) hipLaunchKernelGGL((turb_apply_fill_kernel<APK_FLUID_GLMMHD, true>), g, blk, 0, s, md->view, f->d_blocks, norm, dt, *eos, ctx->d_flags, dt_bits);
-    else hipLaunchKernelGGL((turb_apply_fill_kernel<APK_FLUID_GLMMHD, false>), g, blk, 0, s, md->view, f->d_blocks, norm, dt, *eos, ctx->d_flags, dt_bits);
-  }
-  return hipGetLastError() == hipSuccess ? APK_OK : set_err(ctx, APK_ERR_DEVICE, "turb_apply_fill launch", hipGetLastError());
+  return turb_apply_fill_impl(ctx, md, f, norm, dt, fluid, eos, estimate_dt, true, stream);
+}
+int apk_turb_apply_dt(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, double norm, double dt, int fluid, const apk_eos *eos,
+                      apk_stream_t stream) {
+  return turb_apply_fill_impl(ctx, md, f, norm, dt, fluid, eos, 1, false, stream);
 }
 
 int apk_turbulence_history(apk_ctx *ctx, const apk_pack *md, int fluid, double gamma, double *out3,

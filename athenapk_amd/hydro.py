@@ -401,8 +401,12 @@ class FewModesFT:
         if allreduce_sum is not None:
             allreduce_sum(ampl)
         norm = accel_rms / np.sqrt(ampl[0] / box_volume)
-        if fill is not None:
-            fluid, eos, estimate_dt = fill
+        if fill is not None and len(fill) == 4 and not fill[3]:  # (fluid, eos, True, store_prim = False): apk_turb_apply_dt
+            fluid, eos = fill[0], fill[1]
+            _check(ctx.lib.apk_turb_apply_dt(ctx.h, self.md.h, self.h, float(norm), float(dt), L.FLUID[fluid], C.byref(eos), _stream()),
+                   ctx.lib, ctx.h)
+        elif fill is not None:
+            fluid, eos, estimate_dt = fill[:3]
             _check(ctx.lib.apk_turb_apply_fill(ctx.h, self.md.h, self.h, float(norm), float(dt), L.FLUID[fluid], C.byref(eos),
                                                int(estimate_dt), _stream()), ctx.lib, ctx.h)
         else:

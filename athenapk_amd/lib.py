@@ -182,6 +182,7 @@ def _signatures():
         "apk_turb_remove_mean": (i, [vp, vp, vp, c_dp, c_dp, vp]),
         "apk_turb_apply": (i, [vp, vp, vp, d, d, vp]),
         "apk_turb_apply_fill": (i, [vp, vp, vp, d, d, i, E, i, vp]),
+        "apk_turb_apply_dt": (i, [vp, vp, vp, d, d, i, E, vp]),
         "apk_turbulence_history": (i, [vp, vp, i, d, c_dp, vp]),
         "apk_history_user_reldivb": (i, [vp, vp, d, c_dp, vp]),
         "apk_refine_plan_create": (i, [vp, C.POINTER(RefineGeom), i, C.POINTER(RefineOp), i, pp]),

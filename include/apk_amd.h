@@ -432,6 +432,10 @@ int apk_turb_apply(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, double norm, d
  * instead of three. */
 int apk_turb_apply_fill(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, double norm, double dt, int fluid,
                         const apk_eos *eos, int estimate_dt, apk_stream_t stream);
+/* The same with the time-step estimate and WITHOUT storing the primitives: for cycles whose next stage derives its
+ * input from the conserved state (apk_stage_args.prim_from_cons).  No passive scalars. */
+int apk_turb_apply_dt(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, double norm, double dt, int fluid,
+                      const apk_eos *eos, apk_stream_t stream);
 /* TurbulenceHst<Ms|Ma|pb> (turbulence.cpp:47-101): out3 = volume sums of sonic Mach number,
  * Alfvenic Mach number, plasma beta.  Synchronises. */
 int apk_turbulence_history(apk_ctx *ctx, const apk_pack *md, int fluid, double gamma, double *out3,

@@ -989,6 +989,15 @@ def test_turbulence_kick_with_fill_derived_and_dt(request, oracle, strict, floor
         ctx.poll_flags()
         return md.cons_host(), md.prim_host(), drv.acc_host(), dt
     a, b = run(True), run(False)
+    # apk_turb_apply_dt: the same kick and estimate, primitives left alone
+    md = hydro.MeshData(ctx, nx, 2, 9, dx=tuple(g.dx), nblocks=nb, cons=cons, prim=np.full_like(prim, -3.0), with_flux=False)
+    drv = hydro.FewModesFT(md, [[p.transpose(2, 1, 0) for p in blk] for blk in phases])
+    drv.Inverse(f.var_hat())
+    drv.Perturb(0.01, 0.5, 1.0, fill=("glmmhd", eos, True, False))
+    dt_only = hydro.StageDt(ctx, 0.3)
+    ctx.poll_flags()
+    assert np.array_equal(md.cons_host(), a[0]) and np.array_equal(drv.acc_host(), a[2]) and dt_only == a[3]
+    assert np.all(md.prim_host() == -3.0)
     assert np.array_equal(H.interior(a[0], nx, 2), H.interior(b[0], nx, 2)) and np.array_equal(a[2], b[2])
     # (product build: ConsToPrim inlined behind the kick contracts into FMAs differently from the separate kernel)
     _cmp(H.interior(a[1], nx, 2), H.interior(b[1], nx, 2), strict, "prim")
