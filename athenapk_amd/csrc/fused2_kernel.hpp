@@ -119,6 +119,13 @@ __device__ unsigned long long g_m12f_phase[8];
 #define APK_TICK(slot) do { } while (0)
 #endif
 
+// does the from-cons finishing march keep the loaded rows in a second LDS ring?  (two rings within the 20 KB a wave may
+// take with two waves per SIMD, with some room)
+template <int FLUID, int RECON>
+constexpr bool m12f_keeps_raw_rows() {
+  return 2 * (2 * recon_halfwidth(RECON) * nvars<FLUID>() * 64 * (int)sizeof(double)) <= 19 * 1024;
+}
+
 template <int FLUID, int RECON, int RS, int EXTRA, bool LEAN, bool FC = false>
 __global__ void __launch_bounds__(64, APK_M12F_WAVES)
 fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves, int per_xcd,
@@ -137,6 +144,12 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
 #endif
   constexpr int LOADS = (APK_M12F_LOADS_GENERAL != 0 && APK_M12F_LOADS == 2 && LEAN && EXTRA == EXTRA_NONE) ? 3 : APK_M12F_LOADS;
   extern __shared__ __attribute__((aligned(16))) double ring[];
+  // FC with room in the LDS (m12f_keeps_raw_rows: the hydro marches, PLM-class GLM-MHD): the rows are ALSO kept as loaded,
+  // in a second ring -- the cell a wave retires is one of them, and its conserved value is what the update reads a second
+  // time from memory otherwise (as u1 in stages with gam0 = 0, as the old u0 in the others): 40 of 160 - 200 B per cell
+  // of a hydro stage.
+  constexpr bool RAW = FC && m12f_keeps_raw_rows<FLUID, RECON>();
+  double *const rawring = ring + NS * NV * 64;
   const int lane = threadIdx.x;
   const int w = (int)(blockIdx.x % 8u) * per_xcd + (int)(blockIdx.x / 8u);
   if (w >= nwaves) return;
@@ -248,6 +261,10 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int m = 0; m < NS; ++m) {
+        if constexpr (RAW) {
+#pragma unroll
+          for (int n = 0; n < NV; ++n) rawring[(m * NV + n) * 64 + lane] = init[m][n];
+        }
         if constexpr (FC) cons_row_to_prim<FLUID>(sp, init[m]);
 #pragma unroll
         for (int n = 0; n < NV; ++n) ring[(m * NV + n) * 64 + lane] = init[m][n];
@@ -285,6 +302,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
       // The x1 phase comes first so that its working set does not overlap the x2 solve's: only
       // its 9 flux differences stay live.
       double du[NV], d3v[NV], u1v[NV];
+      double rawv[RAW ? NV : 1];  // the retiring cell's row as loaded
       if constexpr (LOADS == 0) {
         if (retire) {
 #pragma unroll
@@ -299,6 +317,10 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
         // (the ring read of variable n+1 is issued before variable n is processed: the branchy PPM
         // code keeps the compiler from hoisting it, and with two waves per SIMD an exposed LDS round
         // trip per variable is a visible share of the iteration)
+        if constexpr (RAW) {
+#pragma unroll
+          for (int n = 0; n < NV; ++n) rawv[n] = rawring[(slot_cm1 * NV + n) * 64 + lane];
+        }
         double q0_next = ring[(slot_cm1 * NV + 0) * 64 + lane];
 #pragma unroll
         for (int n = 0; n < NV; ++n) {
@@ -357,6 +379,11 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
       }
       APK_TICK(2);  // x1 Riemann + flux difference
       // ---- (3) x2: reconstruct cell c from ring rows c-H..c+H-1 and the register row c+H
+      double Praw[RAW ? NV : 1];
+      if constexpr (RAW) {
+#pragma unroll
+        for (int n = 0; n < NV; ++n) Praw[n] = Pn[n];
+      }
       if constexpr (FC) cons_row_to_prim<FLUID>(sp, Pn);  // (every lane: the row goes into the ring as the x1 stencil of its neighbours)
       double qln[NV], qrn[NV];
       if (need_r2) {
@@ -393,6 +420,10 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
       if (more) {
 #pragma unroll
         for (int n = 0; n < NV; ++n) ring[(slot0 * NV + n) * 64 + lane] = Pn[n];
+        if constexpr (RAW) {
+#pragma unroll
+          for (int n = 0; n < NV; ++n) rawring[(slot0 * NV + n) * 64 + lane] = Praw[n];
+        }
         slot0 = (slot0 + 1) & (NS - 1);
 #pragma unroll
         for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + row_off(c + 1 + H)];
@@ -421,8 +452,13 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
             if (active) {  // (ghost-column and overlap lanes retire nothing: 13 % of the lanes)
 #pragma unroll
               for (int n = 0; n < NV; ++n) d3v[n] = as_global(d3)[n * u0.sn + done];
+              if (RAW && sp.prim_from_cons == 1) {  // (wave-uniform: the input state IS u1)
 #pragma unroll
-              for (int n = 0; n < NV; ++n) u1v[n] = as_global(c1)[n * u0.sn + done];
+                for (int n = 0; n < NV; ++n) u1v[n] = rawv[RAW ? n : 0];
+              } else {
+#pragma unroll
+                for (int n = 0; n < NV; ++n) u1v[n] = as_global(c1)[n * u0.sn + done];
+              }
             } else {
 #pragma unroll
               for (int n = 0; n < NV; ++n) d3v[n] = 0.0, u1v[n] = 0.0;
@@ -448,7 +484,13 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
                 m[st] = f[0];
               }
             }
-            finish_cell<FLUID, EXTRA, LEAN>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd);
+            if constexpr (RAW) {
+              // (prim_from_cons = 2: the input state is the old u0 the update reads)
+              if (sp.prim_from_cons == 2) finish_cell_old_held<FLUID, EXTRA, LEAN>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd, rawv);
+              else finish_cell<FLUID, EXTRA, LEAN>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd);
+            } else {
+              finish_cell<FLUID, EXTRA, LEAN>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd);
+            }
           }
           APK_TICK(6);  // update, Dedner, ConsToPrim, dt, stores issued
         }
@@ -560,8 +602,9 @@ inline void launch_m12f(const PackView &u0, const PackView &u1, const StageParam
     static const int lockstep = std::getenv("APK_M12F_LOCKSTEP") ? std::atoi(std::getenv("APK_M12F_LOCKSTEP")) : 1;  // A/B switch
 #define APK_LAUNCH_M12F(EXTRA_, LEAN_) \
   hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, LEAN_>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows, lockstep)
+    constexpr int lds_fc = m12f_keeps_raw_rows<FLUID, RECON>() ? 2 * lds : lds;  // (the rows as loaded, too)
 #define APK_LAUNCH_M12F_FC(EXTRA_) \
-  hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, true, true>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows, lockstep)
+  hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, true, true>), g, dim3(64), lds_fc, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows, lockstep)
     if (sp.prim_from_cons) {  // (lean forms only: launch_fused_stage has checked)
       if (extra == EXTRA_C2P_DT) APK_LAUNCH_M12F_FC(EXTRA_C2P_DT);
       else if (extra == EXTRA_C2P) APK_LAUNCH_M12F_FC(EXTRA_C2P);

@@ -119,11 +119,13 @@ inline bool stage_is_lean(const StageParams &sp) {
 // -beta_dt / V of a block (product build; the parity build divides by V per cell as the reference does)
 APK_DEV double update_coefficient(const StageParams &sp, double vol) { return to_sgpr(-sp.beta_dt / vol); }
 
-template <int FLUID, int EXTRA = EXTRA_NONE, bool LEAN = false>
-APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
-                         const double (&u1v)[nvars<FLUID>()], int64_t cell,
-                         const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp,
-                         double &lane_min_dt, double *prim_dst = nullptr, double upd = 0.0, bool store_cons = true) {
+// (HELD: old_held is the old u0 of this cell, already in registers -- the from-cons finishing march keeps the rows it loaded)
+template <int FLUID, int EXTRA, bool LEAN, bool HELD>
+APK_DEV void finish_cell_impl(const PackView &pv, const apk_block_desc &b0,
+                              const double (&u1v)[nvars<FLUID>()], int64_t cell,
+                              const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp,
+                              double &lane_min_dt, double *prim_dst, double upd, bool store_cons,
+                              const double (&old_held)[nvars<FLUID>()]) {
   constexpr int NV = nvars<FLUID>();
   double un[NV];
   if constexpr (LEAN) {
@@ -134,8 +136,13 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
 #endif
     if (sp.gam0 != 0.0) {  // wave-uniform
       double old[NV];
+      if constexpr (HELD) {
 #pragma unroll
-      for (int n = 0; n < NV; ++n) old[n] = as_global(b0.cons)[n * pv.sn + cell];
+        for (int n = 0; n < NV; ++n) old[n] = old_held[n];
+      } else {
+#pragma unroll
+        for (int n = 0; n < NV; ++n) old[n] = as_global(b0.cons)[n * pv.sn + cell];
+      }
 #pragma unroll
       for (int n = 0; n < NV; ++n) un[n] = sp.gam0 * old[n] + sp.gam1 * u1v[n] + APK_UPD_TERM(n);
     } else {
@@ -213,6 +220,21 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0,
   if constexpr (!LEAN) {
     if (bad) atomicAdd(sp.bad_count, 1ull);
   }
+}
+
+template <int FLUID, int EXTRA = EXTRA_NONE, bool LEAN = false>
+APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0, const double (&u1v)[nvars<FLUID>()], int64_t cell,
+                         const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp, double &lane_min_dt,
+                         double *prim_dst = nullptr, double upd = 0.0, bool store_cons = true) {
+  const double none[nvars<FLUID>()] = {};
+  finish_cell_impl<FLUID, EXTRA, LEAN, false>(pv, b0, u1v, cell, du, vol, sp, lane_min_dt, prim_dst, upd, store_cons, none);
+}
+template <int FLUID, int EXTRA, bool LEAN>
+APK_DEV void finish_cell_old_held(const PackView &pv, const apk_block_desc &b0, const double (&u1v)[nvars<FLUID>()], int64_t cell,
+                                  const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp, double &lane_min_dt,
+                                  double *prim_dst, double upd, const double (&old_held)[nvars<FLUID>()]) {
+  static_assert(LEAN, "lean form only");
+  finish_cell_impl<FLUID, EXTRA, LEAN, true>(pv, b0, u1v, cell, du, vol, sp, lane_min_dt, prim_dst, upd, true, old_held);
 }
 
 // ==============================================================================================
