@@ -202,7 +202,9 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     const apk_block_desc b0 = u0.blocks[b];
     const double *c1 = u1.blocks[b].cons;
     double *prim_dst = (EXTRA != EXTRA_NONE && !sp.no_prim_store) ? u1.blocks[b].prim : nullptr;
-    const double *d3 = sp.du + (int64_t)b * u0.sn * u0.nvar;
+    // (the x3 sweep's flux differences: in the cells' layout, or compact -- StageParams.du_pitch)
+    const int64_t d3_sn = sp.du_pitch > 0 ? (int64_t)sp.du_pitch * u0.nx2 * u0.nx3 : u0.sn;
+    const double *d3 = sp.du + (int64_t)b * d3_sn * u0.nvar;
 
     const int64_t t = (int64_t)chunk * CPW + lane - FIRST;
     const bool in_run = (t >= 0) && (t < run);
@@ -212,6 +214,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     const bool active = in_run && (lane >= FIRST) && (lane <= LAST) && (i >= u0.is) && (i <= u0.ie);
     const int s = u0.js + j0, e = s + nrows - 1;
     const int64_t base = (int64_t)(u0.ks + krow) * u0.sk + i;
+    const int d3col = (i < u0.is) ? 0 : ((i > u0.ie) ? u0.nx1 - 1 : i - u0.is);
     // lanes whose x1 face flux somebody uses: a retiring cell needs the flux of its own lower face and that of the lane above
     const bool need_f1 = !(APK_M12F_MASK_IDLE & 2) || active ||
                          (__builtin_amdgcn_update_dpp(0, active ? 1 : 0, 0x138, 0xf, 0xf, true) != 0);  // wave_shr:1 = lane l-1
@@ -291,6 +294,8 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     int slot0 = 0;  // slot holding row c-H
     for (; c <= e + 1; ++c) {
       const int64_t done = base + (int64_t)(c - 1) * st;  // the cell this iteration retires
+      // (its place in d3; lanes that retire nothing get a valid column)
+      const int64_t d3done = sp.du_pitch > 0 ? ((int64_t)krow * u0.nx2 + (c - 1 - u0.js)) * sp.du_pitch + d3col : done;
       const bool retire = (c >= s + 1);                   // wave-uniform
       APK_TICK(0);
       // ---- (1) x1 faces of row c-1 (every lane takes part in the wave shifts).  The row's own
@@ -306,7 +311,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
       if constexpr (LOADS == 0) {
         if (retire) {
 #pragma unroll
-          for (int n = 0; n < NV; ++n) d3v[n] = d3[n * u0.sn + done];
+          for (int n = 0; n < NV; ++n) d3v[n] = d3[n * d3_sn + d3done];
 #pragma unroll
           for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
         }
@@ -367,7 +372,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
         if constexpr (LOADS == 1) {
           asm volatile("" ::: "memory");
 #pragma unroll
-          for (int n = 0; n < NV; ++n) d3v[n] = d3[n * u0.sn + done];
+          for (int n = 0; n < NV; ++n) d3v[n] = d3[n * d3_sn + d3done];
 #pragma unroll
           for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
         }
@@ -443,7 +448,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
           if constexpr (LOADS == 3) {
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int n = 0; n < NV; ++n) d3v[n] = active ? d3[n * u0.sn + done] : 0.0;
+            for (int n = 0; n < NV; ++n) d3v[n] = active ? d3[n * d3_sn + d3done] : 0.0;
           }
           if constexpr (LOADS == 2) {
             asm volatile("" ::: "memory");
@@ -451,7 +456,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
             // -- their exposed latency is the price of not holding 36 VGPRs through the x2 solve.)
             if (active) {  // (ghost-column and overlap lanes retire nothing: 13 % of the lanes)
 #pragma unroll
-              for (int n = 0; n < NV; ++n) d3v[n] = as_global(d3)[n * u0.sn + done];
+              for (int n = 0; n < NV; ++n) d3v[n] = as_global(d3)[n * d3_sn + d3done];
               if (RAW && sp.prim_from_cons == 1) {  // (wave-uniform: the input state IS u1)
 #pragma unroll
                 for (int n = 0; n < NV; ++n) u1v[n] = rawv[RAW ? n : 0];

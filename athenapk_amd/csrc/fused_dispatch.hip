@@ -33,6 +33,7 @@ int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
   sp.dedner_coeff = dedner_coeff;
   sp.du = nullptr;
   sp.du_first = 0;
+  sp.du_pitch = 0;
   sp.ctx = ctx;
   sp.eos = a.eos;
   sp.flags = ctx->d_flags + (a.trial ? 1 : 0);

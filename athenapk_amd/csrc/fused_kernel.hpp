@@ -33,6 +33,10 @@ struct StageParams {
   int dedner;  // 0 off, 1 plain, 2 extended
   double *du;  // scratch: [nblocks][nvar][Nk][Nj][Ni]
   int du_first;  // non-finishing march: WRITE its flux difference to du instead of adding to it
+  // Two-kernel stage: the x3 sweep's flux differences in a layout of their own -- interior cells only, rows of du_pitch
+  // doubles (a multiple of 16) from a 128-byte boundary: [block][var][k][j][du_pitch].  The sweep's 512-byte stores are
+  // then whole cache lines (in the cell arrays' layout they straddle five, two of them partly).  0: the cells' layout.
+  int du_pitch;
   // optional work of the finishing sweep (apk_stage_args.fill_derived / estimate_dt)
   apk_eos eos;                   // floors / ceilings for the in-place ConsToPrim
   unsigned *flags;               // latched APK_FLAG_* word
@@ -432,7 +436,9 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
   const double dx = b0.dx[DIR - 1];
   const double area = (DIR == 2) ? b0.dx[0] * b0.dx[2] : b0.dx[0] * b0.dx[1];
   const double vol = b0.dx[0] * b0.dx[1] * b0.dx[2];
-  double *dscratch = sp.du + (int64_t)b * u0.sn * u0.nvar;
+  const bool du_compact = !FINAL && sp.du_pitch > 0;  // (wave-uniform)
+  const int64_t du_sn = du_compact ? (int64_t)sp.du_pitch * u0.nx2 * u0.nx3 : u0.sn;
+  double *dscratch = sp.du + (int64_t)b * du_sn * u0.nvar;
   // the stage's input: u0's primitives, or the conserved state of u1 / u0 (FC, see cons_row_to_prim)
   const apk_block_desc *srcb = (FC && sp.prim_from_cons != 2) ? u1.blocks : u0.blocks;  // (wave-uniform)
   auto input_of = [&](int blk) -> const double * { return FC ? srcb[blk].cons : u0.blocks[blk].prim; };
@@ -638,8 +644,10 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
           if constexpr (FINAL) {
             finish_cell<FLUID, EXTRA>(u0, b0, u1v, cell, du, vol, sp, lane_min_dt, prim_dst);
           } else {
+            // (du_compact: DIR = 3, the row (k, j) = (c - 1, trans) of the interior, column ii - is)
+            const int64_t dcell = du_compact ? ((int64_t)(c - 1 - u0.ks) * u0.nx2 + trans) * sp.du_pitch + (ii - u0.is) : cell;
 #pragma unroll
-            for (int n = 0; n < NV; ++n) store_result(&dscratch[n * u0.sn + cell], du[n]);
+            for (int n = 0; n < NV; ++n) store_result(&dscratch[n * du_sn + dcell], du[n]);
           }
         }
       }
@@ -1571,9 +1579,12 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
       // two-kernel stage (fused2_kernel.hpp): the x3 sweep writes its flux difference, then one
       // march does x1 + x2 and finishes.  A split stage runs the x3 sweep on plane windows in
       // phase 1 (it reads x3 ghost zones only) and the finishing march in phase 2.
+      static const bool du_cells = std::getenv("APK_DU_CELL_LAYOUT") != nullptr;  // A/B switch: the cells' layout
+      const int du_pitch = du_cells ? 0 : ((u0.nx1 + 15) / 16) * 16;
       if (do_x1) {
         StageParams sp1 = sp;
         sp1.du_first = 1;
+        sp1.du_pitch = du_pitch;
         const int rpw = march_rows_per_wave(u0.nx1, u0.nx2);
         dim3 g3((u0.nx1 + 64 / rpw - 1) / (64 / rpw), (u0.nx2 + rpw - 1) / rpw, u0.nblocks);
         const int nseg = march_segments((int64_t)g3.x * g3.y * g3.z, u0.nx3);
@@ -1587,6 +1598,7 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
       if (do_rest) {
         StageParams sp2 = sp;
         sp2.window = nullptr;
+        sp2.du_pitch = du_pitch;
         ScopedTiming t(sp.ctx, TS + 0, s);
         launch_m12f<FLUID, RECON, RS>(u0, u1, sp2, extra, s);
       }

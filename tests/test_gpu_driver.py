@@ -464,6 +464,11 @@ def test_rk_cycle_without_stored_primitives_equals_the_cycle_with_them(strict, s
           "parthenon/meshblock/nx1=%d" % m1, "parthenon/meshblock/nx2=%d" % m2, "parthenon/meshblock/nx3=%d" % m3,
           "parthenon/time/integrator=%s" % integ, "hydro/reconstruction=%s" % recon, "hydro/riemann=%s" % riemann,
           "parthenon/mesh/nghost=%d" % ng] + extra
+    # (product build: the two cycles convert the same conserved values in different kernels, whose multiply-adds contract
+    # differently -- last-bit differences, and a last bit can flip one of PPM's extremum tests: a limited instead of an
+    # unlimited interface value somewhere, 5e-8 of the state after three cycles of RK2 PPM, as any perturbation of that size
+    # does in either build.  The parity build, first parameter, is the test of the logic.)
+    same = lambda x, y, st: _assert_same(x, y, st, tol=1e-6)
     a = _sim(deck, ov, strict=strict).initialize()
     b = _sim(deck, ov, strict=strict)
     b.set_prim_free(False)
@@ -472,24 +477,24 @@ def test_rk_cycle_without_stored_primitives_equals_the_cycle_with_them(strict, s
         a.step()
         b.step()
     assert a.prim_is_stale and not b.prim_is_stale
-    _assert_same(np.asarray(a.dt), np.asarray(b.dt), strict)
-    _assert_same(a.gather(), b.gather(), strict)
-    _assert_same(a.gather("prim"), b.gather("prim"), strict)   # (materialised by the accessor)
+    same(np.asarray(a.dt), np.asarray(b.dt), strict)
+    same(a.gather(), b.gather(), strict)
+    same(a.gather("prim"), b.gather("prim"), strict)   # (materialised by the accessor)
     assert not a.prim_is_stale
     a.step()                                                    # stage 1 reads stored primitives again ...
     b.step()
     assert a.prim_is_stale                                      # ... and the cycle ends without them
     for lb in range(a.info.nblocks_local):
         for field in ("cons", "prim"):
-            _assert_same(a.read_block(lb, field), b.read_block(lb, field), strict)   # ghost zones included
+            same(a.read_block(lb, field), b.read_block(lb, field), strict)   # ghost zones included
     a.step()
     a.set_prim_free(False)                                      # switching it off in mid-run
     b.step()
     a.step()
     b.step()
     assert not a.prim_is_stale
-    _assert_same(a.gather(), b.gather(), strict)
-    _assert_same(np.asarray(a.dt), np.asarray(b.dt), strict)
+    same(a.gather(), b.gather(), strict)
+    same(np.asarray(a.dt), np.asarray(b.dt), strict)
 
 
 # ---- direct neighbour addressing: the uniform-mesh cycle without same-rank ghost copies ------------------
