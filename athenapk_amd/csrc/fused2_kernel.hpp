@@ -215,6 +215,9 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     const int s = u0.js + j0, e = s + nrows - 1;
     const int64_t base = (int64_t)(u0.ks + krow) * u0.sk + i;
     const int d3col = (i < u0.is) ? 0 : ((i > u0.ie) ? u0.nx1 - 1 : i - u0.is);
+    // (row c - 1 of this column in d3: d3base + (c - 1) * d3st, like `done` in the cells' layout)
+    const int64_t d3st = sp.du_pitch > 0 ? (int64_t)sp.du_pitch : st;
+    const int64_t d3base = sp.du_pitch > 0 ? ((int64_t)krow * u0.nx2 - u0.js) * sp.du_pitch + d3col : base;
     // lanes whose x1 face flux somebody uses: a retiring cell needs the flux of its own lower face and that of the lane above
     const bool need_f1 = !(APK_M12F_MASK_IDLE & 2) || active ||
                          (__builtin_amdgcn_update_dpp(0, active ? 1 : 0, 0x138, 0xf, 0xf, true) != 0);  // wave_shr:1 = lane l-1
@@ -295,7 +298,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     for (; c <= e + 1; ++c) {
       const int64_t done = base + (int64_t)(c - 1) * st;  // the cell this iteration retires
       // (its place in d3; lanes that retire nothing get a valid column)
-      const int64_t d3done = sp.du_pitch > 0 ? ((int64_t)krow * u0.nx2 + (c - 1 - u0.js)) * sp.du_pitch + d3col : done;
+      const int64_t d3done = d3base + (int64_t)(c - 1) * d3st;
       const bool retire = (c >= s + 1);                   // wave-uniform
       APK_TICK(0);
       // ---- (1) x1 faces of row c-1 (every lane takes part in the wave shifts).  The row's own
