@@ -376,13 +376,23 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
           asm volatile("" ::: "memory");
 #pragma unroll
           for (int n = 0; n < NV; ++n) d3v[n] = d3[n * d3_sn + d3done];
+          if (RAW && sp.prim_from_cons == 1) {
 #pragma unroll
-          for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
+            for (int n = 0; n < NV; ++n) u1v[n] = rawv[RAW ? n : 0];
+          } else {
+#pragma unroll
+            for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
+          }
         }
         if constexpr (LOADS == 3) {  // (A/B) u1 early, d3 late
           asm volatile("" ::: "memory");
+          if (RAW && sp.prim_from_cons == 1) {  // (wave-uniform: the input state IS u1, and the row is at hand)
 #pragma unroll
-          for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
+            for (int n = 0; n < NV; ++n) u1v[n] = rawv[RAW ? n : 0];
+          } else {
+#pragma unroll
+            for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
+          }
         }
       }
       APK_TICK(2);  // x1 Riemann + flux difference
