@@ -1231,6 +1231,14 @@ fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, 
       for (int n = 0; n < NV; ++n) w[n] = u[n];
     }
   };
+  // With FROM_CONS the conserved values of the plane just completed ARE the u1 the update reads: they stay in registers
+  // (both cells: 242 VGPRs, no scratch, in the forms with ConsToPrim; the form without it has no room) instead of being
+  // read a second time, 72 of the 259 B per cell the march moved -- 1.13 -> 1.05 - 1.07 ms.  (-DAPK_DC3R2_HOLD=0 / 1: A/B)
+#ifndef APK_DC3R2_HOLD
+#define APK_DC3R2_HOLD 2
+#endif
+  constexpr int HOLD = (FROM_CONS && EXTRA != EXTRA_NONE) ? APK_DC3R2_HOLD : 0;
+  double held[HOLD > 0 ? HOLD : 1][NV];
   if constexpr (PF) load_raw(s);
   for (int c = s; c <= e + 1; ++c) {
     const int64_t off = (int64_t)c * u0.sk;
@@ -1261,10 +1269,19 @@ fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, 
           const int n = perm<3>(q);
           du[n] = st_du[r][n * 64] + (area3 * f3[q] - area3 * st_f3[r][q * 64]);
         }
+        if (r < HOLD) {
 #pragma unroll
-        for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
+          for (int n = 0; n < NV; ++n) u1v[n] = held[r < HOLD ? r : 0][n];
+        } else {
+#pragma unroll
+          for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
+        }
         const bool store = sp.cons_store == 0 || (sp.cons_store == 1 && (shell_ij[r] || c - 1 < u0.ks + u0.ng || c - 1 > u0.ke - u0.ng));
         if (active) finish_cell<FLUID, EXTRA, true>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd, store);
+      }
+      if (r < HOLD) {  // (plane c of this cell, for the next iteration)
+#pragma unroll
+        for (int n = 0; n < NV; ++n) held[r < HOLD ? r : 0][n] = raw[r][n];
       }
 #pragma unroll
       for (int q = 0; q < NV; ++q) st_f3[r][q * 64] = f3[q];
