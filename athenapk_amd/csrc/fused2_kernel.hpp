@@ -271,7 +271,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
 #pragma unroll
           for (int n = 0; n < NV; ++n) rawring[(m * NV + n) * 64 + lane] = init[m][n];
         }
-        if constexpr (FC) cons_row_to_prim<FLUID>(sp, init[m]);
+        if constexpr (FC) (void)cons_row_to_prim<FLUID>(sp, init[m]);
 #pragma unroll
         for (int n = 0; n < NV; ++n) ring[(m * NV + n) * 64 + lane] = init[m][n];
       }
@@ -402,7 +402,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
 #pragma unroll
         for (int n = 0; n < NV; ++n) Praw[n] = Pn[n];
       }
-      if constexpr (FC) cons_row_to_prim<FLUID>(sp, Pn);  // (every lane: the row goes into the ring as the x1 stencil of its neighbours)
+      if constexpr (FC) (void)cons_row_to_prim<FLUID>(sp, Pn);  // (every lane: the row goes into the ring as the x1 stencil of its neighbours)
       double qln[NV], qrn[NV];
       if (need_r2) {
       double an[NS];  // ring rows of the next variable (software-pipelined LDS reads)

@@ -371,15 +371,20 @@ constexpr int kMarchMinWaves = 2;
 // a row is requested one iteration ahead and converted in registers where it is first used.  The input state is u1's
 // (prim_from_cons = 1: stages with gam0 = 0, whose output is another buffer) or u0's (2: the stage then writes its
 // result out of place, cons_out_delta != 0, because neighbouring waves still read the old values).
+// Returns the APK_FLAG_* bits of the converted cell.  A prim-free RK cycle stores the results of its stages without
+// ConsToPrim, so the x3 sweep of the NEXT stage -- whose lanes are interior columns and whose rows are all valid cells
+// -- is where a negative density / pressure of that state is first seen: it latches the bits (the reference aborts in
+// the FillDerived right after the stage, adiabatic_hydro.hpp:77-79,111-113; the driver reads the word once per cycle).
 template <int FLUID>
-APK_DEV void cons_row_to_prim(const StageParams &sp, double (&q)[nvars<FLUID>()]) {
+APK_DEV unsigned cons_row_to_prim(const StageParams &sp, double (&q)[nvars<FLUID>()]) {
   constexpr int NV = nvars<FLUID>();
   double u[NV], w[NV], di;
 #pragma unroll
   for (int n = 0; n < NV; ++n) u[n] = q[n];
-  (void)cons_to_prim_core<FLUID, true>(sp.eos, sp.k.eos_gm1, sp.k.vceil_sq, sp.k.pfloor_over_gm1, u, w, di);
+  const unsigned fl = cons_to_prim_core<FLUID, true>(sp.eos, sp.k.eos_gm1, sp.k.vceil_sq, sp.k.pfloor_over_gm1, u, w, di);
 #pragma unroll
   for (int n = 0; n < NV; ++n) q[n] = w[n];
+  return fl;
 }
 
 template <int FLUID, int RECON>
@@ -468,7 +473,10 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
     double row[NV];
 #pragma unroll
     for (int n = 0; n < NV; ++n) row[n] = prim[n * u0.sn + row_off(r0 + m)];
-    if constexpr (FC) cons_row_to_prim<FLUID>(sp, row);
+    if constexpr (FC) {
+      const unsigned fl = cons_row_to_prim<FLUID>(sp, row);
+      if (active && fl) atomicOr(sp.flags, fl);
+    }
 #pragma unroll
     for (int n = 0; n < NV; ++n) ring[(m * NV + n) * 64 + lane] = row[n];
   }
@@ -498,7 +506,10 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
     // the streaming operands of the cell that completes in this iteration (c-1) are requested
     // first, so they are in flight during the reconstruction and the Riemann solve
     const int64_t done = base + (int64_t)(c - 1) * st;
-    if constexpr (FC) cons_row_to_prim<FLUID>(sp, Pn);
+    if constexpr (FC) {
+      const unsigned fl = cons_row_to_prim<FLUID>(sp, Pn);
+      if (active && fl) atomicOr(sp.flags, fl);
+    }
     double duv[NV], u1v[NV];
     if (c >= s + 1) {
       if (FINAL || !sp.du_first) {

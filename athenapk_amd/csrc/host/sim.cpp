@@ -555,6 +555,11 @@ bool rk_prim_free_cycle(const apk_sim *s) {
   if (pkg.nscalars != 0 || (pkg.fluid == APK_FLUID_GLMMHD && pkg.glmmhd_source_extended) || !pkg.calc_dt_hyp) return false;
   const apk_eos &e = pkg.eos;
   if (!(e.vceil > 1.0e300 && e.eceil > 1.0e300 && e.pfloor <= 0.0)) return false;  // (eos_is_lean)
+  // Stages that are not the last store their result without ConsToPrim (fill_derived = 0): a density or internal-energy
+  // floor would act on the register copy the next stage converts but never reach the stored conserved state, where the
+  // reference's FillDerived after every stage writes the floored values back (adiabatic_hydro.hpp:81,129-136).  With
+  // floors the cycle keeps its primitives (every stage fill_derived = 2).
+  if (e.dfloor > 0.0 || e.efloor > 0.0) return false;
   if (pkg.flux_first_stage.recon == APK_RC_DC || pkg.flux_other_stage.recon == APK_RC_DC) return false;
   return apk_stage_split_axis(s->mu0(), &pkg.flux_first_stage, 0) == 3 && apk_stage_split_axis(s->mu0(), &pkg.flux_other_stage, 0) == 3;
 }
@@ -855,7 +860,10 @@ int turbulence_driving(apk_sim *s, double dt, bool fill, bool no_prim) {
   // follow it, hydro_driver.cpp:559-577, 589-603 -- instead of a full ConsToPrim pass and a dt pass afterwards)
   // (no_prim: the stages of this cycle stored no primitives and the next one derives its input from the conserved state --
   // rk_prim_free_cycle --: the kick estimates the time step and leaves the primitives where they are, stale)
-  if (fill && no_prim) SIM_TRY(s, apk_turb_apply_dt(s->ctx, s->mu0(), s->fm_dev, norm, dt, s->pkg.fluid, &s->pkg.eos, s->stream));
+  if (fill && no_prim) {
+    SIM_TRY(s, apk_turb_apply_dt(s->ctx, s->mu0(), s->fm_dev, norm, dt, s->pkg.fluid, &s->pkg.eos, s->stream));
+    s->turb_dt_kicks += 1;
+  }
   else if (fill) SIM_TRY(s, apk_turb_apply_fill(s->ctx, s->mu0(), s->fm_dev, norm, dt, s->pkg.fluid, &s->pkg.eos, s->pkg.calc_dt_hyp ? 1 : 0, s->stream));
   else SIM_TRY(s, apk_turb_apply(s->ctx, s->mu0(), s->fm_dev, norm, dt, s->stream));
   return APK_OK;
@@ -1014,9 +1022,14 @@ int do_stage(apk_sim *s, int stage) {
     }
     SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
     s->stage_dt_pending = a.estimate_dt != 0;
-    if (from_cons) s->prim_stale = false;  // (the predictor has written the half-step primitives: the current buffer is valid again)
+    // (a stage that stored primitives -- the predictor's half-step ones -- makes the current buffer valid again; one that
+    // stored none leaves them stale: the stages of a prim-free RK cycle, and its last stage under the turbulence driver,
+    // whose kick then estimates the time step without storing them either)
     if (no_prim) s->prim_stale = true;
-    else if (swap_prim) s->pcur = 1 - s->pcur;
+    else if (a.fill_derived == 1 || a.fill_derived == 2) {
+      s->prim_stale = false;
+      if (swap_prim) s->pcur = 1 - s->pcur;
+    }
     s->cur = outbuf;  // (its ghost zones are filled by the exchange below)
     if (s->amr) {
       SIM_TRY(s, ensure_flux_arrays(s));
@@ -1422,6 +1435,7 @@ int apk_sim_set_thin_exchange(apk_sim *s, int on) {
 }
 long long apk_sim_thin_exchanges(const apk_sim *s) { return s ? s->thin_exchanges : 0; }
 int apk_sim_prim_is_stale(const apk_sim *s) { return (s && s->prim_stale) ? 1 : 0; }
+long long apk_sim_turb_dt_kicks(const apk_sim *s) { return s ? s->turb_dt_kicks : 0; }
 int apk_sim_set_amr_full_exchange(apk_sim *s, int on) {
   if (!s) return APK_ERR_INVALID;
   if (!s->host_only) SIM_TRY(s, sync_ghosts(s));

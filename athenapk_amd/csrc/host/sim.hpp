@@ -160,6 +160,7 @@ struct apk_sim {
   // to date one layer deep only -- sync_ghosts completes them (a collective, like the one of refined meshes).
   bool thin_on = true, thin_msgs = false, xchg_thin = false, remote_ghosts_thin = false;
   long long thin_exchanges = 0;
+  long long turb_dt_kicks = 0;  // kicks that estimated the time step without storing primitives (apk_turb_apply_dt)
   int pending_c2p = 0;  // the exchange in flight converts ghost zones as it fills them (GHOST_C2P / GHOST_PRIM_ONLY)
   int pending_cons = 0;  // cons buffer whose ghost zones the exchange in flight fills (roles may swap meanwhile)
   // device window tables (apk_stage_args.window, 8 ints per block) of the split stages:

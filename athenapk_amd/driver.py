@@ -185,7 +185,15 @@ class _MeshView:
 
 
 class Simulation(_FmftHost, _MeshView):
-    """apk_sim: deck + overrides -> mesh partition, packs, ghost plans, stage loop (C++)."""
+    """apk_sim: deck + overrides -> mesh partition, packs, ghost plans, stage loop (C++).
+
+    COLLECTIVE accessors on N > 1 ranks: read_block / write_block / gather / history / turbulence_history / reldivb and
+    the error norms bring the ghost zones of the current state up to date first (apk_host.h: sync_ghosts).  After a
+    cycle that ended with a one-layer exchange (set_thin_exchange, the default of periodic uniform VL2 runs) or on a
+    refined mesh that completion is a full halo exchange, i.e. a collective: call these on EVERY rank, in the same
+    order, like the stage loop itself -- a call on one rank alone blocks in the exchange.  set_thin_exchange(False)
+    restores rank-local accessors on uniform meshes.
+    """
 
     def __init__(self, deck, overrides=(), rank=0, nranks=1, strict=False, use_torch_alloc=True,
                  group=None, comm=None):
@@ -423,6 +431,10 @@ class Simulation(_FmftHost, _MeshView):
     def prim_is_stale(self):
         return bool(self.lib.apk_sim_prim_is_stale(self.h))
 
+    def turb_dt_kicks(self):
+        """forcing kicks so far that estimated the time step without storing primitives (apk_sim_turb_dt_kicks)"""
+        return self.lib.apk_sim_turb_dt_kicks(self.h)
+
     def set_amr_full_exchange(self, on):
         """refined meshes: 1 = the stage loop exchanges every ghost zone, not only those behind block faces"""
         self._check(self.lib.apk_sim_set_amr_full_exchange(self.h, int(on)))
@@ -458,6 +470,7 @@ class Simulation(_FmftHost, _MeshView):
         return (i.nhydro + i.nscalars, nk, nj, i.mb[0] + 2 * i.ng)
 
     def read_block(self, lb, field="cons"):
+        """one local block incl. ghost zones (collective on N > 1 ranks: see the class docstring)"""
         out = np.empty(self.block_shape)
         self._check(self.lib.apk_sim_read_block(self.h, lb, {"cons": 0, "prim": 1, "u1": 2}[field],
                                                 out.ctypes.data_as(L.c_dp)))

@@ -198,7 +198,7 @@ def DednerSource(md, extended, alpha, c_h, mindx, beta_dt):
 
 def StageFused(u0, u1, fluid, recon, riemann, eos, c_h, gam0, gam1, beta_dt, dedner=0,
                glmmhd_alpha=0.1, mindx=1.0, fill_derived=False, estimate_dt=False, phase=0, window=None,
-               face_neighbor=None, cons_store=0, prim_from_cons=False):
+               face_neighbor=None, cons_store=0, prim_from_cons=False, cons_out=None):
     """Fused CalculateFluxes -> UpdateWithFluxDivergence -> DednerSource for one RK stage;
     optionally also FillDerived / the dt estimate on the updated cells.  phase / x1_window split
     the stage around a halo exchange (window: int32 CUDA tensor [nblocks][8] =
@@ -220,6 +220,9 @@ def StageFused(u0, u1, fluid, recon, riemann, eos, c_h, gam0, gam1, beta_dt, ded
         assert face_neighbor.dtype == torch.int32 and face_neighbor.is_cuda and face_neighbor.shape == (u0.nblocks, 6)
         a.face_neighbor = face_neighbor.data_ptr()
     a.prim_from_cons = int(prim_from_cons)  # the stage derives its input primitives from u1.cons (apk_stage_args.prim_from_cons)
+    if cons_out is not None:  # the updated conserved state goes to this MeshData of identical layout (apk_stage_args.cons_out_delta)
+        assert cons_out.cons.shape == u0.cons.shape
+        a.cons_out_delta = (cons_out.cons.data_ptr() - u0.cons.data_ptr()) // 8
     a.cons_store = int(cons_store)  # 0 all cells, 1 the nghost-deep shell of every block, 2 none (apk_stage_args.cons_store)
     _check(ctx.lib.apk_stage_fused(ctx.h, u0.h, u1.h, C.byref(a), _stream()), ctx.lib, ctx.h)
 

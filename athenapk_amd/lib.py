@@ -227,6 +227,7 @@ def _signatures():
         "apk_sim_set_amr_full_exchange": (C.c_int, [vp, C.c_int]),
         "apk_sim_set_prim_free": (C.c_int, [vp, C.c_int]),
         "apk_sim_prim_is_stale": (C.c_int, [vp]),
+        "apk_sim_turb_dt_kicks": (ll, [vp]),
         "apk_sim_loop_seconds": (d, [vp]),
         "apk_sim_loop_cycles": (i, [vp]),
         "apk_sim_get_info": (i, [vp, C.POINTER(SimInfo)]),

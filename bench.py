@@ -229,15 +229,37 @@ def stage_figures(timing, fluid, integrator, zones_local, ndim=3):
     return per_kernel, stage_ms, b_stage, achieved, dominant
 
 
+# Workloads that only appear under `other_workloads` (never the headline): BASELINE configs[3] WITH its forcing
+# (inputs/turbulence.in: 30 modes, the deck's amplitudes; the scheme of the config) and configs[2], the Orszag-Tang
+# vortex 512 x 512 thin in x3 with the deck's first_order_flux_correct off and on (inputs/orszag_tang.in:15-51).
+# (deck, fluid, integrator, recon, riemann, mesh, meshblock, description, extra overrides)
+EXTRA_WORKLOADS = {
+    "mhd_wenoz_hlld_rk3_256_forced": ("turbulence", "glmmhd", "rk3", "wenoz", "hlld", (256, 256, 256), (128, 128, 128),
+                                      "BASELINE config 4 as specified: GLM-MHD WENOZ+HLLD RK3 with the few-modes forcing on "
+                                      "(inputs/turbulence.in), 256^3 per GPU in 128^3 meshblocks",
+                                      ["parthenon/mesh/nghost=3"]),
+    "orszag_tang_512x512x4_vl2": ("orszag_tang", "glmmhd", "vl2", "ppm", "hlld", (512, 512, 4), (128, 128, 4),
+                                  "BASELINE config 3: Orszag-Tang 512 x 512 x 4 (thin-z 3-D), GLM-MHD PPM+HLLD+Dedner VL2, "
+                                  "first_order_flux_correct off", ["hydro/first_order_flux_correct=false"]),
+    "orszag_tang_512x512x4_vl2_fofc": ("orszag_tang", "glmmhd", "vl2", "ppm", "hlld", (512, 512, 4), (128, 128, 4),
+                                       "BASELINE config 3 as decked: the same with first_order_flux_correct on",
+                                       ["hydro/first_order_flux_correct=true"]),
+}
+
+
 def other_workload(name, steps=4, warmup=2):
-    """One of the non-headline workloads of WORKLOADS on this GPU, a few cycles: rate, ms per cycle, the high-order
+    """One of the non-headline workloads on this GPU, a few cycles: rate, ms per cycle, the high-order
     stage against the HBM roofline and the dominant kernel (the reference's own performance suite is a matrix of
     schemes, tst/regression/test_suites/performance/performance.py:32-54)."""
     import torch
     from athenapk_amd import decks, driver
-    deck, fluid, integrator, recon, riemann, brick, mb, desc = WORKLOADS[name]
-    ov = ["parthenon/mesh/nx%d=%d" % (d + 1, brick) for d in range(3)] + ["parthenon/meshblock/nx%d=%d" % (d + 1, mb) for d in range(3)]
-    ov += ["parthenon/time/integrator=%s" % integrator, "hydro/reconstruction=%s" % recon, "hydro/riemann=%s" % riemann]
+    if name in EXTRA_WORKLOADS:
+        deck, fluid, integrator, recon, riemann, mesh, mbs, desc, extra = EXTRA_WORKLOADS[name]
+    else:
+        deck, fluid, integrator, recon, riemann, brick, mb, desc = WORKLOADS[name]
+        mesh, mbs, extra = (brick,) * 3, (mb,) * 3, []
+    ov = ["parthenon/mesh/nx%d=%d" % (d + 1, mesh[d]) for d in range(3)] + ["parthenon/meshblock/nx%d=%d" % (d + 1, mbs[d]) for d in range(3)]
+    ov += ["parthenon/time/integrator=%s" % integrator, "hydro/reconstruction=%s" % recon, "hydro/riemann=%s" % riemann] + extra
     sim = driver.Simulation(decks.load(deck), ov, strict=False).initialize()
     try:
         for _ in range(warmup):
@@ -253,12 +275,23 @@ def other_workload(name, steps=4, warmup=2):
         timing = sim.read_kernel_timing()
         info = sim.info
         per_kernel, stage_ms, b_stage, achieved, dominant = stage_figures(timing, fluid, integrator, int(info.zones_local), info.ndim)
-        return {"description": desc, "value": int(info.zones_total) * steps / dt, "unit": "cell-updates/s", "steps": steps,
-                "ms_per_step": dt / steps * 1e3, "high_order_stage_ms": stage_ms,
-                "dc_predictor_stage_ms": per_kernel["fused_dc_x1"] + per_kernel["fused_dc_x2"] + per_kernel["fused_dc_x3"],
-                "algorithmic_bytes_per_cell_stage": b_stage, "stage_achieved_GBps": achieved, "stage_frac": achieved / HBM_PEAK_GBS,
-                "dominant_timing_slot": dominant, "dominant_kernel": rocprof_kernels(fluid, recon, riemann).get(dominant, dominant),
-                "per_kernel_avg_ms": {k: v for k, v in per_kernel.items() if v > 0.0}}
+        out = {"description": desc, "value": int(info.zones_total) * steps / dt, "unit": "cell-updates/s", "steps": steps,
+               "ms_per_step": dt / steps * 1e3, "high_order_stage_ms": stage_ms,
+               "dc_predictor_stage_ms": per_kernel["fused_dc_x1"] + per_kernel["fused_dc_x2"] + per_kernel["fused_dc_x3"],
+               "algorithmic_bytes_per_cell_stage": b_stage, "stage_achieved_GBps": achieved, "stage_frac": achieved / HBM_PEAK_GBS,
+               "dominant_timing_slot": dominant,
+               "dominant_kernel": (rocprof_kernels(fluid, recon, riemann).get(dominant, dominant) if info.ndim == 3 and min(mbs) >= 16 else dominant),
+               "per_kernel_avg_ms": {k: v for k, v in per_kernel.items() if v > 0.0}}
+        if deck == "orszag_tang":
+            # FirstOrderFluxCorrect (hydro.cpp:1223-1342): cells whose fluxes were replaced / stages whose optimistic fused
+            # form was rejected and redone on the flux arrays, per cycle over warm-up + timed cycles (the vortex is smooth
+            # this early: the option costs its admissibility test, not corrections)
+            ncyc = max(1, sim.ncycle)
+            out["fofc_cells_corrected_per_cycle"] = sim.fofc_count / ncyc
+            out["fofc_fallback_stages_per_cycle"] = sim.fofc_fallback_stages() / ncyc
+        if deck == "turbulence":
+            out["forcing_kicks_without_stored_primitives"] = sim.turb_dt_kicks()
+        return out
     finally:
         sim.close()
 
@@ -338,12 +371,14 @@ def rehearsal_8gpu_rank(workload, n1_ms, steps=10, warmup=2):
 
 
 def other_workloads():
-    """BASELINE configs 2, 4 (its scheme, unforced) and 5 (its mesh) next to the headline: a few cycles each, after the
-    headline's timed region so that nothing perturbs it."""
+    """BASELINE configs 2, 3 (first-order flux correction off and on), 4 (its scheme unforced, and as specified with the
+    forcing) and 5 (its mesh) next to the headline: a few cycles each, after the headline's timed regions so that nothing
+    perturbs them."""
     out = {}
-    for name in ("hydro_plm_hllc_rk2_256", "mhd_wenoz_hlld_rk3_256"):
+    for name in ("hydro_plm_hllc_rk2_256", "mhd_wenoz_hlld_rk3_256", "mhd_wenoz_hlld_rk3_256_forced",
+                 "orszag_tang_512x512x4_vl2", "orszag_tang_512x512x4_vl2_fofc"):
         try:
-            out[name] = other_workload(name)
+            out[name] = other_workload(name, steps=8 if name.startswith("orszag") else 4)
         except Exception as e:  # supplementary figures; never lose the headline
             out[name] = {"error": repr(e)}
     try:
@@ -351,6 +386,51 @@ def other_workloads():
     except Exception as e:
         out["amr_blast_cfg5_mesh"] = {"error": repr(e)}
     return out
+
+
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz; MI355X_MICROARCH.md)
+N_SIMD = 1024                  # 256 CUs x 4
+FP64_ISSUE_CYCLES = 4.0        # a wave64 fp64 instruction occupies its SIMD's 16 lanes for 4 cycles
+
+
+def valu_roofline(stage_ms):
+    """The compute-side roof SURVEY 8(d) asks for next to the HBM one (the fp64 vector ALU), for the general PPM+HLLD
+    stage: fp64 add / mul / fma wave-instructions per stage from the newest COMMITTED counter profile of the stage
+    benchmark (profiles/rNN_pmc_instruction_mix.json: SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 of the two stage kernels, product
+    build), priced at full width (64 lanes, an fma = 2 flop) against `stage_ms` measured live in this run."""
+    for rnd in ("r05", "r04"):
+        path = os.path.join(ROOT, "profiles", "%s_pmc_instruction_mix.json" % rnd)
+        if not os.path.exists(path):
+            continue
+        try:
+            with open(path) as f:
+                mix = json.load(f)["mix"]
+            add = sum(k["SQ_INSTS_VALU_ADD_F64"] for k in mix.values())
+            mul = sum(k["SQ_INSTS_VALU_MUL_F64"] for k in mix.values())
+            fma = sum(k["SQ_INSTS_VALU_FMA_F64"] for k in mix.values())
+            valu = sum(k["SQ_INSTS_VALU"] for k in mix.values())
+            lanes = sum(k["SQ_THREAD_CYCLES_VALU"] for k in mix.values()) / valu  # live lanes per VALU instruction
+            flops = 64.0 * (add + mul + 2.0 * fma)
+            tf = flops / (stage_ms * 1e-3) / 1e12
+            commit = _profile_commit(path)
+            return {"kernel": "general PPM+HLLD stage (x3 sweep + finishing march), the `general_stage` of this line",
+                    "fp64_arith_wave_instructions_per_stage": add + mul + fma,
+                    "valu_wave_instructions_per_stage": valu,
+                    "live_lanes_per_valu_instruction": lanes,
+                    "fp64_flops_per_stage": flops, "achieved_TFLOPs": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / FP64_VALU_PEAK_TFLOPS,
+                    # the time the stage would take if nothing but its fp64 add / mul / fma were issued, at full rate, and
+                    # the same for every VALU instruction it executes (compares, selects, moves, DPP, address arithmetic)
+                    "fp64_issue_floor_ms": {"at_2.4_GHz_nominal": (add + mul + fma) * FP64_ISSUE_CYCLES / N_SIMD / 2.4e9 * 1e3,
+                                            "at_2.0_GHz_measured_under_load": (add + mul + fma) * FP64_ISSUE_CYCLES / N_SIMD / 2.0e9 * 1e3},
+                    "all_valu_issue_floor_ms_at_2.0_GHz": valu * FP64_ISSUE_CYCLES / N_SIMD / 2.0e9 * 1e3,
+                    "stage_ms": stage_ms,
+                    "frac_of_hbm_roofline_at_the_fp64_issue_floor": 288.0 * 16777216 / ((add + mul + fma) * FP64_ISSUE_CYCLES / N_SIMD / 2.0e9) / 1e9 / HBM_PEAK_GBS,
+                    "source": "profiles/%s_pmc_instruction_mix.json%s -- a COMMITTED counter profile of the stage benchmark, not this run; "
+                              "flops at full width (masked lanes counted), fma = 2" % (rnd, " @ " + commit if commit else "")}
+        except Exception:
+            continue
+    return None
 
 
 def _profile_commit(path):
@@ -401,6 +481,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--regions", type=int, default=3, help="timed regions of --steps cycles each; the median one is reported")
+    ap.add_argument("--sustained", type=int, default=500, help="cycles of the 'sustained' figure of the N = 1 line (0: skip)")
     ap.add_argument("--workload", default="mhd_ppm_hlld_vl2_256", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-copies-base", action="store_true",
@@ -502,23 +584,42 @@ def main():
     info = sim.info
     sim.kernel_timing(True)
     sim.read_kernel_timing()
-    barrier()
+    # THREE timed regions of exactly --steps cycles each, every one bracketed by barrier + synchronize and reduced with
+    # MAX over the ranks; `value` / `ms_per_step` are those of the MEDIAN region (a region of 20 cycles is 70 ms: too
+    # short to separate a 2 % kernel change from the box, round-4 review), all three are listed in `timed_regions_ms`.
+    regions, region_timing = [], []
     comm_before = sim.comm_stats() if world > 1 else None
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sim.step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    timing = sim.read_kernel_timing()
+    for _ in range(max(1, args.regions)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sim.step()
+        torch.cuda.synchronize()
+        barrier()
+        e = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([e], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        regions.append(e)
+        region_timing.append(sim.read_kernel_timing())  # (read = reset: the slots of this region)
+    med = sorted(range(len(regions)), key=lambda q: regions[q])[len(regions) // 2]
+    elapsed, timing = regions[med], region_timing[med]
     sim.kernel_timing(False)
     comm_stats = sim.comm_stats() if world > 1 else None
     skipped_per_cycle = sim.skipped_local_exchanges() / max(1, sim.ncycle)
     overlapped_per_cycle = sim.overlapped_exchanges / max(1, sim.ncycle)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # 500 cycles back to back (N = 1): does the rate hold once the clocks have settled under the power cap?
+    sustained = None
+    if world == 1 and not args.unfused and args.sustained > 0 and not (args.brick or args.meshblock):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.sustained):
+            sim.step()
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t1
+        sustained = {"value": int(info.zones_total) * args.sustained / e2, "unit": "cell-updates/s", "cycles": args.sustained,
+                     "ms_per_step": e2 / args.sustained * 1e3}
     # The honest base of a weak-scaling curve: at N = 1 every block face is a same-rank face and direct
     # neighbour addressing skips ALL ghost copies, while at N > 1 the faces between bricks are packed, sent
     # and unpacked.  Same workload once more with the same-rank ghost copies done as at N > 1 (a second
@@ -584,6 +685,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "timed_regions_ms": [e * 1e3 for e in regions],
+            "timed_region_reported": "median of %d regions of %d cycles each (barrier + synchronize around each, max over ranks)" % (len(regions), args.steps),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -600,8 +703,8 @@ def main():
                                         if world > 1 else None),
                        "overlapped_exchanges_per_cycle": overlapped_per_cycle if world > 1 else None,
                        # collectives per cycle on the reduction communicator (dt and the c_h estimate travel together)
-                       "reductions_per_cycle": ((comm_stats["reductions"] - comm_before["reductions"]) / args.steps) if comm_stats else None,
-                       "halo_exchanges_per_cycle": ((comm_stats["exchanges"] - comm_before["exchanges"]) / args.steps) if comm_stats else None,
+                       "reductions_per_cycle": ((comm_stats["reductions"] - comm_before["reductions"]) / (args.steps * len(regions))) if comm_stats else None,
+                       "halo_exchanges_per_cycle": ((comm_stats["exchanges"] - comm_before["exchanges"]) / (args.steps * len(regions))) if comm_stats else None,
                        # stage boundaries per cycle whose same-rank ghost copies were skipped (direct neighbour addressing)
                        "same_rank_ghost_copies_skipped_per_cycle": skipped_per_cycle},
             "cell_stage_updates_per_s": value * nstages,
@@ -620,13 +723,16 @@ def main():
                 "stage_ms": stage_ms,
                 "dc_predictor_stage_ms": per_kernel["fused_dc_x1"] + per_kernel["fused_dc_x2"] + per_kernel["fused_dc_x3"],
                 "frac_of_measured_copy_bandwidth": achieved / HBM_COPY_GBS,
-                "note": "fp64 VALU-issue bound and power-limited (executed VALU instructions per cell-stage: SQ_INSTS_VALU in "
-                        "the newest profiles/rNN_pmc_sq.json; effective clock 1.8 - 2.0 GHz of a nominal 2.4 under these kernels, "
-                        "profiles/r03_clock_and_latency.json, at 1320 W of the 1400 W cap, profiles/r03_power_while_stage_loops.txt; "
-                        "issue rates of the instruction classes: profiles/r02_clock_and_issue_rate.json); `peak` is the 8 TB/s "
-                        "spec, frac_of_measured_copy_bandwidth prices against the 6.29 TB/s a float4 copy reaches "
-                        "(MI355X_MICROARCH.md); PRODUCT build: FMA contraction, rsq/rcp-based roots and reciprocals, "
-                        "<= 1e-12 of the bit-exact parity build (which is what the parity tests pin); see DESIGN.md section 7",
+                # `bound` names the roof `achieved` / `peak` / `frac` are priced against (HBM, as north_star asks); what
+                # the counters say actually binds the stage kernels is in `binding_limit` and priced in `valu`
+                "binding_limit": "fp64 vector-ALU issue (SQ counters: profiles/r05_pmc_sq.json, r05_pmc_instruction_mix.json) "
+                                 "under the 1400 W power cap (effective clock profiles/r05_clock.json), next to the access pattern of "
+                                 "the march (profiles/r04_ubench_march_traffic.jsonl); see roofline.valu for the compute roof",
+                "note": "`peak` is the 8 TB/s HBM3E spec, frac_of_measured_copy_bandwidth prices against the 6.29 TB/s a float4 copy "
+                        "reaches (MI355X_MICROARCH.md); kernel resources (VGPRs, scalar spills, LDS): profiles/r05_kernel_resources.txt. "
+                        "PRODUCT build (FMA contraction, rsq/rcp-based roots and reciprocals): L1 norms within 1e-12 of the bit-exact "
+                        "parity build (which is what the parity tests pin); PPM states can differ by ~1e-8 after a few cycles "
+                        "(a last-bit difference flips an extremum test); DESIGN.md sections 4 and 7",
                 "per_kernel_avg_ms": per_kernel,
                 "dominant_kernel": ROCPROF_KERNEL.get(dominant, dominant) if fluid == "glmmhd" and recon == "ppm" else dominant,
                 "dominant_timing_slot": dominant,
@@ -635,12 +741,16 @@ def main():
                                 "frac": value / world * b_cycle / 1e9 / HBM_PEAK_GBS},
             },
         }
+        if sustained:
+            out["sustained_%d_cycles" % sustained["cycles"]] = sustained
         if copies_base:
             out["weak_scaling_base_with_ghost_copies"] = copies_base
         if world == 1 and fluid == "glmmhd" and not args.unfused:
             try:
                 sim.close()
                 out["roofline"]["general_stage"] = general_stage_bench(recon, riemann)
+                if recon == "ppm" and riemann == "hlld":
+                    out["roofline"]["valu"] = valu_roofline(out["roofline"]["general_stage"]["ms_per_stage"])
             except Exception as e:  # supplementary figure; never lose the headline
                 out["roofline"]["general_stage"] = {"error": repr(e)}
         if world == 1 and not args.unfused and not args.no_rehearsal and not (args.brick or args.meshblock):

@@ -117,7 +117,7 @@ long long apk_sim_overlapped_exchanges(const apk_sim *sim);
  * on demand (every accessor does).  Results are identical.  APK_DIRECT_NEIGHBORS=0 in the environment
  * switches it off.  Returns the number of stage boundaries so far whose same-rank copies were skipped. */
 long long apk_sim_skipped_local_exchanges(const apk_sim *sim);
-int apk_sim_set_direct_neighbors(apk_sim *sim, int on);
+int apk_sim_set_direct_neighbors(apk_sim *sim, int on); /* 1 (default) / 0 = always copy */
 /* Full-step primitives kept out of memory (on by default where it applies: uniform 3-D meshes, VL2 -- a donor-cell
  * predictor followed by a two-kernel stage --, default equation-of-state limits, no passive scalars, no extended Dedner
  * source, no forcing): the last stage of a cycle computes the primitives of the new state for the time-step estimate
@@ -137,7 +137,10 @@ int apk_sim_set_prim_free(apk_sim *sim, int on);
  * of one-layer exchanges so far. */
 int apk_sim_set_thin_exchange(apk_sim *sim, int on);
 long long apk_sim_thin_exchanges(const apk_sim *sim);
-int apk_sim_prim_is_stale(const apk_sim *sim); /* 1 (default) / 0 = always copy */
+int apk_sim_prim_is_stale(const apk_sim *sim);
+/* forced turbulence in a cycle that stores no primitives: number of kicks that estimated the time step without storing
+ * them (apk_turb_apply_dt) so far */
+long long apk_sim_turb_dt_kicks(const apk_sim *sim);
 /* Refined meshes: the stage loop's exchange leaves out the ghost zones behind block edges and corners
  * (no sweep or flux correction reads them; accessors, tagging and the last exchange of a cycle that
  * checks the refinement criteria complete them).  1 = always exchange in full (what APK_AMR_FULL_EXCHANGE=1

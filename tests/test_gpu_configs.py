@@ -106,6 +106,9 @@ def test_config4_forced_turbulence_wenoz_hlld_rk3_matches_oracle(oracle, strict)
     for _ in range(CFG4_CYCLES):
         s.step()
         o.step()
+    # (round-4 advisor: no stage of this cycle stores primitives and the kick after the last one estimates the time step
+    # without storing them either -- apk_turb_apply_dt, once per cycle -- so they are stale until an accessor asks)
+    assert s.prim_is_stale and s.turb_dt_kicks() == CFG4_CYCLES
     np.testing.assert_allclose(s.fmft_var_hat(), o.var_hat(), rtol=1e-12, atol=1e-14)
     assert abs(s.time - o.time) <= 1e-13 * o.time
     np.testing.assert_allclose(s.gather("cons"), o.gather_cons(), rtol=1e-11, atol=1e-13)
@@ -250,6 +253,33 @@ def test_config5_adaptive_mhd_blast_as_decked():
     for lb in range(i.nblocks_local):
         w = s.read_block(lb, "prim")[:, g:-g, g:-g, g:-g]
         assert np.all(np.isfinite(w)) and w[0].min() > 0.0 and w[4].min() > 0.0
+
+
+def _forest_is_reflection_symmetric(s, root_blocks):
+    from amr_emulator import placement
+    locs = {(p[0], tuple(p[1])) for p in placement(s)}
+    for lev, loc in locs:
+        n1 = root_blocks * 2 ** lev
+        for d in range(3):
+            m = list(loc)
+            m[d] = n1 - 1 - m[d]
+            if (lev, tuple(m)) not in locs:
+                return False
+    return True
+
+
+def test_config5_parity_build_keeps_the_forest_mirror_symmetric_every_cycle():
+    """The tolerance of _forest_octant_symmetric_within is for what floating point does NOT keep: axis permutations
+    (the flux differences are summed x1, x2, x3) and, in the product build, mirror images of contracted a*b - c*d.  The
+    parity build contracts nothing and the reference's groupings are mirror symmetric (the "KGF" parentheses of PPM,
+    ppm_simple.hpp:53-63), so there the forest must equal its three mirror images after EVERY cycle -- no slack."""
+    ov = CFG5 + ["parthenon/time/tlim=1.0"]
+    s = _sim("blast_3d_amr", ov, strict=True).initialize()
+    assert _forest_is_reflection_symmetric(s, 4)
+    for _ in range(40):
+        s.step()
+        assert _forest_is_reflection_symmetric(s, 4)
+    assert s.amr_stats()[0] > 0
 
 
 def test_config5_with_first_order_flux_correct_enabled():

@@ -223,6 +223,33 @@ def test_rk_with_walls_and_outflow_matches_oracle(oracle, strict, scheme):
     _assert_same(np.asarray(s.dt), np.asarray(o.dt), strict)
 
 
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("scheme", [("rk2", "plm", 2), ("rk3", "ppm", 3)], ids=["rk2_plm", "rk3_ppm"])
+def test_rk_with_a_density_floor_that_fires_in_every_stage_matches_oracle(oracle, strict, scheme):
+    """Round-4 advisor (high): a prim-free RK cycle stores the results of its stages without ConsToPrim, so a density
+    floor would act on the register copy the next stage converts and never reach the stored conserved state, where the
+    reference's FillDerived after EVERY stage writes the floored density back (adiabatic_hydro.hpp:81).  With
+    hydro/dfloor the cycle must keep its primitives.  Two receding streams (u = -/+ 2.5) empty the middle of the tube
+    below the floor in every stage of every cycle; against the oracle, whose ConsToPrim floors after every stage."""
+    integ, recon, ng = scheme
+    ov = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=32", "parthenon/meshblock/nx1=32",
+          "parthenon/meshblock/nx2=32", "parthenon/meshblock/nx3=32", "parthenon/time/integrator=%s" % integ,
+          "hydro/reconstruction=%s" % recon, "parthenon/mesh/nghost=%d" % ng, "hydro/dfloor=0.3",
+          "problem/sod/rho_l=1.0", "problem/sod/pres_l=0.4", "problem/sod/u_l=-2.5",
+          "problem/sod/rho_r=1.0", "problem/sod/pres_r=0.4", "problem/sod/u_r=2.5", "parthenon/time/tlim=0.08"]
+    s = _sim("sod", ov, strict=strict).initialize()
+    o = oracle.Sim(fluid="euler", recon=recon, riemann="hllc", integrator=integ, nx=(64, 32, 32), mb=(32, 32, 32), ng=ng,
+                   bc=("outflow", "periodic", "periodic"), xmin=(0.0, -0.5, -0.5), xmax=(1.0, 0.5, 0.5), cfl=0.3,
+                   eos=oracle.make_eos(1.4, dfloor=0.3)).pgen("sod", rho_l=1.0, pres_l=0.4, u_l=-2.5, rho_r=1.0, pres_r=0.4,
+                                                             u_r=2.5)
+    assert s.run() == o.run(0.08)
+    assert not s.prim_is_stale                      # (the cycle stores its primitives: every stage floors what it stores)
+    u = s.gather()
+    assert u[0].min() == 0.3 and (u[0] == 0.3).sum() > 32 * 32  # the floor is what holds the middle up
+    _assert_same(u, o.gather_cons(), strict)
+    _assert_same(np.asarray(s.dt), np.asarray(o.dt), strict)
+
+
 def test_config2_full_size_sod_stays_one_dimensional():
     """256^3, 8 meshblocks of 128^3 (BASELINE config 2).  Size-independent property: a
     planar problem keeps zero transverse momentum and no transverse structure, bitwise."""

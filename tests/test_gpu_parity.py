@@ -1168,6 +1168,83 @@ def test_direct_neighbor_addressing_equals_filled_ghost_zones(request, fluid, re
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("kind", ["smooth", "rough"])
+@pytest.mark.parametrize("faces", ["filled_ghosts", "face_table"])
+@pytest.mark.parametrize("mode", ["input_u1", "input_u1_dt_only", "input_u0_third_buffer", "input_u0_third_buffer_dt_only"])
+@pytest.mark.parametrize("fluid,recon,riemann", [("glmmhd", "ppm", "hlld"), ("glmmhd", "wenoz", "hlld"), ("euler", "plm", "hllc")])
+def test_two_kernel_stage_takes_its_input_from_the_conserved_state(request, oracle, fluid, recon, riemann, mode, faces, kind, strict):
+    """apk_stage_fused in the forms a prim-free RK cycle is made of (round-4 review, item 6), each against
+    orc_stage + orc_c2p through the C-ABI:
+      prim_from_cons = 1   the input state is u1.cons (gam0 = 0); u0.prim holds NaN, u0.cons something unrelated;
+      prim_from_cons = 2   the input state is u0.cons itself (gam0 != 0): the result goes to a third buffer
+                           (cons_out_delta) and u0.cons stays as it was, bit for bit;
+      fill_derived   = 3   ... and the primitives of the updated cells feed the time-step estimate only: no prim array is
+                           written.
+    With filled ghost zones, and through a face table with the ghost zones behind its faces poisoned."""
+    import ctypes as C
+    import torch
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    nx = (36, 9, 10)
+    ng, prim, g = _case(fluid, recon, nx, kind=kind, seed=211, nblocks=3)
+    table = [[1, 1, 2, -1, 0, -1],
+             [0, 2, -1, 2, 1, 1],
+             [-1, 0, 1, 0, -1, 2]]
+    use_table = faces == "face_table"
+    if use_table:
+        prim = _fill_faces_from_neighbors(prim, table, nx, ng)
+    state = H.prim_to_cons(fluid, prim, GAMMA)                      # the stage's input, as a conserved state
+    _, prim_of_state, bad = H.orc_c2p(fluid, g, state.copy(), oracle.make_eos(GAMMA))
+    assert bad == 0
+    state_dev = _poison_faces(state, table, nx, ng) if use_table else state
+    tab = torch.tensor(table, dtype=torch.int32, device="cuda") if use_table else None
+    own_input = mode.startswith("input_u0")
+    dt_only = mode.endswith("dt_only")
+    gam0 = 0.25 if own_input else 0.0
+    bdt = 0.004 if kind == "smooth" else 0.0004       # (uniform random states: a small step keeps the update admissible)
+    nh, ded = NHYDRO[fluid], (1 if fluid == "glmmhd" else 0)
+    nan = np.full_like(prim, np.nan)
+    if own_input:
+        u0c, u1c = state_dev, state * 1.01
+    else:
+        u0c, u1c = np.full_like(state, 123.0), state_dev
+    m0 = hydro.MeshData(ctx, nx, ng, nh, dx=tuple(g.dx), nblocks=3, cons=u0c, prim=nan, with_flux=False)
+    m1 = hydro.MeshData(ctx, nx, ng, nh, dx=tuple(g.dx), nblocks=3, cons=u1c, prim=np.full_like(prim, -7.0), with_flux=False)
+    m2 = hydro.MeshData(ctx, nx, ng, nh, dx=tuple(g.dx), nblocks=3, cons=np.full_like(state, -7.0), with_flux=False) if own_input else None
+    cfg = hydro._cfg(fluid, recon, riemann)
+    assert ctx.lib.apk_stage_split_axis(m0.h, C.byref(cfg), 0) == 3
+    ctx.poll_flags()
+    eos = hydro.L.make_eos(GAMMA)
+    kw = dict(dedner=ded, glmmhd_alpha=0.1, mindx=0.07, face_neighbor=tab)
+    hydro.StageFused(m0, m1, fluid, recon, riemann, eos, C_H, gam0, 1.0 - gam0, bdt, fill_derived=3 if dt_only else 0,
+                     estimate_dt=dt_only, prim_from_cons=2 if own_input else 1, cons_out=m2, **kw)
+    dt = hydro.StageDt(ctx, 0.3) if dt_only else None
+    assert ctx.poll_flags() == 0
+    want = H.orc_stage(fluid, recon, riemann, g, state if own_input else np.zeros_like(state), state * 1.01 if own_input else state,
+                       prim_of_state, GAMMA, C_H, gam0, 1.0 - gam0, bdt, dedner=ded, alpha=0.1, mindx=0.07)
+    got = (m2 if own_input else m0).cons_host()
+    _cmp(H.interior(got, nx, ng), H.interior(want, nx, ng), strict, "updated conserved state")
+    if own_input:
+        assert np.array_equal(m0.cons_host(), u0c, equal_nan=True), "u0.cons is the stage's input: it must stay as it was"
+        ghosts = np.ones(got.shape, dtype=bool)
+        H.interior(ghosts, nx, ng)[...] = False
+        assert np.all(got[ghosts] == -7.0), "interior cells only"
+    assert np.all(np.isnan(m0.prim_host())) and np.all(m1.prim_host() == -7.0), "no primitives are stored in these forms"
+    if dt_only:
+        _, want_prim, bad = H.orc_c2p(fluid, g, want.copy(), oracle.make_eos(GAMMA))
+        want_dt = 0.3 * H.orc_min_dt(fluid, g, want_prim, GAMMA)
+        assert bad == 0 and (dt == want_dt if strict else dt == pytest.approx(want_dt, rel=1e-12))
+    # refusals: an equation of state with limits the lean forms do not compile; the own-input form without a third buffer
+    with pytest.raises(Exception):
+        hydro.StageFused(m0, m1, fluid, recon, riemann, hydro.L.make_eos(GAMMA, pfloor=1e-6), C_H, gam0, 1.0 - gam0, bdt,
+                         prim_from_cons=2 if own_input else 1, cons_out=m2, **kw)
+    if own_input:
+        with pytest.raises(Exception):
+            hydro.StageFused(m0, m1, fluid, recon, riemann, eos, C_H, gam0, 1.0 - gam0, bdt, prim_from_cons=2, **kw)
+
+
+@pytest.mark.gpu
 def test_direct_neighbor_addressing_rejects_stage_forms_that_read_ghost_zones(request):
     import torch
     from athenapk_amd import hydro
