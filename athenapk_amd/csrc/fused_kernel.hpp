@@ -1427,6 +1427,7 @@ inline void launch_scalar_update(const PackView &u0, const PackView &u1, const S
 
 }  // namespace apk
 #include "fused2_kernel.hpp"
+#include "fused3_kernel.hpp"
 namespace apk {
 
 // ---- launch helpers ---------------------------------------------------------------------------
@@ -1603,6 +1604,11 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
       ScopedTiming t(sp.ctx, TS + 0, s);
       hipLaunchKernelGGL((fused_march12_kernel<FLUID, RECON, RS>), dim3(wpb, 1, u0.nblocks), dim3(64), lds, s,
                          u0, u1, sp, wpb);
+    } else if (two_kernel_stage_applies(u0, RECON, extra, sp) && single_march_stage_applies<FLUID, RECON>(u0, extra, sp)) {
+      // the whole stage in one march (fused3_kernel.hpp: three-point reconstructions, input from a conserved state)
+      ScopedTiming t(sp.ctx, TS + 0, s);
+      launch_s3<FLUID, RECON, RS>(u0, u1, sp, extra, s);
+      return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
     } else if (two_kernel_stage_applies(u0, RECON, extra, sp)) {
       // two-kernel stage (fused2_kernel.hpp): the x3 sweep writes its flux difference, then one
       // march does x1 + x2 and finishes.  A split stage runs the x3 sweep on plane windows in

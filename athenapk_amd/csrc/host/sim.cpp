@@ -1722,6 +1722,7 @@ int apk_sim_history(apk_sim *s, double *out8) {
 // UserHistoryOperation::sum
 int apk_sim_turbulence_history(apk_sim *s, double *out3) {
   if (!s || s->host_only || !out3) return APK_ERR_INVALID;
+  if (s->prim_stale) SIM_TRY(s, sync_ghosts(s));  // (the Mach numbers are sums over the PRIMITIVES of the interior)
   SIM_TRY(s, apk_turbulence_history(s->ctx, s->mu0(), s->pkg.fluid, s->pkg.eos.gamma, out3, s->stream));
   if (s->have_comm && s->nranks > 1) {
     if (s->comm.allreduce_sum(s->comm.user, out3, 3) != 0) return fail(s, APK_ERR_DEVICE, "allreduce_sum failed");

@@ -299,38 +299,57 @@ APK_DEV double ppm_interface(double qm1, double q0, double qp1, double qp2) {
   return face;
 }
 
+// (the extremum limiter proper: steps 4 of ppm_simple.hpp:104-150 for a cell the extremum test has picked)
+APK_DEV void ppm_cell_limited(double qm2, double qm1, double q0, double qp1, double qp2, double face_m, double face_p,
+                              double dminus, double dplus, double &l, double &r) {
+  constexpr double C2 = 1.25;
+  // The second differences and the limited ratio are only consumed here, so they are only computed here.
+  // (d2_c and d2_p are also what ppm_interface's extremum branch computes for the interface above this cell: left
+  // alone, the compiler evaluates them in front of BOTH branches, i.e. in every lane of every pencil -- 4 full-width
+  // instructions per variable and direction to save 4 few-lane ones where both limiters engage)
+  const double q0x = opaque(q0), qp1x = opaque(qp1);
+  const double d2_m = qm2 + q0x - 2.0 * qm1;
+  const double d2_c = qm1 + qp1x - 2.0 * q0x;
+  const double d2_p = q0x + qp2 - 2.0 * qp1x;
+  const double d2_face = 6.0 * (face_m + face_p - 2.0 * q0x);
+  const bool s = neg(d2_m);
+  const bool agree = (s == neg(d2_c)) && (s == neg(d2_p)) && (s == neg(d2_face));
+  const double mag = min2(min2(C2 * fabs(d2_m), C2 * fabs(d2_c)), min2(C2 * fabs(d2_p), fabs(d2_face)));
+  const double d2lim = agree ? with_sign(neg(d2_face), mag) : 0.0;
+  const double scale_lo = max_abs2(qm1, qm2);
+  const double scale_hi = max_with_abs(max_abs2(q0, qp1), qp2);
+  double ratio = 0.0;
+  if (fabs(d2_face) > (1.0e-12) * max_plain(scale_lo, scale_hi)) ratio = d2lim / d2_face;
+  l = face_p;
+  r = face_m;
+  if (ratio <= (1.0 - (1.0e-12))) {
+    r = q0 - ratio * dminus;
+    l = q0 + ratio * dplus;
+  }
+}
 APK_DEV void ppm_cell(double qm2, double qm1, double q0, double qp1, double qp2, double face_m,
                       double face_p, double &ql, double &qr) {
-  constexpr double C2 = 1.25;
   const double dminus = q0 - face_m;
   const double dplus = face_p - q0;
   const double ext_a = dminus * dplus;
   const double ext_b = (qp1 - q0) * (q0 - qm1);
+#ifdef APK_PPM_NO_FLAT_SKIP  // (A/B)
+  const bool ext = ext_a <= 0.0 || ext_b <= 0.0;  // local extremum: CS limiter on the parabola
+#else
+  // A variable that does not change along the sweep direction -- the field components of an unmagnetised run and the
+  // ambient medium of a blast (config 5), every variable along x3 of a thin-z run (config 3), a velocity component at
+  // rest -- passes the reference's extremum test in EVERY lane ((q_i+1 - q_i)(q_i - q_i-1) = 0 <= 0) and would run the
+  // limiter at full width to no effect: with both one-sided differences zero the parabola's second difference
+  // 6 (f_m + f_p - 2 q) is zero, the roundoff guard leaves the ratio at 0 and the limited states are q -/+ 0 * 0 = q.
+  // The overshoot tests of the other branch give the same values there (|0| >= 2 |0|: q -/+ 2 * 0 = q), so such lanes
+  // are taken out of the extremum set: one v_max_f64 and one compare per call, and config 5's stage kernels execute a
+  // third fewer instructions.
+  const bool ext = (ext_a <= 0.0 || ext_b <= 0.0) && !(max_abs2(dminus, dplus) == 0.0);
+#endif
 
   double r = face_m, l = face_p;
-  if (ext_a <= 0.0 || ext_b <= 0.0) {
-    // local extremum: CS limiter on the parabola (steps 4 of ppm_simple.hpp:104-150).  The second
-    // differences and the limited ratio are only consumed here, so they are only computed here.
-    // (d2_c and d2_p are also what ppm_interface's extremum branch computes for the interface above this cell: left
-    // alone, the compiler evaluates them in front of BOTH branches, i.e. in every lane of every pencil -- 4 full-width
-    // instructions per variable and direction to save 4 few-lane ones where both limiters engage)
-    const double q0x = opaque(q0), qp1x = opaque(qp1);
-    const double d2_m = qm2 + q0x - 2.0 * qm1;
-    const double d2_c = qm1 + qp1x - 2.0 * q0x;
-    const double d2_p = q0x + qp2 - 2.0 * qp1x;
-    const double d2_face = 6.0 * (face_m + face_p - 2.0 * q0x);
-    const bool s = neg(d2_m);
-    const bool agree = (s == neg(d2_c)) && (s == neg(d2_p)) && (s == neg(d2_face));
-    const double mag = min2(min2(C2 * fabs(d2_m), C2 * fabs(d2_c)), min2(C2 * fabs(d2_p), fabs(d2_face)));
-    const double d2lim = agree ? with_sign(neg(d2_face), mag) : 0.0;
-    const double scale_lo = max_abs2(qm1, qm2);
-    const double scale_hi = max_with_abs(max_abs2(q0, qp1), qp2);
-    double ratio = 0.0;
-    if (fabs(d2_face) > (1.0e-12) * max_plain(scale_lo, scale_hi)) ratio = d2lim / d2_face;
-    if (ratio <= (1.0 - (1.0e-12))) {
-      r = q0 - ratio * dminus;
-      l = q0 + ratio * dplus;
-    }
+  if (ext) {
+    ppm_cell_limited(qm2, qm1, q0, qp1, qp2, face_m, face_p, dminus, dplus, l, r);
   } else {
     if (fabs(dminus) >= 2.0 * fabs(dplus)) r = q0 - 2.0 * dplus;
     if (fabs(dplus) >= 2.0 * fabs(dminus)) l = q0 + 2.0 * dminus;

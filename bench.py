@@ -288,7 +288,7 @@ def other_workload(name, steps=4, warmup=2):
             # this early: the option costs its admissibility test, not corrections)
             ncyc = max(1, sim.ncycle)
             out["fofc_cells_corrected_per_cycle"] = sim.fofc_count / ncyc
-            out["fofc_fallback_stages_per_cycle"] = sim.fofc_fallback_stages() / ncyc
+            out["fofc_fallback_stages_per_cycle"] = sim.fofc_fallback_stages / ncyc
         if deck == "turbulence":
             out["forcing_kicks_without_stored_primitives"] = sim.turb_dt_kicks()
         return out

@@ -1186,7 +1186,8 @@ def test_two_kernel_stage_takes_its_input_from_the_conserved_state(request, orac
     import torch
     from athenapk_amd import hydro
     ctx = _ctx(request, strict)
-    nx = (36, 9, 10)
+    # (hydro PLM takes the single-march form of these stages -- fused3_kernel.hpp -- which wants an even number of x2 rows)
+    nx = (36, 10, 9) if fluid == "euler" else (36, 9, 10)
     ng, prim, g = _case(fluid, recon, nx, kind=kind, seed=211, nblocks=3)
     table = [[1, 1, 2, -1, 0, -1],
              [0, 2, -1, 2, 1, 1],
@@ -1217,9 +1218,21 @@ def test_two_kernel_stage_takes_its_input_from_the_conserved_state(request, orac
     ctx.poll_flags()
     eos = hydro.L.make_eos(GAMMA)
     kw = dict(dedner=ded, glmmhd_alpha=0.1, mindx=0.07, face_neighbor=tab)
+    slots = {name: q for q, name in enumerate(hydro.L.TIMING_SLOTS)}
+
+    def launches(name):
+        ms, cnt = C.c_double(0.0), C.c_longlong(0)
+        assert ctx.lib.apk_kernel_timing_read(ctx.h, slots[name], C.byref(ms), C.byref(cnt)) == 0
+        return cnt.value
+    ctx.lib.apk_kernel_timing_enable(ctx.h, 1)
+    launches("fused_x1"), launches("fused_x3")                        # (read = reset)
     hydro.StageFused(m0, m1, fluid, recon, riemann, eos, C_H, gam0, 1.0 - gam0, bdt, fill_derived=3 if dt_only else 0,
                      estimate_dt=dt_only, prim_from_cons=2 if own_input else 1, cons_out=m2, **kw)
     dt = hydro.StageDt(ctx, 0.3) if dt_only else None
+    n1, n3 = launches("fused_x1"), launches("fused_x3")
+    ctx.lib.apk_kernel_timing_enable(ctx.h, 0)
+    # the form that ran: one march for hydro PLM, the x3 sweep + the finishing march for the others
+    assert (n1, n3) == ((1, 0) if (fluid, recon) == ("euler", "plm") else (1, 1))
     assert ctx.poll_flags() == 0
     want = H.orc_stage(fluid, recon, riemann, g, state if own_input else np.zeros_like(state), state * 1.01 if own_input else state,
                        prim_of_state, GAMMA, C_H, gam0, 1.0 - gam0, bdt, dedner=ded, alpha=0.1, mindx=0.07)
