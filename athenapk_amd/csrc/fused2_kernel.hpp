@@ -33,38 +33,20 @@
 
 namespace apk {
 
-// Neighbour-lane access of K2: value of lane (l - K) for K = 1, 2 (shr) / lane (l + K) (shl); lanes
-// without such a neighbour get an unspecified valid lane's value (they never retire a cell).
-// APK_M12F_BPERMUTE (A/B): through the LDS crossbar (ds_bpermute_b32: no VALU issue slot, two per
-// double) instead of DPP wave shifts (v_mov_b32_dpp: 4.4 cycles of VALU issue each, measured).
-#ifndef APK_M12F_BPERMUTE
-#define APK_M12F_BPERMUTE 0  // measured on 8 x 128^3: 3.26 ms per stage against 3.11 with DPP
-#endif
+// Neighbour-lane access of K2: value of lane (l - K) for K = 1, 2 (shr) / lane (l + K) (shl) by DPP wave shifts; lanes
+// without such a neighbour receive 0 (they never retire a cell).  (Through the LDS crossbar instead -- ds_bpermute_b32, no
+// VALU issue slot -- measured 3.26 ms per stage against 3.11 in round 2.)
 template <int K>
-APK_DEV double lane_below(double x, int lane) {
-  if constexpr (APK_M12F_BPERMUTE != 0) {
-    const int src = (lane >= K ? lane - K : lane) << 2;
-    const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(x));
-    const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(x));
-    return __hiloint2double(hi, lo);
-  } else {
-    double r = wave_shr1(x);
-    if constexpr (K == 2) r = wave_shr1(r);
-    return r;
-  }
+APK_DEV double lane_below(double x, int) {
+  double r = wave_shr1(x);
+  if constexpr (K == 2) r = wave_shr1(r);
+  return r;
 }
 template <int K>
-APK_DEV double lane_above(double x, int lane) {
-  if constexpr (APK_M12F_BPERMUTE != 0) {
-    const int src = (lane + K <= 63 ? lane + K : lane) << 2;
-    const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(x));
-    const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(x));
-    return __hiloint2double(hi, lo);
-  } else {
-    double r = wave_shl1(x);
-    if constexpr (K == 2) r = wave_shl1(r);
-    return r;
-  }
+APK_DEV double lane_above(double x, int) {
+  double r = wave_shl1(x);
+  if constexpr (K == 2) r = wave_shl1(r);
+  return r;
 }
 
 // Lanes of a K2 wave that retire a cell.  A cell needs the fluxes of both its x1 faces; a face needs
@@ -75,25 +57,6 @@ APK_DEV double lane_above(double x, int lane) {
 constexpr int m12_first_lane(int recon) { return recon_halfwidth(recon) + 1; }
 constexpr int m12_last_lane(int recon) { return 62 - recon_halfwidth(recon); }
 
-#ifndef APK_M12F_LOADS
-// where the d3 / u1 loads of the retiring cell are issued (A/B switch): 0 top of the iteration,
-// 1 after the x1 phase, 2 after the x2 solve.  Measured on 8 x 128^3 PPM+HLLD: 3.44 / 3.10 / 2.36 ms
-// with two waves per SIMD -- the earlier the loads, the more of the 256 VGPRs they hold through an
-// HLLD solve and the more the compiler spills (148 / 156 / 12 B of scratch per lane); with one wave
-// per SIMD (512 VGPRs, APK_M12F_WAVES = 1) nothing spills but 2.63 ms at best.  3 = u1 after the x1
-// phase, d3 after the x2 solve: 100 B of scratch, 2.81 against 2.60 ms on the same box.
-#define APK_M12F_LOADS 2
-#endif
-#ifndef APK_M12F_MASK_IDLE
-// 1: lanes that retire no cell (overlap lanes at the ends of the wave, ghost columns: 13 % of the lanes on 128^3 blocks)
-// sit out the x2 reconstruction and both Riemann solves -- they only have to carry their column through the ring as the
-// x1 stencil of their neighbours.  The stage runs at 94 % of the socket's 1400 W (rocm-smi while it loops; effective clock
-// 1.8 - 2.0 of 2.4 GHz), so energy per cell is what the clock answers to: every lane-operation not executed counts.
-#define APK_M12F_MASK_IDLE 1
-#endif
-#ifndef APK_M12F_WAVES
-#define APK_M12F_WAVES 2  // resident waves per SIMD the kernel is compiled for (A/B: 1 = 512 VGPRs)
-#endif
 
 #ifndef APK_M12F_TIMING
 // 1 (diagnostic variant build, `make variant VAR=tm VARFLAGS=-DAPK_M12F_TIMING=1`): per-phase shader-clock sums of the
@@ -127,22 +90,22 @@ constexpr bool m12f_keeps_raw_rows() {
 }
 
 template <int FLUID, int RECON, int RS, int EXTRA, bool LEAN, bool FC = false>
-__global__ void __launch_bounds__(64, APK_M12F_WAVES)
+__global__ void __launch_bounds__(64, 2)
 fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves, int per_xcd,
-                  long long total_rows, int sched_lockstep) {
+                  long long total_rows) {
   static_assert(RECON != APK_RC_DC, "donor-cell stages have their own single-kernel form");
   static_assert(!FC || LEAN, "prim_from_cons: lean form only");
   constexpr int NV = nvars<FLUID>();
   constexpr int H = recon_halfwidth(RECON);
   constexpr int NS = 2 * H;
   constexpr int FIRST = m12_first_lane(RECON), LAST = m12_last_lane(RECON), CPW = LAST - FIRST + 1;
-  // where d3 / u1 are requested (APK_M12F_LOADS above).  The lean march WITHOUT ConsToPrim (the stages of RK2 / RK3 that
-  // are not the last, the north-star stage benchmark) has the registers to request u1 after the x1 phase without
-  // scratch (244 VGPRs): general stage 3.07 -> 2.98 ms, same box.  (A/B: -DAPK_M12F_LOADS_GENERAL=0)
-#ifndef APK_M12F_LOADS_GENERAL
-#define APK_M12F_LOADS_GENERAL 1
-#endif
-  constexpr int LOADS = (APK_M12F_LOADS_GENERAL != 0 && APK_M12F_LOADS == 2 && LEAN && EXTRA == EXTRA_NONE) ? 3 : APK_M12F_LOADS;
+  // Where d3 / u1 of the retiring cell are requested: LOADS = 2 after the x2 solve (measured in round 2 on 8 x 128^3
+  // PPM+HLLD: at the top of the iteration 3.44 ms with 148 B of scratch per lane, after the x1 phase 3.10 ms / 156 B, after
+  // the x2 solve 2.36 ms / 12 B -- the earlier the loads, the more of the 256 VGPRs they hold through an HLLD solve; one
+  // wave per SIMD with 512 VGPRs spills nothing but takes 2.63 ms at best).  The lean march WITHOUT ConsToPrim (the stages
+  // of RK2 / RK3 that are not the last, the north-star stage benchmark) has the registers to request u1 after the x1
+  // phase without scratch (LOADS = 3; 244 VGPRs): general stage 3.07 -> 2.98 ms, same box.
+  constexpr int LOADS = (LEAN && EXTRA == EXTRA_NONE) ? 3 : 2;
   extern __shared__ __attribute__((aligned(16))) double ring[];
   // FC with room in the LDS (m12f_keeps_raw_rows: the hydro marches, PLM-class GLM-MHD): the rows are ALSO kept as loaded,
   // in a second ring -- the cell a wave retires is one of them, and its conserved value is what the update reads a second
@@ -161,41 +124,29 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
   unsigned long long tick_ = clock64();
 #endif
 
-  // Work of this wave (wave-uniform).  sched_lockstep = 0: the (block, chunk) columns x nx2 rows as one list cut into
-  // equal contiguous ranges.  1 (default): wave w marches WHOLE columns w, w + nwaves, ... and then a segment of the
-  // columns left over, neighbouring waves taking neighbouring columns over the same rows -- all waves of an XCD are then
-  // at (about) the same row at the same time, and the two waves that share a cache line at the seam of their 58-cell
-  // chunks write it within an iteration of each other: the L2 merges the two partial writes into one full line.  Written
-  // apart (ranges that start 20 rows apart, as in the equal split) every seam line goes to memory twice as a partial
-  // write.  tools/ubench/ubench_march_traffic.hip: the march's 27 load + 18 store streams, no arithmetic, 1.86 ms with
-  // the equal split and 1.36 ms in lockstep (profiles/r04_ubench_march_traffic.jsonl).
+  // Work of this wave (wave-uniform), the LOCKSTEP schedule: wave w marches WHOLE columns w, w + nwaves, ... of the
+  // (block, chunk) list and then a segment of the columns left over, neighbouring waves taking neighbouring columns over
+  // the same rows -- all waves of an XCD are then at (about) the same row at the same time, and the two waves that share
+  // a cache line at the seam of their 58-cell chunks write it within an iteration of each other: the L2 merges the two
+  // partial writes into one full line.  Written apart (one list of wave-rows cut into equal contiguous ranges that start
+  // 20 rows apart: the schedule of rounds 2 - 3) every seam line goes to memory twice as a partial write.
+  // tools/ubench/ubench_march_traffic.hip: the march's 27 load + 18 store streams, no arithmetic, 1.86 ms with the equal
+  // split and 1.36 ms in lockstep (profiles/r04_ubench_march_traffic.jsonl).
   const int ncol = (int)(total_rows / u0.nx2);
-  const int full = sched_lockstep ? ncol / nwaves : 0, left_cols = ncol - full * nwaves;
-  const int per_col = (sched_lockstep && left_cols > 0) ? nwaves / left_cols : 0;  // segments per leftover column (>= 1)
+  const int full = ncol / nwaves, left_cols = ncol - full * nwaves;
+  const int per_col = (left_cols > 0) ? nwaves / left_cols : 0;  // segments per leftover column (>= 1)
   const int seg = per_col > 0 ? (u0.nx2 + per_col - 1) / per_col : 0;
-  long long r = total_rows * w / nwaves;
-  const long long r_end = total_rows * (w + 1) / nwaves;
-  int piece = 0;
-  while (sched_lockstep ? piece <= full : r < r_end) {  // wave-uniform
+  for (int piece = 0; piece <= full; ++piece) {  // wave-uniform
     // ---- this piece: rows s..e of column chunk `chunk` of block b
     int item, j0, nrows;
-    if (sched_lockstep) {
-      if (piece < full) {
-        item = piece * nwaves + w, j0 = 0, nrows = u0.nx2;
-      } else {
-        if (left_cols <= 0) break;
-        const int sidx = w / left_cols, lc = w - sidx * left_cols;
-        if (sidx >= per_col || sidx * seg >= u0.nx2) break;
-        item = full * nwaves + lc, j0 = sidx * seg;
-        nrows = (j0 + seg <= u0.nx2) ? seg : u0.nx2 - j0;
-      }
-      ++piece;
+    if (piece < full) {
+      item = piece * nwaves + w, j0 = 0, nrows = u0.nx2;
     } else {
-      item = (int)(r / u0.nx2);
-      j0 = (int)(r - (long long)item * u0.nx2);
-      const long long left = r_end - r;
-      nrows = (left < (long long)(u0.nx2 - j0)) ? (int)left : (u0.nx2 - j0);
-      r += nrows;
+      if (left_cols <= 0) break;
+      const int sidx = w / left_cols, lc = w - sidx * left_cols;
+      if (sidx >= per_col || sidx * seg >= u0.nx2) break;
+      item = full * nwaves + lc, j0 = sidx * seg;
+      nrows = (j0 + seg <= u0.nx2) ? seg : u0.nx2 - j0;
     }
     const int b = item / wpb;
     const int chunk = item - b * wpb;
@@ -218,11 +169,11 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     // (row c - 1 of this column in d3: d3base + (c - 1) * d3st, like `done` in the cells' layout)
     const int64_t d3st = sp.du_pitch > 0 ? (int64_t)sp.du_pitch : st;
     const int64_t d3base = sp.du_pitch > 0 ? ((int64_t)krow * u0.nx2 - u0.js) * sp.du_pitch + d3col : base;
-    // lanes whose x1 face flux somebody uses: a retiring cell needs the flux of its own lower face and that of the lane above
-    const bool need_f1 = !(APK_M12F_MASK_IDLE & 2) || active ||
-                         (__builtin_amdgcn_update_dpp(0, active ? 1 : 0, 0x138, 0xf, 0xf, true) != 0);  // wave_shr:1 = lane l-1
-    const bool need_x2 = !(APK_M12F_MASK_IDLE & 1) || active;       // x2 Riemann
-    const bool need_r2 = !(APK_M12F_MASK_IDLE & 4) || active;       // x2 reconstruction
+    // Lanes that retire no cell (overlap lanes at the ends of the wave, ghost columns: 13 % of the lanes on 128^3 blocks)
+    // sit out the x2 Riemann solve -- they only have to carry their column through the ring as the x1 stencil of their
+    // neighbours.  The stage runs at 94 % of the socket's 1400 W, so every lane-operation not executed counts.  (Masking
+    // the x1 solve and the x2 reconstruction as well costs more in exec-mask bookkeeping than it saves: round 3.)
+    const bool need_x2 = active;
     const double dx1 = b0.dx[0], dx2 = b0.dx[1];
     const double area1 = to_sgpr(b0.dx[1] * b0.dx[2]);  // (per block: wave-uniform)
     const double area2 = to_sgpr(b0.dx[0] * b0.dx[2]);
@@ -311,14 +262,6 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
       // its 9 flux differences stay live.
       double du[NV], d3v[NV], u1v[NV];
       double rawv[RAW ? NV : 1];  // the retiring cell's row as loaded
-      if constexpr (LOADS == 0) {
-        if (retire) {
-#pragma unroll
-          for (int n = 0; n < NV; ++n) d3v[n] = d3[n * d3_sn + d3done];
-#pragma unroll
-          for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
-        }
-      }
       if (retire) {
         const int slot_cm1 = (slot0 + H - 1) & (NS - 1);
         double ql1[NV], qr1[NV];
@@ -356,7 +299,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
           wl[q] = lane_below<1>(ql1[perm<1>(q)], lane);
           wr[q] = qr1[perm<1>(q)];
         }
-        if (need_f1) riemann<FLUID, RS>(wl, wr, sp.k, f1);
+        riemann<FLUID, RS>(wl, wr, sp.k, f1);
         double fup0 = 0.0;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
@@ -372,19 +315,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
           }
         }
         // (2) streaming operands of the cell being retired: in flight during the x2 phase
-        if constexpr (LOADS == 1) {
-          asm volatile("" ::: "memory");
-#pragma unroll
-          for (int n = 0; n < NV; ++n) d3v[n] = d3[n * d3_sn + d3done];
-          if (RAW && sp.prim_from_cons == 1) {
-#pragma unroll
-            for (int n = 0; n < NV; ++n) u1v[n] = rawv[RAW ? n : 0];
-          } else {
-#pragma unroll
-            for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
-          }
-        }
-        if constexpr (LOADS == 3) {  // (A/B) u1 early, d3 late
+        if constexpr (LOADS == 3) {  // u1 early, d3 late
           asm volatile("" ::: "memory");
           if (RAW && sp.prim_from_cons == 1) {  // (wave-uniform: the input state IS u1, and the row is at hand)
 #pragma unroll
@@ -404,7 +335,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
       }
       if constexpr (FC) (void)cons_row_to_prim<FLUID>(sp, Pn);  // (every lane: the row goes into the ring as the x1 stencil of its neighbours)
       double qln[NV], qrn[NV];
-      if (need_r2) {
+      {
       double an[NS];  // ring rows of the next variable (software-pipelined LDS reads)
 #pragma unroll
       for (int m = 0; m < NS; ++m) an[m] = ring[(((slot0 + m) & (NS - 1)) * NV + 0) * 64 + lane];
@@ -573,7 +504,7 @@ inline int resident_march_waves() {
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     }
-    return cus * 4 * APK_M12F_WAVES;
+    return cus * 4 * 2;
   }();
   return n;
 }
@@ -587,7 +518,7 @@ inline int resident_march_waves() {
 inline bool two_kernel_stage_applies(const PackView &u0, int recon, int extra, const StageParams &sp) {
   static const int mode = std::getenv("APK_STAGE_MODE") ? std::atoi(std::getenv("APK_STAGE_MODE")) : 2;  // A/B switch: 3 = three sweeps
   if (mode == 3) return false;
-  static const int min_nx1 = std::getenv("APK_M12_MIN_NX1") ? std::atoi(std::getenv("APK_M12_MIN_NX1")) : 16;  // A/B switch
+  constexpr int min_nx1 = 16;
   // (blocks narrower than 32 cells only if they are deep enough along x3 for the plane windows of a split stage --
   // 4 nghost planes: the driver's overlap rule -- so that taking this form never costs an overlapped exchange)
   const bool wide_enough = u0.nx1 >= 32 || (u0.nx1 >= min_nx1 && u0.nx3 >= 4 * u0.ng);
@@ -604,25 +535,16 @@ inline void launch_m12f(const PackView &u0, const PackView &u1, const StageParam
     const long long total_rows = (long long)u0.nblocks * wpb * u0.nx2;
     // as many waves as the device holds, but no ranges shorter than ~16 rows
     long long nw = resident_march_waves();
-    {
-      // (A/B: waves per SIMD the grid is sized for -- the hydro marches need 130 - 144 VGPRs and 5 - 10 KB of LDS per wave,
-      // three of them fit a SIMD)
-      static const int per_simd = std::getenv("APK_M12F_GRID_WAVES") ? std::atoi(std::getenv("APK_M12F_GRID_WAVES")) : 0;
-      if (per_simd > 0) nw = nw / APK_M12F_WAVES * per_simd;
-    }
     if (total_rows / 16 < nw) nw = total_rows / 16 > 0 ? total_rows / 16 : 1;
     const int nwaves = (int)nw;
     const int per_xcd = (nwaves + 7) / 8;
     const dim3 g((unsigned)(per_xcd * 8), 1, 1);
-    // (APK_NO_LEAN=1: the general kernel also where the lean one applies, A/B)
-    static const bool no_lean = std::getenv("APK_NO_LEAN") && std::atoi(std::getenv("APK_NO_LEAN")) != 0;
-    const bool lean = stage_is_lean(sp) && !no_lean;
-    static const int lockstep = std::getenv("APK_M12F_LOCKSTEP") ? std::atoi(std::getenv("APK_M12F_LOCKSTEP")) : 1;  // A/B switch
+    const bool lean = stage_is_lean(sp);
 #define APK_LAUNCH_M12F(EXTRA_, LEAN_) \
-  hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, LEAN_>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows, lockstep)
+  hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, LEAN_>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows)
     constexpr int lds_fc = m12f_keeps_raw_rows<FLUID, RECON>() ? 2 * lds : lds;  // (the rows as loaded, too)
 #define APK_LAUNCH_M12F_FC(EXTRA_) \
-  hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, true, true>), g, dim3(64), lds_fc, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows, lockstep)
+  hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, true, true>), g, dim3(64), lds_fc, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows)
     if (sp.prim_from_cons) {  // (lean forms only: launch_fused_stage has checked)
       if (extra == EXTRA_C2P_DT) APK_LAUNCH_M12F_FC(EXTRA_C2P_DT);
       else if (extra == EXTRA_C2P) APK_LAUNCH_M12F_FC(EXTRA_C2P);

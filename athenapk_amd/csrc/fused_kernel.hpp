@@ -359,12 +359,6 @@ fused_x1_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_plane) {
 // the Riemann problem of the previous face is solved.  Keeping the ring out of the VGPR file
 // (it would be 2H*NV doubles = 72 VGPRs for PPM/GLM-MHD) is what lets two waves share a SIMD.
 constexpr int kMarchMinWaves = 2;
-#ifndef APK_PPM_DEFER
-#define APK_PPM_DEFER 0  // 1: PPM's extremum limiter deferred to one pass per direction in the marches (hydro_math.hpp: ppm_cell_defer), A/B
-#endif
-#ifndef APK_PPM_PAIRS
-#define APK_PPM_PAIRS 0  // 1: PPM reconstructs two variables per pass in the marches (hydro_math.hpp: ppm_interface2 / ppm_cell2), A/B
-#endif
 
 // apk_stage_args.prim_from_cons in the two-kernel stage: the sweeps load rows of the CONSERVED input state and convert
 // them (ConsToPrim in its lean form, the function the stage that produced the state would have applied: same bits) --
@@ -530,63 +524,6 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
 #pragma unroll
       for (int m = 0; m < NS; ++m) an[m] = ring[(((slot0 + m) & (NS - 1)) * NV + 0) * 64 + lane];
     }
-#if APK_PPM_DEFER
-    if constexpr (RECON == APK_RC_PPM) {
-      PpmPending pend;
-      ppm_pending_clear(pend);
-#pragma unroll
-      for (int n = 0; n < NV; ++n) {
-        double a[NS];
-#pragma unroll
-        for (int m = 0; m < NS; ++m) a[m] = an[m];
-        if (n + 1 < NV) {
-#pragma unroll
-          for (int m = 0; m < NS; ++m) an[m] = ring[(((slot0 + m) & (NS - 1)) * NV + n + 1) * 64 + lane];
-        }
-        const double face_p = ppm_interface(a[1], a[2], a[3], Pn[n]);
-        ppm_cell_defer(a[0], a[1], a[2], a[3], Pn[n], face_carry[n], face_p, n, pend, qln[n], qrn[n]);
-        face_carry[n] = face_p;
-      }
-      double le, re;
-      ppm_pending_limit(pend, le, re);
-#pragma unroll
-      for (int n = 0; n < NV; ++n) {
-        const bool mine = pend.full && pend.var == n;
-        qln[n] = mine ? le : qln[n];
-        qrn[n] = mine ? re : qrn[n];
-      }
-    } else
-#elif APK_PPM_PAIRS
-    if constexpr (RECON == APK_RC_PPM) {
-      // two variables per pass (ppm_interface2 / ppm_cell2): the ring rows of the NEXT pair are requested first
-      auto ring_rows = [&](int n, double (&q)[5]) {
-#pragma unroll
-        for (int m = 0; m < NS; ++m) q[m] = ring[(((slot0 + m) & (NS - 1)) * NV + n) * 64 + lane];
-        q[4] = Pn[n];
-      };
-      double qa[5], qb[5], na[5], nb[5];
-      ring_rows(0, na);
-      ring_rows(1, nb);
-#pragma unroll
-      for (int n = 0; n + 1 < NV; n += 2) {
-#pragma unroll
-        for (int m = 0; m < 5; ++m) qa[m] = na[m], qb[m] = nb[m];
-        if (n + 2 < NV) ring_rows(n + 2, na);
-        if (n + 3 < NV) ring_rows(n + 3, nb);
-        double fa, fb;
-        ppm_interface2(qa[1], qa[2], qa[3], qa[4], qb[1], qb[2], qb[3], qb[4], fa, fb);
-        ppm_cell2(qa, face_carry[n], fa, qb, face_carry[n + 1], fb, qln[n], qrn[n], qln[n + 1], qrn[n + 1]);
-        face_carry[n] = fa;
-        face_carry[n + 1] = fb;
-      }
-      if constexpr (NV % 2 == 1) {
-        constexpr int n = NV - 1;
-        const double face_p = ppm_interface(na[1], na[2], na[3], na[4]);
-        ppm_cell(na[0], na[1], na[2], na[3], na[4], face_carry[n], face_p, qln[n], qrn[n]);
-        face_carry[n] = face_p;
-      }
-    } else
-#endif
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
       double a[NS > 0 ? NS : 1];
@@ -844,12 +781,6 @@ fused_march12_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_blo
 // against 504 B/cell of the two-march schedule.  prim is only read, so no lane can observe a
 // half-updated state; FillDerived of the stage is left to ConservedToPrimitive.
 // ==============================================================================================
-#ifndef APK_DC3_PREFETCH
-#define APK_DC3_PREFETCH 1  // A/B switch
-#endif
-#ifndef APK_DC3_WAVES
-#define APK_DC3_WAVES 2  // resident waves per SIMD the donor-cell march is compiled for (A/B)
-#endif
 // Input state of a donor-cell march lane: nine loads at `p` and, when the stage derives its primitives from the
 // conserved state (apk_stage_args.prim_from_cons), ConsToPrim of what was loaded -- the function the finishing sweep of the
 // previous stage applied to the same values (lean form: no floor but the density / energy ones, no flags: the state was
@@ -869,7 +800,7 @@ APK_DEV void load_input_state(const double *p, int64_t sn, const StageParams &sp
 }
 
 template <int FLUID, int RS, int EXTRA = EXTRA_NONE, bool LEAN = false, bool FROM_CONS = false>
-__global__ void __launch_bounds__(64, APK_DC3_WAVES)
+__global__ void __launch_bounds__(64, 2)
 fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, int nseg, int per_xcd) {
   constexpr int NV = nvars<FLUID>();
   double lane_min_dt = 1.7976931348623157e308;
@@ -984,7 +915,7 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
   // The next plane is requested one iteration ahead (its 9 loads have a whole iteration of four Riemann
   // solves to land: 1.69 -> 1.62 ms on 8 x 128^3) where the registers allow it: with FillDerived in the
   // kernel 243 VGPRs; without (refined meshes) the 18 extra registers would spill.
-  constexpr bool PF = (APK_DC3_PREFETCH != 0) && (EXTRA != EXTRA_NONE) && !FROM_CONS;
+  constexpr bool PF = (EXTRA != EXTRA_NONE) && !FROM_CONS;
   double wnext[NV];
   if constexpr (PF) {
 #pragma unroll
@@ -1130,9 +1061,6 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
 // working set of a solve stays what it was; the carried state doubles: 2 x 9 doubles of the previous plane in VGPRs,
 // 4 x 9 rows in the LDS stash (18.4 KB per wave, inside the 20 KB two waves per SIMD leave).
 // ==============================================================================================
-#ifndef APK_DC3_ROWS
-#define APK_DC3_ROWS 2  // 1: always the one-row kernel (A/B)
-#endif
 template <int FLUID, int RS, int EXTRA, bool FROM_CONS = false>
 __global__ void __launch_bounds__(64, 2)
 fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, int nseg, int per_xcd) {
@@ -1218,11 +1146,6 @@ fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, 
       cf3_prev[r] = cf_of(wp3);
     }
   }
-  // (APK_DC3R2_PREFETCH: the raw values of the next plane's two cells are requested one iteration ahead, A/B)
-#ifndef APK_DC3R2_PREFETCH
-#define APK_DC3R2_PREFETCH 0
-#endif
-  constexpr bool PF = APK_DC3R2_PREFETCH != 0;
   double raw[2][NV];
   auto load_raw = [&](int c) {
     const double *pc = ((c > u0.ke) ? prim_khi : prim) + (int64_t)c * u0.sk;  // wave-uniform
@@ -1244,22 +1167,16 @@ fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, 
   };
   // With FROM_CONS the conserved values of the plane just completed ARE the u1 the update reads: they stay in registers
   // (both cells: 242 VGPRs, no scratch, in the forms with ConsToPrim; the form without it has no room) instead of being
-  // read a second time, 72 of the 259 B per cell the march moved -- 1.13 -> 1.05 - 1.07 ms.  (-DAPK_DC3R2_HOLD=0 / 1: A/B)
-#ifndef APK_DC3R2_HOLD
-#define APK_DC3R2_HOLD 2
-#endif
-  constexpr int HOLD = (FROM_CONS && EXTRA != EXTRA_NONE) ? APK_DC3R2_HOLD : 0;
+  // read a second time, 72 of the 259 B per cell the march moved -- 1.13 -> 1.05 - 1.07 ms.  (A register prefetch of the next
+  // plane on top of it -- 256 VGPRs + 20 B of scratch -- measured 1.15 -> 1.17 ms in round 4 and is gone.)
+  constexpr int HOLD = (FROM_CONS && EXTRA != EXTRA_NONE) ? 2 : 0;
   double held[HOLD > 0 ? HOLD : 1][NV];
-  if constexpr (PF) load_raw(s);
   for (int c = s; c <= e + 1; ++c) {
     const int64_t off = (int64_t)c * u0.sk;
     double wc[2][NV];
-    if constexpr (!PF) load_raw(c);
+    load_raw(c);
     to_input(raw[0], wc[0]);
     to_input(raw[1], wc[1]);
-    if constexpr (PF) {
-      if (c <= e) load_raw(c + 1);
-    }
     // ---- x3 faces c of both cells; plane c-1 is complete
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -1441,11 +1358,10 @@ inline int march_rows_per_wave(int nx1, int ntrans) {
 }
 
 inline int march_segments(int64_t waves, int n_along) {
-  static const int forced = std::getenv("APK_MARCH_NSEG") ? std::atoi(std::getenv("APK_MARCH_NSEG")) : 0;  // A/B switch
-  int nseg = forced > 0 ? forced : (int)((4096 + waves - 1) / waves);
+  int nseg = (int)((4096 + waves - 1) / waves);
   // (segments no shorter than 8 rows: a pack of 232 16^3 blocks is 928 march waves on 2048 slots in one piece,
   // 1856 in two -- 1.14 -> 1.09 ms per cycle of the refined MHD blast; 4-row segments lose it again)
-  static const int min_rows = std::getenv("APK_MARCH_MIN_ROWS") ? std::atoi(std::getenv("APK_MARCH_MIN_ROWS")) : 8;  // A/B switch
+  constexpr int min_rows = 8;
   const int max_seg = n_along / min_rows > 0 ? n_along / min_rows : 1;
   if (nseg > max_seg) nseg = max_seg;
   return nseg < 1 ? 1 : nseg;
@@ -1521,11 +1437,8 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
         // whole donor-cell stage in one march (see fused_dc3_kernel); its FillDerived is out of place
         const int64_t run3 = sp.window ? (int64_t)sp.window_rows * sp.window_rl : (int64_t)u0.nx2 * (u0.nx1 + 2);
         const int wpb = (int)((run3 + 61) / 62);
-        static const int forced_kseg = std::getenv("APK_DC3_KSEG") ? std::atoi(std::getenv("APK_DC3_KSEG")) : 0;  // A/B switch
         int kseg = (u0.nx3 >= 16) ? 8 : u0.nx3;  // measured on 8 x 128^3: 8 and 16 within 1 %, 64 is 12 % slower
-        if (forced_kseg > 0) {
-          kseg = forced_kseg < u0.nx3 ? forced_kseg : u0.nx3;
-        } else if (u0.nx3 >= 16 && (int64_t)wpb * ((u0.nx3 + 7) / 8) * u0.nblocks < 4 * 2048) {
+        if (u0.nx3 >= 16 && (int64_t)wpb * ((u0.nx3 + 7) / 8) * u0.nblocks < 4 * 2048) {
           // small packs (refined meshes of 16^3 blocks): the march waves run in a few rounds of the 2048 resident ones
           // (2 per SIMD), so pick the segment length with the fewest plane-steps over all rounds -- a segment costs its
           // planes plus about 1.5 for the prologue (232 blocks: 2320 waves of 8 planes = 2 rounds x 9.5; of 6 = 2 x 7.5)
@@ -1543,10 +1456,8 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
         const dim3 g((unsigned)(per_xcd * 8), 1, 1);
         constexpr int lds3 = 2 * nvars<FLUID>() * 64 * (int)sizeof(double);
         ScopedTiming t(sp.ctx, TS + 0, s);
-        static const bool no_lean = std::getenv("APK_NO_LEAN") && std::atoi(std::getenv("APK_NO_LEAN")) != 0;  // (A/B)
-        const bool lean = stage_is_lean(sp) && !no_lean;
-        static const int dc_rows = std::getenv("APK_DC3_ROWS") ? std::atoi(std::getenv("APK_DC3_ROWS")) : APK_DC3_ROWS;  // (A/B)
-        if (lean && dc_rows == 2 && !sp.window && u0.nx2 % 2 == 0 && u0.nx2 >= 4) {
+        const bool lean = stage_is_lean(sp);
+        if (lean && !sp.window && u0.nx2 % 2 == 0 && u0.nx2 >= 4) {
           // two rows per lane (fused_dc3r2_kernel): whole blocks only -- a split stage's windows keep the one-row kernel
           const int64_t run2 = (int64_t)(u0.nx2 / 2) * (u0.nx1 + 2);
           const int wpb2 = (int)((run2 + 61) / 62);
@@ -1613,8 +1524,7 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
       // two-kernel stage (fused2_kernel.hpp): the x3 sweep writes its flux difference, then one
       // march does x1 + x2 and finishes.  A split stage runs the x3 sweep on plane windows in
       // phase 1 (it reads x3 ghost zones only) and the finishing march in phase 2.
-      static const bool du_cells = std::getenv("APK_DU_CELL_LAYOUT") != nullptr;  // A/B switch: the cells' layout
-      const int du_pitch = du_cells ? 0 : ((u0.nx1 + 15) / 16) * 16;
+      const int du_pitch = ((u0.nx1 + 15) / 16) * 16;
       if (do_x1) {
         StageParams sp1 = sp;
         sp1.du_first = 1;

@@ -395,14 +395,6 @@ int exchange_begin(apk_sim *s, bool async, int c2p, bool skip_local, bool thin) 
     // direct neighbour addressing: the stages read their same-rank neighbours' interiors
     s->local_ghosts_stale = true;
     s->skipped_local_exchanges += 1;
-  } else if (async && s->copy_stream) {
-    // same-rank copies on the copy stream, behind everything enqueued so far (the stage that
-    // produced the state; the kernels of the previous stage that read these ghost zones)
-    SIM_HIP(s, hipEventRecord(static_cast<hipEvent_t>(s->ev_stage_done), hs(s)));
-    SIM_HIP(s, hipStreamWaitEvent(static_cast<hipStream_t>(s->copy_stream), static_cast<hipEvent_t>(s->ev_stage_done), 0));
-    SIM_TRY(s, run_ghost_plan(s, s->cur, PH_LOCAL, c2p, s->copy_stream));
-    SIM_HIP(s, hipEventRecord(static_cast<hipEvent_t>(s->ev_copies_done), static_cast<hipStream_t>(s->copy_stream)));
-    s->copies_in_flight = true;
   } else {
     SIM_TRY(s, run_ghost_plan(s, s->cur, PH_LOCAL, c2p));
   }
@@ -427,10 +419,6 @@ int exchange_end(apk_sim *s, int c2p) {
   // first stage of the next cycle has swapped the buffer roles by the time it completes it
   const int buf = s->exchange_pending ? s->pending_cons : s->cur;
   if (s->exchange_pending) {
-    if (s->copies_in_flight) {
-      SIM_HIP(s, hipStreamWaitEvent(hs(s), static_cast<hipEvent_t>(s->ev_copies_done), 0));
-      s->copies_in_flight = false;
-    }
     if (!s->mesh.peers.empty() && s->comm.exchange_end(s->comm.user) != 0)
       return fail(s, APK_ERR_DEVICE, std::string("halo exchange (end) failed ") + apk_sim_comm_error(s));
     s->exchange_pending = false;
@@ -455,10 +443,9 @@ int exchange_ghosts(apk_sim *s, int c2p, bool skip_local, bool thin) {
 bool direct_neighbors(const apk_sim *s) {
   static const int mode = std::getenv("APK_DIRECT_NEIGHBORS") ? std::atoi(std::getenv("APK_DIRECT_NEIGHBORS")) : 1;  // A/B switch
   static const int dc_mode = std::getenv("APK_DC_MODE") ? std::atoi(std::getenv("APK_DC_MODE")) : 2;
-  static const bool no_copy_c2p = std::getenv("APK_NO_COPY_C2P") != nullptr;
   const HydroPackage &pkg = s->pkg;
   if (!mode || !s->direct_on || !s->d_face_nbr || s->amr || s->mesh.ndim != 3 || !stage_can_fuse(s)) return false;
-  if (pkg.nscalars != 0 || s->copy_stream || no_copy_c2p || !ghost_c2p_fusable(s)) return false;
+  if (pkg.nscalars != 0 || !ghost_c2p_fusable(s)) return false;
   if (pkg.fluid == APK_FLUID_GLMMHD && pkg.glmmhd_source_extended) return false;
   const apk_flux_cfg *cfgs[2] = {&pkg.flux_first_stage, &pkg.flux_other_stage};
   for (const apk_flux_cfg *cfg : cfgs) {
@@ -505,10 +492,8 @@ bool amr_faces_only(const apk_sim *s) {
 // and so must the first stage of the next cycle: a donor-cell stage (the VL2 predictor) reads one layer, PLM two.
 // (Whoever needs more -- accessors, the data transfer of a regridding that does change the mesh -- calls sync_ghosts.)
 bool amr_shell_before_check(const apk_sim *s) {
-  static const bool off = std::getenv("APK_NO_AMR_SHELL") != nullptr;      // A/B switches
-  static const bool no_c2p_dt = std::getenv("APK_NO_C2P_DT") != nullptr;
   const HydroPackage &pkg = s->pkg;
-  if (off || no_c2p_dt || !s->amr || !amr_faces_only(s) || !amr_has_shell(s) || !stage_can_fuse(s) || !pkg.calc_dt_hyp) return false;
+  if (!s->amr || !amr_faces_only(s) || !amr_has_shell(s) || !stage_can_fuse(s) || !pkg.calc_dt_hyp) return false;
   // the shell is AMR_SHELL_DEPTH layers deep: the first stage of the next cycle may read no deeper -- its stencil
   // half width plus the face it reconstructs for (DC 1 layer, PLM 2; PPM / WENO-Z 3 would read stale cells)
   const int recon = pkg.flux_first_stage.recon;
@@ -661,12 +646,10 @@ int build_windows(apk_sim *s) {
   for (auto &t : dc) t.assign(8 * (size_t)nlb, 0);
   std::vector<unsigned> late(nlb, 0u);
   for (int lb = 0; lb < nlb; ++lb) {
-    // Every face of an active direction is "late": ghost zones filled by same-rank copies arrive on
-    // the copy stream, those of other ranks by message, physical boundaries are applied after both.
+    // "late" faces: ghost zones filled by messages of other ranks (physical boundaries are applied after them)
     int L[3][2];
-    for (int d = 0; d < 3; ++d) L[d][0] = L[d][1] = (m.Active(d) && (s->copy_stream || m.LateFace(lb, d, -1))) ? 1 : 0;
-    if (!s->copy_stream)
-      for (int d = 0; d < 3; ++d) L[d][1] = m.LateFace(lb, d, +1) ? 1 : 0;
+    for (int d = 0; d < 3; ++d) L[d][0] = (m.Active(d) && m.LateFace(lb, d, -1)) ? 1 : 0;
+    for (int d = 0; d < 3; ++d) L[d][1] = m.LateFace(lb, d, +1) ? 1 : 0;
     // x1 sweep of a high-order stage: everything farther than nghost from a late x1 face, then the slabs
     put(x1[0], lb, 0, m.ni, m.is + W * L[0][0], m.ie - W * L[0][1], m.js, m.je, m.ks, m.ke);
     // (two columns of margin on the left: the L state of the cell below the first retired one needs, with
@@ -698,7 +681,7 @@ int build_windows(apk_sim *s) {
           if (!sx && !sy && !sz) continue;
           if ((sx && !m.Active(0)) || (sy && !m.Active(1)) || (sz && !m.Active(2))) continue;
           const int o[3] = {sx, sy, sz};
-          const bool is_late = s->copy_stream != nullptr || !m.Neighbor(bc, o, nbc) || m.NeighborRank(bc, o, nbc) != m.rank;
+          const bool is_late = !m.Neighbor(bc, o, nbc) || m.NeighborRank(bc, o, nbc) != m.rank;
           if (is_late) late[lb] |= 1u << ((sx + 1) + 3 * (sy + 1) + 9 * (sz + 1));
         }
   }
@@ -750,7 +733,7 @@ bool can_overlap_next(const apk_sim *s, int next) {
   // (messages to other ranks and / or same-rank copies on the copy stream)
   if (!(s->overlap && !s->amr && stage_can_fuse(s) && m.ndim >= 2 && s->x1win[0].d)) return false;
   if (!m.peers.empty() && !(s->have_comm && s->comm.exchange_begin && s->comm.exchange_end)) return false;
-  if (m.peers.empty() && !s->copy_stream) return false;
+  if (m.peers.empty()) return false;
   const apk_flux_cfg &cfg = (next == 1) ? s->pkg.flux_first_stage : s->pkg.flux_other_stage;
   const bool ext_dedner = s->pkg.fluid == APK_FLUID_GLMMHD && s->pkg.glmmhd_source_extended;
   if (cfg.recon == APK_RC_DC) {
@@ -969,12 +952,11 @@ int do_stage(apk_sim *s, int stage) {
       // The predictor of VL2: the corrector has gam0 = 0 and takes its fluxes from the predictor's primitives, so the
       // half-step CONSERVED state is read by nobody but the ghost exchange -- the nghost-deep shell of every block --
       // and by nothing at all when every face is crossed through the face table (apk_stage_args.cons_store).
-      static const int mode = std::getenv("APK_CONS_STORE") ? std::atoi(std::getenv("APK_CONS_STORE")) : 2;  // A/B switch: 0 stores all
       const bool dead = dc3 && swap_prim && stage < s->nstages && s->gam0[stage] == 0.0 && !s->amr && !s->fmft && pkg.nscalars == 0;
       bool all_periodic = true;
       for (int d = 0; d < 3; ++d)
         if (mm.Active(d) && (mm.bc_in[d] != BC_PERIODIC || mm.bc_out[d] != BC_PERIODIC)) all_periodic = false;
-      if (dead && mode > 0) a.cons_store = (direct && mm.peers.empty() && all_periodic && mode > 1) ? 2 : 1;
+      if (dead) a.cons_store = (direct && mm.peers.empty() && all_periodic) ? 2 : 1;
       // (physical boundary phases copy conserved values out of ghost zones filled before them: periodic boxes only)
       ghost_cons_dead = a.cons_store != 0 && all_periodic;
     }
@@ -984,9 +966,8 @@ int do_stage(apk_sim *s, int stage) {
       // seven launches; whole, it runs two rows per lane (3.5 Riemann problems per cell instead of 4).  The one-GPU
       // rehearsal of an 8-GPU rank (bench.py) measures the split at +0.3 ms per cycle against 0.19 ms of wire time it
       // could hide: the exchange in flight at the start of a cycle is completed before the predictor instead
-      // (APK_OVERLAP_DC=1: split it as in round 3, A/B).
-      static const bool overlap_dc = std::getenv("APK_OVERLAP_DC") && std::atoi(std::getenv("APK_OVERLAP_DC")) != 0;
-      if (s->exchange_pending && dc3 && swap_prim && !overlap_dc) SIM_TRY(s, finish_pending(s));
+      // (round 3 split it: measured slower).
+      if (s->exchange_pending && dc3 && swap_prim) SIM_TRY(s, finish_pending(s));
     }
     if (s->exchange_pending) {
       // The previous stage's halo messages are still in flight.  Ghost zones filled by same-rank
@@ -1122,11 +1103,9 @@ int do_stage(apk_sim *s, int stage) {
     }
   }
   if (s->fmft && stage == s->nstages) {
-    static const bool plain_kick = std::getenv("APK_TURB_PLAIN_KICK") != nullptr;  // A/B switch
-    const bool kick_fills = !fused_fill && !s->amr && !plain_kick;
+    const bool kick_fills = !fused_fill && !s->amr;
     // (a cycle whose stages store no primitives: the kick leaves them stale too, the next stage 1 reads the conserved state)
-    static const bool kick_stores = std::getenv("APK_KICK_STORES_PRIM") != nullptr;  // A/B switch
-    const bool kick_no_prim = kick_fills && s->prim_stale && rk_prim_free_cycle(s) && !kick_stores;
+    const bool kick_no_prim = kick_fills && s->prim_stale && rk_prim_free_cycle(s);
     SIM_TRY(s, turbulence_driving(s, s->dt, kick_fills, kick_no_prim));
     if (kick_fills && !kick_no_prim) s->prim_stale = false;  // (the kick wrote the primitives of every cell it touched)
     if (kick_fills) {  // as after a stage whose finishing sweep did FillDerived and the dt estimate
@@ -1134,15 +1113,12 @@ int do_stage(apk_sim *s, int stage) {
       s->stage_dt_pending = pkg.calc_dt_hyp;
     }
   }
-  static const bool no_copy_c2p = std::getenv("APK_NO_COPY_C2P") != nullptr;  // A/B switch
   // (a last stage that stored no primitives: the ghost zones get none either -- the next predictor reads the conserved
-  // state there as everywhere; APK_STALE_GHOST_C2P=1 converts them as before, A/B)
-  static const bool stale_c2p = std::getenv("APK_STALE_GHOST_C2P") != nullptr;
-  const bool ghost_prims = !s->prim_stale || stale_c2p;
-  static const bool no_prim_only = std::getenv("APK_NO_PRIM_ONLY_GHOSTS") != nullptr;  // A/B switch
-  const int c2p_in_copy = !(fused_fill && ghost_c2p_fusable(s) && !no_copy_c2p && ghost_prims)
+  // state there as everywhere)
+  const bool ghost_prims = !s->prim_stale;
+  const int c2p_in_copy = !(fused_fill && ghost_c2p_fusable(s) && ghost_prims)
                               ? GHOST_COPY
-                              : ((ghost_cons_dead && !no_prim_only) ? GHOST_PRIM_ONLY : GHOST_C2P);
+                              : (ghost_cons_dead ? GHOST_PRIM_ONLY : GHOST_C2P);
   if (fused_fill && can_overlap_next(s, stage < s->nstages ? stage + 1 : 1)) {
     // post the messages and leave them in flight: the next stage (of this or of the next cycle)
     // completes the exchange
@@ -1151,11 +1127,10 @@ int do_stage(apk_sim *s, int stage) {
     // refined meshes: nothing in the stage loop reads a ghost cell behind an edge or a corner of a block -- the
     // exchange skips those boxes (37 % of the ghost cells of a 16^3 block with nghost = 4) and ConsToPrim the cells
     // (nor, with amr_direct, the ghost zones behind faces the stages cross by the face table)
-    static const bool no_c2p_dt = std::getenv("APK_NO_C2P_DT") != nullptr;  // A/B switch
     const bool dir = amr_direct(s);
     SIM_TRY(s, amr_exchange(s, s->cur, dir ? AMR_XCHG_DIRECT : AMR_XCHG_FACES));
     if (dir) s->skipped_local_exchanges += 1;
-    if (stage == s->nstages && pkg.calc_dt_hyp && !no_c2p_dt) {  // (the time-step estimate on the way, as below)
+    if (stage == s->nstages && pkg.calc_dt_hyp) {  // (the time-step estimate on the way, as below)
       SIM_TRY(s, apk_cons_to_prim_faces_dt(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, dir ? s->d_face_nbr : nullptr, s->stream));
       s->stage_dt_pending = true;
     } else if (dir) {
@@ -1172,10 +1147,9 @@ int do_stage(apk_sim *s, int stage) {
   } else {
     // (without a fused FillDerived the full-block ConsToPrim below reads every ghost zone)
     SIM_TRY(s, exchange_ghosts(s, c2p_in_copy, direct && fused_fill, fused_fill && stage == s->nstages && thin_exchange_cycle(s)));
-    static const bool no_c2p_dt = std::getenv("APK_NO_C2P_DT") != nullptr;  // A/B switch
     if (fused_fill) {
       if (!c2p_in_copy && ghost_prims) SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
-    } else if (stage == s->nstages && pkg.calc_dt_hyp && !no_c2p_dt) {
+    } else if (stage == s->nstages && pkg.calc_dt_hyp) {
       // the last FillDerived of the cycle and the time-step estimate that follows it (hydro_driver.cpp:571-603) in
       // one pass: the interior cells' primitives are in registers anyway (refined meshes, flux-array stages)
       SIM_TRY(s, apk_cons_to_prim_dt(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, -1, s->stream));
@@ -1326,27 +1300,12 @@ int apk_sim_create(const char *deck, const char *const *overrides, int noverride
     return bail(rc);
   }
   if ((rc = build_copy_plans(s)) != APK_OK) return bail(rc);
-  {  // A/B switch APK_COPY_STREAM=1: same-rank ghost copies on a second stream, overlapped with the part
-     // of the next stage that needs no ghost zone (all faces "late").  Measured on 8 x 128^3 PPM+HLLD VL2:
-     // 5.73 ms per cycle against 5.24 with the copies on the sim's stream -- the thin slab launches next to
-     // every face and the copy kernel's share of the memory system (0.26 -> 0.60 ms) cost more than the
-     // overlap hides; off by default.
-    static const bool on = std::getenv("APK_COPY_STREAM") && std::atoi(std::getenv("APK_COPY_STREAM")) == 1;
-    if (on && s->mesh.ndim >= 2) {
-      hipStream_t cs = nullptr;
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess &&
-          hipEventCreateWithFlags(&e0, hipEventDisableTiming) == hipSuccess &&
-          hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess) {
-        s->copy_stream = cs, s->ev_stage_done = e0, s->ev_copies_done = e1;
-      } else {
-        s->err = "copy stream creation failed";
-        return bail(APK_ERR_DEVICE);
-      }
-    }
-  }
+  // (Same-rank ghost copies on a second stream, overlapped with the part of the next stage that needs no ghost zone, were
+  // measured in round 2 on 8 x 128^3 PPM+HLLD VL2: 5.73 ms per cycle against 5.24 -- the thin slab launches next to every
+  // face and the copy kernel's share of the memory system cost more than the overlap hid; direct neighbour addressing
+  // then removed the copies altogether.)
   if (s->mesh.rehearse && (rc = comm_loopback_attach(s)) != APK_OK) return bail(rc);
-  if ((s->copy_stream || !s->mesh.peers.empty()) && (rc = build_windows(s)) != APK_OK) return bail(rc);
+  if (!s->mesh.peers.empty() && (rc = build_windows(s)) != APK_OK) return bail(rc);
   if (s->mesh.ndim == 3 && (rc = build_face_table(s)) != APK_OK) return bail(rc);
   if (s->fmft && (rc = turbulence_device_setup(s)) != APK_OK) return bail(rc);
   return APK_OK;
@@ -1359,9 +1318,6 @@ void apk_sim_destroy(apk_sim *s) {
     (void)hipDeviceSynchronize();
     rccl_transport_destroy(s->rccl);
     s->rccl = nullptr;
-    if (s->ev_stage_done) (void)hipEventDestroy(static_cast<hipEvent_t>(s->ev_stage_done));
-    if (s->ev_copies_done) (void)hipEventDestroy(static_cast<hipEvent_t>(s->ev_copies_done));
-    if (s->copy_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(s->copy_stream));
     for (auto &pp : s->plans_of)
       for (auto &p : pp) apk_copy_plan_destroy(p);
     for (int p = 0; p < 3; ++p)

@@ -150,9 +150,6 @@ struct apk_sim {
   // (and the ConsToPrim fused into them) on a second HIP stream, ordered against the sim's stream by two
   // events, overlapping with the part of the next stage that needs no ghost zone -- like messages in
   // flight; every face of every block then counts as "late" in the window tables.
-  void *copy_stream = nullptr;                            // hipStream_t
-  void *ev_stage_done = nullptr, *ev_copies_done = nullptr;  // hipEvent_t
-  bool copies_in_flight = false;
   bool exchange_pending = false;
   // One-layer exchanges (mesh.hpp PH_PACK_THIN): the exchange at the end of a cycle whose first stage is the
   // donor-cell predictor.  thin_msgs: the message set apk_sim_peer reports is the one-layer one (transports read it at
@@ -235,7 +232,7 @@ struct apk_sim {
   // the tagging criteria and a donor-cell / PLM first stage read); accessors and regridding complete them first
   // (sync_ghosts)
   int amr_ghost_state = 0;  // AMR_GHOSTS_COMPLETE
-  bool amr_full_exchange = std::getenv("APK_AMR_FULL_EXCHANGE") != nullptr;  // apk_sim_set_amr_full_exchange
+  bool amr_full_exchange = false;  // apk_sim_set_amr_full_exchange
   const MsgSet *active_msgs = nullptr;  // the message set apk_sim_peer reports (null: the uniform mesh's)
   long long msg_generation = 0;         // bumped whenever that set, its sizes or its buffers change
   struct AmrDevice {

@@ -465,7 +465,6 @@ int amr_rebuild(apk_sim *s) {
       SIM_TRY(s, amr_make_copy_plan(s, par, p.fine_bc[d], nullptr, &a.fine_bc[par][d]));
     }
   }
-  static const bool fix_averages = std::getenv("APK_NO_FIX_AVERAGE") == nullptr;  // A/B switch
   for (int d = 0; d < s->mesh.ndim; ++d) {
     SIM_TRY(s, amr_make_refine_plans(s, 0, p.flux_restrict[d], a.flux_restrict[d]));
     SIM_TRY(s, amr_make_refine_plans(s, 0, p.flux_restrict_remote[d], a.flux_restrict_remote[d]));
@@ -473,7 +472,7 @@ int amr_rebuild(apk_sim *s) {
     SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_pack[d], &s->amr_fluxmsg, &a.flux_pack[d]));
     SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_unpack[d], &s->amr_fluxmsg, &a.flux_unpack[d]));
     for (int par = 0; par < 2; ++par) {
-      SIM_TRY(s, amr_make_fix_plan(s, par, d, p.flux_copy[d], nullptr, &a.flux_fix[par][d], fix_averages ? &p.flux_fused_ops[d] : nullptr));
+      SIM_TRY(s, amr_make_fix_plan(s, par, d, p.flux_copy[d], nullptr, &a.flux_fix[par][d], &p.flux_fused_ops[d]));
       SIM_TRY(s, amr_make_fix_plan(s, par, d, p.flux_unpack[d], &s->amr_fluxmsg, &a.flux_fix_unpack[par][d]));
     }
   }
@@ -650,14 +649,11 @@ int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi
   if (!amr_has_coarse_fine_faces(s)) return APK_OK;
   auto &a = s->amr_dev;
   const int psi_var = (s->pkg.fluid == APK_FLUID_GLMMHD) ? 8 : -1;
-  static const bool all_planes = std::getenv("APK_AMR_ALL_PLANES") != nullptr;  // A/B switch
-  if (all_planes) SIM_TRY(s, apk_calculate_fluxes_boundary(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, s->stream));
-  else SIM_TRY(s, apk_calculate_fluxes_boundary_list(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, a.d_cf_faces, a.n_cf_faces, s->stream));
-  static const bool fix_averages = std::getenv("APK_NO_FIX_AVERAGE") == nullptr;  // A/B switch (see amr_rebuild)
+  SIM_TRY(s, apk_calculate_fluxes_boundary_list(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, a.d_cf_faces, a.n_cf_faces, s->stream));
   for (int d = 0; d < s->mesh.ndim; ++d) {
     // (same-rank faces: the fix kernel averages the fine fluxes itself; only faces whose coarse side lives elsewhere
     // are restricted into the coarse buffer, for the message)
-    for (apk_refine_plan *p : (fix_averages ? a.flux_restrict_remote[d] : a.flux_restrict[d])) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
+    for (apk_refine_plan *p : a.flux_restrict_remote[d]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
     SIM_TRY(s, apk_flux_fix_plan_run(s->ctx, a.flux_fix[s->cur][d], beta_dt, psi_var, psi_factor, s->stream));
     SIM_TRY(s, apk_copy_plan_run(s->ctx, a.flux_pack[d], s->stream));
   }

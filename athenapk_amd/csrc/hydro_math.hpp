@@ -41,34 +41,19 @@ APK_DEV double sqr(double x) { return x * x; }
 // flat_load / flat_store -- which count on lgkmcnt as well as vmcnt (a flat access may turn out to be LDS), so every
 // s_waitcnt lgkmcnt(0) in front of a ring read also waits for the stores of the previous row to be acknowledged.
 // Every field lives in global memory: say so.
-#ifdef APK_NO_GLOBAL_CAST  // (A/B)
-template <class T> APK_DEV T *as_global(T *p) { return p; }
-#else
 template <class T>
 APK_DEV __attribute__((address_space(1))) T *as_global(T *p) {
   return (__attribute__((address_space(1))) T *)p;
 }
-#endif
 // Results of a stage kernel (new conserved state, new primitives, the x3 sweep's partial divergences): never read again by
-// the kernel that writes them.  APK_NT_STORES=1 marks those stores non-temporal (A/B: do they leave more of the L2 to the
-// rows neighbouring waves share?).
-#ifndef APK_NT_STORES
-#define APK_NT_STORES 0
-#endif
+// the kernel that writes them.  (Non-temporal stores were measured in round 4: no gain.)
 template <class P>
 APK_DEV void store_result(P p, double v) {
-#if APK_NT_STORES
-  __builtin_nontemporal_store(v, p);
-#else
   *p = v;
-#endif
 }
 // a wave-uniform value the vector ALU had to compute (there is no scalar fp64 unit), moved into a scalar register
 // pair: it stops occupying two VGPRs of every lane for as long as it lives
 APK_DEV double to_sgpr(double x) {
-#ifdef APK_NO_STAGE_CONSTS  // (A/B)
-  return x;
-#endif
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
 
@@ -82,7 +67,7 @@ APK_DEV double to_sgpr(double x) {
 // (results within 1-2 ulp) without the range scaling -- the arguments here are densities,
 // pressures and squared speeds, never denormal -- and hand out the by-products (1/sqrt(x) comes
 // for free with sqrt(x); several quotients share one reciprocal).
-#if defined(APK_FP_STRICT) || defined(APK_NO_FAST_SQRT)
+#ifdef APK_FP_STRICT
 #define APK_PLAIN_SQRT 1
 APK_DEV double fsqrt(double x) { return sqrt(x); }
 APK_DEV double fsqrt_pos(double x) { return sqrt(x); }
@@ -92,11 +77,7 @@ APK_DEV double frcp(double x) { return 1.0 / x; }
 // v_rsq_f64 / v_rcp_f64 deliver 24 good bits (measured on gfx950 over 1e-12 .. 1e12, tools/ubench/ubench_lat.hip:
 // max relative error 4.6e-8 / 5.2e-8; round 2 assumed 8-10 bits and spent one quadratically converging step
 // too many everywhere): 24 -> 48 -> 96 bits, i.e. TWO Newton steps for a reciprocal, one Goldschmidt step +
-// ONE residual correction for a root, one Newton step for 1/sqrt from the converged pair.  APK_NEWTON_EXTRA=1
-// restores the round-2 sequences (A/B).
-#ifndef APK_NEWTON_EXTRA
-#define APK_NEWTON_EXTRA 0
-#endif
+// ONE residual correction for a root, one Newton step for 1/sqrt from the converged pair.
 APK_DEV void fsqrt_rsqrt(double x, double &root, double &inv_root) {
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
@@ -105,17 +86,9 @@ APK_DEV void fsqrt_rsqrt(double x, double &root, double &inv_root) {
   h = fma(h, r, h);
   double d = fma(-g, g, x);
   g = fma(d, h, g);  // full
-  if constexpr (APK_NEWTON_EXTRA != 0) {
-    d = fma(-g, g, x);
-    g = fma(d, h, g);
-  }
   // 1/sqrt(x) from the converged root: Newton on rs -> rs (2 - g rs), rs = 2 h has 48 bits
   double rs = h + h;
   double e = fma(-g, rs, 1.0);
-  if constexpr (APK_NEWTON_EXTRA != 0) {
-    rs = fma(rs, e, rs);
-    e = fma(-g, rs, 1.0);
-  }
   root = g;
   inv_root = fma(rs, e, rs);
 }
@@ -127,10 +100,6 @@ APK_DEV double fsqrt(double x) {
   h = fma(h, r, h);
   double d = fma(-g, g, x);
   g = fma(d, h, g);
-  if constexpr (APK_NEWTON_EXTRA != 0) {
-    d = fma(-g, g, x);
-    g = fma(d, h, g);
-  }
   return (x == 0.0) ? 0.0 : g;  // rsq(0) = inf
 }
 // fsqrt without the `x == 0 ? 0 : ...` guard (a compare and two selects): for arguments that are positive whenever the
@@ -144,10 +113,6 @@ APK_DEV double fsqrt_pos(double x) {
   h = fma(h, r, h);
   double d = fma(-g, g, x);
   g = fma(d, h, g);
-  if constexpr (APK_NEWTON_EXTRA != 0) {
-    d = fma(-g, g, x);
-    g = fma(d, h, g);
-  }
   return g;
 }
 APK_DEV double fsqrt_nonneg(double x) { return fsqrt_pos(fmax(x, 1.0e-300)); }
@@ -156,10 +121,6 @@ APK_DEV double frcp(double x) {
   double e = fma(-x, y, 1.0);
   y = fma(y, e, y);  // 48 bits
   e = fma(-x, y, 1.0);
-  if constexpr (APK_NEWTON_EXTRA != 0) {
-    y = fma(y, e, y);
-    e = fma(-x, y, 1.0);
-  }
   return fma(y, e, y);
 }
 #endif
@@ -168,7 +129,7 @@ APK_DEV double frcp(double x) {
 // compiler's own -freciprocal-math quotient adds a residual correction (8 instructions, <= 1 ulp); WENO-Z has five
 // per pencil and variable.  NOT used where a comparison against an exact tie follows (PPM's limited ratio) or where
 // round-off is amplified (fast speeds next to HLLD's degenerate states, DESIGN.md "Floating point").
-#if defined(APK_PLAIN_SQRT) || defined(APK_NO_FDIV)
+#ifdef APK_PLAIN_SQRT
 APK_DEV double fdiv(double a, double b) { return a / b; }
 #else
 APK_DEV double fdiv(double a, double b) { return a * frcp(b); }
@@ -185,7 +146,7 @@ APK_DEV double max2(double a, double b) { return fmax(a, b); }
 // makes the compiler canonicalise each of them first (v_max_f64 x, x, x: IEEE mode must quiet a signalling NaN it cannot
 // rule out) -- five extra instructions in PPM's extremum limiter, whose scale is a maximum over the five stencil cells.
 // v_max_f64 itself quiets its operands in IEEE mode, so the product build issues the instruction directly.
-#if defined(APK_FP_STRICT) || defined(APK_NO_ASM_MINMAX)  // (A/B)
+#ifdef APK_FP_STRICT
 APK_DEV double max_abs2(double a, double b) { return max2(fabs(a), fabs(b)); }
 APK_DEV double max_with_abs(double a, double b) { return max2(a, fabs(b)); }
 APK_DEV double max_plain(double a, double b) { return max2(a, b); }
@@ -209,9 +170,7 @@ APK_DEV double max_plain(double a, double b) {
 // An opaque copy of x (no instruction): expressions built on it are not recognised as equal to expressions built on x,
 // which keeps the compiler from hoisting code that two rarely taken branches share in front of both of them.
 APK_DEV double opaque(double x) {
-#ifndef APK_NO_OPAQUE  // (A/B)
   asm("" : "+v"(x));
-#endif
   return x;
 }
 // Parthenon SIGN(x) = (x < 0) ? -1 : 1 ; carried as a bool "is negative"
@@ -219,13 +178,8 @@ APK_DEV bool neg(double x) { return x < 0.0; }
 // x > 0 with NaN -> false, decided on the bit pattern so that no fast-math assumption a build may
 // be given can fold the NaN case away: a blown-up state must still be flagged
 APK_DEV bool strictly_positive(double x) {
-#ifdef APK_NO_CLASS_TEST  // (A/B: two 64-bit integer compares)
-  const long long b = __double_as_longlong(x);
-  return b > 0 && b <= 0x7ff0000000000000LL;
-#else
   // one v_cmp_class_f64: +denormal | +normal | +infinity (bits 7, 8, 9 of the class mask)
   return __builtin_amdgcn_class(x, 0x380);
-#endif
 }
 APK_DEV double with_sign(bool negative, double mag) { return negative ? -mag : mag; }
 
@@ -333,19 +287,11 @@ APK_DEV void ppm_cell(double qm2, double qm1, double q0, double qp1, double qp2,
   const double dplus = face_p - q0;
   const double ext_a = dminus * dplus;
   const double ext_b = (qp1 - q0) * (q0 - qm1);
-#ifdef APK_PPM_NO_FLAT_SKIP  // (A/B)
+  // (Taking lanes whose stencil is flat -- both one-sided differences zero: the field of an unmagnetised run, the ambient
+  // medium of a blast, every variable along x3 of a thin-z run -- out of the extremum set, where the limiter runs at full
+  // width to no effect, was measured in round 5: the test costs the headline 3 - 4 % in either of two forms and buys
+  // configs 3 and 5 nothing measurable; those kernels are not bound by their instruction count.)
   const bool ext = ext_a <= 0.0 || ext_b <= 0.0;  // local extremum: CS limiter on the parabola
-#else
-  // A variable that does not change along the sweep direction -- the field components of an unmagnetised run and the
-  // ambient medium of a blast (config 5), every variable along x3 of a thin-z run (config 3), a velocity component at
-  // rest -- passes the reference's extremum test in EVERY lane ((q_i+1 - q_i)(q_i - q_i-1) = 0 <= 0) and would run the
-  // limiter at full width to no effect: with both one-sided differences zero the parabola's second difference
-  // 6 (f_m + f_p - 2 q) is zero, the roundoff guard leaves the ratio at 0 and the limited states are q -/+ 0 * 0 = q.
-  // The overshoot tests of the other branch give the same values there (|0| >= 2 |0|: q -/+ 2 * 0 = q), so such lanes
-  // are taken out of the extremum set: one v_max_f64 and one compare per call, and config 5's stage kernels execute a
-  // third fewer instructions.
-  const bool ext = (ext_a <= 0.0 || ext_b <= 0.0) && !(max_abs2(dminus, dplus) == 0.0);
-#endif
 
   double r = face_m, l = face_p;
   if (ext) {
@@ -356,165 +302,6 @@ APK_DEV void ppm_cell(double qm2, double qm1, double q0, double qp1, double qp2,
   }
   ql = l;
   qr = r;
-}
-
-// ---- PPM for TWO variables at once (APK_PPM_PAIRS) ----------------------------------------------------------------
-// The limiter branches of ppm_interface / ppm_cell are entered by the wave whenever SOME lane sits at an extremum of
-// the variable -- on smooth data about one lane per wave-row and variable, i.e. nearly always -- and then run as one
-// dependent chain of masked instructions per variable, nine times per direction.  Two variables share their branch
-// regions here: the region is entered when a lane needs either limiter, both limiter chains run inside it on those
-// lanes (independent chains the scheduler interleaves: the latency of one instead of two), and each lane keeps the
-// result of the variable it needed.  Same operations on the same operands per variable: bit-identical results.
-struct PpmFace {
-  double face, half_sum, below;
-  bool need;
-};
-APK_DEV PpmFace ppm_interface_open(double qm1, double q0, double qp1, double qp2) {
-  const double da = q0 - qm1;
-  const double db = qp1 - q0;
-  const double dd_c = 0.5 * db + 0.5 * da;
-  const double dd_p = 0.5 * (qp2 - qp1) + 0.5 * db;
-  PpmFace f;
-  f.half_sum = 0.5 * (q0 + qp1);
-  f.face = f.half_sum + APK_DIV6(dd_c - dd_p);
-  f.below = f.face - q0;
-  const double above = qp1 - f.face;
-  f.need = f.below * above < 0.0;
-  return f;
-}
-APK_DEV double ppm_interface_limited(double qm1, double q0, double qp1, double qp2, double face) {
-  constexpr double C2 = 1.25;
-  const double d2_c = qm1 + qp1 - 2.0 * q0;
-  const double d2_p = q0 + qp2 - 2.0 * qp1;
-  const double d2f = 3.0 * (q0 + qp1 - 2.0 * face);
-  const bool sg = neg(d2f);
-  const bool agree = (sg == neg(d2_c)) && (sg == neg(d2_p));
-  const double mag = min2(C2 * fabs(d2_c), min2(C2 * fabs(d2_p), fabs(d2f)));
-  const double lim = agree ? with_sign(sg, mag) : 0.0;
-  return 0.5 * (q0 + qp1) - APK_DIV6(lim);
-}
-APK_DEV void ppm_interface2(double am1, double a0, double ap1, double ap2, double bm1, double b0, double bp1, double bp2,
-                            double &face_a, double &face_b) {
-  const PpmFace fa = ppm_interface_open(am1, a0, ap1, ap2);
-  const PpmFace fb = ppm_interface_open(bm1, b0, bp1, bp2);
-  face_a = fa.face;
-  face_b = fb.face;
-  if (fa.need || fb.need) {
-    const double la = ppm_interface_limited(opaque(am1), a0, ap1, ap2, fa.face);
-    const double lb = ppm_interface_limited(opaque(bm1), b0, bp1, bp2, fb.face);
-    if (fa.need) face_a = la;
-    if (fb.need) face_b = lb;
-  }
-}
-// the extremum limiter of ppm_cell (steps 4 of ppm_simple.hpp:104-150): the limited states, or the interface values
-// where the limited ratio stays above 1 - 1e-12
-APK_DEV void ppm_cell_extremum(double qm2, double qm1, double q0, double qp1, double qp2, double face_m, double face_p,
-                               double dminus, double dplus, double &l, double &r) {
-  constexpr double C2 = 1.25;
-  const double q0x = opaque(q0), qp1x = opaque(qp1);
-  const double d2_m = qm2 + q0x - 2.0 * qm1;
-  const double d2_c = qm1 + qp1x - 2.0 * q0x;
-  const double d2_p = q0x + qp2 - 2.0 * qp1x;
-  const double d2_face = 6.0 * (face_m + face_p - 2.0 * q0x);
-  const bool s = neg(d2_m);
-  const bool agree = (s == neg(d2_c)) && (s == neg(d2_p)) && (s == neg(d2_face));
-  const double mag = min2(min2(C2 * fabs(d2_m), C2 * fabs(d2_c)), min2(C2 * fabs(d2_p), fabs(d2_face)));
-  const double d2lim = agree ? with_sign(neg(d2_face), mag) : 0.0;
-  const double scale_lo = max_abs2(qm1, qm2);
-  const double scale_hi = max_with_abs(max_abs2(q0, qp1), qp2);
-  double ratio = 0.0;
-  if (fabs(d2_face) > (1.0e-12) * max_plain(scale_lo, scale_hi)) ratio = d2lim / d2_face;
-  l = face_p;
-  r = face_m;
-  if (ratio <= (1.0 - (1.0e-12))) {
-    r = q0 - ratio * dminus;
-    l = q0 + ratio * dplus;
-  }
-}
-APK_DEV void ppm_cell2(const double (&a)[5], double fa_m, double fa_p, const double (&b)[5], double fb_m, double fb_p,
-                       double &ql_a, double &qr_a, double &ql_b, double &qr_b) {
-  // a[0..4] = qm2, qm1, q0, qp1, qp2
-  const double dma = a[2] - fa_m, dpa = fa_p - a[2];
-  const double dmb = b[2] - fb_m, dpb = fb_p - b[2];
-  const bool xa = (dma * dpa <= 0.0) || ((a[3] - a[2]) * (a[2] - a[1]) <= 0.0);
-  const bool xb = (dmb * dpb <= 0.0) || ((b[3] - b[2]) * (b[2] - b[1]) <= 0.0);
-  // the monotone case (every other lane)
-  double ra = fa_m, la = fa_p, rb = fb_m, lb = fb_p;
-  if (fabs(dma) >= 2.0 * fabs(dpa)) ra = a[2] - 2.0 * dpa;
-  if (fabs(dpa) >= 2.0 * fabs(dma)) la = a[2] + 2.0 * dma;
-  if (fabs(dmb) >= 2.0 * fabs(dpb)) rb = b[2] - 2.0 * dpb;
-  if (fabs(dpb) >= 2.0 * fabs(dmb)) lb = b[2] + 2.0 * dmb;
-  if (xa || xb) {
-    double lea, rea, leb, reb;
-    ppm_cell_extremum(a[0], a[1], a[2], a[3], a[4], fa_m, fa_p, dma, dpa, lea, rea);
-    ppm_cell_extremum(b[0], b[1], b[2], b[3], b[4], fb_m, fb_p, dmb, dpb, leb, reb);
-    if (xa) la = lea, ra = rea;
-    if (xb) lb = leb, rb = reb;
-  }
-  ql_a = la;
-  qr_a = ra;
-  ql_b = lb;
-  qr_b = rb;
-}
-
-// ---- PPM with the extremum limiter DEFERRED (APK_PPM_DEFER) ----------------------------------------------------------
-// Every VALU instruction costs a wave the same issue slot however few of its lanes are live, and on smooth data about
-// one lane per wave-row sits at an extremum of each variable: the 52-instruction limiter of ppm_cell runs nine times per
-// direction for nine lanes' worth of work.  Here a lane that needs the limiter for variable n parks that variable's
-// seven operands in a pending slot (15 selects) and goes on; after the ninth variable ONE masked pass limits every
-// pending item at once -- different lanes, different variables -- and each lane copies its result into the states of
-// the variable it was for.  A lane that already holds a pending item when another of its variables needs the limiter (an
-// extremum of two variables in one cell) runs that one on the spot, as before.  Same operations on the same operands
-// per item: bit-identical.
-struct PpmPending {
-  double qm2, qm1, q0, qp1, qp2, face_m, face_p;
-  int var;     // variable the item belongs to
-  bool full;   // the lane holds an item
-};
-APK_DEV void ppm_pending_clear(PpmPending &p) {
-  p.qm2 = p.qm1 = p.q0 = p.qp1 = p.qp2 = p.face_m = p.face_p = 0.0;
-  p.var = -1;
-  p.full = false;
-}
-APK_DEV void ppm_cell_defer(double qm2, double qm1, double q0, double qp1, double qp2, double face_m, double face_p, int var,
-                            PpmPending &pend, double &ql, double &qr) {
-  const double dminus = q0 - face_m;
-  const double dplus = face_p - q0;
-  const bool extremum = (dminus * dplus <= 0.0) || ((qp1 - q0) * (q0 - qm1) <= 0.0);
-  // the monotone case (what every other lane takes)
-  double r = face_m, l = face_p;
-  if (fabs(dminus) >= 2.0 * fabs(dplus)) r = q0 - 2.0 * dplus;
-  if (fabs(dplus) >= 2.0 * fabs(dminus)) l = q0 + 2.0 * dminus;
-  const bool take = extremum && !pend.full;
-  const bool collide = extremum && pend.full;
-  pend.qm2 = take ? qm2 : pend.qm2;
-  pend.qm1 = take ? qm1 : pend.qm1;
-  pend.q0 = take ? q0 : pend.q0;
-  pend.qp1 = take ? qp1 : pend.qp1;
-  pend.qp2 = take ? qp2 : pend.qp2;
-  pend.face_m = take ? face_m : pend.face_m;
-  pend.face_p = take ? face_p : pend.face_p;
-  pend.var = take ? var : pend.var;
-  pend.full = pend.full || take;
-  if (collide) {
-    asm volatile("" ::: );
-    double le, re;
-    ppm_cell_extremum(qm2, qm1, q0, qp1, qp2, face_m, face_p, dminus, dplus, le, re);
-    l = le;
-    r = re;
-  }
-  ql = l;
-  qr = r;
-}
-// the one masked pass over the pending items; (l, r) are valid in the lanes with pend.full
-APK_DEV void ppm_pending_limit(const PpmPending &pend, double &l, double &r) {
-  l = 0.0;
-  r = 0.0;
-  if (pend.full) {
-    asm volatile("" ::: );
-    ppm_cell_extremum(pend.qm2, pend.qm1, pend.q0, pend.qp1, pend.qp2, pend.face_m, pend.face_p, pend.q0 - pend.face_m,
-                      pend.face_p - pend.q0, l, r);
-  }
 }
 
 // src/recon/ppm_simple.hpp:39-162, one cell on its own (flux-array kernels, passive scalars)
@@ -534,7 +321,7 @@ APK_DEV void wenoz(double qm2, double qm1, double q0, double qp1, double qp2, do
   const double b2 = c0 * sqr(qp2 + q0 - 2.0 * qp1) + c1 * sqr(qp2 + 3.0 * q0 - 4.0 * qp1);
   constexpr double eps = 1.0e-42;
   const double tau5 = fabs(b0 - b2);
-#if defined(APK_PLAIN_SQRT) || defined(APK_NO_FDIV) || defined(APK_WENOZ_SEPARATE_QUOTIENTS)  // (A/B)
+#ifdef APK_PLAIN_SQRT
   const double i0 = fdiv(tau5, (b0 + eps));
   const double i1 = fdiv(tau5, (b1 + eps));
   const double i2 = fdiv(tau5, (b2 + eps));
@@ -675,11 +462,7 @@ APK_DEV double fast_speed(double gamma, double d, double p, double bx, double by
   // build along the planes where By and Bz change sign.)
   // (the inner argument is a sum of squares -- zero only where Bx^2 = gamma p and By = Bz = 0 exactly --, the outer
   // one a squared speed, positive whenever rho and p are: the product build drops fsqrt's zero guards, see fsqrt_pos)
-#ifdef APK_SQRT_GUARDS  // (A/B)
-  return fsqrt(0.5 * (qsq + fsqrt(tmp * tmp + 4.0 * asq * ct2)) / d);
-#else
   return fsqrt_pos(0.5 * (qsq + fsqrt_nonneg(tmp * tmp + 4.0 * asq * ct2)) / d);
-#endif
 }
 
 // ======================================================================================
@@ -985,7 +768,7 @@ APK_DEV void hlld_star_transverse(const double (&w)[NGLMMHD], const Cons1D &u, d
   const double t2 = (u.d * sqr(sd) - bxsq) * inv;
 #endif
   const bool degenerate = fabs(denom) < (kHlldSmall)*ptst;
-#if defined(APK_FP_STRICT) || defined(APK_HLLD_SELECT_OUTPUTS)  // (A/B)
+#ifdef APK_FP_STRICT
   ust.my = degenerate ? ust.d * w[IV2] : ust.d * (w[IV2] - u.by * t1);
   ust.mz = degenerate ? ust.d * w[IV3] : ust.d * (w[IV3] - u.bz * t1);
   ust.by = degenerate ? u.by : u.by * t2;
@@ -1050,13 +833,9 @@ APK_DEV void glmmhd_hlld_cf(const double (&wl)[NGLMMHD], const double (&wr)[NGLM
 // the same with the stage's constants from the host (StageConsts)
 APK_DEV void glmmhd_hlld_cf(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD], const StageConsts &k,
                             double cfl, double cfr, double (&f)[NGLMMHD]) {
-#ifdef APK_NO_STAGE_CONSTS
-  glmmhd_hlld_cf(wl, wr, k.gamma, k.c_h, cfl, cfr, f);
-#else
   double bxi, psii;
   glm_interface(wl, wr, k, bxi, psii);
   glmmhd_hlld_core(wl, wr, k.igm1, bxi, psii, k.ch_sq, cfl, cfr, f);
-#endif
 }
 APK_DEV void glmmhd_hlld(const double (&wl)[NGLMMHD], const double (&wr)[NGLMMHD], const StageConsts &k,
                          double (&f)[NGLMMHD]) {
@@ -1210,17 +989,6 @@ APK_DEV void glmmhd_hlld_core(const double (&wl)[NGLMMHD], const double (&wr)[NG
 
   hlld_jump(udst, ust, s_inner);  // double-star before star: the star state is overwritten next
   hlld_jump(ust, u, s_outer);
-#ifdef APK_HLLD_SELECT_SUMS  // (A/B: round 3's form, two selects per component on the three candidate sums)
-#define APK_HLLD_SUM(c) (outer ? fx.c : (with_dstar ? (fx.c + ust.c + udst.c) : (fx.c + ust.c)))
-  f[IDN] = APK_HLLD_SUM(d);
-  f[IV1] = APK_HLLD_SUM(mx);
-  f[IV2] = APK_HLLD_SUM(my);
-  f[IV3] = APK_HLLD_SUM(mz);
-  f[IEN] = APK_HLLD_SUM(e);
-  f[IB2] = APK_HLLD_SUM(by);
-  f[IB3] = APK_HLLD_SUM(bz);
-#undef APK_HLLD_SUM
-#else
   // F, F + j_outer or (F + j_outer) + j_inner: the additions run under the lanes' execution mask instead of selecting
   // among three sums afterwards -- 14 masked v_add_f64 and a few scalar instructions instead of 14 additions + 28
   // v_cndmask_b32.  (The empty volatile asm statements keep the compiler from turning the branches back into
@@ -1253,7 +1021,6 @@ APK_DEV void glmmhd_hlld_core(const double (&wl)[NGLMMHD], const double (&wr)[NG
   f[IEN] = fl.e;
   f[IB2] = fl.by;
   f[IB3] = fl.bz;
-#endif
 }
 
 // src/hydro/rsolvers/glmmhd_dc_llf.hpp:46-179
@@ -1323,12 +1090,8 @@ APK_DEV void riemann(const double (&wl)[nvars<FLUID>()], const double (&wr)[nvar
 template <int FLUID, int RS>
 APK_DEV void riemann(const double (&wl)[nvars<FLUID>()], const double (&wr)[nvars<FLUID>()], const StageConsts &k,
                      double (&f)[nvars<FLUID>()]) {
-#ifdef APK_NO_STAGE_CONSTS  // (A/B: the constants derived in the kernel, as in round 2)
-  riemann<FLUID, RS>(wl, wr, k.gamma, k.c_h, f);
-#else
   if constexpr (FLUID == APK_FLUID_GLMMHD && RS == APK_RS_HLLD) glmmhd_hlld(wl, wr, k, f);
   else riemann<FLUID, RS>(wl, wr, k.gamma, k.c_h, f);
-#endif
 }
 
 // Direction permutation (e.g. glmmhd_hlld.hpp:45-49): natural index of the permuted slot.
@@ -1369,11 +1132,7 @@ APK_DEV unsigned cons_to_prim_cell(const apk_eos &eos, double (&u)[nvars<FLUID>(
 template <int FLUID, bool LEAN = false>
 APK_DEV unsigned cons_to_prim_cell(const apk_eos &eos, const StageConsts &k, double (&u)[nvars<FLUID>()],
                                    double (&w)[nvars<FLUID>()], double &di_out) {
-#ifdef APK_NO_STAGE_CONSTS
-  return cons_to_prim_cell<FLUID>(eos, u, w, di_out);
-#else
   return cons_to_prim_core<FLUID, LEAN>(eos, k.eos_gm1, k.vceil_sq, k.pfloor_over_gm1, u, w, di_out);
-#endif
 }
 template <int FLUID, bool LEAN>
 APK_DEV unsigned cons_to_prim_core(const apk_eos &eos, double gm1, double vceil_sq, double pfloor_over_gm1,
@@ -1458,7 +1217,7 @@ APK_DEV unsigned cons_to_prim_core(const apk_eos &eos, double gm1, double vceil_
 template <int FLUID>
 APK_DEV double cell_dt_hyp(double gamma, const double (&w)[nvars<FLUID>()], double di, int ndim, double dx0, double dx1,
                            double dx2) {
-#if defined(APK_FP_STRICT) || defined(APK_NO_FAST_DT)  // (A/B)
+#ifdef APK_FP_STRICT
   double lx, ly = 0.0, lz = 0.0;
   if constexpr (FLUID == APK_FLUID_EULER) {
     lx = sound_speed(gamma, w[IDN], w[IPR]);

@@ -479,8 +479,7 @@ int apk_tag_blocks_begin(apk_ctx *ctx, const apk_pack *md, int criterion, int *p
   }
   auto *d_max = reinterpret_cast<unsigned long long *>(ctx->d_partial);
   APK_HIP_TRY(ctx, hipMemsetAsync(d_max, 0, sizeof(unsigned long long) * nb, s));
-  static const int forced = std::getenv("APK_TAG_KCHUNKS") ? std::atoi(std::getenv("APK_TAG_KCHUNKS")) : 0;  // A/B switch
-  const int kchunks = forced > 0 ? forced : ((pv.nx3 >= 12 && nb < 4096) ? 3 : 1);
+  const int kchunks = (pv.nx3 >= 12 && nb < 4096) ? 3 : 1;
   const dim3 grid = rect_grid(pv.nx1 + 2, pv.nx2 + 2, nb * kchunks), block(64, 4, 1);
   if (criterion == APK_TAG_PRESSURE_GRADIENT)
     hipLaunchKernelGGL(tag_kernel<APK_TAG_PRESSURE_GRADIENT>, grid, block, 0, s, pv, d_max, kchunks);

@@ -719,10 +719,7 @@ int launch_copy_regions(const apk_copy_plan &plan, hipStream_t s, int c2p_fluid,
 #undef APK_LAUNCH_COPY_C2P
     }
   } else {
-    static const bool per_item = std::getenv("APK_COPY_PER_ITEM") != nullptr;  // A/B switch
-    if (per_item && plan.nchunks_items > 0)
-      hipLaunchKernelGGL(copy_regions_kernel, dim3(plan.nchunks_items), dim3(256), 0, s, plan.d_regions, plan.d_chunks_items);
-    else if (!per_item && plan.nchunks_cells > 0)
+    if (plan.nchunks_cells > 0)
       hipLaunchKernelGGL(copy_regions_cells_kernel, dim3(plan.nchunks_cells), dim3(256), 0, s, plan.d_regions, plan.d_chunks_cells);
   }
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;

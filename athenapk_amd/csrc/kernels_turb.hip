@@ -450,8 +450,7 @@ int apk_fmft_inverse(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, const double
   APK_HIP_TRY(ctx, hipMemcpyAsync(f->d_var_hat, var_hat_host, sizeof(double) * 3 * f->num_modes * 2,
                                   hipMemcpyHostToDevice, s));
 #ifndef APK_FP_STRICT
-  static const bool plain = std::getenv("APK_FMFT_PLAIN") != nullptr;  // A/B switch
-  if (!plain && f->num_modes <= kMaxRowModes) {
+  if (f->num_modes <= kMaxRowModes) {
     const PackView &pv = md->view;
     hipLaunchKernelGGL(fmft_inverse_rows_kernel, dim3((pv.nx2 + 3) / 4, pv.nx3 * pv.nblocks, 1), dim3(64, 4, 1), 0, s, pv,
                        f->d_blocks, f->d_var_hat, f->num_modes);

@@ -1185,6 +1185,9 @@ def test_two_kernel_stage_takes_its_input_from_the_conserved_state(request, orac
     import ctypes as C
     import torch
     from athenapk_amd import hydro
+    if kind == "rough" and not strict:
+        pytest.skip("uniform random states reconstruct negative pressures here and there: NaNs, which only the parity build "
+                    "is asked to reproduce place for place (as in the registry tests on rough data)")
     ctx = _ctx(request, strict)
     # (hydro PLM takes the single-march form of these stages -- fused3_kernel.hpp -- which wants an even number of x2 rows)
     nx = (36, 10, 9) if fluid == "euler" else (36, 9, 10)
@@ -1233,8 +1236,10 @@ def test_two_kernel_stage_takes_its_input_from_the_conserved_state(request, orac
     ctx.lib.apk_kernel_timing_enable(ctx.h, 0)
     # the form that ran: one march for hydro PLM, the x3 sweep + the finishing march for the others
     assert (n1, n3) == ((1, 0) if (fluid, recon) == ("euler", "plm") else (1, 1))
-    assert ctx.poll_flags() == 0
-    want = H.orc_stage(fluid, recon, riemann, g, state if own_input else np.zeros_like(state), state * 1.01 if own_input else state,
+    rough = kind == "rough"                                            # (NaN cells raise the flags, rightly)
+    assert rough or ctx.poll_flags() == 0
+    # (gam0 = 0 in the u1-input forms: the oracle's u0 only lends its ghost zones to the ConsToPrim of the whole block below)
+    want = H.orc_stage(fluid, recon, riemann, g, state, state * 1.01 if own_input else state,
                        prim_of_state, GAMMA, C_H, gam0, 1.0 - gam0, bdt, dedner=ded, alpha=0.1, mindx=0.07)
     got = (m2 if own_input else m0).cons_host()
     _cmp(H.interior(got, nx, ng), H.interior(want, nx, ng), strict, "updated conserved state")
@@ -1243,8 +1248,9 @@ def test_two_kernel_stage_takes_its_input_from_the_conserved_state(request, orac
         ghosts = np.ones(got.shape, dtype=bool)
         H.interior(ghosts, nx, ng)[...] = False
         assert np.all(got[ghosts] == -7.0), "interior cells only"
+    ctx.poll_flags()
     assert np.all(np.isnan(m0.prim_host())) and np.all(m1.prim_host() == -7.0), "no primitives are stored in these forms"
-    if dt_only:
+    if dt_only and not rough:
         _, want_prim, bad = H.orc_c2p(fluid, g, want.copy(), oracle.make_eos(GAMMA))
         want_dt = 0.3 * H.orc_min_dt(fluid, g, want_prim, GAMMA)
         assert bad == 0 and (dt == want_dt if strict else dt == pytest.approx(want_dt, rel=1e-12))
