@@ -315,6 +315,18 @@ int apk_stage_split_axis(const apk_pack *u0, const apk_flux_cfg *cfg, int fill_d
   return apk::two_kernel_stage_applies(u0->view, cfg->recon, extra, sp) ? 3 : 1;
 }
 
+int apk_stage_single_march(const apk_pack *u0, const apk_flux_cfg *cfg) {
+  if (!u0 || !cfg) return 0;
+  apk::StageParams sp{};  // a whole-block lean stage whose input is a conserved state
+  sp.prim_from_cons = 1;
+  sp.eos.vceil = sp.eos.eceil = __builtin_inf();
+  sp.eos.pfloor = sp.eos.dfloor = sp.eos.efloor = -1.0;
+  if (!apk::two_kernel_stage_applies(u0->view, cfg->recon, apk::EXTRA_NONE, sp)) return 0;
+  if (cfg->fluid == APK_FLUID_EULER && cfg->recon == APK_RC_PLM)
+    return apk::single_march_stage_applies<APK_FLUID_EULER, APK_RC_PLM>(u0->view, apk::EXTRA_NONE, sp) ? 1 : 0;
+  return 0;
+}
+
 int apk_cons_to_prim(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos,
                      apk_stream_t stream) {
   if (!ctx || !md || !valid_eos(eos) || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||

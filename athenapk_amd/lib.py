@@ -194,6 +194,7 @@ def _signatures():
         "apk_poll_device_flags": (i, [vp, C.POINTER(C.c_uint), vp]),
         "apk_trial_flags": (i, [vp, i, vp]),
         "apk_stage_split_axis": (i, [vp, vp, i]),
+        "apk_stage_single_march": (i, [vp, vp]),
         "apk_stage_unphysical_read": (i, [vp, C.POINTER(C.c_longlong), vp]),
         "apk_copy_plan_create": (i, [vp, C.POINTER(CopyRegion), i, pp]),
         "apk_copy_plan_destroy": (None, [vp]),

@@ -270,6 +270,11 @@ int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
  * synchronises the stream */
 int apk_stage_unphysical_read(apk_ctx *ctx, long long *count, apk_stream_t stream);
 int apk_stage_split_axis(const apk_pack *u0, const apk_flux_cfg *cfg, int fill_derived);
+/* 1 if a whole-block stage of this scheme in its lean form with prim_from_cons != 0 runs as ONE march (hydro with PLM:
+ * x1 by wave shifts, two x2 rows per lane, x3 carried along the march -- no flux-difference array; the three tasks
+ * hydro.cpp:1025-1208 + hydro_driver.cpp:534-544 in a single pass over the conserved state), 0 if it takes the two-kernel
+ * form.  A split stage (phase != 0) always takes the two kernels: a caller that can choose leaves such a stage whole. */
+int apk_stage_single_march(const apk_pack *u0, const apk_flux_cfg *cfg);
 
 /* Replaces EquationOfState::ConservedToPrimitive(MeshData<Real>*) over the ENTIRE block
  * src/eos/adiabatic_hydro.cpp:33-55, adiabatic_glmmhd.cpp:33-56 (pkg->FillDerivedMesh,
