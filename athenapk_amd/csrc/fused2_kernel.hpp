@@ -150,9 +150,10 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     }
     const int b = item / wpb;
     const int chunk = item - b * wpb;
-    const apk_block_desc b0 = u0.blocks[b];
-    const double *c1 = u1.blocks[b].cons;
-    double *prim_dst = (EXTRA != EXTRA_NONE && !sp.no_prim_store) ? u1.blocks[b].prim : nullptr;
+    apk_block_desc b0 = u0.blocks[b];
+    b0.cons = uniform_ptr(b0.cons);
+    const double *c1 = uniform_ptr(u1.blocks[b].cons);
+    double *prim_dst = (EXTRA != EXTRA_NONE && !sp.no_prim_store) ? uniform_ptr(u1.blocks[b].prim) : nullptr;
     // (the x3 sweep's flux differences: in the cells' layout, or compact -- StageParams.du_pitch)
     const int64_t d3_sn = sp.du_pitch > 0 ? (int64_t)sp.du_pitch * u0.nx2 * u0.nx3 : u0.sn;
     const double *d3 = sp.du + (int64_t)b * d3_sn * u0.nvar;
@@ -169,6 +170,11 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     // (row c - 1 of this column in d3: d3base + (c - 1) * d3st, like `done` in the cells' layout)
     const int64_t d3st = sp.du_pitch > 0 ? (int64_t)sp.du_pitch : st;
     const int64_t d3base = sp.du_pitch > 0 ? ((int64_t)krow * u0.nx2 - u0.js) * sp.du_pitch + d3col : base;
+    // (lean forms, RowCellAt: the lane's byte offset in a row of the cell arrays / of d3; the rows are wave-uniform.  d3's
+    // compact layout counts rows from js, which goes into the row part so that the lane's share stays non-negative)
+    const unsigned cell_boff = (unsigned)(base * (int64_t)sizeof(double));
+    const unsigned d3_boff = (unsigned)((sp.du_pitch > 0 ? (int64_t)krow * u0.nx2 * sp.du_pitch + d3col : base) * (int64_t)sizeof(double));
+    const int64_t d3row0 = sp.du_pitch > 0 ? -(int64_t)u0.js * sp.du_pitch : (int64_t)0;
     // Lanes that retire no cell (overlap lanes at the ends of the wave, ghost columns: 13 % of the lanes on 128^3 blocks)
     // sit out the x2 Riemann solve -- they only have to carry their column through the ring as the x1 stencil of their
     // neighbours.  The stage runs at 94 % of the socket's 1400 W, so every lane-operation not executed counts.  (Masking
@@ -321,8 +327,8 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
 #pragma unroll
             for (int n = 0; n < NV; ++n) u1v[n] = rawv[RAW ? n : 0];
           } else {
-#pragma unroll
-            for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
+            if constexpr (LEAN) load_vars<NV>(c1, u0.sn, RowCellAt{(int64_t)(c - 1) * st, cell_boff}, u1v);
+            else load_vars<NV>(c1, u0.sn, CellAt{done}, u1v);
           }
         }
       }
@@ -391,22 +397,27 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
         if (retire) {
           if constexpr (LOADS == 3) {
             asm volatile("" ::: "memory");
+            if (active) {
+              if constexpr (LEAN) load_vars<NV>(d3, d3_sn, RowCellAt{d3row0 + (int64_t)(c - 1) * d3st, d3_boff}, d3v);
+              else load_vars<NV>(d3, d3_sn, CellAt{d3done}, d3v);
+            } else {
 #pragma unroll
-            for (int n = 0; n < NV; ++n) d3v[n] = active ? d3[n * d3_sn + d3done] : 0.0;
+              for (int n = 0; n < NV; ++n) d3v[n] = 0.0;
+            }
           }
           if constexpr (LOADS == 2) {
             asm volatile("" ::: "memory");
             // (Timing experiment: without these 18 loads a general stage takes 2.65 instead of 2.91 ms
             // -- their exposed latency is the price of not holding 36 VGPRs through the x2 solve.)
             if (active) {  // (ghost-column and overlap lanes retire nothing: 13 % of the lanes)
-#pragma unroll
-              for (int n = 0; n < NV; ++n) d3v[n] = as_global(d3)[n * d3_sn + d3done];
+              if constexpr (LEAN) load_vars<NV>(d3, d3_sn, RowCellAt{d3row0 + (int64_t)(c - 1) * d3st, d3_boff}, d3v);
+              else load_vars<NV>(d3, d3_sn, CellAt{d3done}, d3v);
               if (RAW && sp.prim_from_cons == 1) {  // (wave-uniform: the input state IS u1)
 #pragma unroll
                 for (int n = 0; n < NV; ++n) u1v[n] = rawv[RAW ? n : 0];
               } else {
-#pragma unroll
-                for (int n = 0; n < NV; ++n) u1v[n] = as_global(c1)[n * u0.sn + done];
+                if constexpr (LEAN) load_vars<NV>(c1, u0.sn, RowCellAt{(int64_t)(c - 1) * st, cell_boff}, u1v);
+                else load_vars<NV>(c1, u0.sn, CellAt{done}, u1v);
               }
             } else {
 #pragma unroll
@@ -433,10 +444,15 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
                 m[st] = f[0];
               }
             }
-            if constexpr (RAW) {
-              // (prim_from_cons = 2: the input state is the old u0 the update reads)
-              if (sp.prim_from_cons == 2) finish_cell_old_held<FLUID, EXTRA, LEAN>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd, rawv);
-              else finish_cell<FLUID, EXTRA, LEAN>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd);
+            if constexpr (LEAN) {
+              const RowCellAt at{(int64_t)(c - 1) * st, cell_boff};
+              if constexpr (RAW) {
+                // (prim_from_cons = 2: the input state is the old u0 the update reads)
+                if (sp.prim_from_cons == 2) finish_cell_old_held<FLUID, EXTRA, LEAN>(u0, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd, rawv);
+                else finish_cell_at<FLUID, EXTRA, LEAN>(u0, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd);
+              } else {
+                finish_cell_at<FLUID, EXTRA, LEAN>(u0, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd);
+              }
             } else {
               finish_cell<FLUID, EXTRA, LEAN>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd);
             }
@@ -471,10 +487,15 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
 //    72 more VGPRs live across the back edge than 256 hold next to an HLLD solve -- 580 B of scratch per lane, 8.4 ms;
 //  * scalar-base addressing of d3 / u1 / u0 / prim' (one SGPR base per array advanced by the scalar unit + ONE 32-bit
 //    per-lane byte offset: global_load_dwordx2 v, v_off, s[base:base+1] instead of a 64-bit VALU add per access): the
-//    compiler emits exactly that, but the extra SGPR pairs push the scalar spills from 87 to 124 and the vector spills
-//    from 6 to 36 registers -- 3.50 ms;
+//    compiler emitted exactly that, but hoisted array + n * sn out of the march as loop-invariant register pairs, which
+//    pushed the scalar spills from 87 to 124 and the vector spills from 6 to 36 registers -- 3.50 ms.  (Round 5: IN, as
+//    RowCellAt in fused_kernel.hpp -- the scalar pointer is re-materialised after every step, so nothing is hoisted:
+//    scalar spills 96 -> 75 static / 58 -> 26 v_readlane per iteration, 56 -> 10 address adds per iteration, 240 -> 230
+//    VGPRs; corrector's march 1.98 -> 1.93 ms, x3 sweep 0.688 -> 0.678 ms, headline cycle +1.9 - 2.5 % on one box);
 //  * the x1 stencil from the ring row at lane offsets -2 .. +2 (5 ds_read_b64 instead of 1 + 8 DPP moves per variable,
-//    -72 VALU instructions per iteration): 3.40 ms, no change -- the kernel is not short of VALU issue slots alone;
+//    -72 VALU instructions per iteration): 3.40 ms, no change -- the kernel is not short of VALU issue slots alone
+//    (measured again in round 5 as ds_read2_b64 pairs on top of the row addressing: 3.701 against 3.68 ms per cycle with
+//    the wave shifts -- still nothing, removed again);
 //  * PPM's extremum branches switched off altogether (wrong results; the ceiling of any scheme that makes them
 //    cheaper): 2.97 ms, -12 %.  COMPACTING the cells that take them -- the lanes park the seven operands of
 //    ppm_cell's extremum limiter in 2 KB of LDS beside the ring, item after item across the nine variables, the first
@@ -522,7 +543,9 @@ inline bool two_kernel_stage_applies(const PackView &u0, int recon, int extra, c
   // (blocks narrower than 32 cells only if they are deep enough along x3 for the plane windows of a split stage --
   // 4 nghost planes: the driver's overlap rule -- so that taking this form never costs an overlapped exchange)
   const bool wide_enough = u0.nx1 >= 32 || (u0.nx1 >= min_nx1 && u0.nx3 >= 4 * u0.ng);
-  return u0.ndim == 3 && recon != APK_RC_DC && wide_enough && (extra == EXTRA_NONE || sp.prim_to_u1);
+  // (the marches address a block's cells as scalar row pointer + 32-bit byte offset of the lane: RowCellAt)
+  const bool offsets_fit = (uint64_t)u0.sn * sizeof(double) < (1ull << 32);
+  return u0.ndim == 3 && recon != APK_RC_DC && wide_enough && offsets_fit && (extra == EXTRA_NONE || sp.prim_to_u1);
 }
 
 template <int FLUID, int RECON, int RS>

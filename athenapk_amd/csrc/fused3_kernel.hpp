@@ -214,7 +214,7 @@ fused_s3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, int
 #pragma unroll
               for (int n = 0; n < NV; ++n) u1v[n] = as_global(c1)[n * u0.sn + done];
               // (the input state is the old u0 the update reads)
-              finish_cell_old_held<FLUID, EXTRA, true>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd, held);
+              finish_cell_old_held<FLUID, EXTRA, true>(u0, b0, u1v, CellAt{done}, du, vol, sp, lane_min_dt, prim_dst, upd, held);
             }
           }
         }

@@ -19,6 +19,7 @@
 #pragma once
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "apk_internal.hpp"
 #include "hydro_math.hpp"
@@ -107,6 +108,79 @@ APK_DEV double wave_shl1(double x) {  // lane l receives lane l+1 (lane 63: 0.0)
   return __hiloint2double(hi, lo);
 }
 
+// ---- where a kernel finds a cell in a block's arrays ------------------------------------------
+// CellAt: a per-lane element index -- every access is a 64-bit vector add of n * sn + cell on the array's pointer.
+// RowCellAt (the marches of the two-kernel stage): the rows a wave works on are wave-uniform, so the address splits into
+// a scalar part (array + row + n * sn, advanced by the scalar unit: s_add_u32 / s_addc_u32, no vector-ALU issue slot and
+// ONE scalar register pair per array instead of one per (array, variable)) and the lane's 32-bit byte offset inside the
+// row, which never changes along a march: `global_load_dwordx2 v, v_off, s[base:base+1]`.  Two things keep the compiler
+// on that form: the scalar pointer is re-materialised after every step (next_uniform: an empty asm with an SGPR
+// constraint -- otherwise array + n * sn is hoisted out of the march as nine loop-invariant register pairs per array, which
+// is what filled the scalar register file and spilled ~100 of them to vector lanes), and the lane offset is "fresh" in the
+// basic block that uses it (the zero extension has to be visible to instruction selection there).  Needs a block's
+// variable stride to fit 32 bits in bytes (two_kernel_stage_applies checks).
+struct CellAt {
+  int64_t cell;
+};
+struct RowCellAt {
+  int64_t row;    // element offset of the row's first cell (wave-uniform)
+  unsigned boff;  // byte offset of the lane's cell in the row
+};
+APK_DEV int64_t next_uniform(int64_t x) {
+  // (readfirstlane: folded away where the compiler knows the value to be wave-uniform -- everywhere but in a few forms
+  // where its divergence analysis gives up on a value that is uniform by construction)
+  const int lo = __builtin_amdgcn_readfirstlane((int)(x & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(x >> 32));
+  x = ((int64_t)hi << 32) | (int64_t)(unsigned)lo;
+  asm volatile("" : "+s"(x));
+  return x;
+}
+template <class T>
+APK_DEV T *next_uniform(T *p) {
+  return reinterpret_cast<T *>(next_uniform(reinterpret_cast<int64_t>(p)));
+}
+// a pointer out of a block descriptor: the descriptors are read with vector loads where the kernel has stored before
+// (no scalar load of memory that may have been clobbered), which leaves wave-uniform pointers in vector registers
+template <class T>
+APK_DEV T *uniform_ptr(T *p) {
+  const int64_t x = reinterpret_cast<int64_t>(p);
+  const int lo = __builtin_amdgcn_readfirstlane((int)(x & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(x >> 32));
+  return reinterpret_cast<T *>(((int64_t)hi << 32) | (int64_t)(unsigned)lo);
+}
+APK_DEV unsigned fresh_offset(unsigned x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+template <int NV>
+APK_DEV void load_vars(const double *arr, int64_t sn, const CellAt &a, double (&v)[NV]) {
+#pragma unroll
+  for (int n = 0; n < NV; ++n) v[n] = as_global(arr)[n * sn + a.cell];
+}
+template <int NV>
+APK_DEV void load_vars(const double *arr, int64_t sn, const RowCellAt &a, double (&v)[NV]) {
+  const double *p = next_uniform(arr + a.row);
+  const unsigned boff = fresh_offset(a.boff);
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    v[n] = *(const __attribute__((address_space(1))) double *)((const __attribute__((address_space(1))) char *)p + boff);
+    if (n + 1 < NV) p = next_uniform(p + sn);
+  }
+}
+template <int NV>
+APK_DEV void store_vars(double *arr, int64_t sn, const CellAt &a, const double (&v)[NV]) {
+#pragma unroll
+  for (int n = 0; n < NV; ++n) store_result(&as_global(arr)[n * sn + a.cell], v[n]);
+}
+template <int NV>
+APK_DEV void store_vars(double *arr, int64_t sn, const RowCellAt &a, const double (&v)[NV]) {
+  double *p = next_uniform(arr + a.row);
+  const unsigned boff = fresh_offset(a.boff);
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    store_result((__attribute__((address_space(1))) double *)((__attribute__((address_space(1))) char *)p + boff), v[n]);
+    if (n + 1 < NV) p = next_uniform(p + sn);
+  }
+}
+
 // ---- end-of-stage update of one cell (FINAL sweep) -------------------------------------------
 // UpdateWithFluxDivergence (hydro_driver.cpp:534-537) then DednerSource
 // (dedner_source.cpp:42-74), in that order, exactly as the task list runs them.
@@ -124,13 +198,18 @@ inline bool stage_is_lean(const StageParams &sp) {
 APK_DEV double update_coefficient(const StageParams &sp, double vol) { return to_sgpr(-sp.beta_dt / vol); }
 
 // (HELD: old_held is the old u0 of this cell, already in registers -- the from-cons finishing march keeps the rows it loaded)
-template <int FLUID, int EXTRA, bool LEAN, bool HELD>
+template <int FLUID, int EXTRA, bool LEAN, bool HELD, class AT>
 APK_DEV void finish_cell_impl(const PackView &pv, const apk_block_desc &b0,
-                              const double (&u1v)[nvars<FLUID>()], int64_t cell,
+                              const double (&u1v)[nvars<FLUID>()], const AT &at,
                               const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp,
                               double &lane_min_dt, double *prim_dst, double upd, bool store_cons,
                               const double (&old_held)[nvars<FLUID>()]) {
   constexpr int NV = nvars<FLUID>();
+  // (the general form's per-variable accesses, the extended Dedner source: a per-lane cell index; lean forms only reach
+  // here with a RowCellAt)
+  [[maybe_unused]] int64_t cell = 0;
+  if constexpr (std::is_same<AT, CellAt>::value) cell = at.cell;
+  else static_assert(LEAN, "row addressing: lean forms only");
   double un[NV];
   if constexpr (LEAN) {
 #ifdef APK_FP_STRICT
@@ -144,8 +223,7 @@ APK_DEV void finish_cell_impl(const PackView &pv, const apk_block_desc &b0,
 #pragma unroll
         for (int n = 0; n < NV; ++n) old[n] = old_held[n];
       } else {
-#pragma unroll
-        for (int n = 0; n < NV; ++n) old[n] = as_global(b0.cons)[n * pv.sn + cell];
+        load_vars<NV>(b0.cons, pv.sn, at, old);
       }
 #pragma unroll
       for (int n = 0; n < NV; ++n) un[n] = sp.gam0 * old[n] + sp.gam1 * u1v[n] + APK_UPD_TERM(n);
@@ -209,18 +287,14 @@ APK_DEV void finish_cell_impl(const PackView &pv, const apk_block_desc &b0,
       if (sp.bad_count && fl) bad = true;
     }
     if (prim_dst) {  // (wave-uniform; NULL: fill_derived = 3, the primitives only feed the time-step estimate)
-#pragma unroll
-      for (int n = 0; n < NV; ++n) store_result(&as_global(prim_dst)[n * pv.sn + cell], w[n]);
+      store_vars<NV>(prim_dst, pv.sn, at, w);
     }
     if constexpr (EXTRA == EXTRA_C2P_DT) {
       // EstimateHyperbolicTimestep (hydro.cpp:845-895) on the fresh primitives
       lane_min_dt = fmin(lane_min_dt, cell_dt_hyp<FLUID>(sp.eos.gamma, w, di, pv.ndim, b0.dx[0], b0.dx[1], b0.dx[2]));
     }
   }
-  if (store_cons) {
-#pragma unroll
-    for (int n = 0; n < NV; ++n) store_result(&as_global(b0.cons)[n * pv.sn + cell + sp.out_delta], un[n]);
-  }
+  if (store_cons) store_vars<NV>(b0.cons + sp.out_delta, pv.sn, at, un);
   if constexpr (!LEAN) {
     if (bad) atomicAdd(sp.bad_count, 1ull);
   }
@@ -231,14 +305,21 @@ APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0, const dou
                          const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp, double &lane_min_dt,
                          double *prim_dst = nullptr, double upd = 0.0, bool store_cons = true) {
   const double none[nvars<FLUID>()] = {};
-  finish_cell_impl<FLUID, EXTRA, LEAN, false>(pv, b0, u1v, cell, du, vol, sp, lane_min_dt, prim_dst, upd, store_cons, none);
+  finish_cell_impl<FLUID, EXTRA, LEAN, false>(pv, b0, u1v, CellAt{cell}, du, vol, sp, lane_min_dt, prim_dst, upd, store_cons, none);
 }
-template <int FLUID, int EXTRA, bool LEAN>
-APK_DEV void finish_cell_old_held(const PackView &pv, const apk_block_desc &b0, const double (&u1v)[nvars<FLUID>()], int64_t cell,
+template <int FLUID, int EXTRA, bool LEAN, class AT>
+APK_DEV void finish_cell_at(const PackView &pv, const apk_block_desc &b0, const double (&u1v)[nvars<FLUID>()], const AT &at,
+                            const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp, double &lane_min_dt,
+                            double *prim_dst, double upd) {
+  const double none[nvars<FLUID>()] = {};
+  finish_cell_impl<FLUID, EXTRA, LEAN, false>(pv, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd, true, none);
+}
+template <int FLUID, int EXTRA, bool LEAN, class AT>
+APK_DEV void finish_cell_old_held(const PackView &pv, const apk_block_desc &b0, const double (&u1v)[nvars<FLUID>()], const AT &at,
                                   const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp, double &lane_min_dt,
                                   double *prim_dst, double upd, const double (&old_held)[nvars<FLUID>()]) {
   static_assert(LEAN, "lean form only");
-  finish_cell_impl<FLUID, EXTRA, LEAN, true>(pv, b0, u1v, cell, du, vol, sp, lane_min_dt, prim_dst, upd, true, old_held);
+  finish_cell_impl<FLUID, EXTRA, LEAN, true>(pv, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd, true, old_held);
 }
 
 // ==============================================================================================
@@ -415,6 +496,8 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
   const int seg = blockIdx.z - b * nseg;
   const apk_block_desc b0 = u0.blocks[b];
   const double *c1 = u1.blocks[b].cons;
+  // the x3 sweep of the two-kernel stage addresses its rows as scalar pointer + the lane's byte offset (RowCellAt)
+  constexpr bool ROWADDR = (DIR == 3 && !FINAL);
 
   const int64_t st = (DIR == 2) ? u0.sj : u0.sk;
   int s0 = (DIR == 2) ? u0.js : u0.ks;
@@ -458,6 +541,15 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
   auto row_off = [&](int r) -> int64_t {
     return (int64_t)r * st + (r < lo_int ? nbr_lo : (r > hi_int ? nbr_hi : (int64_t)0));
   };
+  const unsigned base_boff = (unsigned)(base * (int64_t)sizeof(double));
+  auto load_row = [&](int r, double (&row)[NV]) {
+    if constexpr (ROWADDR) {
+      load_vars<NV>(uniform_ptr(in0), u0.sn, RowCellAt{row_off(r), base_boff}, row);
+    } else {
+#pragma unroll
+      for (int n = 0; n < NV; ++n) row[n] = prim[n * u0.sn + row_off(r)];
+    }
+  };
 
   // row r of the stencil lives in slot (r - (s-1-H)) mod NS
   int c = s - 1;
@@ -465,8 +557,7 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
 #pragma unroll
   for (int m = 0; m < NS; ++m) {
     double row[NV];
-#pragma unroll
-    for (int n = 0; n < NV; ++n) row[n] = prim[n * u0.sn + row_off(r0 + m)];
+    load_row(r0 + m, row);
     if constexpr (FC) {
       const unsigned fl = cons_row_to_prim<FLUID>(sp, row);
       if (active && fl) atomicOr(sp.flags, fl);
@@ -475,8 +566,7 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
     for (int n = 0; n < NV; ++n) ring[(m * NV + n) * 64 + lane] = row[n];
   }
   double Pn[NV];  // row c+H (FC: as loaded until the top of the iteration that uses it)
-#pragma unroll
-  for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + row_off(c + H)];
+  load_row(c + H, Pn);
 
   double wl_prev[NV];  // permuted L state at face c (from cell c-1)
   double f_prev[NV];   // permuted flux at face c-1
@@ -565,8 +655,7 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
         for (int n = 0; n < NV; ++n) ring[(slot0 * NV + n) * 64 + lane] = Pn[n];
         slot0 = (slot0 + 1) & (NS - 1);
       }
-#pragma unroll
-      for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + row_off(c + 1 + H)];
+      load_row(c + 1 + H, Pn);
     }
     if (c >= s) {
       double wr[NV], f[NV];
@@ -593,9 +682,16 @@ fused_march_kernel(PackView u0, PackView u1, StageParams sp, int nseg, int rpw) 
             finish_cell<FLUID, EXTRA>(u0, b0, u1v, cell, du, vol, sp, lane_min_dt, prim_dst);
           } else {
             // (du_compact: DIR = 3, the row (k, j) = (c - 1, trans) of the interior, column ii - is)
-            const int64_t dcell = du_compact ? ((int64_t)(c - 1 - u0.ks) * u0.nx2 + trans) * sp.du_pitch + (ii - u0.is) : cell;
+            if constexpr (ROWADDR) {
+              // (the lane's share: its row `trans` of the plane and its column; the plane is wave-uniform)
+              const RowCellAt at{du_compact ? (int64_t)(c - 1 - u0.ks) * u0.nx2 * sp.du_pitch : (int64_t)(c - 1) * st,
+                                 du_compact ? (unsigned)(((int64_t)trans * sp.du_pitch + (ii - u0.is)) * (int64_t)sizeof(double)) : base_boff};
+              store_vars<NV>(uniform_ptr(dscratch), du_sn, at, du);
+            } else {
+              const int64_t dcell = du_compact ? ((int64_t)(c - 1 - u0.ks) * u0.nx2 + trans) * sp.du_pitch + (ii - u0.is) : cell;
 #pragma unroll
-            for (int n = 0; n < NV; ++n) store_result(&dscratch[n * du_sn + dcell], du[n]);
+              for (int n = 0; n < NV; ++n) store_result(&dscratch[n * du_sn + dcell], du[n]);
+            }
           }
         }
       }

@@ -246,8 +246,17 @@ def test_rk_with_a_density_floor_that_fires_in_every_stage_matches_oracle(oracle
     assert not s.prim_is_stale                      # (the cycle stores its primitives: every stage floors what it stores)
     u = s.gather()
     assert u[0].min() == 0.3 and (u[0] == 0.3).sum() > 32 * 32  # the floor is what holds the middle up
-    _assert_same(u, o.gather_cons(), strict)
-    _assert_same(np.asarray(s.dt), np.asarray(o.dt), strict)
+    if strict or recon != "ppm":
+        _assert_same(u, o.gather_cons(), strict)
+        _assert_same(np.asarray(s.dt), np.asarray(o.dt), strict)
+    else:
+        # product build (FMA contraction, reciprocal seeds) with PPM: a last-bit difference decides in single cells at the
+        # edge of the evacuated region whether the floor fires or an extremum test flips, and the next stages carry that
+        # on (measured: 2.8e-3 in a few cells after 0.08 time units) -- the parity build above is the bit-for-bit check
+        uo = o.gather_cons()
+        d = np.abs(u - uo)
+        assert np.max(d) < 2e-2 and np.mean(d) < 1e-5 * np.mean(np.abs(uo))
+        assert s.dt == pytest.approx(o.dt, rel=1e-4)
 
 
 def test_config2_full_size_sod_stays_one_dimensional():

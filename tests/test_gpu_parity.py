@@ -1241,6 +1241,10 @@ def test_two_kernel_stage_takes_its_input_from_the_conserved_state(request, orac
     # (gam0 = 0 in the u1-input forms: the oracle's u0 only lends its ghost zones to the ConsToPrim of the whole block below)
     want = H.orc_stage(fluid, recon, riemann, g, state, state * 1.01 if own_input else state,
                        prim_of_state, GAMMA, C_H, gam0, 1.0 - gam0, bdt, dedner=ded, alpha=0.1, mindx=0.07)
+    if dt_only:
+        # FillDerived acts on the conserved state it converts (adiabatic_hydro.hpp:81: the density "floor" of -1 replaces
+        # a NaN density, `(u_d > floor) ? u_d : floor`): the stored state is the oracle's AFTER its ConsToPrim
+        want = H.orc_c2p(fluid, g, want, oracle.make_eos(GAMMA))[0]
     got = (m2 if own_input else m0).cons_host()
     _cmp(H.interior(got, nx, ng), H.interior(want, nx, ng), strict, "updated conserved state")
     if own_input:
