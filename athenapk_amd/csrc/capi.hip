@@ -73,6 +73,49 @@ int ensure_mark(apk_ctx *ctx, size_t n) {
 
 }  // namespace
 
+namespace apk {
+namespace {
+// word 4 = the stage's time-step minimum, word 5 = the two flag words; h = pinned host memory (device address)
+__global__ void cycle_gather_kernel(unsigned long long *u64, unsigned long long *h, const unsigned long long *tag_words, double *h_tags,
+                                    int ntags) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < ntags) {
+    h_tags[t] = __longlong_as_double((long long)tag_words[t]);
+    const_cast<unsigned long long *>(tag_words)[t] = 0ull;
+  }
+  if (t == 0) {
+    h[4] = u64[4];
+    h[5] = u64[5];
+    u64[4] = u64[15];                                  // +max: ready for the next reduction
+    reinterpret_cast<unsigned *>(u64 + 5)[0] = 0u;     // latched flags handed over ([1], the trial stage's, stays)
+  }
+}
+}  // namespace
+
+int prepare_dt_word(apk_ctx *ctx, hipStream_t s) {
+  if (!ctx->dt_word_clean) {
+    // +max (neutral element of the min), device to device so the launch path never blocks the host
+    if (hipMemcpyAsync(ctx->d_u64 + 4, ctx->d_u64 + 15, sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess) return APK_ERR_DEVICE;
+  }
+  ctx->dt_word_clean = false;  // (about to be reduced into)
+  return APK_OK;
+}
+
+int launch_cycle_gather(apk_ctx *ctx, hipStream_t s) {
+  const int ntags = (ctx->tags_pending > 0 && ctx->h_partial_dev) ? ctx->tags_pending : 0;
+  const int blocks = ntags > 0 ? (ntags + 255) / 256 : 1;
+  hipLaunchKernelGGL(cycle_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ctx->d_u64, ctx->h_pinned_dev,
+                     ctx->d_tagmax, ctx->h_partial_dev, ntags);
+  if (hipGetLastError() != hipSuccess) return APK_ERR_DEVICE;
+  ctx->dt_word_clean = true;
+  if (ntags > 0) {
+    ctx->tag_words_clean = ntags;
+    ctx->tags_pending = 0;
+  }
+  return APK_OK;
+}
+}  // namespace apk
+
 extern "C" {
 
 int apk_version(void) { return APK_AMD_VERSION; }
@@ -116,6 +159,11 @@ int apk_create(apk_ctx **out) {
     const double huge = 1.7976931348623157e308;  // word 15: constant +max, the neutral element of the dt min
     (void)hipMemcpy(ctx->d_u64 + 15, &huge, sizeof(double), hipMemcpyHostToDevice);
   }
+  {
+    void *dev = nullptr;  // (pinned host memory is mapped into the device's address space by default; if not: copies)
+    if (hipHostGetDevicePointer(&dev, ctx->h_pinned, 0) == hipSuccess) ctx->h_pinned_dev = static_cast<unsigned long long *>(dev);
+    else (void)hipGetLastError();
+  }
   *out = ctx;
   return APK_OK;
 }
@@ -125,6 +173,7 @@ void apk_destroy(apk_ctx *ctx) {
   if (ctx->d_u64) (void)hipFree(ctx->d_u64);  // (d_flags points into it)
   if (ctx->d_mflux) (void)hipFree(ctx->d_mflux);
   if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+  if (ctx->d_tagmax) (void)hipFree(ctx->d_tagmax);
   if (ctx->d_mark) (void)hipFree(ctx->d_mark);
   if (ctx->d_du) (void)hipFree(ctx->d_du);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -344,7 +393,7 @@ int apk_cons_to_prim_dt(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_e
     return set_err(ctx, APK_ERR_INVALID, "apk_cons_to_prim_dt: bad argument");
   hipStream_t s = as_stream(stream);
   unsigned long long *dt_bits = ctx->d_u64 + 4;  // the stage's word: apk_stage_dt_read / apk_stage_dt_flags_read
-  APK_HIP_TRY(ctx, hipMemcpyAsync(dt_bits, ctx->d_u64 + 15, sizeof(double), hipMemcpyDeviceToDevice, s));
+  if (apk::prepare_dt_word(ctx, s) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "time-step word reset", hipGetLastError());
   ScopedTiming timing(ctx, APK_T_C2P, s);
   int rc = launch_cons_to_prim(md->view, fluid, *eos, ctx->d_flags, s, false, nullptr, 0, false, nullptr, dt_bits, ghost_depth);
   if (rc != APK_OK) return set_err(ctx, rc, "cons_to_prim kernel launch failed", hipGetLastError());
@@ -379,7 +428,7 @@ int apk_cons_to_prim_faces_dt(apk_ctx *ctx, const apk_pack *md, int fluid, const
     return set_err(ctx, APK_ERR_INVALID, "apk_cons_to_prim_faces_dt: bad argument");
   hipStream_t s = as_stream(stream);
   unsigned long long *dt_bits = ctx->d_u64 + 4;  // the stage's word: apk_stage_dt_read / apk_stage_dt_flags_read
-  APK_HIP_TRY(ctx, hipMemcpyAsync(dt_bits, ctx->d_u64 + 15, sizeof(double), hipMemcpyDeviceToDevice, s));
+  if (apk::prepare_dt_word(ctx, s) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "time-step word reset", hipGetLastError());
   ScopedTiming timing(ctx, APK_T_C2P, s);
   int rc = launch_cons_to_prim(md->view, fluid, *eos, ctx->d_flags, s, false, nullptr, 0, true, face_neighbor, dt_bits);
   if (rc != APK_OK) return set_err(ctx, rc, "cons_to_prim kernel launch failed", hipGetLastError());
@@ -517,9 +566,15 @@ int apk_stage_dt_flags_read(apk_ctx *ctx, double cfl, double *dt_out, unsigned *
   if (!ctx || !dt_out || !flags) return APK_ERR_INVALID;
   hipStream_t s = as_stream(stream);
   auto *h = static_cast<unsigned long long *>(ctx->h_pinned);
-  // words 4 (the stage's minimum) and 5 (the flag words) in one copy
-  APK_HIP_TRY(ctx, hipMemcpyAsync(h + 4, ctx->d_u64 + 4, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-  APK_HIP_TRY(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(unsigned), s));
+  if (ctx->h_pinned_dev) {
+    // one small kernel hands words 4 / 5 (and the tag criteria an apk_tag_blocks_begin left pending) to the host and
+    // leaves the device words ready for the next cycle
+    if (apk::launch_cycle_gather(ctx, s) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "cycle gather launch", hipGetLastError());
+  } else {
+    // words 4 (the stage's minimum) and 5 (the flag words) in one copy
+    APK_HIP_TRY(ctx, hipMemcpyAsync(h + 4, ctx->d_u64 + 4, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    APK_HIP_TRY(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(unsigned), s));
+  }
   APK_HIP_TRY(ctx, hipStreamSynchronize(s));
   double m;
   std::memcpy(&m, h + 4, sizeof(m));

@@ -105,6 +105,9 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
   // wave per SIMD with 512 VGPRs spills nothing but takes 2.63 ms at best).  The lean march WITHOUT ConsToPrim (the stages
   // of RK2 / RK3 that are not the last, the north-star stage benchmark) has the registers to request u1 after the x1
   // phase without scratch (LOADS = 3; 244 VGPRs): general stage 3.07 -> 2.98 ms, same box.
+  // (Round 5, after the row addressing freed 10 - 17 VGPRs: u1 after the x1 phase in every lean form -- 247 VGPRs, no
+  // scratch -- and d3 there as well in the forms without ConsToPrim -- 256, no scratch: both within +-0.5 % of this
+  // placement on the headline, the WENOZ RK3 cycle and the general stage, same box.)
   constexpr int LOADS = (LEAN && EXTRA == EXTRA_NONE) ? 3 : 2;
   extern __shared__ __attribute__((aligned(16))) double ring[];
   // FC with room in the LDS (m12f_keeps_raw_rows: the hydro marches, PLM-class GLM-MHD): the rows are ALSO kept as loaded,

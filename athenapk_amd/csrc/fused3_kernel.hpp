@@ -44,9 +44,10 @@ fused_s3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, int
   const int chunk = vid % wpb;
   const int segid = (vid / wpb) % nseg;
   const int b = vid / (wpb * nseg);
-  const apk_block_desc b0 = u0.blocks[b];
-  const double *c1 = u1.blocks[b].cons;
-  double *prim_dst = (EXTRA != EXTRA_NONE && !sp.no_prim_store) ? u1.blocks[b].prim : nullptr;
+  apk_block_desc b0 = u0.blocks[b];
+  b0.cons = uniform_ptr(b0.cons);
+  const double *c1 = uniform_ptr(u1.blocks[b].cons);
+  double *prim_dst = (EXTRA != EXTRA_NONE && !sp.no_prim_store) ? uniform_ptr(u1.blocks[b].prim) : nullptr;
 
   const int i0 = u0.is - kS3Halo, rl = u0.nx1 + 2 * kS3Halo;
   const int64_t run = (int64_t)(u0.nx2 / 2) * rl;
@@ -59,6 +60,7 @@ fused_s3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, int
   const bool active = in_run && (lane >= kS3Halo) && (lane <= 63 - kS3Halo) && (i >= u0.is) && (i <= u0.ie);
   const int ja = u0.js + 2 * rowpair;  // rows ja (cell A) and ja + 1 (cell B)
   const int64_t col = (int64_t)ja * u0.sj + i;
+  const unsigned col_boff = (unsigned)(col * (int64_t)sizeof(double));  // (RowCellAt: the lane's share of a cell's address)
 
   const apk_block_desc *srcb = (SRC == 1) ? u1.blocks : u0.blocks;
   const double *in = srcb[b].cons + col;                           // rows ja, ja + 1
@@ -197,7 +199,7 @@ fused_s3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, int
         }
         riemann<FLUID, RS>(wl, wr, sp.k, f3);
         if (c >= s + 1) {
-          const int64_t done = col + (int64_t)(c - 1) * u0.sk + r * u0.sj;
+          const RowCellAt done{(int64_t)(c - 1) * u0.sk + r * u0.sj, col_boff};
           double du[NV], u1v[NV], held[NV];
 #pragma unroll
           for (int q = 0; q < NV; ++q) {
@@ -208,13 +210,12 @@ fused_s3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, int
           for (int n = 0; n < NV; ++n) held[n] = rawslot[n * 64];
           if constexpr (SRC == 1) {
             // (the input state IS u1: the plane just completed is at hand)
-            if (active) finish_cell<FLUID, EXTRA, true>(u0, b0, held, done, du, vol, sp, lane_min_dt, prim_dst, upd);
+            if (active) finish_cell_at<FLUID, EXTRA, true>(u0, b0, held, done, du, vol, sp, lane_min_dt, prim_dst, upd);
           } else {
             if (active) {
-#pragma unroll
-              for (int n = 0; n < NV; ++n) u1v[n] = as_global(c1)[n * u0.sn + done];
+              load_vars<NV>(c1, u0.sn, done, u1v);
               // (the input state is the old u0 the update reads)
-              finish_cell_old_held<FLUID, EXTRA, true>(u0, b0, u1v, CellAt{done}, du, vol, sp, lane_min_dt, prim_dst, upd, held);
+              finish_cell_old_held<FLUID, EXTRA, true>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd, held);
             }
           }
         }
@@ -326,7 +327,7 @@ template <int FLUID, int RECON>
 inline bool single_march_stage_applies(const PackView &u0, int extra, const StageParams &sp) {
   static const int mode = std::getenv("APK_S3") ? std::atoi(std::getenv("APK_S3")) : 1;
   if constexpr (!single_march_compiled<FLUID, RECON>()) return false;
-  return mode != 0 && u0.ndim == 3 && sp.prim_from_cons != 0 && sp.phase == 0 && sp.window == nullptr && stage_is_lean(sp) &&
+  return mode != 0 && u0.ndim == 3 && (uint64_t)u0.sn * sizeof(double) < (1ull << 32) && sp.prim_from_cons != 0 && sp.phase == 0 && sp.window == nullptr && stage_is_lean(sp) &&
          u0.nx2 % 2 == 0 && u0.nx2 >= 4 && u0.ng >= 2 && (extra == EXTRA_NONE || (extra == EXTRA_C2P_DT && sp.no_prim_store)) &&
          (sp.prim_from_cons == 1 || sp.out_delta != 0);
 }

@@ -68,9 +68,7 @@ int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
     return APK_ERR_INVALID;
   }
   if (extra == EXTRA_C2P_DT && a.phase != 1) {  // (a split stage reduces dt in phase 2)
-    // +max (neutral element of the min), device to device so the launch path never blocks the host
-    if (hipMemcpyAsync(sp.dt_bits, ctx->d_u64 + 15, sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
-      return APK_ERR_DEVICE;
+    if (prepare_dt_word(ctx, s) != APK_OK) return APK_ERR_DEVICE;
   }
   if (u0.ndim > 1) {
     const size_t need = (size_t)u0.nblocks * (size_t)u0.nvar * (size_t)u0.sn;

@@ -1533,15 +1533,22 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
         // whole donor-cell stage in one march (see fused_dc3_kernel); its FillDerived is out of place
         const int64_t run3 = sp.window ? (int64_t)sp.window_rows * sp.window_rl : (int64_t)u0.nx2 * (u0.nx1 + 2);
         const int wpb = (int)((run3 + 61) / 62);
+        const bool lean = stage_is_lean(sp);
+        // two rows per lane (fused_dc3r2_kernel): whole blocks only -- a split stage's windows keep the one-row kernel
+        const bool two_rows = lean && !sp.window && u0.nx2 % 2 == 0 && u0.nx2 >= 4;
+        const int wpb2 = (int)(((int64_t)(u0.nx2 / 2) * (u0.nx1 + 2) + 61) / 62);
+        const int wpb_run = two_rows ? wpb2 : wpb;  // wave columns per block of the kernel that will run
         int kseg = (u0.nx3 >= 16) ? 8 : u0.nx3;  // measured on 8 x 128^3: 8 and 16 within 1 %, 64 is 12 % slower
-        if (u0.nx3 >= 16 && (int64_t)wpb * ((u0.nx3 + 7) / 8) * u0.nblocks < 4 * 2048) {
+        if (u0.nx3 >= 16 && (int64_t)wpb_run * ((u0.nx3 + 7) / 8) * u0.nblocks < 4 * 2048) {
           // small packs (refined meshes of 16^3 blocks): the march waves run in a few rounds of the 2048 resident ones
           // (2 per SIMD), so pick the segment length with the fewest plane-steps over all rounds -- a segment costs its
-          // planes plus about 1.5 for the prologue (232 blocks: 2320 waves of 8 planes = 2 rounds x 9.5; of 6 = 2 x 7.5)
+          // planes plus about 1.5 for the prologue.  (Round 5: counted with the wave columns of the kernel that RUNS: the
+          // two-row march has 3 per 16^3 block where the one-row march has 5, and 232 blocks in segments of 6 planes --
+          // the one-row optimum -- were 2088 waves: a second round for 40 of them.  Segments of 8: 1392 waves, one round.)
           double best = 1.0e300;
           for (const int cand : {4, 6, 8, 16}) {
             if (cand > u0.nx3) continue;
-            const int64_t waves = (int64_t)wpb * ((u0.nx3 + cand - 1) / cand) * u0.nblocks;
+            const int64_t waves = (int64_t)wpb_run * ((u0.nx3 + cand - 1) / cand) * u0.nblocks;
             const double cost = (double)((waves + 2047) / 2048) * (cand + 1.5);
             if (cost < best) best = cost, kseg = cand;
           }
@@ -1552,11 +1559,7 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
         const dim3 g((unsigned)(per_xcd * 8), 1, 1);
         constexpr int lds3 = 2 * nvars<FLUID>() * 64 * (int)sizeof(double);
         ScopedTiming t(sp.ctx, TS + 0, s);
-        const bool lean = stage_is_lean(sp);
-        if (lean && !sp.window && u0.nx2 % 2 == 0 && u0.nx2 >= 4) {
-          // two rows per lane (fused_dc3r2_kernel): whole blocks only -- a split stage's windows keep the one-row kernel
-          const int64_t run2 = (int64_t)(u0.nx2 / 2) * (u0.nx1 + 2);
-          const int wpb2 = (int)((run2 + 61) / 62);
+        if (two_rows) {
           const int64_t total2 = (int64_t)wpb2 * nseg * u0.nblocks;
           const int per_xcd2 = (int)((total2 + 7) / 8);
           const dim3 g2((unsigned)(per_xcd2 * 8), 1, 1);

@@ -257,6 +257,7 @@ struct apk_sim {
     apk_copy_plan *fine_bc_shell[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     void *xchg_pre_shell[2] = {nullptr, nullptr}, *xchg_post_shell[2] = {nullptr, nullptr};
     apk_flux_fix_plan *flux_fix[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    apk_flux_fix_plan *flux_fix_all[2] = {nullptr, nullptr}, *flux_fix_unpack_all[2] = {nullptr, nullptr};  // all directions in one launch
     // the faces (6 * local block + face) with a coarser or finer block behind them: the only boundary-plane
     // fluxes the correction after a fused stage reads (apk_calculate_fluxes_boundary_list)
     int *d_cf_faces = nullptr;

@@ -307,15 +307,19 @@ void amr_destroy_device_plans(apk_sim *s) {
       a.flux_fix[par][d] = a.flux_fix_unpack[par][d] = nullptr;
     }
   }
+  for (int par = 0; par < 2; ++par) {
+    apk_flux_fix_plan_destroy(a.flux_fix_all[par]);
+    apk_flux_fix_plan_destroy(a.flux_fix_unpack_all[par]);
+    a.flux_fix_all[par] = a.flux_fix_unpack_all[par] = nullptr;
+  }
 }
 
 // the flux-correction copies of direction d as corrections of the cells next to the face (fused path)
 // (ops: the restriction operator of every region -- same-rank faces: the kernel averages the fine block's fluxes
 // itself, no restricted plane in between; null: the regions' sources hold the averages)
-int amr_make_fix_plan(apk_sim *s, int parity, int d, const std::vector<BoxRegion> &regions, const apk_sim::MsgSet *msgs,
-                      apk_flux_fix_plan **out, const std::vector<AmrRefOp> *ops = nullptr) {
+int amr_fix_regions(apk_sim *s, int parity, int d, const std::vector<BoxRegion> &regions, const apk_sim::MsgSet *msgs,
+                    std::vector<apk_flux_fix_region> &regs, const std::vector<AmrRefOp> *ops = nullptr) {
   const AmrGeom &g = s->amr_geom;
-  std::vector<apk_flux_fix_region> regs;
   if (ops && ops->size() != regions.size()) return fail(s, APK_ERR_INVALID, "flux correction: operators and copies out of step");
   for (size_t n = 0; n < regions.size(); ++n) {
     const BoxRegion &r = regions[n];
@@ -352,7 +356,28 @@ int amr_make_fix_plan(apk_sim *s, int parity, int d, const std::vector<BoxRegion
     f.scale = (lower ? 1.0 : -1.0) / level_dx(s, block_level(s, r.dst_block), d);
     regs.push_back(f);
   }
-  return apk_flux_fix_plan_create(s->ctx, regs.data(), (int)regs.size(), out);
+  return APK_OK;
+}
+
+// The fix plans of one conserved buffer: ONE plan for the regions of all directions (one launch per stage instead of
+// three: the launches are 7 - 8 us each for a few hundred small regions), or -- a forest whose regions the merged form
+// refuses -- one per direction as before.
+int amr_make_fix_plans(apk_sim *s, int parity, const std::vector<BoxRegion> (&regions)[3], const apk_sim::MsgSet *msgs,
+                       const std::vector<AmrRefOp> (*ops)[3], apk_flux_fix_plan **merged, apk_flux_fix_plan *(&per_dir)[3]) {
+  std::vector<apk_flux_fix_region> per[3], all;
+  int nd[3] = {0, 0, 0};
+  for (int d = 0; d < s->mesh.ndim; ++d) {
+    SIM_TRY(s, amr_fix_regions(s, parity, d, regions[d], msgs, per[d], ops ? &(*ops)[d] : nullptr));
+    nd[d] = (int)per[d].size();
+    all.insert(all.end(), per[d].begin(), per[d].end());
+  }
+  *merged = nullptr;
+  const int rc = apk_flux_fix_plan_create_merged(s->ctx, all.data(), nd, s->d_cons2[parity], s->nper, merged);
+  if (rc == APK_OK) return APK_OK;
+  if (rc != APK_ERR_UNSUPPORTED) return fail(s, rc, apk_last_error(s->ctx));
+  *merged = nullptr;
+  for (int d = 0; d < s->mesh.ndim; ++d) SIM_TRY(s, apk_flux_fix_plan_create(s->ctx, per[d].data(), nd[d], &per_dir[d]));
+  return APK_OK;
 }
 
 // message buffers of a set: (re)allocated when a message outgrows its buffer, never shrunk
@@ -471,10 +496,10 @@ int amr_rebuild(apk_sim *s) {
     SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_copy[d], nullptr, &a.flux_copy[d]));
     SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_pack[d], &s->amr_fluxmsg, &a.flux_pack[d]));
     SIM_TRY(s, amr_make_copy_plan(s, 0, p.flux_unpack[d], &s->amr_fluxmsg, &a.flux_unpack[d]));
-    for (int par = 0; par < 2; ++par) {
-      SIM_TRY(s, amr_make_fix_plan(s, par, d, p.flux_copy[d], nullptr, &a.flux_fix[par][d], &p.flux_fused_ops[d]));
-      SIM_TRY(s, amr_make_fix_plan(s, par, d, p.flux_unpack[d], &s->amr_fluxmsg, &a.flux_fix_unpack[par][d]));
-    }
+  }
+  for (int par = 0; par < 2; ++par) {
+    SIM_TRY(s, amr_make_fix_plans(s, par, p.flux_copy, nullptr, &p.flux_fused_ops, &a.flux_fix_all[par], a.flux_fix[par]));
+    SIM_TRY(s, amr_make_fix_plans(s, par, p.flux_unpack, &s->amr_fluxmsg, nullptr, &a.flux_fix_unpack_all[par], a.flux_fix_unpack[par]));
   }
   {  // faces with a level change behind them
     const int nlb = (int)s->mesh.local_gids.size(), first = s->amr_part.first[s->rank];
@@ -650,16 +675,22 @@ int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi
   auto &a = s->amr_dev;
   const int psi_var = (s->pkg.fluid == APK_FLUID_GLMMHD) ? 8 : -1;
   SIM_TRY(s, apk_calculate_fluxes_boundary_list(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, a.d_cf_faces, a.n_cf_faces, s->stream));
+  // (same-rank faces: the fix kernel averages the fine fluxes itself, reading the blocks' flux arrays; only faces whose
+  // coarse side lives elsewhere are restricted into the coarse buffer, for the message -- direction by direction,
+  // because the restricted planes of all three directions share the coarse buffers)
+  if (a.flux_fix_all[s->cur]) SIM_TRY(s, apk_flux_fix_plan_run(s->ctx, a.flux_fix_all[s->cur], beta_dt, psi_var, psi_factor, s->stream));
   for (int d = 0; d < s->mesh.ndim; ++d) {
-    // (same-rank faces: the fix kernel averages the fine fluxes itself; only faces whose coarse side lives elsewhere
-    // are restricted into the coarse buffer, for the message)
     for (apk_refine_plan *p : a.flux_restrict_remote[d]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
-    SIM_TRY(s, apk_flux_fix_plan_run(s->ctx, a.flux_fix[s->cur][d], beta_dt, psi_var, psi_factor, s->stream));
+    if (!a.flux_fix_all[s->cur]) SIM_TRY(s, apk_flux_fix_plan_run(s->ctx, a.flux_fix[s->cur][d], beta_dt, psi_var, psi_factor, s->stream));
     SIM_TRY(s, apk_copy_plan_run(s->ctx, a.flux_pack[d], s->stream));
   }
   SIM_TRY(s, amr_exchange_messages(s, s->amr_fluxmsg));
-  for (int d = 0; d < s->mesh.ndim; ++d)
-    SIM_TRY(s, apk_flux_fix_plan_run(s->ctx, a.flux_fix_unpack[s->cur][d], beta_dt, psi_var, psi_factor, s->stream));
+  if (a.flux_fix_unpack_all[s->cur]) {
+    SIM_TRY(s, apk_flux_fix_plan_run(s->ctx, a.flux_fix_unpack_all[s->cur], beta_dt, psi_var, psi_factor, s->stream));
+  } else {
+    for (int d = 0; d < s->mesh.ndim; ++d)
+      SIM_TRY(s, apk_flux_fix_plan_run(s->ctx, a.flux_fix_unpack[s->cur][d], beta_dt, psi_var, psi_factor, s->stream));
+  }
   return APK_OK;
 }
 

@@ -3,6 +3,7 @@
 // one thread per coarse cell and variable, i fastest, so reads of the coarse buffer and the
 // paired (fi, fi+1) writes of the fine array coalesce; one launch covers every box of the plan
 // (blockIdx.x = box), which is what matters for AMR meshes made of many 16^3 blocks.
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -10,10 +11,17 @@
 #include "apk_internal.hpp"
 #include "hydro_math.hpp"
 
+// (merged plans, apk_flux_fix_plan_create_merged: the regions of all directions in ONE launch)
+struct FixRegionBox {
+  int lo[3];       // first cell of the region, as indices of the destination block's array
+  int dir;         // direction of the face the region corrects
+  int partner[8];  // other regions of the plan that share cells with this one (-1: none), lower directions first
+};
 struct apk_flux_fix_plan {
   apk_flux_fix_region *d_regions = nullptr;
   int n = 0;
   int64_t max_items = 0;
+  FixRegionBox *d_boxes = nullptr;  // non-null: a merged plan
 };
 
 struct apk_refine_plan {
@@ -209,20 +217,10 @@ __global__ void __launch_bounds__(256) refine_ops_kernel(apk_refine_geom g, int 
   }
 }
 
-// flux correction after a fused stage: one thread per (face cell, variable) of a region
-__global__ void __launch_bounds__(256) flux_fix_kernel(const apk_flux_fix_region *regions, double beta_dt, int psi_var,
-                                                       double psi_factor) {
-  const apk_flux_fix_region r = regions[blockIdx.x];
-  const int64_t cells = (int64_t)r.ext[0] * r.ext[1] * r.ext[2], items = cells * r.nvar;
-  for (int64_t t = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; t < items; t += (int64_t)gridDim.y * blockDim.x) {
-    const int v = (int)(t / cells);
-    int64_t c = t - (int64_t)v * cells;
-    const int i = (int)(c % r.ext[0]);
-    c /= r.ext[0];
-    const int j = (int)(c % r.ext[1]);
-    const int k = (int)(c / r.ext[1]);
+// the correction of element (i, j, k, v) of a region: beta_dt * scale * (fine average - coarse flux) [* psi_factor]
+template <class R>
+APK_DEV double flux_fix_term(const R &r, int i, int j, int k, int v, int64_t d, double beta_dt, int psi_var, double psi_factor) {
     const int64_t so = i * r.src_stride[0] + j * r.src_stride[1] + k * r.src_stride[2] + v * r.src_stride[3];
-    const int64_t d = i * r.dst_stride[0] + j * r.dst_stride[1] + k * r.dst_stride[2] + v * r.dst_stride[3];
     double avg;
     if (r.average == 0) {
       avg = r.fine_avg[so];
@@ -251,7 +249,67 @@ __global__ void __launch_bounds__(256) flux_fix_kernel(const apk_flux_fix_region
     }
     double dv = (beta_dt * r.scale) * (avg - r.coarse_flux[d]);
     if (v == psi_var) dv *= psi_factor;
-    r.cons[d] += dv;
+    return dv;
+}
+
+// flux correction after a fused stage: one thread per (face cell, variable) of a region
+__global__ void __launch_bounds__(256) flux_fix_kernel(const apk_flux_fix_region *regions, double beta_dt, int psi_var,
+                                                       double psi_factor) {
+  const apk_flux_fix_region r = regions[blockIdx.x];
+  const int64_t cells = (int64_t)r.ext[0] * r.ext[1] * r.ext[2], items = cells * r.nvar;
+  for (int64_t t = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; t < items; t += (int64_t)gridDim.y * blockDim.x) {
+    const int v = (int)(t / cells);
+    int64_t c = t - (int64_t)v * cells;
+    const int i = (int)(c % r.ext[0]);
+    c /= r.ext[0];
+    const int j = (int)(c % r.ext[1]);
+    const int k = (int)(c / r.ext[1]);
+    const int64_t d = i * r.dst_stride[0] + j * r.dst_stride[1] + k * r.dst_stride[2] + v * r.dst_stride[3];
+    r.cons[d] += flux_fix_term(r, i, j, k, v, d, beta_dt, psi_var, psi_factor);
+  }
+}
+
+// The same for the regions of ALL directions in one launch.  A coarse cell on an edge of its block can lie next to two or
+// three coarse-fine faces; the launches per direction corrected it direction by direction, ((u + d1) + d2) + d3.  Here the
+// region of the LOWEST direction that holds the cell owns it: it applies its own term and then the terms of the higher
+// directions, in order (the regions that share cells with it are listed in its box record) -- same additions, same
+// order, no two threads on one cell.
+__global__ void __launch_bounds__(256) flux_fix_merged_kernel(const apk_flux_fix_region *regions, const FixRegionBox *boxes,
+                                                              double beta_dt, int psi_var, double psi_factor) {
+  const apk_flux_fix_region r = regions[blockIdx.x];
+  const FixRegionBox bx = boxes[blockIdx.x];
+  const int64_t cells = (int64_t)r.ext[0] * r.ext[1] * r.ext[2], items = cells * r.nvar;
+  for (int64_t t = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; t < items; t += (int64_t)gridDim.y * blockDim.x) {
+    const int v = (int)(t / cells);
+    int64_t c = t - (int64_t)v * cells;
+    const int i = (int)(c % r.ext[0]);
+    c /= r.ext[0];
+    const int j = (int)(c % r.ext[1]);
+    const int k = (int)(c / r.ext[1]);
+    const int64_t d = i * r.dst_stride[0] + j * r.dst_stride[1] + k * r.dst_stride[2] + v * r.dst_stride[3];
+    const int ci = bx.lo[0] + i, cj = bx.lo[1] + j, ck = bx.lo[2] + k;  // the cell in its block
+    bool owner = true;
+    double later[2];
+    int nlater = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int pi = bx.partner[q];  // (block-uniform; sorted by direction)
+      if (pi < 0) break;
+      const FixRegionBox pb = boxes[pi];
+      const int li = ci - pb.lo[0], lj = cj - pb.lo[1], lk = ck - pb.lo[2];
+      const apk_flux_fix_region *pr = regions + pi;
+      if (li < 0 || lj < 0 || lk < 0 || li >= pr->ext[0] || lj >= pr->ext[1] || lk >= pr->ext[2]) continue;
+      if (pb.dir < bx.dir) {
+        owner = false;  // the region of the lower direction applies this region's term too
+        break;
+      }
+      const int64_t pd = li * pr->dst_stride[0] + lj * pr->dst_stride[1] + lk * pr->dst_stride[2] + v * pr->dst_stride[3];
+      if (nlater < 2) later[nlater++] = flux_fix_term(*pr, li, lj, lk, v, pd, beta_dt, psi_var, psi_factor);
+    }
+    if (!owner) continue;
+    double u = r.cons[d] + flux_fix_term(r, i, j, k, v, d, beta_dt, psi_var, psi_factor);
+    for (int q = 0; q < nlater; ++q) u += later[q];
+    r.cons[d] = u;
   }
 }
 
@@ -426,9 +484,89 @@ int apk_flux_fix_plan_create(apk_ctx *ctx, const apk_flux_fix_region *regions, i
   return APK_OK;
 }
 
+// The regions of up to three directions (direction 0's first, then 1's, then 2's: n_by_dir) as ONE plan that runs in one
+// launch (flux_fix_merged_kernel).  field_base / block_elems locate a region's cons pointer in its block: the regions'
+// destinations are cells of cell-shaped arrays [block][var][k][j][i] that start at field_base, block_elems apart, with
+// the strides the regions carry (dst_stride[0] = 1).  Regions that share cells (the edges of a coarse block with finer
+// blocks behind two or three of its faces) are linked, at most 8 per region; a mesh that needs more is refused and the
+// caller keeps one plan per direction.
+int apk_flux_fix_plan_create_merged(apk_ctx *ctx, const apk_flux_fix_region *regions, const int n_by_dir[3], const double *field_base,
+                                    int64_t block_elems, apk_flux_fix_plan **out) {
+  if (!ctx || !out || !n_by_dir || !field_base || block_elems <= 0)
+    return set_err(ctx, APK_ERR_INVALID, "apk_flux_fix_plan_create_merged: bad argument");
+  const int n = n_by_dir[0] + n_by_dir[1] + n_by_dir[2];
+  int rc = apk_flux_fix_plan_create(ctx, regions, n, out);
+  if (rc != APK_OK || n == 0) return rc;
+  apk_flux_fix_plan *p = *out;
+  std::vector<FixRegionBox> boxes((size_t)n);
+  std::vector<int64_t> blk((size_t)n);
+  for (int q = 0; q < n; ++q) {
+    const apk_flux_fix_region &r = regions[q];
+    FixRegionBox &b = boxes[(size_t)q];
+    b.dir = q < n_by_dir[0] ? 0 : (q < n_by_dir[0] + n_by_dir[1] ? 1 : 2);
+    for (int m = 0; m < 8; ++m) b.partner[m] = -1;
+    // (cells of variable 0 of the block: offset = k * sk + j * sj + i)
+    const int64_t off = r.cons - field_base;
+    const int64_t sj = r.dst_stride[1], sk = r.dst_stride[2];
+    const bool ok = off >= 0 && r.dst_stride[0] == 1 && sj > 0 && (sk > 0 ? sk % sj == 0 : r.ext[2] == 1);
+    blk[(size_t)q] = ok ? off / block_elems : -1;
+    int64_t in = ok ? off % block_elems : 0;
+    b.lo[2] = sk > 0 ? (int)(in / sk) : 0;
+    in -= (int64_t)b.lo[2] * (sk > 0 ? sk : 0);
+    b.lo[1] = sj > 0 ? (int)(in / sj) : 0;
+    b.lo[0] = (int)(in - (int64_t)b.lo[1] * sj);
+    if (!ok) {
+      apk_flux_fix_plan_destroy(p);
+      *out = nullptr;
+      return set_err(ctx, APK_ERR_UNSUPPORTED, "apk_flux_fix_plan_create_merged: region layout");
+    }
+  }
+  // regions of one block, different directions, overlapping boxes
+  std::vector<int> order((size_t)n);
+  for (int q = 0; q < n; ++q) order[(size_t)q] = q;
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return blk[(size_t)a] != blk[(size_t)b] ? blk[(size_t)a] < blk[(size_t)b] : a < b; });
+  auto overlap = [&](int a, int b) {
+    for (int d = 0; d < 3; ++d) {
+      const int alo = boxes[(size_t)a].lo[d], ahi = alo + regions[a].ext[d] - 1;
+      const int blo = boxes[(size_t)b].lo[d], bhi = blo + regions[b].ext[d] - 1;
+      if (ahi < blo || bhi < alo) return false;
+    }
+    return true;
+  };
+  for (size_t x = 0; x < order.size();) {
+    size_t y = x;
+    while (y < order.size() && blk[(size_t)order[y]] == blk[(size_t)order[x]]) ++y;
+    for (size_t a = x; a < y; ++a) {
+      const int qa = order[a];
+      int np = 0;
+      // (ascending region index = ascending direction: the kernel meets the lower directions first)
+      for (size_t bq = x; bq < y; ++bq) {
+        const int qb = order[bq];
+        if (qb == qa || boxes[(size_t)qb].dir == boxes[(size_t)qa].dir || !overlap(qa, qb)) continue;
+        if (np == 8) {
+          apk_flux_fix_plan_destroy(p);
+          *out = nullptr;
+          return set_err(ctx, APK_ERR_UNSUPPORTED, "apk_flux_fix_plan_create_merged: more than 8 regions share cells with one");
+        }
+        boxes[(size_t)qa].partner[np++] = qb;
+      }
+    }
+    x = y;
+  }
+  hipError_t e = hipMalloc(&p->d_boxes, sizeof(FixRegionBox) * (size_t)n);
+  if (e == hipSuccess) e = hipMemcpy(p->d_boxes, boxes.data(), sizeof(FixRegionBox) * (size_t)n, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    apk_flux_fix_plan_destroy(p);
+    *out = nullptr;
+    return set_err(ctx, APK_ERR_DEVICE, "apk_flux_fix_plan_create_merged", e);
+  }
+  return APK_OK;
+}
+
 void apk_flux_fix_plan_destroy(apk_flux_fix_plan *p) {
   if (!p) return;
   if (p->d_regions) (void)hipFree(p->d_regions);
+  if (p->d_boxes) (void)hipFree(p->d_boxes);
   delete p;
 }
 
@@ -441,6 +579,11 @@ int apk_flux_fix_plan_run(apk_ctx *ctx, const apk_flux_fix_plan *p, double beta_
   if (gy > 1024) gy = 1024;
   for (int off = 0; off < p->n; off += 1 << 20) {  // (gridDim.x is ample; chunked for symmetry with the copy plans)
     const int m = (p->n - off < (1 << 20)) ? p->n - off : (1 << 20);
+    if (p->d_boxes) {  // (a merged plan is one launch: the partner indices are plan-wide)
+      hipLaunchKernelGGL(flux_fix_merged_kernel, dim3((unsigned)p->n, (unsigned)gy), dim3(256), 0, s, p->d_regions, p->d_boxes, beta_dt,
+                         psi_var, psi_factor);
+      break;
+    }
     hipLaunchKernelGGL(flux_fix_kernel, dim3((unsigned)m, (unsigned)gy), dim3(256), 0, s, p->d_regions + off, beta_dt, psi_var,
                        psi_factor);
   }
@@ -463,22 +606,29 @@ int apk_tag_blocks_begin(apk_ctx *ctx, const apk_pack *md, int criterion, int *p
   if (criterion == APK_TAG_PRESSURE_GRADIENT && ndim == 1) return APK_OK;  // gradient.cpp:56-58: AmrTag::same
   if (criterion == APK_TAG_VELOCITY_GRADIENT && ndim == 1)
     return set_err(ctx, APK_ERR_UNSUPPORTED, "xyvelocity_gradient needs at least two dimensions");
-  if (ctx->partial_cap < (size_t)nb) {
-    if (ctx->d_partial) (void)hipFree(ctx->d_partial);
-    ctx->d_partial = nullptr;
-    ctx->partial_cap = 0;
-    APK_HIP_TRY(ctx, hipMalloc(&ctx->d_partial, sizeof(double) * (nb + 64)));
-    ctx->partial_cap = nb + 64;
+  if (ctx->tagmax_cap < (size_t)nb) {
+    if (ctx->d_tagmax) (void)hipFree(ctx->d_tagmax);
+    ctx->d_tagmax = nullptr;
+    ctx->tagmax_cap = 0;
+    ctx->tag_words_clean = 0;
+    APK_HIP_TRY(ctx, hipMalloc(&ctx->d_tagmax, sizeof(unsigned long long) * (nb + 64)));
+    ctx->tagmax_cap = nb + 64;
   }
   if (ctx->h_partial_cap < (size_t)nb) {  // (pinned: a pageable destination costs a staging copy every cycle)
     if (ctx->h_partial) (void)hipHostFree(ctx->h_partial);
     ctx->h_partial = nullptr;
+    ctx->h_partial_dev = nullptr;
     ctx->h_partial_cap = 0;
     APK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_partial), sizeof(double) * (nb + 64), hipHostMallocDefault));
     ctx->h_partial_cap = nb + 64;
+    void *dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, ctx->h_partial, 0) == hipSuccess) ctx->h_partial_dev = static_cast<double *>(dev);
+    else (void)hipGetLastError();
   }
-  auto *d_max = reinterpret_cast<unsigned long long *>(ctx->d_partial);
-  APK_HIP_TRY(ctx, hipMemsetAsync(d_max, 0, sizeof(unsigned long long) * nb, s));
+  unsigned long long *d_max = ctx->d_tagmax;
+  // (the gather at the end of the previous cycle left the words at zero: apk_ctx::tag_words_clean)
+  if (ctx->tag_words_clean < nb) APK_HIP_TRY(ctx, hipMemsetAsync(d_max, 0, sizeof(unsigned long long) * nb, s));
+  ctx->tag_words_clean = 0;
   const int kchunks = (pv.nx3 >= 12 && nb < 4096) ? 3 : 1;
   const dim3 grid = rect_grid(pv.nx1 + 2, pv.nx2 + 2, nb * kchunks), block(64, 4, 1);
   if (criterion == APK_TAG_PRESSURE_GRADIENT)
@@ -487,7 +637,14 @@ int apk_tag_blocks_begin(apk_ctx *ctx, const apk_pack *md, int criterion, int *p
     hipLaunchKernelGGL(tag_kernel<APK_TAG_VELOCITY_GRADIENT>, grid, block, 0, s, pv, d_max, kchunks);
   else
     hipLaunchKernelGGL(tag_kernel<APK_TAG_MAX_DENSITY>, grid, block, 0, s, pv, d_max, kchunks);
-  APK_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partial, d_max, sizeof(double) * nb, hipMemcpyDeviceToHost, s));
+  if (ctx->h_pinned_dev && ctx->h_partial_dev) {
+    // the criteria ride to the host with the time-step word (apk_stage_dt_flags_read's gather kernel) if the caller
+    // reads that next -- the driver does --, else apk_tag_blocks_end fetches them
+    ctx->tags_pending = nb;
+  } else {
+    APK_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partial, d_max, sizeof(double) * nb, hipMemcpyDeviceToHost, s));
+    ctx->tags_pending = 0;
+  }
   *pending = 1;
   return APK_OK;
 }
@@ -505,6 +662,11 @@ int apk_tag_blocks_end(apk_ctx *ctx, int nblocks, int criterion, int pending, do
     return APK_OK;
   }
   if ((size_t)nblocks > ctx->h_partial_cap) return set_err(ctx, APK_ERR_INVALID, "apk_tag_blocks_end without apk_tag_blocks_begin");
+  if (ctx->tags_pending > 0) {  // (nobody gathered them meanwhile)
+    APK_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partial, ctx->d_tagmax, sizeof(double) * ctx->tags_pending, hipMemcpyDeviceToHost,
+                                    reinterpret_cast<hipStream_t>(stream)));
+    ctx->tags_pending = 0;
+  }
   APK_HIP_TRY(ctx, hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
   const double *h = ctx->h_partial;
   const double refine_above = p0;

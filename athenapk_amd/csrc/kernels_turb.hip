@@ -396,8 +396,7 @@ int turb_apply_fill_impl(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, double n
     if (store_prim && !b.prim) return set_err(ctx, APK_ERR_INVALID, "apk_turb_apply_fill: block without prim pointer");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   unsigned long long *dt_bits = ctx->d_u64 + 4;  // the stage's word: apk_stage_dt_read / apk_stage_dt_flags_read
-  if (estimate_dt && hipMemcpyAsync(dt_bits, ctx->d_u64 + 15, sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
-    return set_err(ctx, APK_ERR_DEVICE, "apk_turb_apply_fill", hipGetLastError());
+  if (estimate_dt && apk::prepare_dt_word(ctx, s) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "apk_turb_apply_fill", hipGetLastError());
   const dim3 g = igrid(md->view), blk(64, 4, 1);
 #define APK_LAUNCH_KICK(FL, DT, SP) \
   hipLaunchKernelGGL((turb_apply_fill_kernel<FL, DT, SP>), g, blk, 0, s, md->view, f->d_blocks, norm, dt, *eos, ctx->d_flags, dt_bits)

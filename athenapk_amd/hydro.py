@@ -304,7 +304,9 @@ class FluxFixPlan:
     regions = list of (fine_avg tensor view, coarse_flux tensor view, cons tensor view, scale) where
     the three views have the same shape [nvar][nk][nj][ni] (strides are taken from the views)."""
 
-    def __init__(self, ctx, regions):
+    def __init__(self, ctx, regions, merged=None):
+        """merged = (n_by_dir, field tensor [nblocks][nvar][nk][nj][ni]): the regions of all directions (direction 0's
+        first) as ONE plan that runs in one launch (apk_flux_fix_plan_create_merged)."""
         self.ctx = ctx
         arr = (L.FluxFixRegion * max(1, len(regions)))()
         self._keep = []
@@ -323,7 +325,15 @@ class FluxFixPlan:
             arr[n].scale = scale
             self._keep += [fa, cf, cons]
         h = C.c_void_p()
-        _check(ctx.lib.apk_flux_fix_plan_create(ctx.h, arr, len(regions), C.byref(h)), ctx.lib, ctx.h)
+        if merged is None:
+            _check(ctx.lib.apk_flux_fix_plan_create(ctx.h, arr, len(regions), C.byref(h)), ctx.lib, ctx.h)
+        else:
+            n_by_dir, field = merged
+            assert sum(n_by_dir) == len(regions) and field.is_contiguous()
+            nd = (C.c_int * 3)(*[int(x) for x in n_by_dir])
+            _check(ctx.lib.apk_flux_fix_plan_create_merged(ctx.h, arr, nd, field.data_ptr(), int(field[0].numel()), C.byref(h)),
+                   ctx.lib, ctx.h)
+            self._keep.append(field)
         self.h = h
 
     def run(self, beta_dt, psi_var=-1, psi_factor=1.0):

@@ -157,6 +157,7 @@ def _signatures():
         "apk_calculate_fluxes_boundary": (i, [vp, vp, FluxCfg, E, d, vp]),
         "apk_calculate_fluxes_boundary_list": (i, [vp, vp, FluxCfg, E, d, vp, C.c_int, vp]),
         "apk_flux_fix_plan_create": (i, [vp, C.POINTER(FluxFixRegion), i, pp]),
+        "apk_flux_fix_plan_create_merged": (i, [vp, C.POINTER(FluxFixRegion), C.POINTER(C.c_int), vp, C.c_int64, pp]),
         "apk_flux_fix_plan_destroy": (None, [vp]),
         "apk_flux_fix_plan_run": (i, [vp, vp, d, i, d, vp]),
         "apk_update_with_flux_divergence": (i, [vp, vp, vp, d, d, d, vp]),

@@ -452,6 +452,8 @@ def measured_traffic(workload):
         return None, None
     # round 2 / 3: the two-kernel stage (x3 sweep + finishing x1/x2 march); round 1: three sweeps
     for fname, stage, note in (
+            ("r05_hbm_traffic.json", ("fused_march_kernel<2, 3, 5, 3, false, 0, false>", "fused_m12f_kernel<2, 3, 5, 2, true, false>"),
+             "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, reads calibrated on the dt kernel's known bytes"),
             ("r04_hbm_traffic.json", ("fused_march_kernel<2, 3, 5, 3, false, 0, false>", "fused_m12f_kernel<2, 3, 5, 2, true, false>"),
              "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, reads calibrated on the dt kernel's known bytes"),
             ("r03_hbm_traffic.json", ("fused_march_kernel<2, 3, 5, 3, false, 0>", "fused_m12f_kernel<2, 3, 5, 2>"),
@@ -738,7 +740,11 @@ def main():
                 "dominant_timing_slot": dominant,
                 "whole_cycle": {"algorithmic_bytes_per_zone_cycle": b_cycle,
                                 "achieved": value / world * b_cycle / 1e9,
-                                "frac": value / world * b_cycle / 1e9 / HBM_PEAK_GBS},
+                                "frac": value / world * b_cycle / 1e9 / HBM_PEAK_GBS,
+                                "note": "SURVEY 8(d)'s per-zone-cycle bytes INCLUDING the ConsToPrim stores and re-reads of "
+                                        "the reference's cycle, which this cycle no longer performs where it can derive the "
+                                        "primitives in registers: a figure of how much reference traffic per second the cycle "
+                                        "stands for, NOT the north-star roofline fraction (that is `frac` / `general_stage.frac`)"},
             },
         }
         if sustained:

@@ -519,6 +519,15 @@ typedef struct apk_flux_fix_region {
 typedef struct apk_flux_fix_plan apk_flux_fix_plan;
 int apk_flux_fix_plan_create(apk_ctx *ctx, const apk_flux_fix_region *regions /* host */, int n,
                              apk_flux_fix_plan **out);
+/* The regions of up to three directions as ONE plan that runs in ONE launch: regions = direction 0's, then 1's, then
+ * 2's (n_by_dir).  A coarse cell on an edge of its block may lie next to two or three coarse-fine faces; the plans per
+ * direction correct it direction by direction, and so does this one: the region of the lowest direction that holds a
+ * cell applies the terms of all of them in that order (same additions, same order: bit-identical to the three plans
+ * run one after the other).  field_base / block_elems: the cell-shaped field [block][var][k][j][i] the regions' cons
+ * pointers point into and its elements per block.  APK_ERR_UNSUPPORTED if a region shares cells with more than 8
+ * others or is not laid out that way (the caller keeps one plan per direction). */
+int apk_flux_fix_plan_create_merged(apk_ctx *ctx, const apk_flux_fix_region *regions /* host */, const int n_by_dir[3],
+                                    const double *field_base, int64_t block_elems, apk_flux_fix_plan **out);
 void apk_flux_fix_plan_destroy(apk_flux_fix_plan *p);
 int apk_flux_fix_plan_run(apk_ctx *ctx, const apk_flux_fix_plan *p, double beta_dt, int psi_var,
                           double psi_factor, apk_stream_t stream);

@@ -384,3 +384,67 @@ def test_count_unphysical_matches_numpy(request, fluid):
         want = int(np.sum(~((u[:, 0] > 0) & (p > 0))))
     assert want >= len(bad)
     assert hydro.CountUnphysical(md, fluid) == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+def test_merged_flux_fix_plan_equals_the_plans_per_direction(request, strict):
+    """apk_flux_fix_plan_create_merged: the regions of all three directions in ONE launch.  Two blocks of 12^3 cells with
+    quarter-face regions (6 x 6 coarse cells, as one fine block behind a coarse face gives) on faces that meet along
+    edges and in corners: cells next to two or three corrected faces must receive ((u + d1) + d2) + d3, the result of the
+    three plans run one after the other, bit for bit; regions that only touch, and a block with a single face, ride along."""
+    import torch
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    rng = np.random.default_rng(77)
+    nvar, ng, nx = 9, 2, 12
+    n = nx + 2 * ng
+    cons0 = torch.from_numpy(rng.standard_normal((2, nvar, n, n, n))).cuda()
+    flux = [torch.from_numpy(rng.standard_normal((2, nvar, n, n, n))).cuda() for _ in range(3)]
+    lo, hi = ng, ng + nx - 1
+
+    def region(blk, d, side, a0, b0):
+        """the quarter (6 x 6 cells from (a0, b0) in the two transverse directions) of face `side` of direction d"""
+        sel = [slice(None)] * 4                                      # [var][k][j][i]
+        ax = 3 - d
+        cell = lo if side == 0 else hi
+        face = lo if side == 0 else hi + 1
+        t = [a for a in (3, 2, 1) if a != ax]                        # transverse axes, i first
+        csel, fsel = list(sel), list(sel)
+        csel[ax], fsel[ax] = slice(cell, cell + 1), slice(face, face + 1)
+        for a, o in zip(t, (a0, b0)):
+            csel[a] = fsel[a] = slice(lo + o, lo + o + 6)
+        csel, fsel = tuple(csel), tuple(fsel)
+        shape = cons0[blk][csel].shape
+        avg = torch.from_numpy(rng.standard_normal(tuple(shape))).cuda()
+        return (blk, d, csel, fsel, avg, (1.0 if side == 0 else -1.0) / (0.1 * (d + 1)))
+    spec = []
+    for d in range(3):                                               # block 0: the low faces of all three directions, all quarters
+        for a0 in (0, 6):
+            for b0 in (0, 6):
+                spec.append(region(0, d, 0, a0, b0))
+    spec.append(region(0, 0, 1, 6, 6))                               # ... and one quarter of the upper x1 face (meets x2 / x3 low? no: touches only)
+    spec.append(region(0, 1, 1, 0, 0))                               # upper x2 face, the quarter at low x1, low x3: meets the low x1 and x3 faces
+    spec.append(region(1, 2, 1, 6, 0))                               # block 1: a single region
+    spec.sort(key=lambda r: r[1])
+    n_by_dir = [sum(1 for r in spec if r[1] == d) for d in range(3)]
+
+    def regions_on(cons):
+        # (coarse flux views must share the cons views' strides: same-shaped parents)
+        return [(avg, flux[d][blk][fsel], cons[blk][csel], scale) for blk, d, csel, fsel, avg, scale in spec]
+    beta_dt, psi_factor = 0.013, 0.85
+    a = cons0.clone()
+    for d in range(3):
+        regs = [r for r, sp_ in zip(regions_on(a), spec) if sp_[1] == d]
+        hydro.FluxFixPlan(ctx, regs).run(beta_dt, psi_var=8, psi_factor=psi_factor)
+    b = cons0.clone()
+    hydro.FluxFixPlan(ctx, regions_on(b), merged=(n_by_dir, b)).run(beta_dt, psi_var=8, psi_factor=psi_factor)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    # the corner cell of block 0 got three terms, its edge neighbours two: not what a single term leaves
+    changed = (a != cons0)
+    assert changed[0, 0, lo, lo, lo] and int(changed.sum()) > 0
+    once = cons0.clone()
+    hydro.FluxFixPlan(ctx, [r for r, sp_ in zip(regions_on(once), spec) if sp_[1] == 0]).run(beta_dt, psi_var=8, psi_factor=psi_factor)
+    torch.cuda.synchronize()
+    assert not torch.equal(once[0, :, lo, lo, lo], a[0, :, lo, lo, lo])
