@@ -183,6 +183,14 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     // neighbours.  The stage runs at 94 % of the socket's 1400 W, so every lane-operation not executed counts.  (Masking
     // the x1 solve and the x2 reconstruction as well costs more in exec-mask bookkeeping than it saves: round 3.)
     const bool need_x2 = active;
+    // lanes whose x1 stencil (by wave shifts) is complete: the interface above the cell needs lanes l-1 .. l+2, the
+    // cell's states l-2 .. l+2 and the interface of lane l-1
+    // -- and whose values a retiring cell uses: the states of columns is-1 .. ie+1, the interfaces above is-2 .. ie+1.
+    // (x2: the lanes that retire a cell, need_x2.)
+    // As the threshold of PPM's extremum tests (hydro_math.hpp: kPpmNever), one register pair each.
+    const double x1_thr_face = opaque((lane >= 1 && lane <= 61 && in_run && i >= u0.is - 2 && i <= u0.ie + 1) ? 0.0 : kPpmNever);
+    const double x1_thr_cell = opaque((lane >= 2 && lane <= 61 && in_run && i >= u0.is - 1 && i <= u0.ie + 1) ? 0.0 : kPpmNever);
+    const double x2_thr = opaque(need_x2 ? 0.0 : kPpmNever);
     const double dx1 = b0.dx[0], dx2 = b0.dx[1];
     const double area1 = to_sgpr(b0.dx[1] * b0.dx[2]);  // (per block: wave-uniform)
     const double area2 = to_sgpr(b0.dx[0] * b0.dx[2]);
@@ -289,9 +297,12 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
           const double qm1 = lane_below<1>(q0, lane), qp1 = lane_above<1>(q0, lane);
           if constexpr (RECON == APK_RC_PPM) {
             const double qm2 = lane_below<2>(q0, lane), qp2 = lane_above<2>(q0, lane);
-            const double face_p = ppm_interface(qm1, q0, qp1, qp2);
+            // (the wave shifts hand lanes 0, 1, 62, 63 zeros for the neighbours they lack; their interface values and
+            // states are not used -- x1_thr_* -- and must not drag the wave through the limiter branches: with a zero
+            // in the stencil nearly every variable "has an extremum" there, in every row)
+            const double face_p = ppm_interface(qm1, q0, qp1, qp2, x1_thr_face);
             const double face_m = lane_below<1>(face_p, lane);
-            ppm_cell(qm2, qm1, q0, qp1, qp2, face_m, face_p, ql1[n], qr1[n]);
+            ppm_cell(qm2, qm1, q0, qp1, qp2, face_m, face_p, ql1[n], qr1[n], x1_thr_cell);
           } else if constexpr (H >= 2) {
             const double qm2 = lane_below<2>(q0, lane), qp2 = lane_above<2>(q0, lane);
             reconstruct<RECON>(qm2, qm1, q0, qp1, qp2, dx1, n, ql1[n], qr1[n]);
@@ -363,8 +374,8 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
         } else {
           const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
           if constexpr (RECON == APK_RC_PPM) {
-            const double face_p = ppm_interface(a1, a2, a3, Pn[n]);
-            ppm_cell(a0, a1, a2, a3, Pn[n], face_carry[n], face_p, qln[n], qrn[n]);
+            const double face_p = ppm_interface(a1, a2, a3, Pn[n], x2_thr);
+            ppm_cell(a0, a1, a2, a3, Pn[n], face_carry[n], face_p, qln[n], qrn[n], x2_thr);
             face_carry[n] = face_p;
           } else {
             reconstruct<RECON>(a0, a1, a2, a3, Pn[n], dx2, n, qln[n], qrn[n]);

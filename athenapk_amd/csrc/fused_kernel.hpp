@@ -384,9 +384,11 @@ fused_x1_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_plane) {
       // every limited interface value once: the lane computes the one above its cell and receives
       // the one below from the lane on its left (see ppm_interface); lane 0 has no left neighbour
       // and produces no valid state, which is why PPM waves retire lanes 2..62
-      const double face_p = ppm_interface(qm1, q0, qp1, qp2);
+      // (lanes that do not reconstruct hold a flat dummy stencil -- "an extremum" by the <= of the test -- and lane 0 a
+      // zero for the interface below it: neither may take the wave into the limiter branches)
+      const double face_p = ppm_interface(qm1, q0, qp1, qp2, do_recon ? 0.0 : kPpmNever);
       const double face_m = wave_shr1(face_p);
-      ppm_cell(qm2, qm1, q0, qp1, qp2, face_m, face_p, qln[n], qrn[n]);
+      ppm_cell(qm2, qm1, q0, qp1, qp2, face_m, face_p, qln[n], qrn[n], (do_recon && lane >= 1) ? 0.0 : kPpmNever);
     } else {
       reconstruct<RECON>(qm2, qm1, q0, qp1, qp2, dx, n, qln[n], qrn[n]);
     }
@@ -1540,16 +1542,19 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
         const int wpb_run = two_rows ? wpb2 : wpb;  // wave columns per block of the kernel that will run
         int kseg = (u0.nx3 >= 16) ? 8 : u0.nx3;  // measured on 8 x 128^3: 8 and 16 within 1 %, 64 is 12 % slower
         if (u0.nx3 >= 16 && (int64_t)wpb_run * ((u0.nx3 + 7) / 8) * u0.nblocks < 4 * 2048) {
-          // small packs (refined meshes of 16^3 blocks): the march waves run in a few rounds of the 2048 resident ones
-          // (2 per SIMD), so pick the segment length with the fewest plane-steps over all rounds -- a segment costs its
-          // planes plus about 1.5 for the prologue.  (Round 5: counted with the wave columns of the kernel that RUNS: the
-          // two-row march has 3 per 16^3 block where the one-row march has 5, and 232 blocks in segments of 6 planes --
-          // the one-row optimum -- were 2088 waves: a second round for 40 of them.  Segments of 8: 1392 waves, one round.)
+          // small packs (refined meshes of 16^3 blocks): a few waves per SIMD in all, so pick the segment length with
+          // the fewest plane-steps on the busiest SIMD -- a segment costs its planes plus about 1.5 for the prologue, a
+          // SIMD (1024 of them) works through ceil(waves / 1024) segments at the rate two resident waves share, and a
+          // wave that has its SIMD to itself runs 1.4 times as fast as one of a pair, not twice.  (Round 5: counted with
+          // the wave columns of the kernel that RUNS -- the two-row march has 3 per 16^3 block where the one-row march has
+          // 5 -- and per SIMD instead of per round of 2048 waves.  232 blocks of 16^3, two-row march, us per launch:
+          // segments of 4 planes 124, 8: 134, 6: 141, 16: 167 -- the order this estimate gives.)
           double best = 1.0e300;
           for (const int cand : {4, 6, 8, 16}) {
             if (cand > u0.nx3) continue;
             const int64_t waves = (int64_t)wpb_run * ((u0.nx3 + cand - 1) / cand) * u0.nblocks;
-            const double cost = (double)((waves + 2047) / 2048) * (cand + 1.5);
+            const double per_simd = waves <= 1024 ? 2.0 / 1.4 : (double)((waves + 1023) / 1024);
+            const double cost = per_simd * (cand + 1.5);
             if (cost < best) best = cost, kseg = cand;
           }
         }

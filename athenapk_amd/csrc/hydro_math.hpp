@@ -225,7 +225,14 @@ APK_DEV void plm(double qm1, double q0, double qp1, double &ql, double &qr) {
 //   ppm_cell(...)  steps 3 + 4 for one cell given its two limited interface values (:100-162).
 // A march keeps face_p of the cell it just reconstructed as face_m of the next one; the x1 sweep
 // passes it one lane to the right.
-APK_DEV double ppm_interface(double qm1, double q0, double qp1, double qp2) {
+// (thr: 0.0, the reference's test.  A lane whose stencil is not valid -- the outermost lanes of a wave that gets its x1
+// neighbours by wave shifts hold zeros there -- and whose value nothing uses passes kPpmNever = -inf: "product < -inf" keeps
+// it out of the extremum branch, which otherwise runs for the whole wave, in nearly every pencil, on behalf of such lanes
+// alone.  A per-lane constant in a register pair: the compare takes it instead of the literal 0, no instruction more --
+// as a boolean ANDed into the branch condition it cost scalar registers the marches do not have, as `take && ...` a
+// branch of its own per call.)
+constexpr double kPpmNever = -__builtin_inf();
+APK_DEV double ppm_interface(double qm1, double q0, double qp1, double qp2, double thr = 0.0) {
   // (Both builds evaluate the reference's grouping.  The algebraically equal 4-operation form
   // (7 (q_i + q_i+1) - (q_i-1 + q_i+2)) / 12 differs in the last bits, which is enough to flip the
   // extremum tests below on smooth data -- 3e-9 after two cycles of the 256^3 benchmark state, far
@@ -239,7 +246,7 @@ APK_DEV double ppm_interface(double qm1, double q0, double qp1, double qp2) {
   // the second differences and the limiter (one division) are evaluated inside that branch only
   const double below = face - q0;
   const double above = qp1 - face;
-  if (below * above < 0.0) {
+  if (below * above < thr) {
     constexpr double C2 = 1.25;
     const double d2_c = qm1 + qp1 - 2.0 * q0;
     const double d2_p = q0 + qp2 - 2.0 * qp1;
@@ -282,7 +289,7 @@ APK_DEV void ppm_cell_limited(double qm2, double qm1, double q0, double qp1, dou
   }
 }
 APK_DEV void ppm_cell(double qm2, double qm1, double q0, double qp1, double qp2, double face_m,
-                      double face_p, double &ql, double &qr) {
+                      double face_p, double &ql, double &qr, double thr = 0.0) {
   const double dminus = q0 - face_m;
   const double dplus = face_p - q0;
   const double ext_a = dminus * dplus;
@@ -291,7 +298,7 @@ APK_DEV void ppm_cell(double qm2, double qm1, double q0, double qp1, double qp2,
   // medium of a blast, every variable along x3 of a thin-z run -- out of the extremum set, where the limiter runs at full
   // width to no effect, was measured in round 5: the test costs the headline 3 - 4 % in either of two forms and buys
   // configs 3 and 5 nothing measurable; those kernels are not bound by their instruction count.)
-  const bool ext = ext_a <= 0.0 || ext_b <= 0.0;  // local extremum: CS limiter on the parabola
+  const bool ext = ext_a <= thr || ext_b <= thr;  // local extremum: CS limiter on the parabola
 
   double r = face_m, l = face_p;
   if (ext) {

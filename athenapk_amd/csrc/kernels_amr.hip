@@ -13,9 +13,14 @@
 
 // (merged plans, apk_flux_fix_plan_create_merged: the regions of all directions in ONE launch)
 struct FixRegionBox {
-  int lo[3];       // first cell of the region, as indices of the destination block's array
-  int dir;         // direction of the face the region corrects
-  int partner[8];  // other regions of the plan that share cells with this one (-1: none), lower directions first
+  int lo[3];  // first cell of the region, as indices of the destination block's array
+  int dir;    // direction of the face the region corrects
+  // the other regions of the plan that share cells with this one, lower directions first; their boxes ride along so that
+  // the test "is this cell theirs too" reads nothing else (a second record per partner made the launch latency-bound)
+  struct Partner {
+    int idx, dir;  // idx < 0: none
+    int lo[3], ext[3];
+  } partner[8];
 };
 struct apk_flux_fix_plan {
   apk_flux_fix_region *d_regions = nullptr;
@@ -277,7 +282,7 @@ __global__ void __launch_bounds__(256) flux_fix_kernel(const apk_flux_fix_region
 __global__ void __launch_bounds__(256) flux_fix_merged_kernel(const apk_flux_fix_region *regions, const FixRegionBox *boxes,
                                                               double beta_dt, int psi_var, double psi_factor) {
   const apk_flux_fix_region r = regions[blockIdx.x];
-  const FixRegionBox bx = boxes[blockIdx.x];
+  const FixRegionBox &bx = boxes[blockIdx.x];
   const int64_t cells = (int64_t)r.ext[0] * r.ext[1] * r.ext[2], items = cells * r.nvar;
   for (int64_t t = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; t < items; t += (int64_t)gridDim.y * blockDim.x) {
     const int v = (int)(t / cells);
@@ -293,16 +298,15 @@ __global__ void __launch_bounds__(256) flux_fix_merged_kernel(const apk_flux_fix
     int nlater = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int pi = bx.partner[q];  // (block-uniform; sorted by direction)
-      if (pi < 0) break;
-      const FixRegionBox pb = boxes[pi];
+      const FixRegionBox::Partner &pb = bx.partner[q];  // (block-uniform; sorted by direction)
+      if (pb.idx < 0) break;
       const int li = ci - pb.lo[0], lj = cj - pb.lo[1], lk = ck - pb.lo[2];
-      const apk_flux_fix_region *pr = regions + pi;
-      if (li < 0 || lj < 0 || lk < 0 || li >= pr->ext[0] || lj >= pr->ext[1] || lk >= pr->ext[2]) continue;
+      if (li < 0 || lj < 0 || lk < 0 || li >= pb.ext[0] || lj >= pb.ext[1] || lk >= pb.ext[2]) continue;
       if (pb.dir < bx.dir) {
         owner = false;  // the region of the lower direction applies this region's term too
         break;
       }
+      const apk_flux_fix_region *pr = regions + pb.idx;
       const int64_t pd = li * pr->dst_stride[0] + lj * pr->dst_stride[1] + lk * pr->dst_stride[2] + v * pr->dst_stride[3];
       if (nlater < 2) later[nlater++] = flux_fix_term(*pr, li, lj, lk, v, pd, beta_dt, psi_var, psi_factor);
     }
@@ -504,7 +508,7 @@ int apk_flux_fix_plan_create_merged(apk_ctx *ctx, const apk_flux_fix_region *reg
     const apk_flux_fix_region &r = regions[q];
     FixRegionBox &b = boxes[(size_t)q];
     b.dir = q < n_by_dir[0] ? 0 : (q < n_by_dir[0] + n_by_dir[1] ? 1 : 2);
-    for (int m = 0; m < 8; ++m) b.partner[m] = -1;
+    for (int m = 0; m < 8; ++m) b.partner[m] = FixRegionBox::Partner{-1, 0, {0, 0, 0}, {0, 0, 0}};
     // (cells of variable 0 of the block: offset = k * sk + j * sj + i)
     const int64_t off = r.cons - field_base;
     const int64_t sj = r.dst_stride[1], sk = r.dst_stride[2];
@@ -548,7 +552,13 @@ int apk_flux_fix_plan_create_merged(apk_ctx *ctx, const apk_flux_fix_region *reg
           *out = nullptr;
           return set_err(ctx, APK_ERR_UNSUPPORTED, "apk_flux_fix_plan_create_merged: more than 8 regions share cells with one");
         }
-        boxes[(size_t)qa].partner[np++] = qb;
+        FixRegionBox::Partner &pp = boxes[(size_t)qa].partner[np++];
+        pp.idx = qb;
+        pp.dir = boxes[(size_t)qb].dir;
+        for (int d = 0; d < 3; ++d) {
+          pp.lo[d] = boxes[(size_t)qb].lo[d];
+          pp.ext[d] = regions[qb].ext[d];
+        }
       }
     }
     x = y;

@@ -318,7 +318,12 @@ def load(strict=False):
                 "%s not found: run athenapk_amd.lib.build() / __graft_entry__.build() "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path)
         lib = C.CDLL(path)
+        # (APK_LIB_PATH: a profiling variant, possibly built from an older commit for a same-box comparison -- entry
+        # points it lacks are left unbound; the product library must export every declared symbol)
+        variant = bool(os.environ.get("APK_LIB_PATH")) and not strict
         for name, (res, args) in _signatures().items():
+            if variant and not hasattr(lib, name):
+                continue
             fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
