@@ -79,7 +79,8 @@ struct apk_ctx {
   double *h_partial_dev = nullptr;             // device address of h_partial
   unsigned long long *d_tagmax = nullptr;      // per-block criterion maxima of apk_tag_blocks (bit patterns), own buffer
   size_t tagmax_cap = 0;
-  bool dt_word_clean = false;                  // word 4 holds +max
+  bool dt_word_clean = false;                  // word 4 holds +max ...
+  hipStream_t clean_stream = nullptr;          // ... as of the gather enqueued on this stream (another stream: reset again)
   int tag_words_clean = 0;                     // the first n words of d_tagmax hold 0
   int tags_pending = 0;                        // criteria of this many blocks reduced, not yet in h_partial
   double *h_partial = nullptr;       // pinned host mirror of d_partial (per-block reductions read back every cycle)

@@ -93,7 +93,7 @@ __global__ void cycle_gather_kernel(unsigned long long *u64, unsigned long long 
 }  // namespace
 
 int prepare_dt_word(apk_ctx *ctx, hipStream_t s) {
-  if (!ctx->dt_word_clean) {
+  if (!ctx->dt_word_clean || ctx->clean_stream != s) {
     // +max (neutral element of the min), device to device so the launch path never blocks the host
     if (hipMemcpyAsync(ctx->d_u64 + 4, ctx->d_u64 + 15, sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess) return APK_ERR_DEVICE;
   }
@@ -108,6 +108,7 @@ int launch_cycle_gather(apk_ctx *ctx, hipStream_t s) {
                      ctx->d_tagmax, ctx->h_partial_dev, ntags);
   if (hipGetLastError() != hipSuccess) return APK_ERR_DEVICE;
   ctx->dt_word_clean = true;
+  ctx->clean_stream = s;
   if (ntags > 0) {
     ctx->tag_words_clean = ntags;
     ctx->tags_pending = 0;

@@ -1540,7 +1540,11 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
         const bool two_rows = lean && !sp.window && u0.nx2 % 2 == 0 && u0.nx2 >= 4;
         const int wpb2 = (int)(((int64_t)(u0.nx2 / 2) * (u0.nx1 + 2) + 61) / 62);
         const int wpb_run = two_rows ? wpb2 : wpb;  // wave columns per block of the kernel that will run
-        int kseg = (u0.nx3 >= 16) ? 8 : u0.nx3;  // measured on 8 x 128^3: 8 and 16 within 1 %, 64 is 12 % slower
+        // measured on 8 x 128^3 (round 5, two-row march from the conserved state, ms per cycle of the headline, same box):
+        // 6 planes 3.67 - 3.70, 8: 3.64 - 3.66, 12: 3.65, 16: 3.61 - 3.63, 32: 3.61 - 3.66 -- the predictor itself is
+        // fastest at 8 (1.07 against 1.08 / 1.16 ms at 16 / 32), but what it leaves of the power budget is clock for the
+        // two kernels after it (finishing march 1.85 -> 1.82 -> 1.76 ms): 16 is the cycle's optimum
+        int kseg = (u0.nx3 >= 32) ? 16 : ((u0.nx3 >= 16) ? 8 : u0.nx3);
         if (u0.nx3 >= 16 && (int64_t)wpb_run * ((u0.nx3 + 7) / 8) * u0.nblocks < 4 * 2048) {
           // small packs (refined meshes of 16^3 blocks): a few waves per SIMD in all, so pick the segment length with
           // the fewest plane-steps on the busiest SIMD -- a segment costs its planes plus about 1.5 for the prologue, a

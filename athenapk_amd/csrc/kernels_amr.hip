@@ -201,15 +201,17 @@ __global__ void __launch_bounds__(256) refine_ops_kernel(apk_refine_geom g, int 
   }
   const RefineDims r = refine_dims(g);
   const int e0 = op.hi[0] - op.lo[0] + 1, e1 = op.hi[1] - op.lo[1] + 1, e2 = op.hi[2] - op.lo[2] + 1;
-  const int64_t cells = (int64_t)e0 * e1 * e2, items = cells * nvar;
-  const int64_t end = (ch.first + (int64_t)kRefineChunkItems < items) ? ch.first + (int64_t)kRefineChunkItems : items;
-  for (int64_t t = (int64_t)ch.first + threadIdx.x; t < end; t += 256) {
+  // (32-bit index arithmetic: apk_refine_plan_create refuses boxes of 2^31 items or more, and the three 64-bit
+  // divisions per item made this kernel compute-bound on the 8^3 boxes of 16^3 blocks)
+  const unsigned cells = (unsigned)e0 * (unsigned)e1 * (unsigned)e2, items = cells * (unsigned)nvar;
+  const unsigned end = ((unsigned)ch.first + (unsigned)kRefineChunkItems < items) ? (unsigned)ch.first + (unsigned)kRefineChunkItems : items;
+  for (unsigned t = (unsigned)ch.first + threadIdx.x; t < end; t += 256u) {
     const int v = (int)(t / cells);
-    int64_t c = t - (int64_t)v * cells;
-    const int i = op.lo[0] + (int)(c % e0);
-    c /= e0;
-    const int j = op.lo[1] + (int)(c % e1);
-    const int k = op.lo[2] + (int)(c / e1);
+    unsigned c = t - (unsigned)v * cells;
+    const int i = op.lo[0] + (int)(c % (unsigned)e0);
+    c /= (unsigned)e0;
+    const int j = op.lo[1] + (int)(c % (unsigned)e1);
+    const int k = op.lo[2] + (int)(c / (unsigned)e1);
     if (op.kind == APK_RO_PROLONGATE) {
       if (r.DIM == 3) prolongate_cell<3>(g, r, op, v, k, j, i);
       else if (r.DIM == 2) prolongate_cell<2>(g, r, op, v, k, j, i);
@@ -283,14 +285,15 @@ __global__ void __launch_bounds__(256) flux_fix_merged_kernel(const apk_flux_fix
                                                               double beta_dt, int psi_var, double psi_factor) {
   const apk_flux_fix_region r = regions[blockIdx.x];
   const FixRegionBox &bx = boxes[blockIdx.x];
-  const int64_t cells = (int64_t)r.ext[0] * r.ext[1] * r.ext[2], items = cells * r.nvar;
-  for (int64_t t = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; t < items; t += (int64_t)gridDim.y * blockDim.x) {
+  // (32-bit index arithmetic: a merged plan's regions are faces of meshblocks, apk_flux_fix_plan_create_merged checks)
+  const unsigned cells = (unsigned)r.ext[0] * (unsigned)r.ext[1] * (unsigned)r.ext[2], items = cells * (unsigned)r.nvar;
+  for (unsigned t = blockIdx.y * blockDim.x + threadIdx.x; t < items; t += gridDim.y * blockDim.x) {
     const int v = (int)(t / cells);
-    int64_t c = t - (int64_t)v * cells;
-    const int i = (int)(c % r.ext[0]);
-    c /= r.ext[0];
-    const int j = (int)(c % r.ext[1]);
-    const int k = (int)(c / r.ext[1]);
+    unsigned c = t - (unsigned)v * cells;
+    const int i = (int)(c % (unsigned)r.ext[0]);
+    c /= (unsigned)r.ext[0];
+    const int j = (int)(c % (unsigned)r.ext[1]);
+    const int k = (int)(c / (unsigned)r.ext[1]);
     const int64_t d = i * r.dst_stride[0] + j * r.dst_stride[1] + k * r.dst_stride[2] + v * r.dst_stride[3];
     const int ci = bx.lo[0] + i, cj = bx.lo[1] + j, ck = bx.lo[2] + k;  // the cell in its block
     bool owner = true;
@@ -417,6 +420,7 @@ int apk_refine_plan_create(apk_ctx *ctx, const apk_refine_geom *geom, int nvar, 
     }
     max_items = cells * nvar > max_items ? cells * nvar : max_items;
   }
+  if (max_items >= ((int64_t)1 << 31)) return set_err(ctx, APK_ERR_UNSUPPORTED, "apk_refine_plan_create: a box of 2^31 items or more");
   apk_refine_plan *p = new (std::nothrow) apk_refine_plan();
   if (!p) return APK_ERR_INVALID;
   p->geom = *geom;
@@ -502,6 +506,11 @@ int apk_flux_fix_plan_create_merged(apk_ctx *ctx, const apk_flux_fix_region *reg
   int rc = apk_flux_fix_plan_create(ctx, regions, n, out);
   if (rc != APK_OK || n == 0) return rc;
   apk_flux_fix_plan *p = *out;
+  if (p->max_items >= ((int64_t)1 << 31)) {
+    apk_flux_fix_plan_destroy(p);
+    *out = nullptr;
+    return set_err(ctx, APK_ERR_UNSUPPORTED, "apk_flux_fix_plan_create_merged: a region of 2^31 items or more");
+  }
   std::vector<FixRegionBox> boxes((size_t)n);
   std::vector<int64_t> blk((size_t)n);
   for (int q = 0; q < n; ++q) {
@@ -637,7 +646,7 @@ int apk_tag_blocks_begin(apk_ctx *ctx, const apk_pack *md, int criterion, int *p
   }
   unsigned long long *d_max = ctx->d_tagmax;
   // (the gather at the end of the previous cycle left the words at zero: apk_ctx::tag_words_clean)
-  if (ctx->tag_words_clean < nb) APK_HIP_TRY(ctx, hipMemsetAsync(d_max, 0, sizeof(unsigned long long) * nb, s));
+  if (ctx->tag_words_clean < nb || ctx->clean_stream != s) APK_HIP_TRY(ctx, hipMemsetAsync(d_max, 0, sizeof(unsigned long long) * nb, s));
   ctx->tag_words_clean = 0;
   const int kchunks = (pv.nx3 >= 12 && nb < 4096) ? 3 : 1;
   const dim3 grid = rect_grid(pv.nx1 + 2, pv.nx2 + 2, nb * kchunks), block(64, 4, 1);

@@ -265,14 +265,20 @@ def other_workload(name, steps=4, warmup=2):
         for _ in range(warmup):
             sim.step()
         torch.cuda.synchronize()
-        sim.kernel_timing(True)
-        sim.read_kernel_timing()
         t0 = time.perf_counter()
         for _ in range(steps):
             sim.step()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        # per-kernel averages from a few more cycles with the in-library event timing on: two event records per launch
+        # are 10 % of the sub-millisecond cycles of the small workloads (config 3), so they stay out of the timed loop
+        sim.kernel_timing(True)
+        sim.read_kernel_timing()
+        for _ in range(max(2, steps // 2)):
+            sim.step()
+        torch.cuda.synchronize()
         timing = sim.read_kernel_timing()
+        sim.kernel_timing(False)
         info = sim.info
         per_kernel, stage_ms, b_stage, achieved, dominant = stage_figures(timing, fluid, integrator, int(info.zones_local), info.ndim)
         out = {"description": desc, "value": int(info.zones_total) * steps / dt, "unit": "cell-updates/s", "steps": steps,
