@@ -58,11 +58,6 @@ constexpr int m12_first_lane(int recon) { return recon_halfwidth(recon) + 1; }
 constexpr int m12_last_lane(int recon) { return 62 - recon_halfwidth(recon); }
 
 
-#ifndef APK_M12F_MASK_DEAD
-// A/B (round 5): 1 = the x1 Riemann solve and the x2 reconstruction under the execution mask of the lanes whose results are
-// used (energy, not instructions: the cycle runs at the clock the 1400 W cap allows)
-#define APK_M12F_MASK_DEAD 0
-#endif
 #ifndef APK_M12F_TIMING
 // 1 (diagnostic variant build, `make variant VAR=tm VARFLAGS=-DAPK_M12F_TIMING=1`): per-phase shader-clock sums of the
 // march, printed by launch_m12f.  Round 3, general PPM+HLLD stage with FillDerived + dt on 8 x 128^3: x1 reconstruction
@@ -186,7 +181,8 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     // Lanes that retire no cell (overlap lanes at the ends of the wave, ghost columns: 13 % of the lanes on 128^3 blocks)
     // sit out the x2 Riemann solve -- they only have to carry their column through the ring as the x1 stencil of their
     // neighbours.  The stage runs at 94 % of the socket's 1400 W, so every lane-operation not executed counts.  (Masking
-    // the x1 solve and the x2 reconstruction as well costs more in exec-mask bookkeeping than it saves: round 3.)
+    // the x1 solve and the x2 reconstruction as well costs more in exec-mask bookkeeping than it saves: round 3; again in
+    // round 5, when the cycle's clock had turned out to follow what its kernels leave of the power budget: +-0.3 %.)
     const bool need_x2 = active;
     // lanes whose x1 stencil (by wave shifts) is complete: the interface above the cell needs lanes l-1 .. l+2, the
     // cell's states l-2 .. l+2 and the interface of lane l-1
@@ -196,9 +192,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
     const double x1_thr_face = opaque((lane >= 1 && lane <= 61 && in_run && i >= u0.is - 2 && i <= u0.ie + 1) ? 0.0 : kPpmNever);
     const double x1_thr_cell = opaque((lane >= 2 && lane <= 61 && in_run && i >= u0.is - 1 && i <= u0.ie + 1) ? 0.0 : kPpmNever);
     const double x2_thr = opaque(need_x2 ? 0.0 : kPpmNever);
-#if APK_M12F_MASK_DEAD
-    const bool x1_face_needed = in_run && lane >= FIRST && lane <= LAST + 1 && i >= u0.is && i <= u0.ie + 1;
-#endif
+
     const double dx1 = b0.dx[0], dx2 = b0.dx[1];
     const double area1 = to_sgpr(b0.dx[1] * b0.dx[2]);  // (per block: wave-uniform)
     const double area2 = to_sgpr(b0.dx[0] * b0.dx[2]);
@@ -327,14 +321,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
           wl[q] = lane_below<1>(ql1[perm<1>(q)], lane);
           wr[q] = qr1[perm<1>(q)];
         }
-#if APK_M12F_MASK_DEAD
-        // (the faces a retiring cell uses: lanes 3 .. 61 on columns is .. ie + 1)
-#pragma unroll
-        for (int q = 0; q < NV; ++q) f1[q] = 0.0;
-        if (x1_face_needed) riemann<FLUID, RS>(wl, wr, sp.k, f1);
-#else
         riemann<FLUID, RS>(wl, wr, sp.k, f1);
-#endif
         double fup0 = 0.0;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
@@ -370,11 +357,6 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
       }
       if constexpr (FC) (void)cons_row_to_prim<FLUID>(sp, Pn);  // (every lane: the row goes into the ring as the x1 stencil of its neighbours)
       double qln[NV], qrn[NV];
-#if APK_M12F_MASK_DEAD
-#pragma unroll
-      for (int n = 0; n < NV; ++n) qln[n] = qrn[n] = 0.0;
-      if (need_x2)
-#endif
       {
       double an[NS];  // ring rows of the next variable (software-pipelined LDS reads)
 #pragma unroll
