@@ -518,6 +518,13 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
 //    lanes of the wave then run the limiter once for all of them and the owners read their results back; bit-exact --
 //    was built for the x3 sweep and measured: 0.809 against 0.770 ms.  Ballots, rank computation, the staging writes
 //    and the second pass cost more than the seven-odd masked executions of the ~60-instruction branch they replace;
+//    (Round 5, in this kernel, after the dead lanes had left the branches: the limiter of ppm_cell DEFERRED -- a lane parks
+//    the seven operands of the variable that needs it under its own execution mask, eight moves in a region only entered
+//    when some lane has an extremum there, and ONE masked pass per direction limits all pending items; 255 VGPRs, no
+//    scratch, bit-exact: 667 -> 643 M vector instructions per launch, 49.0 -> 52.4 live lanes, but +20 % scalar
+//    instructions and +44 % branches: 1.764 -> 1.748 ms on average over four same-box pairs, the cycle -0.3 %, the general
+//    stage +0.3 %.  The limiter blocks that are entered for real extrema cost less than their static size suggested;
+//    not kept.)
 //  * PPM without divergent branches (the extremum limiters of ppm_interface / ppm_cell evaluated by every lane and
 //    selected, one scheduling pin per variable so that nothing spills): x3 sweep 0.76 -> 0.93 ms, this kernel 2.31 ->
 //    2.55 ms.  The masked branches are CHEAP: an instruction with one or two live lanes does not cost a full wave's
