@@ -389,6 +389,11 @@ int apk_cons_to_prim(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos 
 }
 
 int apk_cons_to_prim_dt(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, int ghost_depth, apk_stream_t stream) {
+  return apk_cons_to_prim_dt_skip(ctx, md, fluid, eos, ghost_depth, nullptr, stream);
+}
+
+int apk_cons_to_prim_dt_skip(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, int ghost_depth, const int *face_neighbor,
+                             apk_stream_t stream) {
   if (!ctx || !md || !valid_eos(eos) || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||
       md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9))
     return set_err(ctx, APK_ERR_INVALID, "apk_cons_to_prim_dt: bad argument");
@@ -396,7 +401,7 @@ int apk_cons_to_prim_dt(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_e
   unsigned long long *dt_bits = ctx->d_u64 + 4;  // the stage's word: apk_stage_dt_read / apk_stage_dt_flags_read
   if (apk::prepare_dt_word(ctx, s) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "time-step word reset", hipGetLastError());
   ScopedTiming timing(ctx, APK_T_C2P, s);
-  int rc = launch_cons_to_prim(md->view, fluid, *eos, ctx->d_flags, s, false, nullptr, 0, false, nullptr, dt_bits, ghost_depth);
+  int rc = launch_cons_to_prim(md->view, fluid, *eos, ctx->d_flags, s, false, nullptr, 0, false, face_neighbor, dt_bits, ghost_depth);
   if (rc != APK_OK) return set_err(ctx, rc, "cons_to_prim kernel launch failed", hipGetLastError());
   return APK_OK;
 }

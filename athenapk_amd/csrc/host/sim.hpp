@@ -220,6 +220,7 @@ struct apk_sim {
     // layers: every ghost zone, edges and corners too, but only that deep (BuildAmrPlans(fill_depth))
     std::vector<apk::AmrRefOp> prolongate_shell;
     std::vector<apk::BoxRegion> fill_shell, fill_pack_shell, fill_unpack_shell, fine_bc_shell[3];
+    std::vector<apk::BoxRegion> fill_shell_direct;  // fill_shell without the same-level face copies
   } amr_local;
   struct MsgSet {
     apk::AmrMessages plan;
@@ -256,6 +257,10 @@ struct apk_sim {
     apk_copy_plan *fill_shell[2] = {nullptr, nullptr}, *fill_pack_shell[2] = {nullptr, nullptr}, *fill_unpack_shell[2] = {nullptr, nullptr};
     apk_copy_plan *fine_bc_shell[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     void *xchg_pre_shell[2] = {nullptr, nullptr}, *xchg_post_shell[2] = {nullptr, nullptr};
+    // the shell exchange without the same-rank same-level face copies (AMR_XCHG_SHELL_DIRECT: the tag kernel, ConsToPrim
+    // and the next predictor follow the face table there)
+    apk_copy_plan *fill_shell_direct[2] = {nullptr, nullptr};
+    void *xchg_pre_shell_direct[2] = {nullptr, nullptr};
     apk_flux_fix_plan *flux_fix[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     apk_flux_fix_plan *flux_fix_all[2] = {nullptr, nullptr}, *flux_fix_unpack_all[2] = {nullptr, nullptr};  // all directions in one launch
     // the faces (6 * local block + face) with a coarser or finer block behind them: the only boundary-plane

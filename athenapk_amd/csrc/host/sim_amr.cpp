@@ -89,6 +89,8 @@ void amr_localize(apk_sim *s) {
     BuildAmrPlans(*s->amr, s->amr_geom, shell, AMR_SHELL_DEPTH);
     AmrRegisterPeers(shell.fill, part, part, rank, s->amr_halo_shell.plan);
     AmrLocalize(shell.fill, part, part, rank, s->amr_halo_shell.plan, l.fill_shell, l.fill_pack_shell, l.fill_unpack_shell);
+    for (const BoxRegion &r : l.fill_shell)
+      if (!r.same_face) l.fill_shell_direct.push_back(r);
     take_ops(shell.prolongate, l.prolongate_shell);
     for (int d = 0; d < 3; ++d) take_bc(shell.fine_bc[d], l.fine_bc_shell[d]);
   }
@@ -279,6 +281,8 @@ void amr_destroy_device_plans(apk_sim *s) {
     for (apk_refine_plan *p : a.prolongate_shell[par]) apk_refine_plan_destroy(p);
     a.prolongate_shell[par].clear();
     apk_copy_plan_destroy(a.fill_shell[par]);
+    apk_copy_plan_destroy(a.fill_shell_direct[par]);
+    a.fill_shell_direct[par] = nullptr;
     apk_copy_plan_destroy(a.fill_pack_shell[par]);
     apk_copy_plan_destroy(a.fill_unpack_shell[par]);
     a.fill_shell[par] = a.fill_pack_shell[par] = a.fill_unpack_shell[par] = nullptr;
@@ -481,6 +485,7 @@ int amr_rebuild(apk_sim *s) {
     if (amr_has_shell(s)) {
       SIM_TRY(s, amr_make_refine_plans(s, par, p.prolongate_shell, a.prolongate_shell[par]));
       SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_shell, nullptr, &a.fill_shell[par]));
+      SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_shell_direct, nullptr, &a.fill_shell_direct[par]));
       SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_pack_shell, &s->amr_halo_shell, &a.fill_pack_shell[par]));
       SIM_TRY(s, amr_make_copy_plan(s, par, p.fill_unpack_shell, &s->amr_halo_shell, &a.fill_unpack_shell[par]));
       for (int d = 0; d < 3; ++d) SIM_TRY(s, amr_make_copy_plan(s, par, p.fine_bc_shell[d], nullptr, &a.fine_bc_shell[par][d]));
@@ -549,6 +554,7 @@ int amr_rebuild(apk_sim *s) {
     amr_capture_half(s, par, true, 2, &a.xchg_pre_direct[par]);
     if (amr_has_shell(s)) {
       amr_capture_half(s, par, true, AMR_XCHG_SHELL, &a.xchg_pre_shell[par]);
+      amr_capture_half(s, par, true, AMR_XCHG_SHELL_DIRECT, &a.xchg_pre_shell_direct[par]);
       amr_capture_half(s, par, false, AMR_XCHG_SHELL, &a.xchg_post_shell[par]);
     }
   }
@@ -565,9 +571,9 @@ bool amr_has_shell(const apk_sim *s) { return s->amr_geom.ng > AMR_SHELL_DEPTH; 
 int amr_exchange_pre(apk_sim *s, int buf, int mode) {
   auto &a = s->amr_dev;
   for (apk_refine_plan *p : a.restrict_own[buf]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
-  if (mode == AMR_XCHG_SHELL) {
+  if (mode == AMR_XCHG_SHELL || mode == AMR_XCHG_SHELL_DIRECT) {
     SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fill_pack_shell[buf], s->stream));
-    return apk_copy_plan_run(s->ctx, a.fill_shell[buf], s->stream);
+    return apk_copy_plan_run(s->ctx, mode == AMR_XCHG_SHELL_DIRECT ? a.fill_shell_direct[buf] : a.fill_shell[buf], s->stream);
   }
   const bool faces = mode != AMR_XCHG_FULL;
   SIM_TRY(s, apk_copy_plan_run(s->ctx, faces ? a.fill_pack_faces[buf] : a.fill_pack[buf], s->stream));
@@ -576,7 +582,7 @@ int amr_exchange_pre(apk_sim *s, int buf, int mode) {
 }
 int amr_exchange_post(apk_sim *s, int buf, int mode) {
   auto &a = s->amr_dev;
-  if (mode == AMR_XCHG_SHELL) {
+  if (mode == AMR_XCHG_SHELL || mode == AMR_XCHG_SHELL_DIRECT) {
     SIM_TRY(s, apk_copy_plan_run(s->ctx, a.fill_unpack_shell[buf], s->stream));
     for (int d = 0; d < 3; ++d) SIM_TRY(s, apk_copy_plan_run(s->ctx, a.coarse_bc[buf][d], s->stream));
     for (apk_refine_plan *p : a.prolongate_shell[buf]) SIM_TRY(s, apk_refine_plan_run(s->ctx, p, s->stream));
@@ -631,6 +637,8 @@ void amr_destroy_graphs(apk_sim *s) {
     if (a.xchg_post_faces[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_post_faces[buf]));
     if (a.xchg_pre_direct[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_pre_direct[buf]));
     if (a.xchg_pre_shell[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_pre_shell[buf]));
+    if (a.xchg_pre_shell_direct[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_pre_shell_direct[buf]));
+    a.xchg_pre_shell_direct[buf] = nullptr;
     if (a.xchg_post_shell[buf]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(a.xchg_post_shell[buf]));
     a.xchg_pre[buf] = a.xchg_post[buf] = a.xchg_pre_faces[buf] = a.xchg_post_faces[buf] = a.xchg_pre_direct[buf] = nullptr;
     a.xchg_pre_shell[buf] = a.xchg_post_shell[buf] = nullptr;
@@ -645,18 +653,21 @@ void amr_destroy_graphs(apk_sim *s) {
 // in the messages).
 int amr_exchange(apk_sim *s, int buf, int mode) {
   auto &a = s->amr_dev;
-  if (mode == AMR_XCHG_SHELL && !amr_has_shell(s)) mode = AMR_XCHG_FULL;
+  if ((mode == AMR_XCHG_SHELL || mode == AMR_XCHG_SHELL_DIRECT) && !amr_has_shell(s)) mode = AMR_XCHG_FULL;
   const bool faces = mode == AMR_XCHG_FACES || mode == AMR_XCHG_DIRECT;
-  void *pre = mode == AMR_XCHG_SHELL ? a.xchg_pre_shell[buf]
+  const bool shell = mode == AMR_XCHG_SHELL || mode == AMR_XCHG_SHELL_DIRECT;
+  void *pre = mode == AMR_XCHG_SHELL_DIRECT ? a.xchg_pre_shell_direct[buf]
+              : mode == AMR_XCHG_SHELL ? a.xchg_pre_shell[buf]
               : mode == AMR_XCHG_DIRECT ? a.xchg_pre_direct[buf] : (faces ? a.xchg_pre_faces[buf] : a.xchg_pre[buf]);
-  void *post = mode == AMR_XCHG_SHELL ? a.xchg_post_shell[buf] : (faces ? a.xchg_post_faces[buf] : a.xchg_post[buf]);
+  void *post = shell ? a.xchg_post_shell[buf] : (faces ? a.xchg_post_faces[buf] : a.xchg_post[buf]);
   if (pre) SIM_HIP(s, hipGraphLaunch(static_cast<hipGraphExec_t>(pre), hs(s)));
   else SIM_TRY(s, amr_exchange_pre(s, buf, mode));
-  SIM_TRY(s, amr_exchange_messages(s, mode == AMR_XCHG_SHELL ? s->amr_halo_shell : (faces ? s->amr_halo_faces : s->amr_halo)));
+  SIM_TRY(s, amr_exchange_messages(s, shell ? s->amr_halo_shell : (faces ? s->amr_halo_faces : s->amr_halo)));
   if (post) SIM_HIP(s, hipGraphLaunch(static_cast<hipGraphExec_t>(post), hs(s)));
   else SIM_TRY(s, amr_exchange_post(s, buf, mode));
   // (of cons; the caller converts to primitives)
-  s->amr_ghost_state = mode == AMR_XCHG_FULL ? AMR_GHOSTS_COMPLETE : (mode == AMR_XCHG_SHELL ? AMR_GHOSTS_SHELL : AMR_GHOSTS_FACES);
+  s->amr_ghost_state = mode == AMR_XCHG_FULL ? AMR_GHOSTS_COMPLETE
+                       : (mode == AMR_XCHG_SHELL ? AMR_GHOSTS_SHELL : (mode == AMR_XCHG_SHELL_DIRECT ? AMR_GHOSTS_SHELL_DIRECT : AMR_GHOSTS_FACES));
   return APK_OK;
 }
 
@@ -922,9 +933,12 @@ int amr_tags_begin(apk_sim *s, AmrTagRequest *req) {
   // behind edges and corners included, which the stage loop's faces-only exchange leaves stale.  The last
   // stage of a checking cycle exchanges in full or AMR_SHELL_DEPTH (= the criteria's reach) layers deep (do_stage),
   // so this is a no-op there; it is what covers apk_sim_regrid / apk_sim_check_refinement between cycles.
+  // (AMR_GHOSTS_SHELL_DIRECT: the shell without the zones behind same-level same-rank faces -- the tag kernel reads those
+  // cells from the neighbours' interiors through the face table, as the stages do)
   if (s->amr_ghost_state == AMR_GHOSTS_FACES) SIM_TRY(s, sync_ghosts(s));
   SIM_TRY(s, refinement_criterion(s, &req->criterion, &req->p0, &req->p1));
-  SIM_TRY(s, apk_tag_blocks_begin(s->ctx, s->mu0(), req->criterion, &req->pending, s->stream));
+  const int *table = s->amr_ghost_state == AMR_GHOSTS_SHELL_DIRECT ? s->d_face_nbr : nullptr;
+  SIM_TRY(s, apk_tag_blocks_begin_skip(s->ctx, s->mu0(), req->criterion, table, &req->pending, s->stream));
   return APK_OK;
 }
 

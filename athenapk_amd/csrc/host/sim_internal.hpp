@@ -119,8 +119,8 @@ void amr_free_buffers(apk_sim *s, apk_sim::MsgSet &m);
 int amr_exchange_messages(apk_sim *s, const apk_sim::MsgSet &m);
 int amr_allocate(apk_sim *s, size_t n, double *cons2[2], double **prim, double *flux[3], double **coarse);
 int amr_rebuild(apk_sim *s);
-enum { AMR_XCHG_FULL = 0, AMR_XCHG_FACES = 1, AMR_XCHG_DIRECT = 2, AMR_XCHG_SHELL = 3 };  // which ghost zones the multilevel exchange fills
-enum { AMR_GHOSTS_COMPLETE = 0, AMR_GHOSTS_SHELL = 1, AMR_GHOSTS_FACES = 2 };  // apk_sim::amr_ghost_state
+enum { AMR_XCHG_FULL = 0, AMR_XCHG_FACES = 1, AMR_XCHG_DIRECT = 2, AMR_XCHG_SHELL = 3, AMR_XCHG_SHELL_DIRECT = 4 };  // which ghost zones the multilevel exchange fills
+enum { AMR_GHOSTS_COMPLETE = 0, AMR_GHOSTS_SHELL = 1, AMR_GHOSTS_FACES = 2, AMR_GHOSTS_SHELL_DIRECT = 3 };  // apk_sim::amr_ghost_state
 constexpr int AMR_SHELL_DEPTH = 2;  // ghost layers of the shell exchange (refinement/gradient.cpp:33-36 reads [s-2, e+2]^3)
 int amr_exchange(apk_sim *s, int buf, int mode = AMR_XCHG_FULL);
 bool amr_direct(const apk_sim *s);

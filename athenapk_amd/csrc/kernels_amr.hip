@@ -323,8 +323,11 @@ __global__ void __launch_bounds__(256) flux_fix_merged_kernel(const apk_flux_fix
 // ---- tagging ---------------------------------------------------------------------------------
 // one workgroup row per (block, k-plane chunk); the criteria are non-negative, so their bit
 // patterns order like unsigned integers and one atomicMax per workgroup suffices
+// face_nbr (apk_stage_args.face_neighbor's table, or null): a ghost cell straight behind a face whose entry is >= 0 is
+// read from that neighbour's interior instead -- the exchange in front of the check then leaves those zones out, as the
+// stage loop's does (same values: the cells the copy would have brought).
 template <int CRIT>
-__global__ void __launch_bounds__(256) tag_kernel(PackView pv, unsigned long long *block_max, int kchunks) {
+__global__ void __launch_bounds__(256) tag_kernel(PackView pv, unsigned long long *block_max, int kchunks, const int *face_nbr) {
   const int b = blockIdx.z / kchunks;
   const int chunk = blockIdx.z - b * kchunks;
   const apk_block_desc blk = pv.blocks[b];
@@ -347,28 +350,75 @@ __global__ void __launch_bounds__(256) tag_kernel(PackView pv, unsigned long lon
   // of 18 dependent plane-steps otherwise; the block's maximum is an atomicMax either way)
   const int klen = (ku - kl + kchunks) / kchunks;
   const int k0 = kl + chunk * klen, k1 = (k0 + klen - 1 < ku) ? k0 + klen - 1 : ku;
+  // (the six neighbours' arrays once per thread: a descriptor load per access made the kernel twice as slow)
+  const double *nbp0 = nullptr, *nbp1 = nullptr, *nbp2 = nullptr, *nbp3 = nullptr, *nbp4 = nullptr, *nbp5 = nullptr;
+  if (face_nbr) {
+    const int *fn = face_nbr + 6 * b;
+    if (fn[0] >= 0) nbp0 = pv.blocks[fn[0]].prim;
+    if (fn[1] >= 0) nbp1 = pv.blocks[fn[1]].prim;
+    if (fn[2] >= 0) nbp2 = pv.blocks[fn[2]].prim;
+    if (fn[3] >= 0) nbp3 = pv.blocks[fn[3]].prim;
+    if (fn[4] >= 0) nbp4 = pv.blocks[fn[4]].prim;
+    if (fn[5] >= 0) nbp5 = pv.blocks[fn[5]].prim;
+  }
+  // primitive `var` of cell (kk, jj, ii): the block's own array, or the interior of the block behind the one face the
+  // cell lies behind
+  auto at = [&](int var, int kk, int jj, int ii) -> double {
+    const double *base = blk.prim;
+    if (face_nbr) {
+      const int gi = (ii < pv.is) ? 1 : ((ii > pv.ie) ? 2 : 0), gj = (jj < pv.js) ? 1 : ((jj > pv.je) ? 2 : 0),
+                gk = (kk < pv.ks) ? 1 : ((kk > pv.ke) ? 2 : 0);
+      if ((gi != 0) + (gj != 0) + (gk != 0) == 1) {
+        const int f = gi ? gi - 1 : (gj ? 1 + gj : 3 + gk);
+        const double *nb = (f == 0) ? nbp0 : (f == 1) ? nbp1 : (f == 2) ? nbp2 : (f == 3) ? nbp3 : (f == 4) ? nbp4 : nbp5;
+        if (nb) {
+          base = nb;
+          if (gi) ii += (gi == 1) ? pv.nx1 : -pv.nx1;
+          if (gj) jj += (gj == 1) ? pv.nx2 : -pv.nx2;
+          if (gk) kk += (gk == 1) ? pv.nx3 : -pv.nx3;
+        }
+      }
+    }
+    return base[var * pv.sn + kk * pv.sk + jj * pv.sj + ii];
+  };
   if (inside && i <= iu && j <= ju) {
     for (int k = k0; k <= k1; ++k) {
       const int64_t c = k * pv.sk + j * pv.sj + i;
+      // (cells whose stencil stays inside the block's own interior: plain pointer arithmetic)
+      const bool deep = !face_nbr || (i > pv.is && i < pv.ie && j > pv.js && j < pv.je && (ndim < 3 || (k > pv.ks && k < pv.ke)));
       if (CRIT == APK_TAG_PRESSURE_GRADIENT) {
-        const double *p = blk.prim + IPR * pv.sn + c;
-        const double a = 0.5 * (p[1] - p[-1]), bb = 0.5 * (p[pv.sj] - p[-pv.sj]);
+        double a, bb, cc = 0.0, p0;
+        if (deep) {
+          const double *p = blk.prim + IPR * pv.sn + c;
+          a = 0.5 * (p[1] - p[-1]), bb = 0.5 * (p[pv.sj] - p[-pv.sj]);
+          if (ndim == 3) cc = 0.5 * (p[pv.sk] - p[-pv.sk]);
+          p0 = p[0];
+        } else {
+          a = 0.5 * (at(IPR, k, j, i + 1) - at(IPR, k, j, i - 1)), bb = 0.5 * (at(IPR, k, j + 1, i) - at(IPR, k, j - 1, i));
+          if (ndim == 3) cc = 0.5 * (at(IPR, k + 1, j, i) - at(IPR, k - 1, j, i));
+          p0 = at(IPR, k, j, i);
+        }
         double eps;
         if (ndim == 3) {
-          const double cc = 0.5 * (p[pv.sk] - p[-pv.sk]);
-          eps = sqrt(sqr(a) + sqr(bb) + sqr(cc)) / p[0];
+          eps = sqrt(sqr(a) + sqr(bb) + sqr(cc)) / p0;
         } else {
-          eps = sqrt(sqr(a) + sqr(bb)) / p[0];
+          eps = sqrt(sqr(a) + sqr(bb)) / p0;
         }
         m = fmax(m, eps);
       } else if (CRIT == APK_TAG_VELOCITY_GRADIENT) {
-        const double *v1 = blk.prim + IV1 * pv.sn + c, *v2 = blk.prim + IV2 * pv.sn + c;
-        const double vgy = fabs(v2[1] - v2[-1]) * 0.5;
-        const double vgx = fabs(v1[pv.sj] - v1[-pv.sj]) * 0.5;
+        double vgy, vgx;
+        if (deep) {
+          const double *v1 = blk.prim + IV1 * pv.sn + c, *v2 = blk.prim + IV2 * pv.sn + c;
+          vgy = fabs(v2[1] - v2[-1]) * 0.5;
+          vgx = fabs(v1[pv.sj] - v1[-pv.sj]) * 0.5;
+        } else {
+          vgy = fabs(at(IV2, k, j, i + 1) - at(IV2, k, j, i - 1)) * 0.5;
+          vgx = fabs(at(IV1, k, j + 1, i) - at(IV1, k, j - 1, i)) * 0.5;
+        }
         const double vg = sqrt(vgx * vgx + vgy * vgy);
         if (vg > m) m = vg;
       } else {
-        m = fmax(m, blk.prim[IDN * pv.sn + c]);
+        m = fmax(m, deep ? blk.prim[IDN * pv.sn + c] : at(IDN, k, j, i));
       }
     }
   }
@@ -614,6 +664,11 @@ int apk_flux_fix_plan_run(apk_ctx *ctx, const apk_flux_fix_plan *p, double beta_
 // pinned host memory; nothing is waited for.  *pending = 0 when there is nothing to read (1-D
 // pressure gradient: "same" everywhere).
 int apk_tag_blocks_begin(apk_ctx *ctx, const apk_pack *md, int criterion, int *pending, apk_stream_t stream) {
+  return apk_tag_blocks_begin_skip(ctx, md, criterion, nullptr, pending, stream);
+}
+
+int apk_tag_blocks_begin_skip(apk_ctx *ctx, const apk_pack *md, int criterion, const int *face_neighbor, int *pending,
+                              apk_stream_t stream) {
   if (!ctx || !md || !pending || criterion < APK_TAG_PRESSURE_GRADIENT || criterion > APK_TAG_MAX_DENSITY)
     return set_err(ctx, APK_ERR_INVALID, "apk_tag_blocks: bad argument");
   const PackView &pv = md->view;
@@ -651,11 +706,11 @@ int apk_tag_blocks_begin(apk_ctx *ctx, const apk_pack *md, int criterion, int *p
   const int kchunks = (pv.nx3 >= 12 && nb < 4096) ? 3 : 1;
   const dim3 grid = rect_grid(pv.nx1 + 2, pv.nx2 + 2, nb * kchunks), block(64, 4, 1);
   if (criterion == APK_TAG_PRESSURE_GRADIENT)
-    hipLaunchKernelGGL(tag_kernel<APK_TAG_PRESSURE_GRADIENT>, grid, block, 0, s, pv, d_max, kchunks);
+    hipLaunchKernelGGL(tag_kernel<APK_TAG_PRESSURE_GRADIENT>, grid, block, 0, s, pv, d_max, kchunks, face_neighbor);
   else if (criterion == APK_TAG_VELOCITY_GRADIENT)
-    hipLaunchKernelGGL(tag_kernel<APK_TAG_VELOCITY_GRADIENT>, grid, block, 0, s, pv, d_max, kchunks);
+    hipLaunchKernelGGL(tag_kernel<APK_TAG_VELOCITY_GRADIENT>, grid, block, 0, s, pv, d_max, kchunks, face_neighbor);
   else
-    hipLaunchKernelGGL(tag_kernel<APK_TAG_MAX_DENSITY>, grid, block, 0, s, pv, d_max, kchunks);
+    hipLaunchKernelGGL(tag_kernel<APK_TAG_MAX_DENSITY>, grid, block, 0, s, pv, d_max, kchunks, face_neighbor);
   if (ctx->h_pinned_dev && ctx->h_partial_dev) {
     // the criteria ride to the host with the time-step word (apk_stage_dt_flags_read's gather kernel) if the caller
     // reads that next -- the driver does --, else apk_tag_blocks_end fetches them

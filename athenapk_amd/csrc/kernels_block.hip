@@ -178,16 +178,35 @@ APK_DEV void block_min_to_word(double lane_min, unsigned long long *word) {
 // registers -- the values min_dt_kernel would read back -- reduced into *dt_bits (apk_cons_to_prim_dt).
 template <int FLUID, bool WITH_DT>
 __global__ void __launch_bounds__(256)
-cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags, unsigned long long *dt_bits, int depth) {
-  int i, j;
-  bool ok = rect_ij(pv.ni, pv.nj, i, j);
-  if (!WITH_DT && !ok) return;
-  const int b = blockIdx.z / pv.nk;
-  const int k = blockIdx.z % pv.nk;
-  // depth >= 0: only the cells within that many layers of the interior (the shell a shallow ghost exchange has filled)
-  if (WITH_DT && depth >= 0)
-    ok = ok && i >= pv.is - depth && i <= pv.ie + depth && (pv.ndim < 2 || (j >= pv.js - depth && j <= pv.je + depth)) &&
-         (pv.ndim < 3 || (k >= pv.ks - depth && k <= pv.ke + depth));
+cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags, unsigned long long *dt_bits, int depth, const int *face_nbr) {
+  // depth >= 0: only the cells within that many layers of the interior (the shell a shallow ghost exchange has filled) --
+  // the launch covers that box, cell after cell (16^3 blocks with four ghost layers, depth 2: 20^3 of 24^3 cells, 32
+  // workgroups a block instead of 72)
+  const bool boxed = WITH_DT && depth >= 0;
+  int i, j, k, b;
+  bool ok;
+  if (boxed) {
+    const int ei = pv.nx1 + 2 * depth, ej = (pv.ndim >= 2) ? pv.nx2 + 2 * depth : pv.nj, ek = (pv.ndim >= 3) ? pv.nx3 + 2 * depth : pv.nk;
+    const unsigned f = blockIdx.y * 256u + threadIdx.y * 64u + threadIdx.x, plane = (unsigned)(ei * ej);
+    const unsigned kk = f / plane, r = f - kk * plane, jj = r / (unsigned)ei;
+    ok = kk < (unsigned)ek;
+    i = pv.is - depth + (int)(r - jj * (unsigned)ei);
+    j = ((pv.ndim >= 2) ? pv.js - depth : 0) + (int)jj;
+    k = ((pv.ndim >= 3) ? pv.ks - depth : 0) + (int)kk;
+    b = blockIdx.z;
+  } else {
+    ok = rect_ij(pv.ni, pv.nj, i, j);
+    if (!WITH_DT && !ok) return;
+    b = blockIdx.z / pv.nk;
+    k = blockIdx.z % pv.nk;
+  }
+  if (WITH_DT && face_nbr) {  // (a ghost zone behind a face its readers cross by the face table: left as it is)
+    const int *fn = face_nbr + 6 * b;  // (block-uniform: scalar loads, next to the descriptor's)
+    const int f0 = fn[0], f1 = fn[1], f2 = fn[2], f3 = fn[3], f4 = fn[4], f5 = fn[5];
+    const int ghost = ((i < pv.is) || (i > pv.ie)) + ((j < pv.js) || (j > pv.je)) + ((k < pv.ks) || (k > pv.ke));
+    const int nb = (i < pv.is) ? f0 : (i > pv.ie) ? f1 : (j < pv.js) ? f2 : (j > pv.je) ? f3 : (k < pv.ks) ? f4 : f5;
+    if (ghost == 1 && nb >= 0) ok = false;
+  }
   double lane_min = 1.7976931348623157e308;
   if (ok) {
     const apk_block_desc blk = pv.blocks[b];
@@ -616,7 +635,13 @@ int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsig
                          late_regions, part);
     return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
   }
-  const dim3 grid = rect_grid(pv.ni, pv.nj, pv.nk * pv.nblocks);
+  dim3 grid = rect_grid(pv.ni, pv.nj, pv.nk * pv.nblocks);
+  if (depth >= pv.ng) depth = -1;  // (the whole block)
+  if (!faces_only && dt_bits && depth >= 0) {  // (cons_to_prim_kernel's box)
+    const int64_t cells = (int64_t)(pv.nx1 + 2 * depth) * (pv.ndim >= 2 ? pv.nx2 + 2 * depth : pv.nj) * (pv.ndim >= 3 ? pv.nx3 + 2 * depth : pv.nk);
+    if (cells < ((int64_t)1 << 31) && (cells + 255) / 256 <= 65535) grid = dim3(1, (unsigned)((cells + 255) / 256), pv.nblocks);
+    else depth = -1;
+  }
   if (faces_only) {
     const bool euler = fluid == APK_FLUID_EULER;
     if (euler && dt_bits)
@@ -629,13 +654,13 @@ int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsig
       hipLaunchKernelGGL((cons_to_prim_faces_kernel<APK_FLUID_GLMMHD, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, face_nbr, dt_bits);
   } else if (dt_bits) {
     if (fluid == APK_FLUID_EULER)
-      hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_EULER, true>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, depth);
+      hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_EULER, true>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, depth, face_nbr);
     else
-      hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_GLMMHD, true>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, depth);
+      hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_GLMMHD, true>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, depth, face_nbr);
   } else if (fluid == APK_FLUID_EULER)
-    hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_EULER, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, -1);
+    hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_EULER, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, -1, nullptr);
   else
-    hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_GLMMHD, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, -1);
+    hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_GLMMHD, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, -1, nullptr);
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }
 

@@ -167,6 +167,7 @@ def _signatures():
         "apk_cons_to_prim_ghosts": (i, [vp, vp, i, E, vp]),
         "apk_cons_to_prim_faces": (i, [vp, vp, i, E, vp]),
         "apk_cons_to_prim_dt": (i, [vp, vp, i, E, i, vp]),
+        "apk_cons_to_prim_dt_skip": (i, [vp, vp, i, E, i, vp, vp]),
         "apk_cons_to_prim_faces_skip": (i, [vp, vp, i, E, vp, vp]),
         "apk_cons_to_prim_faces_dt": (i, [vp, vp, i, E, vp, vp]),
         "apk_cons_to_prim_ghosts_split": (i, [vp, vp, i, E, vp, i, vp]),
@@ -191,6 +192,7 @@ def _signatures():
         "apk_refine_plan_run": (i, [vp, vp, vp]),
         "apk_tag_blocks": (i, [vp, vp, i, d, d, C.POINTER(C.c_int), c_dp, vp]),
         "apk_tag_blocks_begin": (i, [vp, vp, i, C.POINTER(C.c_int), vp]),
+        "apk_tag_blocks_begin_skip": (i, [vp, vp, i, vp, C.POINTER(C.c_int), vp]),
         "apk_tag_blocks_end": (i, [vp, i, i, i, d, d, C.POINTER(C.c_int), c_dp, vp]),
         "apk_poll_device_flags": (i, [vp, C.POINTER(C.c_uint), vp]),
         "apk_trial_flags": (i, [vp, i, vp]),

@@ -290,6 +290,10 @@ int apk_cons_to_prim(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos 
  * most that many layers outside it (edges and corners included) -- the shell a shallow ghost exchange has
  * filled; primitives further out are left as they were. */
 int apk_cons_to_prim_dt(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, int ghost_depth, apk_stream_t stream);
+/* ... leaving out the ghost cells straight behind a face whose entry in face_neighbor (device, [nblocks][6], or NULL) is
+ * >= 0: zones an exchange that follows the face table has not filled and no reader of the table visits. */
+int apk_cons_to_prim_dt_skip(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, int ghost_depth,
+                             const int *face_neighbor, apk_stream_t stream);
 /* ConsToPrim (Update::FillDerived, hydro_driver.cpp:571-577; src/eos/adiabatic_hydro.cpp:33) of the interior
  * and of the ghost cells straight behind a block FACE only (at most one ghost coordinate): what the unsplit
  * sweeps (hydro.cpp:1025-1199) and the flux correction read.  The refined-mesh stage loop of the standalone
@@ -545,6 +549,11 @@ int apk_tag_blocks(apk_ctx *ctx, const apk_pack *md, int criterion, double p0, d
  * _begin launches the reduction and the read-back into pinned memory without waiting; _end waits
  * for the stream and converts (pending = what _begin returned). */
 int apk_tag_blocks_begin(apk_ctx *ctx, const apk_pack *md, int criterion, int *pending, apk_stream_t stream);
+/* ... with apk_stage_args.face_neighbor's table (device, [nblocks][6]): ghost cells straight behind a face whose entry is
+ * >= 0 are read from that block's interior, so the exchange in front of the check may leave those zones out (edges and
+ * corners are read from the block's own ghost zones as before).  Same criteria, bit for bit. */
+int apk_tag_blocks_begin_skip(apk_ctx *ctx, const apk_pack *md, int criterion, const int *face_neighbor, int *pending,
+                              apk_stream_t stream);
 int apk_tag_blocks_end(apk_ctx *ctx, int nblocks, int criterion, int pending, double p0, double p1, int *tags,
                        double *crit, apk_stream_t stream);
 
