@@ -1004,6 +1004,12 @@ int do_stage(apk_sim *s, int stage) {
       a.window_rl = a.window_rows = 0;
       s->overlapped += 1;
     }
+    // (refined meshes: the flux correction's boundary-plane fluxes beside the stage -- the stage stores no primitives there)
+    bool planes_ahead = false;
+    if (s->amr && a.fill_derived == 0) {
+      SIM_TRY(s, ensure_flux_arrays(s));
+      planes_ahead = amr_flux_planes_ahead(s, cfg);
+    }
     SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
     s->stage_dt_pending = a.estimate_dt != 0;
     // (a stage that stored primitives -- the predictor's half-step ones -- makes the current buffer valid again; one that
@@ -1018,7 +1024,7 @@ int do_stage(apk_sim *s, int stage) {
     if (s->amr) {
       SIM_TRY(s, ensure_flux_arrays(s));
       const double psi_factor = a.dedner != 0 ? std::exp(-pkg.glmmhd_alpha * pkg.c_h * beta_dt / pkg.mindx) : 1.0;
-      SIM_TRY(s, amr_flux_fix(s, cfg, beta_dt, psi_factor));
+      SIM_TRY(s, amr_flux_fix(s, cfg, beta_dt, psi_factor, planes_ahead));
     }
   } else {
     // first_order_flux_correct and a stage that does not read the old u0 (gam0 = 0: every VL2 stage,
@@ -1337,6 +1343,9 @@ void apk_sim_destroy(apk_sim *s) {
         apk_pack_destroy(s->mu1_of[p][w]);
       }
     apk_fmft_destroy(s->fm_dev);
+    if (s->side_stream) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(s->side_stream));
+    if (s->ev_fork) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(s->ev_fork));
+    if (s->ev_join) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(s->ev_join));
     if (s->amr) amr_destroy_device_plans(s);
     amr_free_buffers(s, s->amr_halo);
     amr_free_buffers(s, s->amr_halo_faces);

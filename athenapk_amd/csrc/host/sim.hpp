@@ -130,6 +130,9 @@ struct apk_sim {
   apk_pack *mu0_of[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}},
            *mu1_of[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   apk_copy_plan *plans_of[3][apk::PH_COUNT] = {};
+  // refined meshes: the boundary-plane fluxes of a fused stage's flux correction run beside the stage kernels
+  // (amr_flux_planes_ahead)
+  void *side_stream = nullptr, *ev_fork = nullptr, *ev_join = nullptr;
   apk_pack *mu0() const { return mu0_of[cur][pcur]; }
   apk_pack *mu1() const { return mu1_of[u1buf][pcur]; }
   double *d_prim() const { return d_prim2[pcur]; }

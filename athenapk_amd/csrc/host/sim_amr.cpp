@@ -681,11 +681,49 @@ bool amr_has_coarse_fine_faces(const apk_sim *s) {
 // The flux correction for a stage that ran fused: the stage has applied every block's own face
 // fluxes; recompute the fluxes on the block boundaries from the stage's input primitives, average
 // the fine ones and correct the coarse cells next to each coarse-fine face by the difference.
-int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi_factor) {
+// The boundary-plane fluxes of that correction only read the stage's input primitives and only write the flux arrays,
+// which the fused stage does not touch: launched on a stream of their own in FRONT of the stage, they run in the wave
+// slots the marches leave empty (a pack of a few hundred 16^3 blocks fills 80 % of them; by themselves the few hundred
+// planes are one wave each and take 25 us of latency per stage).  Returns whether they were launched; amr_flux_fix then
+// waits for them instead of computing them.  The caller has the flux arrays in place (ensure_flux_arrays).
+bool amr_flux_planes_ahead(apk_sim *s, const apk_flux_cfg &cfg) {
+  static const bool off = std::getenv("APK_AMR_PLANES_INLINE") != nullptr;  // A/B switch
+  if (off || !amr_has_coarse_fine_faces(s)) return false;
+  auto &a = s->amr_dev;
+  if (!s->side_stream) {
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) {
+      if (e0) (void)hipEventDestroy(e0);
+      (void)hipStreamDestroy(st);
+      return false;
+    }
+    s->side_stream = st, s->ev_fork = e0, s->ev_join = e1;
+  }
+  hipStream_t side = reinterpret_cast<hipStream_t>(s->side_stream);
+  if (hipEventRecord(reinterpret_cast<hipEvent_t>(s->ev_fork), hs(s)) != hipSuccess) return false;
+  if (hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(s->ev_fork), 0) != hipSuccess) return false;
+  const int rc = apk_calculate_fluxes_boundary_list(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, a.d_cf_faces, a.n_cf_faces,
+                                                    reinterpret_cast<apk_stream_t>(side));
+  // (whatever was enqueued is joined below either way)
+  (void)hipEventRecord(reinterpret_cast<hipEvent_t>(s->ev_join), side);
+  if (rc != APK_OK) {
+    (void)hipStreamWaitEvent(hs(s), reinterpret_cast<hipEvent_t>(s->ev_join), 0);
+    return false;
+  }
+  return true;
+}
+
+int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi_factor, bool planes_ahead) {
   if (!amr_has_coarse_fine_faces(s)) return APK_OK;
   auto &a = s->amr_dev;
   const int psi_var = (s->pkg.fluid == APK_FLUID_GLMMHD) ? 8 : -1;
-  SIM_TRY(s, apk_calculate_fluxes_boundary_list(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, a.d_cf_faces, a.n_cf_faces, s->stream));
+  if (planes_ahead) {
+    SIM_HIP(s, hipStreamWaitEvent(hs(s), reinterpret_cast<hipEvent_t>(s->ev_join), 0));
+  } else {
+    SIM_TRY(s, apk_calculate_fluxes_boundary_list(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, a.d_cf_faces, a.n_cf_faces, s->stream));
+  }
   // (same-rank faces: the fix kernel averages the fine fluxes itself, reading the blocks' flux arrays; only faces whose
   // coarse side lives elsewhere are restricted into the coarse buffer, for the message -- direction by direction,
   // because the restricted planes of all three directions share the coarse buffers)

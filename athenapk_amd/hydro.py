@@ -233,11 +233,16 @@ def ConservedToPrimitive(md, fluid, eos):
     _check(ctx.lib.apk_cons_to_prim(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), _stream()), ctx.lib, ctx.h)
 
 
-def ConservedToPrimitiveDt(md, fluid, eos, cfl, ghost_depth=-1):
+def ConservedToPrimitiveDt(md, fluid, eos, cfl, ghost_depth=-1, face_neighbor=None):
     """ConsToPrim of every cell (ghost_depth >= 0: of the cells at most that many layers outside the interior) and the
-    hyperbolic time-step estimate of the interior in one pass (apk_cons_to_prim_dt)."""
+    hyperbolic time-step estimate of the interior in one pass (apk_cons_to_prim_dt); face_neighbor (int32 device tensor
+    [nblocks, 6]): not the ghost cells straight behind the faces whose entry is >= 0 (apk_cons_to_prim_dt_skip)."""
     ctx = md.ctx
-    _check(ctx.lib.apk_cons_to_prim_dt(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), ghost_depth, _stream()), ctx.lib, ctx.h)
+    if face_neighbor is None:
+        _check(ctx.lib.apk_cons_to_prim_dt(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), ghost_depth, _stream()), ctx.lib, ctx.h)
+    else:
+        _check(ctx.lib.apk_cons_to_prim_dt_skip(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), ghost_depth,
+                                                C.c_void_p(face_neighbor.data_ptr()), _stream()), ctx.lib, ctx.h)
     return StageDt(ctx, cfl)
 
 
@@ -477,13 +482,23 @@ class RefinePlan:
             pass
 
 
-def TagBlocks(md, criterion, p0, p1=0.0):
+def TagBlocks(md, criterion, p0, p1=0.0, face_neighbor=None):
     """refinement::gradient::PressureGradient / VelocityGradient (src/refinement/gradient.cpp:18-99),
     refinement::other::MaxDensity (src/refinement/other.cpp:18-44) for every block of the pack.
-    Returns (tags, criterion values); tags: +1 refine, 0 same, -1 derefine."""
+    Returns (tags, criterion values); tags: +1 refine, 0 same, -1 derefine.  face_neighbor (int32 device tensor
+    [nblocks, 6]): the ghost cells straight behind the faces whose entry is >= 0 are read from that block's interior
+    (apk_tag_blocks_begin_skip + apk_tag_blocks_end)."""
     ctx = md.ctx
     tags = (C.c_int * md.nblocks)()
     crit = (C.c_double * md.nblocks)()
-    _check(ctx.lib.apk_tag_blocks(ctx.h, md.h, L.TAG_CRITERIA[criterion], float(p0), float(p1), tags, crit, _stream()),
-           ctx.lib, ctx.h)
+    if face_neighbor is None:
+        _check(ctx.lib.apk_tag_blocks(ctx.h, md.h, L.TAG_CRITERIA[criterion], float(p0), float(p1), tags, crit, _stream()),
+               ctx.lib, ctx.h)
+    else:
+        pending = C.c_int(0)
+        code = L.TAG_CRITERIA[criterion]
+        _check(ctx.lib.apk_tag_blocks_begin_skip(ctx.h, md.h, code, C.c_void_p(face_neighbor.data_ptr()), C.byref(pending), _stream()),
+               ctx.lib, ctx.h)
+        _check(ctx.lib.apk_tag_blocks_end(ctx.h, md.nblocks, code, pending.value, float(p0), float(p1), tags, crit, _stream()),
+               ctx.lib, ctx.h)
     return np.array(tags[:]), np.array(crit[:])

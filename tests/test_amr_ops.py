@@ -230,6 +230,49 @@ def test_tag_blocks_matches_oracle(request, oracle, nx):
         assert list(t2) == list(tags) and list(v2) == list(vals)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,ng", [((16, 16, 16), 4), ((8, 8, 8), 2), ((32, 16, 1), 2)], ids=["16c", "8c", "2d"])
+def test_tag_blocks_through_the_face_table_equals_filled_ghost_zones(request, nx, ng):
+    """apk_tag_blocks_begin_skip: a ghost cell straight behind a face whose table entry is >= 0 is read from that
+    neighbour's interior -- the values an exchange would have copied there.  Four blocks, some faces joined (a block
+    is its own neighbour across a periodic direction too), the zones behind the joined faces poisoned: same criteria
+    and tags, bit for bit, as with the zones filled and no table."""
+    import torch
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    nb = 4
+    g = H.geom("glmmhd", nx, ng, 0, (0.1, 0.1, 0.1))
+    prim = H.random_prim("glmmhd", nx, ng, seed=21, kind="smooth", nblocks=nb)
+    prim[1, 0] *= 3.0
+    tab = np.array([[1, 1, -1, 2, -1, 3], [0, 0, 2, -1, 1, 1], [-1, 3, 0, 2, -1, -1], [2, -1, -1, -1, 0, 3]], dtype=np.int32)
+    if nx[2] == 1:
+        tab[:, 4:] = -1
+    I = [slice(ng, ng + nx[0]), slice(ng, ng + nx[1]), slice(ng, ng + nx[2]) if nx[2] > 1 else slice(None)]
+    filled, poisoned = prim.copy(), prim.copy()
+    for b in range(nb):
+        for f in range(6):
+            if tab[b, f] < 0:
+                continue
+            d, hi = f // 2, f % 2
+            dst, src = list(I), list(I)
+            dst[d] = slice(ng + nx[d], 2 * ng + nx[d]) if hi else slice(0, ng)
+            src[d] = slice(ng, 2 * ng) if hi else slice(nx[d], nx[d] + ng)
+            filled[b][:, dst[2], dst[1], dst[0]] = prim[tab[b, f]][:, src[2], src[1], src[0]]
+            poisoned[b][:, dst[2], dst[1], dst[0]] = 1e30
+    a = hydro.MeshData(ctx, nx, ng, 9, dx=tuple(g.dx), nblocks=nb, prim=filled, with_flux=False)
+    b_ = hydro.MeshData(ctx, nx, ng, 9, dx=tuple(g.dx), nblocks=nb, prim=poisoned, with_flux=False)
+    dtab = torch.from_numpy(tab).cuda()
+    for crit in ("pressure_gradient", "xyvelocity_gradient", "maxdensity"):
+        _, vals = hydro.TagBlocks(a, crit, 1e300, 0.0)
+        p0, p1 = 0.5 * (sorted(vals)[-1] + sorted(vals)[-2]), 0.5 * (sorted(vals)[0] + sorted(vals)[1])
+        want_t, want_v = hydro.TagBlocks(a, crit, p0, p1)
+        got_t, got_v = hydro.TagBlocks(b_, crit, p0, p1, face_neighbor=dtab)
+        assert np.all(np.isfinite(want_v)) and list(got_v) == list(want_v) and list(got_t) == list(want_t), crit
+        assert len(set(want_t)) > 1, crit
+        if crit == "pressure_gradient":  # (without the table the poisoned zones are read)
+            assert list(hydro.TagBlocks(b_, crit, p0, p1)[1]) != list(want_v)
+
+
 # ---- the pieces of the flux correction after a fused stage, through the C-ABI --------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("fluid,recon,riemann,ng", [("euler", "plm", "hllc", 2), ("glmmhd", "ppm", "hlld", 4),

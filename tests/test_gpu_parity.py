@@ -398,6 +398,21 @@ def test_cons_to_prim_with_time_step_estimate(request, fluid, nx, strict):
     assert hydro.ConservedToPrimitiveDt(md, fluid, eos, 0.3, ghost_depth=1) == dt
     got = md.prim_host()
     assert np.array_equal(got[:, :, ~deep], ref.prim_host()[:, :, ~deep]) and np.all(got[:, :, deep] == -3.0) and deep.any()
+    # apk_cons_to_prim_dt_skip: nor the ghost cells straight behind the faces a face table joins to another block
+    import torch
+    tab = np.array([[1, -1, 2, 0, -1, -1], [-1, 0, -1, -1, 1, 2], [2, 2, -1, 1, 0, -1]], dtype=np.int32)
+    nghost = ((I < ng) | (I >= ng + nx[0])).astype(int) + (act[1] & ((J < ng) | (J >= ng + nx[1]))) + (act[2] & ((K < ng) | (K >= ng + nx[2])))
+    zones = ((I < ng), (I >= ng + nx[0]), act[1] & (J < ng), act[1] & (J >= ng + nx[1]), act[2] & (K < ng), act[2] & (K >= ng + nx[2]))
+    for depth in (1, -1):
+        md = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=u, prim=np.full_like(u, -3.0), with_flux=False)
+        assert hydro.ConservedToPrimitiveDt(md, fluid, eos, 0.3, ghost_depth=depth, face_neighbor=torch.from_numpy(tab).cuda()) == dt
+        got = md.prim_host()
+        for b in range(3):
+            left = np.broadcast_to(deep if depth == 1 else np.zeros_like(deep), u.shape[2:]).copy()
+            for f in range(6):
+                if tab[b, f] >= 0:
+                    left |= np.broadcast_to(zones[f] & (nghost == 1), u.shape[2:])
+            assert np.array_equal(got[b][:, ~left], ref.prim_host()[b][:, ~left]) and np.all(got[b][:, left] == -3.0) and left.any()
     # apk_cons_to_prim_faces_dt: what apk_cons_to_prim_faces converts, and the same estimate
     a = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=u, prim=np.full_like(u, -3.0), with_flux=False)
     b = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=u, prim=np.full_like(u, -3.0), with_flux=False)
