@@ -440,12 +440,26 @@ int exchange_ghosts(apk_sim *s, int c2p, bool skip_local, bool thin) {
 // kernels that follow the table, and nothing else in the cycle may read ghost zones.  (do_stage skips
 // the copies only after stages whose FillDerived was fused -- into the finishing sweep or, with the
 // turbulence driver, into the kick; an exchange followed by a full-block ConsToPrim is a complete one.)
+// one rank, every active direction periodic: the face table covers every face of every block, so an exchange that
+// follows it has no ghost zone left to fill (edges and corners are read by no stage that follows the table)
+bool table_covers_all_faces(const apk_sim *s) {
+  const Mesh &m = s->mesh;
+  if (!m.peers.empty()) return false;
+  for (int d = 0; d < 3; ++d)
+    if (m.Active(d) && (m.bc_in[d] != BC_PERIODIC || m.bc_out[d] != BC_PERIODIC)) return false;
+  return true;
+}
+
 bool direct_neighbors(const apk_sim *s) {
   static const int mode = std::getenv("APK_DIRECT_NEIGHBORS") ? std::atoi(std::getenv("APK_DIRECT_NEIGHBORS")) : 1;  // A/B switch
   static const int dc_mode = std::getenv("APK_DC_MODE") ? std::atoi(std::getenv("APK_DC_MODE")) : 2;
   const HydroPackage &pkg = s->pkg;
   if (!mode || !s->direct_on || !s->d_face_nbr || s->amr || s->mesh.ndim != 3 || !stage_can_fuse(s)) return false;
-  if (pkg.nscalars != 0 || !ghost_c2p_fusable(s)) return false;
+  // (floors and ceilings: ConsToPrim is not fused into the ghost fills then, and the separate pass over the ghost zones
+  // would convert the zones nobody filled -- unless no zone is left to fill at all.  What the stages read across a face
+  // is the neighbour's floored interior state either way: the values the reference's ConsToPrim of a ghost cell produces
+  // from the same conserved input.)
+  if (pkg.nscalars != 0 || (!ghost_c2p_fusable(s) && !table_covers_all_faces(s))) return false;
   if (pkg.fluid == APK_FLUID_GLMMHD && pkg.glmmhd_source_extended) return false;
   const apk_flux_cfg *cfgs[2] = {&pkg.flux_first_stage, &pkg.flux_other_stage};
   for (const apk_flux_cfg *cfg : cfgs) {
@@ -505,9 +519,13 @@ bool amr_shell_before_check(const apk_sim *s) {
 int materialize_local_ghosts(apk_sim *s) {
   if (!s->local_ghosts_stale) return APK_OK;
   s->local_ghosts_stale = false;
-  SIM_TRY(s, run_ghost_plan(s, s->cur, PH_LOCAL, GHOST_C2P));
+  // (floors / ceilings: plain copies, then the pass over the ghost zones -- the order of a cycle without the table)
+  const int mode = ghost_c2p_fusable(s) ? GHOST_C2P : GHOST_COPY;
+  SIM_TRY(s, run_ghost_plan(s, s->cur, PH_LOCAL, mode));
   // (physical boundaries copy corner cells out of ghost zones the same-rank copies fill)
-  for (int ph = PH_BC1; ph <= PH_BC3; ++ph) SIM_TRY(s, run_ghost_plan(s, s->cur, ph, GHOST_C2P));
+  for (int ph = PH_BC1; ph <= PH_BC3; ++ph) SIM_TRY(s, run_ghost_plan(s, s->cur, ph, mode));
+  // (no stored primitives: the caller converts whole blocks, materialize_prim)
+  if (mode == GHOST_COPY && !s->prim_stale) SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), s->pkg.fluid, &s->pkg.eos, s->stream));
   return APK_OK;
 }
 
@@ -1165,7 +1183,9 @@ int do_stage(apk_sim *s, int stage) {
     // (without a fused FillDerived the full-block ConsToPrim below reads every ghost zone)
     SIM_TRY(s, exchange_ghosts(s, c2p_in_copy, direct && fused_fill, fused_fill && stage == s->nstages && thin_exchange_cycle(s)));
     if (fused_fill) {
-      if (!c2p_in_copy && ghost_prims) SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
+      // (not after an exchange that filled nothing: direct addressing on a mesh whose faces the table covers)
+      const bool filled_none = direct && table_covers_all_faces(s);
+      if (!c2p_in_copy && ghost_prims && !filled_none) SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->stream));
     } else if (stage == s->nstages && pkg.calc_dt_hyp) {
       // the last FillDerived of the cycle and the time-step estimate that follows it (hydro_driver.cpp:571-603) in
       // one pass: the interior cells' primitives are in registers anyway (refined meshes, flux-array stages)

@@ -577,6 +577,36 @@ def test_direct_neighbor_cycle_equals_the_cycle_with_ghost_copies(strict, scheme
     same(a.dt, b.dt)
 
 
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("scheme", [("vl2", "ppm", 3), ("rk2", "plm", 2)], ids=["vl2_ppm", "rk2_plm"])
+@pytest.mark.parametrize("floors", [["hydro/dfloor=0.9", "hydro/pfloor=1.0e-8"], ["hydro/dfloor=0.9"]], ids=["dfloor_pfloor", "dfloor"])
+def test_direct_neighbor_cycle_with_floors_on_a_periodic_box(strict, scheme, floors):
+    """With a floor or a ceiling set, ConsToPrim is not fused into the ghost fills and a separate pass converts the ghost
+    zones -- which would read the zones a table-following exchange leaves unfilled.  On one rank with every direction
+    periodic the table covers every face, nothing is left to fill or convert, and the direct cycle runs all the same
+    (BASELINE config 3's deck sets a pressure floor).  A density floor that fires in a fifth of the cells every stage and
+    a pressure floor that never does (and the density floor alone: the lean stage forms, and VL2 without stored full-step
+    primitives): the same bits as the cycle with the copies, ghost zones included."""
+    integ, recon, ng = scheme
+    ov = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=32", "parthenon/mesh/nx3=16", "parthenon/meshblock/nx1=32",
+          "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=16", "parthenon/time/integrator=%s" % integ,
+          "hydro/reconstruction=%s" % recon, "parthenon/mesh/nghost=%d" % ng] + floors
+    a = _sim("synthetic_mhd", ov, strict=strict).initialize()
+    b = _sim("synthetic_mhd", ov, strict=strict)
+    b.set_direct_neighbors(False)
+    b.initialize()
+    for _ in range(3):
+        a.step()
+        b.step()
+    assert a.skipped_local_exchanges() == 6 and b.skipped_local_exchanges() == 0
+    rho = np.asarray(a.gather())[0]
+    assert 0.02 < np.mean(rho == 0.9) < 0.6          # the floor is at work
+    _assert_same(np.asarray(a.dt), np.asarray(b.dt), strict)
+    for lb in range(a.info.nblocks_local):
+        for field in ("cons", "prim"):
+            _assert_same(np.asarray(a.read_block(lb, field)), np.asarray(b.read_block(lb, field)), strict)
+
+
 # ---- config 4 forcing: few-modes turbulence driver ---------------------------------------------------
 def _turb_k_vec():
     from athenapk_amd import decks
