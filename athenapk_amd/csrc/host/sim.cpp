@@ -454,7 +454,13 @@ bool direct_neighbors(const apk_sim *s) {
   static const int mode = std::getenv("APK_DIRECT_NEIGHBORS") ? std::atoi(std::getenv("APK_DIRECT_NEIGHBORS")) : 1;  // A/B switch
   static const int dc_mode = std::getenv("APK_DC_MODE") ? std::atoi(std::getenv("APK_DC_MODE")) : 2;
   const HydroPackage &pkg = s->pkg;
-  if (!mode || !s->direct_on || !s->d_face_nbr || s->amr || s->mesh.ndim != 3 || !stage_can_fuse(s)) return false;
+  if (!mode || !s->direct_on || !s->d_face_nbr || s->amr || s->mesh.ndim != 3) return false;
+  // first-order flux correction: every stage runs as the optimistic fused stage (do_stage) -- the same kernels with the
+  // admissibility test in the finishing sweep; a stage that fails it is redone through the flux arrays, which read ghost
+  // zones: do_stage fills them first (materialize_local_ghosts).  One-rank periodic boxes, no forcing.
+  const bool optimistic = s->fused && pkg.first_order_flux_correct && !s->fmft && pkg.riemann != APK_RS_NONE && pkg.riemann != APK_RS_LLF &&
+                          table_covers_all_faces(s);
+  if (!stage_can_fuse(s) && !optimistic) return false;
   // (floors and ceilings: ConsToPrim is not fused into the ghost fills then, and the separate pass over the ghost zones
   // would convert the zones nobody filled -- unless no zone is left to fill at all.  What the stages read across a face
   // is the neighbour's floored interior state either way: the values the reference's ConsToPrim of a ghost cell produces
@@ -515,17 +521,20 @@ bool amr_shell_before_check(const apk_sim *s) {
   return reach <= AMR_SHELL_DEPTH && !(pkg.fluid == APK_FLUID_GLMMHD && pkg.glmmhd_source_extended && AMR_SHELL_DEPTH < 2);
 }
 
-// fill the ghost zones that direct neighbour addressing left stale (cons and prim of the current state)
-int materialize_local_ghosts(apk_sim *s) {
+// fill the ghost zones that direct neighbour addressing left stale: cons of buffer `buf` (default: the current state)
+// and the stored primitives, which are that buffer's
+int materialize_local_ghosts(apk_sim *s, int buf) {
   if (!s->local_ghosts_stale) return APK_OK;
   s->local_ghosts_stale = false;
+  if (buf < 0) buf = s->cur;
   // (floors / ceilings: plain copies, then the pass over the ghost zones -- the order of a cycle without the table)
   const int mode = ghost_c2p_fusable(s) ? GHOST_C2P : GHOST_COPY;
-  SIM_TRY(s, run_ghost_plan(s, s->cur, PH_LOCAL, mode));
+  SIM_TRY(s, run_ghost_plan(s, buf, PH_LOCAL, mode));
   // (physical boundaries copy corner cells out of ghost zones the same-rank copies fill)
-  for (int ph = PH_BC1; ph <= PH_BC3; ++ph) SIM_TRY(s, run_ghost_plan(s, s->cur, ph, mode));
+  for (int ph = PH_BC1; ph <= PH_BC3; ++ph) SIM_TRY(s, run_ghost_plan(s, buf, ph, mode));
   // (no stored primitives: the caller converts whole blocks, materialize_prim)
-  if (mode == GHOST_COPY && !s->prim_stale) SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0(), s->pkg.fluid, &s->pkg.eos, s->stream));
+  if (mode == GHOST_COPY && !s->prim_stale)
+    SIM_TRY(s, apk_cons_to_prim_ghosts(s->ctx, s->mu0_of[buf][s->pcur], s->pkg.fluid, &s->pkg.eos, s->stream));
   return APK_OK;
 }
 
@@ -1060,7 +1069,10 @@ int do_stage(apk_sim *s, int stage) {
     // result into a third buffer instead, so that u0 survives a rejected trial; an accepted one makes
     // that buffer the current state.  (Not with passive scalars: their kernel updates in place; not on
     // refined meshes: the flux correction after the stage addresses the current buffer.)
-    const bool trial_out_of_place = g0 != 0.0;
+    // (With the face table, so does a later stage that does not read it -- VL2's corrector: a rejected trial is redone
+    // through the flux arrays, whose sweeps read ghost primitives the table-following stages left stale, and those are
+    // regenerated from the conserved state they belong to -- which an in-place trial would have overwritten.)
+    const bool trial_out_of_place = g0 != 0.0 || (direct && stage > 1);
     if (s->fused && pkg.first_order_flux_correct && (g0 == 0.0 || (pkg.nscalars == 0 && !s->amr)) &&
         !pkg.glmmhd_source_extended && s->mesh.ndim >= 2 && pkg.riemann != APK_RS_NONE && pkg.riemann != APK_RS_LLF) {
       if (trial_out_of_place) SIM_TRY(s, ensure_trial_cons(s));
@@ -1083,6 +1095,7 @@ int do_stage(apk_sim *s, int stage) {
       a.mindx = pkg.mindx;
       a.fill_derived = fill ? 2 : 0;
       a.estimate_dt = (fill && stage == s->nstages && pkg.calc_dt_hyp) ? 1 : 0;
+      a.face_neighbor = direct ? s->d_face_nbr : nullptr;
       a.trial = 1;  // its ConsToPrim latches flags into the trial word: kept or dropped below
       // the finishing sweep applies FirstOrderFluxCorrect's test to the update it has in registers
       // (passive scalars ride a separate kernel: there the stored state is tested afterwards)
@@ -1112,6 +1125,10 @@ int do_stage(apk_sim *s, int stage) {
       }
     }
     if (!done) {
+    // (the flux arrays' sweeps and FirstOrderFluxCorrect read the primitives of ghost cells: after stages that followed
+    // the face table those are stale -- fill them, from the conserved buffer the stored primitives belong to: the
+    // register u1 in stage 1, whose buffers have swapped roles above, the current state otherwise)
+    if (s->local_ghosts_stale) SIM_TRY(s, materialize_local_ghosts(s, stage == 1 ? s->u1buf : s->cur));
     SIM_TRY(s, ensure_flux_arrays(s));
     // (faces of interior cells only: nothing downstream reads the reference's extra transverse rows)
     SIM_TRY(s, apk_calculate_fluxes_tight(s->ctx, s->mu0(), cfg, &pkg.eos, pkg.c_h, s->stream));

@@ -81,7 +81,7 @@ int finish_pending(apk_sim *s);
 bool direct_neighbors(const apk_sim *s);
 bool amr_faces_only(const apk_sim *s);
 bool regrid_check_follows(const apk_sim *s);
-int materialize_local_ghosts(apk_sim *s);
+int materialize_local_ghosts(apk_sim *s, int buf = -1);
 int sync_ghosts(apk_sim *s);  // finish_pending + materialize_local_ghosts
 int fill_derived(apk_sim *s);
 int pre_step(apk_sim *s);

@@ -1078,6 +1078,9 @@ def test_first_order_flux_correction_with_fallback_matches_oracle(oracle, fluid,
     assert s.fofc_count == o.fofc_count and s.fofc_count > 0
     nstages = {"vl2": 2, "rk2": 2, "rk3": 3}[integrator]
     assert 0 < s.fofc_fallback_stages < ncyc * nstages                   # some trial stages stood, some were redone
+    # (one rank, periodic: the trial stages follow the face table, and a rejected one fills the ghost zones it left stale
+    # before the flux arrays' sweeps read them)
+    assert s.skipped_local_exchanges() == ncyc * nstages - s.fofc_fallback_stages
 
 
 # ---- the product build's arithmetic on hard data ---------------------------------------------------------------
