@@ -11,7 +11,8 @@ cat > /tmp/ot_prof.py <<'P'
 import sys, time, torch
 sys.path.insert(0, ".")
 from athenapk_amd import decks, driver
-ov = ["parthenon/mesh/nx3=4", "parthenon/meshblock/nx3=4", "parthenon/meshblock/nx1=128", "parthenon/meshblock/nx2=128", "hydro/first_order_flux_correct=false"]
+import os
+ov = ([] if os.environ.get("OT_2D") else ["parthenon/mesh/nx3=4", "parthenon/meshblock/nx3=4"]) + ["parthenon/meshblock/nx1=128", "parthenon/meshblock/nx2=128", "hydro/first_order_flux_correct=false"]
 s = driver.Simulation(decks.load("orszag_tang"), ov + sys.argv[1:]).initialize()
 for _ in range(3): s.step()
 torch.cuda.synchronize(); t = time.perf_counter()
