@@ -38,43 +38,103 @@ inline dim3 igrid(const PackView &pv) { return rect_grid(pv.nx1, pv.nx2, pv.nx3 
 // Differs from the reference's grouping (few_modes_ft.cpp:330-347, kept by the parity build below) in the last
 // bits only.
 constexpr int kMaxRowModes = 64;
+// Who keeps what: the phases along x1 belong to the CELL COLUMN (mode, i), the coefficients A to the ROW (mode, j, k).
+// Read per row, the table phases_i of a block -- 2 M nx1 doubles, 61 KB for 30 modes on 128-cell rows -- misses the L1
+// and came out of the L2 once per wave: 4 GB per launch on 256^3, 0.57 ms at the L2's rate; staged in the LDS per
+// workgroup it was the LDS's rate instead, 0.43 ms.  So a lane now keeps its column's phases in REGISTERS, kModeChunk
+// modes at a time, and works through the kRowsPerWave rows of its wave with them: per mode and cell six FMAs and the
+// row's three coefficient pairs as broadcast LDS reads, nothing else.  The rows' coefficients are formed once per wave
+// (lane = mode) into a slice of the LDS of its own; modes beyond M are padded with zero coefficients.
+constexpr int kModeChunk = 10;
+constexpr int kRowsPerWave = 8;
 __global__ void __launch_bounds__(256)
-fmft_inverse_rows_kernel(PackView pv, const apk_fmft_block *blocks, const double *var_hat, int M) {
-  __shared__ __attribute__((aligned(16))) double A[4][kMaxRowModes][6];
+fmft_inverse_rows_kernel(PackView pv, const apk_fmft_block *blocks, const double *var_hat, int M, int Mpad, int groups_per_block, int xpasses) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x, wv = threadIdx.y;
-  const int jo = blockIdx.x * 4 + wv;
-  const int b = blockIdx.y / pv.nx3, ko = blockIdx.y % pv.nx3;
-  const bool row = jo < pv.nx2;
+  const int xp = blockIdx.x % xpasses, bg = blockIdx.x / xpasses;
+  const int b = bg / groups_per_block, g = bg - b * groups_per_block;
   const apk_fmft_block blk = blocks[b];
-  const int64_t n1 = pv.nx1, n2 = pv.nx2, n3 = pv.nx3;
-  if (row && lane < M) {
-    const int m = lane;
-    const double jr = blk.phases_j[m * n2 + jo], ji = blk.phases_j[(M + m) * n2 + jo];
-    const double kr = blk.phases_k[m * n3 + ko], ki = blk.phases_k[(M + m) * n3 + ko];
-    const double pr = jr * kr - ji * ki, pim = jr * ki + ji * kr;
+  const int n1 = pv.nx1, n2 = pv.nx2, n3 = pv.nx3;
+  const int rows = n2 * n3;
+  const int r0 = (g * 4 + wv) * kRowsPerWave;
+  double *A = lds + (size_t)wv * kRowsPerWave * Mpad * 6;  // [row][mode][6], this wave's
+  for (int m = lane; m < Mpad; m += 64) {
+    double vr[3] = {0.0, 0.0, 0.0}, vi[3] = {0.0, 0.0, 0.0};
+    if (m < M) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const double vr = var_hat[(c * M + m) * 2], vi = var_hat[(c * M + m) * 2 + 1];
-      A[wv][m][2 * c] = vr * pr - vi * pim;
-      A[wv][m][2 * c + 1] = vr * pim + vi * pr;
+      for (int c = 0; c < 3; ++c) vr[c] = var_hat[(c * M + m) * 2], vi[c] = var_hat[(c * M + m) * 2 + 1];
+    }
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave; ++q) {
+      const int r = (r0 + q < rows) ? r0 + q : rows - 1;
+      const int ko = r / n2, jo = r - ko * n2;
+      double pr = 0.0, pim = 0.0;
+      if (m < M) {
+        const double jr = blk.phases_j[m * n2 + jo], ji = blk.phases_j[(M + m) * n2 + jo];
+        const double kr = blk.phases_k[m * n3 + ko], ki = blk.phases_k[(M + m) * n3 + ko];
+        pr = jr * kr - ji * ki, pim = jr * ki + ji * kr;
+      }
+      double *a = A + ((size_t)q * Mpad + m) * 6;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        a[2 * c] = vr[c] * pr - vi[c] * pim;
+        a[2 * c + 1] = vr[c] * pim + vi[c] * pr;
+      }
     }
   }
-  __syncthreads();
-  if (!row) return;
-  const int64_t rowcell = (int64_t)(pv.ks + ko) * pv.sk + (int64_t)(pv.js + jo) * pv.sj + pv.is;
-  for (int io = lane; io < pv.nx1; io += 64) {
-    const double *pi = blk.phases_i + io;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int m = 0; m < M; ++m) {
-      const double ir = pi[m * n1], ii = pi[(M + m) * n1];
-      const double *a = A[wv][m];
-      s0 += a[0] * ir - a[1] * ii;
-      s1 += a[2] * ir - a[3] * ii;
-      s2 += a[4] * ir - a[5] * ii;
+  // (the slice is this wave's own: its LDS writes are complete before its reads below are issued)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // two cells per lane (io, io + 64): a broadcast read hands its 16 bytes to all 64 lanes -- 1 KB of LDS bandwidth per
+  // instruction, which is what bounded the one-cell form (0.43 ms) -- and serves both
+  const int io0 = xp * 128 + lane, io1 = io0 + 64;
+  const int il0 = io0 < n1 ? io0 : n1 - 1, il1 = io1 < n1 ? io1 : n1 - 1;
+  double acc[kRowsPerWave][3], bcc[kRowsPerWave][3];
+#pragma unroll
+  for (int q = 0; q < kRowsPerWave; ++q) acc[q][0] = acc[q][1] = acc[q][2] = bcc[q][0] = bcc[q][1] = bcc[q][2] = 0.0;
+  for (int c0 = 0; c0 < Mpad; c0 += kModeChunk) {
+    double ir[kModeChunk], ii[kModeChunk], jr[kModeChunk], ji[kModeChunk];
+#pragma unroll
+    for (int u = 0; u < kModeChunk; ++u) {
+      const int m = (c0 + u < M) ? c0 + u : M - 1;  // (padding: its coefficients are zero)
+      ir[u] = blk.phases_i[(int64_t)m * n1 + il0];
+      ii[u] = blk.phases_i[(int64_t)(M + m) * n1 + il0];
+      jr[u] = blk.phases_i[(int64_t)m * n1 + il1];
+      ji[u] = blk.phases_i[(int64_t)(M + m) * n1 + il1];
     }
-    blk.acc[0 * pv.sn + rowcell + io] = 2. * s0;
-    blk.acc[1 * pv.sn + rowcell + io] = 2. * s1;
-    blk.acc[2 * pv.sn + rowcell + io] = 2. * s2;
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave; ++q) {
+      const double *a = A + ((size_t)q * Mpad + c0) * 6;
+#pragma unroll
+      for (int u = 0; u < kModeChunk; ++u) {
+        const double a0 = a[6 * u + 0], a1 = a[6 * u + 1], a2 = a[6 * u + 2], a3 = a[6 * u + 3], a4 = a[6 * u + 4], a5 = a[6 * u + 5];
+        acc[q][0] += a0 * ir[u] - a1 * ii[u];
+        acc[q][1] += a2 * ir[u] - a3 * ii[u];
+        acc[q][2] += a4 * ir[u] - a5 * ii[u];
+        bcc[q][0] += a0 * jr[u] - a1 * ji[u];
+        bcc[q][1] += a2 * jr[u] - a3 * ji[u];
+        bcc[q][2] += a4 * jr[u] - a5 * ji[u];
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kRowsPerWave; ++q) {
+    const int r = r0 + q;
+    if (r < rows) {
+      const int ko = r / n2, jo = r - ko * n2;
+      const int64_t cell = (int64_t)(pv.ks + ko) * pv.sk + (int64_t)(pv.js + jo) * pv.sj + pv.is;
+      if (io0 < n1) {
+        blk.acc[0 * pv.sn + cell + io0] = 2. * acc[q][0];
+        blk.acc[1 * pv.sn + cell + io0] = 2. * acc[q][1];
+        blk.acc[2 * pv.sn + cell + io0] = 2. * acc[q][2];
+      }
+      if (io1 < n1) {
+        blk.acc[0 * pv.sn + cell + io1] = 2. * bcc[q][0];
+        blk.acc[1 * pv.sn + cell + io1] = 2. * bcc[q][1];
+        blk.acc[2 * pv.sn + cell + io1] = 2. * bcc[q][2];
+      }
+    }
   }
 }
 #endif
@@ -449,11 +509,20 @@ int apk_fmft_inverse(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, const double
   APK_HIP_TRY(ctx, hipMemcpyAsync(f->d_var_hat, var_hat_host, sizeof(double) * 3 * f->num_modes * 2,
                                   hipMemcpyHostToDevice, s));
 #ifndef APK_FP_STRICT
+  const PackView &pv = md->view;
   if (f->num_modes <= kMaxRowModes) {
-    const PackView &pv = md->view;
-    hipLaunchKernelGGL(fmft_inverse_rows_kernel, dim3((pv.nx2 + 3) / 4, pv.nx3 * pv.nblocks, 1), dim3(64, 4, 1), 0, s, pv,
-                       f->d_blocks, f->d_var_hat, f->num_modes);
-    return hipGetLastError() == hipSuccess ? APK_OK : set_err(ctx, APK_ERR_DEVICE, "fmft_inverse launch", hipGetLastError());
+    const int Mpad = (f->num_modes + kModeChunk - 1) / kModeChunk * kModeChunk;
+    const int groups = (pv.nx2 * pv.nx3 + 4 * kRowsPerWave - 1) / (4 * kRowsPerWave), xpasses = (pv.nx1 + 127) / 128;
+    const size_t lds = sizeof(double) * 4 * kRowsPerWave * (size_t)Mpad * 6;
+    // (30 modes: 46 KB; more than 64 KB -- 42 modes and up -- has to be asked for: gfx950 has 160 KB per CU)
+    constexpr int lds_max = (int)sizeof(double) * 4 * kRowsPerWave * ((kMaxRowModes + kModeChunk - 1) / kModeChunk * kModeChunk) * 6;
+    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(fmft_inverse_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   lds_max) == hipSuccess;
+    if (lds_ok || lds <= 64 * 1024) {
+      hipLaunchKernelGGL(fmft_inverse_rows_kernel, dim3((unsigned)(groups * pv.nblocks * xpasses), 1, 1), dim3(64, 4, 1), lds, s, pv,
+                         f->d_blocks, f->d_var_hat, f->num_modes, Mpad, groups, xpasses);
+      return hipGetLastError() == hipSuccess ? APK_OK : set_err(ctx, APK_ERR_DEVICE, "fmft_inverse launch", hipGetLastError());
+    }
   }
 #endif
   hipLaunchKernelGGL(fmft_inverse_kernel, igrid(md->view), dim3(64, 4, 1), 0, s, md->view, f->d_blocks,

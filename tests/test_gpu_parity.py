@@ -943,10 +943,13 @@ def test_fused_fill_derived_rejected_where_unsafe(request):
 
 
 # ---- few-modes turbulence driver kernels ------------------------------------------------------------
-def _turb_case(oracle, nblocks_axis=2, n=16, ng=2):
+def _turb_case(oracle, nblocks_axis=2, n=16, ng=2, nmodes=8):
     """an n^3 box split in nblocks_axis^3 blocks; returns geometry, spectral state, phases per block"""
     rng = np.random.default_rng(5)
     kv = np.array([[1, 0, 0, 1, 2, 0, -1, 2], [0, 1, 0, 1, -1, 2, 1, 2], [0, 0, 1, -1, 0, 1, 2, 2]], dtype=np.float64)
+    if nmodes != 8:
+        kv = np.concatenate([kv, rng.integers(-3, 4, size=(3, nmodes - 8)).astype(np.float64)], axis=1)
+        kv[:, np.all(kv == 0, axis=0)] = 1.0
     f = oracle.Fmft(oracle.load(), kv, k_peak=2.0, sol_weight=0.7, t_corr=0.5, rseed=7)
     f.evolve(0.1)
     f.evolve(0.1)
@@ -962,10 +965,14 @@ def _turb_case(oracle, nblocks_axis=2, n=16, ng=2):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
-def test_fmft_inverse(request, oracle, strict):
+@pytest.mark.parametrize("case", [(2, 16, 8), (1, 136, 23)], ids=["8cubed_blocks_8_modes", "136cubed_block_23_modes"])
+def test_fmft_inverse(request, oracle, strict, case):
+    """few_modes_ft.cpp:330-347.  The product build's kernel keeps a cell column's phases in registers, ten modes at a
+    time, two columns per lane: 8-cell rows (one lane in eight at work), a row of 136 cells (two passes, the second one
+    with its upper columns off the row) and mode counts that are not a multiple of ten (zero-padded coefficients)."""
     from athenapk_amd import hydro
     ctx = _ctx(request, strict)
-    f, g, mb, phases = _turb_case(oracle)
+    f, g, mb, phases = _turb_case(oracle, nblocks_axis=case[0], n=case[1], nmodes=case[2])
     nb = len(phases)
     md = hydro.MeshData(ctx, (mb, mb, mb), 2, 9, dx=tuple(g.dx), nblocks=nb, with_flux=False)
     drv = hydro.FewModesFT(md, [[p.transpose(2, 1, 0) for p in blk] for blk in phases])
