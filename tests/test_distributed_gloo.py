@@ -10,6 +10,8 @@ import sys
 import numpy as np
 import pytest
 
+from _spawn import spawn
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -98,4 +100,4 @@ def _worker(rank, world, port, case):
 @pytest.mark.parametrize("case", ["mhd3d", "sod"])
 def test_two_rank_halo_exchange_over_gloo(case):
     import torch.multiprocessing as mp
-    mp.spawn(_worker, args=(2, _free_port(), case), nprocs=2, join=True)
+    spawn(_worker, lambda port: (2, port, case), 2)

@@ -819,11 +819,8 @@ def test_refined_mesh_on_several_ranks_matches_one_rank(tmp_path, case, world):
     want = {}
     for lb in range(ri.nblocks_local):
         want["b_%d_%d_%d_%d" % ((ref.block_level(lb),) + tuple(ref.block_gid(lb)[1]))] = ref.read_block(lb, "cons")
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    mp.spawn(_amr_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    from _spawn import spawn
+    spawn(_amr_worker, lambda port: (world, port, case, str(tmp_path)), world)
     seen = set()
     counts = []
     for r in range(world):

@@ -18,6 +18,8 @@ import sys
 import numpy as np
 import pytest
 
+from _spawn import spawn
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -143,7 +145,7 @@ def test_config4_forced_turbulence_on_two_ranks_matches_oracle(oracle, tmp_path)
     o = _cfg4_oracle(oracle)
     for _ in range(CFG4_CYCLES):
         o.step()
-    mp.spawn(_cfg4_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    spawn(_cfg4_worker, lambda port: (2, port, str(tmp_path)), 2)
     seen = set()
     for r in range(2):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))

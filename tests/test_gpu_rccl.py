@@ -15,6 +15,8 @@ import sys
 import numpy as np
 import pytest
 
+from _spawn import spawn
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -87,7 +89,7 @@ def test_native_rccl_transport_two_gpus_matches_oracle(oracle, tmp_path, case, o
     o.pgen(pgen, **pkw)
     for _ in range(ncyc):
         o.step()
-    mp.spawn(_worker, args=(2, _free_port(), case, str(tmp_path), overlap), nprocs=2, join=True)
+    spawn(_worker, lambda port: (2, port, case, str(tmp_path), overlap), 2)
     seen = set()
     for r in range(2):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))

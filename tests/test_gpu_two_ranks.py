@@ -10,6 +10,8 @@ import sys
 import numpy as np
 import pytest
 
+from _spawn import spawn
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -148,7 +150,7 @@ def test_ranks_sharing_one_gpu_match_oracle(oracle, tmp_path, case, world, overl
     o.pgen(pgen, **pkw)
     for _ in range(ncyc):
         o.step()
-    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path), overlap), nprocs=world, join=True)
+    spawn(_worker, lambda port: (world, port, case, str(tmp_path), overlap), world)
     seen = set()
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
@@ -202,7 +204,7 @@ def test_turbulence_driver_on_two_ranks(oracle, tmp_path):
     o.pgen("turbulence", k_vec=_turb_k_vec())
     for _ in range(8):
         o.step()
-    mp.spawn(_turb_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    spawn(_turb_worker, lambda port: (2, port, str(tmp_path)), 2)
     for r in range(2):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         assert np.array_equal(z["var_hat"], o.var_hat())
