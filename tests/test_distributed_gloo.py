@@ -4,7 +4,6 @@ SAME HaloExchanger / all-reduce code the GPU path uses over RCCL, unpacks, and m
 with exactly the oracle's whole-mesh ghost fill.  (Pack/unpack are done with numpy here --
 on the GPU they are the copy_regions kernel.)"""
 import os
-import socket
 import sys
 
 import numpy as np
@@ -13,14 +12,6 @@ import pytest
 from _spawn import spawn
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
 
 
 def _apply(regions, base):

@@ -809,7 +809,6 @@ def test_refined_mesh_on_several_ranks_matches_one_rank(tmp_path, case, world):
     staged through the host): level-crossing halo messages, flux-correction messages, replicated
     forest updates from all-reduced tags and block migration on regridding must reproduce the
     one-rank run bit for bit"""
-    import socket
     import torch.multiprocessing as mp
     deck, ov, ncyc = AMR_RANK_CASES[case]
     ref = _sim(deck, ov, strict=True).initialize()

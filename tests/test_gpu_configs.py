@@ -12,7 +12,6 @@
         while no cell fails FirstOrderFluxCorrect's test
 """
 import os
-import socket
 import sys
 
 import numpy as np
@@ -29,14 +28,6 @@ GAMMA_DECK = 1.666666666666667
 def _sim(deck, overrides, strict=True, **kw):
     from athenapk_amd import decks, driver
     return driver.Simulation(decks.load(deck), overrides, strict=strict, **kw)
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
 
 
 # ---- config 3 as "thin-z 3-D" ----------------------------------------------------------------------------

@@ -9,7 +9,6 @@ peer on a dedicated HIP stream, ncclAllReduce on a second communicator.
   gloo with ranks sharing a GPU."""
 import ctypes as C
 import os
-import socket
 import sys
 
 import numpy as np
@@ -19,14 +18,6 @@ from _spawn import spawn
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
 
 
 @pytest.mark.parametrize("n", [1, 4097, 1 << 20])

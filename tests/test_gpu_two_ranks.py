@@ -4,7 +4,6 @@ RCCL needs one GPU per rank and the test box has one), dt / c_h / history / turb
 all-reduced.  Results must equal the oracle's single-process run: bit for bit for the pure
 hydro path in the strict build, to round-off where global sums are involved."""
 import os
-import socket
 import sys
 
 import numpy as np
@@ -13,14 +12,6 @@ import pytest
 from _spawn import spawn
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
 
 
 CASES = {
