@@ -249,6 +249,8 @@ struct apk_sim {
     // arguments: each half is captured once per mesh into a hipGraph and replayed as ONE launch
     // (void* = hipGraphExec_t; null = not captured, the plans are launched one by one)
     void *xchg_pre[2] = {nullptr, nullptr}, *xchg_post[2] = {nullptr, nullptr};
+    // no messages between the two halves (one rank): the `pre` graphs hold both halves -- one graph launch per exchange
+    bool xchg_whole = false;
     // the faces-only exchange of the stage loop (AmrLocalPlans::fill_faces ...)
     std::vector<apk_refine_plan *> prolongate_faces[2];
     apk_copy_plan *fill_faces[2] = {nullptr, nullptr}, *fill_pack_faces[2] = {nullptr, nullptr}, *fill_unpack_faces[2] = {nullptr, nullptr};

@@ -546,15 +546,19 @@ int amr_rebuild(apk_sim *s) {
     s->d_face_nbr = reinterpret_cast<int *>(p8);
     SIM_HIP(s, hipMemcpy(s->d_face_nbr, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
   }
+  // (a graph launch costs the host ~8 us and the stream a gap of that size: with no messages to wait for between the
+  // halves -- one rank -- an exchange is ONE graph; APK_NO_GRAPH=1 launches everything one by one)
+  a.xchg_whole = s->amr_halo.plan.peers.empty() && s->amr_halo_faces.plan.peers.empty() && s->amr_halo_shell.plan.peers.empty();
+  const bool w = a.xchg_whole;
   for (int par = 0; par < 2; ++par) {
-    amr_capture_half(s, par, true, 0, &a.xchg_pre[par]);
+    amr_capture_half(s, par, true, 0, &a.xchg_pre[par], w);
     amr_capture_half(s, par, false, 0, &a.xchg_post[par]);
-    amr_capture_half(s, par, true, 1, &a.xchg_pre_faces[par]);
+    amr_capture_half(s, par, true, 1, &a.xchg_pre_faces[par], w);
     amr_capture_half(s, par, false, 1, &a.xchg_post_faces[par]);
-    amr_capture_half(s, par, true, 2, &a.xchg_pre_direct[par]);
+    amr_capture_half(s, par, true, 2, &a.xchg_pre_direct[par], w);
     if (amr_has_shell(s)) {
-      amr_capture_half(s, par, true, AMR_XCHG_SHELL, &a.xchg_pre_shell[par]);
-      amr_capture_half(s, par, true, AMR_XCHG_SHELL_DIRECT, &a.xchg_pre_shell_direct[par]);
+      amr_capture_half(s, par, true, AMR_XCHG_SHELL, &a.xchg_pre_shell[par], w);
+      amr_capture_half(s, par, true, AMR_XCHG_SHELL_DIRECT, &a.xchg_pre_shell_direct[par], w);
       amr_capture_half(s, par, false, AMR_XCHG_SHELL, &a.xchg_post_shell[par]);
     }
   }
@@ -601,7 +605,8 @@ int amr_exchange_post(apk_sim *s, int buf, int mode) {
 // which cannot be captured: the launches are recorded on a private stream (nothing executes) and
 // the graph is launched on the sim's stream later.  Any failure leaves *out null: the caller then
 // launches the plans one by one as before.
-void amr_capture_half(apk_sim *s, int buf, bool pre, int mode, void **out) {
+// whole (with pre): both halves in one graph -- for meshes whose exchange has no messages between them
+void amr_capture_half(apk_sim *s, int buf, bool pre, int mode, void **out, bool whole) {
   *out = nullptr;
   static const bool disabled = std::getenv("APK_NO_GRAPH") != nullptr;  // A/B switch
   if (disabled) return;
@@ -614,7 +619,8 @@ void amr_capture_half(apk_sim *s, int buf, bool pre, int mode, void **out) {
     const apk_stream_t saved = s->stream;
     const std::string saved_err = s->err;
     s->stream = reinterpret_cast<apk_stream_t>(cs);
-    const int rc = pre ? amr_exchange_pre(s, buf, mode) : amr_exchange_post(s, buf, mode);
+    int rc = pre ? amr_exchange_pre(s, buf, mode) : amr_exchange_post(s, buf, mode);
+    if (rc == APK_OK && pre && whole) rc = amr_exchange_post(s, buf, mode);
     s->stream = saved;
     ok = hipStreamEndCapture(cs, &graph) == hipSuccess && rc == APK_OK && graph != nullptr;
     if (rc != APK_OK) s->err = saved_err;
@@ -662,9 +668,11 @@ int amr_exchange(apk_sim *s, int buf, int mode) {
   void *post = shell ? a.xchg_post_shell[buf] : (faces ? a.xchg_post_faces[buf] : a.xchg_post[buf]);
   if (pre) SIM_HIP(s, hipGraphLaunch(static_cast<hipGraphExec_t>(pre), hs(s)));
   else SIM_TRY(s, amr_exchange_pre(s, buf, mode));
-  SIM_TRY(s, amr_exchange_messages(s, shell ? s->amr_halo_shell : (faces ? s->amr_halo_faces : s->amr_halo)));
-  if (post) SIM_HIP(s, hipGraphLaunch(static_cast<hipGraphExec_t>(post), hs(s)));
-  else SIM_TRY(s, amr_exchange_post(s, buf, mode));
+  if (!(pre && a.xchg_whole)) {  // (else the graph held both halves)
+    SIM_TRY(s, amr_exchange_messages(s, shell ? s->amr_halo_shell : (faces ? s->amr_halo_faces : s->amr_halo)));
+    if (post) SIM_HIP(s, hipGraphLaunch(static_cast<hipGraphExec_t>(post), hs(s)));
+    else SIM_TRY(s, amr_exchange_post(s, buf, mode));
+  }
   // (of cons; the caller converts to primitives)
   s->amr_ghost_state = mode == AMR_XCHG_FULL ? AMR_GHOSTS_COMPLETE
                        : (mode == AMR_XCHG_SHELL ? AMR_GHOSTS_SHELL : (mode == AMR_XCHG_SHELL_DIRECT ? AMR_GHOSTS_SHELL_DIRECT : AMR_GHOSTS_FACES));

@@ -128,7 +128,7 @@ bool amr_has_shell(const apk_sim *s);
 bool amr_shell_before_check(const apk_sim *s);
 int amr_exchange_pre(apk_sim *s, int buf, int mode);
 int amr_exchange_post(apk_sim *s, int buf, int mode);
-void amr_capture_half(apk_sim *s, int buf, bool pre, int mode, void **out);
+void amr_capture_half(apk_sim *s, int buf, bool pre, int mode, void **out, bool whole = false);
 void amr_destroy_graphs(apk_sim *s);
 bool amr_has_coarse_fine_faces(const apk_sim *s);
 int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi_factor, bool planes_ahead = false);
