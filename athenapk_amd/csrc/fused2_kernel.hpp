@@ -89,12 +89,18 @@ constexpr bool m12f_keeps_raw_rows() {
   return 2 * (2 * recon_halfwidth(RECON) * nvars<FLUID>() * 64 * (int)sizeof(double)) <= 19 * 1024;
 }
 
-template <int FLUID, int RECON, int RS, int EXTRA, bool LEAN, bool FC = false>
+// X1H (apk_stage_args.x1_halo; lean forms that read stored primitives): lanes on x1 ghost columns behind a face with a
+// receive segment load their rows from that segment -- a per-lane stride between variables and a per-lane row offset,
+// where every other lane adds the wave-uniform n * sn + row * st to its pointer -- and lanes that retire a cell within
+// `send_depth` of a face with a send segment store it a second time, into the segment.  A template parameter: the
+// per-lane stride is a register pair the marches without it do not carry.
+template <int FLUID, int RECON, int RS, int EXTRA, bool LEAN, bool FC = false, bool X1H = false>
 __global__ void __launch_bounds__(64, 2)
 fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves, int per_xcd,
                   long long total_rows) {
   static_assert(RECON != APK_RC_DC, "donor-cell stages have their own single-kernel form");
   static_assert(!FC || LEAN, "prim_from_cons: lean form only");
+  static_assert(!X1H || (LEAN && !FC), "x1_halo: the lean form that reads stored primitives");
   constexpr int NV = nvars<FLUID>();
   constexpr int H = recon_halfwidth(RECON);
   constexpr int NS = 2 * H;
@@ -219,11 +225,61 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
         if (nb >= 0) prim_generic = input_of(nb) + base + (i < u0.is ? u0.nx1 : -u0.nx1);
       }
     }
+    // x1_halo, receive side: a ghost-column lane whose face has a segment reads its rows there -- [var][k][j][depth]
+    // (rows outside the interior, which only the x2 stencil of interior columns needs, repeat the nearest row: valid
+    // addresses, unused values)
+    [[maybe_unused]] int64_t lsn = u0.sn;  // (X1H: per lane)
+    [[maybe_unused]] int gseg = 0;       // (X1H: per lane, tested afresh at every use -- see X1Store)
+#ifndef APK_X1H_NO_RECV
+    if constexpr (X1H) {
+      if (sp.x1_blocks && sp.x1_recv_depth > 0 && ((i < u0.is) || (i > u0.ie))) {
+        const int dpt = sp.x1_recv_depth, side = (i < u0.is) ? 0 : 1;
+        const int col = side ? i - (u0.ie + 1) : i - (u0.is - dpt);
+        const double *seg = sp.x1_blocks[b].recv[side];
+        if (seg && col >= 0 && col < dpt) {
+          prim_generic = seg + (int64_t)krow * dpt * u0.nx2 + col;
+          lsn = (int64_t)dpt * u0.nx2 * u0.nx3;
+          gseg = 1;
+        }
+      }
+    }
+#endif
     const auto prim = as_global(prim_generic);
     auto row_off = [&](int r) -> int64_t {
       const int64_t d = (r < u0.js) ? nbr_lo : ((r > u0.je) ? nbr_hi : (int64_t)0);  // wave-uniform
-      return (int64_t)r * st + (gcol ? (int64_t)0 : d);
+      const int64_t ord = (int64_t)r * st + (gcol ? (int64_t)0 : d);
+      if constexpr (X1H) {
+        const int rc = (r < u0.js) ? 0 : ((r > u0.je) ? u0.nx2 - 1 : r - u0.js);  // wave-uniform
+        asm volatile("" : "+v"(gseg));
+        return gseg ? (int64_t)rc * sp.x1_recv_depth : ord;
+      } else {
+        return ord;
+      }
     };
+    // the NV variables of row r of this lane's column.  X1H: the stride between them is the lane's own, so the addresses
+    // are a chain of per-lane additions -- pinned, or the compiler keeps the eight multiples n * lsn in registers across
+    // the march (+16 VGPRs where 15 are free)
+    auto load_row = [&](int r, double (&row)[NV]) {
+      if constexpr (X1H) {
+        auto p = prim + row_off(r);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+          row[n] = *p;
+          if (n + 1 < NV) {
+            p += lsn;
+            asm volatile("" : "+v"(p), "+v"(lsn));
+          }
+        }
+      } else {
+#pragma unroll
+        for (int n = 0; n < NV; ++n) row[n] = prim[n * u0.sn + row_off(r)];
+      }
+    };
+    // x1_halo, send side
+    [[maybe_unused]] X1Store xs;
+#ifndef APK_X1H_NO_SEND
+    if constexpr (X1H) xs = x1_store_of<true>(sp, u0, b, i, active, (int64_t)krow * sp.x1_send_depth * u0.nx2, sp.x1_send_depth);
+#endif
 
     int c = s - 1;
     const int r0 = c - H;
@@ -232,8 +288,12 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
       double init[NS][NV];
 #pragma unroll
       for (int m = 0; m < NS; ++m)
+        if constexpr (X1H) {
+          load_row(r0 + m, init[m]);
+        } else {
 #pragma unroll
-        for (int n = 0; n < NV; ++n) init[m][n] = prim[n * u0.sn + row_off(r0 + m)];
+          for (int n = 0; n < NV; ++n) init[m][n] = prim[n * u0.sn + row_off(r0 + m)];
+        }
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int m = 0; m < NS; ++m) {
@@ -247,8 +307,12 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
       }
     }
     double Pn[NV];  // row c+H (FC: as loaded until the x2 reconstruction that first uses it)
+    if constexpr (X1H) {
+      load_row(c + H, Pn);
+    } else {
 #pragma unroll
-    for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + row_off(c + H)];
+      for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + row_off(c + H)];
+    }
 
     double wl_prev[NV], f_prev[NV];  // x2: permuted L state at face c / flux at face c-1
 #pragma unroll
@@ -396,8 +460,12 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
           for (int n = 0; n < NV; ++n) rawring[(slot0 * NV + n) * 64 + lane] = Praw[n];
         }
         slot0 = (slot0 + 1) & (NS - 1);
+        if constexpr (X1H) {
+          load_row(c + 1 + H, Pn);
+        } else {
 #pragma unroll
-        for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + row_off(c + 1 + H)];
+          for (int n = 0; n < NV; ++n) Pn[n] = prim[n * u0.sn + row_off(c + 1 + H)];
+        }
       }
       APK_TICK(3);  // x2 reconstruction, ring write, next-row loads issued
       // ---- (4) x2 face between rows c-1 and c; retire row c-1
@@ -467,7 +535,8 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
                 if (sp.prim_from_cons == 2) finish_cell_old_held<FLUID, EXTRA, LEAN>(u0, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd, rawv);
                 else finish_cell_at<FLUID, EXTRA, LEAN>(u0, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd);
               } else {
-                finish_cell_at<FLUID, EXTRA, LEAN>(u0, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd);
+                if constexpr (X1H) finish_cell_at<FLUID, EXTRA, LEAN>(u0, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd, &xs, c - 1 - u0.js);
+                else finish_cell_at<FLUID, EXTRA, LEAN>(u0, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd);
               }
             } else {
               finish_cell<FLUID, EXTRA, LEAN>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd);
@@ -571,6 +640,17 @@ inline bool two_kernel_stage_applies(const PackView &u0, int recon, int extra, c
   return u0.ndim == 3 && recon != APK_RC_DC && wide_enough && offsets_fit && (extra == EXTRA_NONE || sp.prim_to_u1);
 }
 
+// does a stage of this form follow apk_stage_args.x1_halo?  (apk_stage_x1_halo; launch_fused_stage refuses the others)
+inline bool x1_halo_stage_ok(const PackView &u0, int recon, int extra, const StageParams &sp) {
+  if (u0.ndim != 3 || sp.mflux || !stage_is_lean(sp) || sp.window) return false;
+  const int deepest = sp.x1_send_depth > sp.x1_recv_depth ? sp.x1_send_depth : sp.x1_recv_depth;
+  if (u0.nx1 < 2 * deepest || sp.x1_send_depth < 0 || sp.x1_recv_depth < 0 || sp.x1_recv_depth > u0.ng) return false;
+  if (sp.x1_send_field == 1 && extra == EXTRA_NONE) return false;  // (primitives to send: a stage that computes them)
+  if (recon == APK_RC_DC)  // the two-row march, which has no form with the time-step estimate for it
+    return sp.phase == 0 && (extra == EXTRA_NONE || (sp.prim_to_u1 && extra == EXTRA_C2P)) && u0.nx2 % 2 == 0 && u0.nx2 >= 4;
+  return two_kernel_stage_applies(u0, recon, extra, sp) && !sp.prim_from_cons;
+}
+
 template <int FLUID, int RECON, int RS>
 inline void launch_m12f(const PackView &u0, const PackView &u1, const StageParams &sp, int extra, hipStream_t s) {
   if constexpr (RECON != APK_RC_DC) {
@@ -591,7 +671,13 @@ inline void launch_m12f(const PackView &u0, const PackView &u1, const StageParam
     constexpr int lds_fc = m12f_keeps_raw_rows<FLUID, RECON>() ? 2 * lds : lds;  // (the rows as loaded, too)
 #define APK_LAUNCH_M12F_FC(EXTRA_) \
   hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, true, true>), g, dim3(64), lds_fc, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows)
-    if (sp.prim_from_cons) {  // (lean forms only: launch_fused_stage has checked)
+#define APK_LAUNCH_M12F_X1H(EXTRA_) \
+  hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, true, false, true>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows)
+    if (sp.x1_blocks) {  // (the lean form that reads stored primitives: launch_fused_stage has checked)
+      if (extra == EXTRA_C2P_DT) APK_LAUNCH_M12F_X1H(EXTRA_C2P_DT);
+      else if (extra == EXTRA_C2P) APK_LAUNCH_M12F_X1H(EXTRA_C2P);
+      else APK_LAUNCH_M12F_X1H(EXTRA_NONE);
+    } else if (sp.prim_from_cons) {  // (lean forms only: launch_fused_stage has checked)
       if (extra == EXTRA_C2P_DT) APK_LAUNCH_M12F_FC(EXTRA_C2P_DT);
       else if (extra == EXTRA_C2P) APK_LAUNCH_M12F_FC(EXTRA_C2P);
       else APK_LAUNCH_M12F_FC(EXTRA_NONE);
@@ -607,6 +693,7 @@ inline void launch_m12f(const PackView &u0, const PackView &u1, const StageParam
     }
 #undef APK_LAUNCH_M12F
 #undef APK_LAUNCH_M12F_FC
+#undef APK_LAUNCH_M12F_X1H
 #if APK_M12F_TIMING
     {
       static int calls = 0;

@@ -41,6 +41,15 @@ int launch_stage_fused(apk_ctx *ctx, const PackView &u0, const PackView &u1,
   sp.bad_count = nullptr;
   sp.out_delta = a.cons_out_delta;
   sp.face_nbr = a.face_neighbor;
+  sp.x1_blocks = nullptr;
+  sp.x1_recv_depth = sp.x1_send_depth = sp.x1_send_field = 0;
+  if (a.x1_halo) {
+    if (!a.x1_halo->blocks || a.x1_halo->send_field < 0 || a.x1_halo->send_field > 1) return APK_ERR_INVALID;
+    sp.x1_blocks = a.x1_halo->blocks;
+    sp.x1_recv_depth = a.x1_halo->recv_depth;
+    sp.x1_send_depth = a.x1_halo->send_depth;
+    sp.x1_send_field = a.x1_halo->send_field;
+  }
   if (a.cons_store < 0 || a.cons_store > 2) return APK_ERR_INVALID;
   // (only the stage whose primitives go out of place may drop its conserved result; a windowed phase keeps everything)
   sp.cons_store = (a.fill_derived == 2 && !a.trial && a.cons_out_delta == 0) ? a.cons_store : 0;

@@ -59,8 +59,75 @@ struct StageParams {
   int cons_store;  // apk_stage_args.cons_store (0 all cells, 1 the nghost-deep shell of every block, 2 none)
   int no_prim_store;   // apk_stage_args.fill_derived = 3: ConsToPrim for the dt estimate only
   int prim_from_cons;  // apk_stage_args.prim_from_cons
+  // apk_stage_args.x1_halo: per block the exchange-buffer segments its x1 ghost columns are read from / its x1 boundary
+  // columns are also stored into (device array, or NULL), their depths in columns, and what is stored (0 cons, 1 prim)
+  const apk_x1_halo_block *x1_blocks;
+  int x1_recv_depth, x1_send_depth, x1_send_field;
   apk_ctx *ctx;  // host side only (kernel timing); never dereferenced on the device
 };
+
+// A lane's share of apk_stage_args.x1_halo on the sending side: where the cells it retires along its march go in the
+// send segment -- seg[n * sn + step * stride], `step` counting along the march from the first interior index -- or
+// seg == nullptr for the lanes (nearly all) whose column is not within `depth` of an x1 face with a segment.  Segments
+// are [var][k][j][depth]; `fixed` = the offset the lane's coordinates across the march contribute (j march: k * depth *
+// nx2, stride depth; k march: j * depth, stride depth * nx2).
+// Everything here lives in VECTOR registers on purpose, wave-uniform values included, and the lane test is redone at
+// every use (lane_fresh): the marches have vector registers to spare and no scalar ones -- a loop-invariant lane mask or
+// stride in scalar registers is spilled to vector lanes and costs a v_readlane per use (first form of this: +46 of them
+// per iteration of the finishing march).
+struct X1Store {
+  double *seg = nullptr;
+  int64_t sn = 0, stride = 0;
+};
+APK_DEV int64_t lane_fresh(int64_t x) {  // (the value as the compiler last saw it -- in a vector register pair, not to be hoisted)
+  asm volatile("" : "+v"(x));
+  return x;
+}
+template <class T>
+APK_DEV T *lane_fresh(T *p) {
+  asm volatile("" : "+v"(p));
+  return p;
+}
+// (IN_VGPRS: the finishing march of the two-kernel stage; the donor-cell march has scalar registers to spare and no
+// vector ones -- there the strides stay wave-uniform)
+template <bool IN_VGPRS>
+APK_DEV X1Store x1_store_of(const StageParams &sp, const PackView &pv, int b, int i, bool active, int64_t fixed, int64_t stride) {
+  X1Store x;
+  if (sp.x1_blocks && sp.x1_send_depth > 0 && active) {
+    const int dpt = sp.x1_send_depth;
+    const int side = (i < pv.is + dpt) ? 0 : ((i > pv.ie - dpt) ? 1 : -1);
+    if (side >= 0) {
+      double *seg = sp.x1_blocks[b].send[side];
+      if (seg) x.seg = seg + fixed + (side ? i - (pv.ie - dpt + 1) : i - pv.is);
+    }
+  }
+  x.sn = (int64_t)sp.x1_send_depth * pv.nx2 * pv.nx3;
+  x.stride = stride;
+  if constexpr (IN_VGPRS) {
+    x.sn = lane_fresh(x.sn);
+    x.stride = lane_fresh(x.stride);
+  }
+  return x;
+}
+template <int NV, bool IN_VGPRS = true>
+APK_DEV void x1_store_row(X1Store &x, int step, const double (&v)[NV]) {
+  if constexpr (IN_VGPRS) {
+    x.seg = lane_fresh(x.seg);
+    if (x.seg) {
+      x.sn = lane_fresh(x.sn);
+      double *p = x.seg + lane_fresh(x.stride) * step;
+#pragma unroll
+      for (int n = 0; n < NV; ++n) {
+        store_result(as_global(p), v[n]);
+        if (n + 1 < NV) p = lane_fresh(p + x.sn);
+      }
+    }
+  } else if (x.seg) {
+    double *p = x.seg + x.stride * step;
+#pragma unroll
+    for (int n = 0; n < NV; ++n) store_result(&as_global(p)[n * x.sn], v[n]);
+  }
+}
 
 // L / R state at the lower `st`-face of the cell c points at (L = ql of the cell below, R = qr of
 // this cell), any reconstruction
@@ -198,12 +265,12 @@ inline bool stage_is_lean(const StageParams &sp) {
 APK_DEV double update_coefficient(const StageParams &sp, double vol) { return to_sgpr(-sp.beta_dt / vol); }
 
 // (HELD: old_held is the old u0 of this cell, already in registers -- the from-cons finishing march keeps the rows it loaded)
-template <int FLUID, int EXTRA, bool LEAN, bool HELD, class AT>
+template <int FLUID, int EXTRA, bool LEAN, bool HELD, class AT, bool XV = true>
 APK_DEV void finish_cell_impl(const PackView &pv, const apk_block_desc &b0,
                               const double (&u1v)[nvars<FLUID>()], const AT &at,
                               const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp,
                               double &lane_min_dt, double *prim_dst, double upd, bool store_cons,
-                              const double (&old_held)[nvars<FLUID>()]) {
+                              const double (&old_held)[nvars<FLUID>()], X1Store *xs = nullptr, int xrow = 0) {
   constexpr int NV = nvars<FLUID>();
   // (the general form's per-variable accesses, the extended Dedner source: a per-lane cell index; lean forms only reach
   // here with a RowCellAt)
@@ -289,12 +356,14 @@ APK_DEV void finish_cell_impl(const PackView &pv, const apk_block_desc &b0,
     if (prim_dst) {  // (wave-uniform; NULL: fill_derived = 3, the primitives only feed the time-step estimate)
       store_vars<NV>(prim_dst, pv.sn, at, w);
     }
+    if (xs && sp.x1_send_field == 1) x1_store_row<NV, XV>(*xs, xrow, w);  // (apk_stage_args.x1_halo: the new primitives)
     if constexpr (EXTRA == EXTRA_C2P_DT) {
       // EstimateHyperbolicTimestep (hydro.cpp:845-895) on the fresh primitives
       lane_min_dt = fmin(lane_min_dt, cell_dt_hyp<FLUID>(sp.eos.gamma, w, di, pv.ndim, b0.dx[0], b0.dx[1], b0.dx[2]));
     }
   }
   if (store_cons) store_vars<NV>(b0.cons + sp.out_delta, pv.sn, at, un);
+  if (xs && sp.x1_send_field == 0) x1_store_row<NV, XV>(*xs, xrow, un);  // (apk_stage_args.x1_halo: the updated conserved state)
   if constexpr (!LEAN) {
     if (bad) atomicAdd(sp.bad_count, 1ull);
   }
@@ -303,16 +372,16 @@ APK_DEV void finish_cell_impl(const PackView &pv, const apk_block_desc &b0,
 template <int FLUID, int EXTRA = EXTRA_NONE, bool LEAN = false>
 APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0, const double (&u1v)[nvars<FLUID>()], int64_t cell,
                          const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp, double &lane_min_dt,
-                         double *prim_dst = nullptr, double upd = 0.0, bool store_cons = true) {
+                         double *prim_dst = nullptr, double upd = 0.0, bool store_cons = true, X1Store *xs = nullptr, int xrow = 0) {
   const double none[nvars<FLUID>()] = {};
-  finish_cell_impl<FLUID, EXTRA, LEAN, false>(pv, b0, u1v, CellAt{cell}, du, vol, sp, lane_min_dt, prim_dst, upd, store_cons, none);
+  finish_cell_impl<FLUID, EXTRA, LEAN, false, CellAt, false>(pv, b0, u1v, CellAt{cell}, du, vol, sp, lane_min_dt, prim_dst, upd, store_cons, none, xs, xrow);
 }
 template <int FLUID, int EXTRA, bool LEAN, class AT>
 APK_DEV void finish_cell_at(const PackView &pv, const apk_block_desc &b0, const double (&u1v)[nvars<FLUID>()], const AT &at,
                             const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp, double &lane_min_dt,
-                            double *prim_dst, double upd) {
+                            double *prim_dst, double upd, X1Store *xs = nullptr, int xrow = 0) {
   const double none[nvars<FLUID>()] = {};
-  finish_cell_impl<FLUID, EXTRA, LEAN, false>(pv, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd, true, none);
+  finish_cell_impl<FLUID, EXTRA, LEAN, false>(pv, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd, true, none, xs, xrow);
 }
 template <int FLUID, int EXTRA, bool LEAN, class AT>
 APK_DEV void finish_cell_old_held(const PackView &pv, const apk_block_desc &b0, const double (&u1v)[nvars<FLUID>()], const AT &at,
@@ -883,14 +952,33 @@ fused_march12_kernel(PackView u0, PackView u1, StageParams sp, int waves_per_blo
 // conserved state (apk_stage_args.prim_from_cons), ConsToPrim of what was loaded -- the function the finishing sweep of the
 // previous stage applied to the same values (lean form: no floor but the density / energy ones, no flags: the state was
 // checked when it was produced).
-template <int FLUID, bool FROM_CONS>
+// the NV variables of one cell when the stride between them is the LANE's (x1_halo: ghost-column lanes read a receive
+// segment): a chain of per-lane additions, pinned -- otherwise the multiples n * sn are kept in registers across the march
+template <int NV>
+APK_DEV void load_chain(const double *p, int64_t lane_sn, double (&v)[NV]) {
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    v[n] = *p;
+    if (n + 1 < NV) {
+      p += lane_sn;
+      asm volatile("" : "+v"(p));
+    }
+  }
+}
+template <int FLUID, bool FROM_CONS, bool LANE_SN = false>
 APK_DEV void load_input_state(const double *p, int64_t sn, const StageParams &sp, double (&w)[nvars<FLUID>()]) {
   constexpr int NV = nvars<FLUID>();
   if constexpr (FROM_CONS) {
     double u[NV], di;
+    if constexpr (LANE_SN) {
+      load_chain<NV>(p, sn, u);
+    } else {
 #pragma unroll
     for (int n = 0; n < NV; ++n) u[n] = p[n * sn];
+    }
     (void)cons_to_prim_core<FLUID, true>(sp.eos, sp.k.eos_gm1, sp.k.vceil_sq, sp.k.pfloor_over_gm1, u, w, di);
+  } else if constexpr (LANE_SN) {
+    load_chain<NV>(p, sn, w);
   } else {
 #pragma unroll
     for (int n = 0; n < NV; ++n) w[n] = p[n * sn];
@@ -1159,7 +1247,10 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
 // working set of a solve stays what it was; the carried state doubles: 2 x 9 doubles of the previous plane in VGPRs,
 // 4 x 9 rows in the LDS stash (18.4 KB per wave, inside the 20 KB two waves per SIMD leave).
 // ==============================================================================================
-template <int FLUID, int RS, int EXTRA, bool FROM_CONS = false>
+// X1H (apk_stage_args.x1_halo): the lanes on the two ghost columns read their cells from the receive segment of that face
+// -- strides of their own between variables, rows and planes -- and the lanes within `send_depth` columns of a face with
+// a send segment store what they retire a second time, into the segment (see fused_m12f_kernel).
+template <int FLUID, int RS, int EXTRA, bool FROM_CONS = false, bool X1H = false>
 __global__ void __launch_bounds__(64, 2)
 fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, int nseg, int per_xcd) {
   constexpr int NV = nvars<FLUID>();
@@ -1208,6 +1299,40 @@ fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, 
       if (fn[5] >= 0) prim_khi = input_of(fn[5]) + col - (int64_t)u0.nx3 * u0.sk;
     }
   }
+  // x1_halo, receive side: [var][k][j][depth]; the ghost column next to the face is the last of the lower segment's
+  // columns, the first of the upper one's.  Planes and rows outside the interior (read by every lane for the x2 / x3
+  // faces of its own cells, which ghost-column lanes do not retire) repeat the nearest one: valid addresses.
+  [[maybe_unused]] int64_t lsn = u0.sn;  // (X1H: per lane)
+  [[maybe_unused]] int lsk = (int)u0.sk, lsj = (int)u0.sj;  // (a block's plane fits 31 bits: two_kernel_stage_applies' rule for sn)
+  [[maybe_unused]] bool gseg = false;
+#ifndef APK_X1H_NO_RECV
+  if constexpr (X1H) {
+    if (sp.x1_blocks && sp.x1_recv_depth > 0 && (i < u0.is || i > u0.ie)) {
+      const int dpt = sp.x1_recv_depth, side = (i < u0.is) ? 0 : 1;
+      const double *seg = sp.x1_blocks[b].recv[side];
+      if (seg) {
+        lsj = dpt;
+        lsk = dpt * u0.nx2;
+        lsn = (int64_t)lsk * u0.nx3;
+        // (plane c of row ja is prim + c * lsk, like everywhere else: the segment's first plane is ks)
+        prim = seg + (int64_t)(ja - u0.js) * lsj + (side ? 0 : dpt - 1) - (int64_t)u0.ks * lsk;
+        prim_jm = (ja - 1 < u0.js) ? prim : prim - lsj;
+        prim_jp = (ja + 2 > u0.je) ? prim + lsj : prim + 2 * lsj;
+        prim_klo = prim_khi = prim;
+        gseg = true;
+      }
+    }
+  }
+#endif
+  auto plane = [&](int c) -> int {  // (wave-uniform candidates, chosen per lane)
+    if constexpr (X1H) return gseg ? ((c < u0.ks) ? u0.ks : ((c > u0.ke) ? u0.ke : c)) : c;
+    else return c;
+  };
+  // x1_halo, send side: cell A's place; cell B's is one row (lsj of the segment = send_depth) further
+  [[maybe_unused]] X1Store xs;
+#ifndef APK_X1H_NO_SEND
+  if constexpr (X1H) xs = x1_store_of<false>(sp, u0, b, i, active, (int64_t)(ja - u0.js) * sp.x1_send_depth, (int64_t)sp.x1_send_depth * u0.nx2);
+#endif
   const double area1 = b0.dx[1] * b0.dx[2], area2 = b0.dx[0] * b0.dx[2], area3 = b0.dx[0] * b0.dx[1];
   const double vol = b0.dx[0] * b0.dx[1] * b0.dx[2];
   const double upd = update_coefficient(sp, vol);
@@ -1231,7 +1356,7 @@ fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, 
   double wprev[2][NV], cf3_prev[2] = {0.0, 0.0};
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    load_input_state<FLUID, FROM_CONS>(((s - 1 < u0.ks) ? prim_klo : prim) + (int64_t)(s - 1) * u0.sk + r * u0.sj, u0.sn, sp, wprev[r]);
+    load_input_state<FLUID, FROM_CONS, X1H>(((s - 1 < u0.ks) ? prim_klo : prim) + (int64_t)plane(s - 1) * lsk + r * lsj, lsn, sp, wprev[r]);
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
       st_f3[r][n * 64] = 0.0;
@@ -1246,11 +1371,16 @@ fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, 
   }
   double raw[2][NV];
   auto load_raw = [&](int c) {
-    const double *pc = ((c > u0.ke) ? prim_khi : prim) + (int64_t)c * u0.sk;  // wave-uniform
+    const double *pc = ((c > u0.ke) ? prim_khi : prim) + (int64_t)plane(c) * lsk;  // (the choice of base is wave-uniform)
+    if constexpr (X1H) {
+      load_chain<NV>(pc, lsn, raw[0]);
+      load_chain<NV>(pc + lsj, lsn, raw[1]);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+      for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int n = 0; n < NV; ++n) raw[r][n] = pc[n * u0.sn + r * u0.sj];
+        for (int n = 0; n < NV; ++n) raw[r][n] = pc[n * u0.sn + r * u0.sj];
+    }
   };
   auto to_input = [&](const double (&u)[NV], double (&w)[NV]) {
     if constexpr (FROM_CONS) {
@@ -1270,7 +1400,7 @@ fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, 
   constexpr int HOLD = (FROM_CONS && EXTRA != EXTRA_NONE) ? 2 : 0;
   double held[HOLD > 0 ? HOLD : 1][NV];
   for (int c = s; c <= e + 1; ++c) {
-    const int64_t off = (int64_t)c * u0.sk;
+    const int64_t off = (int64_t)plane(c) * lsk;
     double wc[2][NV];
     load_raw(c);
     to_input(raw[0], wc[0]);
@@ -1303,7 +1433,15 @@ fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, 
           for (int n = 0; n < NV; ++n) u1v[n] = c1[n * u0.sn + done];
         }
         const bool store = sp.cons_store == 0 || (sp.cons_store == 1 && (shell_ij[r] || c - 1 < u0.ks + u0.ng || c - 1 > u0.ke - u0.ng));
-        if (active) finish_cell<FLUID, EXTRA, true>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd, store);
+        if constexpr (X1H) {
+          if (active) {
+            X1Store xr = xs;
+            if (r == 1 && xr.seg) xr.seg += sp.x1_send_depth;
+            finish_cell<FLUID, EXTRA, true>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd, store, &xr, c - 1 - u0.ks);
+          }
+        } else {
+          if (active) finish_cell<FLUID, EXTRA, true>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd, store);
+        }
       }
       if (r < HOLD) {  // (plane c of this cell, for the next iteration)
 #pragma unroll
@@ -1343,7 +1481,7 @@ fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, 
       solve(wa, wb, cfa, cfb, fmid);
       {
         double wm[NV], flo[NV], wnat[NV];
-        load_input_state<FLUID, FROM_CONS>(prim_jm + off, u0.sn, sp, wnat);
+        load_input_state<FLUID, FROM_CONS, X1H>(prim_jm + off, lsn, sp, wnat);
 #pragma unroll
         for (int q = 0; q < NV; ++q) wm[q] = wnat[perm<2>(q)];
         solve(wm, wa, cf_of(wm), cfa, flo);
@@ -1355,7 +1493,7 @@ fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, 
       }
       {
         double wp[NV], fhi[NV], wnat[NV];
-        load_input_state<FLUID, FROM_CONS>(prim_jp + off, u0.sn, sp, wnat);
+        load_input_state<FLUID, FROM_CONS, X1H>(prim_jp + off, lsn, sp, wnat);
 #pragma unroll
         for (int q = 0; q < NV; ++q) wp[q] = wnat[perm<2>(q)];
         solve(wb, wp, cfb, cf_of(wp), fhi);
@@ -1512,7 +1650,9 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
                                               : two_kernel_stage_applies(u0, RECON, extra, sp);
     if (u0.ndim != 3 || sp.mflux || sp.dedner == 2 || !form_ok) return APK_ERR_UNSUPPORTED;
   }
-  // apk_stage_args.fill_derived = 3 / prim_from_cons: the lean two-kernel stage / the lean single-march donor-cell stage only
+  // apk_stage_args.x1_halo: the lean two-row donor-cell march and the lean two-kernel stage's finishing march (phase 1 of
+  // a split two-kernel stage is the x3 sweep, which reads no x1 ghost column and retires nothing: it ignores the table)
+  if (sp.x1_blocks && !(RECON != APK_RC_DC && sp.phase == 1) && !x1_halo_stage_ok(u0, RECON, extra, sp)) return APK_ERR_UNSUPPORTED;
   if (sp.no_prim_store && !(u0.ndim == 3 && RECON != APK_RC_DC && stage_is_lean(sp) && two_kernel_stage_applies(u0, RECON, extra, sp)))
     return APK_ERR_UNSUPPORTED;
   if (sp.prim_from_cons) {
@@ -1575,7 +1715,18 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
           constexpr int lds4 = 4 * nvars<FLUID>() * 64 * (int)sizeof(double);
 #define APK_LAUNCH_DC3R2(EXTRA_, FC_) \
   hipLaunchKernelGGL((fused_dc3r2_kernel<FLUID, RS, EXTRA_, FC_>), g2, dim3(64), lds4, s, u0, u1, sp, kseg, wpb2, nseg, per_xcd2)
-          if (extra == EXTRA_C2P_DT) {
+#define APK_LAUNCH_DC3R2_X1H(EXTRA_, FC_) \
+  hipLaunchKernelGGL((fused_dc3r2_kernel<FLUID, RS, EXTRA_, FC_, true>), g2, dim3(64), lds4, s, u0, u1, sp, kseg, wpb2, nseg, per_xcd2)
+          if (sp.x1_blocks) {  // (apk_stage_args.x1_halo: stages without the dt estimate -- the predictor's place in a cycle)
+            if (extra == EXTRA_C2P_DT) return APK_ERR_UNSUPPORTED;
+            if (extra == EXTRA_C2P) {
+              if (sp.prim_from_cons) APK_LAUNCH_DC3R2_X1H(EXTRA_C2P, true);
+              else APK_LAUNCH_DC3R2_X1H(EXTRA_C2P, false);
+            } else {
+              if (sp.prim_from_cons) APK_LAUNCH_DC3R2_X1H(EXTRA_NONE, true);
+              else APK_LAUNCH_DC3R2_X1H(EXTRA_NONE, false);
+            }
+          } else if (extra == EXTRA_C2P_DT) {
             if (sp.prim_from_cons) APK_LAUNCH_DC3R2(EXTRA_C2P_DT, true);
             else APK_LAUNCH_DC3R2(EXTRA_C2P_DT, false);
           } else if (extra == EXTRA_C2P) {
@@ -1586,8 +1737,10 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
             else APK_LAUNCH_DC3R2(EXTRA_NONE, false);
           }
 #undef APK_LAUNCH_DC3R2
+#undef APK_LAUNCH_DC3R2_X1H
           return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
         }
+        if (sp.x1_blocks) return APK_ERR_UNSUPPORTED;  // (x1_halo: the two-row march only)
         if (sp.prim_from_cons) {  // (one row per lane: odd row counts, the windows of a split stage)
 #define APK_LAUNCH_DC3FC(EXTRA_) \
   hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_, true, true>), g, dim3(64), lds3, s, u0, u1, sp, kseg, wpb, nseg, per_xcd)

@@ -151,23 +151,66 @@ int rccl_exchange_begin(void *user) {
 // the halo stream waits for the pack kernel, the sim's stream later waits for the halo stream -- with one
 // device-to-device copy per peer standing in for the ncclSend / ncclRecv pair: the message the periodic image of this
 // rank would send is this rank's own send buffer.  Everything but the wire (xGMI) is as in the 8-GPU run.
+// (ONE kernel for the whole group, as RCCL launches one kernel per ncclGroupEnd: seven hipMemcpyAsync calls were seven
+// blit launches of 5 - 25 us each in a row)
+constexpr int kLoopbackSpans = 16;
+struct LoopbackSpans {
+  const double *src[kLoopbackSpans];
+  double *dst[kLoopbackSpans];
+  long long n[kLoopbackSpans];
+};
+__global__ void __launch_bounds__(256) loopback_spans_kernel(LoopbackSpans sp) {
+  const double *src = sp.src[blockIdx.y];
+  double *dst = sp.dst[blockIdx.y];
+  const long long n = sp.n[blockIdx.y];
+  const long long stride = (long long)gridDim.x * 256;
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
+    const long long n2 = n >> 1;
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+    double2 *d2 = reinterpret_cast<double2 *>(dst);
+    for (long long q = t; q < n2; q += stride) d2[q] = s2[q];
+    if ((n & 1) && t == 0) dst[n - 1] = src[n - 1];
+  } else {
+    for (long long q = t; q < n; q += stride) dst[q] = src[q];
+  }
+}
+
 int loopback_exchange_begin(void *user) {
   apk_sim *s = static_cast<apk_sim *>(user);
   RcclTransport *t = s->rccl;
   if (!hip_ok(t, hipEventRecord(t->ev_ready, hs(s)), "hipEventRecord")) return 1;
   if (!hip_ok(t, hipStreamWaitEvent(t->s_halo, t->ev_ready, 0), "hipStreamWaitEvent")) return 1;
   const int np = apk_sim_num_peers(s);
+  LoopbackSpans sp{};
+  int nsp = 0;
+  long long longest = 0;
   for (int p = 0; p < np; ++p) {
     apk_peer_info pi;
     if (apk_sim_peer(s, p, &pi) != APK_OK || pi.send_count != pi.recv_count) {
       t->err = "loopback: a peer's send and receive sizes differ";
       return 1;
     }
-    if (pi.send_count > 0 &&
-        !hip_ok(t, hipMemcpyAsync(pi.recv_buf, pi.send_buf, sizeof(double) * (size_t)pi.send_count, hipMemcpyDeviceToDevice, t->s_halo),
-                "hipMemcpyAsync"))
-      return 1;
+    if (pi.send_count <= 0) continue;
     t->loopback_bytes += (long long)sizeof(double) * pi.send_count;
+    if (np > kLoopbackSpans) {
+      if (!hip_ok(t, hipMemcpyAsync(pi.recv_buf, pi.send_buf, sizeof(double) * (size_t)pi.send_count, hipMemcpyDeviceToDevice, t->s_halo),
+                  "hipMemcpyAsync"))
+        return 1;
+      continue;
+    }
+    sp.src[nsp] = static_cast<const double *>(pi.send_buf);
+    sp.dst[nsp] = static_cast<double *>(pi.recv_buf);
+    sp.n[nsp] = pi.send_count;
+    if (pi.send_count > longest) longest = pi.send_count;
+    ++nsp;
+  }
+  if (nsp > 0) {
+    long long gx = (longest / 2 + 256 * 8 - 1) / (256 * 8);  // eight double2 per thread of the longest message
+    if (gx < 1) gx = 1;
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(loopback_spans_kernel, dim3((unsigned)gx, (unsigned)nsp), dim3(256), 0, t->s_halo, sp);
+    if (!hip_ok(t, hipGetLastError(), "loopback_spans_kernel")) return 1;
   }
   if (!hip_ok(t, hipEventRecord(t->ev_done, t->s_halo), "hipEventRecord")) return 1;
   t->exchanges += 1;

@@ -20,7 +20,13 @@ enum BcKind { BC_PERIODIC = 0, BC_OUTFLOW = 1, BC_REFLECT = 2 };
 enum RegionKind { RK_BLOCK = 0, RK_SEND = 1, RK_RECV = 2 };
 // PH_PACK_THIN / PH_UNPACK_THIN: the same messages ONE layer deep (kThinDepth) -- all that the exchange in front of a
 // donor-cell stage has to deliver (VL2: the one at the end of a cycle); same buffers, a prefix of them.
-enum PlanPhase { PH_LOCAL = 0, PH_PACK = 1, PH_UNPACK = 2, PH_BC1 = 3, PH_BC2 = 4, PH_BC3 = 5, PH_PACK_THIN = 6, PH_UNPACK_THIN = 7, PH_COUNT = 8 };
+// PH_*_NOX1: the same plans without the regions of x1 FACES (offset (+-1, 0, 0)) -- the segments keep their places in the
+// messages -- for exchanges whose x1 strips never pass through a copy kernel: the finishing kernel of the stage stores
+// its x1 boundary columns straight into the send buffers, the next stage's kernels read their x1 ghost columns straight
+// from the receive buffers (apk_stage_args.x1_halo; Mesh::x1_send / x1_recv say where).  A row of an x1 strip is
+// nghost doubles: 24 of every 128-byte line a copy kernel fetches from (or writes into) the block.
+enum PlanPhase { PH_LOCAL = 0, PH_PACK = 1, PH_UNPACK = 2, PH_BC1 = 3, PH_BC2 = 4, PH_BC3 = 5, PH_PACK_THIN = 6, PH_UNPACK_THIN = 7,
+                 PH_PACK_NOX1 = 8, PH_UNPACK_NOX1 = 9, PH_PACK_THIN_NOX1 = 10, PH_UNPACK_THIN_NOX1 = 11, PH_COUNT = 12 };
 constexpr int kThinDepth = 1;
 
 struct BoxRegion {
@@ -32,6 +38,12 @@ struct BoxRegion {
   int corner = 0;  // refined meshes: fills a block's ghost zone behind an EDGE or a CORNER (nothing in the stage loop reads it)
   int same_face = 0;  // refined meshes: fills the ghost zone behind a FACE from the interior of a block of the same level
                       // (not needed by a stage that reads that block directly, apk_stage_args.face_neighbor)
+};
+
+// where the x1 strip of a local block's lower / upper x1 face sits in a message (Mesh::x1_send / x1_recv)
+struct X1Segment {
+  int peer = -1;                 // index into Mesh::peers (-1: that face has no neighbour on another rank)
+  int64_t off = 0, off_thin = 0;  // element offset of the segment in the peer's full / one-layer message
 };
 
 struct PeerPlan {
@@ -61,6 +73,10 @@ struct Mesh {
   std::map<int, int> gid_local; // gid -> local index
   std::vector<PeerPlan> peers;
   std::vector<BoxRegion> plan[PH_COUNT];
+  // per local block and x1 side (0 lower, 1 upper): the segment its interior strip next to that face is packed into /
+  // the segment its ghost strip behind that face is unpacked from.  Segment layout (Compact): [var][k][j][depth], the
+  // interior extent in x2 and x3, depth = nghost (full) or kThinDepth (one-layer) columns counted in x1 order.
+  std::vector<std::array<X1Segment, 2>> x1_send, x1_recv;
 
   static uint64_t Morton(unsigned x, unsigned y, unsigned z) {
     uint64_t m = 0;
@@ -202,6 +218,8 @@ struct Mesh {
   void BuildPlans() {
     for (auto &p : plan) p.clear();
     peers.clear();
+    x1_send.assign(local_gids.size(), {});
+    x1_recv.assign(local_gids.size(), {});
     std::map<int, std::vector<Segment>> sends, recvs;  // by peer rank
     int lo[3], hi[3];
     for (int lb = 0; lb < (int)local_gids.size(); ++lb) {
@@ -281,6 +299,9 @@ struct Mesh {
         r.dst_off = pp.send_count;
         pp.send_count += (int64_t)r.ext[0] * r.ext[1] * r.ext[2] * nvar;
         plan[PH_PACK].push_back(r);
+        // (I am the receiver's neighbour at sgm.o: at its upper x1 side I send my LOWER strip)
+        const bool x1face = sgm.o[0] != 0 && sgm.o[1] == 0 && sgm.o[2] == 0;
+        if (!x1face) plan[PH_PACK_NOX1].push_back(r);
         BoxRegion t = r;  // the one-layer form of the same strip
         t.src_off = 0;
         for (int d = 0; d < 3; ++d) {
@@ -292,6 +313,8 @@ struct Mesh {
         t.dst_off = pp.send_count_thin;
         pp.send_count_thin += (int64_t)t.ext[0] * t.ext[1] * t.ext[2] * nvar;
         plan[PH_PACK_THIN].push_back(t);
+        if (!x1face) plan[PH_PACK_THIN_NOX1].push_back(t);
+        else x1_send[sgm.block][sgm.o[0] > 0 ? 0 : 1] = X1Segment{pidx, r.dst_off, t.dst_off};
       }
       for (const auto &sgm : rv) {  // unpack into my ghost region at offset sgm.o
         BoxRegion r;
@@ -310,6 +333,8 @@ struct Mesh {
         r.src_off = pp.recv_count;
         pp.recv_count += (int64_t)r.ext[0] * r.ext[1] * r.ext[2] * nvar;
         plan[PH_UNPACK].push_back(r);
+        const bool x1face = sgm.o[0] != 0 && sgm.o[1] == 0 && sgm.o[2] == 0;
+        if (!x1face) plan[PH_UNPACK_NOX1].push_back(r);
         BoxRegion t = r;
         t.dst_off = 0;
         for (int d = 0; d < 3; ++d) {
@@ -321,6 +346,8 @@ struct Mesh {
         t.src_off = pp.recv_count_thin;
         pp.recv_count_thin += (int64_t)t.ext[0] * t.ext[1] * t.ext[2] * nvar;
         plan[PH_UNPACK_THIN].push_back(t);
+        if (!x1face) plan[PH_UNPACK_THIN_NOX1].push_back(t);
+        else x1_recv[sgm.block][sgm.o[0] < 0 ? 0 : 1] = X1Segment{pidx, r.src_off, t.src_off};
       }
       peers.push_back(pp);
     }

@@ -227,7 +227,8 @@ int ensure_spare_prim(apk_sim *s) {
   const size_t bytes = (size_t)s->nper * s->mesh.local_gids.size() * sizeof(double);
   SIM_TRY(s, dev_alloc(s, "prim2", bytes, &s->d_prim2[1 - s->pcur]));
   SIM_HIP(s, hipMemsetAsync(s->d_prim2[1 - s->pcur], 0, bytes, hs(s)));
-  return build_packs(s);
+  SIM_TRY(s, build_packs(s));
+  return build_prim_plans(s);
 }
 
 int ensure_flux_arrays(apk_sim *s) {
@@ -252,25 +253,23 @@ bool stage_can_fuse(const apk_sim *s) {
          s->pkg.riemann != APK_RS_LLF;
 }
 
-double *region_base(apk_sim *s, int parity, int kind, int block) {
-  if (kind == RK_BLOCK) return s->d_cons2[parity] + (int64_t)block * s->nper;
-  if (kind == RK_SEND) return s->send_buf[block];
-  return s->recv_buf[block];
-}
-
-int build_copy_plans(apk_sim *s) {
-  for (int par = 0; par < 3; ++par)
+// the plans of one field buffer (`field`: the first block's array; blocks follow at nper doubles)
+static int make_plans(apk_sim *s, double *field, apk_copy_plan *(&out)[PH_COUNT]) {
   for (int ph = 0; ph < PH_COUNT; ++ph) {
-    if (s->plans_of[par][ph]) {
-      apk_copy_plan_destroy(s->plans_of[par][ph]);
-      s->plans_of[par][ph] = nullptr;
+    if (out[ph]) {
+      apk_copy_plan_destroy(out[ph]);
+      out[ph] = nullptr;
     }
-    if (!s->d_cons2[par]) continue;
+    if (!field) continue;
     std::vector<apk_copy_region> regs;
+    auto base = [&](int kind, int block) -> double * {
+      if (kind == RK_BLOCK) return field + (int64_t)block * s->nper;
+      return kind == RK_SEND ? s->send_buf[block] : s->recv_buf[block];
+    };
     for (const BoxRegion &r : s->mesh.plan[ph]) {
       apk_copy_region c{};
-      c.src = region_base(s, par, r.src_kind, r.src_block) + r.src_off;
-      c.dst = region_base(s, par, r.dst_kind, r.dst_block) + r.dst_off;
+      c.src = base(r.src_kind, r.src_block) + r.src_off;
+      c.dst = base(r.dst_kind, r.dst_block) + r.dst_off;
       for (int q = 0; q < 3; ++q) c.ext[q] = r.ext[q];
       c.nvar = r.nvar;
       for (int q = 0; q < 4; ++q) {
@@ -280,8 +279,20 @@ int build_copy_plans(apk_sim *s) {
       c.flip_var = r.flip_var;
       regs.push_back(c);
     }
-    SIM_TRY(s, apk_copy_plan_create(s->ctx, regs.data(), (int)regs.size(), &s->plans_of[par][ph]));
+    SIM_TRY(s, apk_copy_plan_create(s->ctx, regs.data(), (int)regs.size(), &out[ph]));
   }
+  return APK_OK;
+}
+
+int build_copy_plans(apk_sim *s) {
+  for (int par = 0; par < 3; ++par) SIM_TRY(s, make_plans(s, s->d_cons2[par], s->plans_of[par]));
+  return build_prim_plans(s);
+}
+
+// (exchanges of stored primitives -- GHOST_PRIM_COPY -- only happen on uniform meshes with remote neighbours or
+// same-rank copies: nothing to build where no plan has a region)
+int build_prim_plans(apk_sim *s) {
+  for (int w = 0; w < 2; ++w) SIM_TRY(s, make_plans(s, s->amr ? nullptr : s->d_prim2[w], s->pplans_of[w]));
   return APK_OK;
 }
 
@@ -361,6 +372,7 @@ bool ghost_c2p_fusable(const apk_sim *s) {
 int run_ghost_plan(apk_sim *s, int buf, int phase, int c2p, apk_stream_t stream) {
   if (!stream) stream = s->stream;
   if (!c2p) return apk_copy_plan_run(s->ctx, s->plans_of[buf][phase], stream);
+  if (c2p == GHOST_PRIM_COPY) return apk_copy_plan_run(s->ctx, s->pplans_of[s->xchg_prim][phase], stream);
   const int64_t delta = s->d_prim2[s->pcur] - s->d_cons2[buf];
   // a boundary phase that is followed by another non-empty one copies corner cells from ghost
   // zones only that later phase fills: their (overwritten) primitives must not raise flags
@@ -385,11 +397,27 @@ int exchange_begin(apk_sim *s, bool async, int c2p, bool skip_local, bool thin) 
   const bool remote = !s->mesh.peers.empty();
   thin = thin && remote;
   s->xchg_thin = thin;
+  // (x1 strips that never pass through a copy kernel: the stage just run has stored them into the send buffers, and the
+  // stage that follows this exchange reads them from the receive buffers -- do_stage has checked that it will)
+  const bool nox1 = remote && s->x1_out_direct;
+  s->x1_out_direct = false;
+  s->xchg_x1_direct = nox1;
+  s->x1_in_recv = false;
   if (remote) {
     select_thin_messages(s, thin);
     s->remote_ghosts_thin = thin;  // (once this exchange is complete)
     if (thin) s->thin_exchanges += 1;
-    SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(thin ? PH_PACK_THIN : PH_PACK), s->stream));
+    if (nox1) s->x1_direct_exchanges += 1;
+    if (c2p == GHOST_PRIM_COPY) {
+      if (thin) return fail(s, APK_ERR_INVALID, "exchange_begin: a one-layer exchange carries the conserved state");
+      s->xchg_prim = s->pcur;
+      SIM_TRY(s, apk_copy_plan_run(s->ctx, s->pplans_of[s->pcur][nox1 ? PH_PACK_NOX1 : PH_PACK], s->stream));
+    } else {
+      if (nox1 && !thin) return fail(s, APK_ERR_INVALID, "exchange_begin: x1 strips of the conserved state are one layer deep");
+      SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(thin ? (nox1 ? PH_PACK_THIN_NOX1 : PH_PACK_THIN) : PH_PACK), s->stream));
+    }
+  } else if (c2p == GHOST_PRIM_COPY) {
+    s->xchg_prim = s->pcur;
   }
   if (skip_local) {
     // direct neighbour addressing: the stages read their same-rank neighbours' interiors
@@ -423,7 +451,11 @@ int exchange_end(apk_sim *s, int c2p) {
       return fail(s, APK_ERR_DEVICE, std::string("halo exchange (end) failed ") + apk_sim_comm_error(s));
     s->exchange_pending = false;
   }
-  if (!s->mesh.peers.empty()) SIM_TRY(s, run_ghost_plan(s, buf, s->xchg_thin ? PH_UNPACK_THIN : PH_UNPACK, c2p));
+  if (!s->mesh.peers.empty()) {
+    const bool nox1 = s->xchg_x1_direct;
+    SIM_TRY(s, run_ghost_plan(s, buf, s->xchg_thin ? (nox1 ? PH_UNPACK_THIN_NOX1 : PH_UNPACK_THIN) : (nox1 ? PH_UNPACK_NOX1 : PH_UNPACK), c2p));
+    s->x1_in_recv = nox1;
+  }
   for (int ph = PH_BC1; ph <= PH_BC3; ++ph) SIM_TRY(s, run_ghost_plan(s, buf, ph, c2p));
   return APK_OK;
 }
@@ -594,6 +626,45 @@ bool thin_exchange_cycle(const apk_sim *s) {
   return true;
 }
 
+// May the x1 strips of this cycle's two exchanges bypass the pack / unpack kernels (apk_stage_args.x1_halo)?  The VL2
+// cycle of a uniform periodic 3-D mesh with remote neighbours in its leanest form: the predictor reads the conserved
+// state (prim_free_cycle) one layer deep (thin_exchange_cycle) and sends primitives (GHOST_PRIM_COPY), the corrector reads
+// those and sends one layer of the conserved state; both in stage forms that follow the table.  APK_X1_DIRECT=0: off (A/B).
+bool x1_direct_cycle(const apk_sim *s) {
+  static const int mode = std::getenv("APK_X1_DIRECT") ? std::atoi(std::getenv("APK_X1_DIRECT")) : 1;
+  const HydroPackage &pkg = s->pkg;
+  if (!mode || !s->x1_on || !s->d_x1_tab[0] || s->nstages != 2 || s->mesh.mb[0] < 2 * s->mesh.ng) return false;
+  if (!thin_exchange_cycle(s) || !prim_free_cycle(s) || !direct_neighbors(s) || !ghost_c2p_fusable(s)) return false;
+  const int ded = (pkg.fluid == APK_FLUID_GLMMHD) ? 1 : 0;
+  return apk_stage_x1_halo(s->mu0(), &pkg.flux_first_stage, &pkg.eos, 2, ded) == 1 &&
+         apk_stage_x1_halo(s->mu0(), &pkg.flux_other_stage, &pkg.eos, 2, ded) == 1;
+}
+
+// the per-block segment tables of apk_stage_args.x1_halo (apk_sim::d_x1_tab), from Mesh::x1_send / x1_recv
+int build_x1_tables(apk_sim *s) {
+  const Mesh &m = s->mesh;
+  if (m.peers.empty() || m.ndim != 3) return APK_OK;
+  const size_t nlb = m.local_gids.size();
+  std::vector<apk_x1_halo_block> pred(nlb), corr(nlb);
+  for (size_t lb = 0; lb < nlb; ++lb)
+    for (int side = 0; side < 2; ++side) {
+      const X1Segment &sd = m.x1_send[lb][side], &rv = m.x1_recv[lb][side];
+      pred[lb].send[side] = sd.peer >= 0 ? s->send_buf[sd.peer] + sd.off : nullptr;
+      corr[lb].send[side] = sd.peer >= 0 ? s->send_buf[sd.peer] + sd.off_thin : nullptr;
+      pred[lb].recv[side] = rv.peer >= 0 ? s->recv_buf[rv.peer] + rv.off_thin : nullptr;
+      corr[lb].recv[side] = rv.peer >= 0 ? s->recv_buf[rv.peer] + rv.off : nullptr;
+    }
+  const char *tags[2] = {"x1_halo_predictor", "x1_halo_corrector"};
+  const std::vector<apk_x1_halo_block> *tabs[2] = {&pred, &corr};
+  for (int q = 0; q < 2; ++q) {
+    double *p = nullptr;
+    SIM_TRY(s, dev_alloc(s, tags[q], sizeof(apk_x1_halo_block) * nlb, &p));
+    s->d_x1_tab[q] = p;
+    SIM_HIP(s, hipMemcpy(p, tabs[q]->data(), sizeof(apk_x1_halo_block) * nlb, hipMemcpyHostToDevice));
+  }
+  return APK_OK;
+}
+
 int materialize_prim(apk_sim *s) {
   if (!s->prim_stale) return APK_OK;
   s->prim_stale = false;
@@ -611,6 +682,7 @@ int materialize_remote_ghosts(apk_sim *s) {
   const int mode = (!s->prim_stale && ghost_c2p_fusable(s)) ? GHOST_C2P : GHOST_COPY;
   select_thin_messages(s, false);
   s->xchg_thin = s->remote_ghosts_thin = false;
+  s->xchg_x1_direct = s->x1_in_recv = s->x1_out_direct = false;
   SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(PH_PACK), s->stream));
   if (s->comm.exchange(s->comm.user) != 0) return fail(s, APK_ERR_DEVICE, "halo exchange failed");
   SIM_TRY(s, run_ghost_plan(s, s->cur, PH_UNPACK, mode));
@@ -672,6 +744,12 @@ int build_windows(apk_sim *s) {
   for (auto &t : k3) t.assign(8 * (size_t)nlb, 0);
   for (auto &t : dc) t.assign(8 * (size_t)nlb, 0);
   std::vector<unsigned> late(nlb, 0u);
+  // (two-kernel stage: when no block has BOTH its x3 faces late -- the 2 x 2 x 2 brick: every block is a corner -- the
+  // low and the high slabs are one table, one launch with twice the waves: a slab launch of half the blocks fills half
+  // the GPU for the length of a whole march prologue)
+  bool k3_one_slab = true;
+  for (int lb = 0; lb < nlb; ++lb)
+    if (m.Active(2) && m.LateFace(lb, 2, -1) && m.LateFace(lb, 2, +1)) k3_one_slab = false;
   for (int lb = 0; lb < nlb; ++lb) {
     // "late" faces: ghost zones filled by messages of other ranks (physical boundaries are applied after them)
     int L[3][2];
@@ -686,8 +764,14 @@ int build_windows(apk_sim *s) {
     // two-kernel stage (3-D): its first kernel is the x3 sweep, which reads x3 ghost zones only --
     // every plane farther than nghost from a late x3 face, then the slabs next to those faces
     put(k3[0], lb, 0, m.ni, m.is, m.ie, m.js, m.je, m.ks + W * L[2][0], m.ke - W * L[2][1]);
-    put(k3[1], lb, 0, L[2][0] ? m.ni : 0, m.is, m.ie, m.js, m.je, m.ks, m.ks + W - 1);
-    put(k3[2], lb, 0, L[2][1] ? m.ni : 0, m.is, m.ie, m.js, m.je, m.ke - W + 1, m.ke);
+    if (k3_one_slab) {
+      const bool hi = L[2][1] != 0;
+      put(k3[1], lb, 0, (L[2][0] || L[2][1]) ? m.ni : 0, m.is, m.ie, m.js, m.je, hi ? m.ke - W + 1 : m.ks, hi ? m.ke : m.ks + W - 1);
+      put(k3[2], lb, 0, 0, m.is, m.ie, m.js, m.je, m.ke - W + 1, m.ke);
+    } else {
+      put(k3[1], lb, 0, L[2][0] ? m.ni : 0, m.is, m.ie, m.js, m.je, m.ks, m.ks + W - 1);
+      put(k3[2], lb, 0, L[2][1] ? m.ni : 0, m.is, m.ie, m.js, m.je, m.ke - W + 1, m.ke);
+    }
     // single-kernel donor-cell stage (3-D): everything but the one-cell layers next to late
     // faces, then disjoint slabs: z (whole planes), y (rows of the remaining planes), x (columns)
     const int lo[3] = {S[0] + L[0][0], S[1] + L[1][0], S[2] + L[2][0]};
@@ -900,6 +984,8 @@ int do_stage(apk_sim *s, int stage) {
   if (s->prim_stale && !from_cons) SIM_TRY(s, sync_ghosts(s));
   // (ghost zones one layer deep: enough for the donor-cell predictor they were left for, and for nothing else)
   if (s->remote_ghosts_thin && !(stage == 1 && thin_exchange_cycle(s))) SIM_TRY(s, sync_ghosts(s));
+  // (... and their x1 strips still in the receive buffers: for a predictor that reads them there, x1_direct_cycle)
+  if (stage == 1 && (s->exchange_pending ? s->xchg_x1_direct : s->x1_in_recv) && !x1_direct_cycle(s)) SIM_TRY(s, sync_ghosts(s));
   if (stage == 1) {
     // "init u1" (hydro_driver.cpp:474-495) without the copy: the buffer holding u0 becomes the
     // register u1 and the stage writes the new u0 into the other buffer.  Valid because
@@ -986,8 +1072,11 @@ int do_stage(apk_sim *s, int stage) {
       bool all_periodic = true;
       for (int d = 0; d < 3; ++d)
         if (mm.Active(d) && (mm.bc_in[d] != BC_PERIODIC || mm.bc_out[d] != BC_PERIODIC)) all_periodic = false;
-      if (dead) a.cons_store = (direct && mm.peers.empty() && all_periodic) ? 2 : 1;
       // (physical boundary phases copy conserved values out of ghost zones filled before them: periodic boxes only)
+      // On a periodic box the exchange after this stage moves the stored primitives themselves (GHOST_PRIM_COPY below;
+      // floors / ceilings keep the unfused order copy, then ConsToPrim of the ghost zones, which reads the shell):
+      // then nothing reads any conserved value of this stage's result.
+      if (dead) a.cons_store = (all_periodic && ((direct && mm.peers.empty()) || ghost_c2p_fusable(s))) ? 2 : 1;
       ghost_cons_dead = a.cons_store != 0 && all_periodic;
     }
     if (s->exchange_pending && cfg.recon == APK_RC_DC && !(dc3 && swap_prim)) SIM_TRY(s, finish_pending(s));
@@ -999,6 +1088,24 @@ int do_stage(apk_sim *s, int stage) {
       // (round 3 split it: measured slower).
       if (s->exchange_pending && dc3 && swap_prim) SIM_TRY(s, finish_pending(s));
     }
+    // x1 strips straight into / from the exchange buffers (x1_direct_cycle): the predictor sends its primitives nghost
+    // deep and reads the one-layer conserved strips the corrector of the cycle before sent; the corrector the other way
+    // round.  The receive side only when the exchange this stage follows left the strips in the buffers.
+    apk_x1_halo x1h{};
+    if (x1_direct_cycle(s)) {
+      const bool predictor = stage == 1 && dc3 && swap_prim && ghost_cons_dead && a.cons_store == 2;
+      const bool corrector = stage == s->nstages && stage > 1 && two_kernel && no_prim;
+      if (predictor || corrector) {
+        const bool from_buffers = s->exchange_pending ? s->xchg_x1_direct : s->x1_in_recv;
+        x1h.blocks = static_cast<const apk_x1_halo_block *>(s->d_x1_tab[predictor ? 0 : 1]);
+        x1h.recv_depth = from_buffers ? (predictor ? kThinDepth : s->mesh.ng) : 0;
+        x1h.send_depth = predictor ? s->mesh.ng : kThinDepth;
+        x1h.send_field = predictor ? 1 : 0;
+        a.x1_halo = &x1h;
+      }
+    }
+    if (s->x1_in_recv && !(a.x1_halo && x1h.recv_depth > 0))
+      return fail(s, APK_ERR_INVALID, "do_stage: x1 ghost columns were left in the receive buffers for a stage that does not read them there");
     if (s->exchange_pending) {
       // The previous stage's halo messages are still in flight.  Ghost zones filled by same-rank
       // copies are ready: convert them, run whatever does not touch a late face (the x1 sweep of
@@ -1039,6 +1146,8 @@ int do_stage(apk_sim *s, int stage) {
     }
     SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
     s->stage_dt_pending = a.estimate_dt != 0;
+    s->x1_in_recv = false;                                // (read; the exchange below starts afresh)
+    s->x1_out_direct = a.x1_halo && x1h.send_depth > 0;  // (consumed by exchange_begin)
     // (a stage that stored primitives -- the predictor's half-step ones -- makes the current buffer valid again; one that
     // stored none leaves them stale: the stages of a prim-free RK cycle, and its last stage under the turbulence driver,
     // whose kick then estimates the time step without storing them either)
@@ -1162,7 +1271,7 @@ int do_stage(apk_sim *s, int stage) {
   const bool ghost_prims = !s->prim_stale;
   const int c2p_in_copy = !(fused_fill && ghost_c2p_fusable(s) && ghost_prims)
                               ? GHOST_COPY
-                              : (ghost_cons_dead ? GHOST_PRIM_ONLY : GHOST_C2P);
+                              : (ghost_cons_dead ? GHOST_PRIM_COPY : GHOST_C2P);
   if (fused_fill && can_overlap_next(s, stage < s->nstages ? stage + 1 : 1)) {
     // post the messages and leave them in flight: the next stage (of this or of the next cycle)
     // completes the exchange
@@ -1360,6 +1469,7 @@ int apk_sim_create(const char *deck, const char *const *overrides, int noverride
   // then removed the copies altogether.)
   if (s->mesh.rehearse && (rc = comm_loopback_attach(s)) != APK_OK) return bail(rc);
   if (!s->mesh.peers.empty() && (rc = build_windows(s)) != APK_OK) return bail(rc);
+  if ((rc = build_x1_tables(s)) != APK_OK) return bail(rc);
   if (s->mesh.ndim == 3 && (rc = build_face_table(s)) != APK_OK) return bail(rc);
   if (s->fmft && (rc = turbulence_device_setup(s)) != APK_OK) return bail(rc);
   return APK_OK;
@@ -1372,6 +1482,9 @@ void apk_sim_destroy(apk_sim *s) {
     (void)hipDeviceSynchronize();
     rccl_transport_destroy(s->rccl);
     s->rccl = nullptr;
+    for (auto &pp : s->pplans_of)
+      for (auto &pl : pp)
+        if (pl) apk_copy_plan_destroy(pl);
     for (auto &pp : s->plans_of)
       for (auto &p : pp) apk_copy_plan_destroy(p);
     for (int p = 0; p < 3; ++p)
@@ -1395,6 +1508,7 @@ void apk_sim_destroy(apk_sim *s) {
     for (auto &t : s->k3win) dev_free(s, reinterpret_cast<double *>(t.d));
     dev_free(s, reinterpret_cast<double *>(s->d_late_regions));
     dev_free(s, reinterpret_cast<double *>(s->d_face_nbr));
+    for (auto &t : s->d_x1_tab) dev_free(s, static_cast<double *>(t));
     dev_free(s, s->d_acc);
     dev_free(s, s->d_phases);
     dev_free(s, s->d_cons2[0]);
@@ -1447,6 +1561,12 @@ int apk_sim_set_thin_exchange(apk_sim *s, int on) {
   return APK_OK;
 }
 long long apk_sim_thin_exchanges(const apk_sim *s) { return s ? s->thin_exchanges : 0; }
+int apk_sim_set_x1_direct(apk_sim *s, int on) {
+  if (!s) return APK_ERR_INVALID;
+  s->x1_on = on != 0;
+  return APK_OK;
+}
+long long apk_sim_x1_direct_exchanges(const apk_sim *s) { return s ? s->x1_direct_exchanges : 0; }
 int apk_sim_prim_is_stale(const apk_sim *s) { return (s && s->prim_stale) ? 1 : 0; }
 long long apk_sim_turb_dt_kicks(const apk_sim *s) { return s ? s->turb_dt_kicks : 0; }
 int apk_sim_set_amr_full_exchange(apk_sim *s, int on) {

@@ -130,6 +130,11 @@ struct apk_sim {
   apk_pack *mu0_of[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}},
            *mu1_of[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   apk_copy_plan *plans_of[3][apk::PH_COUNT] = {};
+  // the same plans over the two primitive buffers: exchanges that carry PRIMITIVES (GHOST_PRIM_COPY: VL2's half-step
+  // state, whose conserved values nobody reads) -- the messages then hold what the face table shows a same-rank reader,
+  // the neighbour's stored primitives, and neither side converts anything
+  apk_copy_plan *pplans_of[2][apk::PH_COUNT] = {};
+  int xchg_prim = 0;  // the primitive buffer such an exchange packs from and fills
   // refined meshes: the boundary-plane fluxes of a fused stage's flux correction run beside the stage kernels
   // (amr_flux_planes_ahead)
   void *side_stream = nullptr, *ev_fork = nullptr, *ev_join = nullptr;
@@ -160,6 +165,19 @@ struct apk_sim {
   // to date one layer deep only -- sync_ghosts completes them (a collective, like the one of refined meshes).
   bool thin_on = true, thin_msgs = false, xchg_thin = false, remote_ghosts_thin = false;
   long long thin_exchanges = 0;
+  // x1 strips without pack / unpack kernels (apk_stage_args.x1_halo; x1_direct_cycle): the finishing kernels of a VL2
+  // cycle store their x1 boundary columns straight into the send buffers (the predictor: primitives, nghost deep, into
+  // the full messages; the corrector: the conserved state, one layer, into the one-layer messages) and read their x1
+  // ghost columns straight from the receive buffers.  d_x1_tab[0]: the predictor's table (receive: one-layer segments,
+  // send: full ones), [1]: the corrector's (receive: full, send: one-layer).
+  //   x1_out_direct   the stage just run has stored its x1 strips: the exchange posted next packs without them
+  //   xchg_x1_direct  the exchange begun last leaves the x1 ghost columns in the receive buffers (unpacks without them)
+  //   x1_in_recv      ... and has completed: the next stage reads them there.  Always together with a one-layer exchange
+  //                   (remote_ghosts_thin: whoever else reads ghost zones repeats the exchange in full) or inside a cycle.
+  bool x1_on = true;  // apk_sim_set_x1_direct / APK_X1_DIRECT=0 (A/B)
+  void *d_x1_tab[2] = {nullptr, nullptr};
+  bool x1_out_direct = false, xchg_x1_direct = false, x1_in_recv = false;
+  long long x1_direct_exchanges = 0;
   long long turb_dt_kicks = 0;  // kicks that estimated the time step without storing primitives (apk_turb_apply_dt)
   int pending_c2p = 0;  // the exchange in flight converts ghost zones as it fills them (GHOST_C2P / GHOST_PRIM_ONLY)
   int pending_cons = 0;  // cons buffer whose ghost zones the exchange in flight fills (roles may swap meanwhile)

@@ -53,8 +53,8 @@ int build_packs(apk_sim *s);
 int ensure_spare_prim(apk_sim *s);
 int ensure_flux_arrays(apk_sim *s);
 bool stage_can_fuse(const apk_sim *s);
-double *region_base(apk_sim *s, int parity, int kind, int block);
 int build_copy_plans(apk_sim *s);
+int build_prim_plans(apk_sim *s);
 void set_global_dt(apk_sim *s, double dt_est);
 struct DtEstimate {  // what one rank measured: see estimate_timestep_read / _commit
   double dt_hyp_local = kHuge;
@@ -66,10 +66,13 @@ int estimate_timestep(apk_sim *s, double *dt_out);  // read + commit
 bool ghost_c2p_fusable(const apk_sim *s);
 // how a ghost-zone fill treats the primitives: not at all / ConsToPrim of every cell it fills / that, without storing the
 // conserved values (ghost zones of a state whose conserved values nothing reads: VL2's half step)
-enum { GHOST_COPY = 0, GHOST_C2P = 1, GHOST_PRIM_ONLY = 2 };
+// GHOST_PRIM_COPY: the exchange moves the stored primitives themselves (plans over the primitive buffers)
+enum { GHOST_COPY = 0, GHOST_C2P = 1, GHOST_PRIM_ONLY = 2, GHOST_PRIM_COPY = 3 };
 int run_ghost_plan(apk_sim *s, int buf, int phase, int c2p, apk_stream_t stream = nullptr);
 int exchange_begin(apk_sim *s, bool async, int c2p, bool skip_local = false, bool thin = false);
 bool thin_exchange_cycle(const apk_sim *s);
+bool x1_direct_cycle(const apk_sim *s);
+int build_x1_tables(apk_sim *s);
 bool rk_prim_free_cycle(const apk_sim *s);
 int materialize_remote_ghosts(apk_sim *s);
 int exchange_end(apk_sim *s, int c2p);

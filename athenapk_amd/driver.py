@@ -416,6 +416,13 @@ class Simulation(_FmftHost, _MeshView):
 
     def set_thin_exchange(self, on):
         self._check(self.lib.apk_sim_set_thin_exchange(self.h, int(on)))
+
+    def x1_direct_exchanges(self):
+        """exchanges so far whose x1 strips bypassed the pack / unpack kernels (apk_sim_set_x1_direct)"""
+        return self.lib.apk_sim_x1_direct_exchanges(self.h)
+
+    def set_x1_direct(self, on):
+        self._check(self.lib.apk_sim_set_x1_direct(self.h, int(on)))
         return self
 
     def set_direct_neighbors(self, on):

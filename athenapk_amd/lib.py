@@ -58,7 +58,15 @@ class StageArgs(C.Structure):
                 ("glmmhd_alpha", C.c_double), ("mindx", C.c_double), ("fill_derived", C.c_int),
                 ("estimate_dt", C.c_int), ("phase", C.c_int), ("window", C.c_void_p),
                 ("window_rl", C.c_int), ("window_rows", C.c_int), ("trial", C.c_int), ("count_unphysical", C.c_int), ("cons_out_delta", C.c_int64),
-                ("face_neighbor", C.c_void_p), ("cons_store", C.c_int), ("prim_from_cons", C.c_int)]
+                ("face_neighbor", C.c_void_p), ("cons_store", C.c_int), ("prim_from_cons", C.c_int), ("x1_halo", C.c_void_p)]
+
+
+class X1HaloBlock(C.Structure):
+    _fields_ = [("recv", C.c_void_p * 2), ("send", C.c_void_p * 2)]
+
+
+class X1Halo(C.Structure):
+    _fields_ = [("blocks", C.c_void_p), ("recv_depth", C.c_int), ("send_depth", C.c_int), ("send_field", C.c_int)]
 
 
 class FmftBlock(C.Structure):
@@ -198,6 +206,7 @@ def _signatures():
         "apk_trial_flags": (i, [vp, i, vp]),
         "apk_stage_split_axis": (i, [vp, vp, i]),
         "apk_stage_single_march": (i, [vp, vp]),
+        "apk_stage_x1_halo": (i, [vp, vp, E, i, i]),
         "apk_stage_unphysical_read": (i, [vp, C.POINTER(C.c_longlong), vp]),
         "apk_copy_plan_create": (i, [vp, C.POINTER(CopyRegion), i, pp]),
         "apk_copy_plan_destroy": (None, [vp]),
@@ -227,6 +236,8 @@ def _signatures():
         "apk_sim_skipped_local_exchanges": (ll, [vp]),
         "apk_sim_set_thin_exchange": (i, [vp, i]),
         "apk_sim_thin_exchanges": (ll, [vp]),
+        "apk_sim_set_x1_direct": (i, [vp, i]),
+        "apk_sim_x1_direct_exchanges": (ll, [vp]),
         "apk_sim_set_direct_neighbors": (C.c_int, [vp, C.c_int]),
         "apk_sim_set_amr_full_exchange": (C.c_int, [vp, C.c_int]),
         "apk_sim_set_prim_free": (C.c_int, [vp, C.c_int]),
@@ -323,12 +334,18 @@ def load(strict=False):
         # (APK_LIB_PATH: a profiling variant, possibly built from an older commit for a same-box comparison -- entry
         # points it lacks are left unbound; the product library must export every declared symbol)
         variant = bool(os.environ.get("APK_LIB_PATH")) and not strict
+        skipped = []
         for name, (res, args) in _signatures().items():
             if variant and not hasattr(lib, name):
+                skipped.append(name)
                 continue
             fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if skipped:  # (said aloud: a call through an unbound entry point would go out with default int argtypes)
+            import warnings
+            warnings.warn("APK_LIB_PATH=%s lacks %d declared entry point(s), left unbound: %s"
+                          % (path, len(skipped), ", ".join(skipped)))
         _LIBS[key] = lib
     return _LIBS[key]
 

@@ -156,6 +156,31 @@ int apk_dedner_source(apk_ctx *ctx, const apk_pack *md, int extended, double alp
  * Divergence -> DednerSource (hydro_driver.cpp:510-544) without materialising the flux
  * arrays in HBM.  Not usable when first-order flux correction or AMR flux correction needs
  * the face fluxes.  u1 may alias u0 only if gam1 == 0. */
+/* x1 strips of a halo exchange that pass through no pack / unpack kernel (apk_stage_args.x1_halo).  The reference
+ * fills every ghost zone through boundary buffers (hydro_driver.cpp:506-569 SendBoundBufs / ReceiveBoundBufs / SetBounds);
+ * a row of an x1 strip is nghost doubles -- 24 of every 128-byte line a copy kernel fetches from, or writes into, a block.
+ * Here the stage kernels go to the buffers themselves:
+ *   recv[side]  the buffer segment holding the ghost columns behind the block's lower (0) / upper (1) x1 face: the stage
+ *               reads those columns from there instead of the block's ghost zone.  NULL: the ghost zone (or the block
+ *               face_neighbor names).
+ *   send[side]  the buffer segment the stage ALSO stores the interior columns next to that face into, as it retires
+ *               them.  NULL: nothing.
+ * A segment is [nvar][nx3][nx2][depth] doubles, `depth` columns in x1 order over the interior extent in x2 and x3 (the
+ * ghost columns is-depth..is-1 / ie+1..ie+depth, the interior columns is..is+depth-1 / ie-depth+1..ie): the layout of an
+ * x1-face segment of the standalone driver's messages.  recv_depth < nghost: the deeper ghost columns are read from the
+ * block as usual.  Needs nx1 >= 2 send_depth.  send_field: 0 = the updated conserved state, 1 = the new primitives
+ * (needs fill_derived = 1 or 2).  Honoured by the stage forms apk_stage_x1_halo() reports; others refuse
+ * (APK_ERR_UNSUPPORTED). */
+typedef struct apk_x1_halo_block {
+  const double *recv[2];
+  double *send[2];
+} apk_x1_halo_block;
+typedef struct apk_x1_halo {
+  const apk_x1_halo_block *blocks; /* DEVICE array, one entry per block of the pack */
+  int recv_depth, send_depth;      /* columns per segment row (0: no segment of that kind is used) */
+  int send_field;
+} apk_x1_halo;
+
 typedef struct apk_stage_args {
   apk_flux_cfg cfg;
   apk_eos eos;
@@ -255,6 +280,8 @@ typedef struct apk_stage_args {
    * fill_derived = 3 (listed here, with estimate_dt = 1): ConsToPrim of the updated cells for the time-step estimate
    * only; neither u0.prim nor u1.prim is written.  Two-kernel 3-D stage in its lean form only. */
   int prim_from_cons;
+  /* x1 strips straight from / into exchange buffers (see apk_x1_halo above), or NULL.  Whole stages only (phase 0 or 2). */
+  const apk_x1_halo *x1_halo;
 } apk_stage_args;
 int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
                     const apk_stage_args *args, apk_stream_t stream);
@@ -270,6 +297,10 @@ int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
  * synchronises the stream */
 int apk_stage_unphysical_read(apk_ctx *ctx, long long *count, apk_stream_t stream);
 int apk_stage_split_axis(const apk_pack *u0, const apk_flux_cfg *cfg, int fill_derived);
+/* 1 if a whole-block stage of this scheme with these options follows apk_stage_args.x1_halo: the lean two-row donor-cell
+ * march (3-D, fill_derived 0 / 2, nx2 even) and the lean two-kernel stage's finishing march, without passive scalars.  A
+ * caller checks BEFORE it leaves x1 strips out of its pack / unpack plans. */
+int apk_stage_x1_halo(const apk_pack *u0, const apk_flux_cfg *cfg, const apk_eos *eos, int fill_derived, int dedner);
 /* 1 if a whole-block stage of this scheme in its lean form with prim_from_cons != 0 runs as ONE march (hydro with PLM:
  * x1 by wave shifts, two x2 rows per lane, x3 carried along the march -- no flux-difference array; the three tasks
  * hydro.cpp:1025-1208 + hydro_driver.cpp:534-544 in a single pass over the conserved state), 0 if it takes the two-kernel
