@@ -198,7 +198,7 @@ def DednerSource(md, extended, alpha, c_h, mindx, beta_dt):
 
 def StageFused(u0, u1, fluid, recon, riemann, eos, c_h, gam0, gam1, beta_dt, dedner=0,
                glmmhd_alpha=0.1, mindx=1.0, fill_derived=False, estimate_dt=False, phase=0, window=None,
-               face_neighbor=None, cons_store=0, prim_from_cons=False, cons_out=None):
+               face_neighbor=None, cons_store=0, prim_from_cons=False, cons_out=None, x1_halo=None):
     """Fused CalculateFluxes -> UpdateWithFluxDivergence -> DednerSource for one RK stage;
     optionally also FillDerived / the dt estimate on the updated cells.  phase / x1_window split
     the stage around a halo exchange (window: int32 CUDA tensor [nblocks][8] =
@@ -224,7 +224,36 @@ def StageFused(u0, u1, fluid, recon, riemann, eos, c_h, gam0, gam1, beta_dt, ded
         assert cons_out.cons.shape == u0.cons.shape
         a.cons_out_delta = (cons_out.cons.data_ptr() - u0.cons.data_ptr()) // 8
     a.cons_store = int(cons_store)  # 0 all cells, 1 the nghost-deep shell of every block, 2 none (apk_stage_args.cons_store)
+    keep = None
+    if x1_halo is not None:
+        # apk_stage_args.x1_halo: dict(recv=[per block (lo, hi) float64 CUDA tensors or None], send=[...], recv_depth=,
+        # send_depth=, send_field=0 cons / 1 prim) -- x1 strips read from / stored into exchange-buffer segments
+        # [nvar][nx3][nx2][depth]
+        nb = u0.nblocks
+        tab = (L.X1HaloBlock * nb)()
+        for b in range(nb):
+            for side in range(2):
+                r = x1_halo.get("recv", [(None, None)] * nb)[b][side]
+                w = x1_halo.get("send", [(None, None)] * nb)[b][side]
+                for t in (r, w):
+                    assert t is None or (t.dtype == torch.float64 and t.is_cuda and t.is_contiguous())
+                tab[b].recv[side] = r.data_ptr() if r is not None else None
+                tab[b].send[side] = w.data_ptr() if w is not None else None
+        dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).cuda()
+        h = L.X1Halo()
+        h.blocks = dev.data_ptr()
+        h.recv_depth, h.send_depth = int(x1_halo.get("recv_depth", 0)), int(x1_halo.get("send_depth", 0))
+        h.send_field = int(x1_halo.get("send_field", 0))
+        a.x1_halo = C.addressof(h)
+        keep = (tab, dev, h)
     _check(ctx.lib.apk_stage_fused(ctx.h, u0.h, u1.h, C.byref(a), _stream()), ctx.lib, ctx.h)
+    if keep is not None:
+        torch.cuda.current_stream().synchronize()  # (the table is a temporary of this call)
+
+
+def StageFollowsX1Halo(u0, fluid, recon, riemann, eos, fill_derived=2, dedner=0):
+    """apk_stage_x1_halo: does a whole-block stage of this scheme follow apk_stage_args.x1_halo?"""
+    return bool(u0.ctx.lib.apk_stage_x1_halo(u0.h, C.byref(_cfg(fluid, recon, riemann)), C.byref(eos), int(fill_derived), int(dedner)))
 
 
 def ConservedToPrimitive(md, fluid, eos):

@@ -104,6 +104,33 @@ def cpu_baseline(fluid, integrator, recon, riemann, target_s=10.0):
                       "serial_value: 1 thread on 64^3" % (cycles, n, mb, best_t, cands, cores, dt)}
 
 
+MIN_REGION_MS = 50.0  # every driver-visible rate: the median of three timed regions at least this long
+
+
+def timed_regions(step, sync, probe_cycles=4, regions=3, min_ms=MIN_REGION_MS, min_cycles=4):
+    """`regions` timed regions of the same number of cycles, each at least `min_ms` long (sized from a short probe);
+    returns (cycles per region, [seconds per region], index of the median region).  The reference's performance suite
+    reads the rate Parthenon prints over a whole run (tst/regression/test_suites/performance/performance.py:32-54);
+    a region of a few milliseconds cannot separate a 2 % change from the box."""
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(probe_cycles):
+        step()
+    sync()
+    per = (time.perf_counter() - t0) / probe_cycles
+    cycles = max(min_cycles, int(math.ceil(1.1 * min_ms * 1e-3 / per)))
+    out = []
+    for _ in range(regions):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(cycles):
+            step()
+        sync()
+        out.append(time.perf_counter() - t0)
+    med = sorted(range(len(out)), key=lambda q: out[q])[len(out) // 2]
+    return cycles, out, med
+
+
 def amr_blast_bench(cycles=40, variants=("hydro_plm_hlle_vl2", "mhd_ppm_hlld_vl2")):
     """BASELINE config 5's shape (inputs/blast_3d_amr.in with root 64^3 in 16^3 meshblocks, 4 levels,
     regridding every cycle) for the hydro deck as it is and for GLM-MHD PPM+HLLD on the deck's own blast
@@ -124,15 +151,29 @@ def amr_blast_bench(cycles=40, variants=("hydro_plm_hlle_vl2", "mhd_ppm_hlld_vl2
         s = driver.Simulation(decks.load("blast_3d_amr"), ov + extra).initialize()
         for _ in range(3):
             s.step()
-        torch.cuda.synchronize()
-        z0, t0 = s.amr_stats()[3], time.perf_counter()
-        for _ in range(cycles):
-            s.step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        # (the mesh grows with the blast: the regions are consecutive stretches of the same run, zone-cycles counted over
+        # the blocks that exist in each cycle; the median RATE is reported)
+        rates, times, per_cycle = [], [], []
+        ncyc = max(cycles, 4)
+        for _ in range(3):
+            torch.cuda.synchronize()
+            z0, t0 = s.amr_stats()[3], time.perf_counter()
+            n = 0
+            while n < ncyc or (time.perf_counter() - t0) * 1e3 < 0.6 * MIN_REGION_MS:
+                s.step()
+                n += 1
+                if n % 8 == 0:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            rates.append((s.amr_stats()[3] - z0) / dt)
+            times.append(dt * 1e3)
+            per_cycle.append(dt / n * 1e3)
+        med = sorted(range(3), key=lambda q: rates[q])[1]
         refined, merged, maxlev, z1 = s.amr_stats()
         i = s.refresh_info()
-        out[name] = {"zone_cycles_per_s": (z1 - z0) / dt, "ms_per_cycle": dt / cycles * 1e3,
+        out[name] = {"zone_cycles_per_s": rates[med], "ms_per_cycle": per_cycle[med], "timed_regions_ms": times,
+                     "zone_cycles_per_s_of_the_regions": rates,
                      "meshblocks": int(i.nblocks_total), "levels": maxlev + 1, "blocks_refined": refined,
                      "sibling_groups_merged": merged}
         s.close()
@@ -264,17 +305,13 @@ def other_workload(name, steps=4, warmup=2):
     try:
         for _ in range(warmup):
             sim.step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            sim.step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        steps, regions, med = timed_regions(sim.step, torch.cuda.synchronize, probe_cycles=max(2, steps // 2))
+        dt = regions[med]
         # per-kernel averages from a few more cycles with the in-library event timing on: two event records per launch
         # are 10 % of the sub-millisecond cycles of the small workloads (config 3), so they stay out of the timed loop
         sim.kernel_timing(True)
         sim.read_kernel_timing()
-        for _ in range(max(2, steps // 2)):
+        for _ in range(max(2, min(16, steps // 2))):
             sim.step()
         torch.cuda.synchronize()
         timing = sim.read_kernel_timing()
@@ -282,7 +319,9 @@ def other_workload(name, steps=4, warmup=2):
         info = sim.info
         per_kernel, stage_ms, b_stage, achieved, dominant = stage_figures(timing, fluid, integrator, int(info.zones_local), info.ndim)
         out = {"description": desc, "value": int(info.zones_total) * steps / dt, "unit": "cell-updates/s", "steps": steps,
-               "ms_per_step": dt / steps * 1e3, "high_order_stage_ms": stage_ms,
+               "ms_per_step": dt / steps * 1e3, "timed_regions_ms": [e * 1e3 for e in regions],
+               "timed_region_reported": "median of %d regions of %d cycles each" % (len(regions), steps),
+               "high_order_stage_ms": stage_ms,
                "dc_predictor_stage_ms": per_kernel["fused_dc_x1"] + per_kernel["fused_dc_x2"] + per_kernel["fused_dc_x3"],
                "algorithmic_bytes_per_cell_stage": b_stage, "stage_achieved_GBps": achieved, "stage_frac": achieved / HBM_PEAK_GBS,
                "dominant_timing_slot": dominant,
@@ -320,30 +359,42 @@ def rehearsal_8gpu_rank(workload, n1_ms, steps=10, warmup=2):
     ov += ["parthenon/time/integrator=%s" % integrator, "hydro/reconstruction=%s" % recon, "hydro/riemann=%s" % riemann,
            "apk_amd/rehearse_remote_faces=true"]
     out = {}
-    for label, overlap in (("overlapped", True), ("synchronous", False)):
-        sim = driver.Simulation(decks.load(deck), ov, strict=False)
+    # the three variants back to back in this function, each the median of three regions of >= 50 ms without event records:
+    # the plain N = 1 brick again (the reference the exposed time is counted from -- the headline's own regions ran
+    # minutes earlier, on other clocks), then the rehearsal with its exchanges overlapped and synchronous
+    for label, overlap, extra in (("n1", True, []), ("overlapped", True, ["apk_amd/rehearse_remote_faces=true"]),
+                                  ("synchronous", False, ["apk_amd/rehearse_remote_faces=true"])):
+        sim = driver.Simulation(decks.load(deck), ov + extra, strict=False)
         sim.set_overlap(overlap)
         sim.initialize()
         try:
             for _ in range(warmup):
                 sim.step()
-            torch.cuda.synchronize()
+            ov0, thin0, x10 = sim.overlapped_exchanges, sim.thin_exchanges(), sim.x1_direct_exchanges()
+            cyc, regions, med = timed_regions(sim.step, torch.cuda.synchronize, probe_cycles=3)
+            dt = regions[med]
+            done = 3 + 3 * cyc
+            out[label] = {"ms_per_step": dt / cyc * 1e3, "timed_regions_ms": [e * 1e3 for e in regions], "cycles_per_region": cyc,
+                          "value": int(sim.info.zones_total) * cyc / dt}
+            if label == "n1":
+                continue
+            # (the copy kernels' HIP-event durations from a few more cycles with the in-library timing on)
             sim.kernel_timing(True)
             sim.read_kernel_timing()
-            ov0, thin0, t0 = sim.overlapped_exchanges, sim.thin_exchanges(), time.perf_counter()
             for _ in range(steps):
                 sim.step()
             torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
             timing = sim.read_kernel_timing()
+            sim.kernel_timing(False)
             peers = sim.messages("uniform")
             thin_peers = sim.messages("uniform_thin")
-            thin_per_cycle = (sim.thin_exchanges() - thin0) / steps
-            out[label] = {"one_layer_exchanges_per_cycle": thin_per_cycle, "ms_per_step": dt / steps * 1e3, "value": int(sim.info.zones_total) * steps / dt,
-                          "overlapped_exchanges_per_cycle": (sim.overlapped_exchanges - ov0) / steps,
-                          "pack_unpack_copy_kernels_ms_per_cycle": timing["copy_regions"][0] / steps}
+            out[label].update({"one_layer_exchanges_per_cycle": (sim.thin_exchanges() - thin0) / (done + steps),
+                               "overlapped_exchanges_per_cycle": (sim.overlapped_exchanges - ov0) / (done + steps),
+                               "exchanges_with_x1_strips_in_the_buffers_per_cycle": (sim.x1_direct_exchanges() - x10) / (done + steps),
+                               "pack_unpack_copy_kernels_ms_per_cycle": timing["copy_regions"][0] / steps})
         finally:
             sim.close()
+    headline_ms, n1_ms = n1_ms, out["n1"]["ms_per_step"]
     nst = len(GAM0[integrator])
     msg = sorted((8.0 * sc for _, sc, _ in peers), reverse=True)
     msg_thin = sorted((8.0 * sc for _, sc, _ in thin_peers), reverse=True)
@@ -359,8 +410,10 @@ def rehearsal_8gpu_rank(workload, n1_ms, steps=10, warmup=2):
     wire_exposed = max(0.0, nst - n_thin - n_over) * wire_ms + n_thin * wire_thin_ms
     out.update({
         "what": "one rank of the 2 x 2 x 2 run rehearsed on one GPU: 7 peers (3 faces, 3 edges, 1 corner), messages delivered by "
-                "device copies on the halo stream (loopback) instead of xGMI; n1_ms_per_step is the plain N = 1 run of this line",
+                "ONE copy kernel on the halo stream (loopback) instead of xGMI; n1_ms_per_step is the plain N = 1 brick timed in the same "
+                "function right before (three regions of >= 50 ms each, median, like the two rehearsals)",
         "n1_ms_per_step": n1_ms,
+        "headline_ms_per_step": headline_ms,
         "exchanges_per_cycle": nst,
         "message_MB_per_peer": [m / 1e6 for m in msg],
         "one_layer_message_MB_per_peer": [m / 1e6 for m in msg_thin],
@@ -370,8 +423,11 @@ def rehearsal_8gpu_rank(workload, n1_ms, steps=10, warmup=2):
         "wire_ms_per_one_layer_exchange_modelled": wire_thin_ms,
         "wire_model": "largest message / %.0f GB/s (one xGMI link per face peer, the three face messages on three links at once; "
                       "edge and corner messages are 1 - 3 %% of a face's)" % XGMI_LINK_GBS,
+        # MODEL on a LOOPBACK rehearsal, not a measurement: N = 1 time / (rehearsed rank time + modelled exposed wire time)
         "predicted_weak_scaling_efficiency": n1_ms / (ms + wire_exposed),
         "predicted_weak_scaling_efficiency_if_no_wire_time_is_hidden": n1_ms / (ms + wire_all),
+        "predicted_weak_scaling_efficiency_is": "a model on a one-GPU loopback rehearsal (no xGMI link was used): N = 1 ms / (rehearsal ms + "
+                                                "modelled exposed wire ms); the measured curve is the driver's SCALE file",
     })
     return out
 
@@ -384,11 +440,11 @@ def other_workloads():
     for name in ("hydro_plm_hllc_rk2_256", "mhd_wenoz_hlld_rk3_256", "mhd_wenoz_hlld_rk3_256_forced",
                  "orszag_tang_512x512x4_vl2", "orszag_tang_512x512x4_vl2_fofc"):
         try:
-            out[name] = other_workload(name, steps=8 if name.startswith("orszag") else 4)
+            out[name] = other_workload(name)
         except Exception as e:  # supplementary figures; never lose the headline
             out[name] = {"error": repr(e)}
     try:
-        out["amr_blast_cfg5_mesh"] = amr_blast_bench(cycles=30, variants=("mhd_ppm_hlld_vl2",))
+        out["amr_blast_cfg5_mesh"] = amr_blast_bench(cycles=40, variants=("mhd_ppm_hlld_vl2",))
     except Exception as e:
         out["amr_blast_cfg5_mesh"] = {"error": repr(e)}
     return out
@@ -590,12 +646,12 @@ def main():
     if err is not None:
         raise err
     info = sim.info
-    sim.kernel_timing(True)
-    sim.read_kernel_timing()
     # THREE timed regions of exactly --steps cycles each, every one bracketed by barrier + synchronize and reduced with
-    # MAX over the ranks; `value` / `ms_per_step` are those of the MEDIAN region (a region of 20 cycles is 70 ms: too
-    # short to separate a 2 % kernel change from the box, round-4 review), all three are listed in `timed_regions_ms`.
-    regions, region_timing = [], []
+    # MAX over the ranks; `value` / `ms_per_step` are those of the MEDIAN region, all three are listed in
+    # `timed_regions_ms`.  No event records in these loops (round-5 review): the kernels' HIP-event durations behind
+    # `roofline` come from a FOURTH region of the same --steps cycles right after them, with the in-library timing on
+    # (two event records per launch on the stream the kernels run on).
+    regions = []
     comm_before = sim.comm_stats() if world > 1 else None
     for _ in range(max(1, args.regions)):
         barrier()
@@ -610,11 +666,21 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             e = float(t.item())
         regions.append(e)
-        region_timing.append(sim.read_kernel_timing())  # (read = reset: the slots of this region)
     med = sorted(range(len(regions)), key=lambda q: regions[q])[len(regions) // 2]
-    elapsed, timing = regions[med], region_timing[med]
+    elapsed = regions[med]
+    comm_after = sim.comm_stats() if world > 1 else None
+    sim.kernel_timing(True)
+    sim.read_kernel_timing()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.step()
+    torch.cuda.synchronize()
+    barrier()
+    event_region = time.perf_counter() - t0
+    timing = sim.read_kernel_timing()
     sim.kernel_timing(False)
-    comm_stats = sim.comm_stats() if world > 1 else None
+    comm_stats = comm_after
     skipped_per_cycle = sim.skipped_local_exchanges() / max(1, sim.ncycle)
     overlapped_per_cycle = sim.overlapped_exchanges / max(1, sim.ncycle)
     # 500 cycles back to back (N = 1): does the rate hold once the clocks have settled under the power cap?
@@ -694,7 +760,8 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "timed_regions_ms": [e * 1e3 for e in regions],
-            "timed_region_reported": "median of %d regions of %d cycles each (barrier + synchronize around each, max over ranks)" % (len(regions), args.steps),
+            "timed_region_reported": "median of %d regions of %d cycles each (barrier + synchronize around each, max over ranks; no event records inside)" % (len(regions), args.steps),
+            "kernel_event_region_ms": event_region * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -717,7 +784,10 @@ def main():
                        "same_rank_ghost_copies_skipped_per_cycle": skipped_per_cycle},
             "cell_stage_updates_per_s": value * nstages,
             "roofline": {
-                "bound": "hbm",
+                # what binds the stage kernels (SQ counters); `achieved` / `peak` / `frac` are priced against HBM bandwidth,
+                # as north_star asks -- `priced_against` -- and against the fp64 vector roof in `valu`
+                "bound": "fp64_valu_issue" if (fluid == "glmmhd" and not args.unfused) else "hbm",
+                "priced_against": "hbm",
                 "kernel": stage_name,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -731,8 +801,6 @@ def main():
                 "stage_ms": stage_ms,
                 "dc_predictor_stage_ms": per_kernel["fused_dc_x1"] + per_kernel["fused_dc_x2"] + per_kernel["fused_dc_x3"],
                 "frac_of_measured_copy_bandwidth": achieved / HBM_COPY_GBS,
-                # `bound` names the roof `achieved` / `peak` / `frac` are priced against (HBM, as north_star asks); what
-                # the counters say actually binds the stage kernels is in `binding_limit` and priced in `valu`
                 "binding_limit": "fp64 vector-ALU issue (SQ counters: profiles/r05_pmc_sq.json, r05_pmc_instruction_mix.json) "
                                  "under the 1400 W power cap (effective clock profiles/r05_clock.json), next to the access pattern of "
                                  "the march (profiles/r04_ubench_march_traffic.jsonl); see roofline.valu for the compute roof",

@@ -383,24 +383,28 @@ def test_synthetic_mhd_256_cubed_conserves_and_matches_flux_array_path():
 @pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
 @pytest.mark.parametrize("scheme", [("vl2", "ppm", 3), ("rk3", "wenoz", 3)], ids=["vl2_ppm", "rk3_wenoz"])
 @pytest.mark.parametrize("overlap", [True, False], ids=["overlapped", "synchronous"])
-def test_rehearsed_remote_faces_give_the_periodic_box(strict, scheme, overlap):
+@pytest.mark.parametrize("x1_direct", [True, False], ids=["x1_strips_in_buffers", "x1_strips_packed"])
+def test_rehearsed_remote_faces_give_the_periodic_box(strict, scheme, overlap, x1_direct):
     """apk_amd/rehearse_remote_faces: the three outer faces of every block of a 2 x 2 x 2 brick (and its edges and corner)
     go through pack -> message on the halo stream -> unpack + ghost ConsToPrim, overlapped with the next stage's x3
     sweep windows, exactly as between the bricks of the 8-GPU run; the loopback transport delivers the rank's own
     messages, which for a periodic box ARE the neighbours' -- so the run must reproduce the plain one-rank run, which
-    reads every neighbour directly and copies nothing: bit for bit in the parity build."""
+    reads every neighbour directly and copies nothing: bit for bit in the parity build.  x1_direct (the default where it
+    applies -- the VL2 cycle): the x1 strips of both exchanges bypass the pack / unpack kernels (apk_sim_set_x1_direct)."""
     integ, recon, ng = scheme
     ov = ["parthenon/mesh/nx%d=64" % d for d in (1, 2, 3)] + ["parthenon/meshblock/nx%d=32" % d for d in (1, 2, 3)] + [
         "parthenon/time/integrator=%s" % integ, "hydro/reconstruction=%s" % recon, "parthenon/mesh/nghost=%d" % ng]
     a = _sim("synthetic_mhd", ov, strict=strict).initialize()
     b = _sim("synthetic_mhd", ov + ["apk_amd/rehearse_remote_faces=true"], strict=strict)
     b.set_overlap(overlap)
+    b.set_x1_direct(x1_direct)
     b.initialize()
     assert a.info.npeers == 0 and b.info.npeers == 7
     for _ in range(4):
         a.step()
         b.step()
     nstages = {"vl2": 2, "rk3": 3}[integ]
+    assert b.x1_direct_exchanges() == (8 if (integ == "vl2" and x1_direct) else 0)
     assert a.skipped_local_exchanges() == 4 * nstages and b.skipped_local_exchanges() == 4 * nstages  # (same-rank faces still direct)
     assert (b.overlapped_exchanges > 0) == overlap
     assert b.thin_exchanges() == (4 if integ == "vl2" else 0)

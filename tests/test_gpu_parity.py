@@ -1191,6 +1191,102 @@ def test_direct_neighbor_addressing_equals_filled_ghost_zones(request, fluid, re
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("fluid,recon,riemann,from_cons", [("glmmhd", "ppm", "hlld", False), ("glmmhd", "dc", "hlld", True),
+                                                           ("glmmhd", "dc", "hlld", False), ("euler", "plm", "hllc", False),
+                                                           ("euler", "dc", "hlle", True), ("glmmhd", "wenoz", "hlld", False)])
+def test_x1_strips_in_exchange_buffers_equal_filled_ghost_zones(request, fluid, recon, riemann, from_cons, strict):
+    """apk_stage_args.x1_halo: a stage whose x1 ghost columns live in receive-buffer segments ([nvar][nx3][nx2][depth];
+    the ghost zones behind those faces poisoned) equals the stage on filled ghost zones bit for bit -- updated state,
+    out-of-place primitives, time step -- and the send segments hold the x1 boundary columns of what it stored: the
+    conserved state one layer deep (the corrector's place in a VL2 cycle) or the new primitives nghost deep (the
+    predictor's).  A face without a segment is read from the block as before."""
+    import torch
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    nx = (36, 8, 10)
+    ng, prim, g = _case(fluid, recon, nx, kind="smooth", seed=71, nblocks=2)
+    table = [[1, 1, -1, -1, -1, -1], [0, -1, -1, -1, -1, -1]]  # x1 faces only; block 1's upper face keeps its ghost zone
+    prim_ref = _fill_faces_from_neighbors(prim, table, nx, ng)
+    cons_ref = H.prim_to_cons(fluid, prim_ref, GAMMA)
+    ded = 1 if fluid == "glmmhd" else 0
+    eos = hydro.L.make_eos(GAMMA)
+    dc = recon == "dc"
+    nv = NHYDRO[fluid]
+    rdepth, sdepth, sfield = (1, ng, 1) if dc else (ng, 1, 0)
+    kw = dict(dedner=ded, glmmhd_alpha=0.1, mindx=0.07, fill_derived=2, estimate_dt=not dc, prim_from_cons=from_cons)
+    assert hydro.StageFollowsX1Halo(hydro.MeshData(ctx, nx, ng, nv, dx=tuple(g.dx), nblocks=2, cons=cons_ref, prim=prim_ref, with_flux=False),
+                                    fluid, recon, riemann, eos, 2, ded)
+    src = cons_ref if from_cons else prim_ref  # the array the stage takes its input from
+    ks, js = slice(ng, ng + nx[2]), slice(ng, ng + nx[1])
+
+    def ghost_cols(b, side, depth):  # the segment of block b's lower / upper x1 ghost strip: the `depth` columns next to the face
+        i0 = ng + nx[0] if side else ng - depth
+        return np.ascontiguousarray(src[b][:, ks, js, i0:i0 + depth])
+
+    def run(halo):
+        w, u = prim_ref, cons_ref
+        if halo:
+            w, u = _poison_faces(prim_ref, table, nx, ng), (_poison_faces(cons_ref, table, nx, ng) if from_cons else cons_ref)
+        a = hydro.MeshData(ctx, nx, ng, nv, dx=tuple(g.dx), nblocks=2, cons=cons_ref * 0.99, prim=w, with_flux=False)
+        b = hydro.MeshData(ctx, nx, ng, nv, dx=tuple(g.dx), nblocks=2, cons=u, prim=np.full_like(w, -7.0), with_flux=False)
+        xh, send = None, None
+        if halo:
+            recv = [tuple(torch.tensor(ghost_cols(blk, side, rdepth), device="cuda") if table[blk][side] >= 0 else None for side in range(2))
+                    for blk in range(2)]
+            send = [tuple(torch.full((nv, nx[2], nx[1], sdepth), -3.0, dtype=torch.float64, device="cuda") if (blk, side) != (1, 0) else None
+                          for side in range(2)) for blk in range(2)]
+            xh = dict(recv=recv, send=send, recv_depth=rdepth, send_depth=sdepth, send_field=sfield)
+        hydro.StageFused(a, b, fluid, recon, riemann, eos, C_H, 0.0, 1.0, 0.004, x1_halo=xh, **kw)
+        dt = hydro.StageDt(ctx, 0.3) if not dc else 0.0
+        return a.cons_host(), b.prim_host(), dt, send
+    want = run(False)
+    got = run(True)
+    I = lambda x: H.interior(x, nx, ng)
+    assert np.all(np.isfinite(I(got[0]))) and np.all(np.isfinite(I(got[1])))
+    assert np.array_equal(I(got[0]), I(want[0])) and np.array_equal(I(got[1]), I(want[1])) and got[2] == want[2]
+    stored = got[1] if sfield else got[0]
+    for blk in range(2):
+        for side in range(2):
+            seg = got[3][blk][side]
+            if seg is None:
+                continue
+            i0 = ng + nx[0] - sdepth if side else ng
+            assert np.array_equal(seg.cpu().numpy(), stored[blk][:, ks, js, i0:i0 + sdepth]), (blk, side)
+    # (and what it is compared with is the oracle's stage -- on the primitives the oracle derives from the conserved
+    # state where the stage derived its own)
+    w_in = H.orc_c2p(fluid, g, cons_ref, H.O.make_eos(GAMMA))[1] if from_cons else prim_ref
+    ref = H.orc_stage(fluid, recon, riemann, g, cons_ref * 0.99, cons_ref, w_in, GAMMA, C_H, 0.0, 1.0, 0.004, dedner=ded, alpha=0.1, mindx=0.07)
+    _cmp(I(want[0]), I(ref), strict, "cons")
+
+
+@pytest.mark.gpu
+def test_stage_forms_that_do_not_follow_the_x1_table_say_so(request):
+    """apk_stage_x1_halo / APK_ERR_UNSUPPORTED: the one-row donor-cell march (odd nx2), blocks narrower than two strips,
+    the flux-array solvers and stages with passive scalars do not follow apk_stage_args.x1_halo -- the query says so and
+    the stage refuses instead of reading stale ghost columns."""
+    import torch
+    from athenapk_amd import hydro
+    ctx = _ctx(request, True)
+    eos = hydro.L.make_eos(GAMMA)
+    for fluid, recon, riemann, nx, ok in [("glmmhd", "dc", "hlld", (36, 9, 10), False), ("glmmhd", "dc", "hlld", (36, 8, 10), True),
+                                          ("glmmhd", "ppm", "hlld", (36, 8, 10), True), ("glmmhd", "ppm", "hlld", (12, 8, 10), False),
+                                          ("euler", "plm", "llf", (36, 8, 10), False)]:
+        ng, prim, g = _case(fluid, recon, nx, kind="smooth", seed=5, nblocks=1)
+        cons = H.prim_to_cons(fluid, prim, GAMMA)
+        nv = NHYDRO[fluid]
+        a = hydro.MeshData(ctx, nx, ng, nv, dx=tuple(g.dx), nblocks=1, cons=cons, prim=prim, with_flux=False)
+        b = hydro.MeshData(ctx, nx, ng, nv, dx=tuple(g.dx), nblocks=1, cons=cons, prim=prim.copy(), with_flux=False)
+        ded = 1 if fluid == "glmmhd" else 0
+        assert hydro.StageFollowsX1Halo(a, fluid, recon, riemann, eos, 2, ded) == ok, (fluid, recon, riemann, nx)
+        if not ok and riemann != "llf":
+            seg = torch.zeros((nv, nx[2], nx[1], 1), dtype=torch.float64, device="cuda")
+            with pytest.raises(hydro.L.ApkError):
+                hydro.StageFused(a, b, fluid, recon, riemann, eos, C_H, 0.0, 1.0, 0.004, dedner=ded, glmmhd_alpha=0.1, mindx=0.07,
+                                 fill_derived=2, x1_halo=dict(recv=[(seg, None)], send=[(None, None)], recv_depth=1, send_depth=0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
 @pytest.mark.parametrize("kind", ["smooth", "rough"])
 @pytest.mark.parametrize("faces", ["filled_ghosts", "face_table"])
 @pytest.mark.parametrize("mode", ["input_u1", "input_u1_dt_only", "input_u0_third_buffer", "input_u0_third_buffer_dt_only"])

@@ -98,6 +98,9 @@ EXPECT_OVERLAPPED["sod_outflow"] = lambda nst, ncyc: 0
 # one-layer exchanges (apk_sim_set_thin_exchange): the exchange at the end of every cycle of VL2 on a periodic 3-D mesh
 # without passive scalars; the blocks compared below include their ghost zones, which the accessor completes first
 EXPECT_THIN = {"mhd_ppm_hlld_vl2", "mhd_ppm_two_kernel", "mhd_8_ranks"}
+# ... whose x1 strips bypass the pack / unpack kernels in both exchanges of a cycle (apk_sim_set_x1_direct) where the
+# meshblocks are wide enough for the two-kernel stage: real messages between ranks, laid out by the pack plans of the peer
+EXPECT_X1_DIRECT = {"mhd_ppm_two_kernel", "mhd_8_ranks"}
 
 
 def _worker(rank, world, port, case, outdir, overlap=True):
@@ -118,7 +121,7 @@ def _worker(rank, world, port, case, outdir, overlap=True):
         thin = s.thin_exchanges()
         blocks = {s.block_gid(lb)[0]: s.read_block(lb, "cons") for lb in range(s.info.nblocks_local)}
         np.savez(os.path.join(outdir, "rank%d.npz" % rank), time=s.time, dt=s.dt, hist=s.history(),
-                 overlapped=s.overlapped_exchanges, thin=thin,
+                 overlapped=s.overlapped_exchanges, thin=thin, x1_direct=s.x1_direct_exchanges(),
                  **{"b%d" % g: a for g, a in blocks.items()})
         s.close()
     finally:
@@ -152,6 +155,10 @@ def test_ranks_sharing_one_gpu_match_oracle(oracle, tmp_path, case, world, overl
         want_ov = EXPECT_OVERLAPPED.get(case, lambda nst, n: nst * n - 1)(nstages, ncyc)
         assert int(z["overlapped"]) == (want_ov if overlap else 0)
         assert int(z["thin"]) == (ncyc if case in EXPECT_THIN else 0)
+        if case in EXPECT_X1_DIRECT:
+            assert int(z["x1_direct"]) == 2 * ncyc
+        else:
+            assert int(z["x1_direct"]) in (0, 2 * ncyc)
         np.testing.assert_allclose(z["hist"], o.history(), rtol=1e-13, atol=1e-15)
         for key in z.files:
             if key.startswith("b"):
