@@ -356,8 +356,7 @@ def rehearsal_8gpu_rank(workload, n1_ms, steps=10, warmup=2):
     from athenapk_amd import decks, driver
     deck, fluid, integrator, recon, riemann, brick, mb, desc = WORKLOADS[workload]
     ov = ["parthenon/mesh/nx%d=%d" % (d + 1, brick) for d in range(3)] + ["parthenon/meshblock/nx%d=%d" % (d + 1, mb) for d in range(3)]
-    ov += ["parthenon/time/integrator=%s" % integrator, "hydro/reconstruction=%s" % recon, "hydro/riemann=%s" % riemann,
-           "apk_amd/rehearse_remote_faces=true"]
+    ov += ["parthenon/time/integrator=%s" % integrator, "hydro/reconstruction=%s" % recon, "hydro/riemann=%s" % riemann]
     out = {}
     # the three variants back to back in this function, each the median of three regions of >= 50 ms without event records:
     # the plain N = 1 brick again (the reference the exposed time is counted from -- the headline's own regions ran
