@@ -79,6 +79,10 @@ struct apk_ctx {
   double *h_partial_dev = nullptr;             // device address of h_partial
   unsigned long long *d_tagmax = nullptr;      // per-block criterion maxima of apk_tag_blocks (bit patterns), own buffer
   size_t tagmax_cap = 0;
+  // the minimum apk_stage_dt_flags_read last took out of word 4 (the read resets the word): repeated reads, and a following
+  // apk_stage_dt_read, return it until the next reduction into the word starts (prepare_dt_word)
+  double last_stage_min = 0.0;
+  bool last_stage_min_valid = false;
   bool dt_word_clean = false;                  // word 4 holds +max ...
   hipStream_t clean_stream = nullptr;          // ... as of the gather enqueued on this stream (another stream: reset again)
   int tag_words_clean = 0;                     // the first n words of d_tagmax hold 0

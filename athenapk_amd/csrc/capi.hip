@@ -98,6 +98,7 @@ int prepare_dt_word(apk_ctx *ctx, hipStream_t s) {
     if (hipMemcpyAsync(ctx->d_u64 + 4, ctx->d_u64 + 15, sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess) return APK_ERR_DEVICE;
   }
   ctx->dt_word_clean = false;  // (about to be reduced into)
+  ctx->last_stage_min_valid = false;
   return APK_OK;
 }
 
@@ -476,6 +477,10 @@ int apk_cons_to_prim_ghosts_split(apk_ctx *ctx, const apk_pack *md, int fluid, c
 
 int apk_stage_dt_read(apk_ctx *ctx, double cfl, double *dt_out, apk_stream_t stream) {
   if (!ctx || !dt_out) return APK_ERR_INVALID;
+  if (ctx->last_stage_min_valid) {  // (apk_stage_dt_flags_read has taken the minimum out of the device word)
+    *dt_out = cfl * ctx->last_stage_min;
+    return APK_OK;
+  }
   hipStream_t s = as_stream(stream);
   auto *h = static_cast<unsigned long long *>(ctx->h_pinned);
   APK_HIP_TRY(ctx, hipMemcpyAsync(h + 4, ctx->d_u64 + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -583,6 +588,10 @@ int apk_stage_dt_flags_read(apk_ctx *ctx, double cfl, double *dt_out, unsigned *
   if (!ctx || !dt_out || !flags) return APK_ERR_INVALID;
   hipStream_t s = as_stream(stream);
   auto *h = static_cast<unsigned long long *>(ctx->h_pinned);
+  if (ctx->last_stage_min_valid) {  // (already consumed: the word on the device has been reset)
+    *dt_out = cfl * ctx->last_stage_min;
+    return apk_poll_device_flags(ctx, flags, stream);
+  }
   if (ctx->h_pinned_dev) {
     // one small kernel hands words 4 / 5 (and the tag criteria an apk_tag_blocks_begin left pending) to the host and
     // leaves the device words ready for the next cycle
@@ -591,10 +600,16 @@ int apk_stage_dt_flags_read(apk_ctx *ctx, double cfl, double *dt_out, unsigned *
     // words 4 (the stage's minimum) and 5 (the flag words) in one copy
     APK_HIP_TRY(ctx, hipMemcpyAsync(h + 4, ctx->d_u64 + 4, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     APK_HIP_TRY(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(unsigned), s));
+    // (the same consume-on-read semantics as the gather kernel's: word 4 back to +max, ready for the next reduction)
+    APK_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_u64 + 4, ctx->d_u64 + 15, sizeof(double), hipMemcpyDeviceToDevice, s));
+    ctx->dt_word_clean = true;
+    ctx->clean_stream = s;
   }
   APK_HIP_TRY(ctx, hipStreamSynchronize(s));
   double m;
   std::memcpy(&m, h + 4, sizeof(m));
+  ctx->last_stage_min = m;
+  ctx->last_stage_min_valid = true;
   *dt_out = cfl * m;  // hydro.cpp:909
   unsigned f[2];
   std::memcpy(f, h + 5, sizeof(f));

@@ -533,8 +533,8 @@ bool regrid_check_follows(const apk_sim *s) {
   return s->amr && s->amr_adaptive && s->amr_check_interval > 0 && (s->ncycle + 1) % s->amr_check_interval == 0;
 }
 
-// may the stage loop of a refined mesh skip the ghost zones behind edges and corners?  (apk_sim_set_amr_full_exchange /
-// APK_AMR_FULL_EXCHANGE=1: never)
+// may the stage loop of a refined mesh skip the ghost zones behind edges and corners?  (apk_sim_set_amr_full_exchange(1):
+// never)
 bool amr_faces_only(const apk_sim *s) {
   return s->amr && !s->amr_full_exchange && s->mesh.ndim >= 2;
 }
@@ -1144,7 +1144,12 @@ int do_stage(apk_sim *s, int stage) {
       SIM_TRY(s, ensure_flux_arrays(s));
       planes_ahead = amr_flux_planes_ahead(s, cfg);
     }
-    SIM_TRY(s, apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream));
+    {
+      const int rc_stage = apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream);
+      // (the boundary-plane fluxes forked onto the side stream are joined on the error path too)
+      if (rc_stage != APK_OK && planes_ahead) (void)hipStreamWaitEvent(hs(s), reinterpret_cast<hipEvent_t>(s->ev_join), 0);
+      SIM_TRY(s, rc_stage);
+    }
     s->stage_dt_pending = a.estimate_dt != 0;
     s->x1_in_recv = false;                                // (read; the exchange below starts afresh)
     s->x1_out_direct = a.x1_halo && x1h.send_depth > 0;  // (consumed by exchange_begin)
@@ -2280,7 +2285,10 @@ int apk_sim_peer(const apk_sim *s, int p, apk_peer_info *o) {
 // phases 0..5: the uniform-mesh plan; 10: multilevel fill copies, 11..13: coarse-buffer boundaries
 // x1..x3, 14..16: block boundaries x1..x3, 17..19: flux-correction copies x1..x3
 const std::vector<BoxRegion> *plan_of_phase(const apk_sim *s, int phase) {
-  if (phase >= 0 && phase < PH_COUNT) return &s->mesh.plan[phase];
+  // (0..7: the uniform mesh's plans PH_LOCAL .. PH_UNPACK_THIN; 60..63: the same pack / unpack plans without the x1 faces,
+  // PH_PACK_NOX1 .. PH_UNPACK_THIN_NOX1 -- the numbers 10..49 below belong to refined meshes)
+  if (phase >= 0 && phase < PH_PACK_NOX1) return &s->mesh.plan[phase];
+  if (phase >= 60 && phase < 60 + (PH_COUNT - PH_PACK_NOX1)) return &s->mesh.plan[PH_PACK_NOX1 + (phase - 60)];
   if (!s->amr) return nullptr;
   // this rank's share (local block numbers; kinds 1 / 2 = message buffers of the halo set for 20..24,
   // of the flux-correction set for 25..33)

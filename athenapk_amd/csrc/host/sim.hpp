@@ -138,6 +138,7 @@ struct apk_sim {
   // refined meshes: the boundary-plane fluxes of a fused stage's flux correction run beside the stage kernels
   // (amr_flux_planes_ahead)
   void *side_stream = nullptr, *ev_fork = nullptr, *ev_join = nullptr;
+  bool side_stream_failed = false;  // its creation failed once: not tried again
   apk_pack *mu0() const { return mu0_of[cur][pcur]; }
   apk_pack *mu1() const { return mu1_of[u1buf][pcur]; }
   double *d_prim() const { return d_prim2[pcur]; }
@@ -154,10 +155,6 @@ struct apk_sim {
   // (exchange_pending); the next stage runs its x1 sweep on all cells farther than nghost from a
   // face with a remote neighbour, completes the exchange, then does the thin slabs and the rest.
   bool overlap = true;
-  // APK_COPY_STREAM=1 (A/B, off by default: measured slower, see apk_sim_create): same-rank ghost copies
-  // (and the ConsToPrim fused into them) on a second HIP stream, ordered against the sim's stream by two
-  // events, overlapping with the part of the next stage that needs no ghost zone -- like messages in
-  // flight; every face of every block then counts as "late" in the window tables.
   bool exchange_pending = false;
   // One-layer exchanges (mesh.hpp PH_PACK_THIN): the exchange at the end of a cycle whose first stage is the
   // donor-cell predictor.  thin_msgs: the message set apk_sim_peer reports is the one-layer one (transports read it at

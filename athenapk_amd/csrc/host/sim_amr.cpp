@@ -696,15 +696,19 @@ bool amr_has_coarse_fine_faces(const apk_sim *s) {
 // waits for them instead of computing them.  The caller has the flux arrays in place (ensure_flux_arrays).
 bool amr_flux_planes_ahead(apk_sim *s, const apk_flux_cfg &cfg) {
   static const bool off = std::getenv("APK_AMR_PLANES_INLINE") != nullptr;  // A/B switch
-  if (off || !amr_has_coarse_fine_faces(s)) return false;
+  if (off || s->side_stream_failed || !amr_has_coarse_fine_faces(s)) return false;
   auto &a = s->amr_dev;
   if (!s->side_stream) {
     hipStream_t st = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+      s->side_stream_failed = true;  // (not retried at every stage: the planes run on the sim's stream from now on)
+      return false;
+    }
     if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) {
       if (e0) (void)hipEventDestroy(e0);
       (void)hipStreamDestroy(st);
+      s->side_stream_failed = true;
       return false;
     }
     s->side_stream = st, s->ev_fork = e0, s->ev_join = e1;
@@ -714,8 +718,12 @@ bool amr_flux_planes_ahead(apk_sim *s, const apk_flux_cfg &cfg) {
   if (hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(s->ev_fork), 0) != hipSuccess) return false;
   const int rc = apk_calculate_fluxes_boundary_list(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, a.d_cf_faces, a.n_cf_faces,
                                                     reinterpret_cast<apk_stream_t>(side));
-  // (whatever was enqueued is joined below either way)
-  (void)hipEventRecord(reinterpret_cast<hipEvent_t>(s->ev_join), side);
+  // (whatever was enqueued is joined either way: through the event -- by amr_flux_fix, or by do_stage if the stage fails
+  // in between -- or, if the event cannot be recorded, by waiting for the side stream here)
+  if (hipEventRecord(reinterpret_cast<hipEvent_t>(s->ev_join), side) != hipSuccess) {
+    (void)hipStreamSynchronize(side);
+    return false;  // (the caller computes the planes on its own stream: the same values once more)
+  }
   if (rc != APK_OK) {
     (void)hipStreamWaitEvent(hs(s), reinterpret_cast<hipEvent_t>(s->ev_join), 0);
     return false;

@@ -187,7 +187,9 @@ cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags, unsigned long lon
   bool ok;
   if (boxed) {
     const int ei = pv.nx1 + 2 * depth, ej = (pv.ndim >= 2) ? pv.nx2 + 2 * depth : pv.nj, ek = (pv.ndim >= 3) ? pv.nx3 + 2 * depth : pv.nk;
-    const unsigned f = blockIdx.y * 256u + threadIdx.y * 64u + threadIdx.x, plane = (unsigned)(ei * ej);
+    // (the box's workgroups are dealt over grid x and y: a box of more than 65535 workgroups -- blocks of ~256^3 cells --
+    // still has its own launch shape instead of falling back to the whole block)
+    const unsigned f = (blockIdx.y * gridDim.x + blockIdx.x) * 256u + threadIdx.y * 64u + threadIdx.x, plane = (unsigned)(ei * ej);
     const unsigned kk = f / plane, r = f - kk * plane, jj = r / (unsigned)ei;
     ok = kk < (unsigned)ek;
     i = pv.is - depth + (int)(r - jj * (unsigned)ei);
@@ -639,8 +641,9 @@ int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsig
   if (depth >= pv.ng) depth = -1;  // (the whole block)
   if (!faces_only && dt_bits && depth >= 0) {  // (cons_to_prim_kernel's box)
     const int64_t cells = (int64_t)(pv.nx1 + 2 * depth) * (pv.ndim >= 2 ? pv.nx2 + 2 * depth : pv.nj) * (pv.ndim >= 3 ? pv.nx3 + 2 * depth : pv.nk);
-    if (cells < ((int64_t)1 << 31) && (cells + 255) / 256 <= 65535) grid = dim3(1, (unsigned)((cells + 255) / 256), pv.nblocks);
-    else depth = -1;
+    const int64_t wgs = (cells + 255) / 256, gy = (wgs + 32767) / 32768, gx = (wgs + gy - 1) / gy;
+    if (cells < ((int64_t)1 << 31) && gy <= 65535) grid = dim3((unsigned)gx, (unsigned)gy, pv.nblocks);
+    else return APK_ERR_UNSUPPORTED;  // (never: a block of 2^31 cells; widening the region would convert stale ghost cells)
   }
   if (faces_only) {
     const bool euler = fluid == APK_FLUID_EULER;

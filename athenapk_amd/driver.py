@@ -108,6 +108,8 @@ class _MeshView:
     """Block placement and ghost-exchange plans of a sim handle (valid without a GPU)."""
 
     PHASES = {"local": 0, "pack": 1, "unpack": 2, "bc1": 3, "bc2": 4, "bc3": 5, "pack_thin": 6, "unpack_thin": 7,
+              # the pack / unpack plans without the x1 faces (apk_sim_set_x1_direct)
+              "pack_nox1": 60, "unpack_nox1": 61, "pack_thin_nox1": 62, "unpack_thin_nox1": 63,
               # refined meshes (src/.. host/amr.hpp): all copies of the multilevel exchange, the
               # physical boundaries of coarse buffers / blocks, the flux-correction copies
               "amr_fill": 10, "amr_coarse_bc1": 11, "amr_coarse_bc2": 12, "amr_coarse_bc3": 13,

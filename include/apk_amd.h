@@ -360,7 +360,10 @@ int apk_cons_to_prim_ghosts_split(apk_ctx *ctx, const apk_pack *md, int fluid, c
  * Synchronises `stream`. */
 int apk_stage_dt_read(apk_ctx *ctx, double cfl, double *dt_out, apk_stream_t stream);
 /* apk_stage_dt_read + apk_poll_device_flags with ONE synchronisation (the per-cycle host round
- * trip of a driver: new dt and the latched negative-density / -pressure flags). */
+ * trip of a driver: new dt and the latched negative-density / -pressure flags).  CONSUMES the reduction: the device word
+ * goes back to +max for the next one (on every platform); the handle remembers the minimum, and repeated calls -- or an
+ * apk_stage_dt_read after it -- return the same value until the next stage / ConsToPrim with a time-step estimate starts
+ * a new reduction. */
 int apk_stage_dt_flags_read(apk_ctx *ctx, double cfl, double *dt_out, unsigned *flags,
                             apk_stream_t stream);
 

@@ -152,8 +152,8 @@ int apk_sim_prim_is_stale(const apk_sim *sim);
 long long apk_sim_turb_dt_kicks(const apk_sim *sim);
 /* Refined meshes: the stage loop's exchange leaves out the ghost zones behind block edges and corners
  * (no sweep or flux correction reads them; accessors, tagging and the last exchange of a cycle that
- * checks the refinement criteria complete them).  1 = always exchange in full (what APK_AMR_FULL_EXCHANGE=1
- * in the environment selects): same results, for A/B timing and for the tests of that statement. */
+ * checks the refinement criteria complete them).  1 = always exchange in full: same results, for A/B timing and
+ * for the tests of that statement. */
 int apk_sim_set_amr_full_exchange(apk_sim *sim, int on);
 
 /* ---- introspection ------------------------------------------------------------------- */

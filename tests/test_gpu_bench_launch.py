@@ -42,7 +42,10 @@ def _check_contract(d, world, steps, warmup):
     assert d["unit"] == "cell-updates/s" and d["scaling"] == "weak" and d["dtype"] == "f64" and d["higher_is_better"] is True
     assert d["value"] > 0 and d["value"] == d["value"] and d["ms_per_step"] > 0
     r = d["roofline"]
-    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # (`bound` names what binds the stage kernels -- the fp64 vector issue rate for the GLM-MHD marches -- while achieved /
+    # peak / frac stay priced against HBM bandwidth, as north_star asks: `priced_against`)
+    assert r["bound"] in ("hbm", "fp64_valu_issue") and r["priced_against"] == "hbm" and r["unit"] == "GB/s"
+    assert 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
 
 
 def test_bench_on_two_ranks_through_the_launcher():

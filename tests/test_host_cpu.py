@@ -111,6 +111,25 @@ def test_rehearsal_of_an_eight_rank_brick_has_that_ranks_messages():
         _plan("synthetic_mhd", ["parthenon/mesh/nx%d=64" % d for d in (1, 2, 3)] + mb + ["apk_amd/rehearse_remote_faces=true"], rank=0, nranks=8)
 
 
+def test_plans_without_x1_faces_keep_the_message_layout():
+    """PH_PACK_NOX1 .. PH_UNPACK_THIN_NOX1 (apk_sim_set_x1_direct: the x1 strips are stored into / read from the buffers by
+    the stage kernels): the same regions at the same places in the same messages, minus exactly the x1 FACES -- one strip
+    of nghost (or one) columns over the whole interior extent in x2 and x3 per block and remote x1 side."""
+    mb = ["parthenon/meshblock/nx%d=16" % d for d in (1, 2, 3)]
+    p = _plan("synthetic_mhd", ["parthenon/mesh/nx%d=64" % d for d in (1, 2, 3)] + mb, rank=3, nranks=8)
+    ng = p.info.ng
+    key = lambda r: (r.src_kind, r.src_block, r.dst_kind, r.dst_block, r.src_off, r.dst_off, tuple(r.ext), r.nvar, tuple(r.src_stride), tuple(r.dst_stride))
+    for full, cut, depth in (("pack", "pack_nox1", ng), ("unpack", "unpack_nox1", ng), ("pack_thin", "pack_thin_nox1", 1),
+                             ("unpack_thin", "unpack_thin_nox1", 1)):
+        a, b = [key(r) for r in p.regions(full)], [key(r) for r in p.regions(cut)]
+        gone = [r for r in a if r not in set(b)]
+        assert set(b) <= set(a) and len(gone) == len(a) - len(b)
+        # every block of the 2 x 2 x 2 brick has ONE x1 face on another rank
+        assert len(gone) == 8 and all(r[6] == (depth, 16, 16) for r in gone)
+        assert sorted({r[1] if "unpack" not in full else r[3] for r in gone}) == list(range(8))
+        assert not any(r[6] == (depth, 16, 16) for r in b)
+
+
 def test_morton_partition_gives_bricks():
     """4x4x4 meshblocks over 8 ranks: each rank owns a 2x2x2 brick."""
     ov = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "parthenon/mesh/nx3=64",
