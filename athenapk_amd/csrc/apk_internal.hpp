@@ -45,9 +45,9 @@ inline PackView make_view(const apk_pack_desc &d, const apk_block_desc *dev_bloc
   v.je = (d.nx[1] > 1) ? d.ng + d.nx[1] - 1 : 0;
   v.ks = (d.nx[2] > 1) ? d.ng : 0;
   v.ke = (d.nx[2] > 1) ? d.ng + d.nx[2] - 1 : 0;
-  v.sj = v.ni;
-  v.sk = (int64_t)v.ni * v.nj;
-  v.sn = v.sk * v.nk;
+  v.sj = d.stride[0] > 0 ? d.stride[0] : v.ni;
+  v.sk = d.stride[1] > 0 ? d.stride[1] : v.sj * v.nj;
+  v.sn = d.stride[2] > 0 ? d.stride[2] : v.sk * v.nk;
   return v;
 }
 

@@ -48,7 +48,7 @@ int check_cfg(apk_ctx *ctx, const apk_pack *md, const apk_flux_cfg &cfg) {
 bool same_shape(const apk_pack *a, const apk_pack *b) {
   const PackView &x = a->view, &y = b->view;
   return x.nblocks == y.nblocks && x.nvar == y.nvar && x.ni == y.ni && x.nj == y.nj &&
-         x.nk == y.nk && x.ng == y.ng;
+         x.nk == y.nk && x.ng == y.ng && x.sj == y.sj && x.sk == y.sk && x.sn == y.sn;
 }
 
 int ensure_partial(apk_ctx *ctx, size_t n) {
@@ -198,6 +198,11 @@ int apk_pack_create(apk_ctx *ctx, const apk_pack_desc *desc, apk_pack **out) {
   if (desc->nscalars < 0 || desc->ng < 1 || desc->nx[0] < 1 || desc->nx[1] < 1 || desc->nx[2] < 1)
     return set_err(ctx, APK_ERR_INVALID, "bad pack geometry");
   if (desc->nx[1] == 1 && desc->nx[2] > 1) return set_err(ctx, APK_ERR_INVALID, "nx2 == 1 requires nx3 == 1");
+  {
+    const PackView t = make_view(*desc, nullptr);  // (explicit strides: no array may overlap the next one)
+    if (desc->stride[0] < 0 || desc->stride[1] < 0 || desc->stride[2] < 0 || t.sj < t.ni || t.sk < t.sj * t.nj || t.sn < t.sk * t.nk)
+      return set_err(ctx, APK_ERR_INVALID, "pack strides smaller than the extents they step over");
+  }
   apk_pack *p = new (std::nothrow) apk_pack();
   if (!p) return APK_ERR_INVALID;
   p->h_blocks.assign(desc->blocks, desc->blocks + desc->nblocks);

@@ -64,6 +64,11 @@ struct Mesh {
   // messages are delivered by the loopback transport (comm_rccl.cpp): with the sender's and the receiver's
   // segment lists ordered by the same key, a rank's own send buffer IS the message its periodic image would send.
   int rehearse = 0;
+  // Row pitch of the block arrays in doubles (0: the natural Ni) and the doubles in front of a block's first cell in its
+  // slot (apk_pack_desc.stride; sim.cpp "apk_amd/row_pitch"): with pitch a multiple of 16 and lead = (-nghost) mod 16 the
+  // first interior cell of every row sits on a 128-byte boundary.  Everything on the host addresses cells through sj / sk /
+  // sn, never through ni / nj.
+  int pitch = 0, lead = 0;
   // derived
   int nb[3] = {1, 1, 1}, nblocks_total = 1, ndim = 1;
   int ni = 1, nj = 1, nk = 1, is = 0, ie = 0, js = 0, je = 0, ks = 0, ke = 0;
@@ -118,8 +123,9 @@ struct Mesh {
     je = Active(1) ? ng + mb[1] - 1 : 0;
     ks = Active(2) ? ng : 0;
     ke = Active(2) ? ng + mb[2] - 1 : 0;
-    sj = ni;
-    sk = (int64_t)ni * nj;
+    if (pitch != 0 && pitch < ni) throw std::runtime_error("row pitch smaller than a row");
+    sj = pitch > 0 ? pitch : ni;
+    sk = sj * nj;
     sn = sk * nk;
 
     // Morton-ordered contiguous ranges, balanced to within one block

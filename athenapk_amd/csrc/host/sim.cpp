@@ -148,8 +148,22 @@ void mesh_initialize(apk_sim *s) {
   // (not a reference parameter: the one-GPU rehearsal of a rank of the 2 x 2 x 2 run, mesh.hpp "rehearse")
   m.rehearse = pin.GetOrAddBoolean("apk_amd", "rehearse_remote_faces", false) ? 1 : 0;
   if (m.rehearse && refinement != "none") throw std::runtime_error("apk_amd/rehearse_remote_faces needs a uniform mesh");
+  // (not a reference parameter either: rows of the block arrays at a cache-line pitch, interior cells line-aligned --
+  // uniform meshes without the turbulence driver, whose acceleration field has its own layout)
+  // natural | aligned | auto (default).  auto = aligned where it was measured to pay (profiles/r06_row_pitch_ab.txt: the
+  // nine-variable GLM-MHD marches on 128-cell rows, -0.7 .. -1.4 % per cycle; hydro PLM+HLLC with its outflow boundary
+  // copies +0.8 %): 3-D GLM-MHD on blocks whose rows are whole lines.
+  const std::string row_pitch = pin.GetOrAddString("apk_amd", "row_pitch", std::getenv("APK_ROW_PITCH") ? std::getenv("APK_ROW_PITCH") : "auto");
+  if (row_pitch != "natural" && row_pitch != "aligned" && row_pitch != "auto") throw std::runtime_error("apk_amd/row_pitch must be natural, aligned or auto");
+  const bool can_pad = refinement == "none" && s->problem_id != "turbulence";
+  const bool pays = s->pkg.fluid == APK_FLUID_GLMMHD && m.mb[2] > 1 && m.mb[0] % 16 == 0 && m.mb[0] >= 64;
+  if (can_pad && (row_pitch == "aligned" || (row_pitch == "auto" && pays))) {
+    m.pitch = (m.mb[0] + 2 * m.ng + 15) / 16 * 16;
+    m.lead = (16 - m.ng % 16) % 16;
+  }
   m.Build();
-  s->nper = m.sn * m.nvar;
+  s->nblk = m.sn * m.nvar;
+  s->nper = m.lead == 0 && m.pitch == 0 ? s->nblk : (s->nblk + m.lead + 15) / 16 * 16;
   if (refinement != "none") amr_initialize(s, refinement == "adaptive");
   s->tlim = pin.GetOrAddReal("parthenon/time", "tlim", 1.0);
   s->nlim = pin.GetOrAddInteger("parthenon/time", "nlim", -1);
@@ -187,12 +201,12 @@ int build_packs(apk_sim *s) {
       double *spare = s->d_prim2[1 - w];  // may be null: then u1 carries no prim
       std::vector<apk_block_desc> b0(nlb), b1(nlb);
       for (int lb = 0; lb < nlb; ++lb) {
-        b0[lb].cons = s->d_cons2[p] + lb * s->nper;
-        b0[lb].prim = s->d_prim2[w] + lb * s->nper;
-        b1[lb].cons = s->d_cons2[p] + lb * s->nper;
-        b1[lb].prim = spare ? spare + lb * s->nper : nullptr;
+        b0[lb].cons = s->blk(s->d_cons2[p], lb);
+        b0[lb].prim = s->blk(s->d_prim2[w], lb);
+        b1[lb].cons = s->blk(s->d_cons2[p], lb);
+        b1[lb].prim = spare ? s->blk(spare, lb) : nullptr;
         for (int d = 0; d < 3; ++d) {
-          b0[lb].flux[d] = s->d_flux[d] ? s->d_flux[d] + lb * s->nper : nullptr;
+          b0[lb].flux[d] = s->d_flux[d] ? s->blk(s->d_flux[d], lb) : nullptr;
           b1[lb].flux[d] = nullptr;
           b0[lb].dx[d] = b1[lb].dx[d] = level_dx(s, block_level(s, lb), d);
         }
@@ -203,6 +217,11 @@ int build_packs(apk_sim *s) {
       d.nscalars = s->pkg.nscalars;
       for (int q = 0; q < 3; ++q) d.nx[q] = s->mesh.mb[q];
       d.ng = s->mesh.ng;
+      if (s->mesh.pitch > 0) {
+        d.stride[0] = s->mesh.sj;
+        d.stride[1] = s->mesh.sk;
+        d.stride[2] = s->mesh.sn;
+      }
       d.blocks = b0.data();
       SIM_TRY(s, apk_pack_create(s->ctx, &d, &s->mu0_of[p][w]));
       d.blocks = b1.data();
@@ -263,7 +282,7 @@ static int make_plans(apk_sim *s, double *field, apk_copy_plan *(&out)[PH_COUNT]
     if (!field) continue;
     std::vector<apk_copy_region> regs;
     auto base = [&](int kind, int block) -> double * {
-      if (kind == RK_BLOCK) return field + (int64_t)block * s->nper;
+      if (kind == RK_BLOCK) return s->blk(field, block);
       return kind == RK_SEND ? s->send_buf[block] : s->recv_buf[block];
     };
     for (const BoxRegion &r : s->mesh.plan[ph]) {
@@ -1597,13 +1616,11 @@ int apk_sim_initialize(apk_sim *s) {
       std::vector<std::vector<double>> blocks;
       SIM_TRY(s, pgen_turbulence(s, blocks));
       for (int lb = 0; lb < nlb; ++lb)
-        SIM_HIP(s, hipMemcpy(s->d_cons() + (int64_t)lb * s->nper, blocks[lb].data(), sizeof(double) * s->nper,
-                             hipMemcpyHostToDevice));
+        SIM_HIP(s, hipMemcpy(s->blk(s->d_cons(), lb), blocks[lb].data(), sizeof(double) * s->nblk, hipMemcpyHostToDevice));
     } else {
       for (int lb = 0; lb < nlb; ++lb) {
         pgen_block(s, lb, host);
-        SIM_HIP(s, hipMemcpy(s->d_cons() + (int64_t)lb * s->nper, host.data(), sizeof(double) * s->nper,
-                             hipMemcpyHostToDevice));
+        SIM_HIP(s, hipMemcpy(s->blk(s->d_cons(), lb), host.data(), sizeof(double) * s->nblk, hipMemcpyHostToDevice));
       }
     }
   } catch (const std::exception &e) {
@@ -1633,7 +1650,7 @@ int apk_sim_initialize(apk_sim *s) {
     try {
       for (int lb = 0; lb < (int)s->mesh.local_gids.size(); ++lb) {
         pgen_block(s, lb, host);
-        SIM_HIP(s, hipMemcpy(s->d_cons() + (int64_t)lb * s->nper, host.data(), sizeof(double) * s->nper, hipMemcpyHostToDevice));
+        SIM_HIP(s, hipMemcpy(s->blk(s->d_cons(), lb), host.data(), sizeof(double) * s->nblk, hipMemcpyHostToDevice));
       }
     } catch (const std::exception &e) {
       return fail(s, APK_ERR_INVALID, e.what());
@@ -1803,15 +1820,43 @@ int apk_sim_regrid(apk_sim *s, int *changed) {
 void *apk_sim_block_ptr(const apk_sim *s, int lb, int field) {
   if (!s || s->host_only || lb < 0 || lb >= (int)s->mesh.local_gids.size()) return nullptr;
   double *base = field == 0 ? s->d_cons() : (field == 1 ? s->d_prim() : (field == 2 ? s->d_cons2[s->u1buf] : nullptr));
-  return base ? base + (int64_t)lb * s->nper : nullptr;
+  return base ? s->blk(base, lb) : nullptr;
 }
 
-int apk_sim_read_block(apk_sim *s, int lb, int field, double *host_out) {
+// The accessors hand blocks over in the natural layout, [nvar][Nk][Nj][Ni], whatever the row pitch on the device
+namespace {
+void unpad_block(const apk_sim *s, const double *padded, double *natural) {
+  const Mesh &m = s->mesh;
+  for (int n = 0; n < m.nvar; ++n)
+    for (int k = 0; k < m.nk; ++k)
+      for (int j = 0; j < m.nj; ++j)
+        std::memcpy(natural + (((int64_t)n * m.nk + k) * m.nj + j) * m.ni, padded + n * m.sn + k * m.sk + j * m.sj, sizeof(double) * m.ni);
+}
+void pad_block(const apk_sim *s, const double *natural, double *padded) {
+  const Mesh &m = s->mesh;
+  for (int n = 0; n < m.nvar; ++n)
+    for (int k = 0; k < m.nk; ++k)
+      for (int j = 0; j < m.nj; ++j)
+        std::memcpy(padded + n * m.sn + k * m.sk + j * m.sj, natural + (((int64_t)n * m.nk + k) * m.nj + j) * m.ni, sizeof(double) * m.ni);
+}
+}  // namespace
+
+// a block as it lies on the device (rows at the mesh's pitch; the block's nblk doubles): the host-side readers of this
+// file index it through mesh.sj / sk / sn
+static int read_block_device_layout(apk_sim *s, int lb, int field, double *host_out) {
   if (s && !s->host_only) SIM_TRY(s, sync_ghosts(s));
   void *p = apk_sim_block_ptr(s, lb, field);
   if (!p || !host_out) return APK_ERR_INVALID;
   SIM_HIP(s, hipStreamSynchronize(hs(s)));
-  SIM_HIP(s, hipMemcpy(host_out, p, sizeof(double) * s->nper, hipMemcpyDeviceToHost));
+  SIM_HIP(s, hipMemcpy(host_out, p, sizeof(double) * s->nblk, hipMemcpyDeviceToHost));
+  return APK_OK;
+}
+
+int apk_sim_read_block(apk_sim *s, int lb, int field, double *host_out) {
+  if (!s || s->host_only || s->mesh.pitch == 0) return read_block_device_layout(s, lb, field, host_out);
+  std::vector<double> tmp((size_t)s->nblk);
+  SIM_TRY(s, read_block_device_layout(s, lb, field, tmp.data()));
+  unpad_block(s, tmp.data(), host_out);
   return APK_OK;
 }
 
@@ -1820,7 +1865,14 @@ int apk_sim_write_block(apk_sim *s, int lb, int field, const double *host_in) {
   void *p = apk_sim_block_ptr(s, lb, field);
   if (!p || !host_in) return APK_ERR_INVALID;
   SIM_HIP(s, hipStreamSynchronize(hs(s)));
-  SIM_HIP(s, hipMemcpy(p, host_in, sizeof(double) * s->nper, hipMemcpyHostToDevice));
+  if (s->mesh.pitch > 0) {
+    std::vector<double> tmp((size_t)s->nblk);
+    SIM_HIP(s, hipMemcpy(tmp.data(), p, sizeof(double) * s->nblk, hipMemcpyDeviceToHost));  // (the padding keeps what it held)
+    pad_block(s, host_in, tmp.data());
+    SIM_HIP(s, hipMemcpy(p, tmp.data(), sizeof(double) * s->nblk, hipMemcpyHostToDevice));
+    return APK_OK;
+  }
+  SIM_HIP(s, hipMemcpy(p, host_in, sizeof(double) * s->nblk, hipMemcpyHostToDevice));
   return APK_OK;
 }
 
@@ -1831,7 +1883,7 @@ int apk_sim_gather(apk_sim *s, int field, double *out) {
   std::vector<double> host((size_t)s->nper);
   const int64_t NX = m.nx[0], NY = m.nx[1], NZ = m.nx[2];
   for (int lb = 0; lb < (int)m.local_gids.size(); ++lb) {
-    int rc = apk_sim_read_block(s, lb, field, host.data());
+    int rc = read_block_device_layout(s, lb, field, host.data());
     if (rc != APK_OK) return rc;
     int bc[3];
     m.Loc(m.local_gids[lb], bc);
@@ -2088,7 +2140,7 @@ static int linear_wave_errors_n(apk_sim *s, int ncol, double *rms, double *l1, d
   std::vector<double> host((size_t)s->nper);
   double acc[16] = {0};
   for (int lb = 0; lb < (int)m.local_gids.size(); ++lb) {
-    int rc = apk_sim_read_block(s, lb, 0, host.data());
+    int rc = read_block_device_layout(s, lb, 0, host.data());
     if (rc != APK_OK) return rc;
     LevelDxScope level_dx_scope(s, lb);
     const double cellvol = s->dx[0] * s->dx[1] * s->dx[2];
@@ -2145,7 +2197,7 @@ int apk_sim_cpaw_errors(apk_sim *s, double *rms, double *err8) {
   std::vector<double> host((size_t)s->nper);
   double err[8] = {0};
   for (int lb = 0; lb < (int)m.local_gids.size(); ++lb) {
-    int rc = apk_sim_read_block(s, lb, 0, host.data());
+    int rc = read_block_device_layout(s, lb, 0, host.data());
     if (rc != APK_OK) return rc;
     double x0[3];
     block_origin(s, lb, x0);

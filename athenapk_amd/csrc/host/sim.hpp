@@ -106,7 +106,10 @@ struct apk_sim {
   bool have_alloc = false;
   apk_comm_ops comm{};
   bool have_comm = false;
-  int64_t nper = 0;  // doubles per field per block
+  // doubles per field per block: nper = the slot a block has in a field's allocation (a multiple of 16 when rows are
+  // padded), nblk = what is addressed from the block's pointer (nvar * sn), which sits mesh.lead doubles into the slot
+  int64_t nper = 0, nblk = 0;
+  double *blk(double *field, int64_t lb) const { return field + lb * nper + mesh.lead; }
   // Two conserved-variable buffers: the stage-1 "u1 <- u0" DeepCopy of the reference
   // (hydro_driver.cpp:474-495) is a buffer-role swap here -- stage 1 has gam0 = 0 for every
   // integrator, so it reads the old state as u1 and writes the new state into the other buffer.

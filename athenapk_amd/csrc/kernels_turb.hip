@@ -447,11 +447,21 @@ int finish_sums(apk_ctx *ctx, int nwg, double *out, hipStream_t s) {
 using namespace apk;
 
 namespace {
+// The acceleration field lives in arrays of its own, [3][Nk][Nj][Ni] per block, addressed with the pack's cell offsets:
+// packs with explicit strides (apk_pack_desc.stride) are refused rather than read across rows.
+static bool natural_layout(const apk_pack *md) {
+  const PackView &v = md->view;
+  return v.sj == v.ni && v.sk == (int64_t)v.ni * v.nj && v.sn == (int64_t)v.ni * v.nj * v.nk;
+}
+#define APK_TURB_NATURAL(ctx, md) \
+  do { if (!natural_layout(md)) return set_err((ctx), APK_ERR_UNSUPPORTED, "turbulence driver: packs with explicit strides are not supported"); } while (0)
+
 int turb_apply_fill_impl(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, double norm, double dt, int fluid, const apk_eos *eos,
                          int estimate_dt, bool store_prim, apk_stream_t stream) {
   if (!ctx || !md || !f || !eos || f->nblocks != md->view.nblocks || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||
       md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9) || (!store_prim && md->view.nvar != md->view.nhydro))
     return set_err(ctx, APK_ERR_INVALID, "apk_turb_apply_fill: bad argument");
+  APK_TURB_NATURAL(ctx, md);
   for (const auto &b : md->h_blocks)
     if (store_prim && !b.prim) return set_err(ctx, APK_ERR_INVALID, "apk_turb_apply_fill: block without prim pointer");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -505,6 +515,7 @@ int apk_fmft_inverse(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, const double
                      apk_stream_t stream) {
   if (!ctx || !md || !f || !var_hat_host || f->nblocks != md->view.nblocks)
     return set_err(ctx, APK_ERR_INVALID, "apk_fmft_inverse: bad argument");
+  APK_TURB_NATURAL(ctx, md);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   APK_HIP_TRY(ctx, hipMemcpyAsync(f->d_var_hat, var_hat_host, sizeof(double) * 3 * f->num_modes * 2,
                                   hipMemcpyHostToDevice, s));
@@ -533,6 +544,7 @@ int apk_fmft_inverse(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, const double
 int apk_turb_mean_momentum(apk_ctx *ctx, const apk_pack *md, const apk_fmft *f, double *sums4,
                            apk_stream_t stream) {
   if (!ctx || !md || !f || !sums4 || f->nblocks != md->view.nblocks) return set_err(ctx, APK_ERR_INVALID, "apk_turb_mean_momentum: bad argument");
+  APK_TURB_NATURAL(ctx, md);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const dim3 g = igrid(md->view);
   const int nwg = g.x * g.y * g.z;
@@ -545,6 +557,7 @@ int apk_turb_remove_mean(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, const do
                          apk_stream_t stream) {
   if (!ctx || !md || !f || !sums4 || !ampl_sum || f->nblocks != md->view.nblocks)
     return set_err(ctx, APK_ERR_INVALID, "apk_turb_remove_mean: bad argument");
+  APK_TURB_NATURAL(ctx, md);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const dim3 g = igrid(md->view);
   const int nwg = g.x * g.y * g.z;
@@ -556,6 +569,7 @@ int apk_turb_remove_mean(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, const do
 
 int apk_turb_apply(apk_ctx *ctx, const apk_pack *md, apk_fmft *f, double norm, double dt, apk_stream_t stream) {
   if (!ctx || !md || !f || f->nblocks != md->view.nblocks) return set_err(ctx, APK_ERR_INVALID, "apk_turb_apply: bad argument");
+  APK_TURB_NATURAL(ctx, md);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(turb_apply_kernel, igrid(md->view), dim3(64, 4, 1), 0, s, md->view, f->d_blocks, norm, dt);
   return hipGetLastError() == hipSuccess ? APK_OK : set_err(ctx, APK_ERR_DEVICE, "turb_apply launch", hipGetLastError());

@@ -7,6 +7,7 @@ torch is plumbing only: it owns device memory (the role Parthenon plays for Athe
 the HIP stream; every operation is one call through the C-ABI of libapk_amd.so.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -62,7 +63,12 @@ class MeshData:
     """
 
     def __init__(self, ctx, nx, ng, nhydro, nscalars=0, dx=(1.0, 1.0, 1.0), nblocks=1,
-                 cons=None, prim=None, with_flux=True):
+                 cons=None, prim=None, with_flux=True, row_pitch=None):
+        """row_pitch: None / "natural" = rows of Ni doubles (LayoutRight, apk_pack_desc.stride = 0); "aligned" = rows at a
+        pitch that is a multiple of 16 doubles from a base that puts the first interior cell of a row on a 128-byte
+        boundary; an int = that pitch.  (APK_TEST_ROW_PITCH in the environment sets the default: the parity tests run
+        unchanged on either layout.)  self.cons / prim / flux[d] are VIEWS [nblocks][nvar][Nk][Nj][Ni] of the padded
+        storage; the padding holds NaNs."""
         self.ctx = ctx
         self.nx, self.ng, self.nhydro, self.nscalars = tuple(nx), ng, nhydro, nscalars
         self.nvar = nhydro + nscalars
@@ -74,21 +80,46 @@ class MeshData:
         self.nblocks = nblocks
         self.dx = tuple(dx)
         dev = torch.device("cuda")
+        if row_pitch is None:
+            row_pitch = os.environ.get("APK_TEST_ROW_PITCH") or None
+        if row_pitch in (None, "natural"):
+            pitch, lead = ni, 0
+        elif row_pitch == "aligned":
+            pitch, lead = (ni + 15) // 16 * 16, (-ng) % 16
+        else:
+            pitch, lead = int(row_pitch), 0
+        assert pitch >= ni
+        self.pitch, self.lead = pitch, lead
+        sk, sn = pitch * nj, pitch * nj * nk
+        natural = pitch == ni and lead == 0
+        slot = self.nvar * sn if natural else (lead + self.nvar * sn + 15) // 16 * 16
+        self._storage = []
 
         def field(src):
+            if natural:
+                if src is None:
+                    return torch.zeros((nblocks,) + self.shape, dtype=torch.float64, device=dev)
+                if isinstance(src, torch.Tensor):
+                    t = src.to(device=dev, dtype=torch.float64).contiguous()
+                else:
+                    t = torch.from_numpy(np.ascontiguousarray(src, dtype=np.float64)).to(dev)
+                return t.reshape((nblocks,) + self.shape).contiguous()
+            store = torch.full((nblocks * slot,), float("nan"), dtype=torch.float64, device=dev)
+            self._storage.append(store)
+            view = store.as_strided((nblocks,) + self.shape, (slot, sn, sk, pitch, 1), lead)
             if src is None:
-                return torch.zeros((nblocks,) + self.shape, dtype=torch.float64, device=dev)
-            if isinstance(src, torch.Tensor):
-                t = src.to(device=dev, dtype=torch.float64).contiguous()
+                view.zero_()
+            elif isinstance(src, torch.Tensor):
+                view.copy_(src.to(device=dev, dtype=torch.float64).reshape((nblocks,) + self.shape))
             else:
-                t = torch.from_numpy(np.ascontiguousarray(src, dtype=np.float64)).to(dev)
-            return t.reshape((nblocks,) + self.shape).contiguous()
+                view.copy_(torch.from_numpy(np.ascontiguousarray(src, dtype=np.float64)).to(dev).reshape((nblocks,) + self.shape))
+            return view
 
         self.cons = field(cons)
         self.prim = field(prim)
         self.flux = [field(None) if (with_flux and d < self.ndim) else None for d in range(3)]
         blocks = (L.BlockDesc * nblocks)()
-        per = int(np.prod(self.shape)) * 8
+        per = slot * 8
         for b in range(nblocks):
             blocks[b].cons = self.cons.data_ptr() + b * per
             blocks[b].prim = self.prim.data_ptr() + b * per
@@ -99,6 +130,8 @@ class MeshData:
         desc.nblocks, desc.nhydro, desc.nscalars, desc.ng = nblocks, nhydro, nscalars, ng
         desc.nx[:] = list(nx)
         desc.blocks = blocks
+        if not natural:
+            desc.stride[:] = [pitch, sk, sn]
         h = C.c_void_p()
         _check(ctx.lib.apk_pack_create(ctx.h, C.byref(desc), C.byref(h)), ctx.lib, ctx.h)
         self.h = h

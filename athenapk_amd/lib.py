@@ -49,7 +49,7 @@ class BlockDesc(C.Structure):
 
 class PackDesc(C.Structure):
     _fields_ = [("nblocks", C.c_int), ("nhydro", C.c_int), ("nscalars", C.c_int),
-                ("nx", C.c_int * 3), ("ng", C.c_int), ("blocks", C.POINTER(BlockDesc))]
+                ("nx", C.c_int * 3), ("ng", C.c_int), ("blocks", C.POINTER(BlockDesc)), ("stride", C.c_int64 * 3)]
 
 
 class StageArgs(C.Structure):

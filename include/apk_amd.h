@@ -91,6 +91,15 @@ typedef struct apk_pack_desc {
   int nx[3];    /* block_size.nx(X1DIR..X3DIR); 1 = collapsed dimension */
   int ng;       /* parthenon/mesh/nghost */
   const apk_block_desc *blocks; /* HOST array [nblocks] */
+  /* Element strides of the j, k and variable index of every array of the pack (cons, prim, flux): `pack(b)(v,k,j,i)` is
+   * base[v * stride[2] + k * stride[1] + j * stride[0] + i] -- the reference's accessor is stride-agnostic
+   * (src/hydro/hydro.cpp:1041-1073), Parthenon's allocations are LayoutRight.  0 = that natural layout:
+   * Ni, Ni * Nj, Ni * Nj * Nk with Ni = nx[0] + 2 ng etc.  Anything else must satisfy stride[0] >= Ni,
+   * stride[1] >= stride[0] * Nj, stride[2] >= stride[1] * Nk (and be the same for every block).  What it is for: rows
+   * at a pitch that is a multiple of a cache line (16 doubles) from a base chosen so that the first INTERIOR cell of a
+   * row sits on a line boundary -- the stage kernels then load and store the 128-cell rows of a 128^3 block as 8 whole
+   * lines instead of 9 - 10 partial ones (the standalone driver: apk_amd/row_pitch = aligned). */
+  int64_t stride[3];
 } apk_pack_desc;
 
 typedef struct apk_ctx apk_ctx;   /* workspace: flag words, reduction scratch */
