@@ -181,6 +181,27 @@ def amr_blast_bench(cycles=40, variants=("hydro_plm_hlle_vl2", "mhd_ppm_hlld_vl2
     return out
 
 
+def scheme_floor(cells, stage_ms, steps=256, reps=8):
+    """The empirical issue floor of the PPM + HLLD scheme on this device (csrc/bench_floor.hip through the C-ABI): every lane of
+    two waves per SIMD -- the stage kernels' occupancy -- runs `steps` sweep steps of nine PPM reconstructions + one HLLD
+    solve on a smooth monotone pencil in registers / its LDS ring and NOTHING else (no global memory, no wave shifts, no
+    limiter block entered, no update / Dedner / ConsToPrim); a cell-stage of the 3-D scheme is three such steps."""
+    import ctypes as C
+    from athenapk_amd import lib as L
+    lib = L.load(False)
+    ms, n = C.c_double(0.0), C.c_longlong(0)
+    rc = lib.apk_bench_scheme_floor(steps, reps, C.byref(ms), C.byref(n))
+    if rc != L.APK_OK:
+        return {"error": "apk_bench_scheme_floor: %d" % rc}
+    per_step_ns = ms.value * 1e6 / n.value          # ns per lane-step with the whole device busy
+    floor_ms = 3.0 * cells * per_step_ns * 1e-6
+    return {"what": "9 PPM reconstructions + 1 HLLD solve per sweep step, nothing else, two waves per SIMD (csrc/bench_floor.hip); "
+                    "floor_ms_per_stage = 3 steps per cell x the cells of the stage benchmark",
+            "lane_steps_per_s": n.value / (ms.value * 1e-3), "floor_ms_per_stage": floor_ms,
+            "frac_of_scheme_floor": floor_ms / stage_ms,
+            "north_star_40pct_ms_per_stage": 288.0 * cells / (0.40 * HBM_PEAK_GBS * 1e9) * 1e3}
+
+
 def general_stage_bench(recon="ppm", riemann="hlld", nb=8, n=128, reps=5):
     """SURVEY 8(d) "synthetic kernel benchmark (north_star target)": one pack of nb random-smooth
     128^3 GLM-MHD blocks, the GENERAL RK stage (gam0 = gam1 = 1/2: u0 is read as well, 288 B per
@@ -230,7 +251,11 @@ def general_stage_bench(recon="ppm", riemann="hlld", nb=8, n=128, reps=5):
     ms = e0.elapsed_time(e1) / reps
     cells = nb * n ** 3
     gbs = 288.0 * cells / (ms * 1e-3) / 1e9
-    return {"description": "one pack of %d smooth %d^3 GLM-MHD blocks, %s+%s general stage (gam0 = gam1 = 1/2), "
+    floor = None
+    if recon == "ppm" and riemann == "hlld":
+        floor = scheme_floor(cells, ms)
+    return {"scheme_floor": floor,
+            "description": "one pack of %d smooth %d^3 GLM-MHD blocks, %s+%s general stage (gam0 = gam1 = 1/2), "
                            "288 B per cell-stage (SURVEY 8(d))" % (nb, n, recon.upper(), riemann.upper()),
             "ms_per_stage": ms, "cell_stage_updates_per_s": cells / (ms * 1e-3), "achieved": gbs, "unit": "GB/s",
             "frac": gbs / HBM_PEAK_GBS, "frac_of_measured_copy_bandwidth": gbs / HBM_COPY_GBS}

@@ -114,6 +114,11 @@ const char *apk_last_error(const apk_ctx *ctx);
 int apk_version(void);
 /* 1 if this library was built with -ffp-contract=off (bit-parity build), else 0 */
 int apk_fp_strict(void);
+/* Measurement aid of bench.py (no counterpart in the reference): the issue floor of the GLM-MHD PPM + HLLD scheme on this
+ * device -- `steps` sweep steps (nine PPM reconstructions + one HLLD solve per lane, nothing else: no global memory, no
+ * limiter block entered) in every lane of two waves per SIMD, `reps` launches timed with events on the null stream.
+ * A cell-stage of the 3-D scheme is three such steps per cell. */
+int apk_bench_scheme_floor(int steps, int reps, double *ms_per_launch, long long *lane_steps_per_launch);
 
 /* Uploads the descriptors (tiny H2D copy, synchronous).  Rebuild after remeshing, like
  * Parthenon rebuilds its packs. */
