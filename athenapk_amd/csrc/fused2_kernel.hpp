@@ -94,13 +94,14 @@ constexpr bool m12f_keeps_raw_rows() {
 // where every other lane adds the wave-uniform n * sn + row * st to its pointer -- and lanes that retire a cell within
 // `send_depth` of a face with a send segment store it a second time, into the segment.  A template parameter: the
 // per-lane stride is a register pair the marches without it do not carry.
-template <int FLUID, int RECON, int RS, int EXTRA, bool LEAN, bool FC = false, bool X1H = false>
+template <int FLUID, int RECON, int RS, int EXTRA, int LEAN, bool FC = false, bool X1H = false>
 __global__ void __launch_bounds__(64, 2)
 fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves, int per_xcd,
                   long long total_rows) {
   static_assert(RECON != APK_RC_DC, "donor-cell stages have their own single-kernel form");
   static_assert(!FC || LEAN, "prim_from_cons: lean form only");
-  static_assert(!X1H || (LEAN && !FC), "x1_halo: the lean form that reads stored primitives");
+  static_assert(!X1H || (LEAN == 1 && !FC), "x1_halo: the lean form that reads stored primitives");
+  static_assert(LEAN != LEAN_PFLOOR || (!FC && EXTRA != EXTRA_NONE), "the lean form with a pressure floor / trial count: stages with FillDerived from stored primitives");
   constexpr int NV = nvars<FLUID>();
   constexpr int H = recon_halfwidth(RECON);
   constexpr int NS = 2 * H;
@@ -661,18 +662,24 @@ inline void launch_m12f(const PackView &u0, const PackView &u1, const StageParam
     const long long total_rows = (long long)u0.nblocks * wpb * u0.nx2;
     // as many waves as the device holds, but no ranges shorter than ~16 rows
     long long nw = resident_march_waves();
-    if (total_rows / 16 < nw) nw = total_rows / 16 > 0 ? total_rows / 16 : 1;
+    // (columns of 32 rows and more are cut down to 10-row ranges before waves are left out: Orszag-Tang 512 x 512 x 4 in
+    // 128 x 128 x 4 blocks, 20480 wave-rows -- 1280 waves of 16 rows 0.215 ms, 2048 of 10 rows 0.163 ms, no further gain
+    // below; the 16-row columns of a refined mesh's 16^3 blocks stay whole: cut in two they run 2 % slower)
+    const int minrows = u0.nx2 >= 32 ? 10 : 16;
+    if (total_rows / minrows < nw) nw = total_rows / minrows > 0 ? total_rows / minrows : 1;
     const int nwaves = (int)nw;
     const int per_xcd = (nwaves + 7) / 8;
     const dim3 g((unsigned)(per_xcd * 8), 1, 1);
-    const bool lean = stage_is_lean(sp);
+    const int lean_level = stage_lean_level(sp);
+    const bool lean = lean_level == 1;
+    const bool lean2 = lean_level == LEAN_PFLOOR && extra != EXTRA_NONE && !sp.prim_from_cons && !sp.x1_blocks;
 #define APK_LAUNCH_M12F(EXTRA_, LEAN_) \
   hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, LEAN_>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows)
     constexpr int lds_fc = m12f_keeps_raw_rows<FLUID, RECON>() ? 2 * lds : lds;  // (the rows as loaded, too)
 #define APK_LAUNCH_M12F_FC(EXTRA_) \
-  hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, true, true>), g, dim3(64), lds_fc, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows)
+  hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, 1, true>), g, dim3(64), lds_fc, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows)
 #define APK_LAUNCH_M12F_X1H(EXTRA_) \
-  hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, true, false, true>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows)
+  hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, 1, false, true>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows)
     if (sp.x1_blocks) {  // (the lean form that reads stored primitives: launch_fused_stage has checked)
       if (extra == EXTRA_C2P_DT) APK_LAUNCH_M12F_X1H(EXTRA_C2P_DT);
       else if (extra == EXTRA_C2P) APK_LAUNCH_M12F_X1H(EXTRA_C2P);
@@ -682,14 +689,16 @@ inline void launch_m12f(const PackView &u0, const PackView &u1, const StageParam
       else if (extra == EXTRA_C2P) APK_LAUNCH_M12F_FC(EXTRA_C2P);
       else APK_LAUNCH_M12F_FC(EXTRA_NONE);
     } else if (extra == EXTRA_C2P_DT) {
-      if (lean) APK_LAUNCH_M12F(EXTRA_C2P_DT, true);
-      else APK_LAUNCH_M12F(EXTRA_C2P_DT, false);
+      if (lean) APK_LAUNCH_M12F(EXTRA_C2P_DT, 1);
+      else if (lean2) APK_LAUNCH_M12F(EXTRA_C2P_DT, LEAN_PFLOOR);
+      else APK_LAUNCH_M12F(EXTRA_C2P_DT, 0);
     } else if (extra == EXTRA_C2P) {
-      if (lean) APK_LAUNCH_M12F(EXTRA_C2P, true);
-      else APK_LAUNCH_M12F(EXTRA_C2P, false);
+      if (lean) APK_LAUNCH_M12F(EXTRA_C2P, 1);
+      else if (lean2) APK_LAUNCH_M12F(EXTRA_C2P, LEAN_PFLOOR);
+      else APK_LAUNCH_M12F(EXTRA_C2P, 0);
     } else {
-      if (lean) APK_LAUNCH_M12F(EXTRA_NONE, true);
-      else APK_LAUNCH_M12F(EXTRA_NONE, false);
+      if (lean) APK_LAUNCH_M12F(EXTRA_NONE, 1);
+      else APK_LAUNCH_M12F(EXTRA_NONE, 0);
     }
 #undef APK_LAUNCH_M12F
 #undef APK_LAUNCH_M12F_FC

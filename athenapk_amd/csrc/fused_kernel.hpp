@@ -261,11 +261,17 @@ APK_DEV void store_vars(double *arr, int64_t sn, const RowCellAt &a, const doubl
 inline bool stage_is_lean(const StageParams &sp) {
   return sp.mflux == nullptr && sp.bad_count == nullptr && sp.dedner != 2 && eos_is_lean(sp.eos);
 }
+// 1: lean; LEAN_PFLOOR (2): lean but for a pressure floor and / or the trial count of first-order flux correction -- the
+// Orszag-Tang deck has both -- whose few instructions the forms <.., LEAN = 2> compile in; 0: the general form
+inline int stage_lean_level(const StageParams &sp) {
+  if (stage_is_lean(sp)) return 1;
+  return (sp.mflux == nullptr && sp.dedner != 2 && eos_is_lean_but_pfloor(sp.eos)) ? LEAN_PFLOOR : 0;
+}
 // -beta_dt / V of a block (product build; the parity build divides by V per cell as the reference does)
 APK_DEV double update_coefficient(const StageParams &sp, double vol) { return to_sgpr(-sp.beta_dt / vol); }
 
 // (HELD: old_held is the old u0 of this cell, already in registers -- the from-cons finishing march keeps the rows it loaded)
-template <int FLUID, int EXTRA, bool LEAN, bool HELD, class AT, bool XV = true>
+template <int FLUID, int EXTRA, int LEAN, bool HELD, class AT, bool XV = true>
 APK_DEV void finish_cell_impl(const PackView &pv, const apk_block_desc &b0,
                               const double (&u1v)[nvars<FLUID>()], const AT &at,
                               const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp,
@@ -332,7 +338,7 @@ APK_DEV void finish_cell_impl(const PackView &pv, const apk_block_desc &b0,
   // (hydro.cpp:1297-1306: rho <= 0 or E - KE [- ME] <= 0, on the update BEFORE any floor) applied to
   // the very `un` this kernel computed.
   bool bad = false;
-  if constexpr (!LEAN) {
+  if constexpr (LEAN != 1) {  // (the general form and the lean form with the trial count / the pressure floor)
   if (sp.bad_count) {
     double new_p = un[IEN] - 0.5 * (sqr(un[IM1]) + sqr(un[IM2]) + sqr(un[IM3])) / un[IDN];
     if constexpr (FLUID == APK_FLUID_GLMMHD) new_p -= 0.5 * (sqr(un[IB1]) + sqr(un[IB2]) + sqr(un[IB3]));
@@ -350,7 +356,7 @@ APK_DEV void finish_cell_impl(const PackView &pv, const apk_block_desc &b0,
     if (fl) atomicOr(sp.flags, fl);
     // (ConsToPrim forms the pressure with 1/rho where the test above divides: a trial stage is
     // only accepted if neither sees a negative state, so an accepted stage never raises flags)
-    if constexpr (!LEAN) {
+    if constexpr (LEAN != 1) {
       if (sp.bad_count && fl) bad = true;
     }
     if (prim_dst) {  // (wave-uniform; NULL: fill_derived = 3, the primitives only feed the time-step estimate)
@@ -364,26 +370,26 @@ APK_DEV void finish_cell_impl(const PackView &pv, const apk_block_desc &b0,
   }
   if (store_cons) store_vars<NV>(b0.cons + sp.out_delta, pv.sn, at, un);
   if (xs && sp.x1_send_field == 0) x1_store_row<NV, XV>(*xs, xrow, un);  // (apk_stage_args.x1_halo: the updated conserved state)
-  if constexpr (!LEAN) {
+  if constexpr (LEAN != 1) {
     if (bad) atomicAdd(sp.bad_count, 1ull);
   }
 }
 
-template <int FLUID, int EXTRA = EXTRA_NONE, bool LEAN = false>
+template <int FLUID, int EXTRA = EXTRA_NONE, int LEAN = 0>
 APK_DEV void finish_cell(const PackView &pv, const apk_block_desc &b0, const double (&u1v)[nvars<FLUID>()], int64_t cell,
                          const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp, double &lane_min_dt,
                          double *prim_dst = nullptr, double upd = 0.0, bool store_cons = true, X1Store *xs = nullptr, int xrow = 0) {
   const double none[nvars<FLUID>()] = {};
   finish_cell_impl<FLUID, EXTRA, LEAN, false, CellAt, false>(pv, b0, u1v, CellAt{cell}, du, vol, sp, lane_min_dt, prim_dst, upd, store_cons, none, xs, xrow);
 }
-template <int FLUID, int EXTRA, bool LEAN, class AT>
+template <int FLUID, int EXTRA, int LEAN, class AT>
 APK_DEV void finish_cell_at(const PackView &pv, const apk_block_desc &b0, const double (&u1v)[nvars<FLUID>()], const AT &at,
                             const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp, double &lane_min_dt,
                             double *prim_dst, double upd, X1Store *xs = nullptr, int xrow = 0) {
   const double none[nvars<FLUID>()] = {};
   finish_cell_impl<FLUID, EXTRA, LEAN, false>(pv, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd, true, none, xs, xrow);
 }
-template <int FLUID, int EXTRA, bool LEAN, class AT>
+template <int FLUID, int EXTRA, int LEAN, class AT>
 APK_DEV void finish_cell_old_held(const PackView &pv, const apk_block_desc &b0, const double (&u1v)[nvars<FLUID>()], const AT &at,
                                   const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp, double &lane_min_dt,
                                   double *prim_dst, double upd, const double (&old_held)[nvars<FLUID>()]) {
@@ -985,7 +991,7 @@ APK_DEV void load_input_state(const double *p, int64_t sn, const StageParams &sp
   }
 }
 
-template <int FLUID, int RS, int EXTRA = EXTRA_NONE, bool LEAN = false, bool FROM_CONS = false>
+template <int FLUID, int RS, int EXTRA = EXTRA_NONE, int LEAN = 0, bool FROM_CONS = false>
 __global__ void __launch_bounds__(64, 2)
 fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, int nseg, int per_xcd) {
   constexpr int NV = nvars<FLUID>();
@@ -1250,9 +1256,10 @@ fused_dc3_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, in
 // X1H (apk_stage_args.x1_halo): the lanes on the two ghost columns read their cells from the receive segment of that face
 // -- strides of their own between variables, rows and planes -- and the lanes within `send_depth` columns of a face with
 // a send segment store what they retire a second time, into the segment (see fused_m12f_kernel).
-template <int FLUID, int RS, int EXTRA, bool FROM_CONS = false, bool X1H = false>
+template <int FLUID, int RS, int EXTRA, bool FROM_CONS = false, bool X1H = false, int LEAN = 1>
 __global__ void __launch_bounds__(64, 2)
 fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, int nseg, int per_xcd) {
+  static_assert(LEAN == 1 || (LEAN == LEAN_PFLOOR && !FROM_CONS && !X1H && EXTRA != EXTRA_NONE), "lean forms");
   constexpr int NV = nvars<FLUID>();
   double lane_min_dt = 1.7976931348623157e308;
   const int lane = threadIdx.x;
@@ -1437,10 +1444,10 @@ fused_dc3r2_kernel(PackView u0, PackView u1, StageParams sp, int kseg, int wpb, 
           if (active) {
             X1Store xr = xs;
             if (r == 1 && xr.seg) xr.seg += sp.x1_send_depth;
-            finish_cell<FLUID, EXTRA, true>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd, store, &xr, c - 1 - u0.ks);
+            finish_cell<FLUID, EXTRA, LEAN>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd, store, &xr, c - 1 - u0.ks);
           }
         } else {
-          if (active) finish_cell<FLUID, EXTRA, true>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd, store);
+          if (active) finish_cell<FLUID, EXTRA, LEAN>(u0, b0, u1v, done, du, vol, sp, lane_min_dt, prim_dst, upd, store);
         }
       }
       if (r < HOLD) {  // (plane c of this cell, for the next iteration)
@@ -1675,9 +1682,12 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
         // whole donor-cell stage in one march (see fused_dc3_kernel); its FillDerived is out of place
         const int64_t run3 = sp.window ? (int64_t)sp.window_rows * sp.window_rl : (int64_t)u0.nx2 * (u0.nx1 + 2);
         const int wpb = (int)((run3 + 61) / 62);
-        const bool lean = stage_is_lean(sp);
+        const int lean_level = stage_lean_level(sp);
+        const bool lean = lean_level == 1;
+        // (the lean form with a pressure floor / the trial count: the two-row march with FillDerived from stored primitives)
+        const bool lean2 = lean_level == LEAN_PFLOOR && extra != EXTRA_NONE && !sp.prim_from_cons && !sp.x1_blocks;
         // two rows per lane (fused_dc3r2_kernel): whole blocks only -- a split stage's windows keep the one-row kernel
-        const bool two_rows = lean && !sp.window && u0.nx2 % 2 == 0 && u0.nx2 >= 4;
+        const bool two_rows = (lean || lean2) && !sp.window && u0.nx2 % 2 == 0 && u0.nx2 >= 4;
         const int wpb2 = (int)(((int64_t)(u0.nx2 / 2) * (u0.nx1 + 2) + 61) / 62);
         const int wpb_run = two_rows ? wpb2 : wpb;  // wave columns per block of the kernel that will run
         // measured on 8 x 128^3 (round 5, two-row march from the conserved state, ms per cycle of the headline, same box):
@@ -1717,7 +1727,10 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
   hipLaunchKernelGGL((fused_dc3r2_kernel<FLUID, RS, EXTRA_, FC_>), g2, dim3(64), lds4, s, u0, u1, sp, kseg, wpb2, nseg, per_xcd2)
 #define APK_LAUNCH_DC3R2_X1H(EXTRA_, FC_) \
   hipLaunchKernelGGL((fused_dc3r2_kernel<FLUID, RS, EXTRA_, FC_, true>), g2, dim3(64), lds4, s, u0, u1, sp, kseg, wpb2, nseg, per_xcd2)
-          if (sp.x1_blocks) {  // (apk_stage_args.x1_halo: stages without the dt estimate -- the predictor's place in a cycle)
+          if (lean2) {
+            if (extra == EXTRA_C2P_DT) hipLaunchKernelGGL((fused_dc3r2_kernel<FLUID, RS, EXTRA_C2P_DT, false, false, LEAN_PFLOOR>), g2, dim3(64), lds4, s, u0, u1, sp, kseg, wpb2, nseg, per_xcd2);
+            else hipLaunchKernelGGL((fused_dc3r2_kernel<FLUID, RS, EXTRA_C2P, false, false, LEAN_PFLOOR>), g2, dim3(64), lds4, s, u0, u1, sp, kseg, wpb2, nseg, per_xcd2);
+          } else if (sp.x1_blocks) {  // (apk_stage_args.x1_halo: stages without the dt estimate -- the predictor's place in a cycle)
             if (extra == EXTRA_C2P_DT) return APK_ERR_UNSUPPORTED;
             if (extra == EXTRA_C2P) {
               if (sp.prim_from_cons) APK_LAUNCH_DC3R2_X1H(EXTRA_C2P, true);
@@ -1743,7 +1756,7 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
         if (sp.x1_blocks) return APK_ERR_UNSUPPORTED;  // (x1_halo: the two-row march only)
         if (sp.prim_from_cons) {  // (one row per lane: odd row counts, the windows of a split stage)
 #define APK_LAUNCH_DC3FC(EXTRA_) \
-  hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_, true, true>), g, dim3(64), lds3, s, u0, u1, sp, kseg, wpb, nseg, per_xcd)
+  hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_, 1, true>), g, dim3(64), lds3, s, u0, u1, sp, kseg, wpb, nseg, per_xcd)
           if (extra == EXTRA_C2P_DT) APK_LAUNCH_DC3FC(EXTRA_C2P_DT);
           else if (extra == EXTRA_C2P) APK_LAUNCH_DC3FC(EXTRA_C2P);
           else APK_LAUNCH_DC3FC(EXTRA_NONE);
@@ -1752,15 +1765,20 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
         }
 #define APK_LAUNCH_DC3(EXTRA_, LEAN_) \
   hipLaunchKernelGGL((fused_dc3_kernel<FLUID, RS, EXTRA_, LEAN_>), g, dim3(64), lds3, s, u0, u1, sp, kseg, wpb, nseg, per_xcd)
+        // (the windows of a split stage and odd row counts take the one-row march in the SAME lean form the whole stage
+        // takes as the two-row march: the product build's update expression is the form's, and a split stage must
+        // reproduce the whole one bit for bit)
         if (extra == EXTRA_C2P_DT) {
-          if (lean) APK_LAUNCH_DC3(EXTRA_C2P_DT, true);
-          else APK_LAUNCH_DC3(EXTRA_C2P_DT, false);
+          if (lean) APK_LAUNCH_DC3(EXTRA_C2P_DT, 1);
+          else if (lean2) APK_LAUNCH_DC3(EXTRA_C2P_DT, LEAN_PFLOOR);
+          else APK_LAUNCH_DC3(EXTRA_C2P_DT, 0);
         } else if (extra == EXTRA_C2P) {
-          if (lean) APK_LAUNCH_DC3(EXTRA_C2P, true);
-          else APK_LAUNCH_DC3(EXTRA_C2P, false);
+          if (lean) APK_LAUNCH_DC3(EXTRA_C2P, 1);
+          else if (lean2) APK_LAUNCH_DC3(EXTRA_C2P, LEAN_PFLOOR);
+          else APK_LAUNCH_DC3(EXTRA_C2P, 0);
         } else {
-          if (lean) APK_LAUNCH_DC3(EXTRA_NONE, true);
-          else APK_LAUNCH_DC3(EXTRA_NONE, false);
+          if (lean) APK_LAUNCH_DC3(EXTRA_NONE, 1);
+          else APK_LAUNCH_DC3(EXTRA_NONE, 0);
         }
 #undef APK_LAUNCH_DC3
         if (sp.mflux && sp.phase == 0) launch_scalar_update<RECON>(u0, u1, sp, extra, s);

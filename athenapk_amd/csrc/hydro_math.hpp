@@ -1149,15 +1149,21 @@ constexpr int perm(int slot) {
 // cons -> prim for one cell (src/eos/adiabatic_hydro.hpp:52-142, adiabatic_glmmhd.hpp:62-167)
 // u/w hold the NH hydro/MHD variables; returns APK_FLAG_* bits.  u may be modified.
 // ======================================================================================
-// LEAN: the caller guarantees eos.vceil = eos.eceil = +inf and eos.pfloor <= 0 (eos_is_lean: the defaults of
+// LEAN = 1: the caller guarantees eos.vceil = eos.eceil = +inf and eos.pfloor <= 0 (eos_is_lean: the defaults of
 // hydro.cpp:507-537, no velocity ceiling, no pressure floor, no internal-energy ceiling), so the three blocks those
 // parameters guard can never act and are not compiled: same results, no registers for their constants, and `u` is
 // only ever modified by the density floor and the internal-energy floor.
-template <int FLUID, bool LEAN = false>
+// LEAN = 2: the same with the pressure floor's block compiled (eos_is_lean_but_pfloor: inputs/orszag_tang.in sets one).
+// LEAN = 0: everything.
+constexpr int LEAN_PFLOOR = 2;
+template <int FLUID, int LEAN = 0>
 APK_DEV unsigned cons_to_prim_core(const apk_eos &eos, double gm1, double vceil_sq, double pfloor_over_gm1,
                                    double (&u)[nvars<FLUID>()], double (&w)[nvars<FLUID>()], double &di_out);
 inline __host__ __device__ bool eos_is_lean(const apk_eos &eos) {
   return eos.vceil == __builtin_inf() && eos.eceil == __builtin_inf() && eos.pfloor <= 0.0;
+}
+inline __host__ __device__ bool eos_is_lean_but_pfloor(const apk_eos &eos) {
+  return eos.vceil == __builtin_inf() && eos.eceil == __builtin_inf();
 }
 template <int FLUID>
 APK_DEV unsigned cons_to_prim_cell(const apk_eos &eos, double (&u)[nvars<FLUID>()],
@@ -1166,12 +1172,12 @@ APK_DEV unsigned cons_to_prim_cell(const apk_eos &eos, double (&u)[nvars<FLUID>(
   return cons_to_prim_core<FLUID>(eos, gm1, sqr(eos.vceil), eos.pfloor / gm1, u, w, di_out);
 }
 // with the stage's constants from the host (StageConsts)
-template <int FLUID, bool LEAN = false>
+template <int FLUID, int LEAN = 0>
 APK_DEV unsigned cons_to_prim_cell(const apk_eos &eos, const StageConsts &k, double (&u)[nvars<FLUID>()],
                                    double (&w)[nvars<FLUID>()], double &di_out) {
   return cons_to_prim_core<FLUID, LEAN>(eos, k.eos_gm1, k.vceil_sq, k.pfloor_over_gm1, u, w, di_out);
 }
-template <int FLUID, bool LEAN>
+template <int FLUID, int LEAN>
 APK_DEV unsigned cons_to_prim_core(const apk_eos &eos, double gm1, double vceil_sq, double pfloor_over_gm1,
                                    double (&u)[nvars<FLUID>()], double (&w)[nvars<FLUID>()], double &di_out) {
   constexpr bool mhd = (FLUID == APK_FLUID_GLMMHD);
@@ -1215,7 +1221,7 @@ APK_DEV unsigned cons_to_prim_core(const apk_eos &eos, double gm1, double vceil_
     e_k = e_k_new;
   }
   }
-  if constexpr (LEAN) {
+  if constexpr (LEAN == 1) {
     if (!(strictly_positive(w[IPR]) || eos.efloor > 0.0)) flags |= APK_FLAG_NEG_PRESSURE;
   } else {
     if (!(strictly_positive(w[IPR]) || eos.pfloor > 0.0 || eos.efloor > 0.0)) flags |= APK_FLAG_NEG_PRESSURE;

@@ -918,7 +918,13 @@ def test_donor_cell_stage_split_around_exchange(request, oracle, fluid, riemann,
         t = torch.tensor(win, dtype=torch.int32, device="cuda")
         hydro.StageFused(m0, m1, fluid, "dc", riemann, eos, C_H, 0.0, 1.0, 0.004, phase=1, window=t, **kw)
     hydro.StageFused(m0, m1, fluid, "dc", riemann, eos, C_H, 0.0, 1.0, 0.004, phase=2, **kw)   # no-op
-    assert np.array_equal(m0.cons_host(), r0.cons_host()) and np.array_equal(m1.prim_host(), r1.prim_host())
+    # (the whole stage runs two rows per lane, the windows one: the same operations in the parity build; the product
+    # build contracts each kernel's expressions its own way -- last-bit differences)
+    if strict:
+        assert np.array_equal(m0.cons_host(), r0.cons_host()) and np.array_equal(m1.prim_host(), r1.prim_host())
+    else:
+        np.testing.assert_allclose(m0.cons_host(), r0.cons_host(), rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(m1.prim_host(), r1.prim_host(), rtol=1e-12, atol=1e-14)
     want = H.orc_stage(fluid, "dc", riemann, g, cons, cons, prim, GAMMA, C_H, 0.0, 1.0, 0.004, dedner=ded, alpha=0.1,
                        mindx=0.07)
     _cmp(H.interior(m0.cons_host(), nx, ng), H.interior(want, nx, ng), strict, "cons")
