@@ -42,7 +42,7 @@ def main():
         # budget, and LDS_Block_Size its static LDS only -- the marches allocate their rings dynamically: the registers,
         # spills and LDS of every kernel are in profiles/rNN_kernel_resources.txt, from the compiler's own remarks)
         rec = {"calls": a["calls"], "avg_us": a["ns"] / a["calls"] / 1e3, "scratch_bytes_per_lane": a["scratch_bytes_per_lane"],
-               "resources": "profiles/r05_kernel_resources.txt"}
+               "resources": "profiles/r06_kernel_resources.txt"}
         c = {k: v / a["calls"] for k, v in a["ctr"].items()}
         rec.update(c)
         if "SQ_INSTS_VALU" in c and c.get("SQ_WAVES"):
