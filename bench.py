@@ -13,7 +13,11 @@ between bricks travel as one RCCL send/recv per peer per stage (torch.distribute
          --master-port P bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline     : algorithmic bytes of one fused stage / live HIP-event time of its kernels
+  value        : the median of three timed regions of --steps cycles each (no event records inside)
+  roofline     : algorithmic bytes of one fused stage / live HIP-event time of its kernels (a fourth region of the same
+                 cycles with the library's event timing on), priced against HBM; `bound` names what binds the kernels;
+                 general_stage.scheme_floor: the issue floor of the scheme's own arithmetic on this device
+  rehearsal_8gpu_rank : one rank of the 2 x 2 x 2 run on this GPU (loopback transport), against the N = 1 brick timed beside it
   cpu_baseline : the CPU oracle (-O3 -march=native, OpenMP) on a bounded sample of the same
                  workload on this box's host cores -- a reported baseline, not the target.
 """
