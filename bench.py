@@ -848,6 +848,10 @@ def main():
                 "traffic": traffic_gb,
                 "traffic_unit": "GB per fused-stage launch (algorithmic: %.2f GB)" % (b_stage * zones_local / 1e9),
                 "traffic_source": traffic_src,
+                "traffic_note": "of the 8.85 GB: 2.4 GB are the x3 sweep's flux differences written and read back (the two-kernel stage's "
+                                "own 144 B per cell on top of the 216 algorithmic ones), the line-aligned rows of round 6 fetch nine lines "
+                                "per 128-cell row where natural rows average 8.4 (+0.9 GB against profiles/r05_hbm_traffic.json, for "
+                                "-1.3 % time: profiles/r06_row_pitch_ab.txt); the kernels are bound by vector issue, not by these bytes",
                 "algorithmic_bytes_per_cell_stage": b_stage,
                 "cells_per_launch": zones_local,
                 "stage_ms": stage_ms,
