@@ -225,18 +225,10 @@ class Simulation(_FmftHost, _MeshView):
                 red_group = dist.new_group(backend="gloo")
         self._red_group = red_group
 
-        skews = {}  # development aid (tools/skew_probe.py): APK_ALLOC_SKEW="cons:4096,prim:8192,..." bytes added to a field's base
-        for item in filter(None, os.environ.get("APK_ALLOC_SKEW", "").split(",")):
-            k, v = item.split(":")
-            skews[k] = int(v)
-
         def _alloc(user, tag, nbytes):
-            skew = skews.get(tag.decode(), 0)
-            t = torch.empty((nbytes + (1 << 25 if skews else 0) + 7) // 8, dtype=torch.float64, device=dev)[skew // 8:]
+            t = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=dev)
             self._tensors[t.data_ptr()] = t
             self._by_tag[tag.decode()] = t
-            if os.environ.get("APK_PRINT_ALLOC") == "1":  # development aid: where the fields landed
-                print("[alloc] %-20s %#016x  %12d bytes" % (tag.decode(), t.data_ptr(), nbytes), flush=True)
             return t.data_ptr()
 
         def _release(user, ptr):
