@@ -337,9 +337,12 @@ inline void launch_s3(const PackView &u0, const PackView &u1, const StageParams 
   if constexpr (single_march_compiled<FLUID, RECON>()) {
     const int64_t run = (int64_t)(u0.nx2 / 2) * (u0.nx1 + 2 * kS3Halo);
     const int wpb = (int)((run + kS3Cells - 1) / kS3Cells);
-    // a segment costs its planes plus two for the prologue (12.5 % at 16): the stage runs at the memory system's rate
+    // a segment costs its planes plus two for the prologue (12.5 % at 16).  Measured on 8 x 128^3 (round 6, same box, ms per
+    // stage): 8 planes 0.742, 12: 0.749, 13: 0.747, **14: 0.705, 15: 0.705**, 16: 0.722, 19: 0.723, 22: 0.737, 24: 0.730,
+    // 32: 0.795, 64: 0.97 -- 15 (nine segments, 10152 waves = 4.96 rounds of the 2048 the device holds) where 16 is
+    // 4.41 rounds with the fifth one mostly empty
     static const int forced_kseg = std::getenv("APK_S3_KSEG") ? std::atoi(std::getenv("APK_S3_KSEG")) : 0;  // A/B switch
-    int kseg = forced_kseg > 0 ? forced_kseg : 16;
+    int kseg = forced_kseg > 0 ? forced_kseg : 15;
     if (kseg > u0.nx3) kseg = u0.nx3;
     const int nseg = (u0.nx3 + kseg - 1) / kseg;
     const int64_t total = (int64_t)wpb * nseg * u0.nblocks;
