@@ -733,6 +733,7 @@ def main():
     timing = sim.read_kernel_timing()
     sim.kernel_timing(False)
     comm_stats = comm_after
+    x1_direct_per_cycle = sim.x1_direct_exchanges() / max(1, sim.ncycle)
     skipped_per_cycle = sim.skipped_local_exchanges() / max(1, sim.ncycle)
     overlapped_per_cycle = sim.overlapped_exchanges / max(1, sim.ncycle)
     # 500 cycles back to back (N = 1): does the rate hold once the clocks have settled under the power cap?
@@ -833,7 +834,9 @@ def main():
                        "reductions_per_cycle": ((comm_stats["reductions"] - comm_before["reductions"]) / (args.steps * len(regions))) if comm_stats else None,
                        "halo_exchanges_per_cycle": ((comm_stats["exchanges"] - comm_before["exchanges"]) / (args.steps * len(regions))) if comm_stats else None,
                        # stage boundaries per cycle whose same-rank ghost copies were skipped (direct neighbour addressing)
-                       "same_rank_ghost_copies_skipped_per_cycle": skipped_per_cycle},
+                       "same_rank_ghost_copies_skipped_per_cycle": skipped_per_cycle,
+                       # exchanges per cycle whose x1 strips bypassed the pack / unpack kernels (apk_stage_args.x1_halo)
+                       "exchanges_with_x1_strips_in_the_buffers_per_cycle": x1_direct_per_cycle if world > 1 else None},
             "cell_stage_updates_per_s": value * nstages,
             "roofline": {
                 # what binds the stage kernels (SQ counters); `achieved` / `peak` / `frac` are priced against HBM bandwidth,

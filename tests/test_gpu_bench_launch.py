@@ -58,6 +58,9 @@ def test_bench_on_two_ranks_through_the_launcher():
     assert c["overlapped_exchanges_per_cycle"] > 0          # the halo messages fly during the next stage's kernels
     assert c["reductions_per_cycle"] == 1.0    # ONE collective per cycle: the time step and the c_h estimate travel together
     assert c["halo_exchanges_per_cycle"] == 2.0  # one per stage
+    # both of them with their x1 strips stored into / read from the message buffers by the stage kernels (warm-up included:
+    # per cycle of the run)
+    assert c["exchanges_with_x1_strips_in_the_buffers_per_cycle"] == 2.0
     assert "cpu_baseline" not in d and "weak_scaling_base_with_ghost_copies" not in d   # N = 1 only
     # value = zones of ALL ranks * steps / max-over-ranks time
     assert abs(d["value"] - 256 * 128 * 128 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
@@ -89,6 +92,7 @@ def test_bench_on_eight_ranks_through_the_launcher():
     c = d["config"]
     assert c["mesh"] == [128, 128, 128] and c["blocks_per_gpu"] == 8 and c["parallelism"].endswith("2x2x2 GPU grid")
     assert c["overlapped_exchanges_per_cycle"] > 0 and c["reductions_per_cycle"] == 1.0 and c["halo_exchanges_per_cycle"] == 2.0
+    assert c["exchanges_with_x1_strips_in_the_buffers_per_cycle"] == 2.0
 
 
 def test_bench_on_one_gpu_reports_the_copy_inclusive_base():
