@@ -371,15 +371,20 @@ int apk_stage_split_axis(const apk_pack *u0, const apk_flux_cfg *cfg, int fill_d
   return apk::two_kernel_stage_applies(u0->view, cfg->recon, extra, sp) ? 3 : 1;
 }
 
-int apk_stage_x1_halo(const apk_pack *u0, const apk_flux_cfg *cfg, const apk_eos *eos, int fill_derived, int dedner) {
+int apk_stage_x1_halo(const apk_pack *u0, const apk_flux_cfg *cfg, const apk_eos *eos, int fill_derived, int dedner, int prim_from_cons) {
   if (!u0 || !cfg || !eos) return 0;
   if (cfg->riemann == APK_RS_NONE || cfg->riemann == APK_RS_LLF || u0->view.nvar != u0->view.nhydro) return 0;
   apk::StageParams sp{};
   sp.eos = *eos;
   sp.dedner = dedner;
   sp.prim_to_u1 = (fill_derived >= 2) ? 1 : 0;
-  const int extra = fill_derived ? apk::EXTRA_C2P : apk::EXTRA_NONE;
-  return apk::x1_halo_stage_ok(u0->view, cfg->recon, extra, sp) ? 1 : 0;
+  sp.no_prim_store = (fill_derived == 3) ? 1 : 0;
+  sp.prim_from_cons = prim_from_cons;
+  sp.out_delta = (prim_from_cons == 2) ? 1 : 0;  // (such a stage writes its result elsewhere: the caller's business)
+  const int extra = fill_derived ? (fill_derived == 3 ? apk::EXTRA_C2P_DT : apk::EXTRA_C2P) : apk::EXTRA_NONE;
+  if (!apk::x1_halo_stage_ok(u0->view, cfg->recon, extra, sp)) return 0;
+  if (cfg->recon != APK_RC_DC && prim_from_cons && apk_stage_single_march(u0, cfg)) return 0;
+  return 1;
 }
 
 int apk_stage_single_march(const apk_pack *u0, const apk_flux_cfg *cfg) {

@@ -100,7 +100,7 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
                   long long total_rows) {
   static_assert(RECON != APK_RC_DC, "donor-cell stages have their own single-kernel form");
   static_assert(!FC || LEAN, "prim_from_cons: lean form only");
-  static_assert(!X1H || (LEAN == 1 && !FC), "x1_halo: the lean form that reads stored primitives");
+  static_assert(!X1H || LEAN == 1, "x1_halo: the lean forms");
   static_assert(LEAN != LEAN_PFLOOR || (!FC && EXTRA != EXTRA_NONE), "the lean form with a pressure floor / trial count: stages with FillDerived from stored primitives");
   constexpr int NV = nvars<FLUID>();
   constexpr int H = recon_halfwidth(RECON);
@@ -533,8 +533,13 @@ fused_m12f_kernel(PackView u0, PackView u1, StageParams sp, int wpb, int nwaves,
               const RowCellAt at{(int64_t)(c - 1) * st, cell_boff};
               if constexpr (RAW) {
                 // (prim_from_cons = 2: the input state is the old u0 the update reads)
-                if (sp.prim_from_cons == 2) finish_cell_old_held<FLUID, EXTRA, LEAN>(u0, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd, rawv);
-                else finish_cell_at<FLUID, EXTRA, LEAN>(u0, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd);
+                if constexpr (X1H) {
+                  if (sp.prim_from_cons == 2) finish_cell_old_held<FLUID, EXTRA, LEAN>(u0, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd, rawv, &xs, c - 1 - u0.js);
+                  else finish_cell_at<FLUID, EXTRA, LEAN>(u0, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd, &xs, c - 1 - u0.js);
+                } else {
+                  if (sp.prim_from_cons == 2) finish_cell_old_held<FLUID, EXTRA, LEAN>(u0, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd, rawv);
+                  else finish_cell_at<FLUID, EXTRA, LEAN>(u0, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd);
+                }
               } else {
                 if constexpr (X1H) finish_cell_at<FLUID, EXTRA, LEAN>(u0, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd, &xs, c - 1 - u0.js);
                 else finish_cell_at<FLUID, EXTRA, LEAN>(u0, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd);
@@ -649,7 +654,9 @@ inline bool x1_halo_stage_ok(const PackView &u0, int recon, int extra, const Sta
   if (sp.x1_send_field == 1 && extra == EXTRA_NONE) return false;  // (primitives to send: a stage that computes them)
   if (recon == APK_RC_DC)  // the two-row march, which has no form with the time-step estimate for it
     return sp.phase == 0 && (extra == EXTRA_NONE || (sp.prim_to_u1 && extra == EXTRA_C2P)) && u0.nx2 % 2 == 0 && u0.nx2 >= 4;
-  return two_kernel_stage_applies(u0, recon, extra, sp) && !sp.prim_from_cons;
+  // (from stored primitives or from a conserved state -- but not the stages that take the single march, fused3_kernel.hpp:
+  // launch_fused_stage asks single_march_stage_applies for those and refuses)
+  return two_kernel_stage_applies(u0, recon, extra, sp);
 }
 
 template <int FLUID, int RECON, int RS>
@@ -680,7 +687,13 @@ inline void launch_m12f(const PackView &u0, const PackView &u1, const StageParam
   hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, 1, true>), g, dim3(64), lds_fc, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows)
 #define APK_LAUNCH_M12F_X1H(EXTRA_) \
   hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, 1, false, true>), g, dim3(64), lds, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows)
-    if (sp.x1_blocks) {  // (the lean form that reads stored primitives: launch_fused_stage has checked)
+#define APK_LAUNCH_M12F_FC_X1H(EXTRA_) \
+  hipLaunchKernelGGL((fused_m12f_kernel<FLUID, RECON, RS, EXTRA_, 1, true, true>), g, dim3(64), lds_fc, s, u0, u1, sp, wpb, nwaves, per_xcd, total_rows)
+    if (sp.x1_blocks && sp.prim_from_cons) {  // (the lean forms: launch_fused_stage has checked)
+      if (extra == EXTRA_C2P_DT) APK_LAUNCH_M12F_FC_X1H(EXTRA_C2P_DT);
+      else if (extra == EXTRA_C2P) APK_LAUNCH_M12F_FC_X1H(EXTRA_C2P);
+      else APK_LAUNCH_M12F_FC_X1H(EXTRA_NONE);
+    } else if (sp.x1_blocks) {
       if (extra == EXTRA_C2P_DT) APK_LAUNCH_M12F_X1H(EXTRA_C2P_DT);
       else if (extra == EXTRA_C2P) APK_LAUNCH_M12F_X1H(EXTRA_C2P);
       else APK_LAUNCH_M12F_X1H(EXTRA_NONE);
@@ -703,6 +716,7 @@ inline void launch_m12f(const PackView &u0, const PackView &u1, const StageParam
 #undef APK_LAUNCH_M12F
 #undef APK_LAUNCH_M12F_FC
 #undef APK_LAUNCH_M12F_X1H
+#undef APK_LAUNCH_M12F_FC_X1H
 #if APK_M12F_TIMING
     {
       static int calls = 0;

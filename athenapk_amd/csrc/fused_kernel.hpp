@@ -392,9 +392,9 @@ APK_DEV void finish_cell_at(const PackView &pv, const apk_block_desc &b0, const 
 template <int FLUID, int EXTRA, int LEAN, class AT>
 APK_DEV void finish_cell_old_held(const PackView &pv, const apk_block_desc &b0, const double (&u1v)[nvars<FLUID>()], const AT &at,
                                   const double (&du)[nvars<FLUID>()], double vol, const StageParams &sp, double &lane_min_dt,
-                                  double *prim_dst, double upd, const double (&old_held)[nvars<FLUID>()]) {
+                                  double *prim_dst, double upd, const double (&old_held)[nvars<FLUID>()], X1Store *xs = nullptr, int xrow = 0) {
   static_assert(LEAN, "lean form only");
-  finish_cell_impl<FLUID, EXTRA, LEAN, true>(pv, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd, true, old_held);
+  finish_cell_impl<FLUID, EXTRA, LEAN, true>(pv, b0, u1v, at, du, vol, sp, lane_min_dt, prim_dst, upd, true, old_held, xs, xrow);
 }
 
 // ==============================================================================================
@@ -1659,7 +1659,9 @@ inline int launch_fused_stage(const PackView &u0, const PackView &u1, const Stag
   }
   // apk_stage_args.x1_halo: the lean two-row donor-cell march and the lean two-kernel stage's finishing march (phase 1 of
   // a split two-kernel stage is the x3 sweep, which reads no x1 ghost column and retires nothing: it ignores the table)
-  if (sp.x1_blocks && !(RECON != APK_RC_DC && sp.phase == 1) && !x1_halo_stage_ok(u0, RECON, extra, sp)) return APK_ERR_UNSUPPORTED;
+  if (sp.x1_blocks && !(RECON != APK_RC_DC && sp.phase == 1) &&
+      (!x1_halo_stage_ok(u0, RECON, extra, sp) || (RECON != APK_RC_DC && single_march_stage_applies<FLUID, RECON>(u0, extra, sp))))
+    return APK_ERR_UNSUPPORTED;
   if (sp.no_prim_store && !(u0.ndim == 3 && RECON != APK_RC_DC && stage_is_lean(sp) && two_kernel_stage_applies(u0, RECON, extra, sp)))
     return APK_ERR_UNSUPPORTED;
   if (sp.prim_from_cons) {

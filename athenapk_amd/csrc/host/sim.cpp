@@ -432,8 +432,7 @@ int exchange_begin(apk_sim *s, bool async, int c2p, bool skip_local, bool thin) 
       s->xchg_prim = s->pcur;
       SIM_TRY(s, apk_copy_plan_run(s->ctx, s->pplans_of[s->pcur][nox1 ? PH_PACK_NOX1 : PH_PACK], s->stream));
     } else {
-      if (nox1 && !thin) return fail(s, APK_ERR_INVALID, "exchange_begin: x1 strips of the conserved state are one layer deep");
-      SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(thin ? (nox1 ? PH_PACK_THIN_NOX1 : PH_PACK_THIN) : PH_PACK), s->stream));
+      SIM_TRY(s, apk_copy_plan_run(s->ctx, s->plan(thin ? (nox1 ? PH_PACK_THIN_NOX1 : PH_PACK_THIN) : (nox1 ? PH_PACK_NOX1 : PH_PACK)), s->stream));
     }
   } else if (c2p == GHOST_PRIM_COPY) {
     s->xchg_prim = s->pcur;
@@ -645,26 +644,43 @@ bool thin_exchange_cycle(const apk_sim *s) {
   return true;
 }
 
-// May the x1 strips of this cycle's two exchanges bypass the pack / unpack kernels (apk_stage_args.x1_halo)?  The VL2
-// cycle of a uniform periodic 3-D mesh with remote neighbours in its leanest form: the predictor reads the conserved
-// state (prim_free_cycle) one layer deep (thin_exchange_cycle) and sends primitives (GHOST_PRIM_COPY), the corrector reads
-// those and sends one layer of the conserved state; both in stage forms that follow the table.  APK_X1_DIRECT=0: off (A/B).
-bool x1_direct_cycle(const apk_sim *s) {
+// May the x1 strips of this cycle's exchanges bypass the pack / unpack kernels (apk_stage_args.x1_halo)?  On a uniform
+// periodic 3-D mesh with remote neighbours, in the leanest forms of a cycle:
+//   1  VL2: the predictor reads the conserved state (prim_free_cycle) one layer deep (thin_exchange_cycle) and sends
+//      primitives (GHOST_PRIM_COPY), the corrector reads those and sends one layer of the conserved state;
+//   2  the RK integrators whose stages all derive their input from the conserved state (rk_prim_free_cycle) in the
+//      two-kernel form: every exchange moves the conserved state nghost deep, and every finishing march stores its x1
+//      strips into the messages and reads the ones of the stage before from them;
+// both in stage forms that follow the table.  0: neither.  APK_X1_DIRECT=0: off (A/B).
+int x1_direct_kind(const apk_sim *s) {
   static const int mode = std::getenv("APK_X1_DIRECT") ? std::atoi(std::getenv("APK_X1_DIRECT")) : 1;
   const HydroPackage &pkg = s->pkg;
-  if (!mode || !s->x1_on || !s->d_x1_tab[0] || s->nstages != 2 || s->mesh.mb[0] < 2 * s->mesh.ng) return false;
-  if (!thin_exchange_cycle(s) || !prim_free_cycle(s) || !direct_neighbors(s) || !ghost_c2p_fusable(s)) return false;
+  const Mesh &mm = s->mesh;
+  if (!mode || !s->x1_on || !s->d_x1_tab[0] || mm.mb[0] < 2 * mm.ng || mm.peers.empty()) return 0;
+  if (!direct_neighbors(s) || !ghost_c2p_fusable(s) || s->fmft) return 0;
+  for (int d = 0; d < 3; ++d)
+    if (mm.bc_in[d] != BC_PERIODIC || mm.bc_out[d] != BC_PERIODIC) return 0;
   const int ded = (pkg.fluid == APK_FLUID_GLMMHD) ? 1 : 0;
-  return apk_stage_x1_halo(s->mu0(), &pkg.flux_first_stage, &pkg.eos, 2, ded) == 1 &&
-         apk_stage_x1_halo(s->mu0(), &pkg.flux_other_stage, &pkg.eos, 2, ded) == 1;
+  if (s->nstages == 2 && thin_exchange_cycle(s) && prim_free_cycle(s)) {
+    return (apk_stage_x1_halo(s->mu0(), &pkg.flux_first_stage, &pkg.eos, 2, ded, 1) == 1 &&
+            apk_stage_x1_halo(s->mu0(), &pkg.flux_other_stage, &pkg.eos, 3, ded, 0) == 1) ? 1 : 0;
+  }
+  if (rk_prim_free_cycle(s)) {
+    // (stage 1 reads u1's state, the others u0's with an out-of-place result; the last computes primitives for dt only)
+    return (apk_stage_x1_halo(s->mu0(), &pkg.flux_first_stage, &pkg.eos, s->nstages == 1 ? 3 : 0, ded, 1) == 1 &&
+            apk_stage_x1_halo(s->mu0(), &pkg.flux_other_stage, &pkg.eos, 0, ded, 2) == 1 &&
+            apk_stage_x1_halo(s->mu0(), &pkg.flux_other_stage, &pkg.eos, 3, ded, 2) == 1) ? 2 : 0;
+  }
+  return 0;
 }
+bool x1_direct_cycle(const apk_sim *s) { return x1_direct_kind(s) != 0; }
 
 // the per-block segment tables of apk_stage_args.x1_halo (apk_sim::d_x1_tab), from Mesh::x1_send / x1_recv
 int build_x1_tables(apk_sim *s) {
   const Mesh &m = s->mesh;
   if (m.peers.empty() || m.ndim != 3) return APK_OK;
   const size_t nlb = m.local_gids.size();
-  std::vector<apk_x1_halo_block> pred(nlb), corr(nlb);
+  std::vector<apk_x1_halo_block> pred(nlb), corr(nlb), full(nlb);
   for (size_t lb = 0; lb < nlb; ++lb)
     for (int side = 0; side < 2; ++side) {
       const X1Segment &sd = m.x1_send[lb][side], &rv = m.x1_recv[lb][side];
@@ -672,10 +688,12 @@ int build_x1_tables(apk_sim *s) {
       corr[lb].send[side] = sd.peer >= 0 ? s->send_buf[sd.peer] + sd.off_thin : nullptr;
       pred[lb].recv[side] = rv.peer >= 0 ? s->recv_buf[rv.peer] + rv.off_thin : nullptr;
       corr[lb].recv[side] = rv.peer >= 0 ? s->recv_buf[rv.peer] + rv.off : nullptr;
+      full[lb].send[side] = pred[lb].send[side];  // (the RK integrators: full messages both ways)
+      full[lb].recv[side] = corr[lb].recv[side];
     }
-  const char *tags[2] = {"x1_halo_predictor", "x1_halo_corrector"};
-  const std::vector<apk_x1_halo_block> *tabs[2] = {&pred, &corr};
-  for (int q = 0; q < 2; ++q) {
+  const char *tags[3] = {"x1_halo_predictor", "x1_halo_corrector", "x1_halo_full"};
+  const std::vector<apk_x1_halo_block> *tabs[3] = {&pred, &corr, &full};
+  for (int q = 0; q < 3; ++q) {
     double *p = nullptr;
     SIM_TRY(s, dev_alloc(s, tags[q], sizeof(apk_x1_halo_block) * nlb, &p));
     s->d_x1_tab[q] = p;
@@ -694,7 +712,7 @@ int materialize_prim(apk_sim *s) {
 // stored).  A collective over the ranks, like the completion of a refined mesh's ghost zones below: accessors that
 // reach it are to be called on every rank.
 int materialize_remote_ghosts(apk_sim *s) {
-  if (!s->remote_ghosts_thin) return APK_OK;
+  if (!s->remote_ghosts_thin && !s->x1_in_recv) return APK_OK;  // (... or it left its x1 strips in the receive buffers)
   if (s->exchange_pending) return fail(s, APK_ERR_INVALID, "materialize_remote_ghosts: an exchange is in flight");
   if (!s->have_comm || !s->comm.exchange) return fail(s, APK_ERR_INVALID, "remote neighbours but no comm ops");
   // (the message half of exchange_begin / exchange_end: same-rank ghost zones are none of its business)
@@ -1004,7 +1022,7 @@ int do_stage(apk_sim *s, int stage) {
   // (ghost zones one layer deep: enough for the donor-cell predictor they were left for, and for nothing else)
   if (s->remote_ghosts_thin && !(stage == 1 && thin_exchange_cycle(s))) SIM_TRY(s, sync_ghosts(s));
   // (... and their x1 strips still in the receive buffers: for a predictor that reads them there, x1_direct_cycle)
-  if (stage == 1 && (s->exchange_pending ? s->xchg_x1_direct : s->x1_in_recv) && !x1_direct_cycle(s)) SIM_TRY(s, sync_ghosts(s));
+  if ((s->exchange_pending ? s->xchg_x1_direct : s->x1_in_recv) && !x1_direct_cycle(s)) SIM_TRY(s, sync_ghosts(s));
   if (stage == 1) {
     // "init u1" (hydro_driver.cpp:474-495) without the copy: the buffer holding u0 becomes the
     // register u1 and the stage writes the new u0 into the other buffer.  Valid because
@@ -1111,15 +1129,25 @@ int do_stage(apk_sim *s, int stage) {
     // deep and reads the one-layer conserved strips the corrector of the cycle before sent; the corrector the other way
     // round.  The receive side only when the exchange this stage follows left the strips in the buffers.
     apk_x1_halo x1h{};
-    if (x1_direct_cycle(s)) {
-      const bool predictor = stage == 1 && dc3 && swap_prim && ghost_cons_dead && a.cons_store == 2;
-      const bool corrector = stage == s->nstages && stage > 1 && two_kernel && no_prim;
-      if (predictor || corrector) {
-        const bool from_buffers = s->exchange_pending ? s->xchg_x1_direct : s->x1_in_recv;
-        x1h.blocks = static_cast<const apk_x1_halo_block *>(s->d_x1_tab[predictor ? 0 : 1]);
-        x1h.recv_depth = from_buffers ? (predictor ? kThinDepth : s->mesh.ng) : 0;
-        x1h.send_depth = predictor ? s->mesh.ng : kThinDepth;
-        x1h.send_field = predictor ? 1 : 0;
+    {
+      const int x1kind = x1_direct_kind(s);
+      const bool from_buffers = s->exchange_pending ? s->xchg_x1_direct : s->x1_in_recv;
+      if (x1kind == 1) {
+        const bool predictor = stage == 1 && dc3 && swap_prim && ghost_cons_dead && a.cons_store == 2;
+        const bool corrector = stage == s->nstages && stage > 1 && two_kernel && no_prim;
+        if (predictor || corrector) {
+          x1h.blocks = static_cast<const apk_x1_halo_block *>(s->d_x1_tab[predictor ? 0 : 1]);
+          x1h.recv_depth = from_buffers ? (predictor ? kThinDepth : s->mesh.ng) : 0;
+          x1h.send_depth = predictor ? s->mesh.ng : kThinDepth;
+          x1h.send_field = predictor ? 1 : 0;
+          a.x1_halo = &x1h;
+        }
+      } else if (x1kind == 2 && two_kernel && rk_free && from_cons && (a.fill_derived == 0 || a.fill_derived == 3)) {
+        // (an RK stage from the conserved state: the full messages both ways, the conserved state nghost deep)
+        x1h.blocks = static_cast<const apk_x1_halo_block *>(s->d_x1_tab[2]);
+        x1h.recv_depth = from_buffers ? s->mesh.ng : 0;
+        x1h.send_depth = s->mesh.ng;
+        x1h.send_field = 0;
         a.x1_halo = &x1h;
       }
     }

@@ -175,7 +175,7 @@ struct apk_sim {
   //   x1_in_recv      ... and has completed: the next stage reads them there.  Always together with a one-layer exchange
   //                   (remote_ghosts_thin: whoever else reads ghost zones repeats the exchange in full) or inside a cycle.
   bool x1_on = true;  // apk_sim_set_x1_direct / APK_X1_DIRECT=0 (A/B)
-  void *d_x1_tab[2] = {nullptr, nullptr};
+  void *d_x1_tab[3] = {nullptr, nullptr, nullptr};  // ([2]: full messages both ways -- the RK integrators)
   bool x1_out_direct = false, xchg_x1_direct = false, x1_in_recv = false;
   long long x1_direct_exchanges = 0;
   long long turb_dt_kicks = 0;  // kicks that estimated the time step without storing primitives (apk_turb_apply_dt)

@@ -72,6 +72,7 @@ int run_ghost_plan(apk_sim *s, int buf, int phase, int c2p, apk_stream_t stream 
 int exchange_begin(apk_sim *s, bool async, int c2p, bool skip_local = false, bool thin = false);
 bool thin_exchange_cycle(const apk_sim *s);
 bool x1_direct_cycle(const apk_sim *s);
+int x1_direct_kind(const apk_sim *s);
 int build_x1_tables(apk_sim *s);
 bool rk_prim_free_cycle(const apk_sim *s);
 int materialize_remote_ghosts(apk_sim *s);

@@ -284,9 +284,10 @@ def StageFused(u0, u1, fluid, recon, riemann, eos, c_h, gam0, gam1, beta_dt, ded
         torch.cuda.current_stream().synchronize()  # (the table is a temporary of this call)
 
 
-def StageFollowsX1Halo(u0, fluid, recon, riemann, eos, fill_derived=2, dedner=0):
+def StageFollowsX1Halo(u0, fluid, recon, riemann, eos, fill_derived=2, dedner=0, prim_from_cons=0):
     """apk_stage_x1_halo: does a whole-block stage of this scheme follow apk_stage_args.x1_halo?"""
-    return bool(u0.ctx.lib.apk_stage_x1_halo(u0.h, C.byref(_cfg(fluid, recon, riemann)), C.byref(eos), int(fill_derived), int(dedner)))
+    return bool(u0.ctx.lib.apk_stage_x1_halo(u0.h, C.byref(_cfg(fluid, recon, riemann)), C.byref(eos), int(fill_derived), int(dedner),
+                                             int(prim_from_cons)))
 
 
 def ConservedToPrimitive(md, fluid, eos):

@@ -207,7 +207,7 @@ def _signatures():
         "apk_stage_split_axis": (i, [vp, vp, i]),
         "apk_stage_single_march": (i, [vp, vp]),
         "apk_bench_scheme_floor": (i, [i, i, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
-        "apk_stage_x1_halo": (i, [vp, vp, E, i, i]),
+        "apk_stage_x1_halo": (i, [vp, vp, E, i, i, i]),
         "apk_stage_unphysical_read": (i, [vp, C.POINTER(C.c_longlong), vp]),
         "apk_copy_plan_create": (i, [vp, C.POINTER(CopyRegion), i, pp]),
         "apk_copy_plan_destroy": (None, [vp]),

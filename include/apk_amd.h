@@ -312,9 +312,10 @@ int apk_stage_fused(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,
 int apk_stage_unphysical_read(apk_ctx *ctx, long long *count, apk_stream_t stream);
 int apk_stage_split_axis(const apk_pack *u0, const apk_flux_cfg *cfg, int fill_derived);
 /* 1 if a whole-block stage of this scheme with these options follows apk_stage_args.x1_halo: the lean two-row donor-cell
- * march (3-D, fill_derived 0 / 2, nx2 even) and the lean two-kernel stage's finishing march, without passive scalars.  A
- * caller checks BEFORE it leaves x1 strips out of its pack / unpack plans. */
-int apk_stage_x1_halo(const apk_pack *u0, const apk_flux_cfg *cfg, const apk_eos *eos, int fill_derived, int dedner);
+ * march (3-D, fill_derived 0 / 2, nx2 even) and the lean two-kernel stage's finishing march -- from stored primitives or
+ * (prim_from_cons != 0) from a conserved state, but not the stages that take the single march (apk_stage_single_march) --
+ * without passive scalars.  A caller checks BEFORE it leaves x1 strips out of its pack / unpack plans. */
+int apk_stage_x1_halo(const apk_pack *u0, const apk_flux_cfg *cfg, const apk_eos *eos, int fill_derived, int dedner, int prim_from_cons);
 /* 1 if a whole-block stage of this scheme in its lean form with prim_from_cons != 0 runs as ONE march (hydro with PLM:
  * x1 by wave shifts, two x2 rows per lane, x3 carried along the march -- no flux-difference array; the three tasks
  * hydro.cpp:1025-1208 + hydro_driver.cpp:534-544 in a single pass over the conserved state), 0 if it takes the two-kernel

@@ -137,12 +137,14 @@ int apk_sim_set_prim_free(apk_sim *sim, int on);
  * of one-layer exchanges so far. */
 int apk_sim_set_thin_exchange(apk_sim *sim, int on);
 long long apk_sim_thin_exchanges(const apk_sim *sim);
-/* x1 strips without pack / unpack kernels (on by default where it applies: the cycles that take one-layer exchanges AND
- * store no full-step primitives -- VL2 on a uniform periodic 3-D mesh over N > 1 ranks): the finishing kernel of a stage
+/* x1 strips without pack / unpack kernels (on by default where it applies, uniform periodic 3-D meshes over N > 1 ranks:
+ * the VL2 cycles that take one-layer exchanges and store no full-step primitives, and the RK integrators whose stages all
+ * derive their input from the conserved state in the two-kernel form): the finishing kernel of a stage
  * stores its x1 boundary columns straight into the send buffers and the kernels of the next stage read their x1 ghost
  * columns straight from the receive buffers (apk_stage_args.x1_halo in apk_amd.h); the pack and unpack plans leave the
  * x1 faces out.  The messages are byte for byte what the pack kernel would have written, so a rank may use the path or
- * not independently of its peers; results are identical.  APK_X1_DIRECT=0 in the environment switches it off.
+ * not independently of its peers; results are identical.  Accessors that read ghost zones repeat such an exchange in full
+ * first (a COLLECTIVE, as after a one-layer exchange).  APK_X1_DIRECT=0 in the environment switches it off.
  * apk_sim_x1_direct_exchanges: the number of exchanges so far whose x1 strips went that way. */
 int apk_sim_set_x1_direct(apk_sim *sim, int on);
 long long apk_sim_x1_direct_exchanges(const apk_sim *sim);

@@ -1199,13 +1199,16 @@ def test_direct_neighbor_addressing_equals_filled_ghost_zones(request, fluid, re
 @pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
 @pytest.mark.parametrize("fluid,recon,riemann,from_cons", [("glmmhd", "ppm", "hlld", False), ("glmmhd", "dc", "hlld", True),
                                                            ("glmmhd", "dc", "hlld", False), ("euler", "plm", "hllc", False),
-                                                           ("euler", "dc", "hlle", True), ("glmmhd", "wenoz", "hlld", False)])
+                                                           ("euler", "dc", "hlle", True), ("glmmhd", "wenoz", "hlld", False),
+                                                           ("glmmhd", "ppm", "hlld", True), ("glmmhd", "wenoz", "hlld", True)])
 def test_x1_strips_in_exchange_buffers_equal_filled_ghost_zones(request, fluid, recon, riemann, from_cons, strict):
     """apk_stage_args.x1_halo: a stage whose x1 ghost columns live in receive-buffer segments ([nvar][nx3][nx2][depth];
     the ghost zones behind those faces poisoned) equals the stage on filled ghost zones bit for bit -- updated state,
     out-of-place primitives, time step -- and the send segments hold the x1 boundary columns of what it stored: the
     conserved state one layer deep (the corrector's place in a VL2 cycle) or the new primitives nghost deep (the
-    predictor's).  A face without a segment is read from the block as before."""
+    predictor's).  A face without a segment is read from the block as before.  from_cons: the stage derives its input from
+    u1's conserved state -- the segments then hold conserved values (the donor-cell predictor of a prim-free VL2 cycle, the
+    finishing marches of the RK integrators)."""
     import torch
     from athenapk_amd import hydro
     ctx = _ctx(request, strict)
@@ -1221,7 +1224,7 @@ def test_x1_strips_in_exchange_buffers_equal_filled_ghost_zones(request, fluid, 
     rdepth, sdepth, sfield = (1, ng, 1) if dc else (ng, 1, 0)
     kw = dict(dedner=ded, glmmhd_alpha=0.1, mindx=0.07, fill_derived=2, estimate_dt=not dc, prim_from_cons=from_cons)
     assert hydro.StageFollowsX1Halo(hydro.MeshData(ctx, nx, ng, nv, dx=tuple(g.dx), nblocks=2, cons=cons_ref, prim=prim_ref, with_flux=False),
-                                    fluid, recon, riemann, eos, 2, ded)
+                                    fluid, recon, riemann, eos, 2, ded, prim_from_cons=int(from_cons))
     src = cons_ref if from_cons else prim_ref  # the array the stage takes its input from
     ks, js = slice(ng, ng + nx[2]), slice(ng, ng + nx[1])
 
@@ -1249,7 +1252,12 @@ def test_x1_strips_in_exchange_buffers_equal_filled_ghost_zones(request, fluid, 
     got = run(True)
     I = lambda x: H.interior(x, nx, ng)
     assert np.all(np.isfinite(I(got[0]))) and np.all(np.isfinite(I(got[1])))
-    assert np.array_equal(I(got[0]), I(want[0])) and np.array_equal(I(got[1]), I(want[1])) and got[2] == want[2]
+    if strict:
+        assert np.array_equal(I(got[0]), I(want[0])) and np.array_equal(I(got[1]), I(want[1])) and got[2] == want[2]
+    else:  # (the product build contracts each kernel form's expressions its own way: last-bit differences)
+        np.testing.assert_allclose(I(got[0]), I(want[0]), rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(I(got[1]), I(want[1]), rtol=1e-12, atol=1e-13)
+        assert abs(got[2] - want[2]) <= 1e-12 * abs(want[2])
     stored = got[1] if sfield else got[0]
     for blk in range(2):
         for side in range(2):

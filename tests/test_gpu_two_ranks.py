@@ -101,6 +101,8 @@ EXPECT_THIN = {"mhd_ppm_hlld_vl2", "mhd_ppm_two_kernel", "mhd_8_ranks"}
 # ... whose x1 strips bypass the pack / unpack kernels in both exchanges of a cycle (apk_sim_set_x1_direct) where the
 # meshblocks are wide enough for the two-kernel stage: real messages between ranks, laid out by the pack plans of the peer
 EXPECT_X1_DIRECT = {"mhd_ppm_two_kernel", "mhd_8_ranks"}
+# (the RK integrators: every exchange but the one after the very first stage, which reads stored primitives)
+EXPECT_X1_DIRECT_RK = {"mhd_wenoz_rk3_two_kernel": 3}
 
 
 def _worker(rank, world, port, case, outdir, overlap=True):
@@ -157,8 +159,10 @@ def test_ranks_sharing_one_gpu_match_oracle(oracle, tmp_path, case, world, overl
         assert int(z["thin"]) == (ncyc if case in EXPECT_THIN else 0)
         if case in EXPECT_X1_DIRECT:
             assert int(z["x1_direct"]) == 2 * ncyc
+        elif case in EXPECT_X1_DIRECT_RK:
+            assert int(z["x1_direct"]) == EXPECT_X1_DIRECT_RK[case] * ncyc - 1
         else:
-            assert int(z["x1_direct"]) in (0, 2 * ncyc)
+            assert int(z["x1_direct"]) in (0, nstages * ncyc, nstages * ncyc - 1)
         np.testing.assert_allclose(z["hist"], o.history(), rtol=1e-13, atol=1e-15)
         for key in z.files:
             if key.startswith("b"):
