@@ -657,7 +657,7 @@ int x1_direct_kind(const apk_sim *s) {
   const HydroPackage &pkg = s->pkg;
   const Mesh &mm = s->mesh;
   if (!mode || !s->x1_on || !s->d_x1_tab[0] || mm.mb[0] < 2 * mm.ng || mm.peers.empty()) return 0;
-  if (!direct_neighbors(s) || !ghost_c2p_fusable(s) || s->fmft) return 0;
+  if (!direct_neighbors(s) || !ghost_c2p_fusable(s)) return 0;
   for (int d = 0; d < 3; ++d)
     if (mm.bc_in[d] != BC_PERIODIC || mm.bc_out[d] != BC_PERIODIC) return 0;
   const int ded = (pkg.fluid == APK_FLUID_GLMMHD) ? 1 : 0;
@@ -1146,9 +1146,11 @@ int do_stage(apk_sim *s, int stage) {
         // (an RK stage from the conserved state: the full messages both ways, the conserved state nghost deep)
         x1h.blocks = static_cast<const apk_x1_halo_block *>(s->d_x1_tab[2]);
         x1h.recv_depth = from_buffers ? s->mesh.ng : 0;
-        x1h.send_depth = s->mesh.ng;
+        // (forced turbulence: the kick after the last stage changes the state the strips were taken from -- that exchange
+        // packs its x1 faces again)
+        x1h.send_depth = (s->fmft && stage == s->nstages) ? 0 : s->mesh.ng;
         x1h.send_field = 0;
-        a.x1_halo = &x1h;
+        if (x1h.recv_depth > 0 || x1h.send_depth > 0) a.x1_halo = &x1h;
       }
     }
     if (s->x1_in_recv && !(a.x1_halo && x1h.recv_depth > 0))

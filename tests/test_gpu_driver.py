@@ -415,6 +415,26 @@ def test_rehearsed_remote_faces_give_the_periodic_box(strict, scheme, overlap, x
     _assert_same(b.gather("prim"), a.gather("prim"), strict)
 
 
+def test_forced_turbulence_keeps_the_x1_strips_of_the_kicked_state_packed():
+    """BASELINE config 4's scheme with its forcing on, rehearsed as a rank of the 8-GPU run: the stages that are not the last
+    store their x1 strips into the messages (apk_sim_set_x1_direct), the exchange after the last one -- behind the kick,
+    which changes the state the strips were taken from -- packs them as before; bit for bit the run with every strip
+    packed (parity build)."""
+    ov = ["parthenon/mesh/nx%d=64" % d for d in (1, 2, 3)] + ["parthenon/meshblock/nx%d=32" % d for d in (1, 2, 3)] + [
+        "parthenon/mesh/nghost=3", "apk_amd/rehearse_remote_faces=true", "parthenon/time/integrator=rk3", "hydro/reconstruction=wenoz",
+        "hydro/riemann=hlld"]
+    runs = []
+    for x1 in (True, False):
+        s = _sim("turbulence", ov, strict=True)
+        s.set_x1_direct(x1)
+        s.initialize()
+        for _ in range(3):
+            s.step()
+        runs.append((s.x1_direct_exchanges(), np.asarray(s.dt), s.gather()))
+    assert runs[0][0] == 2 * 3 - 1 and runs[1][0] == 0   # (two of the three exchanges of a cycle; not after the very first stage)
+    assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+
+
 @pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
 @pytest.mark.parametrize("overlap", [True, False], ids=["overlapped", "synchronous"])
 @pytest.mark.parametrize("prim_free", [True, False], ids=["prim_free", "stored_prims"])
