@@ -75,6 +75,9 @@ CASES["mhd_wenoz_rk3_two_kernel"] = ("synthetic_mhd",
                                       "parthenon/time/integrator=rk3", "hydro/reconstruction=wenoz"],
                                      dict(fluid="glmmhd", recon="wenoz", riemann="hlld", integrator="rk3", nx=(64, 32, 32),
                                           mb=(32, 16, 16), ng=3, cfl=0.3, gamma=1.666666666666667), "synthetic", {}, 2)
+# ... the same with line-aligned rows (apk_amd/row_pitch = aligned: a pitch of 48 doubles for these 38-cell rows, 13 doubles in
+# front of every block): pack / unpack plans, x1 strips in the buffers and the accessors on the padded layout
+CASES["mhd_ppm_two_kernel_padded_rows"] = (CASES["mhd_ppm_two_kernel"][0], CASES["mhd_ppm_two_kernel"][1] + ["apk_amd/row_pitch=aligned"]) + CASES["mhd_ppm_two_kernel"][2:]
 # the layout of the 8-GPU benchmark in small: 64 meshblocks, a 2x2x2 brick of them per rank, 7 peers
 CASES["mhd_8_ranks"] = ("synthetic_mhd",
                         ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=64", "parthenon/mesh/nx3=64",
@@ -86,7 +89,7 @@ EXPECT_OVERLAPPED = {"ot_2d": lambda nst, ncyc: ncyc, "ot_2d_fofc": lambda nst, 
                      "lw_implode_2d": lambda nst, ncyc: ncyc}
 # 3-D VL2 (round 4): the exchange in flight at the start of a cycle is completed before the donor-cell predictor, which
 # then runs whole (two rows per lane, one launch) instead of on seven windows; the one before the corrector is overlapped
-for _case in ("mhd_ppm_hlld_vl2", "mhd_scalars_vl2", "mhd_ppm_two_kernel", "mhd_8_ranks"):
+for _case in ("mhd_ppm_hlld_vl2", "mhd_scalars_vl2", "mhd_ppm_two_kernel", "mhd_ppm_two_kernel_padded_rows", "mhd_8_ranks"):
     EXPECT_OVERLAPPED[_case] = lambda nst, ncyc: ncyc
 
 
@@ -97,10 +100,10 @@ EXPECT_OVERLAPPED["sod_outflow"] = lambda nst, ncyc: 0
 
 # one-layer exchanges (apk_sim_set_thin_exchange): the exchange at the end of every cycle of VL2 on a periodic 3-D mesh
 # without passive scalars; the blocks compared below include their ghost zones, which the accessor completes first
-EXPECT_THIN = {"mhd_ppm_hlld_vl2", "mhd_ppm_two_kernel", "mhd_8_ranks"}
+EXPECT_THIN = {"mhd_ppm_hlld_vl2", "mhd_ppm_two_kernel", "mhd_ppm_two_kernel_padded_rows", "mhd_8_ranks"}
 # ... whose x1 strips bypass the pack / unpack kernels in both exchanges of a cycle (apk_sim_set_x1_direct) where the
 # meshblocks are wide enough for the two-kernel stage: real messages between ranks, laid out by the pack plans of the peer
-EXPECT_X1_DIRECT = {"mhd_ppm_two_kernel", "mhd_8_ranks"}
+EXPECT_X1_DIRECT = {"mhd_ppm_two_kernel", "mhd_ppm_two_kernel_padded_rows", "mhd_8_ranks"}
 # (the RK integrators: every exchange but the one after the very first stage, which reads stored primitives)
 EXPECT_X1_DIRECT_RK = {"mhd_wenoz_rk3_two_kernel": 3}
 
