@@ -134,6 +134,20 @@ APK_DEV double fdiv(double a, double b) { return a / b; }
 #else
 APK_DEV double fdiv(double a, double b) { return a * frcp(b); }
 #endif
+// The same with ONE Newton step on v_rcp_f64 (raw result 4.6e-8 relative, profiles/r03_clock_and_latency.json: one step
+// squares it, 2.1e-15 = 19 ulp; four instructions and the multiply): the limited slope of PLM and the weights and
+// normalisations of WENO-Z, whose own truncation error is orders of magnitude above it and whose results feed no
+// comparison.  Product build only; the parity build divides.
+#if defined(APK_FP_STRICT) || defined(APK_PLAIN_SQRT) || defined(APK_RCP_FULL)
+APK_DEV double frcp48(double x) { return frcp(x); }
+APK_DEV double fdiv48(double a, double b) { return fdiv(a, b); }
+#else
+APK_DEV double frcp48(double x) {
+  const double y = __builtin_amdgcn_rcp(x);
+  return fma(y, fma(-x, y, 1.0), y);
+}
+APK_DEV double fdiv48(double a, double b) { return a * frcp48(b); }
+#endif
 #ifdef APK_FP_STRICT
 APK_DEV double min2(double a, double b) { return (b < a) ? b : a; }  // std::min
 APK_DEV double max2(double a, double b) { return (a < b) ? b : a; }  // std::max
@@ -209,7 +223,7 @@ APK_DEV void plm(double qm1, double q0, double qp1, double &ql, double &qr) {
   const double dr = qp1 - q0;
   const double prod = dl * dr;
   double slope = 0.0;
-  if (prod > 0.0) slope = fdiv(prod, (dl + dr));
+  if (prod > 0.0) slope = fdiv48(prod, (dl + dr));
   ql = q0 + slope;
   qr = q0 - slope;
 }
@@ -344,7 +358,7 @@ APK_DEV void wenoz(double qm2, double qm1, double q0, double qp1, double qp2, do
   // (p_k >= 1e-42 and p_k <= ~ q^2: the product stays between 1e-126 and the square of anything a state holds)
   const double p0 = b0 + eps, p1 = b1 + eps, p2 = b2 + eps;
   const double p01 = p0 * p1;
-  const double tinv = tau5 * frcp(p01 * p2);
+  const double tinv = tau5 * frcp48(p01 * p2);
   const double i0 = tinv * (p1 * p2);
   const double i1 = tinv * (p0 * p2);
   const double i2 = tinv * p01;
@@ -369,8 +383,8 @@ APK_DEV void wenoz(double qm2, double qm1, double q0, double qp1, double qp2, do
   const double num_r = (f0 * a0 + f1 * a1 + f2 * a2);
   // (the two weight sums keep a reciprocal each: they grow like (tau5 / eps)^2 next to a discontinuity and their
   // product can leave the range of a double)
-  ql = fdiv(num_l, asum_l);
-  qr = fdiv(num_r, asum);
+  ql = fdiv48(num_l, asum_l);
+  qr = fdiv48(num_r, asum);
 }
 
 // src/recon/weno3_simple.hpp:26-63

@@ -595,7 +595,7 @@ def measured_traffic(workload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--regions", type=int, default=3, help="timed regions of --steps cycles each; the median one is reported")
     ap.add_argument("--sustained", type=int, default=500, help="cycles of the 'sustained' figure of the N = 1 line (0: skip)")
