@@ -340,6 +340,7 @@ APK_DEV void ppm(double qm2, double qm1, double q0, double qp1, double qp2, doub
 }
 
 // src/recon/wenoz_simple.hpp:28-81
+#if defined(APK_FP_STRICT) || defined(APK_PLAIN_SQRT) || defined(APK_WENOZ_REF_FORM)
 APK_DEV void wenoz(double qm2, double qm1, double q0, double qp1, double qp2, double &ql,
                    double &qr) {
   constexpr double c0 = 13. / 12., c1 = 0.25;
@@ -348,20 +349,17 @@ APK_DEV void wenoz(double qm2, double qm1, double q0, double qp1, double qp2, do
   const double b2 = c0 * sqr(qp2 + q0 - 2.0 * qp1) + c1 * sqr(qp2 + 3.0 * q0 - 4.0 * qp1);
   constexpr double eps = 1.0e-42;
   const double tau5 = fabs(b0 - b2);
-#ifdef APK_PLAIN_SQRT
-  const double i0 = fdiv(tau5, (b0 + eps));
-  const double i1 = fdiv(tau5, (b1 + eps));
-  const double i2 = fdiv(tau5, (b2 + eps));
-#else
-  // the three quotients share one reciprocal, evaluated per lane: tau5 / p_k = tau5 (p_l p_m) / (p_0 p_1 p_2) -- one
-  // v_rcp_f64 + Newton steps instead of three (the transcendental unit issues at a quarter of the fp64 rate), <= 2 ulp.
-  // (p_k >= 1e-42 and p_k <= ~ q^2: the product stays between 1e-126 and the square of anything a state holds)
+#ifdef APK_WENOZ_REF_FORM
   const double p0 = b0 + eps, p1 = b1 + eps, p2 = b2 + eps;
   const double p01 = p0 * p1;
   const double tinv = tau5 * frcp48(p01 * p2);
   const double i0 = tinv * (p1 * p2);
   const double i1 = tinv * (p0 * p2);
   const double i2 = tinv * p01;
+#else
+  const double i0 = fdiv(tau5, (b0 + eps));
+  const double i1 = fdiv(tau5, (b1 + eps));
+  const double i2 = fdiv(tau5, (b2 + eps));
 #endif
 
   double f0 = (2.0 * qm2 - 7.0 * qm1 + 11.0 * q0);
@@ -381,11 +379,52 @@ APK_DEV void wenoz(double qm2, double qm1, double q0, double qp1, double qp2, do
   a2 = 0.3 * (1.0 + sqr(i0));
   asum = 6.0 * (a0 + a1 + a2);
   const double num_r = (f0 * a0 + f1 * a1 + f2 * a2);
-  // (the two weight sums keep a reciprocal each: they grow like (tau5 / eps)^2 next to a discontinuity and their
-  // product can leave the range of a double)
   ql = fdiv48(num_l, asum_l);
   qr = fdiv48(num_r, asum);
 }
+#else
+// The product build's form: the same weights up to factors that cancel in the quotients.
+//  * smoothness indicators divided by 13/12 (b_k' = d2_k^2 + 3/13 d1_k^2, eps' = 12/13 eps): tau5 / (b_k + eps) unchanged;
+//  * the three quotients share one reciprocal, evaluated per lane: tau5 / p_k = tau5 (p_l p_m) / (p_0 p_1 p_2) -- one
+//    v_rcp_f64 instead of three (the transcendental unit issues at a quarter of the fp64 rate); p_k >= 9e-43 and
+//    p_k <= ~ q^2: the product stays between 1e-126 and the square of anything a state holds;
+//  * the linear weights 0.1, 0.6, 0.3 divided by 0.1, and the 1/6 of the candidate polynomials, the 6 and the 3 folded into
+//    the polynomials' coefficients: q = (s_0 f_0/6 + s_1 f_1 + s_2 f_2/2) / (s_0 + 6 s_1 + 3 s_2) with s_k = 1 + i_k^2 --
+//    8 multiplications fewer than alpha_k = c_k s_k, 6 sum(alpha_k);
+//  * (the two weight sums keep a reciprocal each: they grow like (tau5 / eps)^2 next to a discontinuity and their
+//    product can leave the range of a double.)
+// ~67 instead of ~78 instructions per cell and variable; results equal to the reference's form to a few ulp
+// (tests/test_gpu_parity.py compares the product build against the oracle with a tolerance, the parity build bit for bit).
+APK_DEV void wenoz(double qm2, double qm1, double q0, double qp1, double qp2, double &ql,
+                   double &qr) {
+  constexpr double r = 3.0 / 13.0, eps = 1.0e-42 * (12.0 / 13.0);
+  const double e0 = qm2 + q0 - 2.0 * qm1, g0 = qm2 + 3.0 * q0 - 4.0 * qm1;
+  const double e1 = qm1 + qp1 - 2.0 * q0, g1 = qm1 - qp1;
+  const double e2 = qp2 + q0 - 2.0 * qp1, g2 = qp2 + 3.0 * q0 - 4.0 * qp1;
+  const double b0 = fma(e0, e0, (r * g0) * g0);
+  const double b1 = fma(e1, e1, (r * g1) * g1);
+  const double b2 = fma(e2, e2, (r * g2) * g2);
+  const double tau5 = fabs(b0 - b2);
+  const double p0 = b0 + eps, p1 = b1 + eps, p2 = b2 + eps;
+  const double p01 = p0 * p1;
+  const double tinv = tau5 * frcp48(p01 * p2);
+  const double i0 = tinv * (p1 * p2);
+  const double i1 = tinv * (p0 * p2);
+  const double i2 = tinv * p01;
+  const double s0 = fma(i0, i0, 1.0), s1 = fma(i1, i1, 1.0), s2 = fma(i2, i2, 1.0);
+  const double s16 = 6.0 * s1;
+  const double den_l = fma(3.0, s2, s16 + s0), den_r = fma(3.0, s0, s16 + s2);
+  constexpr double a = 1.0 / 3.0, b = 7.0 / 6.0, c = 11.0 / 6.0;
+  const double c0q = c * q0;
+  const double f0l = fma(a, qm2, fma(-b, qm1, c0q)), f0r = fma(a, qp2, fma(-b, qp1, c0q));
+  const double f1l = fma(2.0, qp1, fma(5.0, q0, -qm1)), f1r = fma(2.0, qm1, fma(5.0, q0, -qp1));
+  const double f2l = fma(2.5, qp1, fma(-0.5, qp2, q0)), f2r = fma(2.5, qm1, fma(-0.5, qm2, q0));
+  const double num_l = fma(s2, f2l, fma(s1, f1l, s0 * f0l));
+  const double num_r = fma(s0, f2r, fma(s1, f1r, s2 * f0r));
+  ql = fdiv48(num_l, den_l);
+  qr = fdiv48(num_r, den_r);
+}
+#endif
 
 // src/recon/weno3_simple.hpp:26-63
 APK_DEV void weno3(double qm1, double q0, double qp1, double dx2, double &ql, double &qr) {
