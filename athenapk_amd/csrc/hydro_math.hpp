@@ -136,7 +136,7 @@ APK_DEV double fdiv(double a, double b) { return a * frcp(b); }
 #endif
 // The same with ONE Newton step on v_rcp_f64 (raw result 4.6e-8 relative, profiles/r03_clock_and_latency.json: one step
 // squares it, 2.1e-15 = 19 ulp; four instructions and the multiply): the limited slope of PLM and the weights and
-// normalisations of WENO-Z, whose own truncation error is orders of magnitude above it and whose results feed no
+// normalisations of WENO-Z and WENO3, whose own truncation error is orders of magnitude above it and whose results feed no
 // comparison.  Product build only; the parity build divides.
 #if defined(APK_FP_STRICT) || defined(APK_PLAIN_SQRT) || defined(APK_RCP_FULL)
 APK_DEV double frcp48(double x) { return frcp(x); }
@@ -431,20 +431,20 @@ APK_DEV void weno3(double qm1, double q0, double qp1, double dx2, double &ql, do
   const double bp = sqr(qp1 - q0);
   const double bm = sqr(q0 - qm1);
   const double tau = sqr(qp1 - 2.0 * q0 + qm1);
-  const double ip = fdiv(tau, (bp + dx2));
-  const double im = fdiv(tau, (bm + dx2));
+  const double ip = fdiv48(tau, (bp + dx2));
+  const double im = fdiv48(tau, (bm + dx2));
   double f0 = q0 + qp1;
   double f1 = -qm1 + 3.0 * q0;
   double a0 = (1.0 + ip) * 2.0 / 3.0;
   double a1 = (1.0 + im) / 3.0;
   double asum = 2.0 * (a0 + a1);
-  ql = fdiv((a0 * f0 + a1 * f1), asum);
+  ql = fdiv48((a0 * f0 + a1 * f1), asum);
   f0 = q0 + qm1;
   f1 = -qp1 + 3.0 * q0;
   a0 = (1.0 + im) * 2.0 / 3.0;
   a1 = (1.0 + ip) / 3.0;
   asum = 2.0 * (a0 + a1);
-  qr = fdiv((a0 * f0 + a1 * f1), asum);
+  qr = fdiv48((a0 * f0 + a1 * f1), asum);
 }
 
 // src/hydro/diffusion/diffusion.hpp:37-47

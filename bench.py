@@ -560,6 +560,20 @@ def measured_traffic(workload):
     COMMITTED rocprofv3 PMC summary of this same command (profiles/rNN_hbm_traffic.json, made by
     profiles/pmc_traffic.py from FETCH_SIZE / WRITE_SIZE collected in separate passes); the source string names
     the file.  Returns (GB, source) or (None, None)."""
+    if workload == "hydro_plm_hllc_rk2_256":
+        # the single-march stage: one launch per stage, the two stages of a cycle (without / with FillDerived + dt) averaged
+        path = os.path.join(ROOT, "profiles", "r06_hbm_traffic_hydro.json")
+        try:
+            with open(path) as f:
+                k = json.load(f)["kernels"]
+            commit = _profile_commit(path)
+            stages = ("fused_s3_kernel<1, 2, 4, 0, 1>", "fused_s3_kernel<1, 2, 4, 2, 2>")
+            return (sum(k[name]["hbm_total_GB"] for name in stages) / len(stages),
+                    "profiles/r06_hbm_traffic_hydro.json%s -- a COMMITTED profile of this command, not this run (rocprofv3 --pmc "
+                    "FETCH_SIZE / WRITE_SIZE in separate passes, reads calibrated on the dt kernel's known bytes; mean of the two "
+                    "stages of a cycle)" % (" @ " + commit if commit else ""))
+        except Exception:
+            return None, None
     if workload != "mhd_ppm_hlld_vl2_256":
         return None, None
     # round 2 / 3: the two-kernel stage (x3 sweep + finishing x1/x2 march); round 1: three sweeps
@@ -841,7 +855,8 @@ def main():
             "roofline": {
                 # what binds the stage kernels (SQ counters); `achieved` / `peak` / `frac` are priced against HBM bandwidth,
                 # as north_star asks -- `priced_against` -- and against the fp64 vector roof in `valu`
-                "bound": "fp64_valu_issue" if (fluid == "glmmhd" and not args.unfused) else "hbm",
+                # (the hydro single march as well: vector issue busy 94 % of its run time, profiles/r06_pmc_sq_hydro.json)
+                "bound": "hbm" if args.unfused else "fp64_valu_issue",
                 "priced_against": "hbm",
                 "kernel": stage_name,
                 "achieved": achieved,
@@ -851,16 +866,19 @@ def main():
                 "traffic": traffic_gb,
                 "traffic_unit": "GB per fused-stage launch (algorithmic: %.2f GB)" % (b_stage * zones_local / 1e9),
                 "traffic_source": traffic_src,
-                "traffic_note": "of the 8.85 GB: 2.4 GB are the x3 sweep's flux differences written and read back (the two-kernel stage's "
-                                "own 144 B per cell on top of the 216 algorithmic ones), the line-aligned rows of round 6 fetch nine lines "
-                                "per 128-cell row where natural rows average 8.4 (+0.9 GB against profiles/r05_hbm_traffic.json, for "
-                                "-1.3 % time: profiles/r06_row_pitch_ab.txt); the kernels are bound by vector issue, not by these bytes",
+                "traffic_note": ("of the 8.85 GB: 2.4 GB are the x3 sweep's flux differences written and read back (the two-kernel stage's "
+                                 "own 144 B per cell on top of the 216 algorithmic ones), the line-aligned rows of round 6 fetch nine lines "
+                                 "per 128-cell row where natural rows average 8.4 (+0.9 GB against profiles/r05_hbm_traffic.json, for "
+                                 "-1.3 % time: profiles/r06_row_pitch_ab.txt); the kernels are bound by vector issue, not by these bytes")
+                                if (args.workload == "mhd_ppm_hlld_vl2_256" and traffic_gb is not None) else None,
                 "algorithmic_bytes_per_cell_stage": b_stage,
                 "cells_per_launch": zones_local,
                 "stage_ms": stage_ms,
                 "dc_predictor_stage_ms": per_kernel["fused_dc_x1"] + per_kernel["fused_dc_x2"] + per_kernel["fused_dc_x3"],
                 "frac_of_measured_copy_bandwidth": achieved / HBM_COPY_GBS,
-                "binding_limit": "fp64 vector-ALU issue (SQ counters: profiles/r06_pmc_sq.json, r06_pmc_instruction_mix.json) "
+                "binding_limit": "fp64 vector-ALU issue (SQ counters: profiles/%s) "
+                                 % ("r06_pmc_sq_hydro.json, r06_pmc_instruction_mix_hydro.json" if fluid != "glmmhd" else
+                                    ("r06_pmc_sq_wenoz.json" if "wenoz" in args.workload else "r06_pmc_sq.json, r06_pmc_instruction_mix.json")) +
                                  "under the 1400 W power cap (effective clock profiles/r06_clock.json), next to the access pattern of "
                                  "the march (profiles/r04_ubench_march_traffic.jsonl); see roofline.valu for the compute roof",
                 "note": "`peak` is the 8 TB/s HBM3E spec, frac_of_measured_copy_bandwidth prices against the 6.29 TB/s a float4 copy "
