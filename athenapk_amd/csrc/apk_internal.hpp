@@ -140,15 +140,25 @@ inline int set_err(apk_ctx *ctx, int code, const char *what, hipError_t e = hipS
   } while (0)
 
 // ---- kernel launchers implemented in the .hip translation units ---------------------
+// input of the boundary-plane fluxes taken from the conserved state (flux_kernel.hpp: face_states_from_cons)
+struct FluxConsInput {
+  int64_t delta;  // from a block's cons array to the array holding the input state (doubles)
+  apk_eos eos;
+  double eos_gm1, vceil_sq, pfloor_over_gm1;
+};
 // flux arrays path (one TU per (fluid, riemann) family to keep compile times parallel)
 int launch_fluxes_euler_hlle(const PackView &pv, int recon, double gamma, double c_h,
-                             hipStream_t s, int faces = 0, const int *face_list = nullptr, int nlist = 0);
+                             hipStream_t s, int faces = 0, const int *face_list = nullptr, int nlist = 0,
+                             const FluxConsInput *from_cons = nullptr);
 int launch_fluxes_euler_hllc(const PackView &pv, int recon, double gamma, double c_h,
-                             hipStream_t s, int faces = 0, const int *face_list = nullptr, int nlist = 0);
+                             hipStream_t s, int faces = 0, const int *face_list = nullptr, int nlist = 0,
+                             const FluxConsInput *from_cons = nullptr);
 int launch_fluxes_mhd_hlle(const PackView &pv, int recon, double gamma, double c_h,
-                           hipStream_t s, int faces = 0, const int *face_list = nullptr, int nlist = 0);
+                           hipStream_t s, int faces = 0, const int *face_list = nullptr, int nlist = 0,
+                             const FluxConsInput *from_cons = nullptr);
 int launch_fluxes_mhd_hlld(const PackView &pv, int recon, double gamma, double c_h,
-                           hipStream_t s, int faces = 0, const int *face_list = nullptr, int nlist = 0);
+                           hipStream_t s, int faces = 0, const int *face_list = nullptr, int nlist = 0,
+                             const FluxConsInput *from_cons = nullptr);
 // (dc,none) and (dc,llf = CalculateFluxesTight) for both fluids
 int launch_fluxes_misc(const PackView &pv, int fluid, int riemann, double gamma, double c_h,
                        hipStream_t s);

@@ -239,14 +239,15 @@ void apk_pack_destroy(apk_pack *pack) {
 
 namespace {
 int calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos, double c_h, int faces,
-                     apk_stream_t stream, const int *face_list = nullptr, int nlist = 0) {
+                     apk_stream_t stream, const int *face_list = nullptr, int nlist = 0, const FluxConsInput *from_cons = nullptr) {
   if (!ctx || !md || !valid_eos(eos)) return set_err(ctx, APK_ERR_INVALID, "apk_calculate_fluxes: bad argument");
   int rc = check_cfg(ctx, md, cfg);
   if (rc != APK_OK) return rc;
   for (int d = 0; d < md->view.ndim; ++d)
     if (!md->have_flux[d]) return set_err(ctx, APK_ERR_INVALID, "pack has no flux arrays");
-  for (const auto &b : md->h_blocks)
-    if (!b.prim) return set_err(ctx, APK_ERR_INVALID, "block without prim pointer");
+  if (!from_cons)
+    for (const auto &b : md->h_blocks)
+      if (!b.prim) return set_err(ctx, APK_ERR_INVALID, "block without prim pointer");
   hipStream_t s = as_stream(stream);
   const PackView &pv = md->view;
   ScopedTiming timing(ctx, APK_T_FLUXES, s);
@@ -255,11 +256,11 @@ int calculate_fluxes(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const a
   if (cfg.riemann == APK_RS_NONE || cfg.riemann == APK_RS_LLF)
     rc = launch_fluxes_misc(pv, cfg.fluid, cfg.riemann, eos->gamma, c_h, s);
   else if (cfg.fluid == APK_FLUID_EULER)
-    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_euler_hlle(pv, cfg.recon, eos->gamma, c_h, s, faces, face_list, nlist)
-                                      : launch_fluxes_euler_hllc(pv, cfg.recon, eos->gamma, c_h, s, faces, face_list, nlist);
+    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_euler_hlle(pv, cfg.recon, eos->gamma, c_h, s, faces, face_list, nlist, from_cons)
+                                      : launch_fluxes_euler_hllc(pv, cfg.recon, eos->gamma, c_h, s, faces, face_list, nlist, from_cons);
   else
-    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_mhd_hlle(pv, cfg.recon, eos->gamma, c_h, s, faces, face_list, nlist)
-                                      : launch_fluxes_mhd_hlld(pv, cfg.recon, eos->gamma, c_h, s, faces, face_list, nlist);
+    rc = (cfg.riemann == APK_RS_HLLE) ? launch_fluxes_mhd_hlle(pv, cfg.recon, eos->gamma, c_h, s, faces, face_list, nlist, from_cons)
+                                      : launch_fluxes_mhd_hlld(pv, cfg.recon, eos->gamma, c_h, s, faces, face_list, nlist, from_cons);
   if (rc != APK_OK) return set_err(ctx, rc, "flux kernel launch failed", hipGetLastError());
   return APK_OK;
 }
@@ -284,6 +285,22 @@ int apk_calculate_fluxes_boundary_list(apk_ctx *ctx, const apk_pack *md, apk_flu
                                        double c_h, const int *faces, int nfaces, apk_stream_t stream) {
   if (!faces || nfaces < 0) return set_err(ctx, APK_ERR_INVALID, "apk_calculate_fluxes_boundary_list: bad argument");
   return calculate_fluxes(ctx, md, cfg, eos, c_h, 2, stream, faces, nfaces);
+}
+
+int apk_calculate_fluxes_boundary_list_from_cons(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos,
+                                                 double c_h, const int *faces, int nfaces, long long cons_delta,
+                                                 apk_stream_t stream) {
+  if (!faces || nfaces < 0 || !valid_eos(eos))
+    return set_err(ctx, APK_ERR_INVALID, "apk_calculate_fluxes_boundary_list_from_cons: bad argument");
+  // (the stencil cells are converted by the lean ConsToPrim, and nothing writes a floored value back)
+  if (!eos_is_lean(*eos) || eos->dfloor > 0.0 || eos->efloor > 0.0)
+    return set_err(ctx, APK_ERR_UNSUPPORTED, "apk_calculate_fluxes_boundary_list_from_cons: floors / ceilings need the stored primitives");
+  if (cfg.riemann == APK_RS_NONE || cfg.riemann == APK_RS_LLF)
+    return set_err(ctx, APK_ERR_UNSUPPORTED, "boundary-plane fluxes are not offered for the none / llf entries");
+  const StageConsts k = make_stage_consts(eos->gamma, c_h, *eos);
+  const FluxConsInput ci{(int64_t)cons_delta, *eos, k.eos_gm1, k.vceil_sq, k.pfloor_over_gm1};
+  const int rc = calculate_fluxes(ctx, md, cfg, eos, c_h, 2, stream, faces, nfaces, &ci);
+  return rc;
 }
 
 int apk_update_with_flux_divergence(apk_ctx *ctx, const apk_pack *u0, const apk_pack *u1,

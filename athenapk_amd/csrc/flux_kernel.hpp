@@ -82,9 +82,45 @@ APK_DEV void face_states(const double *c, int64_t st, double dx, int var, double
   }
 }
 
+// Boundary planes from the CONSERVED state (apk_calculate_fluxes_boundary_list_from_cons: a refined mesh whose stages
+// derive their input from the conserved state and store no primitives): the stencil cells are converted in registers by
+// the lean ConsToPrim -- the function the pass over the block would have applied: same bits.  `delta`: from a block's
+// cons array of the pack to the array that holds the input state (doubles; 0: the pack's own).
+// (struct FluxConsInput: apk_internal.hpp)
+template <int FLUID, int RECON>
+APK_DEV void face_states_from_cons(const double *c, int64_t sn, int64_t st, double dx, const FluxConsInput &ci,
+                                   double (&wl)[nvars<FLUID>()], double (&wr)[nvars<FLUID>()]) {
+  constexpr int NV = nvars<FLUID>();
+  constexpr int LO = (RECON == APK_RC_DC) ? -1 : ((RECON == APK_RC_PPM || RECON == APK_RC_WENOZ) ? -3 : -2);
+  constexpr int HI = (RECON == APK_RC_DC) ? 0 : ((RECON == APK_RC_PPM || RECON == APK_RC_WENOZ) ? 2 : 1);
+  double w[HI - LO + 1][NV];
+#pragma unroll
+  for (int m = LO; m <= HI; ++m) {
+    double u[NV], di;
+#pragma unroll
+    for (int n = 0; n < NV; ++n) u[n] = c[n * sn + m * st];
+    (void)cons_to_prim_core<FLUID, 1>(ci.eos, ci.eos_gm1, ci.vceil_sq, ci.pfloor_over_gm1, u, w[m - LO], di);
+  }
+  double dummy;
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    if constexpr (RECON == APK_RC_DC) {
+      wl[n] = w[0][n];
+      wr[n] = w[1][n];
+    } else if constexpr (RECON == APK_RC_PPM || RECON == APK_RC_WENOZ) {
+      reconstruct<RECON>(w[0][n], w[1][n], w[2][n], w[3][n], w[4][n], dx, n, wl[n], dummy);
+      reconstruct<RECON>(w[1][n], w[2][n], w[3][n], w[4][n], w[5][n], dx, n, dummy, wr[n]);
+    } else {
+      reconstruct<RECON>(0.0, w[0][n], w[1][n], w[2][n], 0.0, dx, n, wl[n], dummy);
+      reconstruct<RECON>(0.0, w[1][n], w[2][n], w[3][n], 0.0, dx, n, dummy, wr[n]);
+    }
+  }
+}
+
 // the flux through the lower DIR-face of cell (k, j, i) of one block
-template <int FLUID, int RECON, int RS, int DIR>
-APK_DEV void flux_face(const PackView &pv, const apk_block_desc &blk, int i, int j, int k, double gamma, double c_h) {
+template <int FLUID, int RECON, int RS, int DIR, bool FROM_CONS = false>
+APK_DEV void flux_face(const PackView &pv, const apk_block_desc &blk, int i, int j, int k, double gamma, double c_h,
+                       const FluxConsInput *ci = nullptr) {
   constexpr int NV = nvars<FLUID>();
   const int64_t st = (DIR == 1) ? 1 : ((DIR == 2) ? pv.sj : pv.sk);
   const int64_t cell = k * pv.sk + j * pv.sj + i;
@@ -92,8 +128,12 @@ APK_DEV void flux_face(const PackView &pv, const apk_block_desc &blk, int i, int
   const double dx = blk.dx[DIR - 1];
 
   double wln[NV], wrn[NV];  // natural order
+  if constexpr (FROM_CONS) {
+    face_states_from_cons<FLUID, RECON>(blk.cons + ci->delta + cell, pv.sn, st, dx, *ci, wln, wrn);
+  } else {
 #pragma unroll
-  for (int n = 0; n < NV; ++n) face_states<RECON>(p + n * pv.sn, st, dx, n, wln[n], wrn[n]);
+    for (int n = 0; n < NV; ++n) face_states<RECON>(p + n * pv.sn, st, dx, n, wln[n], wrn[n]);
+  }
 
   double wl[NV], wr[NV], f[NV];  // direction-permuted order
 #pragma unroll
@@ -152,9 +192,9 @@ inline void launch_flux_dir(const PackView &pv, const FluxExtent &e, double gamm
 // face = {x1 lower, x1 upper, x2 lower, ...} -- on a refined mesh the faces with a coarser or finer
 // block behind them, a fraction of all faces, and six launches of a few dozen small planes each
 // would run at the launch-latency floor.
-template <int FLUID, int RECON, int RS>
+template <int FLUID, int RECON, int RS, bool FROM_CONS = false>
 __global__ void __launch_bounds__(256)
-flux_planes_kernel(PackView pv, const int *faces, double gamma, double c_h) {
+flux_planes_kernel(PackView pv, const int *faces, double gamma, double c_h, FluxConsInput ci) {
   const int code = faces[blockIdx.y];
   const int b = code / 6, f = code - 6 * b, dir = f / 2 + 1, side = f & 1;
   const int na = (dir == 1) ? pv.nx2 : pv.nx1;
@@ -163,9 +203,9 @@ flux_planes_kernel(PackView pv, const int *faces, double gamma, double c_h) {
   const int a1 = t / na, a0 = t - a1 * na;
   if (a1 >= nb) return;
   const apk_block_desc blk = pv.blocks[b];
-  if (dir == 1) flux_face<FLUID, RECON, RS, 1>(pv, blk, side ? pv.ie + 1 : pv.is, pv.js + a0, pv.ks + a1, gamma, c_h);
-  else if (dir == 2) flux_face<FLUID, RECON, RS, 2>(pv, blk, pv.is + a0, side ? pv.je + 1 : pv.js, pv.ks + a1, gamma, c_h);
-  else flux_face<FLUID, RECON, RS, 3>(pv, blk, pv.is + a0, pv.js + a1, side ? pv.ke + 1 : pv.ks, gamma, c_h);
+  if (dir == 1) flux_face<FLUID, RECON, RS, 1, FROM_CONS>(pv, blk, side ? pv.ie + 1 : pv.is, pv.js + a0, pv.ks + a1, gamma, c_h, &ci);
+  else if (dir == 2) flux_face<FLUID, RECON, RS, 2, FROM_CONS>(pv, blk, pv.is + a0, side ? pv.je + 1 : pv.js, pv.ks + a1, gamma, c_h, &ci);
+  else flux_face<FLUID, RECON, RS, 3, FROM_CONS>(pv, blk, pv.is + a0, pv.js + a1, side ? pv.ke + 1 : pv.ks, gamma, c_h, &ci);
 }
 
 // which faces a flux call covers
@@ -199,7 +239,9 @@ inline void launch_flux_faces(const PackView &pv, double gamma, double c_h, hipS
 // face_list != NULL (with faces == FLUX_FACES_BOUNDARY): only the listed (block, face) planes, one launch
 template <int FLUID, int RECON, int RS>
 inline int launch_flux_all_dirs(const PackView &pv, double gamma, double c_h, hipStream_t s,
-                                int faces = FLUX_FACES_REFERENCE, const int *face_list = nullptr, int nlist = 0) {
+                                int faces = FLUX_FACES_REFERENCE, const int *face_list = nullptr, int nlist = 0,
+                                const FluxConsInput *from_cons = nullptr) {
+  if (from_cons && !face_list) return APK_ERR_UNSUPPORTED;
   if (face_list) {
     if (faces != FLUX_FACES_BOUNDARY) return APK_ERR_UNSUPPORTED;
     if (nlist <= 0) return APK_OK;
@@ -208,8 +250,14 @@ inline int launch_flux_all_dirs(const PackView &pv, double gamma, double c_h, hi
     if ((int64_t)pv.nx2 * pv.nx3 > plane) plane = (int64_t)pv.nx2 * pv.nx3;
     for (int off = 0; off < nlist; off += 65535) {  // gridDim.y is limited to 65535
       const int m = (nlist - off > 65535) ? 65535 : nlist - off;
-      hipLaunchKernelGGL((flux_planes_kernel<FLUID, RECON, RS>), dim3((unsigned)((plane + 255) / 256), (unsigned)m, 1), dim3(256), 0, s,
-                         pv, face_list + off, gamma, c_h);
+      const dim3 grid((unsigned)((plane + 255) / 256), (unsigned)m, 1);
+      if (from_cons) {
+        // (passive scalars ride the stored primitives' arrays: not offered)
+        if (pv.nvar != nvars<FLUID>()) return APK_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((flux_planes_kernel<FLUID, RECON, RS, true>), grid, dim3(256), 0, s, pv, face_list + off, gamma, c_h, *from_cons);
+      } else {
+        hipLaunchKernelGGL((flux_planes_kernel<FLUID, RECON, RS, false>), grid, dim3(256), 0, s, pv, face_list + off, gamma, c_h, FluxConsInput{});
+      }
     }
     return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
   }
@@ -222,14 +270,15 @@ inline int launch_flux_all_dirs(const PackView &pv, double gamma, double c_h, hi
 // recon dispatch for one (fluid, riemann) family: the registry of hydro.cpp:386-416
 template <int FLUID, int RS>
 inline int launch_flux_family(const PackView &pv, int recon, double gamma, double c_h,
-                              hipStream_t s, int faces, const int *face_list = nullptr, int nlist = 0) {
+                              hipStream_t s, int faces, const int *face_list = nullptr, int nlist = 0,
+                              const FluxConsInput *from_cons = nullptr) {
   switch (recon) {
-  case APK_RC_DC: return launch_flux_all_dirs<FLUID, APK_RC_DC, RS>(pv, gamma, c_h, s, faces, face_list, nlist);
-  case APK_RC_PLM: return launch_flux_all_dirs<FLUID, APK_RC_PLM, RS>(pv, gamma, c_h, s, faces, face_list, nlist);
-  case APK_RC_PPM: return launch_flux_all_dirs<FLUID, APK_RC_PPM, RS>(pv, gamma, c_h, s, faces, face_list, nlist);
-  case APK_RC_WENOZ: return launch_flux_all_dirs<FLUID, APK_RC_WENOZ, RS>(pv, gamma, c_h, s, faces, face_list, nlist);
-  case APK_RC_WENO3: return launch_flux_all_dirs<FLUID, APK_RC_WENO3, RS>(pv, gamma, c_h, s, faces, face_list, nlist);
-  case APK_RC_LIMO3: return launch_flux_all_dirs<FLUID, APK_RC_LIMO3, RS>(pv, gamma, c_h, s, faces, face_list, nlist);
+  case APK_RC_DC: return launch_flux_all_dirs<FLUID, APK_RC_DC, RS>(pv, gamma, c_h, s, faces, face_list, nlist, from_cons);
+  case APK_RC_PLM: return launch_flux_all_dirs<FLUID, APK_RC_PLM, RS>(pv, gamma, c_h, s, faces, face_list, nlist, from_cons);
+  case APK_RC_PPM: return launch_flux_all_dirs<FLUID, APK_RC_PPM, RS>(pv, gamma, c_h, s, faces, face_list, nlist, from_cons);
+  case APK_RC_WENOZ: return launch_flux_all_dirs<FLUID, APK_RC_WENOZ, RS>(pv, gamma, c_h, s, faces, face_list, nlist, from_cons);
+  case APK_RC_WENO3: return launch_flux_all_dirs<FLUID, APK_RC_WENO3, RS>(pv, gamma, c_h, s, faces, face_list, nlist, from_cons);
+  case APK_RC_LIMO3: return launch_flux_all_dirs<FLUID, APK_RC_LIMO3, RS>(pv, gamma, c_h, s, faces, face_list, nlist, from_cons);
   default: return APK_ERR_UNSUPPORTED;
   }
 }

@@ -4,7 +4,7 @@
 
 namespace apk {
 int launch_fluxes_mhd_hlld(const PackView &pv, int recon, double gamma, double c_h,
-                          hipStream_t s, int faces, const int *face_list, int nlist) {
-  return launch_flux_family<APK_FLUID_GLMMHD, APK_RS_HLLD>(pv, recon, gamma, c_h, s, faces, face_list, nlist);
+                          hipStream_t s, int faces, const int *face_list, int nlist, const FluxConsInput *from_cons) {
+  return launch_flux_family<APK_FLUID_GLMMHD, APK_RS_HLLD>(pv, recon, gamma, c_h, s, faces, face_list, nlist, from_cons);
 }
 }  // namespace apk

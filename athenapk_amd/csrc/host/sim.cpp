@@ -626,6 +626,25 @@ bool rk_prim_free_cycle(const apk_sim *s) {
   return apk_stage_split_axis(s->mu0(), &pkg.flux_first_stage, 0) == 3 && apk_stage_split_axis(s->mu0(), &pkg.flux_other_stage, 0) == 3;
 }
 
+// Refined meshes, VL2 with a high-order corrector in the two-kernel form (BASELINE config 5): may the corrector derive
+// its input from the half-step CONSERVED state (apk_stage_args.prim_from_cons = 2) -- so that no ConsToPrim pass runs
+// between the two stages, 38 of 810 us per cycle on config 5's mesh -- and the flux correction's boundary planes likewise
+// (apk_calculate_fluxes_boundary_list_from_cons)?  The corrector's result goes over the register u1, cell by cell the
+// value the lane has just read, and the two buffers swap roles.  No floors or ceilings (the in-register ConsToPrim is
+// the lean one and writes nothing back), no passive scalars, no forcing.  apk_sim_set_prim_free(0) / APK_AMR_PRIM_FREE=0
+// switch it off (A/B).
+bool amr_prim_free_cycle(const apk_sim *s) {
+  static const int mode = std::getenv("APK_AMR_PRIM_FREE") ? std::atoi(std::getenv("APK_AMR_PRIM_FREE")) : 1;
+  const HydroPackage &pkg = s->pkg;
+  if (!mode || !s->prim_free_on || !s->amr || s->fmft || s->mesh.ndim != 3 || !stage_can_fuse(s) || !amr_faces_only(s)) return false;
+  if (pkg.nscalars != 0 || (pkg.fluid == APK_FLUID_GLMMHD && pkg.glmmhd_source_extended)) return false;
+  const apk_eos &e = pkg.eos;
+  if (!(e.vceil > 1.0e300 && e.eceil > 1.0e300 && e.pfloor <= 0.0 && e.dfloor <= 0.0 && e.efloor <= 0.0)) return false;
+  if (pkg.flux_first_stage.recon != APK_RC_DC || pkg.flux_other_stage.recon == APK_RC_DC || s->nstages != 2) return false;
+  if (s->gam0[1] != 0.0) return false;  // (the corrector must not read the old u0: VL2)
+  return apk_stage_split_axis(s->mu0(), &pkg.flux_other_stage, 0) == 3 && apk_stage_split_axis(s->mu0(), &pkg.flux_other_stage, 2) == 3;
+}
+
 // May the exchange at the end of a cycle deliver ONE layer of ghost cells (mesh.hpp PH_PACK_THIN)?  The first stage of the
 // next cycle must be the single-march donor-cell stage (it reads one layer; the corrector's exchange stays a full one),
 // nothing else in a cycle may read ghost zones (no forcing, no refinement), and the box must be periodic: a physical
@@ -1101,6 +1120,13 @@ int do_stage(apk_sim *s, int stage) {
       a.prim_from_cons = 2;
       a.cons_out_delta = s->d_cons2[outbuf] - s->d_cons2[s->cur];
     }
+    // (refined meshes: the corrector from the half-step conserved state, over u1 -- amr_prim_free_cycle)
+    const bool amr_fc = s->amr && stage == 2 && two_kernel && a.fill_derived == 0 && amr_prim_free_cycle(s);
+    if (amr_fc) {
+      outbuf = s->u1buf;
+      a.prim_from_cons = 2;
+      a.cons_out_delta = s->d_cons2[outbuf] - s->d_cons2[s->cur];
+    }
     {
       // The predictor of VL2: the corrector has gam0 = 0 and takes its fluxes from the predictor's primitives, so the
       // half-step CONSERVED state is read by nobody but the ghost exchange -- the nghost-deep shell of every block --
@@ -1191,7 +1217,7 @@ int do_stage(apk_sim *s, int stage) {
     bool planes_ahead = false;
     if (s->amr && a.fill_derived == 0) {
       SIM_TRY(s, ensure_flux_arrays(s));
-      planes_ahead = amr_flux_planes_ahead(s, cfg);
+      planes_ahead = amr_flux_planes_ahead(s, cfg, amr_fc);
     }
     {
       const int rc_stage = apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream);
@@ -1210,11 +1236,16 @@ int do_stage(apk_sim *s, int stage) {
       s->prim_stale = false;
       if (swap_prim) s->pcur = 1 - s->pcur;
     }
-    s->cur = outbuf;  // (its ghost zones are filled by the exchange below)
-    if (s->amr) {
-      SIM_TRY(s, ensure_flux_arrays(s));
-      const double psi_factor = a.dedner != 0 ? std::exp(-pkg.glmmhd_alpha * pkg.c_h * beta_dt / pkg.mindx) : 1.0;
-      SIM_TRY(s, amr_flux_fix(s, cfg, beta_dt, psi_factor, planes_ahead));
+    {
+      const int inbuf = s->cur;
+      s->cur = outbuf;  // (its ghost zones are filled by the exchange below)
+      if (amr_fc) s->u1buf = inbuf;  // (the half-step state: scratch from here on)
+      if (s->amr) {
+        SIM_TRY(s, ensure_flux_arrays(s));
+        const double psi_factor = a.dedner != 0 ? std::exp(-pkg.glmmhd_alpha * pkg.c_h * beta_dt / pkg.mindx) : 1.0;
+        // (boundary planes not computed beside the stage: from the state the stage read -- now the register's buffer)
+        SIM_TRY(s, amr_flux_fix(s, cfg, beta_dt, psi_factor, planes_ahead, amr_fc ? inbuf : -1));
+      }
     }
   } else {
     // first_order_flux_correct and a stage that does not read the old u0 (gam0 = 0: every VL2 stage,
@@ -1340,6 +1371,9 @@ int do_stage(apk_sim *s, int stage) {
     if (stage == s->nstages && pkg.calc_dt_hyp) {  // (the time-step estimate on the way, as below)
       SIM_TRY(s, apk_cons_to_prim_faces_dt(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, dir ? s->d_face_nbr : nullptr, s->stream));
       s->stage_dt_pending = true;
+    } else if (stage == 1 && amr_prim_free_cycle(s)) {
+      // (the corrector converts what it loads: no pass over the blocks here)
+      s->amr_c2p_passes_skipped += 1;
     } else if (dir) {
       SIM_TRY(s, apk_cons_to_prim_faces_skip(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, s->d_face_nbr, s->stream));
     } else {
@@ -1597,6 +1631,7 @@ int apk_sim_set_overlap(apk_sim *s, int overlap) {
 
 long long apk_sim_overlapped_exchanges(const apk_sim *s) { return s ? s->overlapped : 0; }
 long long apk_sim_skipped_local_exchanges(const apk_sim *s) { return s ? s->skipped_local_exchanges : 0; }
+long long apk_sim_amr_c2p_passes_skipped(const apk_sim *s) { return s ? s->amr_c2p_passes_skipped : 0; }
 int apk_sim_set_direct_neighbors(apk_sim *s, int on) {
   if (!s) return APK_ERR_INVALID;
   if (!s->host_only) SIM_TRY(s, sync_ghosts(s));

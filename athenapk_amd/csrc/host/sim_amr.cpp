@@ -694,7 +694,7 @@ bool amr_has_coarse_fine_faces(const apk_sim *s) {
 // slots the marches leave empty (a pack of a few hundred 16^3 blocks fills 80 % of them; by themselves the few hundred
 // planes are one wave each and take 25 us of latency per stage).  Returns whether they were launched; amr_flux_fix then
 // waits for them instead of computing them.  The caller has the flux arrays in place (ensure_flux_arrays).
-bool amr_flux_planes_ahead(apk_sim *s, const apk_flux_cfg &cfg) {
+bool amr_flux_planes_ahead(apk_sim *s, const apk_flux_cfg &cfg, bool from_cons) {
   static const bool off = std::getenv("APK_AMR_PLANES_INLINE") != nullptr;  // A/B switch
   if (off || s->side_stream_failed || !amr_has_coarse_fine_faces(s)) return false;
   auto &a = s->amr_dev;
@@ -716,8 +716,11 @@ bool amr_flux_planes_ahead(apk_sim *s, const apk_flux_cfg &cfg) {
   hipStream_t side = reinterpret_cast<hipStream_t>(s->side_stream);
   if (hipEventRecord(reinterpret_cast<hipEvent_t>(s->ev_fork), hs(s)) != hipSuccess) return false;
   if (hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(s->ev_fork), 0) != hipSuccess) return false;
-  const int rc = apk_calculate_fluxes_boundary_list(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, a.d_cf_faces, a.n_cf_faces,
-                                                    reinterpret_cast<apk_stream_t>(side));
+  // (from_cons: the stage's input is the conserved state of the pack's own blocks -- prim_from_cons = 2)
+  const int rc = from_cons ? apk_calculate_fluxes_boundary_list_from_cons(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, a.d_cf_faces,
+                                                                          a.n_cf_faces, 0, reinterpret_cast<apk_stream_t>(side))
+                           : apk_calculate_fluxes_boundary_list(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, a.d_cf_faces, a.n_cf_faces,
+                                                                reinterpret_cast<apk_stream_t>(side));
   // (whatever was enqueued is joined either way: through the event -- by amr_flux_fix, or by do_stage if the stage fails
   // in between -- or, if the event cannot be recorded, by waiting for the side stream here)
   if (hipEventRecord(reinterpret_cast<hipEvent_t>(s->ev_join), side) != hipSuccess) {
@@ -731,12 +734,16 @@ bool amr_flux_planes_ahead(apk_sim *s, const apk_flux_cfg &cfg) {
   return true;
 }
 
-int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi_factor, bool planes_ahead) {
+int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi_factor, bool planes_ahead, int cons_input) {
   if (!amr_has_coarse_fine_faces(s)) return APK_OK;
   auto &a = s->amr_dev;
   const int psi_var = (s->pkg.fluid == APK_FLUID_GLMMHD) ? 8 : -1;
   if (planes_ahead) {
     SIM_HIP(s, hipStreamWaitEvent(hs(s), reinterpret_cast<hipEvent_t>(s->ev_join), 0));
+  } else if (cons_input >= 0) {
+    // (the stage derived its input from the conserved state in buffer `cons_input`: so do the planes)
+    SIM_TRY(s, apk_calculate_fluxes_boundary_list_from_cons(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, a.d_cf_faces, a.n_cf_faces,
+                                                            (long long)(s->d_cons2[cons_input] - s->d_cons2[s->cur]), s->stream));
   } else {
     SIM_TRY(s, apk_calculate_fluxes_boundary_list(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, a.d_cf_faces, a.n_cf_faces, s->stream));
   }

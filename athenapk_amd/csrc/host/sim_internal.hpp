@@ -84,6 +84,7 @@ bool can_overlap_next(const apk_sim *s, int next);
 int finish_pending(apk_sim *s);
 bool direct_neighbors(const apk_sim *s);
 bool amr_faces_only(const apk_sim *s);
+bool amr_prim_free_cycle(const apk_sim *s);
 bool regrid_check_follows(const apk_sim *s);
 int materialize_local_ghosts(apk_sim *s, int buf = -1);
 int sync_ghosts(apk_sim *s);  // finish_pending + materialize_local_ghosts
@@ -135,8 +136,8 @@ int amr_exchange_post(apk_sim *s, int buf, int mode);
 void amr_capture_half(apk_sim *s, int buf, bool pre, int mode, void **out, bool whole = false);
 void amr_destroy_graphs(apk_sim *s);
 bool amr_has_coarse_fine_faces(const apk_sim *s);
-int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi_factor, bool planes_ahead = false);
-bool amr_flux_planes_ahead(apk_sim *s, const apk_flux_cfg &cfg);
+int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi_factor, bool planes_ahead = false, int cons_input = -1);
+bool amr_flux_planes_ahead(apk_sim *s, const apk_flux_cfg &cfg, bool from_cons = false);
 int amr_flux_correction(apk_sim *s);
 int refinement_criterion(apk_sim *s, int *criterion, double *p0, double *p1);
 bool amr_update_tree(apk_sim *s, const std::vector<int> &tags, bool allow_derefine);

@@ -414,6 +414,10 @@ class Simulation(_FmftHost, _MeshView):
     def skipped_local_exchanges(self):
         return self.lib.apk_sim_skipped_local_exchanges(self.h)
 
+    def amr_c2p_passes_skipped(self):
+        """ConsToPrim passes between the stages a refined mesh did without (apk_sim_amr_c2p_passes_skipped)"""
+        return self.lib.apk_sim_amr_c2p_passes_skipped(self.h)
+
     def thin_exchanges(self):
         """one-layer exchanges so far (apk_sim_set_thin_exchange)"""
         return self.lib.apk_sim_thin_exchanges(self.h)

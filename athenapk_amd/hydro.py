@@ -199,12 +199,21 @@ class CopyPlan:
 
 
 # ---- the task functions ---------------------------------------------------------------------
-def CalculateFluxes(md, fluid, recon, riemann, eos, c_h=0.0, tight=False, boundary=False, face_list=None):
+def CalculateFluxes(md, fluid, recon, riemann, eos, c_h=0.0, tight=False, boundary=False, face_list=None, from_cons=None):
     """Hydro::CalculateFluxes<fluid,recon,rsolver>(md)  -- src/hydro/hydro.cpp:1025; tight: only the
     faces of interior cells (the loop limits of CalculateFluxesTight, hydro.cpp:1006-1009); boundary:
     only the 2 ndim block-boundary planes (for the flux correction after a fused stage), with face_list
-    (int32 CUDA tensor of 6 * block + face codes) only the listed planes, in one launch"""
+    (int32 CUDA tensor of 6 * block + face codes) only the listed planes, in one launch; from_cons (with
+    face_list): a MeshData of the same shape whose CONSERVED state is the input, converted in registers
+    (apk_calculate_fluxes_boundary_list_from_cons) -- md itself for its own state"""
     ctx = md.ctx
+    if from_cons is not None:
+        assert boundary and face_list is not None and face_list.dtype == torch.int32 and face_list.is_cuda and face_list.dim() == 1
+        delta = (from_cons.cons.data_ptr() - md.cons.data_ptr()) // 8
+        _check(ctx.lib.apk_calculate_fluxes_boundary_list_from_cons(ctx.h, md.h, _cfg(fluid, recon, riemann), C.byref(eos), float(c_h),
+                                                                    face_list.data_ptr(), int(face_list.numel()), int(delta), _stream()),
+               ctx.lib, ctx.h)
+        return
     if face_list is not None:
         assert boundary and face_list.dtype == torch.int32 and face_list.is_cuda and face_list.dim() == 1
         _check(ctx.lib.apk_calculate_fluxes_boundary_list(ctx.h, md.h, _cfg(fluid, recon, riemann), C.byref(eos), float(c_h),

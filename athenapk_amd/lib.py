@@ -164,6 +164,7 @@ def _signatures():
         "apk_calculate_fluxes_tight": (i, [vp, vp, FluxCfg, E, d, vp]),
         "apk_calculate_fluxes_boundary": (i, [vp, vp, FluxCfg, E, d, vp]),
         "apk_calculate_fluxes_boundary_list": (i, [vp, vp, FluxCfg, E, d, vp, C.c_int, vp]),
+        "apk_calculate_fluxes_boundary_list_from_cons": (i, [vp, vp, FluxCfg, E, d, vp, C.c_int, C.c_longlong, vp]),
         "apk_flux_fix_plan_create": (i, [vp, C.POINTER(FluxFixRegion), i, pp]),
         "apk_flux_fix_plan_create_merged": (i, [vp, C.POINTER(FluxFixRegion), C.POINTER(C.c_int), vp, C.c_int64, pp]),
         "apk_flux_fix_plan_destroy": (None, [vp]),
@@ -235,6 +236,7 @@ def _signatures():
         "apk_sim_set_overlap": (i, [vp, i]),
         "apk_sim_overlapped_exchanges": (ll, [vp]),
         "apk_sim_skipped_local_exchanges": (ll, [vp]),
+        "apk_sim_amr_c2p_passes_skipped": (ll, [vp]),
         "apk_sim_set_thin_exchange": (i, [vp, i]),
         "apk_sim_thin_exchanges": (ll, [vp]),
         "apk_sim_set_x1_direct": (i, [vp, i]),

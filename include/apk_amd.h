@@ -151,6 +151,15 @@ int apk_calculate_fluxes_boundary(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg
  * flux is what the average replaces); the planes of unlisted faces are left untouched. */
 int apk_calculate_fluxes_boundary_list(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos,
                                        double c_h, const int *faces, int nfaces, apk_stream_t stream);
+/* The same with the stencil cells taken from the CONSERVED state and converted in registers (the ConsToPrim the pass
+ * over the blocks applies, adiabatic_hydro.hpp:61-169, without its floor / ceiling blocks: eos without dfloor, efloor,
+ * pfloor, vceil, eceil only -- APK_ERR_UNSUPPORTED otherwise; no passive scalars): for cycles of a refined mesh whose
+ * stages derive their input from the conserved state (apk_stage_args.prim_from_cons) and store no primitives.
+ * cons_delta: offset in doubles from a block's `cons` array of the pack to the array that holds the input state (0: the
+ * pack's own -- the stage's u0 --; the distance to u1's array for a stage whose input is u1). */
+int apk_calculate_fluxes_boundary_list_from_cons(apk_ctx *ctx, const apk_pack *md, apk_flux_cfg cfg, const apk_eos *eos,
+                                                 double c_h, const int *faces, int nfaces, long long cons_delta,
+                                                 apk_stream_t stream);
 
 /* Replaces parthenon::Update::UpdateWithFluxDivergence<MeshData<Real>>(u0,u1,gam0,gam1,
  * beta_dt); call site src/hydro/hydro_driver.cpp:534-537.

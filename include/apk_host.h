@@ -118,6 +118,13 @@ long long apk_sim_overlapped_exchanges(const apk_sim *sim);
  * switches it off.  Returns the number of stage boundaries so far whose same-rank copies were skipped. */
 long long apk_sim_skipped_local_exchanges(const apk_sim *sim);
 int apk_sim_set_direct_neighbors(apk_sim *sim, int on); /* 1 (default) / 0 = always copy */
+/* Refined meshes, VL2 with a high-order corrector in the two-kernel form, default equation-of-state limits, no passive
+ * scalars: the corrector derives its input from the half-step conserved state (apk_stage_args.prim_from_cons = 2, its
+ * result over the register u1) and the flux correction's boundary planes likewise
+ * (apk_calculate_fluxes_boundary_list_from_cons), so that no ConsToPrim pass runs between the two stages.  Results are
+ * identical.  apk_sim_set_prim_free(sim, 0) / APK_AMR_PRIM_FREE=0 in the environment switch it off.  Returns the number
+ * of passes done without. */
+long long apk_sim_amr_c2p_passes_skipped(const apk_sim *sim);
 /* Full-step primitives kept out of memory (on by default where it applies: uniform 3-D meshes, VL2 -- a donor-cell
  * predictor followed by a two-kernel stage --, default equation-of-state limits, no passive scalars, no extended Dedner
  * source, no forcing): the last stage of a cycle computes the primitives of the new state for the time-step estimate

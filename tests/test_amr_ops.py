@@ -323,6 +323,43 @@ def test_boundary_plane_fluxes_equal_the_full_sweeps(request, fluid, recon, riem
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("fluid,recon,riemann,ng", [("euler", "plm", "hllc", 2), ("euler", "dc", "hlle", 2), ("glmmhd", "ppm", "hlld", 4),
+                                                    ("glmmhd", "dc", "hlld", 4), ("glmmhd", "wenoz", "hlle", 3)])
+def test_boundary_plane_fluxes_from_the_conserved_state(request, strict, fluid, recon, riemann, ng):
+    """apk_calculate_fluxes_boundary_list_from_cons: the listed planes from the conserved state of the pack itself or of
+    another one, equal to the planes from the primitives ConsToPrim stores (parity build: bit for bit); floors refuse"""
+    import torch
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    nx, nb = (16, 8, 8), 3
+    nh = 9 if fluid == "glmmhd" else 5
+    gamma = 5.0 / 3.0
+    prim = H.random_prim(fluid, nx, ng, seed=21, kind="smooth", nblocks=nb)
+    cons = np.stack([H.prim_to_cons(fluid, prim[b], gamma) for b in range(nb)])
+    eos = hydro.L.make_eos(gamma)
+    ref = hydro.MeshData(ctx, nx, ng, nh, dx=(0.1, 0.2, 0.3), nblocks=nb, cons=cons)
+    hydro.ConservedToPrimitive(ref, fluid, eos)
+    codes = torch.tensor([6 * blk + f for blk in range(nb) for f in range(6) if (blk + f) % 2 == 0], dtype=torch.int32, device="cuda")
+    hydro.CalculateFluxes(ref, fluid, recon, riemann, eos, 1.3, boundary=True, face_list=codes)
+    own = hydro.MeshData(ctx, nx, ng, nh, dx=(0.1, 0.2, 0.3), nblocks=nb, cons=cons, prim=np.full_like(cons, np.nan))
+    hydro.CalculateFluxes(own, fluid, recon, riemann, eos, 1.3, boundary=True, face_list=codes, from_cons=own)
+    other = hydro.MeshData(ctx, nx, ng, nh, dx=(0.1, 0.2, 0.3), nblocks=nb, cons=np.full_like(cons, np.nan), prim=np.full_like(cons, np.nan))
+    hydro.CalculateFluxes(other, fluid, recon, riemann, eos, 1.3, boundary=True, face_list=codes, from_cons=own)
+    for d in range(3):
+        want = ref.flux_host(d)
+        assert np.abs(want).max() > 0
+        for got in (own.flux_host(d), other.flux_host(d)):
+            if strict:
+                assert np.array_equal(got, want)
+            else:
+                np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13)
+    floored = hydro.L.make_eos(gamma, pfloor=1e-9)
+    with pytest.raises(hydro.L.ApkError):
+        hydro.CalculateFluxes(own, fluid, recon, riemann, floored, 1.3, boundary=True, face_list=codes, from_cons=own)
+
+
+@pytest.mark.gpu
 def test_flux_fix_plan_against_numpy(request):
     """cons += beta_dt * scale * (fine_avg - coarse_flux), psi scaled by its damping factor; strided
     sources (a message buffer laid out compactly) and destinations (a plane inside a block)"""

@@ -684,7 +684,14 @@ def test_face_table_on_a_refined_mesh_changes_nothing(case, bc, strict):
         "parthenon/mesh/derefine_count=2", "problem/blast/pressure_ambient=1.0", "problem/blast/pressure_ratio=1000",
         "problem/blast/radius_outer=0.1", "problem/blast/radius_inner=0.05", "refinement/threshold_pressure_gradient=0.5"]
     ov += _bc(bc)  # (periodic: two root blocks per direction -- the block behind the lower and the upper face is the same one)
-    a = _sim("blast_3d_amr", ov, strict=strict).initialize()
+    a = _sim("blast_3d_amr", ov, strict=strict)
+    # (VL2: `a` would also run its corrector from the conserved state, apk_sim_amr_c2p_passes_skipped, which the run
+    # with complete exchanges does not -- the same bits in the parity build, and the comparison there covers it; in the
+    # product build the two forms of ConsToPrim contract differently, so there both runs keep the pass:
+    # test_refined_mesh_corrector_from_the_conserved_state compares the two forms)
+    if not strict:
+        a.set_prim_free(False)
+    a.initialize()
     b = _sim("blast_3d_amr", ov, strict=strict)
     b.set_direct_neighbors(False)
     b.set_amr_full_exchange(True)
@@ -701,11 +708,56 @@ def test_face_table_on_a_refined_mesh_changes_nothing(case, bc, strict):
         sizes.add(a.refresh_info().nblocks_total)
     assert len(sizes) > 1, "the mesh never changed (%s)" % sorted(sizes)
     assert a.skipped_local_exchanges() > 0 and b.skipped_local_exchanges() == 0
+    assert (a.amr_c2p_passes_skipped() > 0) == (strict and integrator == "vl2") and b.amr_c2p_passes_skipped() == 0
     pa, pb = placement(a), placement(b)
     assert [(p[0], tuple(p[1])) for p in pa] == [(p[0], tuple(p[1])) for p in pb]
     for lb in range(len(pa)):
         for field in ("cons", "prim"):
             assert np.array_equal(a.read_block(lb, field), b.read_block(lb, field)), "%s of block %d" % (field, lb)
+
+
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("bc", ["outflow", "periodic"])
+def test_refined_mesh_corrector_from_the_conserved_state(bc, strict):
+    """VL2 on a refined mesh (BASELINE config 5's scheme): the corrector derives its input from the half-step conserved
+    state and writes over the register u1, the flux correction's boundary planes come from the conserved state as well,
+    and no ConsToPrim pass runs between the stages (apk_sim_amr_c2p_passes_skipped) -- against the run that keeps the
+    pass (apk_sim_set_prim_free(0)): forest, time steps and every cell bit for bit in the parity build, to round-off in
+    the product build (the in-register ConsToPrim contracts differently); regridding on the way."""
+    ov = ["parthenon/meshblock/nx%d=16" % d for d in (1, 2, 3)] + [
+        "parthenon/mesh/nghost=4", "hydro/fluid=glmmhd", "hydro/riemann=hlld", "hydro/reconstruction=ppm",
+        "parthenon/time/integrator=vl2", "parthenon/mesh/check_refine_interval=2",
+        "parthenon/mesh/derefine_count=2", "problem/blast/pressure_ambient=1.0", "problem/blast/pressure_ratio=1000",
+        "problem/blast/radius_outer=0.1", "problem/blast/radius_inner=0.05", "refinement/threshold_pressure_gradient=0.5"]
+    ov += _bc(bc)
+    a = _sim("blast_3d_amr", ov, strict=strict).initialize()
+    b = _sim("blast_3d_amr", ov, strict=strict)
+    b.set_prim_free(False)
+    b.initialize()
+    rng = np.random.default_rng(11)
+    sizes = set()
+    for cyc in range(10):
+        if cyc in (3, 6):
+            tags = rng.choice([1, 0, 0, -1, -1], size=a.refresh_info().nblocks_total)
+            assert a.apply_tags(tags) and b.apply_tags(tags)
+        a.step()
+        b.step()
+        if strict:
+            assert a.dt == b.dt and a.time == b.time, cyc
+        else:
+            assert abs(a.dt - b.dt) <= 1e-12 * b.dt, cyc
+        sizes.add(a.refresh_info().nblocks_total)
+    assert len(sizes) > 1, "the mesh never changed (%s)" % sorted(sizes)
+    assert a.amr_c2p_passes_skipped() == 10 and b.amr_c2p_passes_skipped() == 0
+    pa, pb = placement(a), placement(b)
+    assert [(p[0], tuple(p[1])) for p in pa] == [(p[0], tuple(p[1])) for p in pb]
+    for lb in range(len(pa)):
+        for field in ("cons", "prim"):
+            x, y = a.read_block(lb, field), b.read_block(lb, field)
+            if strict:
+                assert np.array_equal(x, y), "%s of block %d" % (field, lb)
+            else:
+                np.testing.assert_allclose(x, y, rtol=1e-6, atol=1e-8, err_msg="%s of block %d" % (field, lb))  # (PPM: a last-bit difference can flip an extremum test)
 
 
 _PLANES_SCRIPT = """
