@@ -170,7 +170,7 @@ int launch_dedner(const PackView &pv, int extended, double coeff, double beta_dt
 int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsigned *d_flags,
                         hipStream_t s, bool ghosts_only = false, const unsigned *late_regions = nullptr,
                         int part = 0, bool faces_only = false, const int *face_nbr = nullptr,
-                        unsigned long long *dt_bits = nullptr, int depth = -1);
+                        unsigned long long *dt_bits = nullptr, int depth = -1, unsigned store_vars = ~0u);
 int launch_min_dt(const PackView &pv, int fluid, double gamma, unsigned long long *d_min_bits,
                   hipStream_t s);
 int launch_history(const PackView &pv, int fluid, double *d_partial, int *nblocks_out,

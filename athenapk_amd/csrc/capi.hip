@@ -445,6 +445,28 @@ int apk_cons_to_prim_dt_skip(apk_ctx *ctx, const apk_pack *md, int fluid, const 
   return APK_OK;
 }
 
+int apk_cons_to_prim_dt_select(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, int ghost_depth, const int *face_neighbor,
+                               unsigned store_vars, apk_stream_t stream) {
+  if (!ctx || !md || !valid_eos(eos) || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||
+      md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9) || ghost_depth < 0 || ghost_depth >= md->view.ng)
+    return set_err(ctx, APK_ERR_INVALID, "apk_cons_to_prim_dt_select: bad argument");
+  if (md->view.nvar != md->view.nhydro || (store_vars >> md->view.nhydro) != 0u)
+    return set_err(ctx, APK_ERR_INVALID, "apk_cons_to_prim_dt_select: store_vars names the hydro primitives of a pack without passive scalars");
+  // (a floor or ceiling writes conserved values back that belong with ALL primitives of the cell)
+  if (!eos_is_lean(*eos) || eos->dfloor > 0.0 || eos->efloor > 0.0)
+    return set_err(ctx, APK_ERR_UNSUPPORTED, "apk_cons_to_prim_dt_select: floors / ceilings need the full ConsToPrim");
+  hipStream_t s = as_stream(stream);
+  unsigned long long *dt_bits = ctx->d_u64 + 4;  // the stage's word: apk_stage_dt_read / apk_stage_dt_flags_read
+  if (apk::prepare_dt_word(ctx, s) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "time-step word reset", hipGetLastError());
+  ScopedTiming timing(ctx, APK_T_C2P, s);
+  // (store_vars = every primitive is the pass apk_cons_to_prim_dt_skip runs; ~0u is the kernels' word for it)
+  const unsigned all = (1u << md->view.nhydro) - 1u;
+  int rc = launch_cons_to_prim(md->view, fluid, *eos, ctx->d_flags, s, false, nullptr, 0, false, face_neighbor, dt_bits, ghost_depth,
+                               store_vars == all ? ~0u : store_vars);
+  if (rc != APK_OK) return set_err(ctx, rc, "cons_to_prim kernel launch failed", hipGetLastError());
+  return APK_OK;
+}
+
 int apk_cons_to_prim_faces(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, apk_stream_t stream) {
   if (!ctx || !md || !valid_eos(eos) || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||
       md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9))

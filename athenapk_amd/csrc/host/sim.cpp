@@ -341,6 +341,7 @@ int estimate_timestep_read(apk_sim *s, DtEstimate *e) {
       have_flags = true;
       s->stage_dt_pending = false;
     } else {
+      if (s->prim_stale) SIM_TRY(s, sync_ghosts(s));  // (the estimate reads stored primitives)
       SIM_TRY(s, apk_estimate_timestep(s->ctx, s->mu0(), s->pkg.fluid, &s->pkg.eos, s->pkg.cfl, &dt, s->stream));
     }
   }
@@ -755,10 +756,11 @@ int sync_ghosts(apk_sim *s) {
     return materialize_prim(s);
   }
   if (s->amr) {
-    if (s->amr_ghost_state == AMR_GHOSTS_COMPLETE) return APK_OK;
+    if (s->amr_ghost_state == AMR_GHOSTS_COMPLETE) return materialize_prim(s);  // (amr_prim_free_cycle may have left them stale)
     // the stage loop left the ghost zones behind edges and corners alone (or filled all of them a few layers deep):
     // complete exchange + ConsToPrim
     SIM_TRY(s, amr_exchange(s, s->cur, AMR_XCHG_FULL));
+    s->prim_stale = false;
     return fill_derived(s);
   }
   SIM_TRY(s, finish_pending(s));
@@ -1036,8 +1038,12 @@ int do_stage(apk_sim *s, int stage) {
   // (the full-step primitives were not stored: only the donor-cell predictor can do without them)
   const bool prim_free = prim_free_cycle(s);
   const bool rk_free = rk_prim_free_cycle(s);
-  const bool from_cons = s->prim_stale && ((stage == 1 && prim_free) || rk_free);
+  // (refined meshes, amr_prim_free_cycle: both stages read the conserved state whether or not primitives are stored --
+  // one set of kernels whatever happened between the cycles)
+  const bool amr_pf = amr_prim_free_cycle(s);
+  const bool from_cons = amr_pf || (s->prim_stale && ((stage == 1 && prim_free) || rk_free));
   if (s->prim_stale && !from_cons) SIM_TRY(s, sync_ghosts(s));
+  if (amr_pf) s->amr_tag_vars_stored = false;  // (the state they were taken from is about to be replaced)
   // (ghost zones one layer deep: enough for the donor-cell predictor they were left for, and for nothing else)
   if (s->remote_ghosts_thin && !(stage == 1 && thin_exchange_cycle(s))) SIM_TRY(s, sync_ghosts(s));
   // (... and their x1 strips still in the receive buffers: for a predictor that reads them there, x1_direct_cycle)
@@ -1121,7 +1127,8 @@ int do_stage(apk_sim *s, int stage) {
       a.cons_out_delta = s->d_cons2[outbuf] - s->d_cons2[s->cur];
     }
     // (refined meshes: the corrector from the half-step conserved state, over u1 -- amr_prim_free_cycle)
-    const bool amr_fc = s->amr && stage == 2 && two_kernel && a.fill_derived == 0 && amr_prim_free_cycle(s);
+    const bool amr_fc = amr_pf && stage == 2 && two_kernel && a.fill_derived == 0;
+    if (amr_pf && stage == 2 && !amr_fc) return fail(s, APK_ERR_INVALID, "do_stage: the corrector of a refined mesh's prim-free cycle is not the two-kernel stage");
     if (amr_fc) {
       outbuf = s->u1buf;
       a.prim_from_cons = 2;
@@ -1217,7 +1224,8 @@ int do_stage(apk_sim *s, int stage) {
     bool planes_ahead = false;
     if (s->amr && a.fill_derived == 0) {
       SIM_TRY(s, ensure_flux_arrays(s));
-      planes_ahead = amr_flux_planes_ahead(s, cfg, amr_fc);
+      // (amr_pf: the planes from the conserved state the stage reads -- u1's buffer in stage 1, the current one in stage 2)
+      planes_ahead = amr_flux_planes_ahead(s, cfg, amr_pf ? (stage == 1 ? s->u1buf : s->cur) : -1);
     }
     {
       const int rc_stage = apk_stage_fused(s->ctx, s->mu0(), s->mu1(), &a, s->stream);
@@ -1244,7 +1252,7 @@ int do_stage(apk_sim *s, int stage) {
         SIM_TRY(s, ensure_flux_arrays(s));
         const double psi_factor = a.dedner != 0 ? std::exp(-pkg.glmmhd_alpha * pkg.c_h * beta_dt / pkg.mindx) : 1.0;
         // (boundary planes not computed beside the stage: from the state the stage read -- now the register's buffer)
-        SIM_TRY(s, amr_flux_fix(s, cfg, beta_dt, psi_factor, planes_ahead, amr_fc ? inbuf : -1));
+        SIM_TRY(s, amr_flux_fix(s, cfg, beta_dt, psi_factor, planes_ahead, amr_pf ? (stage == 1 ? s->u1buf : inbuf) : -1));
       }
     }
   } else {
@@ -1368,10 +1376,16 @@ int do_stage(apk_sim *s, int stage) {
     const bool dir = amr_direct(s);
     SIM_TRY(s, amr_exchange(s, s->cur, dir ? AMR_XCHG_DIRECT : AMR_XCHG_FACES));
     if (dir) s->skipped_local_exchanges += 1;
-    if (stage == s->nstages && pkg.calc_dt_hyp) {  // (the time-step estimate on the way, as below)
+    if (stage == s->nstages && pkg.calc_dt_hyp && amr_pf) {
+      // (the next predictor reads the conserved state: the estimate alone, no primitive stored)
+      SIM_TRY(s, apk_cons_to_prim_dt_select(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, 0, nullptr, 0u, s->stream));
+      s->stage_dt_pending = true;
+      s->prim_stale = true;
+      s->amr_c2p_passes_skipped += 1;
+    } else if (stage == s->nstages && pkg.calc_dt_hyp) {  // (the time-step estimate on the way, as below)
       SIM_TRY(s, apk_cons_to_prim_faces_dt(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, dir ? s->d_face_nbr : nullptr, s->stream));
       s->stage_dt_pending = true;
-    } else if (stage == 1 && amr_prim_free_cycle(s)) {
+    } else if (stage == 1 && amr_pf) {
       // (the corrector converts what it loads: no pass over the blocks here)
       s->amr_c2p_passes_skipped += 1;
     } else if (dir) {
@@ -1391,7 +1405,20 @@ int do_stage(apk_sim *s, int stage) {
       if (s->mesh.Active(d) && (s->mesh.bc_in[d] != BC_PERIODIC || s->mesh.bc_out[d] != BC_PERIODIC)) dir = false;
     SIM_TRY(s, amr_exchange(s, s->cur, dir ? AMR_XCHG_SHELL_DIRECT : AMR_XCHG_SHELL));
     if (dir) s->skipped_local_exchanges += 1;
-    SIM_TRY(s, apk_cons_to_prim_dt_skip(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, AMR_SHELL_DEPTH, dir ? s->d_face_nbr : nullptr, s->stream));
+    int crit = -1;
+    double crit_p0 = 0.0, crit_p1 = 0.0;
+    if (amr_pf && pkg.calc_dt_hyp) SIM_TRY(s, refinement_criterion(s, &crit, &crit_p0, &crit_p1));
+    if (crit >= 0) {
+      // (the next predictor reads the conserved state: of the primitives only what the refinement criterion reads)
+      // (the reference's order of the primitives: IDN = 0, IV1 .. IV3 = 1 .. 3, IPR = 4)
+      const unsigned vars = crit == APK_TAG_PRESSURE_GRADIENT ? (1u << 4) : (crit == APK_TAG_VELOCITY_GRADIENT ? ((1u << 1) | (1u << 2)) : (1u << 0));
+      SIM_TRY(s, apk_cons_to_prim_dt_select(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, AMR_SHELL_DEPTH, dir ? s->d_face_nbr : nullptr, vars, s->stream));
+      s->prim_stale = true;
+      s->amr_tag_vars_stored = true;
+      s->amr_c2p_passes_skipped += 1;
+    } else {
+      SIM_TRY(s, apk_cons_to_prim_dt_skip(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, AMR_SHELL_DEPTH, dir ? s->d_face_nbr : nullptr, s->stream));
+    }
     s->stage_dt_pending = true;
   } else {
     // (without a fused FillDerived the full-block ConsToPrim below reads every ghost zone)

@@ -206,6 +206,7 @@ struct apk_sim {
   bool prim_stale = false;
   bool prim_free_on = true;  // apk_sim_set_prim_free / APK_PRIM_FREE=0 (A/B)
   long long skipped_local_exchanges = 0;
+  bool amr_tag_vars_stored = false;  // the primitives a refinement criterion reads are those of the current state (amr_prim_free_cycle)
   long long amr_c2p_passes_skipped = 0;  // ConsToPrim passes between the stages a refined mesh did without (amr_prim_free_cycle)
   // mesh refinement (parthenon/mesh/refinement = static | adaptive; one rank): the forest of
   // blocks, the index-box plans of the multilevel ghost exchange / flux correction and their device

@@ -694,7 +694,7 @@ bool amr_has_coarse_fine_faces(const apk_sim *s) {
 // slots the marches leave empty (a pack of a few hundred 16^3 blocks fills 80 % of them; by themselves the few hundred
 // planes are one wave each and take 25 us of latency per stage).  Returns whether they were launched; amr_flux_fix then
 // waits for them instead of computing them.  The caller has the flux arrays in place (ensure_flux_arrays).
-bool amr_flux_planes_ahead(apk_sim *s, const apk_flux_cfg &cfg, bool from_cons) {
+bool amr_flux_planes_ahead(apk_sim *s, const apk_flux_cfg &cfg, int cons_input) {
   static const bool off = std::getenv("APK_AMR_PLANES_INLINE") != nullptr;  // A/B switch
   if (off || s->side_stream_failed || !amr_has_coarse_fine_faces(s)) return false;
   auto &a = s->amr_dev;
@@ -716,11 +716,13 @@ bool amr_flux_planes_ahead(apk_sim *s, const apk_flux_cfg &cfg, bool from_cons) 
   hipStream_t side = reinterpret_cast<hipStream_t>(s->side_stream);
   if (hipEventRecord(reinterpret_cast<hipEvent_t>(s->ev_fork), hs(s)) != hipSuccess) return false;
   if (hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(s->ev_fork), 0) != hipSuccess) return false;
-  // (from_cons: the stage's input is the conserved state of the pack's own blocks -- prim_from_cons = 2)
-  const int rc = from_cons ? apk_calculate_fluxes_boundary_list_from_cons(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, a.d_cf_faces,
-                                                                          a.n_cf_faces, 0, reinterpret_cast<apk_stream_t>(side))
-                           : apk_calculate_fluxes_boundary_list(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, a.d_cf_faces, a.n_cf_faces,
-                                                                reinterpret_cast<apk_stream_t>(side));
+  // (cons_input >= 0: the stage's input is the conserved state in that buffer -- prim_from_cons)
+  const int rc = cons_input >= 0
+                     ? apk_calculate_fluxes_boundary_list_from_cons(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, a.d_cf_faces, a.n_cf_faces,
+                                                                    (long long)(s->d_cons2[cons_input] - s->d_cons2[s->cur]),
+                                                                    reinterpret_cast<apk_stream_t>(side))
+                     : apk_calculate_fluxes_boundary_list(s->ctx, s->mu0(), cfg, &s->pkg.eos, s->pkg.c_h, a.d_cf_faces, a.n_cf_faces,
+                                                          reinterpret_cast<apk_stream_t>(side));
   // (whatever was enqueued is joined either way: through the event -- by amr_flux_fix, or by do_stage if the stage fails
   // in between -- or, if the event cannot be recorded, by waiting for the side stream here)
   if (hipEventRecord(reinterpret_cast<hipEvent_t>(s->ev_join), side) != hipSuccess) {
@@ -996,7 +998,9 @@ int amr_tags_begin(apk_sim *s, AmrTagRequest *req) {
   // so this is a no-op there; it is what covers apk_sim_regrid / apk_sim_check_refinement between cycles.
   // (AMR_GHOSTS_SHELL_DIRECT: the shell without the zones behind same-level same-rank faces -- the tag kernel reads those
   // cells from the neighbours' interiors through the face table, as the stages do)
-  if (s->amr_ghost_state == AMR_GHOSTS_FACES) SIM_TRY(s, sync_ghosts(s));
+  // (amr_prim_free_cycle: ... and stores of the primitives only what the criterion reads, amr_tag_vars_stored; between
+  // cycles, stale primitives are regenerated first)
+  if (s->amr_ghost_state == AMR_GHOSTS_FACES || (s->prim_stale && !s->amr_tag_vars_stored)) SIM_TRY(s, sync_ghosts(s));
   SIM_TRY(s, refinement_criterion(s, &req->criterion, &req->p0, &req->p1));
   const int *table = s->amr_ghost_state == AMR_GHOSTS_SHELL_DIRECT ? s->d_face_nbr : nullptr;
   SIM_TRY(s, apk_tag_blocks_begin_skip(s->ctx, s->mu0(), req->criterion, table, &req->pending, s->stream));
@@ -1057,6 +1061,8 @@ int amr_regrid(apk_sim *s, bool *changed, const AmrTagRequest *posted) {
   SIM_TRY(s, amr_transfer(s, old, old_part));
   SIM_TRY(s, exchange_ghosts(s));
   SIM_TRY(s, fill_derived(s));
+  s->prim_stale = false;  // (every cell of the new mesh)
+  s->amr_tag_vars_stored = false;
   *changed = true;
   return APK_OK;
 }

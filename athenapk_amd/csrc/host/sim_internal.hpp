@@ -137,7 +137,7 @@ void amr_capture_half(apk_sim *s, int buf, bool pre, int mode, void **out, bool 
 void amr_destroy_graphs(apk_sim *s);
 bool amr_has_coarse_fine_faces(const apk_sim *s);
 int amr_flux_fix(apk_sim *s, const apk_flux_cfg &cfg, double beta_dt, double psi_factor, bool planes_ahead = false, int cons_input = -1);
-bool amr_flux_planes_ahead(apk_sim *s, const apk_flux_cfg &cfg, bool from_cons = false);
+bool amr_flux_planes_ahead(apk_sim *s, const apk_flux_cfg &cfg, int cons_input = -1);
 int amr_flux_correction(apk_sim *s);
 int refinement_criterion(apk_sim *s, int *criterion, double *p0, double *p1);
 bool amr_update_tree(apk_sim *s, const std::vector<int> &tags, bool allow_derefine);

@@ -112,9 +112,10 @@ APK_DEV double wave_sum(double v) {
 }
 
 // ---- ConservedToPrimitive over the ENTIRE block (src/eos/adiabatic_hydro.cpp:33-55) -----
+// store_vars: bit n set = primitive n is stored (all ones: FillDerived; apk_cons_to_prim_dt_select stores a subset)
 template <int FLUID>
 APK_DEV void cons_to_prim_at_w(const PackView &pv, const apk_block_desc &blk, const apk_eos &eos, unsigned *flags,
-                               int64_t cell, double (&w)[nvars<FLUID>()]) {
+                               int64_t cell, double (&w)[nvars<FLUID>()], unsigned store_vars = ~0u) {
   constexpr int NV = nvars<FLUID>();
   double u[NV];
 #pragma unroll
@@ -131,9 +132,10 @@ APK_DEV void cons_to_prim_at_w(const PackView &pv, const apk_block_desc &blk, co
   if (u[IM3] != m3) blk.cons[IM3 * pv.sn + cell] = u[IM3];
   if (u[IEN] != e_in) blk.cons[IEN * pv.sn + cell] = u[IEN];
 #pragma unroll
-  for (int n = 0; n < NV; ++n) blk.prim[n * pv.sn + cell] = w[n];
+  for (int n = 0; n < NV; ++n)
+    if ((store_vars >> n) & 1u) blk.prim[n * pv.sn + cell] = w[n];
   for (int n = NV; n < pv.nvar; ++n)  // passive scalars (:139-141)
-    blk.prim[n * pv.sn + cell] = blk.cons[n * pv.sn + cell] * di;
+    if (store_vars == ~0u) blk.prim[n * pv.sn + cell] = blk.cons[n * pv.sn + cell] * di;
 }
 template <int FLUID>
 APK_DEV void cons_to_prim_at(const PackView &pv, const apk_block_desc &blk, const apk_eos &eos, unsigned *flags,
@@ -178,7 +180,8 @@ APK_DEV void block_min_to_word(double lane_min, unsigned long long *word) {
 // registers -- the values min_dt_kernel would read back -- reduced into *dt_bits (apk_cons_to_prim_dt).
 template <int FLUID, bool WITH_DT>
 __global__ void __launch_bounds__(256)
-cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags, unsigned long long *dt_bits, int depth, const int *face_nbr) {
+cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags, unsigned long long *dt_bits, int depth, const int *face_nbr,
+                    unsigned store_vars) {
   // depth >= 0: only the cells within that many layers of the interior (the shell a shallow ghost exchange has filled) --
   // the launch covers that box, cell after cell (16^3 blocks with four ghost layers, depth 2: 20^3 of 24^3 cells, 32
   // workgroups a block instead of 72)
@@ -213,7 +216,7 @@ cons_to_prim_kernel(PackView pv, apk_eos eos, unsigned *flags, unsigned long lon
   if (ok) {
     const apk_block_desc blk = pv.blocks[b];
     double w[nvars<FLUID>()];
-    cons_to_prim_at_w<FLUID>(pv, blk, eos, flags, k * pv.sk + j * pv.sj + i, w);
+    cons_to_prim_at_w<FLUID>(pv, blk, eos, flags, k * pv.sk + j * pv.sj + i, w, store_vars);
     if constexpr (WITH_DT) {
       if (i >= pv.is && i <= pv.ie && j >= pv.js && j <= pv.je && k >= pv.ks && k <= pv.ke) lane_min = cell_dt_hyp<FLUID>(pv, blk, eos.gamma, w);
     }
@@ -623,7 +626,7 @@ int launch_dedner(const PackView &pv, int extended, double coeff, double beta_dt
 
 int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsigned *d_flags,
                         hipStream_t s, bool ghosts_only, const unsigned *late_regions, int part, bool faces_only,
-                        const int *face_nbr, unsigned long long *dt_bits, int depth) {
+                        const int *face_nbr, unsigned long long *dt_bits, int depth, unsigned store_vars) {
   if (ghosts_only) {
     const int64_t na = (int64_t)(pv.nk - pv.nx3) * pv.nj * pv.ni;
     const int64_t nb = (int64_t)pv.nx3 * (pv.nj - pv.nx2) * pv.ni;
@@ -639,6 +642,7 @@ int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsig
   }
   dim3 grid = rect_grid(pv.ni, pv.nj, pv.nk * pv.nblocks);
   if (depth >= pv.ng) depth = -1;  // (the whole block)
+  if (store_vars != ~0u && (faces_only || !dt_bits || depth < 0)) return APK_ERR_UNSUPPORTED;  // (the boxed pass with the estimate)
   if (!faces_only && dt_bits && depth >= 0) {  // (cons_to_prim_kernel's box)
     const int64_t cells = (int64_t)(pv.nx1 + 2 * depth) * (pv.ndim >= 2 ? pv.nx2 + 2 * depth : pv.nj) * (pv.ndim >= 3 ? pv.nx3 + 2 * depth : pv.nk);
     const int64_t wgs = (cells + 255) / 256, gy = (wgs + 32767) / 32768, gx = (wgs + gy - 1) / gy;
@@ -657,13 +661,13 @@ int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsig
       hipLaunchKernelGGL((cons_to_prim_faces_kernel<APK_FLUID_GLMMHD, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, face_nbr, dt_bits);
   } else if (dt_bits) {
     if (fluid == APK_FLUID_EULER)
-      hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_EULER, true>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, depth, face_nbr);
+      hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_EULER, true>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, depth, face_nbr, store_vars);
     else
-      hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_GLMMHD, true>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, depth, face_nbr);
+      hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_GLMMHD, true>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, depth, face_nbr, store_vars);
   } else if (fluid == APK_FLUID_EULER)
-    hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_EULER, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, -1, nullptr);
+    hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_EULER, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, -1, nullptr, ~0u);
   else
-    hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_GLMMHD, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, -1, nullptr);
+    hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_GLMMHD, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, -1, nullptr, ~0u);
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }
 

@@ -305,11 +305,17 @@ def ConservedToPrimitive(md, fluid, eos):
     _check(ctx.lib.apk_cons_to_prim(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), _stream()), ctx.lib, ctx.h)
 
 
-def ConservedToPrimitiveDt(md, fluid, eos, cfl, ghost_depth=-1, face_neighbor=None):
+def ConservedToPrimitiveDt(md, fluid, eos, cfl, ghost_depth=-1, face_neighbor=None, store_vars=None):
     """ConsToPrim of every cell (ghost_depth >= 0: of the cells at most that many layers outside the interior) and the
     hyperbolic time-step estimate of the interior in one pass (apk_cons_to_prim_dt); face_neighbor (int32 device tensor
-    [nblocks, 6]): not the ghost cells straight behind the faces whose entry is >= 0 (apk_cons_to_prim_dt_skip)."""
+    [nblocks, 6]): not the ghost cells straight behind the faces whose entry is >= 0 (apk_cons_to_prim_dt_skip);
+    store_vars (a bit mask of primitives, with ghost_depth >= 0): only those are stored (apk_cons_to_prim_dt_select)."""
     ctx = md.ctx
+    if store_vars is not None:
+        fn = C.c_void_p(face_neighbor.data_ptr()) if face_neighbor is not None else None
+        _check(ctx.lib.apk_cons_to_prim_dt_select(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), ghost_depth, fn, int(store_vars), _stream()),
+               ctx.lib, ctx.h)
+        return StageDt(ctx, cfl)
     if face_neighbor is None:
         _check(ctx.lib.apk_cons_to_prim_dt(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), ghost_depth, _stream()), ctx.lib, ctx.h)
     else:

@@ -177,6 +177,7 @@ def _signatures():
         "apk_cons_to_prim_faces": (i, [vp, vp, i, E, vp]),
         "apk_cons_to_prim_dt": (i, [vp, vp, i, E, i, vp]),
         "apk_cons_to_prim_dt_skip": (i, [vp, vp, i, E, i, vp, vp]),
+        "apk_cons_to_prim_dt_select": (i, [vp, vp, i, E, i, vp, C.c_uint, vp]),
         "apk_cons_to_prim_faces_skip": (i, [vp, vp, i, E, vp, vp]),
         "apk_cons_to_prim_faces_dt": (i, [vp, vp, i, E, vp, vp]),
         "apk_cons_to_prim_ghosts_split": (i, [vp, vp, i, E, vp, i, vp]),

@@ -349,6 +349,15 @@ int apk_cons_to_prim_dt(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_e
  * >= 0: zones an exchange that follows the face table has not filled and no reader of the table visits. */
 int apk_cons_to_prim_dt_skip(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, int ghost_depth,
                              const int *face_neighbor, apk_stream_t stream);
+/* ... storing only the primitives whose bit is set in store_vars (bit n = primitive n of the reference's order: IDN,
+ * IV1, IV2, IV3, IPR [, IB1, IB2, IB3, IPS]; 0: none -- the time-step estimate alone; every bit: apk_cons_to_prim_dt_skip):
+ * the end of a cycle whose successor derives its input from the conserved state (apk_stage_args.prim_from_cons) and
+ * whose only reader of stored primitives is a refinement criterion -- the pressure for pressure_gradient, the two
+ * velocities for xyvelocity_gradient, the density for maxdensity (apk_tag_blocks).  ghost_depth >= 0 (0: the interior).
+ * Without floors and ceilings in eos (they write conserved values back that belong with all primitives of a cell:
+ * APK_ERR_UNSUPPORTED), packs without passive scalars. */
+int apk_cons_to_prim_dt_select(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, int ghost_depth,
+                               const int *face_neighbor, unsigned store_vars, apk_stream_t stream);
 /* ConsToPrim (Update::FillDerived, hydro_driver.cpp:571-577; src/eos/adiabatic_hydro.cpp:33) of the interior
  * and of the ghost cells straight behind a block FACE only (at most one ghost coordinate): what the unsplit
  * sweeps (hydro.cpp:1025-1199) and the flux correction read.  The refined-mesh stage loop of the standalone

@@ -413,6 +413,20 @@ def test_cons_to_prim_with_time_step_estimate(request, fluid, nx, strict):
                 if tab[b, f] >= 0:
                     left |= np.broadcast_to(zones[f] & (nghost == 1), u.shape[2:])
             assert np.array_equal(got[b][:, ~left], ref.prim_host()[b][:, ~left]) and np.all(got[b][:, left] == -3.0) and left.any()
+    # apk_cons_to_prim_dt_select: the same estimate, and of the primitives only those named -- in the cells of the box
+    for depth, mask in ((1, 1 << 4), (0, 0), (1, 0b00110), (1, (1 << NHYDRO[fluid]) - 1)):
+        md = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=u, prim=np.full_like(u, -3.0), with_flux=False)
+        assert hydro.ConservedToPrimitiveDt(md, fluid, eos, 0.3, ghost_depth=depth, store_vars=mask) == dt
+        got = md.prim_host()
+        box = ~deep if depth == 1 else np.broadcast_to(((I >= ng) & (I < ng + nx[0])) & (~np.bool_(act[1]) | ((J >= ng) & (J < ng + nx[1])))
+                                                       & (~np.bool_(act[2]) | ((K >= ng) & (K < ng + nx[2]))), deep.shape)
+        for n in range(NHYDRO[fluid]):
+            if (mask >> n) & 1:
+                assert np.array_equal(got[:, n][:, box], ref.prim_host()[:, n][:, box]) and np.all(got[:, n][:, ~box] == -3.0)
+            else:
+                assert np.all(got[:, n] == -3.0)
+    with pytest.raises(hydro.L.ApkError):  # (a floor writes conserved values back: the full pass only)
+        hydro.ConservedToPrimitiveDt(md, fluid, hydro.L.make_eos(GAMMA, dfloor=1e-9), 0.3, ghost_depth=1, store_vars=1 << 4)
     # apk_cons_to_prim_faces_dt: what apk_cons_to_prim_faces converts, and the same estimate
     a = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=u, prim=np.full_like(u, -3.0), with_flux=False)
     b = hydro.MeshData(ctx, nx, ng, NHYDRO[fluid], dx=tuple(g.dx), nblocks=3, cons=u, prim=np.full_like(u, -3.0), with_flux=False)
