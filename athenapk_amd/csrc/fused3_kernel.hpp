@@ -327,7 +327,10 @@ template <int FLUID, int RECON>
 inline bool single_march_stage_applies(const PackView &u0, int extra, const StageParams &sp) {
   static const int mode = std::getenv("APK_S3") ? std::atoi(std::getenv("APK_S3")) : 1;
   if constexpr (!single_march_compiled<FLUID, RECON>()) return false;
-  return mode != 0 && u0.ndim == 3 && (uint64_t)u0.sn * sizeof(double) < (1ull << 32) && sp.prim_from_cons != 0 && sp.phase == 0 && sp.window == nullptr && stage_is_lean(sp) &&
+  // (rows of 32 cells and more: on the 16^3 blocks of a refined mesh the march's x1 halo lanes outnumber its cells and the
+  // two-kernel form is faster -- refined hydro blast of BASELINE config 5, zone-cycles/s, same box: 16^3 blocks 2.02e9 with
+  // this march against 2.32e9 with the two-kernel stage; 32^3: 4.55e9 against 4.17e9; 48^3: 5.85e9 against 5.23e9)
+  return mode != 0 && u0.ndim == 3 && u0.nx1 >= 32 && (uint64_t)u0.sn * sizeof(double) < (1ull << 32) && sp.prim_from_cons != 0 && sp.phase == 0 && sp.window == nullptr && stage_is_lean(sp) &&
          u0.nx2 % 2 == 0 && u0.nx2 >= 4 && u0.ng >= 2 && (extra == EXTRA_NONE || (extra == EXTRA_C2P_DT && sp.no_prim_store)) &&
          (sp.prim_from_cons == 1 || sp.out_delta != 0);
 }

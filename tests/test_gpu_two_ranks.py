@@ -21,7 +21,14 @@ CASES = {
                           "parthenon/meshblock/nx1=16", "parthenon/meshblock/nx2=16", "parthenon/meshblock/nx3=16"],
                          dict(fluid="glmmhd", recon="ppm", riemann="hlld", integrator="vl2", nx=(32, 32, 32),
                               mb=(16, 16, 16), ng=3, cfl=0.3, gamma=1.666666666666667), "synthetic", {}, 4),
+    # (rows of 32 cells: hydro PLM's single march, fused3_kernel.hpp; of 16: the two-kernel form)
     "sod_outflow": ("sod",
+                    ["parthenon/mesh/nx1=128", "parthenon/mesh/nx2=8", "parthenon/mesh/nx3=8",
+                     "parthenon/meshblock/nx1=32", "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=8"],
+                    dict(fluid="euler", recon="plm", riemann="hllc", integrator="rk2", nx=(128, 8, 8), mb=(32, 8, 8),
+                         ng=2, bc=("outflow", "periodic", "periodic"), xmin=(0.0, -0.5, -0.5), xmax=(1.0, 0.5, 0.5),
+                         gamma=1.4, cfl=0.3), "sod", {}, 6),
+    "sod_outflow_narrow_blocks": ("sod",
                     ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=8", "parthenon/mesh/nx3=8",
                      "parthenon/meshblock/nx1=16", "parthenon/meshblock/nx2=8", "parthenon/meshblock/nx3=8"],
                     dict(fluid="euler", recon="plm", riemann="hllc", integrator="rk2", nx=(64, 8, 8), mb=(16, 8, 8),
