@@ -131,7 +131,8 @@ long long apk_sim_amr_c2p_passes_skipped(const apk_sim *sim);
  * only (apk_stage_args.fill_derived = 3) and the predictor of the next cycle derives its input from the conserved state
  * (prim_from_cons) -- the reference stores them in FillDerived (hydro_driver.cpp:571-577) and reads them back in
  * CalculateFluxes.  Every accessor materialises them on demand; results are identical.  APK_PRIM_FREE=0 in the
- * environment switches it off.  apk_sim_prim_is_stale: 1 while the primitives of the current state are not in memory. */
+ * environment switches it off.  apk_sim_prim_is_stale: 1 while the primitives of the current state are not in memory.
+ * The same switch governs the stage loop of refined meshes (apk_sim_amr_c2p_passes_skipped above). */
 int apk_sim_set_prim_free(apk_sim *sim, int on);
 /* One-layer exchanges (on by default where they apply: N > 1 ranks, uniform periodic 3-D meshes, VL2, no passive
  * scalars, no extended Dedner source, no forcing): the exchange at the end of a cycle delivers ONE layer of ghost
