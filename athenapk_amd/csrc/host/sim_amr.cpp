@@ -626,7 +626,11 @@ void amr_capture_half(apk_sim *s, int buf, bool pre, int mode, void **out, bool 
     if (rc != APK_OK) s->err = saved_err;
   }
   size_t nodes = 0;
-  if (ok) ok = hipGraphGetNodes(graph, nullptr, &nodes) == hipSuccess && nodes > 1;  // (a single launch gains nothing)
+  // (A graph launch leaves ~8 us of idle stream in front of its first node; launched one by one, kernels follow each other
+  // within 1 - 2 us as long as the host is ahead -- it is, by half a cycle, on meshes of a few hundred blocks.  A graph pays
+  // where it replaces many launches: physical-boundary phases, several prolongation plans.  Round 6, config 5's mesh, one
+  // rank, periodic -- 4 - 5 nodes per exchange: 1.354e9 zone-cycles/s as graphs, 1.373e9 launched one by one, same box.)
+  if (ok) ok = hipGraphGetNodes(graph, nullptr, &nodes) == hipSuccess && nodes > 6;
   if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
   if (graph) (void)hipGraphDestroy(graph);
   (void)hipStreamDestroy(cs);
