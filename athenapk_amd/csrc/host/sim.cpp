@@ -636,7 +636,9 @@ bool rk_prim_free_cycle(const apk_sim *s) {
 // switch it off (A/B).
 bool amr_prim_free_cycle(const apk_sim *s) {
   static const int mode = std::getenv("APK_AMR_PRIM_FREE") ? std::atoi(std::getenv("APK_AMR_PRIM_FREE")) : 1;
+  static const int dc_mode = std::getenv("APK_DC_MODE") ? std::atoi(std::getenv("APK_DC_MODE")) : 2;  // (the predictor's form)
   const HydroPackage &pkg = s->pkg;
+  if (dc_mode != 2) return false;
   if (!mode || !s->prim_free_on || !s->amr || s->fmft || s->mesh.ndim != 3 || !stage_can_fuse(s) || !amr_faces_only(s)) return false;
   if (pkg.nscalars != 0 || (pkg.fluid == APK_FLUID_GLMMHD && pkg.glmmhd_source_extended)) return false;
   const apk_eos &e = pkg.eos;
