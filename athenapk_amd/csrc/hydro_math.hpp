@@ -1233,6 +1233,14 @@ APK_DEV unsigned cons_to_prim_cell(const apk_eos &eos, const StageConsts &k, dou
 template <int FLUID, int LEAN>
 APK_DEV unsigned cons_to_prim_core(const apk_eos &eos, double gm1, double vceil_sq, double pfloor_over_gm1,
                                    double (&u)[nvars<FLUID>()], double (&w)[nvars<FLUID>()], double &di_out) {
+  // No contraction in here, in the product build either: the primitives of a cell must not depend on which kernel this
+  // function was inlined into.  Stages that derive their input from the conserved state convert the same cell in several
+  // kernels -- on a refined mesh the stage kernels AND the kernel of the flux correction's boundary planes, whose flux
+  // through a coarse-fine face has to be the one the stage applied: with primitives that differed in the last bit between
+  // the two, PPM's limiters now and then decided differently, the correction subtracted a flux the stage had not used, and
+  // the mass of the refined MHD blast drifted by 1e-6 in 1500 cycles (round 6, tools/soak_r06.py; 2e-16 with this).
+  // (frcp's Newton steps are explicit fma calls: the same everywhere.)
+#pragma clang fp contract(off)
   constexpr bool mhd = (FLUID == APK_FLUID_GLMMHD);
   unsigned flags = 0;
   if (!(strictly_positive(u[IDN]) || eos.dfloor > 0.0)) flags |= APK_FLAG_NEG_DENSITY;

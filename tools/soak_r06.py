@@ -1,0 +1,37 @@
+"""Development aid: longer runs of the paths of round 6 in the product build -- finite states and conserved mass after
+hundreds of cycles (x1 strips in the exchange buffers on the one-GPU rehearsal of an 8-GPU rank, VL2 and RK3; the prim-free
+cycle of refined meshes with regridding, MHD and hydro; forced turbulence on the RK3 rehearsal)."""
+import sys, time, numpy as np, torch
+sys.path.insert(0, ".")
+from athenapk_amd import decks, driver
+
+
+def run(deck, ov, n, label, refined=False):
+    s = driver.Simulation(decks.load(deck), ov, strict=False).initialize()
+    m0 = s.history()[0]
+    t = time.perf_counter()
+    for _ in range(n):
+        s.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    h = s.history()
+    if refined:
+        nb = s.refresh_info().nblocks_total
+        fin = all(bool(np.isfinite(s.read_block(lb)).all()) for lb in range(0, nb, 5))
+        extra = "blocks %d passes skipped %d" % (nb, s.amr_c2p_passes_skipped())
+    else:
+        fin = bool(np.isfinite(s.gather()).all())
+        extra = "x1 direct %d" % s.x1_direct_exchanges()
+    print(label, "cycles", n, "ms/cycle %.3f" % (dt / n * 1e3), "finite", fin, "mass drift %.2e" % (abs(h[0] - m0) / abs(m0)), extra, flush=True)
+    assert fin
+    s.close()
+
+
+b = lambda n, m: ["parthenon/mesh/nx%d=%d" % (d, n) for d in (1, 2, 3)] + ["parthenon/meshblock/nx%d=%d" % (d, m) for d in (1, 2, 3)]
+run("synthetic_mhd", b(256, 128) + ["apk_amd/rehearse_remote_faces=true"], 400, "mhd vl2 ppm, rehearsed remote faces 256^3")
+run("synthetic_mhd", b(256, 128) + ["parthenon/time/integrator=rk3", "hydro/reconstruction=wenoz", "apk_amd/rehearse_remote_faces=true"], 120,
+    "mhd rk3 wenoz, rehearsed remote faces 256^3")
+amr = ["parthenon/mesh/nx%d=64" % d for d in (1, 2, 3)] + ["parthenon/meshblock/nx%d=16" % d for d in (1, 2, 3)] + ["parthenon/mesh/numlevel=4", "parthenon/time/tlim=10.0"]
+run("blast_3d_amr", amr + ["hydro/fluid=glmmhd", "hydro/riemann=hlld", "hydro/reconstruction=ppm", "parthenon/mesh/nghost=4",
+                           "problem/blast/pressure_ambient=1.0", "problem/blast/pressure_ratio=100"], 1500, "refined mhd blast (config 5's mesh)", refined=True)
+run("blast_3d_amr", amr, 1500, "refined hydro blast as decked", refined=True)
