@@ -35,3 +35,11 @@ amr = ["parthenon/mesh/nx%d=64" % d for d in (1, 2, 3)] + ["parthenon/meshblock/
 run("blast_3d_amr", amr + ["hydro/fluid=glmmhd", "hydro/riemann=hlld", "hydro/reconstruction=ppm", "parthenon/mesh/nghost=4",
                            "problem/blast/pressure_ambient=1.0", "problem/blast/pressure_ratio=100"], 1500, "refined mhd blast (config 5's mesh)", refined=True)
 run("blast_3d_amr", amr, 1500, "refined hydro blast as decked", refined=True)
+
+# forced turbulence (config 4's scheme) and Orszag-Tang with first-order flux correction (config 3's deck): mass to round-off
+b3 = lambda n, m: ["parthenon/mesh/nx%d=%d" % (d, n) for d in (1, 2, 3)] + ["parthenon/meshblock/nx%d=%d" % (d, m) for d in (1, 2, 3)]
+run("turbulence", b3(128, 64) + ["parthenon/time/tlim=100.0", "parthenon/mesh/nghost=3", "hydro/reconstruction=wenoz", "hydro/riemann=hlld", "parthenon/time/integrator=rk3"], 300,
+    "forced turbulence mhd rk3 wenoz 128^3")
+run("orszag_tang", ["parthenon/mesh/nx1=512", "parthenon/mesh/nx2=512", "parthenon/mesh/nx3=4", "parthenon/meshblock/nx1=128", "parthenon/meshblock/nx2=128",
+                    "parthenon/meshblock/nx3=4", "parthenon/time/tlim=100.0", "hydro/first_order_flux_correct=true"], 4000,
+    "orszag-tang 512 x 512 x 4 vl2 with first-order flux correction (past t = 0.94)")
