@@ -1032,7 +1032,7 @@ def test_turbulence_kick_with_fill_derived_and_dt(request, oracle, strict, floor
         return md.cons_host(), md.prim_host(), drv.acc_host(), dt
     a, b = run(True), run(False)
     # apk_turb_apply_dt: the same kick and estimate, primitives left alone
-    md = hydro.MeshData(ctx, nx, 2, 9, dx=tuple(g.dx), nblocks=nb, cons=cons, prim=np.full_like(prim, -3.0), with_flux=False)
+    md = hydro.MeshData(ctx, nx, 2, 9, dx=tuple(g.dx), nblocks=nb, cons=cons, prim=np.full_like(prim, -3.0), with_flux=False, row_pitch="natural")
     drv = hydro.FewModesFT(md, [[p.transpose(2, 1, 0) for p in blk] for blk in phases])
     drv.Inverse(f.var_hat())
     drv.Perturb(0.01, 0.5, 1.0, fill=("glmmhd", eos, True, False))
@@ -1052,7 +1052,7 @@ def test_turbulence_kick_with_fill_derived_and_dt(request, oracle, strict, floor
 
 
 def run_unfloored(ctx, hydro, f, g, phases, nx, cons, prim):
-    md = hydro.MeshData(ctx, nx, 2, 9, dx=tuple(g.dx), nblocks=len(phases), cons=cons, prim=prim, with_flux=False)
+    md = hydro.MeshData(ctx, nx, 2, 9, dx=tuple(g.dx), nblocks=len(phases), cons=cons, prim=prim, with_flux=False, row_pitch="natural")
     drv = hydro.FewModesFT(md, [[p.transpose(2, 1, 0) for p in blk] for blk in phases])
     drv.Inverse(f.var_hat())
     drv.Perturb(0.01, 0.5, 1.0)
