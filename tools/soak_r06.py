@@ -43,3 +43,19 @@ run("turbulence", b3(128, 64) + ["parthenon/time/tlim=100.0", "parthenon/mesh/ng
 run("orszag_tang", ["parthenon/mesh/nx1=512", "parthenon/mesh/nx2=512", "parthenon/mesh/nx3=4", "parthenon/meshblock/nx1=128", "parthenon/meshblock/nx2=128",
                     "parthenon/meshblock/nx3=4", "parthenon/time/tlim=100.0", "hydro/first_order_flux_correct=true"], 4000,
     "orszag-tang 512 x 512 x 4 vl2 with first-order flux correction (past t = 0.94)")
+
+# a uniform-mesh blast (flat ambient state: ties in PPM's extremum tests everywhere) in blocks that meet through the face
+# table: every face between two blocks is solved once by each of them -- mass to round-off
+for integ, recon in (("vl2", "ppm"), ("rk3", "wenoz"), ("rk2", "ppm")):
+    run("blast", b3(128, 64) + ["parthenon/mesh/nghost=3", "hydro/fluid=glmmhd", "hydro/riemann=hlld", "hydro/reconstruction=%s" % recon,
+                                "parthenon/time/integrator=%s" % integ, "parthenon/time/tlim=10.0", "problem/blast/pressure_ambient=1.0",
+                                "problem/blast/pressure_ratio=100"] + ["parthenon/mesh/ix%d_bc=periodic" % d for d in (1, 2, 3)] +
+        ["parthenon/mesh/ox%d_bc=periodic" % d for d in (1, 2, 3)], 400, "uniform mhd blast 128^3 in 64^3 blocks, %s %s" % (integ, recon))
+run("blast", b3(128, 64) + ["parthenon/time/integrator=rk2", "parthenon/time/tlim=10.0"] + ["parthenon/mesh/ix%d_bc=periodic" % d for d in (1, 2, 3)] +
+    ["parthenon/mesh/ox%d_bc=periodic" % d for d in (1, 2, 3)], 400, "uniform hydro blast 128^3 in 64^3 blocks as decked, rk2")
+# ... and the same with its outer faces exchanged like those between the bricks of an 8-GPU run (split stages: windows and
+# slabs solve the faces between them twice, in different launches)
+run("blast", b3(128, 64) + ["parthenon/mesh/nghost=3", "hydro/fluid=glmmhd", "hydro/riemann=hlld", "hydro/reconstruction=ppm",
+                            "parthenon/time/integrator=vl2", "parthenon/time/tlim=10.0", "problem/blast/pressure_ambient=1.0",
+                            "problem/blast/pressure_ratio=100", "apk_amd/rehearse_remote_faces=true"] + ["parthenon/mesh/ix%d_bc=periodic" % d for d in (1, 2, 3)] +
+    ["parthenon/mesh/ox%d_bc=periodic" % d for d in (1, 2, 3)], 400, "uniform mhd blast 128^3 in 64^3 blocks, vl2 ppm, rehearsed remote faces")
