@@ -29,7 +29,7 @@ CMD="python tools/stage_time.py --gam0 0.5 --fill 2 --dt --reps 6"
 pmc mix SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT64 SQ_THREAD_CYCLES_VALU
 pmc other SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_FLAT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU
 python bench.py --no-cpu-baseline --no-rehearsal --sustained 0 --steps 10 --workload mhd_wenoz_hlld_rk3_256 > $O/bench_wenoz.json 2> /dev/null
-python bench.py --no-cpu-baseline --no-rehearsal --sustained 0 --steps 20 --workload hydro_plm_hllc_rk2_256 > $O/bench_hydro.json 2> /dev/null
+python bench.py --no-cpu-baseline --no-rehearsal --sustained 0 --steps 40 --workload hydro_plm_hllc_rk2_256 > $O/bench_hydro.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/hydro_stats -o s -- $B --steps 20 --workload hydro_plm_hllc_rk2_256 > $O/bench_hydro_under_rocprof.json 2> /dev/null
 python bench.py --no-cpu-baseline --no-copies-base --no-rehearsal --no-other-workloads --sustained 0 --amr-extra > $O/bench_amr_extra.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/amr_stats -o s -- python tools/amr_prof.py > $O/amr_prof.txt 2> /dev/null
