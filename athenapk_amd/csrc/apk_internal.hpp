@@ -171,6 +171,9 @@ int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsig
                         hipStream_t s, bool ghosts_only = false, const unsigned *late_regions = nullptr,
                         int part = 0, bool faces_only = false, const int *face_nbr = nullptr,
                         unsigned long long *dt_bits = nullptr, int depth = -1, unsigned store_vars = ~0u);
+int tag_from_cons_kchunks(const PackView &pv);
+int launch_tag_pgrad_from_cons(const PackView &pv, int fluid, const apk_eos &eos, unsigned *d_flags, unsigned long long *dt_bits,
+                               unsigned long long *block_max, const int *face_nbr, hipStream_t s);
 int launch_min_dt(const PackView &pv, int fluid, double gamma, unsigned long long *d_min_bits,
                   hipStream_t s);
 int launch_history(const PackView &pv, int fluid, double *d_partial, int *nblocks_out,

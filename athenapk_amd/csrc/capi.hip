@@ -448,7 +448,7 @@ int apk_cons_to_prim_dt_skip(apk_ctx *ctx, const apk_pack *md, int fluid, const 
 int apk_cons_to_prim_dt_select(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, int ghost_depth, const int *face_neighbor,
                                unsigned store_vars, apk_stream_t stream) {
   if (!ctx || !md || !valid_eos(eos) || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||
-      md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9) || ghost_depth < 0 || ghost_depth >= md->view.ng)
+      md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9) || ghost_depth < 0 || ghost_depth > md->view.ng)
     return set_err(ctx, APK_ERR_INVALID, "apk_cons_to_prim_dt_select: bad argument");
   if (md->view.nvar != md->view.nhydro || (store_vars >> md->view.nhydro) != 0u)
     return set_err(ctx, APK_ERR_INVALID, "apk_cons_to_prim_dt_select: store_vars names the hydro primitives of a pack without passive scalars");

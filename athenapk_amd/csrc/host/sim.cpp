@@ -1045,7 +1045,7 @@ int do_stage(apk_sim *s, int stage) {
   const bool amr_pf = amr_prim_free_cycle(s);
   const bool from_cons = amr_pf || (s->prim_stale && ((stage == 1 && prim_free) || rk_free));
   if (s->prim_stale && !from_cons) SIM_TRY(s, sync_ghosts(s));
-  if (amr_pf) s->amr_tag_vars_stored = false;  // (the state they were taken from is about to be replaced)
+  if (amr_pf) s->amr_tag_vars_stored = s->amr_tags_posted = false;  // (the state they were taken from is about to be replaced)
   // (ghost zones one layer deep: enough for the donor-cell predictor they were left for, and for nothing else)
   if (s->remote_ghosts_thin && !(stage == 1 && thin_exchange_cycle(s))) SIM_TRY(s, sync_ghosts(s));
   // (... and their x1 strips still in the receive buffers: for a predictor that reads them there, x1_direct_cycle)
@@ -1410,7 +1410,25 @@ int do_stage(apk_sim *s, int stage) {
     int crit = -1;
     double crit_p0 = 0.0, crit_p1 = 0.0;
     if (amr_pf && pkg.calc_dt_hyp) SIM_TRY(s, refinement_criterion(s, &crit, &crit_p0, &crit_p1));
-    if (crit >= 0) {
+    static const int fused_tag = std::getenv("APK_AMR_FUSED_TAG") ? std::atoi(std::getenv("APK_AMR_FUSED_TAG")) : 1;  // A/B switch
+    bool tags_done = false;
+    if (crit == APK_TAG_PRESSURE_GRADIENT && fused_tag && s->mesh.ndim == 3) {
+      // (... and for the pressure gradient not even that: the criterion is reduced in the same pass, its pressures in LDS)
+      int pending = 0;
+      const int rc_tag = apk_tag_blocks_dt_from_cons(s->ctx, s->mu0(), pkg.fluid, &pkg.eos, dir ? s->d_face_nbr : nullptr, &pending, s->stream);
+      if (rc_tag == APK_OK) {
+        tags_done = true;
+        s->amr_tags_posted = true;
+        s->amr_posted_criterion = crit, s->amr_posted_pending = pending, s->amr_posted_p0 = crit_p0, s->amr_posted_p1 = crit_p1;
+        s->prim_stale = true;
+        s->amr_tag_vars_stored = false;
+        s->amr_c2p_passes_skipped += 1;
+      } else if (rc_tag != APK_ERR_UNSUPPORTED) {  // (blocks too wide for the pressure tile: the two passes below)
+        return fail(s, rc_tag, std::string("apk_tag_blocks_dt_from_cons: ") + apk_last_error(s->ctx));
+      }
+    }
+    if (tags_done) {
+    } else if (crit >= 0) {
       // (the next predictor reads the conserved state: of the primitives only what the refinement criterion reads)
       // (the reference's order of the primitives: IDN = 0, IV1 .. IV3 = 1 .. 3, IPR = 4)
       const unsigned vars = crit == APK_TAG_PRESSURE_GRADIENT ? (1u << 4) : (crit == APK_TAG_VELOCITY_GRADIENT ? ((1u << 1) | (1u << 2)) : (1u << 0));

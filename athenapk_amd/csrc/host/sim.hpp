@@ -206,6 +206,11 @@ struct apk_sim {
   bool prim_stale = false;
   bool prim_free_on = true;  // apk_sim_set_prim_free / APK_PRIM_FREE=0 (A/B)
   long long skipped_local_exchanges = 0;
+  // ... or the criterion itself was reduced with the time-step estimate at the end of the last stage
+  // (apk_tag_blocks_dt_from_cons): amr_tags_begin hands this request on instead of launching one
+  bool amr_tags_posted = false;
+  int amr_posted_criterion = -1, amr_posted_pending = 0;
+  double amr_posted_p0 = 0.0, amr_posted_p1 = 0.0;
   bool amr_tag_vars_stored = false;  // the primitives a refinement criterion reads are those of the current state (amr_prim_free_cycle)
   long long amr_c2p_passes_skipped = 0;  // ConsToPrim passes between the stages a refined mesh did without (amr_prim_free_cycle)
   // mesh refinement (parthenon/mesh/refinement = static | adaptive; one rank): the forest of

@@ -996,6 +996,11 @@ int amr_transfer(apk_sim *s, const std::vector<AmrLeaf> &old, const AmrPartition
 // In two halves: _begin launches the reduction and its read-back, _end waits and converts -- whatever the
 // caller reads back in between (the time-step estimate at the end of a cycle) shares the host round trip.
 int amr_tags_begin(apk_sim *s, AmrTagRequest *req) {
+  if (s->amr_tags_posted) {  // (reduced with the time-step estimate at the end of the last stage: do_stage)
+    s->amr_tags_posted = false;
+    req->criterion = s->amr_posted_criterion, req->pending = s->amr_posted_pending, req->p0 = s->amr_posted_p0, req->p1 = s->amr_posted_p1;
+    return APK_OK;
+  }
   // the criteria difference every cell of the ring [s-1, e+1]^3 (refinement/gradient.cpp:33-36): ghost cells
   // behind edges and corners included, which the stage loop's faces-only exchange leaves stale.  The last
   // stage of a checking cycle exchanges in full or AMR_SHELL_DEPTH (= the criteria's reach) layers deep (do_stage),
@@ -1066,7 +1071,7 @@ int amr_regrid(apk_sim *s, bool *changed, const AmrTagRequest *posted) {
   SIM_TRY(s, exchange_ghosts(s));
   SIM_TRY(s, fill_derived(s));
   s->prim_stale = false;  // (every cell of the new mesh)
-  s->amr_tag_vars_stored = false;
+  s->amr_tag_vars_stored = s->amr_tags_posted = false;
   *changed = true;
   return APK_OK;
 }

@@ -667,19 +667,9 @@ int apk_tag_blocks_begin(apk_ctx *ctx, const apk_pack *md, int criterion, int *p
   return apk_tag_blocks_begin_skip(ctx, md, criterion, nullptr, pending, stream);
 }
 
-int apk_tag_blocks_begin_skip(apk_ctx *ctx, const apk_pack *md, int criterion, const int *face_neighbor, int *pending,
-                              apk_stream_t stream) {
-  if (!ctx || !md || !pending || criterion < APK_TAG_PRESSURE_GRADIENT || criterion > APK_TAG_MAX_DENSITY)
-    return set_err(ctx, APK_ERR_INVALID, "apk_tag_blocks: bad argument");
-  const PackView &pv = md->view;
-  if (pv.ng < 1) return set_err(ctx, APK_ERR_NGHOST, "apk_tag_blocks needs one ghost cell");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int nb = pv.nblocks;
-  const int ndim = (pv.nx3 > 1) ? 3 : ((pv.nx2 > 1) ? 2 : 1);
-  *pending = 0;
-  if (criterion == APK_TAG_PRESSURE_GRADIENT && ndim == 1) return APK_OK;  // gradient.cpp:56-58: AmrTag::same
-  if (criterion == APK_TAG_VELOCITY_GRADIENT && ndim == 1)
-    return set_err(ctx, APK_ERR_UNSUPPORTED, "xyvelocity_gradient needs at least two dimensions");
+namespace {
+// the per-block maxima' words and their pinned host copy, cleared for a new reduction
+int tag_words_prepare(apk_ctx *ctx, int nb, hipStream_t s) {
   if (ctx->tagmax_cap < (size_t)nb) {
     if (ctx->d_tagmax) (void)hipFree(ctx->d_tagmax);
     ctx->d_tagmax = nullptr;
@@ -699,10 +689,42 @@ int apk_tag_blocks_begin_skip(apk_ctx *ctx, const apk_pack *md, int criterion, c
     if (hipHostGetDevicePointer(&dev, ctx->h_partial, 0) == hipSuccess) ctx->h_partial_dev = static_cast<double *>(dev);
     else (void)hipGetLastError();
   }
-  unsigned long long *d_max = ctx->d_tagmax;
   // (the gather at the end of the previous cycle left the words at zero: apk_ctx::tag_words_clean)
-  if (ctx->tag_words_clean < nb || ctx->clean_stream != s) APK_HIP_TRY(ctx, hipMemsetAsync(d_max, 0, sizeof(unsigned long long) * nb, s));
+  if (ctx->tag_words_clean < nb || ctx->clean_stream != s) APK_HIP_TRY(ctx, hipMemsetAsync(ctx->d_tagmax, 0, sizeof(unsigned long long) * nb, s));
   ctx->tag_words_clean = 0;
+  return APK_OK;
+}
+// the read-back of a reduction just launched
+int tag_words_request(apk_ctx *ctx, int nb, hipStream_t s, int *pending) {
+  if (ctx->h_pinned_dev && ctx->h_partial_dev) {
+    // the criteria ride to the host with the time-step word (apk_stage_dt_flags_read's gather kernel) if the caller
+    // reads that next -- the driver does --, else apk_tag_blocks_end fetches them
+    ctx->tags_pending = nb;
+  } else {
+    APK_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partial, ctx->d_tagmax, sizeof(double) * nb, hipMemcpyDeviceToHost, s));
+    ctx->tags_pending = 0;
+  }
+  *pending = 1;
+  return APK_OK;
+}
+}  // namespace
+
+int apk_tag_blocks_begin_skip(apk_ctx *ctx, const apk_pack *md, int criterion, const int *face_neighbor, int *pending,
+                              apk_stream_t stream) {
+  if (!ctx || !md || !pending || criterion < APK_TAG_PRESSURE_GRADIENT || criterion > APK_TAG_MAX_DENSITY)
+    return set_err(ctx, APK_ERR_INVALID, "apk_tag_blocks: bad argument");
+  const PackView &pv = md->view;
+  if (pv.ng < 1) return set_err(ctx, APK_ERR_NGHOST, "apk_tag_blocks needs one ghost cell");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int nb = pv.nblocks;
+  const int ndim = (pv.nx3 > 1) ? 3 : ((pv.nx2 > 1) ? 2 : 1);
+  *pending = 0;
+  if (criterion == APK_TAG_PRESSURE_GRADIENT && ndim == 1) return APK_OK;  // gradient.cpp:56-58: AmrTag::same
+  if (criterion == APK_TAG_VELOCITY_GRADIENT && ndim == 1)
+    return set_err(ctx, APK_ERR_UNSUPPORTED, "xyvelocity_gradient needs at least two dimensions");
+  const int rc = tag_words_prepare(ctx, nb, s);
+  if (rc != APK_OK) return rc;
+  unsigned long long *d_max = ctx->d_tagmax;
   const int kchunks = (pv.nx3 >= 12 && nb < 4096) ? 3 : 1;
   const dim3 grid = rect_grid(pv.nx1 + 2, pv.nx2 + 2, nb * kchunks), block(64, 4, 1);
   if (criterion == APK_TAG_PRESSURE_GRADIENT)
@@ -711,16 +733,27 @@ int apk_tag_blocks_begin_skip(apk_ctx *ctx, const apk_pack *md, int criterion, c
     hipLaunchKernelGGL(tag_kernel<APK_TAG_VELOCITY_GRADIENT>, grid, block, 0, s, pv, d_max, kchunks, face_neighbor);
   else
     hipLaunchKernelGGL(tag_kernel<APK_TAG_MAX_DENSITY>, grid, block, 0, s, pv, d_max, kchunks, face_neighbor);
-  if (ctx->h_pinned_dev && ctx->h_partial_dev) {
-    // the criteria ride to the host with the time-step word (apk_stage_dt_flags_read's gather kernel) if the caller
-    // reads that next -- the driver does --, else apk_tag_blocks_end fetches them
-    ctx->tags_pending = nb;
-  } else {
-    APK_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_partial, d_max, sizeof(double) * nb, hipMemcpyDeviceToHost, s));
-    ctx->tags_pending = 0;
-  }
-  *pending = 1;
-  return APK_OK;
+  return tag_words_request(ctx, nb, s, pending);
+}
+
+int apk_tag_blocks_dt_from_cons(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, const int *face_neighbor, int *pending,
+                                apk_stream_t stream) {
+  if (!ctx || !md || !pending || !eos || (fluid != APK_FLUID_EULER && fluid != APK_FLUID_GLMMHD) ||
+      md->view.nhydro != ((fluid == APK_FLUID_EULER) ? 5 : 9))
+    return set_err(ctx, APK_ERR_INVALID, "apk_tag_blocks_dt_from_cons: bad argument");
+  const PackView &pv = md->view;
+  // (the lean ConsToPrim in registers, nothing written back; the pressure tile of a few planes in LDS)
+  if (!eos_is_lean(*eos) || eos->dfloor > 0.0 || eos->efloor > 0.0 || pv.nvar != pv.nhydro || apk::tag_from_cons_kchunks(pv) <= 0)
+    return set_err(ctx, APK_ERR_UNSUPPORTED, "apk_tag_blocks_dt_from_cons: 3-D packs of blocks whose planes fit the LDS, two ghost layers, no floors / ceilings, no passive scalars");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int nb = pv.nblocks;
+  *pending = 0;
+  int rc = tag_words_prepare(ctx, nb, s);
+  if (rc != APK_OK) return rc;
+  if (apk::prepare_dt_word(ctx, s) != APK_OK) return set_err(ctx, APK_ERR_DEVICE, "time-step word reset", hipGetLastError());
+  rc = apk::launch_tag_pgrad_from_cons(pv, fluid, *eos, ctx->d_flags, ctx->d_u64 + 4, ctx->d_tagmax, face_neighbor, s);
+  if (rc != APK_OK) return set_err(ctx, rc, "tag_pgrad_from_cons kernel launch failed", hipGetLastError());
+  return tag_words_request(ctx, nb, s, pending);
 }
 
 // The read half: waits for the stream (a no-op if the caller synchronised it meanwhile, e.g. by reading

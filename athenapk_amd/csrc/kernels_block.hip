@@ -254,6 +254,84 @@ cons_to_prim_faces_kernel(PackView pv, apk_eos eos, unsigned *flags, const int *
   if constexpr (WITH_DT) block_min_to_word(lane_min, dt_bits);
 }
 
+// The end of a cycle of a refined mesh whose stage loop stores no primitives (apk_tag_blocks_begin_from_cons): the
+// pressure-gradient criterion (refinement/gradient.cpp:18-61) and the time-step estimate (hydro.cpp:845-895) in ONE pass
+// over the conserved state.  A workgroup takes the planes [k0, k1] of the criterion's range [ks - 1, ke + 1] of one block:
+//   1  the pressure of the planes k0 - 1 .. k1 + 1 over [js - 2, je + 2] x [is - 2, ie + 2] into LDS, each cell by the
+//      lean ConsToPrim -- a ghost cell straight behind a face whose face_nbr entry is >= 0 from that neighbour's interior
+//      (the zones the exchange in front of the check leaves out, as apk_tag_blocks_begin_skip reads them) -- and, for the
+//      interior cells of its own planes, the time-step estimate from the primitives it has in registers;
+//   2  the criterion of its cells from LDS, the expressions of tag_kernel.
+// Against apk_cons_to_prim_dt_select(pressure) + apk_tag_blocks_begin_skip: no pressure array written and read back, one
+// launch; the same maxima and the same minimum, bit for bit.
+template <int FLUID>
+__global__ void __launch_bounds__(256)
+tag_pgrad_from_cons_kernel(PackView pv, apk_eos eos, unsigned *flags, unsigned long long *dt_bits, unsigned long long *block_max,
+                           int kchunks, const int *face_nbr) {
+  constexpr int NV = nvars<FLUID>();
+  extern __shared__ __attribute__((aligned(16))) double ptile[];
+  const int b = blockIdx.x / kchunks, chunk = blockIdx.x - b * kchunks;
+  const apk_block_desc blk = pv.blocks[b];
+  const int kl = pv.ks - 1, ku = pv.ke + 1;
+  const int klen = (ku - kl + kchunks) / kchunks;
+  const int k0 = kl + chunk * klen, k1 = (k0 + klen - 1 < ku) ? k0 + klen - 1 : ku;
+  const int ti = pv.nx1 + 4, tj = pv.nx2 + 4, tk = k1 - k0 + 3;  // tile extents (k0 - 1 .. k1 + 1)
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  double lane_min = 1.7976931348623157e308, m = 0.0;
+  if (k0 <= ku) {
+    const int *fn = face_nbr ? face_nbr + 6 * b : nullptr;
+    const int f0 = fn ? fn[0] : -1, f1 = fn ? fn[1] : -1, f2 = fn ? fn[2] : -1, f3 = fn ? fn[3] : -1, f4 = fn ? fn[4] : -1,
+              f5 = fn ? fn[5] : -1;
+    const double gm1 = eos.gamma - 1.0, vceil_sq = eos.vceil * eos.vceil, pf = eos.pfloor / gm1;
+    for (int t = tid; t < ti * tj * tk; t += 256) {
+      const int kk = t / (ti * tj), r = t - kk * (ti * tj), jj = r / ti, ii = r - jj * ti;
+      int i = pv.is - 2 + ii, j = pv.js - 2 + jj, k = k0 - 1 + kk;
+      const int gi = (i < pv.is) ? 1 : ((i > pv.ie) ? 2 : 0), gj = (j < pv.js) ? 1 : ((j > pv.je) ? 2 : 0),
+                gk = (k < pv.ks) ? 1 : ((k > pv.ke) ? 2 : 0);
+      const double *base = blk.cons;
+      if ((gi != 0) + (gj != 0) + (gk != 0) == 1) {
+        const int nb = gi ? (gi == 1 ? f0 : f1) : (gj ? (gj == 1 ? f2 : f3) : (gk == 1 ? f4 : f5));
+        if (nb >= 0) {
+          base = pv.blocks[nb].cons;
+          if (gi) i += (gi == 1) ? pv.nx1 : -pv.nx1;
+          if (gj) j += (gj == 1) ? pv.nx2 : -pv.nx2;
+          if (gk) k += (gk == 1) ? pv.nx3 : -pv.nx3;
+        }
+      }
+      const int64_t cell = (int64_t)k * pv.sk + (int64_t)j * pv.sj + i;
+      double u[NV], w[NV], di;
+#pragma unroll
+      for (int n = 0; n < NV; ++n) u[n] = base[n * pv.sn + cell];
+      const unsigned fl = cons_to_prim_core<FLUID, 1>(eos, gm1, vceil_sq, pf, u, w, di);
+      if (fl) atomicOr(flags, fl);
+      ptile[t] = w[IPR];
+      // (the estimate: interior cells of the chunk's own planes -- every interior cell belongs to exactly one chunk)
+      if (gi == 0 && gj == 0 && gk == 0 && kk >= 1 && kk <= tk - 2) lane_min = fmin(lane_min, cell_dt_hyp<FLUID>(pv, blk, eos.gamma, w));
+    }
+  }
+  __syncthreads();
+  if (k0 <= ku) {
+    const int ci = pv.nx1 + 2, cj = pv.nx2 + 2, ck = k1 - k0 + 1;  // the criterion's cells: [s - 1, e + 1]
+    for (int t = tid; t < ci * cj * ck; t += 256) {
+      const int kk = t / (ci * cj), r = t - kk * (ci * cj), jj = r / ci, ii = r - jj * ci;
+      const double *p = ptile + ((kk + 1) * tj + (jj + 1)) * ti + (ii + 1);
+      const double a = 0.5 * (p[1] - p[-1]), bb = 0.5 * (p[ti] - p[-ti]), cc = 0.5 * (p[ti * tj] - p[-ti * tj]);
+      const double eps = sqrt(sqr(a) + sqr(bb) + sqr(cc)) / p[0];
+      m = fmax(m, eps);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+  __shared__ double part[4];
+  if ((tid & 63) == 0) part[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0 && k0 <= ku) {
+    const double mm = fmax(fmax(part[0], part[1]), fmax(part[2], part[3]));
+    atomicMax(block_max + b, (unsigned long long)__double_as_longlong(mm));
+  }
+  block_min_to_word(lane_min, dt_bits);
+}
+
 // Ghost zones only (the interior was converted by the finishing sweep of the fused stage).  The
 // ghost shell of a block is enumerated as three groups of slabs so that no thread is launched
 // for an interior cell: x3 slabs (whole planes), x2 slabs of the interior planes (whole rows),
@@ -641,7 +719,8 @@ int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsig
     return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
   }
   dim3 grid = rect_grid(pv.ni, pv.nj, pv.nk * pv.nblocks);
-  if (depth >= pv.ng) depth = -1;  // (the whole block)
+  if (depth >= pv.ng && store_vars == ~0u) depth = -1;  // (the whole block)
+  if (depth > pv.ng) depth = pv.ng;               // (a subset of the primitives: the box that is the whole block)
   if (store_vars != ~0u && (faces_only || !dt_bits || depth < 0)) return APK_ERR_UNSUPPORTED;  // (the boxed pass with the estimate)
   if (!faces_only && dt_bits && depth >= 0) {  // (cons_to_prim_kernel's box)
     const int64_t cells = (int64_t)(pv.nx1 + 2 * depth) * (pv.ndim >= 2 ? pv.nx2 + 2 * depth : pv.nj) * (pv.ndim >= 3 ? pv.nx3 + 2 * depth : pv.nk);
@@ -668,6 +747,32 @@ int launch_cons_to_prim(const PackView &pv, int fluid, const apk_eos &eos, unsig
     hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_EULER, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, -1, nullptr, ~0u);
   else
     hipLaunchKernelGGL((cons_to_prim_kernel<APK_FLUID_GLMMHD, false>), grid, dim3(64, 4, 1), 0, s, pv, eos, d_flags, dt_bits, -1, nullptr, ~0u);
+  return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
+}
+
+// planes per workgroup so that the pressure tile fits the LDS a workgroup may take; 0: the blocks are too wide
+int tag_from_cons_kchunks(const PackView &pv) {
+  const size_t plane = sizeof(double) * (size_t)(pv.nx1 + 4) * (size_t)(pv.nx2 + 4);
+  const int budget = 48 * 1024;
+  const int planes = (int)(budget / plane);  // tile planes a workgroup can hold: its own and one either side
+  if (pv.ndim != 3 || planes < 3 || pv.ng < 2) return 0;
+  const int own = planes - 2, range = pv.nx3 + 2;
+  int kchunks = (range + own - 1) / own;
+  if (kchunks < 3 && pv.nx3 >= 12) kchunks = 3;  // (as the tag kernel: a pack of a few hundred narrow blocks is too few workgroups)
+  return kchunks;
+}
+
+int launch_tag_pgrad_from_cons(const PackView &pv, int fluid, const apk_eos &eos, unsigned *d_flags, unsigned long long *dt_bits,
+                               unsigned long long *block_max, const int *face_nbr, hipStream_t s) {
+  const int kchunks = tag_from_cons_kchunks(pv);
+  if (kchunks <= 0) return APK_ERR_UNSUPPORTED;
+  const int range = pv.nx3 + 2, klen = (range - 1 + kchunks) / kchunks;
+  const size_t lds = sizeof(double) * (size_t)(pv.nx1 + 4) * (size_t)(pv.nx2 + 4) * (size_t)(klen + 2);
+  const dim3 grid((unsigned)(pv.nblocks * kchunks), 1, 1), block(64, 4, 1);
+  if (fluid == APK_FLUID_EULER)
+    hipLaunchKernelGGL(tag_pgrad_from_cons_kernel<APK_FLUID_EULER>, grid, block, lds, s, pv, eos, d_flags, dt_bits, block_max, kchunks, face_nbr);
+  else
+    hipLaunchKernelGGL(tag_pgrad_from_cons_kernel<APK_FLUID_GLMMHD>, grid, block, lds, s, pv, eos, d_flags, dt_bits, block_max, kchunks, face_nbr);
   return hipGetLastError() == hipSuccess ? APK_OK : APK_ERR_DEVICE;
 }
 

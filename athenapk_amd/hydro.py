@@ -560,6 +560,21 @@ class RefinePlan:
             pass
 
 
+def TagBlocksDtFromCons(md, fluid, eos, cfl, p0, face_neighbor=None):
+    """The pressure-gradient criterion and the hyperbolic time-step estimate in one pass over the conserved state
+    (apk_tag_blocks_dt_from_cons + apk_tag_blocks_end).  Returns (tags, criterion values, dt)."""
+    ctx = md.ctx
+    tags = (C.c_int * md.nblocks)()
+    crit = (C.c_double * md.nblocks)()
+    pending = C.c_int(0)
+    fn = C.c_void_p(face_neighbor.data_ptr()) if face_neighbor is not None else None
+    _check(ctx.lib.apk_tag_blocks_dt_from_cons(ctx.h, md.h, L.FLUID[fluid], C.byref(eos), fn, C.byref(pending), _stream()), ctx.lib, ctx.h)
+    dt = StageDt(ctx, cfl)
+    code = L.TAG_CRITERIA["pressure_gradient"]
+    _check(ctx.lib.apk_tag_blocks_end(ctx.h, md.nblocks, code, pending.value, float(p0), 0.0, tags, crit, _stream()), ctx.lib, ctx.h)
+    return np.array(tags[:]), np.array(crit[:]), dt
+
+
 def TagBlocks(md, criterion, p0, p1=0.0, face_neighbor=None):
     """refinement::gradient::PressureGradient / VelocityGradient (src/refinement/gradient.cpp:18-99),
     refinement::other::MaxDensity (src/refinement/other.cpp:18-44) for every block of the pack.

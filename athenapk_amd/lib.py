@@ -203,6 +203,7 @@ def _signatures():
         "apk_tag_blocks": (i, [vp, vp, i, d, d, C.POINTER(C.c_int), c_dp, vp]),
         "apk_tag_blocks_begin": (i, [vp, vp, i, C.POINTER(C.c_int), vp]),
         "apk_tag_blocks_begin_skip": (i, [vp, vp, i, vp, C.POINTER(C.c_int), vp]),
+        "apk_tag_blocks_dt_from_cons": (i, [vp, vp, i, E, vp, C.POINTER(C.c_int), vp]),
         "apk_tag_blocks_end": (i, [vp, i, i, i, d, d, C.POINTER(C.c_int), c_dp, vp]),
         "apk_poll_device_flags": (i, [vp, C.POINTER(C.c_uint), vp]),
         "apk_trial_flags": (i, [vp, i, vp]),

@@ -621,6 +621,15 @@ int apk_tag_blocks_begin(apk_ctx *ctx, const apk_pack *md, int criterion, int *p
  * corners are read from the block's own ghost zones as before).  Same criteria, bit for bit. */
 int apk_tag_blocks_begin_skip(apk_ctx *ctx, const apk_pack *md, int criterion, const int *face_neighbor, int *pending,
                               apk_stream_t stream);
+/* The pressure-gradient criterion (gradient.cpp:18-61) AND the hyperbolic time-step estimate (hydro.cpp:845-895) in one
+ * pass over the CONSERVED state: the end of a cycle whose stage loop stores no primitives (apk_stage_args.prim_from_cons).
+ * What apk_cons_to_prim_dt_select(pressure, two layers) followed by apk_tag_blocks_begin_skip(APK_TAG_PRESSURE_GRADIENT)
+ * computes, bit for bit, with no pressure array written and read back: the minimum goes to the stage's time-step word
+ * (apk_stage_dt_read / apk_stage_dt_flags_read), the maxima are read by apk_tag_blocks_end(APK_TAG_PRESSURE_GRADIENT,
+ * pending).  3-D packs with at least two ghost layers whose blocks are narrow enough for a few pressure planes in LDS
+ * (16^3 .. 64^3), no passive scalars, eos without floors and ceilings: APK_ERR_UNSUPPORTED otherwise. */
+int apk_tag_blocks_dt_from_cons(apk_ctx *ctx, const apk_pack *md, int fluid, const apk_eos *eos, const int *face_neighbor,
+                                int *pending, apk_stream_t stream);
 int apk_tag_blocks_end(apk_ctx *ctx, int nblocks, int criterion, int pending, double p0, double p1, int *tags,
                        double *crit, apk_stream_t stream);
 

@@ -273,6 +273,61 @@ def test_tag_blocks_through_the_face_table_equals_filled_ghost_zones(request, nx
             assert list(hydro.TagBlocks(b_, crit, p0, p1)[1]) != list(want_v)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False], ids=["strict", "fma"])
+@pytest.mark.parametrize("fluid", ["euler", "glmmhd"])
+@pytest.mark.parametrize("nx,ng", [((16, 16, 16), 4), ((8, 12, 10), 2), ((40, 24, 16), 3)], ids=["16c", "8x12x10", "40x24x16"])
+def test_pressure_gradient_and_time_step_from_the_conserved_state(request, nx, ng, fluid, strict):
+    """apk_tag_blocks_dt_from_cons: the criterion and the estimate in one pass over the conserved state, against the two
+    passes it replaces -- apk_cons_to_prim_dt_select (pressure, two layers) + apk_tag_blocks_begin_skip -- with filled
+    ghost zones and through a face table whose zones are poisoned: the same maxima, tags and time step (parity build: bit
+    for bit).  Wide blocks, scalars and floors refuse."""
+    import torch
+    from athenapk_amd import hydro
+    ctx = _ctx(request, strict)
+    nb, nh = 4, (9 if fluid == "glmmhd" else 5)
+    g = H.geom(fluid, nx, ng, 0, (0.1, 0.07, 0.13))
+    prim = H.random_prim(fluid, nx, ng, seed=33, kind="smooth", nblocks=nb)
+    prim[1, 4] *= 3.0
+    prim[2, 1:4] *= 4.0
+    tab = np.array([[1, 1, -1, 2, -1, 3], [0, 0, 2, -1, 1, 1], [-1, 3, 0, 2, -1, -1], [2, -1, -1, -1, 0, 3]], dtype=np.int32)
+    I = [slice(ng, ng + nx[0]), slice(ng, ng + nx[1]), slice(ng, ng + nx[2])]
+    cons = np.stack([H.prim_to_cons(fluid, prim[b], 5.0 / 3.0) for b in range(nb)])
+    filled, poisoned = cons.copy(), cons.copy()
+    for b in range(nb):
+        for f in range(6):
+            if tab[b, f] < 0:
+                continue
+            d, hi = f // 2, f % 2
+            dst, src = list(I), list(I)
+            dst[d] = slice(ng + nx[d], 2 * ng + nx[d]) if hi else slice(0, ng)
+            src[d] = slice(ng, 2 * ng) if hi else slice(nx[d], nx[d] + ng)
+            filled[b][:, dst[2], dst[1], dst[0]] = cons[tab[b, f]][:, src[2], src[1], src[0]]
+            poisoned[b][:, dst[2], dst[1], dst[0]] = np.nan
+    eos = hydro.L.make_eos(5.0 / 3.0)
+    dtab = torch.from_numpy(tab).cuda()
+    ref = hydro.MeshData(ctx, nx, ng, nh, dx=tuple(g.dx), nblocks=nb, cons=filled, prim=np.full_like(cons, np.nan), with_flux=False)
+    want_dt = hydro.ConservedToPrimitiveDt(ref, fluid, eos, 0.3, ghost_depth=2, store_vars=1 << 4)
+    _, vals = hydro.TagBlocks(ref, "pressure_gradient", 1e300)
+    p0 = 0.5 * (sorted(vals)[-1] + sorted(vals)[-2])
+    want_t, want_v = hydro.TagBlocks(ref, "pressure_gradient", p0)
+    assert np.all(np.isfinite(want_v)) and len(set(want_t)) > 1
+    for state, table in ((filled, None), (poisoned, dtab), (filled, dtab)):
+        md = hydro.MeshData(ctx, nx, ng, nh, dx=tuple(g.dx), nblocks=nb, cons=state, prim=np.full_like(cons, np.nan), with_flux=False)
+        t, v, dt = hydro.TagBlocksDtFromCons(md, fluid, eos, 0.3, p0, face_neighbor=table)
+        assert np.all(np.isnan(md.prim_host()))                      # (nothing stored)
+        if strict:
+            assert list(v) == list(want_v) and list(t) == list(want_t) and dt == want_dt
+        else:
+            np.testing.assert_allclose(v, want_v, rtol=1e-13)
+            assert list(t) == list(want_t) and abs(dt - want_dt) <= 4e-16 * want_dt
+    with pytest.raises(hydro.L.ApkError):
+        hydro.TagBlocksDtFromCons(md, fluid, hydro.L.make_eos(5.0 / 3.0, pfloor=1e-9), 0.3, p0)
+    wide = hydro.MeshData(ctx, (128, 128, 8), ng, nh, dx=tuple(g.dx), nblocks=1, with_flux=False)
+    with pytest.raises(hydro.L.ApkError):
+        hydro.TagBlocksDtFromCons(wide, fluid, eos, 0.3, p0)
+
+
 # ---- the pieces of the flux correction after a fused stage, through the C-ABI --------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("fluid,recon,riemann,ng", [("euler", "plm", "hllc", 2), ("glmmhd", "ppm", "hlld", 4),
