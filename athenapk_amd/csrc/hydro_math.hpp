@@ -513,7 +513,19 @@ APK_DEV void reconstruct(double qm2, double qm1, double q0, double qp1, double q
 // EOS helpers
 // ======================================================================================
 // src/eos/adiabatic_hydro.hpp:43-45
+#if defined(APK_FP_STRICT) || defined(APK_PLAIN_SQRT) || defined(APK_SOUND_SPEED_DIVIDE)
 APK_DEV double sound_speed(double gamma, double d, double p) { return fsqrt(gamma * p / d); }
+#else
+// Product build: sqrt(x / d) = x / sqrt(x d) -- one v_rsq_f64 with its Newton steps instead of a quotient (v_rcp_f64, two
+// steps, a residual correction) AND a root; within 2 ulp of the reference's form.  (Hydro only calls this; the fast speed
+// of GLM-MHD keeps the reference's form in both builds: see fast_speed.)
+APK_DEV double sound_speed(double gamma, double d, double p) {
+  const double x = gamma * p, z = x * d;
+  double root, inv_root;
+  fsqrt_rsqrt(z, root, inv_root);
+  return (z == 0.0) ? 0.0 : x * inv_root;  // rsq(0) = inf
+}
+#endif
 // src/eos/adiabatic_glmmhd.hpp:47-54
 APK_DEV double fast_speed(double gamma, double d, double p, double bx, double by, double bz) {
   const double asq = gamma * p;
@@ -610,8 +622,16 @@ APK_DEV void hydro_hllc(const double (&wl)[NHYDRO], const double (&wr)[NHYDRO], 
   const double tr = wr[IPR] + vxr * wr[IDN] * wr[IV1];
   const double ml = wl[IDN] * vxl;
   const double mr = -(wr[IDN] * vxr);
+#if defined(APK_FP_STRICT) || defined(APK_PLAIN_SQRT) || defined(APK_HLLC_REF_FORM)
   const double am = (tl - tr) / (ml + mr);
   double cp = (ml * tr + mr * tl) / (ml + mr);
+#else
+  // (product build: the two quotients share their reciprocal, and so do the two of the branch below -- the denominator is
+  // picked first; three v_rcp_f64 sequences a face fewer, results within 2 ulp of the reference's form)
+  const double inv_m = frcp(ml + mr);
+  const double am = (tl - tr) * inv_m;
+  double cp = (ml * tr + mr * tl) * inv_m;
+#endif
   cp = cp > 0.0 ? cp : 0.0;
   vxl = wl[IV1] - bm;
   vxr = wr[IV1] - bp;
@@ -627,6 +647,7 @@ APK_DEV void hydro_hllc(const double (&wl)[NHYDRO], const double (&wr)[NHYDRO], 
   fl[IEN] = el * vxl + wl[IPR] * wl[IV1];
   fr[IEN] = er * vxr + wr[IPR] * wr[IV1];
   double sl, sr, sm;
+#if defined(APK_FP_STRICT) || defined(APK_PLAIN_SQRT) || defined(APK_HLLC_REF_FORM)
   if (am >= 0.0) {
     sl = am / (am - bm);
     sr = 0.0;
@@ -636,6 +657,15 @@ APK_DEV void hydro_hllc(const double (&wl)[NHYDRO], const double (&wr)[NHYDRO], 
     sr = -am / (bp - am);
     sm = bp / (bp - am);
   }
+#else
+  {
+    const bool pos = am >= 0.0;
+    const double inv = frcp(pos ? (am - bm) : (bp - am));
+    sl = pos ? am * inv : 0.0;
+    sr = pos ? 0.0 : -am * inv;
+    sm = pos ? -bm * inv : bp * inv;
+  }
+#endif
   f[IDN] = sl * fl[IDN] + sr * fr[IDN];
   f[IV1] = sl * fl[IV1] + sr * fr[IV1] + sm * cp;
   f[IV2] = sl * fl[IV2] + sr * fr[IV2];
